@@ -1,0 +1,227 @@
+"""ctypes front end of the CPU oracle (oracle/hmx_oracle.cpp) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (htool_amd/) never does.  See the header of hmx_oracle.cpp for what is restated and
+how the restatement is pinned to the reference.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
+PARTITIONINGS = {  # name -> (direction, splitting, partition_n)
+    "pca_regular": (0, 0, 0),
+    "pca_geometric": (0, 1, 0),
+    "bbox_regular": (1, 0, 0),
+    "bbox_geometric": (1, 1, 0),
+    "n_pca_regular": (0, 0, 1),
+    "n_bbox_regular": (1, 0, 1),
+}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "_build", "libhmx_oracle.so")
+    src = os.path.join(_HERE, "hmx_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.orc_cluster_create.restype = C.c_void_p
+        L.orc_cluster_create.argtypes = [C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_cluster_destroy.argtypes = [C.c_void_p]
+        L.orc_cluster_num_nodes.argtypes = [C.c_void_p]
+        L.orc_cluster_num_partitions.argtypes = [C.c_void_p]
+        L.orc_cluster_get.argtypes = [C.c_void_p, ip, ip, dp, ip]
+        L.orc_geometry.argtypes = [C.c_char_p, C.c_int, C.c_double, dp]
+        L.orc_hmatrix_build.restype = C.c_void_p
+        L.orc_hmatrix_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int]
+        L.orc_hmatrix_destroy.argtypes = [C.c_void_p]
+        L.orc_hmatrix_num_leaves.argtypes = [C.c_void_p]
+        L.orc_hmatrix_leaves.argtypes = [C.c_void_p, C.c_int, ip]
+        L.orc_hmatrix_rootinfo.argtypes = [C.c_void_p, ip]
+        L.orc_hmatrix_block.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, ip]
+        L.orc_hmatrix_matvec.argtypes = [C.c_void_p, C.c_int, C.c_char, C.c_double, dp, C.c_double, dp]
+        L.orc_hmatrix_matmat_row_major.argtypes = [C.c_void_p, C.c_char, C.c_double, dp, C.c_double, dp, C.c_int]
+        L.orc_compress_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, ip, dp]
+        L.orc_generate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, dp]
+        L.orc_hmatrix_from_blocks.restype = C.c_void_p
+        L.orc_hmatrix_from_blocks.argtypes = [C.c_int, ip, C.POINTER(C.c_int64), dp, ip, C.c_char, C.c_char]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def geometry(name, n, z=0.0):
+    out = np.empty((n, 3), dtype=np.float64)
+    lib().orc_geometry(name.encode(), n, z, _dp(out))
+    return out
+
+
+class ClusterTree:
+    def __init__(self, coords, leaf=100, children=2, partitions=2, partitioning="pca_regular"):
+        self.coords = np.ascontiguousarray(coords, dtype=np.float64)
+        n, dim = self.coords.shape
+        d, s, pn = PARTITIONINGS[partitioning]
+        self.h = lib().orc_cluster_create(n, dim, _dp(self.coords), leaf, children, partitions, d, s, pn)
+        nn = lib().orc_cluster_num_nodes(self.h)
+        npart = lib().orc_cluster_num_partitions(self.h)
+        self.perm = np.empty(n, dtype=np.int32)
+        self.nodes_int = np.empty((nn, 6), dtype=np.int32)
+        self.nodes_real = np.empty((nn, 4), dtype=np.float64)
+        self.partition = np.empty((npart, 2), dtype=np.int32)
+        lib().orc_cluster_get(self.h, _ip(self.perm), _ip(self.nodes_int), _dp(self.nodes_real), _ip(self.partition))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_cluster_destroy(self.h)
+            self.h = None
+
+
+class HMatrix:
+    """Oracle H-matrix: block tree + compressed leaves + reference-order leaf loop."""
+
+    def __init__(self, tct, sct, delta=1e-5, scale=1.0, eps=1e-4, eta=10.0, sym="N", uplo="N", reqrank=-1,
+                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, _handle=None):
+        if _handle is not None:
+            self.h = _handle
+            self._keep = ()
+        else:
+            self._keep = (tct, sct)
+            self.h = lib().orc_hmatrix_build(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta,
+                                             scale, eps, eta, sym.encode(), uplo.encode(), reqrank,
+                                             COMPRESSORS[compressor], mindepth, mindepth, rank, rank, int(consistent),
+                                             int(parallel))
+        n = lib().orc_hmatrix_num_leaves(self.h)
+        self.leaves = np.empty((n, 6), dtype=np.int32)
+        self.leaves_dfs = np.empty((n, 6), dtype=np.int32)
+        lib().orc_hmatrix_leaves(self.h, 0, _ip(self.leaves))
+        lib().orc_hmatrix_leaves(self.h, 1, _ip(self.leaves_dfs))
+        self.rootinfo = np.empty(7, dtype=np.int32)
+        lib().orc_hmatrix_rootinfo(self.h, _ip(self.rootinfo))
+
+    @classmethod
+    def from_blocks(cls, desc, payload_offsets, data, root, sym_for_leaves="N", uplo="N"):
+        desc = np.ascontiguousarray(desc, dtype=np.int32)
+        offs = np.ascontiguousarray(payload_offsets, dtype=np.int64)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        root = np.ascontiguousarray(root, dtype=np.int32)
+        h = lib().orc_hmatrix_from_blocks(len(desc), _ip(desc), offs.ctypes.data_as(C.POINTER(C.c_int64)), _dp(data),
+                                          _ip(root), sym_for_leaves.encode(), uplo.encode())
+        return cls(None, None, _handle=h)
+
+    def block(self, b, with_pivots=False):
+        t_off, m, s_off, n, rank, _ = self.leaves[b]
+        if rank >= 0:
+            U = np.empty((rank, m), dtype=np.float64)  # column-major M x r  <=> C-order (r, M)
+            V = np.empty((n, rank), dtype=np.float64)  # column-major r x N  <=> C-order (N, r)
+            piv = np.empty(2 * rank, dtype=np.int32)
+            lib().orc_hmatrix_block(self.h, b, _dp(U), _dp(V), None, _ip(piv))
+            return (U.T, V.T, piv.reshape(-1, 2)) if with_pivots else (U.T, V.T)
+        D = np.empty((n, m), dtype=np.float64)
+        lib().orc_hmatrix_block(self.h, b, None, None, _dp(D), None)
+        return D.T
+
+    def matvec(self, x, trans="N", alpha=1.0, beta=0.0, y=None, policy="seq"):
+        nout = self.rootinfo[1] if trans == "N" else self.rootinfo[3]
+        out = np.zeros(nout) if y is None else np.array(y, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lib().orc_hmatrix_matvec(self.h, 0 if policy == "seq" else 1, trans.encode(), alpha, _dp(x), beta, _dp(out))
+        return out
+
+    def matmat_row_major(self, X, trans="N", alpha=1.0, beta=0.0, Y=None):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        mu = X.shape[1]
+        nout = self.rootinfo[1] if trans == "N" else self.rootinfo[3]
+        out = np.zeros((nout, mu)) if Y is None else np.array(Y, dtype=np.float64)
+        lib().orc_hmatrix_matmat_row_major(self.h, trans.encode(), alpha, _dp(X), beta, _dp(out), mu)
+        return out
+
+    def to_dense(self):
+        """Dense matrix of the stored leaves only (no symmetric mirroring), cluster numbering, local offsets."""
+        r = self.rootinfo
+        A = np.zeros((r[1], r[3]))
+        for b, (t_off, m, s_off, n, rank, _) in enumerate(self.leaves):
+            blk = self.block(b)
+            blk = blk[0] @ blk[1] if rank >= 0 else blk
+            A[t_off - r[0]:t_off - r[0] + m, s_off - r[2]:s_off - r[2] + n] = blk
+        return A
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_hmatrix_destroy(self.h)
+            self.h = None
+
+
+def compress_block(tct, sct, compressor, M, N, row_off, col_off, eps, reqrank=-1, delta=0.0, scale=4 * np.pi):
+    U = np.empty((min(M, N) + 1, M))
+    V = np.empty((N, min(M, N) + 1))
+    piv = np.zeros(2 * (min(M, N) + 1), dtype=np.int32)
+    sing = np.zeros(min(M, N))
+    r = lib().orc_compress_block(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta, scale,
+                                 COMPRESSORS[compressor], M, N, row_off, col_off, eps, reqrank, _dp(U), _dp(V),
+                                 _ip(piv), _dp(sing))
+    Uf = U.reshape(-1)[:M * r].reshape(r, M).T
+    Vf = V.reshape(-1)[:N * r].reshape(N, r).T
+    return r, Uf, Vf, piv[:2 * r].reshape(-1, 2), sing
+
+
+def generate_block(tct, sct, M, N, row_off, col_off, delta, scale):
+    out = np.empty((N, M))
+    lib().orc_generate_block(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta, scale, M, N,
+                             row_off, col_off, _dp(out))
+    return out.T
+
+
+def read_dump(path):
+    """Reader for the ref_driver dump format (see oracle/ref/ref_driver.cpp header)."""
+    out = {}
+    with open(path, "rb") as f:
+        buf = f.read()
+    p = 0
+    while p < len(buf):
+        (nl,) = struct.unpack_from("<I", buf, p)
+        p += 4
+        name = buf[p:p + nl].decode()
+        p += nl
+        dtype = chr(buf[p])
+        p += 1
+        (nd,) = struct.unpack_from("<I", buf, p)
+        p += 4
+        dims = struct.unpack_from("<%dQ" % nd, buf, p)
+        p += 8 * nd
+        np_dt = {"i": np.int32, "l": np.int64, "d": np.float64}[dtype]
+        cnt = int(np.prod(dims)) if nd else 1
+        arr = np.frombuffer(buf, dtype=np_dt, count=cnt, offset=p).reshape(dims)
+        p += cnt * np.dtype(np_dt).itemsize
+        out[name] = arr.copy()
+    return out
+
+
+def hashed_vector(n, salt):
+    """Closed-form test input shared with oracle/ref/ref_driver.cpp (`hashed` lambda)."""
+    i = np.arange(1, n + 1, dtype=np.uint64)
+    v = (i * np.uint64(2654435761) + np.uint64(salt * 40503)) & np.uint64(0xFFFFFFFF)
+    return v.astype(np.float64) / 4294967296.0

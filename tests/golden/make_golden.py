@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz from the REAL reference (dev container only).
+
+Runs oracle/_ref/ref_driver (oracle/ref/ref_driver.cpp compiled against the htool headers where they
+lie under /root/reference/include + the image's MKL; `make -C oracle ref`) on a list of small cases and
+stores inputs + expected outputs as compressed .npz fixtures.  The fixtures are DATA (seeded inputs,
+permutations, cluster tables, leaf lists, ranks, a few U/V/dense payloads, matvec results); no reference
+source text is stored.  The reference's own tests hold no golden vectors for this path (SURVEY.md section 4:
+random inputs, tolerance checks against a dense product), so outputs of the reference itself are the pin.
+
+Usage: python tests/golden/make_golden.py            (needs /root/reference; not run on the GPU box)
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle.oracle import read_dump  # noqa: E402
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+# name -> (mode, params).  Parameters mirror ref_driver's key=value options.
+CASES = {
+    # plumbing config C1 analogue (BASELINE.json configs[0]) at fixture size; keeps coords to pin geometry
+    "ball_n2000_partial": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, eta=10, compressor="partialACA", keep_coords=1)),
+    "ellipse_n3000_partial": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, eta=10, compressor="partialACA", keep_coords=1)),
+    # shipped-example style: symmetric storage, default compressor (sympartialACA), Partitioning_N
+    "ellipse_n3000_symL_default": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, eta=10, sym="S", uplo="L", compressor="default", partitioning="n_pca_regular")),
+    "ellipse_n3000_symU_sympartial": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, eta=10, sym="S", uplo="U", compressor="sympartialACA")),
+    "ball_n2000_symL_eta3": ("hmat", dict(n=2000, geom="ball", leaf=40, eps=1e-3, eta=3, sym="S", uplo="L", compressor="sympartialACA")),
+    # single-partition quirk (root with exactly one child)
+    "disk_n1500_p1": ("hmat", dict(n=1500, geom="disk", leaf=60, partitions=1, eps=1e-4, compressor="partialACA")),
+    # minimal block depth (SURVEY.md B-1 workaround used at N=1e6)
+    "ellipse_n4000_mindepth3": ("hmat", dict(n=4000, geom="ellipse", leaf=100, eps=1e-4, mindepth=3, compressor="partialACA")),
+    # rectangular, different target/source geometry
+    "rect_ball1500_disk1000": ("hmat", dict(n=1500, nsrc=1000, geom="ball", sgeom="disk", sz=2.5, leaf=60, eps=1e-4, compressor="partialACA")),
+    # clustering strategies
+    "ball_n2000_bbox_regular": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitioning="bbox_regular", dump_blocks=0)),
+    "ball_n2000_pca_geometric": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitioning="pca_geometric", dump_blocks=0)),
+    "ball_n2000_bbox_geometric": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitioning="bbox_geometric", dump_blocks=0)),
+    "ball_n2000_n_pca_c4": ("hmat", dict(n=2000, geom="ball", leaf=50, children=4, partitions=4, eps=1e-3, partitioning="n_pca_regular", dump_blocks=0)),
+    "ball_n2000_n_bbox_c8": ("hmat", dict(n=2000, geom="ball", leaf=30, children=8, partitions=8, eps=1e-3, partitioning="n_bbox_regular", dump_blocks=0)),
+    "ellipse_n2000_c3_p3": ("hmat", dict(n=2000, geom="ellipse", leaf=50, children=3, partitions=3, eps=1e-3, dump_blocks=0)),
+    # other compressors
+    "ball_n1200_fullACA": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="fullACA", dump_blocks=2)),
+    "ball_n1200_SVD": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="SVD", dump_blocks=2)),
+    "ball_n1200_reqrank5": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, reqrank=5, compressor="partialACA", dump_blocks=2)),
+    # row partition (DistributedOperator local blocks): p=4, every rank; symmetric with p=2
+    **{"ellipse_n4000_p4_rank%d" % r: ("hmat", dict(n=4000, geom="ellipse", leaf=100, partitions=4, rank=r, eps=1e-4, compressor="partialACA", dump_blocks=1)) for r in range(4)},
+    **{"ball_n2000_p2_symL_rank%d" % r: ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=2, rank=r, eps=1e-3, sym="S", uplo="L", compressor="sympartialACA", dump_blocks=1)) for r in range(2)},
+    **{"ball_n2000_p2_symU_rank%d" % r: ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=2, rank=r, eps=1e-3, sym="S", uplo="U", compressor="sympartialACA", dump_blocks=1)) for r in range(2)},
+    # the reference's own compressor test block (500 x 100, two disks at distance d)
+    **{"lrmat_d%d" % d: ("lrmat", dict(distance=d, eps=1e-4)) for d in (15, 20, 30, 40)},
+}
+
+
+def main():
+    if not os.path.exists(DRIVER):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    manifest = {}
+    only = set(sys.argv[1:])
+    for name, (mode, params) in CASES.items():
+        if only and name not in only:
+            continue
+        params = dict(params)
+        keep_coords = params.pop("keep_coords", 0)
+        with tempfile.NamedTemporaryFile(suffix=".bin") as tmp:
+            cmd = [DRIVER, mode] + ["%s=%s" % (k, v) for k, v in params.items()] + ["out=" + tmp.name]
+            print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            d = read_dump(tmp.name)
+        if not keep_coords and mode == "hmat":
+            d.pop("xt", None)
+            d.pop("xs", None)
+        if mode == "hmat":
+            for k in ("x", "xT", "y0", "y0T"):  # closed-form inputs (oracle.hashed_vector), not stored
+                d.pop(k, None)
+        if mode == "lrmat":
+            d.pop("xt", None)
+            d.pop("xs", None)
+            if params["distance"] in (20, 30):  # keep ranks only for the middle distances
+                d = {k: v for k, v in d.items() if k.endswith("_info") or k.endswith("perm")}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        manifest[name] = dict(mode=mode, **params)
+    if not only:
+        with open(os.path.join(HERE, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote", len(manifest), "fixtures")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,35 @@
+"""Shared test helpers: load golden fixtures, build the oracle for a fixture's parameters."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    MANIFEST = json.load(_f)
+
+HMAT_CASES = sorted(k for k, v in MANIFEST.items() if v["mode"] == "hmat")
+LRMAT_CASES = sorted(k for k, v in MANIFEST.items() if v["mode"] == "lrmat")
+
+DEFAULTS = dict(nsrc=0, geom="ellipse", sz=0.0, leaf=100, children=2, partitions=2, partitioning="pca_regular", eps=1e-4,
+                eta=10.0, sym="N", uplo="N", compressor="partialACA", delta=1e-5, scale=1.0, mindepth=0, rank=-1,
+                reqrank=-1, alpha=3.0, beta=2.0)
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def params(name):
+    p = dict(DEFAULTS)
+    p.update(MANIFEST[name])
+    p.setdefault("sgeom", p["geom"])
+    if p["compressor"] == "default":  # hmatrix/tree_builder/tree_builder.hpp:384-386
+        p["compressor"] = "sympartialACA"
+    return p
+
+
+def rel_err(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
