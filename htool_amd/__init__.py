@@ -1,0 +1,10 @@
+"""htool_amd -- MI355X-native H-matrix compression + H-matvec engine behind htool's plugin surface.
+
+Only the hot path lives here: csrc/ holds the HIP kernels and the C ABI
+(include/hmx.h); api.py mirrors htool's ClusterTreeBuilder / HMatrixTreeBuilder / add_hmatrix_vector_product
+operator interface over that ABI; distributed.py is the row-partitioned DistributedOperator.
+"""
+from ._lib import HmxError, lib  # noqa: F401
+from .api import (ClusterTreeBuilder, Cluster, HMatrixTreeBuilder, HMatrix, InvDistGenerator,  # noqa: F401
+                  add_hmatrix_vector_product, internal_add_hmatrix_vector_product,
+                  internal_add_hmatrix_matrix_product_row_major, create_geometry)

@@ -1,0 +1,97 @@
+"""ctypes binding of libhmx.so (C ABI: include/hmx.h).
+
+The library is built in-tree (htool_amd/libhmx.so, `make -C htool_amd/csrc`).  There is no Python or
+CPU fallback: if the library is missing, or a compute entry point is called without a HIP device, the
+call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmx.so")
+
+HMX_MEM_HOST, HMX_MEM_DEVICE = 0, 1
+COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
+DIRECTIONS = {"largest_extent": 0, "bounding_box": 1}
+SPLITTINGS = {"regular": 0, "geometric": 1}
+
+
+class HmxError(RuntimeError):
+    pass
+
+
+class ClusterNode(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("offset", C.c_int32), ("size", C.c_int32), ("rank", C.c_int32),
+                ("counter", C.c_int32), ("n_children", C.c_int32), ("radius", C.c_double), ("center", C.c_double * 3)]
+
+
+class Leaf(C.Structure):
+    _fields_ = [("t_offset", C.c_int32), ("t_size", C.c_int32), ("s_offset", C.c_int32), ("s_size", C.c_int32),
+                ("admissible", C.c_int32), ("mirror", C.c_int32), ("symmetric", C.c_int32), ("rank", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_dense", C.c_int64), ("n_lowrank", C.c_int64), ("n_false_positive", C.c_int64),
+                ("cgen_dense", C.c_int64), ("cgen_lowrank", C.c_int64), ("rank_min", C.c_int32),
+                ("rank_max", C.c_int32), ("rank_mean", C.c_double), ("stream_bytes", C.c_int64),
+                ("t_compress_s", C.c_double), ("t_assemble_s", C.c_double), ("t_pack_s", C.c_double)]
+
+
+# every symbol include/hmx.h declares: (name, restype, argtypes)
+_dp, _ip, _vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+SYMBOLS = [
+    ("hmx_last_error", C.c_char_p, []),
+    ("hmx_device_count", C.c_int, []),
+    ("hmx_geometry", C.c_int, [C.c_char_p, C.c_int, C.c_double, _dp]),
+    ("hmx_cluster_tree_create", C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("hmx_cluster_tree_destroy", None, [_vp]),
+    ("hmx_cluster_tree_size", C.c_int, [_vp]),
+    ("hmx_cluster_tree_num_nodes", C.c_int, [_vp]),
+    ("hmx_cluster_tree_num_partitions", C.c_int, [_vp]),
+    ("hmx_cluster_tree_permutation", _ip, [_vp]),
+    ("hmx_cluster_tree_nodes", C.c_int, [_vp, C.POINTER(ClusterNode)]),
+    ("hmx_cluster_tree_partition", C.c_int, [_vp, _ip]),
+    ("hmx_block_tree_create", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("hmx_block_tree_destroy", None, [_vp]),
+    ("hmx_block_tree_num_leaves", C.c_int64, [_vp]),
+    ("hmx_block_tree_leaves", C.c_int, [_vp, C.POINTER(Leaf)]),
+    ("hmx_block_tree_root", C.c_int, [_vp, _ip, C.c_char_p, C.c_char_p]),
+    ("hmx_hmatrix_create", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("hmx_hmatrix_destroy", None, [_vp]),
+    ("hmx_hmatrix_set_kernel", C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
+    ("hmx_hmatrix_compress", C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
+    ("hmx_hmatrix_set_block_lowrank", C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp]),
+    ("hmx_hmatrix_set_block_dense", C.c_int, [_vp, C.c_int64, _dp]),
+    ("hmx_hmatrix_finalize", C.c_int, [_vp]),
+    ("hmx_hmatrix_leaf_ranks", C.c_int, [_vp, _ip]),
+    ("hmx_hmatrix_get_block", C.c_int, [_vp, C.c_int64, _dp, _dp]),
+    ("hmx_hmatrix_stats", C.c_int, [_vp, C.POINTER(Stats)]),
+    ("hmx_hmatrix_matvec", C.c_int, [_vp, C.c_char, C.c_double, _vp, C.c_double, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matvec_user", C.c_int, [_vp, C.c_char, C.c_double, _vp, C.c_double, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matmat_row_major", C.c_int, [_vp, C.c_char, C.c_double, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp]),
+    ("hmx_hmatrix_last_kernel_times", C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+    ("hmx_hmatrix_set_profiling", C.c_int, [_vp, C.c_int]),
+    ("hmx_device_copy_bandwidth", C.c_int, [C.c_int, C.c_int64, C.c_int, _dp]),
+]
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HmxError("libhmx.so not found at %s -- build it with `make -C htool_amd/csrc` "
+                           "(or __graft_entry__.build()); htool_amd has no fallback path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the C ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise HmxError("libhmx error %d: %s" % (rc, lib().hmx_last_error().decode()))

@@ -1,0 +1,338 @@
+"""Host-side mirror of htool's operator interface for the hot path, over the C ABI (include/hmx.h).
+
+Names, argument meaning and error behaviour follow the reference (paths relative to htool's
+include/htool/):
+
+  ClusterTreeBuilder            clustering/tree_builder/tree_builder.hpp:22-49
+  Cluster                       clustering/cluster_node.hpp:17-82
+  HMatrixTreeBuilder            hmatrix/tree_builder/tree_builder.hpp:27-274
+  HMatrix                       hmatrix/hmatrix.hpp:28-245
+  add_hmatrix_vector_product    hmatrix/linalg/add_hmatrix_vector_product.hpp:173-206 (user numbering)
+  internal_add_hmatrix_vector_product            same file :107-170 (cluster numbering)
+  internal_add_hmatrix_matrix_product_row_major  hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:112-178
+
+Vectors may be numpy arrays (host memory; staged over PCIe by the library) or torch CUDA tensors
+(device memory; only their data_ptr() crosses the C ABI).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HmxError, check, lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def create_geometry(name, n, z=0.0):
+    """testing/geometry.hpp: "ellipse" (create_rotated_ellipse 4:1), "disk", "ball" -- seeded mt19937(0)."""
+    out = np.empty((n, 3), dtype=np.float64)
+    check(lib().hmx_geometry(name.encode(), n, z, _dp(out)))
+    return out
+
+
+class Cluster:
+    """Root of a cluster tree (read-only view of the host structure)."""
+
+    def __init__(self, handle, coords):
+        self._h = handle
+        self.coordinates = coords
+        L = lib()
+        self._n = L.hmx_cluster_tree_size(handle)
+        nn = L.hmx_cluster_tree_num_nodes(handle)
+        nodes = (_lib.ClusterNode * nn)()
+        check(L.hmx_cluster_tree_nodes(handle, nodes))
+        self.nodes = np.ctypeslib.as_array(nodes).copy() if nn else None
+        self._nodes_struct = nodes
+        p = L.hmx_cluster_tree_permutation(handle)
+        self._perm = np.ctypeslib.as_array(p, shape=(self._n,)).copy()
+        npart = L.hmx_cluster_tree_num_partitions(handle)
+        part = np.zeros((npart, 2), dtype=np.int32)
+        check(L.hmx_cluster_tree_partition(handle, part.ctypes.data_as(C.POINTER(C.c_int32))))
+        self._partition = part
+
+    # htool getters
+    def get_size(self):
+        return self._n
+
+    def get_offset(self):
+        return 0
+
+    def get_permutation(self):
+        return self._perm
+
+    def get_clusters_on_partition(self):
+        """(offset, size) of every partition cluster (Cluster::get_clusters_on_partition)."""
+        return self._partition
+
+    def nodes_int(self):
+        s = self._nodes_struct
+        return np.array([[c.depth, c.offset, c.size, c.rank, c.counter, c.n_children] for c in s], dtype=np.int32)
+
+    def nodes_real(self):
+        s = self._nodes_struct
+        return np.array([[c.radius, c.center[0], c.center[1], c.center[2]] for c in s], dtype=np.float64)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().hmx_cluster_tree_destroy(self._h)
+            self._h = None
+
+
+class ClusterTreeBuilder:
+    def __init__(self):
+        self._leaf = 10  # htool default (tree_builder.hpp:25)
+        self._direction, self._splitting, self._n = "largest_extent", "regular", False
+
+    def set_maximal_leaf_size(self, n):
+        self._leaf = int(n)
+
+    def set_partitioning_strategy(self, direction="largest_extent", splitting="regular", partitioning_n=False):
+        """Partitioning<Direction,Splitting> or Partitioning_N<...> (clustering/implementations/partitioning.hpp)."""
+        if direction not in _lib.DIRECTIONS or splitting not in _lib.SPLITTINGS:
+            raise HmxError("unknown partitioning strategy")
+        self._direction, self._splitting, self._n = direction, splitting, bool(partitioning_n)
+
+    def create_cluster_tree(self, number_of_points, spatial_dimension, coordinates, number_of_children, size_of_partition,
+                            radii=None, weights=None):
+        x = np.ascontiguousarray(coordinates, dtype=np.float64).reshape(number_of_points, spatial_dimension)
+        r = None if radii is None else np.ascontiguousarray(radii, dtype=np.float64)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().hmx_cluster_tree_create(number_of_points, spatial_dimension, _dp(x), None if r is None else _dp(r),
+                                            None if w is None else _dp(w), self._leaf, number_of_children,
+                                            size_of_partition, _lib.DIRECTIONS[self._direction],
+                                            _lib.SPLITTINGS[self._splitting], int(self._n), C.byref(h)))
+        return Cluster(h, x)
+
+
+class InvDistGenerator:
+    """Device-evaluable VirtualGenerator: K(x,y) = 1 / (delta + scale * |x - y|)
+    (examples/use_hmatrix.cpp:33 has delta=1e-5, scale=1; testing/generator_test.hpp:159 delta=0, scale=4*pi)."""
+
+    def __init__(self, spatial_dimension, target_coordinates, source_coordinates, delta=1e-5, scale=1.0):
+        self.dim = spatial_dimension
+        self.xt = np.ascontiguousarray(target_coordinates, dtype=np.float64)
+        self.xs = np.ascontiguousarray(source_coordinates, dtype=np.float64)
+        self.delta, self.scale = float(delta), float(scale)
+
+
+def _vec_ptr(v):
+    """(pointer, mem kind, keepalive) for a numpy array or a torch CUDA tensor."""
+    if isinstance(v, np.ndarray):
+        if v.dtype != np.float64 or not v.flags["C_CONTIGUOUS"]:
+            raise HmxError("host vectors must be C-contiguous float64")
+        return v.ctypes.data, _lib.HMX_MEM_HOST
+    if hasattr(v, "data_ptr"):
+        import torch
+        if v.dtype != torch.float64 or not v.is_contiguous():
+            raise HmxError("device vectors must be contiguous float64")
+        return v.data_ptr(), (_lib.HMX_MEM_DEVICE if v.is_cuda else _lib.HMX_MEM_HOST)
+    raise HmxError("unsupported vector type %r" % type(v))
+
+
+def _stream_ptr(v):
+    if hasattr(v, "is_cuda") and v.is_cuda:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(v.device).cuda_stream)
+    return None
+
+
+class HMatrix:
+    """Compressed operator resident in HBM."""
+
+    def __init__(self, bt_handle, hm_handle, target_cluster, source_cluster):
+        self._bt, self._h = bt_handle, hm_handle
+        self._keep = (target_cluster, source_cluster)
+        L = lib()
+        r = np.zeros(4, dtype=np.int32)
+        sym, uplo = C.create_string_buffer(1), C.create_string_buffer(1)
+        check(L.hmx_block_tree_root(bt_handle, r.ctypes.data_as(C.POINTER(C.c_int32)), sym, uplo))
+        self.target_offset, self.target_size, self.source_offset, self.source_size = [int(v) for v in r]
+        self._sym, self._uplo = sym.raw.decode(), uplo.raw.decode()
+        self.refresh_leaves()
+
+    def refresh_leaves(self):
+        L = lib()
+        n = L.hmx_block_tree_num_leaves(self._bt)
+        leaves = (_lib.Leaf * n)()
+        check(L.hmx_block_tree_leaves(self._bt, leaves))
+        arr = np.ctypeslib.as_array(leaves).copy() if n else np.zeros(0, dtype=[("t_offset", "<i4")])
+        ranks = np.zeros(n, dtype=np.int32)
+        check(L.hmx_hmatrix_leaf_ranks(self._h, ranks.ctypes.data_as(C.POINTER(C.c_int32))))
+        self.leaves = arr
+        self.ranks = ranks
+
+    # htool getters
+    def nb_rows(self):
+        return self.target_size
+
+    def nb_cols(self):
+        return self.source_size
+
+    def get_symmetry_for_leaves(self):
+        return self._sym
+
+    def get_UPLO_for_leaves(self):
+        return self._uplo
+
+    def leaf_table(self):
+        """n x 6 int table in htool's leaf order: t_off t_size s_off s_size rank(-1 dense) mirror
+        (save_leaves_with_rank format, hmatrix/hmatrix_output.hpp:43-54, plus the mirror flag)."""
+        a = self.leaves
+        return np.stack([a["t_offset"], a["t_size"], a["s_offset"], a["s_size"], self.ranks, a["mirror"]], axis=1).astype(np.int32)
+
+    def get_block(self, leaf):
+        """(U, V) with U M x r and V r x N, or the dense M x N block."""
+        a = self.leaves[leaf]
+        M, N, r = int(a["t_size"]), int(a["s_size"]), int(self.ranks[leaf])
+        if r >= 0:
+            U, V = np.empty((r, M)), np.empty((N, r))
+            check(lib().hmx_hmatrix_get_block(self._h, leaf, _dp(U), _dp(V)))
+            return U.T, V.T
+        D = np.empty((N, M))
+        check(lib().hmx_hmatrix_get_block(self._h, leaf, _dp(D), None))
+        return D.T
+
+    def set_block_lowrank(self, leaf, U, V):
+        U = np.asfortranarray(U, dtype=np.float64)
+        V = np.asfortranarray(V, dtype=np.float64)
+        check(lib().hmx_hmatrix_set_block_lowrank(self._h, leaf, U.shape[1], U.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  V.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def set_block_dense(self, leaf, D):
+        D = np.asfortranarray(D, dtype=np.float64)
+        check(lib().hmx_hmatrix_set_block_dense(self._h, leaf, D.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def finalize(self):
+        check(lib().hmx_hmatrix_finalize(self._h))
+        self.refresh_leaves()
+
+    def stats(self):
+        s = _lib.Stats()
+        check(lib().hmx_hmatrix_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def set_profiling(self, on):
+        check(lib().hmx_hmatrix_set_profiling(self._h, int(on)))
+
+    def last_kernel_times(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = lib().hmx_hmatrix_last_kernel_times(self._h, 32, names, ms)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().hmx_hmatrix_destroy(self._h)
+            self._h = None
+        if getattr(self, "_bt", None):
+            lib().hmx_block_tree_destroy(self._bt)
+            self._bt = None
+
+
+class BlockTree:
+    """Structure-only view (no GPU needed): the leaf list HMatrixTreeBuilder would build."""
+
+    def __init__(self, handle):
+        self._bt = handle
+        L = lib()
+        n = L.hmx_block_tree_num_leaves(handle)
+        leaves = (_lib.Leaf * n)()
+        check(L.hmx_block_tree_leaves(handle, leaves))
+        self.leaves = np.ctypeslib.as_array(leaves).copy() if n else None
+        r = np.zeros(4, dtype=np.int32)
+        sym, uplo = C.create_string_buffer(1), C.create_string_buffer(1)
+        check(L.hmx_block_tree_root(handle, r.ctypes.data_as(C.POINTER(C.c_int32)), sym, uplo))
+        self.root = r
+        self.symmetry_for_leaves, self.uplo_for_leaves = sym.raw.decode(), uplo.raw.decode()
+
+    def __del__(self):
+        if getattr(self, "_bt", None):
+            lib().hmx_block_tree_destroy(self._bt)
+            self._bt = None
+
+
+class HMatrixTreeBuilder:
+    def __init__(self, epsilon, eta, symmetry, UPLO, reqrank=-1, low_rank_strategy=None):
+        self._eps, self._eta, self._sym, self._uplo, self._reqrank = float(epsilon), float(eta), symmetry, UPLO, int(reqrank)
+        # default compressor is sympartialACA (tree_builder.hpp:384-386)
+        self._compressor = low_rank_strategy or "sympartialACA"
+        self._mint = self._mins = 0
+        self._consistent = True
+
+    def set_low_rank_generator(self, name):
+        if name not in _lib.COMPRESSORS:
+            raise HmxError("unknown compressor %r" % name)
+        self._compressor = name
+
+    def set_minimal_target_depth(self, d):
+        self._mint = int(d)
+
+    def set_minimal_source_depth(self, d):
+        self._mins = int(d)
+
+    def set_block_tree_consistency(self, c):
+        self._consistent = bool(c)
+
+    def _block_tree(self, target, source, target_partition_number, partition_number_for_symmetry):
+        h = C.c_void_p()
+        check(lib().hmx_block_tree_create(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(),
+                                          self._mint, self._mins, target_partition_number, partition_number_for_symmetry,
+                                          int(self._consistent), C.byref(h)))
+        return h
+
+    def build_block_tree(self, target, source, target_partition_number=-1, partition_number_for_symmetry=-1):
+        return BlockTree(self._block_tree(target, source, target_partition_number, partition_number_for_symmetry))
+
+    def build(self, generator, target_root_cluster_tree, source_root_cluster_tree, target_partition_number=-1,
+              partition_number_for_symmetry=-1, device=0, compress=True):
+        """HMatrixTreeBuilder::build (tree_builder.hpp:199-210).  With compress=False only the structure is
+        created on the device and blocks are expected through HMatrix.set_block_*() + finalize()."""
+        bt = self._block_tree(target_root_cluster_tree, source_root_cluster_tree, target_partition_number,
+                              partition_number_for_symmetry)
+        h = C.c_void_p()
+        check(lib().hmx_hmatrix_create(bt, device, C.byref(h)))
+        H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
+        if generator is not None:
+            if not isinstance(generator, InvDistGenerator):
+                raise HmxError("device compression needs a device-evaluable generator (InvDistGenerator); "
+                               "use compress=False and upload blocks for arbitrary generators")
+            params = np.array([generator.delta, generator.scale], dtype=np.float64)
+            check(lib().hmx_hmatrix_set_kernel(h, 0, _dp(params), 2, generator.dim, _dp(generator.xt), _dp(generator.xs)))
+        if compress:
+            check(lib().hmx_hmatrix_compress(h, _lib.COMPRESSORS[self._compressor], self._eps, self._reqrank))
+            H.refresh_leaves()
+        return H
+
+
+def internal_add_hmatrix_vector_product(trans, alpha, A, x, beta, y):
+    """y = alpha*op(A)*x + beta*y in cluster numbering (vectors local to A's root clusters)."""
+    px, mx = _vec_ptr(x)
+    py, my = _vec_ptr(y)
+    if mx != my:
+        raise HmxError("in and out must live in the same memory space")
+    check(lib().hmx_hmatrix_matvec(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
+    return y
+
+
+def add_hmatrix_vector_product(trans, alpha, A, x, beta, y):
+    """User-numbering front end (permutations on the device)."""
+    px, mx = _vec_ptr(x)
+    py, my = _vec_ptr(y)
+    if mx != my:
+        raise HmxError("in and out must live in the same memory space")
+    check(lib().hmx_hmatrix_matvec_user(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
+    return y
+
+
+def internal_add_hmatrix_matrix_product_row_major(trans, alpha, A, X, beta, Y, mu):
+    """Row-major (mu fastest) multi-RHS product in cluster numbering."""
+    px, mx = _vec_ptr(X)
+    py, my = _vec_ptr(Y)
+    if mx != my:
+        raise HmxError("in and out must live in the same memory space")
+    check(lib().hmx_hmatrix_matmat_row_major(A._h, trans.encode(), alpha, px, beta, py, mu, mx, _stream_ptr(X)))
+    return Y

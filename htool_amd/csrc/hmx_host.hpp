@@ -1,0 +1,69 @@
+// hmx_host.hpp -- host-side structures of libhmx (cluster tree, block tree).  C++14.
+//
+// The host structure layer reproduces htool's indexing bit-for-bit (permutation, cluster table, leaf
+// order) but is laid out for the device engine: flat arrays, no pointer trees, level-parallel build.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/hmx.h"
+
+namespace hmx {
+
+struct ClusterNode {
+    int parent      = -1;
+    int first_child = -1; // children are contiguous in ClusterTree::nodes
+    int n_children  = 0;
+    int depth       = 0;
+    int offset      = 0;
+    int size        = 0;
+    int rank        = -1;
+    int counter     = 0;
+    double radius   = 0;
+    double center[3] = {0, 0, 0};
+};
+
+struct ClusterTreeOptions {
+    int maximal_leaf_size  = 10; // htool default, clustering/tree_builder/tree_builder.hpp:25
+    int number_of_children = 2;
+    int size_of_partition  = 1;
+    int direction          = HMX_DIR_LARGEST_EXTENT;
+    int splitting          = HMX_SPLIT_REGULAR;
+    bool partitioning_n    = false;
+};
+
+} // namespace hmx
+
+// The C ABI's opaque types are these structs.
+struct hmx_cluster_tree {
+    int n = 0, dim = 3;
+    hmx::ClusterTreeOptions opt;
+    std::vector<int32_t> perm;             // cluster position -> user index
+    std::vector<hmx::ClusterNode> nodes;   // nodes[0] = root; children contiguous
+    std::vector<int> on_partition;         // node id of partition k
+    bool permutation_is_local = false;
+    std::vector<int> preorder() const;     // node ids in preorder (children in creation order)
+    bool is_leaf(int v) const { return nodes[v].n_children == 0; }
+};
+
+struct hmx_block_tree {
+    const hmx_cluster_tree *target = nullptr, *source = nullptr;
+    double eta = 10;
+    char symmetry = 'N', uplo = 'N';
+    int min_target_depth = 0, min_source_depth = 0;
+    int target_partition = -1, partition_for_symmetry = -1;
+    bool consistent = true;
+    // root after reset_root_of_block_tree
+    int root_t_offset = 0, root_t_size = 0, root_s_offset = 0, root_s_size = 0;
+    char symmetry_for_leaves = 'N', uplo_for_leaves = 'N';
+    std::vector<hmx_leaf> leaves; // htool build order (preorder of the block tree)
+};
+
+namespace hmx {
+void set_error(const std::string &msg);
+int build_cluster_tree(int n, int dim, const double *coords, const double *radii, const double *weights,
+                       const ClusterTreeOptions &opt, hmx_cluster_tree &out);
+int build_block_tree(hmx_block_tree &bt);
+void make_geometry(const std::string &name, int n, double z, double *coords);
+} // namespace hmx

@@ -1,0 +1,642 @@
+// kernels.hpp -- hand-written HIP kernels for gfx950 (CDNA4, wave64).  Compiled with -ffp-contract=off:
+// every FMA in this file is an explicit __builtin_fma, so the compression kernels evaluate exactly the
+// IEEE sequence the reference's scalar code spells out (SURVEY.md "Hard parts": ACA parity) while the
+// matvec kernels still issue v_fma_f64.
+//
+// Data layout in HBM: the compressed operator is NOT kept as htool's per-block
+// U (M x r) / V (r x N) / dense (M x N) matrices.  It is re-laid out as two sets of streams:
+//   E-stream  (expand): for every target row range R (<= 64 rows, aligned to cluster boundaries) one
+//             column-major len_R x C_R matrix holding, side by side, the slice of every block that
+//             touches R: n_b columns for a dense block, r_b columns (its U slice) for a low-rank block.
+//             y_R = E_R * z_R, z_R gathered from Z = [x | a].  lane = row, no cross-lane reduction.
+//   R-stream  (reduce): for every source range S one row-major len_S x C_S matrix (128-column chunks)
+//             holding the V slices of every low-rank block that touches S.  a_partial = x_S^T * R_S,
+//             lane = column pair, no cross-lane reduction.
+// Every stored coefficient is read exactly once per matvec, by fully coalesced wave loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmx {
+
+constexpr int WAVE = 64;
+
+struct KernelSpec { // device-evaluable generator
+    int kind;
+    int dim;
+    double p0, p1;
+};
+
+// K(x,y) = 1/(p0 + p1*|x-y|); squared differences accumulated left to right from 0, one sqrt, one
+// multiply, one add, one divide -- the order of examples/use_hmatrix.cpp:33 / testing/generator_test.hpp:159.
+__device__ __forceinline__ double eval_kernel(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
+    double s        = 0.0;
+    const double d0 = tx - sx;
+    s               = s + d0 * d0;
+    const double d1 = ty - sy;
+    s               = s + d1 * d1;
+    if (ks.dim == 3) {
+        const double d2 = tz - sz;
+        s               = s + d2 * d2;
+    }
+    return 1.0 / (ks.p0 + ks.p1 * sqrt(s));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compression: partially pivoted ACA, one workgroup per admissible block.
+// ---------------------------------------------------------------------------------------------
+struct AcaArgs {
+    KernelSpec ks;
+    const double *tx, *ty, *tz; // target coordinates, cluster order (SoA)
+    const double *sx, *sy, *sz; // source coordinates, cluster order (SoA)
+    const int32_t *order;       // launch order -> block id (largest first)
+    const int32_t *t_off, *t_size, *s_off, *s_size;
+    int symmetric_pivoting;     // sympartialACA: pivot on the larger-offset cluster first
+    double epsilon;
+    int reqrank;
+    double *pool;               // cross storage, bump allocated
+    unsigned long long *pool_head;
+    unsigned long long pool_cap;
+    const int64_t *colptr;      // per block: first slot in cross_off
+    const int32_t *colcap;      // per block: slots available
+    int64_t *cross_off;         // per (block, k): pool offset of [uu_k (n1) | vv_k (n2)]
+    unsigned char *visited;     // per block: n1 + n2 flags
+    const int64_t *vis_ptr;
+    int32_t *rank_out;          // > 0 rank; 0 = compressor failed (dense fallback); -2 = pool exhausted
+    int32_t *swapped_out;       // 1 when index "1" is the source side (sympartialACA.hpp:48-63)
+};
+
+template <int NT>
+__device__ __forceinline__ void block_argmax(double &val, int &idx, double *sval, int *sidx) {
+    // maximum of |.|, ties -> larger index (the reference scans upward and replaces on ">=")
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(val, o, WAVE);
+        const int oi    = __shfl_xor(idx, o, WAVE);
+        if (ov > val || (ov == val && oi > idx)) {
+            val = ov;
+            idx = oi;
+        }
+    }
+    const int w = threadIdx.x / WAVE;
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        sval[w] = val;
+        sidx[w] = idx;
+    }
+    __syncthreads();
+    val = sval[0];
+    idx = sidx[0];
+#pragma unroll
+    for (int k = 1; k < NT / WAVE; k++)
+        if (sval[k] > val || (sval[k] == val && sidx[k] > idx)) {
+            val = sval[k];
+            idx = sidx[k];
+        }
+    __syncthreads();
+}
+
+template <int NT, int G>
+__device__ __forceinline__ void block_sum_group(double (&acc)[G], double *sbuf) {
+#pragma unroll
+    for (int g = 0; g < G; g++)
+        acc[g] = wave_sum(acc[g]);
+    const int w = threadIdx.x / WAVE;
+    if ((threadIdx.x & (WAVE - 1)) == 0)
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            sbuf[w * G + g] = acc[g];
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        double s = sbuf[g];
+#pragma unroll
+        for (int k = 1; k < NT / WAVE; k++)
+            s += sbuf[k * G + g];
+        acc[g] = s;
+    }
+    __syncthreads();
+}
+
+// partialACA::copy_low_rank_approximation (hmatrix/lrmat/partialACA.hpp:42-184) and
+// sympartialACA (hmatrix/lrmat/sympartialACA.hpp:41-216) share this kernel: index "1" is the
+// row side unless symmetric pivoting asks for the larger-offset side.
+template <int NT>
+__global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
+    __shared__ double sval[NT / WAVE];
+    __shared__ int sidx[NT / WAVE];
+    __shared__ double sbuf[(NT / WAVE) * 8];
+    __shared__ unsigned long long s_off;
+
+    const int b      = A.order[blockIdx.x];
+    const int M      = A.t_size[b], N = A.s_size[b];
+    const int roff   = A.t_off[b], coff = A.s_off[b];
+    const bool swap  = A.symmetric_pivoting && !(roff >= coff);
+    const int n1     = swap ? N : M, n2 = swap ? M : N;
+    // coordinates of index-1 points (p1*) and index-2 points (p2*)
+    const double *p1x = swap ? A.sx + coff : A.tx + roff, *p1y = swap ? A.sy + coff : A.ty + roff, *p1z = swap ? A.sz + coff : A.tz + roff;
+    const double *p2x = swap ? A.tx + roff : A.sx + coff, *p2y = swap ? A.ty + roff : A.sy + coff, *p2z = swap ? A.tz + roff : A.sz + coff;
+    unsigned char *vis1 = A.visited + A.vis_ptr[b];
+    unsigned char *vis2 = vis1 + n1;
+    int64_t *cross      = A.cross_off + A.colptr[b];
+    const int cap       = A.colcap[b];
+    const int tid       = threadIdx.x;
+
+    int I1 = 0, I2 = 0, q = 0;
+    double frob = 0, aux = 0;
+    const int reqrank = A.reqrank;
+    const int minmn   = n1 < n2 ? n1 : n2;
+    while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (q == 0 || sqrt(aux / frob) > A.epsilon))) {
+        q += 1;
+        if ((long long)q * ((long long)n1 + n2) > (long long)n1 * n2 || q > cap) { // not advantageous any more
+            q = -1;
+            break;
+        }
+        if (tid == 0)
+            s_off = atomicAdd(A.pool_head, (unsigned long long)(n1 + n2));
+        __syncthreads();
+        const unsigned long long off = s_off;
+        if (off + (unsigned long long)(n1 + n2) > A.pool_cap) {
+            q = -2;
+            break;
+        }
+        double *u2 = A.pool + off;      // new uu (length n1)
+        double *u1 = A.pool + off + n1; // new vv (length n2)
+        // ---- cross row: entries (I1, k), k over index 2 ------------------------------------------
+        const double ax = p1x[I1], ay = p1y[I1], az = p1z[I1];
+        double best = -1.0;
+        int besti   = -1;
+        for (int k = tid; k < n2; k += NT) {
+            double v = swap ? eval_kernel(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_kernel(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]);
+            for (int j = 0; j < q - 1; j++) {
+                const double *cj  = A.pool + cross[j];
+                const double coef = -cj[I1];
+                v                 = coef * cj[n1 + k] + v;
+            }
+            u1[k] = v;
+            if (!vis2[k]) {
+                const double a = fabs(v);
+                if (a >= best) { // k increases per thread: ">=" keeps the last maximum
+                    best  = a;
+                    besti = k;
+                }
+            }
+        }
+        block_argmax<NT>(best, besti, sval, sidx); // also makes u1 visible to the whole workgroup
+        if (besti >= 0)
+            I2 = besti;
+        if (tid == 0)
+            vis1[I1] = 1;
+        const double piv   = u1[I2];
+        const double gamma = 1.0 / piv;
+        if (fabs(piv) > 1e-15) {
+            // ---- cross column: entries (k, I2), k over index 1 -----------------------------------
+            const double bx = p2x[I2], by = p2y[I2], bz = p2z[I2];
+            best  = -1.0;
+            besti = -1;
+            for (int k = tid; k < n1; k += NT) {
+                double v = swap ? eval_kernel(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_kernel(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz);
+                for (int j = 0; j < q - 1; j++) {
+                    const double *cj  = A.pool + cross[j];
+                    const double coef = -cj[n1 + I2];
+                    v                 = coef * cj[k] + v;
+                }
+                v     = v * gamma;
+                u2[k] = v;
+                if (!vis1[k] && k != I1) {
+                    const double a = fabs(v);
+                    if (a >= best) {
+                        best  = a;
+                        besti = k;
+                    }
+                }
+            }
+            block_argmax<NT>(best, besti, sval, sidx);
+            const int nextI1 = besti >= 0 ? besti : I1;
+            if (tid == 0) {
+                vis2[I2]     = 1;
+                cross[q - 1] = (int64_t)off;
+            }
+            if (reqrank < 0) {
+                // error estimator (partialACA.hpp:136-148): |c.c||r.r| + 2 sum_j (vv_j.r)(uu_j.c)
+                double acc2[2] = {0, 0};
+                for (int k = tid; k < n1; k += NT)
+                    acc2[0] += u2[k] * u2[k];
+                for (int k = tid; k < n2; k += NT)
+                    acc2[1] += u1[k] * u1[k];
+                block_sum_group<NT, 2>(acc2, sbuf);
+                aux             = fabs(acc2[0]) * fabs(acc2[1]);
+                double frob_aux = 0;
+                for (int j0 = 0; j0 < q - 1; j0 += 4) {
+                    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const int nj  = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
+                    for (int g = 0; g < nj; g++) {
+                        const double *cj = A.pool + cross[j0 + g];
+                        double a1 = 0, a2 = 0;
+                        for (int k = tid; k < n2; k += NT)
+                            a1 += cj[n1 + k] * u1[k];
+                        for (int k = tid; k < n1; k += NT)
+                            a2 += cj[k] * u2[k];
+                        acc[2 * g]     = a1;
+                        acc[2 * g + 1] = a2;
+                    }
+                    block_sum_group<NT, 8>(acc, sbuf);
+                    for (int g = 0; g < nj; g++)
+                        frob_aux += acc[2 * g] * acc[2 * g + 1];
+                }
+                frob += aux + 2 * frob_aux;
+            }
+            __syncthreads();
+            I1 = nextI1;
+        } else {
+            q -= 1;
+            if (q == 0)
+                q = -1;
+            break;
+        }
+    }
+    if (tid == 0) {
+        A.rank_out[b]    = q > 0 ? q : (q == -2 ? -2 : 0);
+        A.swapped_out[b] = swap ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pack: move compressed data into the matvec streams
+// ---------------------------------------------------------------------------------------------
+struct PackLrArgs {
+    const double *pool;
+    const int64_t *cross_off; // per (block,k)
+    const int64_t *colptr;
+    const int32_t *rank;
+    const int32_t *swapped;
+    const int32_t *t_off, *t_size, *s_off, *s_size;
+    // pair lists
+    const int32_t *pair_block, *pair_range, *pair_col; // column offset inside the range's stream
+    const int32_t *range_off, *range_len;
+    const int64_t *range_base;
+    const int32_t *range_cols; // C of the range (R-stream only)
+    double *stream;
+    int origin;                // global cluster position of local offset 0 (T0 for E-streams, S0 for R-streams)
+};
+
+// U slices -> E-stream (column-major len x C per target range)
+__global__ void pack_lr_expand_kernel(PackLrArgs P, int64_t npairs) {
+    const int64_t p = blockIdx.x;
+    if (p >= npairs)
+        return;
+    const int b = P.pair_block[p], R = P.pair_range[p], col = P.pair_col[p];
+    const int len = P.range_len[R], r = P.rank[b];
+    const int n1  = P.swapped[b] ? P.s_size[b] : P.t_size[b]; // length of uu in a cross
+    const int rel = P.range_off[R] + P.origin - P.t_off[b];
+    const int64_t *cross = P.cross_off + P.colptr[b];
+    double *dst          = P.stream + P.range_base[R] + (int64_t)col * len;
+    for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
+        const int k = e / len, i = e - k * len;
+        // U(:,k) = uu_k when index 1 is the row side, vv_k otherwise (sympartialACA.hpp:198-212)
+        const double *src = P.pool + cross[k] + (P.swapped[b] ? n1 : 0);
+        dst[e]            = src[rel + i];
+    }
+}
+
+__device__ __forceinline__ int64_t rstream_index(int64_t base, int len, int C, int i, int col) {
+    // row-major, 128-column chunks; a chunk of width w is stored with row pitch w rounded up to even
+    const int ch = col >> 7, cw = col & 127;
+    int w        = C - (ch << 7);
+    w            = w > 128 ? 128 : w;
+    w            = (w + 1) & ~1;
+    return base + (int64_t)ch * len * 128 + (int64_t)i * w + cw;
+}
+
+// V slices -> R-stream
+__global__ void pack_lr_reduce_kernel(PackLrArgs P, int64_t npairs) {
+    const int64_t p = blockIdx.x;
+    if (p >= npairs)
+        return;
+    const int b = P.pair_block[p], S = P.pair_range[p], col = P.pair_col[p];
+    const int len = P.range_len[S], r = P.rank[b], C = P.range_cols[S];
+    const int n1  = P.swapped[b] ? P.s_size[b] : P.t_size[b];
+    const int rel = P.range_off[S] + P.origin - P.s_off[b];
+    const int64_t *cross = P.cross_off + P.colptr[b];
+    for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
+        const int k = e / len, i = e - k * len;
+        const double *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
+        P.stream[rstream_index(P.range_base[S], len, C, i, col + k)] = src[rel + i];
+    }
+}
+
+struct PackDenseArgs {
+    KernelSpec ks;
+    const double *tx, *ty, *tz, *sx, *sy, *sz;
+    const int32_t *pair_block, *pair_range, *pair_col;
+    const int32_t *range_off, *range_len;
+    const int64_t *range_base;
+    const int32_t *t_off, *t_size, *s_off, *s_size;
+    const int64_t *staged_off; // >= 0: uploaded dense block (column-major M x N) in `pool`; < 0: generate
+    const int32_t *sym_uplo;   // 0 none, 1 'L', 2 'U' : uploaded symmetric leaf, only that triangle is valid
+    const double *pool;
+    double *stream;
+    int origin; // T0
+};
+
+// dense leaves -> E-stream: HMatrix::compute_dense_data (hmatrix/hmatrix.hpp:222-226) fused with the
+// layout change; entries are generated straight into their final position.
+__global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
+    const int64_t p = blockIdx.x;
+    if (p >= npairs)
+        return;
+    const int b = P.pair_block[p], R = P.pair_range[p], col = P.pair_col[p];
+    const int len = P.range_len[R], N = P.s_size[b], M = P.t_size[b];
+    const int row0 = P.range_off[R] + P.origin; // global cluster position of the range's first row
+    const int rel  = row0 - P.t_off[b];
+    const int c0   = P.s_off[b];
+    double *dst    = P.stream + P.range_base[R] + (int64_t)col * len;
+    const int64_t st = P.staged_off[b];
+    const int su     = P.sym_uplo[b];
+    for (int e = threadIdx.x; e < N * len; e += blockDim.x) {
+        const int j = e / len, i = e - j * len;
+        double v;
+        if (st >= 0) {
+            int ii = rel + i, jj = j;
+            if ((su == 1 && ii < jj) || (su == 2 && ii > jj)) { // symv semantics: mirror the stored triangle
+                const int t = ii;
+                ii          = jj;
+                jj          = t;
+            }
+            v = P.pool[st + ii + (int64_t)M * jj];
+        } else {
+            v = eval_kernel(P.ks, P.tx[row0 + i], P.ty[row0 + i], P.tz[row0 + i], P.sx[c0 + j], P.sy[c0 + j], P.sz[c0 + j]);
+        }
+        dst[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// H-matvec, trans = 'N'
+// ---------------------------------------------------------------------------------------------
+// Stage 1 (add_lrmat_vector_product.hpp:16, a = V x): one wave per (source range, 128-column chunk).
+// lane owns two adjacent columns, walks the rows; x_S[i] is wave-uniform.
+struct ReduceArgs {
+    const double *stream;
+    const int32_t *task_range, *task_chunk;
+    const int32_t *range_off, *range_len, *range_cols;
+    const int64_t *range_base;
+    const int64_t *range_colbase; // first entry of the range in out_idx
+    const int32_t *out_idx;       // per column: destination in Z (an `a` slot or a partial slot)
+    const double *x;              // input vector, local to the source root
+    double *Z;
+    int ntasks;
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6)); // wave-uniform
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S];
+    int w = C - (ch << 7);
+    w     = w > 128 ? 128 : w;
+    const int wp     = (w + 1) & ~1;
+    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * 128 + 2 * lane;
+    const double *xs  = A.x + A.range_off[S];
+    double a0 = 0, a1 = 0;
+    if (2 * lane < wp) {
+        int i = 0;
+        for (; i + 8 <= len; i += 8) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                v[u] = *reinterpret_cast<const double2 *>(src + (int64_t)(i + u) * wp);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double xi = xs[i + u];
+                a0              = __builtin_fma(v[u].x, xi, a0);
+                a1              = __builtin_fma(v[u].y, xi, a1);
+            }
+        }
+        for (; i < len; i++) {
+            const double2 v = *reinterpret_cast<const double2 *>(src + (int64_t)i * wp);
+            const double xi = xs[i];
+            a0              = __builtin_fma(v.x, xi, a0);
+            a1              = __builtin_fma(v.y, xi, a1);
+        }
+        const int64_t cb = A.range_colbase[S] + (ch << 7) + 2 * lane;
+        if (2 * lane < w)
+            A.Z[A.out_idx[cb]] = a0;
+        if (2 * lane + 1 < w)
+            A.Z[A.out_idx[cb + 1]] = a1;
+    }
+}
+
+// Stage 1b: blocks whose source cluster spans several ranges: a_b[k] = sum_s partial[b][s][k]
+struct CombineArgs {
+    const int32_t *dst, *src, *stride, *count;
+    double *Z;
+    int n;
+};
+__global__ void combine_kernel(CombineArgs A) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n)
+        return;
+    const double *p = A.Z + A.src[e];
+    const int st = A.stride[e], cnt = A.count[e];
+    double s = 0;
+    for (int k = 0; k < cnt; k++)
+        s += p[(int64_t)k * st];
+    A.Z[A.dst[e]] = s;
+}
+
+// Stage 2 (dense leaves: add_matrix_vector_product.hpp:18; low rank: add_lrmat_vector_product.hpp:17,
+// y += U a; final alpha/beta as openmp_internal_add_hmatrix_vector_product :134-136,168):
+// one workgroup per target row range, lane = row, the waves split the columns in 64-column chunks.
+struct ExpandArgs {
+    const double *stream;
+    const int32_t *range_off, *range_len, *range_cols;
+    const int64_t *range_base;
+    const int64_t *range_colbase;
+    const int32_t *z_idx; // per column: index into Z = [x | a | ...]
+    const double *Z;
+    double *y;            // output, local to the target root
+    double alpha, beta;
+    int nranges;
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
+    __shared__ double part[WAVES][WAVE];
+    const int R = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const double *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const bool active   = lane < len;
+    const int row       = active ? lane : 0;
+    double acc = 0;
+    for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
+        const int nc   = (C - c0) < 64 ? (C - c0) : 64;
+        const double z = lane < nc ? A.Z[zidx[c0 + lane]] : 0.0;
+        const double *col = E + (int64_t)c0 * len + row;
+        int j = 0;
+        for (; j + 8 <= nc; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                v[u] = col[(int64_t)(j + u) * len];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                acc = __builtin_fma(v[u], readlane_f64(z, j + u), acc);
+        }
+        for (; j < nc; j++)
+            acc = __builtin_fma(col[(int64_t)j * len], readlane_f64(z, j), acc);
+    }
+    part[wv][lane] = active ? acc : 0.0;
+    __syncthreads();
+    if (wv == 0 && active) {
+        double s = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            s += part[k][lane];
+        double *yo = A.y + A.range_off[R] + lane;
+        *yo        = A.beta == 0.0 ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed / mirrored passes (trans = 'T', and the symmetric mirror pass
+// add_hmatrix_vector_product.hpp:97-103,154-163).  Same streams, read in the "wrong" orientation:
+// every column (resp. row) needs a cross-lane reduction and results are accumulated with fp64 atomics
+// into a zeroed work vector W = [out | aT].  Correct and coalesced, but not the tuned path.
+// ---------------------------------------------------------------------------------------------
+struct ColReduceArgs { // over E-streams: W[dst[c]] += sum_i E[i,c] * in[R.off + i]
+    const double *stream;
+    const int32_t *range_off, *range_len, *range_cols;
+    const int64_t *range_base, *range_colbase;
+    const int32_t *dst; // per column, -1 = skip
+    const double *in;
+    double *W;
+    int nranges;
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void colreduce_kernel(ColReduceArgs A) {
+    const int R = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const double *E    = A.stream + A.range_base[R];
+    const int32_t *dst = A.dst + A.range_colbase[R];
+    const double xin   = lane < len ? A.in[A.range_off[R] + lane] : 0.0;
+    for (int c = wv; c < C; c += WAVES) {
+        const int d = dst[c];
+        if (d < 0)
+            continue;
+        double v = lane < len ? E[(int64_t)c * len + lane] * xin : 0.0;
+        v        = wave_sum(v);
+        if (lane == 0)
+            atomicAdd(&A.W[d], v);
+    }
+}
+
+struct RowReduceArgs { // over R-streams: W[S.off + i] += sum_col Rs[i,col] * W[coef[col]]
+    const double *stream;
+    const int32_t *task_range, *task_chunk;
+    const int32_t *range_off, *range_len, *range_cols;
+    const int64_t *range_base, *range_colbase;
+    const int32_t *coef; // per column index into W, -1 = skip
+    double *W;
+    int ntasks;
+    int row_shift; // added to the range's local offset to address W (mirror pass: S0 - T0)
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A) {
+    const int task = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S];
+    int w = C - (ch << 7);
+    w     = w > 128 ? 128 : w;
+    const int wp      = (w + 1) & ~1;
+    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * 128;
+    const int64_t cb  = A.range_colbase[S] + (ch << 7);
+    double c0 = 0, c1 = 0;
+    if (lane < w) {
+        const int d = A.coef[cb + lane];
+        c0          = d >= 0 ? A.W[d] : 0.0;
+    }
+    bool any = false;
+    if (lane + 64 < w) {
+        const int d = A.coef[cb + lane + 64];
+        c1          = d >= 0 ? A.W[d] : 0.0;
+        any         = d >= 0;
+    }
+    if (lane < w)
+        any = any || A.coef[cb + lane] >= 0;
+    if (!__any(any))
+        return; // no selected column in this chunk (e.g. mirror pass over an off-diagonal stripe)
+    for (int i = 0; i < len; i++) {
+        double v = 0;
+        if (lane < wp)
+            v = src[(int64_t)i * wp + lane] * c0;
+        if (lane + 64 < wp)
+            v = __builtin_fma(src[(int64_t)i * wp + lane + 64], c1, v);
+        v = wave_sum(v);
+        if (lane == 0)
+            atomicAdd(&A.W[A.range_off[S] + A.row_shift + i], v);
+    }
+}
+
+// small helpers -----------------------------------------------------------------------------------
+__global__ void axpby_kernel(int n, double alpha, const double *w, double beta, double *y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        y[i] = beta == 0.0 ? alpha * w[i] : alpha * w[i] + beta * y[i];
+}
+// user_to_cluster: out[i] = in[perm[i] - base]; cluster_to_user: out[perm[i] - base] = in[i]
+// (clustering/cluster_node.hpp:150-175)
+__global__ void gather_kernel(int n, const int32_t *perm, int base, const double *in, double *out, int mu) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)n * mu) {
+        const int i = e / mu, c = e - (int64_t)i * mu;
+        out[e]      = in[(int64_t)(perm[i] - base) * mu + c];
+    }
+}
+__global__ void scatter_kernel(int n, const int32_t *perm, int base, const double *in, double *out, int mu) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)n * mu) {
+        const int i = e / mu, c = e - (int64_t)i * mu;
+        out[(int64_t)(perm[i] - base) * mu + c] = in[e];
+    }
+}
+// strided column extract / insert for row-major multi-RHS (X[n][mu])
+__global__ void col_extract_kernel(int n, int mu, int c, const double *X, double *x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        x[i] = X[(int64_t)i * mu + c];
+}
+__global__ void col_insert_kernel(int n, int mu, int c, const double *y, double *Y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        Y[(int64_t)i * mu + c] = y[i];
+}
+__global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
+    int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = in[i];
+}
+
+} // namespace hmx

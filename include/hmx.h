@@ -1,0 +1,154 @@
+/* hmx.h -- C ABI of libhmx: MI355X-native H-matrix block compression + H-matvec engine.
+ *
+ * This is the drop-in boundary.  Every entry point states the htool interface it
+ * replaces (paths relative to htool's include/htool/).  Plain pointers and sizes only; no C++ or torch
+ * types.  All functions return 0 on success and a negative hmx_status otherwise; nothing throws across
+ * the boundary (htool's convention is "log and continue / return false", misc/logger.hpp:74-76 -- the
+ * C++ adaptor in htool_amd/include/hmx/htool_adaptor.hpp maps non-zero to that).
+ *
+ * Numbering: "cluster numbering" = htool's internal numbering (position i holds user point perm[i],
+ * clustering/cluster_tree_data.hpp:21); "user numbering" = the caller's.
+ * Vectors may live in host or device memory (hmx_mem).  Device pointers are what a one-process-per-GPU
+ * caller (torch tensor .data_ptr()) passes; `stream` is a hipStream_t cast to void* (NULL = default).
+ */
+#ifndef HMX_H
+#define HMX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    HMX_OK                = 0,
+    HMX_ERR_INVALID       = -1, /* bad argument / unsupported combination (htool logs ERROR, e.g. add_hmatrix_vector_product.hpp:59-62) */
+    HMX_ERR_NO_DEVICE     = -2, /* HIP device missing: the engine never falls back to a CPU path */
+    HMX_ERR_HIP           = -3, /* a HIP runtime call failed; see hmx_last_error() */
+    HMX_ERR_STATE         = -4, /* call order violated (e.g. matvec before compress) */
+    HMX_ERR_UNSUPPORTED   = -5
+} hmx_status;
+
+typedef enum { HMX_MEM_HOST = 0, HMX_MEM_DEVICE = 1 } hmx_mem;
+
+/* clustering/implementations/partitioning.hpp: direction policy x splitting policy x (Partitioning | Partitioning_N) */
+typedef enum { HMX_DIR_LARGEST_EXTENT = 0, HMX_DIR_BOUNDING_BOX = 1 } hmx_direction;
+typedef enum { HMX_SPLIT_REGULAR = 0, HMX_SPLIT_GEOMETRIC = 1 } hmx_splitting;
+
+/* hmatrix/lrmat/{partialACA,sympartialACA,fullACA,SVD}.hpp */
+typedef enum { HMX_PARTIAL_ACA = 0, HMX_SYMPARTIAL_ACA = 1, HMX_FULL_ACA = 2, HMX_SVD = 3 } hmx_compressor;
+
+/* Device-evaluable generators (the user's VirtualGenerator::copy_submatrix, hmatrix/interfaces/virtual_generator.hpp:24,
+ * for the BEM-style kernels the reference ships: examples/use_hmatrix.cpp:33, testing/generator_test.hpp:159,185):
+ *   HMX_KERNEL_INV_DIST : K(x,y) = 1 / (params[0] + params[1] * |x - y|)                                  */
+typedef enum { HMX_KERNEL_INV_DIST = 0 } hmx_kernel;
+
+typedef struct hmx_cluster_tree hmx_cluster_tree;
+typedef struct hmx_block_tree hmx_block_tree;
+typedef struct hmx_hmatrix hmx_hmatrix;
+
+/* one row of the cluster table, preorder (clustering/cluster_output.hpp:60-71 fields) */
+typedef struct {
+    int32_t depth, offset, size, rank, counter, n_children;
+    double radius;
+    double center[3];
+} hmx_cluster_node;
+
+/* one leaf of the block tree, in htool's build order (hmatrix/hmatrix_output.hpp:43-54 fields + flags) */
+typedef struct {
+    int32_t t_offset, t_size, s_offset, s_size;
+    int32_t admissible; /* 1: low-rank candidate (m_admissible_tasks), 0: dense task                     */
+    int32_t mirror;     /* 1: leaf is in leaves_for_symmetry (hmatrix/hmatrix.hpp:262-264)                 */
+    int32_t symmetric;  /* 1: diagonal leaf carrying symmetry/UPLO (tree_builder.hpp:125-132)              */
+    int32_t rank;       /* after compression: rank, or -1 for dense (HMatrix::get_rank, hmatrix.hpp:137)   */
+} hmx_leaf;
+
+typedef struct {
+    int64_t n_dense, n_lowrank, n_false_positive;
+    int64_t cgen_dense, cgen_lowrank; /* number_of_generated_coefficient, hmatrix/hmatrix_output.hpp:153-175 */
+    int32_t rank_min, rank_max;
+    double rank_mean;
+    int64_t stream_bytes;        /* bytes resident in HBM for the matvec streams                            */
+    double t_compress_s, t_assemble_s, t_pack_s; /* hipEvent timings of the build phases                   */
+} hmx_stats;
+
+const char *hmx_last_error(void);
+int hmx_device_count(void);
+
+/* ---- test geometries (testing/geometry.hpp:11-61), seeded mt19937(0) --------------------------------- */
+int hmx_geometry(const char *name /* "ellipse" | "disk" | "ball" */, int n, double z, double *coords /* n*3 */);
+
+/* ---- cluster tree: ClusterTreeBuilder::create_cluster_tree (clustering/tree_builder/tree_builder.hpp:52-207) */
+int hmx_cluster_tree_create(int n, int dim, const double *coords /* n*dim, AoS */, const double *radii /* n or NULL */,
+                            const double *weights /* n or NULL */, int maximal_leaf_size, int number_of_children,
+                            int size_of_partition, int direction, int splitting, int partitioning_n,
+                            hmx_cluster_tree **out);
+void hmx_cluster_tree_destroy(hmx_cluster_tree *);
+int hmx_cluster_tree_size(const hmx_cluster_tree *);            /* number of points                         */
+int hmx_cluster_tree_num_nodes(const hmx_cluster_tree *);
+int hmx_cluster_tree_num_partitions(const hmx_cluster_tree *);
+const int32_t *hmx_cluster_tree_permutation(const hmx_cluster_tree *); /* Cluster::get_permutation           */
+int hmx_cluster_tree_nodes(const hmx_cluster_tree *, hmx_cluster_node *out /* num_nodes, preorder */);
+int hmx_cluster_tree_partition(const hmx_cluster_tree *, int32_t *offset_size /* 2*num_partitions */);
+
+/* ---- block tree: HMatrixTreeBuilder::build_block_tree + reset_root (hmatrix/tree_builder/tree_builder.hpp:417-566) */
+int hmx_block_tree_create(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
+                          char uplo, int min_target_depth, int min_source_depth, int target_partition_number,
+                          int partition_number_for_symmetry, int block_tree_consistency, hmx_block_tree **out);
+void hmx_block_tree_destroy(hmx_block_tree *);
+int64_t hmx_block_tree_num_leaves(const hmx_block_tree *);
+int hmx_block_tree_leaves(const hmx_block_tree *, hmx_leaf *out);
+int hmx_block_tree_root(const hmx_block_tree *, int32_t *t_off_size_s_off_size /* 4 */, char *symmetry_for_leaves, char *uplo_for_leaves);
+
+/* ---- H-matrix on the device ---------------------------------------------------------------------------- */
+int hmx_hmatrix_create(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out);
+void hmx_hmatrix_destroy(hmx_hmatrix *);
+
+/* generator = built-in kernel on (target coords, source coords), both in USER numbering (AoS, dim <= 3) */
+int hmx_hmatrix_set_kernel(hmx_hmatrix *, int kernel, const double *params, int nparams, int dim,
+                           const double *target_coords, const double *source_coords);
+
+/* HMatrixTreeBuilder::{sequential,openmp}_compute_blocks (tree_builder.hpp:568-666): compress every
+ * admissible leaf (fallback to dense when the compressor reports failure), assemble every dense leaf
+ * (HMatrix::compute_dense_data, hmatrix.hpp:222-226), then lay the result out as matvec streams. */
+int hmx_hmatrix_compress(hmx_hmatrix *, int compressor, double epsilon, int reqrank);
+
+/* Upload path: blocks compressed elsewhere (e.g. by htool's own CPU compressors behind a user
+ * VirtualGenerator).  Low rank: U is M x r column-major, V is r x N column-major (LowRankMatrix,
+ * hmatrix/lrmat/lrmat.hpp:15-45); dense: M x N column-major (matrix/matrix.hpp:100).
+ * Call hmx_hmatrix_finalize() after the last block. */
+int hmx_hmatrix_set_block_lowrank(hmx_hmatrix *, int64_t leaf, int rank, const double *U, const double *V);
+int hmx_hmatrix_set_block_dense(hmx_hmatrix *, int64_t leaf, const double *D);
+int hmx_hmatrix_finalize(hmx_hmatrix *);
+
+/* Download path (so the reference's CPU leaf loop can multiply the engine's blocks): */
+int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *, int32_t *rank /* num_leaves, -1 dense */);
+int hmx_hmatrix_get_block(const hmx_hmatrix *, int64_t leaf, double *U_or_D, double *V);
+int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);
+
+/* openmp_internal_add_hmatrix_vector_product (hmatrix/linalg/add_hmatrix_vector_product.hpp:107-170):
+ * out = alpha * op(H) * in + beta * out, cluster numbering, vectors local to the H-matrix' root clusters.
+ * trans in {'N','T'}.  mu = 1. */
+int hmx_hmatrix_matvec(hmx_hmatrix *, char trans, double alpha, const double *in, double beta, double *out,
+                       int mem /* hmx_mem */, void *stream);
+/* add_hmatrix_vector_product (same file :173-197): user numbering; permutations done on the device.
+ * Only valid when the block tree root is the cluster-tree root (or a partition with local permutation). */
+int hmx_hmatrix_matvec_user(hmx_hmatrix *, char trans, double alpha, const double *in, double beta, double *out,
+                            int mem, void *stream);
+/* openmp_internal_add_hmatrix_matrix_product_row_major (hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:112-178):
+ * in/out row-major (mu fastest), cluster numbering. */
+int hmx_hmatrix_matmat_row_major(hmx_hmatrix *, char trans, double alpha, const double *in, double beta, double *out,
+                                 int mu, int mem, void *stream);
+
+/* Timing hooks for bench.py: average duration (ms) of the last matvec's kernels measured with HIP
+ * events on the launch stream; names[i] is a static string. */
+int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *, int max, const char **names, float *ms);
+/* Enable/disable per-kernel event timing (adds event records to the stream). */
+int hmx_hmatrix_set_profiling(hmx_hmatrix *, int enabled);
+
+/* Device bandwidth probe: plain 16 B/lane copy of `bytes` bytes, returns GB/s (read+write counted). */
+int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""Product host layer (libhmx cluster tree + block tree) against the reference's golden fixtures: bit-exact
+permutation, cluster table (ints and fp64) and leaf list, for every clustering strategy, symmetry, row
+partition and minimal-depth case the fixtures hold.  No GPU needed; no compute entry point is called."""
+import numpy as np
+import pytest
+
+import htool_amd as hm
+from helpers import HMAT_CASES, load, params
+
+STRATEGY = {"pca_regular": ("largest_extent", "regular", False), "pca_geometric": ("largest_extent", "geometric", False),
+            "bbox_regular": ("bounding_box", "regular", False), "bbox_geometric": ("bounding_box", "geometric", False),
+            "n_pca_regular": ("largest_extent", "regular", True), "n_bbox_regular": ("bounding_box", "regular", True)}
+
+
+def build_trees(p):
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(p["leaf"])
+    b.set_partitioning_strategy(*STRATEGY[p["partitioning"]])
+    xt = hm.create_geometry(p["geom"], p["n"])
+    T = b.create_cluster_tree(p["n"], 3, xt, p["children"], p["partitions"])
+    if p["nsrc"]:
+        xs = hm.create_geometry(p["sgeom"], p["nsrc"], p["sz"])
+        S = b.create_cluster_tree(p["nsrc"], 3, xs, p["children"], p["partitions"])
+    else:
+        S = T
+    return T, S
+
+
+@pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_partial"])
+def test_geometry(name):
+    p, g = params(name), load(name)
+    assert np.array_equal(hm.create_geometry(p["geom"], p["n"]), g["xt"])
+
+
+@pytest.mark.parametrize("name", HMAT_CASES)
+def test_cluster_tree_bit_exact(name):
+    p, g = params(name), load(name)
+    T, S = build_trees(p)
+    assert np.array_equal(T.get_permutation(), g["t_perm"])
+    assert np.array_equal(T.nodes_int(), g["t_nodes_int"])
+    assert np.array_equal(T.nodes_real(), g["t_nodes_real"])
+    assert np.array_equal(T.get_clusters_on_partition(), g["t_partition"])
+    if p["nsrc"]:
+        assert np.array_equal(S.get_permutation(), g["s_perm"])
+        assert np.array_equal(S.nodes_int(), g["s_nodes_int"])
+        assert np.array_equal(S.nodes_real(), g["s_nodes_real"])
+
+
+@pytest.mark.parametrize("name", HMAT_CASES)
+def test_block_tree_bit_exact(name):
+    p, g = params(name), load(name)
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
+    tb.set_minimal_target_depth(p["mindepth"])
+    tb.set_minimal_source_depth(p["mindepth"])
+    bt = tb.build_block_tree(T, S, p["rank"], p["rank"])
+    a = bt.leaves
+    ref = g["leaves"]
+    got = np.stack([a["t_offset"], a["t_size"], a["s_offset"], a["s_size"]], axis=1)
+    assert np.array_equal(got, ref[:, :4])
+    assert np.array_equal(a["mirror"], ref[:, 5])
+    # a dense task can never end up low rank; an admissible task may fall back to dense (false positive)
+    assert np.all(a["admissible"][ref[:, 4] >= 0] == 1)
+    if g["rootinfo"][4] == 0:
+        assert np.array_equal(a["admissible"] == 1, ref[:, 4] >= 0)
+    assert list(bt.root) == list(g["rootinfo"][:4])
+    assert ord(bt.symmetry_for_leaves) == g["rootinfo"][5] and ord(bt.uplo_for_leaves) == g["rootinfo"][6]
+
+
+def test_larger_tree_matches_oracle():
+    """Beyond fixture size: product vs oracle restatement at N = 60 000 (both geometries)."""
+    from oracle import oracle as O
+    for geom in ("ellipse", "ball"):
+        x = hm.create_geometry(geom, 60000)
+        b = hm.ClusterTreeBuilder()
+        b.set_maximal_leaf_size(100)
+        T = b.create_cluster_tree(60000, 3, x, 2, 4)
+        To = O.ClusterTree(x, 100, 2, 4)
+        assert np.array_equal(T.get_permutation(), To.perm)
+        assert np.array_equal(T.nodes_int(), To.nodes_int)
+        assert np.array_equal(T.nodes_real(), To.nodes_real)
+        tb = hm.HMatrixTreeBuilder(1e-4, 10.0, "N", "N")
+        bt = tb.build_block_tree(T, T, 2, 2)
+        Ho = O.HMatrix(To, To, eps=1e-1, eta=10.0, rank=2, reqrank=1, parallel=True)
+        a = bt.leaves
+        assert np.array_equal(np.stack([a["t_offset"], a["t_size"], a["s_offset"], a["s_size"]], axis=1), Ho.leaves[:, :4])
+
+
+def test_invalid_arguments_are_reported():
+    x = hm.create_geometry("disk", 100)
+    b = hm.ClusterTreeBuilder()
+    T = b.create_cluster_tree(100, 3, x, 2, 2)
+    with pytest.raises(hm.HmxError):
+        hm.HMatrixTreeBuilder(1e-3, 10.0, "S", "N").build_block_tree(T, T)  # check_inputs, tree_builder.hpp:79-91
+    with pytest.raises(hm.HmxError):
+        hm.HMatrixTreeBuilder(1e-3, 10.0, "N", "N").build_block_tree(T, T, 5, 5)  # partition number too large
+    with pytest.raises(hm.HmxError):
+        b.create_cluster_tree(100, 5, np.zeros((100, 5)), 2, 2)
