@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- H-matvec throughput of the HIP engine on MI355X (BASELINE.json metric).
+
+A "step" is one H-matrix-vector product y = H x of the whole operator (trans='N', alpha=1, beta=0), input
+vector already resident in HBM in cluster ("partition") numbering:
+  N = 1 : config "N=1e6 fp64, eta=10, eps=1e-4, 1xMI355X" (BASELINE.json configs[2]; the metric is quoted at
+          N=1e6 and it fits one GPU), planar 4:1 ellipse, kernel 1/(1e-5+|x-y|), leaf 100, partialACA,
+          minimal block depth 5.
+  N > 1 : the same operator row-partitioned over N GPUs (DistributedOperator, configs[3]): local product +
+          all-gather of the output slices over RCCL; strong scaling (total work fixed).
+value = algorithmic bytes of the whole job / step time, B_alg = 8 * [C_gen + (N_source + N_target)] per rank
+(C_gen = htool's number_of_generated_coefficient), summed over ranks, max time over ranks.
+
+One JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     : dominant kernel (expand_kernel) algorithmic bytes per launch / its average duration measured
+                 with HIP events on the launch stream, against the 8 TB/s HBM3E peak.
+  cpu_baseline : the CPU restatement of htool's OpenMP leaf loop (oracle/, "port") timed on this box's host
+                 cores on a bounded sample (the block rows of the first 1/16 of the rows) of the SAME
+                 compressed operator.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--geom", default="ellipse")
+    ap.add_argument("--eps", type=float, default=1e-4)
+    ap.add_argument("--eta", type=float, default=10.0)
+    ap.add_argument("--leaf", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
+    return ap.parse_args()
+
+
+def minimal_depth(n):
+    """Smallest d with n / 2^d <= 46340 (no admissible block can reach M*N >= 2^31)."""
+    d = 0
+    while n / (2 ** d) > 46340:
+        d += 1
+    return d
+
+
+def cpu_baseline(H, T, frac, log):
+    """Time the CPU restatement of openmp_internal_add_hmatrix_vector_product on a row slab of the operator."""
+    from oracle import oracle as O
+    tab = H.leaf_table()
+    n = T.get_size()
+    nodes = T.nodes_int()
+    # row slab [0, cut): the smallest cluster at offset 0 that is at least as large as the largest leaf's
+    # target cluster and as frac*n -- no leaf straddles it, so rows [0,cut) depend on the selected leaves only
+    need = max(int(tab[:, 1].max()), int(frac * n))
+    cand = nodes[(nodes[:, 1] == 0) & (nodes[:, 2] >= need)]
+    cut = int(cand[:, 2].min())
+    sel = np.nonzero(tab[:, 0] + tab[:, 1] <= cut)[0]
+    t0 = time.time()
+    data, offs, pos = [], [], 0
+    for b in sel:
+        blk = H.get_block(int(b))
+        if tab[b, 4] >= 0:
+            u, v = np.asfortranarray(blk[0]).ravel("F"), np.asfortranarray(blk[1]).ravel("F")
+            offs.append((pos, pos + u.size))
+            data += [u, v]
+            pos += u.size + v.size
+        else:
+            d = np.asfortranarray(blk).ravel("F")
+            offs.append((pos, 0))
+            data.append(d)
+            pos += d.size
+    log("cpu_baseline: downloaded %d leaves (%.2f GB) in %.1fs" % (len(sel), pos * 8 / 1e9, time.time() - t0))
+    Ho = O.HMatrix.from_blocks(tab[sel], np.array(offs), np.concatenate(data), [0, cut, 0, H.source_size])
+    x = O.hashed_vector(H.source_size, 1)
+    best = 1e30
+    y = None
+    for _ in range(4):
+        t = time.time()
+        y = Ho.matvec(x, "N", 1.0, 0.0, policy="omp")
+        best = min(best, time.time() - t)
+    bytes_alg = 8.0 * (pos + H.source_size + cut)
+    return dict(value=bytes_alg / best / 1e9, unit="GB/s", cores=int(O.lib().orc_num_threads()), kind="port",
+                sample="block rows [0,%d) of the same compressed operator (%d leaves, %.2f GB), "
+                       "openmp leaf loop, best of 4" % (cut, len(sel), pos * 8 / 1e9)), y, cut
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    import torch
+    import torch.distributed as dist
+    import htool_amd as hm
+    from htool_amd import distributed as D
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.n
+    t0 = time.time()
+    x = hm.create_geometry(args.geom, n)
+    ctb = hm.ClusterTreeBuilder()
+    ctb.set_maximal_leaf_size(args.leaf)
+    # single GPU: HMatrixBuilder's default of 2 partitions (hmatrix/utility.hpp:23), whole operator on the GPU
+    T = ctb.create_cluster_tree(n, 3, x, 2, world if world > 1 else 2)
+    t_tree = time.time() - t0
+    tb = hm.HMatrixTreeBuilder(args.eps, args.eta, "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    d = minimal_depth(n)
+    tb.set_minimal_target_depth(d)
+    tb.set_minimal_source_depth(d)
+    gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0)
+    t0 = time.time()
+    part = world > 1
+    H = tb.build(gen, T, T, rank if part else -1, rank if part else -1, device=local_rank)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    st = H.stats()
+    log("cluster tree %.1fs, device build %.1fs (ACA %.2fs, pack+assemble %.2fs): %d dense + %d low-rank leaves, rank %d/%.2f/%d, "
+        "C_gen %.3e + %.3e, %.2f GB in HBM" % (t_tree, t_build, st["t_compress_s"], st["t_pack_s"], st["n_dense"], st["n_lowrank"],
+                                               st["rank_min"], st["rank_mean"], st["rank_max"], st["cgen_dense"], st["cgen_lowrank"],
+                                               st["stream_bytes"] / 1e9))
+
+    tp = D.PartitionFromCluster(T)
+    A = D.DistributedOperator(tp, tp)
+    A.add_global_to_local_operator(D.RestrictedGlobalToLocalHMatrix(H))
+    xin = torch.from_numpy(np.random.default_rng(1).random(n)).to(dev)  # partition numbering, resident in HBM
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    y_loc = torch.zeros(H.nb_rows(), dtype=torch.float64, device=dev)
+
+    def step():
+        if part:
+            D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y)
+        else:
+            hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y_loc)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    b_alg = torch.tensor([8.0 * (st["cgen_dense"] + st["cgen_lowrank"] + n + H.nb_rows())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(b_alg, op=dist.ReduceOp.SUM)
+    ms_per_step = float(tmax.item()) / args.steps * 1e3
+    value = float(b_alg.item()) / (ms_per_step * 1e-3) / 1e9
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, same steps ------------------------
+    H.set_profiling(True)
+    acc = {}
+    nprof = max(3, min(args.steps, 10))
+    for _ in range(nprof):
+        hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y_loc)
+        for name, ms in H.last_kernel_times():
+            acc.setdefault(name, []).append(ms)
+    H.set_profiling(False)
+    kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+    exp_bytes = 8.0 * (st["expand_coeffs"] + st["a_total"] + n + H.nb_rows())
+    red_bytes = 8.0 * (st["reduce_coeffs"] + st["a_total"] + n)
+    exp_ms = kern_ms.get("expand_kernel", float("nan"))
+    achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")  # measured separately with rocprofv3 --pmc
+    if os.path.exists(tf) and world == 1 and n == 1000000:
+        traffic = json.load(open(tf)).get("expand_kernel_hbm_bytes_per_launch")
+    roofline = dict(bound="hbm", kernel="expand_kernel", achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
+                    traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
+                    kernels_ms=kern_ms, reduce_kernel_GBps=red_bytes / (kern_ms.get("reduce_kernel", float("nan")) * 1e-3) / 1e9)
+
+    out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
+                           parallelism="row-partition x%d + all-gather" % world if part else "single GPU",
+                           n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
+                           algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
+                           build_s=dict(cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
+               roofline=roofline)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cb, y_cpu, cut = cpu_baseline(H, T, args.cpu_sample_frac, log)
+            # the same sample through the engine: parity on the slab while we are at it
+            xh = torch.from_numpy(__import__("oracle.oracle", fromlist=["x"]).hashed_vector(n, 1)).to(dev)
+            yh = torch.zeros(H.nb_rows(), dtype=torch.float64, device=dev)
+            hm.internal_add_hmatrix_vector_product("N", 1.0, H, xh, 0.0, yh)
+            err = float(np.linalg.norm(yh[:cut].cpu().numpy() - y_cpu) / np.linalg.norm(y_cpu))
+            cb["rel_err_engine_vs_cpu_on_sample"] = err
+            out["cpu_baseline"] = cb
+        except Exception as e:  # the baseline is a reported number, never the product path
+            out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,7 @@ class Stats(C.Structure):
     _fields_ = [("n_dense", C.c_int64), ("n_lowrank", C.c_int64), ("n_false_positive", C.c_int64),
                 ("cgen_dense", C.c_int64), ("cgen_lowrank", C.c_int64), ("rank_min", C.c_int32),
                 ("rank_max", C.c_int32), ("rank_mean", C.c_double), ("stream_bytes", C.c_int64),
+                ("expand_coeffs", C.c_int64), ("reduce_coeffs", C.c_int64), ("a_total", C.c_int64),
                 ("t_compress_s", C.c_double), ("t_assemble_s", C.c_double), ("t_pack_s", C.c_double)]
 
 
@@ -83,6 +84,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise HmxError("libhmx.so not found at %s -- build it with `make -C htool_amd/csrc` "
                            "(or __graft_entry__.build()); htool_amd has no fallback path" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime (soname libamdhip64.so.7).  Two HIP runtimes in
+        # one process cannot both open the GPU, so when torch is installed it is imported FIRST: libhmx's
+        # NEEDED libamdhip64.so.7 then resolves to the runtime torch already loaded (one runtime, one context;
+        # torch tensors, streams and RCCL interoperate with libhmx's pointers).  HMX_NO_TORCH=1 skips this.
+        if not os.environ.get("HMX_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the C ABI lost a symbol

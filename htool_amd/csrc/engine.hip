@@ -438,6 +438,12 @@ static int build_streams(hmx_hmatrix &H) {
     H.stats.t_pack_s     = tim.s();
     H.stats.t_assemble_s = ms * 1e-3;
     H.stats.stream_bytes = (E.elems + R.elems) * 8;
+    H.stats.expand_coeffs = E.elems;
+    H.stats.a_total       = A_total;
+    H.stats.reduce_coeffs = 0;
+    for (int64_t b = 0; b < nb; b++)
+        if (H.kind[b] == LK_LOWRANK && H.leaves[b].rank > 0)
+            H.stats.reduce_coeffs += (int64_t)H.leaves[b].rank * H.leaves[b].s_size;
     H.finalized          = true;
     return HMX_OK;
 }

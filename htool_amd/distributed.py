@@ -1,0 +1,215 @@
+"""Row-partitioned DistributedOperator over torch.distributed (RCCL over xGMI on MI355X; gloo in CPU tests).
+
+Mirror of the reference's MPI layer for the hot path (paths relative to htool's include/htool/):
+
+  VirtualPartition / PartitionFromCluster   distributed_operator/implementations/partition_from_cluster.hpp:11-42
+  VirtualGlobalToLocalOperator              distributed_operator/interfaces/virtual_global_to_local_operator.hpp:16-33
+  RestrictedGlobalToLocalHMatrix            distributed_operator/implementations/global_to_local_operators/hmatrix.hpp:15-35
+  DistributedOperator                       distributed_operator/distributed_operator.hpp:20-61
+  DefaultApproximationBuilder               distributed_operator/utility.hpp:38-61
+  internal_add_..._global_to_global         distributed_operator/linalg/add_distributed_operator_vector_product_global_to_global.hpp:18-85
+  add_..._global_to_global                  same file :97-118
+  internal_add_..._local_to_local           distributed_operator/linalg/add_distributed_operator_vector_product_local_to_local.hpp:19-89
+
+One process per GPU; rank k owns the block rows of partition cluster k.  The MPI collectives map to
+  MPI_Allgatherv (trans='N', C1/C3)  -> all_gather_into_tensor on a max-size padded buffer (RCCL has no allgatherv;
+                                        partition sizes differ by at most the split remainder)
+  MPI_Allreduce  (trans!='N', C2)    -> all_reduce(SUM)
+  MPI_Alltoallv + axpys (C4)         -> reduce_scatter on the padded layout
+Vectors are torch tensors that stay on the device; only pointers cross the C ABI.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class PartitionFromCluster:
+    """Partition k = cluster on partition k of the cluster tree; "partition numbering" is the tree's
+    cluster numbering (global_to_partition_numbering = global_to_root_cluster, cluster_node.hpp:100-119)."""
+
+    def __init__(self, cluster):
+        self._cluster = cluster
+        self._part = np.asarray(cluster.get_clusters_on_partition())
+        self._perm = torch.from_numpy(np.asarray(cluster.get_permutation()).astype(np.int64))
+        self._perm_dev = {}
+
+    def get_size_of_partition(self, k):
+        return int(self._part[k, 1])
+
+    def get_offset_of_partition(self, k):
+        return int(self._part[k, 0])
+
+    def get_global_size(self):
+        return int(self._cluster.get_size())
+
+    def number_of_partitions(self):
+        return len(self._part)
+
+    def _perm_on(self, device):
+        key = str(device)
+        if key not in self._perm_dev:
+            self._perm_dev[key] = self._perm.to(device)
+        return self._perm_dev[key]
+
+    def global_to_partition_numbering(self, x):
+        return x.index_select(0, self._perm_on(x.device))
+
+    def partition_to_global_numbering(self, x, out=None):
+        out = torch.empty_like(x) if out is None else out
+        out.index_copy_(0, self._perm_on(x.device), x)
+        return out
+
+
+class RestrictedGlobalToLocalHMatrix:
+    """Local (N/p) x N H-matrix of this rank as a global-to-local operator.  `in` is the whole input
+    vector in partition numbering for trans='N' (the local slice for trans!='N'); `out` the local slice
+    (the whole vector for trans!='N').  Calls the HIP engine through the C ABI."""
+
+    def __init__(self, hmatrix):
+        self.hmatrix = hmatrix
+
+    def add_vector_product(self, trans, alpha, x, beta, y):
+        from . import api
+        api.internal_add_hmatrix_vector_product(trans, alpha, self.hmatrix, x, beta, y)
+
+    def add_matrix_product_row_major(self, trans, alpha, X, beta, Y, mu):
+        from . import api
+        api.internal_add_hmatrix_matrix_product_row_major(trans, alpha, self.hmatrix, X, beta, Y, mu)
+
+
+class DistributedOperator:
+    def __init__(self, target_partition, source_partition, group=None):
+        self.target_partition, self.source_partition = target_partition, source_partition
+        self.group = group
+        self.global_to_local_operators = []
+        self.local_to_local_operators = []
+        self._pad = {}
+
+    def add_global_to_local_operator(self, op):
+        self.global_to_local_operators.append(op)
+
+    def add_local_to_local_operator(self, op):
+        self.local_to_local_operators.append(op)
+
+    # communicator
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _gather_slices(self, local, partition, out):
+        """out[offset_k : offset_k + size_k] = rank k's `local` (MPI_Allgatherv)."""
+        p = self.size()
+        if p == 1:
+            out.copy_(local)
+            return
+        sizes = [partition.get_size_of_partition(k) for k in range(p)]
+        m = max(sizes)
+        key = (m, p, local.device, local.dtype, tuple(local.shape[1:]))
+        if key not in self._pad:
+            self._pad[key] = (torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device),
+                              torch.empty((p * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device))
+        send, recv = self._pad[key]
+        send[:local.shape[0]].copy_(local)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        for k in range(p):
+            out[partition.get_offset_of_partition(k):partition.get_offset_of_partition(k) + sizes[k]].copy_(recv[k * m:k * m + sizes[k]])
+
+
+def internal_add_distributed_operator_vector_product_global_to_global(trans, alpha, A, x, beta, y):
+    """Partition numbering; x and y are whole vectors replicated on every rank."""
+    rank = A.rank()
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    off_in, n_in = in_part.get_offset_of_partition(rank), in_part.get_size_of_partition(rank)
+    off_out, n_out = out_part.get_offset_of_partition(rank), out_part.get_size_of_partition(rank)
+    if trans == "N":
+        local = y[off_out:off_out + n_out].clone() if beta != 0 else torch.zeros(n_out, dtype=y.dtype, device=y.device)
+        apply_beta = True
+        for op in A.global_to_local_operators:
+            op.add_vector_product(trans, alpha, x, beta if apply_beta else 1.0, local)
+            apply_beta = False
+        for op in A.local_to_local_operators:
+            op.add_vector_product(trans, alpha, x[off_in:off_in + n_in], beta if apply_beta else 1.0, local)
+            apply_beta = False
+        A._gather_slices(local, out_part, y)
+    else:
+        y_old = y.clone() if beta != 0 else None
+        y.zero_()
+        x_loc = x[off_in:off_in + n_in].contiguous()
+        apply_beta = True
+        for op in A.global_to_local_operators:
+            op.add_vector_product(trans, alpha, x_loc, beta if apply_beta else 1.0, y)
+            apply_beta = False
+        for op in A.local_to_local_operators:
+            op.add_vector_product(trans, alpha, x_loc, beta if apply_beta else 1.0, y[off_out:off_out + n_out])
+            apply_beta = False
+        if A.size() > 1:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=A.group)
+        if beta != 0:
+            y.add_(y_old, alpha=beta)
+    return y
+
+
+def add_distributed_operator_vector_product_global_to_global(trans, alpha, A, x, beta, y):
+    """User numbering: permute to partition numbering, multiply, permute back."""
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    xp = in_part.global_to_partition_numbering(x)
+    yp = out_part.global_to_partition_numbering(y) if beta != 0 else torch.zeros_like(y)
+    internal_add_distributed_operator_vector_product_global_to_global(trans, alpha, A, xp, beta, yp)
+    out_part.partition_to_global_numbering(yp, out=y)
+    return y
+
+
+def internal_add_distributed_operator_vector_product_local_to_local(trans, alpha, A, x_loc, beta, y_loc):
+    """The Krylov-side contract (wrappers/wrapper_hpddm.hpp:121): local slices in and out, partition numbering.
+    trans='N': all-gather the input, local product, output stays local.  trans!='N': local product into a
+    zeroed global buffer, reduce-scatter."""
+    rank, p = A.rank(), A.size()
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    if trans == "N":
+        apply_beta = True
+        for op in A.local_to_local_operators:
+            op.add_vector_product(trans, alpha, x_loc, beta if apply_beta else 1.0, y_loc)
+            apply_beta = False
+        if A.global_to_local_operators:
+            x = torch.empty(in_part.get_global_size(), dtype=x_loc.dtype, device=x_loc.device)
+            A._gather_slices(x_loc, in_part, x)  # local_to_global, linalg/utility.hpp:11-28
+            for op in A.global_to_local_operators:
+                op.add_vector_product(trans, alpha, x, beta if apply_beta else 1.0, y_loc)
+                apply_beta = False
+    else:
+        if beta != 1:
+            y_loc.mul_(beta)
+        for op in A.local_to_local_operators:
+            op.add_vector_product(trans, alpha, x_loc, 1.0, y_loc)
+        if A.global_to_local_operators:
+            buf = torch.zeros(out_part.get_global_size(), dtype=x_loc.dtype, device=x_loc.device)
+            for op in A.global_to_local_operators:
+                op.add_vector_product(trans, alpha, x_loc, 1.0, buf)
+            if p > 1:
+                # MPI_Alltoallv + p axpys == a reduce-scatter; done as all_reduce + slice to keep uneven
+                # partitions simple (N doubles over xGMI; the local product dominates)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=A.group)
+            off, n = out_part.get_offset_of_partition(rank), out_part.get_size_of_partition(rank)
+            y_loc.add_(buf[off:off + n])
+    return y_loc
+
+
+class DefaultApproximationBuilder:
+    """Builds this rank's block rows on its GPU and wires them into a DistributedOperator
+    (distributed_operator/utility.hpp:38-61).  Holds `hmatrix`, `distributed_operator`."""
+
+    def __init__(self, generator, target_cluster, source_cluster, hmatrix_tree_builder, group=None, device=None):
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if device is None:
+            device = torch.cuda.current_device()
+        self.target_partition = PartitionFromCluster(target_cluster)
+        self.source_partition = PartitionFromCluster(source_cluster)
+        self.hmatrix = hmatrix_tree_builder.build(generator, target_cluster, source_cluster, rank, rank, device=device)
+        self.local_hmatrix = RestrictedGlobalToLocalHMatrix(self.hmatrix)
+        self.distributed_operator = DistributedOperator(self.target_partition, self.source_partition, group)
+        self.distributed_operator.add_global_to_local_operator(self.local_hmatrix)

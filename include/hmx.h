@@ -68,6 +68,9 @@ typedef struct {
     int32_t rank_min, rank_max;
     double rank_mean;
     int64_t stream_bytes;        /* bytes resident in HBM for the matvec streams                            */
+    int64_t expand_coeffs;       /* coefficients streamed by the expand kernel (dense + U panels)           */
+    int64_t reduce_coeffs;       /* coefficients streamed by the reduce kernel (V panels)                   */
+    int64_t a_total;             /* sum of ranks (length of the intermediate vector a = V x)                */
     double t_compress_s, t_assemble_s, t_pack_s; /* hipEvent timings of the build phases                   */
 } hmx_stats;
 
