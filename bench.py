@@ -195,6 +195,13 @@ def main():
                     traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
                     kernels_ms=kern_ms, reduce_kernel_GBps=red_bytes / (kern_ms.get("reduce_kernel", float("nan")) * 1e-3) / 1e9)
 
+    # measured device copy bandwidth (16 B/lane copy kernel, read+write) as the practical HBM ceiling on this box
+    import ctypes
+    bw = ctypes.c_double(0.0)
+    hm.lib().hmx_device_copy_bandwidth(local_rank, 2 << 30, 5, ctypes.byref(bw))
+    roofline["measured_copy_GBps"] = bw.value
+    roofline["frac_of_measured_copy"] = achieved / bw.value if bw.value > 0 else None
+
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
