@@ -1,0 +1,50 @@
+// Test program (dev container only: needs the htool headers): builds an htool cluster tree + H-matrix on the
+// CPU and checks that the adaptor's hmx structure mirrors it leaf for leaf.  No GPU: the device step is expected
+// to report an error through htool's Logger and return false.
+#include <htool/clustering/tree_builder/tree_builder.hpp>
+#include <htool/hmatrix/tree_builder/tree_builder.hpp>
+#include <htool/hmatrix/lrmat/partialACA.hpp>
+#include <htool/testing/geometry.hpp>
+#include "hmx/htool_adaptor.hpp"
+#include <cstdio>
+using namespace htool;
+class Gen : public VirtualGenerator<double> {
+    const std::vector<double> &x;
+  public:
+    explicit Gen(const std::vector<double> &x_) : x(x_) {}
+    void copy_submatrix(int M, int N, const int *rows, const int *cols, double *ptr) const override {
+        for (int j = 0; j < M; j++)
+            for (int k = 0; k < N; k++) {
+                double s = 0;
+                for (int p = 0; p < 3; p++) { double d = x[3 * rows[j] + p] - x[3 * cols[k] + p]; s = s + d * d; }
+                ptr[j + (size_t)M * k] = 1. / (1e-5 + std::sqrt(s));
+            }
+    }
+};
+int main() {
+    const int n = 3000;
+    std::vector<double> x(3 * n);
+    create_rotated_ellipse(3, 4., 1., 0., 0., n, x.data());
+    ClusterTreeBuilder<double> ctb;
+    ctb.set_maximal_leaf_size(100);
+    Cluster<double> T = ctb.create_cluster_tree(n, 3, x.data(), 2, 2);
+    Gen A(x);
+    HMatrixTreeBuilder<double> tb(1e-4, 10., 'S', 'L');
+    HMatrix<double> H = tb.sequential_build(A, T, T);
+    hmx_htool::ClusterOptions opt;
+    opt.maximal_leaf_size = 100; opt.number_of_children = 2; opt.size_of_partition = 2;
+    hmx_htool::Engine E(T, n, x.data(), T, n, x.data(), 3, opt);
+    bool device = E.setup_block_tree(10., 'S', 'L', 0, 0, -1, -1, 0);
+    size_t nleaves = 0, missing = 0;
+    std::vector<const HMatrix<double> *> st{&H};
+    while (!st.empty()) {
+        auto *c = st.back(); st.pop_back();
+        if (c->is_leaf()) {
+            nleaves++;
+            if (E.find_leaf(c->get_target_cluster().get_offset(), c->get_target_cluster().get_size(), c->get_source_cluster().get_offset(), c->get_source_cluster().get_size()) < 0) missing++;
+        }
+        for (auto &ch : c->get_children()) st.push_back(ch.get());
+    }
+    std::printf("htool_leaves=%zu hmx_leaves=%zu missing=%zu device=%d\n", nleaves, E.number_of_leaves(), missing, (int)device);
+    return (missing == 0 && nleaves == E.number_of_leaves()) ? 0 : 1;
+}
