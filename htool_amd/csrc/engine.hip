@@ -58,13 +58,13 @@ struct DArr { // device array with RAII
 
 // One family of streams (E = expand over target ranges, R = reduce over source ranges)
 struct StreamSet {
-    std::vector<int32_t> off, len, cols; // per range: local offset, rows, columns
+    std::vector<int32_t> off, len, cols, cw; // per range: local offset, rows, columns, chunk width (R only)
     std::vector<int64_t> base, colbase;  // per range: first element in `stream`, first entry in index arrays
     int64_t elems = 0, total_cols = 0;
-    DArr<int32_t> d_off, d_len, d_cols;
+    DArr<int32_t> d_off, d_len, d_cols, d_cw;
     DArr<int64_t> d_base, d_colbase;
     DArr<double> stream;
-    // R only: one task per (range, 128-column chunk)
+    // R: one task per (range, column chunk), heaviest first.  E: task_range = launch order of the ranges.
     std::vector<int32_t> task_range, task_chunk;
     DArr<int32_t> d_task_range, d_task_chunk;
     int nranges() const { return (int)off.size(); }
@@ -73,6 +73,7 @@ struct StreamSet {
         if ((e = d_off.upload(off)) != hipSuccess) return e;
         if ((e = d_len.upload(len)) != hipSuccess) return e;
         if ((e = d_cols.upload(cols)) != hipSuccess) return e;
+        if ((e = d_cw.upload(cw)) != hipSuccess) return e;
         if ((e = d_base.upload(base)) != hipSuccess) return e;
         if ((e = d_colbase.upload(colbase)) != hipSuccess) return e;
         if ((e = d_task_range.upload(task_range)) != hipSuccess) return e;
@@ -185,27 +186,41 @@ struct Timer {
 static int build_streams(hmx_hmatrix &H) {
     Timer tim;
     const int64_t nb = (int64_t)H.leaves.size();
-    constexpr int TR_MAX = 64, SR_MAX = 256;
+    constexpr int TR_MAX = 64, SR_MAX = 512;
     // ---- ranges ---------------------------------------------------------------------------------
-    std::vector<int> tbp{H.T0, H.T0 + H.nT}, sbp;
+    // E ranges partition the local rows at every block boundary (each output row has exactly one owner).
+    // R ranges are per DISTINCT source cluster of the low-rank leaves (cut into pieces of <= SR_MAX rows): a
+    // block is reduced over ceil(n/SR_MAX) pieces of its own cluster instead of over every leaf cluster below
+    // it, so blocks up to SR_MAX columns need no partial sums at all and the largest ones a few dozen.
+    std::vector<int> tbp{H.T0, H.T0 + H.nT};
+    std::vector<std::pair<int, int>> sclusters;
     for (int64_t b = 0; b < nb; b++) {
         const hmx_leaf &l = H.leaves[b];
         tbp.push_back(l.t_offset);
         tbp.push_back(l.t_offset + l.t_size);
-        if (H.kind[b] == LK_LOWRANK && l.rank > 0) {
-            sbp.push_back(l.s_offset);
-            sbp.push_back(l.s_offset + l.s_size);
-        }
+        if (H.kind[b] == LK_LOWRANK && l.rank > 0)
+            sclusters.emplace_back(l.s_offset, l.s_size);
     }
+    std::sort(sclusters.begin(), sclusters.end());
+    sclusters.erase(std::unique(sclusters.begin(), sclusters.end()), sclusters.end());
     StreamSet &E = H.E, &R = H.R;
     make_ranges(tbp, TR_MAX, H.T0, E.off, E.len);
-    make_ranges(sbp, SR_MAX, H.S0, R.off, R.len);
+    R.off.clear();
+    R.len.clear();
+    std::vector<int32_t> scluster_first(sclusters.size() + 1, 0);
+    for (size_t c = 0; c < sclusters.size(); c++) {
+        std::vector<int> bp{sclusters[c].first, sclusters[c].first + sclusters[c].second};
+        std::vector<int32_t> o, ln;
+        make_ranges(bp, SR_MAX, H.S0, o, ln);
+        scluster_first[c] = (int32_t)R.off.size();
+        R.off.insert(R.off.end(), o.begin(), o.end());
+        R.len.insert(R.len.end(), ln.begin(), ln.end());
+    }
+    scluster_first[sclusters.size()] = (int32_t)R.off.size();
     // position -> range lookup
-    std::vector<int32_t> t_pos2range(H.nT + 1, -1), s_pos2range(H.nS + 1, -1);
+    std::vector<int32_t> t_pos2range(H.nT + 1, -1);
     for (int r = 0; r < E.nranges(); r++)
         t_pos2range[E.off[r]] = r;
-    for (int r = 0; r < R.nranges(); r++)
-        s_pos2range[R.off[r]] = r;
     auto range_span = [](const std::vector<int32_t> &pos2range, const StreamSet &S, int lo, int hi, int &ra, int &rb) {
         ra = pos2range[lo];
         rb = ra;
@@ -214,6 +229,7 @@ static int build_streams(hmx_hmatrix &H) {
     };
     // ---- columns per range, pair lists, a / partial offsets ----------------------------------------
     E.cols.assign(E.nranges(), 0);
+    E.cw.assign(E.nranges(), 0);
     R.cols.assign(R.nranges(), 0);
     std::vector<int32_t> elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c;
     std::vector<int64_t> aoff(nb, -1), poff(nb, -1);
@@ -239,8 +255,8 @@ static int build_streams(hmx_hmatrix &H) {
         if (lr) {
             aoff[b] = A_total;
             A_total += l.rank;
-            int sa, sb;
-            range_span(s_pos2range, R, l.s_offset - H.S0, l.s_offset - H.S0 + l.s_size, sa, sb);
+            const size_t sc = std::lower_bound(sclusters.begin(), sclusters.end(), std::make_pair((int)l.s_offset, (int)l.s_size)) - sclusters.begin();
+            const int sa = scluster_first[sc], sb = scluster_first[sc + 1];
             ns_of[b]   = sb - sa;
             s_first[b] = sa;
             if (sb - sa > 1) {
@@ -278,24 +294,50 @@ static int build_streams(hmx_hmatrix &H) {
         E.elems += (int64_t)E.len[r] * E.cols[r];
         E.total_cols += E.cols[r];
     }
+    E.task_range.resize(E.nranges());
+    std::iota(E.task_range.begin(), E.task_range.end(), 0);
+    if (!getenv("HMX_SORT_TASKS") || atoi(getenv("HMX_SORT_TASKS")))
+        std::stable_sort(E.task_range.begin(), E.task_range.end(), [&](int a, int b) { return (int64_t)E.len[a] * E.cols[a] > (int64_t)E.len[b] * E.cols[b]; });
+    E.task_chunk.clear();
     R.base.assign(R.nranges(), 0);
     R.colbase.assign(R.nranges(), 0);
     R.elems = R.total_cols = 0;
     R.task_range.clear();
     R.task_chunk.clear();
+    R.cw.assign(R.nranges(), 2);
     for (int r = 0; r < R.nranges(); r++) {
         R.base[r]    = R.elems;
         R.colbase[r] = R.total_cols;
         const int C = R.cols[r], nch = (C + 127) / 128;
-        if (C > 0) {
-            const int wlast = C - (nch - 1) * 128;
-            R.elems += (int64_t)R.len[r] * ((int64_t)(nch - 1) * 128 + ((wlast + 1) & ~1));
+        if (C > 0) { // balanced chunks: nch chunks of width cw (even), the last one takes what is left
+            const int cw = (((C + nch - 1) / nch) + 1) & ~1;
+            R.cw[r]      = cw;
+            const int wlast = C - (nch - 1) * cw;
+            R.elems += (int64_t)R.len[r] * ((int64_t)(nch - 1) * cw + ((wlast + 1) & ~1));
         }
         R.total_cols += C;
         for (int c = 0; c < nch; c++) {
             R.task_range.push_back(r);
             R.task_chunk.push_back(c);
         }
+    }
+    if (!getenv("HMX_SORT_TASKS") || atoi(getenv("HMX_SORT_TASKS"))) { // longest tasks first: shorter kernel tail (-8 % on reduce_kernel)
+        std::vector<int> ord(R.task_range.size());
+        std::iota(ord.begin(), ord.end(), 0);
+        auto work = [&](int t) {
+            const int r = R.task_range[t], c = R.task_chunk[t];
+            int w = R.cols[r] - c * R.cw[r];
+            w     = std::min(w, (int)R.cw[r]);
+            return (int64_t)R.len[r] * w;
+        };
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return work(a) > work(b); });
+        std::vector<int32_t> tr(ord.size()), tc(ord.size());
+        for (size_t k = 0; k < ord.size(); k++) {
+            tr[k] = R.task_range[ord[k]];
+            tc[k] = R.task_chunk[ord[k]];
+        }
+        R.task_range.swap(tr);
+        R.task_chunk.swap(tc);
     }
     if (E.total_cols >= (int64_t(1) << 31) || R.total_cols >= (int64_t(1) << 31) || (int64_t)H.nS + A_total + P_total + 2 >= (int64_t(1) << 31)) {
         set_error("operator too large for 32-bit column indices");
@@ -403,7 +445,7 @@ static int build_streams(hmx_hmatrix &H) {
             HMX_HIP(pr.upload(elr_r));
             HMX_HIP(pc.upload(elr_c));
             PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.stream.d, H.T0};
+                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0};
             hipLaunchKernelGGL(pack_lr_expand_kernel, dim3((unsigned)elr_b.size()), dim3(256), 0, 0, P, (int64_t)elr_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -413,7 +455,7 @@ static int build_streams(hmx_hmatrix &H) {
             HMX_HIP(pr.upload(rlr_r));
             HMX_HIP(pc.upload(rlr_c));
             PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.stream.d, H.S0};
+                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0};
             hipLaunchKernelGGL(pack_lr_reduce_kernel, dim3((unsigned)rlr_b.size()), dim3(256), 0, 0, P, (int64_t)rlr_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -505,12 +547,18 @@ static int run_forward(hmx_hmatrix &H, const int32_t *zidx, const double *x_src,
             HMX_HIP(hipMemcpyAsync(H.Z.d + (lo - H.S0), x_src + (lo - H.T0), (size_t)(hi - lo) * 8, hipMemcpyDeviceToDevice, st));
     }
     prof_mark(H, st, "copy_x");
-    constexpr int RW = 4, EW = 4;
+    static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 4; // tuning knobs
+    static const int EW = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 4;
     const int ntasks = (int)H.R.task_range.size();
     if (ntasks > 0) {
-        ReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_base.d, H.R.d_colbase.d,
+        ReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                      H.r_outidx.d, H.Z.d, H.Z.d, ntasks};
-        hipLaunchKernelGGL(reduce_kernel<RW>, dim3((ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, A);
+        switch (RW) {
+        case 1: hipLaunchKernelGGL(reduce_kernel<1>, dim3(ntasks), dim3(64), 0, st, A); break;
+        case 2: hipLaunchKernelGGL(reduce_kernel<2>, dim3((ntasks + 1) / 2), dim3(128), 0, st, A); break;
+        case 8: hipLaunchKernelGGL(reduce_kernel<8>, dim3((ntasks + 7) / 8), dim3(512), 0, st, A); break;
+        default: hipLaunchKernelGGL(reduce_kernel<4>, dim3((ntasks + 3) / 4), dim3(256), 0, st, A); break;
+        }
         prof_mark(H, st, "reduce_kernel");
     }
     if (H.n_combine > 0) {
@@ -519,8 +567,13 @@ static int run_forward(hmx_hmatrix &H, const int32_t *zidx, const double *x_src,
         prof_mark(H, st, "combine_kernel");
     }
     if (H.E.nranges() > 0) {
-        ExpandArgs X{H.E.stream.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges()};
-        hipLaunchKernelGGL(expand_kernel<EW>, dim3(H.E.nranges()), dim3(EW * 64), 0, st, X);
+        ExpandArgs X{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges()};
+        switch (EW) {
+        case 1: hipLaunchKernelGGL(expand_kernel<1>, dim3(H.E.nranges()), dim3(64), 0, st, X); break;
+        case 2: hipLaunchKernelGGL(expand_kernel<2>, dim3(H.E.nranges()), dim3(128), 0, st, X); break;
+        case 8: hipLaunchKernelGGL(expand_kernel<8>, dim3(H.E.nranges()), dim3(512), 0, st, X); break;
+        default: hipLaunchKernelGGL(expand_kernel<4>, dim3(H.E.nranges()), dim3(256), 0, st, X); break;
+        }
         prof_mark(H, st, "expand_kernel");
     }
     HMX_HIP(hipGetLastError());
@@ -546,7 +599,7 @@ static int run_transposed(hmx_hmatrix &H, bool mirror, const double *in, double 
     const int ntasks = (int)H.R.task_range.size();
     if (ntasks > 0) {
         // rows of the R-streams are source positions; the mirror pass writes them into a target-local vector
-        RowReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_base.d, H.R.d_colbase.d,
+        RowReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                         mirror ? H.r_tcoef_mirror.d : H.r_tcoef.d, H.W.d, ntasks, mirror ? H.S0 - H.T0 : 0};
         hipLaunchKernelGGL(rowreduce_kernel<RW>, dim3((ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, A);
         prof_mark(H, st, "rowreduce_kernel");

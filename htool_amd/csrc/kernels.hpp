@@ -288,6 +288,7 @@ struct PackLrArgs {
     const int32_t *range_off, *range_len;
     const int64_t *range_base;
     const int32_t *range_cols; // C of the range (R-stream only)
+    const int32_t *range_cw;   // chunk width of the range (R-stream only)
     double *stream;
     int origin;                // global cluster position of local offset 0 (T0 for E-streams, S0 for R-streams)
 };
@@ -311,13 +312,14 @@ __global__ void pack_lr_expand_kernel(PackLrArgs P, int64_t npairs) {
     }
 }
 
-__device__ __forceinline__ int64_t rstream_index(int64_t base, int len, int C, int i, int col) {
-    // row-major, 128-column chunks; a chunk of width w is stored with row pitch w rounded up to even
-    const int ch = col >> 7, cw = col & 127;
-    int w        = C - (ch << 7);
-    w            = w > 128 ? 128 : w;
+__device__ __forceinline__ int64_t rstream_index(int64_t base, int len, int C, int cw, int i, int col) {
+    // row-major, chunks of cw columns (cw even, <= 128, chosen per range so the chunks are balanced); the last
+    // chunk may be narrower and is stored with its own row pitch rounded up to even
+    const int ch = col / cw, within = col - ch * cw;
+    int w        = C - ch * cw;
+    w            = w > cw ? cw : w;
     w            = (w + 1) & ~1;
-    return base + (int64_t)ch * len * 128 + (int64_t)i * w + cw;
+    return base + (int64_t)ch * len * cw + (int64_t)i * w + within;
 }
 
 // V slices -> R-stream
@@ -333,7 +335,7 @@ __global__ void pack_lr_reduce_kernel(PackLrArgs P, int64_t npairs) {
     for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
         const int k = e / len, i = e - k * len;
         const double *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
-        P.stream[rstream_index(P.range_base[S], len, C, i, col + k)] = src[rel + i];
+        P.stream[rstream_index(P.range_base[S], len, C, P.range_cw[S], i, col + k)] = src[rel + i];
     }
 }
 
@@ -386,12 +388,13 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
 // ---------------------------------------------------------------------------------------------
 // H-matvec, trans = 'N'
 // ---------------------------------------------------------------------------------------------
-// Stage 1 (add_lrmat_vector_product.hpp:16, a = V x): one wave per (source range, 128-column chunk).
-// lane owns two adjacent columns, walks the rows; x_S[i] is wave-uniform.
+// Stage 1 (add_lrmat_vector_product.hpp:16, a = V x): one wave per (source range, column chunk).
+// lane owns two adjacent columns and walks the rows; the x slice is loaded 64 rows at a time (one
+// coalesced load) and broadcast with v_readlane, so the row loop contains only the 16-B stream loads.
 struct ReduceArgs {
     const double *stream;
     const int32_t *task_range, *task_chunk;
-    const int32_t *range_off, *range_len, *range_cols;
+    const int32_t *range_off, *range_len, *range_cols, *range_cw;
     const int64_t *range_base;
     const int64_t *range_colbase; // first entry of the range in out_idx
     const int32_t *out_idx;       // per column: destination in Z (an `a` slot or a partial slot)
@@ -407,34 +410,40 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
         return;
     const int lane = threadIdx.x & 63;
     const int S = A.task_range[task], ch = A.task_chunk[task];
-    const int len = A.range_len[S], C = A.range_cols[S];
-    int w = C - (ch << 7);
-    w     = w > 128 ? 128 : w;
-    const int wp     = (w + 1) & ~1;
-    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * 128 + 2 * lane;
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp      = (w + 1) & ~1;
+    const bool active = 2 * lane < wp;
+    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
     const double *xs  = A.x + A.range_off[S];
     double a0 = 0, a1 = 0;
-    if (2 * lane < wp) {
-        int i = 0;
-        for (; i + 8 <= len; i += 8) {
+    for (int i0 = 0; i0 < len; i0 += 64) {
+        const int nr    = (len - i0) < 64 ? (len - i0) : 64;
+        const double xv = lane < nr ? xs[i0 + lane] : 0.0;
+        const double *p = src + (int64_t)i0 * wp;
+        int j = 0;
+        for (; j + 8 <= nr; j += 8) {
             double2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = *reinterpret_cast<const double2 *>(src + (int64_t)(i + u) * wp);
+                v[u] = *reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const double xi = xs[i + u];
+                const double xi = readlane_f64(xv, j + u);
                 a0              = __builtin_fma(v[u].x, xi, a0);
                 a1              = __builtin_fma(v[u].y, xi, a1);
             }
         }
-        for (; i < len; i++) {
-            const double2 v = *reinterpret_cast<const double2 *>(src + (int64_t)i * wp);
-            const double xi = xs[i];
+        for (; j < nr; j++) {
+            const double2 v = *reinterpret_cast<const double2 *>(p + (int64_t)j * wp);
+            const double xi = readlane_f64(xv, j);
             a0              = __builtin_fma(v.x, xi, a0);
             a1              = __builtin_fma(v.y, xi, a1);
         }
-        const int64_t cb = A.range_colbase[S] + (ch << 7) + 2 * lane;
+    }
+    if (active) {
+        const int64_t cb = A.range_colbase[S] + ch * cw + 2 * lane;
         if (2 * lane < w)
             A.Z[A.out_idx[cb]] = a0;
         if (2 * lane + 1 < w)
@@ -465,6 +474,7 @@ __global__ void combine_kernel(CombineArgs A) {
 // one workgroup per target row range, lane = row, the waves split the columns in 64-column chunks.
 struct ExpandArgs {
     const double *stream;
+    const int32_t *order; // launch position -> range (heaviest ranges first)
     const int32_t *range_off, *range_len, *range_cols;
     const int64_t *range_base;
     const int64_t *range_colbase;
@@ -478,7 +488,7 @@ struct ExpandArgs {
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
     __shared__ double part[WAVES][WAVE];
-    const int R = blockIdx.x;
+    const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
     const double *E     = A.stream + A.range_base[R];
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void colreduce_kernel(ColReduceArgs A)
 struct RowReduceArgs { // over R-streams: W[S.off + i] += sum_col Rs[i,col] * W[coef[col]]
     const double *stream;
     const int32_t *task_range, *task_chunk;
-    const int32_t *range_off, *range_len, *range_cols;
+    const int32_t *range_off, *range_len, *range_cols, *range_cw;
     const int64_t *range_base, *range_colbase;
     const int32_t *coef; // per column index into W, -1 = skip
     double *W;
@@ -566,12 +576,12 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
         return;
     const int lane = threadIdx.x & 63;
     const int S = A.task_range[task], ch = A.task_chunk[task];
-    const int len = A.range_len[S], C = A.range_cols[S];
-    int w = C - (ch << 7);
-    w     = w > 128 ? 128 : w;
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
-    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * 128;
-    const int64_t cb  = A.range_colbase[S] + (ch << 7);
+    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const int64_t cb  = A.range_colbase[S] + ch * cw;
     double c0 = 0, c1 = 0;
     if (lane < w) {
         const int d = A.coef[cb + lane];

@@ -106,6 +106,10 @@ class DistributedOperator:
             return
         sizes = [partition.get_size_of_partition(k) for k in range(p)]
         m = max(sizes)
+        if min(sizes) == m and out.is_contiguous() and partition.get_offset_of_partition(0) == 0:
+            # equal partitions (e.g. N = 1e6 over 8 GPUs): gather straight into the output, no staging copies
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+            return
         key = (m, p, local.device, local.dtype, tuple(local.shape[1:]))
         if key not in self._pad:
             self._pad[key] = (torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device),
