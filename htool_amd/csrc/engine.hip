@@ -755,10 +755,11 @@ int hmx_hmatrix_compress(hmx_hmatrix *Hp, int compressor, double epsilon, int re
         set_error("hmx_hmatrix_compress: no generator set (hmx_hmatrix_set_kernel)");
         return HMX_ERR_STATE;
     }
-    if (compressor != HMX_PARTIAL_ACA && compressor != HMX_SYMPARTIAL_ACA) {
-        set_error("hmx_hmatrix_compress: only partialACA and sympartialACA run on the device in this build");
-        return HMX_ERR_UNSUPPORTED;
+    if (compressor < HMX_PARTIAL_ACA || compressor > HMX_SVD) {
+        set_error("hmx_hmatrix_compress: unknown compressor");
+        return HMX_ERR_INVALID;
     }
+    const bool assembled = (compressor == HMX_FULL_ACA || compressor == HMX_SVD); // works on the assembled block
     if (reqrank == 0)
         reqrank = -1;
     HMX_HIP(hipSetDevice(H.device));
@@ -781,7 +782,8 @@ int hmx_hmatrix_compress(hmx_hmatrix *Hp, int compressor, double epsilon, int re
         const int64_t M = l.t_size, N = l.s_size;
         int64_t qmax = (M * N) / (M + N);
         if (reqrank > 0)
-            qmax = std::min<int64_t>(qmax, std::min<int64_t>(reqrank, std::min(M, N)));
+            qmax = compressor == HMX_SVD ? std::min<int64_t>(reqrank, std::min(M, N)) // SVD.hpp:64-92: no advantage test
+                                         : std::min<int64_t>(qmax, std::min<int64_t>(reqrank, std::min(M, N)));
         qmax        = std::max<int64_t>(1, std::min<int64_t>(qmax, RANK_CAP));
         H.colptr[b] = ncross;
         colcap[b]   = (int32_t)qmax;
@@ -823,7 +825,66 @@ int hmx_hmatrix_compress(hmx_hmatrix *Hp, int compressor, double epsilon, int re
     HMX_HIP(hipEventCreate(&e0));
     HMX_HIP(hipEventCreate(&e1));
     HMX_HIP(hipEventRecord(e0, 0));
-    if (!order.empty()) {
+    if (!order.empty() && assembled) {
+        // fullACA / SVD need the whole block: process the admissible leaves in batches that fit a scratch slab
+        std::vector<int64_t> need_elems(nb, 0);
+        int64_t largest = 0;
+        for (int32_t b : order) {
+            const int64_t M = H.leaves[b].t_size, N = H.leaves[b].s_size, m = std::max(M, N), n = std::min(M, N);
+            if (M * N >= (int64_t(1) << 31)) {
+                set_error("hmx_hmatrix_compress: fullACA/SVD need M*N < 2^31 per block (use a minimal block depth, as the reference must)");
+                return HMX_ERR_UNSUPPORTED;
+            }
+            need_elems[b] = compressor == HMX_FULL_ACA ? M * N : m * n + n * n + 2 * n;
+            largest       = std::max(largest, need_elems[b]);
+        }
+        size_t free2 = 0, total2 = 0;
+        HMX_HIP(hipMemGetInfo(&free2, &total2));
+        const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free2 / 8.0));
+        if ((double)largest * 8.0 > 0.9 * (double)free2) {
+            set_error("hmx_hmatrix_compress: an admissible block does not fit in HBM for fullACA/SVD");
+            return HMX_ERR_HIP;
+        }
+        DArr<double> scratch;
+        HMX_HIP(scratch.alloc(slab));
+        std::vector<int64_t> soff(nb, 0);
+        DArr<int64_t> d_soff;
+        size_t pos = 0;
+        while (pos < order.size()) {
+            int64_t used = 0;
+            size_t end   = pos;
+            while (end < order.size() && used + need_elems[order[end]] <= slab) {
+                soff[order[end]] = used;
+                used += need_elems[order[end]];
+                end++;
+            }
+            HMX_HIP(d_soff.upload(soff));
+            DenseCompressArgs D{};
+            D.ks = H.ks;
+            D.tx = H.tx.d; D.ty = H.ty.d; D.tz = H.tz.d;
+            D.sx = H.sx.d; D.sy = H.sy.d; D.sz = H.sz.d;
+            D.order = d_order.d + pos;
+            D.t_off = H.d_t_off.d; D.t_size = H.d_t_size.d; D.s_off = H.d_s_off.d; D.s_size = H.d_s_size.d;
+            D.scratch_off = d_soff.d;
+            D.scratch     = scratch.d;
+            D.epsilon     = epsilon;
+            D.reqrank     = reqrank;
+            D.pool        = H.pool.d;
+            D.pool_head   = head.d;
+            D.pool_cap    = cap;
+            D.colptr      = H.d_colptr.d;
+            D.colcap      = d_colcap.d;
+            D.cross_off   = H.d_cross_off.d;
+            D.rank_out    = H.d_rank.d;
+            if (compressor == HMX_FULL_ACA)
+                hipLaunchKernelGGL(fullaca_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
+            else
+                hipLaunchKernelGGL(svd_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
+            HMX_HIP(hipGetLastError());
+            HMX_HIP(hipDeviceSynchronize());
+            pos = end;
+        }
+    } else if (!order.empty()) {
         AcaArgs A{};
         A.ks = H.ks;
         A.tx = H.tx.d; A.ty = H.ty.d; A.tz = H.tz.d;

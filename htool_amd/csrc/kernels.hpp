@@ -274,6 +274,272 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Compression of an ASSEMBLED block: fully pivoted ACA and truncated SVD (small blocks; O(M N min(M,N))).
+// One workgroup per block, the block lives in a scratch slab; results are written as crosses
+// [U(:,k) | V(k,:)] into the same pool the partial ACA uses, so packing is shared.
+// ---------------------------------------------------------------------------------------------
+struct DenseCompressArgs {
+    KernelSpec ks;
+    const double *tx, *ty, *tz, *sx, *sy, *sz;
+    const int32_t *order; // launch order -> block id
+    const int32_t *t_off, *t_size, *s_off, *s_size;
+    const int64_t *scratch_off; // per block: first double of its slab in `scratch`
+    double *scratch;
+    double epsilon;
+    int reqrank;
+    double *pool;
+    unsigned long long *pool_head;
+    unsigned long long pool_cap;
+    const int64_t *colptr;
+    const int32_t *colcap;
+    int64_t *cross_off;
+    int32_t *rank_out;
+};
+
+// fullACA::copy_low_rank_approximation (hmatrix/lrmat/fullACA.hpp:38-88)
+template <int NT>
+__global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
+    __shared__ double sval[NT / WAVE];
+    __shared__ int sidx[NT / WAVE];
+    __shared__ double sbuf[(NT / WAVE) * 2];
+    __shared__ unsigned long long s_off;
+    const int b = A.order[blockIdx.x];
+    const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
+    const int64_t MN = (int64_t)M * N;
+    double *mat      = A.scratch + A.scratch_off[b];
+    int64_t *cross   = A.cross_off + A.colptr[b];
+    const int cap    = A.colcap[b];
+    const int tid    = threadIdx.x;
+    double acc1[1]   = {0};
+    for (int64_t e = tid; e < MN; e += NT) {
+        const int i = (int)(e % M), j = (int)(e / M);
+        const double v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        mat[e]         = v;
+        acc1[0] += v * v;
+    }
+    block_sum_group<NT, 1>(acc1, sbuf);
+    const double Norm = sqrt(acc1[0]);
+    double cur        = Norm; // Frobenius norm of the current residual
+    int q             = 0;
+    const int reqrank = A.reqrank;
+    const int minmn   = M < N ? M : N;
+    while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (cur / Norm > A.epsilon || q == 0))) {
+        q += 1;
+        if ((long long)q * ((long long)M + N) > MN || q > cap) {
+            q = -1;
+            break;
+        }
+        // std::max_element over the column-major array: first maximum of |.| (matrix/utils/math.hpp:18-23)
+        double best = -1.0;
+        int64_t bi  = -1;
+        for (int64_t e = tid; e < MN; e += NT) {
+            const double a = fabs(mat[e]);
+            if (a > best) {
+                best = a;
+                bi   = e;
+            }
+        }
+        // block reduction with "smaller index wins ties": reuse block_argmax on (value, -index)
+        int neg = bi >= 0 ? (int)(-bi) : -2147483647; // MN < 2^31 is guaranteed by the caller
+        block_argmax<NT>(best, neg, sval, sidx);
+        const int64_t pe = -(int64_t)neg;
+        const int pi = (int)(pe % M), pj = (int)(pe / M);
+        const double pivot = mat[pe];
+        if (fabs(pivot) < 1e-15) {
+            q += -1;
+            break;
+        }
+        if (tid == 0)
+            s_off = atomicAdd(A.pool_head, (unsigned long long)(M + N));
+        __syncthreads();
+        const unsigned long long off = s_off;
+        if (off + (unsigned long long)(M + N) > A.pool_cap) {
+            q = -2;
+            break;
+        }
+        double *u = A.pool + off, *v = A.pool + off + M;
+        for (int i = tid; i < M; i += NT)
+            u[i] = mat[i + (int64_t)M * pj];
+        for (int j = tid; j < N; j += NT)
+            v[j] = mat[pi + (int64_t)M * j] / pivot;
+        __syncthreads();
+        acc1[0] = 0;
+        for (int64_t e = tid; e < MN; e += NT) {
+            const int i = (int)(e % M), j = (int)(e / M);
+            const double r = mat[e] - u[i] * v[j];
+            mat[e]         = r;
+            acc1[0] += r * r;
+        }
+        block_sum_group<NT, 1>(acc1, sbuf);
+        cur = sqrt(acc1[0]);
+        if (tid == 0)
+            cross[q - 1] = (int64_t)off;
+    }
+    if (tid == 0)
+        A.rank_out[b] = q > 0 ? q : (q == -2 ? -2 : 0);
+}
+
+// SVD::copy_low_rank_approximation (hmatrix/lrmat/SVD.hpp:27-92) with gesvd replaced by a one-sided Jacobi
+// SVD (LAPACK is a third-party dependency of the reference; its contract -- A = u diag(s) vt, s descending --
+// is what is reproduced) and the truncation rule of matrix/utils/SVD_truncation.hpp:37-52.
+// Slab layout: W (m x n, m >= n, column-major; A or A^T) | Vm (n x n) | sv (n) | order (n, as doubles)
+template <int NT>
+__global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
+    __shared__ int s_changed;
+    __shared__ int s_rank;
+    __shared__ unsigned long long s_off;
+    const int b = A.order[blockIdx.x];
+    const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
+    const bool tr = M < N;
+    const int m = tr ? N : M, n = tr ? M : N;
+    double *W   = A.scratch + A.scratch_off[b];
+    double *Vm  = W + (int64_t)m * n;
+    double *sv  = Vm + (int64_t)n * n;
+    double *ord = sv + n;
+    int64_t *cross = A.cross_off + A.colptr[b];
+    const int cap  = A.colcap[b];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = NT / WAVE;
+    for (int64_t e = tid; e < (int64_t)M * N; e += NT) {
+        const int i = (int)(e % M), j = (int)(e / M);
+        const double v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        if (tr)
+            W[j + (int64_t)m * i] = v;
+        else
+            W[i + (int64_t)m * j] = v;
+    }
+    for (int64_t e = tid; e < (int64_t)n * n; e += NT)
+        Vm[e] = (e % n == e / n) ? 1.0 : 0.0;
+    __syncthreads();
+    // cyclic one-sided Jacobi; the pairs of one round-robin round touch disjoint columns -> one wave per pair
+    const int np = (n + 1) & ~1; // players (one dummy when n is odd)
+    for (int sweep = 0; sweep < 60; sweep++) {
+        if (tid == 0)
+            s_changed = 0;
+        __syncthreads();
+        for (int round = 0; round < np - 1; round++) {
+            for (int k = wv; k < np / 2; k += NW) {
+                // circle method: position 0 is fixed, the others rotate
+                int p = k == 0 ? 0 : 1 + (k - 1 + round) % (np - 1);
+                int qq = 1 + (np - 1 - k - 1 + round) % (np - 1);
+                if (p > qq) {
+                    const int t = p;
+                    p           = qq;
+                    qq          = t;
+                }
+                if (qq >= n || p == qq)
+                    continue;
+                double *wp = W + (int64_t)m * p, *wq = W + (int64_t)m * qq;
+                double app = 0, aqq = 0, apq = 0;
+                for (int i = lane; i < m; i += WAVE) {
+                    const double a = wp[i], c = wq[i];
+                    app += a * a;
+                    aqq += c * c;
+                    apq += a * c;
+                }
+                app = wave_sum(app);
+                aqq = wave_sum(aqq);
+                apq = wave_sum(apq);
+                if (fabs(apq) <= 1e-300 || fabs(apq) <= 1e-17 * sqrt(app * aqq))
+                    continue;
+                if (fabs(apq) / sqrt(app * aqq) >= 1e-15 && lane == 0)
+                    s_changed = 1;
+                const double zeta = (aqq - app) / (2.0 * apq);
+                const double t    = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = lane; i < m; i += WAVE) {
+                    const double a = wp[i], c = wq[i];
+                    wp[i]          = cs * a - sn * c;
+                    wq[i]          = sn * a + cs * c;
+                }
+                double *vp = Vm + (int64_t)n * p, *vq = Vm + (int64_t)n * qq;
+                for (int i = lane; i < n; i += WAVE) {
+                    const double a = vp[i], c = vq[i];
+                    vp[i]          = cs * a - sn * c;
+                    vq[i]          = sn * a + cs * c;
+                }
+            }
+            __syncthreads();
+        }
+        const int changed = s_changed;
+        __syncthreads();
+        if (!changed)
+            break;
+    }
+    // singular values = column norms, descending order by counting
+    for (int j = wv; j < n; j += NW) {
+        double nn = 0;
+        for (int i = lane; i < m; i += WAVE)
+            nn += W[i + (int64_t)m * j] * W[i + (int64_t)m * j];
+        nn = wave_sum(nn);
+        if (lane == 0)
+            sv[j] = sqrt(nn);
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += NT) {
+        int pos = 0;
+        for (int k = 0; k < n; k++)
+            pos += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
+        ord[pos] = (double)j;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int r;
+        if (A.reqrank > 0) {
+            r = A.reqrank < n ? A.reqrank : n;
+        } else { // SVD_truncation.hpp:37-52: smallest k whose discarded tail stays below epsilon
+            double norm2 = 0, err = 0;
+            for (int k = 0; k < n; k++)
+                norm2 += sv[(int)ord[k]] * sv[(int)ord[k]];
+            const double nrm = sqrt(norm2);
+            int j = n;
+            do {
+                j = j - 1;
+                err += sv[(int)ord[j]] * sv[(int)ord[j]];
+            } while (j > 0 && sqrt(err) / nrm < A.epsilon);
+            r = j + 1;
+            if ((long long)r * ((long long)M + N) > (long long)M * N || r <= 0)
+                r = 0;
+        }
+        if (r > cap)
+            r = 0;
+        s_rank = r;
+        if (r > 0)
+            s_off = atomicAdd(A.pool_head, (unsigned long long)r * (unsigned long long)(M + N));
+    }
+    __syncthreads();
+    const int r = s_rank;
+    if (r > 0) {
+        const unsigned long long off = s_off;
+        if (off + (unsigned long long)r * (unsigned long long)(M + N) > A.pool_cap) {
+            if (tid == 0)
+                A.rank_out[b] = -2;
+            return;
+        }
+        for (int k = 0; k < r; k++) {
+            const int j     = (int)ord[k];
+            const double sj = sv[j], isj = sj > 0 ? 1.0 / sj : 0.0;
+            double *u = A.pool + off + (unsigned long long)k * (M + N), *v = u + M;
+            if (!tr) { // A = (W) Vm^T: U(:,k) = u_k s_k = W(:,j), V(k,:) = Vm(:,j)
+                for (int i = tid; i < M; i += NT)
+                    u[i] = W[i + (int64_t)m * j];
+                for (int c = tid; c < N; c += NT)
+                    v[c] = Vm[c + (int64_t)n * j];
+            } else { // A^T = W Vm^T  =>  A = Vm W^T: U(:,k) = Vm(:,j) s_j, V(k,:) = W(:,j) / s_j
+                for (int i = tid; i < M; i += NT)
+                    u[i] = Vm[i + (int64_t)n * j] * sj;
+                for (int c = tid; c < N; c += NT)
+                    v[c] = W[c + (int64_t)m * j] * isj;
+            }
+            if (tid == 0)
+                cross[k] = (int64_t)(off + (unsigned long long)k * (M + N));
+        }
+    }
+    if (tid == 0)
+        A.rank_out[b] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pack: move compressed data into the matvec streams
 // ---------------------------------------------------------------------------------------------
 struct PackLrArgs {

@@ -14,8 +14,8 @@ from test_host_structure import build_trees
 
 pytestmark = pytest.mark.gpu
 
-DEVICE_COMPRESSORS = ("partialACA", "sympartialACA")
-ACA_CASES = [c for c in HMAT_CASES if params(c)["compressor"] in DEVICE_COMPRESSORS]
+DEVICE_COMPRESSORS = ("partialACA", "sympartialACA", "fullACA", "SVD")
+ACA_CASES = [c for c in HMAT_CASES if params(c)["compressor"] in ("partialACA", "sympartialACA")]
 
 
 def build_engine(p, compress=True, generator=True):
@@ -175,3 +175,67 @@ def test_midsize_round_trip_properties():
     d = np.sqrt(((x[rows, None, :] - x[None, :, :]) ** 2).sum(-1))
     ref = (1.0 / (1e-5 + d)) @ u
     assert rel_err(yu[rows], ref) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["ball_n1200_fullACA", "ball_n1200_SVD"])
+def test_assembled_block_compressors_match_reference(name):
+    """fullACA and SVD on the device against the reference fixtures (fullACA: identical ranks; SVD: Jacobi vs
+    LAPACK gesvd, ranks may differ by one at the truncation threshold, as for the CPU oracle)."""
+    p, g = params(name), load(name)
+    T, S, H = build_engine(p)
+    tab, ref = H.leaf_table(), g["leaves"]
+    assert np.array_equal(tab[:, :4], ref[:, :4]) and np.array_equal(tab[:, 5], ref[:, 5])
+    if p["compressor"] == "fullACA":
+        assert np.array_equal(tab[:, 4], ref[:, 4])
+    else:
+        assert np.abs(tab[:, 4] - ref[:, 4]).max() <= 1 and (tab[:, 4] != ref[:, 4]).mean() < 0.02
+    for k in g:
+        if k.startswith("U_"):
+            b = int(k[2:])
+            U, V = H.get_block(b)
+            if U.shape[1] == g[k].shape[0]:
+                assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 1e-9
+    x, xT, y0, y0T = inputs(H)
+    alpha, beta = g["alphabeta"]
+    tol = 1e-10 if p["compressor"] == "fullACA" else 5e-4
+    y = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+    assert rel_err(y, g["yN"]) < tol
+    y = y0T.copy()
+    hm.internal_add_hmatrix_vector_product("T", alpha, H, xT, beta, y)
+    assert rel_err(y, g["yT"]) < tol
+
+
+@pytest.mark.parametrize("distance", [15, 20, 30, 40])
+def test_compressors_on_the_reference_test_block(distance):
+    """The reference's own compressor test (tests/functional_tests/hmatrix/lrmat/test_lrmat_build.hpp:32-78):
+    a 500 x 100 block between two unit disks, kernel 1/(4 pi r), eps 1e-4.  Fixed rank 10: rank == 10, absolute
+    Frobenius error < 1e-8, space saving in (0.87, 0.89); automatic rank: error < eps, space saving in the
+    reference's interval.  The block is made the single admissible leaf of a one-partition block tree."""
+    from oracle import oracle as O
+    nr, nc, eps = 500, 100, 1e-4
+    xt, xs = hm.create_geometry("disk", nr, 0.0), hm.create_geometry("disk", nc, float(distance))
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(10)
+    T, S = b.create_cluster_tree(nr, 3, xt, 2, 1), b.create_cluster_tree(nc, 3, xs, 2, 1)
+    gen = hm.InvDistGenerator(3, xt, xs, 0.0, 4 * np.pi)
+    To, So = O.ClusterTree(xt, 10, 2, 1), O.ClusterTree(xs, 10, 2, 1)
+    A = O.generate_block(To, So, nr, nc, 0, 0, 0.0, 4 * np.pi)
+    intervals = {"partialACA": (0.93, 0.96), "sympartialACA": (0.93, 0.96), "fullACA": (0.95, 0.97), "SVD": (0.95, 0.97)}
+    for comp in DEVICE_COMPRESSORS:
+        for reqrank in (10, -1):
+            tb = hm.HMatrixTreeBuilder(eps, 10.0, "N", "N", reqrank)
+            tb.set_low_rank_generator(comp)
+            H = tb.build(gen, T, S)
+            tab = H.leaf_table()
+            assert len(tab) == 1 and list(tab[0, :4]) == [0, nr, 0, nc]
+            U, V = H.get_block(0)
+            r = U.shape[1]
+            ro, Uo, Vo, _, _ = O.compress_block(To, So, comp, nr, nc, 0, 0, eps, reqrank=reqrank)
+            assert r == ro  # same rank as the CPU restatement on the same permutation
+            saving = 1.0 - r * (nr + nc) / float(nr * nc)  # LowRankMatrix::space_saving
+            if reqrank > 0:
+                assert r == 10 and np.linalg.norm(A - U @ V) < 1e-8 and 0.87 < saving < 0.89
+            else:
+                assert np.linalg.norm(A - U @ V) < eps and intervals[comp][0] < saving < intervals[comp][1]
+            assert rel_err(U @ V, Uo @ Vo) < 1e-9
