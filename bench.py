@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--eta", type=float, default=10.0)
     ap.add_argument("--leaf", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the row-partition + collective code path even with one rank (testing)")
+    ap.add_argument("--mu", type=int, default=1, help="number of right-hand sides (row-major multi-RHS product when > 1)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
     return ap.parse_args()
 
@@ -110,7 +112,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.n
@@ -119,7 +124,7 @@ def main():
     ctb = hm.ClusterTreeBuilder()
     ctb.set_maximal_leaf_size(args.leaf)
     # single GPU: HMatrixBuilder's default of 2 partitions (hmatrix/utility.hpp:23), whole operator on the GPU
-    T = ctb.create_cluster_tree(n, 3, x, 2, world if world > 1 else 2)
+    T = ctb.create_cluster_tree(n, 3, x, 2, world if use_dist else 2)
     t_tree = time.time() - t0
     tb = hm.HMatrixTreeBuilder(args.eps, args.eta, "N", "N")
     tb.set_low_rank_generator("partialACA")
@@ -128,7 +133,7 @@ def main():
     tb.set_minimal_source_depth(d)
     gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0)
     t0 = time.time()
-    part = world > 1
+    part = use_dist
     H = tb.build(gen, T, T, rank if part else -1, rank if part else -1, device=local_rank)
     torch.cuda.synchronize()
     t_build = time.time() - t0
@@ -145,15 +150,22 @@ def main():
     y = torch.zeros(n, dtype=torch.float64, device=dev)
     y_loc = torch.zeros(H.nb_rows(), dtype=torch.float64, device=dev)
 
+    mu = args.mu
+    if mu > 1:
+        Xmu = torch.from_numpy(np.random.default_rng(2).random((n, mu))).to(dev)
+        Ymu = torch.zeros((H.nb_rows(), mu), dtype=torch.float64, device=dev)
+
     def step():
-        if part:
+        if mu > 1:
+            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, Xmu, 0.0, Ymu, mu)
+        elif part:
             D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y)
         else:
             hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y_loc)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -166,8 +178,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    b_alg = torch.tensor([8.0 * (st["cgen_dense"] + st["cgen_lowrank"] + n + H.nb_rows())], dtype=torch.float64, device=dev)
-    if world > 1:
+    b_alg = torch.tensor([8.0 * (st["cgen_dense"] + st["cgen_lowrank"] + mu * (n + H.nb_rows()))], dtype=torch.float64, device=dev)
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(b_alg, op=dist.ReduceOp.SUM)
     ms_per_step = float(tmax.item()) / args.steps * 1e3
@@ -178,14 +190,17 @@ def main():
     acc = {}
     nprof = max(3, min(args.steps, 10))
     for _ in range(nprof):
-        hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y_loc)
+        if mu > 1:
+            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, Xmu, 0.0, Ymu, mu)
+        else:
+            hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y_loc)
         for name, ms in H.last_kernel_times():
             acc.setdefault(name, []).append(ms)
     H.set_profiling(False)
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
     exp_bytes = 8.0 * (st["expand_coeffs"] + st["a_total"] + n + H.nb_rows())
     red_bytes = 8.0 * (st["reduce_coeffs"] + st["a_total"] + n)
-    exp_ms = kern_ms.get("expand_kernel", float("nan"))
+    exp_ms = kern_ms.get("expand_kernel" if mu == 1 else "expand_mu_kernel", float("nan"))
     achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")  # measured separately with rocprofv3 --pmc
@@ -204,7 +219,7 @@ def main():
 
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
+               config=dict(mu=mu, workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
                            parallelism="row-partition x%d + all-gather" % world if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
@@ -224,7 +239,7 @@ def main():
             out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

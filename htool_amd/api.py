@@ -336,3 +336,27 @@ def internal_add_hmatrix_matrix_product_row_major(trans, alpha, A, X, beta, Y, m
         raise HmxError("in and out must live in the same memory space")
     check(lib().hmx_hmatrix_matmat_row_major(A._h, trans.encode(), alpha, px, beta, py, mu, mx, _stream_ptr(X)))
     return Y
+
+
+def add_hmatrix_matrix_product(transa, alpha, A, B, beta, Cm):
+    """Column-major multi-RHS front end in USER numbering (hmatrix/linalg/add_hmatrix_matrix_product.hpp:176-205):
+    Cm = alpha * op(A) * B + beta * Cm with B (n x mu) and Cm (m x mu) column-major (Fortran order).  As in the
+    reference (same file :26-77) every column is permuted to cluster numbering, the operands are transposed to
+    row-major (mu fastest), the row-major kernel runs, and the result is transposed and permuted back."""
+    if not (isinstance(B, np.ndarray) and isinstance(Cm, np.ndarray)):
+        raise HmxError("add_hmatrix_matrix_product takes host (numpy) matrices; use the row-major entry point for device tensors")
+    mu = B.shape[1]
+    tgt, src = A._keep
+    pin = (src if transa == "N" else tgt).get_permutation()
+    pout = (tgt if transa == "N" else src).get_permutation()
+    oin = A.source_offset if transa == "N" else A.target_offset
+    oout = A.target_offset if transa == "N" else A.source_offset
+    nin = A.source_size if transa == "N" else A.target_size
+    nout = A.target_size if transa == "N" else A.source_size
+    pin = pin[oin:oin + nin] - oin
+    pout = pout[oout:oout + nout] - oout
+    X = np.ascontiguousarray(np.asarray(B)[pin, :], dtype=np.float64)       # user_to_cluster per column + transpose
+    Y = np.ascontiguousarray(np.asarray(Cm)[pout, :], dtype=np.float64)
+    internal_add_hmatrix_matrix_product_row_major(transa, alpha, A, X, beta, Y, mu)
+    Cm[pout, :] = Y
+    return Cm

@@ -124,7 +124,7 @@ struct hmx_hmatrix {
     int n_combine       = 0;
     int64_t A_total     = 0, P_total = 0;
     int64_t zero_slot   = 0;
-    DArr<double> Z, W;
+    DArr<double> Z, W, Zmu;
     DArr<double> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
     DArr<int32_t> d_perm_t, d_perm_s;
     bool finalized = false;
@@ -576,6 +576,70 @@ static int run_forward(hmx_hmatrix &H, const int32_t *zidx, const double *x_src,
         }
         prof_mark(H, st, "expand_kernel");
     }
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+template <int MU>
+static void launch_mu(hmx_hmatrix &H, ReduceArgs &RA, ExpandArgs &XA, int mu, int cbase, hipStream_t st) {
+    constexpr int RW = 4;
+    if (RA.ntasks > 0)
+        hipLaunchKernelGGL((reduce_mu_kernel<RW, MU>), dim3((RA.ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, RA, mu, cbase);
+    prof_mark(H, st, "reduce_mu_kernel");
+    (void)XA;
+}
+template <int MU>
+static void launch_mu_expand(hmx_hmatrix &H, ExpandArgs &XA, int mu, int cbase, hipStream_t st) {
+    constexpr int EW = 4;
+    if (XA.nranges > 0)
+        hipLaunchKernelGGL((expand_mu_kernel<EW, MU>), dim3(XA.nranges), dim3(EW * 64), 0, st, XA, mu, cbase);
+    prof_mark(H, st, "expand_mu_kernel");
+}
+
+// Fused multi-RHS forward pass (trans='N', no mirror leaves): Y = alpha * H * X + beta * Y, X and Y row-major.
+static int run_forward_mu(hmx_hmatrix &H, const double *X, double alpha, double beta, double *Y, int mu, hipStream_t st) {
+    const size_t need = (size_t)(H.zero_slot + 1) * mu;
+    if (H.Zmu.n < need)
+        HMX_HIP(H.Zmu.alloc(need));
+    HMX_HIP(hipMemcpyAsync(H.Zmu.d, X, (size_t)H.nS * mu * 8, hipMemcpyDeviceToDevice, st));
+    prof_mark(H, st, "copy_x");
+    ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
+                  H.r_outidx.d, H.Zmu.d, H.Zmu.d, (int)H.R.task_range.size()};
+    ExpandArgs XA{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges()};
+    // stage 1 for every group of right-hand sides, then the partial sums, then stage 2
+    auto for_groups = [&](auto &&fn) {
+        int c = 0;
+        while (c < mu) {
+            const int left = mu - c;
+            const int g    = left >= 16 ? 16 : (left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1)));
+            fn(g, c);
+            c += g;
+        }
+    };
+    for_groups([&](int g, int c) {
+        switch (g) {
+        case 16: launch_mu<16>(H, RA, XA, mu, c, st); break;
+        case 8: launch_mu<8>(H, RA, XA, mu, c, st); break;
+        case 4: launch_mu<4>(H, RA, XA, mu, c, st); break;
+        case 2: launch_mu<2>(H, RA, XA, mu, c, st); break;
+        default: launch_mu<1>(H, RA, XA, mu, c, st); break;
+        }
+    });
+    if (H.n_combine > 0) {
+        CombineArgs C{H.c_dst.d, H.c_src.d, H.c_stride.d, H.c_count.d, H.Zmu.d, H.n_combine};
+        const int64_t tot = (int64_t)H.n_combine * mu;
+        hipLaunchKernelGGL(combine_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, mu);
+        prof_mark(H, st, "combine_mu_kernel");
+    }
+    for_groups([&](int g, int c) {
+        switch (g) {
+        case 16: launch_mu_expand<16>(H, XA, mu, c, st); break;
+        case 8: launch_mu_expand<8>(H, XA, mu, c, st); break;
+        case 4: launch_mu_expand<4>(H, XA, mu, c, st); break;
+        case 2: launch_mu_expand<2>(H, XA, mu, c, st); break;
+        default: launch_mu_expand<1>(H, XA, mu, c, st); break;
+        }
+    });
     HMX_HIP(hipGetLastError());
     return HMX_OK;
 }
@@ -1217,7 +1281,31 @@ int hmx_hmatrix_matmat_row_major(hmx_hmatrix *Hp, char trans, double alpha, cons
         HMX_HIP(H.tmp_in2.alloc(nin));
     if (H.tmp_out2.n < (size_t)nout)
         HMX_HIP(H.tmp_out2.alloc(nout));
-    // first version of the multi-RHS path: one streaming pass per right-hand side
+    if (trans == 'N' && !H.has_mirror && H.finalized && !getenv("HMX_NO_FUSED_MU")) {
+        // fused path: the streams are read once for up to 16 right-hand sides
+        H.ev_names.clear();
+        prof_mark(H, st, "begin");
+        rc = run_forward_mu(H, din, alpha, beta, dout, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        if (H.profiling) {
+            HMX_HIP(hipStreamSynchronize(st));
+            H.last_ms.clear();
+            H.last_names.clear();
+            for (size_t k = 1; k < H.ev_names.size(); k++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
+                H.last_ms.push_back(ms);
+                H.last_names.push_back(H.ev_names[k]);
+            }
+        }
+        if (staged) {
+            HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * 8, hipMemcpyDeviceToHost, st));
+            HMX_HIP(hipStreamSynchronize(st));
+        }
+        return HMX_OK;
+    }
+    // transposed products and symmetric storage: one streaming pass per right-hand side (not fused yet)
     for (int c = 0; c < mu; c++) {
         hipLaunchKernelGGL(col_extract_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, mu, c, din, H.tmp_in2.d);
         if (beta != 0.0)

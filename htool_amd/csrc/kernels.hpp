@@ -792,6 +792,162 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused multi-RHS (row-major, mu fastest) H-matvec, trans = 'N':
+// openmp_internal_add_hmatrix_matrix_product_row_major (hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:112-178),
+// leaf products add_matrix_matrix_product_row_major / add_lrmat_matrix_product_row_major (K7-K9 of SURVEY.md 2.2).
+// The streams are read ONCE for MU right-hand sides; Z, x and y are [index][mu] with a row pitch of `mu`
+// doubles and this launch handles the MU columns starting at `cbase`.  The wave-uniform operand (x rows
+// in the reduce stage, gathered coefficients in the expand stage) is staged in a wave-private LDS tile and read
+// back as broadcast ds_read_b128, so the inner loops are one stream load + MU FMAs per lane.
+// ---------------------------------------------------------------------------------------------
+template <int WAVES, int MU>
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, int mu, int cbase) {
+    __shared__ __attribute__((aligned(16))) double xt[WAVES][WAVE][MU];
+    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES + wv;
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp      = (w + 1) & ~1;
+    const bool active = 2 * lane < wp;
+    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const double *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
+    double a0[MU], a1[MU];
+#pragma unroll
+    for (int c = 0; c < MU; c++)
+        a0[c] = a1[c] = 0.0;
+    for (int i0 = 0; i0 < len; i0 += 64) {
+        const int nr = (len - i0) < 64 ? (len - i0) : 64;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nr) {
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                xt[wv][lane][c] = xs[(int64_t)(i0 + lane) * mu + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double *p = src + (int64_t)i0 * wp;
+        int j = 0;
+        for (; j + 4 <= nr; j += 4) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                v[u] = *reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int c = 0; c < MU; c++) {
+                    const double xi = xt[wv][j + u][c];
+                    a0[c]           = __builtin_fma(v[u].x, xi, a0[c]);
+                    a1[c]           = __builtin_fma(v[u].y, xi, a1[c]);
+                }
+            }
+        }
+        for (; j < nr; j++) {
+            const double2 v = *reinterpret_cast<const double2 *>(p + (int64_t)j * wp);
+#pragma unroll
+            for (int c = 0; c < MU; c++) {
+                const double xi = xt[wv][j][c];
+                a0[c]           = __builtin_fma(v.x, xi, a0[c]);
+                a1[c]           = __builtin_fma(v.y, xi, a1[c]);
+            }
+        }
+    }
+    if (active) {
+        const int64_t cb = A.range_colbase[S] + ch * cw + 2 * lane;
+        if (2 * lane < w) {
+            double *dst = A.Z + (int64_t)A.out_idx[cb] * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                dst[c] = a0[c];
+        }
+        if (2 * lane + 1 < w) {
+            double *dst = A.Z + (int64_t)A.out_idx[cb + 1] * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                dst[c] = a1[c];
+        }
+    }
+}
+
+__global__ void combine_mu_kernel(CombineArgs A, int mu) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)A.n * mu)
+        return;
+    const int e = (int)(t / mu), c = (int)(t - (int64_t)e * mu);
+    const double *p = A.Z + (int64_t)A.src[e] * mu + c;
+    const int st = A.stride[e], cnt = A.count[e];
+    double s = 0;
+    for (int k = 0; k < cnt; k++)
+        s += p[(int64_t)k * st * mu];
+    A.Z[(int64_t)A.dst[e] * mu + c] = s;
+}
+
+template <int WAVES, int MU>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, int mu, int cbase) {
+    __shared__ __attribute__((aligned(16))) double zt[WAVES][WAVE][MU]; // coefficient tiles, reused for the final reduction
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const double *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const bool active   = lane < len;
+    const int row       = active ? lane : 0;
+    double acc[MU];
+#pragma unroll
+    for (int c = 0; c < MU; c++)
+        acc[c] = 0.0;
+    for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
+        const int nc = (C - c0) < 64 ? (C - c0) : 64;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nc) {
+            const double *zr = A.Z + (int64_t)zidx[c0 + lane] * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                zt[wv][lane][c] = zr[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double *col = E + (int64_t)c0 * len + row;
+        int j = 0;
+        for (; j + 8 <= nc; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                v[u] = col[(int64_t)(j + u) * len];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int c = 0; c < MU; c++)
+                    acc[c] = __builtin_fma(v[u], zt[wv][j + u][c], acc[c]);
+        }
+        for (; j < nc; j++) {
+            const double v = col[(int64_t)j * len];
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                acc[c] = __builtin_fma(v, zt[wv][j][c], acc[c]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < MU; c++)
+        zt[wv][lane][c] = active ? acc[c] : 0.0;
+    __syncthreads();
+    // rows x MU outputs, summed over the waves; consecutive threads write consecutive right-hand sides
+    for (int e = threadIdx.x; e < len * MU; e += WAVES * WAVE) {
+        const int i = e / MU, c = e - i * MU;
+        double s = zt[0][i][c];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            s += zt[k][i][c];
+        double *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo        = A.beta == 0.0 ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Transposed / mirrored passes (trans = 'T', and the symmetric mirror pass
 // add_hmatrix_vector_product.hpp:97-103,154-163).  Same streams, read in the "wrong" orientation:
 // every column (resp. row) needs a cross-lane reduction and results are accumulated with fp64 atomics

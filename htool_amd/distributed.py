@@ -217,3 +217,32 @@ class DefaultApproximationBuilder:
         self.local_hmatrix = RestrictedGlobalToLocalHMatrix(self.hmatrix)
         self.distributed_operator = DistributedOperator(self.target_partition, self.source_partition, group)
         self.distributed_operator.add_global_to_local_operator(self.local_hmatrix)
+
+
+def internal_add_distributed_operator_matrix_product_row_major_global_to_global(trans, alpha, A, X, beta, Y, mu):
+    """Multi-RHS, row-major (mu fastest), partition numbering
+    (distributed_operator/linalg/add_distributed_operator_matrix_product_row_major_global_to_global.hpp:18-85):
+    same collectives as the vector product on mu-interleaved rows (C5)."""
+    rank = A.rank()
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    off_in, n_in = in_part.get_offset_of_partition(rank), in_part.get_size_of_partition(rank)
+    off_out, n_out = out_part.get_offset_of_partition(rank), out_part.get_size_of_partition(rank)
+    if trans == "N":
+        local = Y[off_out:off_out + n_out].clone() if beta != 0 else torch.zeros((n_out, mu), dtype=Y.dtype, device=Y.device)
+        apply_beta = True
+        for op in A.global_to_local_operators:
+            op.add_matrix_product_row_major(trans, alpha, X, beta if apply_beta else 1.0, local, mu)
+            apply_beta = False
+        A._gather_slices(local, out_part, Y)
+    else:
+        Y_old = Y.clone() if beta != 0 else None
+        Y.zero_()
+        X_loc = X[off_in:off_in + n_in].contiguous()
+        for op in A.global_to_local_operators:
+            op.add_matrix_product_row_major(trans, alpha, X_loc, 1.0, Y, mu)
+        if A.size() > 1:
+            dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=A.group)
+        if beta != 0:
+            Y.add_(Y_old, alpha=beta)
+    return Y

@@ -27,6 +27,10 @@ class OracleLocalOperator:
         out = self.H.matvec(x.numpy(), trans, alpha, beta, y.numpy())
         y.copy_(torch.from_numpy(out))
 
+    def add_matrix_product_row_major(self, trans, alpha, X, beta, Y, mu):
+        out = self.H.matmat_row_major(X.numpy(), trans, alpha, beta, Y.numpy())
+        Y.copy_(torch.from_numpy(out))
+
 
 def _free_port():
     s = socket.socket()
@@ -77,6 +81,12 @@ def _worker(rank, world, port, sym, uplo, q):
             y = torch.from_numpy(y0.copy())
             D.internal_add_distributed_operator_vector_product_global_to_global(trans, 1.0, A, torch.from_numpy(xin), 0.0, y)
             errs.append(rel_err(y.numpy(), Hfull.matvec(xin, trans, 1.0, 0.0)))
+        if sym == "N":  # multi-RHS row-major, mu = 3
+            X, Y0 = O.hashed_vector(3 * n, 9).reshape(n, 3), O.hashed_vector(3 * n, 10).reshape(n, 3)
+            for trans in ("N", "T"):
+                Y = torch.from_numpy(Y0.copy())
+                D.internal_add_distributed_operator_matrix_product_row_major_global_to_global(trans, 3.0, A, torch.from_numpy(X.copy()), 2.0, Y, 3)
+                errs.append(rel_err(Y.numpy(), Hfull.matmat_row_major(X, trans, 3.0, 2.0, Y0)))
         q.put((rank, max(errs)))
     finally:
         dist.destroy_process_group()

@@ -239,3 +239,30 @@ def test_compressors_on_the_reference_test_block(distance):
             else:
                 assert np.linalg.norm(A - U @ V) < eps and intervals[comp][0] < saving < intervals[comp][1]
             assert rel_err(U @ V, Uo @ Vo) < 1e-9
+
+
+def test_column_major_multi_rhs_front_end():
+    """add_hmatrix_matrix_product (hmatrix/linalg/add_hmatrix_matrix_product.hpp:176-205): user numbering,
+    column-major operands, checked against a dense product on a row sample and against mu separate matvecs."""
+    n, mu = 6000, 5
+    x = hm.create_geometry("ellipse", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(100)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    tb = hm.HMatrixTreeBuilder(1e-7, 10.0, "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T)
+    rng = np.random.default_rng(3)
+    B = np.asfortranarray(rng.random((n, mu)))
+    C0 = np.asfortranarray(rng.random((n, mu)))
+    for trans in ("N", "T"):
+        C = C0.copy(order="F")
+        hm.add_hmatrix_matrix_product(trans, 1.5, H, B, 0.5, C)
+        for c in range(mu):
+            y = np.ascontiguousarray(C0[:, c]).copy()
+            hm.add_hmatrix_vector_product(trans, 1.5, H, np.ascontiguousarray(B[:, c]), 0.5, y)
+            assert rel_err(C[:, c], y) < 1e-13
+        rows = rng.choice(n, 100, replace=False)
+        d = np.sqrt(((x[rows, None, :] - x[None, :, :]) ** 2).sum(-1))
+        ref = 1.5 * (1.0 / (1e-5 + d)) @ B + 0.5 * C0[rows]
+        assert rel_err(C[rows], ref) < 1e-6
