@@ -172,6 +172,39 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Row-partitioned runs are launch-bound per rank (a few hundred microseconds of kernels at 8 GPUs): capture one
+    # step -- local kernels + the RCCL all-gather -- in a HIP graph and replay it.  Falls back to eager launches.
+    graphed = False
+    if part and mu == 1 and not os.environ.get("HMX_BENCH_NO_GRAPH"):
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            eager_step = step
+            y_ref = y.clone()
+            g.replay()
+            torch.cuda.synchronize()
+            if not torch.equal(y, y_ref):
+                raise RuntimeError("graph replay does not reproduce the eager result")
+            step = g.replay
+            graphed = True
+        except Exception as ex:  # keep the eager path
+            log("HIP graph capture of the distributed step failed (%r): timing eager launches" % (ex,))
+            torch.cuda.synchronize()
+    flag = torch.tensor([1 if graphed else 0], device=dev)
+    if use_dist:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must agree (a collective inside a graph on some ranks only would hang)
+    if part and mu == 1 and graphed and int(flag.item()) == 0:
+        step, graphed = eager_step, False
+    for _ in range(2):
+        step()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -220,7 +253,7 @@ def main():
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(mu=mu, workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
-                           parallelism="row-partition x%d + all-gather" % world if part else "single GPU",
+                           parallelism=("row-partition x%d + all-gather%s" % (world, ", step replayed from a HIP graph" if graphed else "")) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
                            build_s=dict(cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
