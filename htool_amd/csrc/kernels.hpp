@@ -49,6 +49,29 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Every coefficient is read exactly once per product, so the stream loads are marked non-temporal: they do
+// not displace x / Z / index lines from L2 and the Infinity Cache.  Measured at N=1e6: expand 1.88 -> 1.74 ms,
+// reduce 1.23-1.33 -> 1.20 ms, and the run-to-run bimodality disappears.  -DHMX_NT=0 disables.
+#ifndef HMX_NT
+#define HMX_NT 1
+#endif
+typedef double hmx_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double stream_load(const double *p) {
+#if HMX_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double2 stream_load(const double2 *p) {
+#if HMX_NT
+    const hmx_d2 v = __builtin_nontemporal_load(reinterpret_cast<const hmx_d2 *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -693,7 +716,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
             double2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = *reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp);
+                v[u] = stream_load(reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp));
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const double xi = readlane_f64(xv, j + u);
@@ -771,7 +794,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = col[(int64_t)(j + u) * len];
+                v[u] = stream_load(col + (int64_t)(j + u) * len);
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 acc = __builtin_fma(v[u], readlane_f64(z, j + u), acc);
@@ -835,7 +858,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
             double2 v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                v[u] = *reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp);
+                v[u] = stream_load(reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp));
 #pragma unroll
             for (int u = 0; u < 4; u++) {
 #pragma unroll
@@ -916,7 +939,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = col[(int64_t)(j + u) * len];
+                v[u] = stream_load(col + (int64_t)(j + u) * len);
 #pragma unroll
             for (int u = 0; u < 8; u++)
 #pragma unroll

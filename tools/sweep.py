@@ -4,7 +4,7 @@ Usage on the GPU box: python tools/sweep.py  (spawns one bench.py per configurat
 import itertools, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 configs = [dict(HMX_REDUCE_WAVES=r, HMX_EXPAND_WAVES=e, HMX_SORT_TASKS=s) for r, e, s in
-           [(4, 4, 0), (4, 4, 1), (4, 4, 0), (4, 4, 1), (2, 4, 1), (2, 4, 0), (4, 4, 0), (4, 4, 1)]]
+           [(4, 4, 1)] * 5]
 extra = sys.argv[1:]
 for c in configs:
     env = dict(os.environ, **{k: str(v) for k, v in c.items()})
