@@ -98,6 +98,10 @@ def cpu_baseline(H, T, frac, log):
 
 def main():
     args = parse()
+    # RCCL / HIP runtime banners go to the C-level stdout; keep fd 1 clean for the single JSON line
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -175,6 +179,8 @@ def main():
     # Row-partitioned runs are launch-bound per rank (a few hundred microseconds of kernels at 8 GPUs): capture one
     # step -- local kernels + the RCCL all-gather -- in a HIP graph and replay it.  Falls back to eager launches.
     graphed = False
+    eager_step = step
+    g = None
     if part and mu == 1 and not os.environ.get("HMX_BENCH_NO_GRAPH"):
         try:
             side = torch.cuda.Stream()
@@ -186,22 +192,30 @@ def main():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 step()
-            eager_step = step
-            y_ref = y.clone()
-            g.replay()
-            torch.cuda.synchronize()
-            if not torch.equal(y, y_ref):
-                raise RuntimeError("graph replay does not reproduce the eager result")
-            step = g.replay
             graphed = True
         except Exception as ex:  # keep the eager path
             log("HIP graph capture of the distributed step failed (%r): timing eager launches" % (ex,))
+            g = None
+        torch.cuda.synchronize()
+    if part:
+        # every rank must take the same path BEFORE anything is replayed: a graph holding a collective replayed on
+        # some ranks only would hang
+        flag = torch.tensor([1 if graphed else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        graphed = bool(int(flag.item()))
+        if graphed:
+            eager_step()
+            y_ref = y.clone()
+            y.zero_()
+            g.replay()
             torch.cuda.synchronize()
-    flag = torch.tensor([1 if graphed else 0], device=dev)
-    if use_dist:
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must agree (a collective inside a graph on some ranks only would hang)
-    if part and mu == 1 and graphed and int(flag.item()) == 0:
-        step, graphed = eager_step, False
+            same = torch.tensor([1 if torch.equal(y, y_ref) else 0], device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if int(same.item()) == 1:
+                step = g.replay
+            else:
+                log("graph replay does not reproduce the eager result: timing eager launches")
+                graphed = False
     for _ in range(2):
         step()
     fence()
@@ -271,7 +285,7 @@ def main():
         except Exception as e:  # the baseline is a reported number, never the product path
             out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
