@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--eta", type=float, default=10.0)
     ap.add_argument("--leaf", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sym", default="N", help="symmetry of the builder: N, or S (lower storage, sympartialACA)")
+    ap.add_argument("--trans", default="N")
     ap.add_argument("--force-dist", action="store_true", help="run the row-partition + collective code path even with one rank (testing)")
     ap.add_argument("--mu", type=int, default=1, help="number of right-hand sides (row-major multi-RHS product when > 1)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
@@ -130,8 +132,8 @@ def main():
     # single GPU: HMatrixBuilder's default of 2 partitions (hmatrix/utility.hpp:23), whole operator on the GPU
     T = ctb.create_cluster_tree(n, 3, x, 2, world if use_dist else 2)
     t_tree = time.time() - t0
-    tb = hm.HMatrixTreeBuilder(args.eps, args.eta, "N", "N")
-    tb.set_low_rank_generator("partialACA")
+    tb = hm.HMatrixTreeBuilder(args.eps, args.eta, args.sym, "L" if args.sym == "S" else "N")
+    tb.set_low_rank_generator("partialACA" if args.sym == "N" else "sympartialACA")
     d = minimal_depth(n)
     tb.set_minimal_target_depth(d)
     tb.set_minimal_source_depth(d)
@@ -165,7 +167,7 @@ def main():
         elif part:
             D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y)
         else:
-            hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y_loc)
+            hm.internal_add_hmatrix_vector_product(args.trans, 1.0, H, xin, 0.0, y_loc)
 
     def fence():
         torch.cuda.synchronize()
@@ -240,7 +242,7 @@ def main():
         if mu > 1:
             hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, Xmu, 0.0, Ymu, mu)
         else:
-            hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y_loc)
+            hm.internal_add_hmatrix_vector_product(args.trans, 1.0, H, xin, 0.0, y_loc)
         for name, ms in H.last_kernel_times():
             acc.setdefault(name, []).append(ms)
     H.set_profiling(False)
@@ -266,7 +268,7 @@ def main():
 
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(mu=mu, workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
+               config=dict(mu=mu, sym=args.sym, trans=args.trans, workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
                            parallelism=("row-partition x%d + all-gather%s" % (world, ", step replayed from a HIP graph" if graphed else "")) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),

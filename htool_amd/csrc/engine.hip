@@ -656,7 +656,7 @@ static int run_transposed(hmx_hmatrix &H, bool mirror, const double *in, double 
     if (H.E.nranges() > 0) {
         // true transposed: `in` is target-local; mirror pass: `in` is source-local, rows are target positions
         const double *in_eff = mirror ? in + (H.T0 - H.S0) : in;
-        ColReduceArgs A{H.E.stream.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, mirror ? H.e_tdst_mirror.d : H.e_tdst.d, in_eff, H.W.d, H.E.nranges()};
+        ColReduceArgs A{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, mirror ? H.e_tdst_mirror.d : H.e_tdst.d, in_eff, H.W.d, H.E.nranges()};
         hipLaunchKernelGGL(colreduce_kernel<CW>, dim3(H.E.nranges()), dim3(CW * 64), 0, st, A);
         prof_mark(H, st, "colreduce_kernel");
     }

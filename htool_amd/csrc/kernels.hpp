@@ -976,8 +976,29 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
 // every column (resp. row) needs a cross-lane reduction and results are accumulated with fp64 atomics
 // into a zeroed work vector W = [out | aT].  Correct and coalesced, but not the tuned path.
 // ---------------------------------------------------------------------------------------------
+// Eight wave-wide sums for the price of ~1.25: each butterfly step halves the number of live values while
+// halving the lane group that owns them.  On return lane l with (l & 7) == 0 holds the complete sum of input
+// value number 4*bit5(l) + 2*bit4(l) + bit3(l).
+__device__ __forceinline__ double reduce8(const double (&v)[8], int lane) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    double t[4], u[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        t[k] = (b5 ? v[k + 4] : v[k]) + __shfl_xor(b5 ? v[k] : v[k + 4], 32, WAVE);
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+        u[k] = (b4 ? t[k + 2] : t[k]) + __shfl_xor(b4 ? t[k] : t[k + 2], 16, WAVE);
+    double r = (b3 ? u[1] : u[0]) + __shfl_xor(b3 ? u[0] : u[1], 8, WAVE);
+    r += __shfl_xor(r, 4, WAVE);
+    r += __shfl_xor(r, 2, WAVE);
+    r += __shfl_xor(r, 1, WAVE);
+    return r;
+}
+__device__ __forceinline__ int reduce8_slot(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
+
 struct ColReduceArgs { // over E-streams: W[dst[c]] += sum_i E[i,c] * in[R.off + i]
     const double *stream;
+    const int32_t *order;
     const int32_t *range_off, *range_len, *range_cols;
     const int64_t *range_base, *range_colbase;
     const int32_t *dst; // per column, -1 = skip
@@ -987,20 +1008,24 @@ struct ColReduceArgs { // over E-streams: W[dst[c]] += sum_i E[i,c] * in[R.off +
 };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void colreduce_kernel(ColReduceArgs A) {
-    const int R = blockIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
-    const double *E    = A.stream + A.range_base[R];
+    const double *E    = A.stream + A.range_base[R] + (lane < len ? lane : 0);
     const int32_t *dst = A.dst + A.range_colbase[R];
     const double xin   = lane < len ? A.in[A.range_off[R] + lane] : 0.0;
-    for (int c = wv; c < C; c += WAVES) {
-        const int d = dst[c];
-        if (d < 0)
-            continue;
-        double v = lane < len ? E[(int64_t)c * len + lane] * xin : 0.0;
-        v        = wave_sum(v);
-        if (lane == 0)
-            atomicAdd(&A.W[d], v);
+    const int slot     = reduce8_slot(lane);
+    for (int c0 = wv * 8; c0 < C; c0 += WAVES * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            v[u] = (c0 + u < C) ? stream_load(E + (int64_t)(c0 + u) * len) * xin : 0.0;
+        const double r = reduce8(v, lane);
+        if ((lane & 7) == 0 && c0 + slot < C) {
+            const int d = dst[c0 + slot];
+            if (d >= 0)
+                atomicAdd(&A.W[d], r);
+        }
     }
 }
 
@@ -1016,7 +1041,7 @@ struct RowReduceArgs { // over R-streams: W[S.off + i] += sum_col Rs[i,col] * W[
 };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A) {
-    const int task = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (task >= A.ntasks)
         return;
     const int lane = threadIdx.x & 63;
@@ -1025,32 +1050,38 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
-    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
-    const int64_t cb  = A.range_colbase[S] + ch * cw;
+    const bool active = 2 * lane < wp;
+    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const int64_t cb  = A.range_colbase[S] + ch * cw + 2 * lane;
     double c0 = 0, c1 = 0;
-    if (lane < w) {
-        const int d = A.coef[cb + lane];
-        c0          = d >= 0 ? A.W[d] : 0.0;
-    }
     bool any = false;
-    if (lane + 64 < w) {
-        const int d = A.coef[cb + lane + 64];
-        c1          = d >= 0 ? A.W[d] : 0.0;
+    if (2 * lane < w) {
+        const int d = A.coef[cb];
+        c0          = d >= 0 ? A.W[d] : 0.0;
         any         = d >= 0;
     }
-    if (lane < w)
-        any = any || A.coef[cb + lane] >= 0;
+    if (2 * lane + 1 < w) {
+        const int d = A.coef[cb + 1];
+        c1          = d >= 0 ? A.W[d] : 0.0;
+        any         = any || d >= 0;
+    }
     if (!__any(any))
         return; // no selected column in this chunk (e.g. mirror pass over an off-diagonal stripe)
-    for (int i = 0; i < len; i++) {
-        double v = 0;
-        if (lane < wp)
-            v = src[(int64_t)i * wp + lane] * c0;
-        if (lane + 64 < wp)
-            v = __builtin_fma(src[(int64_t)i * wp + lane + 64], c1, v);
-        v = wave_sum(v);
-        if (lane == 0)
-            atomicAdd(&A.W[A.range_off[S] + A.row_shift + i], v);
+    const int slot = reduce8_slot(lane);
+    double *out    = A.W + A.range_off[S] + A.row_shift;
+    for (int i0 = 0; i0 < len; i0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            v[u] = 0.0;
+            if (active && i0 + u < len) {
+                const double2 e = stream_load(reinterpret_cast<const double2 *>(src + (int64_t)(i0 + u) * wp));
+                v[u]            = __builtin_fma(e.x, c0, e.y * c1);
+            }
+        }
+        const double r = reduce8(v, lane);
+        if ((lane & 7) == 0 && i0 + slot < len)
+            atomicAdd(&out[i0 + slot], r);
     }
 }
 
