@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--sym", default="N", help="symmetry of the builder: N, or S (lower storage, sympartialACA)")
     ap.add_argument("--trans", default="N")
     ap.add_argument("--force-dist", action="store_true", help="run the row-partition + collective code path even with one rank (testing)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single process: build and time only the block rows of --emulate-rank out of this many partitions (per-rank cost of a multi-GPU run, no collective)")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--mu", type=int, default=1, help="number of right-hand sides (row-major multi-RHS product when > 1)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
     return ap.parse_args()
@@ -98,6 +100,42 @@ def cpu_baseline(H, T, frac, log):
                        "openmp leaf loop, best of 4" % (cut, len(sel), pos * 8 / 1e9)), y, cut
 
 
+def reference_baseline(log):
+    """htool ITSELF (oracle/_ref/ref_driver: the real headers + the image's MKL, OpenMP policy) timed on this box's
+    host cores on configs[1] (N=1e5, same geometry / kernel / eps / eta / leaf size).  Only runs where the binary
+    built in the dev container travelled with the repo; never touches /root/reference at run time."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(exe):
+        return None
+    try:
+        best = None
+        for threads in (16, 64, os.cpu_count()):  # the reference's per-thread temporaries make "all cores" a poor choice
+            t0 = time.time()
+            out = subprocess.run([exe, "hmat", "n=100000", "geom=ellipse", "eps=1e-4", "eta=10", "leaf=100", "compressor=partialACA", "par=1",
+                                  "time_reps=10", "dump_blocks=0", "out=/dev/null"], capture_output=True, text=True, timeout=240,
+                                 env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+            m = re.search(r"cgen=(\d+)\+(\d+).*build=([0-9.]+)s matvec=([0-9.]+)s", out.stdout)
+            if not m:
+                log("reference driver produced no timing: %s" % (out.stdout[-200:] + out.stderr[-200:]))
+                continue
+            cgen = int(m.group(1)) + int(m.group(2))
+            t_mv = float(m.group(4))
+            log("reference (htool, OpenMP, %d threads) N=1e5: build %.2fs matvec %.4fs (%.1fs wall)" % (threads, float(m.group(3)), t_mv, time.time() - t0))
+            if best is None or t_mv < best[1]:
+                best = (threads, t_mv, float(m.group(3)), cgen)
+        if best is None:
+            return None
+        threads, t_mv, t_build, cgen = best
+        return dict(value=8.0 * (cgen + 2e5) / t_mv / 1e9, unit="GB/s", cores=threads, kind="reference",
+                    sample="htool itself (openmp_internal_add_hmatrix_vector_product, MKL sequential BLAS), N=1e5 ellipse eps=1e-4 (configs[1]), "
+                           "best of 10 repetitions and of 16/64/all threads", build_s=t_build, matvec_s=t_mv)
+    except Exception as e:
+        log("reference driver failed: %r" % (e,))
+        return None
+
+
 def main():
     args = parse()
     # RCCL / HIP runtime banners go to the C-level stdout; keep fd 1 clean for the single JSON line
@@ -130,7 +168,8 @@ def main():
     ctb = hm.ClusterTreeBuilder()
     ctb.set_maximal_leaf_size(args.leaf)
     # single GPU: HMatrixBuilder's default of 2 partitions (hmatrix/utility.hpp:23), whole operator on the GPU
-    T = ctb.create_cluster_tree(n, 3, x, 2, world if use_dist else 2)
+    emu = args.emulate_world
+    T = ctb.create_cluster_tree(n, 3, x, 2, emu if emu else (world if use_dist else 2))
     t_tree = time.time() - t0
     tb = hm.HMatrixTreeBuilder(args.eps, args.eta, args.sym, "L" if args.sym == "S" else "N")
     tb.set_low_rank_generator("partialACA" if args.sym == "N" else "sympartialACA")
@@ -140,7 +179,8 @@ def main():
     gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0)
     t0 = time.time()
     part = use_dist
-    H = tb.build(gen, T, T, rank if part else -1, rank if part else -1, device=local_rank)
+    brank = args.emulate_rank if emu else (rank if part else -1)
+    H = tb.build(gen, T, T, brank, brank, device=local_rank)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     st = H.stats()
@@ -284,6 +324,9 @@ def main():
             err = float(np.linalg.norm(yh[:cut].cpu().numpy() - y_cpu) / np.linalg.norm(y_cpu))
             cb["rel_err_engine_vs_cpu_on_sample"] = err
             out["cpu_baseline"] = cb
+            ref = reference_baseline(log)
+            if ref is not None:
+                out["cpu_reference_htool"] = ref
         except Exception as e:  # the baseline is a reported number, never the product path
             out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
     if rank == 0:

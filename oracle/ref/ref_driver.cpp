@@ -202,6 +202,7 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     int dump_blocks       = geti(kv, "dump_blocks", 2);
     int dump_all          = geti(kv, "dump_all", 0); // dump every block's payload (U,V / dense), concatenated
     int time_reps         = geti(kv, "time_reps", 0);
+    int par               = geti(kv, "par", 0); // 1: openmp_build + openmp_internal_add_hmatrix_vector_product (the reference's MPI+OpenMP CPU path, one rank)
     double alpha          = getd(kv, "alpha", 3.);
     double beta           = getd(kv, "beta", 2.);
     std::string out       = gets(kv, "out", "/tmp/ref_hmat.bin");
@@ -251,7 +252,7 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     tb.set_minimal_source_depth(mindepth);
 
     auto t2           = std::chrono::steady_clock::now();
-    HMatrix<double> H = tb.sequential_build(A, tct, sct, rank, rank);
+    HMatrix<double> H = par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank);
     auto t3           = std::chrono::steady_clock::now();
 
     // Leaves in natural preorder (children in creation order)
@@ -365,14 +366,17 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
         double best = 1e30;
         for (int r = 0; r < time_reps; r++) {
             auto a = std::chrono::steady_clock::now();
-            sequential_internal_add_hmatrix_vector_product('N', 1., H, x.data(), 0., y.data());
+            if (par)
+                openmp_internal_add_hmatrix_vector_product('N', 1., H, x.data(), 0., y.data());
+            else
+                sequential_internal_add_hmatrix_vector_product('N', 1., H, x.data(), 0., y.data());
             auto b = std::chrono::steady_clock::now();
             best   = std::min(best, std::chrono::duration<double>(b - a).count());
         }
         t_mv = best;
     }
     D.f64("stats", {(double)n_dense, (double)n_lr, (double)cgen_dense, (double)cgen_lr, (double)rmin, n_lr ? rsum / n_lr : 0., (double)rmax, t_tree, t_build, t_mv});
-    printf("n=%d dense=%d lowrank=%d cgen=%lld+%lld rank=%d/%.2f/%d false_pos=%d tree=%.3fs build=%.3fs matvec_seq=%.4fs\n", n, n_dense, n_lr, cgen_dense, cgen_lr, rmin, n_lr ? rsum / n_lr : 0., rmax, tb.get_false_positive(), t_tree, t_build, t_mv);
+    printf("n=%d dense=%d lowrank=%d cgen=%lld+%lld rank=%d/%.2f/%d false_pos=%d tree=%.3fs build=%.3fs matvec=%.4fs\n", n, n_dense, n_lr, cgen_dense, cgen_lr, rmin, n_lr ? rsum / n_lr : 0., rmax, tb.get_false_positive(), t_tree, t_build, t_mv);
     return 0;
 }
 
