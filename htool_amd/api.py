@@ -28,7 +28,7 @@ def _dp(a):
 
 def create_geometry(name, n, z=0.0):
     """testing/geometry.hpp: "ellipse" (create_rotated_ellipse 4:1), "disk", "ball" -- seeded mt19937(0)."""
-    out = np.empty((n, 3), dtype=np.float64)
+    out = np.empty((n, 2 if name == "disk2d" else 3), dtype=np.float64)
     check(lib().hmx_geometry(name.encode(), n, z, _dp(out)))
     return out
 

@@ -20,7 +20,7 @@ int hmx_geometry(const char *name, int n, double z, double *coords) {
         return HMX_ERR_INVALID;
     }
     const std::string g(name);
-    if (g != "ellipse" && g != "disk" && g != "ball") {
+    if (g != "ellipse" && g != "disk" && g != "ball" && g != "disk2d") {
         hmx::set_error("hmx_geometry: unknown geometry " + g);
         return HMX_ERR_INVALID;
     }

@@ -30,7 +30,9 @@ void make_geometry(const std::string &name, int n, double z, double *xyz) {
         }
         return;
     }
-    // create_rotated_ellipse(3, a, b, alpha=0, z, n): planar ellipse embedded in 3-D; disk = (1,1)
+    // create_rotated_ellipse(dim, a, b, alpha=0, z, n): planar ellipse embedded in 3-D; disk = (1,1); "disk2d" is
+    // the 2-D point cloud (no z column)
+    const int dim  = name == "disk2d" ? 2 : 3;
     const double a = name == "ellipse" ? 4. : 1., b = 1., alpha = 0.;
     const double ca = std::cos(alpha), sa = std::sin(alpha);
     for (int j = 0; j < n; j++) {
@@ -40,9 +42,10 @@ void make_geometry(const std::string &name, int n, double z, double *xyz) {
         const double phi   = 2 * static_cast<double>(M_PI) * theta;
         const double xp    = a * r * std::cos(phi);
         const double yp    = b * r * std::sin(phi);
-        xyz[3 * j + 0]     = ca * xp - sa * yp;
-        xyz[3 * j + 1]     = sa * xp + ca * yp;
-        xyz[3 * j + 2]     = z;
+        xyz[dim * j + 0]   = ca * xp - sa * yp;
+        xyz[dim * j + 1]   = sa * xp + ca * yp;
+        if (dim == 3)
+            xyz[dim * j + 2] = z;
     }
 }
 

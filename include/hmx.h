@@ -78,7 +78,7 @@ const char *hmx_last_error(void);
 int hmx_device_count(void);
 
 /* ---- test geometries (testing/geometry.hpp:11-61), seeded mt19937(0) --------------------------------- */
-int hmx_geometry(const char *name /* "ellipse" | "disk" | "ball" */, int n, double z, double *coords /* n*3 */);
+int hmx_geometry(const char *name /* "ellipse" | "disk" | "ball" (n*3 doubles) | "disk2d" (n*2) */, int n, double z, double *coords);
 
 /* ---- cluster tree: ClusterTreeBuilder::create_cluster_tree (clustering/tree_builder/tree_builder.hpp:52-207) */
 int hmx_cluster_tree_create(int n, int dim, const double *coords /* n*dim, AoS */, const double *radii /* n or NULL */,

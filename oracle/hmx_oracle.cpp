@@ -1491,7 +1491,9 @@ extern "C" {
 
 void orc_geometry(const char *name, int n, double z, double *out) {
     std::string g(name);
-    if (g == "ellipse")
+    if (g == "disk2d")
+        rotated_ellipse(2, 1., 1., 0., z, n, out);
+    else if (g == "ellipse")
         rotated_ellipse(3, 4., 1., 0., z, n, out);
     else if (g == "disk")
         rotated_ellipse(3, 1., 1., 0., z, n, out);

@@ -75,7 +75,7 @@ def _ip(a):
 
 
 def geometry(name, n, z=0.0):
-    out = np.empty((n, 3), dtype=np.float64)
+    out = np.empty((n, 2 if name == "disk2d" else 3), dtype=np.float64)
     lib().orc_geometry(name.encode(), n, z, _dp(out))
     return out
 

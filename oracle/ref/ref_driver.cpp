@@ -112,9 +112,12 @@ static std::string gets(std::map<std::string, std::string> &kv, const std::strin
 static double getd(std::map<std::string, std::string> &kv, const std::string &k, double d) { return kv.count(k) ? atof(kv[k].c_str()) : d; }
 static int geti(std::map<std::string, std::string> &kv, const std::string &k, int d) { return kv.count(k) ? atoi(kv[k].c_str()) : d; }
 
+static int geometry_dim(const std::string &geom) { return geom == "disk2d" ? 2 : 3; }
 static void make_geometry(const std::string &geom, int n, double z, std::vector<double> &x) {
-    x.assign(3 * (size_t)n, 0.);
-    if (geom == "ellipse")
+    x.assign(geometry_dim(geom) * (size_t)n, 0.);
+    if (geom == "disk2d")
+        create_disk(2, z, n, x.data());
+    else if (geom == "ellipse")
         create_rotated_ellipse(3, 4., 1., 0., z, n, x.data());
     else if (geom == "disk")
         create_disk(3, z, n, x.data());
@@ -207,6 +210,8 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     double beta           = getd(kv, "beta", 2.);
     std::string out       = gets(kv, "out", "/tmp/ref_hmat.bin");
     bool square           = (nsrc == 0);
+    int consistent        = geti(kv, "consistent", 1);
+    const int dim         = geometry_dim(geom);
 
     std::vector<double> xt, xs_store;
     make_geometry(geom, n, 0., xt);
@@ -216,26 +221,28 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     int ns                        = square ? n : nsrc;
 
     Dump D(out);
-    D.f64("xt", xt, {(uint64_t)n, 3});
+    D.f64("xt", xt, {(uint64_t)n, (uint64_t)dim});
     if (!square)
-        D.f64("xs", xs, {(uint64_t)ns, 3});
+        D.f64("xs", xs, {(uint64_t)ns, (uint64_t)dim});
 
     ClusterTreeBuilder<double> ctb;
     ctb.set_maximal_leaf_size(leaf);
     ctb.set_partitioning_strategy(make_partitioning(partstr));
     auto t0             = std::chrono::steady_clock::now();
-    Cluster<double> tct = ctb.create_cluster_tree(n, 3, xt.data(), children, partitions);
+    Cluster<double> tct = ctb.create_cluster_tree(n, dim, xt.data(), children, partitions);
     auto t1             = std::chrono::steady_clock::now();
     std::unique_ptr<Cluster<double>> sct_store;
     if (!square)
-        sct_store = std::make_unique<Cluster<double>>(ctb.create_cluster_tree(ns, 3, xs.data(), children, partitions));
+        sct_store = std::make_unique<Cluster<double>>(ctb.create_cluster_tree(ns, dim, xs.data(), children, partitions));
     const Cluster<double> &sct = square ? tct : *sct_store;
     dump_cluster_tree(D, "t_", tct);
     if (!square)
         dump_cluster_tree(D, "s_", sct);
 
-    InvDistGenerator A(3, xt, xs, delta, scale);
+    InvDistGenerator A(dim, xt, xs, delta, scale);
     HMatrixTreeBuilder<double> tb(eps, eta, sym[0], uplo[0], reqrank);
+    if (!consistent)
+        tb.set_block_tree_consistency(false);
     if (comp == "partialACA")
         tb.set_low_rank_generator(std::make_shared<partialACA<double>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
     else if (comp == "sympartialACA")

@@ -47,6 +47,13 @@ CASES = {
     "ball_n2000_n_pca_c4": ("hmat", dict(n=2000, geom="ball", leaf=50, children=4, partitions=4, eps=1e-3, partitioning="n_pca_regular", dump_blocks=0)),
     "ball_n2000_n_bbox_c8": ("hmat", dict(n=2000, geom="ball", leaf=30, children=8, partitions=8, eps=1e-3, partitioning="n_bbox_regular", dump_blocks=0)),
     "ellipse_n2000_c3_p3": ("hmat", dict(n=2000, geom="ellipse", leaf=50, children=3, partitions=3, eps=1e-3, dump_blocks=0)),
+    # 2-D point cloud (solve_EVP_2 branch), non-consistent block tree, near-full-rank accuracy
+    "disk2d_n2000": ("hmat", dict(n=2000, geom="disk2d", leaf=50, eps=1e-4, eta=10, compressor="partialACA")),
+    "disk2d_n2000_bbox_symL": ("hmat", dict(n=2000, geom="disk2d", leaf=50, eps=1e-4, eta=5, sym="S", uplo="L", compressor="sympartialACA", partitioning="bbox_regular")),
+    "rect_ball1500_disk1000_nonconsistent": ("hmat", dict(n=1500, nsrc=1000, geom="ball", sgeom="disk", sz=2.5, leaf=60, eps=1e-4, compressor="partialACA", consistent=0)),
+    "ball_n1500_eps1e-12": ("hmat", dict(n=1500, geom="ball", leaf=50, eps=1e-12, eta=10, compressor="partialACA", dump_blocks=1)),
+    "ball_n1500_eps1e-8": ("hmat", dict(n=1500, geom="ball", leaf=100, eps=1e-8, eta=10, compressor="partialACA", dump_blocks=1)),
+    "ball_n300_small": ("hmat", dict(n=300, geom="ball", leaf=100, eps=1e-4, compressor="partialACA", partitions=4, dump_blocks=1)),
     # other compressors
     "ball_n1200_fullACA": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="fullACA", dump_blocks=2)),
     "ball_n1200_SVD": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="SVD", dump_blocks=2)),
@@ -88,9 +95,14 @@ def main():
                 d = {k: v for k, v in d.items() if k.endswith("_info") or k.endswith("perm")}
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         manifest[name] = dict(mode=mode, **params)
-    if not only:
-        with open(os.path.join(HERE, "manifest.json"), "w") as f:
-            json.dump(manifest, f, indent=1, sort_keys=True)
+    mpath = os.path.join(HERE, "manifest.json")
+    if only and os.path.exists(mpath):  # partial regeneration: merge into the existing manifest
+        with open(mpath) as f:
+            old = json.load(f)
+        old.update(manifest)
+        manifest = old
+    with open(mpath, "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
     print("wrote", len(manifest), "fixtures")
 
 

@@ -15,7 +15,7 @@ LRMAT_CASES = sorted(k for k, v in MANIFEST.items() if v["mode"] == "lrmat")
 
 DEFAULTS = dict(nsrc=0, geom="ellipse", sz=0.0, leaf=100, children=2, partitions=2, partitioning="pca_regular", eps=1e-4,
                 eta=10.0, sym="N", uplo="N", compressor="partialACA", delta=1e-5, scale=1.0, mindepth=0, rank=-1,
-                reqrank=-1, alpha=3.0, beta=2.0)
+                reqrank=-1, alpha=3.0, beta=2.0, consistent=1)
 
 
 def load(name):
@@ -26,6 +26,7 @@ def params(name):
     p = dict(DEFAULTS)
     p.update(MANIFEST[name])
     p.setdefault("sgeom", p["geom"])
+    p["dim"] = 2 if p["geom"] == "disk2d" else 3
     if p["compressor"] == "default":  # hmatrix/tree_builder/tree_builder.hpp:384-386
         p["compressor"] = "sympartialACA"
     return p

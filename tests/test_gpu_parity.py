@@ -24,7 +24,8 @@ def build_engine(p, compress=True, generator=True):
     tb.set_low_rank_generator(p["compressor"] if p["compressor"] in DEVICE_COMPRESSORS else "partialACA")
     tb.set_minimal_target_depth(p["mindepth"])
     tb.set_minimal_source_depth(p["mindepth"])
-    gen = hm.InvDistGenerator(3, T.coordinates, S.coordinates, p["delta"], p["scale"]) if generator else None
+    tb.set_block_tree_consistency(bool(p["consistent"]))
+    gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]) if generator else None
     H = tb.build(gen, T, S, p["rank"], p["rank"], compress=compress)
     return T, S, H
 
@@ -45,7 +46,9 @@ def test_compression_matches_reference(name):
         if k.startswith("U_"):
             b = int(k[2:])
             U, V = H.get_block(b)
-            assert rel_err(U, g[k].T) < 1e-9 and rel_err(V, g["V_%d" % b].T) < 1e-9
+            ftol = 1e-9 if U.shape[1] <= 20 else 1e-6
+            assert rel_err(U, g[k].T) < ftol and rel_err(V, g["V_%d" % b].T) < ftol
+            assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 1e-9
         if k.startswith("D_"):
             assert np.array_equal(H.get_block(int(k[2:])), g[k].T)  # kernel entries bit-exact
 
@@ -266,3 +269,53 @@ def test_column_major_multi_rhs_front_end():
         d = np.sqrt(((x[rows, None, :] - x[None, :, :]) ** 2).sum(-1))
         ref = 1.5 * (1.0 / (1e-5 + d)) @ B + 0.5 * C0[rows]
         assert rel_err(C[rows], ref) < 1e-6
+
+
+def test_edge_cases_alpha_beta_dense_only_and_determinism():
+    from oracle import oracle as O
+    n = 1200
+    x = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(64)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    To = O.ClusterTree(x, 64, 2, 2)
+    gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0)
+    u, y0 = O.hashed_vector(n, 11), O.hashed_vector(n, 12)
+    # eta so small that nothing is admissible: dense-only operator == the exact matrix
+    tb = hm.HMatrixTreeBuilder(1e-4, 1e-6, "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    H = tb.build(gen, T, T)
+    assert H.stats()["n_lowrank"] == 0 and (H.leaf_table()[:, 4] == -1).all()
+    perm = T.get_permutation()
+    xc = x[perm]
+    A = 1.0 / (1e-5 + np.sqrt(((xc[:, None, :] - xc[None, :, :]) ** 2).sum(-1)))
+    y = np.zeros(n)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, H, u, 0.0, y)
+    assert rel_err(y, A @ u) < 1e-13
+    # alpha / beta corner values; beta = 0 must ignore (not propagate) whatever is in y, including NaN
+    Hh = hm.HMatrixTreeBuilder(1e-6, 10.0, "N", "N")
+    Hh.set_low_rank_generator("partialACA")
+    H = Hh.build(gen, T, T)
+    Ho = O.HMatrix(To, To, eps=1e-6, eta=10.0, compressor="partialACA")
+    for alpha, beta in ((0.0, 0.0), (0.0, 1.0), (1.0, 1.0), (-2.5, 0.0), (1.0, -1.0)):
+        for trans in ("N", "T"):
+            y = y0.copy() if beta != 0 else np.full(n, np.nan)
+            hm.internal_add_hmatrix_vector_product(trans, alpha, H, u, beta, y)
+            ref = Ho.matvec(u, trans, alpha, beta, y0 if beta != 0 else np.zeros(n))
+            assert np.isfinite(y).all()
+            assert np.linalg.norm(y - ref) <= 1e-10 * max(np.linalg.norm(ref), 1.0)
+    # bit-identical results run to run on the untransposed path (no atomics)
+    y1, y2 = np.zeros(n), np.zeros(n)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, H, u, 0.0, y1)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, H, u, 0.0, y2)
+    assert np.array_equal(y1, y2)
+    # every block downloads to exactly what the oracle holds for dense leaves, and to rounding for low rank
+    tab = H.leaf_table()
+    assert np.array_equal(tab, Ho.leaves)
+    for bidx in range(0, len(tab), 7):
+        if tab[bidx, 4] < 0:
+            assert np.array_equal(H.get_block(bidx), Ho.block(bidx))
+        else:
+            Ug, Vg = H.get_block(bidx)
+            Uo, Vo = Ho.block(bidx)
+            assert rel_err(Ug @ Vg, Uo @ Vo) < 1e-10

@@ -17,10 +17,10 @@ def build_trees(p):
     b.set_maximal_leaf_size(p["leaf"])
     b.set_partitioning_strategy(*STRATEGY[p["partitioning"]])
     xt = hm.create_geometry(p["geom"], p["n"])
-    T = b.create_cluster_tree(p["n"], 3, xt, p["children"], p["partitions"])
+    T = b.create_cluster_tree(p["n"], p["dim"], xt, p["children"], p["partitions"])
     if p["nsrc"]:
         xs = hm.create_geometry(p["sgeom"], p["nsrc"], p["sz"])
-        S = b.create_cluster_tree(p["nsrc"], 3, xs, p["children"], p["partitions"])
+        S = b.create_cluster_tree(p["nsrc"], p["dim"], xs, p["children"], p["partitions"])
     else:
         S = T
     return T, S
@@ -53,6 +53,7 @@ def test_block_tree_bit_exact(name):
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
     tb.set_minimal_target_depth(p["mindepth"])
     tb.set_minimal_source_depth(p["mindepth"])
+    tb.set_block_tree_consistency(bool(p["consistent"]))
     bt = tb.build_block_tree(T, S, p["rank"], p["rank"])
     a = bt.leaves
     ref = g["leaves"]

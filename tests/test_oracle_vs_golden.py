@@ -21,7 +21,7 @@ def build_oracle(name):
     else:
         S = T
     H = O.HMatrix(T, S, delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
-                  reqrank=p["reqrank"], compressor=p["compressor"], mindepth=p["mindepth"], rank=p["rank"])
+                  reqrank=p["reqrank"], compressor=p["compressor"], mindepth=p["mindepth"], rank=p["rank"], consistent=bool(p["consistent"]))
     return p, T, S, H
 
 
@@ -65,7 +65,11 @@ def test_payload_and_matvec(name):
             if p["compressor"] == "SVD":
                 assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 1e-9
             else:
-                assert rel_err(U, g[k].T) < 1e-9 and rel_err(V, g["V_%d" % b].T) < 1e-9
+                # factor-wise: rounding differences (MKL's axpy fuses multiply-add) grow with the number of ACA
+                # iterations; the product U V is what the matvec sees
+                ftol = 1e-9 if U.shape[1] <= 20 else 1e-6
+                assert rel_err(U, g[k].T) < ftol and rel_err(V, g["V_%d" % b].T) < ftol
+                assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 1e-9
         if k.startswith("D_"):
             assert np.array_equal(H.block(int(k[2:])), g[k].T)  # kernel entries bit-exact
     nr, nc = H.rootinfo[1], H.rootinfo[3]
