@@ -293,7 +293,7 @@ def main():
     achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")  # measured separately with rocprofv3 --pmc
-    if os.path.exists(tf) and world == 1 and n == 1000000:
+    if os.path.exists(tf) and world == 1 and n == 1000000 and args.geom == "ellipse" and args.sym == "N" and args.trans == "N" and mu == 1 and not emu and not use_dist:
         traffic = json.load(open(tf)).get("expand_kernel_hbm_bytes_per_launch")
     roofline = dict(bound="hbm", kernel="expand_kernel", achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
                     traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,

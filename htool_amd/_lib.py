@@ -39,7 +39,7 @@ class Stats(C.Structure):
 
 
 # every symbol include/hmx.h declares: (name, restype, argtypes)
-_dp, _ip, _vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+_dp, _ip, _vp, _fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_float)
 SYMBOLS = [
     ("hmx_last_error", C.c_char_p, []),
     ("hmx_device_count", C.c_int, []),
@@ -58,7 +58,15 @@ SYMBOLS = [
     ("hmx_block_tree_leaves", C.c_int, [_vp, C.POINTER(Leaf)]),
     ("hmx_block_tree_root", C.c_int, [_vp, _ip, C.c_char_p, C.c_char_p]),
     ("hmx_hmatrix_create", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("hmx_hmatrix_create_s", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("hmx_hmatrix_is_f32", C.c_int, [_vp]),
     ("hmx_hmatrix_destroy", None, [_vp]),
+    ("hmx_hmatrix_set_block_lowrank_s", C.c_int, [_vp, C.c_int64, C.c_int, _fp, _fp]),
+    ("hmx_hmatrix_set_block_dense_s", C.c_int, [_vp, C.c_int64, _fp]),
+    ("hmx_hmatrix_get_block_s", C.c_int, [_vp, C.c_int64, _fp, _fp]),
+    ("hmx_hmatrix_matvec_s", C.c_int, [_vp, C.c_char, C.c_float, _vp, C.c_float, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matvec_user_s", C.c_int, [_vp, C.c_char, C.c_float, _vp, C.c_float, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matmat_row_major_s", C.c_int, [_vp, C.c_char, C.c_float, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_hmatrix_set_kernel", C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
     ("hmx_hmatrix_compress", C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
     ("hmx_hmatrix_set_block_lowrank", C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp]),

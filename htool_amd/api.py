@@ -119,16 +119,16 @@ class InvDistGenerator:
         self.delta, self.scale = float(delta), float(scale)
 
 
-def _vec_ptr(v):
-    """(pointer, mem kind, keepalive) for a numpy array or a torch CUDA tensor."""
+def _vec_ptr(v, f32=False):
+    """(pointer, mem kind) for a numpy array or a torch tensor of the operator's coefficient precision."""
     if isinstance(v, np.ndarray):
-        if v.dtype != np.float64 or not v.flags["C_CONTIGUOUS"]:
-            raise HmxError("host vectors must be C-contiguous float64")
+        if v.dtype != (np.float32 if f32 else np.float64) or not v.flags["C_CONTIGUOUS"]:
+            raise HmxError("host vectors must be C-contiguous %s" % ("float32" if f32 else "float64"))
         return v.ctypes.data, _lib.HMX_MEM_HOST
     if hasattr(v, "data_ptr"):
         import torch
-        if v.dtype != torch.float64 or not v.is_contiguous():
-            raise HmxError("device vectors must be contiguous float64")
+        if v.dtype != (torch.float32 if f32 else torch.float64) or not v.is_contiguous():
+            raise HmxError("device vectors must be contiguous %s" % ("float32" if f32 else "float64"))
         return v.data_ptr(), (_lib.HMX_MEM_DEVICE if v.is_cuda else _lib.HMX_MEM_HOST)
     raise HmxError("unsupported vector type %r" % type(v))
 
@@ -145,6 +145,8 @@ class HMatrix:
 
     def __init__(self, bt_handle, hm_handle, target_cluster, source_cluster):
         self._bt, self._h = bt_handle, hm_handle
+        self.f32 = bool(lib().hmx_hmatrix_is_f32(hm_handle))
+        self.dtype = np.float32 if self.f32 else np.float64
         self._keep = (target_cluster, source_cluster)
         L = lib()
         r = np.zeros(4, dtype=np.int32)
@@ -188,23 +190,28 @@ class HMatrix:
         """(U, V) with U M x r and V r x N, or the dense M x N block."""
         a = self.leaves[leaf]
         M, N, r = int(a["t_size"]), int(a["s_size"]), int(self.ranks[leaf])
+        get = lib().hmx_hmatrix_get_block_s if self.f32 else lib().hmx_hmatrix_get_block
+        ptr = (lambda arr: arr.ctypes.data_as(C.POINTER(C.c_float))) if self.f32 else _dp
         if r >= 0:
-            U, V = np.empty((r, M)), np.empty((N, r))
-            check(lib().hmx_hmatrix_get_block(self._h, leaf, _dp(U), _dp(V)))
+            U, V = np.empty((r, M), dtype=self.dtype), np.empty((N, r), dtype=self.dtype)
+            check(get(self._h, leaf, ptr(U), ptr(V)))
             return U.T, V.T
-        D = np.empty((N, M))
-        check(lib().hmx_hmatrix_get_block(self._h, leaf, _dp(D), None))
+        D = np.empty((N, M), dtype=self.dtype)
+        check(get(self._h, leaf, ptr(D), None))
         return D.T
 
     def set_block_lowrank(self, leaf, U, V):
-        U = np.asfortranarray(U, dtype=np.float64)
-        V = np.asfortranarray(V, dtype=np.float64)
-        check(lib().hmx_hmatrix_set_block_lowrank(self._h, leaf, U.shape[1], U.ctypes.data_as(C.POINTER(C.c_double)),
-                                                  V.ctypes.data_as(C.POINTER(C.c_double))))
+        U = np.asfortranarray(U, dtype=self.dtype)
+        V = np.asfortranarray(V, dtype=self.dtype)
+        ct = C.c_float if self.f32 else C.c_double
+        fn = lib().hmx_hmatrix_set_block_lowrank_s if self.f32 else lib().hmx_hmatrix_set_block_lowrank
+        check(fn(self._h, leaf, U.shape[1], U.ctypes.data_as(C.POINTER(ct)), V.ctypes.data_as(C.POINTER(ct))))
 
     def set_block_dense(self, leaf, D):
-        D = np.asfortranarray(D, dtype=np.float64)
-        check(lib().hmx_hmatrix_set_block_dense(self._h, leaf, D.ctypes.data_as(C.POINTER(C.c_double))))
+        D = np.asfortranarray(D, dtype=self.dtype)
+        ct = C.c_float if self.f32 else C.c_double
+        fn = lib().hmx_hmatrix_set_block_dense_s if self.f32 else lib().hmx_hmatrix_set_block_dense
+        check(fn(self._h, leaf, D.ctypes.data_as(C.POINTER(ct))))
 
     def finalize(self):
         check(lib().hmx_hmatrix_finalize(self._h))
@@ -288,13 +295,16 @@ class HMatrixTreeBuilder:
         return BlockTree(self._block_tree(target, source, target_partition_number, partition_number_for_symmetry))
 
     def build(self, generator, target_root_cluster_tree, source_root_cluster_tree, target_partition_number=-1,
-              partition_number_for_symmetry=-1, device=0, compress=True):
+              partition_number_for_symmetry=-1, device=0, compress=True, dtype=np.float64):
         """HMatrixTreeBuilder::build (tree_builder.hpp:199-210).  With compress=False only the structure is
         created on the device and blocks are expected through HMatrix.set_block_*() + finalize()."""
         bt = self._block_tree(target_root_cluster_tree, source_root_cluster_tree, target_partition_number,
                               partition_number_for_symmetry)
         h = C.c_void_p()
-        check(lib().hmx_hmatrix_create(bt, device, C.byref(h)))
+        if np.dtype(dtype) == np.float32:  # HMatrix<float,double>: fp32 coefficients, fp64 geometry
+            check(lib().hmx_hmatrix_create_s(bt, device, C.byref(h)))
+        else:
+            check(lib().hmx_hmatrix_create(bt, device, C.byref(h)))
         H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
         if generator is not None:
             if not isinstance(generator, InvDistGenerator):
@@ -310,31 +320,34 @@ class HMatrixTreeBuilder:
 
 def internal_add_hmatrix_vector_product(trans, alpha, A, x, beta, y):
     """y = alpha*op(A)*x + beta*y in cluster numbering (vectors local to A's root clusters)."""
-    px, mx = _vec_ptr(x)
-    py, my = _vec_ptr(y)
+    px, mx = _vec_ptr(x, A.f32)
+    py, my = _vec_ptr(y, A.f32)
     if mx != my:
         raise HmxError("in and out must live in the same memory space")
-    check(lib().hmx_hmatrix_matvec(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
+    fn = lib().hmx_hmatrix_matvec_s if A.f32 else lib().hmx_hmatrix_matvec
+    check(fn(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
     return y
 
 
 def add_hmatrix_vector_product(trans, alpha, A, x, beta, y):
     """User-numbering front end (permutations on the device)."""
-    px, mx = _vec_ptr(x)
-    py, my = _vec_ptr(y)
+    px, mx = _vec_ptr(x, A.f32)
+    py, my = _vec_ptr(y, A.f32)
     if mx != my:
         raise HmxError("in and out must live in the same memory space")
-    check(lib().hmx_hmatrix_matvec_user(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
+    fn = lib().hmx_hmatrix_matvec_user_s if A.f32 else lib().hmx_hmatrix_matvec_user
+    check(fn(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
     return y
 
 
 def internal_add_hmatrix_matrix_product_row_major(trans, alpha, A, X, beta, Y, mu):
     """Row-major (mu fastest) multi-RHS product in cluster numbering."""
-    px, mx = _vec_ptr(X)
-    py, my = _vec_ptr(Y)
+    px, mx = _vec_ptr(X, A.f32)
+    py, my = _vec_ptr(Y, A.f32)
     if mx != my:
         raise HmxError("in and out must live in the same memory space")
-    check(lib().hmx_hmatrix_matmat_row_major(A._h, trans.encode(), alpha, px, beta, py, mu, mx, _stream_ptr(X)))
+    fn = lib().hmx_hmatrix_matmat_row_major_s if A.f32 else lib().hmx_hmatrix_matmat_row_major
+    check(fn(A._h, trans.encode(), alpha, px, beta, py, mu, mx, _stream_ptr(X)))
     return Y
 
 
@@ -355,8 +368,8 @@ def add_hmatrix_matrix_product(transa, alpha, A, B, beta, Cm):
     nout = A.target_size if transa == "N" else A.source_size
     pin = pin[oin:oin + nin] - oin
     pout = pout[oout:oout + nout] - oout
-    X = np.ascontiguousarray(np.asarray(B)[pin, :], dtype=np.float64)       # user_to_cluster per column + transpose
-    Y = np.ascontiguousarray(np.asarray(Cm)[pout, :], dtype=np.float64)
+    X = np.ascontiguousarray(np.asarray(B)[pin, :], dtype=A.dtype)       # user_to_cluster per column + transpose
+    Y = np.ascontiguousarray(np.asarray(Cm)[pout, :], dtype=A.dtype)
     internal_add_hmatrix_matrix_product_row_major(transa, alpha, A, X, beta, Y, mu)
     Cm[pout, :] = Y
     return Cm

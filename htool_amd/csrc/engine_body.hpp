@@ -1,0 +1,1230 @@
+// engine_body.hpp -- host orchestration of the device engine, written against `real` (coefficient type) and included
+// twice by engine.hip (namespace hmx::f64 with real = double, hmx::f32 with real = float).  No include guard on purpose.
+
+struct StreamSet {
+    std::vector<int32_t> off, len, cols, cw; // per range: local offset, rows, columns, chunk width (R only)
+    std::vector<int64_t> base, colbase;  // per range: first element in `stream`, first entry in index arrays
+    int64_t elems = 0, total_cols = 0;
+    DArr<int32_t> d_off, d_len, d_cols, d_cw;
+    DArr<int64_t> d_base, d_colbase;
+    DArr<real> stream;
+    // R: one task per (range, column chunk), heaviest first.  E: task_range = launch order of the ranges.
+    std::vector<int32_t> task_range, task_chunk;
+    DArr<int32_t> d_task_range, d_task_chunk;
+    int nranges() const { return (int)off.size(); }
+    hipError_t upload_meta() {
+        hipError_t e;
+        if ((e = d_off.upload(off)) != hipSuccess) return e;
+        if ((e = d_len.upload(len)) != hipSuccess) return e;
+        if ((e = d_cols.upload(cols)) != hipSuccess) return e;
+        if ((e = d_cw.upload(cw)) != hipSuccess) return e;
+        if ((e = d_base.upload(base)) != hipSuccess) return e;
+        if ((e = d_colbase.upload(colbase)) != hipSuccess) return e;
+        if ((e = d_task_range.upload(task_range)) != hipSuccess) return e;
+        return d_task_chunk.upload(task_chunk);
+    }
+};
+
+
+struct HMat {
+    int device = 0;
+    // structure (copied from the block tree)
+    std::vector<hmx_leaf> leaves;
+    std::vector<int> kind; // LeafKind per leaf
+    int T0 = 0, nT = 0, S0 = 0, nS = 0;
+    int nT_total = 0, nS_total = 0;
+    char symmetry_for_leaves = 'N', uplo_for_leaves = 'N';
+    bool has_mirror = false;
+    std::vector<int32_t> perm_t, perm_s; // full permutations (cluster -> user)
+    bool t_root_is_tree_root = false, perm_local = false;
+
+    // generator
+    bool has_kernel = false;
+    KernelSpec ks{};
+    DArr<double> tx, ty, tz, sx, sy, sz; // cluster-order coordinates (SoA)
+
+    // per-leaf metadata on device
+    DArr<int32_t> d_t_off, d_t_size, d_s_off, d_s_size, d_rank, d_swapped, d_sym_uplo;
+    DArr<int64_t> d_colptr, d_cross_off, d_staged_off;
+    std::vector<int64_t> colptr;
+    std::vector<int32_t> swapped;
+    // compressed data before packing ("crosses": [uu_k | vv_k]) and staged dense uploads
+    DArr<real> pool;
+    unsigned long long pool_used = 0;
+    // host staging for the upload path
+    std::vector<std::vector<real>> staged_U, staged_V, staged_D;
+
+    // streams
+    StreamSet E, R;
+    DArr<int32_t> e_zidx, e_zidx_mirror, e_tdst, e_tdst_mirror;
+    DArr<int32_t> r_outidx, r_tcoef, r_tcoef_mirror;
+    std::vector<int32_t> h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag, h_e_tdst_all, h_e_tdst_mir;
+    DArr<int32_t> c_dst, c_src, c_stride, c_count;
+    int n_combine       = 0;
+    int64_t A_total     = 0, P_total = 0;
+    int64_t zero_slot   = 0;
+    DArr<real> Z, W, Zmu;
+    DArr<real> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
+    DArr<int32_t> d_perm_t, d_perm_s;
+    bool finalized = false;
+
+    hmx_stats stats{};
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<const char *> ev_names;
+    std::vector<float> last_ms;
+    std::vector<const char *> last_names;
+
+    ~HMat() {
+        for (auto e : ev)
+            (void)hipEventDestroy(e);
+    }
+};
+
+
+static int build_streams(HMat &H) {
+    Timer tim;
+    const int64_t nb = (int64_t)H.leaves.size();
+    constexpr int TR_MAX = 64, SR_MAX = 512;
+    // ---- ranges ---------------------------------------------------------------------------------
+    // E ranges partition the local rows at every block boundary (each output row has exactly one owner).
+    // R ranges are per DISTINCT source cluster of the low-rank leaves (cut into pieces of <= SR_MAX rows): a
+    // block is reduced over ceil(n/SR_MAX) pieces of its own cluster instead of over every leaf cluster below
+    // it, so blocks up to SR_MAX columns need no partial sums at all and the largest ones a few dozen.
+    std::vector<int> tbp{H.T0, H.T0 + H.nT};
+    std::vector<std::pair<int, int>> sclusters;
+    for (int64_t b = 0; b < nb; b++) {
+        const hmx_leaf &l = H.leaves[b];
+        tbp.push_back(l.t_offset);
+        tbp.push_back(l.t_offset + l.t_size);
+        if (H.kind[b] == LK_LOWRANK && l.rank > 0)
+            sclusters.emplace_back(l.s_offset, l.s_size);
+    }
+    std::sort(sclusters.begin(), sclusters.end());
+    sclusters.erase(std::unique(sclusters.begin(), sclusters.end()), sclusters.end());
+    StreamSet &E = H.E, &R = H.R;
+    make_ranges(tbp, TR_MAX, H.T0, E.off, E.len);
+    R.off.clear();
+    R.len.clear();
+    std::vector<int32_t> scluster_first(sclusters.size() + 1, 0);
+    for (size_t c = 0; c < sclusters.size(); c++) {
+        std::vector<int> bp{sclusters[c].first, sclusters[c].first + sclusters[c].second};
+        std::vector<int32_t> o, ln;
+        make_ranges(bp, SR_MAX, H.S0, o, ln);
+        scluster_first[c] = (int32_t)R.off.size();
+        R.off.insert(R.off.end(), o.begin(), o.end());
+        R.len.insert(R.len.end(), ln.begin(), ln.end());
+    }
+    scluster_first[sclusters.size()] = (int32_t)R.off.size();
+    // position -> range lookup
+    std::vector<int32_t> t_pos2range(H.nT + 1, -1);
+    for (int r = 0; r < E.nranges(); r++)
+        t_pos2range[E.off[r]] = r;
+    auto range_span = [](const std::vector<int32_t> &pos2range, const StreamSet &S, int lo, int hi, int &ra, int &rb) {
+        ra = pos2range[lo];
+        rb = ra;
+        while (rb < S.nranges() && S.off[rb] < hi)
+            rb++;
+    };
+    // ---- columns per range, pair lists, a / partial offsets ----------------------------------------
+    E.cols.assign(E.nranges(), 0);
+    E.cw.assign(E.nranges(), 0);
+    R.cols.assign(R.nranges(), 0);
+    std::vector<int32_t> elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c;
+    std::vector<int64_t> aoff(nb, -1), poff(nb, -1);
+    std::vector<int32_t> ns_of(nb, 0), s_first(nb, 0);
+    int64_t A_total = 0, P_total = 0;
+    H.stats = hmx_stats{};
+    H.stats.rank_min = 1 << 30;
+    double rank_sum  = 0;
+    for (int64_t b = 0; b < nb; b++) {
+        const hmx_leaf &l = H.leaves[b];
+        const bool lr     = H.kind[b] == LK_LOWRANK;
+        if (lr && l.rank <= 0)
+            continue; // rank-0 low-rank block: contributes nothing (add_lrmat_vector_product.hpp:11)
+        const int ncols = lr ? l.rank : l.s_size;
+        int ra, rb;
+        range_span(t_pos2range, E, l.t_offset - H.T0, l.t_offset - H.T0 + l.t_size, ra, rb);
+        for (int r = ra; r < rb; r++) {
+            (lr ? elr_b : ed_b).push_back((int32_t)b);
+            (lr ? elr_r : ed_r).push_back(r);
+            (lr ? elr_c : ed_c).push_back(E.cols[r]);
+            E.cols[r] += ncols;
+        }
+        if (lr) {
+            aoff[b] = A_total;
+            A_total += l.rank;
+            const size_t sc = std::lower_bound(sclusters.begin(), sclusters.end(), std::make_pair((int)l.s_offset, (int)l.s_size)) - sclusters.begin();
+            const int sa = scluster_first[sc], sb = scluster_first[sc + 1];
+            ns_of[b]   = sb - sa;
+            s_first[b] = sa;
+            if (sb - sa > 1) {
+                poff[b] = P_total;
+                P_total += (int64_t)(sb - sa) * l.rank;
+            }
+            for (int r = sa; r < sb; r++) {
+                rlr_b.push_back((int32_t)b);
+                rlr_r.push_back(r);
+                rlr_c.push_back(R.cols[r]);
+                R.cols[r] += l.rank;
+            }
+            H.stats.n_lowrank++;
+            H.stats.cgen_lowrank += (int64_t)l.rank * (l.t_size + l.s_size);
+            H.stats.rank_min = std::min(H.stats.rank_min, l.rank);
+            H.stats.rank_max = std::max(H.stats.rank_max, l.rank);
+            rank_sum += l.rank;
+        } else {
+            H.stats.n_dense++;
+            H.stats.cgen_dense += (int64_t)l.t_size * l.s_size;
+        }
+    }
+    if (H.stats.n_lowrank == 0)
+        H.stats.rank_min = 0;
+    H.stats.rank_mean = H.stats.n_lowrank ? rank_sum / H.stats.n_lowrank : 0;
+    H.A_total = A_total;
+    H.P_total = P_total;
+    // ---- bases ------------------------------------------------------------------------------------
+    E.base.assign(E.nranges(), 0);
+    E.colbase.assign(E.nranges(), 0);
+    E.elems = E.total_cols = 0;
+    for (int r = 0; r < E.nranges(); r++) {
+        E.base[r]    = E.elems;
+        E.colbase[r] = E.total_cols;
+        E.elems += (int64_t)E.len[r] * E.cols[r];
+        E.total_cols += E.cols[r];
+    }
+    E.task_range.resize(E.nranges());
+    std::iota(E.task_range.begin(), E.task_range.end(), 0);
+    if (!getenv("HMX_SORT_TASKS") || atoi(getenv("HMX_SORT_TASKS")))
+        std::stable_sort(E.task_range.begin(), E.task_range.end(), [&](int a, int b) { return (int64_t)E.len[a] * E.cols[a] > (int64_t)E.len[b] * E.cols[b]; });
+    E.task_chunk.clear();
+    R.base.assign(R.nranges(), 0);
+    R.colbase.assign(R.nranges(), 0);
+    R.elems = R.total_cols = 0;
+    R.task_range.clear();
+    R.task_chunk.clear();
+    R.cw.assign(R.nranges(), 2);
+    for (int r = 0; r < R.nranges(); r++) {
+        R.base[r]    = R.elems;
+        R.colbase[r] = R.total_cols;
+        const int C = R.cols[r], nch = (C + 127) / 128;
+        if (C > 0) { // balanced chunks: nch chunks of width cw (even), the last one takes what is left
+            const int cw = (((C + nch - 1) / nch) + 1) & ~1;
+            R.cw[r]      = cw;
+            const int wlast = C - (nch - 1) * cw;
+            R.elems += (int64_t)R.len[r] * ((int64_t)(nch - 1) * cw + ((wlast + 1) & ~1));
+        }
+        R.total_cols += C;
+        for (int c = 0; c < nch; c++) {
+            R.task_range.push_back(r);
+            R.task_chunk.push_back(c);
+        }
+    }
+    if (!getenv("HMX_SORT_TASKS") || atoi(getenv("HMX_SORT_TASKS"))) { // longest tasks first: shorter kernel tail (-8 % on reduce_kernel)
+        std::vector<int> ord(R.task_range.size());
+        std::iota(ord.begin(), ord.end(), 0);
+        auto work = [&](int t) {
+            const int r = R.task_range[t], c = R.task_chunk[t];
+            int w = R.cols[r] - c * R.cw[r];
+            w     = std::min(w, (int)R.cw[r]);
+            return (int64_t)R.len[r] * w;
+        };
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return work(a) > work(b); });
+        std::vector<int32_t> tr(ord.size()), tc(ord.size());
+        for (size_t k = 0; k < ord.size(); k++) {
+            tr[k] = R.task_range[ord[k]];
+            tc[k] = R.task_chunk[ord[k]];
+        }
+        R.task_range.swap(tr);
+        R.task_chunk.swap(tc);
+    }
+    if (E.total_cols >= (int64_t(1) << 31) || R.total_cols >= (int64_t(1) << 31) || (int64_t)H.nS + A_total + P_total + 2 >= (int64_t(1) << 31)) {
+        set_error("operator too large for 32-bit column indices");
+        return HMX_ERR_UNSUPPORTED;
+    }
+    // ---- index arrays -------------------------------------------------------------------------------
+    const int64_t zA = H.nS, zP = H.nS + A_total;
+    H.zero_slot      = H.nS + A_total + P_total;
+    H.h_e_zidx.assign(E.total_cols, 0);
+    H.h_e_mirrorflag.assign(H.has_mirror ? E.total_cols : 0, 0);
+    auto fill_e = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
+        for (size_t p = 0; p < pb.size(); p++) {
+            const int b = pb[p], r = pr[p];
+            const hmx_leaf &l = H.leaves[b];
+            const int ncols   = lr ? l.rank : l.s_size;
+            const int64_t z0  = lr ? zA + aoff[b] : (int64_t)(l.s_offset - H.S0);
+            int32_t *dst      = H.h_e_zidx.data() + E.colbase[r] + pc[p];
+            for (int j = 0; j < ncols; j++)
+                dst[j] = (int32_t)(z0 + j);
+            if (H.has_mirror && l.mirror)
+                std::fill_n(H.h_e_mirrorflag.data() + E.colbase[r] + pc[p], ncols, 1);
+        }
+    };
+    fill_e(elr_b, elr_r, elr_c, true);
+    fill_e(ed_b, ed_r, ed_c, false);
+    std::vector<int32_t> h_outidx(R.total_cols, 0);
+    H.h_r_aidx.assign(R.total_cols, 0);
+    H.h_r_mirrorflag.assign(H.has_mirror ? R.total_cols : 0, 0);
+    for (size_t p = 0; p < rlr_b.size(); p++) {
+        const int b = rlr_b[p], r = rlr_r[p];
+        const hmx_leaf &l = H.leaves[b];
+        const int64_t cb  = R.colbase[r] + rlr_c[p];
+        for (int k = 0; k < l.rank; k++) {
+            H.h_r_aidx[cb + k] = (int32_t)(aoff[b] + k);
+            h_outidx[cb + k]   = ns_of[b] == 1 ? (int32_t)(zA + aoff[b] + k) : (int32_t)(zP + poff[b] + (int64_t)(r - s_first[b]) * l.rank + k);
+            if (H.has_mirror && l.mirror)
+                H.h_r_mirrorflag[cb + k] = 1;
+        }
+    }
+    std::vector<int32_t> cd, cs, cst, cc;
+    for (int64_t b = 0; b < nb; b++)
+        if (poff[b] >= 0)
+            for (int k = 0; k < H.leaves[b].rank; k++) {
+                cd.push_back((int32_t)(zA + aoff[b] + k));
+                cs.push_back((int32_t)(zP + poff[b] + k));
+                cst.push_back(H.leaves[b].rank);
+                cc.push_back(ns_of[b]);
+            }
+    H.n_combine = (int)cd.size();
+    // transposed-pass destinations (built lazily on first use; keep what is needed to build them)
+    H.h_e_tdst_all.assign(E.total_cols, -1);
+    {
+        auto fill_t = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
+            for (size_t p = 0; p < pb.size(); p++) {
+                const int b = pb[p], r = pr[p];
+                const hmx_leaf &l = H.leaves[b];
+                const int ncols   = lr ? l.rank : l.s_size;
+                int32_t *dst      = H.h_e_tdst_all.data() + E.colbase[r] + pc[p];
+                for (int j = 0; j < ncols; j++) // dense: global source position (shifted at use); low rank: -(2 + a index)
+                    dst[j] = lr ? (int32_t)(-2 - (aoff[b] + j)) : (int32_t)(l.s_offset + j);
+            }
+        };
+        fill_t(elr_b, elr_r, elr_c, true);
+        fill_t(ed_b, ed_r, ed_c, false);
+    }
+
+    // ---- upload metadata, allocate streams ------------------------------------------------------------
+    HMX_HIP(E.upload_meta());
+    HMX_HIP(R.upload_meta());
+    HMX_HIP(E.stream.alloc(std::max<int64_t>(E.elems, 1)));
+    HMX_HIP(R.stream.alloc(std::max<int64_t>(R.elems, 1)));
+    HMX_HIP(R.stream.zero()); // padded odd-width chunks keep a zero column
+    HMX_HIP(H.e_zidx.upload(H.h_e_zidx));
+    HMX_HIP(H.r_outidx.upload(h_outidx));
+    HMX_HIP(H.c_dst.upload(cd));
+    HMX_HIP(H.c_src.upload(cs));
+    HMX_HIP(H.c_stride.upload(cst));
+    HMX_HIP(H.c_count.upload(cc));
+    HMX_HIP(H.Z.alloc(H.zero_slot + 1));
+    HMX_HIP(H.Z.zero());
+    HMX_HIP(H.W.alloc(std::max(H.nS, H.nT) + A_total + 1));
+    H.e_zidx_mirror.release();
+    H.e_tdst.release();
+    H.e_tdst_mirror.release();
+    H.r_tcoef.release();
+    H.r_tcoef_mirror.release();
+
+    // ---- pack ---------------------------------------------------------------------------------------------
+    std::vector<int32_t> ranks(nb), symu(nb, 0);
+    for (int64_t b = 0; b < nb; b++) {
+        ranks[b] = H.leaves[b].rank;
+        if (H.leaves[b].symmetric && H.kind[b] == LK_DENSE_STAGED)
+            symu[b] = H.uplo_for_leaves == 'L' ? 1 : (H.uplo_for_leaves == 'U' ? 2 : 0);
+    }
+    HMX_HIP(H.d_rank.upload(ranks));
+    HMX_HIP(H.d_sym_uplo.upload(symu));
+    hipEvent_t e0, e1;
+    HMX_HIP(hipEventCreate(&e0));
+    HMX_HIP(hipEventCreate(&e1));
+    HMX_HIP(hipEventRecord(e0, 0));
+    {
+        DArr<int32_t> pb, pr, pc;
+        if (!elr_b.empty()) {
+            HMX_HIP(pb.upload(elr_b));
+            HMX_HIP(pr.upload(elr_r));
+            HMX_HIP(pc.upload(elr_c));
+            PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
+                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0};
+            hipLaunchKernelGGL(pack_lr_expand_kernel, dim3((unsigned)elr_b.size()), dim3(256), 0, 0, P, (int64_t)elr_b.size());
+            HMX_HIP(hipGetLastError());
+            HMX_HIP(hipDeviceSynchronize());
+        }
+        if (!rlr_b.empty()) {
+            HMX_HIP(pb.upload(rlr_b));
+            HMX_HIP(pr.upload(rlr_r));
+            HMX_HIP(pc.upload(rlr_c));
+            PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
+                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0};
+            hipLaunchKernelGGL(pack_lr_reduce_kernel, dim3((unsigned)rlr_b.size()), dim3(256), 0, 0, P, (int64_t)rlr_b.size());
+            HMX_HIP(hipGetLastError());
+            HMX_HIP(hipDeviceSynchronize());
+        }
+        if (!ed_b.empty()) {
+            HMX_HIP(pb.upload(ed_b));
+            HMX_HIP(pr.upload(ed_r));
+            HMX_HIP(pc.upload(ed_c));
+            PackDenseArgs P{H.ks, H.tx.d, H.ty.d, H.tz.d, H.sx.d, H.sy.d, H.sz.d, pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d,
+                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.pool.d, E.stream.d, H.T0};
+            hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)ed_b.size()), dim3(256), 0, 0, P, (int64_t)ed_b.size());
+            HMX_HIP(hipGetLastError());
+            HMX_HIP(hipDeviceSynchronize());
+        }
+    }
+    HMX_HIP(hipEventRecord(e1, 0));
+    HMX_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    H.stats.t_pack_s     = tim.s();
+    H.stats.t_assemble_s = ms * 1e-3;
+    H.stats.stream_bytes = (E.elems + R.elems) * (int64_t)sizeof(real);
+    H.stats.expand_coeffs = E.elems;
+    H.stats.a_total       = A_total;
+    H.stats.reduce_coeffs = 0;
+    for (int64_t b = 0; b < nb; b++)
+        if (H.kind[b] == LK_LOWRANK && H.leaves[b].rank > 0)
+            H.stats.reduce_coeffs += (int64_t)H.leaves[b].rank * H.leaves[b].s_size;
+    H.finalized          = true;
+    return HMX_OK;
+}
+
+// lazily built index arrays for the transposed / mirrored passes
+static int ensure_transposed_indices(HMat &H) {
+    if (H.e_tdst.d || H.E.total_cols == 0)
+        return HMX_OK;
+    // true transposed product: W = [out (nS, source-local) | aT]; mirror pass: W = [out (nT, target-local) | aT]
+    const int64_t nE = H.E.total_cols, nR = H.R.total_cols;
+    std::vector<int32_t> tall(nE), tmir(nE), call(nR), cmir(nR), zmir(nE);
+    for (int64_t c = 0; c < nE; c++) {
+        const int32_t v  = H.h_e_tdst_all[c];
+        const bool mir   = H.has_mirror && H.h_e_mirrorflag[c];
+        const bool lr    = v <= -2;
+        tall[c]          = lr ? (int32_t)(H.nS + (-2 - v)) : v - H.S0;
+        tmir[c]          = !mir ? -1 : (lr ? (int32_t)(H.nT + (-2 - v)) : v - H.T0);
+        zmir[c]          = mir ? H.h_e_zidx[c] : (int32_t)H.zero_slot;
+    }
+    for (int64_t c = 0; c < nR; c++) {
+        const bool mir = H.has_mirror && H.h_r_mirrorflag[c];
+        call[c]        = (int32_t)(H.nS + H.h_r_aidx[c]);
+        cmir[c]        = mir ? (int32_t)(H.nT + H.h_r_aidx[c]) : -1;
+    }
+    HMX_HIP(H.e_tdst.upload(tall));
+    HMX_HIP(H.r_tcoef.upload(call));
+    if (H.has_mirror) {
+        HMX_HIP(H.e_tdst_mirror.upload(tmir));
+        HMX_HIP(H.r_tcoef_mirror.upload(cmir));
+        HMX_HIP(H.e_zidx_mirror.upload(zmir));
+    }
+    return HMX_OK;
+}
+
+static void prof_mark(HMat &H, hipStream_t st, const char *name) {
+    if (!H.profiling)
+        return;
+    hipEvent_t e;
+    if (H.ev.size() <= H.ev_names.size()) {
+        (void)hipEventCreate(&e);
+        H.ev.push_back(e);
+    }
+    e = H.ev[H.ev_names.size()];
+    (void)hipEventRecord(e, st);
+    H.ev_names.push_back(name);
+}
+
+// forward pass on device pointers: y = alpha * (sum over leaves) x + beta * y using the fast kernels
+// zidx: coefficient index array of the E-streams (all leaves, or mirror leaves only)
+static int run_forward(HMat &H, const int32_t *zidx, const real *x_src, int x_shift, real alpha, real beta, real *y, hipStream_t st) {
+    // Z[x region] <- x.  x_shift != 0 (mirror pass of a transposed product): the input is indexed by target
+    // positions, the x region by source positions.
+    if (x_shift == 0) {
+        HMX_HIP(hipMemcpyAsync(H.Z.d, x_src, (size_t)H.nS * sizeof(real), hipMemcpyDeviceToDevice, st));
+    } else {
+        HMX_HIP(hipMemsetAsync(H.Z.d, 0, (size_t)H.nS * sizeof(real), st));
+        const int lo = std::max(H.S0, H.T0), hi = std::min(H.S0 + H.nS, H.T0 + H.nT);
+        if (hi > lo)
+            HMX_HIP(hipMemcpyAsync(H.Z.d + (lo - H.S0), x_src + (lo - H.T0), (size_t)(hi - lo) * sizeof(real), hipMemcpyDeviceToDevice, st));
+    }
+    prof_mark(H, st, "copy_x");
+    static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 4; // tuning knobs
+    static const int EW = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 4;
+    const int ntasks = (int)H.R.task_range.size();
+    if (ntasks > 0) {
+        ReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
+                     H.r_outidx.d, H.Z.d, H.Z.d, ntasks};
+        switch (RW) {
+        case 1: hipLaunchKernelGGL(reduce_kernel<1>, dim3(ntasks), dim3(64), 0, st, A); break;
+        case 2: hipLaunchKernelGGL(reduce_kernel<2>, dim3((ntasks + 1) / 2), dim3(128), 0, st, A); break;
+        case 8: hipLaunchKernelGGL(reduce_kernel<8>, dim3((ntasks + 7) / 8), dim3(512), 0, st, A); break;
+        default: hipLaunchKernelGGL(reduce_kernel<4>, dim3((ntasks + 3) / 4), dim3(256), 0, st, A); break;
+        }
+        prof_mark(H, st, "reduce_kernel");
+    }
+    if (H.n_combine > 0) {
+        CombineArgs C{H.c_dst.d, H.c_src.d, H.c_stride.d, H.c_count.d, H.Z.d, H.n_combine};
+        hipLaunchKernelGGL(combine_kernel, dim3((H.n_combine + 255) / 256), dim3(256), 0, st, C);
+        prof_mark(H, st, "combine_kernel");
+    }
+    if (H.E.nranges() > 0) {
+        ExpandArgs X{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges()};
+        switch (EW) {
+        case 1: hipLaunchKernelGGL(expand_kernel<1>, dim3(H.E.nranges()), dim3(64), 0, st, X); break;
+        case 2: hipLaunchKernelGGL(expand_kernel<2>, dim3(H.E.nranges()), dim3(128), 0, st, X); break;
+        case 8: hipLaunchKernelGGL(expand_kernel<8>, dim3(H.E.nranges()), dim3(512), 0, st, X); break;
+        default: hipLaunchKernelGGL(expand_kernel<4>, dim3(H.E.nranges()), dim3(256), 0, st, X); break;
+        }
+        prof_mark(H, st, "expand_kernel");
+    }
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+template <int MU>
+static void launch_mu(HMat &H, ReduceArgs &RA, ExpandArgs &XA, int mu, int cbase, hipStream_t st) {
+    constexpr int RW = 4;
+    if (RA.ntasks > 0)
+        hipLaunchKernelGGL((reduce_mu_kernel<RW, MU>), dim3((RA.ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, RA, mu, cbase);
+    prof_mark(H, st, "reduce_mu_kernel");
+    (void)XA;
+}
+template <int MU>
+static void launch_mu_expand(HMat &H, ExpandArgs &XA, int mu, int cbase, hipStream_t st) {
+    constexpr int EW = 4;
+    if (XA.nranges > 0)
+        hipLaunchKernelGGL((expand_mu_kernel<EW, MU>), dim3(XA.nranges), dim3(EW * 64), 0, st, XA, mu, cbase);
+    prof_mark(H, st, "expand_mu_kernel");
+}
+
+// Fused multi-RHS forward pass (trans='N', no mirror leaves): Y = alpha * H * X + beta * Y, X and Y row-major.
+static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y, int mu, hipStream_t st) {
+    const size_t need = (size_t)(H.zero_slot + 1) * mu;
+    if (H.Zmu.n < need)
+        HMX_HIP(H.Zmu.alloc(need));
+    HMX_HIP(hipMemcpyAsync(H.Zmu.d, X, (size_t)H.nS * mu * sizeof(real), hipMemcpyDeviceToDevice, st));
+    prof_mark(H, st, "copy_x");
+    ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
+                  H.r_outidx.d, H.Zmu.d, H.Zmu.d, (int)H.R.task_range.size()};
+    ExpandArgs XA{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges()};
+    // stage 1 for every group of right-hand sides, then the partial sums, then stage 2
+    auto for_groups = [&](auto &&fn) {
+        int c = 0;
+        while (c < mu) {
+            const int left = mu - c;
+            const int g    = left >= 16 ? 16 : (left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1)));
+            fn(g, c);
+            c += g;
+        }
+    };
+    for_groups([&](int g, int c) {
+        switch (g) {
+        case 16: launch_mu<16>(H, RA, XA, mu, c, st); break;
+        case 8: launch_mu<8>(H, RA, XA, mu, c, st); break;
+        case 4: launch_mu<4>(H, RA, XA, mu, c, st); break;
+        case 2: launch_mu<2>(H, RA, XA, mu, c, st); break;
+        default: launch_mu<1>(H, RA, XA, mu, c, st); break;
+        }
+    });
+    if (H.n_combine > 0) {
+        CombineArgs C{H.c_dst.d, H.c_src.d, H.c_stride.d, H.c_count.d, H.Zmu.d, H.n_combine};
+        const int64_t tot = (int64_t)H.n_combine * mu;
+        hipLaunchKernelGGL(combine_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, mu);
+        prof_mark(H, st, "combine_mu_kernel");
+    }
+    for_groups([&](int g, int c) {
+        switch (g) {
+        case 16: launch_mu_expand<16>(H, XA, mu, c, st); break;
+        case 8: launch_mu_expand<8>(H, XA, mu, c, st); break;
+        case 4: launch_mu_expand<4>(H, XA, mu, c, st); break;
+        case 2: launch_mu_expand<2>(H, XA, mu, c, st); break;
+        default: launch_mu_expand<1>(H, XA, mu, c, st); break;
+        }
+    });
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+// transposed pass: out = alpha * sum_leaves leaf^T in + beta * out, accumulated through W with atomics.
+// mirror=true restricts to leaves_for_symmetry and uses target-local output / source... (see ensure_transposed_indices)
+static int run_transposed(HMat &H, bool mirror, const real *in, real alpha, real beta, real *out, hipStream_t st) {
+    int rc = ensure_transposed_indices(H);
+    if (rc != HMX_OK)
+        return rc;
+    const int nout = mirror ? H.nT : H.nS;
+    HMX_HIP(hipMemsetAsync(H.W.d, 0, (size_t)(nout + H.A_total) * sizeof(real), st));
+    constexpr int CW = 4, RW = 4;
+    if (H.E.nranges() > 0) {
+        // true transposed: `in` is target-local; mirror pass: `in` is source-local, rows are target positions
+        const real *in_eff = mirror ? in + (H.T0 - H.S0) : in;
+        ColReduceArgs A{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, mirror ? H.e_tdst_mirror.d : H.e_tdst.d, in_eff, H.W.d, H.E.nranges()};
+        hipLaunchKernelGGL(colreduce_kernel<CW>, dim3(H.E.nranges()), dim3(CW * 64), 0, st, A);
+        prof_mark(H, st, "colreduce_kernel");
+    }
+    const int ntasks = (int)H.R.task_range.size();
+    if (ntasks > 0) {
+        // rows of the R-streams are source positions; the mirror pass writes them into a target-local vector
+        RowReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
+                        mirror ? H.r_tcoef_mirror.d : H.r_tcoef.d, H.W.d, ntasks, mirror ? H.S0 - H.T0 : 0};
+        hipLaunchKernelGGL(rowreduce_kernel<RW>, dim3((ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, A);
+        prof_mark(H, st, "rowreduce_kernel");
+    }
+    hipLaunchKernelGGL(axpby_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, alpha, H.W.d, beta, out);
+    prof_mark(H, st, "axpby_kernel");
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+static int matvec_device(HMat &H, char trans, real alpha, const real *in, real beta, real *out, hipStream_t st) {
+    if (!H.finalized) {
+        set_error("hmx_hmatrix_matvec: operator not built (call hmx_hmatrix_compress or hmx_hmatrix_finalize first)");
+        return HMX_ERR_STATE;
+    }
+    if (trans != 'N' && trans != 'T') { // 'C' with 'S' leaves is an error in the reference too (add_hmatrix_vector_product.hpp:59-62)
+        set_error("hmx_hmatrix_matvec: trans must be 'N' or 'T'");
+        return HMX_ERR_INVALID;
+    }
+    if (H.has_mirror && (H.S0 > H.T0 || H.S0 + H.nS < H.T0 + H.nT)) {
+        set_error("symmetric storage needs the target rows to be a sub-range of the source columns");
+        return HMX_ERR_UNSUPPORTED;
+    }
+    H.ev_names.clear();
+    prof_mark(H, st, "begin");
+    int rc;
+    if (trans == 'N') {
+        rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st);
+        if (rc == HMX_OK && H.has_mirror)
+            rc = run_transposed(H, true, in, alpha, 1.0, out, st);
+    } else {
+        rc = run_transposed(H, false, in, alpha, beta, out, st);
+        if (rc == HMX_OK && H.has_mirror) {
+            // mirror leaves applied un-transposed: input indexed by target positions, output by source positions
+            rc = run_forward(H, H.e_zidx_mirror.d, in, 1, alpha, 1.0, out + (H.T0 - H.S0), st);
+        }
+    }
+    if (rc != HMX_OK)
+        return rc;
+    if (H.profiling) {
+        HMX_HIP(hipStreamSynchronize(st));
+        H.last_ms.clear();
+        H.last_names.clear();
+        for (size_t k = 1; k < H.ev_names.size(); k++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
+            H.last_ms.push_back(ms);
+            H.last_names.push_back(H.ev_names[k]);
+        }
+    }
+    return HMX_OK;
+}
+
+
+static int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
+    if (!bt || !out) {
+        set_error("hmx_hmatrix_create: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    int rc = ensure_device(device_id);
+    if (rc != HMX_OK)
+        return rc;
+    auto *H   = new HMat();
+    H->device = device_id;
+    H->leaves = bt->leaves;
+    H->kind.assign(H->leaves.size(), LK_PENDING);
+    H->T0 = bt->root_t_offset;
+    H->nT = bt->root_t_size;
+    H->S0 = bt->root_s_offset;
+    H->nS = bt->root_s_size;
+    H->nT_total            = bt->target->n;
+    H->nS_total            = bt->source->n;
+    H->symmetry_for_leaves = bt->symmetry_for_leaves;
+    H->uplo_for_leaves     = bt->uplo_for_leaves;
+    H->perm_t              = bt->target->perm;
+    H->perm_s              = bt->source->perm;
+    H->t_root_is_tree_root = (H->T0 == 0 && H->nT == bt->target->n);
+    H->perm_local          = bt->target->permutation_is_local;
+    for (auto &l : H->leaves)
+        H->has_mirror = H->has_mirror || l.mirror;
+    const size_t nb = H->leaves.size();
+    std::vector<int32_t> a(nb), b(nb), c(nb), d(nb);
+    for (size_t i = 0; i < nb; i++) {
+        a[i] = H->leaves[i].t_offset;
+        b[i] = H->leaves[i].t_size;
+        c[i] = H->leaves[i].s_offset;
+        d[i] = H->leaves[i].s_size;
+    }
+    // leaf offsets on the device are GLOBAL cluster positions (they index coordinates); stream ranges are
+    // root-local, the pack kernels add the origin back.
+    if (H->d_t_off.upload(a) != hipSuccess || H->d_t_size.upload(b) != hipSuccess || H->d_s_off.upload(c) != hipSuccess || H->d_s_size.upload(d) != hipSuccess) {
+        set_error("hmx_hmatrix_create: device allocation failed");
+        delete H;
+        return HMX_ERR_HIP;
+    }
+    H->staged_U.resize(nb);
+    H->staged_V.resize(nb);
+    H->staged_D.resize(nb);
+    *out = H;
+    return HMX_OK;
+}
+
+
+static int api_set_kernel(HMat *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc) {
+    if (!H || !params || !tc || !sc || kernel != HMX_KERNEL_INV_DIST || nparams < 2 || (dim != 2 && dim != 3)) {
+        set_error("hmx_hmatrix_set_kernel: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    HMX_HIP(hipSetDevice(H->device));
+    H->ks = KernelSpec{kernel, dim, params[0], params[1]};
+    // coordinates permuted once into cluster order so block rows / columns are contiguous
+    auto soa = [&](const double *xyz, const std::vector<int32_t> &perm, DArr<double> &X, DArr<double> &Y, DArr<double> &Zc) -> hipError_t {
+        const size_t n = perm.size();
+        std::vector<double> x(n), y(n), z(n, 0.0);
+        for (size_t i = 0; i < n; i++) {
+            const double *p = xyz + (size_t)dim * perm[i];
+            x[i]            = p[0];
+            y[i]            = p[1];
+            if (dim == 3)
+                z[i] = p[2];
+        }
+        hipError_t e;
+        if ((e = X.upload(x)) != hipSuccess) return e;
+        if ((e = Y.upload(y)) != hipSuccess) return e;
+        return Zc.upload(z);
+    };
+    HMX_HIP(soa(tc, H->perm_t, H->tx, H->ty, H->tz));
+    HMX_HIP(soa(sc, H->perm_s, H->sx, H->sy, H->sz));
+    H->has_kernel = true;
+    return HMX_OK;
+}
+
+static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
+    if (!Hp) {
+        set_error("hmx_hmatrix_compress: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    if (!H.has_kernel) {
+        set_error("hmx_hmatrix_compress: no generator set (hmx_hmatrix_set_kernel)");
+        return HMX_ERR_STATE;
+    }
+    if (compressor < HMX_PARTIAL_ACA || compressor > HMX_SVD) {
+        set_error("hmx_hmatrix_compress: unknown compressor");
+        return HMX_ERR_INVALID;
+    }
+    const bool assembled = (compressor == HMX_FULL_ACA || compressor == HMX_SVD); // works on the assembled block
+    if (reqrank == 0)
+        reqrank = -1;
+    HMX_HIP(hipSetDevice(H.device));
+    const size_t nb = H.leaves.size();
+    // ---- scratch for the admissible leaves ---------------------------------------------------------
+    std::vector<int32_t> order;
+    H.colptr.assign(nb, 0);
+    std::vector<int32_t> colcap(nb, 0);
+    std::vector<int64_t> visptr(nb, 0);
+    int64_t ncross = 0, nvis = 0;
+    double need = 0;
+    constexpr int RANK_CAP = 4096;
+    for (size_t b = 0; b < nb; b++) {
+        const hmx_leaf &l = H.leaves[b];
+        if (!l.admissible) {
+            H.kind[b] = LK_DENSE_GEN;
+            continue;
+        }
+        order.push_back((int32_t)b);
+        const int64_t M = l.t_size, N = l.s_size;
+        int64_t qmax = (M * N) / (M + N);
+        if (reqrank > 0)
+            qmax = compressor == HMX_SVD ? std::min<int64_t>(reqrank, std::min(M, N)) // SVD.hpp:64-92: no advantage test
+                                         : std::min<int64_t>(qmax, std::min<int64_t>(reqrank, std::min(M, N)));
+        qmax        = std::max<int64_t>(1, std::min<int64_t>(qmax, RANK_CAP));
+        H.colptr[b] = ncross;
+        colcap[b]   = (int32_t)qmax;
+        ncross += qmax;
+        visptr[b] = nvis;
+        nvis += M + N;
+        need += (double)qmax * (double)(M + N);
+    }
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        const int64_t sa = (int64_t)H.leaves[a].t_size + H.leaves[a].s_size, sb = (int64_t)H.leaves[b].t_size + H.leaves[b].s_size;
+        return sa != sb ? sa > sb : a < b;
+    });
+    size_t free_b = 0, total_b = 0;
+    HMX_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double budget        = 0.40 * (double)free_b / sizeof(real);
+    const unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(need, budget));
+    HMX_HIP(H.pool.alloc(cap));
+    DArr<unsigned long long> head;
+    HMX_HIP(head.alloc(1));
+    HMX_HIP(head.zero());
+    DArr<unsigned char> visited;
+    HMX_HIP(visited.alloc(std::max<int64_t>(nvis, 1)));
+    HMX_HIP(visited.zero());
+    DArr<int64_t> d_visptr;
+    DArr<int32_t> d_order, d_colcap;
+    HMX_HIP(d_visptr.upload(visptr));
+    HMX_HIP(d_order.upload(order));
+    HMX_HIP(d_colcap.upload(colcap));
+    HMX_HIP(H.d_colptr.upload(H.colptr));
+    HMX_HIP(H.d_cross_off.alloc(std::max<int64_t>(ncross, 1)));
+    HMX_HIP(H.d_rank.alloc(std::max<size_t>(nb, 1)));
+    HMX_HIP(H.d_rank.zero());
+    HMX_HIP(H.d_swapped.alloc(std::max<size_t>(nb, 1)));
+    HMX_HIP(H.d_swapped.zero());
+    std::vector<int64_t> staged(nb, -1);
+    HMX_HIP(H.d_staged_off.upload(staged));
+
+    hipEvent_t e0, e1;
+    HMX_HIP(hipEventCreate(&e0));
+    HMX_HIP(hipEventCreate(&e1));
+    HMX_HIP(hipEventRecord(e0, 0));
+    if (!order.empty() && assembled) {
+        // fullACA / SVD need the whole block: process the admissible leaves in batches that fit a scratch slab
+        std::vector<int64_t> need_elems(nb, 0);
+        int64_t largest = 0;
+        for (int32_t b : order) {
+            const int64_t M = H.leaves[b].t_size, N = H.leaves[b].s_size, m = std::max(M, N), n = std::min(M, N);
+            if (M * N >= (int64_t(1) << 31)) {
+                set_error("hmx_hmatrix_compress: fullACA/SVD need M*N < 2^31 per block (use a minimal block depth, as the reference must)");
+                return HMX_ERR_UNSUPPORTED;
+            }
+            need_elems[b] = compressor == HMX_FULL_ACA ? M * N : m * n + n * n + 2 * n;
+            largest       = std::max(largest, need_elems[b]);
+        }
+        size_t free2 = 0, total2 = 0;
+        HMX_HIP(hipMemGetInfo(&free2, &total2));
+        const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free2 / sizeof(real)));
+        if ((double)largest * sizeof(real) > 0.9 * (double)free2) {
+            set_error("hmx_hmatrix_compress: an admissible block does not fit in HBM for fullACA/SVD");
+            return HMX_ERR_HIP;
+        }
+        DArr<real> scratch;
+        HMX_HIP(scratch.alloc(slab));
+        std::vector<int64_t> soff(nb, 0);
+        DArr<int64_t> d_soff;
+        size_t pos = 0;
+        while (pos < order.size()) {
+            int64_t used = 0;
+            size_t end   = pos;
+            while (end < order.size() && used + need_elems[order[end]] <= slab) {
+                soff[order[end]] = used;
+                used += need_elems[order[end]];
+                end++;
+            }
+            HMX_HIP(d_soff.upload(soff));
+            DenseCompressArgs D{};
+            D.ks = H.ks;
+            D.tx = H.tx.d; D.ty = H.ty.d; D.tz = H.tz.d;
+            D.sx = H.sx.d; D.sy = H.sy.d; D.sz = H.sz.d;
+            D.order = d_order.d + pos;
+            D.t_off = H.d_t_off.d; D.t_size = H.d_t_size.d; D.s_off = H.d_s_off.d; D.s_size = H.d_s_size.d;
+            D.scratch_off = d_soff.d;
+            D.scratch     = scratch.d;
+            D.epsilon     = epsilon;
+            D.reqrank     = reqrank;
+            D.pool        = H.pool.d;
+            D.pool_head   = head.d;
+            D.pool_cap    = cap;
+            D.colptr      = H.d_colptr.d;
+            D.colcap      = d_colcap.d;
+            D.cross_off   = H.d_cross_off.d;
+            D.rank_out    = H.d_rank.d;
+            if (compressor == HMX_FULL_ACA)
+                hipLaunchKernelGGL(fullaca_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
+            else
+                hipLaunchKernelGGL(svd_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
+            HMX_HIP(hipGetLastError());
+            HMX_HIP(hipDeviceSynchronize());
+            pos = end;
+        }
+    } else if (!order.empty()) {
+        AcaArgs A{};
+        A.ks = H.ks;
+        A.tx = H.tx.d; A.ty = H.ty.d; A.tz = H.tz.d;
+        A.sx = H.sx.d; A.sy = H.sy.d; A.sz = H.sz.d;
+        A.order  = d_order.d;
+        A.t_off  = H.d_t_off.d; A.t_size = H.d_t_size.d; A.s_off = H.d_s_off.d; A.s_size = H.d_s_size.d;
+        A.symmetric_pivoting = compressor == HMX_SYMPARTIAL_ACA;
+        A.epsilon   = epsilon;
+        A.reqrank   = reqrank;
+        A.pool      = H.pool.d;
+        A.pool_head = head.d;
+        A.pool_cap  = cap;
+        A.colptr    = H.d_colptr.d;
+        A.colcap    = d_colcap.d;
+        A.cross_off = H.d_cross_off.d;
+        A.visited   = visited.d;
+        A.vis_ptr   = d_visptr.d;
+        A.rank_out  = H.d_rank.d;
+        A.swapped_out = H.d_swapped.d;
+        hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)order.size()), dim3(256), 0, 0, A);
+        HMX_HIP(hipGetLastError());
+    }
+    HMX_HIP(hipEventRecord(e1, 0));
+    HMX_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::vector<int32_t> ranks(nb, 0);
+    H.swapped.assign(nb, 0);
+    if (nb) {
+        HMX_HIP(hipMemcpy(ranks.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
+        HMX_HIP(hipMemcpy(H.swapped.data(), H.d_swapped.d, nb * 4, hipMemcpyDeviceToHost));
+    }
+    HMX_HIP(hipMemcpy(&H.pool_used, head.d, 8, hipMemcpyDeviceToHost));
+    int64_t false_pos = 0;
+    for (int32_t b : order) {
+        if (ranks[b] == -2) {
+            set_error("hmx_hmatrix_compress: compression pool exhausted (not enough free HBM)");
+            return HMX_ERR_HIP;
+        }
+        if (ranks[b] > 0) {
+            H.kind[b]        = LK_LOWRANK;
+            H.leaves[b].rank = ranks[b];
+        } else { // compressor failed -> dense block (tree_builder.hpp:572-577)
+            H.kind[b]        = LK_DENSE_GEN;
+            H.leaves[b].rank = -1;
+            false_pos++;
+        }
+    }
+    for (size_t b = 0; b < nb; b++)
+        if (H.kind[b] != LK_LOWRANK)
+            H.leaves[b].rank = -1;
+    int rc = build_streams(H);
+    if (rc != HMX_OK)
+        return rc;
+    H.stats.n_false_positive = false_pos;
+    H.stats.t_compress_s     = ms * 1e-3;
+    return HMX_OK;
+}
+
+static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const real *U, const real *V) {
+    if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || rank < 0 || (rank > 0 && (!U || !V))) {
+        set_error("hmx_hmatrix_set_block_lowrank: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    const hmx_leaf &l = H->leaves[leaf];
+    H->staged_U[leaf].assign(U, U + (size_t)l.t_size * rank);
+    // V arrives r x N column-major; keep it k-major (row k contiguous) like a cross
+    H->staged_V[leaf].resize((size_t)l.s_size * rank);
+    for (int k = 0; k < rank; k++)
+        for (int j = 0; j < l.s_size; j++)
+            H->staged_V[leaf][(size_t)k * l.s_size + j] = V[k + (size_t)rank * j];
+    H->staged_D[leaf].clear();
+    H->kind[leaf]        = LK_LOWRANK;
+    H->leaves[leaf].rank = rank;
+    H->finalized         = false;
+    return HMX_OK;
+}
+static int api_set_block_dense(HMat *H, int64_t leaf, const real *D) {
+    if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || !D) {
+        set_error("hmx_hmatrix_set_block_dense: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    const hmx_leaf &l = H->leaves[leaf];
+    H->staged_D[leaf].assign(D, D + (size_t)l.t_size * l.s_size);
+    H->staged_U[leaf].clear();
+    H->staged_V[leaf].clear();
+    H->kind[leaf]        = LK_DENSE_STAGED;
+    H->leaves[leaf].rank = -1;
+    H->finalized         = false;
+    return HMX_OK;
+}
+static int api_finalize(HMat *Hp) {
+    if (!Hp)
+        return HMX_ERR_INVALID;
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    const size_t nb = H.leaves.size();
+    // every leaf needs a payload
+    int64_t total = 0, ncross = 0;
+    for (size_t b = 0; b < nb; b++) {
+        if (H.kind[b] == LK_PENDING || H.kind[b] == LK_DENSE_GEN) {
+            if (H.has_kernel && !H.leaves[b].admissible) { // dense leaves may be left to the device generator
+                H.kind[b] = LK_DENSE_GEN;
+            } else {
+                set_error("hmx_hmatrix_finalize: leaf " + std::to_string(b) + " has no uploaded payload");
+                return HMX_ERR_STATE;
+            }
+        }
+        total += (int64_t)H.staged_U[b].size() + H.staged_V[b].size() + H.staged_D[b].size();
+        if (H.kind[b] == LK_LOWRANK)
+            ncross += H.leaves[b].rank;
+    }
+    std::vector<real> host(std::max<int64_t>(total, 1));
+    std::vector<int64_t> cross(std::max<int64_t>(ncross, 1)), staged(nb, -1);
+    H.colptr.assign(nb, 0);
+    H.swapped.assign(nb, 0);
+    int64_t pos = 0, cpos = 0;
+    for (size_t b = 0; b < nb; b++) {
+        const hmx_leaf &l = H.leaves[b];
+        if (H.kind[b] == LK_LOWRANK) {
+            H.colptr[b] = cpos;
+            for (int k = 0; k < l.rank; k++) { // cross k = [U(:,k) | V(k,:)]
+                cross[cpos++] = pos;
+                std::copy_n(H.staged_U[b].data() + (size_t)k * l.t_size, l.t_size, host.data() + pos);
+                pos += l.t_size;
+                std::copy_n(H.staged_V[b].data() + (size_t)k * l.s_size, l.s_size, host.data() + pos);
+                pos += l.s_size;
+            }
+        } else if (H.kind[b] == LK_DENSE_STAGED) {
+            staged[b] = pos;
+            std::copy(H.staged_D[b].begin(), H.staged_D[b].end(), host.begin() + pos);
+            pos += (int64_t)H.staged_D[b].size();
+        }
+    }
+    HMX_HIP(H.pool.upload(host));
+    H.pool_used = (unsigned long long)pos;
+    HMX_HIP(H.d_cross_off.upload(cross));
+    HMX_HIP(H.d_colptr.upload(H.colptr));
+    HMX_HIP(H.d_swapped.upload(H.swapped));
+    HMX_HIP(H.d_staged_off.upload(staged));
+    if (!H.has_kernel) { // pack_dense never evaluates the generator on this path, but needs valid pointers
+        H.ks = KernelSpec{0, 3, 0, 0};
+    }
+    return build_streams(H);
+}
+
+static int api_leaf_ranks(const HMat *H, int32_t *rank) {
+    if (!H || !rank)
+        return HMX_ERR_INVALID;
+    for (size_t b = 0; b < H->leaves.size(); b++)
+        rank[b] = H->leaves[b].rank;
+    return HMX_OK;
+}
+
+static int api_get_block(const HMat *Hc, int64_t leaf, real *U_or_D, real *V) {
+    HMat *H = const_cast<HMat *>(Hc);
+    if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || !U_or_D) {
+        set_error("hmx_hmatrix_get_block: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    if (!H->finalized) {
+        set_error("hmx_hmatrix_get_block: operator not built");
+        return HMX_ERR_STATE;
+    }
+    HMX_HIP(hipSetDevice(H->device));
+    const hmx_leaf &l = H->leaves[leaf];
+    const int M = l.t_size, N = l.s_size;
+    if (H->kind[leaf] == LK_LOWRANK) {
+        if (!V)
+            return HMX_ERR_INVALID;
+        const int r  = l.rank;
+        const bool sw = H->swapped[leaf] != 0;
+        const int n1 = sw ? N : M, n2 = sw ? M : N;
+        std::vector<int64_t> cross(std::max(r, 1));
+        HMX_HIP(hipMemcpy(cross.data(), H->d_cross_off.d + H->colptr[leaf], (size_t)r * 8, hipMemcpyDeviceToHost));
+        std::vector<real> buf((size_t)n1 + n2);
+        for (int k = 0; k < r; k++) {
+            HMX_HIP(hipMemcpy(buf.data(), H->pool.d + cross[k], buf.size() * sizeof(real), hipMemcpyDeviceToHost));
+            const real *ucol = sw ? buf.data() + n1 : buf.data();
+            const real *vrow = sw ? buf.data() : buf.data() + n1;
+            std::copy_n(ucol, M, U_or_D + (size_t)k * M);
+            for (int j = 0; j < N; j++)
+                V[k + (size_t)r * j] = vrow[j];
+        }
+        return HMX_OK;
+    }
+    // dense: gather the slices back out of the E-streams
+    const StreamSet &E = H->E;
+    int r0 = (int)(std::lower_bound(E.off.begin(), E.off.end(), l.t_offset - H->T0) - E.off.begin());
+    for (int r = r0; r < E.nranges() && E.off[r] < l.t_offset - H->T0 + M; r++) {
+        // find this block's first column in range r: scan the z index of the range for its x position
+        const int64_t cb = E.colbase[r];
+        int col          = -1;
+        for (int c = 0; c < E.cols[r]; c++)
+            if (H->h_e_zidx[cb + c] == l.s_offset - H->S0 && H->h_e_tdst_all[cb + c] == l.s_offset) {
+                col = c;
+                break;
+            }
+        if (col < 0) {
+            set_error("hmx_hmatrix_get_block: internal lookup failed");
+            return HMX_ERR_STATE;
+        }
+        const int len = E.len[r], rel = E.off[r] - (l.t_offset - H->T0);
+        std::vector<real> buf((size_t)len * N);
+        HMX_HIP(hipMemcpy(buf.data(), E.stream.d + E.base[r] + (int64_t)col * len, buf.size() * sizeof(real), hipMemcpyDeviceToHost));
+        for (int j = 0; j < N; j++)
+            for (int i = 0; i < len; i++)
+                U_or_D[(size_t)(rel + i) + (size_t)M * j] = buf[(size_t)j * len + i];
+    }
+    return HMX_OK;
+}
+
+static int api_stats(const HMat *H, hmx_stats *out) {
+    if (!H || !out)
+        return HMX_ERR_INVALID;
+    *out = H->stats;
+    return HMX_OK;
+}
+
+static int with_buffers(HMat &H, char trans, const real *in, real *out, int mu, int mem, hipStream_t st, real beta,
+                        const real **din, real **dout, bool &staged) {
+    const size_t nin = (size_t)(trans == 'N' ? H.nS : H.nT) * mu, nout = (size_t)(trans == 'N' ? H.nT : H.nS) * mu;
+    staged = (mem == HMX_MEM_HOST);
+    if (!staged) {
+        *din  = in;
+        *dout = out;
+        return HMX_OK;
+    }
+    if (H.tmp_in.n < nin)
+        HMX_HIP(H.tmp_in.alloc(nin));
+    if (H.tmp_out.n < nout)
+        HMX_HIP(H.tmp_out.alloc(nout));
+    HMX_HIP(hipMemcpyAsync(H.tmp_in.d, in, nin * sizeof(real), hipMemcpyHostToDevice, st));
+    if (beta != 0.0)
+        HMX_HIP(hipMemcpyAsync(H.tmp_out.d, out, nout * sizeof(real), hipMemcpyHostToDevice, st));
+    *din  = H.tmp_in.d;
+    *dout = H.tmp_out.d;
+    return HMX_OK;
+}
+
+static int api_matvec(HMat *Hp, char trans, real alpha, const real *in, real beta, real *out, int mem, void *stream) {
+    if (!Hp || !in || !out) {
+        set_error("hmx_hmatrix_matvec: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    hipStream_t st = (hipStream_t)stream;
+    const real *din;
+    real *dout;
+    bool staged;
+    int rc = with_buffers(H, trans, in, out, 1, mem, st, beta, &din, &dout, staged);
+    if (rc != HMX_OK)
+        return rc;
+    rc = matvec_device(H, trans, alpha, din, beta, dout, st);
+    if (rc != HMX_OK)
+        return rc;
+    if (staged) {
+        const size_t nout = (size_t)(trans == 'N' ? H.nT : H.nS);
+        HMX_HIP(hipMemcpyAsync(out, dout, nout * sizeof(real), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipStreamSynchronize(st));
+    }
+    return HMX_OK;
+}
+
+static int api_matvec_user(HMat *Hp, char trans, real alpha, const real *in, real beta, real *out, int mem, void *stream) {
+    if (!Hp || !in || !out) {
+        set_error("hmx_hmatrix_matvec_user: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    // cluster_to_user / user_to_cluster are only stable for a root cluster or a local permutation
+    // (clustering/cluster_node.hpp:152-157)
+    if (!(H.t_root_is_tree_root || H.perm_local) || !(H.S0 == 0 && H.nS == H.nS_total)) {
+        set_error("hmx_hmatrix_matvec_user: cluster is neither root nor local, permutation is not stable");
+        return HMX_ERR_INVALID;
+    }
+    HMX_HIP(hipSetDevice(H.device));
+    hipStream_t st = (hipStream_t)stream;
+    const real *din;
+    real *dout;
+    bool staged;
+    int rc = with_buffers(H, trans, in, out, 1, mem, st, beta, &din, &dout, staged);
+    if (rc != HMX_OK)
+        return rc;
+    if (!H.d_perm_t.d) {
+        HMX_HIP(H.d_perm_t.upload(H.perm_t));
+        HMX_HIP(H.d_perm_s.upload(H.perm_s));
+    }
+    const int nin = trans == 'N' ? H.nS : H.nT, nout = trans == 'N' ? H.nT : H.nS;
+    const int32_t *pin = trans == 'N' ? H.d_perm_s.d + H.S0 : H.d_perm_t.d + H.T0, *pout = trans == 'N' ? H.d_perm_t.d + H.T0 : H.d_perm_s.d + H.S0;
+    const int bin = trans == 'N' ? H.S0 : H.T0, bout = trans == 'N' ? H.T0 : H.S0;
+    if (H.tmp_in2.n < (size_t)nin)
+        HMX_HIP(H.tmp_in2.alloc(nin));
+    if (H.tmp_out2.n < (size_t)nout)
+        HMX_HIP(H.tmp_out2.alloc(nout));
+    hipLaunchKernelGGL(gather_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, pin, bin, din, H.tmp_in2.d, 1);
+    if (beta != 0.0)
+        hipLaunchKernelGGL(gather_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const real *)dout, H.tmp_out2.d, 1);
+    rc = matvec_device(H, trans, alpha, H.tmp_in2.d, beta, H.tmp_out2.d, st);
+    if (rc != HMX_OK)
+        return rc;
+    hipLaunchKernelGGL(scatter_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const real *)H.tmp_out2.d, dout, 1);
+    HMX_HIP(hipGetLastError());
+    if (staged) {
+        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * sizeof(real), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipStreamSynchronize(st));
+    }
+    return HMX_OK;
+}
+
+static int api_matmat_row_major(HMat *Hp, char trans, real alpha, const real *in, real beta, real *out, int mu, int mem, void *stream) {
+    if (!Hp || !in || !out || mu < 1) {
+        set_error("hmx_hmatrix_matmat_row_major: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    hipStream_t st = (hipStream_t)stream;
+    const real *din;
+    real *dout;
+    bool staged;
+    int rc = with_buffers(H, trans, in, out, mu, mem, st, beta, &din, &dout, staged);
+    if (rc != HMX_OK)
+        return rc;
+    const int nin = trans == 'N' ? H.nS : H.nT, nout = trans == 'N' ? H.nT : H.nS;
+    if (H.tmp_in2.n < (size_t)nin)
+        HMX_HIP(H.tmp_in2.alloc(nin));
+    if (H.tmp_out2.n < (size_t)nout)
+        HMX_HIP(H.tmp_out2.alloc(nout));
+    if (trans == 'N' && !H.has_mirror && H.finalized && !getenv("HMX_NO_FUSED_MU")) {
+        // fused path: the streams are read once for up to 16 right-hand sides
+        H.ev_names.clear();
+        prof_mark(H, st, "begin");
+        rc = run_forward_mu(H, din, alpha, beta, dout, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        if (H.profiling) {
+            HMX_HIP(hipStreamSynchronize(st));
+            H.last_ms.clear();
+            H.last_names.clear();
+            for (size_t k = 1; k < H.ev_names.size(); k++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
+                H.last_ms.push_back(ms);
+                H.last_names.push_back(H.ev_names[k]);
+            }
+        }
+        if (staged) {
+            HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(real), hipMemcpyDeviceToHost, st));
+            HMX_HIP(hipStreamSynchronize(st));
+        }
+        return HMX_OK;
+    }
+    // transposed products and symmetric storage: one streaming pass per right-hand side (not fused yet)
+    for (int c = 0; c < mu; c++) {
+        hipLaunchKernelGGL(col_extract_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, mu, c, din, H.tmp_in2.d);
+        if (beta != 0.0)
+            hipLaunchKernelGGL(col_extract_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, mu, c, (const real *)dout, H.tmp_out2.d);
+        rc = matvec_device(H, trans, alpha, H.tmp_in2.d, beta, H.tmp_out2.d, st);
+        if (rc != HMX_OK)
+            return rc;
+        hipLaunchKernelGGL(col_insert_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, mu, c, (const real *)H.tmp_out2.d, dout);
+    }
+    HMX_HIP(hipGetLastError());
+    if (staged) {
+        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(real), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipStreamSynchronize(st));
+    }
+    return HMX_OK;
+}
+
+static int api_set_profiling(HMat *H, int enabled) {
+    if (!H)
+        return HMX_ERR_INVALID;
+    H->profiling = enabled != 0;
+    return HMX_OK;
+}
+static int api_last_kernel_times(const HMat *H, int max, const char **names, float *ms) {
+    if (!H)
+        return 0;
+    int n = std::min<int>(max, (int)H->last_ms.size());
+    for (int k = 0; k < n; k++) {
+        names[k] = H->last_names[k];
+        ms[k]    = H->last_ms[k];
+    }
+    return n;
+}
+
+

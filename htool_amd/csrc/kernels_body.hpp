@@ -1,82 +1,16 @@
-// kernels.hpp -- hand-written HIP kernels for gfx950 (CDNA4, wave64).  Compiled with -ffp-contract=off:
-// every FMA in this file is an explicit __builtin_fma, so the compression kernels evaluate exactly the
-// IEEE sequence the reference's scalar code spells out (SURVEY.md "Hard parts": ACA parity) while the
-// matvec kernels still issue v_fma_f64.
-//
-// Data layout in HBM: the compressed operator is NOT kept as htool's per-block
-// U (M x r) / V (r x N) / dense (M x N) matrices.  It is re-laid out as two sets of streams:
-//   E-stream  (expand): for every target row range R (<= 64 rows, aligned to cluster boundaries) one
-//             column-major len_R x C_R matrix holding, side by side, the slice of every block that
-//             touches R: n_b columns for a dense block, r_b columns (its U slice) for a low-rank block.
-//             y_R = E_R * z_R, z_R gathered from Z = [x | a].  lane = row, no cross-lane reduction.
-//   R-stream  (reduce): for every source range S one row-major len_S x C_S matrix (128-column chunks)
-//             holding the V slices of every low-rank block that touches S.  a_partial = x_S^T * R_S,
-//             lane = column pair, no cross-lane reduction.
-// Every stored coefficient is read exactly once per matvec, by fully coalesced wave loads.
-#pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+// kernels_body.hpp -- the kernels, written against `real` / `real2` (coefficient type) and included twice by
+// engine.hip: once in namespace hmx::f64 (real = double) and once in hmx::f32 (real = float; htool's
+// HMatrix<float,double>: fp32 coefficients, fp64 coordinates).  No include guard on purpose.
+// Layout and design notes: kernels_common.hpp.  Compiled with -ffp-contract=off, FMAs are explicit (hmx_fma).
 
-namespace hmx {
-
-constexpr int WAVE = 64;
-
-struct KernelSpec { // device-evaluable generator
-    int kind;
-    int dim;
-    double p0, p1;
-};
-
-// K(x,y) = 1/(p0 + p1*|x-y|); squared differences accumulated left to right from 0, one sqrt, one
-// multiply, one add, one divide -- the order of examples/use_hmatrix.cpp:33 / testing/generator_test.hpp:159.
-__device__ __forceinline__ double eval_kernel(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
-    double s        = 0.0;
-    const double d0 = tx - sx;
-    s               = s + d0 * d0;
-    const double d1 = ty - sy;
-    s               = s + d1 * d1;
-    if (ks.dim == 3) {
-        const double d2 = tz - sz;
-        s               = s + d2 * d2;
-    }
-    return 1.0 / (ks.p0 + ks.p1 * sqrt(s));
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ real wave_sum(real v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         v += __shfl_xor(v, o, WAVE);
     return v;
 }
 
-// Every coefficient is read exactly once per product, so the stream loads are marked non-temporal: they do
-// not displace x / Z / index lines from L2 and the Infinity Cache.  Measured at N=1e6: expand 1.88 -> 1.74 ms,
-// reduce 1.23-1.33 -> 1.20 ms, and the run-to-run bimodality disappears.  -DHMX_NT=0 disables.
-#ifndef HMX_NT
-#define HMX_NT 1
-#endif
-typedef double hmx_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double stream_load(const double *p) {
-#if HMX_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ double2 stream_load(const double2 *p) {
-#if HMX_NT
-    const hmx_d2 v = __builtin_nontemporal_load(reinterpret_cast<const hmx_d2 *>(p));
-    return make_double2(v.x, v.y);
-#else
-    return *p;
-#endif
-}
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Compression: partially pivoted ACA, one workgroup per admissible block.
@@ -90,7 +24,7 @@ struct AcaArgs {
     int symmetric_pivoting;     // sympartialACA: pivot on the larger-offset cluster first
     double epsilon;
     int reqrank;
-    double *pool;               // cross storage, bump allocated
+    real *pool;               // cross storage, bump allocated
     unsigned long long *pool_head;
     unsigned long long pool_cap;
     const int64_t *colptr;      // per block: first slot in cross_off
@@ -103,11 +37,11 @@ struct AcaArgs {
 };
 
 template <int NT>
-__device__ __forceinline__ void block_argmax(double &val, int &idx, double *sval, int *sidx) {
+__device__ __forceinline__ void block_argmax(real &val, int &idx, real *sval, int *sidx) {
     // maximum of |.|, ties -> larger index (the reference scans upward and replaces on ">=")
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(val, o, WAVE);
+        const real ov = __shfl_xor(val, o, WAVE);
         const int oi    = __shfl_xor(idx, o, WAVE);
         if (ov > val || (ov == val && oi > idx)) {
             val = ov;
@@ -132,7 +66,7 @@ __device__ __forceinline__ void block_argmax(double &val, int &idx, double *sval
 }
 
 template <int NT, int G>
-__device__ __forceinline__ void block_sum_group(double (&acc)[G], double *sbuf) {
+__device__ __forceinline__ void block_sum_group(real (&acc)[G], real *sbuf) {
 #pragma unroll
     for (int g = 0; g < G; g++)
         acc[g] = wave_sum(acc[g]);
@@ -144,7 +78,7 @@ __device__ __forceinline__ void block_sum_group(double (&acc)[G], double *sbuf) 
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        double s = sbuf[g];
+        real s = sbuf[g];
 #pragma unroll
         for (int k = 1; k < NT / WAVE; k++)
             s += sbuf[k * G + g];
@@ -158,9 +92,9 @@ __device__ __forceinline__ void block_sum_group(double (&acc)[G], double *sbuf) 
 // row side unless symmetric pivoting asks for the larger-offset side.
 template <int NT>
 __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
-    __shared__ double sval[NT / WAVE];
+    __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
-    __shared__ double sbuf[(NT / WAVE) * 8];
+    __shared__ real sbuf[(NT / WAVE) * 8];
     __shared__ unsigned long long s_off;
 
     const int b      = A.order[blockIdx.x];
@@ -178,10 +112,10 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
     const int tid       = threadIdx.x;
 
     int I1 = 0, I2 = 0, q = 0;
-    double frob = 0, aux = 0;
+    real frob = 0, aux = 0;
     const int reqrank = A.reqrank;
     const int minmn   = n1 < n2 ? n1 : n2;
-    while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (q == 0 || sqrt(aux / frob) > A.epsilon))) {
+    while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (q == 0 || sqrt(aux / frob) > (real)A.epsilon))) {
         q += 1;
         if ((long long)q * ((long long)n1 + n2) > (long long)n1 * n2 || q > cap) { // not advantageous any more
             q = -1;
@@ -195,22 +129,22 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
             q = -2;
             break;
         }
-        double *u2 = A.pool + off;      // new uu (length n1)
-        double *u1 = A.pool + off + n1; // new vv (length n2)
+        real *u2 = A.pool + off;      // new uu (length n1)
+        real *u1 = A.pool + off + n1; // new vv (length n2)
         // ---- cross row: entries (I1, k), k over index 2 ------------------------------------------
         const double ax = p1x[I1], ay = p1y[I1], az = p1z[I1];
-        double best = -1.0;
+        real best = -1.0;
         int besti   = -1;
         for (int k = tid; k < n2; k += NT) {
-            double v = swap ? eval_kernel(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_kernel(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]);
+            real v = swap ? eval_kernel(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_kernel(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]);
             for (int j = 0; j < q - 1; j++) {
-                const double *cj  = A.pool + cross[j];
-                const double coef = -cj[I1];
+                const real *cj  = A.pool + cross[j];
+                const real coef = -cj[I1];
                 v                 = coef * cj[n1 + k] + v;
             }
             u1[k] = v;
             if (!vis2[k]) {
-                const double a = fabs(v);
+                const real a = fabs(v);
                 if (a >= best) { // k increases per thread: ">=" keeps the last maximum
                     best  = a;
                     besti = k;
@@ -222,24 +156,24 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
             I2 = besti;
         if (tid == 0)
             vis1[I1] = 1;
-        const double piv   = u1[I2];
-        const double gamma = 1.0 / piv;
+        const real piv   = u1[I2];
+        const real gamma = real(1) / piv;
         if (fabs(piv) > 1e-15) {
             // ---- cross column: entries (k, I2), k over index 1 -----------------------------------
             const double bx = p2x[I2], by = p2y[I2], bz = p2z[I2];
             best  = -1.0;
             besti = -1;
             for (int k = tid; k < n1; k += NT) {
-                double v = swap ? eval_kernel(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_kernel(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz);
+                real v = swap ? eval_kernel(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_kernel(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz);
                 for (int j = 0; j < q - 1; j++) {
-                    const double *cj  = A.pool + cross[j];
-                    const double coef = -cj[n1 + I2];
+                    const real *cj  = A.pool + cross[j];
+                    const real coef = -cj[n1 + I2];
                     v                 = coef * cj[k] + v;
                 }
                 v     = v * gamma;
                 u2[k] = v;
                 if (!vis1[k] && k != I1) {
-                    const double a = fabs(v);
+                    const real a = fabs(v);
                     if (a >= best) {
                         best  = a;
                         besti = k;
@@ -254,20 +188,20 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
             }
             if (reqrank < 0) {
                 // error estimator (partialACA.hpp:136-148): |c.c||r.r| + 2 sum_j (vv_j.r)(uu_j.c)
-                double acc2[2] = {0, 0};
+                real acc2[2] = {0, 0};
                 for (int k = tid; k < n1; k += NT)
                     acc2[0] += u2[k] * u2[k];
                 for (int k = tid; k < n2; k += NT)
                     acc2[1] += u1[k] * u1[k];
                 block_sum_group<NT, 2>(acc2, sbuf);
                 aux             = fabs(acc2[0]) * fabs(acc2[1]);
-                double frob_aux = 0;
+                real frob_aux = 0;
                 for (int j0 = 0; j0 < q - 1; j0 += 4) {
-                    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    real acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                     const int nj  = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
                     for (int g = 0; g < nj; g++) {
-                        const double *cj = A.pool + cross[j0 + g];
-                        double a1 = 0, a2 = 0;
+                        const real *cj = A.pool + cross[j0 + g];
+                        real a1 = 0, a2 = 0;
                         for (int k = tid; k < n2; k += NT)
                             a1 += cj[n1 + k] * u1[k];
                         for (int k = tid; k < n1; k += NT)
@@ -306,11 +240,11 @@ struct DenseCompressArgs {
     const double *tx, *ty, *tz, *sx, *sy, *sz;
     const int32_t *order; // launch order -> block id
     const int32_t *t_off, *t_size, *s_off, *s_size;
-    const int64_t *scratch_off; // per block: first double of its slab in `scratch`
-    double *scratch;
+    const int64_t *scratch_off; // per block: first real of its slab in `scratch`
+    real *scratch;
     double epsilon;
     int reqrank;
-    double *pool;
+    real *pool;
     unsigned long long *pool_head;
     unsigned long long pool_cap;
     const int64_t *colptr;
@@ -322,41 +256,41 @@ struct DenseCompressArgs {
 // fullACA::copy_low_rank_approximation (hmatrix/lrmat/fullACA.hpp:38-88)
 template <int NT>
 __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
-    __shared__ double sval[NT / WAVE];
+    __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
-    __shared__ double sbuf[(NT / WAVE) * 2];
+    __shared__ real sbuf[(NT / WAVE) * 2];
     __shared__ unsigned long long s_off;
     const int b = A.order[blockIdx.x];
     const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
     const int64_t MN = (int64_t)M * N;
-    double *mat      = A.scratch + A.scratch_off[b];
+    real *mat      = A.scratch + A.scratch_off[b];
     int64_t *cross   = A.cross_off + A.colptr[b];
     const int cap    = A.colcap[b];
     const int tid    = threadIdx.x;
-    double acc1[1]   = {0};
+    real acc1[1]   = {0};
     for (int64_t e = tid; e < MN; e += NT) {
         const int i = (int)(e % M), j = (int)(e / M);
-        const double v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        const real v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
         mat[e]         = v;
         acc1[0] += v * v;
     }
     block_sum_group<NT, 1>(acc1, sbuf);
-    const double Norm = sqrt(acc1[0]);
-    double cur        = Norm; // Frobenius norm of the current residual
+    const real Norm = sqrt(acc1[0]);
+    real cur        = Norm; // Frobenius norm of the current residual
     int q             = 0;
     const int reqrank = A.reqrank;
     const int minmn   = M < N ? M : N;
-    while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (cur / Norm > A.epsilon || q == 0))) {
+    while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (cur / Norm > (real)A.epsilon || q == 0))) {
         q += 1;
         if ((long long)q * ((long long)M + N) > MN || q > cap) {
             q = -1;
             break;
         }
         // std::max_element over the column-major array: first maximum of |.| (matrix/utils/math.hpp:18-23)
-        double best = -1.0;
+        real best = -1.0;
         int64_t bi  = -1;
         for (int64_t e = tid; e < MN; e += NT) {
-            const double a = fabs(mat[e]);
+            const real a = fabs(mat[e]);
             if (a > best) {
                 best = a;
                 bi   = e;
@@ -367,7 +301,7 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
         block_argmax<NT>(best, neg, sval, sidx);
         const int64_t pe = -(int64_t)neg;
         const int pi = (int)(pe % M), pj = (int)(pe / M);
-        const double pivot = mat[pe];
+        const real pivot = mat[pe];
         if (fabs(pivot) < 1e-15) {
             q += -1;
             break;
@@ -380,7 +314,7 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
             q = -2;
             break;
         }
-        double *u = A.pool + off, *v = A.pool + off + M;
+        real *u = A.pool + off, *v = A.pool + off + M;
         for (int i = tid; i < M; i += NT)
             u[i] = mat[i + (int64_t)M * pj];
         for (int j = tid; j < N; j += NT)
@@ -389,7 +323,7 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
         acc1[0] = 0;
         for (int64_t e = tid; e < MN; e += NT) {
             const int i = (int)(e % M), j = (int)(e / M);
-            const double r = mat[e] - u[i] * v[j];
+            const real r = mat[e] - u[i] * v[j];
             mat[e]         = r;
             acc1[0] += r * r;
         }
@@ -415,17 +349,17 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
     const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
     const bool tr = M < N;
     const int m = tr ? N : M, n = tr ? M : N;
-    double *W   = A.scratch + A.scratch_off[b];
-    double *Vm  = W + (int64_t)m * n;
-    double *sv  = Vm + (int64_t)n * n;
-    double *ord = sv + n;
+    real *W   = A.scratch + A.scratch_off[b];
+    real *Vm  = W + (int64_t)m * n;
+    real *sv  = Vm + (int64_t)n * n;
+    real *ord = sv + n;
     int64_t *cross = A.cross_off + A.colptr[b];
     const int cap  = A.colcap[b];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = NT / WAVE;
     for (int64_t e = tid; e < (int64_t)M * N; e += NT) {
         const int i = (int)(e % M), j = (int)(e / M);
-        const double v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        const real v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
         if (tr)
             W[j + (int64_t)m * i] = v;
         else
@@ -452,10 +386,10 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
                 }
                 if (qq >= n || p == qq)
                     continue;
-                double *wp = W + (int64_t)m * p, *wq = W + (int64_t)m * qq;
-                double app = 0, aqq = 0, apq = 0;
+                real *wp = W + (int64_t)m * p, *wq = W + (int64_t)m * qq;
+                real app = 0, aqq = 0, apq = 0;
                 for (int i = lane; i < m; i += WAVE) {
-                    const double a = wp[i], c = wq[i];
+                    const real a = wp[i], c = wq[i];
                     app += a * a;
                     aqq += c * c;
                     apq += a * c;
@@ -467,17 +401,17 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
                     continue;
                 if (fabs(apq) / sqrt(app * aqq) >= 1e-15 && lane == 0)
                     s_changed = 1;
-                const double zeta = (aqq - app) / (2.0 * apq);
-                const double t    = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                const real zeta = (aqq - app) / (2.0 * apq);
+                const real t    = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const real cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
                 for (int i = lane; i < m; i += WAVE) {
-                    const double a = wp[i], c = wq[i];
+                    const real a = wp[i], c = wq[i];
                     wp[i]          = cs * a - sn * c;
                     wq[i]          = sn * a + cs * c;
                 }
-                double *vp = Vm + (int64_t)n * p, *vq = Vm + (int64_t)n * qq;
+                real *vp = Vm + (int64_t)n * p, *vq = Vm + (int64_t)n * qq;
                 for (int i = lane; i < n; i += WAVE) {
-                    const double a = vp[i], c = vq[i];
+                    const real a = vp[i], c = vq[i];
                     vp[i]          = cs * a - sn * c;
                     vq[i]          = sn * a + cs * c;
                 }
@@ -491,7 +425,7 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
     }
     // singular values = column norms, descending order by counting
     for (int j = wv; j < n; j += NW) {
-        double nn = 0;
+        real nn = 0;
         for (int i = lane; i < m; i += WAVE)
             nn += W[i + (int64_t)m * j] * W[i + (int64_t)m * j];
         nn = wave_sum(nn);
@@ -503,7 +437,7 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
         int pos = 0;
         for (int k = 0; k < n; k++)
             pos += (sv[k] > sv[j] || (sv[k] == sv[j] && k < j)) ? 1 : 0;
-        ord[pos] = (double)j;
+        ord[pos] = (real)j;
     }
     __syncthreads();
     if (tid == 0) {
@@ -511,15 +445,15 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
         if (A.reqrank > 0) {
             r = A.reqrank < n ? A.reqrank : n;
         } else { // SVD_truncation.hpp:37-52: smallest k whose discarded tail stays below epsilon
-            double norm2 = 0, err = 0;
+            real norm2 = 0, err = 0;
             for (int k = 0; k < n; k++)
                 norm2 += sv[(int)ord[k]] * sv[(int)ord[k]];
-            const double nrm = sqrt(norm2);
+            const real nrm = sqrt(norm2);
             int j = n;
             do {
                 j = j - 1;
                 err += sv[(int)ord[j]] * sv[(int)ord[j]];
-            } while (j > 0 && sqrt(err) / nrm < A.epsilon);
+            } while (j > 0 && sqrt(err) / nrm < (real)A.epsilon);
             r = j + 1;
             if ((long long)r * ((long long)M + N) > (long long)M * N || r <= 0)
                 r = 0;
@@ -541,8 +475,8 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
         }
         for (int k = 0; k < r; k++) {
             const int j     = (int)ord[k];
-            const double sj = sv[j], isj = sj > 0 ? 1.0 / sj : 0.0;
-            double *u = A.pool + off + (unsigned long long)k * (M + N), *v = u + M;
+            const real sj = sv[j], isj = sj > 0 ? 1.0 / sj : 0.0;
+            real *u = A.pool + off + (unsigned long long)k * (M + N), *v = u + M;
             if (!tr) { // A = (W) Vm^T: U(:,k) = u_k s_k = W(:,j), V(k,:) = Vm(:,j)
                 for (int i = tid; i < M; i += NT)
                     u[i] = W[i + (int64_t)m * j];
@@ -566,7 +500,7 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
 // Pack: move compressed data into the matvec streams
 // ---------------------------------------------------------------------------------------------
 struct PackLrArgs {
-    const double *pool;
+    const real *pool;
     const int64_t *cross_off; // per (block,k)
     const int64_t *colptr;
     const int32_t *rank;
@@ -578,7 +512,7 @@ struct PackLrArgs {
     const int64_t *range_base;
     const int32_t *range_cols; // C of the range (R-stream only)
     const int32_t *range_cw;   // chunk width of the range (R-stream only)
-    double *stream;
+    real *stream;
     int origin;                // global cluster position of local offset 0 (T0 for E-streams, S0 for R-streams)
 };
 
@@ -592,11 +526,11 @@ __global__ void pack_lr_expand_kernel(PackLrArgs P, int64_t npairs) {
     const int n1  = P.swapped[b] ? P.s_size[b] : P.t_size[b]; // length of uu in a cross
     const int rel = P.range_off[R] + P.origin - P.t_off[b];
     const int64_t *cross = P.cross_off + P.colptr[b];
-    double *dst          = P.stream + P.range_base[R] + (int64_t)col * len;
+    real *dst          = P.stream + P.range_base[R] + (int64_t)col * len;
     for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
         const int k = e / len, i = e - k * len;
         // U(:,k) = uu_k when index 1 is the row side, vv_k otherwise (sympartialACA.hpp:198-212)
-        const double *src = P.pool + cross[k] + (P.swapped[b] ? n1 : 0);
+        const real *src = P.pool + cross[k] + (P.swapped[b] ? n1 : 0);
         dst[e]            = src[rel + i];
     }
 }
@@ -623,7 +557,7 @@ __global__ void pack_lr_reduce_kernel(PackLrArgs P, int64_t npairs) {
     const int64_t *cross = P.cross_off + P.colptr[b];
     for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
         const int k = e / len, i = e - k * len;
-        const double *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
+        const real *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
         P.stream[rstream_index(P.range_base[S], len, C, P.range_cw[S], i, col + k)] = src[rel + i];
     }
 }
@@ -637,8 +571,8 @@ struct PackDenseArgs {
     const int32_t *t_off, *t_size, *s_off, *s_size;
     const int64_t *staged_off; // >= 0: uploaded dense block (column-major M x N) in `pool`; < 0: generate
     const int32_t *sym_uplo;   // 0 none, 1 'L', 2 'U' : uploaded symmetric leaf, only that triangle is valid
-    const double *pool;
-    double *stream;
+    const real *pool;
+    real *stream;
     int origin; // T0
 };
 
@@ -653,12 +587,12 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
     const int row0 = P.range_off[R] + P.origin; // global cluster position of the range's first row
     const int rel  = row0 - P.t_off[b];
     const int c0   = P.s_off[b];
-    double *dst    = P.stream + P.range_base[R] + (int64_t)col * len;
+    real *dst    = P.stream + P.range_base[R] + (int64_t)col * len;
     const int64_t st = P.staged_off[b];
     const int su     = P.sym_uplo[b];
     for (int e = threadIdx.x; e < N * len; e += blockDim.x) {
         const int j = e / len, i = e - j * len;
-        double v;
+        real v;
         if (st >= 0) {
             int ii = rel + i, jj = j;
             if ((su == 1 && ii < jj) || (su == 2 && ii > jj)) { // symv semantics: mirror the stored triangle
@@ -681,14 +615,14 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
 // lane owns two adjacent columns and walks the rows; the x slice is loaded 64 rows at a time (one
 // coalesced load) and broadcast with v_readlane, so the row loop contains only the 16-B stream loads.
 struct ReduceArgs {
-    const double *stream;
+    const real *stream;
     const int32_t *task_range, *task_chunk;
     const int32_t *range_off, *range_len, *range_cols, *range_cw;
     const int64_t *range_base;
     const int64_t *range_colbase; // first entry of the range in out_idx
     const int32_t *out_idx;       // per column: destination in Z (an `a` slot or a partial slot)
-    const double *x;              // input vector, local to the source root
-    double *Z;
+    const real *x;              // input vector, local to the source root
+    real *Z;
     int ntasks;
 };
 
@@ -704,31 +638,31 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
     const bool active = 2 * lane < wp;
-    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
-    const double *xs  = A.x + A.range_off[S];
-    double a0 = 0, a1 = 0;
+    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const real *xs  = A.x + A.range_off[S];
+    real a0 = 0, a1 = 0;
     for (int i0 = 0; i0 < len; i0 += 64) {
         const int nr    = (len - i0) < 64 ? (len - i0) : 64;
-        const double xv = lane < nr ? xs[i0 + lane] : 0.0;
-        const double *p = src + (int64_t)i0 * wp;
+        const real xv = lane < nr ? xs[i0 + lane] : 0.0;
+        const real *p = src + (int64_t)i0 * wp;
         int j = 0;
         for (; j + 8 <= nr; j += 8) {
-            double2 v[8];
+            real2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = stream_load(reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp));
+                v[u] = stream_load(reinterpret_cast<const real2 *>(p + (int64_t)(j + u) * wp));
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const double xi = readlane_f64(xv, j + u);
-                a0              = __builtin_fma(v[u].x, xi, a0);
-                a1              = __builtin_fma(v[u].y, xi, a1);
+                const real xi = readlane_val(xv, j + u);
+                a0              = hmx_fma(v[u].x, xi, a0);
+                a1              = hmx_fma(v[u].y, xi, a1);
             }
         }
         for (; j < nr; j++) {
-            const double2 v = *reinterpret_cast<const double2 *>(p + (int64_t)j * wp);
-            const double xi = readlane_f64(xv, j);
-            a0              = __builtin_fma(v.x, xi, a0);
-            a1              = __builtin_fma(v.y, xi, a1);
+            const real2 v = *reinterpret_cast<const real2 *>(p + (int64_t)j * wp);
+            const real xi = readlane_val(xv, j);
+            a0              = hmx_fma(v.x, xi, a0);
+            a1              = hmx_fma(v.y, xi, a1);
         }
     }
     if (active) {
@@ -743,16 +677,16 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
 // Stage 1b: blocks whose source cluster spans several ranges: a_b[k] = sum_s partial[b][s][k]
 struct CombineArgs {
     const int32_t *dst, *src, *stride, *count;
-    double *Z;
+    real *Z;
     int n;
 };
 __global__ void combine_kernel(CombineArgs A) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.n)
         return;
-    const double *p = A.Z + A.src[e];
+    const real *p = A.Z + A.src[e];
     const int st = A.stride[e], cnt = A.count[e];
-    double s = 0;
+    real s = 0;
     for (int k = 0; k < cnt; k++)
         s += p[(int64_t)k * st];
     A.Z[A.dst[e]] = s;
@@ -762,54 +696,54 @@ __global__ void combine_kernel(CombineArgs A) {
 // y += U a; final alpha/beta as openmp_internal_add_hmatrix_vector_product :134-136,168):
 // one workgroup per target row range, lane = row, the waves split the columns in 64-column chunks.
 struct ExpandArgs {
-    const double *stream;
+    const real *stream;
     const int32_t *order; // launch position -> range (heaviest ranges first)
     const int32_t *range_off, *range_len, *range_cols;
     const int64_t *range_base;
     const int64_t *range_colbase;
     const int32_t *z_idx; // per column: index into Z = [x | a | ...]
-    const double *Z;
-    double *y;            // output, local to the target root
-    double alpha, beta;
+    const real *Z;
+    real *y;            // output, local to the target root
+    real alpha, beta;
     int nranges;
 };
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
-    __shared__ double part[WAVES][WAVE];
+    __shared__ real part[WAVES][WAVE];
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
-    const double *E     = A.stream + A.range_base[R];
+    const real *E     = A.stream + A.range_base[R];
     const int32_t *zidx = A.z_idx + A.range_colbase[R];
     const bool active   = lane < len;
     const int row       = active ? lane : 0;
-    double acc = 0;
+    real acc = 0;
     for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
         const int nc   = (C - c0) < 64 ? (C - c0) : 64;
-        const double z = lane < nc ? A.Z[zidx[c0 + lane]] : 0.0;
-        const double *col = E + (int64_t)c0 * len + row;
+        const real z = lane < nc ? A.Z[zidx[c0 + lane]] : 0.0;
+        const real *col = E + (int64_t)c0 * len + row;
         int j = 0;
         for (; j + 8 <= nc; j += 8) {
-            double v[8];
+            real v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 v[u] = stream_load(col + (int64_t)(j + u) * len);
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                acc = __builtin_fma(v[u], readlane_f64(z, j + u), acc);
+                acc = hmx_fma(v[u], readlane_val(z, j + u), acc);
         }
         for (; j < nc; j++)
-            acc = __builtin_fma(col[(int64_t)j * len], readlane_f64(z, j), acc);
+            acc = hmx_fma(col[(int64_t)j * len], readlane_val(z, j), acc);
     }
     part[wv][lane] = active ? acc : 0.0;
     __syncthreads();
     if (wv == 0 && active) {
-        double s = part[0][lane];
+        real s = part[0][lane];
 #pragma unroll
         for (int k = 1; k < WAVES; k++)
             s += part[k][lane];
-        double *yo = A.y + A.range_off[R] + lane;
+        real *yo = A.y + A.range_off[R] + lane;
         *yo        = A.beta == 0.0 ? A.alpha * s : A.alpha * s + A.beta * (*yo);
     }
 }
@@ -825,7 +759,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
 // ---------------------------------------------------------------------------------------------
 template <int WAVES, int MU>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) double xt[WAVES][WAVE][MU];
+    __shared__ __attribute__((aligned(16))) real xt[WAVES][WAVE][MU];
     const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.x * WAVES + wv;
     if (task >= A.ntasks)
@@ -837,9 +771,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
     const bool active = 2 * lane < wp;
-    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
-    const double *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
-    double a0[MU], a1[MU];
+    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const real *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
+    real a0[MU], a1[MU];
 #pragma unroll
     for (int c = 0; c < MU; c++)
         a0[c] = a1[c] = 0.0;
@@ -852,43 +786,43 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
                 xt[wv][lane][c] = xs[(int64_t)(i0 + lane) * mu + c];
         }
         __builtin_amdgcn_wave_barrier();
-        const double *p = src + (int64_t)i0 * wp;
+        const real *p = src + (int64_t)i0 * wp;
         int j = 0;
         for (; j + 4 <= nr; j += 4) {
-            double2 v[4];
+            real2 v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                v[u] = stream_load(reinterpret_cast<const double2 *>(p + (int64_t)(j + u) * wp));
+                v[u] = stream_load(reinterpret_cast<const real2 *>(p + (int64_t)(j + u) * wp));
 #pragma unroll
             for (int u = 0; u < 4; u++) {
 #pragma unroll
                 for (int c = 0; c < MU; c++) {
-                    const double xi = xt[wv][j + u][c];
-                    a0[c]           = __builtin_fma(v[u].x, xi, a0[c]);
-                    a1[c]           = __builtin_fma(v[u].y, xi, a1[c]);
+                    const real xi = xt[wv][j + u][c];
+                    a0[c]           = hmx_fma(v[u].x, xi, a0[c]);
+                    a1[c]           = hmx_fma(v[u].y, xi, a1[c]);
                 }
             }
         }
         for (; j < nr; j++) {
-            const double2 v = *reinterpret_cast<const double2 *>(p + (int64_t)j * wp);
+            const real2 v = *reinterpret_cast<const real2 *>(p + (int64_t)j * wp);
 #pragma unroll
             for (int c = 0; c < MU; c++) {
-                const double xi = xt[wv][j][c];
-                a0[c]           = __builtin_fma(v.x, xi, a0[c]);
-                a1[c]           = __builtin_fma(v.y, xi, a1[c]);
+                const real xi = xt[wv][j][c];
+                a0[c]           = hmx_fma(v.x, xi, a0[c]);
+                a1[c]           = hmx_fma(v.y, xi, a1[c]);
             }
         }
     }
     if (active) {
         const int64_t cb = A.range_colbase[S] + ch * cw + 2 * lane;
         if (2 * lane < w) {
-            double *dst = A.Z + (int64_t)A.out_idx[cb] * mu + cbase;
+            real *dst = A.Z + (int64_t)A.out_idx[cb] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 dst[c] = a0[c];
         }
         if (2 * lane + 1 < w) {
-            double *dst = A.Z + (int64_t)A.out_idx[cb + 1] * mu + cbase;
+            real *dst = A.Z + (int64_t)A.out_idx[cb + 1] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 dst[c] = a1[c];
@@ -901,9 +835,9 @@ __global__ void combine_mu_kernel(CombineArgs A, int mu) {
     if (t >= (int64_t)A.n * mu)
         return;
     const int e = (int)(t / mu), c = (int)(t - (int64_t)e * mu);
-    const double *p = A.Z + (int64_t)A.src[e] * mu + c;
+    const real *p = A.Z + (int64_t)A.src[e] * mu + c;
     const int st = A.stride[e], cnt = A.count[e];
-    double s = 0;
+    real s = 0;
     for (int k = 0; k < cnt; k++)
         s += p[(int64_t)k * st * mu];
     A.Z[(int64_t)A.dst[e] * mu + c] = s;
@@ -911,15 +845,15 @@ __global__ void combine_mu_kernel(CombineArgs A, int mu) {
 
 template <int WAVES, int MU>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) double zt[WAVES][WAVE][MU]; // coefficient tiles, reused for the final reduction
+    __shared__ __attribute__((aligned(16))) real zt[WAVES][WAVE][MU]; // coefficient tiles, reused for the final reduction
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
-    const double *E     = A.stream + A.range_base[R];
+    const real *E     = A.stream + A.range_base[R];
     const int32_t *zidx = A.z_idx + A.range_colbase[R];
     const bool active   = lane < len;
     const int row       = active ? lane : 0;
-    double acc[MU];
+    real acc[MU];
 #pragma unroll
     for (int c = 0; c < MU; c++)
         acc[c] = 0.0;
@@ -927,16 +861,16 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
         const int nc = (C - c0) < 64 ? (C - c0) : 64;
         __builtin_amdgcn_wave_barrier();
         if (lane < nc) {
-            const double *zr = A.Z + (int64_t)zidx[c0 + lane] * mu + cbase;
+            const real *zr = A.Z + (int64_t)zidx[c0 + lane] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 zt[wv][lane][c] = zr[c];
         }
         __builtin_amdgcn_wave_barrier();
-        const double *col = E + (int64_t)c0 * len + row;
+        const real *col = E + (int64_t)c0 * len + row;
         int j = 0;
         for (; j + 8 <= nc; j += 8) {
-            double v[8];
+            real v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 v[u] = stream_load(col + (int64_t)(j + u) * len);
@@ -944,13 +878,13 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
             for (int u = 0; u < 8; u++)
 #pragma unroll
                 for (int c = 0; c < MU; c++)
-                    acc[c] = __builtin_fma(v[u], zt[wv][j + u][c], acc[c]);
+                    acc[c] = hmx_fma(v[u], zt[wv][j + u][c], acc[c]);
         }
         for (; j < nc; j++) {
-            const double v = col[(int64_t)j * len];
+            const real v = col[(int64_t)j * len];
 #pragma unroll
             for (int c = 0; c < MU; c++)
-                acc[c] = __builtin_fma(v, zt[wv][j][c], acc[c]);
+                acc[c] = hmx_fma(v, zt[wv][j][c], acc[c]);
         }
     }
     __syncthreads();
@@ -961,11 +895,11 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
     // rows x MU outputs, summed over the waves; consecutive threads write consecutive right-hand sides
     for (int e = threadIdx.x; e < len * MU; e += WAVES * WAVE) {
         const int i = e / MU, c = e - i * MU;
-        double s = zt[0][i][c];
+        real s = zt[0][i][c];
 #pragma unroll
         for (int k = 1; k < WAVES; k++)
             s += zt[k][i][c];
-        double *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
         *yo        = A.beta == 0.0 ? A.alpha * s : A.alpha * s + A.beta * (*yo);
     }
 }
@@ -979,16 +913,16 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
 // Eight wave-wide sums for the price of ~1.25: each butterfly step halves the number of live values while
 // halving the lane group that owns them.  On return lane l with (l & 7) == 0 holds the complete sum of input
 // value number 4*bit5(l) + 2*bit4(l) + bit3(l).
-__device__ __forceinline__ double reduce8(const double (&v)[8], int lane) {
+__device__ __forceinline__ real reduce8(const real (&v)[8], int lane) {
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
-    double t[4], u[2];
+    real t[4], u[2];
 #pragma unroll
     for (int k = 0; k < 4; k++)
         t[k] = (b5 ? v[k + 4] : v[k]) + __shfl_xor(b5 ? v[k] : v[k + 4], 32, WAVE);
 #pragma unroll
     for (int k = 0; k < 2; k++)
         u[k] = (b4 ? t[k + 2] : t[k]) + __shfl_xor(b4 ? t[k] : t[k + 2], 16, WAVE);
-    double r = (b3 ? u[1] : u[0]) + __shfl_xor(b3 ? u[0] : u[1], 8, WAVE);
+    real r = (b3 ? u[1] : u[0]) + __shfl_xor(b3 ? u[0] : u[1], 8, WAVE);
     r += __shfl_xor(r, 4, WAVE);
     r += __shfl_xor(r, 2, WAVE);
     r += __shfl_xor(r, 1, WAVE);
@@ -997,13 +931,13 @@ __device__ __forceinline__ double reduce8(const double (&v)[8], int lane) {
 __device__ __forceinline__ int reduce8_slot(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
 
 struct ColReduceArgs { // over E-streams: W[dst[c]] += sum_i E[i,c] * in[R.off + i]
-    const double *stream;
+    const real *stream;
     const int32_t *order;
     const int32_t *range_off, *range_len, *range_cols;
     const int64_t *range_base, *range_colbase;
     const int32_t *dst; // per column, -1 = skip
-    const double *in;
-    double *W;
+    const real *in;
+    real *W;
     int nranges;
 };
 template <int WAVES>
@@ -1011,16 +945,16 @@ __global__ __launch_bounds__(WAVES *WAVE) void colreduce_kernel(ColReduceArgs A)
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
-    const double *E    = A.stream + A.range_base[R] + (lane < len ? lane : 0);
+    const real *E    = A.stream + A.range_base[R] + (lane < len ? lane : 0);
     const int32_t *dst = A.dst + A.range_colbase[R];
-    const double xin   = lane < len ? A.in[A.range_off[R] + lane] : 0.0;
+    const real xin   = lane < len ? A.in[A.range_off[R] + lane] : 0.0;
     const int slot     = reduce8_slot(lane);
     for (int c0 = wv * 8; c0 < C; c0 += WAVES * 8) {
-        double v[8];
+        real v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++)
             v[u] = (c0 + u < C) ? stream_load(E + (int64_t)(c0 + u) * len) * xin : 0.0;
-        const double r = reduce8(v, lane);
+        const real r = reduce8(v, lane);
         if ((lane & 7) == 0 && c0 + slot < C) {
             const int d = dst[c0 + slot];
             if (d >= 0)
@@ -1030,12 +964,12 @@ __global__ __launch_bounds__(WAVES *WAVE) void colreduce_kernel(ColReduceArgs A)
 }
 
 struct RowReduceArgs { // over R-streams: W[S.off + i] += sum_col Rs[i,col] * W[coef[col]]
-    const double *stream;
+    const real *stream;
     const int32_t *task_range, *task_chunk;
     const int32_t *range_off, *range_len, *range_cols, *range_cw;
     const int64_t *range_base, *range_colbase;
     const int32_t *coef; // per column index into W, -1 = skip
-    double *W;
+    real *W;
     int ntasks;
     int row_shift; // added to the range's local offset to address W (mirror pass: S0 - T0)
 };
@@ -1051,9 +985,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
     const bool active = 2 * lane < wp;
-    const double *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
     const int64_t cb  = A.range_colbase[S] + ch * cw + 2 * lane;
-    double c0 = 0, c1 = 0;
+    real c0 = 0, c1 = 0;
     bool any = false;
     if (2 * lane < w) {
         const int d = A.coef[cb];
@@ -1068,39 +1002,39 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
     if (!__any(any))
         return; // no selected column in this chunk (e.g. mirror pass over an off-diagonal stripe)
     const int slot = reduce8_slot(lane);
-    double *out    = A.W + A.range_off[S] + A.row_shift;
+    real *out    = A.W + A.range_off[S] + A.row_shift;
     for (int i0 = 0; i0 < len; i0 += 8) {
-        double v[8];
+        real v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             v[u] = 0.0;
             if (active && i0 + u < len) {
-                const double2 e = stream_load(reinterpret_cast<const double2 *>(src + (int64_t)(i0 + u) * wp));
-                v[u]            = __builtin_fma(e.x, c0, e.y * c1);
+                const real2 e = stream_load(reinterpret_cast<const real2 *>(src + (int64_t)(i0 + u) * wp));
+                v[u]            = hmx_fma(e.x, c0, e.y * c1);
             }
         }
-        const double r = reduce8(v, lane);
+        const real r = reduce8(v, lane);
         if ((lane & 7) == 0 && i0 + slot < len)
             atomicAdd(&out[i0 + slot], r);
     }
 }
 
 // small helpers -----------------------------------------------------------------------------------
-__global__ void axpby_kernel(int n, double alpha, const double *w, double beta, double *y) {
+__global__ void axpby_kernel(int n, real alpha, const real *w, real beta, real *y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
         y[i] = beta == 0.0 ? alpha * w[i] : alpha * w[i] + beta * y[i];
 }
 // user_to_cluster: out[i] = in[perm[i] - base]; cluster_to_user: out[perm[i] - base] = in[i]
 // (clustering/cluster_node.hpp:150-175)
-__global__ void gather_kernel(int n, const int32_t *perm, int base, const double *in, double *out, int mu) {
+__global__ void gather_kernel(int n, const int32_t *perm, int base, const real *in, real *out, int mu) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (int64_t)n * mu) {
         const int i = e / mu, c = e - (int64_t)i * mu;
         out[e]      = in[(int64_t)(perm[i] - base) * mu + c];
     }
 }
-__global__ void scatter_kernel(int n, const int32_t *perm, int base, const double *in, double *out, int mu) {
+__global__ void scatter_kernel(int n, const int32_t *perm, int base, const real *in, real *out, int mu) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (int64_t)n * mu) {
         const int i = e / mu, c = e - (int64_t)i * mu;
@@ -1108,21 +1042,13 @@ __global__ void scatter_kernel(int n, const int32_t *perm, int base, const doubl
     }
 }
 // strided column extract / insert for row-major multi-RHS (X[n][mu])
-__global__ void col_extract_kernel(int n, int mu, int c, const double *X, double *x) {
+__global__ void col_extract_kernel(int n, int mu, int c, const real *X, real *x) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
         x[i] = X[(int64_t)i * mu + c];
 }
-__global__ void col_insert_kernel(int n, int mu, int c, const double *y, double *Y) {
+__global__ void col_insert_kernel(int n, int mu, int c, const real *y, real *Y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
         Y[(int64_t)i * mu + c] = y[i];
 }
-__global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
-    int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride)
-        out[i] = in[i];
-}
-
-} // namespace hmx

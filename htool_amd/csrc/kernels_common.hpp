@@ -1,0 +1,101 @@
+// kernels_common.hpp + kernels_body.hpp -- hand-written HIP kernels for gfx950 (CDNA4, wave64).  Compiled with -ffp-contract=off:
+// every FMA in this file is an explicit __builtin_fma, so the compression kernels evaluate exactly the
+// IEEE sequence the reference's scalar code spells out (SURVEY.md "Hard parts": ACA parity) while the
+// matvec kernels still issue v_fma_f64.
+//
+// Data layout in HBM: the compressed operator is NOT kept as htool's per-block
+// U (M x r) / V (r x N) / dense (M x N) matrices.  It is re-laid out as two sets of streams:
+//   E-stream  (expand): for every target row range R (<= 64 rows, aligned to cluster boundaries) one
+//             column-major len_R x C_R matrix holding, side by side, the slice of every block that
+//             touches R: n_b columns for a dense block, r_b columns (its U slice) for a low-rank block.
+//             y_R = E_R * z_R, z_R gathered from Z = [x | a].  lane = row, no cross-lane reduction.
+//   R-stream  (reduce): for every source range S one row-major len_S x C_S matrix (128-column chunks)
+//             holding the V slices of every low-rank block that touches S.  a_partial = x_S^T * R_S,
+//             lane = column pair, no cross-lane reduction.
+// Every stored coefficient is read exactly once per matvec, by fully coalesced wave loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmx {
+
+constexpr int WAVE = 64;
+
+struct KernelSpec { // device-evaluable generator
+    int kind;
+    int dim;
+    double p0, p1;
+};
+
+// K(x,y) = 1/(p0 + p1*|x-y|); squared differences accumulated left to right from 0, one sqrt, one
+// multiply, one add, one divide -- the order of examples/use_hmatrix.cpp:33 / testing/generator_test.hpp:159.
+__device__ __forceinline__ double eval_kernel(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
+    double s        = 0.0;
+    const double d0 = tx - sx;
+    s               = s + d0 * d0;
+    const double d1 = ty - sy;
+    s               = s + d1 * d1;
+    if (ks.dim == 3) {
+        const double d2 = tz - sz;
+        s               = s + d2 * d2;
+    }
+    return 1.0 / (ks.p0 + ks.p1 * sqrt(s));
+}
+
+// ---- type-generic helpers shared by the f64 and f32 instantiations of kernels_body.hpp -------------------------
+__device__ __forceinline__ double hmx_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float hmx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double readlane_val(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_val(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// Every coefficient is read exactly once per product, so the stream loads are marked non-temporal: they do
+// not displace x / Z / index lines from L2 and the Infinity Cache.  Measured at N=1e6 (fp64): expand 1.88 -> 1.74 ms,
+// reduce 1.23-1.33 -> 1.20 ms, and the run-to-run bimodality disappears.  -DHMX_NT=0 disables.
+#ifndef HMX_NT
+#define HMX_NT 1
+#endif
+typedef double hmx_d2 __attribute__((ext_vector_type(2)));
+typedef float hmx_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double stream_load(const double *p) {
+#if HMX_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float stream_load(const float *p) {
+#if HMX_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double2 stream_load(const double2 *p) {
+#if HMX_NT
+    const hmx_d2 v = __builtin_nontemporal_load(reinterpret_cast<const hmx_d2 *>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float2 stream_load(const float2 *p) {
+#if HMX_NT
+    const hmx_f2 v = __builtin_nontemporal_load(reinterpret_cast<const hmx_f2 *>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
+__global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
+    int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = in[i];
+}
+
+} // namespace hmx

@@ -17,6 +17,7 @@
 #include <htool/clustering/cluster_node.hpp>
 #include <htool/distributed_operator/interfaces/virtual_global_to_local_operator.hpp>
 #include <htool/hmatrix/hmatrix.hpp>
+#include <htool/hmatrix/interfaces/virtual_dense_blocks_generator.hpp>
 #include <htool/hmatrix/interfaces/virtual_lrmat_generator.hpp>
 #include <htool/misc/logger.hpp>
 
@@ -163,6 +164,26 @@ class DeviceLowRankGenerator final : public htool::VirtualInternalLowRankGenerat
     }
     bool copy_low_rank_approximation(int M, int N, int row_offset, int col_offset, int, htool::LowRankMatrix<double> &lrmat) const override {
         return copy_low_rank_approximation(M, N, row_offset, col_offset, lrmat); // the device build already used reqrank
+    }
+};
+
+// Plugged in with HMatrixTreeBuilder::set_dense_blocks_generator (hmatrix/tree_builder/tree_builder.hpp:258):
+// htool hands over ALL dense leaves in one batched call (tree_builder.hpp:585-600) with zero-filled destinations;
+// they are filled from the blocks the device assembled.
+class DeviceDenseBlocksGenerator final : public htool::VirtualDenseBlocksGenerator<double> {
+    const Engine &m_engine;
+
+  public:
+    explicit DeviceDenseBlocksGenerator(const Engine &engine) : m_engine(engine) {}
+    void copy_dense_blocks(const std::vector<int> &M, const std::vector<int> &N, const std::vector<int> &rows, const std::vector<int> &cols, std::vector<double *> &ptr) const override {
+        for (size_t b = 0; b < ptr.size(); b++) {
+            const int64_t leaf = m_engine.find_leaf(rows[b], M[b], cols[b], N[b]);
+            if (leaf < 0) {
+                htool::Logger::get_instance().log(htool::LogLevel::ERROR, "[hmx] dense block not present in the hmx block tree");
+                continue;
+            }
+            ok(hmx_hmatrix_get_block(m_engine.hmatrix(), leaf, ptr[b], nullptr), "get dense block");
+        }
     }
 };
 

@@ -103,7 +103,9 @@ int hmx_block_tree_leaves(const hmx_block_tree *, hmx_leaf *out);
 int hmx_block_tree_root(const hmx_block_tree *, int32_t *t_off_size_s_off_size /* 4 */, char *symmetry_for_leaves, char *uplo_for_leaves);
 
 /* ---- H-matrix on the device ---------------------------------------------------------------------------- */
-int hmx_hmatrix_create(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out);
+int hmx_hmatrix_create(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out);   /* HMatrix<double,double> */
+int hmx_hmatrix_create_s(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out); /* HMatrix<float,double>: fp32 coefficients, fp64 coordinates */
+int hmx_hmatrix_is_f32(const hmx_hmatrix *);
 void hmx_hmatrix_destroy(hmx_hmatrix *);
 
 /* generator = built-in kernel on (target coords, source coords), both in USER numbering (AoS, dim <= 3) */
@@ -141,6 +143,15 @@ int hmx_hmatrix_matvec_user(hmx_hmatrix *, char trans, double alpha, const doubl
  * in/out row-major (mu fastest), cluster numbering. */
 int hmx_hmatrix_matmat_row_major(hmx_hmatrix *, char trans, double alpha, const double *in, double beta, double *out,
                                  int mu, int mem, void *stream);
+
+/* fp32-coefficient variants (handles created with hmx_hmatrix_create_s); same semantics, float data.
+ * All arithmetic of compression and product is then done in float, as htool does for CoefficientPrecision=float. */
+int hmx_hmatrix_set_block_lowrank_s(hmx_hmatrix *, int64_t leaf, int rank, const float *U, const float *V);
+int hmx_hmatrix_set_block_dense_s(hmx_hmatrix *, int64_t leaf, const float *D);
+int hmx_hmatrix_get_block_s(const hmx_hmatrix *, int64_t leaf, float *U_or_D, float *V);
+int hmx_hmatrix_matvec_s(hmx_hmatrix *, char trans, float alpha, const float *in, float beta, float *out, int mem, void *stream);
+int hmx_hmatrix_matvec_user_s(hmx_hmatrix *, char trans, float alpha, const float *in, float beta, float *out, int mem, void *stream);
+int hmx_hmatrix_matmat_row_major_s(hmx_hmatrix *, char trans, float alpha, const float *in, float beta, float *out, int mu, int mem, void *stream);
 
 /* Timing hooks for bench.py: average duration (ms) of the last matvec's kernels measured with HIP
  * events on the launch stream; names[i] is a static string. */

@@ -319,3 +319,39 @@ def test_edge_cases_alpha_beta_dense_only_and_determinism():
             Ug, Vg = H.get_block(bidx)
             Uo, Vo = Ho.block(bidx)
             assert rel_err(Ug @ Vg, Uo @ Vo) < 1e-10
+
+
+def test_fp32_coefficients_against_fp64_engine():
+    """HMatrix<float,double> (BASELINE config 5 precision): same block structure, float arithmetic throughout.
+    Sanity bar (the fp32 floor of the reference itself is ~2e-6 at eps=1e-4): the fp32 product
+    agrees with the fp64 engine on the same operator to a few 1e-6, ranks stay close, dense entries are the fp64
+    entries rounded to float."""
+    n = 8000
+    x = hm.create_geometry("ellipse", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(100)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0)
+    for sym, comp in (("N", "partialACA"), ("S", "sympartialACA")):
+        tb = hm.HMatrixTreeBuilder(1e-4, 10.0, sym, "L" if sym == "S" else "N")
+        tb.set_low_rank_generator(comp)
+        H64 = tb.build(gen, T, T)
+        H32 = tb.build(gen, T, T, dtype=np.float32)
+        t64, t32 = H64.leaf_table(), H32.leaf_table()
+        assert np.array_equal(t64[:, :4], t32[:, :4]) and np.array_equal(t64[:, 5], t32[:, 5])
+        assert np.array_equal(t64[:, 4] < 0, t32[:, 4] < 0)
+        assert np.abs(t64[:, 4] - t32[:, 4]).max() <= 4 and np.abs(t64[:, 4] - t32[:, 4]).mean() < 0.5
+        d = int(np.nonzero(t64[:, 4] < 0)[0][0])
+        assert np.array_equal(H32.get_block(d), H64.get_block(d).astype(np.float32))
+        rng = np.random.default_rng(5)
+        u = rng.random(n)
+        for trans in ("N", "T"):
+            y64, y32 = np.zeros(n), np.zeros(n, dtype=np.float32)
+            hm.internal_add_hmatrix_vector_product(trans, 1.0, H64, u, 0.0, y64)
+            hm.internal_add_hmatrix_vector_product(trans, 1.0, H32, u.astype(np.float32), 0.0, y32)
+            assert rel_err(y32, y64) < 2e-5
+        X = rng.random((n, 4))
+        Y64, Y32 = np.zeros((n, 4)), np.zeros((n, 4), dtype=np.float32)
+        hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H64, X, 0.0, Y64, 4)
+        hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H32, X.astype(np.float32), 0.0, Y32, 4)
+        assert rel_err(Y32, Y64) < 2e-5
