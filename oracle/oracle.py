@@ -48,7 +48,7 @@ def lib():
         L.orc_hmatrix_build.restype = C.c_void_p
         L.orc_hmatrix_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.c_int, C.c_int, C.c_int]
+                                        C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_hmatrix_destroy.argtypes = [C.c_void_p]
         L.orc_hmatrix_num_leaves.argtypes = [C.c_void_p]
         L.orc_hmatrix_leaves.argtypes = [C.c_void_p, C.c_int, ip]
@@ -57,11 +57,11 @@ def lib():
         L.orc_hmatrix_matvec.argtypes = [C.c_void_p, C.c_int, C.c_char, C.c_double, dp, C.c_double, dp]
         L.orc_hmatrix_matmat_row_major.argtypes = [C.c_void_p, C.c_char, C.c_double, dp, C.c_double, dp, C.c_int]
         L.orc_compress_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
-                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, ip, dp]
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, ip, dp, C.c_int]
         L.orc_generate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
                                          C.c_int, C.c_int, C.c_int, dp]
         L.orc_hmatrix_from_blocks.restype = C.c_void_p
-        L.orc_hmatrix_from_blocks.argtypes = [C.c_int, ip, C.POINTER(C.c_int64), dp, ip, C.c_char, C.c_char]
+        L.orc_hmatrix_from_blocks.argtypes = [C.c_int, ip, C.POINTER(C.c_int64), dp, ip, C.c_char, C.c_char, C.c_int]
         _LIB = L
     return _LIB
 
@@ -104,7 +104,9 @@ class HMatrix:
     """Oracle H-matrix: block tree + compressed leaves + reference-order leaf loop."""
 
     def __init__(self, tct, sct, delta=1e-5, scale=1.0, eps=1e-4, eta=10.0, sym="N", uplo="N", reqrank=-1,
-                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, _handle=None):
+                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, f32=False, _handle=None):
+        """f32=True: htool's HMatrix<float,double> -- fp32 coefficients and arithmetic, fp64 geometry.  Values cross
+        this Python boundary as float64 in both cases (converted inside the library)."""
         if _handle is not None:
             self.h = _handle
             self._keep = ()
@@ -113,7 +115,7 @@ class HMatrix:
             self.h = lib().orc_hmatrix_build(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta,
                                              scale, eps, eta, sym.encode(), uplo.encode(), reqrank,
                                              COMPRESSORS[compressor], mindepth, mindepth, rank, rank, int(consistent),
-                                             int(parallel))
+                                             int(parallel), int(f32))
         n = lib().orc_hmatrix_num_leaves(self.h)
         self.leaves = np.empty((n, 6), dtype=np.int32)
         self.leaves_dfs = np.empty((n, 6), dtype=np.int32)
@@ -123,13 +125,13 @@ class HMatrix:
         lib().orc_hmatrix_rootinfo(self.h, _ip(self.rootinfo))
 
     @classmethod
-    def from_blocks(cls, desc, payload_offsets, data, root, sym_for_leaves="N", uplo="N"):
+    def from_blocks(cls, desc, payload_offsets, data, root, sym_for_leaves="N", uplo="N", f32=False):
         desc = np.ascontiguousarray(desc, dtype=np.int32)
         offs = np.ascontiguousarray(payload_offsets, dtype=np.int64)
         data = np.ascontiguousarray(data, dtype=np.float64)
         root = np.ascontiguousarray(root, dtype=np.int32)
         h = lib().orc_hmatrix_from_blocks(len(desc), _ip(desc), offs.ctypes.data_as(C.POINTER(C.c_int64)), _dp(data),
-                                          _ip(root), sym_for_leaves.encode(), uplo.encode())
+                                          _ip(root), sym_for_leaves.encode(), uplo.encode(), int(f32))
         return cls(None, None, _handle=h)
 
     def block(self, b, with_pivots=False):
@@ -175,14 +177,14 @@ class HMatrix:
             self.h = None
 
 
-def compress_block(tct, sct, compressor, M, N, row_off, col_off, eps, reqrank=-1, delta=0.0, scale=4 * np.pi):
+def compress_block(tct, sct, compressor, M, N, row_off, col_off, eps, reqrank=-1, delta=0.0, scale=4 * np.pi, f32=False):
     U = np.empty((min(M, N) + 1, M))
     V = np.empty((N, min(M, N) + 1))
     piv = np.zeros(2 * (min(M, N) + 1), dtype=np.int32)
     sing = np.zeros(min(M, N))
     r = lib().orc_compress_block(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta, scale,
                                  COMPRESSORS[compressor], M, N, row_off, col_off, eps, reqrank, _dp(U), _dp(V),
-                                 _ip(piv), _dp(sing))
+                                 _ip(piv), _dp(sing), int(f32))
     Uf = U.reshape(-1)[:M * r].reshape(r, M).T
     Vf = V.reshape(-1)[:N * r].reshape(N, r).T
     return r, Uf, Vf, piv[:2 * r].reshape(-1, 2), sing

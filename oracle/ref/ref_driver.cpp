@@ -69,12 +69,27 @@ struct Dump {
         rec(name, 'd', dims, v.data(), 8);
     }
     void f64p(const std::string &name, const double *p, std::vector<uint64_t> dims) { rec(name, 'd', dims, p, 8); }
+    void f64p(const std::string &name, const float *p, std::vector<uint64_t> dims) { // fp32 payloads are stored as float64 (exact)
+        size_t n = 1;
+        for (auto d : dims)
+            n *= d;
+        std::vector<double> tmp(p, p + n);
+        rec(name, 'd', dims, tmp.data(), 8);
+    }
+    template <typename T>
+    void vec(const std::string &name, const std::vector<T> &v, std::vector<uint64_t> dims = {}) {
+        if (dims.empty())
+            dims = {v.size()};
+        std::vector<double> tmp(v.begin(), v.end());
+        rec(name, 'd', dims, tmp.data(), 8);
+    }
 };
 
 // Kernel family K(x,y) = 1 / (delta + scale * |x-y|), evaluated with the same operation order as the
 // reference's own generators (examples/use_hmatrix.cpp:33, testing/generator_test.hpp:159,185):
 // squared differences accumulated left to right from 0, one sqrt, one multiply, one add, one divide.
-class InvDistGenerator : public VirtualGenerator<double> {
+template <typename T>
+class InvDistGenerator : public VirtualGenerator<T> {
     int m_dim;
     const std::vector<double> &m_xt, &m_xs;
     double m_delta, m_scale;
@@ -89,10 +104,10 @@ class InvDistGenerator : public VirtualGenerator<double> {
         }
         return 1. / (m_delta + m_scale * std::sqrt(s));
     }
-    void copy_submatrix(int M, int N, const int *rows, const int *cols, double *ptr) const override {
+    void copy_submatrix(int M, int N, const int *rows, const int *cols, T *ptr) const override {
         for (int j = 0; j < M; j++)
             for (int k = 0; k < N; k++)
-                ptr[j + (size_t)M * k] = get_coef(rows[j], cols[k]);
+                ptr[j + (size_t)M * k] = get_coef(rows[j], cols[k]); // double expression assigned to T, as a user generator would
     }
 };
 
@@ -155,8 +170,8 @@ static void dump_cluster_tree(Dump &D, const std::string &prefix, const Cluster<
     D.i32(prefix + "partition", part, {part.size() / 2, 2});
 }
 
-template <typename F>
-static void preorder_leaves(const HMatrix<double> &h, bool sym_anc, F &&f) {
+template <typename HM, typename F>
+static void preorder_leaves(const HM &h, bool sym_anc, F &&f) {
     if (h.is_leaf()) {
         f(h, sym_anc);
         return;
@@ -182,7 +197,9 @@ static std::shared_ptr<VirtualPartitioning<double>> make_partitioning(const std:
     exit(2);
 }
 
+template <typename T>
 static int run_hmat(std::map<std::string, std::string> &kv) {
+    using HM = HMatrix<T, double>;
     int n                 = geti(kv, "n", 2000);
     int nsrc              = geti(kv, "nsrc", 0); // 0 => square, source == target geometry
     std::string geom      = gets(kv, "geom", "ellipse");
@@ -239,18 +256,18 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     if (!square)
         dump_cluster_tree(D, "s_", sct);
 
-    InvDistGenerator A(dim, xt, xs, delta, scale);
-    HMatrixTreeBuilder<double> tb(eps, eta, sym[0], uplo[0], reqrank);
+    InvDistGenerator<T> A(dim, xt, xs, delta, scale);
+    HMatrixTreeBuilder<T, double> tb(eps, eta, sym[0], uplo[0], reqrank);
     if (!consistent)
         tb.set_block_tree_consistency(false);
     if (comp == "partialACA")
-        tb.set_low_rank_generator(std::make_shared<partialACA<double>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
+        tb.set_low_rank_generator(std::make_shared<partialACA<T>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
     else if (comp == "sympartialACA")
-        tb.set_low_rank_generator(std::make_shared<sympartialACA<double>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
+        tb.set_low_rank_generator(std::make_shared<sympartialACA<T>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
     else if (comp == "fullACA")
-        tb.set_low_rank_generator(std::make_shared<fullACA<double>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
+        tb.set_low_rank_generator(std::make_shared<fullACA<T>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
     else if (comp == "SVD")
-        tb.set_low_rank_generator(std::make_shared<SVD<double>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
+        tb.set_low_rank_generator(std::make_shared<SVD<T>>(A, tct.get_permutation().data(), sct.get_permutation().data()));
     else if (comp != "default") {
         fprintf(stderr, "unknown compressor\n");
         return 2;
@@ -259,13 +276,13 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     tb.set_minimal_source_depth(mindepth);
 
     auto t2           = std::chrono::steady_clock::now();
-    HMatrix<double> H = par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank);
+    HM H = par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank);
     auto t3           = std::chrono::steady_clock::now();
 
     // Leaves in natural preorder (children in creation order)
     std::vector<int> leaves; // t_off t_size s_off s_size rank(-1 dense) mirror
-    std::vector<const HMatrix<double> *> leaf_ptr;
-    preorder_leaves(H, H.get_symmetry() != 'N', [&](const HMatrix<double> &l, bool sym_anc) {
+    std::vector<const HM *> leaf_ptr;
+    preorder_leaves(H, H.get_symmetry() != 'N', [&](const HM &l, bool sym_anc) {
         leaves.push_back(l.get_target_cluster().get_offset());
         leaves.push_back(l.get_target_cluster().get_size());
         leaves.push_back(l.get_source_cluster().get_offset());
@@ -281,7 +298,7 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     // Payload of the first few low-rank and dense leaves (or all of them, concatenated)
     {
         int nlr = 0, nd = 0;
-        std::vector<double> allU, allV, allD;
+        std::vector<T> allU, allV, allD;
         for (size_t b = 0; b < leaf_ptr.size(); b++) {
             auto *l = leaf_ptr[b];
             if (l->is_low_rank()) {
@@ -305,9 +322,9 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
             }
         }
         if (dump_all) {
-            D.f64("allU", allU);
-            D.f64("allV", allV);
-            D.f64("allD", allD);
+            D.vec("allU", allU);
+            D.vec("allV", allV);
+            D.vec("allD", allD);
         }
     }
 
@@ -318,33 +335,33 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     // Inputs are a closed-form hash of the index (reproducible from numpy: oracle/oracle.py hashed_vector),
     // so fixtures only need to store outputs.
     auto hashed = [](size_t n, unsigned salt) {
-        std::vector<double> v(n);
+        std::vector<T> v(n);
         for (size_t i = 0; i < n; i++)
-            v[i] = double((uint32_t)((uint32_t)(i + 1) * 2654435761u + salt * 40503u)) / 4294967296.0;
+            v[i] = (T)(double((uint32_t)((uint32_t)(i + 1) * 2654435761u + salt * 40503u)) / 4294967296.0);
         return v;
     };
-    std::vector<double> x = hashed(ncols, 1), xT = hashed(nrows, 2), y0 = hashed(nrows, 3), y0T = hashed(ncols, 4);
+    std::vector<T> x = hashed(ncols, 1), xT = hashed(nrows, 2), y0 = hashed(nrows, 3), y0T = hashed(ncols, 4);
     D.f64("alphabeta", {alpha, beta});
     {
-        std::vector<double> y = y0;
-        sequential_internal_add_hmatrix_vector_product('N', alpha, H, x.data(), beta, y.data());
-        D.f64("yN", y);
-        std::vector<double> yt = y0T;
-        sequential_internal_add_hmatrix_vector_product('T', alpha, H, xT.data(), beta, yt.data());
-        D.f64("yT", yt);
+        std::vector<T> y = y0;
+        sequential_internal_add_hmatrix_vector_product('N', (T)alpha, H, x.data(), (T)beta, y.data());
+        D.vec("yN", y);
+        std::vector<T> yt = y0T;
+        sequential_internal_add_hmatrix_vector_product('T', (T)alpha, H, xT.data(), (T)beta, yt.data());
+        D.vec("yT", yt);
     }
     if (rank < 0 && square) {
         // user-numbering front end (a16)
-        std::vector<double> y = y0;
-        add_hmatrix_vector_product('N', alpha, H, x.data(), beta, y.data());
-        D.f64("yN_user", y);
+        std::vector<T> y = y0;
+        add_hmatrix_vector_product('N', (T)alpha, H, x.data(), (T)beta, y.data());
+        D.vec("yN_user", y);
     }
     // multi-RHS row-major (a18), mu = 3
     {
         int mu                = 2;
-        std::vector<double> X = hashed(ncols * (size_t)mu, 5), Y = hashed(nrows * (size_t)mu, 6);
-        sequential_internal_add_hmatrix_matrix_product_row_major('N', 'N', alpha, H, X.data(), beta, Y.data(), mu);
-        D.f64("YNrm", Y, {(uint64_t)nrows, (uint64_t)mu});
+        std::vector<T> X = hashed(ncols * (size_t)mu, 5), Y = hashed(nrows * (size_t)mu, 6);
+        sequential_internal_add_hmatrix_matrix_product_row_major('N', 'N', (T)alpha, H, X.data(), (T)beta, Y.data(), mu);
+        D.vec("YNrm", Y, {(uint64_t)nrows, (uint64_t)mu});
     }
 
     // stats (hmatrix_output.hpp:153-175 semantics)
@@ -369,14 +386,14 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     double t_build = std::chrono::duration<double>(t3 - t2).count();
     double t_mv    = 0;
     if (time_reps > 0) {
-        std::vector<double> y(nrows, 0.);
+        std::vector<T> y(nrows, 0.);
         double best = 1e30;
         for (int r = 0; r < time_reps; r++) {
             auto a = std::chrono::steady_clock::now();
             if (par)
-                openmp_internal_add_hmatrix_vector_product('N', 1., H, x.data(), 0., y.data());
+                openmp_internal_add_hmatrix_vector_product('N', T(1.), H, x.data(), T(0.), y.data());
             else
-                sequential_internal_add_hmatrix_vector_product('N', 1., H, x.data(), 0., y.data());
+                sequential_internal_add_hmatrix_vector_product('N', T(1.), H, x.data(), T(0.), y.data());
             auto b = std::chrono::steady_clock::now();
             best   = std::min(best, std::chrono::duration<double>(b - a).count());
         }
@@ -402,7 +419,7 @@ static int run_lrmat(std::map<std::string, std::string> &kv) {
     ClusterTreeBuilder<double> ctb;
     Cluster<double> t = ctb.create_cluster_tree(nr, 3, xt.data(), 2, 2);
     Cluster<double> s = ctb.create_cluster_tree(nc, 3, xt.data(), 2, 2);
-    InvDistGenerator A(3, xt, xs, 0., 4 * M_PI);
+    InvDistGenerator<double> A(3, xt, xs, 0., 4 * M_PI);
     Dump D(out);
     D.f64("xt", xt, {(uint64_t)nr, 3});
     D.f64("xs", xs, {(uint64_t)nc, 3});
@@ -431,7 +448,7 @@ int main(int argc, char **argv) {
     auto kv          = parse(argc, argv);
     std::string mode = gets(kv, "mode", "hmat");
     if (mode == "hmat")
-        return run_hmat(kv);
+        return gets(kv, "prec", "f64") == "f32" ? run_hmat<float>(kv) : run_hmat<double>(kv);
     if (mode == "lrmat")
         return run_lrmat(kv);
     fprintf(stderr, "unknown mode\n");

@@ -54,6 +54,10 @@ CASES = {
     "ball_n1500_eps1e-12": ("hmat", dict(n=1500, geom="ball", leaf=50, eps=1e-12, eta=10, compressor="partialACA", dump_blocks=1)),
     "ball_n1500_eps1e-8": ("hmat", dict(n=1500, geom="ball", leaf=100, eps=1e-8, eta=10, compressor="partialACA", dump_blocks=1)),
     "ball_n300_small": ("hmat", dict(n=300, geom="ball", leaf=100, eps=1e-4, compressor="partialACA", partitions=4, dump_blocks=1)),
+    # fp32 coefficients, fp64 geometry: htool's HMatrix<float,double> (BASELINE config 5 precision)
+    "ellipse_n3000_f32_partial": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, eta=10, compressor="partialACA", prec="f32")),
+    "ellipse_n3000_f32_symL_eps1e-6": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-6, eta=10, sym="S", uplo="L", compressor="sympartialACA", prec="f32")),
+    "ball_n2000_f32_p2_rank1": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitions=2, rank=1, compressor="partialACA", prec="f32", dump_blocks=1)),
     # other compressors
     "ball_n1200_fullACA": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="fullACA", dump_blocks=2)),
     "ball_n1200_SVD": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="SVD", dump_blocks=2)),

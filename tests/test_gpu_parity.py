@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import htool_amd as hm
-from helpers import HMAT_CASES, load, params, rel_err
+from helpers import F32_CASES, HMAT_CASES, load, params, rel_err
 from test_host_structure import build_trees
 
 pytestmark = pytest.mark.gpu
@@ -355,3 +355,40 @@ def test_fp32_coefficients_against_fp64_engine():
         hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H64, X, 0.0, Y64, 4)
         hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H32, X.astype(np.float32), 0.0, Y32, 4)
         assert rel_err(Y32, Y64) < 2e-5
+
+
+@pytest.mark.parametrize("name", F32_CASES)
+def test_fp32_engine_against_reference(name):
+    """fp32 engine vs htool's own HMatrix<float,double> results (fixtures generated by the reference): structure
+    bit-exact, dense entries bit-exact (fp64 kernel value rounded to float), ranks equal at eps >= 1e-4 (within 3 on
+    the fp32 noise floor, eps = 1e-6), products within the fp32 bar of SURVEY.md App. D (1e-5 relative)."""
+    p, g = params(name), load(name)
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    tb.set_low_rank_generator(p["compressor"])
+    H = tb.build(hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]), T, S, p["rank"], p["rank"], dtype=np.float32)
+    tab, ref = H.leaf_table(), g["leaves"]
+    assert np.array_equal(tab[:, :4], ref[:, :4]) and np.array_equal(tab[:, 5], ref[:, 5])
+    if p["eps"] >= 1e-4:
+        assert np.array_equal(tab[:, 4], ref[:, 4])
+    else:
+        assert np.array_equal(tab[:, 4] < 0, ref[:, 4] < 0) and np.abs(tab[:, 4] - ref[:, 4]).max() <= 3
+    for k in g:
+        if k.startswith("D_"):
+            assert np.array_equal(H.get_block(int(k[2:])).astype(np.float64), g[k].T)
+        if k.startswith("U_"):
+            b = int(k[2:])
+            U, V = H.get_block(b)
+            assert rel_err(U.astype(np.float64) @ V.astype(np.float64), g[k].T @ g["V_%d" % b].T) < 2e-5
+    from oracle.oracle import hashed_vector
+    nr, nc = H.nb_rows(), H.nb_cols()
+    alpha, beta = g["alphabeta"]
+    y = hashed_vector(nr, 3).astype(np.float32)
+    hm.internal_add_hmatrix_vector_product("N", alpha, H, hashed_vector(nc, 1).astype(np.float32), beta, y)
+    assert rel_err(y, g["yN"]) < 1e-5
+    y = hashed_vector(nc, 4).astype(np.float32)
+    hm.internal_add_hmatrix_vector_product("T", alpha, H, hashed_vector(nr, 2).astype(np.float32), beta, y)
+    assert rel_err(y, g["yT"]) < 1e-5
+    Y = hashed_vector(nr * 2, 6).reshape(nr, 2).astype(np.float32)
+    hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, hashed_vector(nc * 2, 5).reshape(nc, 2).astype(np.float32), beta, Y, 2)
+    assert rel_err(Y, g["YNrm"]) < 1e-5

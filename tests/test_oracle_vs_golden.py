@@ -122,3 +122,38 @@ def test_compressors_on_reference_test_block(name):
             for k in range(1, 6):
                 _, Uk, Vk, _, _ = O.compress_block(T, S, comp, nr, nc, 0, 0, 1e-4, reqrank=k)
                 assert abs(np.linalg.norm(A - Uk @ Vk) - np.sqrt((sing[k:] ** 2).sum())) < 1e-10
+
+
+from helpers import F32_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", F32_CASES)
+def test_fp32_oracle_against_reference(name):
+    """HMatrix<float,double>: structure bit-exact (geometry is fp64), dense entries = fp64 entries rounded to float
+    (bit-exact), ranks equal, factors / products to float rounding."""
+    g, p = load(name), params(name)
+    xt = O.geometry(p["geom"], p["n"])
+    T = O.ClusterTree(xt, p["leaf"], p["children"], p["partitions"], p["partitioning"])
+    H = O.HMatrix(T, T, delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
+                  compressor=p["compressor"], rank=p["rank"], f32=True)
+    assert np.array_equal(H.leaves[:, :4], g["leaves"][:, :4]) and np.array_equal(H.leaves[:, 5], g["leaves"][:, 5])
+    if p["eps"] >= 1e-4:
+        assert np.array_equal(H.leaves[:, 4], g["leaves"][:, 4])
+    else:
+        # eps = 1e-6 sits on the fp32 noise floor: the ACA stopping estimate (BLAS sdot / saxpy in the reference, summation
+        # order and FMA use vendor-defined) decides +-a few iterations differently; SURVEY.md App. D states the fp32 bar
+        # as ~1e-5 relative on the product
+        assert np.array_equal(H.leaves[:, 4] < 0, g["leaves"][:, 4] < 0)
+        assert np.abs(H.leaves[:, 4] - g["leaves"][:, 4]).max() <= 3
+    for k in g:
+        if k.startswith("D_"):
+            assert np.array_equal(H.block(int(k[2:])), g[k].T)
+        if k.startswith("U_"):
+            b = int(k[2:])
+            U, V = H.block(b)
+            assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 2e-5
+    nr, nc = H.rootinfo[1], H.rootinfo[3]
+    f = lambda n, s: O.hashed_vector(n, s).astype(np.float32).astype(np.float64)
+    alpha, beta = g["alphabeta"]
+    assert rel_err(H.matvec(f(nc, 1), "N", alpha, beta, f(nr, 3)), g["yN"]) < 1e-5
+    assert rel_err(H.matvec(f(nr, 2), "T", alpha, beta, f(nc, 4)), g["yT"]) < 1e-5
