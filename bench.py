@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sym", default="N", help="symmetry of the builder: N, or S (lower storage, sympartialACA)")
     ap.add_argument("--trans", default="N")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="coefficient precision (f32 = htool's HMatrix<float,double>)")
     ap.add_argument("--force-dist", action="store_true", help="run the row-partition + collective code path even with one rank (testing)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: build and time only the block rows of --emulate-rank out of this many partitions (per-rank cost of a multi-GPU run, no collective)")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -180,7 +181,10 @@ def main():
     t0 = time.time()
     part = use_dist
     brank = args.emulate_rank if emu else (rank if part else -1)
-    H = tb.build(gen, T, T, brank, brank, device=local_rank)
+    np_dt = np.float32 if args.dtype == "f32" else np.float64
+    t_dt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4.0 if args.dtype == "f32" else 8.0
+    H = tb.build(gen, T, T, brank, brank, device=local_rank, dtype=np_dt)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     st = H.stats()
@@ -192,14 +196,14 @@ def main():
     tp = D.PartitionFromCluster(T)
     A = D.DistributedOperator(tp, tp)
     A.add_global_to_local_operator(D.RestrictedGlobalToLocalHMatrix(H))
-    xin = torch.from_numpy(np.random.default_rng(1).random(n)).to(dev)  # partition numbering, resident in HBM
-    y = torch.zeros(n, dtype=torch.float64, device=dev)
-    y_loc = torch.zeros(H.nb_rows(), dtype=torch.float64, device=dev)
+    xin = torch.from_numpy(np.random.default_rng(1).random(n).astype(np_dt)).to(dev)  # partition numbering, resident in HBM
+    y = torch.zeros(n, dtype=t_dt, device=dev)
+    y_loc = torch.zeros(H.nb_rows(), dtype=t_dt, device=dev)
 
     mu = args.mu
     if mu > 1:
-        Xmu = torch.from_numpy(np.random.default_rng(2).random((n, mu))).to(dev)
-        Ymu = torch.zeros((H.nb_rows(), mu), dtype=torch.float64, device=dev)
+        Xmu = torch.from_numpy(np.random.default_rng(2).random((n, mu)).astype(np_dt)).to(dev)
+        Ymu = torch.zeros((H.nb_rows(), mu), dtype=t_dt, device=dev)
 
     def step():
         if mu > 1:
@@ -267,7 +271,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    b_alg = torch.tensor([8.0 * (st["cgen_dense"] + st["cgen_lowrank"] + mu * (n + H.nb_rows()))], dtype=torch.float64, device=dev)
+    b_alg = torch.tensor([esz * (st["cgen_dense"] + st["cgen_lowrank"] + mu * (n + H.nb_rows()))], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(b_alg, op=dist.ReduceOp.SUM)
@@ -287,8 +291,8 @@ def main():
             acc.setdefault(name, []).append(ms)
     H.set_profiling(False)
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
-    exp_bytes = 8.0 * (st["expand_coeffs"] + st["a_total"] + n + H.nb_rows())
-    red_bytes = 8.0 * (st["reduce_coeffs"] + st["a_total"] + n)
+    exp_bytes = esz * (st["expand_coeffs"] + st["a_total"] + n + H.nb_rows())
+    red_bytes = esz * (st["reduce_coeffs"] + st["a_total"] + n)
     exp_ms = kern_ms.get("expand_kernel" if mu == 1 else "expand_mu_kernel", float("nan"))
     achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
     traffic = None
@@ -307,14 +311,14 @@ def main():
     roofline["frac_of_measured_copy"] = achieved / bw.value if bw.value > 0 else None
 
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(mu=mu, sym=args.sym, trans=args.trans, workload="H-matvec N=%d fp64, eta=%g, partialACA eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, args.eta, args.eps, args.leaf, args.geom, d),
+               ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype=args.dtype, data="synthetic",
+               config=dict(mu=mu, sym=args.sym, trans=args.trans, workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, "fp32" if args.dtype == "f32" else "fp64", args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
                            parallelism=("row-partition x%d + all-gather%s" % (world, ", step replayed from a HIP graph" if graphed else "")) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
                            build_s=dict(cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
                roofline=roofline)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
         try:
             cb, y_cpu, cut = cpu_baseline(H, T, args.cpu_sample_frac, log)
             # the same sample through the engine: parity on the slab while we are at it

@@ -34,7 +34,9 @@ struct HMat {
     int T0 = 0, nT = 0, S0 = 0, nS = 0;
     int nT_total = 0, nS_total = 0;
     char symmetry_for_leaves = 'N', uplo_for_leaves = 'N';
-    bool has_mirror = false;
+    bool has_mirror = false;   // the block tree has leaves_for_symmetry
+    bool sym_expanded = false; // ... and they were laid out explicitly (no mirror pass needed)
+    std::vector<int64_t> staged_off;
     std::vector<int32_t> perm_t, perm_s; // full permutations (cluster -> user)
     bool t_root_is_tree_root = false, perm_local = false;
 
@@ -44,7 +46,7 @@ struct HMat {
     DArr<double> tx, ty, tz, sx, sy, sz; // cluster-order coordinates (SoA)
 
     // per-leaf metadata on device
-    DArr<int32_t> d_t_off, d_t_size, d_s_off, d_s_size, d_rank, d_swapped, d_sym_uplo;
+    DArr<int32_t> d_t_off, d_t_size, d_s_off, d_s_size, d_rank, d_swapped, d_sym_uplo, d_transposed;
     DArr<int64_t> d_colptr, d_cross_off, d_staged_off;
     std::vector<int64_t> colptr;
     std::vector<int32_t> swapped;
@@ -85,8 +87,38 @@ struct HMat {
 
 static int build_streams(HMat &H) {
     Timer tim;
-    const int64_t nb = (int64_t)H.leaves.size();
+    const int64_t nb_real = (int64_t)H.leaves.size();
     constexpr int TR_MAX = 64, SR_MAX = 512;
+    // Symmetric storage ('S','L'/'U'): by default every leaf of leaves_for_symmetry is ALSO laid out as its transpose
+    // (same crosses, roles of U and V exchanged; same dense generator), i.e. the streams hold the full operator and
+    // the product is a single untransposed pass through the tuned kernels (incl. the fused multi-RHS path).
+    // That costs the memory symmetric storage would save; HMX_SYM_COMPACT=1 keeps the compact form and uses the
+    // mirror pass (colreduce/rowreduce kernels) instead.  Measured at N=1e6 fp64: 3.0 ms expanded vs 3.9 ms compact.
+    H.sym_expanded = H.has_mirror && !(getenv("HMX_SYM_COMPACT") && atoi(getenv("HMX_SYM_COMPACT")));
+    std::vector<hmx_leaf> XL = H.leaves;
+    std::vector<int> XK      = H.kind;
+    std::vector<int64_t> xcolptr = H.colptr, xstaged = H.staged_off;
+    std::vector<int32_t> xswapped = H.swapped, xtransposed(nb_real, 0);
+    xcolptr.resize(nb_real, 0);
+    xstaged.resize(nb_real, -1);
+    xswapped.resize(nb_real, 0);
+    if (H.sym_expanded)
+        for (int64_t b = 0; b < nb_real; b++) {
+            if (!H.leaves[b].mirror)
+                continue;
+            hmx_leaf v = H.leaves[b];
+            std::swap(v.t_offset, v.s_offset);
+            std::swap(v.t_size, v.s_size);
+            v.mirror = 0;
+            XL.push_back(v);
+            XK.push_back(H.kind[b]);
+            xcolptr.push_back(xcolptr[b]);
+            xstaged.push_back(xstaged[b]);
+            xswapped.push_back(xswapped[b] ? 0 : 1);
+            xtransposed.push_back(1);
+        }
+    const int64_t nb = (int64_t)XL.size();
+    const bool mirror_flags = H.has_mirror && !H.sym_expanded;
     // ---- ranges ---------------------------------------------------------------------------------
     // E ranges partition the local rows at every block boundary (each output row has exactly one owner).
     // R ranges are per DISTINCT source cluster of the low-rank leaves (cut into pieces of <= SR_MAX rows): a
@@ -95,10 +127,10 @@ static int build_streams(HMat &H) {
     std::vector<int> tbp{H.T0, H.T0 + H.nT};
     std::vector<std::pair<int, int>> sclusters;
     for (int64_t b = 0; b < nb; b++) {
-        const hmx_leaf &l = H.leaves[b];
+        const hmx_leaf &l = XL[b];
         tbp.push_back(l.t_offset);
         tbp.push_back(l.t_offset + l.t_size);
-        if (H.kind[b] == LK_LOWRANK && l.rank > 0)
+        if (XK[b] == LK_LOWRANK && l.rank > 0)
             sclusters.emplace_back(l.s_offset, l.s_size);
     }
     std::sort(sclusters.begin(), sclusters.end());
@@ -139,8 +171,8 @@ static int build_streams(HMat &H) {
     H.stats.rank_min = 1 << 30;
     double rank_sum  = 0;
     for (int64_t b = 0; b < nb; b++) {
-        const hmx_leaf &l = H.leaves[b];
-        const bool lr     = H.kind[b] == LK_LOWRANK;
+        const hmx_leaf &l = XL[b];
+        const bool lr     = XK[b] == LK_LOWRANK;
         if (lr && l.rank <= 0)
             continue; // rank-0 low-rank block: contributes nothing (add_lrmat_vector_product.hpp:11)
         const int ncols = lr ? l.rank : l.s_size;
@@ -169,12 +201,14 @@ static int build_streams(HMat &H) {
                 rlr_c.push_back(R.cols[r]);
                 R.cols[r] += l.rank;
             }
-            H.stats.n_lowrank++;
-            H.stats.cgen_lowrank += (int64_t)l.rank * (l.t_size + l.s_size);
-            H.stats.rank_min = std::min(H.stats.rank_min, l.rank);
-            H.stats.rank_max = std::max(H.stats.rank_max, l.rank);
-            rank_sum += l.rank;
-        } else {
+            if (b < nb_real) { // statistics describe the stored leaves (htool's definitions), not the mirrored copies
+                H.stats.n_lowrank++;
+                H.stats.cgen_lowrank += (int64_t)l.rank * (l.t_size + l.s_size);
+                H.stats.rank_min = std::min(H.stats.rank_min, l.rank);
+                H.stats.rank_max = std::max(H.stats.rank_max, l.rank);
+                rank_sum += l.rank;
+            }
+        } else if (b < nb_real) {
             H.stats.n_dense++;
             H.stats.cgen_dense += (int64_t)l.t_size * l.s_size;
         }
@@ -247,17 +281,17 @@ static int build_streams(HMat &H) {
     const int64_t zA = H.nS, zP = H.nS + A_total;
     H.zero_slot      = H.nS + A_total + P_total;
     H.h_e_zidx.assign(E.total_cols, 0);
-    H.h_e_mirrorflag.assign(H.has_mirror ? E.total_cols : 0, 0);
+    H.h_e_mirrorflag.assign(mirror_flags ? E.total_cols : 0, 0);
     auto fill_e = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
         for (size_t p = 0; p < pb.size(); p++) {
             const int b = pb[p], r = pr[p];
-            const hmx_leaf &l = H.leaves[b];
+            const hmx_leaf &l = XL[b];
             const int ncols   = lr ? l.rank : l.s_size;
             const int64_t z0  = lr ? zA + aoff[b] : (int64_t)(l.s_offset - H.S0);
             int32_t *dst      = H.h_e_zidx.data() + E.colbase[r] + pc[p];
             for (int j = 0; j < ncols; j++)
                 dst[j] = (int32_t)(z0 + j);
-            if (H.has_mirror && l.mirror)
+            if (mirror_flags && l.mirror)
                 std::fill_n(H.h_e_mirrorflag.data() + E.colbase[r] + pc[p], ncols, 1);
         }
     };
@@ -265,25 +299,25 @@ static int build_streams(HMat &H) {
     fill_e(ed_b, ed_r, ed_c, false);
     std::vector<int32_t> h_outidx(R.total_cols, 0);
     H.h_r_aidx.assign(R.total_cols, 0);
-    H.h_r_mirrorflag.assign(H.has_mirror ? R.total_cols : 0, 0);
+    H.h_r_mirrorflag.assign(mirror_flags ? R.total_cols : 0, 0);
     for (size_t p = 0; p < rlr_b.size(); p++) {
         const int b = rlr_b[p], r = rlr_r[p];
-        const hmx_leaf &l = H.leaves[b];
+        const hmx_leaf &l = XL[b];
         const int64_t cb  = R.colbase[r] + rlr_c[p];
         for (int k = 0; k < l.rank; k++) {
             H.h_r_aidx[cb + k] = (int32_t)(aoff[b] + k);
             h_outidx[cb + k]   = ns_of[b] == 1 ? (int32_t)(zA + aoff[b] + k) : (int32_t)(zP + poff[b] + (int64_t)(r - s_first[b]) * l.rank + k);
-            if (H.has_mirror && l.mirror)
+            if (mirror_flags && l.mirror)
                 H.h_r_mirrorflag[cb + k] = 1;
         }
     }
     std::vector<int32_t> cd, cs, cst, cc;
     for (int64_t b = 0; b < nb; b++)
         if (poff[b] >= 0)
-            for (int k = 0; k < H.leaves[b].rank; k++) {
+            for (int k = 0; k < XL[b].rank; k++) {
                 cd.push_back((int32_t)(zA + aoff[b] + k));
                 cs.push_back((int32_t)(zP + poff[b] + k));
-                cst.push_back(H.leaves[b].rank);
+                cst.push_back(XL[b].rank);
                 cc.push_back(ns_of[b]);
             }
     H.n_combine = (int)cd.size();
@@ -293,7 +327,7 @@ static int build_streams(HMat &H) {
         auto fill_t = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
             for (size_t p = 0; p < pb.size(); p++) {
                 const int b = pb[p], r = pr[p];
-                const hmx_leaf &l = H.leaves[b];
+                const hmx_leaf &l = XL[b];
                 const int ncols   = lr ? l.rank : l.s_size;
                 int32_t *dst      = H.h_e_tdst_all.data() + E.colbase[r] + pc[p];
                 for (int j = 0; j < ncols; j++) // dense: global source position (shifted at use); low rank: -(2 + a index)
@@ -328,12 +362,29 @@ static int build_streams(HMat &H) {
     // ---- pack ---------------------------------------------------------------------------------------------
     std::vector<int32_t> ranks(nb), symu(nb, 0);
     for (int64_t b = 0; b < nb; b++) {
-        ranks[b] = H.leaves[b].rank;
-        if (H.leaves[b].symmetric && H.kind[b] == LK_DENSE_STAGED)
+        ranks[b] = XL[b].rank;
+        if (XL[b].symmetric && XK[b] == LK_DENSE_STAGED)
             symu[b] = H.uplo_for_leaves == 'L' ? 1 : (H.uplo_for_leaves == 'U' ? 2 : 0);
     }
     HMX_HIP(H.d_rank.upload(ranks));
     HMX_HIP(H.d_sym_uplo.upload(symu));
+    {
+        std::vector<int32_t> a(nb), bb(nb), c(nb), d(nb);
+        for (int64_t i = 0; i < nb; i++) {
+            a[i]  = XL[i].t_offset;
+            bb[i] = XL[i].t_size;
+            c[i]  = XL[i].s_offset;
+            d[i]  = XL[i].s_size;
+        }
+        HMX_HIP(H.d_t_off.upload(a));
+        HMX_HIP(H.d_t_size.upload(bb));
+        HMX_HIP(H.d_s_off.upload(c));
+        HMX_HIP(H.d_s_size.upload(d));
+        HMX_HIP(H.d_colptr.upload(xcolptr));
+        HMX_HIP(H.d_swapped.upload(xswapped));
+        HMX_HIP(H.d_staged_off.upload(xstaged));
+        HMX_HIP(H.d_transposed.upload(xtransposed));
+    }
     hipEvent_t e0, e1;
     HMX_HIP(hipEventCreate(&e0));
     HMX_HIP(hipEventCreate(&e1));
@@ -365,7 +416,7 @@ static int build_streams(HMat &H) {
             HMX_HIP(pr.upload(ed_r));
             HMX_HIP(pc.upload(ed_c));
             PackDenseArgs P{H.ks, H.tx.d, H.ty.d, H.tz.d, H.sx.d, H.sy.d, H.sz.d, pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d,
-                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.pool.d, E.stream.d, H.T0};
+                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.pool.d, E.stream.d, H.T0};
             hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)ed_b.size()), dim3(256), 0, 0, P, (int64_t)ed_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -384,8 +435,8 @@ static int build_streams(HMat &H) {
     H.stats.a_total       = A_total;
     H.stats.reduce_coeffs = 0;
     for (int64_t b = 0; b < nb; b++)
-        if (H.kind[b] == LK_LOWRANK && H.leaves[b].rank > 0)
-            H.stats.reduce_coeffs += (int64_t)H.leaves[b].rank * H.leaves[b].s_size;
+        if (XK[b] == LK_LOWRANK && XL[b].rank > 0)
+            H.stats.reduce_coeffs += (int64_t)XL[b].rank * XL[b].s_size;
     H.finalized          = true;
     return HMX_OK;
 }
@@ -399,20 +450,20 @@ static int ensure_transposed_indices(HMat &H) {
     std::vector<int32_t> tall(nE), tmir(nE), call(nR), cmir(nR), zmir(nE);
     for (int64_t c = 0; c < nE; c++) {
         const int32_t v  = H.h_e_tdst_all[c];
-        const bool mir   = H.has_mirror && H.h_e_mirrorflag[c];
+        const bool mir   = H.has_mirror && !H.sym_expanded && H.h_e_mirrorflag[c];
         const bool lr    = v <= -2;
         tall[c]          = lr ? (int32_t)(H.nS + (-2 - v)) : v - H.S0;
         tmir[c]          = !mir ? -1 : (lr ? (int32_t)(H.nT + (-2 - v)) : v - H.T0);
         zmir[c]          = mir ? H.h_e_zidx[c] : (int32_t)H.zero_slot;
     }
     for (int64_t c = 0; c < nR; c++) {
-        const bool mir = H.has_mirror && H.h_r_mirrorflag[c];
+        const bool mir = H.has_mirror && !H.sym_expanded && H.h_r_mirrorflag[c];
         call[c]        = (int32_t)(H.nS + H.h_r_aidx[c]);
         cmir[c]        = mir ? (int32_t)(H.nT + H.h_r_aidx[c]) : -1;
     }
     HMX_HIP(H.e_tdst.upload(tall));
     HMX_HIP(H.r_tcoef.upload(call));
-    if (H.has_mirror) {
+    if (H.has_mirror && !H.sym_expanded) {
         HMX_HIP(H.e_tdst_mirror.upload(tmir));
         HMX_HIP(H.r_tcoef_mirror.upload(cmir));
         HMX_HIP(H.e_zidx_mirror.upload(zmir));
@@ -592,11 +643,11 @@ static int matvec_device(HMat &H, char trans, real alpha, const real *in, real b
     int rc;
     if (trans == 'N') {
         rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st);
-        if (rc == HMX_OK && H.has_mirror)
+        if (rc == HMX_OK && H.has_mirror && !H.sym_expanded)
             rc = run_transposed(H, true, in, alpha, 1.0, out, st);
     } else {
         rc = run_transposed(H, false, in, alpha, beta, out, st);
-        if (rc == HMX_OK && H.has_mirror) {
+        if (rc == HMX_OK && H.has_mirror && !H.sym_expanded) {
             // mirror leaves applied un-transposed: input indexed by target positions, output by source positions
             rc = run_forward(H, H.e_zidx_mirror.d, in, 1, alpha, 1.0, out + (H.T0 - H.S0), st);
         }
@@ -769,8 +820,8 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     HMX_HIP(H.d_rank.zero());
     HMX_HIP(H.d_swapped.alloc(std::max<size_t>(nb, 1)));
     HMX_HIP(H.d_swapped.zero());
-    std::vector<int64_t> staged(nb, -1);
-    HMX_HIP(H.d_staged_off.upload(staged));
+    H.staged_off.assign(nb, -1);
+    HMX_HIP(H.d_staged_off.upload(H.staged_off));
 
     hipEvent_t e0, e1;
     HMX_HIP(hipEventCreate(&e0));
@@ -978,6 +1029,7 @@ static int api_finalize(HMat *Hp) {
     HMX_HIP(H.d_colptr.upload(H.colptr));
     HMX_HIP(H.d_swapped.upload(H.swapped));
     HMX_HIP(H.d_staged_off.upload(staged));
+    H.staged_off = staged;
     if (!H.has_kernel) { // pack_dense never evaluates the generator on this path, but needs valid pointers
         H.ks = KernelSpec{0, 3, 0, 0};
     }
@@ -1168,7 +1220,7 @@ static int api_matmat_row_major(HMat *Hp, char trans, real alpha, const real *in
         HMX_HIP(H.tmp_in2.alloc(nin));
     if (H.tmp_out2.n < (size_t)nout)
         HMX_HIP(H.tmp_out2.alloc(nout));
-    if (trans == 'N' && !H.has_mirror && H.finalized && !getenv("HMX_NO_FUSED_MU")) {
+    if (trans == 'N' && (!H.has_mirror || H.sym_expanded) && H.finalized && !getenv("HMX_NO_FUSED_MU")) {
         // fused path: the streams are read once for up to 16 right-hand sides
         H.ev_names.clear();
         prof_mark(H, st, "begin");

@@ -571,6 +571,7 @@ struct PackDenseArgs {
     const int32_t *t_off, *t_size, *s_off, *s_size;
     const int64_t *staged_off; // >= 0: uploaded dense block (column-major M x N) in `pool`; < 0: generate
     const int32_t *sym_uplo;   // 0 none, 1 'L', 2 'U' : uploaded symmetric leaf, only that triangle is valid
+    const int32_t *transposed; // 1: this entry is the mirrored copy of a stored leaf -- read the staged block transposed
     const real *pool;
     real *stream;
     int origin; // T0
@@ -600,7 +601,7 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
                 ii          = jj;
                 jj          = t;
             }
-            v = P.pool[st + ii + (int64_t)M * jj];
+            v = P.transposed[b] ? P.pool[st + jj + (int64_t)N * ii] : P.pool[st + ii + (int64_t)M * jj];
         } else {
             v = eval_kernel(P.ks, P.tx[row0 + i], P.ty[row0 + i], P.tz[row0 + i], P.sx[c0 + j], P.sy[c0 + j], P.sz[c0 + j]);
         }

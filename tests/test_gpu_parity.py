@@ -392,3 +392,29 @@ def test_fp32_engine_against_reference(name):
     Y = hashed_vector(nr * 2, 6).reshape(nr, 2).astype(np.float32)
     hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, hashed_vector(nc * 2, 5).reshape(nc, 2).astype(np.float32), beta, Y, 2)
     assert rel_err(Y, g["YNrm"]) < 1e-5
+
+
+SYM_CASES = [c for c in ACA_CASES if params(c)["sym"] == "S"]
+
+
+@pytest.mark.parametrize("name", SYM_CASES)
+def test_symmetric_storage_compact_mode(name, monkeypatch):
+    """Symmetric storage has two device layouts: expanded (default, mirrored leaves laid out explicitly) and compact
+    (HMX_SYM_COMPACT=1, mirror pass through the transposed kernels).  Both must reproduce the reference."""
+    monkeypatch.setenv("HMX_SYM_COMPACT", "1")
+    p, g = params(name), load(name)
+    T, S, H = build_engine(p)
+    assert np.array_equal(H.leaf_table(), g["leaves"])
+    x, xT, y0, y0T = inputs(H)
+    alpha, beta = g["alphabeta"]
+    y = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+    assert rel_err(y, g["yN"]) < 1e-10
+    y = y0T.copy()
+    hm.internal_add_hmatrix_vector_product("T", alpha, H, xT, beta, y)
+    assert rel_err(y, g["yT"]) < 1e-10
+    from oracle.oracle import hashed_vector
+    nr, nc = H.nb_rows(), H.nb_cols()
+    X, Y = hashed_vector(nc * 2, 5).reshape(nc, 2), hashed_vector(nr * 2, 6).reshape(nr, 2).copy()
+    hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y, 2)
+    assert rel_err(Y, g["YNrm"]) < 1e-10
