@@ -334,7 +334,15 @@ def main():
         except Exception as e:  # the baseline is a reported number, never the product path
             out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
     if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        def clean(o):  # strict JSON: no NaN / Infinity
+            if isinstance(o, dict):
+                return {k: clean(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [clean(v) for v in o]
+            if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+                return None
+            return o
+        os.write(json_fd, (json.dumps(clean(out)) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
