@@ -53,6 +53,7 @@ SYMBOLS = [
     ("hmx_cluster_tree_nodes", C.c_int, [_vp, C.POINTER(ClusterNode)]),
     ("hmx_cluster_tree_partition", C.c_int, [_vp, _ip]),
     ("hmx_block_tree_create", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("hmx_block_tree_create_local", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_block_tree_destroy", None, [_vp]),
     ("hmx_block_tree_num_leaves", C.c_int64, [_vp]),
     ("hmx_block_tree_leaves", C.c_int, [_vp, C.POINTER(Leaf)]),

@@ -291,15 +291,27 @@ class HMatrixTreeBuilder:
                                           int(self._consistent), C.byref(h)))
         return h
 
+    def _local_block_tree(self, target, source, target_partition, source_partition):
+        h = C.c_void_p()
+        check(lib().hmx_block_tree_create_local(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(), self._mint,
+                                                self._mins, target_partition, source_partition, int(self._consistent), C.byref(h)))
+        return h
+
+    def build_local_block_tree(self, target, source, target_partition, source_partition):
+        return BlockTree(self._local_block_tree(target, source, target_partition, source_partition))
+
     def build_block_tree(self, target, source, target_partition_number=-1, partition_number_for_symmetry=-1):
         return BlockTree(self._block_tree(target, source, target_partition_number, partition_number_for_symmetry))
 
     def build(self, generator, target_root_cluster_tree, source_root_cluster_tree, target_partition_number=-1,
-              partition_number_for_symmetry=-1, device=0, compress=True, dtype=np.float64):
+              partition_number_for_symmetry=-1, device=0, compress=True, dtype=np.float64, local_partitions=None):
         """HMatrixTreeBuilder::build (tree_builder.hpp:199-210).  With compress=False only the structure is
         created on the device and blocks are expected through HMatrix.set_block_*() + finalize()."""
-        bt = self._block_tree(target_root_cluster_tree, source_root_cluster_tree, target_partition_number,
-                              partition_number_for_symmetry)
+        if local_partitions is not None:  # rooted at (target partition, source partition): block-diagonal operator
+            bt = self._local_block_tree(target_root_cluster_tree, source_root_cluster_tree, *local_partitions)
+        else:
+            bt = self._block_tree(target_root_cluster_tree, source_root_cluster_tree, target_partition_number,
+                                  partition_number_for_symmetry)
         h = C.c_void_p()
         if np.dtype(dtype) == np.float32:  # HMatrix<float,double>: fp32 coefficients, fp64 geometry
             check(lib().hmx_hmatrix_create_s(bt, device, C.byref(h)))

@@ -154,17 +154,25 @@ int build_block_tree(hmx_block_tree &bt) {
         set_error("hmx_block_tree_create: partition number exceeds number of partitions");
         return HMX_ERR_INVALID;
     }
+    if (bt.target_root_partition >= np || bt.source_root_partition >= (int)S.on_partition.size()) {
+        set_error("hmx_block_tree_create_local: partition number exceeds number of partitions");
+        return HMX_ERR_INVALID;
+    }
+    // DefaultLocalApproximationBuilder (distributed_operator/utility.hpp:64-88) builds from the partition clusters
+    // themselves: same recursion, different starting pair
+    const int t_start = bt.target_root_partition >= 0 ? T.on_partition[bt.target_root_partition] : 0;
+    const int s_start = bt.source_root_partition >= 0 ? S.on_partition[bt.source_root_partition] : 0;
     Walker W(bt);
-    const int root = W.make(0, 0);
+    const int root = W.make(t_start, s_start);
     W.arena[root].symmetric = false; // the root is flagged after re-rooting (tree_builder.hpp:408-410)
     W.descend(root);
 
     // reset_root_of_block_tree (tree_builder.hpp:533-566): when the root's target cluster is not the
     // requested partition, the new root adopts every node whose target cluster has that rank, in the
     // order an explicit LIFO stack discovers them.
-    int root_t = 0;
+    int root_t = t_start;
     std::vector<int> top = W.arena[root].children;
-    if (!W.in_partition(T.nodes[0])) {
+    if (!W.in_partition(T.nodes[t_start])) {
         std::vector<int> adopted, stack{root};
         while (!stack.empty()) {
             const int cur = stack.back();
@@ -182,12 +190,12 @@ int build_block_tree(hmx_block_tree &bt) {
     }
     W.arena[root].children  = top;
     W.arena[root].t         = root_t;
-    W.arena[root].symmetric = W.diagonal(T.nodes[root_t], S.nodes[0]);
+    W.arena[root].symmetric = W.diagonal(T.nodes[root_t], S.nodes[s_start]);
 
     bt.root_t_offset = T.nodes[root_t].offset;
     bt.root_t_size   = T.nodes[root_t].size;
-    bt.root_s_offset = S.nodes[0].offset;
-    bt.root_s_size   = S.nodes[0].size;
+    bt.root_s_offset = S.nodes[s_start].offset;
+    bt.root_s_size   = S.nodes[s_start].size;
 
     // symmetry_for_leaves of the root (tree_builder.hpp:134-150)
     bool flagged = false;

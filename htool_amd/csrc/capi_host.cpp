@@ -113,6 +113,32 @@ int hmx_block_tree_create(const hmx_cluster_tree *target, const hmx_cluster_tree
     *out = bt;
     return HMX_OK;
 }
+int hmx_block_tree_create_local(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry, char uplo,
+                                int min_target_depth, int min_source_depth, int target_partition, int source_partition,
+                                int block_tree_consistency, hmx_block_tree **out) {
+    if (!target || !source || !out || target_partition < 0 || source_partition < 0) {
+        hmx::set_error("hmx_block_tree_create_local: invalid argument");
+        return HMX_ERR_INVALID;
+    }
+    auto *bt                  = new hmx_block_tree();
+    bt->target                = target;
+    bt->source                = source;
+    bt->eta                   = eta;
+    bt->symmetry              = symmetry;
+    bt->uplo                  = uplo;
+    bt->min_target_depth      = min_target_depth;
+    bt->min_source_depth      = min_source_depth;
+    bt->target_root_partition = target_partition;
+    bt->source_root_partition = source_partition;
+    bt->consistent            = block_tree_consistency != 0;
+    const int rc              = hmx::build_block_tree(*bt);
+    if (rc != HMX_OK) {
+        delete bt;
+        return rc;
+    }
+    *out = bt;
+    return HMX_OK;
+}
 void hmx_block_tree_destroy(hmx_block_tree *bt) { delete bt; }
 int64_t hmx_block_tree_num_leaves(const hmx_block_tree *bt) { return bt ? (int64_t)bt->leaves.size() : 0; }
 int hmx_block_tree_leaves(const hmx_block_tree *bt, hmx_leaf *out) {

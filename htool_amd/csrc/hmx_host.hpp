@@ -53,6 +53,7 @@ struct hmx_block_tree {
     char symmetry = 'N', uplo = 'N';
     int min_target_depth = 0, min_source_depth = 0;
     int target_partition = -1, partition_for_symmetry = -1;
+    int target_root_partition = -1, source_root_partition = -1; // >= 0: the block tree is rooted at these partition clusters
     bool consistent = true;
     // root after reset_root_of_block_tree
     int root_t_offset = 0, root_t_size = 0, root_s_offset = 0, root_s_size = 0;

@@ -76,6 +76,41 @@ class RestrictedGlobalToLocalHMatrix:
         from . import api
         api.internal_add_hmatrix_matrix_product_row_major(trans, alpha, self.hmatrix, X, beta, Y, mu)
 
+    def add_sub_matrix_product_to_local(self, X, Y, mu, offset, size):
+        add_sub_matrix_product_to_local(self, self.hmatrix.source_offset, self.hmatrix.source_size, X, Y, mu, offset, size)
+
+
+class LocalToLocalHMatrix:
+    """H-matrix on (target partition k) x (source partition k) as a local-to-local operator
+    (distributed_operator/implementations/local_to_local_operators/hmatrix.hpp:15-56): local slices in and out."""
+
+    def __init__(self, hmatrix):
+        self.hmatrix = hmatrix
+
+    def add_vector_product(self, trans, alpha, x, beta, y):
+        from . import api
+        api.internal_add_hmatrix_vector_product(trans, alpha, self.hmatrix, x, beta, y)
+
+    def add_matrix_product_row_major(self, trans, alpha, X, beta, Y, mu):
+        from . import api
+        api.internal_add_hmatrix_matrix_product_row_major(trans, alpha, self.hmatrix, X, beta, Y, mu)
+
+    def add_sub_matrix_product_to_local(self, X, Y, mu, offset, size):
+        add_sub_matrix_product_to_local(self, self.hmatrix.source_offset, self.hmatrix.source_size, X, Y, mu, offset, size)
+
+
+def add_sub_matrix_product_to_local(op, source_offset, source_size, X, Y, mu, offset, size):
+    """Y += op * (X zero-extended): X holds rows [offset, offset+size) of the source numbering, row-major with mu
+    columns (restricted_operator.hpp:170-193, local_to_local_operators/hmatrix.hpp:33-51)."""
+    lo, hi = max(offset, source_offset), min(offset + size, source_offset + source_size)
+    if offset == source_offset and hi == source_offset + source_size and size == source_size:
+        op.add_matrix_product_row_major("N", 1.0, X, 1.0, Y, mu)
+        return
+    ext = torch.zeros((source_size, mu), dtype=X.dtype, device=X.device)
+    if hi > lo:
+        ext[lo - source_offset:hi - source_offset] = X[lo - offset:hi - offset]
+    op.add_matrix_product_row_major("N", 1.0, ext, 1.0, Y, mu)
+
 
 class DistributedOperator:
     def __init__(self, target_partition, source_partition, group=None):
@@ -246,3 +281,21 @@ def internal_add_distributed_operator_matrix_product_row_major_global_to_global(
         if beta != 0:
             Y.add_(Y_old, alpha=beta)
     return Y
+
+
+class DefaultLocalApproximationBuilder:
+    """Block-diagonal operator: rank k compresses only (target partition k) x (source partition k) and registers it as a
+    local-to-local operator (distributed_operator/utility.hpp:64-88).  `block_diagonal_hmatrix` is that H-matrix."""
+
+    def __init__(self, generator, target_cluster, source_cluster, hmatrix_tree_builder, group=None, device=None, rank=None):
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if device is None:
+            device = torch.cuda.current_device()
+        self.target_partition = PartitionFromCluster(target_cluster)
+        self.source_partition = PartitionFromCluster(source_cluster)
+        self.hmatrix = hmatrix_tree_builder.build(generator, target_cluster, source_cluster, device=device, local_partitions=(rank, rank))
+        self.block_diagonal_hmatrix = self.hmatrix
+        self.local_hmatrix = LocalToLocalHMatrix(self.hmatrix)
+        self.distributed_operator = DistributedOperator(self.target_partition, self.source_partition, group)
+        self.distributed_operator.add_local_to_local_operator(self.local_hmatrix)

@@ -97,6 +97,11 @@ int hmx_cluster_tree_partition(const hmx_cluster_tree *, int32_t *offset_size /*
 int hmx_block_tree_create(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
                           char uplo, int min_target_depth, int min_source_depth, int target_partition_number,
                           int partition_number_for_symmetry, int block_tree_consistency, hmx_block_tree **out);
+/* Block tree rooted at a pair of PARTITION clusters (block-diagonal / local-to-local operator):
+ * DefaultLocalApproximationBuilder, distributed_operator/utility.hpp:64-88 */
+int hmx_block_tree_create_local(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
+                                char uplo, int min_target_depth, int min_source_depth, int target_partition,
+                                int source_partition, int block_tree_consistency, hmx_block_tree **out);
 void hmx_block_tree_destroy(hmx_block_tree *);
 int64_t hmx_block_tree_num_leaves(const hmx_block_tree *);
 int hmx_block_tree_leaves(const hmx_block_tree *, hmx_leaf *out);

@@ -618,17 +618,17 @@ static auto with_h(void *h, F &&f) {
 }
 }
 
-void *orc_hmatrix_build(void *tct, void *sct, int dim, const double *xt, const double *xs, double delta, double scale, double eps, double eta, char sym, char uplo, int reqrank, int compressor, int mint, int mins, int target_partition, int partition_for_symmetry, int consistent, int parallel, int f32) {
+void *orc_hmatrix_build(void *tct, void *sct, int dim, const double *xt, const double *xs, double delta, double scale, double eps, double eta, char sym, char uplo, int reqrank, int compressor, int mint, int mins, int target_partition, int partition_for_symmetry, int consistent, int parallel, int f32, int root_partition) {
     auto *T = static_cast<ClusterTree *>(tct);
     auto *S = static_cast<ClusterTree *>(sct);
     auto *o = new OracleH();
     o->f32  = f32 != 0;
     if (o->f32) {
         o->gs = orc::f32::Generator{dim, xt, xs, T->td.perm.data(), S->td.perm.data(), delta, scale};
-        o->s  = orc::f32::build_hmatrix(*T, *S, o->gs, (float)eps, eta, sym, uplo, reqrank, compressor, mint, mins, target_partition, partition_for_symmetry, consistent != 0, parallel != 0);
+        o->s  = orc::f32::build_hmatrix(*T, *S, o->gs, (float)eps, eta, sym, uplo, reqrank, compressor, mint, mins, target_partition, partition_for_symmetry, consistent != 0, parallel != 0, root_partition);
     } else {
         o->gd = orc::f64::Generator{dim, xt, xs, T->td.perm.data(), S->td.perm.data(), delta, scale};
-        o->d  = orc::f64::build_hmatrix(*T, *S, o->gd, eps, eta, sym, uplo, reqrank, compressor, mint, mins, target_partition, partition_for_symmetry, consistent != 0, parallel != 0);
+        o->d  = orc::f64::build_hmatrix(*T, *S, o->gd, eps, eta, sym, uplo, reqrank, compressor, mint, mins, target_partition, partition_for_symmetry, consistent != 0, parallel != 0, root_partition);
     }
     return o;
 }

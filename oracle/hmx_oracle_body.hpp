@@ -671,11 +671,13 @@ static char symmetry_for_leaves(const Block &b, char sym) {
     return res;
 }
 
-static std::unique_ptr<HMat> build_hmatrix(const ClusterTree &tt, const ClusterTree &st, const Generator &A, real eps, double eta, char sym, char uplo, int reqrank, int compressor, int mint, int mins, int target_partition, int partition_for_symmetry, bool consistent, bool parallel) {
+static std::unique_ptr<HMat> build_hmatrix(const ClusterTree &tt, const ClusterTree &st, const Generator &A, real eps, double eta, char sym, char uplo, int reqrank, int compressor, int mint, int mins, int target_partition, int partition_for_symmetry, bool consistent, bool parallel, int root_partition = -1) {
     auto H     = std::make_unique<HMat>();
     H->root    = std::make_unique<Block>();
-    H->root->t = tt.root.get();
-    H->root->s = st.root.get();
+    // root_partition >= 0: DefaultLocalApproximationBuilder (distributed_operator/utility.hpp:64-88) builds from the
+    // partition clusters themselves
+    H->root->t = root_partition >= 0 ? tt.td.on_partition[root_partition] : tt.root.get();
+    H->root->s = root_partition >= 0 ? st.td.on_partition[root_partition] : st.root.get();
     H->sym     = sym;
     H->uplo    = uplo;
     BuildParams P{eta, sym, uplo, mint, mins, target_partition, partition_for_symmetry, consistent, tt.root.get(), st.root.get()};

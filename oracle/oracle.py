@@ -48,7 +48,7 @@ def lib():
         L.orc_hmatrix_build.restype = C.c_void_p
         L.orc_hmatrix_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.c_int, C.c_int, C.c_int, C.c_int]
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_hmatrix_destroy.argtypes = [C.c_void_p]
         L.orc_hmatrix_num_leaves.argtypes = [C.c_void_p]
         L.orc_hmatrix_leaves.argtypes = [C.c_void_p, C.c_int, ip]
@@ -104,7 +104,7 @@ class HMatrix:
     """Oracle H-matrix: block tree + compressed leaves + reference-order leaf loop."""
 
     def __init__(self, tct, sct, delta=1e-5, scale=1.0, eps=1e-4, eta=10.0, sym="N", uplo="N", reqrank=-1,
-                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, f32=False, _handle=None):
+                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, f32=False, root_partition=-1, _handle=None):
         """f32=True: htool's HMatrix<float,double> -- fp32 coefficients and arithmetic, fp64 geometry.  Values cross
         this Python boundary as float64 in both cases (converted inside the library)."""
         if _handle is not None:
@@ -115,7 +115,7 @@ class HMatrix:
             self.h = lib().orc_hmatrix_build(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta,
                                              scale, eps, eta, sym.encode(), uplo.encode(), reqrank,
                                              COMPRESSORS[compressor], mindepth, mindepth, rank, rank, int(consistent),
-                                             int(parallel), int(f32))
+                                             int(parallel), int(f32), root_partition)
         n = lib().orc_hmatrix_num_leaves(self.h)
         self.leaves = np.empty((n, 6), dtype=np.int32)
         self.leaves_dfs = np.empty((n, 6), dtype=np.int32)

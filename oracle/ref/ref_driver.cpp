@@ -228,6 +228,7 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     std::string out       = gets(kv, "out", "/tmp/ref_hmat.bin");
     bool square           = (nsrc == 0);
     int consistent        = geti(kv, "consistent", 1);
+    int local             = geti(kv, "local", -1); // >= 0: block-diagonal operator rooted at partition clusters (DefaultLocalApproximationBuilder)
     const int dim         = geometry_dim(geom);
 
     std::vector<double> xt, xs_store;
@@ -276,7 +277,8 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     tb.set_minimal_source_depth(mindepth);
 
     auto t2           = std::chrono::steady_clock::now();
-    HM H = par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank);
+    HM H = local >= 0 ? tb.sequential_build(A, tct.get_cluster_on_partition(local), sct.get_cluster_on_partition(local))
+                      : (par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank));
     auto t3           = std::chrono::steady_clock::now();
 
     // Leaves in natural preorder (children in creation order)
@@ -350,7 +352,7 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
         sequential_internal_add_hmatrix_vector_product('T', (T)alpha, H, xT.data(), (T)beta, yt.data());
         D.vec("yT", yt);
     }
-    if (rank < 0 && square) {
+    if (rank < 0 && square && local < 0) {
         // user-numbering front end (a16)
         std::vector<T> y = y0;
         add_hmatrix_vector_product('N', (T)alpha, H, x.data(), (T)beta, y.data());

@@ -87,6 +87,20 @@ def _worker(rank, world, port, sym, uplo, q):
                 Y = torch.from_numpy(Y0.copy())
                 D.internal_add_distributed_operator_matrix_product_row_major_global_to_global(trans, 3.0, A, torch.from_numpy(X.copy()), 2.0, Y, 3)
                 errs.append(rel_err(Y.numpy(), Hfull.matmat_row_major(X, trans, 3.0, 2.0, Y0)))
+        # block-diagonal operator (DefaultLocalApproximationBuilder): local-to-local operators only
+        Hdiag = O.HMatrix(To, To, eps=1e-6, eta=10.0, sym=sym, uplo=uplo, compressor=comp, root_partition=rank)
+        B = D.DistributedOperator(tp, tp)
+        B.add_local_to_local_operator(OracleLocalOperator(Hdiag))
+        off, sz = tp.get_offset_of_partition(rank), tp.get_size_of_partition(rank)
+        for trans in ("N", "T"):
+            y = torch.from_numpy(y0.copy())
+            D.internal_add_distributed_operator_vector_product_global_to_global(trans, 3.0, B, torch.from_numpy(xin), 2.0, y)
+            # every rank's diagonal block acts on its own slice; the off-diagonal part of y is beta * y0
+            ref_loc = Hdiag.matvec(xin[off:off + sz], trans, 3.0, 2.0, y0[off:off + sz])
+            errs.append(rel_err(y.numpy()[off:off + sz], ref_loc))
+            yl = torch.from_numpy(y0[off:off + sz].copy())
+            D.internal_add_distributed_operator_vector_product_local_to_local(trans, 3.0, B, torch.from_numpy(xin[off:off + sz].copy()), 2.0, yl)
+            errs.append(rel_err(yl.numpy(), ref_loc))
         q.put((rank, max(errs)))
     finally:
         dist.destroy_process_group()

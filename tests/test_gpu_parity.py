@@ -26,7 +26,7 @@ def build_engine(p, compress=True, generator=True):
     tb.set_minimal_source_depth(p["mindepth"])
     tb.set_block_tree_consistency(bool(p["consistent"]))
     gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]) if generator else None
-    H = tb.build(gen, T, S, p["rank"], p["rank"], compress=compress)
+    H = tb.build(gen, T, S, p["rank"], p["rank"], compress=compress, local_partitions=(p["local"], p["local"]) if p["local"] >= 0 else None)
     return T, S, H
 
 

@@ -54,7 +54,7 @@ def test_block_tree_bit_exact(name):
     tb.set_minimal_target_depth(p["mindepth"])
     tb.set_minimal_source_depth(p["mindepth"])
     tb.set_block_tree_consistency(bool(p["consistent"]))
-    bt = tb.build_block_tree(T, S, p["rank"], p["rank"])
+    bt = tb.build_local_block_tree(T, S, p["local"], p["local"]) if p["local"] >= 0 else tb.build_block_tree(T, S, p["rank"], p["rank"])
     a = bt.leaves
     ref = g["leaves"]
     got = np.stack([a["t_offset"], a["t_size"], a["s_offset"], a["s_size"]], axis=1)

@@ -21,7 +21,7 @@ def build_oracle(name):
     else:
         S = T
     H = O.HMatrix(T, S, delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
-                  reqrank=p["reqrank"], compressor=p["compressor"], mindepth=p["mindepth"], rank=p["rank"], consistent=bool(p["consistent"]))
+                  reqrank=p["reqrank"], compressor=p["compressor"], mindepth=p["mindepth"], rank=p["rank"], consistent=bool(p["consistent"]), root_partition=p["local"])
     return p, T, S, H
 
 
