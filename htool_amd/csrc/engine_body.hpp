@@ -557,6 +557,11 @@ static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                   H.r_outidx.d, H.Zmu.d, H.Zmu.d, (int)H.R.task_range.size()};
     ExpandArgs XA{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges()};
+    // groups of 16 right-hand sides go to the matrix cores (HMX_NO_MFMA=1: VALU kernels, for A/B comparison)
+    // Measured at N=1e6, mu=16: fp64 4.34 ms (MFMA) vs 4.72 ms (VALU); fp32 2.68 ms (MFMA: 64-byte row segments) vs 2.28 ms
+    // (VALU) -- so the matrix cores take the fp64 groups only unless HMX_MFMA_F32=1.
+    const bool mfma_ok  = sizeof(real) == 8 || (getenv("HMX_MFMA_F32") && atoi(getenv("HMX_MFMA_F32")));
+    const bool use_mfma = mfma_ok && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")));
     // stage 1 for every group of right-hand sides, then the partial sums, then stage 2
     auto for_groups = [&](auto &&fn) {
         int c = 0;
@@ -568,6 +573,12 @@ static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y
         }
     };
     for_groups([&](int g, int c) {
+        if (g == 16 && use_mfma) {
+            if (RA.ntasks > 0)
+                hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
+            prof_mark(H, st, "reduce_mfma16_kernel");
+            return;
+        }
         switch (g) {
         case 16: launch_mu<16>(H, RA, XA, mu, c, st); break;
         case 8: launch_mu<8>(H, RA, XA, mu, c, st); break;
@@ -583,6 +594,12 @@ static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y
         prof_mark(H, st, "combine_mu_kernel");
     }
     for_groups([&](int g, int c) {
+        if (g == 16 && use_mfma) {
+            if (XA.nranges > 0)
+                hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
+            prof_mark(H, st, "expand_mfma16_kernel");
+            return;
+        }
         switch (g) {
         case 16: launch_mu_expand<16>(H, XA, mu, c, st); break;
         case 8: launch_mu_expand<8>(H, XA, mu, c, st); break;

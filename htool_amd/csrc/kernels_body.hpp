@@ -906,6 +906,124 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// 16 right-hand sides on the matrix cores.  With mu = 16 the leaf products are real GEMMs
+// (K7-K9 of SURVEY.md 2.2: [rows x cols] x [cols x 16]); the VALU kernels above then spend their time re-reading the
+// 16 wave-uniform operands from LDS (8 broadcast ds_read_b128 per streamed column).  v_mfma_*_16x16x4 takes that
+// operand as ONE register per lane: stream tile = A (16 x 4), operand tile = B (4 x 16), 16 x 16 accumulators.
+// fp64/fp32 MFMA peak equals the vector peak on gfx950, so this is not about FLOP/s: it takes the LDS and VALU-issue
+// pressure off a kernel that should be HBM-bound.  Results differ from the VALU kernels only by summation order.
+// ---------------------------------------------------------------------------------------------
+typedef Acc4<real>::type acc4;
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16_kernel(ExpandArgs A, int mu, int cbase) {
+    __shared__ __attribute__((aligned(16))) real red[WAVES][WAVE][16];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const real *E       = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4; // A: row m of the tile, column kk of the group; B: column kk, rhs m
+    acc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    // four groups of 4 columns per step: all 22 loads of a step are issued before its 16 MFMAs
+    constexpr int G = 4;
+    for (int c0 = wv * 4 * G; c0 < C; c0 += WAVES * 4 * G) {
+        real b[G], a[G][4];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int col  = c0 + 4 * g + kk;
+            const bool cok = col < C;
+            b[g]           = cok ? A.Z[(int64_t)zidx[col] * mu + cbase + m] : real(0);
+            const real *cp = E + (int64_t)(cok ? col : 0) * len;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int row = 16 * t + m;
+                a[g][t]       = (cok && row < len) ? stream_load(cp + row) : real(0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                acc[t] = mfma16(a[g][t], b[g], acc[t]);
+    }
+    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, rhs l & 15): stage as [row][rhs]
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 16; e += WAVES * WAVE) {
+        const int i = e >> 4, c = e & 15;
+        real s = red[0][i][c];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++)
+            s += red[w][i][c];
+        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A, int mu, int cbase) {
+    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES + wv;
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp      = (w + 1) & ~1;
+    const int ntile   = (w + 15) >> 4; // <= 8 column tiles of 16
+    const real *src   = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const real *xs    = A.x + (int64_t)A.range_off[S] * mu + cbase;
+    const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, rhs m
+    acc4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    // two 4-row steps per iteration: 16 stream loads + 2 operand loads in flight before the MFMAs
+    for (int i0 = 0; i0 < len; i0 += 8) {
+        real b[2], a[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int row  = i0 + 4 * h + kk;
+            const bool rok = row < len;
+            b[h]           = rok ? xs[(int64_t)row * mu + m] : real(0);
+            const real *rp = src + (int64_t)(rok ? row : 0) * wp;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int col = 16 * t + m;
+                a[h][t]       = (t < ntile && rok && col < w) ? stream_load(rp + col) : real(0);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (t < ntile)
+                    acc[t] = mfma16(a[h][t], b[h], acc[t]);
+    }
+    const int64_t cb = A.range_colbase[S] + ch * cw;
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        if (t < ntile)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int col = 16 * t + mfma16_row(real(0), lane, j);
+                if (col < w)
+                    A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Transposed / mirrored passes (trans = 'T', and the symmetric mirror pass
 // add_hmatrix_vector_product.hpp:97-103,154-163).  Same streams, read in the "wrong" orientation:
 // every column (resp. row) needs a cross-lane reduction and results are accumulated with fp64 atomics

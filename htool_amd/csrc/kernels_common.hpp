@@ -91,6 +91,20 @@ __device__ __forceinline__ float2 stream_load(const float2 *p) {
 #endif
 }
 
+// ---- MFMA 16x16x4 (fp64 and exact-fp32 forms), used by the 16-right-hand-side kernels ------------------------------
+// A: lane l holds A[m = l & 15][k = l >> 4]; B: lane l holds B[k = l >> 4][n = l & 15] (one element per lane).
+// C/D: 4 results per lane, column n = l & 15; row = (l >> 4) + 4*reg for f64, 4*(l >> 4) + reg for f32
+// (cdna_hip_programming.md section 3: the f64 form does NOT use the f32 row map).
+typedef double hmx_d4 __attribute__((ext_vector_type(4)));
+typedef float hmx_f4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Acc4;
+template <> struct Acc4<double> { typedef hmx_d4 type; };
+template <> struct Acc4<float> { typedef hmx_f4 type; };
+__device__ __forceinline__ hmx_d4 mfma16(double a, double b, hmx_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ hmx_f4 mfma16(float a, float b, hmx_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int mfma16_row(double, int lane, int reg) { return (lane >> 4) + 4 * reg; }
+__device__ __forceinline__ int mfma16_row(float, int lane, int reg) { return 4 * (lane >> 4) + reg; }
+
 __global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
     int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

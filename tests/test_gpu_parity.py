@@ -418,3 +418,39 @@ def test_symmetric_storage_compact_mode(name, monkeypatch):
     X, Y = hashed_vector(nc * 2, 5).reshape(nc, 2), hashed_vector(nr * 2, 6).reshape(nr, 2).copy()
     hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y, 2)
     assert rel_err(Y, g["YNrm"]) < 1e-10
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-5)])
+def test_sixteen_rhs_mfma_path(dtype, tol, monkeypatch):
+    """mu = 16 runs on the matrix cores (v_mfma_f64_16x16x4 / v_mfma_f32_16x16x4).  Checked against 16 separate
+    single-vector products, against the VALU multi-RHS kernels (HMX_NO_MFMA=1), with ragged mu (19 = 16 + 2 + 1) and
+    with alpha/beta, on a symmetric (expanded) and a rectangular operator."""
+    monkeypatch.setenv("HMX_MFMA_F32", "1")  # exercise the fp32 MFMA form too (off by default: slower than VALU)
+    n = 5000
+    x = hm.create_geometry("ball", n)
+    xs = hm.create_geometry("disk", 3000, 2.0)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(100)
+    T, S = b.create_cluster_tree(n, 3, x, 2, 2), b.create_cluster_tree(3000, 3, xs, 2, 2)
+    rng = np.random.default_rng(7)
+    for (tgt, src, xt_, xs_, sym) in ((T, T, x, x, "S"), (T, S, x, xs, "N")):
+        tb = hm.HMatrixTreeBuilder(1e-5, 10.0, sym, "L" if sym == "S" else "N")
+        tb.set_low_rank_generator("sympartialACA" if sym == "S" else "partialACA")
+        H = tb.build(hm.InvDistGenerator(3, xt_, xs_, 1e-5, 1.0), tgt, src, dtype=dtype)
+        nr, nc = H.nb_rows(), H.nb_cols()
+        for mu in (16, 19):
+            X = rng.random((nc, mu)).astype(dtype)
+            Y0 = rng.random((nr, mu)).astype(dtype)
+            Y = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, Y, mu)
+            ref = np.empty_like(Y0)
+            for c in range(mu):
+                y = np.ascontiguousarray(Y0[:, c]).copy()
+                hm.internal_add_hmatrix_vector_product("N", 1.5, H, np.ascontiguousarray(X[:, c]), 0.5, y)
+                ref[:, c] = y
+            assert rel_err(Y, ref) < tol
+            monkeypatch.setenv("HMX_NO_MFMA", "1")
+            Yv = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, Yv, mu)
+            monkeypatch.delenv("HMX_NO_MFMA")
+            assert rel_err(Y, Yv) < tol
