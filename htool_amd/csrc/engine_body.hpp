@@ -88,7 +88,8 @@ struct HMat {
 static int build_streams(HMat &H) {
     Timer tim;
     const int64_t nb_real = (int64_t)H.leaves.size();
-    constexpr int TR_MAX = 64, SR_MAX = 512;
+    constexpr int TR_MAX = 64;
+    const int SR_MAX     = getenv("HMX_SR_MAX") ? std::max(64, atoi(getenv("HMX_SR_MAX"))) : 512;
     // Symmetric storage ('S','L'/'U'): by default every leaf of leaves_for_symmetry is ALSO laid out as its transpose
     // (same crosses, roles of U and V exchanged; same dense generator), i.e. the streams hold the full operator and
     // the product is a single untransposed pass through the tuned kernels (incl. the fused multi-RHS path).

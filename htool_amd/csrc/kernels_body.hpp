@@ -687,10 +687,18 @@ __global__ void combine_kernel(CombineArgs A) {
         return;
     const real *p = A.Z + A.src[e];
     const int st = A.stride[e], cnt = A.count[e];
-    real s = 0;
-    for (int k = 0; k < cnt; k++)
-        s += p[(int64_t)k * st];
-    A.Z[A.dst[e]] = s;
+    // four independent partial sums keep four loads in flight; the order is fixed, so results stay reproducible
+    real s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        s0 += p[(int64_t)k * st];
+        s1 += p[(int64_t)(k + 1) * st];
+        s2 += p[(int64_t)(k + 2) * st];
+        s3 += p[(int64_t)(k + 3) * st];
+    }
+    for (; k < cnt; k++)
+        s0 += p[(int64_t)k * st];
+    A.Z[A.dst[e]] = (s0 + s1) + (s2 + s3);
 }
 
 // Stage 2 (dense leaves: add_matrix_vector_product.hpp:18; low rank: add_lrmat_vector_product.hpp:17,
