@@ -60,7 +60,7 @@ struct HMat {
     StreamSet E, R;
     DArr<int32_t> e_zidx, e_zidx_mirror, e_tdst, e_tdst_mirror;
     DArr<int32_t> r_outidx, r_tcoef, r_tcoef_mirror;
-    std::vector<int32_t> h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag, h_e_tdst_all, h_e_tdst_mir;
+    std::vector<int32_t> h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag, h_e_tdst_all;
     DArr<int32_t> c_dst, c_src, c_stride, c_count;
     int n_combine       = 0;
     int64_t A_total     = 0, P_total = 0;
