@@ -70,6 +70,7 @@ SYMBOLS = [
     ("hmx_hmatrix_matmat_row_major_s", C.c_int, [_vp, C.c_char, C.c_float, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_hmatrix_set_kernel", C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
     ("hmx_hmatrix_compress", C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
+    ("hmx_hmatrix_recompress", C.c_int, [_vp, C.c_double]),
     ("hmx_hmatrix_set_block_lowrank", C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp]),
     ("hmx_hmatrix_set_block_dense", C.c_int, [_vp, C.c_int64, _dp]),
     ("hmx_hmatrix_finalize", C.c_int, [_vp]),

@@ -213,6 +213,11 @@ class HMatrix:
         fn = lib().hmx_hmatrix_set_block_dense_s if self.f32 else lib().hmx_hmatrix_set_block_dense
         check(fn(self._h, leaf, D.ctypes.data_as(C.POINTER(ct))))
 
+    def recompress(self, epsilon=-1.0):
+        """recompression(hmatrix) (hmatrix/utils/recompression.hpp:8-13): SVD recompression of every low-rank leaf."""
+        check(lib().hmx_hmatrix_recompress(self._h, float(epsilon)))
+        self.refresh_leaves()
+
     def finalize(self):
         check(lib().hmx_hmatrix_finalize(self._h))
         self.refresh_leaves()

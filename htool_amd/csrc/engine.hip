@@ -186,6 +186,7 @@ int hmx_hmatrix_set_kernel(hmx_hmatrix *H, int kernel, const double *params, int
 int hmx_hmatrix_compress(hmx_hmatrix *H, int compressor, double epsilon, int reqrank) {
     HMX_DISPATCH(H, hmx::f64::api_compress(H->d, compressor, epsilon, reqrank), hmx::f32::api_compress(H->s, compressor, epsilon, reqrank));
 }
+int hmx_hmatrix_recompress(hmx_hmatrix *H, double epsilon) { HMX_DISPATCH(H, hmx::f64::api_recompress(H->d, epsilon), hmx::f32::api_recompress(H->s, epsilon)); }
 int hmx_hmatrix_finalize(hmx_hmatrix *H) { HMX_DISPATCH(H, hmx::f64::api_finalize(H->d), hmx::f32::api_finalize(H->s)); }
 int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *H, int32_t *rank) { HMX_DISPATCH(H, hmx::f64::api_leaf_ranks(H->d, rank), hmx::f32::api_leaf_ranks(H->s, rank)); }
 int hmx_hmatrix_stats(const hmx_hmatrix *H, hmx_stats *out) { HMX_DISPATCH(H, hmx::f64::api_stats(H->d, out), hmx::f32::api_stats(H->s, out)); }

@@ -34,6 +34,7 @@ struct HMat {
     int T0 = 0, nT = 0, S0 = 0, nS = 0;
     int nT_total = 0, nS_total = 0;
     char symmetry_for_leaves = 'N', uplo_for_leaves = 'N';
+    double build_epsilon = 0;  // accuracy the low-rank leaves were built with (LowRankMatrix::get_epsilon)
     bool has_mirror = false;   // the block tree has leaves_for_symmetry
     bool sym_expanded = false; // ... and they were laid out explicitly (no mirror pass needed)
     std::vector<int64_t> staged_off;
@@ -782,6 +783,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     const bool assembled = (compressor == HMX_FULL_ACA || compressor == HMX_SVD); // works on the assembled block
     if (reqrank == 0)
         reqrank = -1;
+    H.build_epsilon = epsilon;
     HMX_HIP(hipSetDevice(H.device));
     const size_t nb = H.leaves.size();
     // ---- scratch for the admissible leaves ---------------------------------------------------------
@@ -964,6 +966,89 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     H.stats.n_false_positive = false_pos;
     H.stats.t_compress_s     = ms * 1e-3;
     return HMX_OK;
+}
+
+// recompression(hmatrix) (hmatrix/utils/recompression.hpp:8-31): SVD recompression of every low-rank leaf with the
+// accuracy the operator was built with (LowRankMatrix::get_epsilon), then the streams are laid out again.
+static int api_recompress(HMat *Hp, double epsilon) {
+    if (!Hp) {
+        set_error("hmx_hmatrix_recompress: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    if (!H.finalized || H.pool.n == 0) {
+        set_error("hmx_hmatrix_recompress: operator not built");
+        return HMX_ERR_STATE;
+    }
+    HMX_HIP(hipSetDevice(H.device));
+    if (epsilon <= 0)
+        epsilon = H.build_epsilon;
+    const size_t nb = H.leaves.size();
+    std::vector<int32_t> order, ranks(nb, 0);
+    std::vector<int64_t> need(nb, 0);
+    int64_t largest = 0;
+    for (size_t b = 0; b < nb; b++) {
+        ranks[b] = H.leaves[b].rank;
+        if (H.kind[b] != LK_LOWRANK || H.leaves[b].rank <= 0)
+            continue;
+        const int64_t M = H.leaves[b].t_size, N = H.leaves[b].s_size, r = H.leaves[b].rank;
+        need[b] = (M + N) * r + 4 * r * r + 4 * r;
+        largest = std::max(largest, need[b]);
+        order.push_back((int32_t)b);
+    }
+    if (order.empty())
+        return HMX_OK;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return need[a] != need[b] ? need[a] > need[b] : a < b; });
+    size_t free_b = 0, total_b = 0;
+    HMX_HIP(hipMemGetInfo(&free_b, &total_b));
+    const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free_b / sizeof(real)));
+    if ((double)largest * sizeof(real) > 0.9 * (double)free_b) {
+        set_error("hmx_hmatrix_recompress: a block does not fit in HBM scratch");
+        return HMX_ERR_HIP;
+    }
+    DArr<real> scratch;
+    HMX_HIP(scratch.alloc(slab));
+    DArr<int32_t> d_order, d_ts, d_ss, d_sw;
+    DArr<int64_t> d_soff, d_colptr;
+    std::vector<int32_t> ts(nb), ss(nb), sw(nb, 0);
+    for (size_t b = 0; b < nb; b++) {
+        ts[b] = H.leaves[b].t_size;
+        ss[b] = H.leaves[b].s_size;
+        sw[b] = b < H.swapped.size() ? H.swapped[b] : 0;
+    }
+    std::vector<int64_t> colptr = H.colptr;
+    colptr.resize(nb, 0);
+    HMX_HIP(d_order.upload(order));
+    HMX_HIP(d_ts.upload(ts));
+    HMX_HIP(d_ss.upload(ss));
+    HMX_HIP(d_sw.upload(sw));
+    HMX_HIP(d_colptr.upload(colptr));
+    HMX_HIP(H.d_rank.upload(ranks));
+    std::vector<int64_t> soff(nb, 0);
+    size_t pos = 0;
+    while (pos < order.size()) {
+        int64_t used = 0;
+        size_t end   = pos;
+        while (end < order.size() && used + need[order[end]] <= slab) {
+            soff[order[end]] = used;
+            used += need[order[end]];
+            end++;
+        }
+        HMX_HIP(d_soff.upload(soff));
+        RecompressArgs A{d_order.d + pos, d_ts.d, d_ss.d, d_sw.d, d_soff.d, scratch.d, epsilon, H.pool.d, d_colptr.d, H.d_cross_off.d, H.d_rank.d};
+        hipLaunchKernelGGL(recompress_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, A);
+        HMX_HIP(hipGetLastError());
+        HMX_HIP(hipDeviceSynchronize());
+        pos = end;
+    }
+    HMX_HIP(hipMemcpy(ranks.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
+    for (int32_t b : order)
+        H.leaves[b].rank = ranks[b];
+    const hmx_stats keep = H.stats;
+    const int rc         = build_streams(H);
+    H.stats.n_false_positive = keep.n_false_positive;
+    H.stats.t_compress_s     = keep.t_compress_s;
+    return rc;
 }
 
 static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const real *U, const real *V) {

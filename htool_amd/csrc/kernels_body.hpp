@@ -336,39 +336,14 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
         A.rank_out[b] = q > 0 ? q : (q == -2 ? -2 : 0);
 }
 
-// SVD::copy_low_rank_approximation (hmatrix/lrmat/SVD.hpp:27-92) with gesvd replaced by a one-sided Jacobi
-// SVD (LAPACK is a third-party dependency of the reference; its contract -- A = u diag(s) vt, s descending --
-// is what is reproduced) and the truncation rule of matrix/utils/SVD_truncation.hpp:37-52.
-// Slab layout: W (m x n, m >= n, column-major; A or A^T) | Vm (n x n) | sv (n) | order (n, as doubles)
+// Cyclic one-sided Jacobi on the columns of W (m x n, column-major): on return the columns are mutually orthogonal
+// (W_out = W_in * Vm, Vm accumulates the rotations, must hold the identity on entry).  The pairs of one round-robin
+// round touch disjoint columns, so each wave rotates one pair; a workgroup barrier separates the rounds.
 template <int NT>
-__global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
-    __shared__ int s_changed;
-    __shared__ int s_rank;
-    __shared__ unsigned long long s_off;
-    const int b = A.order[blockIdx.x];
-    const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
-    const bool tr = M < N;
-    const int m = tr ? N : M, n = tr ? M : N;
-    real *W   = A.scratch + A.scratch_off[b];
-    real *Vm  = W + (int64_t)m * n;
-    real *sv  = Vm + (int64_t)n * n;
-    real *ord = sv + n;
-    int64_t *cross = A.cross_off + A.colptr[b];
-    const int cap  = A.colcap[b];
+__device__ void jacobi_orthogonalize(real *W, int m, int n, real *Vm, int *s_changed_ptr) {
+    int &s_changed = *s_changed_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = NT / WAVE;
-    for (int64_t e = tid; e < (int64_t)M * N; e += NT) {
-        const int i = (int)(e % M), j = (int)(e / M);
-        const real v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
-        if (tr)
-            W[j + (int64_t)m * i] = v;
-        else
-            W[i + (int64_t)m * j] = v;
-    }
-    for (int64_t e = tid; e < (int64_t)n * n; e += NT)
-        Vm[e] = (e % n == e / n) ? 1.0 : 0.0;
-    __syncthreads();
-    // cyclic one-sided Jacobi; the pairs of one round-robin round touch disjoint columns -> one wave per pair
     const int np = (n + 1) & ~1; // players (one dummy when n is odd)
     for (int sweep = 0; sweep < 60; sweep++) {
         if (tid == 0)
@@ -423,6 +398,41 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
         if (!changed)
             break;
     }
+}
+
+// SVD::copy_low_rank_approximation (hmatrix/lrmat/SVD.hpp:27-92) with gesvd replaced by a one-sided Jacobi
+// SVD (LAPACK is a third-party dependency of the reference; its contract -- A = u diag(s) vt, s descending --
+// is what is reproduced) and the truncation rule of matrix/utils/SVD_truncation.hpp:37-52.
+// Slab layout: W (m x n, m >= n, column-major; A or A^T) | Vm (n x n) | sv (n) | order (n, as doubles)
+template <int NT>
+__global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
+    __shared__ int s_changed;
+    __shared__ int s_rank;
+    __shared__ unsigned long long s_off;
+    const int b = A.order[blockIdx.x];
+    const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
+    const bool tr = M < N;
+    const int m = tr ? N : M, n = tr ? M : N;
+    real *W   = A.scratch + A.scratch_off[b];
+    real *Vm  = W + (int64_t)m * n;
+    real *sv  = Vm + (int64_t)n * n;
+    real *ord = sv + n;
+    int64_t *cross = A.cross_off + A.colptr[b];
+    const int cap  = A.colcap[b];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = NT / WAVE;
+    for (int64_t e = tid; e < (int64_t)M * N; e += NT) {
+        const int i = (int)(e % M), j = (int)(e / M);
+        const real v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        if (tr)
+            W[j + (int64_t)m * i] = v;
+        else
+            W[i + (int64_t)m * j] = v;
+    }
+    for (int64_t e = tid; e < (int64_t)n * n; e += NT)
+        Vm[e] = (e % n == e / n) ? 1.0 : 0.0;
+    __syncthreads();
+    jacobi_orthogonalize<NT>(W, m, n, Vm, &s_changed);
     // singular values = column norms, descending order by counting
     for (int j = wv; j < n; j += NW) {
         real nn = 0;
@@ -494,6 +504,130 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
     }
     if (tid == 0)
         A.rank_out[b] = r;
+}
+
+// SVD_recompression (hmatrix/lrmat/utils/SVD_recompression.hpp:19-181) of an existing U (M x r) * V (r x N):
+// the reference does QR(U), LQ(V), SVD(R L) with LAPACK; here both thin factors are orthogonalised by one-sided
+// Jacobi (U G_u = Q_u S_u, V^T G_v = Q_v S_v), the r x r core C = S_u G_u^T G_v S_v gets a Jacobi SVD, the rank is
+// truncated with SVD_truncation's rule and the factors are rebuilt as U' = Q_u u sqrt(s), V' = sqrt(s) vt Q_v^T.
+// As in the reference the block is only rewritten when the rank drops.
+// Slab: Uw (M x r) | Vw (N x r) | Gu, Gv, Cm, Gc (r x r each) | su, sv, sc, ord (r each)
+struct RecompressArgs {
+    const int32_t *order;
+    const int32_t *t_size, *s_size;
+    const int32_t *swapped;
+    const int64_t *scratch_off;
+    real *scratch;
+    double epsilon;
+    real *pool;
+    const int64_t *colptr;
+    const int64_t *cross_off;
+    int32_t *rank; // in: current rank, out: new rank
+};
+template <int NT>
+__global__ __launch_bounds__(NT) void recompress_kernel(RecompressArgs A) {
+    __shared__ int s_changed;
+    __shared__ int s_rank;
+    const int b = A.order[blockIdx.x];
+    const int M = A.t_size[b], N = A.s_size[b], r = A.rank[b];
+    const bool sw = A.swapped[b] != 0;
+    const int n1  = sw ? N : M; // length of the first vector of a cross
+    const int64_t *cross = A.cross_off + A.colptr[b];
+    real *Uw = A.scratch + A.scratch_off[b];
+    real *Vw = Uw + (int64_t)M * r;
+    real *Gu = Vw + (int64_t)N * r, *Gv = Gu + r * r, *Cm = Gv + r * r, *Gc = Cm + r * r;
+    real *su = Gc + r * r, *sv = su + r, *sc = sv + r, *ord = sc + r;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = NT / WAVE;
+    for (int k = 0; k < r; k++) {
+        const real *c  = A.pool + cross[k];
+        const real *uk = sw ? c + n1 : c, *vk = sw ? c : c + n1; // U(:,k), V(k,:)
+        for (int i = tid; i < M; i += NT)
+            Uw[i + (int64_t)M * k] = uk[i];
+        for (int j = tid; j < N; j += NT)
+            Vw[j + (int64_t)N * k] = vk[j];
+    }
+    for (int e = tid; e < r * r; e += NT) {
+        Gu[e] = Gv[e] = Gc[e] = (e % r == e / r) ? real(1) : real(0);
+    }
+    __syncthreads();
+    jacobi_orthogonalize<NT>(Uw, M, r, Gu, &s_changed);
+    jacobi_orthogonalize<NT>(Vw, N, r, Gv, &s_changed);
+    for (int j = wv; j < 2 * r; j += NW) { // column norms of both factors
+        const real *col = j < r ? Uw + (int64_t)M * j : Vw + (int64_t)N * (j - r);
+        const int len   = j < r ? M : N;
+        real nn = 0;
+        for (int i = lane; i < len; i += WAVE)
+            nn += col[i] * col[i];
+        nn = wave_sum(nn);
+        if (lane == 0)
+            (j < r ? su : sv)[j < r ? j : j - r] = sqrt(nn);
+    }
+    __syncthreads();
+    // core C = S_u (G_u^T G_v) S_v
+    for (int e = tid; e < r * r; e += NT) {
+        const int i = e % r, j = e / r;
+        real s = 0;
+        for (int l = 0; l < r; l++)
+            s += Gu[l + r * i] * Gv[l + r * j];
+        Cm[e] = su[i] * s * sv[j];
+    }
+    __syncthreads();
+    jacobi_orthogonalize<NT>(Cm, r, r, Gc, &s_changed); // Cm <- C Gc = u_c diag(sc)
+    for (int j = tid; j < r; j += NT) {
+        real nn = 0;
+        for (int i = 0; i < r; i++)
+            nn += Cm[i + r * j] * Cm[i + r * j];
+        sc[j] = sqrt(nn);
+    }
+    __syncthreads();
+    for (int j = tid; j < r; j += NT) {
+        int pos = 0;
+        for (int l = 0; l < r; l++)
+            pos += (sc[l] > sc[j] || (sc[l] == sc[j] && l < j)) ? 1 : 0;
+        ord[pos] = (real)j;
+    }
+    __syncthreads();
+    if (tid == 0) { // SVD_truncation.hpp:37-52
+        real norm2 = 0, err = 0;
+        for (int l = 0; l < r; l++)
+            norm2 += sc[l] * sc[l];
+        const real nrm = sqrt(norm2);
+        int j = r;
+        do {
+            j = j - 1;
+            err += sc[(int)ord[j]] * sc[(int)ord[j]];
+        } while (j > 0 && sqrt(err) / nrm < (real)A.epsilon);
+        s_rank = j + 1;
+    }
+    __syncthreads();
+    const int kr = s_rank;
+    if (kr < r) {
+        // U'(:,k) = sqrt(s_k) * sum_i Q_u(:,i) u_c(i,k) ,  Q_u(:,i) = Uw(:,i)/su_i ,  u_c(:,k) = Cm(:,jk)/sc_jk
+        // V'(k,:) = sqrt(s_k) * sum_i Gc(i,jk) Q_v(:,i)^T ,  Q_v(:,i) = Vw(:,i)/sv_i
+        for (int k = 0; k < kr; k++) {
+            const int jk   = (int)ord[k];
+            const real sk  = sc[jk], rs = sqrt(sk), isk = sk > 0 ? real(1) / sk : real(0);
+            real *c   = A.pool + cross[k];
+            real *uk  = sw ? c + n1 : c, *vk = sw ? c : c + n1;
+            for (int i = tid; i < M; i += NT) {
+                real s = 0;
+                for (int l = 0; l < r; l++)
+                    if (su[l] > 0)
+                        s += Uw[i + (int64_t)M * l] / su[l] * (Cm[l + r * jk] * isk);
+                uk[i] = rs * s;
+            }
+            for (int j = tid; j < N; j += NT) {
+                real s = 0;
+                for (int l = 0; l < r; l++)
+                    if (sv[l] > 0)
+                        s += Vw[j + (int64_t)N * l] / sv[l] * Gc[l + r * jk];
+                vk[j] = rs * s;
+            }
+        }
+        if (tid == 0)
+            A.rank[b] = kr;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -122,6 +122,11 @@ int hmx_hmatrix_set_kernel(hmx_hmatrix *, int kernel, const double *params, int 
  * (HMatrix::compute_dense_data, hmatrix.hpp:222-226), then lay the result out as matvec streams. */
 int hmx_hmatrix_compress(hmx_hmatrix *, int compressor, double epsilon, int reqrank);
 
+/* recompression(hmatrix) / RecompressedLowRankGenerator (hmatrix/utils/recompression.hpp:8-31,
+ * hmatrix/lrmat/utils/SVD_recompression.hpp:19-181): SVD recompression of every low-rank leaf; epsilon <= 0 uses the
+ * accuracy of hmx_hmatrix_compress.  Ranks can only decrease; the matvec streams are rebuilt. */
+int hmx_hmatrix_recompress(hmx_hmatrix *, double epsilon);
+
 /* Upload path: blocks compressed elsewhere (e.g. by htool's own CPU compressors behind a user
  * VirtualGenerator).  Low rank: U is M x r column-major, V is r x N column-major (LowRankMatrix,
  * hmatrix/lrmat/lrmat.hpp:15-45); dense: M x N column-major (matrix/matrix.hpp:100).

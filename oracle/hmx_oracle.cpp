@@ -683,6 +683,16 @@ int orc_hmatrix_block(void *h, int b, double *U, double *V, double *D, int *pivo
         return -1;
     });
 }
+// recompression(hmatrix) (hmatrix/utils/recompression.hpp:8-13)
+void orc_hmatrix_recompress(void *h, double epsilon) {
+    with_h(h, [&](auto &H) {
+        using R = typename std::decay<decltype(H.preorder[0].b->dense[0])>::type;
+        for (auto &l : H.preorder)
+            if (l.b->kind == 2)
+                svd_recompression(l.b->lr, (R)epsilon);
+        return 0;
+    });
+}
 void orc_hmatrix_matvec(void *h, int policy, char trans, double alpha, const double *in, double beta, double *out) {
     with_h(h, [&](auto &H) {
         using R        = typename std::decay<decltype(H.preorder[0].b->dense[0])>::type;

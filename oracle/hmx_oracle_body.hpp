@@ -440,6 +440,83 @@ static bool svd_compress(const Generator &A, int M, int N, int row_off, int col_
     return true;
 }
 
+// SVD_recompression (hmatrix/lrmat/utils/SVD_recompression.hpp:19-181), branch rank <= min(M,N):
+// U = Q1 R (geqrf), V = L Q2 (gelqf), SVD(R L) = u S vt, truncation (SVD_truncation.hpp:37-52), and only if the rank
+// drops: U' = Q1 (u sqrt(S)), V' = (sqrt(S) vt) Q2.  LAPACK's Householder QR/LQ are restated by two-pass modified
+// Gram-Schmidt (explicit thin Q); the r x r SVD by the Jacobi routine above.
+static void thin_qr(int m, int r, const std::vector<real> &A, std::vector<real> &Q, std::vector<real> &R) { // A m x r col-major
+    Q = A;
+    R.assign((size_t)r * r, real(0));
+    for (int j = 0; j < r; j++) {
+        for (int pass = 0; pass < 2; pass++)
+            for (int i = 0; i < j; i++) {
+                real d = 0;
+                for (int k = 0; k < m; k++)
+                    d += Q[k + (size_t)m * i] * Q[k + (size_t)m * j];
+                R[i + (size_t)r * j] += d;
+                for (int k = 0; k < m; k++)
+                    Q[k + (size_t)m * j] -= d * Q[k + (size_t)m * i];
+            }
+        real nn = 0;
+        for (int k = 0; k < m; k++)
+            nn += Q[k + (size_t)m * j] * Q[k + (size_t)m * j];
+        nn                  = std::sqrt(nn);
+        R[j + (size_t)r * j] = nn;
+        for (int k = 0; k < m; k++)
+            Q[k + (size_t)m * j] = nn > 0 ? Q[k + (size_t)m * j] / nn : real(0);
+    }
+}
+static void svd_recompression(LowRank &lr, real epsilon) {
+    const int M = lr.M, N = lr.N, r = lr.rank;
+    if (r <= 0 || r > std::min(M, N))
+        return;
+    std::vector<real> Q1, R, Vt((size_t)N * r), Q2t, Rv;
+    thin_qr(M, r, lr.U, Q1, R);
+    for (int k = 0; k < r; k++)
+        for (int j = 0; j < N; j++)
+            Vt[j + (size_t)N * k] = lr.V[k + (size_t)r * j];
+    thin_qr(N, r, Vt, Q2t, Rv); // V^T = Q2^T Rv  =>  V = Rv^T Q2 = L Q2
+    std::vector<real> RL((size_t)r * r, real(0)); // R * L, L = Rv^T
+    for (int i = 0; i < r; i++)
+        for (int j = 0; j < r; j++) {
+            real s = 0;
+            for (int l = 0; l < r; l++)
+                s += R[i + (size_t)r * l] * Rv[j + (size_t)r * l];
+            RL[i + (size_t)r * j] = s;
+        }
+    std::vector<real> s, u, vt;
+    jacobi_svd(r, r, RL, s, u, vt);
+    int k;
+    {
+        int j         = r;
+        real svd_norm = 0, error = 0;
+        for (auto &e : s)
+            svd_norm += e * e;
+        svd_norm = std::sqrt(svd_norm);
+        do {
+            j = j - 1;
+            error += std::pow(std::abs(s[j]), 2);
+        } while (j > 0 && std::sqrt(error) / svd_norm < epsilon);
+        k = j + 1;
+    }
+    if (k >= r)
+        return;
+    std::vector<real> nU((size_t)M * k, real(0)), nV((size_t)k * N, real(0));
+    for (int c = 0; c < k; c++) {
+        const real rs = std::sqrt(s[c]);
+        for (int l = 0; l < r; l++) {
+            const real cu = u[l + (size_t)r * c] * rs, cv = vt[c + (size_t)r * l] * rs;
+            for (int i = 0; i < M; i++)
+                nU[i + (size_t)M * c] += Q1[i + (size_t)M * l] * cu;
+            for (int j = 0; j < N; j++)
+                nV[c + (size_t)k * j] += cv * Q2t[j + (size_t)N * l];
+        }
+    }
+    lr.U.swap(nU);
+    lr.V.swap(nV);
+    lr.rank = k;
+}
+
 enum Compressor { PARTIAL_ACA = 0,
                   SYMPARTIAL_ACA = 1,
                   FULL_ACA = 2,

@@ -54,6 +54,7 @@ def lib():
         L.orc_hmatrix_leaves.argtypes = [C.c_void_p, C.c_int, ip]
         L.orc_hmatrix_rootinfo.argtypes = [C.c_void_p, ip]
         L.orc_hmatrix_block.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, ip]
+        L.orc_hmatrix_recompress.argtypes = [C.c_void_p, C.c_double]
         L.orc_hmatrix_matvec.argtypes = [C.c_void_p, C.c_int, C.c_char, C.c_double, dp, C.c_double, dp]
         L.orc_hmatrix_matmat_row_major.argtypes = [C.c_void_p, C.c_char, C.c_double, dp, C.c_double, dp, C.c_int]
         L.orc_compress_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
@@ -145,6 +146,11 @@ class HMatrix:
         D = np.empty((n, m), dtype=np.float64)
         lib().orc_hmatrix_block(self.h, b, None, None, _dp(D), None)
         return D.T
+
+    def recompress(self, epsilon):
+        lib().orc_hmatrix_recompress(self.h, float(epsilon))
+        lib().orc_hmatrix_leaves(self.h, 0, _ip(self.leaves))
+        lib().orc_hmatrix_leaves(self.h, 1, _ip(self.leaves_dfs))
 
     def matvec(self, x, trans="N", alpha=1.0, beta=0.0, y=None, policy="seq"):
         nout = self.rootinfo[1] if trans == "N" else self.rootinfo[3]

@@ -22,6 +22,7 @@
 #include <htool/hmatrix/lrmat/partialACA.hpp>
 #include <htool/hmatrix/lrmat/sympartialACA.hpp>
 #include <htool/hmatrix/tree_builder/tree_builder.hpp>
+#include <htool/hmatrix/utils/recompression.hpp>
 #include <htool/testing/geometry.hpp>
 
 #include <chrono>
@@ -279,6 +280,8 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     auto t2           = std::chrono::steady_clock::now();
     HM H = local >= 0 ? tb.sequential_build(A, tct.get_cluster_on_partition(local), sct.get_cluster_on_partition(local))
                       : (par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank));
+    if (geti(kv, "recompress", 0))
+        recompression(H); // hmatrix/utils/recompression.hpp:8-13 (SVD_recompression of every low-rank leaf)
     auto t3           = std::chrono::steady_clock::now();
 
     // Leaves in natural preorder (children in creation order)

@@ -61,6 +61,9 @@ CASES = {
     # block-diagonal (local-to-local) operator rooted at the partition clusters: DefaultLocalApproximationBuilder
     "ellipse_n4000_p4_local2": ("hmat", dict(n=4000, geom="ellipse", leaf=100, partitions=4, local=2, eps=1e-4, compressor="partialACA", dump_blocks=1)),
     "ball_n2000_p2_local1_symL": ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=2, local=1, eps=1e-3, sym="S", uplo="L", compressor="sympartialACA", dump_blocks=1)),
+    # SVD recompression of the ACA output (recompression(hmatrix))
+    "ellipse_n3000_recompressed": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, eta=10, compressor="partialACA", recompress=1)),
+    "ball_n2000_symL_recompressed": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, eta=10, sym="S", uplo="L", compressor="sympartialACA", recompress=1)),
     # other compressors
     "ball_n1200_fullACA": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="fullACA", dump_blocks=2)),
     "ball_n1200_SVD": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="SVD", dump_blocks=2)),

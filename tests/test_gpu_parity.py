@@ -27,6 +27,8 @@ def build_engine(p, compress=True, generator=True):
     tb.set_block_tree_consistency(bool(p["consistent"]))
     gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]) if generator else None
     H = tb.build(gen, T, S, p["rank"], p["rank"], compress=compress, local_partitions=(p["local"], p["local"]) if p["local"] >= 0 else None)
+    if compress and p["recompress"]:
+        H.recompress()
     return T, S, H
 
 
@@ -47,7 +49,8 @@ def test_compression_matches_reference(name):
             b = int(k[2:])
             U, V = H.get_block(b)
             ftol = 1e-9 if U.shape[1] <= 20 else 1e-6
-            assert rel_err(U, g[k].T) < ftol and rel_err(V, g["V_%d" % b].T) < ftol
+            if not p["recompress"]:  # after an SVD recompression the factors are unique only up to sign
+                assert rel_err(U, g[k].T) < ftol and rel_err(V, g["V_%d" % b].T) < ftol
             assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 1e-9
         if k.startswith("D_"):
             assert np.array_equal(H.get_block(int(k[2:])), g[k].T)  # kernel entries bit-exact

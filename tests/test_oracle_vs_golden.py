@@ -22,6 +22,8 @@ def build_oracle(name):
         S = T
     H = O.HMatrix(T, S, delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
                   reqrank=p["reqrank"], compressor=p["compressor"], mindepth=p["mindepth"], rank=p["rank"], consistent=bool(p["consistent"]), root_partition=p["local"])
+    if p["recompress"]:
+        H.recompress(p["eps"])
     return p, T, S, H
 
 
