@@ -515,6 +515,7 @@ static void svd_recompression(LowRank &lr, real epsilon) {
     lr.U.swap(nU);
     lr.V.swap(nV);
     lr.rank = k;
+    lr.pivots.clear(); // the ACA pivots no longer describe these factors
 }
 
 enum Compressor { PARTIAL_ACA = 0,

@@ -64,7 +64,7 @@ def test_payload_and_matvec(name):
             U, V = H.block(b)
             if U.shape[1] != g[k].shape[0]:
                 continue
-            if p["compressor"] == "SVD":
+            if p["compressor"] == "SVD" or p["recompress"]:  # singular vectors are unique only up to sign
                 assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 1e-9
             else:
                 # factor-wise: rounding differences (MKL's axpy fuses multiply-add) grow with the number of ACA
