@@ -38,6 +38,9 @@ class Stats(C.Structure):
                 ("t_compress_s", C.c_double), ("t_assemble_s", C.c_double), ("t_pack_s", C.c_double)]
 
 
+GENERATOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double))
+GENERATOR_FN_S = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float))
+
 # every symbol include/hmx.h declares: (name, restype, argtypes)
 _dp, _ip, _vp, _fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_float)
 SYMBOLS = [
@@ -69,6 +72,8 @@ SYMBOLS = [
     ("hmx_hmatrix_matvec_user_s", C.c_int, [_vp, C.c_char, C.c_float, _vp, C.c_float, _vp, C.c_int, _vp]),
     ("hmx_hmatrix_matmat_row_major_s", C.c_int, [_vp, C.c_char, C.c_float, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_hmatrix_set_kernel", C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
+    ("hmx_hmatrix_set_callback", C.c_int, [_vp, GENERATOR_FN, _vp]),
+    ("hmx_hmatrix_set_callback_s", C.c_int, [_vp, GENERATOR_FN_S, _vp]),
     ("hmx_hmatrix_compress", C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
     ("hmx_hmatrix_recompress", C.c_int, [_vp, C.c_double]),
     ("hmx_hmatrix_set_block_lowrank", C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp]),

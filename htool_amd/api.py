@@ -119,6 +119,27 @@ class InvDistGenerator:
         self.delta, self.scale = float(delta), float(scale)
 
 
+class VirtualGenerator:
+    """User-defined generator, mirror of htool's VirtualGenerator (hmatrix/interfaces/virtual_generator.hpp:17-31):
+    subclass and implement copy_submatrix(M, N, rows, cols) -> array of shape (M, N) holding A[rows[j], cols[k]]
+    (rows / cols are numpy int32 arrays in USER numbering).  The generator runs on the host; the engine calls it for
+    one cross row / column per block and ACA iteration and for the dense leaves, everything else runs on the GPU."""
+
+    def copy_submatrix(self, M, N, rows, cols):
+        raise NotImplementedError
+
+    def _as_callback(self, f32):
+        ctype, fn_t = (C.c_float, _lib.GENERATOR_FN_S) if f32 else (C.c_double, _lib.GENERATOR_FN)
+        dt = np.float32 if f32 else np.float64
+
+        def trampoline(_user, M, N, rows, cols, out):
+            r = np.ctypeslib.as_array(rows, shape=(M,))
+            c = np.ctypeslib.as_array(cols, shape=(N,))
+            block = np.asarray(self.copy_submatrix(M, N, r, c), dtype=dt).reshape(M, N)
+            np.ctypeslib.as_array(out, shape=(N, M))[:] = block.T  # column-major M x N
+        return fn_t(trampoline)
+
+
 def _vec_ptr(v, f32=False):
     """(pointer, mem kind) for a numpy array or a torch tensor of the operator's coefficient precision."""
     if isinstance(v, np.ndarray):
@@ -323,10 +344,14 @@ class HMatrixTreeBuilder:
         else:
             check(lib().hmx_hmatrix_create(bt, device, C.byref(h)))
         H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
-        if generator is not None:
+        if isinstance(generator, VirtualGenerator):
+            H._callback = generator._as_callback(H.f32)  # keep the ctypes thunk alive as long as the operator
+            setter = lib().hmx_hmatrix_set_callback_s if H.f32 else lib().hmx_hmatrix_set_callback
+            check(setter(h, H._callback, None))
+        elif generator is not None:
             if not isinstance(generator, InvDistGenerator):
-                raise HmxError("device compression needs a device-evaluable generator (InvDistGenerator); "
-                               "use compress=False and upload blocks for arbitrary generators")
+                raise HmxError("generator must be an InvDistGenerator (evaluated on the device) or a VirtualGenerator "
+                               "subclass (evaluated on the host through a callback)")
             params = np.array([generator.delta, generator.scale], dtype=np.float64)
             check(lib().hmx_hmatrix_set_kernel(h, 0, _dp(params), 2, generator.dim, _dp(generator.xt), _dp(generator.xs)))
         if compress:

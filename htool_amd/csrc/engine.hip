@@ -183,6 +183,14 @@ int hmx_hmatrix_is_f32(const hmx_hmatrix *H) { return H && H->s ? 1 : 0; }
 int hmx_hmatrix_set_kernel(hmx_hmatrix *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc) {
     HMX_DISPATCH(H, hmx::f64::api_set_kernel(H->d, kernel, params, nparams, dim, tc, sc), hmx::f32::api_set_kernel(H->s, kernel, params, nparams, dim, tc, sc));
 }
+int hmx_hmatrix_set_callback(hmx_hmatrix *H, hmx_generator_fn fn, void *user) {
+    HMX_NEED(H, d, "hmx_hmatrix_set_callback");
+    return hmx::f64::api_set_callback(H->d, fn, user);
+}
+int hmx_hmatrix_set_callback_s(hmx_hmatrix *H, hmx_generator_fn_s fn, void *user) {
+    HMX_NEED(H, s, "hmx_hmatrix_set_callback_s");
+    return hmx::f32::api_set_callback(H->s, fn, user);
+}
 int hmx_hmatrix_compress(hmx_hmatrix *H, int compressor, double epsilon, int reqrank) {
     HMX_DISPATCH(H, hmx::f64::api_compress(H->d, compressor, epsilon, reqrank), hmx::f32::api_compress(H->s, compressor, epsilon, reqrank));
 }

@@ -42,6 +42,10 @@ struct HMat {
     bool t_root_is_tree_root = false, perm_local = false;
 
     // generator
+    // host generator: VirtualGenerator::copy_submatrix semantics (user numbering, column-major output)
+    void (*callback)(void *, int, int, const int32_t *, const int32_t *, real *) = nullptr;
+    void *callback_user = nullptr;
+    DArr<real> dense_stage; // dense leaves evaluated by the host generator (pack_dense reads them from here)
     bool has_kernel = false;
     KernelSpec ks{};
     DArr<double> tx, ty, tz, sx, sy, sz; // cluster-order coordinates (SoA)
@@ -365,7 +369,7 @@ static int build_streams(HMat &H) {
     std::vector<int32_t> ranks(nb), symu(nb, 0);
     for (int64_t b = 0; b < nb; b++) {
         ranks[b] = XL[b].rank;
-        if (XL[b].symmetric && XK[b] == LK_DENSE_STAGED)
+        if (XL[b].symmetric && XK[b] == LK_DENSE_STAGED && !H.dense_stage.d) // uploaded symmetric leaf: one triangle is valid
             symu[b] = H.uplo_for_leaves == 'L' ? 1 : (H.uplo_for_leaves == 'U' ? 2 : 0);
     }
     HMX_HIP(H.d_rank.upload(ranks));
@@ -418,7 +422,7 @@ static int build_streams(HMat &H) {
             HMX_HIP(pr.upload(ed_r));
             HMX_HIP(pc.upload(ed_c));
             PackDenseArgs P{H.ks, H.tx.d, H.ty.d, H.tz.d, H.sx.d, H.sy.d, H.sz.d, pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d,
-                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.pool.d, E.stream.d, H.T0};
+                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.dense_stage.d ? H.dense_stage.d : H.pool.d, E.stream.d, H.T0};
             hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)ed_b.size()), dim3(256), 0, 0, P, (int64_t)ed_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -766,16 +770,32 @@ static int api_set_kernel(HMat *H, int kernel, const double *params, int nparams
     return HMX_OK;
 }
 
+static int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, const int32_t *, real *), void *user) {
+    if (!H || !fn) {
+        set_error("hmx_hmatrix_set_callback: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    H->callback      = fn;
+    H->callback_user = user;
+    H->has_kernel    = false;
+    return HMX_OK;
+}
+
 static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     if (!Hp) {
         set_error("hmx_hmatrix_compress: NULL handle");
         return HMX_ERR_INVALID;
     }
     HMat &H = *Hp;
-    if (!H.has_kernel) {
-        set_error("hmx_hmatrix_compress: no generator set (hmx_hmatrix_set_kernel)");
+    if (!H.has_kernel && !H.callback) {
+        set_error("hmx_hmatrix_compress: no generator set (hmx_hmatrix_set_kernel or hmx_hmatrix_set_callback)");
         return HMX_ERR_STATE;
     }
+    const bool use_cb = H.callback != nullptr && !H.has_kernel;
+    // evaluate one sub-block through the host generator: rows/cols are cluster positions, mapped to user numbers
+    auto gen = [&](int M, int N, int row_pos, int col_pos, real *out) {
+        H.callback(H.callback_user, M, N, H.perm_t.data() + row_pos, H.perm_s.data() + col_pos, out);
+    };
     if (compressor < HMX_PARTIAL_ACA || compressor > HMX_SVD) {
         set_error("hmx_hmatrix_compress: unknown compressor");
         return HMX_ERR_INVALID;
@@ -882,6 +902,25 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
             }
             HMX_HIP(d_soff.upload(soff));
             DenseCompressArgs D{};
+            DArr<real> pre;
+            DArr<int64_t> d_preoff;
+            if (use_cb) { // the host generator assembles the blocks of this batch
+                std::vector<int64_t> preoff(nb, 0);
+                int64_t tot = 0;
+                for (size_t k = pos; k < end; k++) {
+                    preoff[order[k]] = tot;
+                    tot += (int64_t)H.leaves[order[k]].t_size * H.leaves[order[k]].s_size;
+                }
+                std::vector<real> host(std::max<int64_t>(tot, 1));
+                for (size_t k = pos; k < end; k++) {
+                    const hmx_leaf &l = H.leaves[order[k]];
+                    gen(l.t_size, l.s_size, l.t_offset, l.s_offset, host.data() + preoff[order[k]]);
+                }
+                HMX_HIP(pre.upload(host));
+                HMX_HIP(d_preoff.upload(preoff));
+                D.pre     = pre.d;
+                D.pre_off = d_preoff.d;
+            }
             D.ks = H.ks;
             D.tx = H.tx.d; D.ty = H.ty.d; D.tz = H.tz.d;
             D.sx = H.sx.d; D.sy = H.sy.d; D.sz = H.sz.d;
@@ -905,6 +944,99 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
             pos = end;
+        }
+    } else if (!order.empty() && use_cb) {
+        // lock-step ACA: the generator runs on the host, everything else on the device (aca_cb_*_kernel)
+        DArr<int32_t> dI1, dI2, dq, dstatus, dactive;
+        DArr<real> dfrob, daux, dgamma, dbuf;
+        DArr<unsigned long long> dcur;
+        DArr<int64_t> dbufoff;
+        for (auto *a : {&dI1, &dI2, &dq, &dstatus}) {
+            HMX_HIP(a->alloc(nb));
+            HMX_HIP(a->zero());
+        }
+        for (auto *a : {&dfrob, &daux, &dgamma}) {
+            HMX_HIP(a->alloc(nb));
+            HMX_HIP(a->zero());
+        }
+        HMX_HIP(dcur.alloc(nb));
+        std::vector<int32_t> status(nb, 1), I1(nb, 0), I2(nb, 0), active = order;
+        for (int32_t b : order)
+            status[b] = 0;
+        const bool sympiv = compressor == HMX_SYMPARTIAL_ACA;
+        std::vector<int64_t> bufoff(nb, 0);
+        std::vector<real> hostbuf;
+        AcaCbArgs A{};
+        A.t_off = H.d_t_off.d; A.t_size = H.d_t_size.d; A.s_off = H.d_s_off.d; A.s_size = H.d_s_size.d;
+        A.symmetric_pivoting = sympiv;
+        A.epsilon = epsilon; A.reqrank = reqrank;
+        A.pool = H.pool.d; A.pool_head = head.d; A.pool_cap = cap;
+        A.colptr = H.d_colptr.d; A.colcap = d_colcap.d; A.cross_off = H.d_cross_off.d;
+        A.visited = visited.d; A.vis_ptr = d_visptr.d;
+        A.I1 = dI1.d; A.I2 = dI2.d; A.q = dq.d; A.status = dstatus.d;
+        A.frob = dfrob.d; A.aux = daux.d; A.gamma = dgamma.d; A.cur_off = dcur.d;
+        A.rank_out = H.d_rank.d; A.swapped_out = H.d_swapped.d;
+        auto phase = [&](bool row_phase) -> int {
+            int64_t tot = 0;
+            for (int32_t b : active) {
+                const hmx_leaf &l = H.leaves[b];
+                const bool sw = sympiv && !(l.t_offset >= l.s_offset);
+                const int n1 = sw ? l.s_size : l.t_size, n2 = sw ? l.t_size : l.s_size;
+                bufoff[b] = tot;
+                tot += row_phase ? n2 : n1;
+            }
+            hostbuf.resize(std::max<int64_t>(tot, 1));
+            for (int32_t b : active) {
+                const hmx_leaf &l = H.leaves[b];
+                const bool sw = sympiv && !(l.t_offset >= l.s_offset);
+                real *out = hostbuf.data() + bufoff[b];
+                if (row_phase) { // entries (I1, k), k over index 2
+                    if (!sw)
+                        gen(1, l.s_size, l.t_offset + I1[b], l.s_offset, out);
+                    else
+                        gen(l.t_size, 1, l.t_offset, l.s_offset + I1[b], out);
+                } else { // entries (k, I2), k over index 1
+                    if (!sw)
+                        gen(l.t_size, 1, l.t_offset, l.s_offset + I2[b], out);
+                    else
+                        gen(1, l.s_size, l.t_offset + I2[b], l.s_offset, out);
+                }
+            }
+            HMX_HIP(dbuf.upload(hostbuf));
+            HMX_HIP(dbufoff.upload(bufoff));
+            HMX_HIP(dactive.upload(active));
+            A.active = dactive.d; A.buf = dbuf.d; A.buf_off = dbufoff.d;
+            if (row_phase)
+                hipLaunchKernelGGL(aca_cb_row_kernel<256>, dim3((unsigned)active.size()), dim3(256), 0, 0, A);
+            else
+                hipLaunchKernelGGL(aca_cb_col_kernel<256>, dim3((unsigned)active.size()), dim3(256), 0, 0, A);
+            HMX_HIP(hipGetLastError());
+            HMX_HIP(hipMemcpy(status.data(), dstatus.d, nb * 4, hipMemcpyDeviceToHost));
+            HMX_HIP(hipMemcpy(I1.data(), dI1.d, nb * 4, hipMemcpyDeviceToHost));
+            HMX_HIP(hipMemcpy(I2.data(), dI2.d, nb * 4, hipMemcpyDeviceToHost));
+            std::vector<int32_t> still;
+            for (int32_t b : active)
+                if (status[b] == 0)
+                    still.push_back(b);
+            active.swap(still);
+            return HMX_OK;
+        };
+        // status was initialised to "active" for the admissible leaves only
+        {
+            std::vector<int32_t> st0(nb, 1);
+            for (int32_t b : order)
+                st0[b] = 0;
+            HMX_HIP(hipMemcpy(dstatus.d, st0.data(), nb * 4, hipMemcpyHostToDevice));
+        }
+        while (!active.empty()) {
+            int rcp = phase(true);
+            if (rcp != HMX_OK)
+                return rcp;
+            if (active.empty())
+                break;
+            rcp = phase(false);
+            if (rcp != HMX_OK)
+                return rcp;
         }
     } else if (!order.empty()) {
         AcaArgs A{};
@@ -960,6 +1092,24 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     for (size_t b = 0; b < nb; b++)
         if (H.kind[b] != LK_LOWRANK)
             H.leaves[b].rank = -1;
+    if (use_cb) { // dense leaves (and failed admissible ones): HMatrix::compute_dense_data through the host generator
+        int64_t tot = 0;
+        for (size_t b = 0; b < nb; b++)
+            if (H.kind[b] != LK_LOWRANK) {
+                H.staged_off[b] = tot;
+                tot += (int64_t)H.leaves[b].t_size * H.leaves[b].s_size;
+            }
+        std::vector<real> host(std::max<int64_t>(tot, 1));
+        for (size_t b = 0; b < nb; b++)
+            if (H.kind[b] != LK_LOWRANK) {
+                const hmx_leaf &l = H.leaves[b];
+                gen(l.t_size, l.s_size, l.t_offset, l.s_offset, host.data() + H.staged_off[b]);
+                H.kind[b] = LK_DENSE_STAGED;
+            }
+        HMX_HIP(H.dense_stage.upload(host));
+    } else {
+        H.dense_stage.release();
+    }
     int rc = build_streams(H);
     if (rc != HMX_OK)
         return rc;

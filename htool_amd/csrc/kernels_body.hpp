@@ -231,6 +231,188 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Partially pivoted ACA for a HOST generator (the user's VirtualGenerator::copy_submatrix, a C callback):
+// the same algorithm as aca_kernel, run in lock step over all admissible blocks.  Per iteration the host
+// evaluates one cross row per active block (callback), aca_cb_row_kernel subtracts the previous crosses and
+// picks the column pivot; the host evaluates those columns, aca_cb_col_kernel finishes the iteration (scaling,
+// row pivot, error estimator, stopping test).  All arithmetic except the generator itself stays on the device.
+// ---------------------------------------------------------------------------------------------
+struct AcaCbArgs {
+    const int32_t *active; // block ids handled by this launch
+    const int32_t *t_off, *t_size, *s_off, *s_size;
+    int symmetric_pivoting;
+    double epsilon;
+    int reqrank;
+    real *pool;
+    unsigned long long *pool_head;
+    unsigned long long pool_cap;
+    const int64_t *colptr;
+    const int32_t *colcap;
+    int64_t *cross_off;
+    unsigned char *visited;
+    const int64_t *vis_ptr;
+    // per-block state carried between launches
+    int32_t *I1, *I2, *q, *status; // status: 0 active, 1 finished
+    real *frob, *aux, *gamma;
+    unsigned long long *cur_off;
+    const real *buf;        // host-evaluated entries of this phase, packed
+    const int64_t *buf_off; // per block: first entry in buf
+    int32_t *rank_out, *swapped_out;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void aca_cb_row_kernel(AcaCbArgs A) {
+    __shared__ real sval[NT / WAVE];
+    __shared__ int sidx[NT / WAVE];
+    __shared__ unsigned long long s_off;
+    const int b = A.active[blockIdx.x];
+    const int M = A.t_size[b], N = A.s_size[b];
+    const bool swap = A.symmetric_pivoting && !(A.t_off[b] >= A.s_off[b]);
+    const int n1 = swap ? N : M, n2 = swap ? M : N;
+    unsigned char *vis1 = A.visited + A.vis_ptr[b], *vis2 = vis1 + n1;
+    int64_t *cross = A.cross_off + A.colptr[b];
+    const int tid  = threadIdx.x;
+    int q          = A.q[b] + 1;
+    const int I1   = A.I1[b];
+    auto finish = [&](int rank) {
+        if (tid == 0) {
+            A.status[b]      = 1;
+            A.rank_out[b]    = rank;
+            A.swapped_out[b] = swap ? 1 : 0;
+        }
+    };
+    if ((long long)q * ((long long)n1 + n2) > (long long)n1 * n2 || q > A.colcap[b]) {
+        finish(0); // not advantageous: the compressor reports failure, dense fallback
+        return;
+    }
+    if (tid == 0)
+        s_off = atomicAdd(A.pool_head, (unsigned long long)(n1 + n2));
+    __syncthreads();
+    const unsigned long long off = s_off;
+    if (off + (unsigned long long)(n1 + n2) > A.pool_cap) {
+        finish(-2);
+        return;
+    }
+    real *u1       = A.pool + off + n1;
+    const real *in = A.buf + A.buf_off[b];
+    real best = -1;
+    int besti = -1;
+    for (int k = tid; k < n2; k += NT) {
+        real v = in[k];
+        for (int j = 0; j < q - 1; j++) {
+            const real *cj  = A.pool + cross[j];
+            const real coef = -cj[I1];
+            v               = coef * cj[n1 + k] + v;
+        }
+        u1[k] = v;
+        if (!vis2[k]) {
+            const real a = fabs(v);
+            if (a >= best) {
+                best  = a;
+                besti = k;
+            }
+        }
+    }
+    block_argmax<NT>(best, besti, sval, sidx);
+    const int I2   = besti >= 0 ? besti : A.I2[b];
+    const real piv = u1[I2];
+    if (tid == 0)
+        vis1[I1] = 1;
+    if (fabs(piv) > 1e-15) {
+        if (tid == 0) {
+            A.I2[b]      = I2;
+            A.gamma[b]   = real(1) / piv;
+            A.cur_off[b] = off;
+            A.q[b]       = q; // provisional: the column phase completes iteration q
+        }
+    } else { // zero row: rank q-1, or failure when nothing was accepted yet
+        finish(q - 1 > 0 ? q - 1 : 0);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
+    __shared__ real sval[NT / WAVE];
+    __shared__ int sidx[NT / WAVE];
+    __shared__ real sbuf[(NT / WAVE) * 8];
+    const int b = A.active[blockIdx.x];
+    const int M = A.t_size[b], N = A.s_size[b];
+    const bool swap = A.symmetric_pivoting && !(A.t_off[b] >= A.s_off[b]);
+    const int n1 = swap ? N : M, n2 = swap ? M : N;
+    unsigned char *vis1 = A.visited + A.vis_ptr[b], *vis2 = vis1 + n1;
+    int64_t *cross = A.cross_off + A.colptr[b];
+    const int tid  = threadIdx.x;
+    const int q = A.q[b], I1 = A.I1[b], I2 = A.I2[b];
+    const real gamma = A.gamma[b];
+    const unsigned long long off = A.cur_off[b];
+    real *u2 = A.pool + off, *u1 = A.pool + off + n1;
+    const real *in = A.buf + A.buf_off[b];
+    real best = -1;
+    int besti = -1;
+    for (int k = tid; k < n1; k += NT) {
+        real v = in[k];
+        for (int j = 0; j < q - 1; j++) {
+            const real *cj  = A.pool + cross[j];
+            const real coef = -cj[n1 + I2];
+            v               = coef * cj[k] + v;
+        }
+        v     = v * gamma;
+        u2[k] = v;
+        if (!vis1[k] && k != I1) {
+            const real a = fabs(v);
+            if (a >= best) {
+                best  = a;
+                besti = k;
+            }
+        }
+    }
+    block_argmax<NT>(best, besti, sval, sidx);
+    real frob = A.frob[b], aux = A.aux[b];
+    if (A.reqrank < 0) {
+        real acc2[2] = {0, 0};
+        for (int k = tid; k < n1; k += NT)
+            acc2[0] += u2[k] * u2[k];
+        for (int k = tid; k < n2; k += NT)
+            acc2[1] += u1[k] * u1[k];
+        block_sum_group<NT, 2>(acc2, sbuf);
+        aux           = fabs(acc2[0]) * fabs(acc2[1]);
+        real frob_aux = 0;
+        for (int j0 = 0; j0 < q - 1; j0 += 4) {
+            real acc[8]  = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int nj = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
+            for (int g = 0; g < nj; g++) {
+                const real *cj = A.pool + cross[j0 + g];
+                real a1 = 0, a2 = 0;
+                for (int k = tid; k < n2; k += NT)
+                    a1 += cj[n1 + k] * u1[k];
+                for (int k = tid; k < n1; k += NT)
+                    a2 += cj[k] * u2[k];
+                acc[2 * g]     = a1;
+                acc[2 * g + 1] = a2;
+            }
+            block_sum_group<NT, 8>(acc, sbuf);
+            for (int g = 0; g < nj; g++)
+                frob_aux += acc[2 * g] * acc[2 * g + 1];
+        }
+        frob += aux + 2 * frob_aux;
+    }
+    const int minmn = n1 < n2 ? n1 : n2;
+    const bool more = (A.reqrank > 0) ? (q < (A.reqrank < minmn ? A.reqrank : minmn)) : (sqrt(aux / frob) > (real)A.epsilon);
+    if (tid == 0) {
+        vis2[I2]     = 1;
+        cross[q - 1] = (int64_t)off;
+        A.I1[b]      = besti >= 0 ? besti : I1;
+        A.frob[b]    = frob;
+        A.aux[b]     = aux;
+        if (!more) {
+            A.status[b]      = 1;
+            A.rank_out[b]    = q;
+            A.swapped_out[b] = swap ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Compression of an ASSEMBLED block: fully pivoted ACA and truncated SVD (small blocks; O(M N min(M,N))).
 // One workgroup per block, the block lives in a scratch slab; results are written as crosses
 // [U(:,k) | V(k,:)] into the same pool the partial ACA uses, so packing is shared.
@@ -251,6 +433,8 @@ struct DenseCompressArgs {
     const int32_t *colcap;
     int64_t *cross_off;
     int32_t *rank_out;
+    const real *pre;        // != NULL: blocks assembled by the host generator (column-major M x N) at pre_off[b]
+    const int64_t *pre_off;
 };
 
 // fullACA::copy_low_rank_approximation (hmatrix/lrmat/fullACA.hpp:38-88)
@@ -270,7 +454,7 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
     real acc1[1]   = {0};
     for (int64_t e = tid; e < MN; e += NT) {
         const int i = (int)(e % M), j = (int)(e / M);
-        const real v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        const real v = A.pre ? A.pre[A.pre_off[b] + e] : (real)eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
         mat[e]         = v;
         acc1[0] += v * v;
     }
@@ -423,7 +607,7 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
     constexpr int NW = NT / WAVE;
     for (int64_t e = tid; e < (int64_t)M * N; e += NT) {
         const int i = (int)(e % M), j = (int)(e / M);
-        const real v = eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        const real v = A.pre ? A.pre[A.pre_off[b] + e] : (real)eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
         if (tr)
             W[j + (int64_t)m * i] = v;
         else

@@ -18,6 +18,7 @@
 #include <htool/distributed_operator/interfaces/virtual_global_to_local_operator.hpp>
 #include <htool/hmatrix/hmatrix.hpp>
 #include <htool/hmatrix/interfaces/virtual_dense_blocks_generator.hpp>
+#include <htool/hmatrix/interfaces/virtual_generator.hpp>
 #include <htool/hmatrix/interfaces/virtual_lrmat_generator.hpp>
 #include <htool/misc/logger.hpp>
 
@@ -97,6 +98,16 @@ class Engine {
     // device compression with a built-in kernel (the generator must be the same function as the user's VirtualGenerator)
     bool compress_on_device(int kernel, const double *params, int nparams, int dim, const double *xt, const double *xs, int compressor, double epsilon, int reqrank) {
         return ok(hmx_hmatrix_set_kernel(m_hmatrix, kernel, params, nparams, dim, xt, xs), "set kernel") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
+    }
+
+    // compression on the device with the USER's generator: htool::VirtualGenerator<double>::copy_submatrix is called on
+    // the host for one cross row / column per block and ACA iteration (and for the dense leaves); the ACA arithmetic
+    // and every later product run on the GPU.  `A` must outlive this call only.
+    bool compress_with_generator(const htool::VirtualGenerator<double> &A, int compressor, double epsilon, int reqrank) {
+        auto thunk = [](void *user, int M, int N, const int32_t *rows, const int32_t *cols, double *out) {
+            static_cast<const htool::VirtualGenerator<double> *>(user)->copy_submatrix(M, N, rows, cols, out);
+        };
+        return ok(hmx_hmatrix_set_callback(m_hmatrix, thunk, const_cast<htool::VirtualGenerator<double> *>(&A)), "set callback") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
     }
 
     // htool-built H-matrix (any generator, any compressor) -> device

@@ -117,6 +117,17 @@ void hmx_hmatrix_destroy(hmx_hmatrix *);
 int hmx_hmatrix_set_kernel(hmx_hmatrix *, int kernel, const double *params, int nparams, int dim,
                            const double *target_coords, const double *source_coords);
 
+/* generator = the user's VirtualGenerator (hmatrix/interfaces/virtual_generator.hpp:24): a host callback with
+ * copy_submatrix semantics -- M x N entries of rows[0..M) x cols[0..N) (USER numbering) written column-major into out.
+ * Compression then runs in lock step: the callback produces one cross row / column per active block and iteration,
+ * all ACA arithmetic (residual updates, pivot search, error estimate) and every later product stay on the device.
+ * Dense leaves and fullACA/SVD blocks are assembled through the callback and uploaded.  The callback is invoked from
+ * the calling thread only. */
+typedef void (*hmx_generator_fn)(void *user, int M, int N, const int32_t *rows, const int32_t *cols, double *out);
+typedef void (*hmx_generator_fn_s)(void *user, int M, int N, const int32_t *rows, const int32_t *cols, float *out);
+int hmx_hmatrix_set_callback(hmx_hmatrix *, hmx_generator_fn fn, void *user);
+int hmx_hmatrix_set_callback_s(hmx_hmatrix *, hmx_generator_fn_s fn, void *user);
+
 /* HMatrixTreeBuilder::{sequential,openmp}_compute_blocks (tree_builder.hpp:568-666): compress every
  * admissible leaf (fallback to dense when the compressor reports failure), assemble every dense leaf
  * (HMatrix::compute_dense_data, hmatrix.hpp:222-226), then lay the result out as matvec streams. */

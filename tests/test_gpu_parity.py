@@ -479,3 +479,52 @@ def test_reference_examples_reproduce_published_errors():
     for P, expected in ((1, 9.8e-5), (2, 9.3e-5), (4, 6.6e-5)):
         e = dist_example.run_emulated(P)
         assert abs(e - expected) < 0.06e-5, (P, e)
+
+
+class _HostInvDist(hm.VirtualGenerator):
+    """A user generator written in numpy with the same operation order as the device kernel and the reference's
+    examples (squared differences summed left to right, one sqrt, one multiply, one add, one divide)."""
+
+    def __init__(self, xt, xs, delta, scale):
+        self.xt, self.xs, self.delta, self.scale = xt, xs, delta, scale
+        self.calls = 0
+
+    def copy_submatrix(self, M, N, rows, cols):
+        self.calls += 1
+        d = self.xt[rows][:, None, :] - self.xs[cols][None, :, :]
+        s = np.zeros((M, N))
+        for p in range(d.shape[2]):
+            s = s + d[:, :, p] * d[:, :, p]
+        return 1.0 / (self.delta + self.scale * np.sqrt(s))
+
+
+@pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_p2_symU_rank1",
+                                  "rect_ball1500_disk1000", "ball_n1200_fullACA", "ball_n1200_SVD", "ball_n1200_reqrank5",
+                                  "ball_n2000_n_bbox_c8"])
+def test_host_callback_generator(name):
+    """The user's VirtualGenerator as a host callback (hmx_hmatrix_set_callback): lock-step ACA with the generator on
+    the host and all arithmetic on the device must give the reference's structure, ranks and products."""
+    p, g = params(name), load(name)
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    tb.set_low_rank_generator(p["compressor"])
+    gen = _HostInvDist(T.coordinates, S.coordinates, p["delta"], p["scale"])
+    H = tb.build(gen, T, S, p["rank"], p["rank"])
+    assert gen.calls > 0
+    tab, ref = H.leaf_table(), g["leaves"]
+    if p["compressor"] == "SVD":
+        assert np.array_equal(tab[:, :4], ref[:, :4]) and np.abs(tab[:, 4] - ref[:, 4]).max() <= 1
+    else:
+        assert np.array_equal(tab, ref)
+    x, xT, y0, y0T = inputs(H)
+    alpha, beta = g["alphabeta"]
+    tol = 1e-10 if p["compressor"] != "SVD" else 5e-4
+    y = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+    assert rel_err(y, g["yN"]) < tol
+    y = y0T.copy()
+    hm.internal_add_hmatrix_vector_product("T", alpha, H, xT, beta, y)
+    assert rel_err(y, g["yT"]) < tol
+    for k in g:
+        if k.startswith("D_"):
+            assert np.array_equal(H.get_block(int(k[2:])), g[k].T)
