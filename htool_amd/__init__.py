@@ -7,4 +7,5 @@ operator interface over that ABI; distributed.py is the row-partitioned Distribu
 from ._lib import HmxError, lib  # noqa: F401
 from .api import (ClusterTreeBuilder, Cluster, HMatrixTreeBuilder, HMatrix, InvDistGenerator, VirtualGenerator,  # noqa: F401
                   add_hmatrix_vector_product, internal_add_hmatrix_vector_product,
-                  internal_add_hmatrix_matrix_product_row_major, add_hmatrix_matrix_product, create_geometry)
+                  internal_add_hmatrix_matrix_product_row_major, add_hmatrix_matrix_product, create_geometry,
+                  save_cluster_tree, read_cluster_tree, save_leaves_with_rank, matrix_to_bytes, bytes_to_matrix)

@@ -55,6 +55,10 @@ SYMBOLS = [
     ("hmx_cluster_tree_permutation", _ip, [_vp]),
     ("hmx_cluster_tree_nodes", C.c_int, [_vp, C.POINTER(ClusterNode)]),
     ("hmx_cluster_tree_partition", C.c_int, [_vp, _ip]),
+    ("hmx_cluster_tree_depths", C.c_int, [_vp, _ip]),
+    ("hmx_cluster_tree_save", C.c_int, [_vp, C.c_char_p]),
+    ("hmx_cluster_tree_load", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    ("hmx_block_tree_save_leaves_with_rank", C.c_int, [_vp, _ip, C.c_char_p]),
     ("hmx_block_tree_create", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_block_tree_create_local", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_block_tree_destroy", None, [_vp]),
@@ -82,6 +86,8 @@ SYMBOLS = [
     ("hmx_hmatrix_leaf_ranks", C.c_int, [_vp, _ip]),
     ("hmx_hmatrix_get_block", C.c_int, [_vp, C.c_int64, _dp, _dp]),
     ("hmx_hmatrix_stats", C.c_int, [_vp, C.POINTER(Stats)]),
+    ("hmx_hmatrix_save", C.c_int, [_vp, C.c_char_p]),
+    ("hmx_hmatrix_load", C.c_int, [_vp, C.c_int, C.c_char_p, C.POINTER(_vp)]),
     ("hmx_hmatrix_matvec", C.c_int, [_vp, C.c_char, C.c_double, _vp, C.c_double, _vp, C.c_int, _vp]),
     ("hmx_hmatrix_matvec_user", C.c_int, [_vp, C.c_char, C.c_double, _vp, C.c_double, _vp, C.c_int, _vp]),
     ("hmx_hmatrix_matmat_row_major", C.c_int, [_vp, C.c_char, C.c_double, _vp, C.c_double, _vp, C.c_int, C.c_int, _vp]),

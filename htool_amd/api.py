@@ -63,6 +63,23 @@ class Cluster:
     def get_permutation(self):
         return self._perm
 
+    def _depths(self):
+        d = np.zeros(4, dtype=np.int32)
+        check(lib().hmx_cluster_tree_depths(self._h, d.ctypes.data_as(C.POINTER(C.c_int32))))
+        return d
+
+    def get_maximal_depth(self):
+        return int(self._depths()[0])
+
+    def get_minimal_depth(self):
+        return int(self._depths()[1])
+
+    def get_maximal_leaf_size(self):
+        return int(self._depths()[2])
+
+    def is_permutation_local(self):
+        return bool(self._depths()[3])
+
     def get_clusters_on_partition(self):
         """(offset, size) of every partition cluster (Cluster::get_clusters_on_partition)."""
         return self._partition
@@ -79,6 +96,48 @@ class Cluster:
         if getattr(self, "_h", None):
             lib().hmx_cluster_tree_destroy(self._h)
             self._h = None
+
+
+def save_cluster_tree(cluster, filename):
+    """clustering/cluster_output.hpp:33-84: writes <filename>_cluster_tree_properties.csv and <filename>_cluster_tree.csv,
+    byte-identical to htool's files for the same tree."""
+    check(lib().hmx_cluster_tree_save(cluster._h, str(filename).encode()))
+
+
+def read_cluster_tree(file_cluster_tree_properties, file_cluster_tree, coordinates=None):
+    """clustering/cluster_output.hpp:87-179: a cluster tree from htool's (or save_cluster_tree's) files.  The files hold
+    radii and centers with 6 significant digits; like htool, the loaded tree carries those rounded values."""
+    h = C.c_void_p()
+    check(lib().hmx_cluster_tree_load(str(file_cluster_tree_properties).encode(), str(file_cluster_tree).encode(), C.byref(h)))
+    return Cluster(h, None if coordinates is None else np.ascontiguousarray(coordinates, dtype=np.float64))
+
+
+def matrix_to_bytes(mat, file):
+    """matrix/utils/output.hpp:41-55: int32 rows, int32 cols, then the column-major coefficients."""
+    a = np.asarray(mat)
+    with open(file, "wb") as f:
+        np.array(a.shape, dtype=np.int32).tofile(f)
+        np.asfortranarray(a).T.tofile(f)  # .T of an F-ordered array is C-contiguous: column-major bytes of `a`
+
+
+def bytes_to_matrix(file, dtype=np.float64):
+    """matrix/utils/output.hpp:57-75."""
+    with open(file, "rb") as f:
+        rows, cols = np.fromfile(f, dtype=np.int32, count=2)
+        data = np.fromfile(f, dtype=dtype, count=int(rows) * int(cols))
+    return data.reshape(cols, rows).T
+
+
+def save_leaves_with_rank(hmatrix, filename):
+    """hmatrix/hmatrix_output.hpp:39-55: writes <filename>.csv ("nt,ns", then t_off,t_size,s_off,s_size,rank per leaf in
+    htool's preorder; rank -1 = dense)."""
+    if isinstance(hmatrix, BlockTree):  # structure only: pass (block_tree, ranks) via the `ranks` attribute if set
+        r = getattr(hmatrix, "ranks", None)
+    else:
+        hmatrix.refresh_leaves()
+        r = hmatrix.ranks
+    ptr = None if r is None else np.ascontiguousarray(r, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))
+    check(lib().hmx_block_tree_save_leaves_with_rank(hmatrix._bt, ptr, str(filename).encode()))
 
 
 class ClusterTreeBuilder:
@@ -176,6 +235,10 @@ class HMatrix:
         self.target_offset, self.target_size, self.source_offset, self.source_size = [int(v) for v in r]
         self._sym, self._uplo = sym.raw.decode(), uplo.raw.decode()
         self.refresh_leaves()
+
+    def save(self, path):
+        """Binary dump of the compressed operator (hmx_hmatrix_save); reload with HMatrixTreeBuilder.load()."""
+        check(lib().hmx_hmatrix_save(self._h, str(path).encode()))
 
     def refresh_leaves(self):
         L = lib()
@@ -358,6 +421,24 @@ class HMatrixTreeBuilder:
             check(lib().hmx_hmatrix_compress(h, _lib.COMPRESSORS[self._compressor], self._eps, self._reqrank))
             H.refresh_leaves()
         return H
+
+
+    def load(self, path, target_root_cluster_tree, source_root_cluster_tree, target_partition_number=-1,
+             partition_number_for_symmetry=-1, device=0, local_partitions=None):
+        """An operator written by HMatrix.save(): the block tree is rebuilt from this builder's parameters (it must be the
+        one the file was written for), the blocks come from the file instead of a compressor."""
+        if local_partitions is not None:
+            bt = self._local_block_tree(target_root_cluster_tree, source_root_cluster_tree, *local_partitions)
+        else:
+            bt = self._block_tree(target_root_cluster_tree, source_root_cluster_tree, target_partition_number,
+                                  partition_number_for_symmetry)
+        h = C.c_void_p()
+        try:
+            check(lib().hmx_hmatrix_load(bt, device, str(path).encode(), C.byref(h)))
+        except HmxError:
+            lib().hmx_block_tree_destroy(bt)
+            raise
+        return HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
 
 
 def internal_add_hmatrix_vector_product(trans, alpha, A, x, beta, y):

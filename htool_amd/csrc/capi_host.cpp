@@ -77,6 +77,40 @@ int hmx_cluster_tree_nodes(const hmx_cluster_tree *T, hmx_cluster_node *out) {
     }
     return HMX_OK;
 }
+int hmx_cluster_tree_save(const hmx_cluster_tree *T, const char *prefix) {
+    if (!T || !prefix) {
+        hmx::set_error("hmx_cluster_tree_save: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    return hmx::save_cluster_tree(*T, prefix);
+}
+int hmx_cluster_tree_load(const char *properties_file, const char *tree_file, hmx_cluster_tree **out) {
+    if (!properties_file || !tree_file || !out) {
+        hmx::set_error("hmx_cluster_tree_load: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    auto *T = new (std::nothrow) hmx_cluster_tree();
+    if (!T)
+        return HMX_ERR_INVALID;
+    const int rc = hmx::load_cluster_tree(properties_file, tree_file, *T);
+    if (rc != HMX_OK) {
+        delete T;
+        return rc;
+    }
+    *out = T;
+    return HMX_OK;
+}
+int hmx_cluster_tree_depths(const hmx_cluster_tree *T, int32_t *max_min_leafsize_local) {
+    if (!T || !max_min_leafsize_local)
+        return HMX_ERR_INVALID;
+    int dmax, dmin;
+    hmx::cluster_tree_depths(*T, dmax, dmin);
+    max_min_leafsize_local[0] = dmax;
+    max_min_leafsize_local[1] = dmin;
+    max_min_leafsize_local[2] = T->opt.maximal_leaf_size;
+    max_min_leafsize_local[3] = T->permutation_is_local ? 1 : 0;
+    return HMX_OK;
+}
 int hmx_cluster_tree_partition(const hmx_cluster_tree *T, int32_t *offset_size) {
     if (!T || !offset_size)
         return HMX_ERR_INVALID;
@@ -159,6 +193,13 @@ int hmx_block_tree_root(const hmx_block_tree *bt, int32_t *r, char *symmetry_for
     if (uplo_for_leaves)
         *uplo_for_leaves = bt->uplo_for_leaves;
     return HMX_OK;
+}
+int hmx_block_tree_save_leaves_with_rank(const hmx_block_tree *bt, const int32_t *rank, const char *name) {
+    if (!bt || !name) {
+        hmx::set_error("hmx_block_tree_save_leaves_with_rank: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    return hmx::save_leaves_with_rank(bt->leaves, rank, bt->root_t_offset, bt->root_t_size, bt->root_s_offset, bt->root_s_size, name);
 }
 
 } // extern "C"

@@ -257,6 +257,42 @@ int hmx_hmatrix_matmat_row_major_s(hmx_hmatrix *H, char trans, float alpha, cons
     return hmx::f32::api_matmat_row_major(H->s, trans, alpha, in, beta, out, mu, mem, stream);
 }
 
+int hmx_hmatrix_save(const hmx_hmatrix *H, const char *path) { HMX_DISPATCH(H, hmx::f64::api_save(H->d, path), hmx::f32::api_save(H->s, path)); }
+int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, hmx_hmatrix **out) {
+    if (!bt || !path || !out) {
+        set_error("hmx_hmatrix_load: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        set_error(std::string("hmx_hmatrix_load: cannot open ") + path);
+        return HMX_ERR_INVALID;
+    }
+    hmx::f64::HmxFileHeader hd; // same layout in both instantiations
+    if (fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, hmx::f64::HMX_FILE_MAGIC, 8) != 0 || (hd.elem_size != 4 && hd.elem_size != 8)) {
+        fclose(f);
+        set_error(std::string("hmx_hmatrix_load: ") + path + " is not an hmx operator file");
+        return HMX_ERR_INVALID;
+    }
+    hmx::f64::HMat *d = nullptr;
+    hmx::f32::HMat *s = nullptr;
+    int rc;
+    if (hd.elem_size == 8) {
+        rc = hmx::f64::api_load(bt, device_id, f, hd, &d);
+    } else {
+        hmx::f32::HmxFileHeader hs;
+        std::memcpy(&hs, &hd, sizeof hs);
+        rc = hmx::f32::api_load(bt, device_id, f, hs, &s);
+    }
+    fclose(f);
+    if (rc != HMX_OK)
+        return rc;
+    *out      = new hmx_hmatrix();
+    (*out)->d = d;
+    (*out)->s = s;
+    return HMX_OK;
+}
+
 int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gbps) {
     int rc = ensure_device(device_id);
     if (rc != HMX_OK)

@@ -1355,6 +1355,128 @@ static int api_get_block(const HMat *Hc, int64_t leaf, real *U_or_D, real *V) {
     return HMX_OK;
 }
 
+// ---- binary dump of the compressed operator (no counterpart in the reference) ---------------------------
+// Layout: HmxFileHeader, hmx_leaf[nleaves] (ranks filled in), then per leaf in htool's leaf order either
+// U (M x r, column-major) followed by V (r x N, column-major) -- LowRankMatrix' own layout (lrmat.hpp:15-128) -- or the
+// dense block (M x N, column-major).  Loading goes through set_block_* + finalize, i.e. the upload path.
+struct HmxFileHeader {
+    char magic[8];
+    int32_t elem_size, reserved;
+    int64_t nleaves;
+    int32_t T0, nT, S0, nS;
+    int32_t symmetry, uplo;
+    double epsilon;
+};
+static const char HMX_FILE_MAGIC[8] = {'H', 'M', 'X', 'B', 'I', 'N', '1', '\0'};
+
+static int api_save(const HMat *Hc, const char *path) {
+    HMat *H = const_cast<HMat *>(Hc);
+    if (!H || !path) {
+        set_error("hmx_hmatrix_save: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    if (!H->finalized) {
+        set_error("hmx_hmatrix_save: operator not built");
+        return HMX_ERR_STATE;
+    }
+    HMX_HIP(hipSetDevice(H->device));
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        set_error(std::string("hmx_hmatrix_save: cannot create ") + path);
+        return HMX_ERR_INVALID;
+    }
+    HmxFileHeader hd{};
+    std::memcpy(hd.magic, HMX_FILE_MAGIC, 8);
+    hd.elem_size = (int32_t)sizeof(real);
+    hd.nleaves   = (int64_t)H->leaves.size();
+    hd.T0 = H->T0, hd.nT = H->nT, hd.S0 = H->S0, hd.nS = H->nS;
+    hd.symmetry = H->symmetry_for_leaves, hd.uplo = H->uplo_for_leaves;
+    hd.epsilon  = H->build_epsilon;
+    bool ok     = fwrite(&hd, sizeof hd, 1, f) == 1;
+    ok          = ok && (H->leaves.empty() || fwrite(H->leaves.data(), sizeof(hmx_leaf), H->leaves.size(), f) == H->leaves.size());
+    // the crosses of every low-rank leaf in one transfer
+    std::vector<real> pool(std::max<size_t>((size_t)H->pool_used, 1));
+    std::vector<int64_t> cross(std::max<size_t>(H->d_cross_off.n, 1));
+    if (H->pool_used)
+        HMX_HIP(hipMemcpy(pool.data(), H->pool.d, (size_t)H->pool_used * sizeof(real), hipMemcpyDeviceToHost));
+    if (H->d_cross_off.n)
+        HMX_HIP(hipMemcpy(cross.data(), H->d_cross_off.d, H->d_cross_off.n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    std::vector<real> buf;
+    for (size_t b = 0; ok && b < H->leaves.size(); b++) {
+        const hmx_leaf &l = H->leaves[b];
+        const int M = l.t_size, N = l.s_size;
+        if (H->kind[b] == LK_LOWRANK) {
+            const int r   = l.rank;
+            const bool sw = H->swapped[b] != 0;
+            const int n1  = sw ? N : M;
+            buf.assign((size_t)r * (M + N), real(0));
+            real *U = buf.data(), *V = buf.data() + (size_t)r * M;
+            for (int k = 0; k < r; k++) {
+                const real *c    = pool.data() + cross[H->colptr[b] + k];
+                const real *ucol = sw ? c + n1 : c, *vrow = sw ? c : c + n1;
+                std::copy_n(ucol, M, U + (size_t)k * M);
+                for (int j = 0; j < N; j++)
+                    V[k + (size_t)r * j] = vrow[j];
+            }
+        } else {
+            buf.assign((size_t)M * N, real(0));
+            const int rc = api_get_block(H, (int64_t)b, buf.data(), nullptr);
+            if (rc != HMX_OK) {
+                fclose(f);
+                return rc;
+            }
+        }
+        ok = buf.empty() || fwrite(buf.data(), sizeof(real), buf.size(), f) == buf.size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        set_error(std::string("hmx_hmatrix_save: write to ") + path + " failed");
+        return HMX_ERR_INVALID;
+    }
+    return HMX_OK;
+}
+
+// `f` is positioned just behind the header (engine.hip reads it to pick the precision)
+static int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxFileHeader &hd, HMat **out) {
+    HMat *H = nullptr;
+    int rc  = api_create(bt, device_id, &H);
+    if (rc != HMX_OK)
+        return rc;
+    auto fail = [&](const std::string &why) {
+        set_error("hmx_hmatrix_load: " + why);
+        delete H;
+        return HMX_ERR_INVALID;
+    };
+    if (hd.nleaves != (int64_t)H->leaves.size() || hd.T0 != H->T0 || hd.nT != H->nT || hd.S0 != H->S0 || hd.nS != H->nS)
+        return fail("the file was written for a different block tree");
+    std::vector<hmx_leaf> fl((size_t)hd.nleaves);
+    if (hd.nleaves && fread(fl.data(), sizeof(hmx_leaf), fl.size(), f) != fl.size())
+        return fail("truncated file");
+    std::vector<real> buf;
+    for (size_t b = 0; b < fl.size(); b++) {
+        const hmx_leaf &a = fl[b], &l = H->leaves[b];
+        if (a.t_offset != l.t_offset || a.t_size != l.t_size || a.s_offset != l.s_offset || a.s_size != l.s_size || a.mirror != l.mirror)
+            return fail("leaf " + std::to_string(b) + " does not match the block tree");
+        const size_t count = a.rank >= 0 ? (size_t)a.rank * (a.t_size + a.s_size) : (size_t)a.t_size * a.s_size;
+        buf.resize(std::max<size_t>(count, 1));
+        if (count && fread(buf.data(), sizeof(real), count, f) != count)
+            return fail("truncated file");
+        rc = a.rank >= 0 ? api_set_block_lowrank(H, (int64_t)b, a.rank, buf.data(), buf.data() + (size_t)a.rank * a.t_size) : api_set_block_dense(H, (int64_t)b, buf.data());
+        if (rc != HMX_OK) {
+            delete H;
+            return rc;
+        }
+    }
+    H->build_epsilon = hd.epsilon;
+    rc               = api_finalize(H);
+    if (rc != HMX_OK) {
+        delete H;
+        return rc;
+    }
+    *out = H;
+    return HMX_OK;
+}
+
 static int api_stats(const HMat *H, hmx_stats *out) {
     if (!H || !out)
         return HMX_ERR_INVALID;

@@ -67,4 +67,9 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
                        const ClusterTreeOptions &opt, hmx_cluster_tree &out);
 int build_block_tree(hmx_block_tree &bt);
 void make_geometry(const std::string &name, int n, double z, double *coords);
+// io.cpp: htool's CSV formats
+int save_cluster_tree(const hmx_cluster_tree &T, const std::string &prefix);
+int load_cluster_tree(const std::string &props_file, const std::string &tree_file, hmx_cluster_tree &T);
+void cluster_tree_depths(const hmx_cluster_tree &T, int &max_depth, int &min_depth);
+int save_leaves_with_rank(const std::vector<hmx_leaf> &leaves, const int32_t *rank, int t0, int nt, int s0, int ns, const std::string &name);
 } // namespace hmx

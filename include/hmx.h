@@ -92,6 +92,13 @@ int hmx_cluster_tree_num_partitions(const hmx_cluster_tree *);
 const int32_t *hmx_cluster_tree_permutation(const hmx_cluster_tree *); /* Cluster::get_permutation           */
 int hmx_cluster_tree_nodes(const hmx_cluster_tree *, hmx_cluster_node *out /* num_nodes, preorder */);
 int hmx_cluster_tree_partition(const hmx_cluster_tree *, int32_t *offset_size /* 2*num_partitions */);
+/* get_maximal_depth, get_minimal_depth, get_maximal_leaf_size, is_permutation_local (clustering/cluster_node.hpp:63-64) */
+int hmx_cluster_tree_depths(const hmx_cluster_tree *, int32_t *max_min_leafsize_local /* 4 */);
+/* save_cluster_tree / read_cluster_tree (clustering/cluster_output.hpp:33-84,87-179): writes / reads
+ * <prefix>_cluster_tree_properties.csv and <prefix>_cluster_tree.csv, byte-compatible with htool's files
+ * (radius and centers carry 6 significant digits there, as in htool). */
+int hmx_cluster_tree_save(const hmx_cluster_tree *, const char *prefix);
+int hmx_cluster_tree_load(const char *properties_file, const char *tree_file, hmx_cluster_tree **out);
 
 /* ---- block tree: HMatrixTreeBuilder::build_block_tree + reset_root (hmatrix/tree_builder/tree_builder.hpp:417-566) */
 int hmx_block_tree_create(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
@@ -106,6 +113,10 @@ void hmx_block_tree_destroy(hmx_block_tree *);
 int64_t hmx_block_tree_num_leaves(const hmx_block_tree *);
 int hmx_block_tree_leaves(const hmx_block_tree *, hmx_leaf *out);
 int hmx_block_tree_root(const hmx_block_tree *, int32_t *t_off_size_s_off_size /* 4 */, char *symmetry_for_leaves, char *uplo_for_leaves);
+/* save_leaves_with_rank (hmatrix/hmatrix_output.hpp:39-55): writes <name>.csv = "nt,ns" then
+ * "t_off,t_size,s_off,s_size,rank" per leaf (offsets relative to the root block, rank -1 = dense).
+ * rank = hmx_hmatrix_leaf_ranks() output, or NULL for the bare block tree. */
+int hmx_block_tree_save_leaves_with_rank(const hmx_block_tree *, const int32_t *rank, const char *name);
 
 /* ---- H-matrix on the device ---------------------------------------------------------------------------- */
 int hmx_hmatrix_create(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out);   /* HMatrix<double,double> */
@@ -150,6 +161,11 @@ int hmx_hmatrix_finalize(hmx_hmatrix *);
 int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *, int32_t *rank /* num_leaves, -1 dense */);
 int hmx_hmatrix_get_block(const hmx_hmatrix *, int64_t leaf, double *U_or_D, double *V);
 int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);
+/* Binary dump of the compressed operator (no counterpart in the reference): header, leaf table with
+ * ranks, then per leaf U (M x r) and V (r x N) or the dense M x N block, all column-major as in htool's
+ * LowRankMatrix / Matrix.  Load needs the block tree the file was written for and picks fp32/fp64 from the file. */
+int hmx_hmatrix_save(const hmx_hmatrix *, const char *path);
+int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, hmx_hmatrix **out);
 
 /* openmp_internal_add_hmatrix_vector_product (hmatrix/linalg/add_hmatrix_vector_product.hpp:107-170):
  * out = alpha * op(H) * in + beta * out, cluster numbering, vectors local to the H-matrix' root clusters.

@@ -12,6 +12,9 @@
 // Dump format (little endian): repeated records
 //   u32 name_len | name bytes | u8 dtype ('i' int32,'l' int64,'d' float64) | u32 ndim | u64 dims[ndim] | payload
 #include <htool/clustering/cluster_node.hpp>
+#include <htool/clustering/cluster_output.hpp>
+#include <htool/hmatrix/hmatrix_output.hpp>
+#include <htool/matrix/utils/output.hpp>
 #include <htool/clustering/implementations/partitioning.hpp>
 #include <htool/clustering/tree_builder/tree_builder.hpp>
 #include <htool/hmatrix/hmatrix.hpp>
@@ -299,6 +302,21 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     D.i32("leaves", leaves, {leaves.size() / 6, 6});
     std::vector<int> rootinfo = {H.get_target_cluster().get_offset(), H.get_target_cluster().get_size(), H.get_source_cluster().get_offset(), H.get_source_cluster().get_size(), tb.get_false_positive(), (int)H.get_symmetry_for_leaves(), (int)H.get_UPLO_for_leaves()};
     D.i32("rootinfo", rootinfo);
+
+    // the reference's own on-disk formats (clustering/cluster_output.hpp:33-84,87-179, hmatrix/hmatrix_output.hpp:39-55):
+    // <prefix>_cluster_tree{,_properties}.csv, the same tree after read_cluster_tree -> save (prefix_reread_*), the leaf list
+    std::string save_prefix = gets(kv, "save_prefix", "");
+    if (!save_prefix.empty()) {
+        save_cluster_tree(tct, save_prefix);
+        Cluster<double> reread = read_cluster_tree<double>(save_prefix + "_cluster_tree_properties.csv", save_prefix + "_cluster_tree.csv");
+        save_cluster_tree(reread, save_prefix + "_reread");
+        save_leaves_with_rank(H, save_prefix + "_leaves");
+        for (auto *l : leaf_ptr)
+            if (l->is_dense()) {
+                matrix_to_bytes(*l->get_dense_data(), save_prefix + "_dense0.bin");
+                break;
+            }
+    }
 
     // Payload of the first few low-rank and dense leaves (or all of them, concatenated)
     {

@@ -72,6 +72,12 @@ CASES = {
     **{"ellipse_n4000_p4_rank%d" % r: ("hmat", dict(n=4000, geom="ellipse", leaf=100, partitions=4, rank=r, eps=1e-4, compressor="partialACA", dump_blocks=1)) for r in range(4)},
     **{"ball_n2000_p2_symL_rank%d" % r: ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=2, rank=r, eps=1e-3, sym="S", uplo="L", compressor="sympartialACA", dump_blocks=1)) for r in range(2)},
     **{"ball_n2000_p2_symU_rank%d" % r: ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=2, rank=r, eps=1e-3, sym="S", uplo="U", compressor="sympartialACA", dump_blocks=1)) for r in range(2)},
+    # the reference's on-disk formats (save_cluster_tree, read_cluster_tree -> save, save_leaves_with_rank, matrix_to_bytes):
+    # the files the reference wrote, stored as bytes
+    "io_ellipse_n1000_p2": ("io", dict(n=1000, geom="ellipse", leaf=50, eps=1e-3, partitions=2, compressor="partialACA")),
+    "io_ball_n1200_c4_p4": ("io", dict(n=1200, geom="ball", leaf=30, children=4, partitions=4, eps=1e-3, partitioning="n_pca_regular", compressor="partialACA")),
+    "io_disk2d_n800_symL_p1": ("io", dict(n=800, geom="disk2d", leaf=40, eps=1e-3, partitions=1, sym="S", uplo="L", compressor="sympartialACA")),
+    "io_ball_n1500_p4_rank2": ("io", dict(n=1500, geom="ball", leaf=50, eps=1e-3, partitions=4, rank=2, compressor="partialACA")),
     # the reference's own compressor test block (500 x 100, two disks at distance d)
     **{"lrmat_d%d" % d: ("lrmat", dict(distance=d, eps=1e-4)) for d in (15, 20, 30, 40)},
 }
@@ -87,6 +93,18 @@ def main():
             continue
         params = dict(params)
         keep_coords = params.pop("keep_coords", 0)
+        if mode == "io":
+            with tempfile.TemporaryDirectory() as tmp:
+                cmd = [DRIVER, "hmat"] + ["%s=%s" % (k, v) for k, v in params.items()] + ["out=" + tmp + "/d.bin", "dump_blocks=0", "save_prefix=" + tmp + "/f"]
+                print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                d = {}
+                for key, fn in (("tree", "f_cluster_tree.csv"), ("properties", "f_cluster_tree_properties.csv"), ("reread_tree", "f_reread_cluster_tree.csv"),
+                                ("reread_properties", "f_reread_cluster_tree_properties.csv"), ("leaves", "f_leaves.csv"), ("dense0", "f_dense0.bin")):
+                    d[key] = np.fromfile(os.path.join(tmp, fn), dtype=np.uint8)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+            manifest[name] = dict(mode=mode, **params)
+            continue
         with tempfile.NamedTemporaryFile(suffix=".bin") as tmp:
             cmd = [DRIVER, mode] + ["%s=%s" % (k, v) for k, v in params.items()] + ["out=" + tmp.name]
             print(" ".join(cmd))
