@@ -19,6 +19,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -534,14 +535,30 @@ static std::unique_ptr<ClusterTree> create_cluster_tree(int n, int dim, const do
 } // namespace orc
 
 namespace orc {
+#define ORC_COMPLEX 0
 namespace f64 {
-using real = double;
+using real   = double;
+using scalar = double;
 #include "hmx_oracle_body.hpp"
 } // namespace f64
 namespace f32 {
-using real = float;
+using real   = float;
+using scalar = float;
 #include "hmx_oracle_body.hpp"
 } // namespace f32
+#undef ORC_COMPLEX
+#define ORC_COMPLEX 1
+namespace z64 { // htool's HMatrix<std::complex<double>, double>
+using real   = double;
+using scalar = std::complex<double>;
+#include "hmx_oracle_body.hpp"
+} // namespace z64
+namespace c32 { // HMatrix<std::complex<float>, double>
+using real   = float;
+using scalar = std::complex<float>;
+#include "hmx_oracle_body.hpp"
+} // namespace c32
+#undef ORC_COMPLEX
 } // namespace orc
 
 
@@ -823,6 +840,132 @@ void *orc_hmatrix_from_blocks(int nb, const int *desc, const int64_t *offs, cons
         from_blocks_impl(*o->d, (orc::f64::Block *)nullptr, nb, desc, offs, data, root, sym_for_leaves, uplo);
     }
     return o;
+}
+
+// ---- complex coefficients: the same restatement instantiated for std::complex; vectors and payloads
+// cross the ABI as interleaved (re, im) doubles -----------------------------------------------------------------
+struct OracleZ {
+    bool c32 = false;
+    std::unique_ptr<orc::z64::HMat> z;
+    std::unique_ptr<orc::c32::HMat> c;
+    orc::z64::Generator gz;
+    orc::c32::Generator gc;
+};
+extern "C++" {
+template <typename F>
+static auto with_z(void *h, F &&f) {
+    auto *o = static_cast<OracleZ *>(h);
+    return o->c32 ? f(*o->c) : f(*o->z);
+}
+template <typename C>
+static std::vector<C> z_in(const double *p, size_t n) {
+    std::vector<C> v(n);
+    for (size_t i = 0; i < n; i++)
+        v[i] = C((typename C::value_type)p[2 * i], (typename C::value_type)p[2 * i + 1]);
+    return v;
+}
+template <typename It>
+static void z_out(It b, It e, double *p) {
+    for (size_t i = 0; b != e; ++b, ++i) {
+        p[2 * i]     = b->real();
+        p[2 * i + 1] = b->imag();
+    }
+}
+}
+void *orc_zhmatrix_build(void *tct, void *sct, int dim, const double *xt, const double *xs, double delta, double scale, double cre, double cim, double eps, double eta, char sym, char uplo, int reqrank, int compressor, int mint, int mins, int target_partition, int partition_for_symmetry, int consistent, int parallel, int c32, int root_partition) {
+    auto *T = static_cast<ClusterTree *>(tct);
+    auto *S = static_cast<ClusterTree *>(sct);
+    auto *o = new OracleZ();
+    o->c32  = c32 != 0;
+    if (o->c32) {
+        o->gc = orc::c32::Generator{dim, xt, xs, T->td.perm.data(), S->td.perm.data(), delta, scale, cre, cim, sym == 'H'};
+        o->c  = orc::c32::build_hmatrix(*T, *S, o->gc, (float)eps, eta, sym, uplo, reqrank, compressor, mint, mins, target_partition, partition_for_symmetry, consistent != 0, parallel != 0, root_partition);
+    } else {
+        o->gz = orc::z64::Generator{dim, xt, xs, T->td.perm.data(), S->td.perm.data(), delta, scale, cre, cim, sym == 'H'};
+        o->z  = orc::z64::build_hmatrix(*T, *S, o->gz, eps, eta, sym, uplo, reqrank, compressor, mint, mins, target_partition, partition_for_symmetry, consistent != 0, parallel != 0, root_partition);
+    }
+    return o;
+}
+void orc_zhmatrix_destroy(void *h) { delete static_cast<OracleZ *>(h); }
+int orc_zhmatrix_num_leaves(void *h) {
+    return with_z(h, [](auto &H) { return (int)H.preorder.size(); });
+}
+void orc_zhmatrix_leaves(void *h, int order, int *out) {
+    with_z(h, [&](auto &H) {
+        auto &ls = order ? H.dfs_order : H.preorder;
+        int i    = 0;
+        for (auto &l : ls) {
+            int *p = out + 6 * i++;
+            p[0]   = l.b->t->offset;
+            p[1]   = l.b->t->size;
+            p[2]   = l.b->s->offset;
+            p[3]   = l.b->s->size;
+            p[4]   = l.b->kind == 2 ? l.b->lr.rank : -1;
+            p[5]   = l.mirror ? 1 : 0;
+        }
+        return 0;
+    });
+}
+void orc_zhmatrix_rootinfo(void *h, int *out) {
+    with_z(h, [&](auto &H) {
+        out[0] = H.root_t->offset;
+        out[1] = H.root_t->size;
+        out[2] = H.root_s->offset;
+        out[3] = H.root_s->size;
+        out[4] = H.false_positive;
+        out[5] = H.sym_for_leaves;
+        out[6] = H.uplo_for_leaves;
+        return 0;
+    });
+}
+int orc_zhmatrix_block(void *h, int b, double *U, double *V, double *D) {
+    return with_z(h, [&](auto &H) {
+        auto *B = H.preorder[b].b;
+        if (B->kind == 2) {
+            if (U)
+                z_out(B->lr.U.begin(), B->lr.U.end(), U);
+            if (V)
+                z_out(B->lr.V.begin(), B->lr.V.end(), V);
+            return B->lr.rank;
+        }
+        if (D)
+            z_out(B->dense.begin(), B->dense.end(), D);
+        return -1;
+    });
+}
+void orc_zhmatrix_matvec(void *h, int policy, char trans, const double *alpha, const double *in, const double *beta, double *out) {
+    with_z(h, [&](auto &H) {
+        using C        = typename std::decay<decltype(H.preorder[0].b->dense[0])>::type;
+        const int nin  = trans == 'N' ? H.root_s->size : H.root_t->size;
+        const int nout = trans == 'N' ? H.root_t->size : H.root_s->size;
+        std::vector<C> x = z_in<C>(in, nin), y = z_in<C>(out, nout);
+        const C al = z_in<C>(alpha, 1)[0], be = z_in<C>(beta, 1)[0];
+        if (policy == 0)
+            matvec_seq(H, trans, al, x.data(), be, y.data());
+        else
+            matvec_omp(H, trans, al, x.data(), be, y.data());
+        z_out(y.begin(), y.end(), out);
+        return 0;
+    });
+}
+void orc_zhmatrix_matmat_row_major(void *h, char trans, const double *alpha, const double *in, const double *beta, double *out, int mu) {
+    with_z(h, [&](auto &H) {
+        using C           = typename std::decay<decltype(H.preorder[0].b->dense[0])>::type;
+        const size_t nin  = (size_t)(trans == 'N' ? H.root_s->size : H.root_t->size) * mu;
+        const size_t nout = (size_t)(trans == 'N' ? H.root_t->size : H.root_s->size) * mu;
+        std::vector<C> x = z_in<C>(in, nin), y = z_in<C>(out, nout);
+        matmat_rm_seq(H, trans, z_in<C>(alpha, 1)[0], x.data(), z_in<C>(beta, 1)[0], y.data(), mu);
+        z_out(y.begin(), y.end(), out);
+        return 0;
+    });
+}
+void orc_zgenerate_block(void *tct, void *sct, int dim, const double *xt, const double *xs, double delta, double scale, double cre, double cim, int hermitian, int M, int N, int row_off, int col_off, double *out) {
+    auto *T = static_cast<ClusterTree *>(tct);
+    auto *S = static_cast<ClusterTree *>(sct);
+    orc::z64::Generator g{dim, xt, xs, T->td.perm.data(), S->td.perm.data(), delta, scale, cre, cim, hermitian};
+    std::vector<std::complex<double>> tmp((size_t)M * N);
+    g.copy_submatrix(M, N, row_off, col_off, tmp.data());
+    z_out(tmp.begin(), tmp.end(), out);
 }
 
 int orc_num_threads() {

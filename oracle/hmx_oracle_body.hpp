@@ -1,6 +1,6 @@
 // hmx_oracle_body.hpp -- TEST INFRASTRUCTURE (part of the CPU oracle, see hmx_oracle.cpp).  The coefficient-typed part
-// of the restatement (generator, compressors, block payloads, leaf products), written against `real` and included
-// twice: namespace orc::f64 (real = double) and orc::f32 (real = float, htool's HMatrix<float,double>).
+// of the restatement (generator, compressors, block payloads, leaf products), written against `scalar` and included
+// twice: namespace orc::f64 (scalar = double) and orc::f32 (scalar = float, htool's HMatrix<float,double>).
 
 // ---------------------------------------------------------------------------------------------
 // Generator: K(x,y) = 1/(delta + scale*|x-y|); examples/use_hmatrix.cpp:24-35,
@@ -12,35 +12,58 @@ struct Generator {
     const double *xt, *xs;
     const int *pt, *ps;
     double delta, scale;
-    inline double coef(int i, int j) const { // user numbering
+    // complex coefficients: (cre + i cim sgn) / (delta + scale |x-y|), sgn = 1 (complex symmetric form of
+    // testing/generator_test.hpp:163-170,189-196) or sign(x_t[0] - x_s[0]) (Hermitian form, :198-205)
+    double cre = 1, cim = 0;
+    int hermitian = 0;
+    inline double denominator(int i, int j) const { // user numbering
         double s = 0;
         for (int p = 0; p < dim; p++) {
             double d = xt[dim * i + p] - xs[dim * j + p];
             s        = s + d * d;
         }
-        return 1. / (delta + scale * std::sqrt(s));
+        return delta + scale * std::sqrt(s);
     }
-    void copy_submatrix(int M, int N, int row_off, int col_off, real *ptr) const { // cluster numbering
+    inline scalar value(int i, int j) const {
+#if ORC_COMPLEX
+        const double u   = xt[dim * i] - xs[dim * j];
+        const double sgn = hermitian ? (u > 0 ? 1. : (u < 0 ? -1. : 0.)) : 1.;
+        return scalar(std::complex<double>(cre, cim * sgn) / denominator(i, j)); // complex<double> / double, then to scalar
+#else
+        return (scalar)(1. / denominator(i, j));
+#endif
+    }
+    void copy_submatrix(int M, int N, int row_off, int col_off, scalar *ptr) const { // cluster numbering
         for (int j = 0; j < M; j++)
             for (int k = 0; k < N; k++)
-                ptr[j + (size_t)M * k] = (real)coef(pt[row_off + j], ps[col_off + k]);
+                ptr[j + (size_t)M * k] = value(pt[row_off + j], ps[col_off + k]);
     }
 };
+
+// conj_if_complex / std::real on either kind of scalar (misc/misc.hpp)
+#if ORC_COMPLEX
+static inline scalar cj(scalar v) { return std::conj(v); }
+static inline real re_part(scalar v) { return v.real(); }
+#else
+static inline scalar cj(scalar v) { return v; }
+static inline real re_part(scalar v) { return v; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Compressors
 // ---------------------------------------------------------------------------------------------
 struct LowRank {
     int M = 0, N = 0, rank = 0;
-    std::vector<real> U; // M x r column-major
-    std::vector<real> V; // r x N column-major
+    std::vector<scalar> U; // M x r column-major
+    std::vector<scalar> V; // r x N column-major
     std::vector<int> pivots; // (I,J) per accepted iteration, for parity checks
 };
 
-static real plain_dot(int n, const real *a, const real *b) {
-    real s = 0;
+// Blas<T>::dot is htool's own loop, conjugating the FIRST argument (wrappers/wrapper_blas.hpp:152-157)
+static scalar plain_dot(int n, const scalar *a, const scalar *b) {
+    scalar s = scalar();
     for (int i = 0; i < n; i++)
-        s += a[i] * b[i];
+        s += cj(a[i]) * b[i];
     return s;
 }
 
@@ -48,10 +71,10 @@ static real plain_dot(int n, const real *a, const real *b) {
 // "not advantageous" test is kept on purpose.
 static bool partial_aca(const Generator &A, int M, int N, int row_off, int col_off, real epsilon, int reqrank, LowRank &lr) {
     int I = 0, J = 0, q = 0;
-    std::vector<std::vector<real>> uu, vv;
+    std::vector<std::vector<scalar>> uu, vv;
     std::vector<bool> vrow(M, false), vcol(N, false);
     real frob = 0, aux = 0, pivot, tmp;
-    std::vector<real> r(N), c(M);
+    std::vector<scalar> r(N), c(M);
     lr.pivots.clear();
     while (((reqrank > 0) && (q < std::min(reqrank, std::min(M, N)))) || ((reqrank < 0) && (q == 0 || sqrt(aux / frob) > epsilon))) {
         q += 1;
@@ -59,10 +82,10 @@ static bool partial_aca(const Generator &A, int M, int N, int row_off, int col_o
             q = -1;
             break;
         }
-        std::fill(r.begin(), r.end(), 0.);
+        std::fill(r.begin(), r.end(), scalar(0));
         A.copy_submatrix(1, N, I + row_off, col_off, r.data());
         for (size_t j = 0; j < uu.size(); j++) {
-            real coef = -uu[j][I];
+            scalar coef = -uu[j][I];
             for (int k = 0; k < N; k++)
                 r[k] += coef * vv[j][k]; // axpy
         }
@@ -77,12 +100,12 @@ static bool partial_aca(const Generator &A, int M, int N, int row_off, int col_o
             J     = k;
         }
         vrow[I]      = true;
-        real gamma = real(1.) / r[J];
+        scalar gamma = scalar(1.) / r[J];
         if (std::abs(r[J]) > 1e-15) {
-            std::fill(c.begin(), c.end(), 0.);
+            std::fill(c.begin(), c.end(), scalar(0));
             A.copy_submatrix(M, 1, row_off, J + col_off, c.data());
             for (size_t k = 0; k < uu.size(); k++) {
-                real coef = -vv[k][J];
+                scalar coef = -vv[k][J];
                 for (int i = 0; i < M; i++)
                     c[i] += coef * uu[k][i];
             }
@@ -102,11 +125,11 @@ static bool partial_aca(const Generator &A, int M, int N, int row_off, int col_o
             }
             vcol[J] = true;
             if (reqrank < 0) {
-                real frob_aux = 0.;
+                scalar frob_aux = scalar(0);
                 aux             = std::abs(plain_dot(M, c.data(), c.data())) * std::abs(plain_dot(N, r.data(), r.data()));
                 for (size_t j = 0; j < uu.size(); j++)
                     frob_aux += plain_dot(N, vv[j].data(), r.data()) * plain_dot(M, uu[j].data(), c.data());
-                frob += aux + 2 * frob_aux;
+                frob += aux + 2 * re_part(frob_aux);
             }
             uu.push_back(c);
             vv.push_back(r);
@@ -150,10 +173,10 @@ static bool sympartial_aca(const Generator &A, int M, int N, int row_off, int co
         i2 = row_off;
     }
     int I1 = 0, I2 = 0, q = 0;
-    std::vector<std::vector<real>> uu, vv;
+    std::vector<std::vector<scalar>> uu, vv;
     std::vector<bool> v1(n1, false), v2(n2, false);
     real frob = 0, aux = 0, pivot, tmp;
-    std::vector<real> u1(n2), u2(n1);
+    std::vector<scalar> u1(n2), u2(n1);
     lr.pivots.clear();
     while (((reqrank > 0) && (q < std::min(reqrank, std::min(n1, n2)))) || ((reqrank < 0) && (q == 0 || sqrt(aux / frob) > epsilon))) {
         q += 1;
@@ -161,13 +184,13 @@ static bool sympartial_aca(const Generator &A, int M, int N, int row_off, int co
             q = -1;
             break;
         }
-        std::fill(u1.begin(), u1.end(), 0.);
+        std::fill(u1.begin(), u1.end(), scalar(0));
         if (rows_first)
             A.copy_submatrix(1, n2, i1 + I1, i2, u1.data());
         else
             A.copy_submatrix(n2, 1, i2, i1 + I1, u1.data());
         for (size_t j = 0; j < uu.size(); j++) {
-            real coef = -uu[j][I1];
+            scalar coef = -uu[j][I1];
             for (int k = 0; k < n2; k++)
                 u1[k] += coef * vv[j][k];
         }
@@ -182,15 +205,15 @@ static bool sympartial_aca(const Generator &A, int M, int N, int row_off, int co
             I2    = k;
         }
         v1[I1]       = true;
-        real gamma = real(1.) / u1[I2];
+        scalar gamma = scalar(1.) / u1[I2];
         if (std::abs(u1[I2]) > 1e-15) {
-            std::fill(u2.begin(), u2.end(), 0.);
+            std::fill(u2.begin(), u2.end(), scalar(0));
             if (rows_first)
                 A.copy_submatrix(n1, 1, i1, i2 + I2, u2.data());
             else
                 A.copy_submatrix(1, n1, i2 + I2, i1, u2.data());
             for (size_t k = 0; k < uu.size(); k++) {
-                real coef = -vv[k][I2];
+                scalar coef = -vv[k][I2];
                 for (int i = 0; i < n1; i++)
                     u2[i] += coef * uu[k][i];
             }
@@ -210,11 +233,11 @@ static bool sympartial_aca(const Generator &A, int M, int N, int row_off, int co
             }
             v2[I2] = true;
             if (reqrank < 0) {
-                real frob_aux = 0.;
+                scalar frob_aux = scalar(0);
                 aux             = std::abs(plain_dot(n1, u2.data(), u2.data())) * std::abs(plain_dot(n2, u1.data(), u1.data()));
                 for (size_t j = 0; j < uu.size(); j++)
                     frob_aux += plain_dot(n2, u1.data(), vv[j].data()) * plain_dot(n1, u2.data(), uu[j].data());
-                frob += aux + 2 * frob_aux;
+                frob += aux + 2 * re_part(frob_aux);
             }
             uu.push_back(u2);
             vv.push_back(u1);
@@ -245,7 +268,7 @@ static bool sympartial_aca(const Generator &A, int M, int N, int row_off, int co
 }
 
 // matrix/utils/math.hpp:7-16
-static real norm_frob(const std::vector<real> &mat, int M, int N) {
+static real norm_frob(const std::vector<scalar> &mat, int M, int N) {
     real norm = 0;
     for (int j = 0; j < M; j++)
         for (int k = 0; k < N; k++)
@@ -255,10 +278,10 @@ static real norm_frob(const std::vector<real> &mat, int M, int N) {
 
 // hmatrix/lrmat/fullACA.hpp:38-88
 static bool full_aca(const Generator &A, int M, int N, int row_off, int col_off, real epsilon, int reqrank, LowRank &lr) {
-    std::vector<real> mat((size_t)M * N);
+    std::vector<scalar> mat((size_t)M * N);
     A.copy_submatrix(M, N, row_off, col_off, mat.data());
     int q = 0;
-    std::vector<std::vector<real>> uu, vv;
+    std::vector<std::vector<scalar>> uu, vv;
     real Norm = norm_frob(mat, M, N);
     lr.pivots.clear();
     while (((reqrank > 0) && (q < std::min(reqrank, std::min(M, N)))) || ((reqrank < 0) && (norm_frob(mat, M, N) / Norm > epsilon || q == 0))) {
@@ -268,16 +291,16 @@ static bool full_aca(const Generator &A, int M, int N, int row_off, int col_off,
             break;
         }
         // matrix/utils/math.hpp:18-23: std::max_element => first maximum in column-major order
-        int p        = std::max_element(mat.begin(), mat.end(), [](real a, real b) { return std::abs(a) < std::abs(b); }) - mat.begin();
+        int p        = std::max_element(mat.begin(), mat.end(), [](scalar a, scalar b) { return std::abs(a) < std::abs(b); }) - mat.begin();
         int pi       = p % M, pj = p / M;
-        real pivot = mat[pi + (size_t)M * pj];
+        scalar pivot = mat[pi + (size_t)M * pj];
         if (std::abs(pivot) < 1e-15) {
             q += -1;
             break;
         }
         lr.pivots.push_back(pi);
         lr.pivots.push_back(pj);
-        std::vector<real> col(M), row(N);
+        std::vector<scalar> col(M), row(N);
         for (int i = 0; i < M; i++)
             col[i] = mat[i + (size_t)M * pj];
         for (int j = 0; j < N; j++)
@@ -305,6 +328,7 @@ static bool full_aca(const Generator &A, int M, int N, int row_off, int col_off,
     return false;
 }
 
+#if !ORC_COMPLEX // LAPACK-backed compressors: real coefficients only in this round
 // One-sided Jacobi SVD of an M x N column-major matrix, standing in for LAPACK gesvd('A','A')
 // (matrix/utils/SVD_truncation.hpp:30-33).  LAPACK is a third-party dependency absent from
 // /root/reference (vendor/version unpinned); gesvd's published contract -- singular
@@ -518,10 +542,13 @@ static void svd_recompression(LowRank &lr, real epsilon) {
     lr.pivots.clear(); // the ACA pivots no longer describe these factors
 }
 
+#endif // !ORC_COMPLEX
+
 enum Compressor { PARTIAL_ACA = 0,
                   SYMPARTIAL_ACA = 1,
                   FULL_ACA = 2,
                   SVD = 3 };
+
 static bool compress(int kind, const Generator &A, int M, int N, int ro, int co, real eps, int reqrank, LowRank &lr) {
     switch (kind) {
     case PARTIAL_ACA:
@@ -531,7 +558,11 @@ static bool compress(int kind, const Generator &A, int M, int N, int ro, int co,
     case FULL_ACA:
         return full_aca(A, M, N, ro, co, eps, reqrank, lr);
     default:
+#if ORC_COMPLEX
+        return false;
+#else
         return svd_compress(A, M, N, ro, co, eps, reqrank, lr);
+#endif
     }
 }
 
@@ -544,7 +575,7 @@ struct Block {
     std::vector<std::unique_ptr<Block>> children;
     // leaf payload
     int kind = 0; // 0 hierarchical, 1 dense, 2 low rank
-    std::vector<real> dense;
+    std::vector<scalar> dense;
     LowRank lr;
     bool admissible_task = false;
     bool is_leaf() const { return children.empty(); }
@@ -804,85 +835,88 @@ static std::unique_ptr<HMat> build_hmatrix(const ClusterTree &tt, const ClusterT
 // as plain loops; BLAS is a third-party dependency, summation order unspecified),
 // hmatrix/lrmat/linalg/add_lrmat_vector_product.hpp:9-24
 // ---------------------------------------------------------------------------------------------
-static void gemv(char trans, int m, int n, real alpha, const real *A, const real *x, real beta, real *y) {
+static void gemv(char trans, int m, int n, scalar alpha, const scalar *A, const scalar *x, scalar beta, scalar *y) {
     if (!(m && n))
         return;
     if (trans == 'N') {
-        if (beta != 1.)
+        if (beta != scalar(1))
             for (int i = 0; i < m; i++)
-                y[i] = beta == 0. ? 0. : beta * y[i];
+                y[i] = beta == scalar(0) ? scalar(0) : beta * y[i];
         for (int j = 0; j < n; j++) {
-            real t        = alpha * x[j];
-            const real *a = A + (size_t)m * j;
+            scalar t        = alpha * x[j];
+            const scalar *a = A + (size_t)m * j;
             for (int i = 0; i < m; i++)
                 y[i] += t * a[i];
         }
-    } else {
+    } else { // 'T', or 'C' (conjugated coefficients)
         for (int j = 0; j < n; j++) {
-            const real *a = A + (size_t)m * j;
-            real t        = 0;
+            const scalar *a = A + (size_t)m * j;
+            scalar t        = scalar(0);
             for (int i = 0; i < m; i++)
-                t += a[i] * x[i];
-            y[j] = alpha * t + (beta == 0. ? 0. : beta * y[j]);
+                t += (trans == 'C' ? cj(a[i]) : a[i]) * x[i];
+            y[j] = alpha * t + (beta == scalar(0) ? scalar(0) : beta * y[j]);
         }
     }
 }
-// symv: only the UPLO triangle of the n x n column-major matrix is referenced
-static void symv(char uplo, int n, real alpha, const real *A, const real *x, real beta, real *y) {
+// symv / hemv: only the UPLO triangle of the n x n column-major matrix is referenced; hemv conjugates the mirrored
+// entries and uses the real part of the diagonal (matrix/linalg/add_matrix_vector_product.hpp:26-52)
+static void symv(char uplo, int n, scalar alpha, const scalar *A, const scalar *x, scalar beta, scalar *y, bool herm = false) {
     if (!n)
         return;
-    if (beta != 1.)
+    if (beta != scalar(1))
         for (int i = 0; i < n; i++)
-            y[i] = beta == 0. ? 0. : beta * y[i];
+            y[i] = beta == scalar(0) ? scalar(0) : beta * y[i];
+    auto diag = [&](int j) { return herm ? scalar(re_part(A[j + (size_t)n * j])) : A[j + (size_t)n * j]; };
+    auto mir  = [&](scalar v) { return herm ? cj(v) : v; };
     for (int j = 0; j < n; j++) {
-        real t1 = alpha * x[j], t2 = 0;
+        scalar t1 = alpha * x[j], t2 = scalar(0);
         if (uplo == 'L') {
-            y[j] += t1 * A[j + (size_t)n * j];
+            y[j] += t1 * diag(j);
             for (int i = j + 1; i < n; i++) {
                 y[i] += t1 * A[i + (size_t)n * j];
-                t2 += A[i + (size_t)n * j] * x[i];
+                t2 += mir(A[i + (size_t)n * j]) * x[i];
             }
         } else {
             for (int i = 0; i < j; i++) {
                 y[i] += t1 * A[i + (size_t)n * j];
-                t2 += A[i + (size_t)n * j] * x[i];
+                t2 += mir(A[i + (size_t)n * j]) * x[i];
             }
-            y[j] += t1 * A[j + (size_t)n * j];
+            y[j] += t1 * diag(j);
         }
         y[j] += alpha * t2;
     }
 }
-static void lrmat_vec(char trans, real alpha, const LowRank &lr, const real *in, real beta, real *out) {
+static void lrmat_vec(char trans, scalar alpha, const LowRank &lr, const scalar *in, scalar beta, scalar *out) {
     int r = lr.rank;
     if (r == 0)
         return; // beta NOT applied (add_lrmat_vector_product.hpp:11)
-    std::vector<real> a(r);
+    std::vector<scalar> a(r);
     if (trans == 'N') {
-        gemv('N', r, lr.N, 1., lr.V.data(), in, 0., a.data());
+        gemv('N', r, lr.N, scalar(1), lr.V.data(), in, scalar(0), a.data());
         gemv('N', lr.M, r, alpha, lr.U.data(), a.data(), beta, out);
     } else {
-        gemv('T', lr.M, r, 1., lr.U.data(), in, 0., a.data());
-        gemv('T', r, lr.N, alpha, lr.V.data(), a.data(), beta, out);
+        gemv(trans, lr.M, r, scalar(1), lr.U.data(), in, scalar(0), a.data());
+        gemv(trans, r, lr.N, alpha, lr.V.data(), a.data(), beta, out);
     }
 }
 // hmatrix/linalg/add_hmatrix_vector_product.hpp:17-33
-static void leaf_vec(char trans, real alpha, const Block &b, const real *in, real beta, real *out) {
+static void leaf_vec(char trans, scalar alpha, const Block &b, const scalar *in, scalar beta, scalar *out) {
     if (b.kind == 1) {
         int M = b.t->size, N = b.s->size;
         if (b.symmetry == 'N')
             gemv(trans, M, N, alpha, b.dense.data(), in, beta, out);
         else
-            symv(b.uplo, M, alpha, b.dense.data(), in, beta, out);
+            symv(b.uplo, M, alpha, b.dense.data(), in, beta, out, b.symmetry == 'H');
     } else if (b.kind == 2) {
         lrmat_vec(trans, alpha, b.lr, in, beta, out);
     }
 }
 
 // add_hmatrix_vector_product.hpp:57-104 (sequential) -- cluster numbering, local offsets
-static void matvec_seq(const HMat &H, char trans, real alpha, const real *in, real beta, real *out) {
+static void matvec_seq(const HMat &H, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out) {
     int out_size = H.root_t->size;
     int lin = H.root_s->offset, lout = H.root_t->offset;
-    char trans_sym = 'T';
+    char trans_sym = H.sym_for_leaves == 'S' ? 'T' : 'C'; // add_hmatrix_vector_product.hpp:70
     bool tr        = trans != 'N';
     if (tr) {
         out_size  = H.root_s->size;
@@ -890,13 +924,13 @@ static void matvec_seq(const HMat &H, char trans, real alpha, const real *in, re
         lout      = H.root_s->offset;
         trans_sym = 'N';
     }
-    if (beta != 1.)
+    if (beta != scalar(1))
         for (int i = 0; i < out_size; i++)
             out[i] = beta * out[i]; // scal
     for (auto &l : H.dfs_order) {
         int io = tr ? l.b->t->offset : l.b->s->offset;
         int oo = tr ? l.b->s->offset : l.b->t->offset;
-        leaf_vec(trans, alpha, *l.b, in + io - lin, 1., out + (oo - lout));
+        leaf_vec(trans, alpha, *l.b, in + io - lin, scalar(1), out + (oo - lout));
     }
     if (H.sym_for_leaves != 'N') {
         for (auto &l : H.dfs_order) {
@@ -904,15 +938,15 @@ static void matvec_seq(const HMat &H, char trans, real alpha, const real *in, re
                 continue;
             int io = tr ? l.b->t->offset : l.b->s->offset;
             int oo = tr ? l.b->s->offset : l.b->t->offset;
-            leaf_vec(trans_sym, alpha, *l.b, in + oo - lin, 1., out + (io - lout));
+            leaf_vec(trans_sym, alpha, *l.b, in + oo - lin, scalar(1), out + (io - lout));
         }
     }
 }
 // add_hmatrix_vector_product.hpp:107-170 (OpenMP): per-thread temp with alpha=1 per leaf, critical axpy
-static void matvec_omp(const HMat &H, char trans, real alpha, const real *in, real beta, real *out) {
+static void matvec_omp(const HMat &H, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out) {
     int out_size = H.root_t->size;
     int lin = H.root_s->offset, lout = H.root_t->offset;
-    char trans_sym = 'T';
+    char trans_sym = H.sym_for_leaves == 'S' ? 'T' : 'C'; // add_hmatrix_vector_product.hpp:70
     bool tr        = trans != 'N';
     if (tr) {
         out_size  = H.root_s->size;
@@ -920,7 +954,7 @@ static void matvec_omp(const HMat &H, char trans, real alpha, const real *in, re
         lout      = H.root_s->offset;
         trans_sym = 'N';
     }
-    if (beta != 1.)
+    if (beta != scalar(1))
         for (int i = 0; i < out_size; i++)
             out[i] = beta * out[i];
     std::vector<const HMat::Leaf *> mirrors;
@@ -929,13 +963,13 @@ static void matvec_omp(const HMat &H, char trans, real alpha, const real *in, re
             mirrors.push_back(&l);
 #pragma omp parallel
     {
-        std::vector<real> temp(out_size, 0.);
+        std::vector<scalar> temp(out_size, scalar(0));
 #pragma omp for schedule(guided) nowait
         for (int b = 0; b < (int)H.dfs_order.size(); b++) {
             auto &l = H.dfs_order[b];
             int io  = tr ? l.b->t->offset : l.b->s->offset;
             int oo  = tr ? l.b->s->offset : l.b->t->offset;
-            leaf_vec(trans, 1., *l.b, in + io - lin, 1., temp.data() + (oo - lout));
+            leaf_vec(trans, scalar(1), *l.b, in + io - lin, scalar(1), temp.data() + (oo - lout));
         }
         if (H.sym_for_leaves != 'N') {
 #pragma omp for schedule(guided) nowait
@@ -943,7 +977,7 @@ static void matvec_omp(const HMat &H, char trans, real alpha, const real *in, re
                 auto &l = *mirrors[b];
                 int io  = tr ? l.b->t->offset : l.b->s->offset;
                 int oo  = tr ? l.b->s->offset : l.b->t->offset;
-                leaf_vec(trans_sym, 1., *l.b, in + oo - lin, 1., temp.data() + (io - lout));
+                leaf_vec(trans_sym, scalar(1), *l.b, in + oo - lin, scalar(1), temp.data() + (io - lout));
             }
         }
 #pragma omp critical
@@ -955,21 +989,21 @@ static void matvec_omp(const HMat &H, char trans, real alpha, const real *in, re
 // Row-major multi-RHS: hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:58-109,
 // matrix/linalg/add_matrix_matrix_product_row_major.hpp:23-46,87-106,
 // hmatrix/lrmat/linalg/add_lrmat_matrix_product_row_major.hpp:11-27.  X[n][mu], Y[m][mu] (mu fastest).
-static void leaf_mat_rm(char trans, const Block &b, const real *in, real *out, int mu) {
+static void leaf_mat_rm(char trans, const Block &b, const scalar *in, scalar *out, int mu) {
     int M = b.t->size, N = b.s->size;
-    auto dense_rm = [&](char tr, int m, int n, const real *A, const real *X, real *Y) {
+    auto dense_rm = [&](char tr, int m, int n, const scalar *A, const scalar *X, scalar *Y) {
         // Y[(out idx)][mu] += op(A) X
         if (tr == 'N') {
             for (int j = 0; j < n; j++)
                 for (int i = 0; i < m; i++) {
-                    real a = A[i + (size_t)m * j];
+                    scalar a = A[i + (size_t)m * j];
                     for (int c = 0; c < mu; c++)
                         Y[(size_t)i * mu + c] += a * X[(size_t)j * mu + c];
                 }
         } else {
             for (int j = 0; j < n; j++)
                 for (int i = 0; i < m; i++) {
-                    real a = A[i + (size_t)m * j];
+                    scalar a = tr == 'C' ? cj(A[i + (size_t)m * j]) : A[i + (size_t)m * j];
                     for (int c = 0; c < mu; c++)
                         Y[(size_t)j * mu + c] += a * X[(size_t)i * mu + c];
                 }
@@ -982,27 +1016,29 @@ static void leaf_mat_rm(char trans, const Block &b, const real *in, real *out, i
             for (int j = 0; j < N; j++)
                 for (int i = 0; i < M; i++) {
                     bool stored = b.uplo == 'L' ? i >= j : i <= j;
-                    real a    = stored ? b.dense[i + (size_t)M * j] : b.dense[j + (size_t)M * i];
+                    scalar a    = stored ? b.dense[i + (size_t)M * j] : (b.symmetry == 'H' ? cj(b.dense[j + (size_t)M * i]) : b.dense[j + (size_t)M * i]);
+                    if (b.symmetry == 'H' && i == j)
+                        a = scalar(re_part(a));
                     for (int c = 0; c < mu; c++)
                         out[(size_t)i * mu + c] += a * in[(size_t)j * mu + c];
                 }
         }
     } else if (b.kind == 2 && b.lr.rank > 0) {
         int r = b.lr.rank;
-        std::vector<real> a((size_t)r * mu, 0.);
+        std::vector<scalar> a((size_t)r * mu, scalar(0));
         if (trans == 'N') {
             dense_rm('N', r, N, b.lr.V.data(), in, a.data());
             dense_rm('N', M, r, b.lr.U.data(), a.data(), out);
         } else {
-            dense_rm('T', M, r, b.lr.U.data(), in, a.data());
-            dense_rm('T', r, N, b.lr.V.data(), a.data(), out);
+            dense_rm(trans, M, r, b.lr.U.data(), in, a.data());
+            dense_rm(trans, r, N, b.lr.V.data(), a.data(), out);
         }
     }
 }
-static void matmat_rm_seq(const HMat &H, char trans, real alpha, const real *in, real beta, real *out, int mu) {
+static void matmat_rm_seq(const HMat &H, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu) {
     int out_size = H.root_t->size;
     int lin = H.root_s->offset, lout = H.root_t->offset;
-    char trans_sym = 'T';
+    char trans_sym = H.sym_for_leaves == 'S' ? 'T' : 'C'; // add_hmatrix_vector_product.hpp:70
     bool tr        = trans != 'N';
     if (tr) {
         out_size  = H.root_s->size;
@@ -1011,10 +1047,10 @@ static void matmat_rm_seq(const HMat &H, char trans, real alpha, const real *in,
         trans_sym = 'N';
     }
     size_t tot = (size_t)out_size * mu;
-    if (beta != 1.)
+    if (beta != scalar(1))
         for (size_t i = 0; i < tot; i++)
             out[i] = beta * out[i];
-    std::vector<real> temp(tot, 0.);
+    std::vector<scalar> temp(tot, scalar(0));
     for (auto &l : H.dfs_order) {
         int io = tr ? l.b->t->offset : l.b->s->offset;
         int oo = tr ? l.b->s->offset : l.b->t->offset;

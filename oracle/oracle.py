@@ -63,6 +63,19 @@ def lib():
                                          C.c_int, C.c_int, C.c_int, dp]
         L.orc_hmatrix_from_blocks.restype = C.c_void_p
         L.orc_hmatrix_from_blocks.argtypes = [C.c_int, ip, C.POINTER(C.c_int64), dp, ip, C.c_char, C.c_char, C.c_int]
+        L.orc_zhmatrix_build.restype = C.c_void_p
+        L.orc_zhmatrix_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_zhmatrix_destroy.argtypes = [C.c_void_p]
+        L.orc_zhmatrix_num_leaves.argtypes = [C.c_void_p]
+        L.orc_zhmatrix_leaves.argtypes = [C.c_void_p, C.c_int, ip]
+        L.orc_zhmatrix_rootinfo.argtypes = [C.c_void_p, ip]
+        L.orc_zhmatrix_block.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
+        L.orc_zhmatrix_matvec.argtypes = [C.c_void_p, C.c_int, C.c_char, dp, dp, dp, dp]
+        L.orc_zhmatrix_matmat_row_major.argtypes = [C.c_void_p, C.c_char, dp, dp, dp, dp, C.c_int]
+        L.orc_zgenerate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
         _LIB = L
     return _LIB
 
@@ -181,6 +194,75 @@ class HMatrix:
         if getattr(self, "h", None):
             lib().orc_hmatrix_destroy(self.h)
             self.h = None
+
+
+def _zp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))  # complex128 = interleaved (re, im) doubles
+
+
+class ZHMatrix:
+    """Oracle H-matrix with complex coefficients (htool's HMatrix<std::complex<double|float>, double>), generator
+    (cre + i cim sgn) / (delta + scale |x-y|); sym in 'N', 'S' (complex symmetric), 'H' (Hermitian: sgn = sign(x_t0 - x_s0)).
+    Values cross this boundary as complex128 (c32=True computes in complex<float> inside)."""
+
+    def __init__(self, tct, sct, delta=1e-5, scale=1.0, cre=1.0, cim=1.0, eps=1e-4, eta=10.0, sym="N", uplo="N", reqrank=-1,
+                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, c32=False, root_partition=-1):
+        self._keep = (tct, sct)
+        self.h = lib().orc_zhmatrix_build(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta, scale,
+                                          cre, cim, eps, eta, sym.encode(), uplo.encode(), reqrank, COMPRESSORS[compressor],
+                                          mindepth, mindepth, rank, rank, int(consistent), int(parallel), int(c32), root_partition)
+        n = lib().orc_zhmatrix_num_leaves(self.h)
+        self.leaves = np.empty((n, 6), dtype=np.int32)
+        self.leaves_dfs = np.empty((n, 6), dtype=np.int32)
+        lib().orc_zhmatrix_leaves(self.h, 0, _ip(self.leaves))
+        lib().orc_zhmatrix_leaves(self.h, 1, _ip(self.leaves_dfs))
+        self.rootinfo = np.empty(7, dtype=np.int32)
+        lib().orc_zhmatrix_rootinfo(self.h, _ip(self.rootinfo))
+
+    def block(self, b):
+        t_off, m, s_off, n, rank, _ = self.leaves[b]
+        if rank >= 0:
+            U = np.empty((rank, m), dtype=np.complex128)
+            V = np.empty((n, rank), dtype=np.complex128)
+            lib().orc_zhmatrix_block(self.h, b, _zp(U), _zp(V), None)
+            return U.T, V.T
+        D = np.empty((n, m), dtype=np.complex128)
+        lib().orc_zhmatrix_block(self.h, b, None, None, _zp(D))
+        return D.T
+
+    def matvec(self, x, trans="N", alpha=1.0, beta=0.0, y=None, policy="seq"):
+        nout = self.rootinfo[1] if trans == "N" else self.rootinfo[3]
+        out = np.zeros(nout, dtype=np.complex128) if y is None else np.array(y, dtype=np.complex128)
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        a, b = np.array([alpha], dtype=np.complex128), np.array([beta], dtype=np.complex128)
+        lib().orc_zhmatrix_matvec(self.h, 0 if policy == "seq" else 1, trans.encode(), _zp(a), _zp(x), _zp(b), _zp(out))
+        return out
+
+    def matmat_row_major(self, X, trans="N", alpha=1.0, beta=0.0, Y=None):
+        X = np.ascontiguousarray(X, dtype=np.complex128)
+        mu = X.shape[1]
+        nout = self.rootinfo[1] if trans == "N" else self.rootinfo[3]
+        out = np.zeros((nout, mu), dtype=np.complex128) if Y is None else np.array(Y, dtype=np.complex128)
+        a, b = np.array([alpha], dtype=np.complex128), np.array([beta], dtype=np.complex128)
+        lib().orc_zhmatrix_matmat_row_major(self.h, trans.encode(), _zp(a), _zp(X), _zp(b), _zp(out), mu)
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_zhmatrix_destroy(self.h)
+            self.h = None
+
+
+def zgenerate_block(tct, sct, M, N, row_off, col_off, delta, scale, cre, cim, hermitian):
+    out = np.empty((N, M), dtype=np.complex128)
+    lib().orc_zgenerate_block(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta, scale, cre, cim,
+                              int(hermitian), M, N, row_off, col_off, _zp(out))
+    return out.T
+
+
+def hashed_zvector(n, salt):
+    """Complex test input of ref_driver: imaginary part = the same hash with salt + 16."""
+    return hashed_vector(n, salt) + 1j * hashed_vector(n, salt + 16)
 
 
 def compress_block(tct, sct, compressor, M, N, row_off, col_off, eps, reqrank=-1, delta=0.0, scale=4 * np.pi, f32=False):

@@ -29,6 +29,8 @@
 #include <htool/testing/geometry.hpp>
 
 #include <chrono>
+#include <complex>
+#include <type_traits>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -87,7 +89,39 @@ struct Dump {
         std::vector<double> tmp(v.begin(), v.end());
         rec(name, 'd', dims, tmp.data(), 8);
     }
+    // complex payloads: float64 pairs, trailing dimension 2 (numpy: .view(complex128))
+    template <typename U>
+    void f64p(const std::string &name, const std::complex<U> *p, std::vector<uint64_t> dims) {
+        size_t n = 1;
+        for (auto d : dims)
+            n *= d;
+        std::vector<double> tmp(2 * n);
+        for (size_t i = 0; i < n; i++) {
+            tmp[2 * i]     = p[i].real();
+            tmp[2 * i + 1] = p[i].imag();
+        }
+        dims.push_back(2);
+        rec(name, 'd', dims, tmp.data(), 8);
+    }
+    template <typename U>
+    void vec(const std::string &name, const std::vector<std::complex<U>> &v, std::vector<uint64_t> dims = {}) {
+        if (dims.empty())
+            dims = {v.size()};
+        f64p(name, v.data(), dims);
+    }
 };
+
+template <typename T>
+struct is_cplx : std::false_type {};
+template <typename U>
+struct is_cplx<std::complex<U>> : std::true_type {};
+template <typename T>
+static T make_value(double re, double im) {
+    if constexpr (is_cplx<T>::value)
+        return T((typename T::value_type)re, (typename T::value_type)im);
+    else
+        return (T)re;
+}
 
 // Kernel family K(x,y) = 1 / (delta + scale * |x-y|), evaluated with the same operation order as the
 // reference's own generators (examples/use_hmatrix.cpp:33, testing/generator_test.hpp:159,185):
@@ -97,21 +131,32 @@ class InvDistGenerator : public VirtualGenerator<T> {
     int m_dim;
     const std::vector<double> &m_xt, &m_xs;
     double m_delta, m_scale;
+    // complex coefficients: (cre + i * cim * sgn) / (delta + scale |x-y|), sgn = 1 (complex symmetric, the form of
+    // testing/generator_test.hpp:163-170,189-196) or sign(x_target[0] - x_source[0]) (Hermitian, :198-205)
+    double m_cre = 1, m_cim = 0;
+    bool m_hermitian = false;
 
   public:
-    InvDistGenerator(int dim, const std::vector<double> &xt, const std::vector<double> &xs, double delta, double scale) : m_dim(dim), m_xt(xt), m_xs(xs), m_delta(delta), m_scale(scale) {}
-    double get_coef(int i, int j) const {
+    InvDistGenerator(int dim, const std::vector<double> &xt, const std::vector<double> &xs, double delta, double scale, double cre = 1, double cim = 0, bool hermitian = false) : m_dim(dim), m_xt(xt), m_xs(xs), m_delta(delta), m_scale(scale), m_cre(cre), m_cim(cim), m_hermitian(hermitian) {}
+    double denominator(int i, int j) const {
         double s = 0;
         for (int p = 0; p < m_dim; p++) {
             double d = m_xt[m_dim * i + p] - m_xs[m_dim * j + p];
             s        = s + d * d;
         }
-        return 1. / (m_delta + m_scale * std::sqrt(s));
+        return m_delta + m_scale * std::sqrt(s);
     }
+    double get_coef(int i, int j) const { return 1. / denominator(i, j); }
     void copy_submatrix(int M, int N, const int *rows, const int *cols, T *ptr) const override {
         for (int j = 0; j < M; j++)
-            for (int k = 0; k < N; k++)
-                ptr[j + (size_t)M * k] = get_coef(rows[j], cols[k]); // double expression assigned to T, as a user generator would
+            for (int k = 0; k < N; k++) {
+                if constexpr (is_cplx<T>::value) {
+                    const double u   = m_xt[m_dim * rows[j]] - m_xs[m_dim * cols[k]];
+                    const double sgn = m_hermitian ? (u > 0 ? 1. : (u < 0 ? -1. : 0.)) : 1.;
+                    ptr[j + (size_t)M * k] = T(std::complex<double>(m_cre, m_cim * sgn) / denominator(rows[j], cols[k])); // complex<double> / double, then to T
+                } else
+                    ptr[j + (size_t)M * k] = get_coef(rows[j], cols[k]); // double expression assigned to T, as a user generator would
+            }
     }
 };
 
@@ -261,7 +306,9 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     if (!square)
         dump_cluster_tree(D, "s_", sct);
 
-    InvDistGenerator<T> A(dim, xt, xs, delta, scale);
+    const bool cplx       = is_cplx<T>::value;
+    const double cre = getd(kv, "cre", 1.), cim = getd(kv, "cim", cplx ? 1. : 0.);
+    InvDistGenerator<T> A(dim, xt, xs, delta, scale, cre, cim, sym == "H");
     HMatrixTreeBuilder<T, double> tb(eps, eta, sym[0], uplo[0], reqrank);
     if (!consistent)
         tb.set_block_tree_consistency(false);
@@ -283,8 +330,9 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     auto t2           = std::chrono::steady_clock::now();
     HM H = local >= 0 ? tb.sequential_build(A, tct.get_cluster_on_partition(local), sct.get_cluster_on_partition(local))
                       : (par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank));
-    if (geti(kv, "recompress", 0))
-        recompression(H); // hmatrix/utils/recompression.hpp:8-13 (SVD_recompression of every low-rank leaf)
+    if constexpr (!is_cplx<T>::value)
+        if (geti(kv, "recompress", 0))
+            recompression(H); // hmatrix/utils/recompression.hpp:8-13 (SVD_recompression of every low-rank leaf)
     auto t3           = std::chrono::steady_clock::now();
 
     // Leaves in natural preorder (children in creation order)
@@ -357,33 +405,43 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     int ncols = H.get_source_cluster().get_size();
     // Inputs are a closed-form hash of the index (reproducible from numpy: oracle/oracle.py hashed_vector),
     // so fixtures only need to store outputs.
-    auto hashed = [](size_t n, unsigned salt) {
+    auto hval = [](size_t i, unsigned salt) { return double((uint32_t)((uint32_t)(i + 1) * 2654435761u + salt * 40503u)) / 4294967296.0; };
+    auto hashed = [&](size_t n, unsigned salt) { // complex: imaginary part = the same hash with salt + 16
         std::vector<T> v(n);
         for (size_t i = 0; i < n; i++)
-            v[i] = (T)(double((uint32_t)((uint32_t)(i + 1) * 2654435761u + salt * 40503u)) / 4294967296.0);
+            v[i] = make_value<T>(hval(i, salt), hval(i, salt + 16));
         return v;
     };
     std::vector<T> x = hashed(ncols, 1), xT = hashed(nrows, 2), y0 = hashed(nrows, 3), y0T = hashed(ncols, 4);
-    D.f64("alphabeta", {alpha, beta});
+    const double alpha_im = getd(kv, "alpha_im", cplx ? 0.5 : 0.), beta_im = getd(kv, "beta_im", cplx ? -0.25 : 0.);
+    const T al = make_value<T>(alpha, alpha_im), be = make_value<T>(beta, beta_im);
+    D.f64("alphabeta", {alpha, beta, alpha_im, beta_im});
     {
         std::vector<T> y = y0;
-        sequential_internal_add_hmatrix_vector_product('N', (T)alpha, H, x.data(), (T)beta, y.data());
+        sequential_internal_add_hmatrix_vector_product('N', al, H, x.data(), be, y.data());
         D.vec("yN", y);
-        std::vector<T> yt = y0T;
-        sequential_internal_add_hmatrix_vector_product('T', (T)alpha, H, xT.data(), (T)beta, yt.data());
-        D.vec("yT", yt);
+        if (sym != "H") { // trans='T' with 'H' leaves is refused by the reference (add_hmatrix_vector_product.hpp:59-62)
+            std::vector<T> yt = y0T;
+            sequential_internal_add_hmatrix_vector_product('T', al, H, xT.data(), be, yt.data());
+            D.vec("yT", yt);
+        }
+        if (cplx && sym != "S") {
+            std::vector<T> yc = y0T;
+            sequential_internal_add_hmatrix_vector_product('C', al, H, xT.data(), be, yc.data());
+            D.vec("yC", yc);
+        }
     }
     if (rank < 0 && square && local < 0) {
         // user-numbering front end (a16)
         std::vector<T> y = y0;
-        add_hmatrix_vector_product('N', (T)alpha, H, x.data(), (T)beta, y.data());
+        add_hmatrix_vector_product('N', al, H, x.data(), be, y.data());
         D.vec("yN_user", y);
     }
-    // multi-RHS row-major (a18), mu = 3
+    // multi-RHS row-major (a18), mu = 2
     {
         int mu                = 2;
         std::vector<T> X = hashed(ncols * (size_t)mu, 5), Y = hashed(nrows * (size_t)mu, 6);
-        sequential_internal_add_hmatrix_matrix_product_row_major('N', 'N', (T)alpha, H, X.data(), (T)beta, Y.data(), mu);
+        sequential_internal_add_hmatrix_matrix_product_row_major('N', 'N', al, H, X.data(), be, Y.data(), mu);
         D.vec("YNrm", Y, {(uint64_t)nrows, (uint64_t)mu});
     }
 
@@ -471,7 +529,16 @@ int main(int argc, char **argv) {
     auto kv          = parse(argc, argv);
     std::string mode = gets(kv, "mode", "hmat");
     if (mode == "hmat")
-        return gets(kv, "prec", "f64") == "f32" ? run_hmat<float>(kv) : run_hmat<double>(kv);
+    {
+        const std::string prec = gets(kv, "prec", "f64");
+        if (prec == "f32")
+            return run_hmat<float>(kv);
+        if (prec == "z64")
+            return run_hmat<std::complex<double>>(kv);
+        if (prec == "c32")
+            return run_hmat<std::complex<float>>(kv);
+        return run_hmat<double>(kv);
+    }
     if (mode == "lrmat")
         return run_lrmat(kv);
     fprintf(stderr, "unknown mode\n");

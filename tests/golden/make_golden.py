@@ -58,6 +58,18 @@ CASES = {
     "ellipse_n3000_f32_partial": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, eta=10, compressor="partialACA", prec="f32")),
     "ellipse_n3000_f32_symL_eps1e-6": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-6, eta=10, sym="S", uplo="L", compressor="sympartialACA", prec="f32")),
     "ball_n2000_f32_p2_rank1": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitions=2, rank=1, compressor="partialACA", prec="f32", dump_blocks=1)),
+    # complex coefficients: HMatrix<std::complex<double>> / <std::complex<float>>, generator
+    # (cre + i cim sgn)/(delta + scale |x-y|) -- complex symmetric form of testing/generator_test.hpp:163-196, Hermitian form :198-205
+    "ball_n2000_z64_partial": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-4, compressor="partialACA", prec="z64", dump_blocks=2)),
+    "ellipse_n3000_z64_symL": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, sym="S", uplo="L", compressor="sympartialACA", prec="z64", cre=0.3, cim=-1.2, dump_blocks=2)),
+    "ball_n2000_z64_hermU": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-4, sym="H", uplo="U", compressor="sympartialACA", prec="z64", dump_blocks=2)),
+    "ball_n2000_c32_hermL": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, sym="H", uplo="L", compressor="default", prec="c32", dump_blocks=1)),
+    "ellipse_n3000_c32_partial": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, compressor="partialACA", prec="c32", dump_blocks=1)),
+    "ball_n2000_z64_p2_rank1": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitions=2, rank=1, compressor="partialACA", prec="z64", dump_blocks=1)),
+    "ball_n2000_z64_p2_hermL_rank0": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitions=2, rank=0, sym="H", uplo="L", compressor="sympartialACA", prec="z64", dump_blocks=1)),
+    "rect_ball1500_disk1000_z64": ("hmat", dict(n=1500, nsrc=1000, geom="ball", sgeom="disk", sz=2.5, leaf=60, eps=1e-4, compressor="partialACA", prec="z64", dump_blocks=1)),
+    "ball_n1200_z64_fullACA": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="fullACA", prec="z64", dump_blocks=1)),
+    "ball_n1200_z64_reqrank5": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, reqrank=5, compressor="partialACA", prec="z64", dump_blocks=1)),
     # block-diagonal (local-to-local) operator rooted at the partition clusters: DefaultLocalApproximationBuilder
     "ellipse_n4000_p4_local2": ("hmat", dict(n=4000, geom="ellipse", leaf=100, partitions=4, local=2, eps=1e-4, compressor="partialACA", dump_blocks=1)),
     "ball_n2000_p2_local1_symL": ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=2, local=1, eps=1e-3, sym="S", uplo="L", compressor="sympartialACA", dump_blocks=1)),
@@ -116,6 +128,11 @@ def main():
         if mode == "hmat":
             for k in ("x", "xT", "y0", "y0T"):  # closed-form inputs (oracle.hashed_vector), not stored
                 d.pop(k, None)
+        if params.get("prec") in ("z64", "c32"):  # float64 pairs -> complex128
+            for k in list(d):
+                if k[:2] in ("U_", "V_", "D_") or k[0] in "yY" or k.startswith("all"):
+                    a = np.ascontiguousarray(d[k], dtype=np.float64)
+                    d[k] = a.view(np.complex128).reshape(a.shape[:-1])
         if mode == "lrmat":
             d.pop("xt", None)
             d.pop("xs", None)

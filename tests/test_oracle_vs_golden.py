@@ -159,3 +159,62 @@ def test_fp32_oracle_against_reference(name):
     alpha, beta = g["alphabeta"]
     assert rel_err(H.matvec(f(nc, 1), "N", alpha, beta, f(nr, 3)), g["yN"]) < 1e-5
     assert rel_err(H.matvec(f(nr, 2), "T", alpha, beta, f(nc, 4)), g["yT"]) < 1e-5
+
+
+from helpers import Z_CASES  # noqa: E402
+
+
+def build_zoracle(name):
+    p = params(name)
+    xt = O.geometry(p["geom"], p["n"])
+    T = O.ClusterTree(xt, p["leaf"], p["children"], p["partitions"], p["partitioning"])
+    S = T
+    if p["nsrc"]:
+        S = O.ClusterTree(O.geometry(p["sgeom"], p["nsrc"], p["sz"]), p["leaf"], p["children"], p["partitions"], p["partitioning"])
+    H = O.ZHMatrix(T, S, delta=p["delta"], scale=p["scale"], cre=p["cre"], cim=p["cim"], eps=p["eps"], eta=p["eta"], sym=p["sym"],
+                   uplo=p["uplo"], reqrank=p["reqrank"], compressor=p["compressor"], rank=p["rank"], c32=p["prec"] == "c32")
+    return p, T, S, H
+
+
+@pytest.mark.parametrize("name", Z_CASES)
+def test_complex_oracle_against_reference(name):
+    """HMatrix<std::complex<double|float>>: complex symmetric ('S') and Hermitian ('H') storage, trans = 'N', 'T', 'C'.
+    Structure and ranks equal; dense entries bit-exact; factors / products to rounding (zaxpy / zdot order in the
+    reference's BLAS is vendor-defined)."""
+    g = load(name)
+    p, T, S, H = build_zoracle(name)
+    c32 = p["prec"] == "c32"
+    assert np.array_equal(H.leaves[:, :4], g["leaves"][:, :4]) and np.array_equal(H.leaves[:, 5], g["leaves"][:, 5])
+    assert np.array_equal(H.leaves[:, 4] < 0, g["leaves"][:, 4] < 0)
+    if c32:
+        assert np.abs(H.leaves[:, 4] - g["leaves"][:, 4]).max() <= 2 and (H.leaves[:, 4] != g["leaves"][:, 4]).mean() < 0.05
+    else:
+        assert np.array_equal(H.leaves[:, 4], g["leaves"][:, 4])
+    assert np.array_equal(H.rootinfo, g["rootinfo"])
+    ptol, vtol = (2e-5, 1e-5) if c32 else (1e-9, 1e-12)
+    for k in g:
+        if k.startswith("D_"):
+            assert np.array_equal(H.block(int(k[2:])), g[k].T)
+        if k.startswith("U_"):
+            b = int(k[2:])
+            U, V = H.block(b)
+            if U.shape[1] == g[k].shape[0]:
+                assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < ptol
+    nr, nc = H.rootinfo[1], H.rootinfo[3]
+    rnd = (lambda v: v.astype(np.complex64).astype(np.complex128)) if c32 else (lambda v: v)
+    x, xT, y0, y0T = (rnd(O.hashed_zvector(n, s)) for n, s in ((nc, 1), (nr, 2), (nr, 3), (nc, 4)))
+    alpha, beta = complex(g["alphabeta"][0], g["alphabeta"][2]), complex(g["alphabeta"][1], g["alphabeta"][3])
+    assert rel_err(H.matvec(x, "N", alpha, beta, y0), g["yN"]) < vtol
+    assert rel_err(H.matvec(x, "N", alpha, beta, y0, policy="omp"), g["yN"]) < vtol
+    if "yT" in g:
+        assert rel_err(H.matvec(xT, "T", alpha, beta, y0T), g["yT"]) < vtol
+    if "yC" in g:
+        assert rel_err(H.matvec(xT, "C", alpha, beta, y0T), g["yC"]) < vtol
+    X, Y0 = rnd(O.hashed_zvector(nc * 2, 5)).reshape(nc, 2), rnd(O.hashed_zvector(nr * 2, 6)).reshape(nr, 2)
+    assert rel_err(H.matmat_row_major(X, "N", alpha, beta, Y0), g["YNrm"]) < vtol
+    if "yN_user" in g:
+        perm = T.perm
+        yc = H.matvec(x[perm], "N", alpha, beta, y0[perm])
+        yu = np.empty_like(yc)
+        yu[perm] = yc
+        assert rel_err(yu, g["yN_user"]) < vtol
