@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhmx.so")
 
 HMX_MEM_HOST, HMX_MEM_DEVICE = 0, 1
+HMX_PREC_F64, HMX_PREC_F32, HMX_PREC_Z64, HMX_PREC_C32 = 0, 1, 2, 3
 COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
 DIRECTIONS = {"largest_extent": 0, "bounding_box": 1}
 SPLITTINGS = {"regular": 0, "geometric": 1}
@@ -67,7 +68,24 @@ SYMBOLS = [
     ("hmx_block_tree_root", C.c_int, [_vp, _ip, C.c_char_p, C.c_char_p]),
     ("hmx_hmatrix_create", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("hmx_hmatrix_create_s", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("hmx_hmatrix_create_z", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    ("hmx_hmatrix_create_c", C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     ("hmx_hmatrix_is_f32", C.c_int, [_vp]),
+    ("hmx_hmatrix_precision", C.c_int, [_vp]),
+    ("hmx_hmatrix_set_callback_z", C.c_int, [_vp, GENERATOR_FN, _vp]),
+    ("hmx_hmatrix_set_callback_c", C.c_int, [_vp, GENERATOR_FN_S, _vp]),
+    ("hmx_hmatrix_set_block_lowrank_z", C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp]),
+    ("hmx_hmatrix_set_block_dense_z", C.c_int, [_vp, C.c_int64, _vp]),
+    ("hmx_hmatrix_get_block_z", C.c_int, [_vp, C.c_int64, _vp, _vp]),
+    ("hmx_hmatrix_matvec_z", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matvec_user_z", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matmat_row_major_z", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    ("hmx_hmatrix_set_block_lowrank_c", C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp]),
+    ("hmx_hmatrix_set_block_dense_c", C.c_int, [_vp, C.c_int64, _vp]),
+    ("hmx_hmatrix_get_block_c", C.c_int, [_vp, C.c_int64, _vp, _vp]),
+    ("hmx_hmatrix_matvec_c", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matvec_user_c", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("hmx_hmatrix_matmat_row_major_c", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_hmatrix_destroy", None, [_vp]),
     ("hmx_hmatrix_set_block_lowrank_s", C.c_int, [_vp, C.c_int64, C.c_int, _fp, _fp]),
     ("hmx_hmatrix_set_block_dense_s", C.c_int, [_vp, C.c_int64, _fp]),

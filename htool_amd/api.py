@@ -171,11 +171,16 @@ class InvDistGenerator:
     """Device-evaluable VirtualGenerator: K(x,y) = 1 / (delta + scale * |x - y|)
     (examples/use_hmatrix.cpp:33 has delta=1e-5, scale=1; testing/generator_test.hpp:159 delta=0, scale=4*pi)."""
 
-    def __init__(self, spatial_dimension, target_coordinates, source_coordinates, delta=1e-5, scale=1.0):
+    def __init__(self, spatial_dimension, target_coordinates, source_coordinates, delta=1e-5, scale=1.0, cre=1.0, cim=0.0,
+                 hermitian=False):
+        """With complex coefficients (HMatrixTreeBuilder.build(dtype=np.complex128 | np.complex64)) the numerator is
+        cre + i*cim*sgn, sgn = 1 or -- hermitian=True -- sign(x_target[0] - x_source[0]): the complex symmetric / Hermitian
+        generators of testing/generator_test.hpp:163-205."""
         self.dim = spatial_dimension
         self.xt = np.ascontiguousarray(target_coordinates, dtype=np.float64)
         self.xs = np.ascontiguousarray(source_coordinates, dtype=np.float64)
         self.delta, self.scale = float(delta), float(scale)
+        self.cre, self.cim, self.hermitian = float(cre), float(cim), bool(hermitian)
 
 
 class VirtualGenerator:
@@ -187,30 +192,58 @@ class VirtualGenerator:
     def copy_submatrix(self, M, N, rows, cols):
         raise NotImplementedError
 
-    def _as_callback(self, f32):
-        ctype, fn_t = (C.c_float, _lib.GENERATOR_FN_S) if f32 else (C.c_double, _lib.GENERATOR_FN)
-        dt = np.float32 if f32 else np.float64
+    def _as_callback(self, prec):
+        dt = _PREC[prec]["np"]
+        fn_t = _lib.GENERATOR_FN_S if prec in (_lib.HMX_PREC_F32, _lib.HMX_PREC_C32) else _lib.GENERATOR_FN
+        cplx = _PREC[prec]["complex"]
+        rdt = np.float32 if prec in (_lib.HMX_PREC_F32, _lib.HMX_PREC_C32) else np.float64
 
         def trampoline(_user, M, N, rows, cols, out):
             r = np.ctypeslib.as_array(rows, shape=(M,))
             c = np.ctypeslib.as_array(cols, shape=(N,))
             block = np.asarray(self.copy_submatrix(M, N, r, c), dtype=dt).reshape(M, N)
-            np.ctypeslib.as_array(out, shape=(N, M))[:] = block.T  # column-major M x N
+            if cplx:  # interleaved (re, im), column-major M x N
+                np.ctypeslib.as_array(out, shape=(N, M, 2))[:] = np.ascontiguousarray(block.T).view(rdt).reshape(N, M, 2)
+            else:
+                np.ctypeslib.as_array(out, shape=(N, M))[:] = block.T  # column-major M x N
         return fn_t(trampoline)
 
 
-def _vec_ptr(v, f32=False):
-    """(pointer, mem kind) for a numpy array or a torch tensor of the operator's coefficient precision."""
+# coefficient types: htool's HMatrix<double>, <float>, <std::complex<double>>, <std::complex<float>>
+_PREC = {
+    _lib.HMX_PREC_F64: dict(np=np.float64, torch="float64", sfx="", complex=False),
+    _lib.HMX_PREC_F32: dict(np=np.float32, torch="float32", sfx="_s", complex=False),
+    _lib.HMX_PREC_Z64: dict(np=np.complex128, torch="complex128", sfx="_z", complex=True),
+    _lib.HMX_PREC_C32: dict(np=np.complex64, torch="complex64", sfx="_c", complex=True),
+}
+
+
+def _vec_ptr(v, A):
+    """(pointer, mem kind) for a numpy array or a torch tensor of the operator's coefficient type."""
+    want = _PREC[A.prec]
     if isinstance(v, np.ndarray):
-        if v.dtype != (np.float32 if f32 else np.float64) or not v.flags["C_CONTIGUOUS"]:
-            raise HmxError("host vectors must be C-contiguous %s" % ("float32" if f32 else "float64"))
+        if v.dtype != want["np"] or not v.flags["C_CONTIGUOUS"]:
+            raise HmxError("host vectors must be C-contiguous %s" % np.dtype(want["np"]).name)
         return v.ctypes.data, _lib.HMX_MEM_HOST
     if hasattr(v, "data_ptr"):
         import torch
-        if v.dtype != (torch.float32 if f32 else torch.float64) or not v.is_contiguous():
-            raise HmxError("device vectors must be contiguous %s" % ("float32" if f32 else "float64"))
+        if v.dtype != getattr(torch, want["torch"]) or not v.is_contiguous():
+            raise HmxError("device vectors must be contiguous %s" % want["torch"])
         return v.data_ptr(), (_lib.HMX_MEM_DEVICE if v.is_cuda else _lib.HMX_MEM_HOST)
     raise HmxError("unsupported vector type %r" % type(v))
+
+
+def _coef_args(A, alpha, beta):
+    """alpha / beta as the C ABI wants them: by value for real coefficients, pointers to one (re, im) pair for complex ones.
+    Returns (alpha_arg, beta_arg, keepalive)."""
+    if not A.complex:
+        return float(alpha), float(beta), None
+    ab = np.array([alpha, beta], dtype=A.dtype)
+    return ab.ctypes.data, ab.ctypes.data + ab.itemsize, ab
+
+
+def _fn(A, name):
+    return getattr(lib(), name + _PREC[A.prec]["sfx"])
 
 
 def _stream_ptr(v):
@@ -225,8 +258,10 @@ class HMatrix:
 
     def __init__(self, bt_handle, hm_handle, target_cluster, source_cluster):
         self._bt, self._h = bt_handle, hm_handle
-        self.f32 = bool(lib().hmx_hmatrix_is_f32(hm_handle))
-        self.dtype = np.float32 if self.f32 else np.float64
+        self.prec = lib().hmx_hmatrix_precision(hm_handle)
+        self.f32 = self.prec == _lib.HMX_PREC_F32
+        self.complex = _PREC[self.prec]["complex"]
+        self.dtype = _PREC[self.prec]["np"]
         self._keep = (target_cluster, source_cluster)
         L = lib()
         r = np.zeros(4, dtype=np.int32)
@@ -274,8 +309,8 @@ class HMatrix:
         """(U, V) with U M x r and V r x N, or the dense M x N block."""
         a = self.leaves[leaf]
         M, N, r = int(a["t_size"]), int(a["s_size"]), int(self.ranks[leaf])
-        get = lib().hmx_hmatrix_get_block_s if self.f32 else lib().hmx_hmatrix_get_block
-        ptr = (lambda arr: arr.ctypes.data_as(C.POINTER(C.c_float))) if self.f32 else _dp
+        get = _fn(self, "hmx_hmatrix_get_block")
+        ptr = self._ptr
         if r >= 0:
             U, V = np.empty((r, M), dtype=self.dtype), np.empty((N, r), dtype=self.dtype)
             check(get(self._h, leaf, ptr(U), ptr(V)))
@@ -284,18 +319,19 @@ class HMatrix:
         check(get(self._h, leaf, ptr(D), None))
         return D.T
 
+    def _ptr(self, arr):
+        if self.complex:
+            return arr.ctypes.data  # void*: interleaved (re, im)
+        return arr.ctypes.data_as(C.POINTER(C.c_float if self.f32 else C.c_double))
+
     def set_block_lowrank(self, leaf, U, V):
         U = np.asfortranarray(U, dtype=self.dtype)
         V = np.asfortranarray(V, dtype=self.dtype)
-        ct = C.c_float if self.f32 else C.c_double
-        fn = lib().hmx_hmatrix_set_block_lowrank_s if self.f32 else lib().hmx_hmatrix_set_block_lowrank
-        check(fn(self._h, leaf, U.shape[1], U.ctypes.data_as(C.POINTER(ct)), V.ctypes.data_as(C.POINTER(ct))))
+        check(_fn(self, "hmx_hmatrix_set_block_lowrank")(self._h, leaf, U.shape[1], self._ptr(U), self._ptr(V)))
 
     def set_block_dense(self, leaf, D):
         D = np.asfortranarray(D, dtype=self.dtype)
-        ct = C.c_float if self.f32 else C.c_double
-        fn = lib().hmx_hmatrix_set_block_dense_s if self.f32 else lib().hmx_hmatrix_set_block_dense
-        check(fn(self._h, leaf, D.ctypes.data_as(C.POINTER(ct))))
+        check(_fn(self, "hmx_hmatrix_set_block_dense")(self._h, leaf, self._ptr(D)))
 
     def recompress(self, epsilon=-1.0):
         """recompression(hmatrix) (hmatrix/utils/recompression.hpp:8-13): SVD recompression of every low-rank leaf."""
@@ -402,21 +438,21 @@ class HMatrixTreeBuilder:
             bt = self._block_tree(target_root_cluster_tree, source_root_cluster_tree, target_partition_number,
                                   partition_number_for_symmetry)
         h = C.c_void_p()
-        if np.dtype(dtype) == np.float32:  # HMatrix<float,double>: fp32 coefficients, fp64 geometry
-            check(lib().hmx_hmatrix_create_s(bt, device, C.byref(h)))
-        else:
-            check(lib().hmx_hmatrix_create(bt, device, C.byref(h)))
+        # HMatrix<T,double>: coefficients of type `dtype`, fp64 geometry
+        prec = [k for k, v in _PREC.items() if np.dtype(v["np"]) == np.dtype(dtype)]
+        if not prec:
+            raise HmxError("dtype must be float64, float32, complex128 or complex64")
+        check(getattr(lib(), "hmx_hmatrix_create" + _PREC[prec[0]]["sfx"])(bt, device, C.byref(h)))
         H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
         if isinstance(generator, VirtualGenerator):
-            H._callback = generator._as_callback(H.f32)  # keep the ctypes thunk alive as long as the operator
-            setter = lib().hmx_hmatrix_set_callback_s if H.f32 else lib().hmx_hmatrix_set_callback
-            check(setter(h, H._callback, None))
+            H._callback = generator._as_callback(H.prec)  # keep the ctypes thunk alive as long as the operator
+            check(_fn(H, "hmx_hmatrix_set_callback")(h, H._callback, None))
         elif generator is not None:
             if not isinstance(generator, InvDistGenerator):
                 raise HmxError("generator must be an InvDistGenerator (evaluated on the device) or a VirtualGenerator "
                                "subclass (evaluated on the host through a callback)")
-            params = np.array([generator.delta, generator.scale], dtype=np.float64)
-            check(lib().hmx_hmatrix_set_kernel(h, 0, _dp(params), 2, generator.dim, _dp(generator.xt), _dp(generator.xs)))
+            params = np.array([generator.delta, generator.scale, generator.cre, generator.cim, float(generator.hermitian)], dtype=np.float64)
+            check(lib().hmx_hmatrix_set_kernel(h, 0, _dp(params), 5, generator.dim, _dp(generator.xt), _dp(generator.xs)))
         if compress:
             check(lib().hmx_hmatrix_compress(h, _lib.COMPRESSORS[self._compressor], self._eps, self._reqrank))
             H.refresh_leaves()
@@ -443,34 +479,34 @@ class HMatrixTreeBuilder:
 
 def internal_add_hmatrix_vector_product(trans, alpha, A, x, beta, y):
     """y = alpha*op(A)*x + beta*y in cluster numbering (vectors local to A's root clusters)."""
-    px, mx = _vec_ptr(x, A.f32)
-    py, my = _vec_ptr(y, A.f32)
+    px, mx = _vec_ptr(x, A)
+    py, my = _vec_ptr(y, A)
     if mx != my:
         raise HmxError("in and out must live in the same memory space")
-    fn = lib().hmx_hmatrix_matvec_s if A.f32 else lib().hmx_hmatrix_matvec
-    check(fn(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
+    a, b, _keep = _coef_args(A, alpha, beta)
+    check(_fn(A, "hmx_hmatrix_matvec")(A._h, trans.encode(), a, px, b, py, mx, _stream_ptr(x)))
     return y
 
 
 def add_hmatrix_vector_product(trans, alpha, A, x, beta, y):
     """User-numbering front end (permutations on the device)."""
-    px, mx = _vec_ptr(x, A.f32)
-    py, my = _vec_ptr(y, A.f32)
+    px, mx = _vec_ptr(x, A)
+    py, my = _vec_ptr(y, A)
     if mx != my:
         raise HmxError("in and out must live in the same memory space")
-    fn = lib().hmx_hmatrix_matvec_user_s if A.f32 else lib().hmx_hmatrix_matvec_user
-    check(fn(A._h, trans.encode(), alpha, px, beta, py, mx, _stream_ptr(x)))
+    a, b, _keep = _coef_args(A, alpha, beta)
+    check(_fn(A, "hmx_hmatrix_matvec_user")(A._h, trans.encode(), a, px, b, py, mx, _stream_ptr(x)))
     return y
 
 
 def internal_add_hmatrix_matrix_product_row_major(trans, alpha, A, X, beta, Y, mu):
     """Row-major (mu fastest) multi-RHS product in cluster numbering."""
-    px, mx = _vec_ptr(X, A.f32)
-    py, my = _vec_ptr(Y, A.f32)
+    px, mx = _vec_ptr(X, A)
+    py, my = _vec_ptr(Y, A)
     if mx != my:
         raise HmxError("in and out must live in the same memory space")
-    fn = lib().hmx_hmatrix_matmat_row_major_s if A.f32 else lib().hmx_hmatrix_matmat_row_major
-    check(fn(A._h, trans.encode(), alpha, px, beta, py, mu, mx, _stream_ptr(X)))
+    a, b, _keep = _coef_args(A, alpha, beta)
+    check(_fn(A, "hmx_hmatrix_matmat_row_major")(A._h, trans.encode(), a, px, b, py, mu, mx, _stream_ptr(X)))
     return Y
 
 

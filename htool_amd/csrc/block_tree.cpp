@@ -140,9 +140,9 @@ struct Walker {
 
 int build_block_tree(hmx_block_tree &bt) {
     const hmx_cluster_tree &T = *bt.target, &S = *bt.source;
-    const bool sym_ok = (bt.symmetry == 'N' && bt.uplo == 'N') || (bt.symmetry == 'S' && (bt.uplo == 'L' || bt.uplo == 'U'));
-    if (!sym_ok) { // check_inputs (tree_builder.hpp:79-91); 'H' needs complex coefficients, not supported here
-        set_error("hmx_block_tree_create: symmetry/UPLO must be ('N','N'), ('S','L') or ('S','U')");
+    const bool sym_ok = (bt.symmetry == 'N' && bt.uplo == 'N') || ((bt.symmetry == 'S' || bt.symmetry == 'H') && (bt.uplo == 'L' || bt.uplo == 'U'));
+    if (!sym_ok) { // check_inputs (tree_builder.hpp:79-91); 'H' (Hermitian) is meant for the complex instantiations
+        set_error("hmx_block_tree_create: symmetry/UPLO must be ('N','N'), ('S'|'H','L') or ('S'|'H','U')");
         return HMX_ERR_INVALID;
     }
     if (bt.symmetry != 'N' && !bt.consistent) {

@@ -99,48 +99,86 @@ struct Timer {
 
 // Compute the stream layout from the final leaf kinds/ranks and move the data into it.
 
+#define HMX_COMPLEX 0
 namespace f64 {
-using real  = double;
-using real2 = double2;
+using real    = double;
+using scalar  = double;
+using scalar2 = double2;
 #include "kernels_body.hpp"
 #include "engine_body.hpp"
 } // namespace f64
 namespace f32 {
-using real  = float;
-using real2 = float2;
+using real    = float;
+using scalar  = float;
+using scalar2 = float2;
 #include "kernels_body.hpp"
 #include "engine_body.hpp"
 } // namespace f32
+#undef HMX_COMPLEX
+#define HMX_COMPLEX 1
+namespace z64 { // htool's HMatrix<std::complex<double>, double>
+using real    = double;
+using scalar  = cplx<double>;
+using scalar2 = cplx2<double>;
+#include "kernels_body.hpp"
+#include "engine_body.hpp"
+} // namespace z64
+namespace c32 { // HMatrix<std::complex<float>, double>
+using real    = float;
+using scalar  = cplx<float>;
+using scalar2 = cplx2<float>;
+#include "kernels_body.hpp"
+#include "engine_body.hpp"
+} // namespace c32
+#undef HMX_COMPLEX
 
 } // namespace hmx
 
 using namespace hmx;
 
-// The opaque handle of the C ABI: one of the two instantiations
+// The opaque handle of the C ABI: one of the four instantiations
 struct hmx_hmatrix {
     hmx::f64::HMat *d = nullptr;
     hmx::f32::HMat *s = nullptr;
+    hmx::z64::HMat *z = nullptr;
+    hmx::c32::HMat *c = nullptr;
     ~hmx_hmatrix() {
         delete d;
         delete s;
+        delete z;
+        delete c;
     }
 };
 
-#define HMX_DISPATCH(H, call_d, call_s)                     \
+// type-independent entry points: the same api_* function in whichever instantiation the handle holds
+#define HMX_ALL(H, fn, ...)                                 \
     do {                                                    \
         if (!(H)) {                                         \
             set_error("NULL hmx_hmatrix handle");           \
             return HMX_ERR_INVALID;                         \
         }                                                   \
-        return (H)->d ? (call_d) : (call_s);                \
+        if ((H)->d)                                         \
+            return hmx::f64::fn((H)->d, ##__VA_ARGS__);     \
+        if ((H)->s)                                         \
+            return hmx::f32::fn((H)->s, ##__VA_ARGS__);     \
+        if ((H)->z)                                         \
+            return hmx::z64::fn((H)->z, ##__VA_ARGS__);     \
+        return hmx::c32::fn((H)->c, ##__VA_ARGS__);         \
     } while (0)
 #define HMX_NEED(H, member, what)                                                                     \
     do {                                                                                              \
         if (!(H) || !(H)->member) {                                                                   \
-            set_error(std::string(what) + ": handle holds the other coefficient precision (f64 entry points take double, *_s take float)"); \
+            set_error(std::string(what) + ": handle holds another coefficient type (plain entry points take double, *_s float, *_z complex double, *_c complex float)"); \
             return HMX_ERR_INVALID;                                                                   \
         }                                                                                             \
     } while (0)
+// complex values cross the C ABI as interleaved (re, im) pairs
+static inline cplx<double> zval(const double *p) { return cplx<double>(p[0], p[1]); }
+static inline cplx<float> cval(const float *p) { return cplx<float>(p[0], p[1]); }
+#define ZP(p) reinterpret_cast<const cplx<double> *>(p)
+#define ZPM(p) reinterpret_cast<cplx<double> *>(p)
+#define CP(p) reinterpret_cast<const cplx<float> *>(p)
+#define CPM(p) reinterpret_cast<cplx<float> *>(p)
 
 extern "C" {
 
@@ -177,11 +215,38 @@ int hmx_hmatrix_create_s(const hmx_block_tree *bt, int device_id, hmx_hmatrix **
     (*out)->s = h;
     return HMX_OK;
 }
+int hmx_hmatrix_create_z(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out) {
+    if (!out) {
+        set_error("hmx_hmatrix_create_z: out is NULL");
+        return HMX_ERR_INVALID;
+    }
+    hmx::z64::HMat *h = nullptr;
+    const int rc      = hmx::z64::api_create(bt, device_id, &h);
+    if (rc != HMX_OK)
+        return rc;
+    *out      = new hmx_hmatrix();
+    (*out)->z = h;
+    return HMX_OK;
+}
+int hmx_hmatrix_create_c(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out) {
+    if (!out) {
+        set_error("hmx_hmatrix_create_c: out is NULL");
+        return HMX_ERR_INVALID;
+    }
+    hmx::c32::HMat *h = nullptr;
+    const int rc      = hmx::c32::api_create(bt, device_id, &h);
+    if (rc != HMX_OK)
+        return rc;
+    *out      = new hmx_hmatrix();
+    (*out)->c = h;
+    return HMX_OK;
+}
 void hmx_hmatrix_destroy(hmx_hmatrix *H) { delete H; }
 int hmx_hmatrix_is_f32(const hmx_hmatrix *H) { return H && H->s ? 1 : 0; }
+int hmx_hmatrix_precision(const hmx_hmatrix *H) { return !H ? -1 : (H->d ? HMX_PREC_F64 : (H->s ? HMX_PREC_F32 : (H->z ? HMX_PREC_Z64 : HMX_PREC_C32))); }
 
 int hmx_hmatrix_set_kernel(hmx_hmatrix *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc) {
-    HMX_DISPATCH(H, hmx::f64::api_set_kernel(H->d, kernel, params, nparams, dim, tc, sc), hmx::f32::api_set_kernel(H->s, kernel, params, nparams, dim, tc, sc));
+    HMX_ALL(H, api_set_kernel, kernel, params, nparams, dim, tc, sc);
 }
 int hmx_hmatrix_set_callback(hmx_hmatrix *H, hmx_generator_fn fn, void *user) {
     HMX_NEED(H, d, "hmx_hmatrix_set_callback");
@@ -192,17 +257,17 @@ int hmx_hmatrix_set_callback_s(hmx_hmatrix *H, hmx_generator_fn_s fn, void *user
     return hmx::f32::api_set_callback(H->s, fn, user);
 }
 int hmx_hmatrix_compress(hmx_hmatrix *H, int compressor, double epsilon, int reqrank) {
-    HMX_DISPATCH(H, hmx::f64::api_compress(H->d, compressor, epsilon, reqrank), hmx::f32::api_compress(H->s, compressor, epsilon, reqrank));
+    HMX_ALL(H, api_compress, compressor, epsilon, reqrank);
 }
-int hmx_hmatrix_recompress(hmx_hmatrix *H, double epsilon) { HMX_DISPATCH(H, hmx::f64::api_recompress(H->d, epsilon), hmx::f32::api_recompress(H->s, epsilon)); }
-int hmx_hmatrix_finalize(hmx_hmatrix *H) { HMX_DISPATCH(H, hmx::f64::api_finalize(H->d), hmx::f32::api_finalize(H->s)); }
-int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *H, int32_t *rank) { HMX_DISPATCH(H, hmx::f64::api_leaf_ranks(H->d, rank), hmx::f32::api_leaf_ranks(H->s, rank)); }
-int hmx_hmatrix_stats(const hmx_hmatrix *H, hmx_stats *out) { HMX_DISPATCH(H, hmx::f64::api_stats(H->d, out), hmx::f32::api_stats(H->s, out)); }
-int hmx_hmatrix_set_profiling(hmx_hmatrix *H, int enabled) { HMX_DISPATCH(H, hmx::f64::api_set_profiling(H->d, enabled), hmx::f32::api_set_profiling(H->s, enabled)); }
+int hmx_hmatrix_recompress(hmx_hmatrix *H, double epsilon) { HMX_ALL(H, api_recompress, epsilon); }
+int hmx_hmatrix_finalize(hmx_hmatrix *H) { HMX_ALL(H, api_finalize); }
+int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *H, int32_t *rank) { HMX_ALL(H, api_leaf_ranks, rank); }
+int hmx_hmatrix_stats(const hmx_hmatrix *H, hmx_stats *out) { HMX_ALL(H, api_stats, out); }
+int hmx_hmatrix_set_profiling(hmx_hmatrix *H, int enabled) { HMX_ALL(H, api_set_profiling, enabled); }
 int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *H, int max, const char **names, float *ms) {
     if (!H)
         return 0;
-    return H->d ? hmx::f64::api_last_kernel_times(H->d, max, names, ms) : hmx::f32::api_last_kernel_times(H->s, max, names, ms);
+    HMX_ALL(H, api_last_kernel_times, max, names, ms);
 }
 
 // ---- fp64 coefficients ----------------------------------------------------------------------------------------
@@ -257,7 +322,65 @@ int hmx_hmatrix_matmat_row_major_s(hmx_hmatrix *H, char trans, float alpha, cons
     return hmx::f32::api_matmat_row_major(H->s, trans, alpha, in, beta, out, mu, mem, stream);
 }
 
-int hmx_hmatrix_save(const hmx_hmatrix *H, const char *path) { HMX_DISPATCH(H, hmx::f64::api_save(H->d, path), hmx::f32::api_save(H->s, path)); }
+// ---- complex coefficients (htool's HMatrix<std::complex<double>> / <std::complex<float>>): interleaved (re, im) ------------
+int hmx_hmatrix_set_callback_z(hmx_hmatrix *H, hmx_generator_fn fn, void *user) {
+    HMX_NEED(H, z, "hmx_hmatrix_set_callback_z");
+    return hmx::z64::api_set_callback(H->z, reinterpret_cast<void (*)(void *, int, int, const int32_t *, const int32_t *, cplx<double> *)>(fn), user);
+}
+int hmx_hmatrix_set_callback_c(hmx_hmatrix *H, hmx_generator_fn_s fn, void *user) {
+    HMX_NEED(H, c, "hmx_hmatrix_set_callback_c");
+    return hmx::c32::api_set_callback(H->c, reinterpret_cast<void (*)(void *, int, int, const int32_t *, const int32_t *, cplx<float> *)>(fn), user);
+}
+int hmx_hmatrix_set_block_lowrank_z(hmx_hmatrix *H, int64_t leaf, int rank, const double *U, const double *V) {
+    HMX_NEED(H, z, "hmx_hmatrix_set_block_lowrank_z");
+    return hmx::z64::api_set_block_lowrank(H->z, leaf, rank, ZP(U), ZP(V));
+}
+int hmx_hmatrix_set_block_dense_z(hmx_hmatrix *H, int64_t leaf, const double *D) {
+    HMX_NEED(H, z, "hmx_hmatrix_set_block_dense_z");
+    return hmx::z64::api_set_block_dense(H->z, leaf, ZP(D));
+}
+int hmx_hmatrix_get_block_z(const hmx_hmatrix *H, int64_t leaf, double *U_or_D, double *V) {
+    HMX_NEED(H, z, "hmx_hmatrix_get_block_z");
+    return hmx::z64::api_get_block(H->z, leaf, ZPM(U_or_D), ZPM(V));
+}
+int hmx_hmatrix_matvec_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mem, void *stream) {
+    HMX_NEED(H, z, "hmx_hmatrix_matvec_z");
+    return hmx::z64::api_matvec(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mem, stream);
+}
+int hmx_hmatrix_matvec_user_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mem, void *stream) {
+    HMX_NEED(H, z, "hmx_hmatrix_matvec_user_z");
+    return hmx::z64::api_matvec_user(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mem, stream);
+}
+int hmx_hmatrix_matmat_row_major_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mu, int mem, void *stream) {
+    HMX_NEED(H, z, "hmx_hmatrix_matmat_row_major_z");
+    return hmx::z64::api_matmat_row_major(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mu, mem, stream);
+}
+int hmx_hmatrix_set_block_lowrank_c(hmx_hmatrix *H, int64_t leaf, int rank, const float *U, const float *V) {
+    HMX_NEED(H, c, "hmx_hmatrix_set_block_lowrank_c");
+    return hmx::c32::api_set_block_lowrank(H->c, leaf, rank, CP(U), CP(V));
+}
+int hmx_hmatrix_set_block_dense_c(hmx_hmatrix *H, int64_t leaf, const float *D) {
+    HMX_NEED(H, c, "hmx_hmatrix_set_block_dense_c");
+    return hmx::c32::api_set_block_dense(H->c, leaf, CP(D));
+}
+int hmx_hmatrix_get_block_c(const hmx_hmatrix *H, int64_t leaf, float *U_or_D, float *V) {
+    HMX_NEED(H, c, "hmx_hmatrix_get_block_c");
+    return hmx::c32::api_get_block(H->c, leaf, CPM(U_or_D), CPM(V));
+}
+int hmx_hmatrix_matvec_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mem, void *stream) {
+    HMX_NEED(H, c, "hmx_hmatrix_matvec_c");
+    return hmx::c32::api_matvec(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mem, stream);
+}
+int hmx_hmatrix_matvec_user_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mem, void *stream) {
+    HMX_NEED(H, c, "hmx_hmatrix_matvec_user_c");
+    return hmx::c32::api_matvec_user(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mem, stream);
+}
+int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mu, int mem, void *stream) {
+    HMX_NEED(H, c, "hmx_hmatrix_matmat_row_major_c");
+    return hmx::c32::api_matmat_row_major(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream);
+}
+
+int hmx_hmatrix_save(const hmx_hmatrix *H, const char *path) { HMX_ALL(H, api_save, path); }
 int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, hmx_hmatrix **out) {
     if (!bt || !path || !out) {
         set_error("hmx_hmatrix_load: invalid arguments");
@@ -269,20 +392,30 @@ int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, 
         return HMX_ERR_INVALID;
     }
     hmx::f64::HmxFileHeader hd; // same layout in both instantiations
-    if (fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, hmx::f64::HMX_FILE_MAGIC, 8) != 0 || (hd.elem_size != 4 && hd.elem_size != 8)) {
+    if (fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, hmx::f64::HMX_FILE_MAGIC, 8) != 0 || (hd.elem_size != 4 && hd.elem_size != 8 && hd.elem_size != 16)) {
         fclose(f);
         set_error(std::string("hmx_hmatrix_load: ") + path + " is not an hmx operator file");
         return HMX_ERR_INVALID;
     }
     hmx::f64::HMat *d = nullptr;
     hmx::f32::HMat *s = nullptr;
+    hmx::z64::HMat *z = nullptr;
+    hmx::c32::HMat *c = nullptr;
     int rc;
-    if (hd.elem_size == 8) {
+    if (hd.elem_size == 8 && !hd.reserved) {
         rc = hmx::f64::api_load(bt, device_id, f, hd, &d);
-    } else {
+    } else if (hd.elem_size == 4) {
         hmx::f32::HmxFileHeader hs;
         std::memcpy(&hs, &hd, sizeof hs);
         rc = hmx::f32::api_load(bt, device_id, f, hs, &s);
+    } else if (hd.elem_size == 16) {
+        hmx::z64::HmxFileHeader hs;
+        std::memcpy(&hs, &hd, sizeof hs);
+        rc = hmx::z64::api_load(bt, device_id, f, hs, &z);
+    } else {
+        hmx::c32::HmxFileHeader hs;
+        std::memcpy(&hs, &hd, sizeof hs);
+        rc = hmx::c32::api_load(bt, device_id, f, hs, &c);
     }
     fclose(f);
     if (rc != HMX_OK)
@@ -290,6 +423,8 @@ int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, 
     *out      = new hmx_hmatrix();
     (*out)->d = d;
     (*out)->s = s;
+    (*out)->z = z;
+    (*out)->c = c;
     return HMX_OK;
 }
 

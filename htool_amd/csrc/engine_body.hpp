@@ -1,5 +1,6 @@
-// engine_body.hpp -- host orchestration of the device engine, written against `real` (coefficient type) and included
-// twice by engine.hip (namespace hmx::f64 with real = double, hmx::f32 with real = float).  No include guard on purpose.
+// engine_body.hpp -- host orchestration of the device engine, written against `scalar` (coefficient type; `real` is its
+// underlying real type) and included four times by engine.hip: namespaces hmx::f64, hmx::f32 (scalar = double / float) and
+// hmx::z64, hmx::c32 (scalar = cplx<double> / cplx<float>, HMX_COMPLEX = 1).  No include guard on purpose.
 
 struct StreamSet {
     std::vector<int32_t> off, len, cols, cw; // per range: local offset, rows, columns, chunk width (R only)
@@ -7,7 +8,7 @@ struct StreamSet {
     int64_t elems = 0, total_cols = 0;
     DArr<int32_t> d_off, d_len, d_cols, d_cw;
     DArr<int64_t> d_base, d_colbase;
-    DArr<real> stream;
+    DArr<scalar> stream;
     // R: one task per (range, column chunk), heaviest first.  E: task_range = launch order of the ranges.
     std::vector<int32_t> task_range, task_chunk;
     DArr<int32_t> d_task_range, d_task_chunk;
@@ -43,9 +44,9 @@ struct HMat {
 
     // generator
     // host generator: VirtualGenerator::copy_submatrix semantics (user numbering, column-major output)
-    void (*callback)(void *, int, int, const int32_t *, const int32_t *, real *) = nullptr;
+    void (*callback)(void *, int, int, const int32_t *, const int32_t *, scalar *) = nullptr;
     void *callback_user = nullptr;
-    DArr<real> dense_stage; // dense leaves evaluated by the host generator (pack_dense reads them from here)
+    DArr<scalar> dense_stage; // dense leaves evaluated by the host generator (pack_dense reads them from here)
     bool has_kernel = false;
     KernelSpec ks{};
     DArr<double> tx, ty, tz, sx, sy, sz; // cluster-order coordinates (SoA)
@@ -56,10 +57,10 @@ struct HMat {
     std::vector<int64_t> colptr;
     std::vector<int32_t> swapped;
     // compressed data before packing ("crosses": [uu_k | vv_k]) and staged dense uploads
-    DArr<real> pool;
+    DArr<scalar> pool;
     unsigned long long pool_used = 0;
     // host staging for the upload path
-    std::vector<std::vector<real>> staged_U, staged_V, staged_D;
+    std::vector<std::vector<scalar>> staged_U, staged_V, staged_D;
 
     // streams
     StreamSet E, R;
@@ -70,8 +71,9 @@ struct HMat {
     int n_combine       = 0;
     int64_t A_total     = 0, P_total = 0;
     int64_t zero_slot   = 0;
-    DArr<real> Z, W, Zmu;
-    DArr<real> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
+    DArr<scalar> Z, W, Zmu;
+    DArr<scalar> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
+    DArr<scalar> conj_in;                             // conjugated input of a trans = 'C' product
     DArr<int32_t> d_perm_t, d_perm_s;
     bool finalized = false;
 
@@ -101,6 +103,10 @@ static int build_streams(HMat &H) {
     // That costs the memory symmetric storage would save; HMX_SYM_COMPACT=1 keeps the compact form and uses the
     // mirror pass (colreduce/rowreduce kernels) instead.  Measured at N=1e6 fp64: 3.0 ms expanded vs 3.9 ms compact.
     H.sym_expanded = H.has_mirror && !(getenv("HMX_SYM_COMPACT") && atoi(getenv("HMX_SYM_COMPACT")));
+    // Hermitian storage ('H'): the mirrored copy is the CONJUGATE transpose; only the expanded layout implements it
+    const int herm = H.symmetry_for_leaves == 'H' ? 1 : 0;
+    if (herm)
+        H.sym_expanded = H.has_mirror;
     std::vector<hmx_leaf> XL = H.leaves;
     std::vector<int> XK      = H.kind;
     std::vector<int64_t> xcolptr = H.colptr, xstaged = H.staged_off;
@@ -402,7 +408,7 @@ static int build_streams(HMat &H) {
             HMX_HIP(pr.upload(elr_r));
             HMX_HIP(pc.upload(elr_c));
             PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0};
+                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0, H.d_transposed.d, herm};
             hipLaunchKernelGGL(pack_lr_expand_kernel, dim3((unsigned)elr_b.size()), dim3(256), 0, 0, P, (int64_t)elr_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -412,7 +418,7 @@ static int build_streams(HMat &H) {
             HMX_HIP(pr.upload(rlr_r));
             HMX_HIP(pc.upload(rlr_c));
             PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0};
+                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0, H.d_transposed.d, herm};
             hipLaunchKernelGGL(pack_lr_reduce_kernel, dim3((unsigned)rlr_b.size()), dim3(256), 0, 0, P, (int64_t)rlr_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -422,7 +428,7 @@ static int build_streams(HMat &H) {
             HMX_HIP(pr.upload(ed_r));
             HMX_HIP(pc.upload(ed_c));
             PackDenseArgs P{H.ks, H.tx.d, H.ty.d, H.tz.d, H.sx.d, H.sy.d, H.sz.d, pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d,
-                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.dense_stage.d ? H.dense_stage.d : H.pool.d, E.stream.d, H.T0};
+                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.dense_stage.d ? H.dense_stage.d : H.pool.d, E.stream.d, H.T0, herm};
             hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)ed_b.size()), dim3(256), 0, 0, P, (int64_t)ed_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -436,7 +442,7 @@ static int build_streams(HMat &H) {
     (void)hipEventDestroy(e1);
     H.stats.t_pack_s     = tim.s();
     H.stats.t_assemble_s = ms * 1e-3;
-    H.stats.stream_bytes = (E.elems + R.elems) * (int64_t)sizeof(real);
+    H.stats.stream_bytes = (E.elems + R.elems) * (int64_t)sizeof(scalar);
     H.stats.expand_coeffs = E.elems;
     H.stats.a_total       = A_total;
     H.stats.reduce_coeffs = 0;
@@ -492,16 +498,16 @@ static void prof_mark(HMat &H, hipStream_t st, const char *name) {
 
 // forward pass on device pointers: y = alpha * (sum over leaves) x + beta * y using the fast kernels
 // zidx: coefficient index array of the E-streams (all leaves, or mirror leaves only)
-static int run_forward(HMat &H, const int32_t *zidx, const real *x_src, int x_shift, real alpha, real beta, real *y, hipStream_t st) {
+static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st) {
     // Z[x region] <- x.  x_shift != 0 (mirror pass of a transposed product): the input is indexed by target
     // positions, the x region by source positions.
     if (x_shift == 0) {
-        HMX_HIP(hipMemcpyAsync(H.Z.d, x_src, (size_t)H.nS * sizeof(real), hipMemcpyDeviceToDevice, st));
+        HMX_HIP(hipMemcpyAsync(H.Z.d, x_src, (size_t)H.nS * sizeof(scalar), hipMemcpyDeviceToDevice, st));
     } else {
-        HMX_HIP(hipMemsetAsync(H.Z.d, 0, (size_t)H.nS * sizeof(real), st));
+        HMX_HIP(hipMemsetAsync(H.Z.d, 0, (size_t)H.nS * sizeof(scalar), st));
         const int lo = std::max(H.S0, H.T0), hi = std::min(H.S0 + H.nS, H.T0 + H.nT);
         if (hi > lo)
-            HMX_HIP(hipMemcpyAsync(H.Z.d + (lo - H.S0), x_src + (lo - H.T0), (size_t)(hi - lo) * sizeof(real), hipMemcpyDeviceToDevice, st));
+            HMX_HIP(hipMemcpyAsync(H.Z.d + (lo - H.S0), x_src + (lo - H.T0), (size_t)(hi - lo) * sizeof(scalar), hipMemcpyDeviceToDevice, st));
     }
     prof_mark(H, st, "copy_x");
     static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 4; // tuning knobs
@@ -554,11 +560,11 @@ static void launch_mu_expand(HMat &H, ExpandArgs &XA, int mu, int cbase, hipStre
 }
 
 // Fused multi-RHS forward pass (trans='N', no mirror leaves): Y = alpha * H * X + beta * Y, X and Y row-major.
-static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y, int mu, hipStream_t st) {
+static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
         HMX_HIP(H.Zmu.alloc(need));
-    HMX_HIP(hipMemcpyAsync(H.Zmu.d, X, (size_t)H.nS * mu * sizeof(real), hipMemcpyDeviceToDevice, st));
+    HMX_HIP(hipMemcpyAsync(H.Zmu.d, X, (size_t)H.nS * mu * sizeof(scalar), hipMemcpyDeviceToDevice, st));
     prof_mark(H, st, "copy_x");
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                   H.r_outidx.d, H.Zmu.d, H.Zmu.d, (int)H.R.task_range.size()};
@@ -566,27 +572,38 @@ static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y
     // groups of 16 right-hand sides go to the matrix cores (HMX_NO_MFMA=1: VALU kernels, for A/B comparison)
     // Measured at N=1e6, mu=16: fp64 4.34 ms (MFMA) vs 4.72 ms (VALU); fp32 2.68 ms (MFMA: 64-byte row segments) vs 2.28 ms
     // (VALU) -- so the matrix cores take the fp64 groups only unless HMX_MFMA_F32=1.
-    const bool mfma_ok  = sizeof(real) == 8 || (getenv("HMX_MFMA_F32") && atoi(getenv("HMX_MFMA_F32")));
+#if HMX_COMPLEX
+    const bool use_mfma = false; // complex groups stay on the VALU kernels, at most 8 right-hand sides per pass (registers, LDS)
+    constexpr int GMAX  = 8;
+#else
+    const bool mfma_ok  = sizeof(scalar) == 8 || (getenv("HMX_MFMA_F32") && atoi(getenv("HMX_MFMA_F32")));
     const bool use_mfma = mfma_ok && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")));
+    constexpr int GMAX  = 16;
+#endif
     // stage 1 for every group of right-hand sides, then the partial sums, then stage 2
     auto for_groups = [&](auto &&fn) {
         int c = 0;
         while (c < mu) {
             const int left = mu - c;
-            const int g    = left >= 16 ? 16 : (left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1)));
+            const int g    = (left >= 16 && GMAX >= 16) ? 16 : (left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1)));
             fn(g, c);
             c += g;
         }
     };
     for_groups([&](int g, int c) {
+#if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
             if (RA.ntasks > 0)
                 hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
             prof_mark(H, st, "reduce_mfma16_kernel");
             return;
         }
+#endif
+        (void)use_mfma;
         switch (g) {
+#if !HMX_COMPLEX
         case 16: launch_mu<16>(H, RA, XA, mu, c, st); break;
+#endif
         case 8: launch_mu<8>(H, RA, XA, mu, c, st); break;
         case 4: launch_mu<4>(H, RA, XA, mu, c, st); break;
         case 2: launch_mu<2>(H, RA, XA, mu, c, st); break;
@@ -600,14 +617,18 @@ static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y
         prof_mark(H, st, "combine_mu_kernel");
     }
     for_groups([&](int g, int c) {
+#if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
             if (XA.nranges > 0)
                 hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
             prof_mark(H, st, "expand_mfma16_kernel");
             return;
         }
+#endif
         switch (g) {
+#if !HMX_COMPLEX
         case 16: launch_mu_expand<16>(H, XA, mu, c, st); break;
+#endif
         case 8: launch_mu_expand<8>(H, XA, mu, c, st); break;
         case 4: launch_mu_expand<4>(H, XA, mu, c, st); break;
         case 2: launch_mu_expand<2>(H, XA, mu, c, st); break;
@@ -620,16 +641,16 @@ static int run_forward_mu(HMat &H, const real *X, real alpha, real beta, real *Y
 
 // transposed pass: out = alpha * sum_leaves leaf^T in + beta * out, accumulated through W with atomics.
 // mirror=true restricts to leaves_for_symmetry and uses target-local output / source... (see ensure_transposed_indices)
-static int run_transposed(HMat &H, bool mirror, const real *in, real alpha, real beta, real *out, hipStream_t st) {
+static int run_transposed(HMat &H, bool mirror, const scalar *in, scalar alpha, scalar beta, scalar *out, hipStream_t st) {
     int rc = ensure_transposed_indices(H);
     if (rc != HMX_OK)
         return rc;
     const int nout = mirror ? H.nT : H.nS;
-    HMX_HIP(hipMemsetAsync(H.W.d, 0, (size_t)(nout + H.A_total) * sizeof(real), st));
+    HMX_HIP(hipMemsetAsync(H.W.d, 0, (size_t)(nout + H.A_total) * sizeof(scalar), st));
     constexpr int CW = 4, RW = 4;
     if (H.E.nranges() > 0) {
         // true transposed: `in` is target-local; mirror pass: `in` is source-local, rows are target positions
-        const real *in_eff = mirror ? in + (H.T0 - H.S0) : in;
+        const scalar *in_eff = mirror ? in + (H.T0 - H.S0) : in;
         ColReduceArgs A{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, mirror ? H.e_tdst_mirror.d : H.e_tdst.d, in_eff, H.W.d, H.E.nranges()};
         hipLaunchKernelGGL(colreduce_kernel<CW>, dim3(H.E.nranges()), dim3(CW * 64), 0, st, A);
         prof_mark(H, st, "colreduce_kernel");
@@ -648,13 +669,34 @@ static int run_transposed(HMat &H, bool mirror, const real *in, real alpha, real
     return HMX_OK;
 }
 
-static int matvec_device(HMat &H, char trans, real alpha, const real *in, real beta, real *out, hipStream_t st) {
+static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, hipStream_t st, bool inner = false) {
     if (!H.finalized) {
         set_error("hmx_hmatrix_matvec: operator not built (call hmx_hmatrix_compress or hmx_hmatrix_finalize first)");
         return HMX_ERR_STATE;
     }
+#if HMX_COMPLEX
+    // add_hmatrix_vector_product.hpp:59-62: trans='T' with 'H' leaves and trans='C' with 'S' leaves are refused
+    if (!inner && ((trans == 'T' && H.symmetry_for_leaves == 'H') || (trans == 'C' && H.symmetry_for_leaves == 'S'))) {
+        set_error(std::string("hmx_hmatrix_matvec: operation is not supported (trans=") + trans + " with " + H.symmetry_for_leaves + " leaves)");
+        return HMX_ERR_INVALID;
+    }
+    if (trans == 'C') { // alpha A^H x + beta y = conj( conj(alpha) A^T conj(x) + conj(beta) conj(y) )
+        const int nin = H.nT, nout = H.nS;
+        if ((int64_t)H.conj_in.n < nin)
+            HMX_HIP(H.conj_in.alloc(std::max(nin, 1)));
+        hipLaunchKernelGGL(conj_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, (int64_t)nin, in, H.conj_in.d);
+        if (!hmx_is_zero(beta))
+            hipLaunchKernelGGL(conj_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, (int64_t)nout, (const scalar *)out, out);
+        const int rc = matvec_device(H, 'T', hmx_conj(alpha), H.conj_in.d, hmx_conj(beta), out, st, true);
+        if (rc != HMX_OK)
+            return rc;
+        hipLaunchKernelGGL(conj_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, (int64_t)nout, (const scalar *)out, out);
+        HMX_HIP(hipGetLastError());
+        return HMX_OK;
+    }
+#endif
     if (trans != 'N' && trans != 'T') { // 'C' with 'S' leaves is an error in the reference too (add_hmatrix_vector_product.hpp:59-62)
-        set_error("hmx_hmatrix_matvec: trans must be 'N' or 'T'");
+        set_error("hmx_hmatrix_matvec: trans must be 'N' or 'T'" + std::string(HMX_COMPLEX ? " or 'C'" : ""));
         return HMX_ERR_INVALID;
     }
     if (H.has_mirror && (H.S0 > H.T0 || H.S0 + H.nS < H.T0 + H.nT)) {
@@ -667,12 +709,12 @@ static int matvec_device(HMat &H, char trans, real alpha, const real *in, real b
     if (trans == 'N') {
         rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st);
         if (rc == HMX_OK && H.has_mirror && !H.sym_expanded)
-            rc = run_transposed(H, true, in, alpha, 1.0, out, st);
+            rc = run_transposed(H, true, in, alpha, scalar(1), out, st);
     } else {
         rc = run_transposed(H, false, in, alpha, beta, out, st);
         if (rc == HMX_OK && H.has_mirror && !H.sym_expanded) {
             // mirror leaves applied un-transposed: input indexed by target positions, output by source positions
-            rc = run_forward(H, H.e_zidx_mirror.d, in, 1, alpha, 1.0, out + (H.T0 - H.S0), st);
+            rc = run_forward(H, H.e_zidx_mirror.d, in, 1, alpha, scalar(1), out + (H.T0 - H.S0), st);
         }
     }
     if (rc != HMX_OK)
@@ -747,7 +789,8 @@ static int api_set_kernel(HMat *H, int kernel, const double *params, int nparams
         return HMX_ERR_INVALID;
     }
     HMX_HIP(hipSetDevice(H->device));
-    H->ks = KernelSpec{kernel, dim, params[0], params[1]};
+    // params: delta, scale [, cre, cim, hermitian] -- the last three only matter for complex coefficients
+    H->ks = KernelSpec{kernel, dim, params[0], params[1], nparams > 2 ? params[2] : 1.0, nparams > 3 ? params[3] : 0.0, (nparams > 4 && params[4] != 0.0) ? 1 : 0};
     // coordinates permuted once into cluster order so block rows / columns are contiguous
     auto soa = [&](const double *xyz, const std::vector<int32_t> &perm, DArr<double> &X, DArr<double> &Y, DArr<double> &Zc) -> hipError_t {
         const size_t n = perm.size();
@@ -770,7 +813,7 @@ static int api_set_kernel(HMat *H, int kernel, const double *params, int nparams
     return HMX_OK;
 }
 
-static int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, const int32_t *, real *), void *user) {
+static int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, const int32_t *, scalar *), void *user) {
     if (!H || !fn) {
         set_error("hmx_hmatrix_set_callback: invalid arguments");
         return HMX_ERR_INVALID;
@@ -793,7 +836,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     }
     const bool use_cb = H.callback != nullptr && !H.has_kernel;
     // evaluate one sub-block through the host generator: rows/cols are cluster positions, mapped to user numbers
-    auto gen = [&](int M, int N, int row_pos, int col_pos, real *out) {
+    auto gen = [&](int M, int N, int row_pos, int col_pos, scalar *out) {
         H.callback(H.callback_user, M, N, H.perm_t.data() + row_pos, H.perm_s.data() + col_pos, out);
     };
     if (compressor < HMX_PARTIAL_ACA || compressor > HMX_SVD) {
@@ -801,6 +844,12 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
         return HMX_ERR_INVALID;
     }
     const bool assembled = (compressor == HMX_FULL_ACA || compressor == HMX_SVD); // works on the assembled block
+#if HMX_COMPLEX
+    if (compressor == HMX_SVD) {
+        set_error("hmx_hmatrix_compress: the SVD compressor is not available for complex coefficients (use an ACA variant, or upload blocks)");
+        return HMX_ERR_UNSUPPORTED;
+    }
+#endif
     if (reqrank == 0)
         reqrank = -1;
     H.build_epsilon = epsilon;
@@ -840,7 +889,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     });
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hipMemGetInfo(&free_b, &total_b));
-    const double budget        = 0.40 * (double)free_b / sizeof(real);
+    const double budget        = 0.40 * (double)free_b / sizeof(scalar);
     const unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(need, budget));
     HMX_HIP(H.pool.alloc(cap));
     DArr<unsigned long long> head;
@@ -882,12 +931,12 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
         }
         size_t free2 = 0, total2 = 0;
         HMX_HIP(hipMemGetInfo(&free2, &total2));
-        const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free2 / sizeof(real)));
-        if ((double)largest * sizeof(real) > 0.9 * (double)free2) {
+        const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free2 / sizeof(scalar)));
+        if ((double)largest * sizeof(scalar) > 0.9 * (double)free2) {
             set_error("hmx_hmatrix_compress: an admissible block does not fit in HBM for fullACA/SVD");
             return HMX_ERR_HIP;
         }
-        DArr<real> scratch;
+        DArr<scalar> scratch;
         HMX_HIP(scratch.alloc(slab));
         std::vector<int64_t> soff(nb, 0);
         DArr<int64_t> d_soff;
@@ -902,7 +951,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
             }
             HMX_HIP(d_soff.upload(soff));
             DenseCompressArgs D{};
-            DArr<real> pre;
+            DArr<scalar> pre;
             DArr<int64_t> d_preoff;
             if (use_cb) { // the host generator assembles the blocks of this batch
                 std::vector<int64_t> preoff(nb, 0);
@@ -911,7 +960,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
                     preoff[order[k]] = tot;
                     tot += (int64_t)H.leaves[order[k]].t_size * H.leaves[order[k]].s_size;
                 }
-                std::vector<real> host(std::max<int64_t>(tot, 1));
+                std::vector<scalar> host(std::max<int64_t>(tot, 1));
                 for (size_t k = pos; k < end; k++) {
                     const hmx_leaf &l = H.leaves[order[k]];
                     gen(l.t_size, l.s_size, l.t_offset, l.s_offset, host.data() + preoff[order[k]]);
@@ -939,8 +988,10 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
             D.rank_out    = H.d_rank.d;
             if (compressor == HMX_FULL_ACA)
                 hipLaunchKernelGGL(fullaca_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
+#if !HMX_COMPLEX
             else
                 hipLaunchKernelGGL(svd_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
+#endif
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
             pos = end;
@@ -948,24 +999,27 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     } else if (!order.empty() && use_cb) {
         // lock-step ACA: the generator runs on the host, everything else on the device (aca_cb_*_kernel)
         DArr<int32_t> dI1, dI2, dq, dstatus, dactive;
-        DArr<real> dfrob, daux, dgamma, dbuf;
+        DArr<real> dfrob, daux;
+        DArr<scalar> dgamma, dbuf;
         DArr<unsigned long long> dcur;
         DArr<int64_t> dbufoff;
         for (auto *a : {&dI1, &dI2, &dq, &dstatus}) {
             HMX_HIP(a->alloc(nb));
             HMX_HIP(a->zero());
         }
-        for (auto *a : {&dfrob, &daux, &dgamma}) {
+        for (auto *a : {&dfrob, &daux}) {
             HMX_HIP(a->alloc(nb));
             HMX_HIP(a->zero());
         }
+        HMX_HIP(dgamma.alloc(nb));
+        HMX_HIP(dgamma.zero());
         HMX_HIP(dcur.alloc(nb));
         std::vector<int32_t> status(nb, 1), I1(nb, 0), I2(nb, 0), active = order;
         for (int32_t b : order)
             status[b] = 0;
         const bool sympiv = compressor == HMX_SYMPARTIAL_ACA;
         std::vector<int64_t> bufoff(nb, 0);
-        std::vector<real> hostbuf;
+        std::vector<scalar> hostbuf;
         AcaCbArgs A{};
         A.t_off = H.d_t_off.d; A.t_size = H.d_t_size.d; A.s_off = H.d_s_off.d; A.s_size = H.d_s_size.d;
         A.symmetric_pivoting = sympiv;
@@ -989,7 +1043,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
             for (int32_t b : active) {
                 const hmx_leaf &l = H.leaves[b];
                 const bool sw = sympiv && !(l.t_offset >= l.s_offset);
-                real *out = hostbuf.data() + bufoff[b];
+                scalar *out = hostbuf.data() + bufoff[b];
                 if (row_phase) { // entries (I1, k), k over index 2
                     if (!sw)
                         gen(1, l.s_size, l.t_offset + I1[b], l.s_offset, out);
@@ -1099,7 +1153,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
                 H.staged_off[b] = tot;
                 tot += (int64_t)H.leaves[b].t_size * H.leaves[b].s_size;
             }
-        std::vector<real> host(std::max<int64_t>(tot, 1));
+        std::vector<scalar> host(std::max<int64_t>(tot, 1));
         for (size_t b = 0; b < nb; b++)
             if (H.kind[b] != LK_LOWRANK) {
                 const hmx_leaf &l = H.leaves[b];
@@ -1125,6 +1179,10 @@ static int api_recompress(HMat *Hp, double epsilon) {
         set_error("hmx_hmatrix_recompress: NULL handle");
         return HMX_ERR_INVALID;
     }
+#if HMX_COMPLEX
+    set_error("hmx_hmatrix_recompress: SVD recompression is not available for complex coefficients");
+    return HMX_ERR_UNSUPPORTED;
+#else
     HMat &H = *Hp;
     if (!H.finalized || H.pool.n == 0) {
         set_error("hmx_hmatrix_recompress: operator not built");
@@ -1151,12 +1209,12 @@ static int api_recompress(HMat *Hp, double epsilon) {
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return need[a] != need[b] ? need[a] > need[b] : a < b; });
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hipMemGetInfo(&free_b, &total_b));
-    const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free_b / sizeof(real)));
-    if ((double)largest * sizeof(real) > 0.9 * (double)free_b) {
+    const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free_b / sizeof(scalar)));
+    if ((double)largest * sizeof(scalar) > 0.9 * (double)free_b) {
         set_error("hmx_hmatrix_recompress: a block does not fit in HBM scratch");
         return HMX_ERR_HIP;
     }
-    DArr<real> scratch;
+    DArr<scalar> scratch;
     HMX_HIP(scratch.alloc(slab));
     DArr<int32_t> d_order, d_ts, d_ss, d_sw;
     DArr<int64_t> d_soff, d_colptr;
@@ -1199,9 +1257,10 @@ static int api_recompress(HMat *Hp, double epsilon) {
     H.stats.n_false_positive = keep.n_false_positive;
     H.stats.t_compress_s     = keep.t_compress_s;
     return rc;
+#endif
 }
 
-static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const real *U, const real *V) {
+static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const scalar *U, const scalar *V) {
     if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || rank < 0 || (rank > 0 && (!U || !V))) {
         set_error("hmx_hmatrix_set_block_lowrank: invalid arguments");
         return HMX_ERR_INVALID;
@@ -1219,7 +1278,7 @@ static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const real *U,
     H->finalized         = false;
     return HMX_OK;
 }
-static int api_set_block_dense(HMat *H, int64_t leaf, const real *D) {
+static int api_set_block_dense(HMat *H, int64_t leaf, const scalar *D) {
     if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || !D) {
         set_error("hmx_hmatrix_set_block_dense: invalid arguments");
         return HMX_ERR_INVALID;
@@ -1254,7 +1313,7 @@ static int api_finalize(HMat *Hp) {
         if (H.kind[b] == LK_LOWRANK)
             ncross += H.leaves[b].rank;
     }
-    std::vector<real> host(std::max<int64_t>(total, 1));
+    std::vector<scalar> host(std::max<int64_t>(total, 1));
     std::vector<int64_t> cross(std::max<int64_t>(ncross, 1)), staged(nb, -1);
     H.colptr.assign(nb, 0);
     H.swapped.assign(nb, 0);
@@ -1284,7 +1343,7 @@ static int api_finalize(HMat *Hp) {
     HMX_HIP(H.d_staged_off.upload(staged));
     H.staged_off = staged;
     if (!H.has_kernel) { // pack_dense never evaluates the generator on this path, but needs valid pointers
-        H.ks = KernelSpec{0, 3, 0, 0};
+        H.ks = KernelSpec{0, 3, 0, 0, 1, 0, 0};
     }
     return build_streams(H);
 }
@@ -1297,7 +1356,7 @@ static int api_leaf_ranks(const HMat *H, int32_t *rank) {
     return HMX_OK;
 }
 
-static int api_get_block(const HMat *Hc, int64_t leaf, real *U_or_D, real *V) {
+static int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V) {
     HMat *H = const_cast<HMat *>(Hc);
     if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || !U_or_D) {
         set_error("hmx_hmatrix_get_block: invalid arguments");
@@ -1318,11 +1377,11 @@ static int api_get_block(const HMat *Hc, int64_t leaf, real *U_or_D, real *V) {
         const int n1 = sw ? N : M, n2 = sw ? M : N;
         std::vector<int64_t> cross(std::max(r, 1));
         HMX_HIP(hipMemcpy(cross.data(), H->d_cross_off.d + H->colptr[leaf], (size_t)r * 8, hipMemcpyDeviceToHost));
-        std::vector<real> buf((size_t)n1 + n2);
+        std::vector<scalar> buf((size_t)n1 + n2);
         for (int k = 0; k < r; k++) {
-            HMX_HIP(hipMemcpy(buf.data(), H->pool.d + cross[k], buf.size() * sizeof(real), hipMemcpyDeviceToHost));
-            const real *ucol = sw ? buf.data() + n1 : buf.data();
-            const real *vrow = sw ? buf.data() : buf.data() + n1;
+            HMX_HIP(hipMemcpy(buf.data(), H->pool.d + cross[k], buf.size() * sizeof(scalar), hipMemcpyDeviceToHost));
+            const scalar *ucol = sw ? buf.data() + n1 : buf.data();
+            const scalar *vrow = sw ? buf.data() : buf.data() + n1;
             std::copy_n(ucol, M, U_or_D + (size_t)k * M);
             for (int j = 0; j < N; j++)
                 V[k + (size_t)r * j] = vrow[j];
@@ -1346,8 +1405,8 @@ static int api_get_block(const HMat *Hc, int64_t leaf, real *U_or_D, real *V) {
             return HMX_ERR_STATE;
         }
         const int len = E.len[r], rel = E.off[r] - (l.t_offset - H->T0);
-        std::vector<real> buf((size_t)len * N);
-        HMX_HIP(hipMemcpy(buf.data(), E.stream.d + E.base[r] + (int64_t)col * len, buf.size() * sizeof(real), hipMemcpyDeviceToHost));
+        std::vector<scalar> buf((size_t)len * N);
+        HMX_HIP(hipMemcpy(buf.data(), E.stream.d + E.base[r] + (int64_t)col * len, buf.size() * sizeof(scalar), hipMemcpyDeviceToHost));
         for (int j = 0; j < N; j++)
             for (int i = 0; i < len; i++)
                 U_or_D[(size_t)(rel + i) + (size_t)M * j] = buf[(size_t)j * len + i];
@@ -1387,7 +1446,8 @@ static int api_save(const HMat *Hc, const char *path) {
     }
     HmxFileHeader hd{};
     std::memcpy(hd.magic, HMX_FILE_MAGIC, 8);
-    hd.elem_size = (int32_t)sizeof(real);
+    hd.elem_size = (int32_t)sizeof(scalar);
+    hd.reserved  = HMX_COMPLEX; // 1: complex coefficients (tells a complex<float> file from a double one)
     hd.nleaves   = (int64_t)H->leaves.size();
     hd.T0 = H->T0, hd.nT = H->nT, hd.S0 = H->S0, hd.nS = H->nS;
     hd.symmetry = H->symmetry_for_leaves, hd.uplo = H->uplo_for_leaves;
@@ -1395,13 +1455,13 @@ static int api_save(const HMat *Hc, const char *path) {
     bool ok     = fwrite(&hd, sizeof hd, 1, f) == 1;
     ok          = ok && (H->leaves.empty() || fwrite(H->leaves.data(), sizeof(hmx_leaf), H->leaves.size(), f) == H->leaves.size());
     // the crosses of every low-rank leaf in one transfer
-    std::vector<real> pool(std::max<size_t>((size_t)H->pool_used, 1));
+    std::vector<scalar> pool(std::max<size_t>((size_t)H->pool_used, 1));
     std::vector<int64_t> cross(std::max<size_t>(H->d_cross_off.n, 1));
     if (H->pool_used)
-        HMX_HIP(hipMemcpy(pool.data(), H->pool.d, (size_t)H->pool_used * sizeof(real), hipMemcpyDeviceToHost));
+        HMX_HIP(hipMemcpy(pool.data(), H->pool.d, (size_t)H->pool_used * sizeof(scalar), hipMemcpyDeviceToHost));
     if (H->d_cross_off.n)
         HMX_HIP(hipMemcpy(cross.data(), H->d_cross_off.d, H->d_cross_off.n * sizeof(int64_t), hipMemcpyDeviceToHost));
-    std::vector<real> buf;
+    std::vector<scalar> buf;
     for (size_t b = 0; ok && b < H->leaves.size(); b++) {
         const hmx_leaf &l = H->leaves[b];
         const int M = l.t_size, N = l.s_size;
@@ -1409,24 +1469,24 @@ static int api_save(const HMat *Hc, const char *path) {
             const int r   = l.rank;
             const bool sw = H->swapped[b] != 0;
             const int n1  = sw ? N : M;
-            buf.assign((size_t)r * (M + N), real(0));
-            real *U = buf.data(), *V = buf.data() + (size_t)r * M;
+            buf.assign((size_t)r * (M + N), scalar(0));
+            scalar *U = buf.data(), *V = buf.data() + (size_t)r * M;
             for (int k = 0; k < r; k++) {
-                const real *c    = pool.data() + cross[H->colptr[b] + k];
-                const real *ucol = sw ? c + n1 : c, *vrow = sw ? c : c + n1;
+                const scalar *c    = pool.data() + cross[H->colptr[b] + k];
+                const scalar *ucol = sw ? c + n1 : c, *vrow = sw ? c : c + n1;
                 std::copy_n(ucol, M, U + (size_t)k * M);
                 for (int j = 0; j < N; j++)
                     V[k + (size_t)r * j] = vrow[j];
             }
         } else {
-            buf.assign((size_t)M * N, real(0));
+            buf.assign((size_t)M * N, scalar(0));
             const int rc = api_get_block(H, (int64_t)b, buf.data(), nullptr);
             if (rc != HMX_OK) {
                 fclose(f);
                 return rc;
             }
         }
-        ok = buf.empty() || fwrite(buf.data(), sizeof(real), buf.size(), f) == buf.size();
+        ok = buf.empty() || fwrite(buf.data(), sizeof(scalar), buf.size(), f) == buf.size();
     }
     ok = (fclose(f) == 0) && ok;
     if (!ok) {
@@ -1452,14 +1512,14 @@ static int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxF
     std::vector<hmx_leaf> fl((size_t)hd.nleaves);
     if (hd.nleaves && fread(fl.data(), sizeof(hmx_leaf), fl.size(), f) != fl.size())
         return fail("truncated file");
-    std::vector<real> buf;
+    std::vector<scalar> buf;
     for (size_t b = 0; b < fl.size(); b++) {
         const hmx_leaf &a = fl[b], &l = H->leaves[b];
         if (a.t_offset != l.t_offset || a.t_size != l.t_size || a.s_offset != l.s_offset || a.s_size != l.s_size || a.mirror != l.mirror)
             return fail("leaf " + std::to_string(b) + " does not match the block tree");
         const size_t count = a.rank >= 0 ? (size_t)a.rank * (a.t_size + a.s_size) : (size_t)a.t_size * a.s_size;
         buf.resize(std::max<size_t>(count, 1));
-        if (count && fread(buf.data(), sizeof(real), count, f) != count)
+        if (count && fread(buf.data(), sizeof(scalar), count, f) != count)
             return fail("truncated file");
         rc = a.rank >= 0 ? api_set_block_lowrank(H, (int64_t)b, a.rank, buf.data(), buf.data() + (size_t)a.rank * a.t_size) : api_set_block_dense(H, (int64_t)b, buf.data());
         if (rc != HMX_OK) {
@@ -1484,8 +1544,8 @@ static int api_stats(const HMat *H, hmx_stats *out) {
     return HMX_OK;
 }
 
-static int with_buffers(HMat &H, char trans, const real *in, real *out, int mu, int mem, hipStream_t st, real beta,
-                        const real **din, real **dout, bool &staged) {
+static int with_buffers(HMat &H, char trans, const scalar *in, scalar *out, int mu, int mem, hipStream_t st, scalar beta,
+                        const scalar **din, scalar **dout, bool &staged) {
     const size_t nin = (size_t)(trans == 'N' ? H.nS : H.nT) * mu, nout = (size_t)(trans == 'N' ? H.nT : H.nS) * mu;
     staged = (mem == HMX_MEM_HOST);
     if (!staged) {
@@ -1497,15 +1557,15 @@ static int with_buffers(HMat &H, char trans, const real *in, real *out, int mu, 
         HMX_HIP(H.tmp_in.alloc(nin));
     if (H.tmp_out.n < nout)
         HMX_HIP(H.tmp_out.alloc(nout));
-    HMX_HIP(hipMemcpyAsync(H.tmp_in.d, in, nin * sizeof(real), hipMemcpyHostToDevice, st));
-    if (beta != 0.0)
-        HMX_HIP(hipMemcpyAsync(H.tmp_out.d, out, nout * sizeof(real), hipMemcpyHostToDevice, st));
+    HMX_HIP(hipMemcpyAsync(H.tmp_in.d, in, nin * sizeof(scalar), hipMemcpyHostToDevice, st));
+    if (!hmx_is_zero(beta))
+        HMX_HIP(hipMemcpyAsync(H.tmp_out.d, out, nout * sizeof(scalar), hipMemcpyHostToDevice, st));
     *din  = H.tmp_in.d;
     *dout = H.tmp_out.d;
     return HMX_OK;
 }
 
-static int api_matvec(HMat *Hp, char trans, real alpha, const real *in, real beta, real *out, int mem, void *stream) {
+static int api_matvec(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mem, void *stream) {
     if (!Hp || !in || !out) {
         set_error("hmx_hmatrix_matvec: NULL argument");
         return HMX_ERR_INVALID;
@@ -1513,8 +1573,8 @@ static int api_matvec(HMat *Hp, char trans, real alpha, const real *in, real bet
     HMat &H = *Hp;
     HMX_HIP(hipSetDevice(H.device));
     hipStream_t st = (hipStream_t)stream;
-    const real *din;
-    real *dout;
+    const scalar *din;
+    scalar *dout;
     bool staged;
     int rc = with_buffers(H, trans, in, out, 1, mem, st, beta, &din, &dout, staged);
     if (rc != HMX_OK)
@@ -1524,13 +1584,13 @@ static int api_matvec(HMat *Hp, char trans, real alpha, const real *in, real bet
         return rc;
     if (staged) {
         const size_t nout = (size_t)(trans == 'N' ? H.nT : H.nS);
-        HMX_HIP(hipMemcpyAsync(out, dout, nout * sizeof(real), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipMemcpyAsync(out, dout, nout * sizeof(scalar), hipMemcpyDeviceToHost, st));
         HMX_HIP(hipStreamSynchronize(st));
     }
     return HMX_OK;
 }
 
-static int api_matvec_user(HMat *Hp, char trans, real alpha, const real *in, real beta, real *out, int mem, void *stream) {
+static int api_matvec_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mem, void *stream) {
     if (!Hp || !in || !out) {
         set_error("hmx_hmatrix_matvec_user: NULL argument");
         return HMX_ERR_INVALID;
@@ -1544,8 +1604,8 @@ static int api_matvec_user(HMat *Hp, char trans, real alpha, const real *in, rea
     }
     HMX_HIP(hipSetDevice(H.device));
     hipStream_t st = (hipStream_t)stream;
-    const real *din;
-    real *dout;
+    const scalar *din;
+    scalar *dout;
     bool staged;
     int rc = with_buffers(H, trans, in, out, 1, mem, st, beta, &din, &dout, staged);
     if (rc != HMX_OK)
@@ -1562,21 +1622,21 @@ static int api_matvec_user(HMat *Hp, char trans, real alpha, const real *in, rea
     if (H.tmp_out2.n < (size_t)nout)
         HMX_HIP(H.tmp_out2.alloc(nout));
     hipLaunchKernelGGL(gather_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, pin, bin, din, H.tmp_in2.d, 1);
-    if (beta != 0.0)
-        hipLaunchKernelGGL(gather_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const real *)dout, H.tmp_out2.d, 1);
+    if (!hmx_is_zero(beta))
+        hipLaunchKernelGGL(gather_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const scalar *)dout, H.tmp_out2.d, 1);
     rc = matvec_device(H, trans, alpha, H.tmp_in2.d, beta, H.tmp_out2.d, st);
     if (rc != HMX_OK)
         return rc;
-    hipLaunchKernelGGL(scatter_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const real *)H.tmp_out2.d, dout, 1);
+    hipLaunchKernelGGL(scatter_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const scalar *)H.tmp_out2.d, dout, 1);
     HMX_HIP(hipGetLastError());
     if (staged) {
-        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * sizeof(real), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * sizeof(scalar), hipMemcpyDeviceToHost, st));
         HMX_HIP(hipStreamSynchronize(st));
     }
     return HMX_OK;
 }
 
-static int api_matmat_row_major(HMat *Hp, char trans, real alpha, const real *in, real beta, real *out, int mu, int mem, void *stream) {
+static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
     if (!Hp || !in || !out || mu < 1) {
         set_error("hmx_hmatrix_matmat_row_major: invalid arguments");
         return HMX_ERR_INVALID;
@@ -1584,8 +1644,8 @@ static int api_matmat_row_major(HMat *Hp, char trans, real alpha, const real *in
     HMat &H = *Hp;
     HMX_HIP(hipSetDevice(H.device));
     hipStream_t st = (hipStream_t)stream;
-    const real *din;
-    real *dout;
+    const scalar *din;
+    scalar *dout;
     bool staged;
     int rc = with_buffers(H, trans, in, out, mu, mem, st, beta, &din, &dout, staged);
     if (rc != HMX_OK)
@@ -1614,7 +1674,7 @@ static int api_matmat_row_major(HMat *Hp, char trans, real alpha, const real *in
             }
         }
         if (staged) {
-            HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(real), hipMemcpyDeviceToHost, st));
+            HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(scalar), hipMemcpyDeviceToHost, st));
             HMX_HIP(hipStreamSynchronize(st));
         }
         return HMX_OK;
@@ -1622,16 +1682,16 @@ static int api_matmat_row_major(HMat *Hp, char trans, real alpha, const real *in
     // transposed products and symmetric storage: one streaming pass per right-hand side (not fused yet)
     for (int c = 0; c < mu; c++) {
         hipLaunchKernelGGL(col_extract_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, mu, c, din, H.tmp_in2.d);
-        if (beta != 0.0)
-            hipLaunchKernelGGL(col_extract_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, mu, c, (const real *)dout, H.tmp_out2.d);
+        if (!hmx_is_zero(beta))
+            hipLaunchKernelGGL(col_extract_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, mu, c, (const scalar *)dout, H.tmp_out2.d);
         rc = matvec_device(H, trans, alpha, H.tmp_in2.d, beta, H.tmp_out2.d, st);
         if (rc != HMX_OK)
             return rc;
-        hipLaunchKernelGGL(col_insert_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, mu, c, (const real *)H.tmp_out2.d, dout);
+        hipLaunchKernelGGL(col_insert_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, mu, c, (const scalar *)H.tmp_out2.d, dout);
     }
     HMX_HIP(hipGetLastError());
     if (staged) {
-        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(real), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(scalar), hipMemcpyDeviceToHost, st));
         HMX_HIP(hipStreamSynchronize(st));
     }
     return HMX_OK;

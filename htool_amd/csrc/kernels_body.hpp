@@ -1,13 +1,35 @@
-// kernels_body.hpp -- the kernels, written against `real` / `real2` (coefficient type) and included twice by
-// engine.hip: once in namespace hmx::f64 (real = double) and once in hmx::f32 (real = float; htool's
-// HMatrix<float,double>: fp32 coefficients, fp64 coordinates).  No include guard on purpose.
+// kernels_body.hpp -- the kernels, written against `scalar` / `scalar2` (coefficient type) and `real` (its underlying
+// real type) and included four times by engine.hip: namespaces hmx::f64 / hmx::f32 (scalar = real = double / float;
+// htool's HMatrix<float,double>: fp32 coefficients, fp64 coordinates) and hmx::z64 / hmx::c32 (scalar = cplx<real>,
+// HMX_COMPLEX = 1: htool's HMatrix<std::complex<...>>).  No include guard on purpose.
 // Layout and design notes: kernels_common.hpp.  Compiled with -ffp-contract=off, FMAs are explicit (hmx_fma).
 
-__device__ __forceinline__ real wave_sum(real v) {
+__device__ __forceinline__ scalar wave_sum(scalar v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o, WAVE);
+        v += hmx_shfl_xor(v, o);
     return v;
+}
+
+template <typename V>
+__device__ __forceinline__ V wave_sum_any(V v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += hmx_shfl_xor(v, o);
+    return v;
+}
+
+// generator entry in coefficient precision (real: 1/den; complex: (cre + i cim sgn)/den, component-wise division as
+// std::complex<double> / double does)
+__device__ __forceinline__ scalar eval_scalar(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
+#if HMX_COMPLEX
+    const double den = eval_kernel_den(ks, tx, ty, tz, sx, sy, sz);
+    const double u   = tx - sx;
+    const double sgn = ks.herm ? (u > 0 ? 1.0 : (u < 0 ? -1.0 : 0.0)) : 1.0;
+    return scalar((real)(ks.cre / den), (real)((ks.cim * sgn) / den));
+#else
+    return (scalar)eval_kernel(ks, tx, ty, tz, sx, sy, sz);
+#endif
 }
 
 
@@ -24,7 +46,7 @@ struct AcaArgs {
     int symmetric_pivoting;     // sympartialACA: pivot on the larger-offset cluster first
     double epsilon;
     int reqrank;
-    real *pool;               // cross storage, bump allocated
+    scalar *pool;               // cross storage, bump allocated
     unsigned long long *pool_head;
     unsigned long long pool_cap;
     const int64_t *colptr;      // per block: first slot in cross_off
@@ -41,8 +63,8 @@ __device__ __forceinline__ void block_argmax(real &val, int &idx, real *sval, in
     // maximum of |.|, ties -> larger index (the reference scans upward and replaces on ">=")
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const real ov = __shfl_xor(val, o, WAVE);
-        const int oi    = __shfl_xor(idx, o, WAVE);
+        const real ov = hmx_shfl_xor(val, o);
+        const int oi    = hmx_shfl_xor(idx, o);
         if (ov > val || (ov == val && oi > idx)) {
             val = ov;
             idx = oi;
@@ -65,11 +87,11 @@ __device__ __forceinline__ void block_argmax(real &val, int &idx, real *sval, in
     __syncthreads();
 }
 
-template <int NT, int G>
-__device__ __forceinline__ void block_sum_group(real (&acc)[G], real *sbuf) {
+template <int NT, int G, typename V>
+__device__ __forceinline__ void block_sum_group(V (&acc)[G], V *sbuf) {
 #pragma unroll
     for (int g = 0; g < G; g++)
-        acc[g] = wave_sum(acc[g]);
+        acc[g] = wave_sum_any(acc[g]);
     const int w = threadIdx.x / WAVE;
     if ((threadIdx.x & (WAVE - 1)) == 0)
 #pragma unroll
@@ -78,7 +100,7 @@ __device__ __forceinline__ void block_sum_group(real (&acc)[G], real *sbuf) {
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        real s = sbuf[g];
+        V s = sbuf[g];
 #pragma unroll
         for (int k = 1; k < NT / WAVE; k++)
             s += sbuf[k * G + g];
@@ -94,7 +116,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
     __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
-    __shared__ real sbuf[(NT / WAVE) * 8];
+    __shared__ scalar sbuf[(NT / WAVE) * 8];
     __shared__ unsigned long long s_off;
 
     const int b      = A.order[blockIdx.x];
@@ -129,22 +151,22 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
             q = -2;
             break;
         }
-        real *u2 = A.pool + off;      // new uu (length n1)
-        real *u1 = A.pool + off + n1; // new vv (length n2)
+        scalar *u2 = A.pool + off;      // new uu (length n1)
+        scalar *u1 = A.pool + off + n1; // new vv (length n2)
         // ---- cross row: entries (I1, k), k over index 2 ------------------------------------------
         const double ax = p1x[I1], ay = p1y[I1], az = p1z[I1];
-        real best = -1.0;
+        real best = -1;
         int besti   = -1;
         for (int k = tid; k < n2; k += NT) {
-            real v = swap ? eval_kernel(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_kernel(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]);
+            scalar v = swap ? eval_scalar(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_scalar(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]);
             for (int j = 0; j < q - 1; j++) {
-                const real *cj  = A.pool + cross[j];
-                const real coef = -cj[I1];
+                const scalar *cj  = A.pool + cross[j];
+                const scalar coef = -cj[I1];
                 v                 = coef * cj[n1 + k] + v;
             }
             u1[k] = v;
             if (!vis2[k]) {
-                const real a = fabs(v);
+                const real a = hmx_abs(v);
                 if (a >= best) { // k increases per thread: ">=" keeps the last maximum
                     best  = a;
                     besti = k;
@@ -156,24 +178,24 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
             I2 = besti;
         if (tid == 0)
             vis1[I1] = 1;
-        const real piv   = u1[I2];
-        const real gamma = real(1) / piv;
-        if (fabs(piv) > 1e-15) {
+        const scalar piv   = u1[I2];
+        const scalar gamma = scalar(1) / piv;
+        if (hmx_abs(piv) > 1e-15) {
             // ---- cross column: entries (k, I2), k over index 1 -----------------------------------
             const double bx = p2x[I2], by = p2y[I2], bz = p2z[I2];
             best  = -1.0;
             besti = -1;
             for (int k = tid; k < n1; k += NT) {
-                real v = swap ? eval_kernel(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_kernel(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz);
+                scalar v = swap ? eval_scalar(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_scalar(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz);
                 for (int j = 0; j < q - 1; j++) {
-                    const real *cj  = A.pool + cross[j];
-                    const real coef = -cj[n1 + I2];
+                    const scalar *cj  = A.pool + cross[j];
+                    const scalar coef = -cj[n1 + I2];
                     v                 = coef * cj[k] + v;
                 }
                 v     = v * gamma;
                 u2[k] = v;
                 if (!vis1[k] && k != I1) {
-                    const real a = fabs(v);
+                    const real a = hmx_abs(v);
                     if (a >= best) {
                         best  = a;
                         besti = k;
@@ -188,24 +210,24 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
             }
             if (reqrank < 0) {
                 // error estimator (partialACA.hpp:136-148): |c.c||r.r| + 2 sum_j (vv_j.r)(uu_j.c)
-                real acc2[2] = {0, 0};
+                scalar acc2[2] = {scalar(0), scalar(0)};
                 for (int k = tid; k < n1; k += NT)
-                    acc2[0] += u2[k] * u2[k];
+                    acc2[0] += hmx_conj(u2[k]) * u2[k];
                 for (int k = tid; k < n2; k += NT)
-                    acc2[1] += u1[k] * u1[k];
+                    acc2[1] += hmx_conj(u1[k]) * u1[k];
                 block_sum_group<NT, 2>(acc2, sbuf);
-                aux             = fabs(acc2[0]) * fabs(acc2[1]);
-                real frob_aux = 0;
+                aux             = hmx_abs(acc2[0]) * hmx_abs(acc2[1]);
+                scalar frob_aux = 0;
                 for (int j0 = 0; j0 < q - 1; j0 += 4) {
-                    real acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    scalar acc[8] = {};
                     const int nj  = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
                     for (int g = 0; g < nj; g++) {
-                        const real *cj = A.pool + cross[j0 + g];
-                        real a1 = 0, a2 = 0;
+                        const scalar *cj = A.pool + cross[j0 + g];
+                        scalar a1 = 0, a2 = 0;
                         for (int k = tid; k < n2; k += NT)
-                            a1 += cj[n1 + k] * u1[k];
+                            a1 += hmx_conj(cj[n1 + k]) * u1[k];
                         for (int k = tid; k < n1; k += NT)
-                            a2 += cj[k] * u2[k];
+                            a2 += hmx_conj(cj[k]) * u2[k];
                         acc[2 * g]     = a1;
                         acc[2 * g + 1] = a2;
                     }
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
                     for (int g = 0; g < nj; g++)
                         frob_aux += acc[2 * g] * acc[2 * g + 1];
                 }
-                frob += aux + 2 * frob_aux;
+                frob += aux + 2 * hmx_re(frob_aux);
             }
             __syncthreads();
             I1 = nextI1;
@@ -243,7 +265,7 @@ struct AcaCbArgs {
     int symmetric_pivoting;
     double epsilon;
     int reqrank;
-    real *pool;
+    scalar *pool;
     unsigned long long *pool_head;
     unsigned long long pool_cap;
     const int64_t *colptr;
@@ -253,9 +275,10 @@ struct AcaCbArgs {
     const int64_t *vis_ptr;
     // per-block state carried between launches
     int32_t *I1, *I2, *q, *status; // status: 0 active, 1 finished
-    real *frob, *aux, *gamma;
+    real *frob, *aux;
+    scalar *gamma;
     unsigned long long *cur_off;
-    const real *buf;        // host-evaluated entries of this phase, packed
+    const scalar *buf;        // host-evaluated entries of this phase, packed
     const int64_t *buf_off; // per block: first entry in buf
     int32_t *rank_out, *swapped_out;
 };
@@ -293,20 +316,20 @@ __global__ __launch_bounds__(NT) void aca_cb_row_kernel(AcaCbArgs A) {
         finish(-2);
         return;
     }
-    real *u1       = A.pool + off + n1;
-    const real *in = A.buf + A.buf_off[b];
+    scalar *u1       = A.pool + off + n1;
+    const scalar *in = A.buf + A.buf_off[b];
     real best = -1;
     int besti = -1;
     for (int k = tid; k < n2; k += NT) {
-        real v = in[k];
+        scalar v = in[k];
         for (int j = 0; j < q - 1; j++) {
-            const real *cj  = A.pool + cross[j];
-            const real coef = -cj[I1];
+            const scalar *cj  = A.pool + cross[j];
+            const scalar coef = -cj[I1];
             v               = coef * cj[n1 + k] + v;
         }
         u1[k] = v;
         if (!vis2[k]) {
-            const real a = fabs(v);
+            const real a = hmx_abs(v);
             if (a >= best) {
                 best  = a;
                 besti = k;
@@ -315,13 +338,13 @@ __global__ __launch_bounds__(NT) void aca_cb_row_kernel(AcaCbArgs A) {
     }
     block_argmax<NT>(best, besti, sval, sidx);
     const int I2   = besti >= 0 ? besti : A.I2[b];
-    const real piv = u1[I2];
+    const scalar piv = u1[I2];
     if (tid == 0)
         vis1[I1] = 1;
-    if (fabs(piv) > 1e-15) {
+    if (hmx_abs(piv) > 1e-15) {
         if (tid == 0) {
             A.I2[b]      = I2;
-            A.gamma[b]   = real(1) / piv;
+            A.gamma[b]   = scalar(1) / piv;
             A.cur_off[b] = off;
             A.q[b]       = q; // provisional: the column phase completes iteration q
         }
@@ -334,7 +357,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
     __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
-    __shared__ real sbuf[(NT / WAVE) * 8];
+    __shared__ scalar sbuf[(NT / WAVE) * 8];
     const int b = A.active[blockIdx.x];
     const int M = A.t_size[b], N = A.s_size[b];
     const bool swap = A.symmetric_pivoting && !(A.t_off[b] >= A.s_off[b]);
@@ -343,23 +366,23 @@ __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
     int64_t *cross = A.cross_off + A.colptr[b];
     const int tid  = threadIdx.x;
     const int q = A.q[b], I1 = A.I1[b], I2 = A.I2[b];
-    const real gamma = A.gamma[b];
+    const scalar gamma = A.gamma[b];
     const unsigned long long off = A.cur_off[b];
-    real *u2 = A.pool + off, *u1 = A.pool + off + n1;
-    const real *in = A.buf + A.buf_off[b];
+    scalar *u2 = A.pool + off, *u1 = A.pool + off + n1;
+    const scalar *in = A.buf + A.buf_off[b];
     real best = -1;
     int besti = -1;
     for (int k = tid; k < n1; k += NT) {
-        real v = in[k];
+        scalar v = in[k];
         for (int j = 0; j < q - 1; j++) {
-            const real *cj  = A.pool + cross[j];
-            const real coef = -cj[n1 + I2];
+            const scalar *cj  = A.pool + cross[j];
+            const scalar coef = -cj[n1 + I2];
             v               = coef * cj[k] + v;
         }
         v     = v * gamma;
         u2[k] = v;
         if (!vis1[k] && k != I1) {
-            const real a = fabs(v);
+            const real a = hmx_abs(v);
             if (a >= best) {
                 best  = a;
                 besti = k;
@@ -369,24 +392,24 @@ __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
     block_argmax<NT>(best, besti, sval, sidx);
     real frob = A.frob[b], aux = A.aux[b];
     if (A.reqrank < 0) {
-        real acc2[2] = {0, 0};
+        scalar acc2[2] = {scalar(0), scalar(0)};
         for (int k = tid; k < n1; k += NT)
-            acc2[0] += u2[k] * u2[k];
+            acc2[0] += hmx_conj(u2[k]) * u2[k];
         for (int k = tid; k < n2; k += NT)
-            acc2[1] += u1[k] * u1[k];
+            acc2[1] += hmx_conj(u1[k]) * u1[k];
         block_sum_group<NT, 2>(acc2, sbuf);
-        aux           = fabs(acc2[0]) * fabs(acc2[1]);
-        real frob_aux = 0;
+        aux           = hmx_abs(acc2[0]) * hmx_abs(acc2[1]);
+        scalar frob_aux = 0;
         for (int j0 = 0; j0 < q - 1; j0 += 4) {
-            real acc[8]  = {0, 0, 0, 0, 0, 0, 0, 0};
+            scalar acc[8]  = {};
             const int nj = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
             for (int g = 0; g < nj; g++) {
-                const real *cj = A.pool + cross[j0 + g];
-                real a1 = 0, a2 = 0;
+                const scalar *cj = A.pool + cross[j0 + g];
+                scalar a1 = 0, a2 = 0;
                 for (int k = tid; k < n2; k += NT)
-                    a1 += cj[n1 + k] * u1[k];
+                    a1 += hmx_conj(cj[n1 + k]) * u1[k];
                 for (int k = tid; k < n1; k += NT)
-                    a2 += cj[k] * u2[k];
+                    a2 += hmx_conj(cj[k]) * u2[k];
                 acc[2 * g]     = a1;
                 acc[2 * g + 1] = a2;
             }
@@ -394,7 +417,7 @@ __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
             for (int g = 0; g < nj; g++)
                 frob_aux += acc[2 * g] * acc[2 * g + 1];
         }
-        frob += aux + 2 * frob_aux;
+        frob += aux + 2 * hmx_re(frob_aux);
     }
     const int minmn = n1 < n2 ? n1 : n2;
     const bool more = (A.reqrank > 0) ? (q < (A.reqrank < minmn ? A.reqrank : minmn)) : (sqrt(aux / frob) > (real)A.epsilon);
@@ -422,18 +445,18 @@ struct DenseCompressArgs {
     const double *tx, *ty, *tz, *sx, *sy, *sz;
     const int32_t *order; // launch order -> block id
     const int32_t *t_off, *t_size, *s_off, *s_size;
-    const int64_t *scratch_off; // per block: first real of its slab in `scratch`
-    real *scratch;
+    const int64_t *scratch_off; // per block: first scalar of its slab in `scratch`
+    scalar *scratch;
     double epsilon;
     int reqrank;
-    real *pool;
+    scalar *pool;
     unsigned long long *pool_head;
     unsigned long long pool_cap;
     const int64_t *colptr;
     const int32_t *colcap;
     int64_t *cross_off;
     int32_t *rank_out;
-    const real *pre;        // != NULL: blocks assembled by the host generator (column-major M x N) at pre_off[b]
+    const scalar *pre;        // != NULL: blocks assembled by the host generator (column-major M x N) at pre_off[b]
     const int64_t *pre_off;
 };
 
@@ -447,16 +470,16 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
     const int b = A.order[blockIdx.x];
     const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
     const int64_t MN = (int64_t)M * N;
-    real *mat      = A.scratch + A.scratch_off[b];
+    scalar *mat      = A.scratch + A.scratch_off[b];
     int64_t *cross   = A.cross_off + A.colptr[b];
     const int cap    = A.colcap[b];
     const int tid    = threadIdx.x;
-    real acc1[1]   = {0};
+    real acc1[1]     = {0};
     for (int64_t e = tid; e < MN; e += NT) {
         const int i = (int)(e % M), j = (int)(e / M);
-        const real v = A.pre ? A.pre[A.pre_off[b] + e] : (real)eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        const scalar v = A.pre ? A.pre[A.pre_off[b] + e] : eval_scalar(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
         mat[e]         = v;
-        acc1[0] += v * v;
+        acc1[0] += hmx_abs2(v);
     }
     block_sum_group<NT, 1>(acc1, sbuf);
     const real Norm = sqrt(acc1[0]);
@@ -471,10 +494,10 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
             break;
         }
         // std::max_element over the column-major array: first maximum of |.| (matrix/utils/math.hpp:18-23)
-        real best = -1.0;
+        real best = -1;
         int64_t bi  = -1;
         for (int64_t e = tid; e < MN; e += NT) {
-            const real a = fabs(mat[e]);
+            const real a = hmx_abs(mat[e]);
             if (a > best) {
                 best = a;
                 bi   = e;
@@ -485,8 +508,8 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
         block_argmax<NT>(best, neg, sval, sidx);
         const int64_t pe = -(int64_t)neg;
         const int pi = (int)(pe % M), pj = (int)(pe / M);
-        const real pivot = mat[pe];
-        if (fabs(pivot) < 1e-15) {
+        const scalar pivot = mat[pe];
+        if (hmx_abs(pivot) < 1e-15) {
             q += -1;
             break;
         }
@@ -498,7 +521,7 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
             q = -2;
             break;
         }
-        real *u = A.pool + off, *v = A.pool + off + M;
+        scalar *u = A.pool + off, *v = A.pool + off + M;
         for (int i = tid; i < M; i += NT)
             u[i] = mat[i + (int64_t)M * pj];
         for (int j = tid; j < N; j += NT)
@@ -507,9 +530,9 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
         acc1[0] = 0;
         for (int64_t e = tid; e < MN; e += NT) {
             const int i = (int)(e % M), j = (int)(e / M);
-            const real r = mat[e] - u[i] * v[j];
+            const scalar r = mat[e] - u[i] * v[j];
             mat[e]         = r;
-            acc1[0] += r * r;
+            acc1[0] += hmx_abs2(r);
         }
         block_sum_group<NT, 1>(acc1, sbuf);
         cur = sqrt(acc1[0]);
@@ -520,6 +543,7 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
         A.rank_out[b] = q > 0 ? q : (q == -2 ? -2 : 0);
 }
 
+#if !HMX_COMPLEX // LAPACK-backed compressors (SVD, SVD recompression): real coefficients only
 // Cyclic one-sided Jacobi on the columns of W (m x n, column-major): on return the columns are mutually orthogonal
 // (W_out = W_in * Vm, Vm accumulates the rotations, must hold the identity on entry).  The pairs of one round-robin
 // round touch disjoint columns, so each wave rotates one pair; a workgroup barrier separates the rounds.
@@ -814,11 +838,13 @@ __global__ __launch_bounds__(NT) void recompress_kernel(RecompressArgs A) {
     }
 }
 
+#endif // !HMX_COMPLEX
+
 // ---------------------------------------------------------------------------------------------
 // Pack: move compressed data into the matvec streams
 // ---------------------------------------------------------------------------------------------
 struct PackLrArgs {
-    const real *pool;
+    const scalar *pool;
     const int64_t *cross_off; // per (block,k)
     const int64_t *colptr;
     const int32_t *rank;
@@ -830,8 +856,10 @@ struct PackLrArgs {
     const int64_t *range_base;
     const int32_t *range_cols; // C of the range (R-stream only)
     const int32_t *range_cw;   // chunk width of the range (R-stream only)
-    real *stream;
+    scalar *stream;
     int origin;                // global cluster position of local offset 0 (T0 for E-streams, S0 for R-streams)
+    const int32_t *transposed; // 1: mirrored copy of a stored leaf (expanded symmetric layout)
+    int herm;                  // Hermitian storage: mirrored copies are conjugated
 };
 
 // U slices -> E-stream (column-major len x C per target range)
@@ -844,12 +872,12 @@ __global__ void pack_lr_expand_kernel(PackLrArgs P, int64_t npairs) {
     const int n1  = P.swapped[b] ? P.s_size[b] : P.t_size[b]; // length of uu in a cross
     const int rel = P.range_off[R] + P.origin - P.t_off[b];
     const int64_t *cross = P.cross_off + P.colptr[b];
-    real *dst          = P.stream + P.range_base[R] + (int64_t)col * len;
+    scalar *dst          = P.stream + P.range_base[R] + (int64_t)col * len;
     for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
         const int k = e / len, i = e - k * len;
         // U(:,k) = uu_k when index 1 is the row side, vv_k otherwise (sympartialACA.hpp:198-212)
-        const real *src = P.pool + cross[k] + (P.swapped[b] ? n1 : 0);
-        dst[e]            = src[rel + i];
+        const scalar *src = P.pool + cross[k] + (P.swapped[b] ? n1 : 0);
+        dst[e]            = (P.herm && P.transposed[b]) ? hmx_conj(src[rel + i]) : src[rel + i];
     }
 }
 
@@ -875,8 +903,8 @@ __global__ void pack_lr_reduce_kernel(PackLrArgs P, int64_t npairs) {
     const int64_t *cross = P.cross_off + P.colptr[b];
     for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
         const int k = e / len, i = e - k * len;
-        const real *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
-        P.stream[rstream_index(P.range_base[S], len, C, P.range_cw[S], i, col + k)] = src[rel + i];
+        const scalar *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
+        P.stream[rstream_index(P.range_base[S], len, C, P.range_cw[S], i, col + k)] = (P.herm && P.transposed[b]) ? hmx_conj(src[rel + i]) : src[rel + i];
     }
 }
 
@@ -890,9 +918,10 @@ struct PackDenseArgs {
     const int64_t *staged_off; // >= 0: uploaded dense block (column-major M x N) in `pool`; < 0: generate
     const int32_t *sym_uplo;   // 0 none, 1 'L', 2 'U' : uploaded symmetric leaf, only that triangle is valid
     const int32_t *transposed; // 1: this entry is the mirrored copy of a stored leaf -- read the staged block transposed
-    const real *pool;
-    real *stream;
+    const scalar *pool;
+    scalar *stream;
     int origin; // T0
+    int herm;   // Hermitian storage: mirrored entries are conjugated, the diagonal of a symmetric leaf is real (hemv)
 };
 
 // dense leaves -> E-stream: HMatrix::compute_dense_data (hmatrix/hmatrix.hpp:222-226) fused with the
@@ -906,22 +935,30 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
     const int row0 = P.range_off[R] + P.origin; // global cluster position of the range's first row
     const int rel  = row0 - P.t_off[b];
     const int c0   = P.s_off[b];
-    real *dst    = P.stream + P.range_base[R] + (int64_t)col * len;
+    scalar *dst    = P.stream + P.range_base[R] + (int64_t)col * len;
     const int64_t st = P.staged_off[b];
     const int su     = P.sym_uplo[b];
     for (int e = threadIdx.x; e < N * len; e += blockDim.x) {
         const int j = e / len, i = e - j * len;
-        real v;
+        scalar v;
         if (st >= 0) {
             int ii = rel + i, jj = j;
-            if ((su == 1 && ii < jj) || (su == 2 && ii > jj)) { // symv semantics: mirror the stored triangle
+            bool cj = false;
+            if ((su == 1 && ii < jj) || (su == 2 && ii > jj)) { // symv / hemv semantics: mirror the stored triangle
                 const int t = ii;
                 ii          = jj;
                 jj          = t;
+                cj          = P.herm != 0;
             }
+            if (P.transposed[b])
+                cj = (P.herm != 0) != cj;
             v = P.transposed[b] ? P.pool[st + jj + (int64_t)N * ii] : P.pool[st + ii + (int64_t)M * jj];
+            if (cj)
+                v = hmx_conj(v);
+            if (P.herm && su && ii == jj)
+                v = scalar(hmx_re(v));
         } else {
-            v = eval_kernel(P.ks, P.tx[row0 + i], P.ty[row0 + i], P.tz[row0 + i], P.sx[c0 + j], P.sy[c0 + j], P.sz[c0 + j]);
+            v = eval_scalar(P.ks, P.tx[row0 + i], P.ty[row0 + i], P.tz[row0 + i], P.sx[c0 + j], P.sy[c0 + j], P.sz[c0 + j]);
         }
         dst[e] = v;
     }
@@ -934,14 +971,14 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
 // lane owns two adjacent columns and walks the rows; the x slice is loaded 64 rows at a time (one
 // coalesced load) and broadcast with v_readlane, so the row loop contains only the 16-B stream loads.
 struct ReduceArgs {
-    const real *stream;
+    const scalar *stream;
     const int32_t *task_range, *task_chunk;
     const int32_t *range_off, *range_len, *range_cols, *range_cw;
     const int64_t *range_base;
     const int64_t *range_colbase; // first entry of the range in out_idx
     const int32_t *out_idx;       // per column: destination in Z (an `a` slot or a partial slot)
-    const real *x;              // input vector, local to the source root
-    real *Z;
+    const scalar *x;              // input vector, local to the source root
+    scalar *Z;
     int ntasks;
 };
 
@@ -957,29 +994,29 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
     const bool active = 2 * lane < wp;
-    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
-    const real *xs  = A.x + A.range_off[S];
-    real a0 = 0, a1 = 0;
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const scalar *xs  = A.x + A.range_off[S];
+    scalar a0 = scalar(0), a1 = scalar(0);
     for (int i0 = 0; i0 < len; i0 += 64) {
         const int nr    = (len - i0) < 64 ? (len - i0) : 64;
-        const real xv = lane < nr ? xs[i0 + lane] : 0.0;
-        const real *p = src + (int64_t)i0 * wp;
+        const scalar xv = lane < nr ? xs[i0 + lane] : scalar(0);
+        const scalar *p = src + (int64_t)i0 * wp;
         int j = 0;
         for (; j + 8 <= nr; j += 8) {
-            real2 v[8];
+            scalar2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = stream_load(reinterpret_cast<const real2 *>(p + (int64_t)(j + u) * wp));
+                v[u] = stream_load(reinterpret_cast<const scalar2 *>(p + (int64_t)(j + u) * wp));
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const real xi = readlane_val(xv, j + u);
+                const scalar xi = readlane_val(xv, j + u);
                 a0              = hmx_fma(v[u].x, xi, a0);
                 a1              = hmx_fma(v[u].y, xi, a1);
             }
         }
         for (; j < nr; j++) {
-            const real2 v = *reinterpret_cast<const real2 *>(p + (int64_t)j * wp);
-            const real xi = readlane_val(xv, j);
+            const scalar2 v = *reinterpret_cast<const scalar2 *>(p + (int64_t)j * wp);
+            const scalar xi = readlane_val(xv, j);
             a0              = hmx_fma(v.x, xi, a0);
             a1              = hmx_fma(v.y, xi, a1);
         }
@@ -996,17 +1033,17 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
 // Stage 1b: blocks whose source cluster spans several ranges: a_b[k] = sum_s partial[b][s][k]
 struct CombineArgs {
     const int32_t *dst, *src, *stride, *count;
-    real *Z;
+    scalar *Z;
     int n;
 };
 __global__ void combine_kernel(CombineArgs A) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.n)
         return;
-    const real *p = A.Z + A.src[e];
+    const scalar *p = A.Z + A.src[e];
     const int st = A.stride[e], cnt = A.count[e];
     // four independent partial sums keep four loads in flight; the order is fixed, so results stay reproducible
-    real s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    scalar s0 = scalar(0), s1 = scalar(0), s2 = scalar(0), s3 = scalar(0);
     int k = 0;
     for (; k + 4 <= cnt; k += 4) {
         s0 += p[(int64_t)k * st];
@@ -1023,36 +1060,36 @@ __global__ void combine_kernel(CombineArgs A) {
 // y += U a; final alpha/beta as openmp_internal_add_hmatrix_vector_product :134-136,168):
 // one workgroup per target row range, lane = row, the waves split the columns in 64-column chunks.
 struct ExpandArgs {
-    const real *stream;
+    const scalar *stream;
     const int32_t *order; // launch position -> range (heaviest ranges first)
     const int32_t *range_off, *range_len, *range_cols;
     const int64_t *range_base;
     const int64_t *range_colbase;
     const int32_t *z_idx; // per column: index into Z = [x | a | ...]
-    const real *Z;
-    real *y;            // output, local to the target root
-    real alpha, beta;
+    const scalar *Z;
+    scalar *y;            // output, local to the target root
+    scalar alpha, beta;
     int nranges;
 };
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
-    __shared__ real part[WAVES][WAVE];
+    __shared__ scalar part[WAVES][WAVE];
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
-    const real *E     = A.stream + A.range_base[R];
+    const scalar *E     = A.stream + A.range_base[R];
     const int32_t *zidx = A.z_idx + A.range_colbase[R];
     const bool active   = lane < len;
     const int row       = active ? lane : 0;
-    real acc = 0;
+    scalar acc = scalar(0);
     for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
         const int nc   = (C - c0) < 64 ? (C - c0) : 64;
-        const real z = lane < nc ? A.Z[zidx[c0 + lane]] : 0.0;
-        const real *col = E + (int64_t)c0 * len + row;
+        const scalar z = lane < nc ? A.Z[zidx[c0 + lane]] : scalar(0);
+        const scalar *col = E + (int64_t)c0 * len + row;
         int j = 0;
         for (; j + 8 <= nc; j += 8) {
-            real v[8];
+            scalar v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 v[u] = stream_load(col + (int64_t)(j + u) * len);
@@ -1063,15 +1100,15 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
         for (; j < nc; j++)
             acc = hmx_fma(col[(int64_t)j * len], readlane_val(z, j), acc);
     }
-    part[wv][lane] = active ? acc : 0.0;
+    part[wv][lane] = active ? acc : scalar(0);
     __syncthreads();
     if (wv == 0 && active) {
-        real s = part[0][lane];
+        scalar s = part[0][lane];
 #pragma unroll
         for (int k = 1; k < WAVES; k++)
             s += part[k][lane];
-        real *yo = A.y + A.range_off[R] + lane;
-        *yo        = A.beta == 0.0 ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        scalar *yo = A.y + A.range_off[R] + lane;
+        *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
     }
 }
 
@@ -1086,7 +1123,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
 // ---------------------------------------------------------------------------------------------
 template <int WAVES, int MU>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) real xt[WAVES][WAVE][MU];
+    __shared__ __attribute__((aligned(16))) scalar xt[WAVES][WAVE][MU];
     const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.x * WAVES + wv;
     if (task >= A.ntasks)
@@ -1098,12 +1135,12 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
     const bool active = 2 * lane < wp;
-    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
-    const real *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
-    real a0[MU], a1[MU];
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const scalar *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
+    scalar a0[MU], a1[MU];
 #pragma unroll
     for (int c = 0; c < MU; c++)
-        a0[c] = a1[c] = 0.0;
+        a0[c] = a1[c] = scalar(0);
     for (int i0 = 0; i0 < len; i0 += 64) {
         const int nr = (len - i0) < 64 ? (len - i0) : 64;
         __builtin_amdgcn_wave_barrier();
@@ -1113,28 +1150,28 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
                 xt[wv][lane][c] = xs[(int64_t)(i0 + lane) * mu + c];
         }
         __builtin_amdgcn_wave_barrier();
-        const real *p = src + (int64_t)i0 * wp;
+        const scalar *p = src + (int64_t)i0 * wp;
         int j = 0;
         for (; j + 4 <= nr; j += 4) {
-            real2 v[4];
+            scalar2 v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                v[u] = stream_load(reinterpret_cast<const real2 *>(p + (int64_t)(j + u) * wp));
+                v[u] = stream_load(reinterpret_cast<const scalar2 *>(p + (int64_t)(j + u) * wp));
 #pragma unroll
             for (int u = 0; u < 4; u++) {
 #pragma unroll
                 for (int c = 0; c < MU; c++) {
-                    const real xi = xt[wv][j + u][c];
+                    const scalar xi = xt[wv][j + u][c];
                     a0[c]           = hmx_fma(v[u].x, xi, a0[c]);
                     a1[c]           = hmx_fma(v[u].y, xi, a1[c]);
                 }
             }
         }
         for (; j < nr; j++) {
-            const real2 v = *reinterpret_cast<const real2 *>(p + (int64_t)j * wp);
+            const scalar2 v = *reinterpret_cast<const scalar2 *>(p + (int64_t)j * wp);
 #pragma unroll
             for (int c = 0; c < MU; c++) {
-                const real xi = xt[wv][j][c];
+                const scalar xi = xt[wv][j][c];
                 a0[c]           = hmx_fma(v.x, xi, a0[c]);
                 a1[c]           = hmx_fma(v.y, xi, a1[c]);
             }
@@ -1143,13 +1180,13 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
     if (active) {
         const int64_t cb = A.range_colbase[S] + ch * cw + 2 * lane;
         if (2 * lane < w) {
-            real *dst = A.Z + (int64_t)A.out_idx[cb] * mu + cbase;
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 dst[c] = a0[c];
         }
         if (2 * lane + 1 < w) {
-            real *dst = A.Z + (int64_t)A.out_idx[cb + 1] * mu + cbase;
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb + 1] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 dst[c] = a1[c];
@@ -1162,9 +1199,9 @@ __global__ void combine_mu_kernel(CombineArgs A, int mu) {
     if (t >= (int64_t)A.n * mu)
         return;
     const int e = (int)(t / mu), c = (int)(t - (int64_t)e * mu);
-    const real *p = A.Z + (int64_t)A.src[e] * mu + c;
+    const scalar *p = A.Z + (int64_t)A.src[e] * mu + c;
     const int st = A.stride[e], cnt = A.count[e];
-    real s = 0;
+    scalar s = scalar(0);
     for (int k = 0; k < cnt; k++)
         s += p[(int64_t)k * st * mu];
     A.Z[(int64_t)A.dst[e] * mu + c] = s;
@@ -1172,32 +1209,32 @@ __global__ void combine_mu_kernel(CombineArgs A, int mu) {
 
 template <int WAVES, int MU>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) real zt[WAVES][WAVE][MU]; // coefficient tiles, reused for the final reduction
+    __shared__ __attribute__((aligned(16))) scalar zt[WAVES][WAVE][MU]; // coefficient tiles, reused for the final reduction
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
-    const real *E     = A.stream + A.range_base[R];
+    const scalar *E     = A.stream + A.range_base[R];
     const int32_t *zidx = A.z_idx + A.range_colbase[R];
     const bool active   = lane < len;
     const int row       = active ? lane : 0;
-    real acc[MU];
+    scalar acc[MU];
 #pragma unroll
     for (int c = 0; c < MU; c++)
-        acc[c] = 0.0;
+        acc[c] = scalar(0);
     for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
         const int nc = (C - c0) < 64 ? (C - c0) : 64;
         __builtin_amdgcn_wave_barrier();
         if (lane < nc) {
-            const real *zr = A.Z + (int64_t)zidx[c0 + lane] * mu + cbase;
+            const scalar *zr = A.Z + (int64_t)zidx[c0 + lane] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 zt[wv][lane][c] = zr[c];
         }
         __builtin_amdgcn_wave_barrier();
-        const real *col = E + (int64_t)c0 * len + row;
+        const scalar *col = E + (int64_t)c0 * len + row;
         int j = 0;
         for (; j + 8 <= nc; j += 8) {
-            real v[8];
+            scalar v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 v[u] = stream_load(col + (int64_t)(j + u) * len);
@@ -1208,7 +1245,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
                     acc[c] = hmx_fma(v[u], zt[wv][j + u][c], acc[c]);
         }
         for (; j < nc; j++) {
-            const real v = col[(int64_t)j * len];
+            const scalar v = col[(int64_t)j * len];
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 acc[c] = hmx_fma(v, zt[wv][j][c], acc[c]);
@@ -1217,20 +1254,21 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < MU; c++)
-        zt[wv][lane][c] = active ? acc[c] : 0.0;
+        zt[wv][lane][c] = active ? acc[c] : scalar(0);
     __syncthreads();
     // rows x MU outputs, summed over the waves; consecutive threads write consecutive right-hand sides
     for (int e = threadIdx.x; e < len * MU; e += WAVES * WAVE) {
         const int i = e / MU, c = e - i * MU;
-        real s = zt[0][i][c];
+        scalar s = zt[0][i][c];
 #pragma unroll
         for (int k = 1; k < WAVES; k++)
             s += zt[k][i][c];
-        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
-        *yo        = A.beta == 0.0 ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
     }
 }
 
+#if !HMX_COMPLEX
 // ---------------------------------------------------------------------------------------------
 // 16 right-hand sides on the matrix cores.  With mu = 16 the leaf products are real GEMMs
 // (K7-K9 of SURVEY.md 2.2: [rows x cols] x [cols x 16]); the VALU kernels above then spend their time re-reading the
@@ -1349,6 +1387,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
             }
 }
 
+#endif // !HMX_COMPLEX
+
 // ---------------------------------------------------------------------------------------------
 // Transposed / mirrored passes (trans = 'T', and the symmetric mirror pass
 // add_hmatrix_vector_product.hpp:97-103,154-163).  Same streams, read in the "wrong" orientation:
@@ -1358,31 +1398,31 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
 // Eight wave-wide sums for the price of ~1.25: each butterfly step halves the number of live values while
 // halving the lane group that owns them.  On return lane l with (l & 7) == 0 holds the complete sum of input
 // value number 4*bit5(l) + 2*bit4(l) + bit3(l).
-__device__ __forceinline__ real reduce8(const real (&v)[8], int lane) {
+__device__ __forceinline__ scalar reduce8(const scalar (&v)[8], int lane) {
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
-    real t[4], u[2];
+    scalar t[4], u[2];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        t[k] = (b5 ? v[k + 4] : v[k]) + __shfl_xor(b5 ? v[k] : v[k + 4], 32, WAVE);
+        t[k] = (b5 ? v[k + 4] : v[k]) + hmx_shfl_xor(b5 ? v[k] : v[k + 4], 32);
 #pragma unroll
     for (int k = 0; k < 2; k++)
-        u[k] = (b4 ? t[k + 2] : t[k]) + __shfl_xor(b4 ? t[k] : t[k + 2], 16, WAVE);
-    real r = (b3 ? u[1] : u[0]) + __shfl_xor(b3 ? u[0] : u[1], 8, WAVE);
-    r += __shfl_xor(r, 4, WAVE);
-    r += __shfl_xor(r, 2, WAVE);
-    r += __shfl_xor(r, 1, WAVE);
+        u[k] = (b4 ? t[k + 2] : t[k]) + hmx_shfl_xor(b4 ? t[k] : t[k + 2], 16);
+    scalar r = (b3 ? u[1] : u[0]) + hmx_shfl_xor(b3 ? u[0] : u[1], 8);
+    r += hmx_shfl_xor(r, 4);
+    r += hmx_shfl_xor(r, 2);
+    r += hmx_shfl_xor(r, 1);
     return r;
 }
 __device__ __forceinline__ int reduce8_slot(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
 
 struct ColReduceArgs { // over E-streams: W[dst[c]] += sum_i E[i,c] * in[R.off + i]
-    const real *stream;
+    const scalar *stream;
     const int32_t *order;
     const int32_t *range_off, *range_len, *range_cols;
     const int64_t *range_base, *range_colbase;
     const int32_t *dst; // per column, -1 = skip
-    const real *in;
-    real *W;
+    const scalar *in;
+    scalar *W;
     int nranges;
 };
 template <int WAVES>
@@ -1390,31 +1430,31 @@ __global__ __launch_bounds__(WAVES *WAVE) void colreduce_kernel(ColReduceArgs A)
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
-    const real *E    = A.stream + A.range_base[R] + (lane < len ? lane : 0);
+    const scalar *E    = A.stream + A.range_base[R] + (lane < len ? lane : 0);
     const int32_t *dst = A.dst + A.range_colbase[R];
-    const real xin   = lane < len ? A.in[A.range_off[R] + lane] : 0.0;
+    const scalar xin   = lane < len ? A.in[A.range_off[R] + lane] : scalar(0);
     const int slot     = reduce8_slot(lane);
     for (int c0 = wv * 8; c0 < C; c0 += WAVES * 8) {
-        real v[8];
+        scalar v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++)
-            v[u] = (c0 + u < C) ? stream_load(E + (int64_t)(c0 + u) * len) * xin : 0.0;
-        const real r = reduce8(v, lane);
+            v[u] = (c0 + u < C) ? stream_load(E + (int64_t)(c0 + u) * len) * xin : scalar(0);
+        const scalar r = reduce8(v, lane);
         if ((lane & 7) == 0 && c0 + slot < C) {
             const int d = dst[c0 + slot];
             if (d >= 0)
-                atomicAdd(&A.W[d], r);
+                hmx_atomic_add(&A.W[d], r);
         }
     }
 }
 
 struct RowReduceArgs { // over R-streams: W[S.off + i] += sum_col Rs[i,col] * W[coef[col]]
-    const real *stream;
+    const scalar *stream;
     const int32_t *task_range, *task_chunk;
     const int32_t *range_off, *range_len, *range_cols, *range_cw;
     const int64_t *range_base, *range_colbase;
     const int32_t *coef; // per column index into W, -1 = skip
-    real *W;
+    scalar *W;
     int ntasks;
     int row_shift; // added to the range's local offset to address W (mirror pass: S0 - T0)
 };
@@ -1430,56 +1470,56 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
     const bool active = 2 * lane < wp;
-    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
     const int64_t cb  = A.range_colbase[S] + ch * cw + 2 * lane;
-    real c0 = 0, c1 = 0;
+    scalar c0 = scalar(0), c1 = scalar(0);
     bool any = false;
     if (2 * lane < w) {
         const int d = A.coef[cb];
-        c0          = d >= 0 ? A.W[d] : 0.0;
+        c0          = d >= 0 ? A.W[d] : scalar(0);
         any         = d >= 0;
     }
     if (2 * lane + 1 < w) {
         const int d = A.coef[cb + 1];
-        c1          = d >= 0 ? A.W[d] : 0.0;
+        c1          = d >= 0 ? A.W[d] : scalar(0);
         any         = any || d >= 0;
     }
     if (!__any(any))
         return; // no selected column in this chunk (e.g. mirror pass over an off-diagonal stripe)
     const int slot = reduce8_slot(lane);
-    real *out    = A.W + A.range_off[S] + A.row_shift;
+    scalar *out    = A.W + A.range_off[S] + A.row_shift;
     for (int i0 = 0; i0 < len; i0 += 8) {
-        real v[8];
+        scalar v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            v[u] = 0.0;
+            v[u] = scalar(0);
             if (active && i0 + u < len) {
-                const real2 e = stream_load(reinterpret_cast<const real2 *>(src + (int64_t)(i0 + u) * wp));
-                v[u]            = hmx_fma(e.x, c0, e.y * c1);
+                const scalar2 e = stream_load(reinterpret_cast<const scalar2 *>(src + (int64_t)(i0 + u) * wp));
+                v[u]              = hmx_fma(e.x, c0, e.y * c1);
             }
         }
-        const real r = reduce8(v, lane);
+        const scalar r = reduce8(v, lane);
         if ((lane & 7) == 0 && i0 + slot < len)
-            atomicAdd(&out[i0 + slot], r);
+            hmx_atomic_add(&out[i0 + slot], r);
     }
 }
 
 // small helpers -----------------------------------------------------------------------------------
-__global__ void axpby_kernel(int n, real alpha, const real *w, real beta, real *y) {
+__global__ void axpby_kernel(int n, scalar alpha, const scalar *w, scalar beta, scalar *y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
-        y[i] = beta == 0.0 ? alpha * w[i] : alpha * w[i] + beta * y[i];
+        y[i] = hmx_is_zero(beta) ? alpha * w[i] : alpha * w[i] + beta * y[i];
 }
 // user_to_cluster: out[i] = in[perm[i] - base]; cluster_to_user: out[perm[i] - base] = in[i]
 // (clustering/cluster_node.hpp:150-175)
-__global__ void gather_kernel(int n, const int32_t *perm, int base, const real *in, real *out, int mu) {
+__global__ void gather_kernel(int n, const int32_t *perm, int base, const scalar *in, scalar *out, int mu) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (int64_t)n * mu) {
         const int i = e / mu, c = e - (int64_t)i * mu;
         out[e]      = in[(int64_t)(perm[i] - base) * mu + c];
     }
 }
-__global__ void scatter_kernel(int n, const int32_t *perm, int base, const real *in, real *out, int mu) {
+__global__ void scatter_kernel(int n, const int32_t *perm, int base, const scalar *in, scalar *out, int mu) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (int64_t)n * mu) {
         const int i = e / mu, c = e - (int64_t)i * mu;
@@ -1487,13 +1527,19 @@ __global__ void scatter_kernel(int n, const int32_t *perm, int base, const real 
     }
 }
 // strided column extract / insert for row-major multi-RHS (X[n][mu])
-__global__ void col_extract_kernel(int n, int mu, int c, const real *X, real *x) {
+__global__ void col_extract_kernel(int n, int mu, int c, const scalar *X, scalar *x) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
         x[i] = X[(int64_t)i * mu + c];
 }
-__global__ void col_insert_kernel(int n, int mu, int c, const real *y, real *Y) {
+__global__ void col_insert_kernel(int n, int mu, int c, const scalar *y, scalar *Y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
         Y[(int64_t)i * mu + c] = y[i];
+}
+// conjugation in place (trans = 'C' is conj o 'T' o conj)
+__global__ void conj_kernel(int64_t n, const scalar *in, scalar *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = hmx_conj(in[i]);
 }

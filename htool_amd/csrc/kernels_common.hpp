@@ -25,6 +25,10 @@ struct KernelSpec { // device-evaluable generator
     int kind;
     int dim;
     double p0, p1;
+    // complex instantiations: (cre + i cim sgn) / (p0 + p1 |x-y|), sgn = 1 or, herm != 0, sign(x_t[0] - x_s[0])
+    // (the complex symmetric / Hermitian forms of testing/generator_test.hpp:163-205)
+    double cre, cim;
+    int herm;
 };
 
 // K(x,y) = 1/(p0 + p1*|x-y|); squared differences accumulated left to right from 0, one sqrt, one
@@ -42,15 +46,94 @@ __device__ __forceinline__ double eval_kernel(const KernelSpec &ks, double tx, d
     return 1.0 / (ks.p0 + ks.p1 * sqrt(s));
 }
 
-// ---- type-generic helpers shared by the f64 and f32 instantiations of kernels_body.hpp -------------------------
+// the denominator of the same family, for the complex instantiations
+__device__ __forceinline__ double eval_kernel_den(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
+    double s        = 0.0;
+    const double d0 = tx - sx;
+    s               = s + d0 * d0;
+    const double d1 = ty - sy;
+    s               = s + d1 * d1;
+    if (ks.dim == 3) {
+        const double d2 = tz - sz;
+        s               = s + d2 * d2;
+    }
+    return ks.p0 + ks.p1 * sqrt(s);
+}
+
+// ---- complex coefficients: htool's HMatrix<std::complex<T>> ----------------------------------------------------------------
+// Layout-compatible with std::complex<T> / C99 T _Complex (interleaved re, im).  operator* and operator/ are the plain
+// unfused formulas (the compression kernels restate the reference's scalar sequence); the matvec kernels use hmx_fma.
+template <typename T>
+struct alignas(2 * sizeof(T)) cplx {
+    T re, im;
+    cplx() = default;
+    __host__ __device__ constexpr cplx(T r, T i = T(0)) : re(r), im(i) {}
+};
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator+(cplx<T> a, cplx<T> b) { return cplx<T>(a.re + b.re, a.im + b.im); }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator-(cplx<T> a, cplx<T> b) { return cplx<T>(a.re - b.re, a.im - b.im); }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator-(cplx<T> a) { return cplx<T>(-a.re, -a.im); }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator*(cplx<T> a, cplx<T> b) { return cplx<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator*(cplx<T> a, T b) { return cplx<T>(a.re * b, a.im * b); }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator*(T a, cplx<T> b) { return cplx<T>(a * b.re, a * b.im); }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator/(cplx<T> a, T b) { return cplx<T>(a.re / b, a.im / b); }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> operator/(cplx<T> x, cplx<T> y) { // Smith's algorithm, as libgcc's __divdc3 / __divsc3
+    const T a = x.re, b = x.im, c = y.re, d = y.im;
+    if ((c < 0 ? -c : c) < (d < 0 ? -d : d)) {
+        const T ratio = c / d, denom = c * ratio + d;
+        return cplx<T>((a * ratio + b) / denom, (b * ratio - a) / denom);
+    }
+    const T ratio = d / c, denom = d * ratio + c;
+    return cplx<T>((b * ratio + a) / denom, (b - a * ratio) / denom);
+}
+template <typename T> __host__ __device__ __forceinline__ cplx<T> &operator+=(cplx<T> &a, cplx<T> b) { a.re += b.re; a.im += b.im; return a; }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> &operator-=(cplx<T> &a, cplx<T> b) { a.re -= b.re; a.im -= b.im; return a; }
+template <typename T> __host__ __device__ __forceinline__ bool operator==(cplx<T> a, cplx<T> b) { return a.re == b.re && a.im == b.im; }
+template <typename T> __host__ __device__ __forceinline__ bool operator!=(cplx<T> a, cplx<T> b) { return !(a == b); }
+template <typename T> struct cplx2 { cplx<T> x, y; }; // two adjacent coefficients of an R-stream row
+
+// ---- type-generic helpers shared by the instantiations of kernels_body.hpp ----------------------------------------
 __device__ __forceinline__ double hmx_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float hmx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ cplx<double> hmx_fma(cplx<double> a, cplx<double> b, cplx<double> c) {
+    return cplx<double>(__builtin_fma(a.re, b.re, __builtin_fma(-a.im, b.im, c.re)), __builtin_fma(a.re, b.im, __builtin_fma(a.im, b.re, c.im)));
+}
+__device__ __forceinline__ cplx<float> hmx_fma(cplx<float> a, cplx<float> b, cplx<float> c) {
+    return cplx<float>(__builtin_fmaf(a.re, b.re, __builtin_fmaf(-a.im, b.im, c.re)), __builtin_fmaf(a.re, b.im, __builtin_fmaf(a.im, b.re, c.im)));
+}
+__host__ __device__ __forceinline__ double hmx_conj(double v) { return v; }
+__host__ __device__ __forceinline__ float hmx_conj(float v) { return v; }
+template <typename T> __host__ __device__ __forceinline__ cplx<T> hmx_conj(cplx<T> v) { return cplx<T>(v.re, -v.im); }
+__host__ __device__ __forceinline__ double hmx_re(double v) { return v; }
+__host__ __device__ __forceinline__ float hmx_re(float v) { return v; }
+template <typename T> __host__ __device__ __forceinline__ T hmx_re(cplx<T> v) { return v.re; }
+__device__ __forceinline__ double hmx_abs(double v) { return fabs(v); }
+__device__ __forceinline__ float hmx_abs(float v) { return fabsf(v); }
+__device__ __forceinline__ double hmx_abs(cplx<double> v) { return hypot(v.re, v.im); } // std::abs(std::complex) is hypot
+__device__ __forceinline__ float hmx_abs(cplx<float> v) { return hypotf(v.re, v.im); }
+// |v|^2 the way matrix/utils/math.hpp:7-16 accumulates it: pow(abs(v), 2)
+__device__ __forceinline__ double hmx_abs2(double v) { return v * v; }
+__device__ __forceinline__ float hmx_abs2(float v) { return v * v; }
+template <typename T> __device__ __forceinline__ T hmx_abs2(cplx<T> v) { const T a = hmx_abs(v); return a * a; }
+__host__ __device__ __forceinline__ bool hmx_is_zero(double v) { return v == 0.0; }
+__host__ __device__ __forceinline__ bool hmx_is_zero(float v) { return v == 0.0f; }
+template <typename T> __host__ __device__ __forceinline__ bool hmx_is_zero(cplx<T> v) { return v.re == T(0) && v.im == T(0); }
+__device__ __forceinline__ double hmx_shfl_xor(double v, int o) { return __shfl_xor(v, o, WAVE); }
+__device__ __forceinline__ float hmx_shfl_xor(float v, int o) { return __shfl_xor(v, o, WAVE); }
+__device__ __forceinline__ int hmx_shfl_xor(int v, int o) { return __shfl_xor(v, o, WAVE); }
+template <typename T> __device__ __forceinline__ cplx<T> hmx_shfl_xor(cplx<T> v, int o) { return cplx<T>(__shfl_xor(v.re, o, WAVE), __shfl_xor(v.im, o, WAVE)); }
+__device__ __forceinline__ void hmx_atomic_add(double *p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void hmx_atomic_add(float *p, float v) { atomicAdd(p, v); }
+template <typename T> __device__ __forceinline__ void hmx_atomic_add(cplx<T> *p, cplx<T> v) {
+    atomicAdd(&p->re, v.re);
+    atomicAdd(&p->im, v.im);
+}
 __device__ __forceinline__ double readlane_val(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float readlane_val(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+template <typename T> __device__ __forceinline__ cplx<T> readlane_val(cplx<T> v, int lane) { return cplx<T>(readlane_val(v.re, lane), readlane_val(v.im, lane)); }
 
 // Every coefficient is read exactly once per product, so the stream loads are marked non-temporal: they do
 // not displace x / Z / index lines from L2 and the Infinity Cache.  Measured at N=1e6 (fp64): expand 1.88 -> 1.74 ms,
@@ -89,6 +172,41 @@ __device__ __forceinline__ float2 stream_load(const float2 *p) {
 #else
     return *p;
 #endif
+}
+
+typedef float hmx_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cplx<double> stream_load(const cplx<double> *p) { // one 16-byte load
+#if HMX_NT
+    const hmx_d2 v = __builtin_nontemporal_load(reinterpret_cast<const hmx_d2 *>(p));
+    return cplx<double>(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ cplx<float> stream_load(const cplx<float> *p) {
+#if HMX_NT
+    const hmx_f2 v = __builtin_nontemporal_load(reinterpret_cast<const hmx_f2 *>(p));
+    return cplx<float>(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ cplx2<double> stream_load(const cplx2<double> *p) { // two 16-byte loads
+    cplx2<double> r;
+    r.x = stream_load(reinterpret_cast<const cplx<double> *>(p));
+    r.y = stream_load(reinterpret_cast<const cplx<double> *>(p) + 1);
+    return r;
+}
+__device__ __forceinline__ cplx2<float> stream_load(const cplx2<float> *p) { // one 16-byte load
+    cplx2<float> r;
+#if HMX_NT
+    const hmx_f4v v = __builtin_nontemporal_load(reinterpret_cast<const hmx_f4v *>(p));
+    r.x = cplx<float>(v.x, v.y);
+    r.y = cplx<float>(v.z, v.w);
+#else
+    r = *p;
+#endif
+    return r;
 }
 
 // ---- MFMA 16x16x4 (fp64 and exact-fp32 forms), used by the 16-right-hand-side kernels ------------------------------

@@ -41,6 +41,15 @@ typedef enum { HMX_PARTIAL_ACA = 0, HMX_SYMPARTIAL_ACA = 1, HMX_FULL_ACA = 2, HM
  * for the BEM-style kernels the reference ships: examples/use_hmatrix.cpp:33, testing/generator_test.hpp:159,185):
  *   HMX_KERNEL_INV_DIST : K(x,y) = 1 / (params[0] + params[1] * |x - y|)                                  */
 typedef enum { HMX_KERNEL_INV_DIST = 0 } hmx_kernel;
+/* With complex coefficients (hmx_hmatrix_create_z / _c) the same family reads
+ *   K(x,y) = (params[2] + i * params[3] * sgn) / (params[0] + params[1] * |x - y|),
+ * sgn = 1, or, when params[4] != 0, sign(x_target[0] - x_source[0]): the complex symmetric and Hermitian test generators
+ * of testing/generator_test.hpp:163-205 (GeneratorTestComplex, ...ComplexSymmetric, ...ComplexHermitian). */
+
+/* coefficient type of an hmx_hmatrix: htool's HMatrix<double>, <float>, <std::complex<double>>, <std::complex<float>>
+ * (coordinates are fp64 in all four).  Complex values cross this ABI as interleaved (re, im) pairs, the layout of
+ * std::complex<T> and C99 T _Complex; alpha / beta are pointers to one such pair. */
+typedef enum { HMX_PREC_F64 = 0, HMX_PREC_F32 = 1, HMX_PREC_Z64 = 2, HMX_PREC_C32 = 3 } hmx_precision;
 
 typedef struct hmx_cluster_tree hmx_cluster_tree;
 typedef struct hmx_block_tree hmx_block_tree;
@@ -121,7 +130,10 @@ int hmx_block_tree_save_leaves_with_rank(const hmx_block_tree *, const int32_t *
 /* ---- H-matrix on the device ---------------------------------------------------------------------------- */
 int hmx_hmatrix_create(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out);   /* HMatrix<double,double> */
 int hmx_hmatrix_create_s(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out); /* HMatrix<float,double>: fp32 coefficients, fp64 coordinates */
+int hmx_hmatrix_create_z(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out); /* HMatrix<std::complex<double>,double> */
+int hmx_hmatrix_create_c(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out); /* HMatrix<std::complex<float>,double> */
 int hmx_hmatrix_is_f32(const hmx_hmatrix *);
+int hmx_hmatrix_precision(const hmx_hmatrix *); /* hmx_precision, -1 for NULL */
 void hmx_hmatrix_destroy(hmx_hmatrix *);
 
 /* generator = built-in kernel on (target coords, source coords), both in USER numbering (AoS, dim <= 3) */
@@ -161,6 +173,27 @@ int hmx_hmatrix_finalize(hmx_hmatrix *);
 int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *, int32_t *rank /* num_leaves, -1 dense */);
 int hmx_hmatrix_get_block(const hmx_hmatrix *, int64_t leaf, double *U_or_D, double *V);
 int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);
+/* Complex coefficients: the entry points above that carry coefficients, for HMatrix<std::complex<double>> (_z) and
+ * HMatrix<std::complex<float>> (_c).  Symmetry 'S' = complex symmetric (mirror pass with trans 'T'), 'H' = Hermitian (mirror pass
+ * with trans 'C', hemv on the diagonal leaves): hmatrix/linalg/add_hmatrix_vector_product.hpp:36-54,70.  trans in {'N','T','C'};
+ * as in the reference ('T' with 'H' leaves) and ('C' with 'S' leaves) are refused (:59-62).  Compressors: partialACA,
+ * sympartialACA, fullACA (conjugated dots as htool's Blas<T>::dot, wrappers/wrapper_blas.hpp:152-157); the LAPACK-backed ones
+ * (SVD, recompression) return HMX_ERR_UNSUPPORTED for complex coefficients in this version. */
+int hmx_hmatrix_set_callback_z(hmx_hmatrix *, hmx_generator_fn fn, void *user);   /* out: M*N interleaved complex doubles */
+int hmx_hmatrix_set_callback_c(hmx_hmatrix *, hmx_generator_fn_s fn, void *user); /* out: M*N interleaved complex floats */
+int hmx_hmatrix_set_block_lowrank_z(hmx_hmatrix *, int64_t leaf, int rank, const double *U, const double *V);
+int hmx_hmatrix_set_block_dense_z(hmx_hmatrix *, int64_t leaf, const double *D);
+int hmx_hmatrix_get_block_z(const hmx_hmatrix *, int64_t leaf, double *U_or_D, double *V);
+int hmx_hmatrix_matvec_z(hmx_hmatrix *, char trans, const double *alpha, const double *in, const double *beta, double *out, int mem, void *stream);
+int hmx_hmatrix_matvec_user_z(hmx_hmatrix *, char trans, const double *alpha, const double *in, const double *beta, double *out, int mem, void *stream);
+int hmx_hmatrix_matmat_row_major_z(hmx_hmatrix *, char trans, const double *alpha, const double *in, const double *beta, double *out, int mu, int mem, void *stream);
+int hmx_hmatrix_set_block_lowrank_c(hmx_hmatrix *, int64_t leaf, int rank, const float *U, const float *V);
+int hmx_hmatrix_set_block_dense_c(hmx_hmatrix *, int64_t leaf, const float *D);
+int hmx_hmatrix_get_block_c(const hmx_hmatrix *, int64_t leaf, float *U_or_D, float *V);
+int hmx_hmatrix_matvec_c(hmx_hmatrix *, char trans, const float *alpha, const float *in, const float *beta, float *out, int mem, void *stream);
+int hmx_hmatrix_matvec_user_c(hmx_hmatrix *, char trans, const float *alpha, const float *in, const float *beta, float *out, int mem, void *stream);
+int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *, char trans, const float *alpha, const float *in, const float *beta, float *out, int mu, int mem, void *stream);
+
 /* Binary dump of the compressed operator (no counterpart in the reference): header, leaf table with
  * ranks, then per leaf U (M x r) and V (r x N) or the dense M x N block, all column-major as in htool's
  * LowRankMatrix / Matrix.  Load needs the block tree the file was written for and picks fp32/fp64 from the file. */

@@ -1,0 +1,207 @@
+"""Complex coefficients on the device: htool's HMatrix<std::complex<double>> / <std::complex<float>> with
+complex symmetric ('S') and Hermitian ('H') storage and trans = 'N', 'T', 'C', against the fixtures the reference itself wrote
+(tests/golden/*z64*, *c32*) and against the CPU oracle on other sizes.  Through the C ABI (hmx_hmatrix_*_z / *_c).
+
+Bars: structure identical; ranks identical for complex double (a few +-1..2 for complex float, whose ACA stopping test sits
+on fp32 rounding); dense entries bit-exact; U V to 1e-9; products to 1e-10 against the reference's own results.
+"""
+import numpy as np
+import pytest
+
+import htool_amd as hm
+from helpers import Z_CASES, load, params, rel_err
+from test_host_structure import build_trees
+
+pytestmark = pytest.mark.gpu
+
+
+def build_zengine(p, compress=True, generator=True, dtype=None):
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    tb.set_low_rank_generator(p["compressor"])
+    gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], p["sym"] == "H") if generator else None
+    dt = dtype or (np.complex64 if p["prec"] == "c32" else np.complex128)
+    return T, S, tb.build(gen, T, S, p["rank"], p["rank"], compress=compress, dtype=dt)
+
+
+def zinputs(H, g):
+    from oracle.oracle import hashed_zvector
+    nr, nc = H.nb_rows(), H.nb_cols()
+    f = lambda n, s: hashed_zvector(n, s).astype(H.dtype)
+    alpha, beta = complex(g["alphabeta"][0], g["alphabeta"][2]), complex(g["alphabeta"][1], g["alphabeta"][3])
+    return f(nc, 1), f(nr, 2), f(nr, 3), f(nc, 4), alpha, beta
+
+
+@pytest.mark.parametrize("name", Z_CASES)
+def test_complex_compression_matches_reference(name):
+    p, g = params(name), load(name)
+    T, S, H = build_zengine(p)
+    lt = H.leaf_table()
+    assert np.array_equal(lt[:, :4], g["leaves"][:, :4]) and np.array_equal(lt[:, 5], g["leaves"][:, 5])
+    assert np.array_equal(lt[:, 4] < 0, g["leaves"][:, 4] < 0)  # the same blocks fall back to dense
+    if p["prec"] == "c32":
+        assert np.abs(lt[:, 4] - g["leaves"][:, 4]).max() <= 2 and (lt[:, 4] != g["leaves"][:, 4]).mean() < 0.05
+    else:
+        assert np.array_equal(lt[:, 4], g["leaves"][:, 4])
+    assert H.stats()["n_false_positive"] == g["rootinfo"][4]
+    assert (H.get_symmetry_for_leaves(), H.get_UPLO_for_leaves()) == (chr(g["rootinfo"][5]), chr(g["rootinfo"][6]))
+    ptol = 2e-5 if p["prec"] == "c32" else 1e-9
+    for k in g:
+        if k.startswith("D_"):
+            assert np.array_equal(H.get_block(int(k[2:])), g[k].T.astype(H.dtype))  # generator entries bit-exact
+        if k.startswith("U_"):
+            b = int(k[2:])
+            U, V = H.get_block(b)
+            if U.shape[1] == g[k].shape[0]:
+                assert rel_err(U.astype(np.complex128) @ V.astype(np.complex128), g[k].T @ g["V_%d" % b].T) < ptol
+
+
+@pytest.mark.parametrize("name", Z_CASES)
+def test_complex_products_match_reference(name):
+    p, g = params(name), load(name)
+    T, S, H = build_zengine(p)
+    x, xT, y0, y0T, alpha, beta = zinputs(H, g)
+    tol = 1e-5 if p["prec"] == "c32" else 1e-10
+    y = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+    assert rel_err(y, g["yN"]) < tol
+    for trans, key in (("T", "yT"), ("C", "yC")):
+        if key in g:
+            y = y0T.copy()
+            hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y)
+            assert rel_err(y, g[key]) < tol
+        else:  # add_hmatrix_vector_product.hpp:59-62: 'T' with 'H' leaves, 'C' with 'S' leaves
+            with pytest.raises(hm.HmxError, match="not supported"):
+                hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y0T.copy())
+    if "yN_user" in g:
+        y = y0.copy()
+        hm.add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+        assert rel_err(y, g["yN_user"]) < tol
+    from oracle.oracle import hashed_zvector
+    nr, nc = H.nb_rows(), H.nb_cols()
+    X = hashed_zvector(nc * 2, 5).reshape(nc, 2).astype(H.dtype)
+    Y = hashed_zvector(nr * 2, 6).reshape(nr, 2).astype(H.dtype)
+    hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y, 2)
+    assert rel_err(Y, g["YNrm"]) < tol
+
+
+@pytest.mark.parametrize("sym,uplo,trans_list", [("N", "N", "NTC"), ("S", "L", "NT"), ("H", "U", "NC"), ("H", "L", "NC")])
+@pytest.mark.parametrize("mu", [1, 5, 16])
+def test_complex_against_oracle_other_size(sym, uplo, trans_list, mu):
+    """A size and shape no fixture holds (N = 5000 ellipse, leaf 64), complex double: engine vs CPU oracle, every supported
+    trans, single and multiple right-hand sides (fused row-major kernels)."""
+    from oracle import oracle as O
+    n, eps = 5000, 1e-5
+    x3 = hm.create_geometry("ellipse", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(64)
+    T = b.create_cluster_tree(n, 3, x3, 2, 2)
+    tb = hm.HMatrixTreeBuilder(eps, 10.0, sym, uplo)
+    tb.set_low_rank_generator("sympartialACA" if sym != "N" else "partialACA")
+    H = tb.build(hm.InvDistGenerator(3, x3, x3, 1e-5, 1.0, 0.7, -0.4, sym == "H"), T, T, dtype=np.complex128)
+    To = O.ClusterTree(x3, 64, 2, 2)
+    Ho = O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=0.7, cim=-0.4, eps=eps, eta=10.0, sym=sym, uplo=uplo,
+                    compressor="sympartialACA" if sym != "N" else "partialACA", parallel=True)
+    assert np.array_equal(H.leaf_table(), Ho.leaves)
+    rng = np.random.default_rng(1)
+    alpha, beta = 1.5 - 0.5j, -0.3 + 0.8j
+    for trans in trans_list:
+        if mu == 1:
+            xin = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            y0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            y = y0.copy()
+            hm.internal_add_hmatrix_vector_product(trans, alpha, H, xin, beta, y)
+            assert rel_err(y, Ho.matvec(xin, trans, alpha, beta, y0)) < 1e-11
+        else:
+            X = rng.standard_normal((n, mu)) + 1j * rng.standard_normal((n, mu))
+            Y0 = rng.standard_normal((n, mu)) + 1j * rng.standard_normal((n, mu))
+            Y = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, mu)
+            assert rel_err(Y, Ho.matmat_row_major(X, trans, alpha, beta, Y0)) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["ball_n2000_z64_hermU", "ellipse_n3000_z64_symL", "ball_n2000_z64_p2_rank1"])
+def test_complex_upload_download_roundtrip(name, tmp_path):
+    """Blocks compressed by the CPU oracle, uploaded through hmx_hmatrix_set_block_*_z, multiplied on the device: equal to
+    the CPU leaf loop on the same blocks; get_block returns them bit for bit; save/load keeps the operator."""
+    from oracle.oracle import hashed_zvector
+    from test_oracle_vs_golden import build_zoracle
+    p, To, So, Ho = build_zoracle(name)
+    T, S, H = build_zengine(p, compress=False, generator=False)
+    assert np.array_equal(H.leaf_table()[:, :4], Ho.leaves[:, :4])
+    for b in range(len(Ho.leaves)):
+        blk = Ho.block(b)
+        if Ho.leaves[b, 4] >= 0:
+            H.set_block_lowrank(b, blk[0], blk[1])
+        else:
+            H.set_block_dense(b, blk)
+    H.finalize()
+    nr, nc = H.nb_rows(), H.nb_cols()
+    alpha, beta = 3.0 + 0.5j, 2.0 - 0.25j
+    for trans in ("N",) + (("T",) if p["sym"] != "H" else ()) + (("C",) if p["sym"] != "S" else ()):
+        nin, nout = (nc, nr) if trans == "N" else (nr, nc)
+        xin, yin = hashed_zvector(nin, 7), hashed_zvector(nout, 8)
+        y = yin.copy()
+        hm.internal_add_hmatrix_vector_product(trans, alpha, H, xin, beta, y)
+        assert rel_err(y, Ho.matvec(xin, trans, alpha, beta, yin)) < 1e-12
+    for b in (0, len(Ho.leaves) // 2, len(Ho.leaves) - 1):
+        ref, got = Ho.block(b), H.get_block(b)
+        if Ho.leaves[b, 4] >= 0:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        else:
+            assert np.array_equal(got, ref)
+    H.save(tmp_path / "z.hmx")
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
+    G = tb.load(tmp_path / "z.hmx", T, S, p["rank"], p["rank"])
+    assert G.dtype == np.complex128 and np.array_equal(G.ranks, H.ranks)
+    xin = hashed_zvector(nc, 9)
+    y1, y2 = np.zeros(nr, dtype=np.complex128), np.zeros(nr, dtype=np.complex128)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y1)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, G, xin, 0.0, y2)
+    assert rel_err(y2, y1) < 1e-14
+
+
+class _HostComplex(hm.VirtualGenerator):
+    def __init__(self, xt, xs, delta, scale, cre, cim, herm):
+        self.xt, self.xs, self.p = xt, xs, (delta, scale, cre, cim, herm)
+
+    def copy_submatrix(self, M, N, rows, cols):
+        delta, scale, cre, cim, herm = self.p
+        d = self.xt[rows][:, None, :] - self.xs[cols][None, :, :]
+        s = np.zeros((M, N))
+        for q in range(d.shape[2]):  # the generator's own summation order
+            s = s + d[:, :, q] * d[:, :, q]
+        den = delta + scale * np.sqrt(s)
+        sgn = np.sign(d[:, :, 0]) if herm else 1.0
+        return cre / den + 1j * ((cim * sgn) / den)
+
+
+@pytest.mark.parametrize("name", ["ball_n2000_z64_hermU", "ball_n2000_z64_partial", "ball_n1200_z64_fullACA"])
+def test_complex_host_callback_generator(name):
+    """hmx_hmatrix_set_callback_z: the user's complex generator on the host, lock-step ACA on the device."""
+    p, g = params(name), load(name)
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    tb.set_low_rank_generator(p["compressor"])
+    A = _HostComplex(T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], p["sym"] == "H")
+    H = tb.build(A, T, S, p["rank"], p["rank"], dtype=np.complex128)
+    assert np.array_equal(H.leaf_table(), g["leaves"])
+    x, xT, y0, y0T, alpha, beta = zinputs(H, g)
+    y = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+    assert rel_err(y, g["yN"]) < 1e-10
+
+
+def test_complex_unsupported_compressors():
+    p = params("ball_n2000_z64_partial")
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], "N", "N")
+    tb.set_low_rank_generator("SVD")
+    with pytest.raises(hm.HmxError, match="SVD compressor is not available for complex"):
+        tb.build(hm.InvDistGenerator(3, T.coordinates, S.coordinates, 1e-5, 1.0, 1.0, 1.0), T, S, dtype=np.complex128)
+    tb.set_low_rank_generator("partialACA")
+    H = tb.build(hm.InvDistGenerator(3, T.coordinates, S.coordinates, 1e-5, 1.0, 1.0, 1.0), T, S, dtype=np.complex128)
+    with pytest.raises(hm.HmxError, match="not available for complex"):
+        H.recompress()
+    with pytest.raises(hm.HmxError, match="complex128"):
+        hm.internal_add_hmatrix_vector_product("N", 1.0, H, np.zeros(p["n"]), 0.0, np.zeros(p["n"]))
