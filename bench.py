@@ -41,9 +41,9 @@ def parse():
     ap.add_argument("--eta", type=float, default=10.0)
     ap.add_argument("--leaf", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sym", default="N", help="symmetry of the builder: N, or S (lower storage, sympartialACA)")
+    ap.add_argument("--sym", default="N", help="symmetry of the builder: N, S (lower storage, sympartialACA), or H (Hermitian, complex dtypes)")
     ap.add_argument("--trans", default="N")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="coefficient precision (f32 = htool's HMatrix<float,double>)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "z64", "c32"], help="coefficient type (f32 = htool's HMatrix<float,double>; z64 / c32 = complex double / float, kernel (1+i)/(1e-5+r))")
     ap.add_argument("--force-dist", action="store_true", help="run the row-partition + collective code path even with one rank (testing)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single process: build and time only the block rows of --emulate-rank out of this many partitions (per-rank cost of a multi-GPU run, no collective)")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -172,18 +172,19 @@ def main():
     emu = args.emulate_world
     T = ctb.create_cluster_tree(n, 3, x, 2, emu if emu else (world if use_dist else 2))
     t_tree = time.time() - t0
-    tb = hm.HMatrixTreeBuilder(args.eps, args.eta, args.sym, "L" if args.sym == "S" else "N")
+    tb = hm.HMatrixTreeBuilder(args.eps, args.eta, args.sym, "L" if args.sym != "N" else "N")
     tb.set_low_rank_generator("partialACA" if args.sym == "N" else "sympartialACA")
     d = minimal_depth(n)
     tb.set_minimal_target_depth(d)
     tb.set_minimal_source_depth(d)
-    gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0)
+    cplx = args.dtype in ("z64", "c32")
+    gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 1.0 if cplx else 0.0, args.sym == "H")
     t0 = time.time()
     part = use_dist
     brank = args.emulate_rank if emu else (rank if part else -1)
-    np_dt = np.float32 if args.dtype == "f32" else np.float64
-    t_dt = torch.float32 if args.dtype == "f32" else torch.float64
-    esz = 4.0 if args.dtype == "f32" else 8.0
+    np_dt = {"f64": np.float64, "f32": np.float32, "z64": np.complex128, "c32": np.complex64}[args.dtype]
+    t_dt = {"f64": torch.float64, "f32": torch.float32, "z64": torch.complex128, "c32": torch.complex64}[args.dtype]
+    esz = float(np.dtype(np_dt).itemsize)
     H = tb.build(gen, T, T, brank, brank, device=local_rank, dtype=np_dt)
     torch.cuda.synchronize()
     t_build = time.time() - t0
@@ -297,7 +298,7 @@ def main():
     achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")  # measured separately with rocprofv3 --pmc
-    if os.path.exists(tf) and world == 1 and n == 1000000 and args.geom == "ellipse" and args.sym == "N" and args.trans == "N" and mu == 1 and not emu and not use_dist:
+    if os.path.exists(tf) and world == 1 and n == 1000000 and args.geom == "ellipse" and args.sym == "N" and args.trans == "N" and mu == 1 and not emu and not use_dist and args.dtype == "f64":
         traffic = json.load(open(tf)).get("expand_kernel_hbm_bytes_per_launch")
     roofline = dict(bound="hbm", kernel="expand_kernel", achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
                     traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
@@ -312,7 +313,7 @@ def main():
 
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype=args.dtype, data="synthetic",
-               config=dict(mu=mu, sym=args.sym, trans=args.trans, workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, "fp32" if args.dtype == "f32" else "fp64", args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
+               config=dict(mu=mu, sym=args.sym, trans=args.trans, workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, {"f64": "fp64", "f32": "fp32", "z64": "complex fp64", "c32": "complex fp32"}[args.dtype], args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
                            parallelism=("row-partition x%d + all-gather%s" % (world, ", step replayed from a HIP graph" if graphed else "")) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),

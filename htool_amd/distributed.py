@@ -23,6 +23,12 @@ import torch
 import torch.distributed as dist
 
 
+def _rv(t):
+    """Complex tensors go through the collectives as their (re, im) float view (same storage): RCCL / gloo reduce and
+    gather real element types."""
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
 class PartitionFromCluster:
     """Partition k = cluster on partition k of the cluster tree; "partition numbering" is the tree's
     cluster numbering (global_to_partition_numbering = global_to_root_cluster, cluster_node.hpp:100-119)."""
@@ -143,7 +149,7 @@ class DistributedOperator:
         m = max(sizes)
         if min(sizes) == m and out.is_contiguous() and partition.get_offset_of_partition(0) == 0:
             # equal partitions (e.g. N = 1e6 over 8 GPUs): gather straight into the output, no staging copies
-            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+            dist.all_gather_into_tensor(_rv(out), _rv(local.contiguous()), group=self.group)
             return
         key = (m, p, local.device, local.dtype, tuple(local.shape[1:]))
         if key not in self._pad:
@@ -151,7 +157,7 @@ class DistributedOperator:
                               torch.empty((p * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device))
         send, recv = self._pad[key]
         send[:local.shape[0]].copy_(local)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        dist.all_gather_into_tensor(_rv(recv), _rv(send), group=self.group)
         for k in range(p):
             out[partition.get_offset_of_partition(k):partition.get_offset_of_partition(k) + sizes[k]].copy_(recv[k * m:k * m + sizes[k]])
 
@@ -185,7 +191,7 @@ def internal_add_distributed_operator_vector_product_global_to_global(trans, alp
             op.add_vector_product(trans, alpha, x_loc, beta if apply_beta else 1.0, y[off_out:off_out + n_out])
             apply_beta = False
         if A.size() > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=A.group)
+            dist.all_reduce(_rv(y), op=dist.ReduceOp.SUM, group=A.group)
         if beta != 0:
             y.add_(y_old, alpha=beta)
     return y
@@ -232,7 +238,7 @@ def internal_add_distributed_operator_vector_product_local_to_local(trans, alpha
             if p > 1:
                 # MPI_Alltoallv + p axpys == a reduce-scatter; done as all_reduce + slice to keep uneven
                 # partitions simple (N doubles over xGMI; the local product dominates)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=A.group)
+                dist.all_reduce(_rv(buf), op=dist.ReduceOp.SUM, group=A.group)
             off, n = out_part.get_offset_of_partition(rank), out_part.get_size_of_partition(rank)
             y_loc.add_(buf[off:off + n])
     return y_loc
@@ -242,13 +248,13 @@ class DefaultApproximationBuilder:
     """Builds this rank's block rows on its GPU and wires them into a DistributedOperator
     (distributed_operator/utility.hpp:38-61).  Holds `hmatrix`, `distributed_operator`."""
 
-    def __init__(self, generator, target_cluster, source_cluster, hmatrix_tree_builder, group=None, device=None):
+    def __init__(self, generator, target_cluster, source_cluster, hmatrix_tree_builder, group=None, device=None, dtype=np.float64):
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         if device is None:
             device = torch.cuda.current_device()
         self.target_partition = PartitionFromCluster(target_cluster)
         self.source_partition = PartitionFromCluster(source_cluster)
-        self.hmatrix = hmatrix_tree_builder.build(generator, target_cluster, source_cluster, rank, rank, device=device)
+        self.hmatrix = hmatrix_tree_builder.build(generator, target_cluster, source_cluster, rank, rank, device=device, dtype=dtype)
         self.local_hmatrix = RestrictedGlobalToLocalHMatrix(self.hmatrix)
         self.distributed_operator = DistributedOperator(self.target_partition, self.source_partition, group)
         self.distributed_operator.add_global_to_local_operator(self.local_hmatrix)
@@ -277,7 +283,7 @@ def internal_add_distributed_operator_matrix_product_row_major_global_to_global(
         for op in A.global_to_local_operators:
             op.add_matrix_product_row_major(trans, alpha, X_loc, 1.0, Y, mu)
         if A.size() > 1:
-            dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=A.group)
+            dist.all_reduce(_rv(Y), op=dist.ReduceOp.SUM, group=A.group)
         if beta != 0:
             Y.add_(Y_old, alpha=beta)
     return Y
@@ -294,7 +300,7 @@ class DefaultLocalApproximationBuilder:
             device = torch.cuda.current_device()
         self.target_partition = PartitionFromCluster(target_cluster)
         self.source_partition = PartitionFromCluster(source_cluster)
-        self.hmatrix = hmatrix_tree_builder.build(generator, target_cluster, source_cluster, device=device, local_partitions=(rank, rank))
+        self.hmatrix = hmatrix_tree_builder.build(generator, target_cluster, source_cluster, device=device, local_partitions=(rank, rank), dtype=dtype)
         self.block_diagonal_hmatrix = self.hmatrix
         self.local_hmatrix = LocalToLocalHMatrix(self.hmatrix)
         self.distributed_operator = DistributedOperator(self.target_partition, self.source_partition, group)

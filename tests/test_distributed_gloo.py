@@ -123,6 +123,62 @@ def test_distributed_products_match_single_process(world, sym, uplo):
     assert max(res.values()) < 1e-5, res
 
 
+def _zworker(rank, world, port, sym, uplo, q):
+    """Complex coefficients: Hermitian / complex symmetric row slabs, trans N / T / C, all-gather and all-reduce of complex
+    vectors (through their real views)."""
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1200
+        x = hm.create_geometry("ball", n)
+        b = hm.ClusterTreeBuilder()
+        b.set_maximal_leaf_size(40)
+        T = b.create_cluster_tree(n, 3, x, 2, world)
+        To = O.ClusterTree(x, 40, 2, world)
+        comp = "sympartialACA" if sym != "N" else "partialACA"
+        kw = dict(cre=0.8, cim=0.6, eps=1e-6, eta=10.0, sym=sym, uplo=uplo, compressor=comp)
+        Hloc, Hfull = O.ZHMatrix(To, To, rank=rank, **kw), O.ZHMatrix(To, To, **kw)
+        tp = D.PartitionFromCluster(T)
+        A = D.DistributedOperator(tp, tp)
+        A.add_global_to_local_operator(OracleLocalOperator(Hloc))
+        xin, y0 = O.hashed_zvector(n, 7), O.hashed_zvector(n, 8)
+        alpha, beta = 3.0 + 0.5j, 2.0 - 0.25j
+        perm = T.get_permutation()
+        errs = []
+        for trans in ("N",) + (("T",) if sym != "H" else ()) + (("C",) if sym != "S" else ()):
+            y = torch.from_numpy(y0.copy())
+            D.internal_add_distributed_operator_vector_product_global_to_global(trans, alpha, A, torch.from_numpy(xin), beta, y)
+            errs.append(rel_err(y.numpy(), Hfull.matvec(xin, trans, alpha, beta, y0)))
+            y = torch.from_numpy(y0.copy())
+            D.add_distributed_operator_vector_product_global_to_global(trans, alpha, A, torch.from_numpy(xin), beta, y)
+            yu = np.empty(n, dtype=np.complex128)
+            yu[perm] = Hfull.matvec(xin[perm], trans, alpha, beta, y0[perm])
+            errs.append(rel_err(y.numpy(), yu))
+            off, sz = tp.get_offset_of_partition(rank), tp.get_size_of_partition(rank)
+            yl = torch.from_numpy(y0[off:off + sz].copy())
+            D.internal_add_distributed_operator_vector_product_local_to_local(trans, alpha, A, torch.from_numpy(xin[off:off + sz].copy()), beta, yl)
+            errs.append(rel_err(yl.numpy(), Hfull.matvec(xin, trans, alpha, beta, y0)[off:off + sz]))
+        q.put((rank, max(errs)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sym,uplo", [(2, "N", "N"), (2, "H", "L"), (2, "S", "U")])
+def test_distributed_complex_products(world, sym, uplo):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zworker, args=(r, world, port, sym, uplo, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert max(res.values()) < 1e-5, res
+
+
 def test_partition_numbering_round_trip():
     x = hm.create_geometry("disk", 500)
     b = hm.ClusterTreeBuilder()
