@@ -100,6 +100,7 @@ struct Timer {
 // Compute the stream layout from the final leaf kinds/ranks and move the data into it.
 
 #define HMX_COMPLEX 0
+#define HMX_SPLIT_COLS 0
 namespace f64 {
 using real    = double;
 using scalar  = double;
@@ -116,6 +117,10 @@ using scalar2 = float2;
 } // namespace f32
 #undef HMX_COMPLEX
 #define HMX_COMPLEX 1
+#undef HMX_SPLIT_COLS
+#define HMX_SPLIT_COLS 1
+#undef HMX_COL0
+#undef HMX_COL1
 namespace z64 { // htool's HMatrix<std::complex<double>, double>
 using real    = double;
 using scalar  = cplx<double>;
@@ -123,6 +128,10 @@ using scalar2 = cplx2<double>;
 #include "kernels_body.hpp"
 #include "engine_body.hpp"
 } // namespace z64
+#undef HMX_SPLIT_COLS
+#define HMX_SPLIT_COLS 0
+#undef HMX_COL0
+#undef HMX_COL1
 namespace c32 { // HMatrix<std::complex<float>, double>
 using real    = float;
 using scalar  = cplx<float>;
@@ -131,6 +140,7 @@ using scalar2 = cplx2<float>;
 #include "engine_body.hpp"
 } // namespace c32
 #undef HMX_COMPLEX
+#undef HMX_SPLIT_COLS
 
 } // namespace hmx
 

@@ -970,6 +970,25 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
 // Stage 1 (add_lrmat_vector_product.hpp:16, a = V x): one wave per (source range, column chunk).
 // lane owns two adjacent columns and walks the rows; the x slice is loaded 64 rows at a time (one
 // coalesced load) and broadcast with v_readlane, so the row loop contains only the 16-B stream loads.
+// The two R-stream columns a lane owns.  Real and complex-float coefficients: two ADJACENT columns, one 16-byte load per
+// row.  Complex double (16-byte coefficients): columns lane and lane + 64, two loads that are each one contiguous KiB per wave.
+#if HMX_SPLIT_COLS
+#define HMX_COL0(lane) (lane)
+#define HMX_COL1(lane) ((lane) + 64)
+__device__ __forceinline__ scalar2 load_pair(const scalar *row, int col0, int col1, int wp) {
+    scalar2 v;
+    v.x = col0 < wp ? stream_load(row + col0) : scalar(0);
+    v.y = col1 < wp ? stream_load(row + col1) : scalar(0);
+    return v;
+}
+#else
+#define HMX_COL0(lane) (2 * (lane))
+#define HMX_COL1(lane) (2 * (lane) + 1)
+__device__ __forceinline__ scalar2 load_pair(const scalar *row, int col0, int col1, int wp) {
+    return stream_load(reinterpret_cast<const scalar2 *>(row + (col0 < wp ? col0 : 0))); // wp is even: both columns or none
+}
+#endif
+
 struct ReduceArgs {
     const scalar *stream;
     const int32_t *task_range, *task_chunk;
@@ -993,8 +1012,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
-    const bool active = 2 * lane < wp;
-    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane); // the two columns of this lane
+    const bool active = col0 < wp;
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
     const scalar *xs  = A.x + A.range_off[S];
     scalar a0 = scalar(0), a1 = scalar(0);
     for (int i0 = 0; i0 < len; i0 += 64) {
@@ -1006,7 +1026,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
             scalar2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = stream_load(reinterpret_cast<const scalar2 *>(p + (int64_t)(j + u) * wp));
+                v[u] = load_pair(p + (int64_t)(j + u) * wp, col0, col1, wp);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const scalar xi = readlane_val(xv, j + u);
@@ -1015,18 +1035,18 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
             }
         }
         for (; j < nr; j++) {
-            const scalar2 v = *reinterpret_cast<const scalar2 *>(p + (int64_t)j * wp);
+            const scalar2 v = load_pair(p + (int64_t)j * wp, col0, col1, wp);
             const scalar xi = readlane_val(xv, j);
             a0              = hmx_fma(v.x, xi, a0);
             a1              = hmx_fma(v.y, xi, a1);
         }
     }
     if (active) {
-        const int64_t cb = A.range_colbase[S] + ch * cw + 2 * lane;
-        if (2 * lane < w)
-            A.Z[A.out_idx[cb]] = a0;
-        if (2 * lane + 1 < w)
-            A.Z[A.out_idx[cb + 1]] = a1;
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        if (col0 < w)
+            A.Z[A.out_idx[cb + col0]] = a0;
+        if (col1 < w)
+            A.Z[A.out_idx[cb + col1]] = a1;
     }
 }
 
@@ -1134,8 +1154,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
-    const bool active = 2 * lane < wp;
-    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
+    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+    const bool active = col0 < wp;
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
     const scalar *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
     scalar a0[MU], a1[MU];
 #pragma unroll
@@ -1156,7 +1177,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
             scalar2 v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                v[u] = stream_load(reinterpret_cast<const scalar2 *>(p + (int64_t)(j + u) * wp));
+                v[u] = load_pair(p + (int64_t)(j + u) * wp, col0, col1, wp);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
 #pragma unroll
@@ -1168,7 +1189,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
             }
         }
         for (; j < nr; j++) {
-            const scalar2 v = *reinterpret_cast<const scalar2 *>(p + (int64_t)j * wp);
+            const scalar2 v = load_pair(p + (int64_t)j * wp, col0, col1, wp);
 #pragma unroll
             for (int c = 0; c < MU; c++) {
                 const scalar xi = xt[wv][j][c];
@@ -1178,15 +1199,15 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
         }
     }
     if (active) {
-        const int64_t cb = A.range_colbase[S] + ch * cw + 2 * lane;
-        if (2 * lane < w) {
-            scalar *dst = A.Z + (int64_t)A.out_idx[cb] * mu + cbase;
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        if (col0 < w) {
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb + col0] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 dst[c] = a0[c];
         }
-        if (2 * lane + 1 < w) {
-            scalar *dst = A.Z + (int64_t)A.out_idx[cb + 1] * mu + cbase;
+        if (col1 < w) {
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb + col1] * mu + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 dst[c] = a1[c];
@@ -1469,18 +1490,19 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
     const int wp      = (w + 1) & ~1;
-    const bool active = 2 * lane < wp;
-    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw + (active ? 2 * lane : 0);
-    const int64_t cb  = A.range_colbase[S] + ch * cw + 2 * lane;
+    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+    const bool active = col0 < wp;
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const int64_t cb  = A.range_colbase[S] + ch * cw;
     scalar c0 = scalar(0), c1 = scalar(0);
     bool any = false;
-    if (2 * lane < w) {
-        const int d = A.coef[cb];
+    if (col0 < w) {
+        const int d = A.coef[cb + col0];
         c0          = d >= 0 ? A.W[d] : scalar(0);
         any         = d >= 0;
     }
-    if (2 * lane + 1 < w) {
-        const int d = A.coef[cb + 1];
+    if (col1 < w) {
+        const int d = A.coef[cb + col1];
         c1          = d >= 0 ? A.W[d] : scalar(0);
         any         = any || d >= 0;
     }
@@ -1494,7 +1516,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
         for (int u = 0; u < 8; u++) {
             v[u] = scalar(0);
             if (active && i0 + u < len) {
-                const scalar2 e = stream_load(reinterpret_cast<const scalar2 *>(src + (int64_t)(i0 + u) * wp));
+                const scalar2 e = load_pair(src + (int64_t)(i0 + u) * wp, col0, col1, wp);
                 v[u]              = hmx_fma(e.x, c0, e.y * c1);
             }
         }
