@@ -223,46 +223,26 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # Row-partitioned runs are launch-bound per rank (a few hundred microseconds of kernels at 8 GPUs): capture one
-    # step -- local kernels + the RCCL all-gather -- in a HIP graph and replay it.  Falls back to eager launches.
+    # Row-partitioned runs are launch-bound per rank (a few hundred microseconds of kernels at 8 GPUs): the local kernels
+    # of a step are captured once in a HIP graph (htool_amd.distributed.GraphedGlobalToGlobalProduct); the RCCL all-gather
+    # is issued eagerly after each replay, so no graph ever holds a collective.  HMX_BENCH_NO_GRAPH=1: eager launches.
     graphed = False
-    eager_step = step
-    g = None
-    if part and mu == 1 and not os.environ.get("HMX_BENCH_NO_GRAPH"):
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step()
-            graphed = True
-        except Exception as ex:  # keep the eager path
-            log("HIP graph capture of the distributed step failed (%r): timing eager launches" % (ex,))
-            g = None
+    if part and mu == 1 and args.trans == "N" and not os.environ.get("HMX_BENCH_NO_GRAPH"):
+        eager_step = step
+        eager_step()
         torch.cuda.synchronize()
-    if part:
-        # every rank must take the same path BEFORE anything is replayed: a graph holding a collective replayed on
-        # some ranks only would hang
-        flag = torch.tensor([1 if graphed else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        graphed = bool(int(flag.item()))
-        if graphed:
-            eager_step()
-            y_ref = y.clone()
-            y.zero_()
-            g.replay()
-            torch.cuda.synchronize()
-            same = torch.tensor([1 if torch.equal(y, y_ref) else 0], device=dev)
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            if int(same.item()) == 1:
-                step = g.replay
-            else:
-                log("graph replay does not reproduce the eager result: timing eager launches")
-                graphed = False
+        y_ref = y.clone()
+        gp = D.GraphedGlobalToGlobalProduct(A, xin, y)
+        y.zero_()
+        gp()
+        torch.cuda.synchronize()
+        ok = torch.tensor([1 if (gp.graph is not None and torch.equal(y, y_ref)) else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # informational: ranks may differ, both paths issue the same collective
+        graphed = bool(int(ok.item()))
+        if torch.equal(y, y_ref):
+            step = gp
+        else:
+            log("graphed product does not reproduce the eager result: timing eager launches")
     for _ in range(2):
         step()
     fence()
@@ -314,7 +294,7 @@ def main():
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(mu=mu, sym=args.sym, trans=args.trans, workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, {"f64": "fp64", "f32": "fp32", "z64": "complex fp64", "c32": "complex fp32"}[args.dtype], args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
-                           parallelism=("row-partition x%d + all-gather%s" % (world, ", step replayed from a HIP graph" if graphed else "")) if part else "single GPU",
+                           parallelism=("row-partition x%d + all-gather%s" % (world, ", local kernels replayed from a HIP graph" if graphed else "")) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
                            build_s=dict(cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
