@@ -52,7 +52,7 @@ struct HMat {
     DArr<double> tx, ty, tz, sx, sy, sz; // cluster-order coordinates (SoA)
 
     // per-leaf metadata on device
-    DArr<int32_t> d_t_off, d_t_size, d_s_off, d_s_size, d_rank, d_swapped, d_sym_uplo, d_transposed;
+    DArr<int32_t> d_t_off, d_t_size, d_s_off, d_s_size, d_rank, d_swapped, d_sym_uplo, d_transposed, d_conj;
     DArr<int64_t> d_colptr, d_cross_off, d_staged_off;
     std::vector<int64_t> colptr;
     std::vector<int32_t> swapped;
@@ -74,6 +74,11 @@ struct HMat {
     DArr<scalar> Z, W, Zmu;
     DArr<scalar> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
     DArr<scalar> conj_in;                             // conjugated input of a trans = 'C' product
+    // trans = 'T': the transposed operator laid out in its own streams (built on first use from the same crosses /
+    // generator, see ensure_transposed_operator); `view_of` is set in that object and points back to the owner
+    std::unique_ptr<HMat> T_op;
+    const HMat *view_of = nullptr;
+    bool T_op_failed    = false;
     DArr<int32_t> d_perm_t, d_perm_s;
     bool finalized = false;
 
@@ -107,13 +112,21 @@ static int build_streams(HMat &H) {
     const int herm = H.symmetry_for_leaves == 'H' ? 1 : 0;
     if (herm)
         H.sym_expanded = H.has_mirror;
+    // a transposed view borrows crosses, staged blocks and generator from its owner
+    const HMat &SRC = H.view_of ? *H.view_of : H;
+    const bool tv   = H.view_of != nullptr;
+    if (!tv)
+        H.T_op.reset(); // the layout changes: a transposed view built earlier is stale
     std::vector<hmx_leaf> XL = H.leaves;
     std::vector<int> XK      = H.kind;
     std::vector<int64_t> xcolptr = H.colptr, xstaged = H.staged_off;
-    std::vector<int32_t> xswapped = H.swapped, xtransposed(nb_real, 0);
+    std::vector<int32_t> xswapped = H.swapped, xtransposed(nb_real, tv ? 1 : 0), xconj(nb_real, 0);
     xcolptr.resize(nb_real, 0);
     xstaged.resize(nb_real, -1);
     xswapped.resize(nb_real, 0);
+    if (tv)
+        for (auto &v : xswapped)
+            v = v ? 0 : 1; // U and V exchange roles
     if (H.sym_expanded)
         for (int64_t b = 0; b < nb_real; b++) {
             if (!H.leaves[b].mirror)
@@ -127,7 +140,8 @@ static int build_streams(HMat &H) {
             xcolptr.push_back(xcolptr[b]);
             xstaged.push_back(xstaged[b]);
             xswapped.push_back(xswapped[b] ? 0 : 1);
-            xtransposed.push_back(1);
+            xtransposed.push_back(tv ? 0 : 1);
+            xconj.push_back(herm); // Hermitian storage: the mirrored copy is the conjugate (transpose)
         }
     const int64_t nb = (int64_t)XL.size();
     const bool mirror_flags = H.has_mirror && !H.sym_expanded;
@@ -375,7 +389,7 @@ static int build_streams(HMat &H) {
     std::vector<int32_t> ranks(nb), symu(nb, 0);
     for (int64_t b = 0; b < nb; b++) {
         ranks[b] = XL[b].rank;
-        if (XL[b].symmetric && XK[b] == LK_DENSE_STAGED && !H.dense_stage.d) // uploaded symmetric leaf: one triangle is valid
+        if (XL[b].symmetric && XK[b] == LK_DENSE_STAGED && !SRC.dense_stage.d) // uploaded symmetric leaf: one triangle is valid
             symu[b] = H.uplo_for_leaves == 'L' ? 1 : (H.uplo_for_leaves == 'U' ? 2 : 0);
     }
     HMX_HIP(H.d_rank.upload(ranks));
@@ -396,6 +410,7 @@ static int build_streams(HMat &H) {
         HMX_HIP(H.d_swapped.upload(xswapped));
         HMX_HIP(H.d_staged_off.upload(xstaged));
         HMX_HIP(H.d_transposed.upload(xtransposed));
+        HMX_HIP(H.d_conj.upload(xconj));
     }
     hipEvent_t e0, e1;
     HMX_HIP(hipEventCreate(&e0));
@@ -407,8 +422,8 @@ static int build_streams(HMat &H) {
             HMX_HIP(pb.upload(elr_b));
             HMX_HIP(pr.upload(elr_r));
             HMX_HIP(pc.upload(elr_c));
-            PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0, H.d_transposed.d, herm};
+            PackLrArgs P{SRC.pool.d, SRC.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
+                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0, H.d_conj.d};
             hipLaunchKernelGGL(pack_lr_expand_kernel, dim3((unsigned)elr_b.size()), dim3(256), 0, 0, P, (int64_t)elr_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -417,8 +432,8 @@ static int build_streams(HMat &H) {
             HMX_HIP(pb.upload(rlr_b));
             HMX_HIP(pr.upload(rlr_r));
             HMX_HIP(pc.upload(rlr_c));
-            PackLrArgs P{H.pool.d, H.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0, H.d_transposed.d, herm};
+            PackLrArgs P{SRC.pool.d, SRC.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
+                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0, H.d_conj.d};
             hipLaunchKernelGGL(pack_lr_reduce_kernel, dim3((unsigned)rlr_b.size()), dim3(256), 0, 0, P, (int64_t)rlr_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -427,8 +442,12 @@ static int build_streams(HMat &H) {
             HMX_HIP(pb.upload(ed_b));
             HMX_HIP(pr.upload(ed_r));
             HMX_HIP(pc.upload(ed_c));
-            PackDenseArgs P{H.ks, H.tx.d, H.ty.d, H.tz.d, H.sx.d, H.sy.d, H.sz.d, pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d,
-                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.dense_stage.d ? H.dense_stage.d : H.pool.d, E.stream.d, H.T0, herm};
+            // row / column coordinates of THIS layout: a transposed view's rows are the owner's source points
+            const DArr<double> &rx = tv ? SRC.sx : SRC.tx, &ry = tv ? SRC.sy : SRC.ty, &rz = tv ? SRC.sz : SRC.tz;
+            const DArr<double> &cx = tv ? SRC.tx : SRC.sx, &cy = tv ? SRC.ty : SRC.sy, &cz = tv ? SRC.tz : SRC.sz;
+            PackDenseArgs P{SRC.ks, rx.d, ry.d, rz.d, cx.d, cy.d, cz.d, pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d,
+                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.d_conj.d,
+                            SRC.dense_stage.d ? SRC.dense_stage.d : SRC.pool.d, E.stream.d, H.T0, herm};
             hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)ed_b.size()), dim3(256), 0, 0, P, (int64_t)ed_b.size());
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
@@ -669,6 +688,52 @@ static int run_transposed(HMat &H, bool mirror, const scalar *in, scalar alpha, 
     return HMX_OK;
 }
 
+// trans = 'T' at the speed of trans = 'N': the transposed operator gets its own E-/R-streams (same crosses with the roles of
+// U and V exchanged, dense leaves regenerated / read transposed), built on the first transposed product.  Costs a second
+// copy of the streams in HBM; HMX_TRANS_STREAMS=0, compact symmetric storage or an allocation failure fall back to the
+// in-place passes (colreduce / rowreduce kernels: wave reductions + atomics).
+static int build_streams(HMat &H);
+static HMat *ensure_transposed_operator(HMat &H) {
+    if (H.T_op)
+        return H.T_op.get();
+    if (H.T_op_failed || H.view_of || (H.has_mirror && !H.sym_expanded) || (getenv("HMX_TRANS_STREAMS") && !atoi(getenv("HMX_TRANS_STREAMS"))))
+        return nullptr;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 1.15 * (double)H.stats.stream_bytes) {
+        H.T_op_failed = true; // not enough HBM for a second layout
+        return nullptr;
+    }
+    std::unique_ptr<HMat> T(new HMat());
+    T->device  = H.device;
+    T->view_of = &H;
+    T->leaves  = H.leaves;
+    for (auto &l : T->leaves) {
+        std::swap(l.t_offset, l.s_offset);
+        std::swap(l.t_size, l.s_size);
+    }
+    T->kind = H.kind;
+    T->T0 = H.S0, T->nT = H.nS, T->S0 = H.T0, T->nS = H.nT;
+    T->nT_total = H.nS_total, T->nS_total = H.nT_total;
+    T->symmetry_for_leaves = H.symmetry_for_leaves;
+    T->uplo_for_leaves     = H.uplo_for_leaves == 'L' ? 'U' : (H.uplo_for_leaves == 'U' ? 'L' : 'N');
+    T->build_epsilon       = H.build_epsilon;
+    T->has_mirror          = H.has_mirror;
+    T->colptr              = H.colptr;
+    T->swapped             = H.swapped;
+    T->staged_off          = H.staged_off;
+    T->profiling           = H.profiling;
+    const hmx_stats keep   = H.stats;
+    const int rc           = build_streams(*T);
+    (void)keep;
+    if (rc != HMX_OK) {
+        H.T_op_failed = true;
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    H.T_op = std::move(T);
+    return H.T_op.get();
+}
+
 static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, hipStream_t st, bool inner = false) {
     if (!H.finalized) {
         set_error("hmx_hmatrix_matvec: operator not built (call hmx_hmatrix_compress or hmx_hmatrix_finalize first)");
@@ -680,6 +745,8 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
         set_error(std::string("hmx_hmatrix_matvec: operation is not supported (trans=") + trans + " with " + H.symmetry_for_leaves + " leaves)");
         return HMX_ERR_INVALID;
     }
+    if (trans == 'C' && H.symmetry_for_leaves == 'H' && H.has_mirror && H.T0 == H.S0 && H.nT == H.nS)
+        trans = 'N'; // a square Hermitian operator is its own conjugate transpose
     if (trans == 'C') { // alpha A^H x + beta y = conj( conj(alpha) A^T conj(x) + conj(beta) conj(y) )
         const int nin = H.nT, nout = H.nS;
         if ((int64_t)H.conj_in.n < nin)
@@ -699,13 +766,27 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
         set_error("hmx_hmatrix_matvec: trans must be 'N' or 'T'" + std::string(HMX_COMPLEX ? " or 'C'" : ""));
         return HMX_ERR_INVALID;
     }
-    if (H.has_mirror && (H.S0 > H.T0 || H.S0 + H.nS < H.T0 + H.nT)) {
+    if (H.has_mirror && !H.sym_expanded && (H.S0 > H.T0 || H.S0 + H.nS < H.T0 + H.nT)) {
         set_error("symmetric storage needs the target rows to be a sub-range of the source columns");
         return HMX_ERR_UNSUPPORTED;
     }
     H.ev_names.clear();
     prof_mark(H, st, "begin");
     int rc;
+    // a square operator stored symmetrically IS its own transpose ('S') / conjugate transpose ('H', handled above as 'C')
+    if (trans == 'T' && !inner && H.symmetry_for_leaves == 'S' && H.has_mirror && H.T0 == H.S0 && H.nT == H.nS)
+        trans = 'N';
+    if (trans == 'T') {
+        if (HMat *T = ensure_transposed_operator(H)) {
+            T->profiling = H.profiling;
+            rc           = matvec_device(*T, 'N', alpha, in, beta, out, st, true);
+            if (rc == HMX_OK && H.profiling) {
+                H.last_ms    = T->last_ms;
+                H.last_names = T->last_names;
+            }
+            return rc;
+        }
+    }
     if (trans == 'N') {
         rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st);
         if (rc == HMX_OK && H.has_mirror && !H.sym_expanded)
@@ -1655,22 +1736,30 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
         HMX_HIP(H.tmp_in2.alloc(nin));
     if (H.tmp_out2.n < (size_t)nout)
         HMX_HIP(H.tmp_out2.alloc(nout));
-    if (trans == 'N' && (!H.has_mirror || H.sym_expanded) && H.finalized && !getenv("HMX_NO_FUSED_MU")) {
+    HMat *F = nullptr; // the layout a fused pass runs on: the operator itself, or its transposed view
+    if (H.finalized && (!H.has_mirror || H.sym_expanded) && !getenv("HMX_NO_FUSED_MU")) {
+        if (trans == 'N')
+            F = &H;
+        else if (trans == 'T' && !(HMX_COMPLEX && H.symmetry_for_leaves == 'H'))
+            F = ensure_transposed_operator(H);
+    }
+    if (F) {
         // fused path: the streams are read once for up to 16 right-hand sides
-        H.ev_names.clear();
-        prof_mark(H, st, "begin");
-        rc = run_forward_mu(H, din, alpha, beta, dout, mu, st);
+        F->profiling = H.profiling;
+        F->ev_names.clear();
+        prof_mark(*F, st, "begin");
+        rc = run_forward_mu(*F, din, alpha, beta, dout, mu, st);
         if (rc != HMX_OK)
             return rc;
         if (H.profiling) {
             HMX_HIP(hipStreamSynchronize(st));
             H.last_ms.clear();
             H.last_names.clear();
-            for (size_t k = 1; k < H.ev_names.size(); k++) {
+            for (size_t k = 1; k < F->ev_names.size(); k++) {
                 float ms = 0;
-                (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
+                (void)hipEventElapsedTime(&ms, F->ev[k - 1], F->ev[k]);
                 H.last_ms.push_back(ms);
-                H.last_names.push_back(H.ev_names[k]);
+                H.last_names.push_back(F->ev_names[k]);
             }
         }
         if (staged) {
@@ -1679,7 +1768,7 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
         }
         return HMX_OK;
     }
-    // transposed products and symmetric storage: one streaming pass per right-hand side (not fused yet)
+    // trans = 'C', compact symmetric storage, or no room for the transposed layout: one pass per right-hand side
     for (int c = 0; c < mu; c++) {
         hipLaunchKernelGGL(col_extract_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, mu, c, din, H.tmp_in2.d);
         if (!hmx_is_zero(beta))

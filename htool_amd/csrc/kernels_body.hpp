@@ -858,8 +858,7 @@ struct PackLrArgs {
     const int32_t *range_cw;   // chunk width of the range (R-stream only)
     scalar *stream;
     int origin;                // global cluster position of local offset 0 (T0 for E-streams, S0 for R-streams)
-    const int32_t *transposed; // 1: mirrored copy of a stored leaf (expanded symmetric layout)
-    int herm;                  // Hermitian storage: mirrored copies are conjugated
+    const int32_t *conjflag;   // 1: this entry of the layout holds the conjugate of the stored factors (Hermitian mirror)
 };
 
 // U slices -> E-stream (column-major len x C per target range)
@@ -877,7 +876,7 @@ __global__ void pack_lr_expand_kernel(PackLrArgs P, int64_t npairs) {
         const int k = e / len, i = e - k * len;
         // U(:,k) = uu_k when index 1 is the row side, vv_k otherwise (sympartialACA.hpp:198-212)
         const scalar *src = P.pool + cross[k] + (P.swapped[b] ? n1 : 0);
-        dst[e]            = (P.herm && P.transposed[b]) ? hmx_conj(src[rel + i]) : src[rel + i];
+        dst[e]            = P.conjflag[b] ? hmx_conj(src[rel + i]) : src[rel + i];
     }
 }
 
@@ -904,7 +903,7 @@ __global__ void pack_lr_reduce_kernel(PackLrArgs P, int64_t npairs) {
     for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
         const int k = e / len, i = e - k * len;
         const scalar *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
-        P.stream[rstream_index(P.range_base[S], len, C, P.range_cw[S], i, col + k)] = (P.herm && P.transposed[b]) ? hmx_conj(src[rel + i]) : src[rel + i];
+        P.stream[rstream_index(P.range_base[S], len, C, P.range_cw[S], i, col + k)] = P.conjflag[b] ? hmx_conj(src[rel + i]) : src[rel + i];
     }
 }
 
@@ -917,7 +916,8 @@ struct PackDenseArgs {
     const int32_t *t_off, *t_size, *s_off, *s_size;
     const int64_t *staged_off; // >= 0: uploaded dense block (column-major M x N) in `pool`; < 0: generate
     const int32_t *sym_uplo;   // 0 none, 1 'L', 2 'U' : uploaded symmetric leaf, only that triangle is valid
-    const int32_t *transposed; // 1: this entry is the mirrored copy of a stored leaf -- read the staged block transposed
+    const int32_t *transposed; // 1: this entry of the layout is the TRANSPOSE of a stored leaf (mirrored copy, or a transposed view)
+    const int32_t *conjflag;   // 1: ... and conjugated (Hermitian mirror)
     const scalar *pool;
     scalar *stream;
     int origin; // T0
@@ -950,15 +950,23 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
                 jj          = t;
                 cj          = P.herm != 0;
             }
-            if (P.transposed[b])
-                cj = (P.herm != 0) != cj;
+            if (P.conjflag[b])
+                cj = !cj;
             v = P.transposed[b] ? P.pool[st + jj + (int64_t)N * ii] : P.pool[st + ii + (int64_t)M * jj];
             if (cj)
                 v = hmx_conj(v);
             if (P.herm && su && ii == jj)
                 v = scalar(hmx_re(v));
+        } else if (P.transposed[b]) {
+            // entry (i, j) of the transpose of a stored leaf: the generator is evaluated at (target = the column's point,
+            // source = the row's point), i.e. at the stored leaf's own (row, column), then conjugated for a Hermitian mirror
+            v = eval_scalar(P.ks, P.sx[c0 + j], P.sy[c0 + j], P.sz[c0 + j], P.tx[row0 + i], P.ty[row0 + i], P.tz[row0 + i]);
+            if (P.conjflag[b])
+                v = hmx_conj(v);
         } else {
             v = eval_scalar(P.ks, P.tx[row0 + i], P.ty[row0 + i], P.tz[row0 + i], P.sx[c0 + j], P.sy[c0 + j], P.sz[c0 + j]);
+            if (P.conjflag[b])
+                v = hmx_conj(v);
         }
         dst[e] = v;
     }

@@ -528,3 +528,43 @@ def test_host_callback_generator(name):
     for k in g:
         if k.startswith("D_"):
             assert np.array_equal(H.get_block(int(k[2:])), g[k].T)
+
+
+@pytest.mark.parametrize("name", ["rect_ball1500_disk1000", "ellipse_n4000_p4_rank2", "ball_n2000_p2_symL_rank1", "ellipse_n3000_symL_default"])
+@pytest.mark.parametrize("mu", [1, 3, 16])
+def test_transposed_products_both_layouts(name, mu, monkeypatch):
+    """trans='T' through the transposed stream layout (default; fused for several right-hand sides) and through the
+    in-place passes (HMX_TRANS_STREAMS=0: wave reductions + atomics): both equal the CPU leaf loop on the same blocks."""
+    from oracle import oracle as O
+    p = params(name)
+    T, S, H = build_engine(p)
+    tab = H.leaf_table()
+    data, offs, pos = [], [], 0
+    for b in range(len(tab)):
+        blk = H.get_block(b)
+        if tab[b, 4] >= 0:
+            u, v = np.asfortranarray(blk[0]).ravel("F"), np.asfortranarray(blk[1]).ravel("F")
+            offs.append((pos, pos + u.size))
+            data += [u, v]
+            pos += u.size + v.size
+        else:
+            d = np.asfortranarray(blk).ravel("F")
+            offs.append((pos, 0))
+            data.append(d)
+            pos += d.size
+    root = [H.target_offset, H.target_size, H.source_offset, H.source_size]
+    Ho = O.HMatrix.from_blocks(tab, np.array(offs), np.concatenate(data), root, H.get_symmetry_for_leaves(), H.get_UPLO_for_leaves())
+    nr, nc = H.nb_rows(), H.nb_cols()
+    rng = np.random.default_rng(3)
+    for layout in ("1", "0"):
+        monkeypatch.setenv("HMX_TRANS_STREAMS", layout)
+        if mu == 1:
+            x, y0 = rng.standard_normal(nr), rng.standard_normal(nc)
+            y = y0.copy()
+            hm.internal_add_hmatrix_vector_product("T", 1.5, H, x, -0.5, y)
+            assert rel_err(y, Ho.matvec(x, "T", 1.5, -0.5, y0)) < 1e-12
+        else:
+            X, Y0 = rng.standard_normal((nr, mu)), rng.standard_normal((nc, mu))
+            Y = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major("T", 1.5, H, X, -0.5, Y, mu)
+            assert rel_err(Y, Ho.matmat_row_major(X, "T", 1.5, -0.5, Y0)) < 1e-12
