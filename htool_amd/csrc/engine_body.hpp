@@ -1737,12 +1737,34 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
     if (H.tmp_out2.n < (size_t)nout)
         HMX_HIP(H.tmp_out2.alloc(nout));
     HMat *F = nullptr; // the layout a fused pass runs on: the operator itself, or its transposed view
+    bool conj_wrap = false;
+    (void)conj_wrap;
     if (H.finalized && (!H.has_mirror || H.sym_expanded) && !getenv("HMX_NO_FUSED_MU")) {
-        if (trans == 'N')
+        const bool square_sym = H.has_mirror && H.T0 == H.S0 && H.nT == H.nS;
+        if (trans == 'N' || (trans == 'T' && square_sym && H.symmetry_for_leaves == 'S') || (trans == 'C' && square_sym && H.symmetry_for_leaves == 'H'))
             F = &H;
         else if (trans == 'T' && !(HMX_COMPLEX && H.symmetry_for_leaves == 'H'))
             F = ensure_transposed_operator(H);
+#if HMX_COMPLEX
+        else if (trans == 'C' && H.symmetry_for_leaves != 'S') { // conj o 'T' o conj on all right-hand sides at once
+            F         = ensure_transposed_operator(H);
+            conj_wrap = F != nullptr;
+        }
+#endif
     }
+#if HMX_COMPLEX
+    if (conj_wrap) {
+        const int64_t tin = (int64_t)nin * mu, tout = (int64_t)nout * mu;
+        if ((int64_t)H.conj_in.n < tin)
+            HMX_HIP(H.conj_in.alloc(tin));
+        hipLaunchKernelGGL(conj_kernel, dim3((unsigned)((tin + 255) / 256)), dim3(256), 0, st, tin, din, H.conj_in.d);
+        if (!hmx_is_zero(beta))
+            hipLaunchKernelGGL(conj_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, tout, (const scalar *)dout, dout);
+        din   = H.conj_in.d;
+        alpha = hmx_conj(alpha);
+        beta  = hmx_conj(beta);
+    }
+#endif
     if (F) {
         // fused path: the streams are read once for up to 16 right-hand sides
         F->profiling = H.profiling;
@@ -1762,13 +1784,19 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
                 H.last_names.push_back(F->ev_names[k]);
             }
         }
+#if HMX_COMPLEX
+        if (conj_wrap) {
+            const int64_t tout = (int64_t)nout * mu;
+            hipLaunchKernelGGL(conj_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, tout, (const scalar *)dout, dout);
+        }
+#endif
         if (staged) {
             HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(scalar), hipMemcpyDeviceToHost, st));
             HMX_HIP(hipStreamSynchronize(st));
         }
         return HMX_OK;
     }
-    // trans = 'C', compact symmetric storage, or no room for the transposed layout: one pass per right-hand side
+    // compact symmetric storage, or no room for the transposed layout: one pass per right-hand side
     for (int c = 0; c < mu; c++) {
         hipLaunchKernelGGL(col_extract_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, mu, c, din, H.tmp_in2.d);
         if (!hmx_is_zero(beta))
