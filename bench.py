@@ -208,7 +208,7 @@ def main():
 
     def step():
         if mu > 1:
-            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, Xmu, 0.0, Ymu, mu)
+            hm.internal_add_hmatrix_matrix_product_row_major(args.trans, 1.0, H, Xmu, 0.0, Ymu, mu)
         elif part:
             D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y)
         else:
@@ -265,7 +265,7 @@ def main():
     nprof = max(3, min(args.steps, 10))
     for _ in range(nprof):
         if mu > 1:
-            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, Xmu, 0.0, Ymu, mu)
+            hm.internal_add_hmatrix_matrix_product_row_major(args.trans, 1.0, H, Xmu, 0.0, Ymu, mu)
         else:
             hm.internal_add_hmatrix_vector_product(args.trans, 1.0, H, xin, 0.0, y_loc)
         for name, ms in H.last_kernel_times():

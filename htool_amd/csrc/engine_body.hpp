@@ -925,12 +925,6 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
         return HMX_ERR_INVALID;
     }
     const bool assembled = (compressor == HMX_FULL_ACA || compressor == HMX_SVD); // works on the assembled block
-#if HMX_COMPLEX
-    if (compressor == HMX_SVD) {
-        set_error("hmx_hmatrix_compress: the SVD compressor is not available for complex coefficients (use an ACA variant, or upload blocks)");
-        return HMX_ERR_UNSUPPORTED;
-    }
-#endif
     if (reqrank == 0)
         reqrank = -1;
     H.build_epsilon = epsilon;
@@ -1069,10 +1063,8 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
             D.rank_out    = H.d_rank.d;
             if (compressor == HMX_FULL_ACA)
                 hipLaunchKernelGGL(fullaca_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
-#if !HMX_COMPLEX
             else
                 hipLaunchKernelGGL(svd_kernel<256>, dim3((unsigned)(end - pos)), dim3(256), 0, 0, D);
-#endif
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
             pos = end;
@@ -1260,10 +1252,6 @@ static int api_recompress(HMat *Hp, double epsilon) {
         set_error("hmx_hmatrix_recompress: NULL handle");
         return HMX_ERR_INVALID;
     }
-#if HMX_COMPLEX
-    set_error("hmx_hmatrix_recompress: SVD recompression is not available for complex coefficients");
-    return HMX_ERR_UNSUPPORTED;
-#else
     HMat &H = *Hp;
     if (!H.finalized || H.pool.n == 0) {
         set_error("hmx_hmatrix_recompress: operator not built");
@@ -1338,7 +1326,6 @@ static int api_recompress(HMat *Hp, double epsilon) {
     H.stats.n_false_positive = keep.n_false_positive;
     H.stats.t_compress_s     = keep.t_compress_s;
     return rc;
-#endif
 }
 
 static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const scalar *U, const scalar *V) {

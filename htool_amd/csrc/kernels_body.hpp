@@ -543,12 +543,11 @@ __global__ __launch_bounds__(NT) void fullaca_kernel(DenseCompressArgs A) {
         A.rank_out[b] = q > 0 ? q : (q == -2 ? -2 : 0);
 }
 
-#if !HMX_COMPLEX // LAPACK-backed compressors (SVD, SVD recompression): real coefficients only
 // Cyclic one-sided Jacobi on the columns of W (m x n, column-major): on return the columns are mutually orthogonal
 // (W_out = W_in * Vm, Vm accumulates the rotations, must hold the identity on entry).  The pairs of one round-robin
 // round touch disjoint columns, so each wave rotates one pair; a workgroup barrier separates the rounds.
 template <int NT>
-__device__ void jacobi_orthogonalize(real *W, int m, int n, real *Vm, int *s_changed_ptr) {
+__device__ void jacobi_orthogonalize(scalar *W, int m, int n, scalar *Vm, int *s_changed_ptr) {
     int &s_changed = *s_changed_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = NT / WAVE;
@@ -569,7 +568,42 @@ __device__ void jacobi_orthogonalize(real *W, int m, int n, real *Vm, int *s_cha
                 }
                 if (qq >= n || p == qq)
                     continue;
-                real *wp = W + (int64_t)m * p, *wq = W + (int64_t)m * qq;
+                scalar *wp = W + (int64_t)m * p, *wq = W + (int64_t)m * qq;
+                scalar *vp = Vm + (int64_t)n * p, *vq = Vm + (int64_t)n * qq;
+#if HMX_COMPLEX
+                // complex columns: a^H c = |apq| e^{i phi}; column q is first turned by e^{-i phi}, which makes the inner
+                // product real and positive, then the real rotation applies
+                real app = 0, aqq = 0;
+                scalar apq = scalar(0);
+                for (int i = lane; i < m; i += WAVE) {
+                    const scalar a = wp[i], c = wq[i];
+                    app += a.re * a.re + a.im * a.im;
+                    aqq += c.re * c.re + c.im * c.im;
+                    apq += hmx_conj(a) * c;
+                }
+                app = wave_sum_any(app);
+                aqq = wave_sum_any(aqq);
+                apq = wave_sum(apq);
+                const real absq = hmx_abs(apq);
+                if (absq <= 1e-300 || absq <= 1e-17 * sqrt(app * aqq))
+                    continue;
+                if (absq / sqrt(app * aqq) >= 1e-15 && lane == 0)
+                    s_changed = 1;
+                const scalar ph = hmx_conj(apq) / absq; // e^{-i phi}
+                const real zeta = (aqq - app) / (2.0 * absq);
+                const real t    = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const real cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = lane; i < m; i += WAVE) {
+                    const scalar a = wp[i], c = wq[i] * ph;
+                    wp[i]          = cs * a - sn * c;
+                    wq[i]          = sn * a + cs * c;
+                }
+                for (int i = lane; i < n; i += WAVE) {
+                    const scalar a = vp[i], c = vq[i] * ph;
+                    vp[i]          = cs * a - sn * c;
+                    vq[i]          = sn * a + cs * c;
+                }
+#else
                 real app = 0, aqq = 0, apq = 0;
                 for (int i = lane; i < m; i += WAVE) {
                     const real a = wp[i], c = wq[i];
@@ -592,12 +626,12 @@ __device__ void jacobi_orthogonalize(real *W, int m, int n, real *Vm, int *s_cha
                     wp[i]          = cs * a - sn * c;
                     wq[i]          = sn * a + cs * c;
                 }
-                real *vp = Vm + (int64_t)n * p, *vq = Vm + (int64_t)n * qq;
                 for (int i = lane; i < n; i += WAVE) {
                     const real a = vp[i], c = vq[i];
                     vp[i]          = cs * a - sn * c;
                     vq[i]          = sn * a + cs * c;
                 }
+#endif
             }
             __syncthreads();
         }
@@ -621,32 +655,32 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
     const int M = A.t_size[b], N = A.s_size[b], roff = A.t_off[b], coff = A.s_off[b];
     const bool tr = M < N;
     const int m = tr ? N : M, n = tr ? M : N;
-    real *W   = A.scratch + A.scratch_off[b];
-    real *Vm  = W + (int64_t)m * n;
-    real *sv  = Vm + (int64_t)n * n;
-    real *ord = sv + n;
+    scalar *W  = A.scratch + A.scratch_off[b];
+    scalar *Vm = W + (int64_t)m * n;
+    real *sv   = reinterpret_cast<real *>(Vm + (int64_t)n * n); // n singular values and n order slots live in the 2n scalars behind Vm
+    real *ord  = sv + n;
     int64_t *cross = A.cross_off + A.colptr[b];
     const int cap  = A.colcap[b];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = NT / WAVE;
     for (int64_t e = tid; e < (int64_t)M * N; e += NT) {
         const int i = (int)(e % M), j = (int)(e / M);
-        const real v = A.pre ? A.pre[A.pre_off[b] + e] : (real)eval_kernel(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
+        const scalar v = A.pre ? A.pre[A.pre_off[b] + e] : eval_scalar(A.ks, A.tx[roff + i], A.ty[roff + i], A.tz[roff + i], A.sx[coff + j], A.sy[coff + j], A.sz[coff + j]);
         if (tr)
             W[j + (int64_t)m * i] = v;
         else
             W[i + (int64_t)m * j] = v;
     }
     for (int64_t e = tid; e < (int64_t)n * n; e += NT)
-        Vm[e] = (e % n == e / n) ? 1.0 : 0.0;
+        Vm[e] = (e % n == e / n) ? scalar(1) : scalar(0);
     __syncthreads();
     jacobi_orthogonalize<NT>(W, m, n, Vm, &s_changed);
     // singular values = column norms, descending order by counting
     for (int j = wv; j < n; j += NW) {
         real nn = 0;
         for (int i = lane; i < m; i += WAVE)
-            nn += W[i + (int64_t)m * j] * W[i + (int64_t)m * j];
-        nn = wave_sum(nn);
+            nn += hmx_re(hmx_conj(W[i + (int64_t)m * j]) * W[i + (int64_t)m * j]);
+        nn = wave_sum_any(nn);
         if (lane == 0)
             sv[j] = sqrt(nn);
     }
@@ -694,15 +728,15 @@ __global__ __launch_bounds__(NT) void svd_kernel(DenseCompressArgs A) {
         for (int k = 0; k < r; k++) {
             const int j     = (int)ord[k];
             const real sj = sv[j], isj = sj > 0 ? 1.0 / sj : 0.0;
-            real *u = A.pool + off + (unsigned long long)k * (M + N), *v = u + M;
-            if (!tr) { // A = (W) Vm^T: U(:,k) = u_k s_k = W(:,j), V(k,:) = Vm(:,j)
+            scalar *u = A.pool + off + (unsigned long long)k * (M + N), *v = u + M;
+            if (!tr) { // A = W Vm^H: U(:,k) = u_k s_k = W(:,j), V(k,:) = Vm(:,j)^H
                 for (int i = tid; i < M; i += NT)
                     u[i] = W[i + (int64_t)m * j];
                 for (int c = tid; c < N; c += NT)
-                    v[c] = Vm[c + (int64_t)n * j];
-            } else { // A^T = W Vm^T  =>  A = Vm W^T: U(:,k) = Vm(:,j) s_j, V(k,:) = W(:,j) / s_j
+                    v[c] = hmx_conj(Vm[c + (int64_t)n * j]);
+            } else { // A^T = W Vm^H  =>  A = conj(Vm) W^T: U(:,k) = conj(Vm(:,j)) s_j, V(k,:) = W(:,j)^T / s_j
                 for (int i = tid; i < M; i += NT)
-                    u[i] = Vm[i + (int64_t)n * j] * sj;
+                    u[i] = hmx_conj(Vm[i + (int64_t)n * j]) * sj;
                 for (int c = tid; c < N; c += NT)
                     v[c] = W[c + (int64_t)m * j] * isj;
             }
@@ -725,9 +759,9 @@ struct RecompressArgs {
     const int32_t *t_size, *s_size;
     const int32_t *swapped;
     const int64_t *scratch_off;
-    real *scratch;
+    scalar *scratch;
     double epsilon;
-    real *pool;
+    scalar *pool;
     const int64_t *colptr;
     const int64_t *cross_off;
     int32_t *rank; // in: current rank, out: new rank
@@ -741,43 +775,43 @@ __global__ __launch_bounds__(NT) void recompress_kernel(RecompressArgs A) {
     const bool sw = A.swapped[b] != 0;
     const int n1  = sw ? N : M; // length of the first vector of a cross
     const int64_t *cross = A.cross_off + A.colptr[b];
-    real *Uw = A.scratch + A.scratch_off[b];
-    real *Vw = Uw + (int64_t)M * r;
-    real *Gu = Vw + (int64_t)N * r, *Gv = Gu + r * r, *Cm = Gv + r * r, *Gc = Cm + r * r;
-    real *su = Gc + r * r, *sv = su + r, *sc = sv + r, *ord = sc + r;
+    scalar *Uw = A.scratch + A.scratch_off[b];
+    scalar *Vw = Uw + (int64_t)M * r;
+    scalar *Gu = Vw + (int64_t)N * r, *Gv = Gu + r * r, *Cm = Gv + r * r, *Gc = Cm + r * r;
+    real *su = reinterpret_cast<real *>(Gc + r * r), *sv = su + r, *sc = sv + r, *ord = sc + r; // 4r reals in the 4r scalars behind Gc
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = NT / WAVE;
     for (int k = 0; k < r; k++) {
-        const real *c  = A.pool + cross[k];
-        const real *uk = sw ? c + n1 : c, *vk = sw ? c : c + n1; // U(:,k), V(k,:)
+        const scalar *c  = A.pool + cross[k];
+        const scalar *uk = sw ? c + n1 : c, *vk = sw ? c : c + n1; // U(:,k), V(k,:)
         for (int i = tid; i < M; i += NT)
             Uw[i + (int64_t)M * k] = uk[i];
         for (int j = tid; j < N; j += NT)
             Vw[j + (int64_t)N * k] = vk[j];
     }
     for (int e = tid; e < r * r; e += NT) {
-        Gu[e] = Gv[e] = Gc[e] = (e % r == e / r) ? real(1) : real(0);
+        Gu[e] = Gv[e] = Gc[e] = (e % r == e / r) ? scalar(1) : scalar(0);
     }
     __syncthreads();
     jacobi_orthogonalize<NT>(Uw, M, r, Gu, &s_changed);
     jacobi_orthogonalize<NT>(Vw, N, r, Gv, &s_changed);
     for (int j = wv; j < 2 * r; j += NW) { // column norms of both factors
-        const real *col = j < r ? Uw + (int64_t)M * j : Vw + (int64_t)N * (j - r);
-        const int len   = j < r ? M : N;
+        const scalar *col = j < r ? Uw + (int64_t)M * j : Vw + (int64_t)N * (j - r);
+        const int len     = j < r ? M : N;
         real nn = 0;
         for (int i = lane; i < len; i += WAVE)
-            nn += col[i] * col[i];
-        nn = wave_sum(nn);
+            nn += hmx_re(hmx_conj(col[i]) * col[i]);
+        nn = wave_sum_any(nn);
         if (lane == 0)
             (j < r ? su : sv)[j < r ? j : j - r] = sqrt(nn);
     }
     __syncthreads();
-    // core C = S_u (G_u^T G_v) S_v
+    // U V = Q_u [S_u G_u^H conj(G_v) S_v] Q_v^T  (V^T = Q_v S_v G_v^H): the core C
     for (int e = tid; e < r * r; e += NT) {
         const int i = e % r, j = e / r;
-        real s = 0;
+        scalar s = scalar(0);
         for (int l = 0; l < r; l++)
-            s += Gu[l + r * i] * Gv[l + r * j];
+            s += hmx_conj(Gu[l + r * i]) * hmx_conj(Gv[l + r * j]);
         Cm[e] = su[i] * s * sv[j];
     }
     __syncthreads();
@@ -785,7 +819,7 @@ __global__ __launch_bounds__(NT) void recompress_kernel(RecompressArgs A) {
     for (int j = tid; j < r; j += NT) {
         real nn = 0;
         for (int i = 0; i < r; i++)
-            nn += Cm[i + r * j] * Cm[i + r * j];
+            nn += hmx_re(hmx_conj(Cm[i + r * j]) * Cm[i + r * j]);
         sc[j] = sqrt(nn);
     }
     __syncthreads();
@@ -812,24 +846,24 @@ __global__ __launch_bounds__(NT) void recompress_kernel(RecompressArgs A) {
     const int kr = s_rank;
     if (kr < r) {
         // U'(:,k) = sqrt(s_k) * sum_i Q_u(:,i) u_c(i,k) ,  Q_u(:,i) = Uw(:,i)/su_i ,  u_c(:,k) = Cm(:,jk)/sc_jk
-        // V'(k,:) = sqrt(s_k) * sum_i Gc(i,jk) Q_v(:,i)^T ,  Q_v(:,i) = Vw(:,i)/sv_i
+        // V'(k,:) = sqrt(s_k) * sum_i conj(Gc(i,jk)) Q_v(:,i)^T ,  Q_v(:,i) = Vw(:,i)/sv_i      (C = u_c diag(sc) Gc^H)
         for (int k = 0; k < kr; k++) {
             const int jk   = (int)ord[k];
             const real sk  = sc[jk], rs = sqrt(sk), isk = sk > 0 ? real(1) / sk : real(0);
-            real *c   = A.pool + cross[k];
-            real *uk  = sw ? c + n1 : c, *vk = sw ? c : c + n1;
+            scalar *c   = A.pool + cross[k];
+            scalar *uk  = sw ? c + n1 : c, *vk = sw ? c : c + n1;
             for (int i = tid; i < M; i += NT) {
-                real s = 0;
+                scalar s = scalar(0);
                 for (int l = 0; l < r; l++)
                     if (su[l] > 0)
                         s += Uw[i + (int64_t)M * l] / su[l] * (Cm[l + r * jk] * isk);
                 uk[i] = rs * s;
             }
             for (int j = tid; j < N; j += NT) {
-                real s = 0;
+                scalar s = scalar(0);
                 for (int l = 0; l < r; l++)
                     if (sv[l] > 0)
-                        s += Vw[j + (int64_t)N * l] / sv[l] * Gc[l + r * jk];
+                        s += Vw[j + (int64_t)N * l] / sv[l] * hmx_conj(Gc[l + r * jk]);
                 vk[j] = rs * s;
             }
         }
@@ -838,7 +872,6 @@ __global__ __launch_bounds__(NT) void recompress_kernel(RecompressArgs A) {
     }
 }
 
-#endif // !HMX_COMPLEX
 
 // ---------------------------------------------------------------------------------------------
 // Pack: move compressed data into the matvec streams

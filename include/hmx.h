@@ -176,9 +176,8 @@ int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);
 /* Complex coefficients: the entry points above that carry coefficients, for HMatrix<std::complex<double>> (_z) and
  * HMatrix<std::complex<float>> (_c).  Symmetry 'S' = complex symmetric (mirror pass with trans 'T'), 'H' = Hermitian (mirror pass
  * with trans 'C', hemv on the diagonal leaves): hmatrix/linalg/add_hmatrix_vector_product.hpp:36-54,70.  trans in {'N','T','C'};
- * as in the reference ('T' with 'H' leaves) and ('C' with 'S' leaves) are refused (:59-62).  Compressors: partialACA,
- * sympartialACA, fullACA (conjugated dots as htool's Blas<T>::dot, wrappers/wrapper_blas.hpp:152-157); the LAPACK-backed ones
- * (SVD, recompression) return HMX_ERR_UNSUPPORTED for complex coefficients in this version. */
+ * as in the reference ('T' with 'H' leaves) and ('C' with 'S' leaves) are refused (:59-62).  All compressors and the
+ * recompression are available (conjugated dots as htool's Blas<T>::dot, wrappers/wrapper_blas.hpp:152-157). */
 int hmx_hmatrix_set_callback_z(hmx_hmatrix *, hmx_generator_fn fn, void *user);   /* out: M*N interleaved complex doubles */
 int hmx_hmatrix_set_callback_c(hmx_hmatrix *, hmx_generator_fn_s fn, void *user); /* out: M*N interleaved complex floats */
 int hmx_hmatrix_set_block_lowrank_z(hmx_hmatrix *, int64_t leaf, int rank, const double *U, const double *V);

@@ -933,6 +933,15 @@ int orc_zhmatrix_block(void *h, int b, double *U, double *V, double *D) {
         return -1;
     });
 }
+void orc_zhmatrix_recompress(void *h, double epsilon) {
+    with_z(h, [&](auto &H) {
+        using C = typename std::decay<decltype(H.preorder[0].b->dense[0])>::type;
+        for (auto &l : H.preorder)
+            if (l.b->kind == 2)
+                svd_recompression(l.b->lr, (typename C::value_type)epsilon);
+        return 0;
+    });
+}
 void orc_zhmatrix_matvec(void *h, int policy, char trans, const double *alpha, const double *in, const double *beta, double *out) {
     with_z(h, [&](auto &H) {
         using C        = typename std::decay<decltype(H.preorder[0].b->dense[0])>::type;

@@ -328,52 +328,60 @@ static bool full_aca(const Generator &A, int M, int N, int row_off, int col_off,
     return false;
 }
 
-#if !ORC_COMPLEX // LAPACK-backed compressors: real coefficients only in this round
 // One-sided Jacobi SVD of an M x N column-major matrix, standing in for LAPACK gesvd('A','A')
 // (matrix/utils/SVD_truncation.hpp:30-33).  LAPACK is a third-party dependency absent from
 // /root/reference (vendor/version unpinned); gesvd's published contract -- singular
 // values descending, A = u diag(s) vt -- is what is restated.  Singular vectors are unique only up to
 // sign, so parity on U,V is checked through the product U*V and the singular values.
 // Returns s (min(M,N)), u (M x min) and vt (min x N) -- the thin factors, which is all SVD.hpp uses.
-static void jacobi_svd(int M, int N, const std::vector<real> &Ain, std::vector<real> &s, std::vector<real> &u, std::vector<real> &vt) {
+static void jacobi_svd(int M, int N, const std::vector<scalar> &Ain, std::vector<real> &s, std::vector<scalar> &u, std::vector<scalar> &vt) {
     bool transposed = M < N;
     int m = transposed ? N : M, n = transposed ? M : N; // work on tall m x n
-    std::vector<real> W((size_t)m * n), Vm((size_t)n * n, 0.);
+    std::vector<scalar> W((size_t)m * n), Vm((size_t)n * n, scalar(0));
     for (int i = 0; i < M; i++)
         for (int j = 0; j < N; j++) {
-            real v = Ain[i + (size_t)M * j];
+            scalar v = Ain[i + (size_t)M * j];
             if (transposed)
                 W[j + (size_t)m * i] = v;
             else
                 W[i + (size_t)m * j] = v;
         }
     for (int i = 0; i < n; i++)
-        Vm[i + (size_t)n * i] = 1.;
+        Vm[i + (size_t)n * i] = scalar(1);
     for (int sweep = 0; sweep < 60; sweep++) {
         real off = 0;
         for (int p = 0; p < n - 1; p++)
             for (int q = p + 1; q < n; q++) {
-                real *wp = &W[(size_t)m * p], *wq = &W[(size_t)m * q];
-                real app = 0, aqq = 0, apq = 0;
+                scalar *wp = &W[(size_t)m * p], *wq = &W[(size_t)m * q];
+                real app = 0, aqq = 0;
+                scalar apq = scalar(0);
                 for (int i = 0; i < m; i++) {
-                    app += wp[i] * wp[i];
-                    aqq += wq[i] * wq[i];
-                    apq += wp[i] * wq[i];
+                    app += re_part(cj(wp[i]) * wp[i]);
+                    aqq += re_part(cj(wq[i]) * wq[i]);
+                    apq += cj(wp[i]) * wq[i];
                 }
-                if (std::abs(apq) <= 1e-300 || std::abs(apq) <= 1e-17 * std::sqrt(app * aqq))
+                const real absq = std::abs(apq);
+                if (absq <= 1e-300 || absq <= 1e-17 * std::sqrt(app * aqq))
                     continue;
-                off          = std::max(off, std::abs(apq) / std::sqrt(app * aqq));
-                real zeta  = (aqq - app) / (2. * apq);
-                real t     = (zeta >= 0 ? 1. : -1.) / (std::abs(zeta) + std::sqrt(1. + zeta * zeta));
-                real cs    = 1. / std::sqrt(1. + t * t), sn = cs * t;
+                off = std::max(off, absq / std::sqrt(app * aqq));
+#if ORC_COMPLEX
+                // turn column q by e^{-i phi} (a^H c = |apq| e^{i phi}) so that the inner product is real and positive
+                const scalar ph = cj(apq) / absq;
+                const real zeta = (aqq - app) / (real(2) * absq);
+#else
+                const scalar ph = scalar(1);
+                const real zeta = (aqq - app) / (2. * apq);
+#endif
+                real t  = (zeta >= 0 ? 1. : -1.) / (std::abs(zeta) + std::sqrt(1. + zeta * zeta));
+                real cs = 1. / std::sqrt(1. + t * t), sn = cs * t;
                 for (int i = 0; i < m; i++) {
-                    real a = wp[i], b = wq[i];
+                    scalar a = wp[i], b = wq[i] * ph;
                     wp[i] = cs * a - sn * b;
                     wq[i] = sn * a + cs * b;
                 }
-                real *vp = &Vm[(size_t)n * p], *vq = &Vm[(size_t)n * q];
+                scalar *vp = &Vm[(size_t)n * p], *vq = &Vm[(size_t)n * q];
                 for (int i = 0; i < n; i++) {
-                    real a = vp[i], b = vq[i];
+                    scalar a = vp[i], b = vq[i] * ph;
                     vp[i] = cs * a - sn * b;
                     vq[i] = sn * a + cs * b;
                 }
@@ -386,27 +394,27 @@ static void jacobi_svd(int M, int N, const std::vector<real> &Ain, std::vector<r
     for (int j = 0; j < n; j++) {
         real nn = 0;
         for (int i = 0; i < m; i++)
-            nn += W[i + (size_t)m * j] * W[i + (size_t)m * j];
+            nn += re_part(cj(W[i + (size_t)m * j]) * W[i + (size_t)m * j]);
         sv[j] = std::sqrt(nn);
     }
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sv[a] > sv[b]; });
     int k = n; // = min(M,N)
     s.resize(k);
-    u.assign((size_t)M * k, 0.);
-    vt.assign((size_t)k * N, 0.);
+    u.assign((size_t)M * k, scalar(0));
+    vt.assign((size_t)k * N, scalar(0));
     for (int jj = 0; jj < k; jj++) {
         int j     = order[jj];
         s[jj]     = sv[j];
         real is = sv[j] > 0 ? 1. / sv[j] : 0.;
-        if (!transposed) { // A = (W/s) s Vm^T
+        if (!transposed) { // A = (W/s) s Vm^H
             for (int i = 0; i < M; i++)
                 u[i + (size_t)M * jj] = W[i + (size_t)m * j] * is;
             for (int c = 0; c < N; c++)
-                vt[jj + (size_t)k * c] = Vm[c + (size_t)n * j];
-        } else { // A^T = (W/s) s Vm^T  =>  A = Vm s (W/s)^T
+                vt[jj + (size_t)k * c] = cj(Vm[c + (size_t)n * j]);
+        } else { // A^T = (W/s) s Vm^H  =>  A = conj(Vm) s (W/s)^T
             for (int i = 0; i < M; i++)
-                u[i + (size_t)M * jj] = Vm[i + (size_t)n * j];
+                u[i + (size_t)M * jj] = cj(Vm[i + (size_t)n * j]);
             for (int c = 0; c < N; c++)
                 vt[jj + (size_t)k * c] = W[c + (size_t)m * j] * is;
         }
@@ -416,9 +424,10 @@ static void jacobi_svd(int M, int N, const std::vector<real> &Ain, std::vector<r
 // hmatrix/lrmat/SVD.hpp:27-62 (auto) and :64-92 (fixed rank); truncation rule
 // matrix/utils/SVD_truncation.hpp:37-52
 static bool svd_compress(const Generator &A, int M, int N, int row_off, int col_off, real epsilon, int reqrank, LowRank &lr, std::vector<real> *sing_out = nullptr) {
-    std::vector<real> mat((size_t)M * N);
+    std::vector<scalar> mat((size_t)M * N);
     A.copy_submatrix(M, N, row_off, col_off, mat.data());
-    std::vector<real> s, u, vt;
+    std::vector<real> s;
+    std::vector<scalar> u, vt;
     jacobi_svd(M, N, mat, s, u, vt);
     if (sing_out)
         *sing_out = s;
@@ -468,47 +477,48 @@ static bool svd_compress(const Generator &A, int M, int N, int row_off, int col_
 // U = Q1 R (geqrf), V = L Q2 (gelqf), SVD(R L) = u S vt, truncation (SVD_truncation.hpp:37-52), and only if the rank
 // drops: U' = Q1 (u sqrt(S)), V' = (sqrt(S) vt) Q2.  LAPACK's Householder QR/LQ are restated by two-pass modified
 // Gram-Schmidt (explicit thin Q); the r x r SVD by the Jacobi routine above.
-static void thin_qr(int m, int r, const std::vector<real> &A, std::vector<real> &Q, std::vector<real> &R) { // A m x r col-major
+static void thin_qr(int m, int r, const std::vector<scalar> &A, std::vector<scalar> &Q, std::vector<scalar> &R) { // A m x r col-major
     Q = A;
-    R.assign((size_t)r * r, real(0));
+    R.assign((size_t)r * r, scalar(0));
     for (int j = 0; j < r; j++) {
         for (int pass = 0; pass < 2; pass++)
             for (int i = 0; i < j; i++) {
-                real d = 0;
+                scalar d = scalar(0);
                 for (int k = 0; k < m; k++)
-                    d += Q[k + (size_t)m * i] * Q[k + (size_t)m * j];
+                    d += cj(Q[k + (size_t)m * i]) * Q[k + (size_t)m * j];
                 R[i + (size_t)r * j] += d;
                 for (int k = 0; k < m; k++)
                     Q[k + (size_t)m * j] -= d * Q[k + (size_t)m * i];
             }
         real nn = 0;
         for (int k = 0; k < m; k++)
-            nn += Q[k + (size_t)m * j] * Q[k + (size_t)m * j];
+            nn += re_part(cj(Q[k + (size_t)m * j]) * Q[k + (size_t)m * j]);
         nn                  = std::sqrt(nn);
-        R[j + (size_t)r * j] = nn;
+        R[j + (size_t)r * j] = scalar(nn);
         for (int k = 0; k < m; k++)
-            Q[k + (size_t)m * j] = nn > 0 ? Q[k + (size_t)m * j] / nn : real(0);
+            Q[k + (size_t)m * j] = nn > 0 ? Q[k + (size_t)m * j] / nn : scalar(0);
     }
 }
 static void svd_recompression(LowRank &lr, real epsilon) {
     const int M = lr.M, N = lr.N, r = lr.rank;
     if (r <= 0 || r > std::min(M, N))
         return;
-    std::vector<real> Q1, R, Vt((size_t)N * r), Q2t, Rv;
+    std::vector<scalar> Q1, R, Vt((size_t)N * r), Q2t, Rv;
     thin_qr(M, r, lr.U, Q1, R);
     for (int k = 0; k < r; k++)
         for (int j = 0; j < N; j++)
             Vt[j + (size_t)N * k] = lr.V[k + (size_t)r * j];
     thin_qr(N, r, Vt, Q2t, Rv); // V^T = Q2^T Rv  =>  V = Rv^T Q2 = L Q2
-    std::vector<real> RL((size_t)r * r, real(0)); // R * L, L = Rv^T
+    std::vector<scalar> RL((size_t)r * r, scalar(0)); // R * L, L = Rv^T
     for (int i = 0; i < r; i++)
         for (int j = 0; j < r; j++) {
-            real s = 0;
+            scalar s = scalar(0);
             for (int l = 0; l < r; l++)
                 s += R[i + (size_t)r * l] * Rv[j + (size_t)r * l];
             RL[i + (size_t)r * j] = s;
         }
-    std::vector<real> s, u, vt;
+    std::vector<real> s;
+    std::vector<scalar> u, vt;
     jacobi_svd(r, r, RL, s, u, vt);
     int k;
     {
@@ -525,11 +535,11 @@ static void svd_recompression(LowRank &lr, real epsilon) {
     }
     if (k >= r)
         return;
-    std::vector<real> nU((size_t)M * k, real(0)), nV((size_t)k * N, real(0));
+    std::vector<scalar> nU((size_t)M * k, scalar(0)), nV((size_t)k * N, scalar(0));
     for (int c = 0; c < k; c++) {
         const real rs = std::sqrt(s[c]);
         for (int l = 0; l < r; l++) {
-            const real cu = u[l + (size_t)r * c] * rs, cv = vt[c + (size_t)r * l] * rs;
+            const scalar cu = u[l + (size_t)r * c] * rs, cv = vt[c + (size_t)r * l] * rs;
             for (int i = 0; i < M; i++)
                 nU[i + (size_t)M * c] += Q1[i + (size_t)M * l] * cu;
             for (int j = 0; j < N; j++)
@@ -542,7 +552,6 @@ static void svd_recompression(LowRank &lr, real epsilon) {
     lr.pivots.clear(); // the ACA pivots no longer describe these factors
 }
 
-#endif // !ORC_COMPLEX
 
 enum Compressor { PARTIAL_ACA = 0,
                   SYMPARTIAL_ACA = 1,
@@ -558,11 +567,7 @@ static bool compress(int kind, const Generator &A, int M, int N, int ro, int co,
     case FULL_ACA:
         return full_aca(A, M, N, ro, co, eps, reqrank, lr);
     default:
-#if ORC_COMPLEX
-        return false;
-#else
         return svd_compress(A, M, N, ro, co, eps, reqrank, lr);
-#endif
     }
 }
 

@@ -72,6 +72,7 @@ def lib():
         L.orc_zhmatrix_leaves.argtypes = [C.c_void_p, C.c_int, ip]
         L.orc_zhmatrix_rootinfo.argtypes = [C.c_void_p, ip]
         L.orc_zhmatrix_block.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
+        L.orc_zhmatrix_recompress.argtypes = [C.c_void_p, C.c_double]
         L.orc_zhmatrix_matvec.argtypes = [C.c_void_p, C.c_int, C.c_char, dp, dp, dp, dp]
         L.orc_zhmatrix_matmat_row_major.argtypes = [C.c_void_p, C.c_char, dp, dp, dp, dp, C.c_int]
         L.orc_zgenerate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double,
@@ -229,6 +230,11 @@ class ZHMatrix:
         D = np.empty((n, m), dtype=np.complex128)
         lib().orc_zhmatrix_block(self.h, b, None, None, _zp(D))
         return D.T
+
+    def recompress(self, epsilon):
+        lib().orc_zhmatrix_recompress(self.h, float(epsilon))
+        lib().orc_zhmatrix_leaves(self.h, 0, _ip(self.leaves))
+        lib().orc_zhmatrix_leaves(self.h, 1, _ip(self.leaves_dfs))
 
     def matvec(self, x, trans="N", alpha=1.0, beta=0.0, y=None, policy="seq"):
         nout = self.rootinfo[1] if trans == "N" else self.rootinfo[3]

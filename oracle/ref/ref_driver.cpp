@@ -330,9 +330,8 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     auto t2           = std::chrono::steady_clock::now();
     HM H = local >= 0 ? tb.sequential_build(A, tct.get_cluster_on_partition(local), sct.get_cluster_on_partition(local))
                       : (par ? tb.openmp_build(A, tct, sct, rank, rank) : tb.sequential_build(A, tct, sct, rank, rank));
-    if constexpr (!is_cplx<T>::value)
-        if (geti(kv, "recompress", 0))
-            recompression(H); // hmatrix/utils/recompression.hpp:8-13 (SVD_recompression of every low-rank leaf)
+    if (geti(kv, "recompress", 0))
+        recompression(H); // hmatrix/utils/recompression.hpp:8-13 (SVD_recompression of every low-rank leaf) // hmatrix/utils/recompression.hpp:8-13 (SVD_recompression of every low-rank leaf)
     auto t3           = std::chrono::steady_clock::now();
 
     // Leaves in natural preorder (children in creation order)

@@ -69,6 +69,9 @@ CASES = {
     "ball_n2000_z64_p2_hermL_rank0": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-3, partitions=2, rank=0, sym="H", uplo="L", compressor="sympartialACA", prec="z64", dump_blocks=1)),
     "rect_ball1500_disk1000_z64": ("hmat", dict(n=1500, nsrc=1000, geom="ball", sgeom="disk", sz=2.5, leaf=60, eps=1e-4, compressor="partialACA", prec="z64", dump_blocks=1)),
     "ball_n1200_z64_fullACA": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="fullACA", prec="z64", dump_blocks=1)),
+    "ball_n1200_z64_SVD": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="SVD", prec="z64", dump_blocks=1)),
+    "ball_n2000_z64_hermU_recompressed": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-4, sym="H", uplo="U", compressor="sympartialACA", prec="z64", recompress=1, dump_blocks=1)),
+    "ellipse_n3000_c32_recompressed": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, compressor="partialACA", prec="c32", recompress=1, dump_blocks=1)),
     "ball_n1200_z64_reqrank5": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, reqrank=5, compressor="partialACA", prec="z64", dump_blocks=1)),
     # block-diagonal (local-to-local) operator rooted at the partition clusters: DefaultLocalApproximationBuilder
     "ellipse_n4000_p4_local2": ("hmat", dict(n=4000, geom="ellipse", leaf=100, partitions=4, local=2, eps=1e-4, compressor="partialACA", dump_blocks=1)),

@@ -173,6 +173,8 @@ def build_zoracle(name):
         S = O.ClusterTree(O.geometry(p["sgeom"], p["nsrc"], p["sz"]), p["leaf"], p["children"], p["partitions"], p["partitioning"])
     H = O.ZHMatrix(T, S, delta=p["delta"], scale=p["scale"], cre=p["cre"], cim=p["cim"], eps=p["eps"], eta=p["eta"], sym=p["sym"],
                    uplo=p["uplo"], reqrank=p["reqrank"], compressor=p["compressor"], rank=p["rank"], c32=p["prec"] == "c32")
+    if p["recompress"]:
+        H.recompress(p["eps"])
     return p, T, S, H
 
 
@@ -186,12 +188,15 @@ def test_complex_oracle_against_reference(name):
     c32 = p["prec"] == "c32"
     assert np.array_equal(H.leaves[:, :4], g["leaves"][:, :4]) and np.array_equal(H.leaves[:, 5], g["leaves"][:, 5])
     assert np.array_equal(H.leaves[:, 4] < 0, g["leaves"][:, 4] < 0)
-    if c32:
+    svd_like = p["compressor"] == "SVD" or p["recompress"]  # Jacobi vs LAPACK: same truncation rule, +-1 at the threshold
+    if c32 or svd_like:
         assert np.abs(H.leaves[:, 4] - g["leaves"][:, 4]).max() <= 2 and (H.leaves[:, 4] != g["leaves"][:, 4]).mean() < 0.05
     else:
         assert np.array_equal(H.leaves[:, 4], g["leaves"][:, 4])
     assert np.array_equal(H.rootinfo, g["rootinfo"])
     ptol, vtol = (2e-5, 1e-5) if c32 else (1e-9, 1e-12)
+    if svd_like:
+        vtol = max(vtol, 5e-4)  # a rank differing by one at the threshold changes the product by O(eps)
     for k in g:
         if k.startswith("D_"):
             assert np.array_equal(H.block(int(k[2:])), g[k].T)
