@@ -11,6 +11,8 @@
 //                                      DistributedOperator::add_global_to_local_operator
 //                                      (distributed_operator/distributed_operator.hpp:47-53); products run on the GPU
 //   Engine::upload(const HMatrix&)     htool-compressed leaves (any VirtualGenerator / compressor) -> device streams
+// Every class is a template on htool's CoefficientPrecision T in {double, float, std::complex<double>, std::complex<float>}
+// (EngineT<T>, DeviceLowRankGeneratorT<T>, ...); the un-suffixed names are the double instantiations.
 #ifndef HMX_HTOOL_ADAPTOR_HPP
 #define HMX_HTOOL_ADAPTOR_HPP
 
@@ -23,6 +25,7 @@
 #include <htool/misc/logger.hpp>
 
 #include <algorithm>
+#include <complex>
 #include <map>
 #include <mutex>
 #include <string>
@@ -41,6 +44,61 @@ inline bool ok(int rc, const char *what) {
     return true;
 }
 
+// The C entry points of one coefficient type (include/hmx.h: plain, _s, _z, _c).  Complex values cross the ABI as interleaved
+// (re, im) pairs, which is the layout of std::complex<T>.
+template <typename T>
+struct Abi;
+template <>
+struct Abi<double> {
+    using R = double;
+    static int create(const hmx_block_tree *bt, int dev, hmx_hmatrix **h) { return hmx_hmatrix_create(bt, dev, h); }
+    static int set_callback(hmx_hmatrix *h, void (*fn)(void *, int, int, const int32_t *, const int32_t *, R *), void *u) { return hmx_hmatrix_set_callback(h, fn, u); }
+    static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const double *U, const double *V) { return hmx_hmatrix_set_block_lowrank(h, leaf, r, U, V); }
+    static int set_dense(hmx_hmatrix *h, int64_t leaf, const double *D) { return hmx_hmatrix_set_block_dense(h, leaf, D); }
+    static int get_block(const hmx_hmatrix *h, int64_t leaf, double *U, double *V) { return hmx_hmatrix_get_block(h, leaf, U, V); }
+    static int matvec(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out) { return hmx_hmatrix_matvec(h, tr, a, in, b, out, HMX_MEM_HOST, nullptr); }
+    static int matmat(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out, int mu) { return hmx_hmatrix_matmat_row_major(h, tr, a, in, b, out, mu, HMX_MEM_HOST, nullptr); }
+};
+template <>
+struct Abi<float> {
+    using R = float;
+    static int create(const hmx_block_tree *bt, int dev, hmx_hmatrix **h) { return hmx_hmatrix_create_s(bt, dev, h); }
+    static int set_callback(hmx_hmatrix *h, void (*fn)(void *, int, int, const int32_t *, const int32_t *, R *), void *u) { return hmx_hmatrix_set_callback_s(h, fn, u); }
+    static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const float *U, const float *V) { return hmx_hmatrix_set_block_lowrank_s(h, leaf, r, U, V); }
+    static int set_dense(hmx_hmatrix *h, int64_t leaf, const float *D) { return hmx_hmatrix_set_block_dense_s(h, leaf, D); }
+    static int get_block(const hmx_hmatrix *h, int64_t leaf, float *U, float *V) { return hmx_hmatrix_get_block_s(h, leaf, U, V); }
+    static int matvec(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out) { return hmx_hmatrix_matvec_s(h, tr, a, in, b, out, HMX_MEM_HOST, nullptr); }
+    static int matmat(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out, int mu) { return hmx_hmatrix_matmat_row_major_s(h, tr, a, in, b, out, mu, HMX_MEM_HOST, nullptr); }
+};
+template <>
+struct Abi<std::complex<double>> {
+    using R = double;
+    using Z = std::complex<double>;
+    static const double *p(const Z *v) { return reinterpret_cast<const double *>(v); }
+    static double *p(Z *v) { return reinterpret_cast<double *>(v); }
+    static int create(const hmx_block_tree *bt, int dev, hmx_hmatrix **h) { return hmx_hmatrix_create_z(bt, dev, h); }
+    static int set_callback(hmx_hmatrix *h, void (*fn)(void *, int, int, const int32_t *, const int32_t *, R *), void *u) { return hmx_hmatrix_set_callback_z(h, fn, u); }
+    static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const Z *U, const Z *V) { return hmx_hmatrix_set_block_lowrank_z(h, leaf, r, p(U), p(V)); }
+    static int set_dense(hmx_hmatrix *h, int64_t leaf, const Z *D) { return hmx_hmatrix_set_block_dense_z(h, leaf, p(D)); }
+    static int get_block(const hmx_hmatrix *h, int64_t leaf, Z *U, Z *V) { return hmx_hmatrix_get_block_z(h, leaf, p(U), p(V)); }
+    static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out) { return hmx_hmatrix_matvec_z(h, tr, p(&a), p(in), p(&b), p(out), HMX_MEM_HOST, nullptr); }
+    static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu) { return hmx_hmatrix_matmat_row_major_z(h, tr, p(&a), p(in), p(&b), p(out), mu, HMX_MEM_HOST, nullptr); }
+};
+template <>
+struct Abi<std::complex<float>> {
+    using R = float;
+    using Z = std::complex<float>;
+    static const float *p(const Z *v) { return reinterpret_cast<const float *>(v); }
+    static float *p(Z *v) { return reinterpret_cast<float *>(v); }
+    static int create(const hmx_block_tree *bt, int dev, hmx_hmatrix **h) { return hmx_hmatrix_create_c(bt, dev, h); }
+    static int set_callback(hmx_hmatrix *h, void (*fn)(void *, int, int, const int32_t *, const int32_t *, R *), void *u) { return hmx_hmatrix_set_callback_c(h, fn, u); }
+    static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const Z *U, const Z *V) { return hmx_hmatrix_set_block_lowrank_c(h, leaf, r, p(U), p(V)); }
+    static int set_dense(hmx_hmatrix *h, int64_t leaf, const Z *D) { return hmx_hmatrix_set_block_dense_c(h, leaf, p(D)); }
+    static int get_block(const hmx_hmatrix *h, int64_t leaf, Z *U, Z *V) { return hmx_hmatrix_get_block_c(h, leaf, p(U), p(V)); }
+    static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out) { return hmx_hmatrix_matvec_c(h, tr, p(&a), p(in), p(&b), p(out), HMX_MEM_HOST, nullptr); }
+    static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu) { return hmx_hmatrix_matmat_row_major_c(h, tr, p(&a), p(in), p(&b), p(out), mu, HMX_MEM_HOST, nullptr); }
+};
+
 struct ClusterOptions { // the arguments the caller gave to htool's ClusterTreeBuilder
     int maximal_leaf_size  = 10;
     int number_of_children = 2;
@@ -50,7 +108,8 @@ struct ClusterOptions { // the arguments the caller gave to htool's ClusterTreeB
     bool partitioning_n    = false;
 };
 
-class Engine {
+template <typename T>
+class EngineT {
     hmx_cluster_tree *m_target = nullptr, *m_source = nullptr;
     hmx_block_tree *m_block_tree = nullptr;
     hmx_hmatrix *m_hmatrix       = nullptr;
@@ -69,20 +128,20 @@ class Engine {
     }
 
   public:
-    Engine(const htool::Cluster<double> &target, int nt, const double *xt, const htool::Cluster<double> &source, int ns, const double *xs, int dim, const ClusterOptions &opt) {
+    EngineT(const htool::Cluster<double> &target, int nt, const double *xt, const htool::Cluster<double> &source, int ns, const double *xs, int dim, const ClusterOptions &opt) {
         m_square = (&target == &source);
         m_target = make_tree(nt, dim, xt, opt, target);
         m_source = m_square ? m_target : make_tree(ns, dim, xs, opt, source);
     }
-    ~Engine() {
+    ~EngineT() {
         hmx_hmatrix_destroy(m_hmatrix);
         hmx_block_tree_destroy(m_block_tree);
         if (!m_square)
             hmx_cluster_tree_destroy(m_source);
         hmx_cluster_tree_destroy(m_target);
     }
-    Engine(const Engine &)            = delete;
-    Engine &operator=(const Engine &) = delete;
+    EngineT(const EngineT &)            = delete;
+    EngineT &operator=(const EngineT &) = delete;
 
     // same arguments as HMatrixTreeBuilder's constructor + build() (hmatrix/tree_builder/tree_builder.hpp:180-210)
     bool setup_block_tree(double eta, char symmetry, char UPLO, int min_target_depth, int min_source_depth, int target_partition_number, int partition_number_for_symmetry, int device) {
@@ -92,7 +151,7 @@ class Engine {
         hmx_block_tree_leaves(m_block_tree, m_leaves.data());
         for (size_t b = 0; b < m_leaves.size(); b++)
             m_leaf_of[std::make_tuple(m_leaves[b].t_offset, m_leaves[b].t_size, m_leaves[b].s_offset, m_leaves[b].s_size)] = (int64_t)b;
-        return ok(hmx_hmatrix_create(m_block_tree, device, &m_hmatrix), "device H-matrix"); // needs a GPU: no CPU path
+        return ok(Abi<T>::create(m_block_tree, device, &m_hmatrix), "device H-matrix"); // needs a GPU: no CPU path
     }
 
     // device compression with a built-in kernel (the generator must be the same function as the user's VirtualGenerator)
@@ -100,21 +159,21 @@ class Engine {
         return ok(hmx_hmatrix_set_kernel(m_hmatrix, kernel, params, nparams, dim, xt, xs), "set kernel") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
     }
 
-    // compression on the device with the USER's generator: htool::VirtualGenerator<double>::copy_submatrix is called on
+    // compression on the device with the USER's generator: htool::VirtualGenerator<T>::copy_submatrix is called on
     // the host for one cross row / column per block and ACA iteration (and for the dense leaves); the ACA arithmetic
     // and every later product run on the GPU.  `A` must outlive this call only.
-    bool compress_with_generator(const htool::VirtualGenerator<double> &A, int compressor, double epsilon, int reqrank) {
-        auto thunk = [](void *user, int M, int N, const int32_t *rows, const int32_t *cols, double *out) {
-            static_cast<const htool::VirtualGenerator<double> *>(user)->copy_submatrix(M, N, rows, cols, out);
+    bool compress_with_generator(const htool::VirtualGenerator<T> &A, int compressor, double epsilon, int reqrank) {
+        auto thunk = [](void *user, int M, int N, const int32_t *rows, const int32_t *cols, typename Abi<T>::R *out) {
+            static_cast<const htool::VirtualGenerator<T> *>(user)->copy_submatrix(M, N, rows, cols, reinterpret_cast<T *>(out));
         };
-        return ok(hmx_hmatrix_set_callback(m_hmatrix, thunk, const_cast<htool::VirtualGenerator<double> *>(&A)), "set callback") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
+        return ok(Abi<T>::set_callback(m_hmatrix, thunk, const_cast<htool::VirtualGenerator<T> *>(&A)), "set callback") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
     }
 
     // htool-built H-matrix (any generator, any compressor) -> device
-    bool upload(const htool::HMatrix<double> &H) {
-        std::vector<const htool::HMatrix<double> *> stack{&H};
+    bool upload(const htool::HMatrix<T> &H) {
+        std::vector<const htool::HMatrix<T> *> stack{&H};
         while (!stack.empty()) {
-            const htool::HMatrix<double> *cur = stack.back();
+            const htool::HMatrix<T> *cur = stack.back();
             stack.pop_back();
             if (cur->is_leaf()) {
                 auto it = m_leaf_of.find(std::make_tuple(cur->get_target_cluster().get_offset(), cur->get_target_cluster().get_size(), cur->get_source_cluster().get_offset(), cur->get_source_cluster().get_size()));
@@ -124,10 +183,10 @@ class Engine {
                 }
                 if (cur->is_low_rank()) {
                     const auto &lr = *cur->get_low_rank_data();
-                    if (!ok(hmx_hmatrix_set_block_lowrank(m_hmatrix, it->second, lr.rank_of(), lr.get_U().data(), lr.get_V().data()), "upload low rank"))
+                    if (!ok(Abi<T>::set_lowrank(m_hmatrix, it->second, lr.rank_of(), lr.get_U().data(), lr.get_V().data()), "upload low rank"))
                         return false;
                 } else if (cur->is_dense()) {
-                    if (!ok(hmx_hmatrix_set_block_dense(m_hmatrix, it->second, cur->get_dense_data()->data()), "upload dense"))
+                    if (!ok(Abi<T>::set_dense(m_hmatrix, it->second, cur->get_dense_data()->data()), "upload dense"))
                         return false;
                 }
             }
@@ -144,18 +203,20 @@ class Engine {
         return it == m_leaf_of.end() ? -1 : it->second;
     }
 };
+using Engine = EngineT<double>;
 
 // Plugged in with HMatrixTreeBuilder::set_low_rank_generator(std::shared_ptr<VirtualInternalLowRankGenerator>)
 // (hmatrix/tree_builder/tree_builder.hpp:251-254).  Called concurrently from OpenMP threads (tree_builder.hpp:606-617).
-class DeviceLowRankGenerator final : public htool::VirtualInternalLowRankGenerator<double> {
-    const Engine &m_engine;
+template <typename T>
+class DeviceLowRankGeneratorT final : public htool::VirtualInternalLowRankGenerator<T> {
+    const EngineT<T> &m_engine;
     mutable std::mutex m_mutex;
     mutable std::vector<int32_t> m_ranks;
 
   public:
-    explicit DeviceLowRankGenerator(const Engine &engine) : m_engine(engine) {}
+    explicit DeviceLowRankGeneratorT(const EngineT<T> &engine) : m_engine(engine) {}
 
-    bool copy_low_rank_approximation(int M, int N, int row_offset, int col_offset, htool::LowRankMatrix<double> &lrmat) const override {
+    bool copy_low_rank_approximation(int M, int N, int row_offset, int col_offset, htool::LowRankMatrix<T> &lrmat) const override {
         const int64_t leaf = m_engine.find_leaf(row_offset, M, col_offset, N);
         if (leaf < 0)
             return false; // unknown block -> htool falls back to a dense block (tree_builder.hpp:572-577)
@@ -171,56 +232,61 @@ class DeviceLowRankGenerator final : public htool::VirtualInternalLowRankGenerat
             return false; // compressor failed on the device as well
         lrmat.get_U().resize(M, r);
         lrmat.get_V().resize(r, N);
-        return ok(hmx_hmatrix_get_block(m_engine.hmatrix(), leaf, lrmat.get_U().data(), lrmat.get_V().data()), "get block");
+        return ok(Abi<T>::get_block(m_engine.hmatrix(), leaf, lrmat.get_U().data(), lrmat.get_V().data()), "get block");
     }
-    bool copy_low_rank_approximation(int M, int N, int row_offset, int col_offset, int, htool::LowRankMatrix<double> &lrmat) const override {
+    bool copy_low_rank_approximation(int M, int N, int row_offset, int col_offset, int, htool::LowRankMatrix<T> &lrmat) const override {
         return copy_low_rank_approximation(M, N, row_offset, col_offset, lrmat); // the device build already used reqrank
     }
 };
+using DeviceLowRankGenerator = DeviceLowRankGeneratorT<double>;
 
 // Plugged in with HMatrixTreeBuilder::set_dense_blocks_generator (hmatrix/tree_builder/tree_builder.hpp:258):
 // htool hands over ALL dense leaves in one batched call (tree_builder.hpp:585-600) with zero-filled destinations;
 // they are filled from the blocks the device assembled.
-class DeviceDenseBlocksGenerator final : public htool::VirtualDenseBlocksGenerator<double> {
-    const Engine &m_engine;
+template <typename T>
+class DeviceDenseBlocksGeneratorT final : public htool::VirtualDenseBlocksGenerator<T> {
+    const EngineT<T> &m_engine;
 
   public:
-    explicit DeviceDenseBlocksGenerator(const Engine &engine) : m_engine(engine) {}
-    void copy_dense_blocks(const std::vector<int> &M, const std::vector<int> &N, const std::vector<int> &rows, const std::vector<int> &cols, std::vector<double *> &ptr) const override {
+    explicit DeviceDenseBlocksGeneratorT(const EngineT<T> &engine) : m_engine(engine) {}
+    void copy_dense_blocks(const std::vector<int> &M, const std::vector<int> &N, const std::vector<int> &rows, const std::vector<int> &cols, std::vector<T *> &ptr) const override {
         for (size_t b = 0; b < ptr.size(); b++) {
             const int64_t leaf = m_engine.find_leaf(rows[b], M[b], cols[b], N[b]);
             if (leaf < 0) {
                 htool::Logger::get_instance().log(htool::LogLevel::ERROR, "[hmx] dense block not present in the hmx block tree");
                 continue;
             }
-            ok(hmx_hmatrix_get_block(m_engine.hmatrix(), leaf, ptr[b], nullptr), "get dense block");
+            ok(Abi<T>::get_block(m_engine.hmatrix(), leaf, ptr[b], nullptr), "get dense block");
         }
     }
 };
+using DeviceDenseBlocksGenerator = DeviceDenseBlocksGeneratorT<double>;
 
 // Same contract as RestrictedGlobalToLocalHMatrix (distributed_operator/implementations/global_to_local_operators/hmatrix.hpp:15-35)
 // for a local H-matrix whose source cluster is the whole source tree.
-class GlobalToLocalHmx final : public htool::VirtualGlobalToLocalOperator<double> {
-    const Engine &m_engine;
+template <typename T>
+class GlobalToLocalHmxT final : public htool::VirtualGlobalToLocalOperator<T> {
+    const EngineT<T> &m_engine;
     int m_source_size;
 
   public:
-    GlobalToLocalHmx(const Engine &engine, int source_size) : m_engine(engine), m_source_size(source_size) {}
-    void add_vector_product(char trans, double alpha, const double *const in, double beta, double *const out) const override {
-        ok(hmx_hmatrix_matvec(m_engine.hmatrix(), trans, alpha, in, beta, out, HMX_MEM_HOST, nullptr), "matvec");
+    GlobalToLocalHmxT(const EngineT<T> &engine, int source_size) : m_engine(engine), m_source_size(source_size) {}
+    void add_vector_product(char trans, T alpha, const T *const in, T beta, T *const out) const override {
+        ok(Abi<T>::matvec(m_engine.hmatrix(), trans, alpha, in, beta, out), "matvec");
     }
-    void add_matrix_product_row_major(char trans, double alpha, const double *const in, double beta, double *const out, int mu) const override {
-        ok(hmx_hmatrix_matmat_row_major(m_engine.hmatrix(), trans, alpha, in, beta, out, mu, HMX_MEM_HOST, nullptr), "matmat");
+    void add_matrix_product_row_major(char trans, T alpha, const T *const in, T beta, T *const out, int mu) const override {
+        ok(Abi<T>::matmat(m_engine.hmatrix(), trans, alpha, in, beta, out, mu), "matmat");
     }
-    void add_sub_matrix_product_to_local(const double *const in, double *const out, int mu, int offset, int size) const override {
+    void add_sub_matrix_product_to_local(const T *const in, T *const out, int mu, int offset, int size) const override {
         // restricted_operator.hpp:170-193: zero-extend the sub-vector to the whole source range
-        std::vector<double> temp((size_t)m_source_size * mu, 0.0);
+        std::vector<T> temp((size_t)m_source_size * mu, T(0));
         const int lo = std::max(offset, 0), hi = std::min(offset + size, m_source_size);
         if (hi > lo)
             std::copy_n(in + (size_t)(lo - offset) * mu, (size_t)(hi - lo) * mu, temp.data() + (size_t)lo * mu);
-        ok(hmx_hmatrix_matmat_row_major(m_engine.hmatrix(), 'N', 1.0, temp.data(), 1.0, out, mu, HMX_MEM_HOST, nullptr), "sub matmat");
+        ok(Abi<T>::matmat(m_engine.hmatrix(), 'N', T(1), temp.data(), T(1), out, mu), "sub matmat");
     }
 };
+using GlobalToLocalHmx = GlobalToLocalHmxT<double>;
 
 } // namespace hmx_htool
 #endif

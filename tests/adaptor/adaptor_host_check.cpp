@@ -6,6 +6,7 @@
 #include <htool/hmatrix/lrmat/partialACA.hpp>
 #include <htool/testing/geometry.hpp>
 #include "hmx/htool_adaptor.hpp"
+#include <complex>
 #include <cstdio>
 using namespace htool;
 class Gen : public VirtualGenerator<double> {
@@ -21,7 +22,57 @@ class Gen : public VirtualGenerator<double> {
             }
     }
 };
+// complex instantiation: Hermitian htool H-matrix mirrored leaf for leaf; the plugin classes must be constructible
+// (i.e. implement every pure virtual of htool's interfaces for std::complex<double>)
+class GenZ : public VirtualGenerator<std::complex<double>> {
+    const std::vector<double> &x;
+  public:
+    explicit GenZ(const std::vector<double> &x_) : x(x_) {}
+    void copy_submatrix(int M, int N, const int *rows, const int *cols, std::complex<double> *ptr) const override {
+        for (int j = 0; j < M; j++)
+            for (int k = 0; k < N; k++) {
+                double s = 0;
+                for (int p = 0; p < 3; p++) { double d = x[3 * rows[j] + p] - x[3 * cols[k] + p]; s = s + d * d; }
+                const double u = x[3 * rows[j]] - x[3 * cols[k]];
+                ptr[j + (size_t)M * k] = std::complex<double>(1., u > 0 ? 1. : (u < 0 ? -1. : 0.)) / (1e-5 + std::sqrt(s));
+            }
+    }
+};
+static int check_complex() {
+    using Z = std::complex<double>;
+    const int n = 1500;
+    std::vector<double> x(3 * n);
+    create_sphere(n, x.data());
+    ClusterTreeBuilder<double> ctb;
+    ctb.set_maximal_leaf_size(50);
+    Cluster<double> T = ctb.create_cluster_tree(n, 3, x.data(), 2, 2);
+    GenZ A(x);
+    HMatrixTreeBuilder<Z> tb(1e-3, 10., 'H', 'U');
+    HMatrix<Z> H = tb.sequential_build(A, T, T);
+    hmx_htool::ClusterOptions opt;
+    opt.maximal_leaf_size = 50; opt.number_of_children = 2; opt.size_of_partition = 2;
+    hmx_htool::EngineT<Z> E(T, n, x.data(), T, n, x.data(), 3, opt);
+    bool device = E.setup_block_tree(10., 'H', 'U', 0, 0, -1, -1, 0);
+    hmx_htool::DeviceLowRankGeneratorT<Z> lrgen(E);
+    hmx_htool::DeviceDenseBlocksGeneratorT<Z> dgen(E);
+    hmx_htool::GlobalToLocalHmxT<Z> op(E, n);
+    (void)lrgen; (void)dgen; (void)op;
+    size_t nleaves = 0, missing = 0;
+    std::vector<const HMatrix<Z> *> st{&H};
+    while (!st.empty()) {
+        auto *c = st.back(); st.pop_back();
+        if (c->is_leaf()) {
+            nleaves++;
+            if (E.find_leaf(c->get_target_cluster().get_offset(), c->get_target_cluster().get_size(), c->get_source_cluster().get_offset(), c->get_source_cluster().get_size()) < 0) missing++;
+        }
+        for (auto &ch : c->get_children()) st.push_back(ch.get());
+    }
+    std::printf("complex: htool_leaves=%zu hmx_leaves=%zu missing=%zu device=%d\n", nleaves, E.number_of_leaves(), missing, (int)device);
+    return (missing == 0 && nleaves == E.number_of_leaves()) ? 0 : 1;
+}
 int main() {
+    if (check_complex() != 0)
+        return 2;
     const int n = 3000;
     std::vector<double> x(3 * n);
     create_rotated_ellipse(3, 4., 1., 0., 0., n, x.data());
