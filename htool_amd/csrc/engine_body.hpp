@@ -905,7 +905,16 @@ static int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t 
     return HMX_OK;
 }
 
+static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqrank, bool full_pool);
 static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
+    // The cross pool is first sized from a rank estimate (allocations beyond a few tens of GB take seconds on this
+    // platform: tools/malloc_timing.hip); if a block runs out of pool the compression is repeated with the full budget.
+    int rc = api_compress_impl(Hp, compressor, epsilon, reqrank, false);
+    if (rc == 1)
+        rc = api_compress_impl(Hp, compressor, epsilon, reqrank, true);
+    return rc;
+}
+static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqrank, bool full_pool) {
     if (!Hp) {
         set_error("hmx_hmatrix_compress: NULL handle");
         return HMX_ERR_INVALID;
@@ -936,8 +945,11 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     std::vector<int32_t> colcap(nb, 0);
     std::vector<int64_t> visptr(nb, 0);
     int64_t ncross = 0, nvis = 0;
-    double need = 0;
+    double need = 0, estimate = 0;
     constexpr int RANK_CAP = 4096;
+    // expected rank of an admissible block: grows like log(1/eps) for the asymptotically smooth kernels H-matrices are for
+    const double rank_guess = getenv("HMX_POOL_RANK_GUESS") ? atof(getenv("HMX_POOL_RANK_GUESS"))
+                              : (reqrank > 0 ? (double)reqrank : std::max(16.0, 8.0 + 3.0 * std::log10(1.0 / std::max(epsilon, 1e-16))));
     for (size_t b = 0; b < nb; b++) {
         const hmx_leaf &l = H.leaves[b];
         if (!l.admissible) {
@@ -957,6 +969,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
         visptr[b] = nvis;
         nvis += M + N;
         need += (double)qmax * (double)(M + N);
+        estimate += std::min((double)qmax, rank_guess) * (double)(M + N);
     }
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
         const int64_t sa = (int64_t)H.leaves[a].t_size + H.leaves[a].s_size, sb = (int64_t)H.leaves[b].t_size + H.leaves[b].s_size;
@@ -965,7 +978,7 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hipMemGetInfo(&free_b, &total_b));
     const double budget        = 0.40 * (double)free_b / sizeof(scalar);
-    const unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(need, budget));
+    const unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : 1.25 * estimate));
     HMX_HIP(H.pool.alloc(cap));
     DArr<unsigned long long> head;
     HMX_HIP(head.alloc(1));
@@ -1204,6 +1217,8 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     int64_t false_pos = 0;
     for (int32_t b : order) {
         if (ranks[b] == -2) {
+            if (!full_pool)
+                return 1; // the rank estimate was too low: repeat with the whole budget
             set_error("hmx_hmatrix_compress: compression pool exhausted (not enough free HBM)");
             return HMX_ERR_HIP;
         }
@@ -1219,6 +1234,16 @@ static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     for (size_t b = 0; b < nb; b++)
         if (H.kind[b] != LK_LOWRANK)
             H.leaves[b].rank = -1;
+    if ((double)H.pool.n > 1.5 * (double)H.pool_used + 1024) { // give the unused part of the pool back
+        DArr<scalar> exact;
+        if (exact.alloc(std::max<size_t>((size_t)H.pool_used, 1)) == hipSuccess) {
+            HMX_HIP(hipMemcpy(exact.d, H.pool.d, (size_t)H.pool_used * sizeof(scalar), hipMemcpyDeviceToDevice));
+            std::swap(exact.d, H.pool.d);
+            std::swap(exact.n, H.pool.n);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (use_cb) { // dense leaves (and failed admissible ones): HMatrix::compute_dense_data through the host generator
         int64_t tot = 0;
         for (size_t b = 0; b < nb; b++)

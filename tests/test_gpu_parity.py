@@ -568,3 +568,18 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
             Y = Y0.copy()
             hm.internal_add_hmatrix_matrix_product_row_major("T", 1.5, H, X, -0.5, Y, mu)
             assert rel_err(Y, Ho.matmat_row_major(X, "T", 1.5, -0.5, Y0)) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["ellipse_n3000_partial", "ball_n1500_eps1e-12", "ball_n1200_fullACA"])
+def test_pool_estimate_too_low_is_retried(name, monkeypatch):
+    """The cross pool is sized from a rank estimate; when a block runs out of pool the compression is repeated with the
+    whole budget and gives the same operator."""
+    p, g = params(name), load(name)
+    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "1")
+    T, S, H = build_engine(p)
+    assert np.array_equal(H.leaf_table(), g["leaves"])
+    x, xT, y0, y0T = inputs(H)
+    alpha, beta = g["alphabeta"][:2]
+    y = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+    assert rel_err(y, g["yN"]) < 1e-10
