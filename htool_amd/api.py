@@ -144,6 +144,10 @@ class ClusterTreeBuilder:
     def __init__(self):
         self._leaf = 10  # htool default (tree_builder.hpp:25)
         self._direction, self._splitting, self._n = "largest_extent", "regular", False
+        self._complete = False
+
+    def set_is_complete(self, is_complete):
+        self._complete = bool(is_complete)
 
     def set_maximal_leaf_size(self, n):
         self._leaf = int(n)
@@ -155,16 +159,33 @@ class ClusterTreeBuilder:
         self._direction, self._splitting, self._n = direction, splitting, bool(partitioning_n)
 
     def create_cluster_tree(self, number_of_points, spatial_dimension, coordinates, number_of_children, size_of_partition,
-                            radii=None, weights=None):
+                            radii=None, weights=None, partition=None, is_given_partition_local=False):
         x = np.ascontiguousarray(coordinates, dtype=np.float64).reshape(number_of_points, spatial_dimension)
         r = None if radii is None else np.ascontiguousarray(radii, dtype=np.float64)
         w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        part = None if partition is None else np.ascontiguousarray(partition, dtype=np.int32)
+        kind = 0 if part is None else (2 if is_given_partition_local else 1)
+        if part is not None and part.size != (2 * size_of_partition if kind == 2 else number_of_points):
+            raise HmxError("partition must hold one part number per point (global) or (offset, size) per part (local)")
         h = C.c_void_p()
-        check(lib().hmx_cluster_tree_create(number_of_points, spatial_dimension, _dp(x), None if r is None else _dp(r),
-                                            None if w is None else _dp(w), self._leaf, number_of_children,
-                                            size_of_partition, _lib.DIRECTIONS[self._direction],
-                                            _lib.SPLITTINGS[self._splitting], int(self._n), C.byref(h)))
+        check(lib().hmx_cluster_tree_create_ex(number_of_points, spatial_dimension, _dp(x), None if r is None else _dp(r),
+                                               None if w is None else _dp(w), self._leaf, number_of_children,
+                                               size_of_partition, _lib.DIRECTIONS[self._direction],
+                                               _lib.SPLITTINGS[self._splitting], int(self._n), int(self._complete),
+                                               None if part is None else part.ctypes.data_as(C.POINTER(C.c_int32)), kind, C.byref(h)))
         return Cluster(h, x)
+
+    def create_cluster_tree_from_global_partition(self, number_of_points, spatial_dimension, coordinates, number_of_children,
+                                                  size_of_partition, partition):
+        """tree_builder.hpp:46: partition[i] = part of point i."""
+        return self.create_cluster_tree(number_of_points, spatial_dimension, coordinates, number_of_children, size_of_partition,
+                                        partition=partition, is_given_partition_local=False)
+
+    def create_cluster_tree_from_local_partition(self, number_of_points, spatial_dimension, coordinates, number_of_children,
+                                                 size_of_partition, partition):
+        """tree_builder.hpp:48: partition[2p], partition[2p+1] = offset and size of part p (points already grouped)."""
+        return self.create_cluster_tree(number_of_points, spatial_dimension, coordinates, number_of_children, size_of_partition,
+                                        partition=partition, is_given_partition_local=True)
 
 
 class InvDistGenerator:

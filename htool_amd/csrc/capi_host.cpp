@@ -53,6 +53,32 @@ int hmx_cluster_tree_create(int n, int dim, const double *coords, const double *
     *out = T;
     return HMX_OK;
 }
+int hmx_cluster_tree_create_ex(int n, int dim, const double *coords, const double *radii, const double *weights, int maximal_leaf_size,
+                               int number_of_children, int size_of_partition, int direction, int splitting, int partitioning_n,
+                               int is_complete, const int32_t *partition, int partition_kind, hmx_cluster_tree **out) {
+    if (!out) {
+        hmx::set_error("hmx_cluster_tree_create_ex: out is NULL");
+        return HMX_ERR_INVALID;
+    }
+    hmx::ClusterTreeOptions opt;
+    opt.maximal_leaf_size  = maximal_leaf_size;
+    opt.number_of_children = number_of_children;
+    opt.size_of_partition  = size_of_partition;
+    opt.direction          = direction;
+    opt.splitting          = splitting;
+    opt.partitioning_n     = partitioning_n != 0;
+    opt.is_complete        = is_complete != 0;
+    auto *T                = new (std::nothrow) hmx_cluster_tree();
+    if (!T)
+        return HMX_ERR_INVALID;
+    const int rc = hmx::build_cluster_tree(n, dim, coords, radii, weights, opt, *T, partition, partition_kind);
+    if (rc != HMX_OK) {
+        delete T;
+        return rc;
+    }
+    *out = T;
+    return HMX_OK;
+}
 void hmx_cluster_tree_destroy(hmx_cluster_tree *T) { delete T; }
 int hmx_cluster_tree_size(const hmx_cluster_tree *T) { return T ? T->n : 0; }
 int hmx_cluster_tree_num_nodes(const hmx_cluster_tree *T) { return T ? (int)T->nodes.size() : 0; }

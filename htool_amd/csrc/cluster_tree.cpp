@@ -405,9 +405,13 @@ void parallel_for(int count, int max_threads, F &&body) {
 } // namespace
 
 int build_cluster_tree(int n, int dim, const double *coords, const double *radii, const double *weights,
-                       const ClusterTreeOptions &opt, hmx_cluster_tree &T) {
+                       const ClusterTreeOptions &opt, hmx_cluster_tree &T, const int32_t *partition, int partition_kind) {
     if (n <= 0 || (dim != 2 && dim != 3) || !coords || opt.number_of_children < 2 || opt.size_of_partition < 1 || opt.maximal_leaf_size < 1) {
         set_error("hmx_cluster_tree_create: invalid arguments (dim must be 2 or 3, children >= 2)");
+        return HMX_ERR_INVALID;
+    }
+    if (partition_kind < 0 || partition_kind > 2 || (partition_kind != 0 && !partition)) {
+        set_error("hmx_cluster_tree_create: invalid partition arguments");
         return HMX_ERR_INVALID;
     }
     T.n   = n;
@@ -441,6 +445,63 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
 
     const int hw = std::max(1u, std::thread::hardware_concurrency());
     std::vector<int> level{0};
+    const bool given = partition_kind != 0;
+    if (given) {
+        // user-given partition (tree_builder.hpp:87-123): the root's children ARE the parts; every part is then split by the
+        // strategy like any other cluster (no node is "above the partition level" any more)
+        partition_depth = -1000;
+        std::vector<int> offs(sp), sizes(sp);
+        if (partition_kind == 2) {
+            for (int p = 0; p < sp; p++) {
+                offs[p]  = partition[2 * p];
+                sizes[p] = partition[2 * p + 1];
+                if (offs[p] < 0 || sizes[p] < 0 || (int64_t)offs[p] + sizes[p] > n) {
+                    set_error("hmx_cluster_tree_create: local partition out of range");
+                    return HMX_ERR_INVALID;
+                }
+            }
+            T.permutation_is_local = true;
+        } else {
+            int cpt    = 0;
+            bool local = true;
+            for (int p = 0; p < sp; p++) {
+                offs[p]  = cpt;
+                sizes[p] = 0;
+                int prev = -1;
+                for (int i = 0; i < n; i++)
+                    if (partition[i] == p) {
+                        T.perm[cpt++] = i;
+                        sizes[p]++;
+                        local = local && (prev < 0 || prev == i - 1);
+                        prev  = i;
+                    }
+            }
+            if (cpt != n) {
+                set_error("hmx_cluster_tree_create: global partition must map every point to a part in [0, size_of_partition)");
+                return HMX_ERR_INVALID;
+            }
+            T.permutation_is_local = local;
+        }
+        level.clear();
+        T.nodes[0].first_child = 1;
+        T.nodes[0].n_children  = sp;
+        for (int p = 0; p < sp; p++) {
+            ClusterNode ch;
+            ch.parent = 0;
+            ch.depth  = 1;
+            ch.offset = offs[p];
+            ch.size   = sizes[p];
+            B.centroid(ch.offset, ch.size, ch.center);
+            ch.radius  = B.bounding_radius(ch.offset, ch.size, ch.center);
+            ch.rank    = p;
+            ch.counter = p;
+            T.nodes.push_back(ch);
+            T.on_partition.push_back(p + 1);
+            level.push_back(p + 1);
+        }
+        if (sp == 1)
+            T.permutation_is_local = true; // tree_builder.hpp:143-145
+    }
     while (!level.empty()) {
         // split every node of this level concurrently: slices of the permutation are disjoint
         std::vector<Parts> parts(level.size());
@@ -490,8 +551,16 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
                         T.on_partition.resize(ch.rank + 1, -1);
                     T.on_partition[ch.rank] = id;
                 }
-                if (ch.size > opt.maximal_leaf_size)
+                if (!opt.is_complete && ch.size > opt.maximal_leaf_size)
                     next.push_back(id);
+            }
+            if (opt.is_complete) { // complete tree: all children are split, or none (tree_builder.hpp:176-182)
+                bool any = false;
+                for (auto &ch : kids[li])
+                    any = any || ch.size > opt.maximal_leaf_size;
+                if (any)
+                    for (int q = 0; q < (int)kids[li].size(); q++)
+                        next.push_back(first + q);
             }
         }
         level.swap(next);

@@ -31,6 +31,7 @@ struct ClusterTreeOptions {
     int direction          = HMX_DIR_LARGEST_EXTENT;
     int splitting          = HMX_SPLIT_REGULAR;
     bool partitioning_n    = false;
+    bool is_complete       = false; // ClusterTreeBuilder::set_is_complete (tree_builder.hpp:26,39,176-192)
 };
 
 } // namespace hmx
@@ -63,8 +64,10 @@ struct hmx_block_tree {
 
 namespace hmx {
 void set_error(const std::string &msg);
+// partition_kind: 0 none ("simple" partition from size_of_partition), 1 global (partition[i] = part of point i),
+// 2 local (partition[2p], partition[2p+1] = offset, size of part p) -- tree_builder.hpp:87-123
 int build_cluster_tree(int n, int dim, const double *coords, const double *radii, const double *weights,
-                       const ClusterTreeOptions &opt, hmx_cluster_tree &out);
+                       const ClusterTreeOptions &opt, hmx_cluster_tree &out, const int32_t *partition = nullptr, int partition_kind = 0);
 int build_block_tree(hmx_block_tree &bt);
 void make_geometry(const std::string &name, int n, double z, double *coords);
 // io.cpp: htool's CSV formats

@@ -94,6 +94,13 @@ int hmx_cluster_tree_create(int n, int dim, const double *coords /* n*dim, AoS *
                             const double *weights /* n or NULL */, int maximal_leaf_size, int number_of_children,
                             int size_of_partition, int direction, int splitting, int partitioning_n,
                             hmx_cluster_tree **out);
+/* The full signature of ClusterTreeBuilder::create_cluster_tree (tree_builder.hpp:42,52-207): is_complete
+ * (set_is_complete, :39,176-192) and a user-given partition -- partition_kind 1 = create_cluster_tree_from_global_partition
+ * (partition[i] = part of point i, :46), 2 = create_cluster_tree_from_local_partition (partition[2p], [2p+1] = offset, size of
+ * part p, :48), 0 = none. */
+int hmx_cluster_tree_create_ex(int n, int dim, const double *coords, const double *radii, const double *weights, int maximal_leaf_size,
+                               int number_of_children, int size_of_partition, int direction, int splitting, int partitioning_n,
+                               int is_complete, const int32_t *partition, int partition_kind, hmx_cluster_tree **out);
 void hmx_cluster_tree_destroy(hmx_cluster_tree *);
 int hmx_cluster_tree_size(const hmx_cluster_tree *);            /* number of points                         */
 int hmx_cluster_tree_num_nodes(const hmx_cluster_tree *);

@@ -467,7 +467,9 @@ static Split compute_partitioning(const Strategy &st, Cluster &c, int dim, const
 }
 
 // tree_builder.hpp:52-207, "Simple" partition type only (no user-given partition)
-static std::unique_ptr<ClusterTree> create_cluster_tree(int n, int dim, const double *x, int leaf_size, int nchildren, int size_partition, const Strategy &st) {
+// partition / partition_kind: user-given partition (tree_builder.hpp:87-123): 1 = global (one part number per point),
+// 2 = local ((offset, size) per part); is_complete: set_is_complete (tree_builder.hpp:176-192)
+static std::unique_ptr<ClusterTree> create_cluster_tree(int n, int dim, const double *x, int leaf_size, int nchildren, int size_partition, const Strategy &st, const int *partition = nullptr, int partition_kind = 0, bool is_complete = false) {
     auto tree = std::make_unique<ClusterTree>();
     std::vector<double> radii(n, 0.), weights(n, 1.);
     auto center      = compute_center(dim, x, weights.data(), 0, n, nullptr);
@@ -498,13 +500,48 @@ static std::unique_ptr<ClusterTree> create_cluster_tree(int n, int dim, const do
     } else {
         depth_of_partition = 1;
     }
+    const bool given = partition && partition_kind != 0;
+    if (given) {
+        depth_of_partition = 1;
+        stack.pop();
+        std::vector<int> offsets(size_partition), sizes(size_partition);
+        if (partition_kind == 2) {
+            tree->td.perm_local = true;
+            for (int p = 0; p < size_partition; p++) {
+                offsets[p] = partition[2 * p];
+                sizes[p]   = partition[2 * p + 1];
+            }
+        } else {
+            int cpt    = 0;
+            bool local = true;
+            for (int p = 0; p < size_partition; p++) {
+                offsets[p] = cpt;
+                sizes[p]   = 0;
+                int prev   = -1;
+                for (int i = 0; i < n; i++)
+                    if (partition[i] == p) {
+                        perm[cpt] = i;
+                        sizes[p]++;
+                        cpt++;
+                        local = local && (prev < 0 || prev == i - 1);
+                        prev  = i;
+                    }
+            }
+            tree->td.perm_local = local;
+        }
+        for (int p = 0; p < size_partition; p++) {
+            center = compute_center(dim, x, weights.data(), offsets[p], sizes[p], perm.data());
+            radius = compute_radius(dim, x, radii.data(), center, offsets[p], sizes[p], perm.data());
+            stack.push(root.add_child(radius, center, p, offsets[p], sizes[p], p, true));
+        }
+    }
     if (size_partition == 1)
         tree->td.perm_local = true;
 
     while (!stack.empty()) {
         Cluster *cur = stack.top();
         stack.pop();
-        bool on_level = (cur->depth == depth_of_partition - 1);
+        bool on_level = !given && (cur->depth == depth_of_partition - 1);
         int k         = on_level ? nchildren_on_partition_level : nchildren;
         if (on_level && cur->counter == std::pow(nchildren, cur->depth) - 1)
             k += additional_children;
@@ -524,9 +561,15 @@ static std::unique_ptr<ClusterTree> create_cluster_tree(int n, int dim, const do
                 }
                 children.push_back(cur->add_child(radius, center, rank_of_child, split[p].first, split[p].second, cnt, on_part));
             }
-            for (auto *ch : children)
-                if (ch->size > leaf_size)
-                    stack.push(ch);
+            if (is_complete) {
+                if (std::any_of(children.begin(), children.end(), [&](Cluster *a) { return a->size > leaf_size; }))
+                    for (auto *ch : children)
+                        stack.push(ch);
+            } else {
+                for (auto *ch : children)
+                    if (ch->size > leaf_size)
+                        stack.push(ch);
+            }
         }
     }
     return tree;
@@ -583,6 +626,10 @@ void orc_geometry(const char *name, int n, double z, double *out) {
 void *orc_cluster_create(int n, int dim, const double *coords, int leaf, int children, int partitions, int direction, int splitting, int partition_n) {
     Strategy st{direction, splitting, partition_n};
     return create_cluster_tree(n, dim, coords, leaf, children, partitions, st).release();
+}
+void *orc_cluster_create_ex(int n, int dim, const double *coords, int leaf, int children, int partitions, int direction, int splitting, int partition_n, const int *partition, int partition_kind, int is_complete) {
+    Strategy st{direction, splitting, partition_n};
+    return create_cluster_tree(n, dim, coords, leaf, children, partitions, st, partition, partition_kind, is_complete != 0).release();
 }
 void orc_cluster_destroy(void *h) { delete static_cast<ClusterTree *>(h); }
 static void preorder_nodes(const Cluster &c, const std::function<void(const Cluster &)> &f) {

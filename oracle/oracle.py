@@ -40,6 +40,8 @@ def lib():
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
         L.orc_cluster_create.restype = C.c_void_p
         L.orc_cluster_create.argtypes = [C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_cluster_create_ex.restype = C.c_void_p
+        L.orc_cluster_create_ex.argtypes = [C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int]
         L.orc_cluster_destroy.argtypes = [C.c_void_p]
         L.orc_cluster_num_nodes.argtypes = [C.c_void_p]
         L.orc_cluster_num_partitions.argtypes = [C.c_void_p]
@@ -96,11 +98,18 @@ def geometry(name, n, z=0.0):
 
 
 class ClusterTree:
-    def __init__(self, coords, leaf=100, children=2, partitions=2, partitioning="pca_regular"):
+    def __init__(self, coords, leaf=100, children=2, partitions=2, partitioning="pca_regular", given_partition=None, given_local=False,
+                 is_complete=False):
+        """given_partition: one part number per point (global) or (offset, size) per part (given_local=True)."""
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         n, dim = self.coords.shape
         d, s, pn = PARTITIONINGS[partitioning]
-        self.h = lib().orc_cluster_create(n, dim, _dp(self.coords), leaf, children, partitions, d, s, pn)
+        if given_partition is None and not is_complete:
+            self.h = lib().orc_cluster_create(n, dim, _dp(self.coords), leaf, children, partitions, d, s, pn)
+        else:
+            gp = None if given_partition is None else np.ascontiguousarray(given_partition, dtype=np.int32)
+            self.h = lib().orc_cluster_create_ex(n, dim, _dp(self.coords), leaf, children, partitions, d, s, pn,
+                                                 None if gp is None else _ip(gp), 0 if gp is None else (2 if given_local else 1), int(is_complete))
         nn = lib().orc_cluster_num_nodes(self.h)
         npart = lib().orc_cluster_num_partitions(self.h)
         self.perm = np.empty(n, dtype=np.int32)
@@ -314,6 +323,16 @@ def read_dump(path):
         p += cnt * np.dtype(np_dt).itemsize
         out[name] = arr.copy()
     return out
+
+
+def given_partition(kind, n, parts):
+    """The closed-form user partitions oracle/ref/ref_driver.cpp uses (option given=global|local)."""
+    if kind == "global":
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        return ((((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(7)) % np.uint64(parts)).astype(np.int32)
+    lo = (np.arange(parts, dtype=np.int64) * n) // parts
+    hi = (np.arange(1, parts + 1, dtype=np.int64) * n) // parts
+    return np.stack([lo, hi - lo], axis=1).ravel().astype(np.int32)
 
 
 def hashed_vector(n, salt):

@@ -295,8 +295,28 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     ClusterTreeBuilder<double> ctb;
     ctb.set_maximal_leaf_size(leaf);
     ctb.set_partitioning_strategy(make_partitioning(partstr));
+    if (geti(kv, "complete", 0))
+        ctb.set_is_complete(true);
+    // user-given partitions (tree_builder.hpp:46-48): "global" = a scattered assignment point -> part (hash of the index),
+    // "local" = contiguous chunks given as (offset, size)
+    const std::string given = gets(kv, "given", "none");
+    std::vector<int> given_partition;
+    if (given == "global") {
+        given_partition.resize(n);
+        for (int i = 0; i < n; i++)
+            given_partition[i] = (int)(((uint32_t)(i + 1) * 2654435761u >> 7) % (uint32_t)partitions);
+    } else if (given == "local") {
+        given_partition.resize(2 * partitions);
+        for (int p = 0; p < partitions; p++) {
+            const int lo = (int)((long long)n * p / partitions), hi = (int)((long long)n * (p + 1) / partitions);
+            given_partition[2 * p]     = lo;
+            given_partition[2 * p + 1] = hi - lo;
+        }
+    }
     auto t0             = std::chrono::steady_clock::now();
-    Cluster<double> tct = ctb.create_cluster_tree(n, dim, xt.data(), children, partitions);
+    Cluster<double> tct = given == "global" ? ctb.create_cluster_tree_from_global_partition(n, dim, xt.data(), children, partitions, given_partition.data())
+                          : given == "local" ? ctb.create_cluster_tree_from_local_partition(n, dim, xt.data(), children, partitions, given_partition.data())
+                                             : ctb.create_cluster_tree(n, dim, xt.data(), children, partitions);
     auto t1             = std::chrono::steady_clock::now();
     std::unique_ptr<Cluster<double>> sct_store;
     if (!square)

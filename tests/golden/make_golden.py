@@ -47,6 +47,12 @@ CASES = {
     "ball_n2000_n_pca_c4": ("hmat", dict(n=2000, geom="ball", leaf=50, children=4, partitions=4, eps=1e-3, partitioning="n_pca_regular", dump_blocks=0)),
     "ball_n2000_n_bbox_c8": ("hmat", dict(n=2000, geom="ball", leaf=30, children=8, partitions=8, eps=1e-3, partitioning="n_bbox_regular", dump_blocks=0)),
     "ellipse_n2000_c3_p3": ("hmat", dict(n=2000, geom="ellipse", leaf=50, children=3, partitions=3, eps=1e-3, dump_blocks=0)),
+    # user-given partitions (create_cluster_tree_from_{global,local}_partition) and complete trees (set_is_complete)
+    "ball_n2000_given_global_p3": ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=3, eps=1e-3, given="global", dump_blocks=0)),
+    "ellipse_n2000_given_local_p4": ("hmat", dict(n=2000, geom="ellipse", leaf=50, partitions=4, eps=1e-3, given="local", dump_blocks=0)),
+    "ball_n2000_given_global_p4_rank2": ("hmat", dict(n=2000, geom="ball", leaf=50, partitions=4, rank=2, eps=1e-3, given="global", dump_blocks=0)),
+    "ball_n2000_complete": ("hmat", dict(n=2000, geom="ball", leaf=60, eps=1e-3, complete=1, dump_blocks=0)),
+    "ellipse_n1500_complete_c3": ("hmat", dict(n=1500, geom="ellipse", leaf=40, children=3, partitions=3, eps=1e-3, complete=1, dump_blocks=0)),
     # 2-D point cloud (solve_EVP_2 branch), non-consistent block tree, near-full-rank accuracy
     "disk2d_n2000": ("hmat", dict(n=2000, geom="disk2d", leaf=50, eps=1e-4, eta=10, compressor="partialACA")),
     "disk2d_n2000_bbox_symL": ("hmat", dict(n=2000, geom="disk2d", leaf=50, eps=1e-4, eta=5, sym="S", uplo="L", compressor="sympartialACA", partitioning="bbox_regular")),

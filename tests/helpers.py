@@ -17,7 +17,7 @@ LRMAT_CASES = sorted(k for k, v in MANIFEST.items() if v["mode"] == "lrmat")
 
 DEFAULTS = dict(nsrc=0, geom="ellipse", sz=0.0, leaf=100, children=2, partitions=2, partitioning="pca_regular", eps=1e-4,
                 eta=10.0, sym="N", uplo="N", compressor="partialACA", delta=1e-5, scale=1.0, mindepth=0, rank=-1,
-                reqrank=-1, alpha=3.0, beta=2.0, consistent=1, prec="f64", local=-1, recompress=0, cre=1.0, cim=1.0)
+                reqrank=-1, alpha=3.0, beta=2.0, consistent=1, prec="f64", local=-1, recompress=0, cre=1.0, cim=1.0, given="none", complete=0)
 
 
 def load(name):

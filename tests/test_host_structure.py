@@ -12,12 +12,28 @@ STRATEGY = {"pca_regular": ("largest_extent", "regular", False), "pca_geometric"
             "n_pca_regular": ("largest_extent", "regular", True), "n_bbox_regular": ("bounding_box", "regular", True)}
 
 
+def _given_partition(kind, n, parts):
+    if kind == "global":
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        return ((((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(7)) % np.uint64(parts)).astype(np.int32)
+    lo = (np.arange(parts, dtype=np.int64) * n) // parts
+    hi = (np.arange(1, parts + 1, dtype=np.int64) * n) // parts
+    return np.stack([lo, hi - lo], axis=1).ravel().astype(np.int32)
+
+
 def build_trees(p):
     b = hm.ClusterTreeBuilder()
     b.set_maximal_leaf_size(p["leaf"])
     b.set_partitioning_strategy(*STRATEGY[p["partitioning"]])
+    b.set_is_complete(bool(p["complete"]))
     xt = hm.create_geometry(p["geom"], p["n"])
-    T = b.create_cluster_tree(p["n"], p["dim"], xt, p["children"], p["partitions"])
+    n, P = p["n"], p["partitions"]
+    if p["given"] == "global":  # the same closed-form assignment as oracle/ref/ref_driver.cpp
+        T = b.create_cluster_tree_from_global_partition(n, p["dim"], xt, p["children"], P, _given_partition("global", n, P))
+    elif p["given"] == "local":
+        T = b.create_cluster_tree_from_local_partition(n, p["dim"], xt, p["children"], P, _given_partition("local", n, P))
+    else:
+        T = b.create_cluster_tree(n, p["dim"], xt, p["children"], P)
     if p["nsrc"]:
         xs = hm.create_geometry(p["sgeom"], p["nsrc"], p["sz"])
         S = b.create_cluster_tree(p["nsrc"], p["dim"], xs, p["children"], p["partitions"])

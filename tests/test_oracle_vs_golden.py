@@ -14,7 +14,9 @@ from oracle import oracle as O
 def build_oracle(name):
     p = params(name)
     xt = O.geometry(p["geom"], p["n"])
-    T = O.ClusterTree(xt, p["leaf"], p["children"], p["partitions"], p["partitioning"])
+    gp = O.given_partition(p["given"], p["n"], p["partitions"]) if p["given"] != "none" else None
+    T = O.ClusterTree(xt, p["leaf"], p["children"], p["partitions"], p["partitioning"], given_partition=gp, given_local=p["given"] == "local",
+                      is_complete=bool(p["complete"]))
     if p["nsrc"]:
         xs = O.geometry(p["sgeom"], p["nsrc"], p["sz"])
         S = O.ClusterTree(xs, p["leaf"], p["children"], p["partitions"], p["partitioning"])
@@ -76,7 +78,7 @@ def test_payload_and_matvec(name):
             assert np.array_equal(H.block(int(k[2:])), g[k].T)  # kernel entries bit-exact
     nr, nc = H.rootinfo[1], H.rootinfo[3]
     x, xT, y0, y0T = O.hashed_vector(nc, 1), O.hashed_vector(nr, 2), O.hashed_vector(nr, 3), O.hashed_vector(nc, 4)
-    alpha, beta = g["alphabeta"]
+    alpha, beta = g["alphabeta"][:2]
     tol = 1e-12 if p["compressor"] != "SVD" else 5e-4
     assert rel_err(H.matvec(x, "N", alpha, beta, y0), g["yN"]) < tol
     assert rel_err(H.matvec(xT, "T", alpha, beta, y0T), g["yT"]) < tol
@@ -156,7 +158,7 @@ def test_fp32_oracle_against_reference(name):
             assert rel_err(U @ V, g[k].T @ g["V_%d" % b].T) < 2e-5
     nr, nc = H.rootinfo[1], H.rootinfo[3]
     f = lambda n, s: O.hashed_vector(n, s).astype(np.float32).astype(np.float64)
-    alpha, beta = g["alphabeta"]
+    alpha, beta = g["alphabeta"][:2]
     assert rel_err(H.matvec(f(nc, 1), "N", alpha, beta, f(nr, 3)), g["yN"]) < 1e-5
     assert rel_err(H.matvec(f(nr, 2), "T", alpha, beta, f(nc, 4)), g["yT"]) < 1e-5
 
