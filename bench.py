@@ -290,6 +290,10 @@ def main():
     hm.lib().hmx_device_copy_bandwidth(local_rank, 2 << 30, 5, ctypes.byref(bw))
     roofline["measured_copy_GBps"] = bw.value
     roofline["frac_of_measured_copy"] = achieved / bw.value if bw.value > 0 else None
+    rbw = ctypes.c_double(0)
+    hm.lib().hmx_device_read_bandwidth(local_rank, 8 << 30, 5, ctypes.byref(rbw))  # what a pure streaming read reaches on this box
+    roofline["measured_read_GBps"] = rbw.value
+    roofline["frac_of_measured_read"] = achieved / rbw.value if rbw.value > 0 else None
 
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype=args.dtype, data="synthetic",

@@ -465,4 +465,34 @@ int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gb
     return HMX_OK;
 }
 
+int hmx_device_read_bandwidth(int device_id, int64_t bytes, int reps, double *gbps) {
+    int rc = ensure_device(device_id);
+    if (rc != HMX_OK)
+        return rc;
+    if (!gbps || bytes < 16 || reps < 1)
+        return HMX_ERR_INVALID;
+    DArr<double2> a;
+    DArr<double> out;
+    const int64_t n = bytes / 16;
+    const int blocks = 4096, threads = 256;
+    HMX_HIP(a.alloc(n));
+    HMX_HIP(out.alloc((size_t)blocks * threads));
+    HMX_HIP(a.zero());
+    hipEvent_t e0, e1;
+    HMX_HIP(hipEventCreate(&e0));
+    HMX_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(read16_kernel, dim3(blocks), dim3(threads), 0, 0, (const double2 *)a.d, out.d, n);
+    HMX_HIP(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; r++)
+        hipLaunchKernelGGL(read16_kernel, dim3(blocks), dim3(threads), 0, 0, (const double2 *)a.d, out.d, n);
+    HMX_HIP(hipEventRecord(e1, 0));
+    HMX_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *gbps = (double)n * 16 * reps / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return HMX_OK;
+}
+
 } // extern "C"

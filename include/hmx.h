@@ -237,6 +237,8 @@ int hmx_hmatrix_set_profiling(hmx_hmatrix *, int enabled);
 
 /* Device bandwidth probe: plain 16 B/lane copy of `bytes` bytes, returns GB/s (read+write counted). */
 int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gbps);
+/* ... and a read-only one (16 B/lane non-temporal loads summed in registers): what a streaming-read kernel can reach at best. */
+int hmx_device_read_bandwidth(int device_id, int64_t bytes, int reps, double *gbps);
 
 #ifdef __cplusplus
 }
