@@ -474,7 +474,7 @@ int hmx_device_read_bandwidth(int device_id, int64_t bytes, int reps, double *gb
     DArr<double2> a;
     DArr<double> out;
     const int64_t n = bytes / 16;
-    const int blocks = 4096, threads = 256;
+    const int blocks = 1024, threads = 256; // 4 workgroups per CU, each on its own contiguous chunk (tools/read_bw.hip: the best of the variants)
     HMX_HIP(a.alloc(n));
     HMX_HIP(out.alloc((size_t)blocks * threads));
     HMX_HIP(a.zero());

@@ -230,21 +230,18 @@ __global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restric
         out[i] = in[i];
 }
 
-// read-only probe: every lane streams 16-byte non-temporal loads and keeps a running sum (one 8-byte write per lane at the end)
-__global__ void read16_kernel(const double2 *__restrict__ in, double *__restrict__ out, int64_t n) {
-    int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// read-only probe: every workgroup streams its own contiguous chunk with 16-byte non-temporal loads (four in flight per lane)
+// and keeps running sums -- the access pattern of the stream kernels without any of their arithmetic or gathers
+__global__ __launch_bounds__(256) void read16_kernel(const double2 *__restrict__ in, double *__restrict__ out, int64_t n) {
+    const int64_t per = n / gridDim.x;
+    const double2 *p  = in + per * blockIdx.x;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const double2 a = stream_load(in + i), b = stream_load(in + i + stride), c = stream_load(in + i + 2 * stride), d = stream_load(in + i + 3 * stride);
+    for (int64_t i = threadIdx.x; i + 3 * 256 < per; i += 4 * 256) {
+        const double2 a = stream_load(p + i), b = stream_load(p + i + 256), c = stream_load(p + i + 512), d = stream_load(p + i + 768);
         s0 += a.x + a.y;
         s1 += b.x + b.y;
         s2 += c.x + c.y;
         s3 += d.x + d.y;
-    }
-    for (; i < n; i += stride) {
-        const double2 a = stream_load(in + i);
-        s0 += a.x + a.y;
     }
     out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = (s0 + s1) + (s2 + s3);
 }
