@@ -350,7 +350,7 @@ class DefaultLocalApproximationBuilder:
     """Block-diagonal operator: rank k compresses only (target partition k) x (source partition k) and registers it as a
     local-to-local operator (distributed_operator/utility.hpp:64-88).  `block_diagonal_hmatrix` is that H-matrix."""
 
-    def __init__(self, generator, target_cluster, source_cluster, hmatrix_tree_builder, group=None, device=None, rank=None):
+    def __init__(self, generator, target_cluster, source_cluster, hmatrix_tree_builder, group=None, device=None, rank=None, dtype=np.float64):
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         if device is None:

@@ -1,0 +1,90 @@
+"""The DistributedOperator layer on a real GPU with the RCCL backend (world size 1: the only size one box offers; sizes 2 and 4
+are covered on CPU with gloo in test_distributed_gloo.py).  Runs in a subprocess so the process group does not leak into the
+rest of the suite.  Checks DefaultApproximationBuilder / DefaultLocalApproximationBuilder, the global-to-global and
+local-to-local products in both numberings, the graphed product and complex vectors against the single-operator product."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    import htool_amd as hm
+    from htool_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    rel = lambda a, b: float(torch.linalg.norm(a - b) / torch.linalg.norm(b))
+    n = 6000
+    x = hm.create_geometry("ellipse", n)
+    b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(80)
+    T = b.create_cluster_tree(n, 3, x, 2, 1)
+    for dtype, tdt, sym, uplo in ((np.float64, torch.float64, "N", "N"), (np.float64, torch.float64, "S", "L"), (np.complex128, torch.complex128, "H", "U")):
+        cplx = dtype == np.complex128
+        tb = hm.HMatrixTreeBuilder(1e-6, 10.0, sym, uplo)
+        tb.set_low_rank_generator("sympartialACA" if sym != "N" else "partialACA")
+        gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 0.5 if cplx else 0.0, sym == "H")
+        B = D.DefaultApproximationBuilder(gen, T, T, tb, dtype=dtype)
+        A, H = B.distributed_operator, B.hmatrix
+        g = torch.Generator().manual_seed(0)
+        xin = torch.randn(n, dtype=tdt, generator=g).to(dev)
+        y0 = torch.randn(n, dtype=tdt, generator=g).to(dev)
+        alpha, beta = (1.5 - 0.5j, 0.25 + 1j) if cplx else (1.5, 0.25)
+        for trans in ("N",) + (("T",) if sym != "H" else ()) + (("C",) if cplx and sym != "S" else ()):
+            ref = y0.clone()
+            hm.internal_add_hmatrix_vector_product(trans, alpha, H, xin, beta, ref)
+            y = y0.clone()
+            D.internal_add_distributed_operator_vector_product_global_to_global(trans, alpha, A, xin, beta, y)
+            assert rel(y, ref) < 1e-13, ("g2g", sym, trans, rel(y, ref))
+            y = y0.clone()
+            D.internal_add_distributed_operator_vector_product_local_to_local(trans, alpha, A, xin, beta, y)
+            assert rel(y, ref) < 1e-13, ("l2l", sym, trans, rel(y, ref))
+            ref_u = y0.clone()
+            hm.add_hmatrix_vector_product(trans, alpha, H, xin, beta, ref_u)
+            y = y0.clone()
+            D.add_distributed_operator_vector_product_global_to_global(trans, alpha, A, xin, beta, y)
+            assert rel(y, ref_u) < 1e-13, ("user", sym, trans, rel(y, ref_u))
+        # graphed product: local kernels replayed from a HIP graph, collective eager
+        yg = torch.zeros(n, dtype=tdt, device=dev)
+        gp = D.GraphedGlobalToGlobalProduct(A, xin, yg)
+        ref = torch.zeros(n, dtype=tdt, device=dev)
+        hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, ref)
+        for _ in range(3):
+            yg.zero_()
+            gp()
+        torch.cuda.synchronize()
+        assert gp.graph is not None and torch.equal(yg, ref), ("graphed", sym)
+        # multi-RHS row-major
+        X = torch.randn((n, 4), dtype=tdt, generator=g).to(dev)
+        Y0 = torch.randn((n, 4), dtype=tdt, generator=g).to(dev)
+        ref = Y0.clone()
+        hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, ref, 4)
+        Y = Y0.clone()
+        D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", alpha, A, X, beta, Y, 4)
+        assert rel(Y, ref) < 1e-13, ("rowmajor", sym)
+        # block-diagonal operator: with one partition it is the whole operator again
+        L = D.DefaultLocalApproximationBuilder(gen, T, T, tb, dtype=dtype)
+        y = y0.clone()
+        D.internal_add_distributed_operator_vector_product_local_to_local("N", alpha, L.distributed_operator, xin, beta, y)
+        ref = y0.clone()
+        hm.internal_add_hmatrix_vector_product("N", alpha, H, xin, beta, ref)
+        assert rel(y, ref) < 1e-12, ("blockdiag", sym, rel(y, ref))
+        print("ok", sym, np.dtype(dtype).name)
+    dist.destroy_process_group()
+''') % ROOT
+
+
+def test_distributed_layer_on_gpu_with_rccl():
+    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok ") == 3, out.stdout
