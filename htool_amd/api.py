@@ -345,6 +345,38 @@ class HMatrix:
             return arr.ctypes.data  # void*: interleaved (re, im)
         return arr.ctypes.data_as(C.POINTER(C.c_float if self.f32 else C.c_double))
 
+    def copy_to_dense(self):
+        """copy_to_dense (hmatrix/hmatrix.hpp): the operator as a dense matrix in cluster numbering, local to the root clusters --
+        every stored leaf (U V for low-rank ones) plus, for symmetric / Hermitian storage, the mirrored (conjugate) transposes;
+        diagonal symmetric leaves are completed from the stored triangle like symv / hemv read them.  Host-side, for checks."""
+        self.refresh_leaves()
+        D = np.zeros((self.target_size, self.source_size), dtype=self.dtype)
+        sym, herm, lower = self._sym != "N", self._sym == "H", self._uplo == "L"
+        for b, (to, m, so, n, r, mirror) in enumerate(self.leaf_table()):
+            blk = self.get_block(b)
+            blk = blk[0] @ blk[1] if r >= 0 else np.array(blk)
+            if sym and r < 0 and to == so and m == n:
+                tri = np.tril(blk) if lower else np.triu(blk)
+                off = tri - np.diag(np.diag(tri))
+                blk = tri + (off.conj().T if herm else off.T)
+            i, j = to - self.target_offset, so - self.source_offset
+            D[i:i + m, j:j + n] = blk
+            if mirror:
+                i2, j2 = so - self.target_offset, to - self.source_offset
+                if 0 <= i2 and i2 + n <= self.target_size and 0 <= j2 and j2 + m <= self.source_size:
+                    D[i2:i2 + n, j2:j2 + m] = blk.conj().T if herm else blk.T
+        return D
+
+    def copy_to_dense_in_user_numbering(self):
+        """copy_to_dense_in_user_numbering (hmatrix/hmatrix.hpp): only for an operator on the whole cluster trees."""
+        tgt, src = self._keep
+        if self.target_offset != 0 or self.source_offset != 0 or self.target_size != tgt.get_size() or self.source_size != src.get_size():
+            raise HmxError("copy_to_dense_in_user_numbering needs an operator on the root clusters")
+        D = self.copy_to_dense()
+        out = np.empty_like(D)
+        out[np.ix_(tgt.get_permutation(), src.get_permutation())] = D
+        return out
+
     def set_block_lowrank(self, leaf, U, V):
         U = np.asfortranarray(U, dtype=self.dtype)
         V = np.asfortranarray(V, dtype=self.dtype)

@@ -48,21 +48,7 @@ def _build(nr, nc, eps, sym, uplo, compressor, dtype, cplx_kind="none"):
 
 
 def _to_dense(H):
-    """copy_to_dense (hmatrix/hmatrix.hpp): stored leaves + their mirror for symmetric / Hermitian storage."""
-    lt = H.leaf_table()
-    D = np.zeros((H.nb_rows(), H.nb_cols()), dtype=H.dtype)
-    herm = H.get_symmetry_for_leaves() == "H"
-    for b, (to, m, so, n, r, mirror) in enumerate(lt):
-        blk = H.get_block(b)
-        blk = blk[0] @ blk[1] if r >= 0 else np.array(blk)
-        if to == so and H.get_symmetry_for_leaves() != "N" and r < 0:  # symmetric diagonal leaf: one triangle is referenced
-            tri = np.tril(blk) if H.get_UPLO_for_leaves() == "L" else np.triu(blk)
-            off = tri - np.diag(np.diag(tri))
-            blk = tri + (off.conj().T if herm else off.T)
-        D[to:to + m, so:so + n] = blk
-        if mirror:
-            D[so:so + n, to:to + m] = blk.conj().T if herm else blk.T
-    return D
+    return H.copy_to_dense()
 
 
 @pytest.mark.parametrize("nr,nc", [(200, 200), (400, 200), (200, 400), (400, 400)])
@@ -73,6 +59,9 @@ def test_hmatrix_build_copy_to_dense(nr, nc, eps, compressor):
     compressors cannot do advantageously becomes dense, the error is rounding)."""
     T, S, H, A = _build(nr, nc, eps, "N", "N", compressor, np.float64)
     assert rel_err(_to_dense(H), A) < max(eps, 1e-13) * (10 if compressor == "sympartialACA" else 1)
+    Au = np.empty_like(A)
+    Au[np.ix_(T.get_permutation(), S.get_permutation())] = A
+    assert rel_err(H.copy_to_dense_in_user_numbering(), Au) < max(eps, 1e-13) * (10 if compressor == "sympartialACA" else 1)
 
 
 @pytest.mark.parametrize("sym,uplo,kind,dtype", [("S", "L", "none", np.float64), ("S", "U", "none", np.float64), ("S", "L", "sym", np.complex128),
