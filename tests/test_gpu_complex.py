@@ -247,3 +247,20 @@ def test_complex_dtype_mismatch_is_refused():
     H = tb.build(hm.InvDistGenerator(3, T.coordinates, S.coordinates, 1e-5, 1.0, 1.0, 1.0), T, S, dtype=np.complex128)
     with pytest.raises(hm.HmxError, match="complex128"):
         hm.internal_add_hmatrix_vector_product("N", 1.0, H, np.zeros(p["n"]), 0.0, np.zeros(p["n"]))
+
+
+def test_complex_symmetric_compact_storage(monkeypatch):
+    """HMX_SYM_COMPACT=1 with complex symmetric ('S') storage: the mirror pass through the in-place transposed kernels
+    (complex atomics); Hermitian storage ignores the knob (always expanded)."""
+    monkeypatch.setenv("HMX_SYM_COMPACT", "1")
+    for name in ("ellipse_n3000_z64_symL", "ball_n2000_z64_hermU"):
+        p, g = params(name), load(name)
+        T, S, H = build_zengine(p)
+        x, xT, y0, y0T, alpha, beta = zinputs(H, g)
+        y = y0.copy()
+        hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+        assert rel_err(y, g["yN"]) < 1e-10
+        key, trans = ("yT", "T") if "yT" in g else ("yC", "C")
+        y = y0T.copy()
+        hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y)
+        assert rel_err(y, g[key]) < 1e-10
