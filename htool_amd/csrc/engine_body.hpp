@@ -520,21 +520,23 @@ static void prof_mark(HMat &H, hipStream_t st, const char *name) {
 static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st) {
     // Z[x region] <- x.  x_shift != 0 (mirror pass of a transposed product): the input is indexed by target
     // positions, the x region by source positions.
-    if (x_shift == 0) {
-        HMX_HIP(hipMemcpyAsync(H.Z.d, x_src, (size_t)H.nS * sizeof(scalar), hipMemcpyDeviceToDevice, st));
-    } else {
+    const scalar *xin = x_src; // x_shift == 0: both stages read the caller's vector directly, nothing is copied
+    int nx            = H.nS;
+    if (x_shift != 0) {
         HMX_HIP(hipMemsetAsync(H.Z.d, 0, (size_t)H.nS * sizeof(scalar), st));
         const int lo = std::max(H.S0, H.T0), hi = std::min(H.S0 + H.nS, H.T0 + H.nT);
         if (hi > lo)
             HMX_HIP(hipMemcpyAsync(H.Z.d + (lo - H.S0), x_src + (lo - H.T0), (size_t)(hi - lo) * sizeof(scalar), hipMemcpyDeviceToDevice, st));
+        xin = H.Z.d;
+        nx  = 0;
+        prof_mark(H, st, "copy_x");
     }
-    prof_mark(H, st, "copy_x");
     static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 4; // tuning knobs
     static const int EW = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 4;
     const int ntasks = (int)H.R.task_range.size();
     if (ntasks > 0) {
         ReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
-                     H.r_outidx.d, H.Z.d, H.Z.d, ntasks};
+                     H.r_outidx.d, xin, H.Z.d, ntasks};
         switch (RW) {
         case 1: hipLaunchKernelGGL(reduce_kernel<1>, dim3(ntasks), dim3(64), 0, st, A); break;
         case 2: hipLaunchKernelGGL(reduce_kernel<2>, dim3((ntasks + 1) / 2), dim3(128), 0, st, A); break;
@@ -549,7 +551,7 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         prof_mark(H, st, "combine_kernel");
     }
     if (H.E.nranges() > 0) {
-        ExpandArgs X{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges()};
+        ExpandArgs X{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx};
         switch (EW) {
         case 1: hipLaunchKernelGGL(expand_kernel<1>, dim3(H.E.nranges()), dim3(64), 0, st, X); break;
         case 2: hipLaunchKernelGGL(expand_kernel<2>, dim3(H.E.nranges()), dim3(128), 0, st, X); break;
@@ -583,11 +585,10 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
         HMX_HIP(H.Zmu.alloc(need));
-    HMX_HIP(hipMemcpyAsync(H.Zmu.d, X, (size_t)H.nS * mu * sizeof(scalar), hipMemcpyDeviceToDevice, st));
-    prof_mark(H, st, "copy_x");
+    // the x region of Zmu is never filled: both stages read the caller's X directly
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
-                  H.r_outidx.d, H.Zmu.d, H.Zmu.d, (int)H.R.task_range.size()};
-    ExpandArgs XA{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges()};
+                  H.r_outidx.d, X, H.Zmu.d, (int)H.R.task_range.size()};
+    ExpandArgs XA{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges(), X, H.nS};
     // groups of 16 right-hand sides go to the matrix cores (HMX_NO_MFMA=1: VALU kernels, for A/B comparison)
     // Measured at N=1e6, mu=16: fp64 4.34 ms (MFMA) vs 4.72 ms (VALU); fp32 2.68 ms (MFMA: 64-byte row segments) vs 2.28 ms
     // (VALU) -- so the matrix cores take the fp64 groups only unless HMX_MFMA_F32=1.

@@ -1131,7 +1131,13 @@ struct ExpandArgs {
     scalar *y;            // output, local to the target root
     scalar alpha, beta;
     int nranges;
+    // Z = [x | a | partials]: indices below nx are read straight from the caller's input vector instead of a copy in Z
+    const scalar *x;
+    int nx;
 };
+__device__ __forceinline__ const scalar *expand_operand(const ExpandArgs &A, int zi, int mu) {
+    return (zi < A.nx ? A.x : A.Z) + (int64_t)zi * mu;
+}
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
@@ -1146,7 +1152,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
     scalar acc = scalar(0);
     for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
         const int nc   = (C - c0) < 64 ? (C - c0) : 64;
-        const scalar z = lane < nc ? A.Z[zidx[c0 + lane]] : scalar(0);
+        const scalar z = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
         const scalar *col = E + (int64_t)c0 * len + row;
         int j = 0;
         for (; j + 8 <= nc; j += 8) {
@@ -1287,7 +1293,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
         const int nc = (C - c0) < 64 ? (C - c0) : 64;
         __builtin_amdgcn_wave_barrier();
         if (lane < nc) {
-            const scalar *zr = A.Z + (int64_t)zidx[c0 + lane] * mu + cbase;
+            const scalar *zr = expand_operand(A, zidx[c0 + lane], mu) + cbase;
 #pragma unroll
             for (int c = 0; c < MU; c++)
                 zt[wv][lane][c] = zr[c];
@@ -1362,7 +1368,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16_kernel(ExpandArgs A
         for (int g = 0; g < G; g++) {
             const int col  = c0 + 4 * g + kk;
             const bool cok = col < C;
-            b[g]           = cok ? A.Z[(int64_t)zidx[col] * mu + cbase + m] : real(0);
+            b[g]           = cok ? expand_operand(A, zidx[col], mu)[cbase + m] : real(0);
             const real *cp = E + (int64_t)(cok ? col : 0) * len;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
