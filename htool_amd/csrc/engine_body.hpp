@@ -256,8 +256,14 @@ static int build_streams(HMat &H) {
     }
     E.task_range.resize(E.nranges());
     std::iota(E.task_range.begin(), E.task_range.end(), 0);
-    if (!getenv("HMX_SORT_TASKS") || atoi(getenv("HMX_SORT_TASKS")))
+    // launch order: heaviest first (shorter tail); HMX_SORT_TASKS=2: heaviest first only across power-of-two weight classes,
+    // address order inside a class (neighbouring workgroups stream neighbouring memory)
+    const int sort_mode = getenv("HMX_SORT_TASKS") ? atoi(getenv("HMX_SORT_TASKS")) : 1;
+    auto weight_class = [](int64_t w) { int c = 0; while (w > 1) { w >>= 1; c++; } return c; };
+    if (sort_mode == 1)
         std::stable_sort(E.task_range.begin(), E.task_range.end(), [&](int a, int b) { return (int64_t)E.len[a] * E.cols[a] > (int64_t)E.len[b] * E.cols[b]; });
+    else if (sort_mode == 2)
+        std::stable_sort(E.task_range.begin(), E.task_range.end(), [&](int a, int b) { return weight_class((int64_t)E.len[a] * E.cols[a]) > weight_class((int64_t)E.len[b] * E.cols[b]); });
     E.task_chunk.clear();
     R.base.assign(R.nranges(), 0);
     R.colbase.assign(R.nranges(), 0);
@@ -281,7 +287,7 @@ static int build_streams(HMat &H) {
             R.task_chunk.push_back(c);
         }
     }
-    if (!getenv("HMX_SORT_TASKS") || atoi(getenv("HMX_SORT_TASKS"))) { // longest tasks first: shorter kernel tail (-8 % on reduce_kernel)
+    if (sort_mode) { // longest tasks first: shorter kernel tail (-8 % on reduce_kernel)
         std::vector<int> ord(R.task_range.size());
         std::iota(ord.begin(), ord.end(), 0);
         auto work = [&](int t) {
@@ -290,7 +296,10 @@ static int build_streams(HMat &H) {
             w     = std::min(w, (int)R.cw[r]);
             return (int64_t)R.len[r] * w;
         };
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return work(a) > work(b); });
+        if (sort_mode == 2)
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return weight_class(work(a)) > weight_class(work(b)); });
+        else
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return work(a) > work(b); });
         std::vector<int32_t> tr(ord.size()), tc(ord.size());
         for (size_t k = 0; k < ord.size(); k++) {
             tr[k] = R.task_range[ord[k]];
