@@ -119,9 +119,16 @@ def add_sub_matrix_product_to_local(op, source_offset, source_size, X, Y, mu, of
 
 
 class DistributedOperator:
-    def __init__(self, target_partition, source_partition, group=None):
+    def __init__(self, target_partition, source_partition, group=None, output_collective=None):
+        """output_collective: how the disjoint output slices of a trans='N' product reach every rank -- "allgather" (default;
+        the reference's MPI_Allgatherv: every rank sends its N/p slice) or "allreduce" (a zero-padded length-N vector summed
+        over the ranks: p times the bytes, one collective fewer to tune; HMX_DIST_COLLECTIVE sets the default)."""
         self.target_partition, self.source_partition = target_partition, source_partition
         self.group = group
+        import os
+        self.output_collective = output_collective or os.environ.get("HMX_DIST_COLLECTIVE", "allgather")
+        if self.output_collective not in ("allgather", "allreduce"):
+            raise ValueError("output_collective must be 'allgather' or 'allreduce'")
         self.global_to_local_operators = []
         self.local_to_local_operators = []
         self._pad = {}
@@ -144,6 +151,12 @@ class DistributedOperator:
         p = self.size()
         if p == 1:
             out.copy_(local)
+            return
+        if self.output_collective == "allreduce":
+            off = partition.get_offset_of_partition(self.rank())
+            out.zero_()
+            out[off:off + local.shape[0]].copy_(local)
+            dist.all_reduce(_rv(out), op=dist.ReduceOp.SUM, group=self.group)
             return
         sizes = [partition.get_size_of_partition(k) for k in range(p)]
         m = max(sizes)

@@ -40,7 +40,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, sym, uplo, q):
+def _worker(rank, world, port, sym, uplo, q, collective="allgather"):
     from oracle import oracle as O
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,7 +55,7 @@ def _worker(rank, world, port, sym, uplo, q):
         Hloc = O.HMatrix(To, To, eps=1e-6, eta=10.0, sym=sym, uplo=uplo, compressor=comp, rank=rank)
         Hfull = O.HMatrix(To, To, eps=1e-6, eta=10.0, sym=sym, uplo=uplo, compressor=comp)
         tp = D.PartitionFromCluster(T)
-        A = D.DistributedOperator(tp, tp)
+        A = D.DistributedOperator(tp, tp, output_collective=collective)
         A.add_global_to_local_operator(OracleLocalOperator(Hloc))
         perm = T.get_permutation()
         xin, y0 = O.hashed_vector(n, 7), O.hashed_vector(n, 8)
@@ -106,12 +106,13 @@ def _worker(rank, world, port, sym, uplo, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,sym,uplo", [(2, "N", "N"), (4, "N", "N"), (2, "S", "L"), (2, "S", "U")])
-def test_distributed_products_match_single_process(world, sym, uplo):
+@pytest.mark.parametrize("world,sym,uplo,collective", [(2, "N", "N", "allgather"), (4, "N", "N", "allgather"), (2, "S", "L", "allgather"),
+                                                       (2, "S", "U", "allgather"), (3, "N", "N", "allreduce")])
+def test_distributed_products_match_single_process(world, sym, uplo, collective):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, sym, uplo, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sym, uplo, q, collective)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
