@@ -1,0 +1,23 @@
+"""The drop-in claim end to end on the GPU: oracle/_ref/adaptor_device_check is the REAL reference (htool headers + MKL)
+compiled in the dev container together with htool_amd/include/hmx/htool_adaptor.hpp and linked to libhmx.so
+(oracle/ref/adaptor_device_check.cpp, `make -C oracle ref`).  It builds the same operator with htool alone on the CPU and
+through every plug-in route (device kernel, htool's builder fed by the device generators, host-callback generator, uploaded
+htool leaves, the distributed local operator, complex Hermitian) and compares the products.  Skipped where the binary did
+not travel (it cannot be built on the GPU box: the reference tree exists only in the dev container)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "adaptor_device_check")
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/adaptor_device_check not built (needs the reference tree: dev container only)")
+def test_reference_with_adaptor_on_device():
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=env)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 9
