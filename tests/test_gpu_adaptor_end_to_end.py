@@ -21,3 +21,20 @@ def test_reference_with_adaptor_on_device():
     print(out.stdout)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 9
+
+
+MPI_EXE = os.path.join(ROOT, "oracle", "_ref", "distributed_device_check")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.skipif(not (os.path.exists(MPI_EXE) and os.path.exists(MPIEXEC)), reason="oracle/_ref/distributed_device_check or MPICH not available")
+@pytest.mark.parametrize("np_", [1, 2])
+def test_reference_distributed_operator_with_device_local_operator(np_):
+    """examples/use_distributed_operator.cpp with htool's own MPI DistributedOperator and the rank's block rows on the GPU
+    (CustomApproximationBuilder + hmx_htool::GlobalToLocalHmx), against htool's DefaultApproximationBuilder on the CPU:
+    global-to-global and local-to-local products, trans N/T, symmetry N and S/U.  All ranks share the box's single GPU."""
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([MPIEXEC, "-n", str(np_), MPI_EXE], capture_output=True, text=True, timeout=900, env=env)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 9
