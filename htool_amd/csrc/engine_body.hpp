@@ -772,8 +772,18 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
         return HMX_OK;
     }
 #endif
-    if (trans != 'N' && trans != 'T') { // 'C' with 'S' leaves is an error in the reference too (add_hmatrix_vector_product.hpp:59-62)
-        set_error("hmx_hmatrix_matvec: trans must be 'N' or 'T'" + std::string(HMX_COMPLEX ? " or 'C'" : ""));
+#if !HMX_COMPLEX
+    if (trans == 'C') { // real coefficients: the conjugate transpose is the transpose (BLAS gemv 'C'); the reference still
+                        // refuses 'C' on 'S' leaves (add_hmatrix_vector_product.hpp:59-62)
+        if (!inner && H.symmetry_for_leaves == 'S') {
+            set_error("hmx_hmatrix_matvec: operation is not supported (trans=C with S leaves)");
+            return HMX_ERR_INVALID;
+        }
+        trans = 'T';
+    }
+#endif
+    if (trans != 'N' && trans != 'T') {
+        set_error("hmx_hmatrix_matvec: trans must be 'N', 'T' or 'C'");
         return HMX_ERR_INVALID;
     }
     if (H.has_mirror && !H.sym_expanded && (H.S0 > H.T0 || H.S0 + H.nS < H.T0 + H.nT)) {
@@ -1758,6 +1768,10 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
         HMX_HIP(H.tmp_in2.alloc(nin));
     if (H.tmp_out2.n < (size_t)nout)
         HMX_HIP(H.tmp_out2.alloc(nout));
+#if !HMX_COMPLEX
+    if (trans == 'C' && H.symmetry_for_leaves != 'S')
+        trans = 'T'; // real coefficients
+#endif
     HMat *F = nullptr; // the layout a fused pass runs on: the operator itself, or its transposed view
     bool conj_wrap = false;
     (void)conj_wrap;

@@ -202,13 +202,13 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *, char trans, const float *alpha
 
 /* Binary dump of the compressed operator (no counterpart in the reference): header, leaf table with
  * ranks, then per leaf U (M x r) and V (r x N) or the dense M x N block, all column-major as in htool's
- * LowRankMatrix / Matrix.  Load needs the block tree the file was written for and picks fp32/fp64 from the file. */
+ * LowRankMatrix / Matrix.  Load needs the block tree the file was written for and picks the coefficient type from the file. */
 int hmx_hmatrix_save(const hmx_hmatrix *, const char *path);
 int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, hmx_hmatrix **out);
 
 /* openmp_internal_add_hmatrix_vector_product (hmatrix/linalg/add_hmatrix_vector_product.hpp:107-170):
  * out = alpha * op(H) * in + beta * out, cluster numbering, vectors local to the H-matrix' root clusters.
- * trans in {'N','T'}.  mu = 1. */
+ * trans in {'N','T','C'} ('C' = 'T' for real coefficients; refused on 'S' leaves as in the reference, :59-62).  mu = 1. */
 int hmx_hmatrix_matvec(hmx_hmatrix *, char trans, double alpha, const double *in, double beta, double *out,
                        int mem /* hmx_mem */, void *stream);
 /* add_hmatrix_vector_product (same file :173-197): user numbering; permutations done on the device.

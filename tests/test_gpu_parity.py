@@ -153,7 +153,7 @@ def test_device_vectors_and_errors():
     torch.cuda.synchronize()
     assert np.array_equal(yd.cpu().numpy(), y_host)  # same kernels, same summation order: bit-identical
     with pytest.raises(hm.HmxError):
-        hm.internal_add_hmatrix_vector_product("C", 1.0, H, x, 0.0, y_host)
+        hm.internal_add_hmatrix_vector_product("X", 1.0, H, x, 0.0, y_host)
     tb = hm.HMatrixTreeBuilder(1e-4, 10.0, "N", "N")
     H2 = tb.build(None, T, S, compress=False)
     with pytest.raises(hm.HmxError):  # matvec before the operator is built
@@ -583,3 +583,24 @@ def test_pool_estimate_too_low_is_retried(name, monkeypatch):
     y = y0.copy()
     hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
     assert rel_err(y, g["yN"]) < 1e-10
+
+
+def test_trans_c_for_real_coefficients():
+    """For real coefficients the conjugate transpose is the transpose (BLAS 'C'); like the reference, 'C' on symmetric
+    ('S') leaves is refused (add_hmatrix_vector_product.hpp:59-62)."""
+    p = params("rect_ball1500_disk1000")
+    T, S, H = build_engine(p)
+    x, xT, y0, y0T = inputs(H)
+    yt, yc = y0T.copy(), y0T.copy()
+    hm.internal_add_hmatrix_vector_product("T", 1.5, H, xT, 0.5, yt)
+    hm.internal_add_hmatrix_vector_product("C", 1.5, H, xT, 0.5, yc)
+    assert np.array_equal(yt, yc)
+    X = np.stack([xT, 2 * xT], axis=1).copy()
+    Yt, Yc = np.zeros((H.nb_cols(), 2)), np.zeros((H.nb_cols(), 2))
+    hm.internal_add_hmatrix_matrix_product_row_major("T", 1.0, H, X, 0.0, Yt, 2)
+    hm.internal_add_hmatrix_matrix_product_row_major("C", 1.0, H, X, 0.0, Yc, 2)
+    assert np.array_equal(Yt, Yc)
+    ps = params("ellipse_n3000_symL_default")
+    Ts, Ss, Hs = build_engine(ps)
+    with pytest.raises(hm.HmxError, match="not supported"):
+        hm.internal_add_hmatrix_vector_product("C", 1.0, Hs, np.zeros(ps["n"]), 0.0, np.zeros(ps["n"]))
