@@ -18,6 +18,7 @@
 
 #include <htool/clustering/cluster_node.hpp>
 #include <htool/distributed_operator/interfaces/virtual_global_to_local_operator.hpp>
+#include <htool/distributed_operator/interfaces/virtual_local_to_local_operator.hpp>
 #include <htool/hmatrix/hmatrix.hpp>
 #include <htool/hmatrix/interfaces/virtual_dense_blocks_generator.hpp>
 #include <htool/hmatrix/interfaces/virtual_generator.hpp>
@@ -154,6 +155,18 @@ class EngineT {
         return ok(Abi<T>::create(m_block_tree, device, &m_hmatrix), "device H-matrix"); // needs a GPU: no CPU path
     }
 
+    // block tree rooted at (target partition, source partition): the block-diagonal / local-to-local operator
+    // (DefaultLocalApproximationBuilder, distributed_operator/utility.hpp:64-88)
+    bool setup_local_block_tree(double eta, char symmetry, char UPLO, int min_target_depth, int min_source_depth, int target_partition, int source_partition, int device) {
+        if (!ok(hmx_block_tree_create_local(m_target, m_source, eta, symmetry, UPLO, min_target_depth, min_source_depth, target_partition, source_partition, 1, &m_block_tree), "local block tree"))
+            return false;
+        m_leaves.resize(hmx_block_tree_num_leaves(m_block_tree));
+        hmx_block_tree_leaves(m_block_tree, m_leaves.data());
+        for (size_t b = 0; b < m_leaves.size(); b++)
+            m_leaf_of[std::make_tuple(m_leaves[b].t_offset, m_leaves[b].t_size, m_leaves[b].s_offset, m_leaves[b].s_size)] = (int64_t)b;
+        return ok(Abi<T>::create(m_block_tree, device, &m_hmatrix), "device H-matrix");
+    }
+
     // device compression with a built-in kernel (the generator must be the same function as the user's VirtualGenerator)
     bool compress_on_device(int kernel, const double *params, int nparams, int dim, const double *xt, const double *xs, int compressor, double epsilon, int reqrank) {
         return ok(hmx_hmatrix_set_kernel(m_hmatrix, kernel, params, nparams, dim, xt, xs), "set kernel") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
@@ -240,6 +253,25 @@ class DeviceLowRankGeneratorT final : public htool::VirtualInternalLowRankGenera
 };
 using DeviceLowRankGenerator = DeviceLowRankGeneratorT<double>;
 
+// The user-numbering flavour, htool::VirtualLowRankGenerator<T> (hmatrix/interfaces/virtual_lrmat_generator.hpp:24-35), plugged in
+// with HMatrixTreeBuilder::set_low_rank_generator(std::shared_ptr<VirtualLowRankGenerator>) (tree_builder.hpp:247-250): htool passes
+// `rows` / `cols` as pointers INTO the cluster permutation arrays (:49-55), so the block offsets are rows - perm_base.
+template <typename T>
+class DeviceUserLowRankGeneratorT final : public htool::VirtualLowRankGenerator<T> {
+    DeviceLowRankGeneratorT<T> m_internal;
+    const int *m_target_permutation, *m_source_permutation;
+
+  public:
+    DeviceUserLowRankGeneratorT(const EngineT<T> &engine, const int *target_permutation, const int *source_permutation) : m_internal(engine), m_target_permutation(target_permutation), m_source_permutation(source_permutation) {}
+    bool copy_low_rank_approximation(int M, int N, const int *rows, const int *cols, htool::LowRankMatrix<T> &lrmat) const override {
+        return m_internal.copy_low_rank_approximation(M, N, (int)(rows - m_target_permutation), (int)(cols - m_source_permutation), lrmat);
+    }
+    bool copy_low_rank_approximation(int M, int N, const int *rows, const int *cols, int, htool::LowRankMatrix<T> &lrmat) const override {
+        return copy_low_rank_approximation(M, N, rows, cols, lrmat);
+    }
+};
+using DeviceUserLowRankGenerator = DeviceUserLowRankGeneratorT<double>;
+
 // Plugged in with HMatrixTreeBuilder::set_dense_blocks_generator (hmatrix/tree_builder/tree_builder.hpp:258):
 // htool hands over ALL dense leaves in one batched call (tree_builder.hpp:585-600) with zero-filled destinations;
 // they are filled from the blocks the device assembled.
@@ -287,6 +319,33 @@ class GlobalToLocalHmxT final : public htool::VirtualGlobalToLocalOperator<T> {
     }
 };
 using GlobalToLocalHmx = GlobalToLocalHmxT<double>;
+
+// htool::VirtualLocalToLocalOperator<T> (distributed_operator/interfaces/virtual_local_to_local_operator.hpp:9-35) for an engine whose
+// block tree is rooted at (target partition k, source partition k) -- Engine::setup_local_block_tree -- i.e. the block-diagonal
+// operator of DefaultLocalApproximationBuilder (distributed_operator/utility.hpp:64-88); registered with
+// DistributedOperator::add_local_to_local_operator or CustomApproximationBuilder (utility.hpp:32-34).  Local slices in and out.
+template <typename T>
+class LocalToLocalHmxT final : public htool::VirtualLocalToLocalOperator<T> {
+    const EngineT<T> &m_engine;
+    int m_source_size; // size of the local source cluster
+
+  public:
+    LocalToLocalHmxT(const EngineT<T> &engine, int local_source_size) : m_engine(engine), m_source_size(local_source_size) {}
+    void add_vector_product(char trans, T alpha, const T *const in, T beta, T *const out) const override {
+        ok(Abi<T>::matvec(m_engine.hmatrix(), trans, alpha, in, beta, out), "matvec");
+    }
+    void add_matrix_product_row_major(char trans, T alpha, const T *const in, T beta, T *const out, int mu) const override {
+        ok(Abi<T>::matmat(m_engine.hmatrix(), trans, alpha, in, beta, out, mu), "matmat");
+    }
+    void add_sub_matrix_product_to_local(const T *const in, T *const out, int mu, int offset, int size) const override {
+        std::vector<T> temp((size_t)m_source_size * mu, T(0));
+        const int lo = std::max(offset, 0), hi = std::min(offset + size, m_source_size);
+        if (hi > lo)
+            std::copy_n(in + (size_t)(lo - offset) * mu, (size_t)(hi - lo) * mu, temp.data() + (size_t)lo * mu);
+        ok(Abi<T>::matmat(m_engine.hmatrix(), 'N', T(1), temp.data(), T(1), out, mu), "sub matmat");
+    }
+};
+using LocalToLocalHmx = LocalToLocalHmxT<double>;
 
 } // namespace hmx_htool
 #endif

@@ -116,6 +116,14 @@ int main() {
         add_hmatrix_vector_product('N', 1.5, Hdev, in.data(), 0.5, y.data());
         report("(b) htool builder fed by DeviceLowRankGenerator/DeviceDenseBlocksGenerator, htool CPU product", rel(y, yref), 1e-10);
 
+        // (b') the user-numbering flavour of the plug-in (VirtualLowRankGenerator: rows / cols point into the permutations)
+        HMatrixTreeBuilder<double> tb2u(eps, eta, 'N', 'N');
+        tb2u.set_low_rank_generator(std::make_shared<hmx_htool::DeviceUserLowRankGenerator>(E, T.get_permutation().data(), T.get_permutation().data()));
+        HMatrix<double> Hdevu = tb2u.sequential_build(A, T, T);
+        y                     = y0;
+        add_hmatrix_vector_product('N', 1.5, Hdevu, in.data(), 0.5, y.data());
+        report("(b') htool builder fed by DeviceUserLowRankGenerator (dense leaves by htool), htool CPU product", rel(y, yref), 1e-10);
+
         // (c) user generator through the host callback
         hmx_htool::Engine Ec(T, n, x.data(), T, n, x.data(), 3, opt);
         if (!Ec.setup_block_tree(eta, 'N', 'N', 0, 0, -1, -1, 0) || !Ec.compress_with_generator(A, HMX_PARTIAL_ACA, eps, -1))
@@ -147,6 +155,21 @@ int main() {
         hmx_htool::GlobalToLocalHmx op(El, n);
         op.add_vector_product('N', 1., xin_cluster.data(), 0., yl.data());
         report("(e) GlobalToLocalHmx (row slab of partition 1) vs htool's restricted H-matrix", rel(yl, ylref), 1e-10);
+
+        // (e') the block-diagonal operator of partition 1 (DefaultLocalApproximationBuilder) as a VirtualLocalToLocalOperator
+        const Cluster<double> &part = T.get_cluster_on_partition(1);
+        HMatrixTreeBuilder<double> tb4(eps, eta, 'N', 'N');
+        tb4.set_low_rank_generator(std::make_shared<partialACA<double>>(A, T.get_permutation().data(), T.get_permutation().data()));
+        HMatrix<double> Hdiag = tb4.sequential_build(A, part, part);
+        const int nd          = part.get_size();
+        std::vector<double> xd(xin_cluster.begin() + part.get_offset(), xin_cluster.begin() + part.get_offset() + nd), yd(nd, 0.), ydref(nd, 0.);
+        sequential_internal_add_hmatrix_vector_product('N', 1., Hdiag, xd.data(), 0., ydref.data());
+        hmx_htool::Engine Ed(T, n, x.data(), T, n, x.data(), 3, opt);
+        if (!Ed.setup_local_block_tree(eta, 'N', 'N', 0, 0, 1, 1, 0) || !Ed.compress_on_device(HMX_KERNEL_INV_DIST, p, 2, 3, x.data(), x.data(), HMX_PARTIAL_ACA, eps, -1))
+            return 3;
+        hmx_htool::LocalToLocalHmx opd(Ed, nd);
+        opd.add_vector_product('N', 1., xd.data(), 0., yd.data());
+        report("(e') LocalToLocalHmx (block-diagonal operator of partition 1) vs htool's build on the partition clusters", rel(yd, ydref), 1e-10);
     }
     {
         using Z = std::complex<double>;
