@@ -565,23 +565,22 @@ def internal_add_hmatrix_matrix_product_row_major(trans, alpha, A, X, beta, Y, m
 
 def add_hmatrix_matrix_product(transa, alpha, A, B, beta, Cm):
     """Column-major multi-RHS front end in USER numbering (hmatrix/linalg/add_hmatrix_matrix_product.hpp:176-205):
-    Cm = alpha * op(A) * B + beta * Cm with B (n x mu) and Cm (m x mu) column-major (Fortran order).  As in the
-    reference (same file :26-77) every column is permuted to cluster numbering, the operands are transposed to
-    row-major (mu fastest), the row-major kernel runs, and the result is transposed and permuted back."""
-    if not (isinstance(B, np.ndarray) and isinstance(Cm, np.ndarray)):
-        raise HmxError("add_hmatrix_matrix_product takes host (numpy) matrices; use the row-major entry point for device tensors")
-    mu = B.shape[1]
-    tgt, src = A._keep
-    pin = (src if transa == "N" else tgt).get_permutation()
-    pout = (tgt if transa == "N" else src).get_permutation()
-    oin = A.source_offset if transa == "N" else A.target_offset
-    oout = A.target_offset if transa == "N" else A.source_offset
-    nin = A.source_size if transa == "N" else A.target_size
-    nout = A.target_size if transa == "N" else A.source_size
-    pin = pin[oin:oin + nin] - oin
-    pout = pout[oout:oout + nout] - oout
-    X = np.ascontiguousarray(np.asarray(B)[pin, :], dtype=A.dtype)       # user_to_cluster per column + transpose
-    Y = np.ascontiguousarray(np.asarray(Cm)[pout, :], dtype=A.dtype)
-    internal_add_hmatrix_matrix_product_row_major(transa, alpha, A, X, beta, Y, mu)
-    Cm[pout, :] = Y
+    Cm = alpha * op(A) * B + beta * Cm with B (n x mu) and Cm (m x mu) column-major (numpy Fortran order, or torch tensors whose
+    .T is contiguous).  As in the reference (same file :26-77) every column is permuted to cluster numbering and the operands are
+    transposed to row-major (mu fastest) -- here by one gather kernel each way on the device --, the fused row-major kernels run,
+    and the result is transposed and permuted back (hmx_hmatrix_matmat_user)."""
+    if isinstance(B, np.ndarray):
+        if not (B.flags["F_CONTIGUOUS"] and Cm.flags["F_CONTIGUOUS"]) or B.dtype != A.dtype or Cm.dtype != A.dtype:
+            raise HmxError("add_hmatrix_matrix_product takes column-major (Fortran-ordered) %s matrices" % np.dtype(A.dtype).name)
+        mu = B.shape[1] if B.ndim == 2 else 1
+        pb, pc, mem, stream = B.ctypes.data, Cm.ctypes.data, _lib.HMX_MEM_HOST, None
+    else:  # torch: column-major n x mu == the transpose of a contiguous mu x n tensor
+        if not (B.T.is_contiguous() and Cm.T.is_contiguous()):
+            raise HmxError("device matrices must be column-major (the transpose of a contiguous mu x n tensor)")
+        _vec_ptr(B.T, A)  # dtype check
+        mu = B.shape[1]
+        pb, pc = B.data_ptr(), Cm.data_ptr()
+        mem, stream = (_lib.HMX_MEM_DEVICE if B.is_cuda else _lib.HMX_MEM_HOST), _stream_ptr(B)
+    a, b, _keep = _coef_args(A, alpha, beta)
+    check(_fn(A, "hmx_hmatrix_matmat_user")(A._h, transa.encode(), a, pb, b, pc, mu, mem, stream))
     return Cm

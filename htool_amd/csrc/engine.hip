@@ -307,6 +307,23 @@ int hmx_hmatrix_matmat_row_major(hmx_hmatrix *H, char trans, double alpha, const
     return hmx::f64::api_matmat_row_major(H->d, trans, alpha, in, beta, out, mu, mem, stream);
 }
 
+int hmx_hmatrix_matmat_user(hmx_hmatrix *H, char trans, double alpha, const double *in, double beta, double *out, int mu, int mem, void *stream) {
+    HMX_NEED(H, d, "hmx_hmatrix_matmat_user");
+    return hmx::f64::api_matmat_user(H->d, trans, alpha, in, beta, out, mu, mem, stream);
+}
+int hmx_hmatrix_matmat_user_s(hmx_hmatrix *H, char trans, float alpha, const float *in, float beta, float *out, int mu, int mem, void *stream) {
+    HMX_NEED(H, s, "hmx_hmatrix_matmat_user_s");
+    return hmx::f32::api_matmat_user(H->s, trans, alpha, in, beta, out, mu, mem, stream);
+}
+int hmx_hmatrix_matmat_user_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mu, int mem, void *stream) {
+    HMX_NEED(H, z, "hmx_hmatrix_matmat_user_z");
+    return hmx::z64::api_matmat_user(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mu, mem, stream);
+}
+int hmx_hmatrix_matmat_user_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mu, int mem, void *stream) {
+    HMX_NEED(H, c, "hmx_hmatrix_matmat_user_c");
+    return hmx::c32::api_matmat_user(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream);
+}
+
 // ---- fp32 coefficients (htool's HMatrix<float,double>) --------------------------------------------------------------
 int hmx_hmatrix_set_block_lowrank_s(hmx_hmatrix *H, int64_t leaf, int rank, const float *U, const float *V) {
     HMX_NEED(H, s, "hmx_hmatrix_set_block_lowrank_s");

@@ -74,6 +74,7 @@ struct HMat {
     DArr<scalar> Z, W, Zmu;
     DArr<scalar> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
     DArr<scalar> conj_in;                             // conjugated input of a trans = 'C' product
+    DArr<scalar> mm_in, mm_out;                       // row-major cluster-numbered operands of the column-major front end
     // trans = 'T': the transposed operator laid out in its own streams (built on first use from the same crosses /
     // generator, see ensure_transposed_operator); `view_of` is set in that object and points back to the owner
     std::unique_ptr<HMat> T_op;
@@ -1749,20 +1750,9 @@ static int api_matvec_user(HMat *Hp, char trans, scalar alpha, const scalar *in,
     return HMX_OK;
 }
 
-static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
-    if (!Hp || !in || !out || mu < 1) {
-        set_error("hmx_hmatrix_matmat_row_major: invalid arguments");
-        return HMX_ERR_INVALID;
-    }
-    HMat &H = *Hp;
-    HMX_HIP(hipSetDevice(H.device));
-    hipStream_t st = (hipStream_t)stream;
-    const scalar *din;
-    scalar *dout;
-    bool staged;
-    int rc = with_buffers(H, trans, in, out, mu, mem, st, beta, &din, &dout, staged);
-    if (rc != HMX_OK)
-        return rc;
+// row-major multi-RHS product on device pointers (the body shared by the row-major and the column-major / user-numbering entry points)
+static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, scalar beta, scalar *dout, int mu, hipStream_t st) {
+    int rc;
     const int nin = trans == 'N' ? H.nS : H.nT, nout = trans == 'N' ? H.nT : H.nS;
     if (H.tmp_in2.n < (size_t)nin)
         HMX_HIP(H.tmp_in2.alloc(nin));
@@ -1826,10 +1816,6 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
             hipLaunchKernelGGL(conj_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, tout, (const scalar *)dout, dout);
         }
 #endif
-        if (staged) {
-            HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(scalar), hipMemcpyDeviceToHost, st));
-            HMX_HIP(hipStreamSynchronize(st));
-        }
         return HMX_OK;
     }
     // compact symmetric storage, or no room for the transposed layout: one pass per right-hand side
@@ -1843,8 +1829,78 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
         hipLaunchKernelGGL(col_insert_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, mu, c, (const scalar *)H.tmp_out2.d, dout);
     }
     HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+
+static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
+    if (!Hp || !in || !out || mu < 1) {
+        set_error("hmx_hmatrix_matmat_row_major: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    hipStream_t st = (hipStream_t)stream;
+    const scalar *din;
+    scalar *dout;
+    bool staged;
+    int rc = with_buffers(H, trans, in, out, mu, mem, st, beta, &din, &dout, staged);
+    if (rc != HMX_OK)
+        return rc;
+    rc = matmat_device(H, trans, alpha, din, beta, dout, mu, st);
+    if (rc != HMX_OK)
+        return rc;
     if (staged) {
-        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)nout * mu * sizeof(scalar), hipMemcpyDeviceToHost, st));
+        const size_t nout = (size_t)(trans == 'N' ? H.nT : H.nS);
+        HMX_HIP(hipMemcpyAsync(out, dout, nout * mu * sizeof(scalar), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipStreamSynchronize(st));
+    }
+    return HMX_OK;
+}
+
+// add_hmatrix_matrix_product (hmatrix/linalg/add_hmatrix_matrix_product.hpp:26-77,176-205): column-major B (n x mu) and C (m x mu)
+// in USER numbering; every column is permuted to cluster numbering and the operands are transposed to row-major (one gather
+// kernel each way), the fused row-major product runs, the result is transposed and permuted back.
+static int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
+    if (!Hp || !in || !out || mu < 1) {
+        set_error("hmx_hmatrix_matmat_user: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    if (!(H.t_root_is_tree_root || H.perm_local) || !(H.S0 == 0 && H.nS == H.nS_total)) {
+        set_error("hmx_hmatrix_matmat_user: cluster is neither root nor local, permutation is not stable");
+        return HMX_ERR_INVALID;
+    }
+    HMX_HIP(hipSetDevice(H.device));
+    hipStream_t st = (hipStream_t)stream;
+    const scalar *din;
+    scalar *dout;
+    bool staged;
+    int rc = with_buffers(H, trans, in, out, mu, mem, st, beta, &din, &dout, staged);
+    if (rc != HMX_OK)
+        return rc;
+    if (!H.d_perm_t.d) {
+        HMX_HIP(H.d_perm_t.upload(H.perm_t));
+        HMX_HIP(H.d_perm_s.upload(H.perm_s));
+    }
+    const int nin = trans == 'N' ? H.nS : H.nT, nout = trans == 'N' ? H.nT : H.nS;
+    const int32_t *pin = trans == 'N' ? H.d_perm_s.d + H.S0 : H.d_perm_t.d + H.T0, *pout = trans == 'N' ? H.d_perm_t.d + H.T0 : H.d_perm_s.d + H.S0;
+    const int bin = trans == 'N' ? H.S0 : H.T0, bout = trans == 'N' ? H.T0 : H.S0;
+    const int64_t tin = (int64_t)nin * mu, tout = (int64_t)nout * mu;
+    if ((int64_t)H.mm_in.n < tin)
+        HMX_HIP(H.mm_in.alloc(tin));
+    if ((int64_t)H.mm_out.n < tout)
+        HMX_HIP(H.mm_out.alloc(tout));
+    hipLaunchKernelGGL(gather_cm_kernel, dim3((unsigned)((tin + 255) / 256)), dim3(256), 0, st, nin, mu, pin, bin, din, H.mm_in.d);
+    if (!hmx_is_zero(beta))
+        hipLaunchKernelGGL(gather_cm_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, nout, mu, pout, bout, (const scalar *)dout, H.mm_out.d);
+    rc = matmat_device(H, trans, alpha, H.mm_in.d, beta, H.mm_out.d, mu, st);
+    if (rc != HMX_OK)
+        return rc;
+    hipLaunchKernelGGL(scatter_cm_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, nout, mu, pout, bout, (const scalar *)H.mm_out.d, dout);
+    HMX_HIP(hipGetLastError());
+    if (staged) {
+        HMX_HIP(hipMemcpyAsync(out, dout, (size_t)tout * sizeof(scalar), hipMemcpyDeviceToHost, st));
         HMX_HIP(hipStreamSynchronize(st));
     }
     return HMX_OK;

@@ -1595,6 +1595,22 @@ __global__ void scatter_kernel(int n, const int32_t *perm, int base, const scala
         out[(int64_t)(perm[i] - base) * mu + c] = in[e];
     }
 }
+// column-major user numbering <-> row-major cluster numbering (add_hmatrix_matrix_product.hpp:44-60: user_to_cluster per column +
+// transpose): rm[i][c] = cm[(perm[i] - base) + n * c]
+__global__ void gather_cm_kernel(int n, int mu, const int32_t *perm, int base, const scalar *cm, scalar *rm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)n * mu) {
+        const int i = (int)(e / mu), c = (int)(e - (int64_t)i * mu);
+        rm[e]       = cm[(int64_t)(perm[i] - base) + (int64_t)n * c];
+    }
+}
+__global__ void scatter_cm_kernel(int n, int mu, const int32_t *perm, int base, const scalar *rm, scalar *cm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)n * mu) {
+        const int i = (int)(e / mu), c = (int)(e - (int64_t)i * mu);
+        cm[(int64_t)(perm[i] - base) + (int64_t)n * c] = rm[e];
+    }
+}
 // strided column extract / insert for row-major multi-RHS (X[n][mu])
 __global__ void col_extract_kernel(int n, int mu, int c, const scalar *X, scalar *x) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

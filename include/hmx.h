@@ -220,6 +220,14 @@ int hmx_hmatrix_matvec_user(hmx_hmatrix *, char trans, double alpha, const doubl
 int hmx_hmatrix_matmat_row_major(hmx_hmatrix *, char trans, double alpha, const double *in, double beta, double *out,
                                  int mu, int mem, void *stream);
 
+/* add_hmatrix_matrix_product (hmatrix/linalg/add_hmatrix_matrix_product.hpp:176-205): column-major in (n x mu) and out (m x mu),
+ * USER numbering; permutation + transposition to the row-major kernels' layout on the device (same file :26-77). */
+int hmx_hmatrix_matmat_user(hmx_hmatrix *, char trans, double alpha, const double *in, double beta, double *out,
+                            int mu, int mem, void *stream);
+int hmx_hmatrix_matmat_user_s(hmx_hmatrix *, char trans, float alpha, const float *in, float beta, float *out, int mu, int mem, void *stream);
+int hmx_hmatrix_matmat_user_z(hmx_hmatrix *, char trans, const double *alpha, const double *in, const double *beta, double *out, int mu, int mem, void *stream);
+int hmx_hmatrix_matmat_user_c(hmx_hmatrix *, char trans, const float *alpha, const float *in, const float *beta, float *out, int mu, int mem, void *stream);
+
 /* fp32-coefficient variants (handles created with hmx_hmatrix_create_s); same semantics, float data.
  * All arithmetic of compression and product is then done in float, as htool does for CoefficientPrecision=float. */
 int hmx_hmatrix_set_block_lowrank_s(hmx_hmatrix *, int64_t leaf, int rank, const float *U, const float *V);

@@ -272,6 +272,13 @@ def test_column_major_multi_rhs_front_end():
         d = np.sqrt(((x[rows, None, :] - x[None, :, :]) ** 2).sum(-1))
         ref = 1.5 * (1.0 / (1e-5 + d)) @ B + 0.5 * C0[rows]
         assert rel_err(C[rows], ref) < 1e-6
+        # the same call on device tensors (column-major = the transpose of a contiguous mu x n tensor): bit-identical
+        import torch
+        Bd = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().T
+        Cd = torch.from_numpy(np.ascontiguousarray(C0.T)).cuda().T
+        hm.add_hmatrix_matrix_product(trans, 1.5, H, Bd, 0.5, Cd)
+        torch.cuda.synchronize()
+        assert np.array_equal(Cd.cpu().numpy(), C)
 
 
 def test_edge_cases_alpha_beta_dense_only_and_determinism():
