@@ -114,6 +114,10 @@ SYMBOLS = [
     ("hmx_hmatrix_matmat_user_s", C.c_int, [_vp, C.c_char, C.c_float, _vp, C.c_float, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_hmatrix_matmat_user_z", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_hmatrix_matmat_user_c", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    ("hmx_dist_create", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    ("hmx_dist_destroy", None, [_vp]),
+    ("hmx_dist_matvec_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
+    ("hmx_dist_matvec_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_hmatrix_last_kernel_times", C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     ("hmx_hmatrix_set_profiling", C.c_int, [_vp, C.c_int]),
     ("hmx_device_copy_bandwidth", C.c_int, [C.c_int, C.c_int64, C.c_int, _dp]),

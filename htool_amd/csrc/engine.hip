@@ -482,6 +482,215 @@ int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gb
     return HMX_OK;
 }
 
+// ---- DistributedOperator over RCCL ------------------------------------------------------------------------------------
+} // extern "C" (reopened below)
+#include <dlfcn.h>
+struct hmx_dist {
+    hmx_hmatrix *local = nullptr;
+    void *comm         = nullptr;
+    int rank = 0, world = 1;
+    hmx_rccl_api api{};
+    std::vector<int> t_off, t_size, s_off, s_size; // partitions of the target / source cluster trees
+    int nt = 0, ns = 0;
+    size_t esz = 8;     // bytes per coefficient
+    int dtype  = 8;     // ncclFloat64 / ncclFloat32 of the underlying real type
+    int reals  = 1;     // real numbers per coefficient (2 for complex)
+    DArr<char> work, work2;
+    bool force = false; // HMX_DIST_FORCE_COLLECTIVES=1: call RCCL even with one rank (tests)
+};
+static int dist_api_from_library(hmx_rccl_api &api) {
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h)
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        set_error(std::string("hmx_dist_create: no RCCL function table given and librccl.so cannot be loaded: ") + dlerror());
+        return HMX_ERR_UNSUPPORTED;
+    }
+    api.all_gather  = reinterpret_cast<decltype(api.all_gather)>(dlsym(h, "ncclAllGather"));
+    api.all_reduce  = reinterpret_cast<decltype(api.all_reduce)>(dlsym(h, "ncclAllReduce"));
+    api.broadcast   = reinterpret_cast<decltype(api.broadcast)>(dlsym(h, "ncclBroadcast"));
+    api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(h, "ncclGroupStart"));
+    api.group_end   = reinterpret_cast<decltype(api.group_end)>(dlsym(h, "ncclGroupEnd"));
+    if (!api.all_gather || !api.all_reduce || !api.broadcast || !api.group_start || !api.group_end) {
+        set_error("hmx_dist_create: librccl.so lacks a collective entry point");
+        return HMX_ERR_UNSUPPORTED;
+    }
+    return HMX_OK;
+}
+#define HMX_NCCL(call)                                                                  \
+    do {                                                                                \
+        const int r_ = (call);                                                          \
+        if (r_ != 0) {                                                                  \
+            set_error(std::string(#call) + ": RCCL error " + std::to_string(r_));      \
+            return HMX_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+// out[off_k : off_k + size_k] = rank k's slice (MPI_Allgatherv)
+static int dist_gather_slices(hmx_dist &D, const std::vector<int> &off, const std::vector<int> &size, const char *local, char *out, hipStream_t st) {
+    if (D.world == 1 && !D.force) {
+        HMX_HIP(hipMemcpyAsync(out + (size_t)off[0] * D.esz, local, (size_t)size[0] * D.esz, hipMemcpyDeviceToDevice, st));
+        return HMX_OK;
+    }
+    bool equal = off[0] == 0;
+    for (int k = 1; k < D.world; k++)
+        equal = equal && size[k] == size[0];
+    if (equal && !(getenv("HMX_DIST_NO_ALLGATHER") && atoi(getenv("HMX_DIST_NO_ALLGATHER")))) {
+        HMX_NCCL(D.api.all_gather(local, out, (size_t)size[0] * D.reals, D.dtype, D.comm, st));
+        return HMX_OK;
+    }
+    HMX_NCCL(D.api.group_start());
+    for (int k = 0; k < D.world; k++)
+        HMX_NCCL(D.api.broadcast(local, out + (size_t)off[k] * D.esz, (size_t)size[k] * D.reals, D.dtype, k, D.comm, st));
+    HMX_NCCL(D.api.group_end());
+    return HMX_OK;
+}
+// the local operator's product on device pointers, whatever its coefficient type
+static int dist_local_product(hmx_dist &D, char trans, const void *alpha, const void *in, const void *beta, void *out, hipStream_t st) {
+    hmx_hmatrix *H = D.local;
+    if (H->d)
+        return hmx::f64::api_matvec(H->d, trans, *static_cast<const double *>(alpha), static_cast<const double *>(in), *static_cast<const double *>(beta), static_cast<double *>(out), HMX_MEM_DEVICE, st);
+    if (H->s)
+        return hmx::f32::api_matvec(H->s, trans, *static_cast<const float *>(alpha), static_cast<const float *>(in), *static_cast<const float *>(beta), static_cast<float *>(out), HMX_MEM_DEVICE, st);
+    if (H->z)
+        return hmx::z64::api_matvec(H->z, trans, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), HMX_MEM_DEVICE, st);
+    return hmx::c32::api_matvec(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), HMX_MEM_DEVICE, st);
+}
+extern "C" {
+int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank, int world_size, const hmx_rccl_api *api, hmx_dist **out) {
+    if (!local || !target || !source || !out || world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !nccl_comm)) {
+        set_error("hmx_dist_create: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    if ((int)target->on_partition.size() != world_size || (int)source->on_partition.size() != world_size) {
+        set_error("hmx_dist_create: the cluster trees must have one partition per rank");
+        return HMX_ERR_INVALID;
+    }
+    auto *D  = new hmx_dist();
+    D->local = local;
+    D->comm  = nccl_comm;
+    D->rank  = rank;
+    D->world = world_size;
+    D->force = getenv("HMX_DIST_FORCE_COLLECTIVES") && atoi(getenv("HMX_DIST_FORCE_COLLECTIVES"));
+    if (api) {
+        D->api = *api;
+    } else if (world_size > 1 || D->force) {
+        const int rc = dist_api_from_library(D->api);
+        if (rc != HMX_OK) {
+            delete D;
+            return rc;
+        }
+    }
+    for (int k = 0; k < world_size; k++) {
+        D->t_off.push_back(target->nodes[target->on_partition[k]].offset);
+        D->t_size.push_back(target->nodes[target->on_partition[k]].size);
+        D->s_off.push_back(source->nodes[source->on_partition[k]].offset);
+        D->s_size.push_back(source->nodes[source->on_partition[k]].size);
+    }
+    D->nt = target->n;
+    D->ns = source->n;
+    const int prec = hmx_hmatrix_precision(local);
+    D->esz   = prec == HMX_PREC_F64 ? 8 : (prec == HMX_PREC_F32 ? 4 : (prec == HMX_PREC_Z64 ? 16 : 8));
+    D->dtype = (prec == HMX_PREC_F64 || prec == HMX_PREC_Z64) ? 8 : 7; // ncclFloat64 : ncclFloat32
+    D->reals = (prec == HMX_PREC_Z64 || prec == HMX_PREC_C32) ? 2 : 1;
+    *out     = D;
+    return HMX_OK;
+}
+void hmx_dist_destroy(hmx_dist *D) { delete D; }
+
+int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha, const void *x, const void *beta, void *y, void *stream) {
+    if (!Dp || !alpha || !beta || !x || !y) {
+        set_error("hmx_dist_matvec_global_to_global: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D    = *Dp;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t e = D.esz;
+    char *yb       = static_cast<char *>(y);
+    const char *xb = static_cast<const char *>(x);
+    if (trans == 'N') { // local = beta * y_slice + alpha * A_loc x ; all-gather of the slices
+        const int off = D.t_off[D.rank], n = D.t_size[D.rank];
+        if (D.work.n < (size_t)n * e)
+            HMX_HIP(D.work.alloc((size_t)n * e));
+        HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
+        int rc = dist_local_product(D, 'N', alpha, x, beta, D.work.d, st);
+        if (rc != HMX_OK)
+            return rc;
+        return dist_gather_slices(D, D.t_off, D.t_size, D.work.d, yb, st);
+    }
+    // transposed: every rank contributes alpha * A_loc^T x_slice to the whole vector; all-reduce; beta * y_old added once
+    const int off = D.t_off[D.rank];
+    const size_t bytes = (size_t)D.ns * e;
+    if (D.work.n < bytes)
+        HMX_HIP(D.work.alloc(bytes));
+    HMX_HIP(hipMemsetAsync(D.work.d, 0, bytes, st));
+    const double zero[2] = {0.0, 0.0};
+    const float zerof[2] = {0.f, 0.f};
+    const void *bz       = D.dtype == 8 ? (const void *)zero : (const void *)zerof;
+    int rc = dist_local_product(D, trans, alpha, xb + (size_t)off * e, bz, D.work.d, st);
+    if (rc != HMX_OK)
+        return rc;
+    if (D.world > 1 || D.force)
+        HMX_NCCL(D.api.all_reduce(D.work.d, D.work.d, (size_t)D.ns * D.reals, D.dtype, 0 /* ncclSum */, D.comm, st));
+    // y = beta * y + work
+    hmx_hmatrix *H = D.local;
+    const int n    = D.ns;
+    if (H->d)
+        hipLaunchKernelGGL(hmx::f64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0, (const double *)D.work.d, *static_cast<const double *>(beta), static_cast<double *>(y));
+    else if (H->s)
+        hipLaunchKernelGGL(hmx::f32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0f, (const float *)D.work.d, *static_cast<const float *>(beta), static_cast<float *>(y));
+    else if (H->z)
+        hipLaunchKernelGGL(hmx::z64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<double>(1.0), ZP(D.work.d), zval(static_cast<const double *>(beta)), ZPM(y));
+    else
+        hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<float>(1.0f), CP(D.work.d), cval(static_cast<const float *>(beta)), CPM(y));
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, const void *x_local, const void *beta, void *y_local, void *stream) {
+    if (!Dp || !alpha || !beta || !x_local || !y_local) {
+        set_error("hmx_dist_matvec_local_to_local: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D    = *Dp;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t e = D.esz;
+    if (trans == 'N') { // all-gather of x, then the local product straight into the local slice
+        const size_t bytes = (size_t)D.ns * e;
+        if (D.work2.n < bytes)
+            HMX_HIP(D.work2.alloc(bytes));
+        int rc = dist_gather_slices(D, D.s_off, D.s_size, static_cast<const char *>(x_local), D.work2.d, st);
+        if (rc != HMX_OK)
+            return rc;
+        return dist_local_product(D, 'N', alpha, D.work2.d, beta, y_local, st);
+    }
+    // transposed: product into a zeroed global vector, all-reduce, y_local = beta * y_local + slice
+    const size_t bytes = (size_t)D.ns * e;
+    if (D.work2.n < bytes)
+        HMX_HIP(D.work2.alloc(bytes));
+    HMX_HIP(hipMemsetAsync(D.work2.d, 0, bytes, st));
+    const double zero[2] = {0.0, 0.0};
+    const float zerof[2] = {0.f, 0.f};
+    const void *bz       = D.dtype == 8 ? (const void *)zero : (const void *)zerof;
+    int rc = dist_local_product(D, trans, alpha, x_local, bz, D.work2.d, st);
+    if (rc != HMX_OK)
+        return rc;
+    if (D.world > 1 || D.force)
+        HMX_NCCL(D.api.all_reduce(D.work2.d, D.work2.d, (size_t)D.ns * D.reals, D.dtype, 0, D.comm, st));
+    const int off = D.s_off[D.rank], n = D.s_size[D.rank];
+    const char *w = D.work2.d + (size_t)off * e;
+    hmx_hmatrix *H = D.local;
+    if (H->d)
+        hipLaunchKernelGGL(hmx::f64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0, (const double *)w, *static_cast<const double *>(beta), static_cast<double *>(y_local));
+    else if (H->s)
+        hipLaunchKernelGGL(hmx::f32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0f, (const float *)w, *static_cast<const float *>(beta), static_cast<float *>(y_local));
+    else if (H->z)
+        hipLaunchKernelGGL(hmx::z64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<double>(1.0), ZP(w), zval(static_cast<const double *>(beta)), ZPM(y_local));
+    else
+        hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<float>(1.0f), CP(w), cval(static_cast<const float *>(beta)), CPM(y_local));
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
 int hmx_device_read_bandwidth(int device_id, int64_t bytes, int reps, double *gbps) {
     int rc = ensure_device(device_id);
     if (rc != HMX_OK)

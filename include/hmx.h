@@ -237,6 +237,34 @@ int hmx_hmatrix_matvec_s(hmx_hmatrix *, char trans, float alpha, const float *in
 int hmx_hmatrix_matvec_user_s(hmx_hmatrix *, char trans, float alpha, const float *in, float beta, float *out, int mem, void *stream);
 int hmx_hmatrix_matmat_row_major_s(hmx_hmatrix *, char trans, float alpha, const float *in, float beta, float *out, int mu, int mem, void *stream);
 
+/* ---- DistributedOperator over RCCL (distributed_operator/distributed_operator.hpp:20-61 with one global-to-local operator, the
+ * rank's row-restricted H-matrix; products of distributed_operator/linalg/add_distributed_operator_vector_product_
+ * {global_to_global,local_to_local}.hpp:18-85,19-89).  One process per GPU; the communicator and the stream are the caller's.
+ * The collectives are called through a table of function pointers so that the caller decides WHICH RCCL (the one it linked, or
+ * the one its framework bundles); a NULL table makes libhmx dlopen("librccl.so").  Vectors are device pointers in PARTITION
+ * (= cluster) numbering.  MPI_Allgatherv -> ncclAllGather for equal parts, otherwise one grouped ncclBroadcast per part;
+ * MPI_Allreduce -> ncclAllReduce(sum). */
+typedef struct {
+    int (*all_gather)(const void *send, void *recv, size_t sendcount, int datatype, void *comm, void *stream);
+    int (*all_reduce)(const void *send, void *recv, size_t count, int datatype, int op, void *comm, void *stream);
+    int (*broadcast)(const void *send, void *recv, size_t count, int datatype, int root, void *comm, void *stream);
+    int (*group_start)(void);
+    int (*group_end)(void);
+} hmx_rccl_api; /* ncclAllGather, ncclAllReduce, ncclBroadcast, ncclGroupStart, ncclGroupEnd (rccl.h) cast to these shapes */
+typedef struct hmx_dist hmx_dist;
+/* `local` = the H-matrix built with target_partition_number = rank on the cluster trees whose partitions define the row
+ * distribution (kept by reference: it must outlive the hmx_dist). */
+int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank,
+                    int world_size, const hmx_rccl_api *api, hmx_dist **out);
+void hmx_dist_destroy(hmx_dist *);
+/* y = alpha * op(A) * x + beta * y, x and y whole vectors replicated on every rank (global_to_global.hpp:18-85); the coefficient
+ * type is the local operator's: pointers to double / float / interleaved complex accordingly, alpha / beta as in the matvec
+ * entry points of that type but always passed by pointer here. */
+int hmx_dist_matvec_global_to_global(hmx_dist *, char trans, const void *alpha, const void *x, const void *beta, void *y, void *stream);
+/* local slices in and out (the Krylov-side contract, local_to_local.hpp:19-89): all-gather of x, local product ('N');
+ * local product into a zeroed global vector, all-reduce, slice (transposed). */
+int hmx_dist_matvec_local_to_local(hmx_dist *, char trans, const void *alpha, const void *x_local, const void *beta, void *y_local, void *stream);
+
 /* Timing hooks for bench.py: average duration (ms) of the last matvec's kernels measured with HIP
  * events on the launch stream; names[i] is a static string. */
 int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *, int max, const char **names, float *ms);
