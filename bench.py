@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--eta", type=float, default=10.0)
     ap.add_argument("--leaf", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--recompress", action="store_true", help="SVD recompression of the ACA output before timing (recompression(hmatrix))")
     ap.add_argument("--sym", default="N", help="symmetry of the builder: N, S (lower storage, sympartialACA), or H (Hermitian, complex dtypes)")
     ap.add_argument("--trans", default="N")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "z64", "c32"], help="coefficient type (f32 = htool's HMatrix<float,double>; z64 / c32 = complex double / float, kernel (1+i)/(1e-5+r))")
@@ -186,6 +187,13 @@ def main():
     t_dt = {"f64": torch.float64, "f32": torch.float32, "z64": torch.complex128, "c32": torch.complex64}[args.dtype]
     esz = float(np.dtype(np_dt).itemsize)
     H = tb.build(gen, T, T, brank, brank, device=local_rank, dtype=np_dt)
+    if args.recompress:
+        tr = time.time()
+        before = H.stats()
+        H.recompress()
+        torch.cuda.synchronize()
+        log("recompression: %.2fs, mean rank %.2f -> %.2f, C_gen low-rank %.3e -> %.3e" % (time.time() - tr, before["rank_mean"], H.stats()["rank_mean"],
+                                                                                        before["cgen_lowrank"], H.stats()["cgen_lowrank"]))
     torch.cuda.synchronize()
     t_build = time.time() - t0
     st = H.stats()
@@ -297,7 +305,7 @@ def main():
 
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype=args.dtype, data="synthetic",
-               config=dict(mu=mu, sym=args.sym, trans=args.trans, workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, {"f64": "fp64", "f32": "fp32", "z64": "complex fp64", "c32": "complex fp32"}[args.dtype], args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
+               config=dict(mu=mu, sym=args.sym, trans=args.trans, recompressed=bool(args.recompress), workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, {"f64": "fp64", "f32": "fp32", "z64": "complex fp64", "c32": "complex fp32"}[args.dtype], args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
                            parallelism=("row-partition x%d + all-gather%s" % (world, ", local kernels replayed from a HIP graph" if graphed else "")) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
