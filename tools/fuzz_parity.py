@@ -1,0 +1,92 @@
+"""Randomised parity sweep: the device engine against the CPU oracle on random configurations (geometry, size, leaf size, children,
+partitions, eta, eps, compressor, symmetry, coefficient type, row partition, minimal depth).  usage: fuzz_parity.py [seconds] [seed]"""
+import sys
+import time
+
+import numpy as np
+
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import htool_amd as hm
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+STRAT = {"pca_regular": ("largest_extent", "regular", False), "pca_geometric": ("largest_extent", "geometric", False),
+         "bbox_regular": ("bounding_box", "regular", False), "bbox_geometric": ("bounding_box", "geometric", False),
+         "n_pca_regular": ("largest_extent", "regular", True), "n_bbox_regular": ("bounding_box", "regular", True)}
+rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+t0, done, worst = time.time(), 0, 0.0
+while time.time() - t0 < budget:
+    geom = rng.choice(["ellipse", "disk", "ball", "disk2d"])
+    n = int(rng.integers(40, 4000))
+    leaf = int(rng.integers(5, 120))
+    children = int(rng.choice([2, 2, 2, 3, 4]))
+    parts = int(rng.choice([1, 2, 2, 3, 4]))
+    strat = rng.choice(list(STRAT))
+    eta = float(rng.choice([0.5, 3.0, 10.0, 100.0]))
+    eps = float(rng.choice([1e-2, 1e-4, 1e-7, 1e-11]))
+    prec = rng.choice(["f64", "f64", "f32", "z64", "c32"])
+    cplx = prec in ("z64", "c32")
+    sym = rng.choice(["N", "N", "S"] + (["H"] if cplx else []))
+    uplo = "N" if sym == "N" else rng.choice(["L", "U"])
+    comp = rng.choice(["partialACA", "sympartialACA", "fullACA"]) if sym == "N" else "sympartialACA"
+    rank = int(rng.integers(-1, parts)) if rng.random() < 0.4 else -1
+    mind = int(rng.choice([0, 0, 1, 2]))
+    cfg = dict(geom=geom, n=n, leaf=leaf, children=children, parts=parts, strat=strat, eta=eta, eps=eps, prec=prec, sym=sym, uplo=uplo, comp=comp, rank=rank, mind=mind)
+    dim = 2 if geom == "disk2d" else 3
+    x = hm.create_geometry(geom, n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(leaf)
+    b.set_partitioning_strategy(*STRAT[strat])
+    try:
+        T = b.create_cluster_tree(n, dim, x, children, parts)
+    except hm.HmxError:
+        continue
+    To = O.ClusterTree(x, leaf, children, parts, strat)
+    assert np.array_equal(T.get_permutation(), To.perm), ("perm", cfg)
+    if len(T.get_clusters_on_partition()) != parts:
+        continue
+    tb = hm.HMatrixTreeBuilder(eps, eta, sym, uplo)
+    tb.set_low_rank_generator(comp)
+    tb.set_minimal_target_depth(mind)
+    tb.set_minimal_source_depth(mind)
+    dt = {"f64": np.float64, "f32": np.float32, "z64": np.complex128, "c32": np.complex64}[prec]
+    cre, cim = (0.7, -0.4) if cplx else (1.0, 0.0)
+    H = tb.build(hm.InvDistGenerator(dim, x, x, 1e-5, 1.0, cre, cim, sym == "H"), T, T, rank, rank, dtype=dt)
+    if cplx:
+        Ho = O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=cre, cim=cim, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, c32=prec == "c32")
+    else:
+        Ho = O.HMatrix(To, To, delta=1e-5, scale=1.0, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, f32=prec == "f32")
+    lt = H.leaf_table()
+    assert np.array_equal(lt[:, :4], Ho.leaves[:, :4]) and np.array_equal(lt[:, 5], Ho.leaves[:, 5]), ("structure", cfg)
+    single = prec in ("f32", "c32")
+    if not single:
+        assert np.array_equal(lt[:, 4], Ho.leaves[:, 4]), ("ranks", cfg, int((lt[:, 4] != Ho.leaves[:, 4]).sum()))
+    nr, nc = H.nb_rows(), H.nb_cols()
+    tol = (2e-3 if eps < 1e-5 else 5e-3) if single else 1e-9
+    if single and not np.array_equal(lt[:, 4], Ho.leaves[:, 4]):
+        tol = max(tol, 30 * eps)
+    alpha, beta = (1.5 - 0.5j, 0.25 + 1j) if cplx else (1.5, 0.25)
+    transes = ["N"] + (["T"] if sym != "H" else []) + (["C"] if cplx and sym != "S" else [])
+    for trans in transes:
+        nin, nout = (nc, nr) if trans == "N" else (nr, nc)
+        xin = (rng.standard_normal(nin) + (1j * rng.standard_normal(nin) if cplx else 0)).astype(dt)
+        y0 = (rng.standard_normal(nout) + (1j * rng.standard_normal(nout) if cplx else 0)).astype(dt)
+        y = y0.copy()
+        hm.internal_add_hmatrix_vector_product(trans, alpha, H, xin, beta, y)
+        big = np.complex128 if cplx else np.float64
+        ref = Ho.matvec(xin.astype(big), trans, alpha, beta, y0.astype(big))
+        e = rel(y, ref)
+        worst = max(worst, e if not single else 0.0)
+        assert e < tol, ("matvec", trans, e, cfg)
+        mu = int(rng.choice([2, 5, 16, 19]))
+        X = (rng.standard_normal((nin, mu)) + (1j * rng.standard_normal((nin, mu)) if cplx else 0)).astype(dt)
+        Y0 = (rng.standard_normal((nout, mu)) + (1j * rng.standard_normal((nout, mu)) if cplx else 0)).astype(dt)
+        Y = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, mu)
+        e = rel(Y, Ho.matmat_row_major(X.astype(big), trans, alpha, beta, Y0.astype(big)))
+        assert e < tol, ("matmat", trans, mu, e, cfg)
+    done += 1
+print("fuzz parity: %d random configurations ok in %.0fs, worst double-precision product error %.2e" % (done, time.time() - t0, worst))
