@@ -57,6 +57,18 @@ struct DArr { // device array with RAII
     hipError_t zero() { return n ? hipMemset(d, 0, n * sizeof(T)) : hipSuccess; }
 };
 
+struct DEvent { // hipEvent_t with RAII, so error returns between create and destroy do not leak it
+    hipEvent_t e = nullptr;
+    DEvent() { (void)hipEventCreate(&e); }
+    DEvent(const DEvent &)            = delete;
+    DEvent &operator=(const DEvent &) = delete;
+    ~DEvent() {
+        if (e)
+            (void)hipEventDestroy(e);
+    }
+    operator hipEvent_t() const { return e; }
+};
+
 // One family of streams (E = expand over target ranges, R = reduce over source ranges)
 enum LeafKind { LK_PENDING = 0, LK_DENSE_GEN = 1, LK_DENSE_STAGED = 2, LK_LOWRANK = 3 };
 
@@ -465,9 +477,7 @@ int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gb
     HMX_HIP(a.alloc(n));
     HMX_HIP(b.alloc(n));
     HMX_HIP(a.zero());
-    hipEvent_t e0, e1;
-    HMX_HIP(hipEventCreate(&e0));
-    HMX_HIP(hipEventCreate(&e1));
+    DEvent e0, e1;
     hipLaunchKernelGGL(copy16_kernel, dim3(2048), dim3(256), 0, 0, (const double2 *)a.d, b.d, n);
     HMX_HIP(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; r++)
@@ -477,8 +487,6 @@ int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gb
     float ms = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
     *gbps = 2.0 * (double)n * 16 * reps / (ms * 1e-3) / 1e9;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return HMX_OK;
 }
 
@@ -704,9 +712,7 @@ int hmx_device_read_bandwidth(int device_id, int64_t bytes, int reps, double *gb
     HMX_HIP(a.alloc(n));
     HMX_HIP(out.alloc((size_t)blocks * threads));
     HMX_HIP(a.zero());
-    hipEvent_t e0, e1;
-    HMX_HIP(hipEventCreate(&e0));
-    HMX_HIP(hipEventCreate(&e1));
+    DEvent e0, e1;
     hipLaunchKernelGGL(read16_kernel, dim3(blocks), dim3(threads), 0, 0, (const double2 *)a.d, out.d, n);
     HMX_HIP(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; r++)
@@ -716,8 +722,6 @@ int hmx_device_read_bandwidth(int device_id, int64_t bytes, int reps, double *gb
     float ms = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
     *gbps = (double)n * 16 * reps / (ms * 1e-3) / 1e9;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return HMX_OK;
 }
 

@@ -422,9 +422,7 @@ static int build_streams(HMat &H) {
         HMX_HIP(H.d_transposed.upload(xtransposed));
         HMX_HIP(H.d_conj.upload(xconj));
     }
-    hipEvent_t e0, e1;
-    HMX_HIP(hipEventCreate(&e0));
-    HMX_HIP(hipEventCreate(&e1));
+    DEvent e0, e1;
     HMX_HIP(hipEventRecord(e0, 0));
     {
         DArr<int32_t> pb, pr, pc;
@@ -467,8 +465,6 @@ static int build_streams(HMat &H) {
     HMX_HIP(hipEventSynchronize(e1));
     float ms = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     H.stats.t_pack_s     = tim.s();
     H.stats.t_assemble_s = ms * 1e-3;
     H.stats.stream_bytes = (E.elems + R.elems) * (int64_t)sizeof(scalar);
@@ -1021,9 +1017,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     H.staged_off.assign(nb, -1);
     HMX_HIP(H.d_staged_off.upload(H.staged_off));
 
-    hipEvent_t e0, e1;
-    HMX_HIP(hipEventCreate(&e0));
-    HMX_HIP(hipEventCreate(&e1));
+    DEvent e0, e1;
     HMX_HIP(hipEventRecord(e0, 0));
     if (!order.empty() && assembled) {
         // fullACA / SVD need the whole block: process the admissible leaves in batches that fit a scratch slab
@@ -1226,8 +1220,6 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     HMX_HIP(hipEventSynchronize(e1));
     float ms = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     std::vector<int32_t> ranks(nb, 0);
     H.swapped.assign(nb, 0);
     if (nb) {
