@@ -1034,7 +1034,10 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         }
         size_t free2 = 0, total2 = 0;
         HMX_HIP(hipMemGetInfo(&free2, &total2));
-        const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free2 / sizeof(scalar)));
+        int64_t total_need = 0;
+        for (int32_t b : order)
+            total_need += need_elems[b];
+        const int64_t slab = std::max<int64_t>(largest, std::min<int64_t>(total_need, (int64_t)(0.5 * (double)free2 / sizeof(scalar))));
         if ((double)largest * sizeof(scalar) > 0.9 * (double)free2) {
             set_error("hmx_hmatrix_compress: an admissible block does not fit in HBM for fullACA/SVD");
             return HMX_ERR_HIP;
@@ -1316,7 +1319,11 @@ static int api_recompress(HMat *Hp, double epsilon) {
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return need[a] != need[b] ? need[a] > need[b] : a < b; });
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hipMemGetInfo(&free_b, &total_b));
-    const int64_t slab = std::max<int64_t>(largest, (int64_t)(0.5 * (double)free_b / sizeof(scalar)));
+    int64_t total_need = 0;
+    for (int32_t b : order)
+        total_need += need[b];
+    // never more scratch than all blocks together need: giant allocations take seconds (tools/malloc_timing.hip)
+    const int64_t slab = std::max<int64_t>(largest, std::min<int64_t>(total_need, (int64_t)(0.5 * (double)free_b / sizeof(scalar))));
     if ((double)largest * sizeof(scalar) > 0.9 * (double)free_b) {
         set_error("hmx_hmatrix_recompress: a block does not fit in HBM scratch");
         return HMX_ERR_HIP;
