@@ -1216,7 +1216,28 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         A.vis_ptr   = d_visptr.d;
         A.rank_out  = H.d_rank.d;
         A.swapped_out = H.d_swapped.d;
-        hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)order.size()), dim3(256), 0, 0, A);
+        // the largest blocks (few, long critical path: every iteration walks n1 + n2 entries) get 1024-thread workgroups on a side
+        // stream, concurrently with the bulk of the blocks in 256-thread workgroups; `order` is sorted by n1 + n2, largest first
+        const int big_threshold = getenv("HMX_ACA_BIG") ? atoi(getenv("HMX_ACA_BIG")) : 8192;
+        size_t nbig = 0;
+        while (nbig < order.size() && (int64_t)H.leaves[order[nbig]].t_size + H.leaves[order[nbig]].s_size >= big_threshold)
+            nbig++;
+        hipStream_t side = nullptr;
+        DEvent big_done;
+        if (nbig > 0) {
+            HMX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            hipLaunchKernelGGL(aca_kernel<1024>, dim3((unsigned)nbig), dim3(1024), 0, side, A);
+            HMX_HIP(hipEventRecord(big_done, side));
+        }
+        if (order.size() > nbig) {
+            A.order = d_order.d + nbig;
+            hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)(order.size() - nbig)), dim3(256), 0, 0, A);
+        }
+        if (nbig > 0) {
+            HMX_HIP(hipStreamWaitEvent(0, big_done, 0));
+            HMX_HIP(hipStreamSynchronize(side));
+            (void)hipStreamDestroy(side);
+        }
         HMX_HIP(hipGetLastError());
     }
     HMX_HIP(hipEventRecord(e1, 0));
