@@ -13,6 +13,7 @@
  */
 #ifndef HMX_H
 #define HMX_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -37,3 +37,13 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower(), "%s mentions the oracle" % f
+
+
+def test_header_is_self_contained_c_and_cxx(tmp_path):
+    """include/hmx.h must compile on its own as C99 and as C++14 (it is the contract a foreign-language binding reads)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "t.c").write_text('#include "hmx.h"\nint main(void) { return (int)sizeof(hmx_leaf) - (int)sizeof(hmx_leaf); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(tmp_path / "t.c")])
+    (tmp_path / "t.cpp").write_text('#include "hmx.h"\nint main() { return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(tmp_path / "t.cpp")])
