@@ -537,8 +537,11 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         nx  = 0;
         prof_mark(H, st, "copy_x");
     }
-    static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 4; // tuning knobs
-    static const int EW = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 4;
+    static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 1; // tuning knobs: one wave per workgroup frees its slot as soon as its task ends
+    // expand: 4 waves per row range; when there are too few ranges to fill the chip more than once (<= 4096: the per-rank share
+    // of an 8-GPU run, or N ~ 1e5) 8 waves per range shorten the tail of the heavy ranges (-5 %), at full size they cost 2 %
+    static const int EW_env = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 0;
+    const int EW            = EW_env ? EW_env : (H.E.nranges() <= 4096 ? 8 : 4);
     const int ntasks = (int)H.R.task_range.size();
     if (ntasks > 0) {
         ReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
