@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -27,26 +28,103 @@ namespace hmx {
         }                                                                                                     \
     } while (0)
 
+// Large device buffers are recycled inside the process: after big frees the runtime's next large hipMalloc can take seconds
+// (tools/malloc_timing.hip, tools/build_timing.py rep 1), which hurts callers that rebuild operators (parameter sweeps, time
+// stepping).  release() parks buffers >= 64 MiB in a per-device free list (at most HMX_CACHE_GB, default 48, in total), alloc()
+// takes the smallest parked buffer that fits with at most 25 % waste.  hmx_device_trim_cache() returns everything to the driver.
+struct DeviceCache {
+    struct Entry {
+        void *p;
+        size_t bytes;
+        int device;
+    };
+    std::mutex mu;
+    std::vector<Entry> parked;
+    size_t total = 0;
+    static DeviceCache &get() {
+        static DeviceCache c;
+        return c;
+    }
+    static size_t limit() {
+        static const size_t l = (size_t)((getenv("HMX_CACHE_GB") ? atof(getenv("HMX_CACHE_GB")) : 48.0) * 1073741824.0);
+        return l;
+    }
+    void *take(size_t bytes, size_t *got) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        int best = -1;
+        for (size_t i = 0; i < parked.size(); i++)
+            if (parked[i].device == dev && parked[i].bytes >= bytes && parked[i].bytes <= bytes + bytes / 4 && (best < 0 || parked[i].bytes < parked[best].bytes))
+                best = (int)i;
+        if (best < 0)
+            return nullptr;
+        void *p = parked[best].p;
+        *got    = parked[best].bytes;
+        total -= parked[best].bytes;
+        parked.erase(parked.begin() + best);
+        return p;
+    }
+    bool park(void *p, size_t bytes) {
+        if (bytes < (size_t(64) << 20) || bytes > limit())
+            return false;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        while (total + bytes > limit() && !parked.empty()) { // evict the oldest
+            (void)hipFree(parked.front().p);
+            total -= parked.front().bytes;
+            parked.erase(parked.begin());
+        }
+        parked.push_back({p, bytes, dev});
+        total += bytes;
+        return true;
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto &e : parked)
+            (void)hipFree(e.p);
+        parked.clear();
+        total = 0;
+    }
+};
+
 template <typename T>
 struct DArr { // device array with RAII
-    T *d     = nullptr;
-    size_t n = 0;
+    T *d        = nullptr;
+    size_t n    = 0;
+    size_t cap_ = 0; // bytes actually owned (>= n * sizeof(T) when the buffer came from the cache)
     DArr() {}
     DArr(const DArr &)            = delete;
     DArr &operator=(const DArr &) = delete;
     ~DArr() { release(); }
     void release() {
-        if (d)
+        if (d && !DeviceCache::get().park(d, cap_))
             (void)hipFree(d);
-        d = nullptr;
-        n = 0;
+        d    = nullptr;
+        n    = 0;
+        cap_ = 0;
     }
     hipError_t alloc(size_t count) {
         release();
         n = count;
         if (count == 0)
             return hipSuccess;
-        return hipMalloc((void **)&d, count * sizeof(T));
+        const size_t bytes = count * sizeof(T);
+        size_t got         = 0;
+        if (void *p = DeviceCache::get().take(bytes, &got)) {
+            d    = static_cast<T *>(p);
+            cap_ = got;
+            return hipSuccess;
+        }
+        cap_               = bytes;
+        const hipError_t e = hipMalloc((void **)&d, bytes);
+        if (e != hipSuccess) { // out of memory: give the parked buffers back and try once more
+            DeviceCache::get().trim();
+            (void)hipGetLastError();
+            return hipMalloc((void **)&d, bytes);
+        }
+        return e;
     }
     hipError_t upload(const std::vector<T> &h) {
         hipError_t e = alloc(h.size());
@@ -696,6 +774,11 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
     else
         hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<float>(1.0f), CP(w), cval(static_cast<const float *>(beta)), CPM(y_local));
     HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+int hmx_device_trim_cache(void) {
+    DeviceCache::get().trim();
     return HMX_OK;
 }
 

@@ -1280,6 +1280,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             HMX_HIP(hipMemcpy(exact.d, H.pool.d, (size_t)H.pool_used * sizeof(scalar), hipMemcpyDeviceToDevice));
             std::swap(exact.d, H.pool.d);
             std::swap(exact.n, H.pool.n);
+            std::swap(exact.cap_, H.pool.cap_);
         } else {
             (void)hipGetLastError();
         }

@@ -272,6 +272,10 @@ int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *, int max, const char **nam
 /* Enable/disable per-kernel event timing (adds event records to the stream). */
 int hmx_hmatrix_set_profiling(hmx_hmatrix *, int enabled);
 
+/* libhmx recycles large device buffers inside the process (rebuilding operators would otherwise hit multi-second hipMalloc calls);
+ * this returns every parked buffer to the driver.  HMX_CACHE_GB (default 48) bounds what is kept. */
+int hmx_device_trim_cache(void);
+
 /* Device bandwidth probe: plain 16 B/lane copy of `bytes` bytes, returns GB/s (read+write counted). */
 int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gbps);
 /* ... and a read-only one (16 B/lane non-temporal loads summed in registers): what a streaming-read kernel can reach at best. */
