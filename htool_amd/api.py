@@ -26,6 +26,12 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def trim_device_cache():
+    """Return the device buffers libhmx keeps parked for reuse (at most HMX_CACHE_GB, default 48 GB per process) to the driver,
+    e.g. before another framework needs the memory."""
+    check(lib().hmx_device_trim_cache())
+
+
 def create_geometry(name, n, z=0.0):
     """testing/geometry.hpp: "ellipse" (create_rotated_ellipse 4:1), "disk", "ball" -- seeded mt19937(0)."""
     out = np.empty((n, 2 if name == "disk2d" else 3), dtype=np.float64)
