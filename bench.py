@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("HMX_BENCH_N", 1000000)))
     ap.add_argument("--geom", default="ellipse")
     ap.add_argument("--eps", type=float, default=1e-4)
     ap.add_argument("--eta", type=float, default=10.0)
@@ -156,13 +156,19 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    if os.environ.get("HMX_BENCH_SAME_DEVICE"):  # test hook: several ranks on one GPU (with HMX_BENCH_BACKEND=gloo; RCCL refuses that)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("HMX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = args.n
     t0 = time.time()
