@@ -1,5 +1,5 @@
 """Randomised parity sweep: the device engine against the CPU oracle on random configurations (geometry, size, leaf size, children,
-partitions, eta, eps, compressor, symmetry, coefficient type, row partition, minimal depth).  usage: fuzz_parity.py [seconds] [seed]"""
+partitions, eta, eps, compressor, symmetry, coefficient type, row partition, minimal depth).  usage: fuzz_parity.py [seconds] [seed] [max points]"""
 import sys
 import time
 
@@ -13,6 +13,7 @@ from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+NMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
 STRAT = {"pca_regular": ("largest_extent", "regular", False), "pca_geometric": ("largest_extent", "geometric", False),
          "bbox_regular": ("bounding_box", "regular", False), "bbox_geometric": ("bounding_box", "geometric", False),
          "n_pca_regular": ("largest_extent", "regular", True), "n_bbox_regular": ("bounding_box", "regular", True)}
@@ -20,7 +21,7 @@ rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg
 t0, done, worst = time.time(), 0, 0.0
 while time.time() - t0 < budget:
     geom = rng.choice(["ellipse", "disk", "ball", "disk2d"])
-    n = int(rng.integers(40, 4000))
+    n = int(rng.integers(40, NMAX))
     leaf = int(rng.integers(5, 120))
     children = int(rng.choice([2, 2, 2, 3, 4]))
     parts = int(rng.choice([1, 2, 2, 3, 4]))
