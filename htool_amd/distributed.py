@@ -245,7 +245,9 @@ class GraphedGlobalToGlobalProduct:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture mode: only this thread's calls are checked against the capture, so the process group's
+            # watchdog thread (event queries on the RCCL streams) cannot invalidate it
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 local_work()
             torch.cuda.synchronize()
             ref = self.local.clone()
