@@ -105,6 +105,7 @@ SYMBOLS = [
     ("hmx_hmatrix_leaf_ranks", C.c_int, [_vp, _ip]),
     ("hmx_hmatrix_get_block", C.c_int, [_vp, C.c_int64, _dp, _dp]),
     ("hmx_hmatrix_stats", C.c_int, [_vp, C.POINTER(Stats)]),
+    ("hmx_hmatrix_release_factors", C.c_int, [_vp, C.c_int]),
     ("hmx_hmatrix_save", C.c_int, [_vp, C.c_char_p]),
     ("hmx_hmatrix_load", C.c_int, [_vp, C.c_int, C.c_char_p, C.POINTER(_vp)]),
     ("hmx_hmatrix_matvec", C.c_int, [_vp, C.c_char, C.c_double, _vp, C.c_double, _vp, C.c_int, _vp]),

@@ -298,6 +298,10 @@ class HMatrix:
         self._sym, self._uplo = sym.raw.decode(), uplo.raw.decode()
         self.refresh_leaves()
 
+    def release_factors(self, with_transposed=False):
+        """Give the compression pool back to the device (products only need the streams); see hmx_hmatrix_release_factors."""
+        check(lib().hmx_hmatrix_release_factors(self._h, int(with_transposed)))
+
     def save(self, path):
         """Binary dump of the compressed operator (hmx_hmatrix_save); reload with HMatrixTreeBuilder.load()."""
         check(lib().hmx_hmatrix_save(self._h, str(path).encode()))

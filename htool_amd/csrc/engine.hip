@@ -498,6 +498,7 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *H, char trans, const float *alph
     return hmx::c32::api_matmat_row_major(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream);
 }
 
+int hmx_hmatrix_release_factors(hmx_hmatrix *H, int with_transposed) { HMX_ALL(H, api_release_factors, with_transposed); }
 int hmx_hmatrix_save(const hmx_hmatrix *H, const char *path) { HMX_ALL(H, api_save, path); }
 int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, hmx_hmatrix **out) {
     if (!bt || !path || !out) {

@@ -80,6 +80,7 @@ struct HMat {
     std::unique_ptr<HMat> T_op;
     const HMat *view_of = nullptr;
     bool T_op_failed    = false;
+    bool factors_released = false; // hmx_hmatrix_release_factors: the cross pool was given back, only the streams remain
     DArr<int32_t> d_perm_t, d_perm_s;
     bool finalized = false;
 
@@ -706,7 +707,7 @@ static int build_streams(HMat &H);
 static HMat *ensure_transposed_operator(HMat &H) {
     if (H.T_op)
         return H.T_op.get();
-    if (H.T_op_failed || H.view_of || (H.has_mirror && !H.sym_expanded) || (getenv("HMX_TRANS_STREAMS") && !atoi(getenv("HMX_TRANS_STREAMS"))))
+    if (H.factors_released || H.T_op_failed || H.view_of || (H.has_mirror && !H.sym_expanded) || (getenv("HMX_TRANS_STREAMS") && !atoi(getenv("HMX_TRANS_STREAMS"))))
         return nullptr;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 1.15 * (double)H.stats.stream_bytes) {
@@ -1319,8 +1320,8 @@ static int api_recompress(HMat *Hp, double epsilon) {
         return HMX_ERR_INVALID;
     }
     HMat &H = *Hp;
-    if (!H.finalized || H.pool.n == 0) {
-        set_error("hmx_hmatrix_recompress: operator not built");
+    if (!H.finalized || H.pool.n == 0 || H.factors_released) {
+        set_error("hmx_hmatrix_recompress: operator not built, or its factors were released");
         return HMX_ERR_STATE;
     }
     HMX_HIP(hipSetDevice(H.device));
@@ -1510,6 +1511,10 @@ static int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V
     if (H->kind[leaf] == LK_LOWRANK) {
         if (!V)
             return HMX_ERR_INVALID;
+        if (H->factors_released) {
+            set_error("hmx_hmatrix_get_block: the low-rank factors were released (hmx_hmatrix_release_factors)");
+            return HMX_ERR_STATE;
+        }
         const int r  = l.rank;
         const bool sw = H->swapped[leaf] != 0;
         const int n1 = sw ? N : M, n2 = sw ? M : N;
@@ -1572,8 +1577,8 @@ static int api_save(const HMat *Hc, const char *path) {
         set_error("hmx_hmatrix_save: invalid arguments");
         return HMX_ERR_INVALID;
     }
-    if (!H->finalized) {
-        set_error("hmx_hmatrix_save: operator not built");
+    if (!H->finalized || H->factors_released) {
+        set_error("hmx_hmatrix_save: operator not built, or its factors were released");
         return HMX_ERR_STATE;
     }
     HMX_HIP(hipSetDevice(H->device));
@@ -1672,6 +1677,28 @@ static int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxF
         return rc;
     }
     *out = H;
+    return HMX_OK;
+}
+
+// Give the compression pool (the ACA crosses / uploaded blocks the streams were packed from) back: products only need the
+// streams.  Afterwards low-rank blocks can no longer be downloaded, saved or recompressed, and a transposed product that has not
+// built its layout yet uses the in-place passes.  with_transposed != 0 builds the transposed layout first.
+static int api_release_factors(HMat *Hp, int with_transposed) {
+    if (!Hp || !Hp->finalized) {
+        set_error("hmx_hmatrix_release_factors: operator not built");
+        return HMX_ERR_STATE;
+    }
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    if (with_transposed)
+        (void)ensure_transposed_operator(H);
+    if (H.dense_stage.d) // host-generated dense leaves live only in the streams from now on
+        H.dense_stage.release();
+    H.pool.release();
+    H.d_cross_off.release();
+    H.pool_used        = 0;
+    H.factors_released = true;
+    DeviceCache::get().trim();
     return HMX_OK;
 }
 

@@ -201,6 +201,12 @@ int hmx_hmatrix_matvec_c(hmx_hmatrix *, char trans, const float *alpha, const fl
 int hmx_hmatrix_matvec_user_c(hmx_hmatrix *, char trans, const float *alpha, const float *in, const float *beta, float *out, int mem, void *stream);
 int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *, char trans, const float *alpha, const float *in, const float *beta, float *out, int mu, int mem, void *stream);
 
+/* Memory: after compression the device holds the streams the products read AND the pool they were packed from (kept for
+ * get_block / save / recompress / the transposed layout; 14 GB next to 18.5 GB of streams at N=1e6).  This gives the pool back:
+ * only products remain possible (a transposed product uses the in-place passes unless with_transposed != 0 built its layout
+ * first). */
+int hmx_hmatrix_release_factors(hmx_hmatrix *, int with_transposed);
+
 /* Binary dump of the compressed operator (no counterpart in the reference): header, leaf table with
  * ranks, then per leaf U (M x r) and V (r x N) or the dense M x N block, all column-major as in htool's
  * LowRankMatrix / Matrix.  Load needs the block tree the file was written for and picks the coefficient type from the file. */

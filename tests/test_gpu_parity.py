@@ -611,3 +611,34 @@ def test_trans_c_for_real_coefficients():
     Ts, Ss, Hs = build_engine(ps)
     with pytest.raises(hm.HmxError, match="not supported"):
         hm.internal_add_hmatrix_vector_product("C", 1.0, Hs, np.zeros(ps["n"]), 0.0, np.zeros(ps["n"]))
+
+
+@pytest.mark.parametrize("with_transposed", [False, True])
+def test_release_factors_keeps_products(with_transposed):
+    """hmx_hmatrix_release_factors: the pool goes back to the device, products (N and T, single and multiple right-hand sides) are
+    unchanged, downloads of low-rank blocks / save / recompress are refused, dense leaves can still be read from the streams."""
+    p, g = params("ellipse_n3000_partial"), load("ellipse_n3000_partial")
+    T, S, H = build_engine(p)
+    x, xT, y0, y0T = inputs(H)
+    ref = {}
+    for trans, xin, yin in (("N", x, y0), ("T", xT, y0T)):
+        ref[trans] = yin.copy()
+        if not with_transposed and trans == "T":
+            continue  # computed after the release, through the in-place passes
+        hm.internal_add_hmatrix_vector_product(trans, 3.0, H, xin, 2.0, ref[trans])
+    first_dense, first_lr = int(np.nonzero(H.ranks < 0)[0][0]), int(np.nonzero(H.ranks > 0)[0][0])
+    D = H.get_block(first_dense)
+    H.release_factors(with_transposed)
+    for trans, xin, yin, key in (("N", x, y0, "yN"), ("T", xT, y0T, "yT")):
+        y = yin.copy()
+        hm.internal_add_hmatrix_vector_product(trans, 3.0, H, xin, 2.0, y)
+        assert rel_err(y, g[key]) < 1e-10
+        if with_transposed or trans == "N":
+            assert np.array_equal(y, ref[trans])
+    assert np.array_equal(H.get_block(first_dense), D)
+    with pytest.raises(hm.HmxError, match="released"):
+        H.get_block(first_lr)
+    with pytest.raises(hm.HmxError, match="released"):
+        H.recompress()
+    with pytest.raises(hm.HmxError, match="released"):
+        H.save("/tmp/should_not_exist.hmx")
