@@ -42,6 +42,8 @@ class Stats(C.Structure):
 GENERATOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double))
 GENERATOR_FN_S = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float))
 
+ADMISSIBILITY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(ClusterNode), C.POINTER(ClusterNode), C.c_double)
+
 # every symbol include/hmx.h declares: (name, restype, argtypes)
 _dp, _ip, _vp, _fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_float)
 SYMBOLS = [
@@ -62,6 +64,7 @@ SYMBOLS = [
     ("hmx_cluster_tree_load", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
     ("hmx_block_tree_save_leaves_with_rank", C.c_int, [_vp, _ip, C.c_char_p]),
     ("hmx_block_tree_create", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("hmx_block_tree_create_adm", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ADMISSIBILITY_FN, _vp, C.POINTER(_vp)]),
     ("hmx_block_tree_create_local", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_block_tree_destroy", None, [_vp]),
     ("hmx_block_tree_num_leaves", C.c_int64, [_vp]),

@@ -472,8 +472,22 @@ class HMatrixTreeBuilder:
     def set_block_tree_consistency(self, c):
         self._consistent = bool(c)
 
+    def set_admissibility_condition(self, condition):
+        """HMatrixTreeBuilder::set_admissibility_condition (tree_builder.hpp:243-246): `condition(target, source, eta) -> bool` with
+        target / source objects exposing depth, offset, size, rank, radius and center (the fields of htool's Cluster); None restores
+        the default Rjasanow-Steinbach condition.  Called on the host while the block tree is built."""
+        if condition is None:
+            self._adm = None
+            return
+        self._adm = _lib.ADMISSIBILITY_FN(lambda _u, t, s, eta: int(bool(condition(t.contents, s.contents, eta))))
+
     def _block_tree(self, target, source, target_partition_number, partition_number_for_symmetry):
         h = C.c_void_p()
+        if getattr(self, "_adm", None) is not None:
+            check(lib().hmx_block_tree_create_adm(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(),
+                                                  self._mint, self._mins, target_partition_number, partition_number_for_symmetry,
+                                                  int(self._consistent), self._adm, None, C.byref(h)))
+            return h
         check(lib().hmx_block_tree_create(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(),
                                           self._mint, self._mins, target_partition_number, partition_number_for_symmetry,
                                           int(self._consistent), C.byref(h)))

@@ -31,7 +31,19 @@ struct Walker {
     const ClusterNode &sn(int v) const { return S.nodes[v]; }
 
     // RjasanowSteinbach (hmatrix/interfaces/virtual_admissibility_condition.hpp:20-23)
+    static hmx_cluster_node public_node(const ClusterNode &c, int dim) {
+        hmx_cluster_node o;
+        o.depth = c.depth, o.offset = c.offset, o.size = c.size, o.rank = c.rank, o.counter = c.counter, o.n_children = c.n_children;
+        o.radius = c.radius;
+        for (int p = 0; p < 3; p++)
+            o.center[p] = p < dim ? c.center[p] : 0.0;
+        return o;
+    }
     bool admissible(const ClusterNode &t, const ClusterNode &s) const {
+        if (bt.admissibility) { // VirtualAdmissibilityCondition supplied by the user
+            const hmx_cluster_node a = public_node(t, T.dim), b = public_node(s, S.dim);
+            return bt.admissibility(bt.admissibility_user, &a, &b, bt.eta) != 0;
+        }
         double d2 = 0.0;
         for (int p = 0; p < T.dim; p++) {
             const double u = t.center[p] - s.center[p];

@@ -173,6 +173,34 @@ int hmx_block_tree_create(const hmx_cluster_tree *target, const hmx_cluster_tree
     *out = bt;
     return HMX_OK;
 }
+int hmx_block_tree_create_adm(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry, char uplo,
+                              int min_target_depth, int min_source_depth, int target_partition_number, int partition_number_for_symmetry,
+                              int block_tree_consistency, hmx_admissibility_fn fn, void *user, hmx_block_tree **out) {
+    if (!target || !source || !out) {
+        hmx::set_error("hmx_block_tree_create_adm: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    auto *bt                   = new hmx_block_tree();
+    bt->target                 = target;
+    bt->source                 = source;
+    bt->eta                    = eta;
+    bt->symmetry               = symmetry;
+    bt->uplo                   = uplo;
+    bt->min_target_depth       = min_target_depth;
+    bt->min_source_depth       = min_source_depth;
+    bt->target_partition       = target_partition_number;
+    bt->partition_for_symmetry = partition_number_for_symmetry;
+    bt->consistent             = block_tree_consistency != 0;
+    bt->admissibility          = fn;
+    bt->admissibility_user     = user;
+    const int rc               = hmx::build_block_tree(*bt);
+    if (rc != HMX_OK) {
+        delete bt;
+        return rc;
+    }
+    *out = bt;
+    return HMX_OK;
+}
 int hmx_block_tree_create_local(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry, char uplo,
                                 int min_target_depth, int min_source_depth, int target_partition, int source_partition,
                                 int block_tree_consistency, hmx_block_tree **out) {

@@ -56,6 +56,8 @@ struct hmx_block_tree {
     int target_partition = -1, partition_for_symmetry = -1;
     int target_root_partition = -1, source_root_partition = -1; // >= 0: the block tree is rooted at these partition clusters
     bool consistent = true;
+    int (*admissibility)(void *, const hmx_cluster_node *, const hmx_cluster_node *, double) = nullptr; // user condition (NULL: Rjasanow-Steinbach)
+    void *admissibility_user = nullptr;
     // root after reset_root_of_block_tree
     int root_t_offset = 0, root_t_size = 0, root_s_offset = 0, root_s_size = 0;
     char symmetry_for_leaves = 'N', uplo_for_leaves = 'N';

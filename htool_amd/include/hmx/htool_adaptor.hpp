@@ -117,6 +117,32 @@ class EngineT {
     bool m_square                = false;
     std::map<std::tuple<int, int, int, int>, int64_t> m_leaf_of; // (t_off, t_size, s_off, s_size) -> leaf
     std::vector<hmx_leaf> m_leaves;
+    const htool::Cluster<double> *m_htool_target = nullptr, *m_htool_source = nullptr;
+
+    // a user's htool::VirtualAdmissibilityCondition, called on htool's own Cluster nodes from the hmx block-tree recursion
+    struct AdmissibilityBridge {
+        const htool::VirtualAdmissibilityCondition<double> *condition = nullptr;
+        std::map<std::tuple<int, int, int>, const htool::Cluster<double> *> target, source; // (depth, offset, size) -> node
+        static void index(const htool::Cluster<double> &root, std::map<std::tuple<int, int, int>, const htool::Cluster<double> *> &out) {
+            std::vector<const htool::Cluster<double> *> stack{&root};
+            while (!stack.empty()) {
+                const htool::Cluster<double> *c = stack.back();
+                stack.pop_back();
+                out[std::make_tuple(c->get_depth(), c->get_offset(), c->get_size())] = c;
+                for (const auto &child : c->get_children())
+                    stack.push_back(child.get());
+            }
+        }
+        static int call(void *user, const hmx_cluster_node *t, const hmx_cluster_node *s, double eta) {
+            const auto *self = static_cast<const AdmissibilityBridge *>(user);
+            const auto a = self->target.find(std::make_tuple(t->depth, t->offset, t->size)), b = self->source.find(std::make_tuple(s->depth, s->offset, s->size));
+            if (a == self->target.end() || b == self->source.end()) {
+                htool::Logger::get_instance().log(htool::LogLevel::ERROR, "[hmx] admissibility bridge: cluster not found in htool's tree");
+                return 0;
+            }
+            return self->condition->ComputeAdmissibility(*a->second, *b->second, eta) ? 1 : 0;
+        }
+    };
 
     static hmx_cluster_tree *make_tree(int n, int dim, const double *x, const ClusterOptions &o, const htool::Cluster<double> &check) {
         hmx_cluster_tree *t = nullptr;
@@ -130,8 +156,10 @@ class EngineT {
 
   public:
     EngineT(const htool::Cluster<double> &target, int nt, const double *xt, const htool::Cluster<double> &source, int ns, const double *xs, int dim, const ClusterOptions &opt) {
-        m_square = (&target == &source);
-        m_target = make_tree(nt, dim, xt, opt, target);
+        m_square       = (&target == &source);
+        m_htool_target = &target;
+        m_htool_source = &source;
+        m_target       = make_tree(nt, dim, xt, opt, target);
         m_source = m_square ? m_target : make_tree(ns, dim, xs, opt, source);
     }
     ~EngineT() {
@@ -145,8 +173,16 @@ class EngineT {
     EngineT &operator=(const EngineT &) = delete;
 
     // same arguments as HMatrixTreeBuilder's constructor + build() (hmatrix/tree_builder/tree_builder.hpp:180-210)
-    bool setup_block_tree(double eta, char symmetry, char UPLO, int min_target_depth, int min_source_depth, int target_partition_number, int partition_number_for_symmetry, int device) {
-        if (!ok(hmx_block_tree_create(m_target, m_source, eta, symmetry, UPLO, min_target_depth, min_source_depth, target_partition_number, partition_number_for_symmetry, 1, &m_block_tree), "block tree"))
+    // `condition`: what the caller gave to HMatrixTreeBuilder::set_admissibility_condition (tree_builder.hpp:243-246), NULL for the
+    // default Rjasanow-Steinbach condition
+    bool setup_block_tree(double eta, char symmetry, char UPLO, int min_target_depth, int min_source_depth, int target_partition_number, int partition_number_for_symmetry, int device, const htool::VirtualAdmissibilityCondition<double> *condition = nullptr) {
+        AdmissibilityBridge bridge;
+        if (condition) {
+            bridge.condition = condition;
+            AdmissibilityBridge::index(*m_htool_target, bridge.target);
+            AdmissibilityBridge::index(*m_htool_source, bridge.source);
+        }
+        if (!ok(hmx_block_tree_create_adm(m_target, m_source, eta, symmetry, UPLO, min_target_depth, min_source_depth, target_partition_number, partition_number_for_symmetry, 1, condition ? &AdmissibilityBridge::call : nullptr, &bridge, &m_block_tree), "block tree"))
             return false;
         m_leaves.resize(hmx_block_tree_num_leaves(m_block_tree));
         hmx_block_tree_leaves(m_block_tree, m_leaves.data());
@@ -211,6 +247,7 @@ class EngineT {
 
     hmx_hmatrix *hmatrix() const { return m_hmatrix; }
     size_t number_of_leaves() const { return m_leaves.size(); }
+    bool leaf_is_admissible(int64_t leaf) const { return m_leaves[leaf].admissible != 0; }
     int64_t find_leaf(int row_offset, int M, int col_offset, int N) const {
         auto it = m_leaf_of.find(std::make_tuple(row_offset, M, col_offset, N));
         return it == m_leaf_of.end() ? -1 : it->second;

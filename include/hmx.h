@@ -121,6 +121,16 @@ int hmx_cluster_tree_load(const char *properties_file, const char *tree_file, hm
 int hmx_block_tree_create(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
                           char uplo, int min_target_depth, int min_source_depth, int target_partition_number,
                           int partition_number_for_symmetry, int block_tree_consistency, hmx_block_tree **out);
+/* A user-defined admissibility condition (VirtualAdmissibilityCondition::ComputeAdmissibility,
+ * hmatrix/interfaces/virtual_admissibility_condition.hpp:12; HMatrixTreeBuilder::set_admissibility_condition,
+ * tree_builder.hpp:243-246) instead of the default Rjasanow-Steinbach one (:20-23): called on the host for every pair of clusters
+ * the recursion visits; returns non-zero when the block (target, source) may be compressed.  NULL restores the default.
+ * The `_adm` variants of the two constructors take it. */
+typedef int (*hmx_admissibility_fn)(void *user, const hmx_cluster_node *target, const hmx_cluster_node *source, double eta);
+int hmx_block_tree_create_adm(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
+                              char uplo, int min_target_depth, int min_source_depth, int target_partition_number,
+                              int partition_number_for_symmetry, int block_tree_consistency, hmx_admissibility_fn fn, void *user,
+                              hmx_block_tree **out);
 /* Block tree rooted at a pair of PARTITION clusters (block-diagonal / local-to-local operator):
  * DefaultLocalApproximationBuilder, distributed_operator/utility.hpp:64-88 */
 int hmx_block_tree_create_local(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,

@@ -70,9 +70,58 @@ static int check_complex() {
     std::printf("complex: htool_leaves=%zu hmx_leaves=%zu missing=%zu device=%d\n", nleaves, E.number_of_leaves(), missing, (int)device);
     return (missing == 0 && nleaves == E.number_of_leaves()) ? 0 : 1;
 }
+// a user admissibility condition (twice as strict as Rjasanow-Steinbach) given to both htool's builder and the adaptor
+class StrictCondition final : public VirtualAdmissibilityCondition<double> {
+  public:
+    mutable long calls = 0;
+    bool ComputeAdmissibility(const Cluster<double> &t, const Cluster<double> &s, double eta) const override {
+        calls++;
+        return 2 * std::min(t.get_radius(), s.get_radius()) < 0.5 * eta * std::max(norm2(t.get_center() - s.get_center()) - t.get_radius() - s.get_radius(), 0.);
+    }
+};
+static int check_user_admissibility() {
+    const int n = 2500;
+    std::vector<double> x(3 * n);
+    create_sphere(n, x.data());
+    ClusterTreeBuilder<double> ctb;
+    ctb.set_maximal_leaf_size(40);
+    Cluster<double> T = ctb.create_cluster_tree(n, 3, x.data(), 2, 2);
+    Gen A(x);
+    HMatrixTreeBuilder<double> tb(1e-3, 10., 'N', 'N');
+    HMatrix<double> Hdefault = tb.sequential_build(A, T, T);
+    auto cond = std::make_shared<StrictCondition>();
+    tb.set_admissibility_condition(cond);
+    HMatrix<double> H = tb.sequential_build(A, T, T);
+    hmx_htool::ClusterOptions opt;
+    opt.maximal_leaf_size = 40; opt.number_of_children = 2; opt.size_of_partition = 2;
+    hmx_htool::Engine E(T, n, x.data(), T, n, x.data(), 3, opt);
+    StrictCondition mine;
+    E.setup_block_tree(10., 'N', 'N', 0, 0, -1, -1, 0, &mine);
+    size_t nleaves = 0, ndefault = 0, missing = 0;
+    std::vector<const HMatrix<double> *> st{&H};
+    while (!st.empty()) {
+        auto *c = st.back(); st.pop_back();
+        if (c->is_leaf()) {
+            nleaves++;
+            int64_t leaf = E.find_leaf(c->get_target_cluster().get_offset(), c->get_target_cluster().get_size(), c->get_source_cluster().get_offset(), c->get_source_cluster().get_size());
+            if (leaf < 0 || (c->is_low_rank() && !E.leaf_is_admissible(leaf))) missing++;
+        }
+        for (auto &ch : c->get_children()) st.push_back(ch.get());
+    }
+    st = {&Hdefault};
+    while (!st.empty()) {
+        auto *c = st.back(); st.pop_back();
+        ndefault += c->is_leaf();
+        for (auto &ch : c->get_children()) st.push_back(ch.get());
+    }
+    std::printf("user admissibility: htool_leaves=%zu (default condition %zu) hmx_leaves=%zu missing=%zu calls=%ld\n", nleaves, ndefault, E.number_of_leaves(), missing, mine.calls);
+    return (missing == 0 && nleaves == E.number_of_leaves() && nleaves != ndefault && mine.calls > 0) ? 0 : 1;
+}
 int main() {
     if (check_complex() != 0)
         return 2;
+    if (check_user_admissibility() != 0)
+        return 3;
     const int n = 3000;
     std::vector<double> x(3 * n);
     create_rotated_ellipse(3, 4., 1., 0., 0., n, x.data());

@@ -642,3 +642,36 @@ def test_release_factors_keeps_products(with_transposed):
         H.recompress()
     with pytest.raises(hm.HmxError, match="released"):
         H.save("/tmp/should_not_exist.hmx")
+
+
+def test_user_admissibility_condition_end_to_end():
+    """HMatrixTreeBuilder.set_admissibility_condition (VirtualAdmissibilityCondition): the default condition re-stated in Python
+    reproduces the golden operator bit for bit; a stricter one gives a different block tree whose product still meets epsilon
+    against the dense matrix."""
+    p, g = params("ball_n2000_partial"), load("ball_n2000_partial")
+    T, S, H0 = build_engine(p)
+    x, _, y0, _ = inputs(H0)
+    yref = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", 3.0, H0, x, 2.0, yref)
+
+    def rs(t, s, eta):
+        d = np.sqrt(sum((t.center[k] - s.center[k]) ** 2 for k in range(3)))
+        return 2 * min(t.radius, s.radius) < eta * max(d - t.radius - s.radius, 0.0)
+
+    gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"])
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    tb.set_low_rank_generator("partialACA")
+    tb.set_admissibility_condition(rs)
+    H1 = tb.build(gen, T, S)
+    assert np.array_equal(H1.leaf_table(), H0.leaf_table())
+    y = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", 3.0, H1, x, 2.0, y)
+    assert np.array_equal(y, yref)
+    tb.set_admissibility_condition(lambda t, s, eta: rs(t, s, eta / 5))
+    H2 = tb.build(gen, T, S)
+    assert len(H2.leaf_table()) > len(H0.leaf_table()) and H2.stats()["n_lowrank"] > 0
+    xt, xs = T.coordinates[T.get_permutation()], S.coordinates[S.get_permutation()]
+    A = 1.0 / (p["delta"] + p["scale"] * np.linalg.norm(xt[:, None, :] - xs[None, :, :], axis=2))
+    y2 = np.zeros(p["n"])
+    hm.internal_add_hmatrix_vector_product("N", 1.0, H2, x, 0.0, y2)
+    assert rel_err(y2, A @ x) < p["eps"]

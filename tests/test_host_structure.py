@@ -113,3 +113,28 @@ def test_invalid_arguments_are_reported():
         hm.HMatrixTreeBuilder(1e-3, 10.0, "N", "N").build_block_tree(T, T, 5, 5)  # partition number too large
     with pytest.raises(hm.HmxError):
         b.create_cluster_tree(100, 5, np.zeros((100, 5)), 2, 2)
+
+
+def test_user_admissibility_condition():
+    """set_admissibility_condition: the default condition re-stated in Python gives the same block tree; a stricter one gives
+    more, smaller admissible blocks; 'never admissible' gives dense leaves only."""
+    p = params("ball_n2000_partial")
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], "N", "N")
+    ref = tb.build_block_tree(T, S).leaves
+
+    def rjasanow_steinbach(t, s, eta):  # hmatrix/interfaces/virtual_admissibility_condition.hpp:20-23
+        d = np.sqrt(sum((t.center[k] - s.center[k]) ** 2 for k in range(3)))
+        return 2 * min(t.radius, s.radius) < eta * max(d - t.radius - s.radius, 0.0)
+
+    tb.set_admissibility_condition(rjasanow_steinbach)
+    got = tb.build_block_tree(T, S).leaves
+    assert np.array_equal(got, ref)
+    tb.set_admissibility_condition(lambda t, s, eta: rjasanow_steinbach(t, s, eta / 4))
+    strict = tb.build_block_tree(T, S).leaves
+    assert len(strict) > len(ref) and strict["admissible"].sum() > 0
+    tb.set_admissibility_condition(lambda t, s, eta: False)
+    dense = tb.build_block_tree(T, S).leaves
+    assert dense["admissible"].sum() == 0 and (dense["t_size"].astype(np.int64) * dense["s_size"]).sum() == p["n"] ** 2
+    tb.set_admissibility_condition(None)
+    assert np.array_equal(tb.build_block_tree(T, S).leaves, ref)
