@@ -288,15 +288,18 @@ def main():
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
     exp_bytes = esz * (st["expand_coeffs"] + st["a_total"] + n + H.nb_rows())
     red_bytes = esz * (st["reduce_coeffs"] + st["a_total"] + n)
-    exp_ms = kern_ms.get("expand_kernel" if mu == 1 else "expand_mu_kernel", float("nan"))
+    # single vector: expand_kernel / reduce_kernel; multi-RHS: the *_mu (LDS operand), *_mus (scalar operand) or *_mfma16 variants
+    exp_name = next((k for k in kern_ms if k.startswith("expand")), "expand_kernel")
+    red_name = next((k for k in kern_ms if k.startswith("reduce")), "reduce_kernel")
+    exp_ms = kern_ms.get(exp_name, float("nan"))
     achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")  # measured separately with rocprofv3 --pmc
     if os.path.exists(tf) and world == 1 and n == 1000000 and args.geom == "ellipse" and args.sym == "N" and args.trans == "N" and mu == 1 and not emu and not use_dist and args.dtype == "f64":
         traffic = json.load(open(tf)).get("expand_kernel_hbm_bytes_per_launch")
-    roofline = dict(bound="hbm", kernel="expand_kernel", achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
+    roofline = dict(bound="hbm", kernel=exp_name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
                     traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
-                    kernels_ms=kern_ms, reduce_kernel_GBps=red_bytes / (kern_ms.get("reduce_kernel", float("nan")) * 1e-3) / 1e9)
+                    kernels_ms=kern_ms, reduce_kernel_GBps=red_bytes / (kern_ms.get(red_name, float("nan")) * 1e-3) / 1e9)
 
     # measured device copy bandwidth (16 B/lane copy kernel, read+write) as the practical HBM ceiling on this box
     import ctypes

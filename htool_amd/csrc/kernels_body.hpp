@@ -1139,8 +1139,14 @@ __device__ __forceinline__ const scalar *expand_operand(const ExpandArgs &A, int
     return (zi < A.nx ? A.x : A.Z) + (int64_t)zi * mu;
 }
 
+// loads in flight per wave in the expand stage: 8 for 8- and 16-byte coefficients, 16 for 4-byte ones (a wave's load is then
+// only 256 bytes; N=1e6 fp32: 0.916 -> 0.899 ms); -DHMX_EXPAND_UNROLL=8 restores 8 for A/B comparison
+#ifndef HMX_EXPAND_UNROLL
+#define HMX_EXPAND_UNROLL 16
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
+    constexpr int EU = sizeof(scalar) == 4 ? HMX_EXPAND_UNROLL : 8;
     __shared__ scalar part[WAVES][WAVE];
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1155,13 +1161,13 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
         const scalar z = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
         const scalar *col = E + (int64_t)c0 * len + row;
         int j = 0;
-        for (; j + 8 <= nc; j += 8) {
-            scalar v[8];
+        for (; j + EU <= nc; j += EU) {
+            scalar v[EU];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < EU; u++)
                 v[u] = stream_load(col + (int64_t)(j + u) * len);
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < EU; u++)
                 acc = hmx_fma(v[u], readlane_val(z, j + u), acc);
         }
         for (; j < nc; j++)
@@ -1337,6 +1343,139 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
 }
 
 #if !HMX_COMPLEX
+// ---------------------------------------------------------------------------------------------
+// Multi-RHS kernels with the wave-uniform operand in SCALAR registers.  The MU coefficients a streamed row (reduce) or
+// column (expand) is multiplied with are the same for all 64 lanes: instead of staging them in LDS and reading them
+// back as broadcast ds_read_b128 (4 per row for 16 floats -- the LDS pipe, not HBM, then bounds the fp32 kernels), they
+// are fetched through the scalar cache (s_load_dwordx16 from a constant-address-space view of X / Z, which no wave of these
+// kernels writes) and enter the packed FMAs as SGPR operands.  Same arithmetic, same order as the *_mu kernels.
+// ---------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) scalar *uniform_ptr;
+typedef const __attribute__((address_space(4))) int32_t *uniform_iptr;
+
+template <int WAVES, int MU>
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_mus_kernel(ReduceArgs A, int mu, int cbase) {
+    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES + wv;
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp      = (w + 1) & ~1;
+    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+    const bool active = col0 < wp;
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    uniform_ptr xs    = (uniform_ptr)(A.x + (int64_t)A.range_off[S] * mu + cbase);
+    scalar a0[MU], a1[MU];
+#pragma unroll
+    for (int c = 0; c < MU; c++)
+        a0[c] = a1[c] = scalar(0);
+    int i = 0;
+    for (; i + 4 <= len; i += 4) {
+        scalar2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            v[u] = load_pair(src + (int64_t)(i + u) * wp, col0, col1, wp);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uniform_ptr xr = xs + (int64_t)(i + u) * mu;
+#pragma unroll
+            for (int c = 0; c < MU; c++) {
+                const scalar xi = xr[c];
+                a0[c]           = hmx_fma(v[u].x, xi, a0[c]);
+                a1[c]           = hmx_fma(v[u].y, xi, a1[c]);
+            }
+        }
+    }
+    for (; i < len; i++) {
+        const scalar2 v = load_pair(src + (int64_t)i * wp, col0, col1, wp);
+        uniform_ptr xr  = xs + (int64_t)i * mu;
+#pragma unroll
+        for (int c = 0; c < MU; c++) {
+            const scalar xi = xr[c];
+            a0[c]           = hmx_fma(v.x, xi, a0[c]);
+            a1[c]           = hmx_fma(v.y, xi, a1[c]);
+        }
+    }
+    if (active) {
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        if (col0 < w) {
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb + col0] * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                dst[c] = a0[c];
+        }
+        if (col1 < w) {
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb + col1] * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                dst[c] = a1[c];
+        }
+    }
+}
+
+template <int WAVES, int MU>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_mus_kernel(ExpandArgs A, int mu, int cbase) {
+    __shared__ __attribute__((aligned(16))) scalar zt[WAVES][WAVE][MU]; // final reduction over the waves only
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E   = A.stream + A.range_base[R];
+    uniform_ptr Zu = (uniform_ptr)A.Z, Xu = (uniform_ptr)A.x;
+    const bool active = lane < len;
+    const int row     = active ? lane : 0;
+    scalar acc[MU];
+#pragma unroll
+    for (int c = 0; c < MU; c++)
+        acc[c] = scalar(0);
+    // 64-column tiles per wave as in expand_mu_kernel; the tile's coefficient indices are one coalesced vector load and
+    // reach the scalar unit through v_readlane, so each column costs one s_load of its MU coefficients
+    for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
+        const int nc   = (C - c0) < 64 ? (C - c0) : 64;
+        const int zi_v = lane < nc ? A.z_idx[A.range_colbase[R] + c0 + lane] : 0;
+        const scalar *col = E + (int64_t)c0 * len + row;
+        int j = 0;
+        for (; j + 8 <= nc; j += 8) {
+            scalar v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                v[u] = stream_load(col + (int64_t)(j + u) * len);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int zi   = __builtin_amdgcn_readlane(zi_v, j + u);
+                uniform_ptr zr = (zi < A.nx ? Xu : Zu) + (int64_t)zi * mu + cbase;
+#pragma unroll
+                for (int c = 0; c < MU; c++)
+                    acc[c] = hmx_fma(v[u], zr[c], acc[c]);
+            }
+        }
+        for (; j < nc; j++) {
+            const scalar v = col[(int64_t)j * len];
+            const int zi   = __builtin_amdgcn_readlane(zi_v, j);
+            uniform_ptr zr = (zi < A.nx ? Xu : Zu) + (int64_t)zi * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                acc[c] = hmx_fma(v, zr[c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MU; c++)
+        zt[wv][lane][c] = active ? acc[c] : scalar(0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * MU; e += WAVES * WAVE) {
+        const int i = e / MU, c = e - i * MU;
+        scalar s = zt[0][i][c];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            s += zt[k][i][c];
+        scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 16 right-hand sides on the matrix cores.  With mu = 16 the leaf products are real GEMMs
 // (K7-K9 of SURVEY.md 2.2: [rows x cols] x [cols x 16]); the VALU kernels above then spend their time re-reading the
