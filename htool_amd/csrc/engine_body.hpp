@@ -579,7 +579,8 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
 // rows miss the scalar cache) vs 1.14 ms (LDS); fp64 1.71 / 1.67 ms and 2.71 / 2.86 ms with the MFMA kernels at 1.64 / 2.53 ms.
 // Default: scalar operands in the fp32 reduce stage only.  HMX_MU_SCALAR=0: never, =1: both stages (A/B comparison).
 static bool mu_scalar_operands(bool reduce_stage) {
-    static const int v = getenv("HMX_MU_SCALAR") ? atoi(getenv("HMX_MU_SCALAR")) : -1;
+    const char *e = getenv("HMX_MU_SCALAR");
+    const int v   = e ? atoi(e) : -1;
     return v < 0 ? (reduce_stage && sizeof(scalar) == 4) : v != 0;
 }
 template <int MU>

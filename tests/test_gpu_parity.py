@@ -462,8 +462,16 @@ def test_sixteen_rhs_mfma_path(dtype, tol, monkeypatch):
             monkeypatch.setenv("HMX_NO_MFMA", "1")
             Yv = Y0.copy()
             hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, Yv, mu)
-            monkeypatch.delenv("HMX_NO_MFMA")
             assert rel_err(Y, Yv) < tol
+            # VALU kernels with the wave-uniform operand in LDS (0) / in scalar registers (1): same arithmetic, same order
+            out = {}
+            for mode in ("0", "1"):
+                monkeypatch.setenv("HMX_MU_SCALAR", mode)
+                out[mode] = Y0.copy()
+                hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, out[mode], mu)
+            monkeypatch.delenv("HMX_MU_SCALAR")
+            monkeypatch.delenv("HMX_NO_MFMA")
+            assert rel_err(out["0"], Yv) < tol and rel_err(out["1"], out["0"]) < tol
 
 
 def test_reference_examples_reproduce_published_errors():
