@@ -458,10 +458,14 @@ class HMatrixTreeBuilder:
         self._mint = self._mins = 0
         self._consistent = True
 
-    def set_low_rank_generator(self, name):
+    def set_low_rank_generator(self, name, recompressed=False):
+        """One of the device compressors; recompressed=True wraps it like htool's RecompressedLowRankGenerator
+        (hmatrix/lrmat/recompressed_low_rank_generator.hpp:12-31): every compressed block goes through SVD_recompression
+        with the builder's epsilon -- the same result as HMatrix.recompress() after the build."""
         if name not in _lib.COMPRESSORS:
             raise HmxError("unknown compressor %r" % name)
         self._compressor = name
+        self._recompressed = bool(recompressed)
 
     def set_minimal_target_depth(self, d):
         self._mint = int(d)
@@ -533,6 +537,8 @@ class HMatrixTreeBuilder:
         if compress:
             check(lib().hmx_hmatrix_compress(h, _lib.COMPRESSORS[self._compressor], self._eps, self._reqrank))
             H.refresh_leaves()
+            if getattr(self, "_recompressed", False):
+                H.recompress()
         return H
 
 

@@ -21,14 +21,13 @@ ACA_CASES = [c for c in HMAT_CASES if params(c)["compressor"] in ("partialACA", 
 def build_engine(p, compress=True, generator=True):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
-    tb.set_low_rank_generator(p["compressor"] if p["compressor"] in DEVICE_COMPRESSORS else "partialACA")
+    # fixtures written with htool's RecompressedLowRankGenerator / recompression(hmatrix): the wrapped form of the compressor
+    tb.set_low_rank_generator(p["compressor"] if p["compressor"] in DEVICE_COMPRESSORS else "partialACA", recompressed=bool(compress and p["recompress"]))
     tb.set_minimal_target_depth(p["mindepth"])
     tb.set_minimal_source_depth(p["mindepth"])
     tb.set_block_tree_consistency(bool(p["consistent"]))
     gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]) if generator else None
     H = tb.build(gen, T, S, p["rank"], p["rank"], compress=compress, local_partitions=(p["local"], p["local"]) if p["local"] >= 0 else None)
-    if compress and p["recompress"]:
-        H.recompress()
     return T, S, H
 
 
