@@ -1042,6 +1042,9 @@ struct ReduceArgs {
     int ntasks;
 };
 
+#ifndef HMX_REDUCE_ROWS
+#define HMX_REDUCE_ROWS 1
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6)); // wave-uniform
@@ -1058,6 +1061,77 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
     const scalar *xs  = A.x + A.range_off[S];
     scalar a0 = scalar(0), a1 = scalar(0);
+    // Narrow chunks (at most half a wave wide: the per-rank share of a multi-GPU run, small problems): the chunk is one
+    // contiguous row-major array, so a wave-wide load covers R = floor(wave elements / wp) whole rows; lane l holds the
+    // columns of row group g = EPL*l / wp.  R times fewer loads for the same bytes; the R partial sums of a column are
+    // added in a fixed tree at the end.  HMX_REDUCE_ROWS=0 (compile time) keeps one row per load.
+    constexpr int EPL = HMX_SPLIT_COLS ? 1 : 2; // stream elements per lane and load
+    if (HMX_REDUCE_ROWS && wp <= 32 * EPL) {
+        const int R  = (64 * EPL) / wp;         // rows per load, >= 2
+        const int hw = wp / EPL;                // lanes per row
+        const int g = lane / hw, e0 = EPL * lane; // row group of this lane, its offset in the R-row window
+        const bool lane_ok = g < R;
+        // the x value of a lane's row comes straight from memory: R distinct addresses per load, always cache hits
+        const scalar *p  = src + e0;
+        const scalar *xg = xs + g;
+        int j = 0;
+        for (; j + 8 * R <= len; j += 8 * R) {
+#if HMX_SPLIT_COLS
+            scalar v[8];
+#else
+            scalar2 v[8];
+#endif
+            scalar xi[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+#if HMX_SPLIT_COLS
+                v[u] = lane_ok ? stream_load(p + (int64_t)(j + u * R) * wp) : scalar(0);
+#else
+                v[u] = lane_ok ? stream_load(reinterpret_cast<const scalar2 *>(p + (int64_t)(j + u * R) * wp)) : scalar2{scalar(0), scalar(0)};
+#endif
+                xi[u] = lane_ok ? xg[j + u * R] : scalar(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+#if HMX_SPLIT_COLS
+                a0 = hmx_fma(v[u], xi[u], a0);
+#else
+                a0 = hmx_fma(v[u].x, xi[u], a0);
+                a1 = hmx_fma(v[u].y, xi[u], a1);
+#endif
+            }
+        }
+        for (; j < len; j += R) {
+            const bool ok   = lane_ok && j + g < len;
+            const scalar xi = ok ? xg[j] : scalar(0);
+#if HMX_SPLIT_COLS
+            const scalar v = ok ? stream_load(p + (int64_t)j * wp) : scalar(0);
+            a0             = hmx_fma(v, xi, a0);
+#else
+            const scalar2 v = ok ? stream_load(reinterpret_cast<const scalar2 *>(p + (int64_t)j * wp)) : scalar2{scalar(0), scalar(0)};
+            a0              = hmx_fma(v.x, xi, a0);
+            a1              = hmx_fma(v.y, xi, a1);
+#endif
+        }
+        for (int n = R; n > 1;) { // row groups 0..n-1 hold partial sums; fold the upper half onto the lower one
+            const int h     = (n + 1) >> 1;
+            const scalar t0 = hmx_shfl(a0, lane + h * hw), t1 = hmx_shfl(a1, lane + h * hw);
+            if (g + h < n) {
+                a0 += t0;
+                a1 += t1;
+            }
+            n = h;
+        }
+        if (lane < hw) {
+            const int64_t cb = A.range_colbase[S] + ch * cw;
+            const int c0     = EPL * lane;
+            if (c0 < w)
+                A.Z[A.out_idx[cb + c0]] = a0;
+            if (EPL == 2 && c0 + 1 < w)
+                A.Z[A.out_idx[cb + c0 + 1]] = a1;
+        }
+        return;
+    }
     for (int i0 = 0; i0 < len; i0 += 64) {
         const int nr    = (len - i0) < 64 ? (len - i0) : 64;
         const scalar xv = lane < nr ? xs[i0 + lane] : scalar(0);

@@ -121,6 +121,9 @@ __device__ __forceinline__ double hmx_shfl_xor(double v, int o) { return __shfl_
 __device__ __forceinline__ float hmx_shfl_xor(float v, int o) { return __shfl_xor(v, o, WAVE); }
 __device__ __forceinline__ int hmx_shfl_xor(int v, int o) { return __shfl_xor(v, o, WAVE); }
 template <typename T> __device__ __forceinline__ cplx<T> hmx_shfl_xor(cplx<T> v, int o) { return cplx<T>(__shfl_xor(v.re, o, WAVE), __shfl_xor(v.im, o, WAVE)); }
+__device__ __forceinline__ double hmx_shfl(double v, int l) { return __shfl(v, l, WAVE); }
+__device__ __forceinline__ float hmx_shfl(float v, int l) { return __shfl(v, l, WAVE); }
+template <typename T> __device__ __forceinline__ cplx<T> hmx_shfl(cplx<T> v, int l) { return cplx<T>(__shfl(v.re, l, WAVE), __shfl(v.im, l, WAVE)); }
 __device__ __forceinline__ void hmx_atomic_add(double *p, double v) { atomicAdd(p, v); }
 __device__ __forceinline__ void hmx_atomic_add(float *p, float v) { atomicAdd(p, v); }
 template <typename T> __device__ __forceinline__ void hmx_atomic_add(cplx<T> *p, cplx<T> v) {

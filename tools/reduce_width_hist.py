@@ -1,15 +1,17 @@
 """Distribution of R-stream chunk widths at N=1e6 (weighted by coefficients): how full are the reduce kernel's waves?"""
 import sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import htool_amd as hm
 n = 1000000
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # >0: the block rows of rank 0 of a `world`-rank run
 x = hm.create_geometry("ellipse", n)
 b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(100)
-T = b.create_cluster_tree(n, 3, x, 2, 2)
+T = b.create_cluster_tree(n, 3, x, 2, world if world else 2)
 tb = hm.HMatrixTreeBuilder(1e-4, 10.0, "N", "N"); tb.set_low_rank_generator("partialACA")
 tb.set_minimal_target_depth(5); tb.set_minimal_source_depth(5)
-H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T)
+H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, 0 if world else -1, 0 if world else -1)
 lt = H.leaf_table()
 lr = lt[lt[:, 4] > 0]
 key = lr[:, 2].astype(np.int64) * (1 << 32) + lr[:, 3]
