@@ -227,11 +227,15 @@ class GraphedGlobalToGlobalProduct:
         self.local = torch.zeros(self.out_part.get_size_of_partition(rank), dtype=y.dtype, device=y.device)
 
         def local_work():
-            self.local.zero_()
+            first = True  # the first operator overwrites the slice (beta = 0): no memset, no read of the old values
             for op in A.global_to_local_operators:
-                op.add_vector_product("N", alpha, x, 1.0, self.local)
+                op.add_vector_product("N", alpha, x, 0.0 if first else 1.0, self.local)
+                first = False
             for op in A.local_to_local_operators:
-                op.add_vector_product("N", alpha, x[off_in:off_in + n_in], 1.0, self.local)
+                op.add_vector_product("N", alpha, x[off_in:off_in + n_in], 0.0 if first else 1.0, self.local)
+                first = False
+            if first:
+                self.local.zero_()
 
         self._eager = local_work
         self.graph = None
