@@ -513,11 +513,14 @@ class HMatrixTreeBuilder:
               partition_number_for_symmetry=-1, device=0, compress=True, dtype=np.float64, local_partitions=None):
         """HMatrixTreeBuilder::build (tree_builder.hpp:199-210).  With compress=False only the structure is
         created on the device and blocks are expected through HMatrix.set_block_*() + finalize()."""
+        import time
+        t_bt = time.perf_counter()
         if local_partitions is not None:  # rooted at (target partition, source partition): block-diagonal operator
             bt = self._local_block_tree(target_root_cluster_tree, source_root_cluster_tree, *local_partitions)
         else:
             bt = self._block_tree(target_root_cluster_tree, source_root_cluster_tree, target_partition_number,
                                   partition_number_for_symmetry)
+        t_bt = time.perf_counter() - t_bt
         h = C.c_void_p()
         # HMatrix<T,double>: coefficients of type `dtype`, fp64 geometry
         prec = [k for k, v in _PREC.items() if np.dtype(v["np"]) == np.dtype(dtype)]
@@ -525,6 +528,8 @@ class HMatrixTreeBuilder:
             raise HmxError("dtype must be float64, float32, complex128 or complex64")
         check(getattr(lib(), "hmx_hmatrix_create" + _PREC[prec[0]]["sfx"])(bt, device, C.byref(h)))
         H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
+        H._tree_parameters = dict(eta=self._eta, epsilon=self._eps, min_target_depth=self._mint, min_source_depth=self._mins)
+        H._block_tree_walltime = t_bt
         if isinstance(generator, VirtualGenerator):
             H._callback = generator._as_callback(H.prec)  # keep the ctypes thunk alive as long as the operator
             check(_fn(H, "hmx_hmatrix_set_callback")(h, H._callback, None))
@@ -557,7 +562,84 @@ class HMatrixTreeBuilder:
         except HmxError:
             lib().hmx_block_tree_destroy(bt)
             raise
-        return HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
+        H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
+        H._tree_parameters = dict(eta=self._eta, epsilon=self._eps, min_target_depth=self._mint, min_source_depth=self._mins)
+        return H
+
+
+def get_tree_parameters(hmatrix):
+    """get_tree_parameters (hmatrix/hmatrix_output.hpp:85-99): the same keys, values formatted as std::to_string does."""
+    p = getattr(hmatrix, "_tree_parameters", None)
+    if p is None:
+        raise HmxError("this HMatrix was not created by HMatrixTreeBuilder.build / load")
+    T, S = hmatrix._keep
+    return {
+        "Eta": "%f" % p["eta"], "Epsilon": "%f" % p["epsilon"],
+        "MinTargetDepth": str(p["min_target_depth"]), "MinSourceDepth": str(p["min_source_depth"]),
+        "MaxClusterLeafSizeTarget": str(T.get_maximal_leaf_size()), "MaxClusterDepthTarget": str(T.get_maximal_depth()),
+        "MinClusterDepthTarget": str(T.get_minimal_depth()),
+        "MaxClusterLeafSizeSource": str(S.get_maximal_leaf_size()), "MaxClusterDepthSource": str(S.get_maximal_depth()),
+        "MinClusterDepthSource": str(S.get_minimal_depth()),
+    }
+
+
+def get_hmatrix_information(hmatrix):
+    """get_hmatrix_information (hmatrix/hmatrix_output.hpp:133-216): block-size / rank statistics, compression ratio and space
+    saving of the stored leaves, the builder's false-positive count and the device build times.  Same keys and number
+    formatting as the reference (its minima start from max(rows, columns), :145); Number_of_threads is an OpenMP figure and is
+    not reported."""
+    nr, nc = hmatrix.nb_rows(), hmatrix.nb_cols()
+    lt = hmatrix.leaf_table()
+    size = lt[:, 1].astype(np.int64) * lt[:, 3].astype(np.int64) if len(lt) else np.zeros(0, dtype=np.int64)
+    lr = lt[:, 4] >= 0 if len(lt) else np.zeros(0, dtype=bool)
+    dn = ~lr
+    cap = max(nr, nc)
+    generated = float((lt[lr, 4].astype(np.int64) * (lt[lr, 1].astype(np.int64) + lt[lr, 3])).sum() + size[dn].sum()) if len(lt) else 0.0
+
+    def mx(v):
+        return int(v.max()) if len(v) else 0
+
+    def mn(v):
+        return min(cap, int(v.min())) if len(v) else 0
+
+    def mean(v):
+        return float(v.sum()) / len(v) if len(v) else 0.0
+
+    st = hmatrix.stats()
+    info = {
+        "Target_size": str(nr), "Source_size": str(nc),
+        "Dense_block_size_max": str(mx(size[dn])), "Dense_block_size_mean": "%f" % mean(size[dn]), "Dense_block_size_min": str(mn(size[dn])),
+        "Low_rank_block_size_max": str(mx(size[lr])), "Low_rank_block_size_mean": "%f" % mean(size[lr]), "Low_rank_block_size_min": str(mn(size[lr])),
+        "Rank_max": str(mx(lt[lr, 4]) if len(lt) else 0), "Rank_mean": "%f" % (mean(lt[lr, 4].astype(np.int64)) if len(lt) else 0.0),
+        "Rank_min": str(mn(lt[lr, 4]) if len(lt) else 0),
+        "Number_of_low_rank_blocks": str(int(lr.sum())), "Number_of_dense_blocks": str(int(dn.sum())),
+        "Compression_ratio": "%f" % ((nr * nc) / generated if generated else float("inf")),
+        "Space_saving": "%f" % (1 - generated / (nr * nc)) if nr * nc else "%f" % 0.0,
+        "Number_of_false_positive": str(int(st["n_false_positive"])),
+        "Blocks_computation_walltime": "%f second(s)" % (st["t_compress_s"] + st["t_assemble_s"] + st["t_pack_s"]),
+        "Block_tree_walltime": "%f second(s)" % getattr(hmatrix, "_block_tree_walltime", 0.0),
+    }
+    return info
+
+
+def _print_map(title, entries, width, file):
+    import sys
+    out = sys.stdout if file is None else file
+    out.write(title + "\n")
+    for k in sorted(entries):  # std::map order
+        out.write(k.ljust(width, "_") + entries[k] + "\n")
+
+
+def print_tree_parameters(hmatrix, file=None):
+    """print_tree_parameters (hmatrix/hmatrix_output.hpp:101-118): the text use_hmatrix.cpp prints, byte for byte."""
+    _print_map("Block tree parameters", get_tree_parameters(hmatrix), 25, file)
+    (__import__("sys").stdout if file is None else file).write("\n")
+
+
+def print_hmatrix_information(hmatrix, file=None):
+    """print_hmatrix_information (hmatrix/hmatrix_output.hpp:218-236)."""
+    info = get_hmatrix_information(hmatrix)
+    _print_map("Hmatrix information", info, 2 + max(len(k) for k in info), file)
 
 
 def internal_add_hmatrix_vector_product(trans, alpha, A, x, beta, y):

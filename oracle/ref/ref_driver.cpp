@@ -34,6 +34,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <map>
 #include <random>
 #include <string>
@@ -378,6 +379,11 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
         Cluster<double> reread = read_cluster_tree<double>(save_prefix + "_cluster_tree_properties.csv", save_prefix + "_cluster_tree.csv");
         save_cluster_tree(reread, save_prefix + "_reread");
         save_leaves_with_rank(H, save_prefix + "_leaves");
+        { // print_tree_parameters + print_hmatrix_information (hmatrix/hmatrix_output.hpp:101-118,218-236), as use_hmatrix.cpp prints them
+            std::ofstream info(save_prefix + "_information.txt");
+            print_tree_parameters(H, info);
+            print_hmatrix_information(H, info);
+        }
         for (auto *l : leaf_ptr)
             if (l->is_dense()) {
                 matrix_to_bytes(*l->get_dense_data(), save_prefix + "_dense0.bin");

@@ -121,7 +121,7 @@ def main():
                 subprocess.check_call(cmd)
                 d = {}
                 for key, fn in (("tree", "f_cluster_tree.csv"), ("properties", "f_cluster_tree_properties.csv"), ("reread_tree", "f_reread_cluster_tree.csv"),
-                                ("reread_properties", "f_reread_cluster_tree_properties.csv"), ("leaves", "f_leaves.csv"), ("dense0", "f_dense0.bin")):
+                                ("reread_properties", "f_reread_cluster_tree_properties.csv"), ("leaves", "f_leaves.csv"), ("dense0", "f_dense0.bin"), ("information", "f_information.txt")):
                     d[key] = np.fromfile(os.path.join(tmp, fn), dtype=np.uint8)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
             manifest[name] = dict(mode=mode, **params)

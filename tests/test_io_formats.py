@@ -132,3 +132,26 @@ def test_operator_binary_dump_roundtrip(name, dtype, tmp_path):
     tb2 = hm.HMatrixTreeBuilder(p["eps"], p["eta"] / 2, p["sym"], p["uplo"])
     with pytest.raises(hm.HmxError, match="different block tree|does not match"):
         tb2.load(tmp_path / "op.hmx", T, S, p["rank"], p["rank"])
+
+
+def _information_lines(text):
+    """The reference's print_tree_parameters + print_hmatrix_information output without the wall-clock / thread-count lines."""
+    return [ln for ln in text.splitlines() if not ln.startswith(("Block_tree_walltime", "Blocks_computation_walltime", "Number_of_threads"))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", IO_CASES)
+def test_tree_parameters_and_hmatrix_information(name):
+    """print_tree_parameters + print_hmatrix_information (what use_hmatrix.cpp prints): byte-identical to the text the
+    reference wrote for the same operator, apart from its timing and OpenMP lines."""
+    p, g = params(name), load(name)
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
+    tb.set_low_rank_generator(p["compressor"])
+    H = tb.build(hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]), T, S, p["rank"], p["rank"])
+    out = io.StringIO()
+    hm.print_tree_parameters(H, out)
+    hm.print_hmatrix_information(H, out)
+    assert _information_lines(out.getvalue()) == _information_lines(g["information"].tobytes().decode())
+    info = hm.get_hmatrix_information(H)
+    assert info["Blocks_computation_walltime"].endswith(" second(s)") and float(info["Compression_ratio"]) > 1
