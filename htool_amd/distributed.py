@@ -381,3 +381,84 @@ class DefaultLocalApproximationBuilder:
         self.local_hmatrix = LocalToLocalHMatrix(self.hmatrix)
         self.distributed_operator = DistributedOperator(self.target_partition, self.source_partition, group)
         self.distributed_operator.add_local_to_local_operator(self.local_hmatrix)
+
+
+def get_distributed_hmatrix_information(hmatrix, group=None):
+    """get_distributed_hmatrix_information (hmatrix/hmatrix_distributed_output.hpp:30-214): block-size / rank statistics of the
+    rank-local H-matrices reduced over the ranks (max / min / sum), compression ratio and space saving of the whole
+    operator, summed integer build information, max / mean / min of the build times.  Same keys and number formatting as
+    the reference; the map is filled on rank 0 only (empty elsewhere), the OpenMP thread-count line is not reported and
+    Number_of_procs is the number of ranks (one GPU each).  `hmatrix` needs nb_rows(), nb_cols(), leaf_table() and stats()."""
+    ini = dist.is_initialized()
+    rank = dist.get_rank(group) if ini else 0
+    world = dist.get_world_size(group) if ini else 1
+    nr, nc = int(hmatrix.nb_rows()), int(hmatrix.nb_cols())
+    local_size = nr * nc
+    lt = np.asarray(hmatrix.leaf_table())
+    lt = lt.reshape(-1, lt.shape[1] if lt.ndim == 2 else 6)
+    size = lt[:, 1].astype(np.int64) * lt[:, 3].astype(np.int64)
+    lr = lt[:, 4] >= 0
+    dn = ~lr
+    ranks = lt[lr, 4].astype(np.int64)
+    generated = int((ranks * (lt[lr, 1].astype(np.int64) + lt[lr, 3])).sum() + size[dn].sum())
+
+    def mx(v):
+        return int(v.max()) if len(v) else 0
+
+    def mn(v):  # the reference starts its minima from the local size (:47)
+        return min(local_size, int(v.min())) if len(v) else local_size
+
+    st = hmatrix.stats()
+    timings = {"Blocks_computation_walltime": float(st.get("t_compress_s", 0.0)) + float(st.get("t_assemble_s", 0.0)) + float(st.get("t_pack_s", 0.0)),
+               "Block_tree_walltime": float(getattr(hmatrix, "_block_tree_walltime", 0.0))}
+    names = sorted(timings)
+    maxi = torch.tensor([mx(size[dn]), mx(size[lr]), mx(ranks), nr, nc] + [0] * len(names), dtype=torch.float64)
+    mini = torch.tensor([mn(size[dn]), mn(size[lr]), mn(ranks), nr, nc] + [0] * len(names), dtype=torch.float64)
+    sums = torch.tensor([float(size[dn].sum()), float(size[lr].sum()), float(ranks.sum()), float(nr), float(nc),
+                         float(dn.sum()), float(lr.sum()), float(local_size), float(generated), float(st["n_false_positive"])] +
+                        [timings[k] for k in names], dtype=torch.float64)
+    for k, name in enumerate(names):
+        maxi[5 + k] = mini[5 + k] = timings[name]
+    if ini and world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        maxi, mini, sums = maxi.to(dev), mini.to(dev), sums.to(dev)
+        dist.all_reduce(maxi, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(mini, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        maxi, mini, sums = maxi.cpu(), mini.cpu(), sums.cpu()
+    if rank != 0:
+        return {}
+    nd, nl, total_size, total_generated = int(sums[5]), int(sums[6]), int(sums[7]), int(sums[8])
+    info = {
+        "Target_size_max": str(int(maxi[3])), "Target_size_mean": "%f" % (float(sums[3]) / world), "Target_size_min": str(int(mini[3])),
+        "Source_size_max": str(int(maxi[4])), "Source_size_mean": "%f" % (float(sums[4]) / world), "Source_size_min": str(int(mini[4])),
+        "Dense_block_size_max": str(int(maxi[0])), "Dense_block_size_mean": "%f" % (float(sums[0]) / nd if nd else 0.0),
+        "Dense_block_size_min": str(int(mini[0]) if nd else 0),
+        "Low_rank_block_size_max": str(int(maxi[1])), "Low_rank_block_size_mean": "%f" % (float(sums[1]) / nl if nl else 0.0),
+        "Low_rank_block_size_min": str(int(mini[1]) if nl else 0),
+        "Rank_max": str(int(maxi[2])), "Rank_mean": "%f" % (float(sums[2]) / nl if nl else 0.0), "Rank_min": str(int(mini[2]) if nl else 0),
+        "Number_of_low_rank_blocks": str(nl), "Number_of_dense_blocks": str(nd),
+        "Compression_ratio": "%f" % (total_size / float(total_generated)) if total_generated else "inf",
+        "Space_saving": "%f" % (1 - float(total_generated) / total_size) if total_size else "%f" % 0.0,
+        "Number_of_MPI_tasks": str(world), "Number_of_procs": str(world),
+        "Number_of_false_positive": str(int(sums[9])),
+    }
+    for k, name in enumerate(names):
+        info[name + "_max"] = "%f second(s)" % float(maxi[5 + k])
+        info[name + "_mean"] = "%f second(s)" % (float(sums[10 + k]) / world)
+        info[name + "_min"] = "%f second(s)" % float(mini[5 + k])
+    return info
+
+
+def print_distributed_hmatrix_information(hmatrix, file=None, group=None):
+    """print_distributed_hmatrix_information (hmatrix/hmatrix_distributed_output.hpp:218-243): rank 0 writes the text
+    use_distributed_operator.cpp prints; every rank must call it (it reduces over the group)."""
+    import sys
+    info = get_distributed_hmatrix_information(hmatrix, group)
+    if not info:
+        return
+    out = sys.stdout if file is None else file
+    width = 2 + max(len(k) for k in info)
+    out.write("Distributed Hmatrix information\n")
+    for k in sorted(info):
+        out.write(k.ljust(width, "_") + info[k] + "\n")

@@ -99,6 +99,10 @@ CASES = {
     "io_ball_n1200_c4_p4": ("io", dict(n=1200, geom="ball", leaf=30, children=4, partitions=4, eps=1e-3, partitioning="n_pca_regular", compressor="partialACA")),
     "io_disk2d_n800_symL_p1": ("io", dict(n=800, geom="disk2d", leaf=40, eps=1e-3, partitions=1, sym="S", uplo="L", compressor="sympartialACA")),
     "io_ball_n1500_p4_rank2": ("io", dict(n=1500, geom="ball", leaf=50, eps=1e-3, partitions=4, rank=2, compressor="partialACA")),
+    # print_distributed_hmatrix_information of the reference run under MPI (oracle/_ref/dist_info, world = partitions): the
+    # text rank 0 prints for the operators whose per-rank leaf tables are the *_p4_rank* / *_p2_symL_rank* fixtures above
+    "distinfo_ellipse_n4000_p4": ("distinfo", dict(n=4000, geom="ellipse", leaf=100, partitions=4, eps=1e-4, compressor="partialACA")),
+    "distinfo_ball_n2000_p2_symL": ("distinfo", dict(n=2000, geom="ball", leaf=50, partitions=2, eps=1e-3, sym="S", uplo="L", compressor="sympartialACA")),
     # the reference's own compressor test block (500 x 100, two disks at distance d)
     **{"lrmat_d%d" % d: ("lrmat", dict(distance=d, eps=1e-4)) for d in (15, 20, 30, 40)},
 }
@@ -114,6 +118,15 @@ def main():
             continue
         params = dict(params)
         keep_coords = params.pop("keep_coords", 0)
+        if mode == "distinfo":
+            with tempfile.TemporaryDirectory() as tmp:
+                exe = os.path.join(ROOT, "oracle", "_ref", "dist_info")
+                cmd = ["/opt/conda/bin/mpiexec", "-n", str(params["partitions"]), exe] + ["%s=%s" % (k, v) for k, v in params.items()] + ["out=" + tmp + "/info.txt"]
+                print(" ".join(cmd))
+                subprocess.check_call(cmd, env=dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs")))
+                np.savez_compressed(os.path.join(HERE, name + ".npz"), information=np.fromfile(os.path.join(tmp, "info.txt"), dtype=np.uint8))
+            manifest[name] = dict(mode=mode, **params)
+            continue
         if mode == "io":
             with tempfile.TemporaryDirectory() as tmp:
                 cmd = [DRIVER, "hmat"] + ["%s=%s" % (k, v) for k, v in params.items()] + ["out=" + tmp + "/d.bin", "dump_blocks=0", "save_prefix=" + tmp + "/f"]

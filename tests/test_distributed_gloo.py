@@ -191,3 +191,65 @@ def test_partition_numbering_round_trip():
     w = p.global_to_partition_numbering(v)
     assert torch.equal(w, torch.from_numpy(T.get_permutation().astype(np.float64)))
     assert torch.equal(p.partition_to_global_numbering(w), v)
+
+
+class _ReferenceLocalHMatrix:
+    """Rank-local H-matrix described by the reference's own leaf table for that rank (fixture *_rank<k>): what
+    get_distributed_hmatrix_information needs from an HMatrix, without a GPU."""
+
+    def __init__(self, fixture):
+        from helpers import load
+        g = load(fixture)
+        self._leaves, self._root = g["leaves"], g["rootinfo"]
+
+    def nb_rows(self):
+        return int(self._root[1])
+
+    def nb_cols(self):
+        return int(self._root[3])
+
+    def leaf_table(self):
+        return self._leaves
+
+    def stats(self):
+        return dict(n_false_positive=int(self._root[4]), t_compress_s=0.01 * (1 + int(self._root[0] > 0)), t_assemble_s=0.0, t_pack_s=0.0)
+
+
+def _info_worker(rank, world, port, stem, q):
+    import io
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = io.StringIO()
+        D.print_distributed_hmatrix_information(_ReferenceLocalHMatrix("%s_rank%d" % (stem, rank)), out)
+        q.put((rank, out.getvalue()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stem,fixture,world", [("ellipse_n4000_p4", "distinfo_ellipse_n4000_p4", 4), ("ball_n2000_p2_symL", "distinfo_ball_n2000_p2_symL", 2)])
+def test_distributed_hmatrix_information_matches_reference_text(stem, fixture, world):
+    """print_distributed_hmatrix_information over gloo, fed with the reference's per-rank leaf tables, against the text the
+    reference printed under MPI for the same operator (tests/golden/distinfo_*: oracle/_ref/dist_info); its wall-clock and
+    OpenMP lines are machine facts and are left out of the comparison."""
+    from helpers import load
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_info_worker, args=(r, world, port, stem, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    skip = ("Block_tree_walltime", "Blocks_computation_walltime", "Number_of_threads_per_tasks", "Number_of_procs")
+
+    def lines(t):
+        return [ln for ln in t.splitlines() if not ln.startswith(skip)]
+
+    ref = load(fixture)["information"].tobytes().decode()
+    assert lines(got[0]) == lines(ref)
+    assert all(got[r] == "" for r in range(1, world))  # rank 0 prints, as in the reference
+    timing = [ln for ln in got[0].splitlines() if ln.startswith("Blocks_computation_walltime")]
+    assert len(timing) == 3 and all(ln.endswith(" second(s)") for ln in timing)
