@@ -457,6 +457,8 @@ class HMatrixTreeBuilder:
         self._compressor = low_rank_strategy or "sympartialACA"
         self._mint = self._mins = 0
         self._consistent = True
+        self._recompressed = False  # RecompressedLowRankGenerator form of the compressor
+        self._adm = None            # user admissibility condition (ctypes thunk), None: Rjasanow-Steinbach
 
     def set_low_rank_generator(self, name, recompressed=False):
         """One of the device compressors; recompressed=True wraps it like htool's RecompressedLowRankGenerator
@@ -483,14 +485,29 @@ class HMatrixTreeBuilder:
         if condition is None:
             self._adm = None
             return
-        self._adm = _lib.ADMISSIBILITY_FN(lambda _u, t, s, eta: int(bool(condition(t.contents, s.contents, eta))))
+        self._adm_error = None
+
+        def thunk(_user, t, s, eta):  # an exception cannot cross the C frames: keep it and raise it after the build
+            try:
+                return int(bool(condition(t.contents, s.contents, eta)))
+            except BaseException as e:  # noqa: B902
+                if self._adm_error is None:
+                    self._adm_error = e
+                return 0
+
+        self._adm = _lib.ADMISSIBILITY_FN(thunk)
 
     def _block_tree(self, target, source, target_partition_number, partition_number_for_symmetry):
         h = C.c_void_p()
-        if getattr(self, "_adm", None) is not None:
+        if self._adm is not None:
+            self._adm_error = None
             check(lib().hmx_block_tree_create_adm(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(),
                                                   self._mint, self._mins, target_partition_number, partition_number_for_symmetry,
                                                   int(self._consistent), self._adm, None, C.byref(h)))
+            if self._adm_error is not None:
+                lib().hmx_block_tree_destroy(h)
+                err, self._adm_error = self._adm_error, None
+                raise err
             return h
         check(lib().hmx_block_tree_create(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(),
                                           self._mint, self._mins, target_partition_number, partition_number_for_symmetry,
@@ -542,7 +559,7 @@ class HMatrixTreeBuilder:
         if compress:
             check(lib().hmx_hmatrix_compress(h, _lib.COMPRESSORS[self._compressor], self._eps, self._reqrank))
             H.refresh_leaves()
-            if getattr(self, "_recompressed", False):
+            if self._recompressed:
                 H.recompress()
         return H
 

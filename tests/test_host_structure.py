@@ -136,5 +136,11 @@ def test_user_admissibility_condition():
     tb.set_admissibility_condition(lambda t, s, eta: False)
     dense = tb.build_block_tree(T, S).leaves
     assert dense["admissible"].sum() == 0 and (dense["t_size"].astype(np.int64) * dense["s_size"]).sum() == p["n"] ** 2
+    def broken(t, s, eta):
+        raise RuntimeError("user condition failed")
+
+    tb.set_admissibility_condition(broken)  # an exception in the callback surfaces after the build instead of being lost
+    with pytest.raises(RuntimeError, match="user condition failed"):
+        tb.build_block_tree(T, S)
     tb.set_admissibility_condition(None)
     assert np.array_equal(tb.build_block_tree(T, S).leaves, ref)
