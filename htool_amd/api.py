@@ -225,10 +225,17 @@ class VirtualGenerator:
         cplx = _PREC[prec]["complex"]
         rdt = np.float32 if prec in (_lib.HMX_PREC_F32, _lib.HMX_PREC_C32) else np.float64
 
+        self._callback_error = None
+
         def trampoline(_user, M, N, rows, cols, out):
             r = np.ctypeslib.as_array(rows, shape=(M,))
             c = np.ctypeslib.as_array(cols, shape=(N,))
-            block = np.asarray(self.copy_submatrix(M, N, r, c), dtype=dt).reshape(M, N)
+            try:
+                block = np.asarray(self.copy_submatrix(M, N, r, c), dtype=dt).reshape(M, N)
+            except BaseException as e:  # noqa: B902 -- cannot cross the C frames: zero block now, raised by build() afterwards
+                if self._callback_error is None:
+                    self._callback_error = e
+                block = np.zeros((M, N), dtype=dt)
             if cplx:  # interleaved (re, im), column-major M x N
                 np.ctypeslib.as_array(out, shape=(N, M, 2))[:] = np.ascontiguousarray(block.T).view(rdt).reshape(N, M, 2)
             else:
@@ -558,6 +565,9 @@ class HMatrixTreeBuilder:
             check(lib().hmx_hmatrix_set_kernel(h, 0, _dp(params), 5, generator.dim, _dp(generator.xt), _dp(generator.xs)))
         if compress:
             check(lib().hmx_hmatrix_compress(h, _lib.COMPRESSORS[self._compressor], self._eps, self._reqrank))
+            if getattr(generator, "_callback_error", None) is not None:  # raised inside copy_submatrix during the build
+                err, generator._callback_error = generator._callback_error, None
+                raise err
             H.refresh_leaves()
             if self._recompressed:
                 H.recompress()

@@ -544,6 +544,26 @@ def test_host_callback_generator(name):
             assert np.array_equal(H.get_block(int(k[2:])), g[k].T)
 
 
+def test_host_callback_generator_exception_surfaces():
+    """An exception raised inside the user's copy_submatrix cannot cross the C frames: build() raises it afterwards."""
+    p = params("ball_n2000_partial")
+    T, S = build_trees(p)
+
+    class Failing(hm.VirtualGenerator):
+        calls = 0
+
+        def copy_submatrix(self, M, N, rows, cols):
+            self.calls += 1
+            if self.calls == 5:
+                raise ValueError("generator failed on purpose")
+            return np.ones((M, N))
+
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    with pytest.raises(ValueError, match="generator failed on purpose"):
+        tb.build(Failing(), T, S)
+
+
 @pytest.mark.parametrize("name", ["rect_ball1500_disk1000", "ellipse_n4000_p4_rank2", "ball_n2000_p2_symL_rank1", "ellipse_n3000_symL_default"])
 @pytest.mark.parametrize("mu", [1, 3, 16])
 def test_transposed_products_both_layouts(name, mu, monkeypatch):
