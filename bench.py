@@ -220,8 +220,13 @@ def main():
         Xmu = torch.from_numpy(np.random.default_rng(2).random((n, mu)).astype(np_dt)).to(dev)
         Ymu = torch.zeros((H.nb_rows(), mu), dtype=t_dt, device=dev)
 
+    if mu > 1 and part:
+        Yg = torch.zeros((n, mu), dtype=t_dt, device=dev)  # every rank receives the whole result (global-to-global contract)
+
     def step():
-        if mu > 1:
+        if mu > 1 and part:  # BASELINE config 5: row-partitioned multi-RHS product, all-gather of the mu-interleaved row slices
+            D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, Yg, mu)
+        elif mu > 1:
             hm.internal_add_hmatrix_matrix_product_row_major(args.trans, 1.0, H, Xmu, 0.0, Ymu, mu)
         elif part:
             D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y)

@@ -14,14 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_one_gpu():
+@pytest.mark.parametrize("extra", [[], ["--mu", "4"]])
+def test_bench_two_ranks_one_gpu(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HMX_BENCH_SAME_DEVICE="1", HMX_BENCH_BACKEND="gloo", HMX_BENCH_N="200000")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
