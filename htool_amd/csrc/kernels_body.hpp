@@ -1268,6 +1268,93 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
 // in the reduce stage, gathered coefficients in the expand stage) is staged in a wave-private LDS tile and read
 // back as broadcast ds_read_b128, so the inner loops are one stream load + MU FMAs per lane.
 // ---------------------------------------------------------------------------------------------
+// Narrow chunk (at most half a wave wide) of the multi-RHS reduce stage, same idea as in reduce_kernel: a wave-wide load
+// covers R = floor(wave elements / wp) whole rows of the contiguous row-major chunk, lane l works on row group EPL*l / wp and
+// reads ITS row's MU operands from the wave-private LDS tile (R distinct rows per ds_read instead of one broadcast row:
+// the same LDS time for R rows of stream).  The R partial sums per column are folded in a fixed tree at the end.
+template <int MU>
+__device__ __forceinline__ void reduce_mu_narrow(const ReduceArgs &A, scalar (*xt)[MU], int lane, int S, int ch, int len, int w, int wp, int cw,
+                                                 const scalar *src, const scalar *xs, int mu, int cbase) {
+    constexpr int EPL = HMX_SPLIT_COLS ? 1 : 2;
+    const int R = (64 * EPL) / wp, hw = wp / EPL;
+    const int g = lane / hw, e0 = EPL * lane;
+    const bool lane_ok = g < R;
+    scalar a0[MU], a1[MU];
+#pragma unroll
+    for (int c = 0; c < MU; c++)
+        a0[c] = a1[c] = scalar(0);
+    for (int i0 = 0; i0 < len; i0 += 64) {
+        const int nr = (len - i0) < 64 ? (len - i0) : 64;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nr) {
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                xt[lane][c] = xs[(int64_t)(i0 + lane) * mu + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const scalar *p = src + (int64_t)i0 * wp + e0;
+        for (int j = 0; j < nr; j += 4 * R) {
+#if HMX_SPLIT_COLS
+            scalar v[4];
+#else
+            scalar2 v[4];
+#endif
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ok[u] = lane_ok && j + u * R + g < nr;
+#if HMX_SPLIT_COLS
+                v[u] = ok[u] ? stream_load(p + (int64_t)(j + u * R) * wp) : scalar(0);
+#else
+                v[u] = ok[u] ? stream_load(reinterpret_cast<const scalar2 *>(p + (int64_t)(j + u * R) * wp)) : scalar2{scalar(0), scalar(0)};
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ok[u]) { // masked lanes do not touch their sums (no 0 * inf)
+                    const scalar *xr = xt[j + u * R + g];
+#pragma unroll
+                    for (int c = 0; c < MU; c++) {
+#if HMX_SPLIT_COLS
+                        a0[c] = hmx_fma(v[u], xr[c], a0[c]);
+#else
+                        a0[c] = hmx_fma(v[u].x, xr[c], a0[c]);
+                        a1[c] = hmx_fma(v[u].y, xr[c], a1[c]);
+#endif
+                    }
+                }
+        }
+    }
+    for (int n = R; n > 1;) {
+        const int h = (n + 1) >> 1;
+#pragma unroll
+        for (int c = 0; c < MU; c++) {
+            const scalar t0 = hmx_shfl(a0[c], lane + h * hw), t1 = hmx_shfl(a1[c], lane + h * hw);
+            if (g + h < n) {
+                a0[c] += t0;
+                a1[c] += t1;
+            }
+        }
+        n = h;
+    }
+    if (lane < hw) {
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        const int c0     = EPL * lane;
+        if (c0 < w) {
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb + c0] * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                dst[c] = a0[c];
+        }
+        if (EPL == 2 && c0 + 1 < w) {
+            scalar *dst = A.Z + (int64_t)A.out_idx[cb + c0 + 1] * mu + cbase;
+#pragma unroll
+            for (int c = 0; c < MU; c++)
+                dst[c] = a1[c];
+        }
+    }
+}
+
 template <int WAVES, int MU>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, int mu, int cbase) {
     __shared__ __attribute__((aligned(16))) scalar xt[WAVES][WAVE][MU];
@@ -1285,6 +1372,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
     const bool active = col0 < wp;
     const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
     const scalar *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
+    if (HMX_REDUCE_ROWS && wp <= (HMX_SPLIT_COLS ? 32 : 64)) {
+        reduce_mu_narrow<MU>(A, xt[wv], lane, S, ch, len, w, wp, cw, src, xs, mu, cbase);
+        return;
+    }
     scalar a0[MU], a1[MU];
 #pragma unroll
     for (int c = 0; c < MU; c++)
@@ -1442,6 +1533,11 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mus_kernel(ReduceArgs A, i
     const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
     const bool active = col0 < wp;
     const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    if (HMX_REDUCE_ROWS && wp <= 64) { // narrow chunk: rows differ between lanes, so the operand cannot be wave-uniform
+        __shared__ __attribute__((aligned(16))) scalar xt[WAVES][WAVE][MU];
+        reduce_mu_narrow<MU>(A, xt[wv], lane, S, ch, len, w, wp, cw, src, A.x + (int64_t)A.range_off[S] * mu + cbase, mu, cbase);
+        return;
+    }
     uniform_ptr xs    = (uniform_ptr)(A.x + (int64_t)A.range_off[S] * mu + cbase);
     scalar a0[MU], a1[MU];
 #pragma unroll
