@@ -1,0 +1,75 @@
+"""BASELINE.json's full-size configurations (N=1e5 and N=1e6 fp64, eta=10, eps=1e-4, partialACA) on the GPU, checked through
+size-independent properties -- the CPU reference needs minutes to hours and > 60 GB for these sizes, so there is no fixture:
+linearity, the adjoint identity <Hx, y> = <x, H^T y>, agreement of the fused multi-RHS product with single products, user
+numbering = permuted cluster numbering, and the error against EXACT kernel rows (evaluated in numpy for a row sample) below
+the compression tolerance."""
+import numpy as np
+import pytest
+
+import htool_amd as hm
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _depth(n):  # bench.py's minimal block depth for large n
+    d = 0
+    while (n >> (d + 1)) >= 8000:
+        d += 1
+    return min(d, 7)
+
+
+@pytest.mark.parametrize("n,geom", [(100000, "ball"), (100000, "ellipse"), (1000000, "ellipse")])
+def test_full_size_operator_properties(n, geom):
+    eps, eta, delta = 1e-4, 10.0, 1e-5
+    x = hm.create_geometry(geom, n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(100)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    tb = hm.HMatrixTreeBuilder(eps, eta, "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    tb.set_minimal_target_depth(_depth(n))
+    tb.set_minimal_source_depth(_depth(n))
+    H = tb.build(hm.InvDistGenerator(3, x, x, delta, 1.0), T, T)
+    st = H.stats()
+    assert st["n_lowrank"] > 0 and st["n_false_positive"] == 0
+    assert st["cgen_dense"] + st["cgen_lowrank"] < 0.1 * float(n) * n  # compressed: < 10 % of the dense matrix (7.9 % for the N=1e5 ball)
+    rng = np.random.default_rng(n)
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+
+    def mv(trans, vec):
+        y = np.zeros(n)
+        hm.internal_add_hmatrix_vector_product(trans, 1.0, H, vec, 0.0, y)
+        return y
+
+    yu, yv = mv("N", u), mv("N", v)
+    # linearity
+    assert rel_err(mv("N", 2 * u - 3 * v), 2 * yu - 3 * yv) < 1e-12
+    # alpha / beta
+    y = v.copy()
+    hm.internal_add_hmatrix_vector_product("N", -0.5, H, u, 2.0, y)
+    assert rel_err(y, -0.5 * yu + 2.0 * v) < 1e-12
+    # adjoint identity with the transposed product (the transposed stream layout at this size)
+    lhs, rhs = float(yu @ v), float(u @ mv("T", v))
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), np.linalg.norm(yu) * np.linalg.norm(v))
+    # fused multi-RHS (row-major) against the single products
+    X = np.ascontiguousarray(np.stack([u, v, u - v, 0.5 * u + v], axis=1))
+    Y = np.zeros((n, 4))
+    hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, X, 0.0, Y, 4)
+    assert rel_err(Y[:, 0], yu) < 1e-12 and rel_err(Y[:, 1], yv) < 1e-12 and rel_err(Y[:, 2], yu - yv) < 1e-12
+    # user numbering = permutation of the cluster numbering
+    perm = T.get_permutation()
+    yuser = np.zeros(n)
+    uu = np.empty(n)
+    uu[perm] = u
+    hm.add_hmatrix_vector_product("N", 1.0, H, uu, 0.0, yuser)
+    assert rel_err(yuser[perm], yu) < 1e-13
+    # exact kernel rows (user numbering): the compressed operator meets epsilon
+    rows = rng.choice(n, 64, replace=False)
+    exact = np.empty(len(rows))
+    for k, i in enumerate(rows):
+        d = np.sqrt(((x[i][None, :] - x) ** 2).sum(-1))
+        exact[k] = (1.0 / (delta + d)) @ uu
+    assert rel_err(yuser[rows], exact) < 2 * eps
+    # deterministic: the same product twice gives the same bits
+    assert np.array_equal(mv("N", u), yu)
