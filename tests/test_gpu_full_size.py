@@ -2,7 +2,7 @@
 size-independent properties -- the CPU reference needs minutes to hours and > 60 GB for these sizes, so there is no fixture:
 linearity, the adjoint identity <Hx, y> = <x, H^T y>, agreement of the fused multi-RHS product with single products, user
 numbering = permuted cluster numbering, and the error against EXACT kernel rows (evaluated in numpy for a row sample) below
-the compression tolerance."""
+the compression tolerance.  The second test covers the other end of the size range (1 ... 33 points, one-point leaves).""" 
 import numpy as np
 import pytest
 
@@ -73,3 +73,53 @@ def test_full_size_operator_properties(n, geom):
     assert rel_err(yuser[rows], exact) < 2 * eps
     # deterministic: the same product twice gives the same bits
     assert np.array_equal(mv("N", u), yu)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_degenerate_sizes_against_dense(dtype):
+    """The other end of the size range: 1 ... 33 points, leaf sizes 1 / 4 / 100 (single-leaf operators, one-point leaves,
+    ragged last clusters), one or two partitions, row restriction -- structure equal to the CPU oracle's, products (N, T, user
+    numbering, 3 right-hand sides) equal to the dense matrix."""
+    from oracle import oracle as O
+    cplx = dtype == np.complex128
+    pts = hm.create_geometry("ball", 64)
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 5, 9, 17, 33):
+        for leaf in (1, 4, 100):
+            for parts in (1, 2):
+                if parts > n:
+                    continue
+                x = pts[:n].copy()
+                b = hm.ClusterTreeBuilder()
+                b.set_maximal_leaf_size(leaf)
+                T = b.create_cluster_tree(n, 3, x, 2, parts)
+                To = O.ClusterTree(x, leaf, 2, parts)
+                assert np.array_equal(T.get_permutation(), To.perm)
+                if len(T.get_clusters_on_partition()) != parts:
+                    continue
+                tb = hm.HMatrixTreeBuilder(1e-6, 10.0, "N", "N")
+                tb.set_low_rank_generator("partialACA")
+                gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 0.5 if cplx else 0.0)
+                for rank in (-1, parts - 1):
+                    H = tb.build(gen, T, T, rank, rank, dtype=dtype)
+                    Ho = (O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=1.0, cim=0.5, eps=1e-6, eta=10.0, compressor="partialACA", rank=rank) if cplx
+                          else O.HMatrix(To, To, delta=1e-5, scale=1.0, eps=1e-6, eta=10.0, compressor="partialACA", rank=rank))
+                    assert np.array_equal(H.leaf_table()[:, :5], Ho.leaves[:, :5]), (n, leaf, parts, rank)
+                    perm = T.get_permutation()
+                    xc = x[perm]
+                    d = np.sqrt(((xc[:, None, :] - xc[None, :, :]) ** 2).sum(-1))
+                    A = ((1.0 + 0.5j) if cplx else 1.0) / (1e-5 + d)
+                    r0 = H.target_offset
+                    A = A[r0:r0 + H.nb_rows(), :]
+                    u = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
+                    w = (rng.standard_normal(H.nb_rows()) + (1j * rng.standard_normal(H.nb_rows()) if cplx else 0)).astype(dtype)
+                    y = np.zeros(H.nb_rows(), dtype=dtype)
+                    hm.internal_add_hmatrix_vector_product("N", 1.0, H, u, 0.0, y)
+                    assert rel_err(y, A @ u) < 1e-5, (n, leaf, parts, rank)
+                    yt = np.zeros(n, dtype=dtype)
+                    hm.internal_add_hmatrix_vector_product("T", 1.0, H, w, 0.0, yt)
+                    assert rel_err(yt, A.T @ w) < 1e-5, (n, leaf, parts, rank)
+                    X = np.ascontiguousarray(np.stack([u, 2 * u, -u], axis=1))
+                    Y = np.zeros((H.nb_rows(), 3), dtype=dtype)
+                    hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, X, 0.0, Y, 3)
+                    assert rel_err(Y, A @ X) < 1e-5, (n, leaf, parts, rank)
