@@ -1250,9 +1250,13 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         A.vis_ptr   = d_visptr.d;
         A.rank_out  = H.d_rank.d;
         A.swapped_out = H.d_swapped.d;
-        // the largest blocks (few, long critical path: every iteration walks n1 + n2 entries) get 1024-thread workgroups on a side
-        // stream, concurrently with the bulk of the blocks in 256-thread workgroups; `order` is sorted by n1 + n2, largest first
-        const int big_threshold = getenv("HMX_ACA_BIG") ? atoi(getenv("HMX_ACA_BIG")) : 8192;
+        // 1024-thread workgroups on a side stream for the largest blocks, concurrently with the rest in 256-thread workgroups
+        // (`order` is sorted by n1 + n2, largest first).  That shortens the critical path of a block (every iteration walks
+        // n1 + n2 entries) but lowers the throughput over many blocks: with ranks as expected it loses (N=1e6: 94 vs 79 ms,
+        // N=4e6 eps=1e-6: 0.37 vs 0.32 s), with a few very high-rank blocks it halves the time (Hermitian sign-discontinuous
+        // generator, ranks up to 646: 17.9 -> 8.7 s).  High ranks show up as an exhausted rank-estimated pool, so the retry
+        // with the full pool is the one that uses it.  HMX_ACA_BIG=<n1 + n2> forces the threshold for both attempts.
+        const int big_threshold = getenv("HMX_ACA_BIG") ? atoi(getenv("HMX_ACA_BIG")) : (full_pool ? 8192 : INT_MAX);
         size_t nbig = 0;
         while (nbig < order.size() && (int64_t)H.leaves[order[nbig]].t_size + H.leaves[order[nbig]].s_size >= big_threshold)
             nbig++;
@@ -1262,6 +1266,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             HMX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
             hipLaunchKernelGGL(aca_kernel<1024>, dim3((unsigned)nbig), dim3(1024), 0, side, A);
             HMX_HIP(hipEventRecord(big_done, side));
+            if (getenv("HMX_ACA_SERIAL") && atoi(getenv("HMX_ACA_SERIAL"))) // diagnosis: the two launches one after the other
+                HMX_HIP(hipStreamSynchronize(side));
         }
         if (order.size() > nbig) {
             A.order = d_order.d + nbig;
