@@ -975,6 +975,17 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         set_error("hmx_hmatrix_compress: no generator set (hmx_hmatrix_set_kernel or hmx_hmatrix_set_callback)");
         return HMX_ERR_STATE;
     }
+    // HMX_BUILD_TIMING=1: wall-clock of the build phases on stderr (tools/build_timing.py)
+    const bool phase_timing = getenv("HMX_BUILD_TIMING") && atoi(getenv("HMX_BUILD_TIMING"));
+    auto phase_t0           = std::chrono::steady_clock::now();
+    auto phase              = [&](const char *name) {
+        if (!phase_timing)
+            return;
+        (void)hipDeviceSynchronize();
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hmx build] %-28s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(t - phase_t0).count());
+        phase_t0 = t;
+    };
     const bool use_cb = H.callback != nullptr && !H.has_kernel;
     // evaluate one sub-block through the host generator: rows/cols are cluster positions, mapped to user numbers
     auto gen = [&](int M, int N, int row_pos, int col_pos, scalar *out) {
@@ -1030,7 +1041,9 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     HMX_HIP(hipMemGetInfo(&free_b, &total_b));
     const double budget        = 0.40 * (double)free_b / sizeof(scalar);
     const unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : 1.25 * estimate));
+    phase("host scratch tables");
     HMX_HIP(H.pool.alloc(cap));
+    phase("pool allocation");
     DArr<unsigned long long> head;
     HMX_HIP(head.alloc(1));
     HMX_HIP(head.zero());
@@ -1051,6 +1064,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     H.staged_off.assign(nb, -1);
     HMX_HIP(H.d_staged_off.upload(H.staged_off));
 
+    phase("scratch upload");
     DEvent e0, e1;
     HMX_HIP(hipEventRecord(e0, 0));
     if (!order.empty() && assembled) {
@@ -1291,6 +1305,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         HMX_HIP(hipMemcpy(H.swapped.data(), H.d_swapped.d, nb * 4, hipMemcpyDeviceToHost));
     }
     HMX_HIP(hipMemcpy(&H.pool_used, head.d, 8, hipMemcpyDeviceToHost));
+    phase("compression kernels");
     int64_t false_pos = 0;
     for (int32_t b : order) {
         if (ranks[b] == -2) {
@@ -1322,6 +1337,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             (void)hipGetLastError();
         }
     }
+    phase("pool shrink");
     if (use_cb) { // dense leaves (and failed admissible ones): HMatrix::compute_dense_data through the host generator
         int64_t tot = 0;
         for (size_t b = 0; b < nb; b++)
@@ -1341,6 +1357,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         H.dense_stage.release();
     }
     int rc = build_streams(H);
+    phase("stream layout + packing");
     if (rc != HMX_OK)
         return rc;
     H.stats.n_false_positive = false_pos;

@@ -1,5 +1,6 @@
 import time, numpy as np, sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # HMX_BUILD_TIMING=1: per-phase times of hmx_hmatrix_compress on stderr
 import htool_amd as hm, ctypes as C
 from htool_amd import _lib
 from htool_amd._lib import lib, check

@@ -3,9 +3,17 @@
 #include <chrono>
 #include <cstdio>
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int main() {
+#include <cstdlib>
+#include <vector>
+int main(int argc, char **argv) {
     hipFree(0);
-    for (double gb : {1.0, 8.0, 32.0, 115.0, 32.0}) {
+    std::vector<double> sizes = {1.0, 8.0, 32.0, 115.0, 32.0};
+    if (argc > 1) { // sizes in GB from the command line
+        sizes.clear();
+        for (int i = 1; i < argc; i++)
+            sizes.push_back(atof(argv[i]));
+    }
+    for (double gb : sizes) {
         void *p = nullptr;
         double t0 = now();
         hipError_t e = hipMalloc(&p, (size_t)(gb * 1e9));
