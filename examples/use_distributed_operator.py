@@ -62,6 +62,14 @@ def run_distributed():
     err = np.linalg.norm(ref - y.cpu().numpy()) / np.linalg.norm(ref)
     if dist.get_rank() == 0:
         print("relative error on global to global matrix vector product : %.3e" % err)
+    # what use_distributed_operator.cpp:118-126 prints and writes
+    local_hmatrix = builder.hmatrix
+    if dist.get_rank() == 0:
+        hm.print_tree_parameters(local_hmatrix)
+        hm.print_hmatrix_information(local_hmatrix)
+    D.print_distributed_hmatrix_information(local_hmatrix)
+    out = [a for a in sys.argv[1:] if not a.startswith("--")]
+    hm.save_leaves_with_rank(local_hmatrix, os.path.join(out[0] if out else "./", "local_hmatrix_%d" % dist.get_rank()))
     dist.destroy_process_group()
 
 

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import htool_amd as hm  # noqa: E402
 
 
-def run(device=0):
+def run(device=0, output_folder=None):
     n = 10000
     coordinates = hm.create_geometry("ellipse", n)
     builder = hm.ClusterTreeBuilder()
@@ -28,10 +28,16 @@ def run(device=0):
     ref = (1.0 / (1e-5 + d)) @ x
     st = hmatrix.stats()
     err = np.linalg.norm(ref - y) / np.linalg.norm(ref)
+    if output_folder is not None:  # what use_hmatrix.cpp:101-103 writes and prints
+        hm.save_leaves_with_rank(hmatrix, os.path.join(output_folder, "hmatrix"))
+        hm.print_tree_parameters(hmatrix)
+        hm.print_hmatrix_information(hmatrix)
     return err, st
 
 
 if __name__ == "__main__":
-    err, st = run()
+    if len(sys.argv) > 2:
+        sys.exit("Usage: %s output_folder" % sys.argv[0])
+    err, st = run(output_folder=sys.argv[1] if len(sys.argv) == 2 else "./")
     print("dense leaves %d, low-rank leaves %d, rank %d/%.2f/%d" % (st["n_dense"], st["n_lowrank"], st["rank_min"], st["rank_mean"], st["rank_max"]))
     print("relative error on matrix vector product : %.3e" % err)
