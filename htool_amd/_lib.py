@@ -66,6 +66,7 @@ SYMBOLS = [
     ("hmx_block_tree_create", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_block_tree_create_adm", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ADMISSIBILITY_FN, _vp, C.POINTER(_vp)]),
     ("hmx_block_tree_create_local", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("hmx_block_tree_create_local_adm", C.c_int, [_vp, _vp, C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ADMISSIBILITY_FN, _vp, C.POINTER(_vp)]),
     ("hmx_block_tree_destroy", None, [_vp]),
     ("hmx_block_tree_num_leaves", C.c_int64, [_vp]),
     ("hmx_block_tree_leaves", C.c_int, [_vp, C.POINTER(Leaf)]),

@@ -465,6 +465,7 @@ class HMatrixTreeBuilder:
         self._mint = self._mins = 0
         self._consistent = True
         self._recompressed = False  # RecompressedLowRankGenerator form of the compressor
+        self._adm_error = None
         self._adm = None            # user admissibility condition (ctypes thunk), None: Rjasanow-Steinbach
 
     def set_low_rank_generator(self, name, recompressed=False):
@@ -523,8 +524,14 @@ class HMatrixTreeBuilder:
 
     def _local_block_tree(self, target, source, target_partition, source_partition):
         h = C.c_void_p()
-        check(lib().hmx_block_tree_create_local(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(), self._mint,
-                                                self._mins, target_partition, source_partition, int(self._consistent), C.byref(h)))
+        self._adm_error = None
+        check(lib().hmx_block_tree_create_local_adm(target._h, source._h, self._eta, self._sym.encode(), self._uplo.encode(), self._mint,
+                                                    self._mins, target_partition, source_partition, int(self._consistent),
+                                                    self._adm if self._adm is not None else _lib.ADMISSIBILITY_FN(), None, C.byref(h)))
+        if self._adm_error is not None:
+            lib().hmx_block_tree_destroy(h)
+            err, self._adm_error = self._adm_error, None
+            raise err
         return h
 
     def build_local_block_tree(self, target, source, target_partition, source_partition):

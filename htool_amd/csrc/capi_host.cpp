@@ -204,6 +204,12 @@ int hmx_block_tree_create_adm(const hmx_cluster_tree *target, const hmx_cluster_
 int hmx_block_tree_create_local(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry, char uplo,
                                 int min_target_depth, int min_source_depth, int target_partition, int source_partition,
                                 int block_tree_consistency, hmx_block_tree **out) {
+    return hmx_block_tree_create_local_adm(target, source, eta, symmetry, uplo, min_target_depth, min_source_depth, target_partition,
+                                           source_partition, block_tree_consistency, nullptr, nullptr, out);
+}
+int hmx_block_tree_create_local_adm(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry, char uplo,
+                                    int min_target_depth, int min_source_depth, int target_partition, int source_partition,
+                                    int block_tree_consistency, hmx_admissibility_fn fn, void *user, hmx_block_tree **out) {
     if (!target || !source || !out || target_partition < 0 || source_partition < 0) {
         hmx::set_error("hmx_block_tree_create_local: invalid argument");
         return HMX_ERR_INVALID;
@@ -219,6 +225,8 @@ int hmx_block_tree_create_local(const hmx_cluster_tree *target, const hmx_cluste
     bt->target_root_partition = target_partition;
     bt->source_root_partition = source_partition;
     bt->consistent            = block_tree_consistency != 0;
+    bt->admissibility         = fn;
+    bt->admissibility_user    = user;
     const int rc              = hmx::build_block_tree(*bt);
     if (rc != HMX_OK) {
         delete bt;

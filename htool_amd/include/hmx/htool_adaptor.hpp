@@ -193,8 +193,14 @@ class EngineT {
 
     // block tree rooted at (target partition, source partition): the block-diagonal / local-to-local operator
     // (DefaultLocalApproximationBuilder, distributed_operator/utility.hpp:64-88)
-    bool setup_local_block_tree(double eta, char symmetry, char UPLO, int min_target_depth, int min_source_depth, int target_partition, int source_partition, int device) {
-        if (!ok(hmx_block_tree_create_local(m_target, m_source, eta, symmetry, UPLO, min_target_depth, min_source_depth, target_partition, source_partition, 1, &m_block_tree), "local block tree"))
+    bool setup_local_block_tree(double eta, char symmetry, char UPLO, int min_target_depth, int min_source_depth, int target_partition, int source_partition, int device, const htool::VirtualAdmissibilityCondition<double> *condition = nullptr) {
+        AdmissibilityBridge bridge;
+        if (condition) {
+            bridge.condition = condition;
+            AdmissibilityBridge::index(*m_htool_target, bridge.target);
+            AdmissibilityBridge::index(*m_htool_source, bridge.source);
+        }
+        if (!ok(hmx_block_tree_create_local_adm(m_target, m_source, eta, symmetry, UPLO, min_target_depth, min_source_depth, target_partition, source_partition, 1, condition ? &AdmissibilityBridge::call : nullptr, &bridge, &m_block_tree), "local block tree"))
             return false;
         m_leaves.resize(hmx_block_tree_num_leaves(m_block_tree));
         hmx_block_tree_leaves(m_block_tree, m_leaves.data());

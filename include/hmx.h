@@ -136,6 +136,9 @@ int hmx_block_tree_create_adm(const hmx_cluster_tree *target, const hmx_cluster_
 int hmx_block_tree_create_local(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
                                 char uplo, int min_target_depth, int min_source_depth, int target_partition,
                                 int source_partition, int block_tree_consistency, hmx_block_tree **out);
+int hmx_block_tree_create_local_adm(const hmx_cluster_tree *target, const hmx_cluster_tree *source, double eta, char symmetry,
+                                char uplo, int min_target_depth, int min_source_depth, int target_partition,
+                                int source_partition, int block_tree_consistency, hmx_admissibility_fn fn, void *user, hmx_block_tree **out); /* with a user admissibility condition (NULL: default) */
 void hmx_block_tree_destroy(hmx_block_tree *);
 int64_t hmx_block_tree_num_leaves(const hmx_block_tree *);
 int hmx_block_tree_leaves(const hmx_block_tree *, hmx_leaf *out);

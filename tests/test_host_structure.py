@@ -144,3 +144,21 @@ def test_user_admissibility_condition():
         tb.build_block_tree(T, S)
     tb.set_admissibility_condition(None)
     assert np.array_equal(tb.build_block_tree(T, S).leaves, ref)
+
+
+def test_user_admissibility_condition_on_local_block_trees():
+    """The user condition also drives block trees rooted at partition clusters (block-diagonal operators)."""
+    p = params("ball_n2000_p2_local1_symL")
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
+    ref = tb.build_local_block_tree(T, S, p["local"], p["local"]).leaves
+
+    def rs(t, s, eta):
+        d = np.sqrt(sum((t.center[k] - s.center[k]) ** 2 for k in range(3)))
+        return 2 * min(t.radius, s.radius) < eta * max(d - t.radius - s.radius, 0.0)
+
+    tb.set_admissibility_condition(rs)
+    assert np.array_equal(tb.build_local_block_tree(T, S, p["local"], p["local"]).leaves, ref)
+    tb.set_admissibility_condition(lambda t, s, eta: False)
+    dense = tb.build_local_block_tree(T, S, p["local"], p["local"]).leaves
+    assert dense["admissible"].sum() == 0 and len(dense) != len(ref)
