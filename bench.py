@@ -165,6 +165,9 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         backend = os.environ.get("HMX_BENCH_BACKEND", "nccl")
+        # one node by contract: RCCL's bootstrap sockets stay on the loopback interface (no dependence on whatever other
+        # interfaces the box has; the data path is xGMI / shared memory either way)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

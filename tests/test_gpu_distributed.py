@@ -23,6 +23,7 @@ SCRIPT = textwrap.dedent('''
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: RCCL bootstrap over loopback
     dist.init_process_group("nccl", device_id=dev)
     rel = lambda a, b: float(torch.linalg.norm(a - b) / torch.linalg.norm(b))
     n = 6000
