@@ -66,7 +66,7 @@ struct HMat {
     StreamSet E, R;
     DArr<int32_t> e_zidx, e_zidx_mirror, e_tdst, e_tdst_mirror;
     DArr<int32_t> r_outidx, r_tcoef, r_tcoef_mirror;
-    std::vector<int32_t> h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag, h_e_tdst_all;
+    std::vector<int32_t> h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag;
     DArr<int32_t> c_dst, c_src, c_stride, c_count;
     int n_combine       = 0;
     int64_t A_total     = 0, P_total = 0;
@@ -101,6 +101,16 @@ struct HMat {
 
 static int build_streams(HMat &H) {
     Timer tim;
+    const bool phase_timing = getenv("HMX_BUILD_TIMING") && atoi(getenv("HMX_BUILD_TIMING"));
+    double phase_last       = 0;
+    auto phase              = [&](const char *name) {
+        if (!phase_timing)
+            return;
+        (void)hipDeviceSynchronize();
+        const double t = tim.s();
+        fprintf(stderr, "[hmx build]   layout: %-20s %8.1f ms\n", name, 1e3 * (t - phase_last));
+        phase_last = t;
+    };
     const int64_t nb_real = (int64_t)H.leaves.size();
     constexpr int TR_MAX = 64;
     const int SR_MAX     = getenv("HMX_SR_MAX") ? std::max(64, atoi(getenv("HMX_SR_MAX"))) : 512;
@@ -246,6 +256,7 @@ static int build_streams(HMat &H) {
     H.stats.rank_mean = H.stats.n_lowrank ? rank_sum / H.stats.n_lowrank : 0;
     H.A_total = A_total;
     H.P_total = P_total;
+    phase("ranges, pair lists");
     // ---- bases ------------------------------------------------------------------------------------
     E.base.assign(E.nranges(), 0);
     E.colbase.assign(E.nranges(), 0);
@@ -315,6 +326,7 @@ static int build_streams(HMat &H) {
         return HMX_ERR_UNSUPPORTED;
     }
     // ---- index arrays -------------------------------------------------------------------------------
+    phase("bases, task order");
     const int64_t zA = H.nS, zP = H.nS + A_total;
     H.zero_slot      = H.nS + A_total + P_total;
     H.h_e_zidx.assign(E.total_cols, 0);
@@ -358,23 +370,9 @@ static int build_streams(HMat &H) {
                 cc.push_back(ns_of[b]);
             }
     H.n_combine = (int)cd.size();
-    // transposed-pass destinations (built lazily on first use; keep what is needed to build them)
-    H.h_e_tdst_all.assign(E.total_cols, -1);
-    {
-        auto fill_t = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
-            for (size_t p = 0; p < pb.size(); p++) {
-                const int b = pb[p], r = pr[p];
-                const hmx_leaf &l = XL[b];
-                const int ncols   = lr ? l.rank : l.s_size;
-                int32_t *dst      = H.h_e_tdst_all.data() + E.colbase[r] + pc[p];
-                for (int j = 0; j < ncols; j++) // dense: global source position (shifted at use); low rank: -(2 + a index)
-                    dst[j] = lr ? (int32_t)(-2 - (aoff[b] + j)) : (int32_t)(l.s_offset + j);
-            }
-        };
-        fill_t(elr_b, elr_r, elr_c, true);
-        fill_t(ed_b, ed_r, ed_c, false);
-    }
+    // transposed-pass destinations are derived from h_e_zidx on first use (ensure_transposed_indices)
 
+    phase("index arrays");
     // ---- upload metadata, allocate streams ------------------------------------------------------------
     HMX_HIP(E.upload_meta());
     HMX_HIP(R.upload_meta());
@@ -423,6 +421,7 @@ static int build_streams(HMat &H) {
         HMX_HIP(H.d_transposed.upload(xtransposed));
         HMX_HIP(H.d_conj.upload(xconj));
     }
+    phase("uploads, allocations");
     DEvent e0, e1;
     HMX_HIP(hipEventRecord(e0, 0));
     {
@@ -466,6 +465,7 @@ static int build_streams(HMat &H) {
     HMX_HIP(hipEventSynchronize(e1));
     float ms = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    phase("pack kernels");
     H.stats.t_pack_s     = tim.s();
     H.stats.t_assemble_s = ms * 1e-3;
     H.stats.stream_bytes = (E.elems + R.elems) * (int64_t)sizeof(scalar);
@@ -487,11 +487,12 @@ static int ensure_transposed_indices(HMat &H) {
     const int64_t nE = H.E.total_cols, nR = H.R.total_cols;
     std::vector<int32_t> tall(nE), tmir(nE), call(nR), cmir(nR), zmir(nE);
     for (int64_t c = 0; c < nE; c++) {
-        const int32_t v  = H.h_e_tdst_all[c];
+        // column c multiplies Z[z]: z < nS is the source position of a dense column, z >= nS the `a` slot of a low-rank one
+        const int32_t z  = H.h_e_zidx[c];
         const bool mir   = H.has_mirror && !H.sym_expanded && H.h_e_mirrorflag[c];
-        const bool lr    = v <= -2;
-        tall[c]          = lr ? (int32_t)(H.nS + (-2 - v)) : v - H.S0;
-        tmir[c]          = !mir ? -1 : (lr ? (int32_t)(H.nT + (-2 - v)) : v - H.T0);
+        const bool lr    = z >= H.nS;
+        tall[c]          = z; // W = [out (nS, source-local) | aT]: the same index
+        tmir[c]          = !mir ? -1 : (lr ? (int32_t)(H.nT + (z - H.nS)) : z + H.S0 - H.T0);
         zmir[c]          = mir ? H.h_e_zidx[c] : (int32_t)H.zero_slot;
     }
     for (int64_t c = 0; c < nR; c++) {
@@ -1592,7 +1593,7 @@ static int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V
         const int64_t cb = E.colbase[r];
         int col          = -1;
         for (int c = 0; c < E.cols[r]; c++)
-            if (H->h_e_zidx[cb + c] == l.s_offset - H->S0 && H->h_e_tdst_all[cb + c] == l.s_offset) {
+            if (H->h_e_zidx[cb + c] == l.s_offset - H->S0) { // a dense column (index below nS) starting at this block's first source point
                 col = c;
                 break;
             }
