@@ -1041,10 +1041,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hipMemGetInfo(&free_b, &total_b));
     const double budget        = 0.40 * (double)free_b / sizeof(scalar);
-    const unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : 1.25 * estimate));
+    unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : 1.25 * estimate));
     phase("host scratch tables");
-    HMX_HIP(H.pool.alloc(cap));
-    phase("pool allocation");
     DArr<unsigned long long> head;
     HMX_HIP(head.alloc(1));
     HMX_HIP(head.zero());
@@ -1066,6 +1064,74 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     HMX_HIP(H.d_staged_off.upload(H.staged_off));
 
     phase("scratch upload");
+    auto aca_args = [&](scalar *pool, unsigned long long pool_cap, const int32_t *order_dev) {
+        AcaArgs A{};
+        A.ks = H.ks;
+        A.tx = H.tx.d; A.ty = H.ty.d; A.tz = H.tz.d;
+        A.sx = H.sx.d; A.sy = H.sy.d; A.sz = H.sz.d;
+        A.order  = order_dev;
+        A.t_off  = H.d_t_off.d; A.t_size = H.d_t_size.d; A.s_off = H.d_s_off.d; A.s_size = H.d_s_size.d;
+        A.symmetric_pivoting = compressor == HMX_SYMPARTIAL_ACA;
+        A.epsilon   = epsilon;
+        A.reqrank   = reqrank;
+        A.pool      = pool;
+        A.pool_head = head.d;
+        A.pool_cap  = pool_cap;
+        A.colptr    = H.d_colptr.d;
+        A.colcap    = d_colcap.d;
+        A.cross_off = H.d_cross_off.d;
+        A.visited   = visited.d;
+        A.vis_ptr   = d_visptr.d;
+        A.rank_out  = H.d_rank.d;
+        A.swapped_out = H.d_swapped.d;
+        return A;
+    };
+    // Pool sizing from a SAMPLE of the blocks.  The a-priori rank guess has to be pessimistic (it decides whether the
+    // compression must be repeated) and is 3-4 times the ranks smooth kernels really give; large allocations cost
+    // seconds on some boxes (tools/malloc_timing.hip) and the pool competes with the streams for HBM.  So every K-th
+    // block of the size-sorted list (<= ~4000 blocks) is compressed first into a small pool, and the full pool is sized
+    // at 1.3 x (measured / guessed) of the estimate.  An overflow still leads to the full-pool retry.  HMX_POOL_SAMPLE=0: off.
+    if (!assembled && !use_cb && !full_pool && order.size() >= 20000 && (double)cap * sizeof(scalar) >= 4e9 && reqrank < 0 &&
+        !(getenv("HMX_POOL_SAMPLE") && atoi(getenv("HMX_POOL_SAMPLE")) == 0) && !getenv("HMX_POOL_RANK_GUESS")) {
+        const size_t K = std::max<size_t>(1, order.size() / 4096);
+        std::vector<int32_t> sample;
+        double guess_s = 0;
+        for (size_t i = 0; i < order.size(); i += K) {
+            const int32_t b = order[i];
+            sample.push_back(b);
+            guess_s += std::min((double)colcap[b], rank_guess) * (double)(H.leaves[b].t_size + H.leaves[b].s_size);
+        }
+        DArr<int32_t> d_sample;
+        DArr<scalar> sample_pool;
+        const unsigned long long scap = (unsigned long long)(1.25 * guess_s) + 1024;
+        if (d_sample.upload(sample) == hipSuccess && sample_pool.alloc(scap) == hipSuccess) {
+            AcaArgs S = aca_args(sample_pool.d, scap, d_sample.d);
+            hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)sample.size()), dim3(256), 0, 0, S);
+            HMX_HIP(hipGetLastError());
+            std::vector<int32_t> r(nb, 0);
+            HMX_HIP(hipMemcpy(r.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
+            double used_s = 0;
+            bool overflow = false;
+            for (int32_t b : sample) {
+                overflow = overflow || r[b] == -2;
+                used_s += (double)std::max(r[b], 1) * (double)(H.leaves[b].t_size + H.leaves[b].s_size); // failed blocks still take one cross
+            }
+            if (!overflow && guess_s > 0) {
+                const double ratio = std::min(1.0, 1.3 * used_s / guess_s + 0.02);
+                cap                = (unsigned long long)std::max(1024.0, std::min((double)cap, ratio * estimate)); // below the 1.5 x that triggers the shrink copy
+            }
+            // leave no trace of the sample run
+            HMX_HIP(head.zero());
+            HMX_HIP(visited.zero());
+            HMX_HIP(H.d_rank.zero());
+            HMX_HIP(H.d_swapped.zero());
+        } else {
+            (void)hipGetLastError();
+        }
+        phase("pool sizing sample");
+    }
+    HMX_HIP(H.pool.alloc(cap));
+    phase("pool allocation");
     DEvent e0, e1;
     HMX_HIP(hipEventRecord(e0, 0));
     if (!order.empty() && assembled) {
@@ -1246,25 +1312,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                 return rcp;
         }
     } else if (!order.empty()) {
-        AcaArgs A{};
-        A.ks = H.ks;
-        A.tx = H.tx.d; A.ty = H.ty.d; A.tz = H.tz.d;
-        A.sx = H.sx.d; A.sy = H.sy.d; A.sz = H.sz.d;
-        A.order  = d_order.d;
-        A.t_off  = H.d_t_off.d; A.t_size = H.d_t_size.d; A.s_off = H.d_s_off.d; A.s_size = H.d_s_size.d;
-        A.symmetric_pivoting = compressor == HMX_SYMPARTIAL_ACA;
-        A.epsilon   = epsilon;
-        A.reqrank   = reqrank;
-        A.pool      = H.pool.d;
-        A.pool_head = head.d;
-        A.pool_cap  = cap;
-        A.colptr    = H.d_colptr.d;
-        A.colcap    = d_colcap.d;
-        A.cross_off = H.d_cross_off.d;
-        A.visited   = visited.d;
-        A.vis_ptr   = d_visptr.d;
-        A.rank_out  = H.d_rank.d;
-        A.swapped_out = H.d_swapped.d;
+        AcaArgs A = aca_args(H.pool.d, cap, d_order.d);
         // 1024-thread workgroups on a side stream for the largest blocks, concurrently with the rest in 256-thread workgroups
         // (`order` is sorted by n1 + n2, largest first).  That shortens the critical path of a block (every iteration walks
         // n1 + n2 entries) but lowers the throughput over many blocks: with ranks as expected it loses (N=1e6: 94 vs 79 ms,
