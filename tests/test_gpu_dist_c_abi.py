@@ -74,3 +74,146 @@ def test_c_level_distributed_operator(env):
     out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=e)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("ok ") == 3, out.stdout
+
+
+MOCK_SCRIPT = textwrap.dedent('''
+    import ctypes as C, os, sys, threading
+    import numpy as np
+    os.environ["HMX_NO_TORCH"] = "1"
+    sys.path.insert(0, %r)
+    import htool_amd as hm
+    from htool_amd._lib import lib, check
+    L = lib()
+    hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    WORLD = int(sys.argv[1])
+    ESZ = {7: 4, 8: 8}  # ncclFloat32, ncclFloat64 (rccl.h)
+
+    # ---- an in-process communicator: WORLD threads, one per rank, all on this GPU.  The collectives have the shapes of
+    # ---- hmx_rccl_api; `comm` carries rank + 1.  Stream order is kept by synchronising the stream first.
+    barrier = threading.Barrier(WORLD)
+    slots = [None] * WORLD
+    calls = dict(all_gather=0, all_reduce=0, broadcast=0)
+    def all_gather(send, recv, count, dtype, comm, stream):
+        r, nbytes = comm - 1, count * ESZ[dtype]
+        calls["all_gather"] += r == 0
+        hip.hipStreamSynchronize(stream)
+        slots[r] = send
+        barrier.wait()
+        for k in range(WORLD):
+            assert hip.hipMemcpy(recv + k * nbytes, slots[k], nbytes, 3) == 0
+        hip.hipStreamSynchronize(None)
+        barrier.wait()
+        return 0
+    def all_reduce(send, recv, count, dtype, op, comm, stream):
+        r, nbytes = comm - 1, count * ESZ[dtype]
+        assert op == 0  # ncclSum
+        calls["all_reduce"] += r == 0
+        hip.hipStreamSynchronize(stream)
+        slots[r] = send
+        barrier.wait()
+        acc = np.zeros(count, dtype=np.float64 if dtype == 8 else np.float32)
+        tmp = np.empty_like(acc)
+        for k in range(WORLD):  # every rank sums in the same order: identical results everywhere
+            assert hip.hipMemcpy(tmp.ctypes.data, slots[k], nbytes, 2) == 0
+            acc += tmp
+        barrier.wait()  # everybody has read the inputs (send may alias recv)
+        assert hip.hipMemcpy(recv, acc.ctypes.data, nbytes, 1) == 0
+        barrier.wait()
+        return 0
+    def broadcast(send, recv, count, dtype, root, comm, stream):
+        r, nbytes = comm - 1, count * ESZ[dtype]
+        calls["broadcast"] += r == 0
+        hip.hipStreamSynchronize(stream)
+        slots[r] = send
+        barrier.wait()
+        assert hip.hipMemcpy(recv, slots[root], nbytes, 3) == 0
+        hip.hipStreamSynchronize(None)
+        barrier.wait()
+        return 0
+    AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+    AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    GR = C.CFUNCTYPE(C.c_int)
+    class Api(C.Structure):
+        _fields_ = [("all_gather", AG), ("all_reduce", AR), ("broadcast", BC), ("group_start", GR), ("group_end", GR)]
+    api = Api(AG(all_gather), AR(all_reduce), BC(broadcast), GR(lambda: 0), GR(lambda: 0))
+
+    def dev(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        return p
+    def host(p, like):
+        out = np.empty_like(like)
+        assert hip.hipMemcpy(out.ctypes.data, p, out.nbytes, 2) == 0
+        return out
+
+    n = 3001 if WORLD == 3 else 4000  # 3 ranks: unequal parts (grouped broadcasts); 4 ranks: equal parts (all-gather)
+    x3 = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(50)
+    T = b.create_cluster_tree(n, 3, x3, 2, WORLD)
+    parts = T.get_clusters_on_partition()
+    assert len(parts) == WORLD
+    rng = np.random.default_rng(1)
+    for dtype in (np.float64, np.complex128):
+        cplx = dtype == np.complex128
+        tb = hm.HMatrixTreeBuilder(1e-6, 10.0, "N", "N"); tb.set_low_rank_generator("partialACA")
+        gen = hm.InvDistGenerator(3, x3, x3, 1e-5, 1.0, 1.0, 0.5 if cplx else 0.0)
+        Hfull = tb.build(gen, T, T, dtype=dtype)
+        Hloc = [tb.build(gen, T, T, k, k, dtype=dtype) for k in range(WORLD)]
+        Ds = []
+        for k in range(WORLD):
+            D = C.c_void_p()
+            check(L.hmx_dist_create(Hloc[k]._h, T._h, T._h, C.c_void_p(k + 1), k, WORLD, C.byref(api), C.byref(D)))
+            Ds.append(D)
+        xin = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
+        y0 = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
+        ab = np.array([1.5 - (0.5j if cplx else 0), 0.25 + (1j if cplx else 0)], dtype=dtype)
+        pa, pb = C.c_void_p(ab.ctypes.data), C.c_void_p(ab.ctypes.data + ab.itemsize)
+        for trans in ("N", "T"):
+            ref = y0.copy()
+            hm.internal_add_hmatrix_vector_product(trans, ab[0], Hfull, xin, ab[1], ref)
+            for local in (False, True):
+                errs, fails = [None] * WORLD, []
+                def rank_main(k):
+                    try:
+                        off, sz = int(parts[k][0]), int(parts[k][1])
+                        xi, yi = (xin[off:off + sz].copy(), y0[off:off + sz].copy()) if local else (xin, y0)
+                        dx, dy = dev(xi), dev(yi)
+                        fn = L.hmx_dist_matvec_local_to_local if local else L.hmx_dist_matvec_global_to_global
+                        check(fn(Ds[k], trans.encode(), pa, dx, pb, dy, None))
+                        assert hip.hipDeviceSynchronize() == 0
+                        y = host(dy, yi)
+                        want = ref[off:off + sz] if local else ref
+                        errs[k] = np.linalg.norm(y - want) / np.linalg.norm(want)
+                    except BaseException as e:
+                        fails.append(e)
+                        barrier.abort()
+                th = [threading.Thread(target=rank_main, args=(k,)) for k in range(WORLD)]
+                [t.start() for t in th]
+                [t.join() for t in th]
+                assert not fails, fails
+                assert max(errs) < 1e-12, (np.dtype(dtype).name, trans, local, errs)
+        for D in Ds:
+            L.hmx_dist_destroy(D)
+        print("ok", np.dtype(dtype).name)
+    print("calls", calls)
+    equal = len(set(int(p[1]) for p in parts)) == 1
+    assert calls["all_reduce"] > 0 and (calls["all_gather"] > 0 if equal else calls["broadcast"] > 0), calls
+''') % ROOT
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_c_level_distributed_operator_multi_rank_with_mock_collectives(world):
+    """hmx_dist_* with SEVERAL ranks on the one GPU a box has: every rank is a thread with its own row-restricted operator and
+    hmx_dist handle, and the hmx_rccl_api table is filled with in-process collectives (barrier + device copies) instead of
+    RCCL's.  Exercises what one rank cannot: the partition offsets, the all-gather route (4 equal parts) and the grouped
+    broadcast route (3 unequal parts), the all-reduce of the transposed products, local-to-local slices; real and complex.
+    Reference: the single-process product of the whole operator."""
+    out = subprocess.run([sys.executable, "-c", MOCK_SCRIPT, str(world)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HMX_NO_TORCH="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok ") == 2 and "calls" in out.stdout, out.stdout
+    print(out.stdout)
