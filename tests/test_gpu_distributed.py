@@ -89,3 +89,88 @@ def test_distributed_layer_on_gpu_with_rccl():
     out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("ok ") == 3, out.stdout
+
+
+MULTI_SCRIPT = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    import htool_amd as hm
+    from htool_amd import distributed as D
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)  # every rank on the box's single GPU; gloo carries the collectives (RCCL refuses a shared device)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    rel = lambda a, b: float(torch.linalg.norm(a - b) / torch.linalg.norm(b))
+    n = 6001
+    x = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(60)
+    T = b.create_cluster_tree(n, 3, x, 2, world)
+    tp = D.PartitionFromCluster(T)
+    off, sz = tp.get_offset_of_partition(rank), tp.get_size_of_partition(rank)
+    for dtype, tdt, sym, uplo in ((np.float64, torch.float64, "N", "N"), (np.float64, torch.float64, "S", "L"), (np.complex128, torch.complex128, "H", "U")):
+        cplx = dtype == np.complex128
+        tb = hm.HMatrixTreeBuilder(1e-6, 10.0, sym, uplo)
+        tb.set_low_rank_generator("sympartialACA" if sym != "N" else "partialACA")
+        gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 0.5 if cplx else 0.0, sym == "H")
+        B = D.DefaultApproximationBuilder(gen, T, T, tb, dtype=dtype)   # this rank's block rows on the GPU
+        A = B.distributed_operator
+        Hfull = tb.build(gen, T, T, dtype=dtype)                        # the whole operator, for reference
+        g = torch.Generator().manual_seed(0)
+        xin = torch.randn(n, dtype=tdt, generator=g).to(dev)
+        y0 = torch.randn(n, dtype=tdt, generator=g).to(dev)
+        alpha, beta = (1.5 - 0.5j, 0.25 + 1j) if cplx else (1.5, 0.25)
+        for trans in ("N",) + (("T",) if sym != "H" else ()) + (("C",) if cplx and sym != "S" else ()):
+            ref = y0.clone()
+            hm.internal_add_hmatrix_vector_product(trans, alpha, Hfull, xin, beta, ref)
+            y = y0.clone()
+            D.internal_add_distributed_operator_vector_product_global_to_global(trans, alpha, A, xin, beta, y)
+            assert rel(y, ref) < 1e-12, ("g2g", sym, trans, rel(y, ref))
+            yl = y0[off:off + sz].clone()
+            D.internal_add_distributed_operator_vector_product_local_to_local(trans, alpha, A, xin[off:off + sz].clone(), beta, yl)
+            assert rel(yl, ref[off:off + sz]) < 1e-12, ("l2l", sym, trans, rel(yl, ref[off:off + sz]))
+            ref_u = y0.clone()
+            hm.add_hmatrix_vector_product(trans, alpha, Hfull, xin, beta, ref_u)
+            y = y0.clone()
+            D.add_distributed_operator_vector_product_global_to_global(trans, alpha, A, xin, beta, y)
+            assert rel(y, ref_u) < 1e-12, ("user", sym, trans, rel(y, ref_u))
+        if sym == "N":  # multi-RHS row-major and the graphed single-vector product
+            X = torch.randn((n, 5), dtype=tdt, generator=g).to(dev)
+            Y = torch.zeros((n, 5), dtype=tdt, device=dev)
+            D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, X, 0.0, Y, 5)
+            R = torch.zeros((n, 5), dtype=tdt, device=dev)
+            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, Hfull, X, 0.0, R, 5)
+            assert rel(Y, R) < 1e-12
+            yg = torch.zeros(n, dtype=tdt, device=dev)
+            gp = D.GraphedGlobalToGlobalProduct(A, xin, yg)
+            gp()
+            torch.cuda.synchronize()
+            ref = torch.zeros(n, dtype=tdt, device=dev)
+            hm.internal_add_hmatrix_vector_product("N", 1.0, Hfull, xin, 0.0, ref)
+            assert rel(yg, ref) < 1e-12
+    if rank == 0:
+        print("multi-rank ok")
+    dist.destroy_process_group()
+''') % ROOT
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_layer_on_gpu_several_ranks_sharing_the_device(world, tmp_path):
+    """The Python DistributedOperator layer with the real HIP engine and MORE than one rank: `world` processes under
+    torch.distributed.run share the box's GPU and talk through gloo.  Row-restricted operators per rank (unequal parts for
+    world 3), g2g / l2l / user numbering, N / T / C, symmetric and Hermitian storage, multi-RHS and the graphed product against
+    the single-process product of the whole operator."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "multi.py"
+    script.write_text(MULTI_SCRIPT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "multi-rank ok" in out.stdout
