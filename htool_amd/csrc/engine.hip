@@ -5,6 +5,7 @@
 // device and reports HMX_ERR_NO_DEVICE / HMX_ERR_HIP otherwise.
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -181,6 +182,21 @@ static void make_ranges(std::vector<int> &bp, int maxlen, int origin, std::vecto
             len.push_back(e - s);
         }
     }
+}
+
+// host loops over millions of (leaf, range) pairs with disjoint outputs: split over a few threads
+template <typename F>
+static void parallel_for(size_t n, F &&body) {
+    const size_t nt = std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), n / 65536 + 1});
+    if (nt <= 1) {
+        body((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++)
+        th.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th)
+        x.join();
 }
 
 struct Timer {

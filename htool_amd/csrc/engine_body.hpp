@@ -332,34 +332,38 @@ static int build_streams(HMat &H) {
     H.h_e_zidx.assign(E.total_cols, 0);
     H.h_e_mirrorflag.assign(mirror_flags ? E.total_cols : 0, 0);
     auto fill_e = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
-        for (size_t p = 0; p < pb.size(); p++) {
-            const int b = pb[p], r = pr[p];
-            const hmx_leaf &l = XL[b];
-            const int ncols   = lr ? l.rank : l.s_size;
-            const int64_t z0  = lr ? zA + aoff[b] : (int64_t)(l.s_offset - H.S0);
-            int32_t *dst      = H.h_e_zidx.data() + E.colbase[r] + pc[p];
-            for (int j = 0; j < ncols; j++)
-                dst[j] = (int32_t)(z0 + j);
-            if (mirror_flags && l.mirror)
-                std::fill_n(H.h_e_mirrorflag.data() + E.colbase[r] + pc[p], ncols, 1);
-        }
+        parallel_for(pb.size(), [&](size_t lo, size_t hi) { // every (leaf, range) pair owns its own columns
+            for (size_t p = lo; p < hi; p++) {
+                const int b = pb[p], r = pr[p];
+                const hmx_leaf &l = XL[b];
+                const int ncols   = lr ? l.rank : l.s_size;
+                const int64_t z0  = lr ? zA + aoff[b] : (int64_t)(l.s_offset - H.S0);
+                int32_t *dst      = H.h_e_zidx.data() + E.colbase[r] + pc[p];
+                for (int j = 0; j < ncols; j++)
+                    dst[j] = (int32_t)(z0 + j);
+                if (mirror_flags && l.mirror)
+                    std::fill_n(H.h_e_mirrorflag.data() + E.colbase[r] + pc[p], ncols, 1);
+            }
+        });
     };
     fill_e(elr_b, elr_r, elr_c, true);
     fill_e(ed_b, ed_r, ed_c, false);
     std::vector<int32_t> h_outidx(R.total_cols, 0);
     H.h_r_aidx.assign(R.total_cols, 0);
     H.h_r_mirrorflag.assign(mirror_flags ? R.total_cols : 0, 0);
-    for (size_t p = 0; p < rlr_b.size(); p++) {
-        const int b = rlr_b[p], r = rlr_r[p];
-        const hmx_leaf &l = XL[b];
-        const int64_t cb  = R.colbase[r] + rlr_c[p];
-        for (int k = 0; k < l.rank; k++) {
-            H.h_r_aidx[cb + k] = (int32_t)(aoff[b] + k);
-            h_outidx[cb + k]   = ns_of[b] == 1 ? (int32_t)(zA + aoff[b] + k) : (int32_t)(zP + poff[b] + (int64_t)(r - s_first[b]) * l.rank + k);
-            if (mirror_flags && l.mirror)
-                H.h_r_mirrorflag[cb + k] = 1;
+    parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
+        for (size_t p = lo; p < hi; p++) {
+            const int b = rlr_b[p], r = rlr_r[p];
+            const hmx_leaf &l = XL[b];
+            const int64_t cb  = R.colbase[r] + rlr_c[p];
+            for (int k = 0; k < l.rank; k++) {
+                H.h_r_aidx[cb + k] = (int32_t)(aoff[b] + k);
+                h_outidx[cb + k]   = ns_of[b] == 1 ? (int32_t)(zA + aoff[b] + k) : (int32_t)(zP + poff[b] + (int64_t)(r - s_first[b]) * l.rank + k);
+                if (mirror_flags && l.mirror)
+                    H.h_r_mirrorflag[cb + k] = 1;
+            }
         }
-    }
+    });
     std::vector<int32_t> cd, cs, cst, cc;
     for (int64_t b = 0; b < nb; b++)
         if (poff[b] >= 0)
