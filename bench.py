@@ -144,6 +144,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # the host driver of this platform only supports dmabuf IPC: RCCL / device-memory sharing between the ranks' processes needs it
+    # (already exported on the GPU boxes; kept here so that a bare environment works too).  Must be set before HIP initialises.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
