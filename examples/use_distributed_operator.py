@@ -47,14 +47,15 @@ def run_emulated(P, device=0):
 
 
 def run_distributed():
+    # both must be in the environment before HIP / HSA initialise (the first cuda call below)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: RCCL bootstrap over loopback
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only mode the platform's host driver supports)
     import torch
     import torch.distributed as dist
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if "MASTER_ADDR" not in os.environ:  # plain `python examples/use_distributed_operator.py`: one rank
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
     torch.cuda.set_device(local_rank)
-    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: RCCL bootstrap over loopback
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only mode the platform's host driver supports)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n, cluster, A, tb, ref = setup(dist.get_world_size())
     builder = D.DefaultApproximationBuilder(A, cluster, cluster, tb, device=local_rank)

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -66,11 +68,24 @@ struct DeviceCache {
         parked.erase(parked.begin() + best);
         return p;
     }
-    bool park(void *p, size_t bytes) {
+    // `dev` is the device the buffer was allocated on (recorded by DArr, not the caller's current device).  hipFree used to
+    // synchronise implicitly; a parked buffer can be handed out again at once, so work still in flight on ANY stream of the owning
+    // device (a caller's non-blocking stream, a graph launch) is waited for first.  Large releases are rare (operator teardown,
+    // buffer growth), so the device-wide wait costs nothing that matters.
+    bool park(void *p, size_t bytes, int dev) {
         if (bytes < (size_t(64) << 20) || bytes > limit())
             return false;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
+        int cur = dev;
+        (void)hipGetDevice(&cur);
+        if (cur != dev)
+            (void)hipSetDevice(dev);
+        const hipError_t se = hipDeviceSynchronize();
+        if (cur != dev)
+            (void)hipSetDevice(cur);
+        if (se != hipSuccess) { // e.g. a stream capture in progress: do not recycle what cannot be proven idle
+            (void)hipGetLastError();
+            return false;
+        }
         std::lock_guard<std::mutex> lock(mu);
         while (total + bytes > limit() && !parked.empty()) { // evict the oldest
             (void)hipFree(parked.front().p);
@@ -95,12 +110,13 @@ struct DArr { // device array with RAII
     T *d        = nullptr;
     size_t n    = 0;
     size_t cap_ = 0; // bytes actually owned (>= n * sizeof(T) when the buffer came from the cache)
+    int dev_    = 0; // device the buffer lives on (current device at alloc time)
     DArr() {}
     DArr(const DArr &)            = delete;
     DArr &operator=(const DArr &) = delete;
     ~DArr() { release(); }
     void release() {
-        if (d && !DeviceCache::get().park(d, cap_))
+        if (d && !DeviceCache::get().park(d, cap_, dev_))
             (void)hipFree(d);
         d    = nullptr;
         n    = 0;
@@ -113,6 +129,7 @@ struct DArr { // device array with RAII
             return hipSuccess;
         const size_t bytes = count * sizeof(T);
         size_t got         = 0;
+        (void)hipGetDevice(&dev_);
         if (void *p = DeviceCache::get().take(bytes, &got)) {
             d    = static_cast<T *>(p);
             cap_ = got;
@@ -267,6 +284,23 @@ struct hmx_hmatrix {
     }
 };
 
+// The C ABI never throws: host-side allocation failures (std::bad_alloc, std::length_error from a corrupt size) and anything
+// else that escapes the engine become an error code + hmx_last_error().
+#define HMX_GUARD(expr)                                                        \
+    do {                                                                       \
+        try {                                                                  \
+            return (expr);                                                     \
+        } catch (const std::bad_alloc &) {                                     \
+            set_error("out of host memory");                                   \
+            return HMX_ERR_INVALID;                                            \
+        } catch (const std::exception &e_) {                                   \
+            set_error(std::string("internal error: ") + e_.what());            \
+            return HMX_ERR_INVALID;                                            \
+        } catch (...) {                                                        \
+            set_error("internal error");                                       \
+            return HMX_ERR_INVALID;                                            \
+        }                                                                      \
+    } while (0)
 // type-independent entry points: the same api_* function in whichever instantiation the handle holds
 #define HMX_ALL(H, fn, ...)                                 \
     do {                                                    \
@@ -275,12 +309,12 @@ struct hmx_hmatrix {
             return HMX_ERR_INVALID;                         \
         }                                                   \
         if ((H)->d)                                         \
-            return hmx::f64::fn((H)->d, ##__VA_ARGS__);     \
+            HMX_GUARD(hmx::f64::fn((H)->d, ##__VA_ARGS__)); \
         if ((H)->s)                                         \
-            return hmx::f32::fn((H)->s, ##__VA_ARGS__);     \
+            HMX_GUARD(hmx::f32::fn((H)->s, ##__VA_ARGS__)); \
         if ((H)->z)                                         \
-            return hmx::z64::fn((H)->z, ##__VA_ARGS__);     \
-        return hmx::c32::fn((H)->c, ##__VA_ARGS__);         \
+            HMX_GUARD(hmx::z64::fn((H)->z, ##__VA_ARGS__)); \
+        HMX_GUARD(hmx::c32::fn((H)->c, ##__VA_ARGS__));     \
     } while (0)
 #define HMX_NEED(H, member, what)                                                                     \
     do {                                                                                              \
@@ -312,7 +346,12 @@ int hmx_hmatrix_create(const hmx_block_tree *bt, int device_id, hmx_hmatrix **ou
         return HMX_ERR_INVALID;
     }
     hmx::f64::HMat *h = nullptr;
-    const int rc      = hmx::f64::api_create(bt, device_id, &h);
+    int rc            = HMX_ERR_INVALID;
+    try {
+        rc = hmx::f64::api_create(bt, device_id, &h);
+    } catch (...) {
+        set_error("hmx_hmatrix_create: out of host memory");
+    }
     if (rc != HMX_OK)
         return rc;
     *out      = new hmx_hmatrix();
@@ -325,7 +364,12 @@ int hmx_hmatrix_create_s(const hmx_block_tree *bt, int device_id, hmx_hmatrix **
         return HMX_ERR_INVALID;
     }
     hmx::f32::HMat *h = nullptr;
-    const int rc      = hmx::f32::api_create(bt, device_id, &h);
+    int rc            = HMX_ERR_INVALID;
+    try {
+        rc = hmx::f32::api_create(bt, device_id, &h);
+    } catch (...) {
+        set_error("hmx_hmatrix_create: out of host memory");
+    }
     if (rc != HMX_OK)
         return rc;
     *out      = new hmx_hmatrix();
@@ -338,7 +382,12 @@ int hmx_hmatrix_create_z(const hmx_block_tree *bt, int device_id, hmx_hmatrix **
         return HMX_ERR_INVALID;
     }
     hmx::z64::HMat *h = nullptr;
-    const int rc      = hmx::z64::api_create(bt, device_id, &h);
+    int rc            = HMX_ERR_INVALID;
+    try {
+        rc = hmx::z64::api_create(bt, device_id, &h);
+    } catch (...) {
+        set_error("hmx_hmatrix_create: out of host memory");
+    }
     if (rc != HMX_OK)
         return rc;
     *out      = new hmx_hmatrix();
@@ -351,14 +400,33 @@ int hmx_hmatrix_create_c(const hmx_block_tree *bt, int device_id, hmx_hmatrix **
         return HMX_ERR_INVALID;
     }
     hmx::c32::HMat *h = nullptr;
-    const int rc      = hmx::c32::api_create(bt, device_id, &h);
+    int rc            = HMX_ERR_INVALID;
+    try {
+        rc = hmx::c32::api_create(bt, device_id, &h);
+    } catch (...) {
+        set_error("hmx_hmatrix_create: out of host memory");
+    }
     if (rc != HMX_OK)
         return rc;
     *out      = new hmx_hmatrix();
     (*out)->c = h;
     return HMX_OK;
 }
-void hmx_hmatrix_destroy(hmx_hmatrix *H) { delete H; }
+void hmx_hmatrix_destroy(hmx_hmatrix *H) {
+    if (!H)
+        return;
+    // products are asynchronous on the caller's stream: nothing of this operator may be freed or recycled while one is in flight
+    const int dev = H->d ? H->d->device : (H->s ? H->s->device : (H->z ? H->z->device : (H->c ? H->c->device : -1)));
+    int cur       = 0;
+    if (dev >= 0 && hipGetDevice(&cur) == hipSuccess) {
+        if (cur != dev)
+            (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        if (cur != dev)
+            (void)hipSetDevice(cur);
+    }
+    delete H;
+}
 int hmx_hmatrix_is_f32(const hmx_hmatrix *H) { return H && H->s ? 1 : 0; }
 int hmx_hmatrix_precision(const hmx_hmatrix *H) { return !H ? -1 : (H->d ? HMX_PREC_F64 : (H->s ? HMX_PREC_F32 : (H->z ? HMX_PREC_Z64 : HMX_PREC_C32))); }
 
@@ -367,11 +435,11 @@ int hmx_hmatrix_set_kernel(hmx_hmatrix *H, int kernel, const double *params, int
 }
 int hmx_hmatrix_set_callback(hmx_hmatrix *H, hmx_generator_fn fn, void *user) {
     HMX_NEED(H, d, "hmx_hmatrix_set_callback");
-    return hmx::f64::api_set_callback(H->d, fn, user);
+    HMX_GUARD(hmx::f64::api_set_callback(H->d, fn, user));
 }
 int hmx_hmatrix_set_callback_s(hmx_hmatrix *H, hmx_generator_fn_s fn, void *user) {
     HMX_NEED(H, s, "hmx_hmatrix_set_callback_s");
-    return hmx::f32::api_set_callback(H->s, fn, user);
+    HMX_GUARD(hmx::f32::api_set_callback(H->s, fn, user));
 }
 int hmx_hmatrix_compress(hmx_hmatrix *H, int compressor, double epsilon, int reqrank) {
     HMX_ALL(H, api_compress, compressor, epsilon, reqrank);
@@ -390,128 +458,128 @@ int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *H, int max, const char **na
 // ---- fp64 coefficients ----------------------------------------------------------------------------------------
 int hmx_hmatrix_set_block_lowrank(hmx_hmatrix *H, int64_t leaf, int rank, const double *U, const double *V) {
     HMX_NEED(H, d, "hmx_hmatrix_set_block_lowrank");
-    return hmx::f64::api_set_block_lowrank(H->d, leaf, rank, U, V);
+    HMX_GUARD(hmx::f64::api_set_block_lowrank(H->d, leaf, rank, U, V));
 }
 int hmx_hmatrix_set_block_dense(hmx_hmatrix *H, int64_t leaf, const double *D) {
     HMX_NEED(H, d, "hmx_hmatrix_set_block_dense");
-    return hmx::f64::api_set_block_dense(H->d, leaf, D);
+    HMX_GUARD(hmx::f64::api_set_block_dense(H->d, leaf, D));
 }
 int hmx_hmatrix_get_block(const hmx_hmatrix *H, int64_t leaf, double *U_or_D, double *V) {
     HMX_NEED(H, d, "hmx_hmatrix_get_block");
-    return hmx::f64::api_get_block(H->d, leaf, U_or_D, V);
+    HMX_GUARD(hmx::f64::api_get_block(H->d, leaf, U_or_D, V));
 }
 int hmx_hmatrix_matvec(hmx_hmatrix *H, char trans, double alpha, const double *in, double beta, double *out, int mem, void *stream) {
     HMX_NEED(H, d, "hmx_hmatrix_matvec");
-    return hmx::f64::api_matvec(H->d, trans, alpha, in, beta, out, mem, stream);
+    HMX_GUARD(hmx::f64::api_matvec(H->d, trans, alpha, in, beta, out, mem, stream));
 }
 int hmx_hmatrix_matvec_user(hmx_hmatrix *H, char trans, double alpha, const double *in, double beta, double *out, int mem, void *stream) {
     HMX_NEED(H, d, "hmx_hmatrix_matvec_user");
-    return hmx::f64::api_matvec_user(H->d, trans, alpha, in, beta, out, mem, stream);
+    HMX_GUARD(hmx::f64::api_matvec_user(H->d, trans, alpha, in, beta, out, mem, stream));
 }
 int hmx_hmatrix_matmat_row_major(hmx_hmatrix *H, char trans, double alpha, const double *in, double beta, double *out, int mu, int mem, void *stream) {
     HMX_NEED(H, d, "hmx_hmatrix_matmat_row_major");
-    return hmx::f64::api_matmat_row_major(H->d, trans, alpha, in, beta, out, mu, mem, stream);
+    HMX_GUARD(hmx::f64::api_matmat_row_major(H->d, trans, alpha, in, beta, out, mu, mem, stream));
 }
 
 int hmx_hmatrix_matmat_user(hmx_hmatrix *H, char trans, double alpha, const double *in, double beta, double *out, int mu, int mem, void *stream) {
     HMX_NEED(H, d, "hmx_hmatrix_matmat_user");
-    return hmx::f64::api_matmat_user(H->d, trans, alpha, in, beta, out, mu, mem, stream);
+    HMX_GUARD(hmx::f64::api_matmat_user(H->d, trans, alpha, in, beta, out, mu, mem, stream));
 }
 int hmx_hmatrix_matmat_user_s(hmx_hmatrix *H, char trans, float alpha, const float *in, float beta, float *out, int mu, int mem, void *stream) {
     HMX_NEED(H, s, "hmx_hmatrix_matmat_user_s");
-    return hmx::f32::api_matmat_user(H->s, trans, alpha, in, beta, out, mu, mem, stream);
+    HMX_GUARD(hmx::f32::api_matmat_user(H->s, trans, alpha, in, beta, out, mu, mem, stream));
 }
 int hmx_hmatrix_matmat_user_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mu, int mem, void *stream) {
     HMX_NEED(H, z, "hmx_hmatrix_matmat_user_z");
-    return hmx::z64::api_matmat_user(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mu, mem, stream);
+    HMX_GUARD(hmx::z64::api_matmat_user(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mu, mem, stream));
 }
 int hmx_hmatrix_matmat_user_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mu, int mem, void *stream) {
     HMX_NEED(H, c, "hmx_hmatrix_matmat_user_c");
-    return hmx::c32::api_matmat_user(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream);
+    HMX_GUARD(hmx::c32::api_matmat_user(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream));
 }
 
 // ---- fp32 coefficients (htool's HMatrix<float,double>) --------------------------------------------------------------
 int hmx_hmatrix_set_block_lowrank_s(hmx_hmatrix *H, int64_t leaf, int rank, const float *U, const float *V) {
     HMX_NEED(H, s, "hmx_hmatrix_set_block_lowrank_s");
-    return hmx::f32::api_set_block_lowrank(H->s, leaf, rank, U, V);
+    HMX_GUARD(hmx::f32::api_set_block_lowrank(H->s, leaf, rank, U, V));
 }
 int hmx_hmatrix_set_block_dense_s(hmx_hmatrix *H, int64_t leaf, const float *D) {
     HMX_NEED(H, s, "hmx_hmatrix_set_block_dense_s");
-    return hmx::f32::api_set_block_dense(H->s, leaf, D);
+    HMX_GUARD(hmx::f32::api_set_block_dense(H->s, leaf, D));
 }
 int hmx_hmatrix_get_block_s(const hmx_hmatrix *H, int64_t leaf, float *U_or_D, float *V) {
     HMX_NEED(H, s, "hmx_hmatrix_get_block_s");
-    return hmx::f32::api_get_block(H->s, leaf, U_or_D, V);
+    HMX_GUARD(hmx::f32::api_get_block(H->s, leaf, U_or_D, V));
 }
 int hmx_hmatrix_matvec_s(hmx_hmatrix *H, char trans, float alpha, const float *in, float beta, float *out, int mem, void *stream) {
     HMX_NEED(H, s, "hmx_hmatrix_matvec_s");
-    return hmx::f32::api_matvec(H->s, trans, alpha, in, beta, out, mem, stream);
+    HMX_GUARD(hmx::f32::api_matvec(H->s, trans, alpha, in, beta, out, mem, stream));
 }
 int hmx_hmatrix_matvec_user_s(hmx_hmatrix *H, char trans, float alpha, const float *in, float beta, float *out, int mem, void *stream) {
     HMX_NEED(H, s, "hmx_hmatrix_matvec_user_s");
-    return hmx::f32::api_matvec_user(H->s, trans, alpha, in, beta, out, mem, stream);
+    HMX_GUARD(hmx::f32::api_matvec_user(H->s, trans, alpha, in, beta, out, mem, stream));
 }
 int hmx_hmatrix_matmat_row_major_s(hmx_hmatrix *H, char trans, float alpha, const float *in, float beta, float *out, int mu, int mem, void *stream) {
     HMX_NEED(H, s, "hmx_hmatrix_matmat_row_major_s");
-    return hmx::f32::api_matmat_row_major(H->s, trans, alpha, in, beta, out, mu, mem, stream);
+    HMX_GUARD(hmx::f32::api_matmat_row_major(H->s, trans, alpha, in, beta, out, mu, mem, stream));
 }
 
 // ---- complex coefficients (htool's HMatrix<std::complex<double>> / <std::complex<float>>): interleaved (re, im) ------------
 int hmx_hmatrix_set_callback_z(hmx_hmatrix *H, hmx_generator_fn fn, void *user) {
     HMX_NEED(H, z, "hmx_hmatrix_set_callback_z");
-    return hmx::z64::api_set_callback(H->z, reinterpret_cast<void (*)(void *, int, int, const int32_t *, const int32_t *, cplx<double> *)>(fn), user);
+    HMX_GUARD(hmx::z64::api_set_callback(H->z, reinterpret_cast<void (*)(void *, int, int, const int32_t *, const int32_t *, cplx<double> *)>(fn), user));
 }
 int hmx_hmatrix_set_callback_c(hmx_hmatrix *H, hmx_generator_fn_s fn, void *user) {
     HMX_NEED(H, c, "hmx_hmatrix_set_callback_c");
-    return hmx::c32::api_set_callback(H->c, reinterpret_cast<void (*)(void *, int, int, const int32_t *, const int32_t *, cplx<float> *)>(fn), user);
+    HMX_GUARD(hmx::c32::api_set_callback(H->c, reinterpret_cast<void (*)(void *, int, int, const int32_t *, const int32_t *, cplx<float> *)>(fn), user));
 }
 int hmx_hmatrix_set_block_lowrank_z(hmx_hmatrix *H, int64_t leaf, int rank, const double *U, const double *V) {
     HMX_NEED(H, z, "hmx_hmatrix_set_block_lowrank_z");
-    return hmx::z64::api_set_block_lowrank(H->z, leaf, rank, ZP(U), ZP(V));
+    HMX_GUARD(hmx::z64::api_set_block_lowrank(H->z, leaf, rank, ZP(U), ZP(V)));
 }
 int hmx_hmatrix_set_block_dense_z(hmx_hmatrix *H, int64_t leaf, const double *D) {
     HMX_NEED(H, z, "hmx_hmatrix_set_block_dense_z");
-    return hmx::z64::api_set_block_dense(H->z, leaf, ZP(D));
+    HMX_GUARD(hmx::z64::api_set_block_dense(H->z, leaf, ZP(D)));
 }
 int hmx_hmatrix_get_block_z(const hmx_hmatrix *H, int64_t leaf, double *U_or_D, double *V) {
     HMX_NEED(H, z, "hmx_hmatrix_get_block_z");
-    return hmx::z64::api_get_block(H->z, leaf, ZPM(U_or_D), ZPM(V));
+    HMX_GUARD(hmx::z64::api_get_block(H->z, leaf, ZPM(U_or_D), ZPM(V)));
 }
 int hmx_hmatrix_matvec_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mem, void *stream) {
     HMX_NEED(H, z, "hmx_hmatrix_matvec_z");
-    return hmx::z64::api_matvec(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mem, stream);
+    HMX_GUARD(hmx::z64::api_matvec(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mem, stream));
 }
 int hmx_hmatrix_matvec_user_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mem, void *stream) {
     HMX_NEED(H, z, "hmx_hmatrix_matvec_user_z");
-    return hmx::z64::api_matvec_user(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mem, stream);
+    HMX_GUARD(hmx::z64::api_matvec_user(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mem, stream));
 }
 int hmx_hmatrix_matmat_row_major_z(hmx_hmatrix *H, char trans, const double *alpha, const double *in, const double *beta, double *out, int mu, int mem, void *stream) {
     HMX_NEED(H, z, "hmx_hmatrix_matmat_row_major_z");
-    return hmx::z64::api_matmat_row_major(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mu, mem, stream);
+    HMX_GUARD(hmx::z64::api_matmat_row_major(H->z, trans, zval(alpha), ZP(in), zval(beta), ZPM(out), mu, mem, stream));
 }
 int hmx_hmatrix_set_block_lowrank_c(hmx_hmatrix *H, int64_t leaf, int rank, const float *U, const float *V) {
     HMX_NEED(H, c, "hmx_hmatrix_set_block_lowrank_c");
-    return hmx::c32::api_set_block_lowrank(H->c, leaf, rank, CP(U), CP(V));
+    HMX_GUARD(hmx::c32::api_set_block_lowrank(H->c, leaf, rank, CP(U), CP(V)));
 }
 int hmx_hmatrix_set_block_dense_c(hmx_hmatrix *H, int64_t leaf, const float *D) {
     HMX_NEED(H, c, "hmx_hmatrix_set_block_dense_c");
-    return hmx::c32::api_set_block_dense(H->c, leaf, CP(D));
+    HMX_GUARD(hmx::c32::api_set_block_dense(H->c, leaf, CP(D)));
 }
 int hmx_hmatrix_get_block_c(const hmx_hmatrix *H, int64_t leaf, float *U_or_D, float *V) {
     HMX_NEED(H, c, "hmx_hmatrix_get_block_c");
-    return hmx::c32::api_get_block(H->c, leaf, CPM(U_or_D), CPM(V));
+    HMX_GUARD(hmx::c32::api_get_block(H->c, leaf, CPM(U_or_D), CPM(V)));
 }
 int hmx_hmatrix_matvec_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mem, void *stream) {
     HMX_NEED(H, c, "hmx_hmatrix_matvec_c");
-    return hmx::c32::api_matvec(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mem, stream);
+    HMX_GUARD(hmx::c32::api_matvec(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mem, stream));
 }
 int hmx_hmatrix_matvec_user_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mem, void *stream) {
     HMX_NEED(H, c, "hmx_hmatrix_matvec_user_c");
-    return hmx::c32::api_matvec_user(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mem, stream);
+    HMX_GUARD(hmx::c32::api_matvec_user(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mem, stream));
 }
 int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *H, char trans, const float *alpha, const float *in, const float *beta, float *out, int mu, int mem, void *stream) {
     HMX_NEED(H, c, "hmx_hmatrix_matmat_row_major_c");
-    return hmx::c32::api_matmat_row_major(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream);
+    HMX_GUARD(hmx::c32::api_matmat_row_major(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream));
 }
 
 int hmx_hmatrix_release_factors(hmx_hmatrix *H, int with_transposed) { HMX_ALL(H, api_release_factors, with_transposed); }
@@ -536,7 +604,8 @@ int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, 
     hmx::f32::HMat *s = nullptr;
     hmx::z64::HMat *z = nullptr;
     hmx::c32::HMat *c = nullptr;
-    int rc;
+    int rc = HMX_ERR_INVALID;
+    try {
     if (hd.elem_size == 8 && !hd.reserved) {
         rc = hmx::f64::api_load(bt, device_id, f, hd, &d);
     } else if (hd.elem_size == 4) {
@@ -551,6 +620,10 @@ int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, 
         hmx::c32::HmxFileHeader hs;
         std::memcpy(&hs, &hd, sizeof hs);
         rc = hmx::c32::api_load(bt, device_id, f, hs, &c);
+    }
+    } catch (...) { // a corrupt size field: std::bad_alloc / std::length_error from a host buffer
+        set_error(std::string("hmx_hmatrix_load: ") + path + " is corrupt (allocation failed)");
+        rc = HMX_ERR_INVALID;
     }
     fclose(f);
     if (rc != HMX_OK)
@@ -656,7 +729,7 @@ static int dist_local_product(hmx_dist &D, char trans, const void *alpha, const 
         return hmx::f32::api_matvec(H->s, trans, *static_cast<const float *>(alpha), static_cast<const float *>(in), *static_cast<const float *>(beta), static_cast<float *>(out), HMX_MEM_DEVICE, st);
     if (H->z)
         return hmx::z64::api_matvec(H->z, trans, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), HMX_MEM_DEVICE, st);
-    return hmx::c32::api_matvec(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), HMX_MEM_DEVICE, st);
+    HMX_GUARD(hmx::c32::api_matvec(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), HMX_MEM_DEVICE, st));
 }
 extern "C" {
 int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank, int world_size, const hmx_rccl_api *api, hmx_dist **out) {

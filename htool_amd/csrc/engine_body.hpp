@@ -38,6 +38,15 @@ struct HMat {
     double build_epsilon = 0;  // accuracy the low-rank leaves were built with (LowRankMatrix::get_epsilon)
     bool has_mirror = false;   // the block tree has leaves_for_symmetry
     bool sym_expanded = false; // ... and they were laid out explicitly (no mirror pass needed)
+    // compact symmetric storage, fused product (expand_sym_kernel / rowreduce_sym_kernel): slots in SW = [a' | partial a' | levels]
+    bool sym_fused = false;
+    DArr<int32_t> s_mdst, s_coef, s_rowdst, s_count;
+    DArr<int64_t> s_task_rowbase;
+    DArr<int32_t> sc_dst, sc_src, sc_stride, sc_count;
+    int n_sym_combine = 0;
+    int64_t s_ybase   = 0;
+    int s_kmax        = 0;
+    DArr<scalar> SW;
     std::vector<int64_t> staged_off;
     std::vector<int32_t> perm_t, perm_s; // full permutations (cluster -> user)
     bool t_root_is_tree_root = false, perm_local = false;
@@ -119,11 +128,17 @@ static int build_streams(HMat &H) {
     // the product is a single untransposed pass through the tuned kernels (incl. the fused multi-RHS path).
     // That costs the memory symmetric storage would save; HMX_SYM_COMPACT=1 keeps the compact form and uses the
     // mirror pass (colreduce/rowreduce kernels) instead.  Measured at N=1e6 fp64: 3.0 ms expanded vs 3.9 ms compact.
-    H.sym_expanded = H.has_mirror && !(getenv("HMX_SYM_COMPACT") && atoi(getenv("HMX_SYM_COMPACT")));
-    // Hermitian storage ('H'): the mirrored copy is the CONJUGATE transpose; only the expanded layout implements it
-    const int herm = H.symmetry_for_leaves == 'H' ? 1 : 0;
-    if (herm)
-        H.sym_expanded = H.has_mirror;
+    // Default since round 2: COMPACT storage with the fused product (each stored coefficient of a dense leaf and of a U factor is
+    // read once, V factors twice: see expand_sym_kernel) -- half the HBM footprint and 0.7 x the traffic of the expanded layout.
+    // HMX_SYM_EXPANDED=1 restores the expanded layout, HMX_SYM_COMPACT=1 the compact layout with the atomics-based mirror pass.
+    const bool want_expanded = getenv("HMX_SYM_EXPANDED") && atoi(getenv("HMX_SYM_EXPANDED"));
+    const bool want_atomic   = getenv("HMX_SYM_COMPACT") && atoi(getenv("HMX_SYM_COMPACT"));
+    const int herm           = H.symmetry_for_leaves == 'H' ? 1 : 0; // 'H': the mirrored leaf is the CONJUGATE transpose
+    H.sym_expanded           = H.has_mirror && want_expanded && !want_atomic;
+    // the atomics-based mirror pass has no conjugating form: Hermitian storage is fused (or expanded)
+    H.sym_fused = H.has_mirror && !H.sym_expanded && (!want_atomic || herm) && !H.view_of;
+    if (H.view_of && H.has_mirror)
+        H.sym_expanded = true; // a transposed view is only ever built from an expanded layout
     // a transposed view borrows crosses, staged blocks and generator from its owner
     const HMat &SRC = H.view_of ? *H.view_of : H;
     const bool tv   = H.view_of != nullptr;
@@ -376,6 +391,117 @@ static int build_streams(HMat &H) {
     H.n_combine = (int)cd.size();
     // transposed-pass destinations are derived from h_e_zidx on first use (ensure_transposed_indices)
 
+    // ---- fused symmetric product: slots of the mirrored partial results ----------------------------------------------------
+    std::vector<int32_t> s_mdst, s_coef, s_rowdst, s_cnt, s_cd, s_cs, s_cst, s_cc;
+    std::vector<int64_t> s_rowbase;
+    H.n_sym_combine = 0;
+    H.s_kmax        = 0;
+    if (H.sym_fused) {
+        s_mdst.assign(E.total_cols, -1);
+        s_coef.assign(R.total_cols, -1);
+        s_cnt.assign(H.nT, 0);
+        // a mirrored low-rank leaf that spans several row ranges gets one partial a' per range, folded by combine_kernel
+        std::vector<int32_t> nrange(nb, 0), first_range(nb, 0);
+        for (size_t p = 0; p < elr_b.size(); p++)
+            if (nrange[elr_b[p]]++ == 0)
+                first_range[elr_b[p]] = elr_r[p];
+        std::vector<int64_t> p2off(nb, -1);
+        int64_t P2 = 0;
+        for (int64_t b = 0; b < nb; b++)
+            if (XL[b].mirror && XK[b] == LK_LOWRANK && XL[b].rank > 0 && nrange[b] > 1) {
+                p2off[b] = P2;
+                P2 += (int64_t)nrange[b] * XL[b].rank;
+            }
+        const int64_t ybase = A_total + P2;
+        H.s_ybase           = ybase;
+        int64_t max_slot    = ybase;
+        bool bad            = false;
+        for (int64_t b = 0; b < nb; b++)
+            if (p2off[b] >= 0)
+                for (int k = 0; k < XL[b].rank; k++) {
+                    s_cd.push_back((int32_t)(aoff[b] + k));
+                    s_cs.push_back((int32_t)(A_total + p2off[b] + k));
+                    s_cst.push_back(XL[b].rank);
+                    s_cc.push_back(nrange[b]);
+                }
+        parallel_for(elr_b.size(), [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; p++) {
+                const int b = elr_b[p], r = elr_r[p];
+                if (!XL[b].mirror)
+                    continue;
+                const int64_t base = nrange[b] == 1 ? aoff[b] : A_total + p2off[b] + (int64_t)(r - first_range[b]) * XL[b].rank;
+                int32_t *dst       = s_mdst.data() + E.colbase[r] + elr_c[p];
+                for (int k = 0; k < XL[b].rank; k++)
+                    dst[k] = (int32_t)(base + k);
+            }
+        });
+        // dense mirrored leaves: column j of the leaf is a contribution to output row s_offset + j; contributions to one row are
+        // numbered in layout order (its "levels")
+        for (size_t p = 0; p < ed_b.size(); p++) {
+            const int b = ed_b[p], r = ed_r[p];
+            const hmx_leaf &l = XL[b];
+            if (!l.mirror)
+                continue;
+            const int j0 = l.s_offset - H.T0;
+            if (j0 < 0 || j0 + l.s_size > H.nT) {
+                bad = true;
+                break;
+            }
+            int32_t *dst = s_mdst.data() + E.colbase[r] + ed_c[p];
+            for (int j = 0; j < l.s_size; j++) {
+                const int64_t slot = ybase + (int64_t)(s_cnt[j0 + j]++) * H.nT + (j0 + j);
+                max_slot           = std::max(max_slot, slot);
+                dst[j]             = (int32_t)slot;
+            }
+        }
+        parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; p++) {
+                const int b = rlr_b[p];
+                if (!XL[b].mirror)
+                    continue;
+                int32_t *dst = s_coef.data() + R.colbase[rlr_r[p]] + rlr_c[p];
+                for (int k = 0; k < XL[b].rank; k++)
+                    dst[k] = (int32_t)(aoff[b] + k);
+            }
+        });
+        // second R sweep: every (piece, chunk) task with a mirrored column writes its rows to their next free level
+        const size_t ntask = R.task_range.size();
+        s_rowbase.assign(ntask, -1);
+        for (size_t t = 0; t < ntask && !bad; t++) {
+            const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
+            const int w = std::min(cw, R.cols[r] - ch * cw);
+            const int32_t *cf = s_coef.data() + R.colbase[r] + (int64_t)ch * cw;
+            bool any = false;
+            for (int c = 0; c < w && !any; c++)
+                any = cf[c] >= 0;
+            if (!any)
+                continue;
+            const int j0 = R.off[r] + H.S0 - H.T0;
+            if (j0 < 0 || j0 + R.len[r] > H.nT) {
+                bad = true;
+                break;
+            }
+            s_rowbase[t] = (int64_t)s_rowdst.size();
+            for (int i = 0; i < R.len[r]; i++) {
+                const int64_t slot = ybase + (int64_t)(s_cnt[j0 + i]++) * H.nT + (j0 + i);
+                max_slot           = std::max(max_slot, slot);
+                s_rowdst.push_back((int32_t)slot);
+            }
+        }
+        if (bad) {
+            set_error("symmetric storage needs the mirrored leaves' source clusters inside the target rows of the operator");
+            return HMX_ERR_UNSUPPORTED;
+        }
+        if (max_slot >= (int64_t(1) << 31) - 1) {
+            set_error("operator too large for 32-bit slots of the fused symmetric product (HMX_SYM_EXPANDED=1 selects the expanded layout)");
+            return HMX_ERR_UNSUPPORTED;
+        }
+        for (int32_t c : s_cnt)
+            H.s_kmax = std::max(H.s_kmax, (int)c);
+        H.n_sym_combine = (int)s_cd.size();
+        phase("fused symmetric slots");
+    }
+
     phase("index arrays");
     // ---- upload metadata, allocate streams ------------------------------------------------------------
     HMX_HIP(E.upload_meta());
@@ -392,6 +518,23 @@ static int build_streams(HMat &H) {
     HMX_HIP(H.Z.alloc(H.zero_slot + 1));
     HMX_HIP(H.Z.zero());
     HMX_HIP(H.W.alloc(std::max(H.nS, H.nT) + A_total + 1));
+    if (H.sym_fused) {
+        HMX_HIP(H.s_mdst.upload(s_mdst));
+        HMX_HIP(H.s_coef.upload(s_coef));
+        HMX_HIP(H.s_rowdst.upload(s_rowdst));
+        HMX_HIP(H.s_count.upload(s_cnt));
+        HMX_HIP(H.s_task_rowbase.upload(s_rowbase));
+        HMX_HIP(H.sc_dst.upload(s_cd));
+        HMX_HIP(H.sc_src.upload(s_cs));
+        HMX_HIP(H.sc_stride.upload(s_cst));
+        HMX_HIP(H.sc_count.upload(s_cc));
+        HMX_HIP(H.SW.alloc(H.s_ybase + (int64_t)H.s_kmax * H.nT + 1));
+    } else {
+        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_rowdst, &H.s_count, &H.sc_dst, &H.sc_src, &H.sc_stride, &H.sc_count})
+            a->release();
+        H.s_task_rowbase.release();
+        H.SW.release();
+    }
     H.e_zidx_mirror.release();
     H.e_tdst.release();
     H.e_tdst_mirror.release();
@@ -529,7 +672,7 @@ static void prof_mark(HMat &H, hipStream_t st, const char *name) {
 
 // forward pass on device pointers: y = alpha * (sum over leaves) x + beta * y using the fast kernels
 // zidx: coefficient index array of the E-streams (all leaves, or mirror leaves only)
-static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st) {
+static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st, bool sym_fused = false) {
     // Z[x region] <- x.  x_shift != 0 (mirror pass of a transposed product): the input is indexed by target
     // positions, the x region by source positions.
     const scalar *xin = x_src; // x_shift == 0: both stages read the caller's vector directly, nothing is copied
@@ -565,7 +708,36 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         hipLaunchKernelGGL(combine_kernel, dim3((H.n_combine + 255) / 256), dim3(256), 0, st, C);
         prof_mark(H, st, "combine_kernel");
     }
-    if (H.E.nranges() > 0) {
+    if (sym_fused) {
+        // compact symmetric storage: forward product and mirrored column sums in one sweep over the E-streams, then a' is
+        // folded, the R-streams are swept a second time (y_s += V^T a') and the output levels are added in their fixed order
+        if (H.E.nranges() > 0) {
+            ExpandSymArgs X{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx},
+                            H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0};
+            switch (EW) {
+            case 1: hipLaunchKernelGGL(expand_sym_kernel<1>, dim3(H.E.nranges()), dim3(64), 0, st, X); break;
+            case 2: hipLaunchKernelGGL(expand_sym_kernel<2>, dim3(H.E.nranges()), dim3(128), 0, st, X); break;
+            case 8: hipLaunchKernelGGL(expand_sym_kernel<8>, dim3(H.E.nranges()), dim3(512), 0, st, X); break;
+            default: hipLaunchKernelGGL(expand_sym_kernel<4>, dim3(H.E.nranges()), dim3(256), 0, st, X); break;
+            }
+            prof_mark(H, st, "expand_sym_kernel");
+        }
+        if (H.n_sym_combine > 0) {
+            CombineArgs C{H.sc_dst.d, H.sc_src.d, H.sc_stride.d, H.sc_count.d, H.SW.d, H.n_sym_combine};
+            hipLaunchKernelGGL(combine_kernel, dim3((H.n_sym_combine + 255) / 256), dim3(256), 0, st, C);
+            prof_mark(H, st, "combine_sym_kernel");
+        }
+        if (ntasks > 0 && H.s_rowdst.n > 0) {
+            RowReduceSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
+                               H.s_coef.d, H.s_task_rowbase.d, H.s_rowdst.d, H.SW.d, ntasks, H.symmetry_for_leaves == 'H' ? 1 : 0};
+            hipLaunchKernelGGL(rowreduce_sym_kernel<1>, dim3(ntasks), dim3(64), 0, st, A);
+            prof_mark(H, st, "rowreduce_sym_kernel");
+        }
+        if (H.s_kmax > 0) {
+            hipLaunchKernelGGL(sym_finish_kernel, dim3((H.nT + 255) / 256), dim3(256), 0, st, H.nT, alpha, (const scalar *)(H.SW.d + H.s_ybase), (const int32_t *)H.s_count.d, y);
+            prof_mark(H, st, "sym_finish_kernel");
+        }
+    } else if (H.E.nranges() > 0) {
         ExpandArgs X{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx};
         switch (EW) {
         case 1: hipLaunchKernelGGL(expand_kernel<1>, dim3(H.E.nranges()), dim3(64), 0, st, X); break;
@@ -844,8 +1016,8 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
         }
     }
     if (trans == 'N') {
-        rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st);
-        if (rc == HMX_OK && H.has_mirror && !H.sym_expanded)
+        rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st, H.sym_fused);
+        if (rc == HMX_OK && H.has_mirror && !H.sym_expanded && !H.sym_fused)
             rc = run_transposed(H, true, in, alpha, scalar(1), out, st);
     } else {
         rc = run_transposed(H, false, in, alpha, beta, out, st);
@@ -1766,6 +1938,8 @@ static int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxF
         const hmx_leaf &a = fl[b], &l = H->leaves[b];
         if (a.t_offset != l.t_offset || a.t_size != l.t_size || a.s_offset != l.s_offset || a.s_size != l.s_size || a.mirror != l.mirror)
             return fail("leaf " + std::to_string(b) + " does not match the block tree");
+        if (a.rank < -1 || a.rank > std::min(a.t_size, a.s_size)) // a corrupt rank would size the buffers below
+            return fail("leaf " + std::to_string(b) + " has an impossible rank");
         const size_t count = a.rank >= 0 ? (size_t)a.rank * (a.t_size + a.s_size) : (size_t)a.t_size * a.s_size;
         buf.resize(std::max<size_t>(count, 1));
         if (count && fread(buf.data(), sizeof(scalar), count, f) != count)

@@ -205,6 +205,23 @@ int load_cluster_tree(const std::string &props_file, const std::string &tree_fil
             set_error("hmx_cluster_tree_load: partition table has holes");
             return HMX_ERR_INVALID;
         }
+    // the permutation and the node ranges become gather / scatter indices on host and device: reject anything out of range
+    {
+        std::vector<char> seen((size_t)std::max(T.n, 0), 0);
+        for (int i = 0; i < T.n; i++) {
+            const int v = T.perm[i];
+            if (v < 0 || v >= T.n || seen[v]) {
+                set_error("hmx_cluster_tree_load: the permutation in " + props_file + " is not a permutation of 0.." + std::to_string(T.n - 1));
+                return HMX_ERR_INVALID;
+            }
+            seen[v] = 1;
+        }
+        for (const auto &nd : T.nodes)
+            if (nd.offset < 0 || nd.size < 0 || (long long)nd.offset + nd.size > (long long)T.n) {
+                set_error("hmx_cluster_tree_load: a cluster of " + tree_file + " lies outside [0, " + std::to_string(T.n) + ")");
+                return HMX_ERR_INVALID;
+            }
+    }
     T.opt.size_of_partition  = (int)T.on_partition.size();
     T.opt.number_of_children = T.nodes[0].n_children;
     return HMX_OK;

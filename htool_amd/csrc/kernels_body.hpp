@@ -1882,6 +1882,156 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused symmetric / Hermitian product on the COMPACT layout (only the stored triangle is in HBM):
+// add_hmatrix_vector_product.hpp:97-103,158-161 -- every leaf of leaves_for_symmetry is applied twice, out[t] += B in[s] and
+// out[s] += B^T in[t] (B^H for 'H').  Here that is ONE sweep over the E-streams: while the tile of a row range sits in
+// registers as lane = row for the forward product, the same registers give, per mirrored column, the column sum
+// sum_i E[i,c] x_t[i] (eight wave reductions at a time, reduce8).  For a dense leaf that is the leaf's contribution to an output
+// row; for a low-rank leaf B = U V it is a slice of a' = U^T x_t, and y_s += V^T a' needs a second sweep over the R-streams once
+// a' is complete (the one factor a streaming product must read twice: U-expand needs V x_s and V-expand needs U^T x_t, so with
+// one read of U the two V passes lie before and after it).  Nothing is accumulated with atomics: every partial result has
+// its own slot in W = [a' | partial a' | output levels] assigned at layout time, folded in a fixed order (combine_kernel for a',
+// sym_finish_kernel for the output rows), so results are bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+struct ExpandSymArgs {
+    ExpandArgs X;
+    const int32_t *mdst; // per E column: slot in W of its column sum, -1: not a mirrored column
+    scalar *W;
+    const scalar *xrow;  // the input at the TARGET positions of this operator: xrow[range_off + i]
+    int herm;            // 'H' storage: the mirrored leaf is the conjugate transpose
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
+    const ExpandArgs &A = S.X;
+    __shared__ scalar part[WAVES][WAVE];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    const bool active   = lane < len;
+    const int row       = active ? lane : 0;
+    const scalar xr     = active ? S.xrow[A.range_off[R] + lane] : scalar(0); // idle lanes contribute exact zeros to the column sums
+    const int slot      = reduce8_slot(lane);
+    const bool herm     = S.herm != 0;
+    scalar acc = scalar(0);
+    for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
+        const int nc   = (C - c0) < 64 ? (C - c0) : 64;
+        const scalar z = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
+        const int md   = lane < nc ? mdst[c0 + lane] : -1;
+        const bool mir = __any(md >= 0); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
+        const scalar *col = E + (int64_t)c0 * len + row;
+        for (int j = 0; j < nc; j += 8) {
+            scalar v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                v[u] = (j + u < nc) ? stream_load(col + (int64_t)(j + u) * len) : scalar(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                acc = hmx_fma(v[u], readlane_val(z, (j + u) & 63), acc);
+            if (mir) {
+                scalar p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    p[u] = (herm ? hmx_conj(v[u]) : v[u]) * xr;
+                const scalar r = reduce8(p, lane);
+                const int d    = __shfl(md, (j + slot) & 63, WAVE);
+                if ((lane & 7) == 0 && j + slot < nc && d >= 0)
+                    S.W[d] = r;
+            }
+        }
+    }
+    part[wv][lane] = active ? acc : scalar(0);
+    __syncthreads();
+    if (wv == 0 && active) {
+        scalar s = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            s += part[k][lane];
+        scalar *yo = A.y + A.range_off[R] + lane;
+        *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+// second sweep over the R-streams: per (source piece, column chunk) the rows sum_col Rs[i,col] a'[col] (conjugated for 'H'),
+// each written to its own output-level slot
+struct RowReduceSymArgs {
+    const scalar *stream;
+    const int32_t *task_range, *task_chunk;
+    const int32_t *range_len, *range_cols, *range_cw;
+    const int64_t *range_base, *range_colbase;
+    const int32_t *coef;         // per R column: slot of a'[col] in W, -1: not a mirrored column
+    const int64_t *task_rowbase; // per task: first entry of its rows in row_dst, -1: no mirrored column in the chunk
+    const int32_t *row_dst;      // per (task, row): output-level slot in W
+    scalar *W;
+    int ntasks;
+    int herm;
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSymArgs A) {
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    if (task >= A.ntasks)
+        return;
+    const int64_t rb = A.task_rowbase[task];
+    if (rb < 0)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp      = (w + 1) & ~1;
+    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+    const bool active = col0 < wp;
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const int64_t cb  = A.range_colbase[S] + ch * cw;
+    scalar c0 = scalar(0), c1 = scalar(0);
+    if (col0 < w) {
+        const int d = A.coef[cb + col0];
+        c0          = d >= 0 ? A.W[d] : scalar(0);
+    }
+    if (col1 < w) {
+        const int d = A.coef[cb + col1];
+        c1          = d >= 0 ? A.W[d] : scalar(0);
+    }
+    const bool herm = A.herm != 0;
+    const int slot  = reduce8_slot(lane);
+    const int32_t *dst = A.row_dst + rb;
+    for (int i0 = 0; i0 < len; i0 += 8) {
+        scalar2 e[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            e[u].x = scalar(0);
+            e[u].y = scalar(0);
+            if (active && i0 + u < len)
+                e[u] = load_pair(src + (int64_t)(i0 + u) * wp, col0, col1, wp);
+        }
+        scalar v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            v[u] = herm ? hmx_fma(hmx_conj(e[u].x), c0, hmx_conj(e[u].y) * c1) : hmx_fma(e[u].x, c0, e[u].y * c1);
+        const scalar r = reduce8(v, lane);
+        if ((lane & 7) == 0 && i0 + slot < len)
+            A.W[dst[i0 + slot]] = r;
+    }
+}
+
+// y[j] += alpha * (level 0 + level 1 + ...): the mirrored contributions of output row j in their fixed layout order
+__global__ void sym_finish_kernel(int n, scalar alpha, const scalar *levels, const int32_t *count, scalar *y) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    const int cnt = count[j];
+    if (cnt == 0)
+        return;
+    scalar s = scalar(0);
+    for (int k = 0; k < cnt; k++)
+        s += levels[(int64_t)k * n + j];
+    y[j] += alpha * s;
+}
+
 // small helpers -----------------------------------------------------------------------------------
 __global__ void axpby_kernel(int n, scalar alpha, const scalar *w, scalar beta, scalar *y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -15,7 +15,8 @@ One process per GPU; rank k owns the block rows of partition cluster k.  The MPI
   MPI_Allgatherv (trans='N', C1/C3)  -> all_gather_into_tensor on a max-size padded buffer (RCCL has no allgatherv;
                                         partition sizes differ by at most the split remainder)
   MPI_Allreduce  (trans!='N', C2)    -> all_reduce(SUM)
-  MPI_Alltoallv + axpys (C4)         -> reduce_scatter on the padded layout
+  MPI_Alltoallv + axpys (C4)         -> reduce_scatter_tensor on the max-size padded layout (straight from the product's
+                                        buffer when the partitions are equal); HMX_DIST_NO_REDUCE_SCATTER=1: all_reduce + slice
 Vectors are torch tensors that stay on the device; only pointers cross the C ABI.
 """
 import numpy as np
@@ -175,6 +176,35 @@ class DistributedOperator:
             out[partition.get_offset_of_partition(k):partition.get_offset_of_partition(k) + sizes[k]].copy_(recv[k * m:k * m + sizes[k]])
 
 
+    def _reduce_scatter_slices(self, full, partition):
+        """Sum of the ranks' `full` (global length, partition numbering; first dimension = rows), returned restricted to THIS
+        rank's slice: the reference's MPI_Alltoallv + p axpys (add_distributed_operator_vector_product_local_to_local.hpp:77,
+        ..._matrix_product_row_major_local_to_local.hpp:84) as ONE reduce-scatter -- every rank receives N/p rows instead of N."""
+        import os
+        p, rank = self.size(), self.rank()
+        off, n = partition.get_offset_of_partition(rank), partition.get_size_of_partition(rank)
+        if p == 1:
+            return full[off:off + n]
+        if os.environ.get("HMX_DIST_NO_REDUCE_SCATTER"):
+            dist.all_reduce(_rv(full), op=dist.ReduceOp.SUM, group=self.group)
+            return full[off:off + n]
+        sizes = [partition.get_size_of_partition(k) for k in range(p)]
+        m = max(sizes)
+        tail = tuple(full.shape[1:])
+        out = torch.empty((m,) + tail, dtype=full.dtype, device=full.device)
+        if min(sizes) == m and partition.get_offset_of_partition(0) == 0 and full.is_contiguous():
+            dist.reduce_scatter_tensor(_rv(out), _rv(full), op=dist.ReduceOp.SUM, group=self.group)
+            return out
+        key = ("rs", m, p, full.device, full.dtype, tail)
+        if key not in self._pad:
+            self._pad[key] = torch.zeros((p * m,) + tail, dtype=full.dtype, device=full.device)
+        send = self._pad[key]
+        for k in range(p):  # rows beyond size_k stay zero
+            send[k * m:k * m + sizes[k]].copy_(full[partition.get_offset_of_partition(k):partition.get_offset_of_partition(k) + sizes[k]])
+        dist.reduce_scatter_tensor(_rv(out), _rv(send), op=dist.ReduceOp.SUM, group=self.group)
+        return out[:n]
+
+
 def internal_add_distributed_operator_vector_product_global_to_global(trans, alpha, A, x, beta, y):
     """Partition numbering; x and y are whole vectors replicated on every rank."""
     rank = A.rank()
@@ -287,8 +317,8 @@ def add_distributed_operator_vector_product_global_to_global(trans, alpha, A, x,
 def internal_add_distributed_operator_vector_product_local_to_local(trans, alpha, A, x_loc, beta, y_loc):
     """The Krylov-side contract (wrappers/wrapper_hpddm.hpp:121): local slices in and out, partition numbering.
     trans='N': all-gather the input, local product, output stays local.  trans!='N': local product into a
-    zeroed global buffer, reduce-scatter."""
-    rank, p = A.rank(), A.size()
+    zeroed global buffer, reduce-scatter of that buffer (DistributedOperator._reduce_scatter_slices)."""
+    rank = A.rank()
     in_part = A.source_partition if trans == "N" else A.target_partition
     out_part = A.target_partition if trans == "N" else A.source_partition
     if trans == "N":
@@ -311,12 +341,7 @@ def internal_add_distributed_operator_vector_product_local_to_local(trans, alpha
             buf = torch.zeros(out_part.get_global_size(), dtype=x_loc.dtype, device=x_loc.device)
             for op in A.global_to_local_operators:
                 op.add_vector_product(trans, alpha, x_loc, 1.0, buf)
-            if p > 1:
-                # MPI_Alltoallv + p axpys == a reduce-scatter; done as all_reduce + slice to keep uneven
-                # partitions simple (N doubles over xGMI; the local product dominates)
-                dist.all_reduce(_rv(buf), op=dist.ReduceOp.SUM, group=A.group)
-            off, n = out_part.get_offset_of_partition(rank), out_part.get_size_of_partition(rank)
-            y_loc.add_(buf[off:off + n])
+            y_loc.add_(A._reduce_scatter_slices(buf, out_part))  # MPI_Alltoallv + p axpys == a reduce-scatter
     return y_loc
 
 
@@ -351,6 +376,9 @@ def internal_add_distributed_operator_matrix_product_row_major_global_to_global(
         for op in A.global_to_local_operators:
             op.add_matrix_product_row_major(trans, alpha, X, beta if apply_beta else 1.0, local, mu)
             apply_beta = False
+        for op in A.local_to_local_operators:  # :68-71 of the reference: the block-diagonal operators see the local rows of X
+            op.add_matrix_product_row_major(trans, alpha, X[off_in:off_in + n_in], beta if apply_beta else 1.0, local, mu)
+            apply_beta = False
         A._gather_slices(local, out_part, Y)
     else:
         Y_old = Y.clone() if beta != 0 else None
@@ -358,6 +386,8 @@ def internal_add_distributed_operator_matrix_product_row_major_global_to_global(
         X_loc = X[off_in:off_in + n_in].contiguous()
         for op in A.global_to_local_operators:
             op.add_matrix_product_row_major(trans, alpha, X_loc, 1.0, Y, mu)
+        for op in A.local_to_local_operators:
+            op.add_matrix_product_row_major(trans, alpha, X_loc, 1.0, Y[off_out:off_out + n_out], mu)
         if A.size() > 1:
             dist.all_reduce(_rv(Y), op=dist.ReduceOp.SUM, group=A.group)
         if beta != 0:

@@ -252,6 +252,11 @@ class EngineT {
     }
 
     hmx_hmatrix *hmatrix() const { return m_hmatrix; }
+    // root block of the block tree: {target offset, target size, source offset, source size} in cluster numbering
+    bool root(int32_t out[4]) const {
+        char sym = 'N', uplo = 'N';
+        return m_block_tree && ok(hmx_block_tree_root(m_block_tree, out, &sym, &uplo), "block tree root");
+    }
     size_t number_of_leaves() const { return m_leaves.size(); }
     bool leaf_is_admissible(int64_t leaf) const { return m_leaves[leaf].admissible != 0; }
     int64_t find_leaf(int row_offset, int M, int col_offset, int N) const {
@@ -370,22 +375,37 @@ using GlobalToLocalHmx = GlobalToLocalHmxT<double>;
 template <typename T>
 class LocalToLocalHmxT final : public htool::VirtualLocalToLocalOperator<T> {
     const EngineT<T> &m_engine;
-    int m_source_size; // size of the local source cluster
+    int m_source_offset = 0, m_source_size = 0; // the local source cluster, GLOBAL cluster numbering (the block tree's root)
 
   public:
-    LocalToLocalHmxT(const EngineT<T> &engine, int local_source_size) : m_engine(engine), m_source_size(local_source_size) {}
+    // `local_source_size` is kept for source compatibility; offset and size are taken from the block tree's root
+    explicit LocalToLocalHmxT(const EngineT<T> &engine, int local_source_size = -1) : m_engine(engine), m_source_size(local_source_size) {
+        int32_t r[4];
+        if (engine.root(r)) {
+            m_source_offset = r[2];
+            m_source_size   = r[3];
+        }
+    }
     void add_vector_product(char trans, T alpha, const T *const in, T beta, T *const out) const override {
         ok(Abi<T>::matvec(m_engine.hmatrix(), trans, alpha, in, beta, out), "matvec");
     }
     void add_matrix_product_row_major(char trans, T alpha, const T *const in, T beta, T *const out, int mu) const override {
         ok(Abi<T>::matmat(m_engine.hmatrix(), trans, alpha, in, beta, out, mu), "matmat");
     }
+    // local_to_local_operators/hmatrix.hpp:33-51: `in` holds rows [offset, offset + size) of the GLOBAL source numbering; the part
+    // inside the local source cluster is zero-extended to the cluster and multiplied.  (For mu > 1 the reference advances `in` by
+    // rows, not rows * mu, :46 -- the row-major meaning of the argument is followed here; both agree for mu = 1.)
     void add_sub_matrix_product_to_local(const T *const in, T *const out, int mu, int offset, int size) const override {
+        const int lo = std::max(offset, m_source_offset), hi = std::min(offset + size, m_source_offset + m_source_size);
+        if (offset == m_source_offset && hi == m_source_offset + m_source_size) {
+            add_matrix_product_row_major('N', T(1), in, T(1), out, mu);
+            return;
+        }
+        if (hi <= lo)
+            return;
         std::vector<T> temp((size_t)m_source_size * mu, T(0));
-        const int lo = std::max(offset, 0), hi = std::min(offset + size, m_source_size);
-        if (hi > lo)
-            std::copy_n(in + (size_t)(lo - offset) * mu, (size_t)(hi - lo) * mu, temp.data() + (size_t)lo * mu);
-        ok(Abi<T>::matmat(m_engine.hmatrix(), 'N', T(1), temp.data(), T(1), out, mu), "sub matmat");
+        std::copy_n(in + (size_t)(lo - offset) * mu, (size_t)(hi - lo) * mu, temp.data() + (size_t)(lo - m_source_offset) * mu);
+        add_matrix_product_row_major('N', T(1), temp.data(), T(1), out, mu);
     }
 };
 using LocalToLocalHmx = LocalToLocalHmxT<double>;

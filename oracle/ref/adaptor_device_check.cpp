@@ -13,6 +13,7 @@
 //   (f) the same as (a),(d) for std::complex<double> with Hermitian storage
 #include <htool/clustering/tree_builder/tree_builder.hpp>
 #include <htool/hmatrix/hmatrix.hpp>
+#include <htool/distributed_operator/implementations/local_to_local_operators/hmatrix.hpp>
 #include <htool/hmatrix/linalg/add_hmatrix_vector_product.hpp>
 #include <htool/hmatrix/lrmat/partialACA.hpp>
 #include <htool/hmatrix/lrmat/sympartialACA.hpp>
@@ -170,6 +171,20 @@ int main() {
         hmx_htool::LocalToLocalHmx opd(Ed, nd);
         opd.add_vector_product('N', 1., xd.data(), 0., yd.data());
         report("(e') LocalToLocalHmx (block-diagonal operator of partition 1) vs htool's build on the partition clusters", rel(yd, ydref), 1e-10);
+        // (e'') add_sub_matrix_product_to_local on partition 1 (source offset > 0): a window of the GLOBAL source numbering that
+        // overlaps the local cluster only partly, the whole cluster, and a window outside it -- against htool's own LocalToLocalHMatrix
+        {
+            LocalToLocalHMatrix<double> href(Hdiag);
+            const int so = part.get_offset();
+            const int windows[3][2] = {{so - 37, nd / 2 + 37}, {so, nd}, {0, std::max(1, so - 1)}};
+            for (const auto &w : windows) {
+                const int off = std::max(0, w[0]), size = w[1];
+                std::vector<double> sub(xin_cluster.begin() + off, xin_cluster.begin() + off + size), a(nd, 0.25), b(nd, 0.25);
+                href.add_sub_matrix_product_to_local(sub.data(), a.data(), 1, off, size);
+                opd.add_sub_matrix_product_to_local(sub.data(), b.data(), 1, off, size);
+                report("(e'') LocalToLocalHmx::add_sub_matrix_product_to_local, window of the global source numbering", rel(b, a), 1e-10);
+            }
+        }
     }
     {
         using Z = std::complex<double>;

@@ -3,7 +3,8 @@
 // Drives the REAL reference (htool headers where they lie under /root/reference/include, compiled
 // in place; nothing is copied) to (1) dump golden fixtures for tests/golden/ and (2) cross-check the
 // CPU restatement in oracle/hmx_oracle.cpp.  Built only in the dev container (oracle/Makefile target
-// `ref`), output binary goes to oracle/_ref/.  The GPU box never runs this file.
+// `ref`), output binary goes to oracle/_ref/ (git-ignored; the BINARY travels to the GPU box with the snapshot, where
+// bench.py times it as the `cpu_baseline` of kind "reference" -- the sources and the htool headers never do).
 //
 // Usage: ref_driver <mode> key=value ... out=<file>
 //   mode=hmat  : cluster tree + block tree + compression + H-matvec fixture
@@ -445,6 +446,14 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
         std::vector<T> y = y0;
         sequential_internal_add_hmatrix_vector_product('N', al, H, x.data(), be, y.data());
         D.vec("yN", y);
+        if (geti(kv, "extra_ab", 0)) { // a second product with alpha = 1, beta = 0 (the timed form)
+            std::vector<T> y1(nrows, T(0));
+            if (par)
+                openmp_internal_add_hmatrix_vector_product('N', T(1.), H, x.data(), T(0.), y1.data());
+            else
+                sequential_internal_add_hmatrix_vector_product('N', T(1.), H, x.data(), T(0.), y1.data());
+            D.vec("yN_a1b0", y1);
+        }
         if (sym != "H") { // trans='T' with 'H' leaves is refused by the reference (add_hmatrix_vector_product.hpp:59-62)
             std::vector<T> yt = y0T;
             sequential_internal_add_hmatrix_vector_product('T', al, H, xT.data(), be, yt.data());
@@ -464,9 +473,12 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     }
     // multi-RHS row-major (a18), mu = 2
     {
-        int mu                = 2;
+        int mu                = geti(kv, "mu", 2);
         std::vector<T> X = hashed(ncols * (size_t)mu, 5), Y = hashed(nrows * (size_t)mu, 6);
-        sequential_internal_add_hmatrix_matrix_product_row_major('N', 'N', al, H, X.data(), be, Y.data(), mu);
+        if (par)
+            openmp_internal_add_hmatrix_matrix_product_row_major('N', 'N', al, H, X.data(), be, Y.data(), mu);
+        else
+            sequential_internal_add_hmatrix_matrix_product_row_major('N', 'N', al, H, X.data(), be, Y.data(), mu);
         D.vec("YNrm", Y, {(uint64_t)nrows, (uint64_t)mu});
     }
 

@@ -8,7 +8,8 @@ permutations, cluster tables, leaf lists, ranks, a few U/V/dense payloads, matve
 source text is stored.  The reference's own tests hold no golden vectors for this path (SURVEY.md section 4:
 random inputs, tolerance checks against a dense product), so outputs of the reference itself are the pin.
 
-Usage: python tests/golden/make_golden.py            (needs /root/reference; not run on the GPU box)
+Usage: python tests/golden/make_golden.py [case ...]       (needs /root/reference; not run on the GPU box)
+       python tests/golden/make_golden.py full [case ...]  BASELINE's own sizes (N=1e5, 1e6): hashes + sampled products
 """
 import json
 import os
@@ -108,7 +109,73 @@ CASES = {
 }
 
 
+# ---- BASELINE.json's own sizes, pinned to the reference ("full" mode) ----------------------------------------------------
+# The reference builds these in this container (N=1e6 ellipse: minutes, 18.5 GB).  Whole outputs would be hundreds of MB,
+# so a fixture keeps: sha256 of the permutation and of the leaf table's structure columns, the rank column, and the
+# products at SAMPLE fixed rows (alpha=3, beta=2 and alpha=1, beta=0; row-major multi-RHS).  min depth at N=1e6 is the
+# bench's (bench.minimal_depth: smallest d with N / 2^d <= 46340).
+SAMPLE = 4096
+FULL_CASES = {
+    "full_ball_n100000": dict(n=100000, geom="ball", leaf=100, eps=1e-4, eta=10, compressor="partialACA"),
+    "full_ellipse_n100000": dict(n=100000, geom="ellipse", leaf=100, eps=1e-4, eta=10, compressor="partialACA"),
+    "full_ellipse_n1000000": dict(n=1000000, geom="ellipse", leaf=100, eps=1e-4, eta=10, compressor="partialACA", mindepth=5),
+    "full_ellipse_n100000_symL": dict(n=100000, geom="ellipse", leaf=100, eps=1e-4, eta=10, sym="S", uplo="L", compressor="sympartialACA"),
+    "full_ball_n100000_symL": dict(n=100000, geom="ball", leaf=100, eps=1e-4, eta=10, sym="S", uplo="L", compressor="sympartialACA"),
+    # BASELINE config 5's shape at a size the reference builds here: fp32 coefficients, 'S','L', sympartialACA, eps=1e-6, 16 RHS
+    "full_ellipse_n100000_f32_symL_mu16": dict(n=100000, geom="ellipse", leaf=100, eps=1e-6, eta=10, sym="S", uplo="L", compressor="sympartialACA", prec="f32", mu=16),
+}
+
+
+def sample_rows(n):
+    """SAMPLE distinct fixed rows, spread over the whole range (closed form: reproducible in the test)."""
+    return np.unique((np.arange(SAMPLE, dtype=np.int64) * 2654435761 + 12345) % n)
+
+
+def make_full(only):
+    import hashlib
+    manifest = {}
+    for name, params in FULL_CASES.items():
+        if only and name not in only:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".bin", dir="/tmp") as tmp:
+            cmd = [DRIVER, "hmat"] + ["%s=%s" % (k, v) for k, v in params.items()] + ["out=" + tmp.name, "par=1", "extra_ab=1", "dump_blocks=0"]
+            print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, env=dict(os.environ, OMP_NUM_THREADS=str(os.cpu_count())))
+            d = read_dump(tmp.name)
+        leaves = np.ascontiguousarray(d["leaves"], dtype=np.int32)
+        structure = np.ascontiguousarray(leaves[:, [0, 1, 2, 3, 5]])
+        rows = sample_rows(params["n"])
+        out = dict(
+            perm_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(d["t_perm"], dtype=np.int32).tobytes()).digest(), dtype=np.uint8),
+            structure_sha256=np.frombuffer(hashlib.sha256(structure.tobytes()).digest(), dtype=np.uint8),
+            nleaves=np.int64(len(leaves)),
+            ranks=leaves[:, 4].astype(np.int16),
+            rows=rows,
+            yN=np.asarray(d["yN"])[rows],
+            yN_a1b0=np.asarray(d["yN_a1b0"])[rows],
+            YNrm=np.asarray(d["YNrm"])[rows],
+            alphabeta=d["alphabeta"],
+            stats=d["stats"],
+            rootinfo=d["rootinfo"],
+        )
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        manifest[name] = dict(mode="full", **params)
+        print(name, "leaves", len(leaves), "stats", d["stats"][:7], flush=True)
+    return manifest
+
+
 def main():
+    if sys.argv[1:2] == ["full"]:
+        if not os.path.exists(DRIVER):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        manifest = make_full(set(sys.argv[2:]))
+        mpath = os.path.join(HERE, "manifest.json")
+        with open(mpath) as f:
+            old = json.load(f)
+        old.update(manifest)
+        with open(mpath, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+        return
     if not os.path.exists(DRIVER):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     manifest = {}

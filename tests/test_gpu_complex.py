@@ -249,18 +249,22 @@ def test_complex_dtype_mismatch_is_refused():
         hm.internal_add_hmatrix_vector_product("N", 1.0, H, np.zeros(p["n"]), 0.0, np.zeros(p["n"]))
 
 
-def test_complex_symmetric_compact_storage(monkeypatch):
-    """HMX_SYM_COMPACT=1 with complex symmetric ('S') storage: the mirror pass through the in-place transposed kernels
-    (complex atomics); Hermitian storage ignores the knob (always expanded)."""
-    monkeypatch.setenv("HMX_SYM_COMPACT", "1")
-    for name in ("ellipse_n3000_z64_symL", "ball_n2000_z64_hermU"):
+@pytest.mark.parametrize("knob", ["HMX_SYM_COMPACT", "HMX_SYM_EXPANDED"])
+def test_complex_symmetric_other_layouts(knob, monkeypatch):
+    """The default layout of symmetric / Hermitian storage is compact with the fused product (what every other test here runs).
+    HMX_SYM_COMPACT=1 with complex symmetric ('S') storage: the mirror pass through the in-place transposed kernels (complex
+    atomics; Hermitian storage has no such pass and stays fused).  HMX_SYM_EXPANDED=1: mirrored leaves laid out explicitly
+    (conjugated for 'H')."""
+    monkeypatch.setenv(knob, "1")
+    for name in ("ellipse_n3000_z64_symL", "ball_n2000_z64_hermU", "ball_n2000_c32_hermL"):
         p, g = params(name), load(name)
         T, S, H = build_zengine(p)
         x, xT, y0, y0T, alpha, beta = zinputs(H, g)
+        tol = 1e-5 if p["prec"] == "c32" else 1e-10
         y = y0.copy()
         hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
-        assert rel_err(y, g["yN"]) < 1e-10
+        assert rel_err(y, g["yN"]) < tol
         key, trans = ("yT", "T") if "yT" in g else ("yC", "C")
         y = y0T.copy()
         hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y)
-        assert rel_err(y, g[key]) < 1e-10
+        assert rel_err(y, g[key]) < tol

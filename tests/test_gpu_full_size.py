@@ -12,11 +12,9 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _depth(n):  # bench.py's minimal block depth for large n
-    d = 0
-    while (n >> (d + 1)) >= 8000:
-        d += 1
-    return min(d, 7)
+def _depth(n):  # the bench's minimal block depth: the property tests build the operator bench.py times
+    import bench
+    return bench.minimal_depth(n)
 
 
 @pytest.mark.parametrize("n,geom", [(100000, "ball"), (100000, "ellipse"), (1000000, "ellipse")])

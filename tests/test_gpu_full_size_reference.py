@@ -1,0 +1,79 @@
+"""BASELINE.json's own sizes against the REFERENCE itself (north star: "<= 1e-10 relative error vs CPU reference" at N=1e6).
+
+tests/golden/full_*.npz were written by htool (oracle/_ref/ref_driver, `python tests/golden/make_golden.py full`): N=1e5 ball and
+ellipse, N=1e6 ellipse with the bench's minimal block depth, the symmetric ('S','L', sympartialACA) N=1e5 operators and BASELINE
+config 5's shape (fp32, 'S','L', eps=1e-6, 16 right-hand sides) at N=1e5.  A fixture holds sha256 of the cluster permutation and of
+the leaf table's structure columns, the rank of every leaf, and the reference's products at 4096 fixed rows.  Here the engine
+builds the same operator on the GPU: permutation and block structure must hash equal, every rank must equal the reference's, and
+the sampled products must agree to 1e-10 (fp64; 2e-5 for the fp32 operator -- the fp32 floor SURVEY.md App. D states)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import htool_amd as hm
+from helpers import MANIFEST, load
+from oracle.oracle import hashed_vector
+
+pytestmark = pytest.mark.gpu
+
+FULL_CASES = sorted(k for k, v in MANIFEST.items() if v["mode"] == "full")
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_full_size_matches_the_reference(name):
+    p, g = MANIFEST[name], load(name)
+    n, mu = p["n"], p.get("mu", 2)
+    f32 = p.get("prec") == "f32"
+    sym, uplo = p.get("sym", "N"), p.get("uplo", "N")
+    x = hm.create_geometry(p["geom"], n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(p["leaf"])
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    assert np.array_equal(_sha(np.asarray(T.get_permutation(), dtype=np.int32)), g["perm_sha256"]), "cluster permutation differs from the reference's"
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], sym, uplo)
+    tb.set_low_rank_generator(p["compressor"])
+    tb.set_minimal_target_depth(p.get("mindepth", 0))
+    tb.set_minimal_source_depth(p.get("mindepth", 0))
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, dtype=np.float32 if f32 else np.float64)
+    tab = np.asarray(H.leaf_table())
+    assert len(tab) == int(g["nleaves"])
+    assert np.array_equal(_sha(tab[:, [0, 1, 2, 3, 5]].astype(np.int32)), g["structure_sha256"]), "block structure differs from the reference's"
+    ref_ranks = g["ranks"].astype(np.int64)
+    diff = tab[:, 4].astype(np.int64) - ref_ranks
+    ndiff = int(np.count_nonzero(diff))
+    print("%s: %d leaves, %d ranks differ from the reference (max |diff| %d)" % (name, len(tab), ndiff, int(np.abs(diff).max())))
+    # the stopping test sums in another order than BLAS dot, so a rank could move by one when the estimate lands
+    # within rounding of epsilon.  fp64: not a single leaf may differ; fp32 (24-bit estimates): at most a handful, by one.
+    if f32:
+        assert ndiff <= 1e-3 * len(tab) and np.abs(diff).max() <= 1
+    else:
+        assert ndiff == 0
+    rows = g["rows"]
+    dt = np.float32 if f32 else np.float64
+    tol = 2e-5 if f32 else 1e-10
+    xin = hashed_vector(n, 1).astype(dt)
+
+    def err(a, ref):
+        return float(np.linalg.norm(a.astype(np.float64) - ref) / np.linalg.norm(ref))
+
+    y = np.zeros(n, dtype=dt)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y)
+    e1 = err(y[rows], g["yN_a1b0"])
+    al, be = float(g["alphabeta"][0]), float(g["alphabeta"][1])
+    y = hashed_vector(n, 3).astype(dt)
+    hm.internal_add_hmatrix_vector_product("N", al, H, xin, be, y)
+    e2 = err(y[rows], g["yN"])
+    X = hashed_vector(n * mu, 5).astype(dt).reshape(n, mu)
+    Y = hashed_vector(n * mu, 6).astype(dt).reshape(n, mu)
+    hm.internal_add_hmatrix_matrix_product_row_major("N", al, H, X, be, Y, mu)
+    e3 = err(Y[rows], g["YNrm"])
+    print("%s: relative error vs the reference at %d rows: %.2e (alpha=1, beta=0), %.2e (alpha=%g, beta=%g), %.2e (%d right-hand sides)" % (name, len(rows), e1, e2, al, be, e3, mu))
+    if ndiff == 0:
+        assert e1 < tol and e2 < tol and e3 < tol
+    else:  # some fp32 ranks moved by one: the products differ by what one cross of those blocks carries (below epsilon)
+        assert e1 < 10 * p["eps"] and e2 < 10 * p["eps"] and e3 < 10 * p["eps"]

@@ -406,11 +406,16 @@ def test_fp32_engine_against_reference(name):
 SYM_CASES = [c for c in ACA_CASES if params(c)["sym"] == "S"]
 
 
+@pytest.mark.parametrize("layout", ["fused", "atomic", "expanded"])
 @pytest.mark.parametrize("name", SYM_CASES)
-def test_symmetric_storage_compact_mode(name, monkeypatch):
-    """Symmetric storage has two device layouts: expanded (default, mirrored leaves laid out explicitly) and compact
-    (HMX_SYM_COMPACT=1, mirror pass through the transposed kernels).  Both must reproduce the reference."""
-    monkeypatch.setenv("HMX_SYM_COMPACT", "1")
+def test_symmetric_storage_layouts(name, layout, monkeypatch):
+    """Symmetric storage has three device layouts: compact with the fused product (default: only the stored triangle in HBM,
+    forward product and mirrored column sums in one sweep), compact with the atomics-based mirror pass (HMX_SYM_COMPACT=1) and
+    expanded (HMX_SYM_EXPANDED=1, mirrored leaves laid out explicitly).  All must reproduce the reference."""
+    if layout == "atomic":
+        monkeypatch.setenv("HMX_SYM_COMPACT", "1")
+    elif layout == "expanded":
+        monkeypatch.setenv("HMX_SYM_EXPANDED", "1")
     p, g = params(name), load(name)
     T, S, H = build_engine(p)
     assert np.array_equal(H.leaf_table(), g["leaves"])
