@@ -40,12 +40,12 @@ struct HMat {
     bool sym_expanded = false; // ... and they were laid out explicitly (no mirror pass needed)
     // compact symmetric storage, fused product (expand_sym_kernel / rowreduce_sym_kernel): slots in SW = [a' | partial a' | levels]
     bool sym_fused = false;
-    DArr<int32_t> s_mdst, s_coef, s_rowdst, s_count;
+    DArr<int32_t> s_mdst, s_coef, s_count, s_list, s_fidx;
     DArr<int64_t> s_task_rowbase;
-    DArr<int32_t> sc_dst, sc_src, sc_stride, sc_count;
-    int n_sym_combine = 0;
-    int64_t s_ybase   = 0;
+    DArr<int32_t> sc_dst, sc_lp, sc_count, sc_k;
+    int n_sym_combine = 0, n_sym_combine_wave = 0; // the first n_sym_combine_wave entries have >= 32 partial sums: one wave each
     int s_kmax        = 0;
+    int s_lds_cols    = 0; // expand_sym_kernel stages the column sums of ranges with at most this many columns in LDS
     DArr<scalar> SW;
     std::vector<int64_t> staged_off;
     std::vector<int32_t> perm_t, perm_s; // full permutations (cluster -> user)
@@ -392,82 +392,88 @@ static int build_streams(HMat &H) {
     // transposed-pass destinations are derived from h_e_zidx on first use (ensure_transposed_indices)
 
     // ---- fused symmetric product: slots of the mirrored partial results ----------------------------------------------------
-    std::vector<int32_t> s_mdst, s_coef, s_rowdst, s_cnt, s_cd, s_cs, s_cst, s_cc;
+    // W = [a' | EW | RW].  Every WRITER owns a contiguous, 128-byte aligned piece: expand_sym_kernel stores the column sums of a
+    // row range at EW[epad(range) + column] (E-column order), rowreduce_sym_kernel the rows of a task at RW[rowbase(task) + row].
+    // (Scattered 8- to 72-byte writes into per-destination slots cost 10-20 % of those kernels in partial-line HBM writes; whole
+    // lines cost nothing measurable.)  The READERS gather: combine_list_kernel folds the partial a' of a leaf that spans several
+    // ranges through a list of its column-group positions, sym_finish_kernel adds the contributions of an output row through a
+    // level-major index array.  All in a fixed order: results are bit-reproducible.
+    std::vector<int32_t> s_mdst, s_coef, s_cnt, s_cd, s_clp, s_cc, s_ck, s_list, s_fidx;
     std::vector<int64_t> s_rowbase;
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
+    int64_t s_total = 0;
     if (H.sym_fused) {
         s_mdst.assign(E.total_cols, -1);
         s_coef.assign(R.total_cols, -1);
         s_cnt.assign(H.nT, 0);
-        // a mirrored low-rank leaf that spans several row ranges gets one partial a' per range, folded by combine_kernel
-        std::vector<int32_t> nrange(nb, 0), first_range(nb, 0);
+        bool bad = false;
+        std::vector<int64_t> epad(E.nranges());
+        int64_t EWN = 0;
+        for (int r = 0; r < E.nranges(); r++) {
+            epad[r] = EWN;
+            EWN += (E.cols[r] + 15) & ~15;
+        }
+        const int64_t EWBASE = (A_total + 15) & ~int64_t(15), RWBASE = EWBASE + EWN;
+        // low-rank mirrored leaves: column sums land in EW; a leaf inside ONE range is complete there (a' is read from EW),
+        // otherwise a list of its column-group positions feeds combine_list_kernel, which writes a'[aoff + k]
+        std::vector<int32_t> nrange(nb, 0);
         for (size_t p = 0; p < elr_b.size(); p++)
-            if (nrange[elr_b[p]]++ == 0)
-                first_range[elr_b[p]] = elr_r[p];
-        std::vector<int64_t> p2off(nb, -1);
-        int64_t P2 = 0;
+            nrange[elr_b[p]]++;
+        std::vector<int64_t> lptr(nb, -1);
+        int64_t LN = 0;
         for (int64_t b = 0; b < nb; b++)
             if (XL[b].mirror && XK[b] == LK_LOWRANK && XL[b].rank > 0 && nrange[b] > 1) {
-                p2off[b] = P2;
-                P2 += (int64_t)nrange[b] * XL[b].rank;
+                lptr[b] = LN;
+                LN += nrange[b];
             }
-        const int64_t ybase = A_total + P2;
-        H.s_ybase           = ybase;
-        int64_t max_slot    = ybase;
-        bool bad            = false;
-        for (int64_t b = 0; b < nb; b++)
-            if (p2off[b] >= 0)
-                for (int k = 0; k < XL[b].rank; k++) {
-                    s_cd.push_back((int32_t)(aoff[b] + k));
-                    s_cs.push_back((int32_t)(A_total + p2off[b] + k));
-                    s_cst.push_back(XL[b].rank);
-                    s_cc.push_back(nrange[b]);
-                }
-        parallel_for(elr_b.size(), [&](size_t lo, size_t hi) {
-            for (size_t p = lo; p < hi; p++) {
+        s_list.assign(LN, 0);
+        std::vector<int64_t> single_slot(nb, -1);
+        {
+            std::vector<int32_t> seen(nb, 0); // pairs of a leaf are consecutive in elr_* (leaf-major): position inside the leaf's list
+            for (size_t p = 0; p < elr_b.size(); p++) {
                 const int b = elr_b[p], r = elr_r[p];
                 if (!XL[b].mirror)
                     continue;
-                const int64_t base = nrange[b] == 1 ? aoff[b] : A_total + p2off[b] + (int64_t)(r - first_range[b]) * XL[b].rank;
-                int32_t *dst       = s_mdst.data() + E.colbase[r] + elr_c[p];
+                const int64_t base = EWBASE + epad[r] + elr_c[p];
+                if (nrange[b] == 1)
+                    single_slot[b] = base;
+                else
+                    s_list[lptr[b] + seen[b]++] = (int32_t)base;
+                int32_t *dst = s_mdst.data() + E.colbase[r] + elr_c[p];
                 for (int k = 0; k < XL[b].rank; k++)
                     dst[k] = (int32_t)(base + k);
             }
-        });
-        // dense mirrored leaves: column j of the leaf is a contribution to output row s_offset + j; contributions to one row are
-        // numbered in layout order (its "levels")
-        for (size_t p = 0; p < ed_b.size(); p++) {
-            const int b = ed_b[p], r = ed_r[p];
-            const hmx_leaf &l = XL[b];
-            if (!l.mirror)
-                continue;
-            const int j0 = l.s_offset - H.T0;
-            if (j0 < 0 || j0 + l.s_size > H.nT) {
-                bad = true;
-                break;
-            }
-            int32_t *dst = s_mdst.data() + E.colbase[r] + ed_c[p];
-            for (int j = 0; j < l.s_size; j++) {
-                const int64_t slot = ybase + (int64_t)(s_cnt[j0 + j]++) * H.nT + (j0 + j);
-                max_slot           = std::max(max_slot, slot);
-                dst[j]             = (int32_t)slot;
-            }
         }
+        H.n_sym_combine_wave = 0;
+        for (int pass = 0; pass < 2; pass++) // entries with many partial sums first (one wave each), then the rest (one thread each)
+            for (int64_t b = 0; b < nb; b++)
+                if (lptr[b] >= 0 && (nrange[b] >= 32) == (pass == 0)) {
+                    for (int k = 0; k < XL[b].rank; k++) {
+                        s_cd.push_back((int32_t)(aoff[b] + k));
+                        s_clp.push_back((int32_t)lptr[b]);
+                        s_cc.push_back(nrange[b]);
+                        s_ck.push_back(k);
+                    }
+                    if (pass == 0)
+                        H.n_sym_combine_wave += XL[b].rank;
+                }
         parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
             for (size_t p = lo; p < hi; p++) {
                 const int b = rlr_b[p];
                 if (!XL[b].mirror)
                     continue;
-                int32_t *dst = s_coef.data() + R.colbase[rlr_r[p]] + rlr_c[p];
+                const int64_t base = single_slot[b] >= 0 ? single_slot[b] : aoff[b];
+                int32_t *dst       = s_coef.data() + R.colbase[rlr_r[p]] + rlr_c[p];
                 for (int k = 0; k < XL[b].rank; k++)
-                    dst[k] = (int32_t)(aoff[b] + k);
+                    dst[k] = (int32_t)(base + k);
             }
         });
-        // second R sweep: every (piece, chunk) task with a mirrored column writes its rows to their next free level
+        // tasks of the second R sweep with at least one mirrored column: a contiguous piece of RW each
         const size_t ntask = R.task_range.size();
         s_rowbase.assign(ntask, -1);
-        for (size_t t = 0; t < ntask && !bad; t++) {
+        int64_t RWN = 0;
+        for (size_t t = 0; t < ntask; t++) {
             const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
             const int w = std::min(cw, R.cols[r] - ch * cw);
             const int32_t *cf = s_coef.data() + R.colbase[r] + (int64_t)ch * cw;
@@ -481,24 +487,66 @@ static int build_streams(HMat &H) {
                 bad = true;
                 break;
             }
-            s_rowbase[t] = (int64_t)s_rowdst.size();
-            for (int i = 0; i < R.len[r]; i++) {
-                const int64_t slot = ybase + (int64_t)(s_cnt[j0 + i]++) * H.nT + (j0 + i);
-                max_slot           = std::max(max_slot, slot);
-                s_rowdst.push_back((int32_t)slot);
+            s_rowbase[t] = RWBASE + RWN;
+            RWN += (R.len[r] + 15) & ~15;
+            for (int i = 0; i < R.len[r]; i++)
+                s_cnt[j0 + i]++;
+        }
+        // contributions per output row: dense mirrored columns (in EW) and task rows (in RW), numbered in layout order ("levels")
+        for (size_t p = 0; p < ed_b.size() && !bad; p++) {
+            const hmx_leaf &l = XL[ed_b[p]];
+            if (!l.mirror)
+                continue;
+            const int j0 = l.s_offset - H.T0;
+            if (j0 < 0 || j0 + l.s_size > H.nT) {
+                bad = true;
+                break;
             }
+            for (int j = 0; j < l.s_size; j++)
+                s_cnt[j0 + j]++;
         }
         if (bad) {
             set_error("symmetric storage needs the mirrored leaves' source clusters inside the target rows of the operator");
             return HMX_ERR_UNSUPPORTED;
         }
-        if (max_slot >= (int64_t(1) << 31) - 1) {
+        s_total = RWBASE + RWN;
+        for (int32_t c : s_cnt)
+            H.s_kmax = std::max(H.s_kmax, (int)c);
+        if (s_total >= (int64_t(1) << 31) - 1 || (int64_t)H.s_kmax * H.nT >= (int64_t(1) << 40)) {
             set_error("operator too large for 32-bit slots of the fused symmetric product (HMX_SYM_EXPANDED=1 selects the expanded layout)");
             return HMX_ERR_UNSUPPORTED;
         }
-        for (int32_t c : s_cnt)
-            H.s_kmax = std::max(H.s_kmax, (int)c);
+        s_fidx.assign((size_t)H.s_kmax * H.nT, -1);
+        std::vector<int32_t> fill(H.nT, 0);
+        for (size_t p = 0; p < ed_b.size(); p++) { // dense pairs first (leaf-major), then the tasks in launch order
+            const int b = ed_b[p], r = ed_r[p];
+            const hmx_leaf &l = XL[b];
+            if (!l.mirror)
+                continue;
+            const int j0       = l.s_offset - H.T0;
+            const int64_t base = EWBASE + epad[r] + ed_c[p];
+            int32_t *dst       = s_mdst.data() + E.colbase[r] + ed_c[p];
+            for (int j = 0; j < l.s_size; j++) {
+                dst[j]                                               = (int32_t)(base + j);
+                s_fidx[(size_t)(fill[j0 + j]++) * H.nT + (j0 + j)] = (int32_t)(base + j);
+            }
+        }
+        for (size_t t = 0; t < ntask; t++) {
+            if (s_rowbase[t] < 0)
+                continue;
+            const int r = R.task_range[t], j0 = R.off[r] + H.S0 - H.T0;
+            for (int i = 0; i < R.len[r]; i++)
+                s_fidx[(size_t)(fill[j0 + i]++) * H.nT + (j0 + i)] = (int32_t)(s_rowbase[t] + i);
+        }
         H.n_sym_combine = (int)s_cd.size();
+        // LDS staging of the column sums: sized for the widest range, capped at 16 KiB per workgroup so that occupancy stays
+        // bound by registers (wider ranges store their sums directly)
+        int maxc = 0;
+        for (int r = 0; r < E.nranges(); r++)
+            maxc = std::max(maxc, (int)E.cols[r]);
+        H.s_lds_cols = std::min(maxc, (int)(16384 / sizeof(scalar)));
+        if (getenv("HMX_SYM_NO_LDS") && atoi(getenv("HMX_SYM_NO_LDS")))
+            H.s_lds_cols = 0;
         phase("fused symmetric slots");
     }
 
@@ -521,16 +569,17 @@ static int build_streams(HMat &H) {
     if (H.sym_fused) {
         HMX_HIP(H.s_mdst.upload(s_mdst));
         HMX_HIP(H.s_coef.upload(s_coef));
-        HMX_HIP(H.s_rowdst.upload(s_rowdst));
         HMX_HIP(H.s_count.upload(s_cnt));
         HMX_HIP(H.s_task_rowbase.upload(s_rowbase));
         HMX_HIP(H.sc_dst.upload(s_cd));
-        HMX_HIP(H.sc_src.upload(s_cs));
-        HMX_HIP(H.sc_stride.upload(s_cst));
+        HMX_HIP(H.sc_lp.upload(s_clp));
         HMX_HIP(H.sc_count.upload(s_cc));
-        HMX_HIP(H.SW.alloc(H.s_ybase + (int64_t)H.s_kmax * H.nT + 1));
+        HMX_HIP(H.sc_k.upload(s_ck));
+        HMX_HIP(H.s_list.upload(s_list));
+        HMX_HIP(H.s_fidx.upload(s_fidx));
+        HMX_HIP(H.SW.alloc(s_total + 1));
     } else {
-        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_rowdst, &H.s_count, &H.sc_dst, &H.sc_src, &H.sc_stride, &H.sc_count})
+        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx})
             a->release();
         H.s_task_rowbase.release();
         H.SW.release();
@@ -713,28 +762,36 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         // folded, the R-streams are swept a second time (y_s += V^T a') and the output levels are added in their fixed order
         if (H.E.nranges() > 0) {
             ExpandSymArgs X{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx},
-                            H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0};
+                            H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0, H.s_lds_cols};
+            const size_t lds = (size_t)H.s_lds_cols * sizeof(scalar);
             switch (EW) {
-            case 1: hipLaunchKernelGGL(expand_sym_kernel<1>, dim3(H.E.nranges()), dim3(64), 0, st, X); break;
-            case 2: hipLaunchKernelGGL(expand_sym_kernel<2>, dim3(H.E.nranges()), dim3(128), 0, st, X); break;
-            case 8: hipLaunchKernelGGL(expand_sym_kernel<8>, dim3(H.E.nranges()), dim3(512), 0, st, X); break;
-            default: hipLaunchKernelGGL(expand_sym_kernel<4>, dim3(H.E.nranges()), dim3(256), 0, st, X); break;
+            case 1: hipLaunchKernelGGL(expand_sym_kernel<1>, dim3(H.E.nranges()), dim3(64), lds, st, X); break;
+            case 2: hipLaunchKernelGGL(expand_sym_kernel<2>, dim3(H.E.nranges()), dim3(128), lds, st, X); break;
+            case 8: hipLaunchKernelGGL(expand_sym_kernel<8>, dim3(H.E.nranges()), dim3(512), lds, st, X); break;
+            default: hipLaunchKernelGGL(expand_sym_kernel<4>, dim3(H.E.nranges()), dim3(256), lds, st, X); break;
             }
             prof_mark(H, st, "expand_sym_kernel");
         }
         if (H.n_sym_combine > 0) {
-            CombineArgs C{H.sc_dst.d, H.sc_src.d, H.sc_stride.d, H.sc_count.d, H.SW.d, H.n_sym_combine};
-            hipLaunchKernelGGL(combine_kernel, dim3((H.n_sym_combine + 255) / 256), dim3(256), 0, st, C);
+            const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw;
+            if (nw > 0) {
+                CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW.d, nw};
+                hipLaunchKernelGGL(combine_list_wave_kernel, dim3((nw + 3) / 4), dim3(256), 0, st, C);
+            }
+            if (nt > 0) {
+                CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW.d, nt};
+                hipLaunchKernelGGL(combine_list_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, C);
+            }
             prof_mark(H, st, "combine_sym_kernel");
         }
-        if (ntasks > 0 && H.s_rowdst.n > 0) {
+        if (ntasks > 0 && H.s_kmax > 0) {
             RowReduceSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
-                               H.s_coef.d, H.s_task_rowbase.d, H.s_rowdst.d, H.SW.d, ntasks, H.symmetry_for_leaves == 'H' ? 1 : 0};
+                               H.s_coef.d, H.s_task_rowbase.d, H.SW.d, ntasks, H.symmetry_for_leaves == 'H' ? 1 : 0, H.s_lds_cols > 0 ? 1 : 0};
             hipLaunchKernelGGL(rowreduce_sym_kernel<1>, dim3(ntasks), dim3(64), 0, st, A);
             prof_mark(H, st, "rowreduce_sym_kernel");
         }
         if (H.s_kmax > 0) {
-            hipLaunchKernelGGL(sym_finish_kernel, dim3((H.nT + 255) / 256), dim3(256), 0, st, H.nT, alpha, (const scalar *)(H.SW.d + H.s_ybase), (const int32_t *)H.s_count.d, y);
+            hipLaunchKernelGGL(sym_finish_kernel, dim3((H.nT + 255) / 256), dim3(256), 0, st, H.nT, alpha, (const scalar *)H.SW.d, (const int32_t *)H.s_fidx.d, (const int32_t *)H.s_count.d, y);
             prof_mark(H, st, "sym_finish_kernel");
         }
     } else if (H.E.nranges() > 0) {
@@ -914,10 +971,12 @@ static int build_streams(HMat &H);
 static HMat *ensure_transposed_operator(HMat &H) {
     if (H.T_op)
         return H.T_op.get();
-    if (H.factors_released || H.T_op_failed || H.view_of || (H.has_mirror && !H.sym_expanded) || (getenv("HMX_TRANS_STREAMS") && !atoi(getenv("HMX_TRANS_STREAMS"))))
+    // (a fused symmetric owner is fine: the view lays the mirrored leaves out explicitly, see build_streams)
+    if (H.factors_released || H.T_op_failed || H.view_of || (H.has_mirror && !H.sym_expanded && !H.sym_fused) || (getenv("HMX_TRANS_STREAMS") && !atoi(getenv("HMX_TRANS_STREAMS"))))
         return nullptr;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 1.15 * (double)H.stats.stream_bytes) {
+    // a fused symmetric owner holds the stored triangle only, its transposed view the whole operator
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < (H.sym_fused ? 2.3 : 1.15) * (double)H.stats.stream_bytes) {
         H.T_op_failed = true; // not enough HBM for a second layout
         return nullptr;
     }

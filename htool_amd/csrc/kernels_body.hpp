@@ -1191,6 +1191,36 @@ __global__ void combine_kernel(CombineArgs A) {
     A.Z[A.dst[e]] = (s0 + s1) + (s2 + s3);
 }
 
+// the same for entries with many partial sums (a mirrored low-rank leaf of 15 625 rows has one per 64-row range): one wave per
+// entry, lane l adds the partial sums l, l + 64, ..., then a fixed all-reduce over the lanes -- reproducible, and 64 loads in flight
+__device__ __forceinline__ scalar wave_sum_dpp(scalar s) {
+    scalar a = s, b = s;
+    lane_swap32(a, b);
+    s = a + b;
+    a = s, b = s;
+    lane_swap16(a, b);
+    s = a + b;
+    s += dpp_move<0x128>(s);
+    s += dpp_move<0x141>(s);
+    s += dpp_move<0xB1>(s);
+    s += dpp_move<0x4E>(s);
+    return s;
+}
+__global__ __launch_bounds__(256) void combine_wave_kernel(CombineArgs A) {
+    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (e >= A.n)
+        return;
+    const int lane  = threadIdx.x & 63;
+    const scalar *p = A.Z + A.src[e];
+    const int st = A.stride[e], cnt = A.count[e];
+    scalar s = scalar(0);
+    for (int k = lane; k < cnt; k += 64)
+        s += p[(int64_t)k * st];
+    s = wave_sum_dpp(s);
+    if (lane == 0)
+        A.Z[A.dst[e]] = s;
+}
+
 // Stage 2 (dense leaves: add_matrix_vector_product.hpp:18; low rank: add_lrmat_vector_product.hpp:17,
 // y += U a; final alpha/beta as openmp_internal_add_hmatrix_vector_product :134-136,168):
 // one workgroup per target row range, lane = row, the waves split the columns in 64-column chunks.
@@ -1775,7 +1805,34 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
 // Eight wave-wide sums for the price of ~1.25: each butterfly step halves the number of live values while
 // halving the lane group that owns them.  On return lane l with (l & 7) == 0 holds the complete sum of input
 // value number 4*bit5(l) + 2*bit4(l) + bit3(l).
+// The lane exchanges are v_permlane32_swap / v_permlane16_swap / DPP row operations: no LDS traffic and none of ds_bpermute's
+// latency in the dependent chain (-DHMX_REDUCE8_DPP=0 restores the ds_bpermute butterfly for A/B runs).  After the three halving
+// steps the eight lanes of a group all-reduce with row_half_mirror (l <-> 7 - l) and the two quad permutations.
+#ifndef HMX_REDUCE8_DPP
+#define HMX_REDUCE8_DPP 1
+#endif
 __device__ __forceinline__ scalar reduce8(const scalar (&v)[8], int lane) {
+#if HMX_REDUCE8_DPP
+    scalar t[4], u[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        scalar a = v[k], b = v[k + 4];
+        lane_swap32(a, b);
+        t[k] = a + b;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        scalar a = t[k], b = t[k + 2];
+        lane_swap16(a, b);
+        u[k] = a + b;
+    }
+    const bool b3 = lane & 8;
+    scalar r = (b3 ? u[1] : u[0]) + dpp_move<0x128>(b3 ? u[0] : u[1]); // row_ror:8 = lane ^ 8 inside a row of 16
+    r += dpp_move<0x141>(r);                                           // row_half_mirror
+    r += dpp_move<0xB1>(r);                                            // quad_perm [1,0,3,2]
+    r += dpp_move<0x4E>(r);                                            // quad_perm [2,3,0,1]
+    return r;
+#else
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
     scalar t[4], u[2];
 #pragma unroll
@@ -1789,6 +1846,7 @@ __device__ __forceinline__ scalar reduce8(const scalar (&v)[8], int lane) {
     r += hmx_shfl_xor(r, 2);
     r += hmx_shfl_xor(r, 1);
     return r;
+#endif
 }
 __device__ __forceinline__ int reduce8_slot(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
 
@@ -1900,11 +1958,20 @@ struct ExpandSymArgs {
     scalar *W;
     const scalar *xrow;  // the input at the TARGET positions of this operator: xrow[range_off + i]
     int herm;            // 'H' storage: the mirrored leaf is the conjugate transpose
+    int lds_cols;        // > 0: the column sums of a range (at most this many columns) are staged in dynamic LDS and stored after the sweep
 };
+// The wave's columns are walked in groups of eight, flattened over its 64-column tiles and software-pipelined: the loads of
+// group g + 1 are issued before group g is reduced, so the dependent chain of the eight-way reduction never leaves the wave
+// without loads in flight.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
     const ExpandArgs &A = S.X;
     __shared__ scalar part[WAVES][WAVE];
+    // The column sums are not stored from inside the sweep: on gfx9 stores and loads share one in-order counter (vmcnt), so a
+    // wave that has a store in flight cannot consume ANY younger load before the store is acknowledged -- one exposed
+    // write latency per tile, 10-15 % of the kernel.  They are parked in LDS and written after the last load was consumed.
+    extern __shared__ __attribute__((aligned(16))) unsigned char sym_dyn_lds[];
+    scalar *colsum = reinterpret_cast<scalar *>(sym_dyn_lds);
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
@@ -1914,37 +1981,94 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
     const bool active   = lane < len;
     const int row       = active ? lane : 0;
     const scalar xr     = active ? S.xrow[A.range_off[R] + lane] : scalar(0); // idle lanes contribute exact zeros to the column sums
-    const int slot      = reduce8_slot(lane);
     const bool herm     = S.herm != 0;
+    const bool staged   = C <= S.lds_cols;
     scalar acc = scalar(0);
-    for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
-        const int nc   = (C - c0) < 64 ? (C - c0) : 64;
-        const scalar z = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
-        const int md   = lane < nc ? mdst[c0 + lane] : -1;
-        const bool mir = __any(md >= 0); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
-        const scalar *col = E + (int64_t)c0 * len + row;
-        for (int j = 0; j < nc; j += 8) {
-            scalar v[8];
+    // always eight loads, no branches (the compiler can then count them: s_waitcnt vmcnt(8) keeps the next group in flight while
+    // this one is used): beyond the last column of the range the last column is read again -- its products meet the zero
+    // coefficients of the lanes >= nc and its column sums are never stored
+    auto load_group = [&](scalar(&v)[8], int c0, int j) {
+        const int last    = C - c0 - j - 1; // >= 0
+        const scalar *col = E + (int64_t)(c0 + j) * len + row;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            v[u] = stream_load(col + (int64_t)(u < last ? u : last) * len);
+    };
+    auto advance = [&](int &c0, int &j) {
+        j += 8;
+        if (j >= 64 || c0 + j >= C) {
+            c0 += WAVES * 64;
+            j = 0;
+        }
+    };
+    scalar z = scalar(0), mine = scalar(0);
+    int md = -1, nc = 0, tile0 = 0;
+    bool mir = false;
+    auto tile_setup = [&](int c0) { // gathered coefficients and mirror slots of the (up to) 64 columns of a tile
+        tile0 = c0;
+        nc  = (C - c0) < 64 ? (C - c0) : 64;
+        z   = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
+        md  = lane < nc ? mdst[c0 + lane] : -1;
+        mir = __any(md >= 0); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
+    };
+    auto process = [&](const scalar(&v)[8], int j) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            acc = hmx_fma(v[u], readlane_val(z, (j + u) & 63), acc);
+        if (mir) {
+            scalar p[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                v[u] = (j + u < nc) ? stream_load(col + (int64_t)(j + u) * len) : scalar(0);
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                acc = hmx_fma(v[u], readlane_val(z, (j + u) & 63), acc);
-            if (mir) {
-                scalar p[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    p[u] = (herm ? hmx_conj(v[u]) : v[u]) * xr;
-                const scalar r = reduce8(p, lane);
-                const int d    = __shfl(md, (j + slot) & 63, WAVE);
-                if ((lane & 7) == 0 && j + slot < nc && d >= 0)
-                    S.W[d] = r;
+                p[u] = (herm ? hmx_conj(v[u]) : v[u]) * xr;
+            // every lane of lane group s = lane >> 3 now holds the sum of column j + s; lane 8 s + g keeps the one of group g = j / 8,
+            // so that after the tile's last group an 8 x 8 transposition of the lane index (one ds_bpermute) puts the sum of
+            // column c into lane c: ONE coalesced store per tile instead of eight 8-lane stores (which cost 10 % of the kernel)
+            const scalar r = reduce8(p, lane);
+            mine           = (lane & 7) == (j >> 3) ? r : mine;
+            if (j + 8 >= nc) {
+                const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
+                if (staged) {
+                    if (lane < nc)
+                        colsum[tile0 + lane] = t;
+                } else if (md >= 0)
+                    S.W[md] = t;
             }
         }
+    };
+    // order inside a step: (tile setup, its own dependent loads) -> prefetch of the next group -> arithmetic on the current
+    // one; the prefetch is unconditional (past the end it re-reads the current group) so that exactly eight newer loads are
+    // outstanding whenever a group is consumed
+    scalar va[8], vb[8];
+    int c0 = wv * 64, j = 0;
+    if (c0 < C)
+        load_group(va, c0, 0);
+    while (c0 < C) {
+        int n0 = c0, nj = j;
+        advance(n0, nj);
+        bool more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(vb, more ? n0 : c0, more ? nj : j);
+        process(va, j);
+        if (!more)
+            break;
+        c0 = n0, j = nj;
+        advance(n0, nj);
+        more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(va, more ? n0 : c0, more ? nj : j);
+        process(vb, j);
+        c0 = n0, j = nj;
     }
     part[wv][lane] = active ? acc : scalar(0);
     __syncthreads();
+    if (staged) // mirrored columns -> their slots (E-column order: one contiguous run per range)
+        for (int c = threadIdx.x; c < C; c += WAVES * WAVE) {
+            const int d = mdst[c];
+            if (d >= 0)
+                S.W[d] = colsum[c];
+        }
     if (wv == 0 && active) {
         scalar s = part[0][lane];
 #pragma unroll
@@ -1963,11 +2087,11 @@ struct RowReduceSymArgs {
     const int32_t *range_len, *range_cols, *range_cw;
     const int64_t *range_base, *range_colbase;
     const int32_t *coef;         // per R column: slot of a'[col] in W, -1: not a mirrored column
-    const int64_t *task_rowbase; // per task: first entry of its rows in row_dst, -1: no mirrored column in the chunk
-    const int32_t *row_dst;      // per (task, row): output-level slot in W
+    const int64_t *task_rowbase; // per task: first slot of its rows in W (its own contiguous, 128-byte aligned piece), -1: no mirrored column in the chunk
     scalar *W;
     int ntasks;
     int herm;
+    int stage; // != 0: row sums of pieces of at most 512 rows are staged in LDS and stored after the sweep
 };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSymArgs A) {
@@ -1997,29 +2121,60 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSym
         c1          = d >= 0 ? A.W[d] : scalar(0);
     }
     const bool herm = A.herm != 0;
-    const int slot  = reduce8_slot(lane);
-    const int32_t *dst = A.row_dst + rb;
-    for (int i0 = 0; i0 < len; i0 += 8) {
-        scalar2 e[8];
+    scalar mine     = scalar(0);
+    scalar *dst     = A.W + rb;
+    __shared__ scalar rowsum[WAVES][512];
+    const int wv      = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool staged = A.stage && len <= 512;
+    // eight rows per reduction, the next eight already in flight (same pipelining as expand_sym_kernel)
+    // always eight loads, no branches: rows beyond the piece re-read its last row (their sums are never stored), lanes beyond
+    // the chunk read column 0 and multiply it with their zero coefficients
+    auto load_rows = [&](scalar2(&e)[8], int i0) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            e[u].x = scalar(0);
-            e[u].y = scalar(0);
-            if (active && i0 + u < len)
-                e[u] = load_pair(src + (int64_t)(i0 + u) * wp, col0, col1, wp);
+            const int i = i0 + u < len ? i0 + u : len - 1;
+            e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
         }
+    };
+    auto process = [&](const scalar2(&e)[8], int i0) {
         scalar v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++)
             v[u] = herm ? hmx_fma(hmx_conj(e[u].x), c0, hmx_conj(e[u].y) * c1) : hmx_fma(e[u].x, c0, e[u].y * c1);
+        // as in expand_sym_kernel: lane 8 s + g keeps the sum of row 64 b + 8 g + s, one transposing ds_bpermute and ONE coalesced
+        // store per 64 rows
         const scalar r = reduce8(v, lane);
-        if ((lane & 7) == 0 && i0 + slot < len)
-            A.W[dst[i0 + slot]] = r;
+        const int g    = (i0 >> 3) & 7;
+        mine           = (lane & 7) == g ? r : mine;
+        if (g == 7 || i0 + 8 >= len) {
+            const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
+            const int i    = (i0 & ~63) + lane;
+            if (i < len) {
+                if (staged)
+                    rowsum[wv][i] = t; // stored after the sweep (see expand_sym_kernel)
+                else
+                    dst[i] = t;
+            }
+        }
+    };
+    scalar2 ea[8], eb[8];
+    load_rows(ea, 0);
+    for (int i0 = 0; i0 < len; i0 += 16) { // unconditional prefetches (clamped to the last row): exactly eight newer loads outstanding at every use
+        load_rows(eb, i0 + 8);
+        process(ea, i0);
+        load_rows(ea, i0 + 16);
+        if (i0 + 8 < len)
+            process(eb, i0 + 8);
     }
+    if (staged)
+        for (int i = lane; i < len; i += 64)
+            dst[i] = rowsum[wv][i];
 }
 
-// y[j] += alpha * (level 0 + level 1 + ...): the mirrored contributions of output row j in their fixed layout order
-__global__ void sym_finish_kernel(int n, scalar alpha, const scalar *levels, const int32_t *count, scalar *y) {
+// y[j] += alpha * (contribution 0 + contribution 1 + ...): the mirrored contributions of output row j in their fixed layout order;
+// fidx is level-major (contribution k of row j at k * n + j), so the index loads are coalesced and neighbouring rows mostly read
+// neighbouring slots
+__global__ void sym_finish_kernel(int n, scalar alpha, const scalar *W, const int32_t *fidx, const int32_t *count, scalar *y) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n)
         return;
@@ -2028,8 +2183,41 @@ __global__ void sym_finish_kernel(int n, scalar alpha, const scalar *levels, con
         return;
     scalar s = scalar(0);
     for (int k = 0; k < cnt; k++)
-        s += levels[(int64_t)k * n + j];
+        s += W[fidx[(int64_t)k * n + j]];
     y[j] += alpha * s;
+}
+
+// a'[dst] = sum_i W[list[lp + i] + k]: the partial column sums of a mirrored low-rank leaf that spans several row ranges, one list
+// entry (position of the leaf's column group in EW) per range
+struct CombineListArgs {
+    const int32_t *dst, *lp, *count, *k, *list;
+    scalar *W;
+    int n;
+};
+__global__ void combine_list_kernel(CombineListArgs A) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n)
+        return;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    scalar s = scalar(0);
+    for (int i = 0; i < cnt; i++)
+        s += A.W[l[i] + k];
+    A.W[A.dst[e]] = s;
+}
+__global__ __launch_bounds__(256) void combine_list_wave_kernel(CombineListArgs A) {
+    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (e >= A.n)
+        return;
+    const int lane   = threadIdx.x & 63;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    scalar s = scalar(0);
+    for (int i = lane; i < cnt; i += 64)
+        s += A.W[l[i] + k];
+    s = wave_sum_dpp(s);
+    if (lane == 0)
+        A.W[A.dst[e]] = s;
 }
 
 // small helpers -----------------------------------------------------------------------------------

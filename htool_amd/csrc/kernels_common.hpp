@@ -138,6 +138,52 @@ __device__ __forceinline__ double readlane_val(double v, int lane) {
 __device__ __forceinline__ float readlane_val(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 template <typename T> __device__ __forceinline__ cplx<T> readlane_val(cplx<T> v, int lane) { return cplx<T>(readlane_val(v.re, lane), readlane_val(v.im, lane)); }
 
+// ---- cross-lane moves without LDS (gfx950): DPP row operations and v_permlane{16,32}_swap, applied to every 32-bit word of a value
+template <int CTRL, typename T>
+__device__ __forceinline__ T dpp_move(T v) { // CTRL: DPP control (0x00-0xFF quad_perm, 0x121-0x12F row_ror, 0x140 row_mirror, 0x141 row_half_mirror)
+    constexpr int N = sizeof(T) / 4;
+    int w[N];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        w[i] = __builtin_amdgcn_update_dpp(0, w[i], CTRL, 0xf, 0xf, false);
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
+// a: lanes 32..63 <-> b: lanes 0..31 (v_permlane32_swap); afterwards a + b is, in lanes 0..31, the sum over the lane pair
+// (l, l + 32) of the OLD a, and in lanes 32..63 the pair sum of the OLD b
+template <typename T>
+__device__ __forceinline__ void lane_swap32(T &a, T &b) {
+    constexpr int N = sizeof(T) / 4;
+    int wa[N], wb[N];
+    __builtin_memcpy(wa, &a, sizeof(T));
+    __builtin_memcpy(wb, &b, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const auto r = __builtin_amdgcn_permlane32_swap(wa[i], wb[i], false, false);
+        wa[i]        = r[0];
+        wb[i]        = r[1];
+    }
+    __builtin_memcpy(&a, wa, sizeof(T));
+    __builtin_memcpy(&b, wb, sizeof(T));
+}
+// a: odd rows of 16 lanes <-> b: even rows (v_permlane16_swap): a + b is the pair sum (l, l ^ 16) of the old a in even rows, of the old b in odd rows
+template <typename T>
+__device__ __forceinline__ void lane_swap16(T &a, T &b) {
+    constexpr int N = sizeof(T) / 4;
+    int wa[N], wb[N];
+    __builtin_memcpy(wa, &a, sizeof(T));
+    __builtin_memcpy(wb, &b, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const auto r = __builtin_amdgcn_permlane16_swap(wa[i], wb[i], false, false);
+        wa[i]        = r[0];
+        wb[i]        = r[1];
+    }
+    __builtin_memcpy(&a, wa, sizeof(T));
+    __builtin_memcpy(&b, wb, sizeof(T));
+}
+
 // Every coefficient is read exactly once per product, so the stream loads are marked non-temporal: they do
 // not displace x / Z / index lines from L2 and the Infinity Cache.  Measured at N=1e6 (fp64): expand 1.88 -> 1.74 ms,
 // reduce 1.23-1.33 -> 1.20 ms, and the run-to-run bimodality disappears.  -DHMX_NT=0 disables.
