@@ -45,7 +45,6 @@ struct HMat {
     DArr<int32_t> sc_dst, sc_lp, sc_count, sc_k;
     int n_sym_combine = 0, n_sym_combine_wave = 0; // the first n_sym_combine_wave entries have >= 32 partial sums: one wave each
     int s_kmax        = 0;
-    int s_lds_cols    = 0; // expand_sym_kernel stages the column sums of ranges with at most this many columns in LDS
     DArr<scalar> SW;
     std::vector<int64_t> staged_off;
     std::vector<int32_t> perm_t, perm_s; // full permutations (cluster -> user)
@@ -539,14 +538,6 @@ static int build_streams(HMat &H) {
                 s_fidx[(size_t)(fill[j0 + i]++) * H.nT + (j0 + i)] = (int32_t)(s_rowbase[t] + i);
         }
         H.n_sym_combine = (int)s_cd.size();
-        // LDS staging of the column sums: sized for the widest range, capped at 16 KiB per workgroup so that occupancy stays
-        // bound by registers (wider ranges store their sums directly)
-        int maxc = 0;
-        for (int r = 0; r < E.nranges(); r++)
-            maxc = std::max(maxc, (int)E.cols[r]);
-        H.s_lds_cols = std::min(maxc, (int)(16384 / sizeof(scalar)));
-        if (getenv("HMX_SYM_NO_LDS") && atoi(getenv("HMX_SYM_NO_LDS")))
-            H.s_lds_cols = 0;
         phase("fused symmetric slots");
     }
 
@@ -762,8 +753,8 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         // folded, the R-streams are swept a second time (y_s += V^T a') and the output levels are added in their fixed order
         if (H.E.nranges() > 0) {
             ExpandSymArgs X{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx},
-                            H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0, H.s_lds_cols};
-            const size_t lds = (size_t)H.s_lds_cols * sizeof(scalar);
+                            H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0};
+            const size_t lds = 0;
             switch (EW) {
             case 1: hipLaunchKernelGGL(expand_sym_kernel<1>, dim3(H.E.nranges()), dim3(64), lds, st, X); break;
             case 2: hipLaunchKernelGGL(expand_sym_kernel<2>, dim3(H.E.nranges()), dim3(128), lds, st, X); break;
@@ -786,7 +777,7 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         }
         if (ntasks > 0 && H.s_kmax > 0) {
             RowReduceSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
-                               H.s_coef.d, H.s_task_rowbase.d, H.SW.d, ntasks, H.symmetry_for_leaves == 'H' ? 1 : 0, H.s_lds_cols > 0 ? 1 : 0};
+                               H.s_coef.d, H.s_task_rowbase.d, H.SW.d, ntasks, H.symmetry_for_leaves == 'H' ? 1 : 0};
             hipLaunchKernelGGL(rowreduce_sym_kernel<1>, dim3(ntasks), dim3(64), 0, st, A);
             prof_mark(H, st, "rowreduce_sym_kernel");
         }

@@ -1958,7 +1958,6 @@ struct ExpandSymArgs {
     scalar *W;
     const scalar *xrow;  // the input at the TARGET positions of this operator: xrow[range_off + i]
     int herm;            // 'H' storage: the mirrored leaf is the conjugate transpose
-    int lds_cols;        // > 0: the column sums of a range (at most this many columns) are staged in dynamic LDS and stored after the sweep
 };
 // The wave's columns are walked in groups of eight, flattened over its 64-column tiles and software-pipelined: the loads of
 // group g + 1 are issued before group g is reduced, so the dependent chain of the eight-way reduction never leaves the wave
@@ -1967,11 +1966,6 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
     const ExpandArgs &A = S.X;
     __shared__ scalar part[WAVES][WAVE];
-    // The column sums are not stored from inside the sweep: on gfx9 stores and loads share one in-order counter (vmcnt), so a
-    // wave that has a store in flight cannot consume ANY younger load before the store is acknowledged -- one exposed
-    // write latency per tile, 10-15 % of the kernel.  They are parked in LDS and written after the last load was consumed.
-    extern __shared__ __attribute__((aligned(16))) unsigned char sym_dyn_lds[];
-    scalar *colsum = reinterpret_cast<scalar *>(sym_dyn_lds);
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
@@ -1982,7 +1976,6 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
     const int row       = active ? lane : 0;
     const scalar xr     = active ? S.xrow[A.range_off[R] + lane] : scalar(0); // idle lanes contribute exact zeros to the column sums
     const bool herm     = S.herm != 0;
-    const bool staged   = C <= S.lds_cols;
     scalar acc = scalar(0);
     // always eight loads, no branches (the compiler can then count them: s_waitcnt vmcnt(8) keeps the next group in flight while
     // this one is used): beyond the last column of the range the last column is read again -- its products meet the zero
@@ -2002,10 +1995,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
         }
     };
     scalar z = scalar(0), mine = scalar(0);
-    int md = -1, nc = 0, tile0 = 0;
+    int md = -1, nc = 0;
     bool mir = false;
     auto tile_setup = [&](int c0) { // gathered coefficients and mirror slots of the (up to) 64 columns of a tile
-        tile0 = c0;
         nc  = (C - c0) < 64 ? (C - c0) : 64;
         z   = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
         md  = lane < nc ? mdst[c0 + lane] : -1;
@@ -2022,15 +2014,14 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
                 p[u] = (herm ? hmx_conj(v[u]) : v[u]) * xr;
             // every lane of lane group s = lane >> 3 now holds the sum of column j + s; lane 8 s + g keeps the one of group g = j / 8,
             // so that after the tile's last group an 8 x 8 transposition of the lane index (one ds_bpermute) puts the sum of
-            // column c into lane c: ONE coalesced store per tile instead of eight 8-lane stores (which cost 10 % of the kernel)
+            // column c into lane c: ONE coalesced store per tile instead of eight 8-lane stores.  (What the stores cost is the write
+            // stream itself: on MI355X 1.6 % of written bytes takes 15-30 % off a streaming read, tools/read_write_mix.hip; staging
+            // the sums in LDS until the end of the workgroup, 128-byte aligned runs or non-temporal stores change nothing.)
             const scalar r = reduce8(p, lane);
             mine           = (lane & 7) == (j >> 3) ? r : mine;
             if (j + 8 >= nc) {
                 const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
-                if (staged) {
-                    if (lane < nc)
-                        colsum[tile0 + lane] = t;
-                } else if (md >= 0)
+                if (md >= 0)
                     S.W[md] = t;
             }
         }
@@ -2063,12 +2054,6 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
     }
     part[wv][lane] = active ? acc : scalar(0);
     __syncthreads();
-    if (staged) // mirrored columns -> their slots (E-column order: one contiguous run per range)
-        for (int c = threadIdx.x; c < C; c += WAVES * WAVE) {
-            const int d = mdst[c];
-            if (d >= 0)
-                S.W[d] = colsum[c];
-        }
     if (wv == 0 && active) {
         scalar s = part[0][lane];
 #pragma unroll
@@ -2091,7 +2076,6 @@ struct RowReduceSymArgs {
     scalar *W;
     int ntasks;
     int herm;
-    int stage; // != 0: row sums of pieces of at most 512 rows are staged in LDS and stored after the sweep
 };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSymArgs A) {
@@ -2123,9 +2107,6 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSym
     const bool herm = A.herm != 0;
     scalar mine     = scalar(0);
     scalar *dst     = A.W + rb;
-    __shared__ scalar rowsum[WAVES][512];
-    const int wv      = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool staged = A.stage && len <= 512;
     // eight rows per reduction, the next eight already in flight (same pipelining as expand_sym_kernel)
     // always eight loads, no branches: rows beyond the piece re-read its last row (their sums are never stored), lanes beyond
     // the chunk read column 0 and multiply it with their zero coefficients
@@ -2149,12 +2130,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSym
         if (g == 7 || i0 + 8 >= len) {
             const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
             const int i    = (i0 & ~63) + lane;
-            if (i < len) {
-                if (staged)
-                    rowsum[wv][i] = t; // stored after the sweep (see expand_sym_kernel)
-                else
-                    dst[i] = t;
-            }
+            if (i < len)
+                dst[i] = t;
         }
     };
     scalar2 ea[8], eb[8];
@@ -2166,9 +2143,6 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSym
         if (i0 + 8 < len)
             process(eb, i0 + 8);
     }
-    if (staged)
-        for (int i = lane; i < len; i += 64)
-            dst[i] = rowsum[wv][i];
 }
 
 // y[j] += alpha * (contribution 0 + contribution 1 + ...): the mirrored contributions of output row j in their fixed layout order;
