@@ -11,6 +11,13 @@ vector already resident in HBM in cluster ("partition") numbering:
 value = algorithmic bytes of the whole job / step time, B_alg = 8 * [C_gen + (N_source + N_target)] per rank
 (C_gen = htool's number_of_generated_coefficient), summed over ranks, max time over ranks.
 
+Launch: `python bench.py --gpus N` under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment, as the driver
+does), or bare -- then bench.py starts its N ranks itself (fresh child processes, before anything touches the GPU).  --gpus must
+equal WORLD_SIZE: a mismatch is an error, never a silent 1-GPU run.
+N > 1 runs the step through libhmx's C-level DistributedOperator (hmx_dist_*: one C call per product, RCCL communicator of its
+own, optional overlap of the output exchange with the expand stage on a side stream -- both variants are timed in the warm-up
+phase and reported, the faster one is the timed region); --dist-impl python selects the torch.distributed layer instead.
+
 One JSON line on rank 0 (contract in the task description) with two extra objects:
   roofline     : dominant kernel (expand_kernel) algorithmic bytes per launch / its average duration measured
                  with HIP events on the launch stream, against the 8 TB/s HBM3E peak.
@@ -50,7 +57,51 @@ def parse():
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--mu", type=int, default=1, help="number of right-hand sides (row-major multi-RHS product when > 1)")
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
+    ap.add_argument("--dist-impl", default=os.environ.get("HMX_BENCH_DIST_IMPL", "native"), choices=["native", "python"],
+                    help="N > 1: hmx_dist_* through one C call per step (native) or the torch.distributed layer (python)")
+    ap.add_argument("--no-reference", action="store_true", help="skip the timing of htool itself (oracle/_ref/ref_driver) on the host cores")
     return ap.parse_args()
+
+
+def spawn_ranks_if_needed(args):
+    """`--gpus N` without a launcher: start the N ranks here, as fresh children, BEFORE anything initialises the GPU in this process
+    (a process that touched the GPU must not start the others).  With a launcher, --gpus must match WORLD_SIZE."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            print("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d "
+                  "bench.py --gpus %d ...) or drop the launcher and let bench.py start its ranks" % (args.gpus, ws, args.gpus, args.gpus), file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+def kernel_sources_hash():
+    """sha256 over the device sources: profiles/traffic.json records it, a PMC measurement of an older binary is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels_common.hpp", "kernels_body.hpp", "engine_body.hpp", "engine.hip"):
+        with open(os.path.join(ROOT, "htool_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def minimal_depth(n):
@@ -102,37 +153,60 @@ def cpu_baseline(H, T, frac, log):
                        "openmp leaf loop, best of 4" % (cut, len(sel), pos * 8 / 1e9)), y, cut
 
 
-def reference_baseline(log):
-    """htool ITSELF (oracle/_ref/ref_driver: the real headers + the image's MKL, OpenMP policy) timed on this box's
-    host cores on configs[1] (N=1e5, same geometry / kernel / eps / eta / leaf size).  Only runs where the binary
-    built in the dev container travelled with the repo; never touches /root/reference at run time."""
+def reference_baseline(log, n, geom, eps, eta, leaf, depth):
+    """htool ITSELF (oracle/_ref/ref_driver: the real headers + the image's MKL, OpenMP policy: openmp_build +
+    openmp_internal_add_hmatrix_vector_product) timed on this box's host cores on THE SAME configuration as the GPU run (geometry,
+    N, kernel, eps, eta, leaf size, minimal block depth).  Time-boxed (HMX_BENCH_REF_TIMEOUT seconds, default 240: the N=1e6 build
+    takes 150 s on 8 cores, ~20 s on 64); when the box is too slow for that the N=1e5 operator (configs[1]) is timed instead and the
+    sample says so.  Only runs where the binary built in the dev container travelled with the repo; never touches /root/reference."""
     import re
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if not os.path.exists(exe):
         return None
+    budget = float(os.environ.get("HMX_BENCH_REF_TIMEOUT", 240))
+    ncpu = os.cpu_count() or 1
+
+    def run(nn, dd, threads, reps, timeout):
+        t0 = time.time()
+        out = subprocess.run([exe, "hmat", "n=%d" % nn, "geom=%s" % geom, "eps=%g" % eps, "eta=%g" % eta, "leaf=%d" % leaf, "mindepth=%d" % dd,
+                              "compressor=partialACA", "par=1", "time_reps=%d" % reps, "dump_blocks=0", "out=/dev/null"], capture_output=True, text=True,
+                             timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        m = re.search(r"cgen=(\d+)\+(\d+).*tree=([0-9.]+)s build=([0-9.]+)s matvec=([0-9.]+)s", out.stdout)
+        if not m:
+            log("reference driver produced no timing: %s" % (out.stdout[-200:] + out.stderr[-200:]))
+            return None
+        log("reference (htool, OpenMP, %d threads) N=%d: tree %.1fs build %.2fs matvec %.4fs (%.1fs wall)" % (threads, nn, float(m.group(3)), float(m.group(4)), float(m.group(5)), time.time() - t0))
+        return dict(cgen=int(m.group(1)) + int(m.group(2)), build_s=float(m.group(4)), matvec_s=float(m.group(5)), threads=threads)
+
     try:
-        best = None
-        for threads in (16, 64, os.cpu_count()):  # the reference's per-thread temporaries make "all cores" a poor choice
-            t0 = time.time()
-            out = subprocess.run([exe, "hmat", "n=100000", "geom=ellipse", "eps=1e-4", "eta=10", "leaf=100", "compressor=partialACA", "par=1",
-                                  "time_reps=10", "dump_blocks=0", "out=/dev/null"], capture_output=True, text=True, timeout=240,
-                                 env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
-            m = re.search(r"cgen=(\d+)\+(\d+).*build=([0-9.]+)s matvec=([0-9.]+)s", out.stdout)
-            if not m:
-                log("reference driver produced no timing: %s" % (out.stdout[-200:] + out.stderr[-200:]))
-                continue
-            cgen = int(m.group(1)) + int(m.group(2))
-            t_mv = float(m.group(4))
-            log("reference (htool, OpenMP, %d threads) N=1e5: build %.2fs matvec %.4fs (%.1fs wall)" % (threads, float(m.group(3)), t_mv, time.time() - t0))
-            if best is None or t_mv < best[1]:
-                best = (threads, t_mv, float(m.group(3)), cgen)
+        best, size = None, n
+        t_start = time.time()
+        # the reference's per-thread temporaries make "all cores" a poor choice for the product: 64 threads first, then 16 if time is left
+        for threads in [t for t in (64, 16) if t <= ncpu] or [ncpu]:
+            left = budget - (time.time() - t_start)
+            if left < (30 if best else 5):
+                break
+            try:
+                r = run(n, depth, threads, 5, left)
+            except subprocess.TimeoutExpired:
+                log("reference at N=%d did not finish in the time box (%d threads)" % (n, threads))
+                break
+            if r and (best is None or r["matvec_s"] < best["matvec_s"]):
+                best = r
+        if best is None and n > 100000:  # fall back to configs[1]
+            size = 100000
+            for threads in [t for t in (64, 16) if t <= ncpu] or [ncpu]:
+                r = run(size, 0, threads, 10, 120)
+                if r and (best is None or r["matvec_s"] < best["matvec_s"]):
+                    best = r
         if best is None:
             return None
-        threads, t_mv, t_build, cgen = best
-        return dict(value=8.0 * (cgen + 2e5) / t_mv / 1e9, unit="GB/s", cores=threads, kind="reference",
-                    sample="htool itself (openmp_internal_add_hmatrix_vector_product, MKL sequential BLAS), N=1e5 ellipse eps=1e-4 (configs[1]), "
-                           "best of 10 repetitions and of 16/64/all threads", build_s=t_build, matvec_s=t_mv)
+        return dict(value=8.0 * (best["cgen"] + 2.0 * size) / best["matvec_s"] / 1e9, unit="GB/s", cores=best["threads"], kind="reference",
+                    sample="htool itself (openmp_internal_add_hmatrix_vector_product, MKL sequential BLAS) on the %s: N=%d %s, eps=%g, eta=%g, leaf %d, "
+                           "min block depth %d; best of 5 products" % ("same configuration" if size == n else "configs[1] operator (the N=%d build did not fit the time box)" % n,
+                                                                        size, geom, eps, eta, leaf, depth if size == n else 0),
+                    build_s=best["build_s"], matvec_s=best["matvec_s"], n=size)
     except Exception as e:
         log("reference driver failed: %r" % (e,))
         return None
@@ -140,6 +214,7 @@ def reference_baseline(log):
 
 def main():
     args = parse()
+    spawn_ranks_if_needed(args)
     # RCCL / HIP runtime banners go to the C-level stdout; keep fd 1 clean for the single JSON line
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -226,6 +301,24 @@ def main():
         Xmu = torch.from_numpy(np.random.default_rng(2).random((n, mu)).astype(np_dt)).to(dev)
         Ymu = torch.zeros((H.nb_rows(), mu), dtype=t_dt, device=dev)
 
+    # N > 1, single vector: the C-level DistributedOperator (one C call per step, its own RCCL communicator).  Every rank must take
+    # the same path: the outcome of the set-up is agreed on over the process group before anything is timed.
+    native, dist_info = None, dict(impl="python (torch.distributed)")
+    if part and mu == 1 and args.trans == "N" and args.dist_impl == "native":
+        ok = 1
+        try:
+            comm = D.NativeCommunicator(backend="gloo" if os.environ.get("HMX_BENCH_BACKEND", "nccl") != "nccl" else "rccl")
+            native = D.NativeDistributedOperator(H, T, T, comm)
+        except Exception as e:  # noqa: BLE001 -- any failure means: use the torch.distributed layer
+            print("[bench] rank %d: native distributed operator unavailable (%r)" % (rank, e), file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            native = None
+        else:
+            dist_info = dict(impl="native (hmx_dist_*, one C call per step)", rccl_ranks=world, communicator=comm.backend)
+
     if mu > 1 and part:
         Yg = torch.zeros((n, mu), dtype=t_dt, device=dev)  # every rank receives the whole result (global-to-global contract)
 
@@ -234,6 +327,8 @@ def main():
             D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, Yg, mu)
         elif mu > 1:
             hm.internal_add_hmatrix_matrix_product_row_major(args.trans, 1.0, H, Xmu, 0.0, Ymu, mu)
+        elif native is not None:
+            native.matvec_global_to_global("N", 1.0, xin, 0.0, y)
         elif part:
             D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y)
         else:
@@ -252,7 +347,48 @@ def main():
     # of a step are captured once in a HIP graph (htool_amd.distributed.GraphedGlobalToGlobalProduct); the RCCL all-gather
     # is issued eagerly after each replay, so no graph ever holds a collective.  HMX_BENCH_NO_GRAPH=1: eager launches.
     graphed = False
-    if part and mu == 1 and args.trans == "N" and not os.environ.get("HMX_BENCH_NO_GRAPH"):
+    if native is not None:
+        # untimed: the result must equal the torch.distributed layer's, then the variants of the output exchange are tried for a few
+        # steps each -- one exchange after the product, or the expand stage in 2 / 4 row chunks with every chunk's exchange on a side
+        # stream under the next chunk's kernel (HMX_DIST_OVERLAP=<chunks> pins the choice) -- and the fastest becomes the timed region
+        y_ref = torch.zeros_like(y)
+        D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y_ref)
+        y.zero_()
+        step()
+        torch.cuda.synchronize()
+        good = torch.tensor([1 if torch.equal(y, y_ref) else 0], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        if int(good.item()) == 0:
+            log("native distributed product differs from the torch.distributed layer: falling back")
+            native, dist_info = None, dict(impl="python (torch.distributed); native result mismatch")
+        else:
+            pinned = os.environ.get("HMX_DIST_OVERLAP")
+            trials = {}
+            for chunks in ([int(pinned)] if pinned is not None else [0, 2, 4]):
+                used = native.set_overlap(chunks, like=y)
+                if chunks > 1 and used != chunks:
+                    continue  # some rank's operator cannot be chunked
+                y.zero_()
+                step()
+                torch.cuda.synchronize()
+                same = torch.tensor([1 if torch.equal(y, y_ref) else 0], device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                if int(same.item()) == 0:
+                    log("overlap with %d chunks does not reproduce the result: skipped" % chunks)
+                    continue
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                fence()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                trials[chunks] = float(tt.item()) / 10 * 1e3
+            best = min(trials, key=trials.get)
+            native.set_overlap(best, like=y)
+            dist_info.update(overlap_chunks=best, overlap_trials_ms={str(k): v for k, v in trials.items()})
+            log("output exchange variants (ms per step, 0 = one exchange after the product): %s -> %d" % (trials, best))
+    if native is None and part and mu == 1 and args.trans == "N" and not os.environ.get("HMX_BENCH_NO_GRAPH"):
         eager_step = step
         eager_step()
         torch.cuda.synchronize()
@@ -304,10 +440,17 @@ def main():
     red_name = next((k for k in kern_ms if k.startswith("reduce")), "reduce_kernel")
     exp_ms = kern_ms.get(exp_name, float("nan"))
     achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: measured separately with rocprofv3 --pmc and stored with the sha256 of the kernel
+    # sources it was measured on -- a number collected on other kernels is not reported
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")  # measured separately with rocprofv3 --pmc
-    if os.path.exists(tf) and world == 1 and n == 1000000 and args.geom == "ellipse" and args.sym == "N" and args.trans == "N" and mu == 1 and not emu and not use_dist and args.dtype == "f64":
-        traffic = json.load(open(tf)).get("expand_kernel_hbm_bytes_per_launch")
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf) and world == 1 and n == 1000000 and args.geom == "ellipse" and args.trans == "N" and mu == 1 and not emu and not use_dist and args.dtype == "f64":
+        rec = json.load(open(tf))
+        key = "expand_kernel_hbm_bytes_per_launch" if args.sym == "N" else "expand_sym_kernel_hbm_bytes_per_launch"
+        if rec.get("kernel_sources_sha256") == kernel_sources_hash():
+            traffic = rec.get(key)
+        else:
+            log("profiles/traffic.json was measured on other kernel sources (hash differs): roofline.traffic = null")
     roofline = dict(bound="hbm", kernel=exp_name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
                     traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
                     kernels_ms=kern_ms, reduce_kernel_GBps=red_bytes / (kern_ms.get(red_name, float("nan")) * 1e-3) / 1e9)
@@ -323,14 +466,54 @@ def main():
     roofline["measured_read_GBps"] = rbw.value
     roofline["frac_of_measured_read"] = achieved / rbw.value if rbw.value > 0 else None
 
+    # per rank: kernel time of the local product (HIP events), its algorithmic bytes; what the step adds on top is the exposed exchange
+    if use_dist:
+        mine = torch.tensor([sum(kern_ms.values()), esz * (st["cgen_dense"] + st["cgen_lowrank"] + n + H.nb_rows()) / 1e9], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dist_info.update(per_rank_local_ms=[float(t[0]) for t in allr], per_rank_GB=[float(t[1]) for t in allr],
+                         exposed_exchange_ms=ms_per_step - max(float(t[0]) for t in allr))
+    # user numbering (permutations on the device) and host vectors (two PCIe copies per product): reported, never `value`
+    extras = {}
+    if not use_dist and mu == 1 and args.trans == "N" and not emu:
+        try:
+            xu, yu = xin.clone(), torch.zeros(n, dtype=t_dt, device=dev)
+            for _ in range(3):
+                hm.add_hmatrix_vector_product("N", 1.0, H, xu, 0.0, yu)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                hm.add_hmatrix_vector_product("N", 1.0, H, xu, 0.0, yu)
+            torch.cuda.synchronize()
+            extras["user_numbering_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+            xh, yh = xin.cpu().numpy(), np.zeros(n, dtype=np_dt)
+            for _ in range(2):
+                hm.internal_add_hmatrix_vector_product("N", 1.0, H, xh, 0.0, yh)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                hm.internal_add_hmatrix_vector_product("N", 1.0, H, xh, 0.0, yh)
+            extras["host_vectors_pcie_inclusive_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        except Exception as e:  # noqa: BLE001
+            extras["error"] = repr(e)
+    # compression as throughput (entries/s, not roofline): kernel entries the ACA evaluated per second of ACA kernel time,
+    # dense entries per second of packing kernels; the rest of the device build is host layout work + allocations
+    t_aca, t_packk = st["t_compress_s"], st.get("t_assemble_s", 0.0)
+    compress = dict(cross_entries_per_s=(st["cgen_lowrank"] / t_aca) if t_aca > 0 else None,
+                    dense_entries_per_s=(st["cgen_dense"] / t_packk) if t_packk > 0 else None,
+                    aca_kernels_s=t_aca, pack_kernels_s=t_packk, host_and_alloc_s=max(0.0, t_build - t_aca - t_packk), device_total_s=t_build)
+
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(mu=mu, sym=args.sym, trans=args.trans, recompressed=bool(args.recompress), workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, {"f64": "fp64", "f32": "fp32", "z64": "complex fp64", "c32": "complex fp32"}[args.dtype], args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
-                           parallelism=("row-partition x%d + all-gather%s" % (world, ", local kernels replayed from a HIP graph" if graphed else "")) if part else "single GPU",
+                           parallelism=("row-partition x%d + all-gather%s" % (world, ", local kernels replayed from a HIP graph" if graphed else (", hmx_dist_* (C)" if native is not None else ""))) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
                            build_s=dict(cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
-               roofline=roofline)
+               roofline=roofline, compress=compress)
+    if use_dist:
+        out["dist"] = dist_info
+    if extras:
+        out["other_entry_points"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
         try:
             cb, y_cpu, cut = cpu_baseline(H, T, args.cpu_sample_frac, log)
@@ -341,9 +524,11 @@ def main():
             err = float(np.linalg.norm(yh[:cut].cpu().numpy() - y_cpu) / np.linalg.norm(y_cpu))
             cb["rel_err_engine_vs_cpu_on_sample"] = err
             out["cpu_baseline"] = cb
-            ref = reference_baseline(log)
+            # htool itself on the same configuration: the `cpu_baseline` of kind "reference" when its binary is here; the port stays next to it
+            ref = None if args.no_reference or args.sym != "N" else reference_baseline(log, n, args.geom, args.eps, args.eta, args.leaf, d)
             if ref is not None:
-                out["cpu_reference_htool"] = ref
+                out["cpu_baseline_port"] = cb
+                out["cpu_baseline"] = ref
         except Exception as e:  # the baseline is a reported number, never the product path
             out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
     if rank == 0:

@@ -123,6 +123,9 @@ SYMBOLS = [
     ("hmx_dist_destroy", None, [_vp]),
     ("hmx_dist_matvec_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matvec_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
+    ("hmx_dist_set_overlap", C.c_int, [_vp, C.c_int, _vp]),
+    ("hmx_dist_overlap_chunks", C.c_int, [_vp]),
+    ("hmx_dist_set_reduce_scatter", C.c_int, [_vp, _vp]),
     ("hmx_hmatrix_last_kernel_times", C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     ("hmx_hmatrix_set_profiling", C.c_int, [_vp, C.c_int]),
     ("hmx_device_trim_cache", C.c_int, []),

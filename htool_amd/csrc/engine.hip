@@ -673,8 +673,26 @@ struct hmx_dist {
     int reals  = 1;     // real numbers per coefficient (2 for complex)
     DArr<char> work, work2;
     bool force = false; // HMX_DIST_FORCE_COLLECTIVES=1: call RCCL even with one rank (tests)
+    int (*reduce_scatter)(const void *, void *, size_t, int, int, void *, void *) = nullptr; // ncclReduceScatter, when available
+    // overlap of the output exchange with the expand stage (hmx_dist_set_overlap): row chunks, side stream, one event per chunk
+    int overlap = 0;                  // requested number of chunks (0 / 1: off)
+    int nchunks = 0;                  // chunks in use (the same on every rank)
+    std::vector<int32_t> bounds;      // [rank][chunk]: first local row of chunk c on rank k; (nchunks + 1) entries per rank
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> chunk_ev;
+    hipEvent_t join_ev = nullptr;
+    hipStream_t cur_stream = nullptr; // the caller's stream of the product in progress (after_chunk callback)
+    int cb_rc = 0;
+    ~hmx_dist() {
+        for (auto e : chunk_ev)
+            (void)hipEventDestroy(e);
+        if (join_ev)
+            (void)hipEventDestroy(join_ev);
+        if (side)
+            (void)hipStreamDestroy(side);
+    }
 };
-static int dist_api_from_library(hmx_rccl_api &api) {
+static int dist_api_from_library(hmx_rccl_api &api, void **reduce_scatter = nullptr) {
     void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h)
         h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -687,6 +705,8 @@ static int dist_api_from_library(hmx_rccl_api &api) {
     api.broadcast   = reinterpret_cast<decltype(api.broadcast)>(dlsym(h, "ncclBroadcast"));
     api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(h, "ncclGroupStart"));
     api.group_end   = reinterpret_cast<decltype(api.group_end)>(dlsym(h, "ncclGroupEnd"));
+    if (reduce_scatter)
+        *reduce_scatter = dlsym(h, "ncclReduceScatter");
     if (!api.all_gather || !api.all_reduce || !api.broadcast || !api.group_start || !api.group_end) {
         set_error("hmx_dist_create: librccl.so lacks a collective entry point");
         return HMX_ERR_UNSUPPORTED;
@@ -731,7 +751,128 @@ static int dist_local_product(hmx_dist &D, char trans, const void *alpha, const 
         return hmx::z64::api_matvec(H->z, trans, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), HMX_MEM_DEVICE, st);
     HMX_GUARD(hmx::c32::api_matvec(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), HMX_MEM_DEVICE, st));
 }
+// chunked local product (trans = 'N'), whatever the coefficient type
+static int dist_local_product_chunked(hmx_dist &D, const void *alpha, const void *in, const void *beta, void *out, hipStream_t st, int nchunks, void (*after)(void *, int, int, int), void *user, int *used) {
+    hmx_hmatrix *H = D.local;
+    if (H->d)
+        return hmx::f64::api_matvec_chunked(H->d, *static_cast<const double *>(alpha), static_cast<const double *>(in), *static_cast<const double *>(beta), static_cast<double *>(out), st, nchunks, after, user, used);
+    if (H->s)
+        return hmx::f32::api_matvec_chunked(H->s, *static_cast<const float *>(alpha), static_cast<const float *>(in), *static_cast<const float *>(beta), static_cast<float *>(out), st, nchunks, after, user, used);
+    if (H->z)
+        return hmx::z64::api_matvec_chunked(H->z, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), st, nchunks, after, user, used);
+    return hmx::c32::api_matvec_chunked(H->c, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), st, nchunks, after, user, used);
+}
+static int dist_chunk_bounds(hmx_dist &D, int nchunks, int *n, int32_t *b) {
+    hmx_hmatrix *H = D.local;
+    if (H->d)
+        return hmx::f64::api_chunk_bounds(H->d, nchunks, n, b);
+    if (H->s)
+        return hmx::f32::api_chunk_bounds(H->s, nchunks, n, b);
+    if (H->z)
+        return hmx::z64::api_chunk_bounds(H->z, nchunks, n, b);
+    return hmx::c32::api_chunk_bounds(H->c, nchunks, n, b);
+}
+// rows [bounds[k][c], bounds[k][c + 1]) of every rank k's slice -> their place in `out`: one grouped broadcast per rank (the chunks
+// of different ranks have different sizes and are not adjacent in `out`, so this is not an ncclAllGather)
+static int dist_gather_chunk(hmx_dist &D, int c, const char *local, char *out, hipStream_t st) {
+    const int nb = D.nchunks + 1;
+    HMX_NCCL(D.api.group_start());
+    for (int k = 0; k < D.world; k++) {
+        const int lo = D.bounds[(size_t)k * nb + c], hi = D.bounds[(size_t)k * nb + c + 1];
+        if (hi <= lo)
+            continue;
+        HMX_NCCL(D.api.broadcast(local + (size_t)(k == D.rank ? lo : 0) * D.esz, out + (size_t)(D.t_off[k] + lo) * D.esz, (size_t)(hi - lo) * D.reals, D.dtype, k, D.comm, st));
+    }
+    HMX_NCCL(D.api.group_end());
+    return HMX_OK;
+}
+struct DistChunkCtx {
+    hmx_dist *D;
+    const char *local;
+    char *out;
+};
+// called on the host right after chunk c of the expand stage was launched on the caller's stream: its exchange goes to the side stream
+static void dist_after_chunk(void *user, int c, int, int) {
+    DistChunkCtx &X = *static_cast<DistChunkCtx *>(user);
+    hmx_dist &D     = *X.D;
+    if (D.cb_rc != HMX_OK)
+        return;
+    if (hipEventRecord(D.chunk_ev[c], D.cur_stream) != hipSuccess || hipStreamWaitEvent(D.side, D.chunk_ev[c], 0) != hipSuccess) {
+        D.cb_rc = HMX_ERR_HIP;
+        return;
+    }
+    D.cb_rc = dist_gather_chunk(D, c, X.local, X.out, D.side);
+}
+
 extern "C" {
+// Overlap of the output exchange with the computation (north star: "overlapped on a side HIP stream with the leaf GEMVs").  With
+// chunks >= 2 the expand stage of a trans = 'N' global-to-global product runs in that many row chunks on the caller's stream; after each
+// chunk an event hands its rows to a side stream, where they are exchanged (grouped ncclBroadcast, one per rank) while the next chunk
+// computes; the caller's stream then waits for the last exchange.  COLLECTIVE: every rank calls it with the same value (the ranks
+// exchange their chunk boundaries; an operator that cannot be chunked -- fused symmetric storage -- makes all ranks fall back to one
+// exchange after the product).  chunks <= 1 switches it off (the default: hmx_dist_create is not collective, this function is).
+int hmx_dist_set_overlap(hmx_dist *Dp, int chunks, void *stream) {
+    if (!Dp) {
+        set_error("hmx_dist_set_overlap: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D = *Dp;
+    D.overlap   = chunks > 1 ? chunks : 0;
+    D.nchunks   = 0;
+    if (!D.overlap || (D.world == 1 && !D.force))
+        return HMX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb   = chunks + 1;
+    std::vector<int32_t> mine(nb, 0);
+    int n = 1;
+    int rc = dist_chunk_bounds(D, chunks, &n, mine.data());
+    if (rc != HMX_OK)
+        return rc;
+    // every rank sends (n, bounds[0..chunks]) as doubles (exact; the mock communicators of the tests only know float types)
+    std::vector<double> send(nb + 1, 0.0), recv((size_t)(nb + 1) * D.world, 0.0);
+    send[0] = n;
+    for (int c = 0; c <= n; c++)
+        send[1 + c] = mine[c];
+    for (int c = n + 1; c < nb; c++)
+        send[1 + c] = mine[n]; // unused chunks are empty
+    DArr<double> ds, dr;
+    HMX_HIP(ds.upload(send));
+    HMX_HIP(dr.alloc(recv.size()));
+    HMX_NCCL(D.api.all_gather(ds.d, dr.d, send.size(), 8 /* ncclFloat64 */, D.comm, st));
+    HMX_HIP(hipStreamSynchronize(st));
+    HMX_HIP(hipMemcpy(recv.data(), dr.d, recv.size() * sizeof(double), hipMemcpyDeviceToHost));
+    bool all_chunked = true;
+    for (int k = 0; k < D.world; k++)
+        all_chunked = all_chunked && (int)recv[(size_t)k * (nb + 1)] == chunks;
+    if (!all_chunked) { // some rank cannot chunk its product: nobody does (the collectives must match)
+        D.nchunks = 0;
+        return HMX_OK;
+    }
+    D.nchunks = chunks;
+    D.bounds.assign((size_t)nb * D.world, 0);
+    for (int k = 0; k < D.world; k++)
+        for (int c = 0; c < nb; c++)
+            D.bounds[(size_t)k * nb + c] = (int32_t)recv[(size_t)k * (nb + 1) + 1 + c];
+    if (!D.side)
+        HMX_HIP(hipStreamCreateWithFlags(&D.side, hipStreamNonBlocking));
+    while ((int)D.chunk_ev.size() < chunks) {
+        hipEvent_t e;
+        HMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        D.chunk_ev.push_back(e);
+    }
+    if (!D.join_ev)
+        HMX_HIP(hipEventCreateWithFlags(&D.join_ev, hipEventDisableTiming));
+    return HMX_OK;
+}
+int hmx_dist_overlap_chunks(const hmx_dist *D) { return D ? D->nchunks : 0; }
+/* ncclReduceScatter for the transposed local-to-local product when the communicator table was given by the caller */
+int hmx_dist_set_reduce_scatter(hmx_dist *D, int (*fn)(const void *, void *, size_t, int, int, void *, void *)) {
+    if (!D)
+        return HMX_ERR_INVALID;
+    D->reduce_scatter = fn;
+    return HMX_OK;
+}
+
 int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank, int world_size, const hmx_rccl_api *api, hmx_dist **out) {
     if (!local || !target || !source || !out || world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !nccl_comm)) {
         set_error("hmx_dist_create: invalid arguments");
@@ -750,11 +891,13 @@ int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hm
     if (api) {
         D->api = *api;
     } else if (world_size > 1 || D->force) {
-        const int rc = dist_api_from_library(D->api);
+        void *rs     = nullptr;
+        const int rc = dist_api_from_library(D->api, &rs);
         if (rc != HMX_OK) {
             delete D;
             return rc;
         }
+        D->reduce_scatter = reinterpret_cast<decltype(D->reduce_scatter)>(rs);
     }
     for (int k = 0; k < world_size; k++) {
         D->t_off.push_back(target->nodes[target->on_partition[k]].offset);
@@ -788,6 +931,27 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
         if (D.work.n < (size_t)n * e)
             HMX_HIP(D.work.alloc((size_t)n * e));
         HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
+        if (D.nchunks > 1 && (D.world > 1 || D.force)) {
+            // chunked expand stage on `st`, each chunk's exchange on the side stream under the next chunk's kernel
+            DistChunkCtx ctx{&D, D.work.d, yb};
+            D.cur_stream = st;
+            D.cb_rc      = HMX_OK;
+            HMX_HIP(hipEventRecord(D.join_ev, st)); // the side stream must not run ahead of what `st` did to y before this call
+            HMX_HIP(hipStreamWaitEvent(D.side, D.join_ev, 0));
+            int used = 0;
+            int rc   = dist_local_product_chunked(D, alpha, x, beta, D.work.d, st, D.nchunks, dist_after_chunk, &ctx, &used);
+            if (rc != HMX_OK)
+                return rc;
+            if (D.cb_rc != HMX_OK)
+                return D.cb_rc;
+            if (used != D.nchunks) {
+                set_error("hmx_dist_matvec_global_to_global: the local operator changed since hmx_dist_set_overlap");
+                return HMX_ERR_STATE;
+            }
+            HMX_HIP(hipEventRecord(D.join_ev, D.side));
+            HMX_HIP(hipStreamWaitEvent(st, D.join_ev, 0));
+            return HMX_OK;
+        }
         int rc = dist_local_product(D, 'N', alpha, x, beta, D.work.d, st);
         if (rc != HMX_OK)
             return rc;
@@ -850,10 +1014,23 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
     int rc = dist_local_product(D, trans, alpha, x_local, bz, D.work2.d, st);
     if (rc != HMX_OK)
         return rc;
-    if (D.world > 1 || D.force)
-        HMX_NCCL(D.api.all_reduce(D.work2.d, D.work2.d, (size_t)D.ns * D.reals, D.dtype, 0, D.comm, st));
     const int off = D.s_off[D.rank], n = D.s_size[D.rank];
     const char *w = D.work2.d + (size_t)off * e;
+    if (D.world > 1 || D.force) {
+        // the reference's MPI_Alltoallv + p axpys (local_to_local.hpp:77) is a reduce-scatter: with equal, contiguous partitions
+        // ncclReduceScatter delivers exactly this rank's slice (N / p instead of N per rank); otherwise all-reduce + slice
+        bool equal = D.s_off[0] == 0 && D.reduce_scatter != nullptr && !(getenv("HMX_DIST_NO_REDUCE_SCATTER") && atoi(getenv("HMX_DIST_NO_REDUCE_SCATTER")));
+        for (int k = 1; k < D.world && equal; k++)
+            equal = D.s_size[k] == D.s_size[0] && D.s_off[k] == k * D.s_size[0];
+        if (equal) {
+            if (D.work.n < (size_t)n * e)
+                HMX_HIP(D.work.alloc((size_t)n * e));
+            HMX_NCCL(D.reduce_scatter(D.work2.d, D.work.d, (size_t)n * D.reals, D.dtype, 0, D.comm, st));
+            w = D.work.d;
+        } else {
+            HMX_NCCL(D.api.all_reduce(D.work2.d, D.work2.d, (size_t)D.ns * D.reals, D.dtype, 0, D.comm, st));
+        }
+    }
     hmx_hmatrix *H = D.local;
     if (H->d)
         hipLaunchKernelGGL(hmx::f64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0, (const double *)w, *static_cast<const double *>(beta), static_cast<double *>(y_local));

@@ -88,9 +88,19 @@ struct HMat {
     std::unique_ptr<HMat> T_op;
     const HMat *view_of = nullptr;
     bool T_op_failed    = false;
+    // compact symmetric storage, several right-hand sides: the fused multi-RHS kernels run on an EXPANDED view of the operator
+    // (same orientation, mirrored leaves laid out explicitly), built on the first such product (ensure_expanded_view)
+    std::unique_ptr<HMat> X_op;
+    bool X_op_failed      = false;
+    bool view_transposed  = true; // of a view: rows and columns exchanged with respect to the owner
     bool factors_released = false; // hmx_hmatrix_release_factors: the cross pool was given back, only the streams remain
     DArr<int32_t> d_perm_t, d_perm_s;
     bool finalized = false;
+    // expand stage in row chunks (hmx_dist overlap: the exchange of chunk c runs under the kernel of chunk c + 1): contiguous groups of
+    // row ranges with about equal work, each group launched heaviest-first
+    int chunk_plan_n = 0;
+    std::vector<int32_t> chunk_first, chunk_count, chunk_row_lo, chunk_row_hi;
+    DArr<int32_t> d_chunk_order;
 
     hmx_stats stats{};
     // profiling
@@ -140,9 +150,13 @@ static int build_streams(HMat &H) {
         H.sym_expanded = true; // a transposed view is only ever built from an expanded layout
     // a transposed view borrows crosses, staged blocks and generator from its owner
     const HMat &SRC = H.view_of ? *H.view_of : H;
-    const bool tv   = H.view_of != nullptr;
-    if (!tv)
-        H.T_op.reset(); // the layout changes: a transposed view built earlier is stale
+    const bool tv   = H.view_of != nullptr && H.view_transposed;
+    H.chunk_plan_n = 0;
+    if (!H.view_of) { // the layout changes: views built earlier are stale
+        H.T_op.reset();
+        H.X_op.reset();
+        H.T_op_failed = H.X_op_failed = false;
+    }
     std::vector<hmx_leaf> XL = H.leaves;
     std::vector<int> XK      = H.kind;
     std::vector<int64_t> xcolptr = H.colptr, xstaged = H.staged_off;
@@ -712,7 +726,53 @@ static void prof_mark(HMat &H, hipStream_t st, const char *name) {
 
 // forward pass on device pointers: y = alpha * (sum over leaves) x + beta * y using the fast kernels
 // zidx: coefficient index array of the E-streams (all leaves, or mirror leaves only)
-static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st, bool sym_fused = false) {
+static int ensure_expand_chunks(HMat &H, int nchunks) {
+    const StreamSet &E = H.E;
+    const int nr       = E.nranges();
+    nchunks            = std::max(1, std::min(nchunks, std::max(nr, 1)));
+    if (H.chunk_plan_n == nchunks && H.d_chunk_order.d)
+        return HMX_OK;
+    auto work = [&](int r) { return (double)E.len[r] * E.cols[r] + 64; }; // + a constant: an empty range still costs a workgroup
+    double total = 0;
+    for (int r = 0; r < nr; r++)
+        total += work(r);
+    H.chunk_first.assign(nchunks, 0);
+    H.chunk_count.assign(nchunks, 0);
+    H.chunk_row_lo.assign(nchunks, 0);
+    H.chunk_row_hi.assign(nchunks, 0);
+    std::vector<int32_t> order(std::max(nr, 1), 0);
+    int r = 0;
+    double acc = 0;
+    for (int c = 0; c < nchunks; c++) { // the ranges are in row order: chunk c takes them up to the (c + 1)-th share of the work
+        const int first   = r;
+        const double upto = total * (c + 1) / nchunks;
+        if (c == nchunks - 1)
+            r = nr;
+        else
+            while (r < nr && nr - r > nchunks - 1 - c && (r == first || acc + 0.5 * work(r) <= upto)) {
+                acc += work(r);
+                r++;
+            }
+        H.chunk_first[c] = first;
+        H.chunk_count[c] = r - first;
+        for (int k = first; k < r; k++)
+            order[k] = k;
+        std::stable_sort(order.begin() + first, order.begin() + r, [&](int a, int b) { return (int64_t)E.len[a] * E.cols[a] > (int64_t)E.len[b] * E.cols[b]; });
+    }
+    for (int c = 0; c < nchunks; c++) { // the ranges partition the local rows: chunk c owns the rows from its first range to the next chunk's
+        H.chunk_row_lo[c] = c == 0 ? 0 : (H.chunk_first[c] < nr ? E.off[H.chunk_first[c]] : H.nT);
+        if (c > 0)
+            H.chunk_row_hi[c - 1] = H.chunk_row_lo[c];
+    }
+    H.chunk_row_hi[nchunks - 1] = H.nT;
+    HMX_HIP(H.d_chunk_order.upload(order));
+    H.chunk_plan_n = nchunks;
+    return HMX_OK;
+}
+
+typedef void (*after_chunk_fn)(void *user, int chunk, int row_lo, int row_hi);
+static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st, bool sym_fused = false,
+                       int nchunks = 0, after_chunk_fn after_chunk = nullptr, void *after_user = nullptr) {
     // Z[x region] <- x.  x_shift != 0 (mirror pass of a transposed product): the input is indexed by target
     // positions, the x region by source positions.
     const scalar *xin = x_src; // x_shift == 0: both stages read the caller's vector directly, nothing is copied
@@ -785,6 +845,27 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
             hipLaunchKernelGGL(sym_finish_kernel, dim3((H.nT + 255) / 256), dim3(256), 0, st, H.nT, alpha, (const scalar *)H.SW.d, (const int32_t *)H.s_fidx.d, (const int32_t *)H.s_count.d, y);
             prof_mark(H, st, "sym_finish_kernel");
         }
+    } else if (H.E.nranges() > 0 && nchunks > 1) {
+        // the same kernel over contiguous groups of row ranges: after group c its rows of y are final and `after_chunk` may start
+        // sending them while group c + 1 computes
+        const int rc = ensure_expand_chunks(H, nchunks);
+        if (rc != HMX_OK)
+            return rc;
+        for (int c = 0; c < H.chunk_plan_n; c++) {
+            const int cnt = H.chunk_count[c];
+            if (cnt > 0) {
+                ExpandArgs X{H.E.stream.d, H.d_chunk_order.d + H.chunk_first[c], H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, cnt, xin, nx};
+                switch (EW) {
+                case 1: hipLaunchKernelGGL(expand_kernel<1>, dim3(cnt), dim3(64), 0, st, X); break;
+                case 2: hipLaunchKernelGGL(expand_kernel<2>, dim3(cnt), dim3(128), 0, st, X); break;
+                case 8: hipLaunchKernelGGL(expand_kernel<8>, dim3(cnt), dim3(512), 0, st, X); break;
+                default: hipLaunchKernelGGL(expand_kernel<4>, dim3(cnt), dim3(256), 0, st, X); break;
+                }
+            }
+            if (after_chunk)
+                after_chunk(after_user, c, H.chunk_row_lo[c], H.chunk_row_hi[c]);
+        }
+        prof_mark(H, st, "expand_kernel");
     } else if (H.E.nranges() > 0) {
         ExpandArgs X{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx};
         switch (EW) {
@@ -1000,6 +1081,45 @@ static HMat *ensure_transposed_operator(HMat &H) {
     }
     H.T_op = std::move(T);
     return H.T_op.get();
+}
+
+// Multi-RHS products on compact symmetric storage.  With mu right-hand sides every mirrored column of a 64-row range yields mu
+// partial sums: for mu = 16 the partial results would be a quarter of the streamed bytes, written and read again -- more traffic
+// than the mirrored copies save.  So the fused multi-RHS kernels run on an expanded layout of the same operator, built from the
+// same crosses when the first multi-RHS product arrives (HBM permitting; otherwise one fused single-vector product per column).
+static HMat *ensure_expanded_view(HMat &H) {
+    if (H.X_op)
+        return H.X_op.get();
+    if (!H.sym_fused || H.factors_released || H.X_op_failed || H.view_of || (getenv("HMX_SYM_NO_VIEW") && atoi(getenv("HMX_SYM_NO_VIEW"))))
+        return nullptr;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 2.3 * (double)H.stats.stream_bytes) {
+        H.X_op_failed = true;
+        return nullptr;
+    }
+    std::unique_ptr<HMat> X(new HMat());
+    X->device          = H.device;
+    X->view_of         = &H;
+    X->view_transposed = false;
+    X->leaves          = H.leaves;
+    X->kind            = H.kind;
+    X->T0 = H.T0, X->nT = H.nT, X->S0 = H.S0, X->nS = H.nS;
+    X->nT_total = H.nT_total, X->nS_total = H.nS_total;
+    X->symmetry_for_leaves = H.symmetry_for_leaves;
+    X->uplo_for_leaves     = H.uplo_for_leaves;
+    X->build_epsilon       = H.build_epsilon;
+    X->has_mirror          = H.has_mirror;
+    X->colptr              = H.colptr;
+    X->swapped             = H.swapped;
+    X->staged_off          = H.staged_off;
+    X->profiling           = H.profiling;
+    if (build_streams(*X) != HMX_OK) {
+        H.X_op_failed = true;
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    H.X_op = std::move(X);
+    return H.X_op.get();
 }
 
 static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, hipStream_t st, bool inner = false) {
@@ -2020,8 +2140,10 @@ static int api_release_factors(HMat *Hp, int with_transposed) {
     }
     HMat &H = *Hp;
     HMX_HIP(hipSetDevice(H.device));
-    if (with_transposed)
+    if (with_transposed & 1)
         (void)ensure_transposed_operator(H);
+    if (with_transposed & 2) // the expanded view multi-RHS products on compact symmetric storage run on
+        (void)ensure_expanded_view(H);
     if (H.dense_stage.d) // host-generated dense leaves live only in the streams from now on
         H.dense_stage.release();
     H.pool.release();
@@ -2082,6 +2204,65 @@ static int api_matvec(HMat *Hp, char trans, scalar alpha, const scalar *in, scal
         HMX_HIP(hipMemcpyAsync(out, dout, nout * sizeof(scalar), hipMemcpyDeviceToHost, st));
         HMX_HIP(hipStreamSynchronize(st));
     }
+    return HMX_OK;
+}
+
+// trans = 'N' product on device pointers with the expand stage in `nchunks` row chunks; after_chunk(user, c, row_lo, row_hi) is called on
+// the host right after chunk c was LAUNCHED on `stream`: rows [row_lo, row_hi) of `out` are final once the stream reaches that point.
+// Returns the number of chunks used through *used (1: the operator could not be chunked -- fused symmetric storage adds to rows after
+// the expand stage -- and after_chunk was called once, for all rows, after the whole product).
+static int api_matvec_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, scalar *out, void *stream, int nchunks, after_chunk_fn after_chunk, void *user, int *used) {
+    if (!Hp || !in || !out) {
+        set_error("hmx_hmatrix_matvec (chunked): NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!H.finalized) {
+        set_error("hmx_hmatrix_matvec: operator not built (call hmx_hmatrix_compress or hmx_hmatrix_finalize first)");
+        return HMX_ERR_STATE;
+    }
+    const bool chunkable = nchunks > 1 && !(H.has_mirror && !H.sym_expanded) && H.E.nranges() > 1;
+    if (!chunkable) {
+        const int rc = matvec_device(H, 'N', alpha, in, beta, out, st);
+        if (rc != HMX_OK)
+            return rc;
+        if (after_chunk)
+            after_chunk(user, 0, 0, H.nT);
+        if (used)
+            *used = 1;
+        return HMX_OK;
+    }
+    H.ev_names.clear();
+    const bool prof = H.profiling; // per-kernel events make no sense with interleaved collectives
+    H.profiling     = false;
+    const int rc    = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st, false, nchunks, after_chunk, user);
+    H.profiling     = prof;
+    if (used)
+        *used = H.chunk_plan_n;
+    return rc;
+}
+// row bounds of the chunks api_matvec_chunked will use (bounds[0..n]; n returned through *n_out; n = 1 when the operator is not chunkable)
+static int api_chunk_bounds(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) {
+    if (!Hp || !n_out || !bounds)
+        return HMX_ERR_INVALID;
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    const bool chunkable = nchunks > 1 && H.finalized && !(H.has_mirror && !H.sym_expanded) && H.E.nranges() > 1;
+    if (!chunkable) {
+        *n_out    = 1;
+        bounds[0] = 0;
+        bounds[1] = H.nT;
+        return HMX_OK;
+    }
+    const int rc = ensure_expand_chunks(H, nchunks);
+    if (rc != HMX_OK)
+        return rc;
+    *n_out = H.chunk_plan_n;
+    for (int c = 0; c < H.chunk_plan_n; c++)
+        bounds[c] = H.chunk_row_lo[c];
+    bounds[H.chunk_plan_n] = H.nT;
     return HMX_OK;
 }
 
@@ -2146,10 +2327,10 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
     HMat *F = nullptr; // the layout a fused pass runs on: the operator itself, or its transposed view
     bool conj_wrap = false;
     (void)conj_wrap;
-    if (H.finalized && (!H.has_mirror || H.sym_expanded) && !getenv("HMX_NO_FUSED_MU")) {
+    if (H.finalized && (!H.has_mirror || H.sym_expanded || H.sym_fused) && !getenv("HMX_NO_FUSED_MU")) {
         const bool square_sym = H.has_mirror && H.T0 == H.S0 && H.nT == H.nS;
         if (trans == 'N' || (trans == 'T' && square_sym && H.symmetry_for_leaves == 'S') || (trans == 'C' && square_sym && H.symmetry_for_leaves == 'H'))
-            F = &H;
+            F = H.sym_fused ? ensure_expanded_view(H) : &H;
         else if (trans == 'T' && !(HMX_COMPLEX && H.symmetry_for_leaves == 'H'))
             F = ensure_transposed_operator(H);
 #if HMX_COMPLEX

@@ -19,6 +19,8 @@ One process per GPU; rank k owns the block rows of partition cluster k.  The MPI
                                         buffer when the partitions are equal); HMX_DIST_NO_REDUCE_SCATTER=1: all_reduce + slice
 Vectors are torch tensors that stay on the device; only pointers cross the C ABI.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -343,6 +345,181 @@ def internal_add_distributed_operator_vector_product_local_to_local(trans, alpha
                 op.add_vector_product(trans, alpha, x_loc, 1.0, buf)
             y_loc.add_(A._reduce_scatter_slices(buf, out_part))  # MPI_Alltoallv + p axpys == a reduce-scatter
     return y_loc
+
+
+# ---- the same products below Python: libhmx's hmx_dist_* (include/hmx.h) over an RCCL communicator of its own ------------------------
+# At 8 GPUs a rank's share of an N=1e6 product is ~0.4 ms of kernels: interpreter + torch.distributed dispatch per collective is then a
+# visible part of every step.  NativeDistributedOperator issues ONE C call per product; the local kernels, the events and the
+# collectives (optionally overlapped on a side stream, hmx_dist_set_overlap) are enqueued by libhmx.
+
+_NCCL_DTYPE_SIZE = {7: 4, 8: 8}  # ncclFloat32, ncclFloat64 (rccl.h)
+
+
+class _RcclApi(C.Structure):  # hmx_rccl_api
+    _fields_ = [("all_gather", C.c_void_p), ("all_reduce", C.c_void_p), ("broadcast", C.c_void_p), ("group_start", C.c_void_p), ("group_end", C.c_void_p)]
+
+
+class NativeCommunicator:
+    """ncclComm_t created through librccl directly (ncclGetUniqueId on rank 0, shipped over the existing torch.distributed group,
+    ncclCommInitRank everywhere).  `api` is the hmx_rccl_api table of THAT library, so libhmx calls the instance the communicator
+    belongs to.  backend="gloo": no RCCL at all -- the table holds host-staged collectives over the torch.distributed group (several
+    ranks sharing one GPU in tests; every call synchronises the stream it is given)."""
+
+    def __init__(self, group=None, backend="rccl", lib_path=None):
+        import os
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = backend
+        self.comm = C.c_void_p(self.rank + 1)
+        self.api = _RcclApi()
+        self.reduce_scatter = None
+        self._keep = []
+        if backend == "rccl":
+            path = lib_path or os.environ.get("HMX_RCCL_LIB")
+            if not path:  # the RCCL torch itself loaded, when there is one: one instance in the process
+                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+                path = cand if os.path.exists(cand) else "librccl.so"
+            self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+            class Uid(C.Structure):
+                _fields_ = [("b", C.c_char * 128)]
+            uid = Uid()
+            if self.rank == 0 and self.lib.ncclGetUniqueId(C.byref(uid)) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+            box = [C.string_at(C.addressof(uid), 128) if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            C.memmove(C.addressof(uid), box[0], 128)
+            self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+            comm = C.c_void_p()
+            rc = self.lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
+            if rc != 0:
+                raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+            self.comm = comm
+            for field, sym in (("all_gather", "ncclAllGather"), ("all_reduce", "ncclAllReduce"), ("broadcast", "ncclBroadcast"),
+                               ("group_start", "ncclGroupStart"), ("group_end", "ncclGroupEnd")):
+                setattr(self.api, field, C.cast(getattr(self.lib, sym), C.c_void_p).value)
+            self.reduce_scatter = C.cast(self.lib.ncclReduceScatter, C.c_void_p)
+        else:
+            self._make_host_staged_table()
+
+    def destroy(self):
+        if self.backend == "rccl" and self.comm:
+            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+    def _make_host_staged_table(self):
+        hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        group = self.group
+
+        def np_dtype(dt):
+            return np.float64 if dt == 8 else np.float32
+
+        def fetch(ptr, count, dt):
+            a = np.empty(count, dtype=np_dtype(dt))
+            assert hip.hipMemcpy(a.ctypes.data, ptr, a.nbytes, 2) == 0
+            return torch.from_numpy(a)
+
+        def store(ptr, t):
+            a = np.ascontiguousarray(t.numpy())
+            assert hip.hipMemcpy(ptr, a.ctypes.data, a.nbytes, 1) == 0
+
+        def all_gather(send, recv, count, dt, comm, stream):
+            hip.hipStreamSynchronize(stream)
+            mine = fetch(send, count, dt)
+            out = torch.empty(count * self.world, dtype=mine.dtype)
+            dist.all_gather_into_tensor(out, mine, group=group)
+            store(recv, out)
+            return 0
+
+        def all_reduce(send, recv, count, dt, op, comm, stream):
+            hip.hipStreamSynchronize(stream)
+            t = fetch(send, count, dt)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            store(recv, t)
+            return 0
+
+        def broadcast(send, recv, count, dt, root, comm, stream):
+            hip.hipStreamSynchronize(stream)
+            t = fetch(send, count, dt) if self.rank == root else torch.empty(count, dtype=torch.float64 if dt == 8 else torch.float32)
+            dist.broadcast(t, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
+            store(recv, t)
+            return 0
+
+        def reduce_scatter(send, recv, recvcount, dt, op, comm, stream):
+            hip.hipStreamSynchronize(stream)
+            t = fetch(send, recvcount * self.world, dt)
+            out = torch.empty(recvcount, dtype=t.dtype)
+            dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
+            store(recv, out)
+            return 0
+
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+        GR = C.CFUNCTYPE(C.c_int)
+        fns = [AG(all_gather), AR(all_reduce), AR(broadcast), GR(lambda: 0), GR(lambda: 0), AR(reduce_scatter)]
+        self._keep = fns
+        for field, f in zip(("all_gather", "all_reduce", "broadcast", "group_start", "group_end"), fns):
+            setattr(self.api, field, C.cast(f, C.c_void_p).value)
+        self.reduce_scatter = C.cast(fns[5], C.c_void_p)
+
+
+class NativeDistributedOperator:
+    """hmx_dist_* (include/hmx.h): the row-restricted H-matrix of this rank + a communicator; products take torch tensors on the
+    device, partition numbering.  set_overlap(chunks) is collective (hmx_dist_set_overlap)."""
+
+    def __init__(self, hmatrix, target_cluster, source_cluster, communicator):
+        from ._lib import check, lib
+        self.hmatrix, self.comm = hmatrix, communicator
+        self._L = lib()
+        self._h = C.c_void_p()
+        check(self._L.hmx_dist_create(hmatrix._h, target_cluster._h, source_cluster._h, communicator.comm, communicator.rank, communicator.world,
+                                      C.byref(communicator.api), C.byref(self._h)))
+        if communicator.reduce_scatter is not None:
+            check(self._L.hmx_dist_set_reduce_scatter(self._h, communicator.reduce_scatter))
+        self._scal = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.hmx_dist_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _scalars(self, alpha, beta, dtype):
+        key = (complex(alpha), complex(beta), dtype)
+        if key not in self._scal:
+            npdt = {torch.float64: np.float64, torch.float32: np.float32, torch.complex128: np.complex128, torch.complex64: np.complex64}[dtype]
+            ab = np.array([alpha, beta], dtype=npdt)
+            self._scal[key] = (ab, C.c_void_p(ab.ctypes.data), C.c_void_p(ab.ctypes.data + ab.itemsize))
+        return self._scal[key][1:]
+
+    @staticmethod
+    def _stream(t):
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def set_overlap(self, chunks, like=None):
+        from ._lib import check
+        st = self._stream(like) if like is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._L.hmx_dist_set_overlap(self._h, int(chunks), st))
+        return int(self._L.hmx_dist_overlap_chunks(self._h))
+
+    def matvec_global_to_global(self, trans, alpha, x, beta, y):
+        from ._lib import check
+        pa, pb = self._scalars(alpha, beta, y.dtype)
+        check(self._L.hmx_dist_matvec_global_to_global(self._h, trans.encode(), pa, C.c_void_p(x.data_ptr()), pb, C.c_void_p(y.data_ptr()), self._stream(y)))
+        return y
+
+    def matvec_local_to_local(self, trans, alpha, x_loc, beta, y_loc):
+        from ._lib import check
+        pa, pb = self._scalars(alpha, beta, y_loc.dtype)
+        check(self._L.hmx_dist_matvec_local_to_local(self._h, trans.encode(), pa, C.c_void_p(x_loc.data_ptr()), pb, C.c_void_p(y_loc.data_ptr()), self._stream(y_loc)))
+        return y_loc
 
 
 class DefaultApproximationBuilder:

@@ -216,8 +216,9 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *, char trans, const float *alpha
 
 /* Memory: after compression the device holds the streams the products read AND the pool they were packed from (kept for
  * get_block / save / recompress / the transposed layout; 14 GB next to 18.5 GB of streams at N=1e6).  This gives the pool back:
- * only products remain possible (a transposed product uses the in-place passes unless with_transposed != 0 built its layout
- * first). */
+ * only products remain possible (a transposed product uses the in-place passes unless bit 0 of with_transposed built its layout
+ * first; bit 1 builds the expanded view that multi-RHS products on compact symmetric storage run on -- without it they fall
+ * back to one single-vector product per right-hand side). */
 int hmx_hmatrix_release_factors(hmx_hmatrix *, int with_transposed);
 
 /* Binary dump of the compressed operator (no counterpart in the reference): header, leaf table with
@@ -284,6 +285,20 @@ int hmx_dist_matvec_global_to_global(hmx_dist *, char trans, const void *alpha, 
 /* local slices in and out (the Krylov-side contract, local_to_local.hpp:19-89): all-gather of x, local product ('N');
  * local product into a zeroed global vector, all-reduce, slice (transposed). */
 int hmx_dist_matvec_local_to_local(hmx_dist *, char trans, const void *alpha, const void *x_local, const void *beta, void *y_local, void *stream);
+
+/* Overlap of the output exchange with the computation ("all via RCCL on a side HIP stream; overlap by chunking the
+ * output range").  chunks >= 2: the expand stage of a trans = 'N' global-to-global product runs in that many row chunks on the
+ * caller's stream; an event after each chunk hands its rows to a side stream, where they are exchanged (grouped ncclBroadcast,
+ * one per rank: MPI_Allgatherv of global_to_global.hpp:76 restricted to the chunk) while the next chunk computes; the caller's
+ * stream waits for the last exchange.  COLLECTIVE (the ranks exchange their chunk boundaries on `stream`): every rank calls it
+ * with the same `chunks`.  If any rank's operator cannot be chunked (fused symmetric storage adds to rows after the expand stage)
+ * all ranks keep the single exchange after the product; hmx_dist_overlap_chunks tells.  chunks <= 1: off (the default). */
+int hmx_dist_set_overlap(hmx_dist *, int chunks, void *stream);
+int hmx_dist_overlap_chunks(const hmx_dist *);
+/* ncclReduceScatter (same argument shapes as rccl.h) for the transposed local-to-local product (MPI_Alltoallv + axpys of
+ * local_to_local.hpp:77) when the collective table was given by the caller; with a NULL table it is taken from librccl.so.
+ * Without it, or with unequal partitions, that product uses all-reduce + slice. */
+int hmx_dist_set_reduce_scatter(hmx_dist *, int (*reduce_scatter)(const void *send, void *recv, size_t recvcount, int datatype, int op, void *comm, void *stream));
 
 /* Timing hooks for bench.py: average duration (ms) of the last matvec's kernels measured with HIP
  * events on the launch stream; names[i] is a static string. */

@@ -32,3 +32,27 @@ def test_bench_two_ranks_one_gpu(extra):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["unit"] == "GB/s" and d["value"] > 0
     assert "row-partition x2" in d["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("impl", ["native", "python"])
+def test_bench_starts_its_own_ranks(impl):
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.py starts the two ranks itself (fresh children, before anything touches the
+    GPU), rank 0's JSON line comes out of the parent.  native: the step is one hmx_dist_* call per product (here over host-staged gloo
+    collectives, since the two ranks share the box's one GPU), the exchange variants (0 / 2 / 4 row chunks on the side stream) are tried and
+    reported; python: the torch.distributed layer."""
+    env = dict(os.environ, HMX_BENCH_SAME_DEVICE="1", HMX_BENCH_BACKEND="gloo", HMX_BENCH_N="200000")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dist-impl", impl],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    assert len(d["dist"]["per_rank_local_ms"]) == 2 and len(d["dist"]["per_rank_GB"]) == 2
+    if impl == "native":
+        assert d["dist"]["impl"].startswith("native"), d["dist"]
+        assert set(d["dist"]["overlap_trials_ms"]) >= {"0", "2"}, d["dist"]
+    else:
+        assert d["dist"]["impl"].startswith("python")

@@ -132,7 +132,25 @@ MOCK_SCRIPT = textwrap.dedent('''
         hip.hipStreamSynchronize(None)
         barrier.wait()
         return 0
+    def reduce_scatter(send, recv, recvcount, dtype, op, comm, stream):
+        r, nbytes = comm - 1, recvcount * ESZ[dtype]
+        assert op == 0
+        calls["reduce_scatter"] = calls.get("reduce_scatter", 0) + (r == 0)
+        hip.hipStreamSynchronize(stream)
+        slots[r] = send
+        barrier.wait()
+        acc = np.zeros(recvcount, dtype=np.float64 if dtype == 8 else np.float32)
+        tmp = np.empty_like(acc)
+        for k in range(WORLD):
+            assert hip.hipMemcpy(tmp.ctypes.data, slots[k] + r * nbytes, nbytes, 2) == 0
+            acc += tmp
+        barrier.wait()
+        assert hip.hipMemcpy(recv, acc.ctypes.data, nbytes, 1) == 0
+        barrier.wait()
+        return 0
     AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+    RS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    rs_fn = RS(reduce_scatter)
     AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
     BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
     GR = C.CFUNCTYPE(C.c_int)
@@ -167,15 +185,16 @@ MOCK_SCRIPT = textwrap.dedent('''
         for k in range(WORLD):
             D = C.c_void_p()
             check(L.hmx_dist_create(Hloc[k]._h, T._h, T._h, C.c_void_p(k + 1), k, WORLD, C.byref(api), C.byref(D)))
+            check(L.hmx_dist_set_reduce_scatter(D, C.cast(rs_fn, C.c_void_p)))
             Ds.append(D)
         xin = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
         y0 = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
         ab = np.array([1.5 - (0.5j if cplx else 0), 0.25 + (1j if cplx else 0)], dtype=dtype)
         pa, pb = C.c_void_p(ab.ctypes.data), C.c_void_p(ab.ctypes.data + ab.itemsize)
-        for trans in ("N", "T"):
+        for trans, overlap in (("N", 0), ("T", 0), ("N", 3), ("N", 2)):
             ref = y0.copy()
             hm.internal_add_hmatrix_vector_product(trans, ab[0], Hfull, xin, ab[1], ref)
-            for local in (False, True):
+            for local in ((False, True) if overlap == 0 else (False,)):
                 errs, fails = [None] * WORLD, []
                 def rank_main(k):
                     try:
@@ -183,6 +202,9 @@ MOCK_SCRIPT = textwrap.dedent('''
                         xi, yi = (xin[off:off + sz].copy(), y0[off:off + sz].copy()) if local else (xin, y0)
                         dx, dy = dev(xi), dev(yi)
                         fn = L.hmx_dist_matvec_local_to_local if local else L.hmx_dist_matvec_global_to_global
+                        # overlap: expand stage in row chunks, each chunk exchanged on the side stream (grouped broadcasts)
+                        check(L.hmx_dist_set_overlap(Ds[k], overlap, None))
+                        assert L.hmx_dist_overlap_chunks(Ds[k]) == overlap
                         check(fn(Ds[k], trans.encode(), pa, dx, pb, dy, None))
                         assert hip.hipDeviceSynchronize() == 0
                         y = host(dy, yi)
@@ -201,7 +223,8 @@ MOCK_SCRIPT = textwrap.dedent('''
         print("ok", np.dtype(dtype).name)
     print("calls", calls)
     equal = len(set(int(p[1]) for p in parts)) == 1
-    assert calls["all_reduce"] > 0 and (calls["all_gather"] > 0 if equal else calls["broadcast"] > 0), calls
+    assert calls["all_reduce"] > 0 and calls["broadcast"] > 0 and calls["all_gather"] > 0, calls
+    assert (calls.get("reduce_scatter", 0) > 0) == equal, calls  # transposed local-to-local: reduce-scatter for equal parts
 ''') % ROOT
 
 
@@ -210,7 +233,9 @@ def test_c_level_distributed_operator_multi_rank_with_mock_collectives(world):
     """hmx_dist_* with SEVERAL ranks on the one GPU a box has: every rank is a thread with its own row-restricted operator and
     hmx_dist handle, and the hmx_rccl_api table is filled with in-process collectives (barrier + device copies) instead of
     RCCL's.  Exercises what one rank cannot: the partition offsets, the all-gather route (4 equal parts) and the grouped
-    broadcast route (3 unequal parts), the all-reduce of the transposed products, local-to-local slices; real and complex.
+    broadcast route (3 unequal parts), the all-reduce of the transposed products, the reduce-scatter of the transposed local-to-local
+    product (equal parts), local-to-local slices, and the overlapped exchange (hmx_dist_set_overlap: expand stage in 2 and 3 row chunks,
+    every chunk's rows exchanged on the side stream); real and complex.
     Reference: the single-process product of the whole operator."""
     out = subprocess.run([sys.executable, "-c", MOCK_SCRIPT, str(world)], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HMX_NO_TORCH="1"))
