@@ -266,6 +266,7 @@ def main():
     tb.set_minimal_target_depth(d)
     tb.set_minimal_source_depth(d)
     cplx = args.dtype in ("z64", "c32")
+    hm.lib().hmx_device_init(local_rank)  # HIP context + load of libhmx's code object: not part of an operator build
     gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 1.0 if cplx else 0.0, args.sym == "H")
     t0 = time.time()
     part = use_dist

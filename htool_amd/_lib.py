@@ -49,6 +49,7 @@ _dp, _ip, _vp, _fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p, C.
 SYMBOLS = [
     ("hmx_last_error", C.c_char_p, []),
     ("hmx_device_count", C.c_int, []),
+    ("hmx_device_init", C.c_int, [C.c_int]),
     ("hmx_geometry", C.c_int, [C.c_char_p, C.c_int, C.c_double, _dp]),
     ("hmx_cluster_tree_create", C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_cluster_tree_create_ex", C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.POINTER(_vp)]),

@@ -340,6 +340,20 @@ int hmx_device_count(void) {
     return n;
 }
 
+// One-time cost of the first call into the device side of the library: HIP context creation and the load of libhmx's code object
+// (every kernel of four coefficient types: ~0.2 s).  Callers that time operator builds call this first.
+int hmx_device_init(int device_id) {
+    const int rc = ensure_device(device_id);
+    if (rc != HMX_OK)
+        return rc;
+    DArr<double2> a;
+    HMX_HIP(a.alloc(64));
+    hipLaunchKernelGGL(copy16_kernel, dim3(1), dim3(64), 0, 0, (const double2 *)a.d, a.d, (int64_t)0);
+    HMX_HIP(hipGetLastError());
+    HMX_HIP(hipDeviceSynchronize());
+    return HMX_OK;
+}
+
 int hmx_hmatrix_create(const hmx_block_tree *bt, int device_id, hmx_hmatrix **out) {
     if (!out) {
         set_error("hmx_hmatrix_create: out is NULL");

@@ -86,6 +86,9 @@ typedef struct {
 
 const char *hmx_last_error(void);
 int hmx_device_count(void);
+/* One-time initialisation of the device side (HIP context, load of the library's code object: ~0.2 s), otherwise paid by the
+ * first hmx_hmatrix_create / compress.  Optional; for callers that time operator builds. */
+int hmx_device_init(int device_id);
 
 /* ---- test geometries (testing/geometry.hpp:11-61), seeded mt19937(0) --------------------------------- */
 int hmx_geometry(const char *name /* "ellipse" | "disk" | "ball" (n*3 doubles) | "disk2d" (n*2) */, int n, double z, double *coords);

@@ -4,6 +4,7 @@
 #include <cstdio>
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #include <cstdlib>
+#include <cstdint>
 #include <vector>
 int main(int argc, char **argv) {
     hipFree(0);
@@ -27,7 +28,13 @@ int main(int argc, char **argv) {
     }
     hipStream_t s;
     hipStreamCreate(&s);
-    for (double gb : {8.0, 32.0, 32.0}) {
+    {
+        hipMemPool_t pool;
+        hipDeviceGetDefaultMemPool(&pool, 0);
+        uint64_t keep = UINT64_MAX; // freed memory stays in the pool
+        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    for (double gb : sizes) {
         void *p = nullptr;
         double t0 = now();
         hipError_t e = hipMallocAsync(&p, (size_t)(gb * 1e9), s);
