@@ -9,4 +9,4 @@ from .api import (ClusterTreeBuilder, Cluster, HMatrixTreeBuilder, HMatrix, InvD
                   add_hmatrix_vector_product, internal_add_hmatrix_vector_product,
                   internal_add_hmatrix_matrix_product_row_major, add_hmatrix_matrix_product, create_geometry,
                   save_cluster_tree, read_cluster_tree, save_leaves_with_rank, matrix_to_bytes, bytes_to_matrix, trim_device_cache,
-                  get_tree_parameters, get_hmatrix_information, print_tree_parameters, print_hmatrix_information)
+                  get_tree_parameters, get_hmatrix_information, print_tree_parameters, print_hmatrix_information, cluster_tree_from_nodes)

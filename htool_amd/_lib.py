@@ -53,6 +53,7 @@ SYMBOLS = [
     ("hmx_geometry", C.c_int, [C.c_char_p, C.c_int, C.c_double, _dp]),
     ("hmx_cluster_tree_create", C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_cluster_tree_create_ex", C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.POINTER(_vp)]),
+    ("hmx_cluster_tree_from_nodes", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, _vp, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(_vp)]),
     ("hmx_cluster_tree_destroy", None, [_vp]),
     ("hmx_cluster_tree_size", C.c_int, [_vp]),
     ("hmx_cluster_tree_num_nodes", C.c_int, [_vp]),

@@ -146,6 +146,28 @@ def save_leaves_with_rank(hmatrix, filename):
     check(lib().hmx_block_tree_save_leaves_with_rank(hmatrix._bt, ptr, str(filename).encode()))
 
 
+def cluster_tree_from_nodes(permutation, nodes_int, nodes_real, partition_nodes, maximal_leaf_size, coordinates, permutation_is_local=False):
+    """An existing cluster tree as the engine's Cluster (hmx_cluster_tree_from_nodes): `nodes_int` / `nodes_real` are the preorder
+    walk of the tree -- per node (depth, offset, size, rank, counter, number of children) and (radius, center[3]) -- the layout
+    Cluster.nodes_int() / nodes_real() return; `partition_nodes[k]` is the preorder index of the cluster of partition k."""
+    ni = np.ascontiguousarray(nodes_int, dtype=np.int32)
+    nr = np.ascontiguousarray(nodes_real, dtype=np.float64)
+    arr = (_lib.ClusterNode * len(ni))()
+    for k in range(len(ni)):
+        c = arr[k]
+        c.depth, c.offset, c.size, c.rank, c.counter, c.n_children = (int(v) for v in ni[k])
+        c.radius = float(nr[k, 0])
+        for p in range(3):
+            c.center[p] = float(nr[k, 1 + p])
+    perm = np.ascontiguousarray(permutation, dtype=np.int32)
+    parts = np.ascontiguousarray(partition_nodes, dtype=np.int32)
+    x = np.ascontiguousarray(coordinates, dtype=np.float64)
+    h = C.c_void_p()
+    check(lib().hmx_cluster_tree_from_nodes(len(perm), x.shape[1], perm.ctypes.data_as(C.POINTER(C.c_int32)), len(ni), C.cast(arr, C.c_void_p), len(parts),
+                                            parts.ctypes.data_as(C.POINTER(C.c_int32)), int(maximal_leaf_size), 1 if permutation_is_local else 0, C.byref(h)))
+    return Cluster(h, x)
+
+
 class ClusterTreeBuilder:
     def __init__(self):
         self._leaf = 10  # htool default (tree_builder.hpp:25)

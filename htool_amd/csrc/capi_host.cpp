@@ -3,6 +3,7 @@
 #include <mutex>
 #include <new>
 
+#include <algorithm>
 #include "hmx_host.hpp"
 
 namespace hmx {
@@ -78,6 +79,118 @@ int hmx_cluster_tree_create_ex(int n, int dim, const double *coords, const doubl
     }
     *out = T;
     return HMX_OK;
+}
+// An EXISTING cluster tree (any builder: a user's VirtualPartitioning, a tree read from disk, another library), given as its
+// preorder node table.  Everything downstream (block tree, device engine) only needs this structure.
+int hmx_cluster_tree_from_nodes(int n, int dim, const int32_t *permutation, int num_nodes, const hmx_cluster_node *nodes, int num_partitions,
+                                const int32_t *partition_nodes, int maximal_leaf_size, int permutation_is_local, hmx_cluster_tree **out) {
+    if (!out || !permutation || !nodes || n < 1 || num_nodes < 1 || (dim != 2 && dim != 3) || num_partitions < 0 || (num_partitions > 0 && !partition_nodes)) {
+        hmx::set_error("hmx_cluster_tree_from_nodes: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    auto fail = [](const std::string &why) {
+        hmx::set_error("hmx_cluster_tree_from_nodes: " + why);
+        return HMX_ERR_INVALID;
+    };
+    try {
+        // the permutation must be one, the root must cover [0, n)
+        std::vector<char> seen((size_t)n, 0);
+        for (int i = 0; i < n; i++) {
+            if (permutation[i] < 0 || permutation[i] >= n || seen[permutation[i]])
+                return fail("the permutation is not a permutation of 0.." + std::to_string(n - 1));
+            seen[permutation[i]] = 1;
+        }
+        if (nodes[0].offset != 0 || nodes[0].size != n)
+            return fail("the first node (root) must cover all points");
+        // preorder -> (parent, children): a node with c children is followed by c subtrees
+        std::vector<int> parent(num_nodes, -1), subtree_end(num_nodes, 0);
+        {
+            std::vector<std::pair<int, int>> stack; // (node, children still to come)
+            for (int v = 0; v < num_nodes; v++) {
+                if (nodes[v].n_children < 0 || nodes[v].size < 0 || nodes[v].offset < 0 || (long long)nodes[v].offset + nodes[v].size > n)
+                    return fail("node " + std::to_string(v) + " is out of range");
+                while (!stack.empty() && stack.back().second == 0)
+                    stack.pop_back();
+                if (v > 0) {
+                    if (stack.empty())
+                        return fail("more nodes than the children counts account for");
+                    parent[v] = stack.back().first;
+                    stack.back().second--;
+                }
+                stack.emplace_back(v, nodes[v].n_children);
+            }
+            while (!stack.empty() && stack.back().second == 0)
+                stack.pop_back();
+            if (!stack.empty())
+                return fail("fewer nodes than the children counts account for");
+        }
+        std::vector<std::vector<int>> children(num_nodes);
+        for (int v = 1; v < num_nodes; v++)
+            children[parent[v]].push_back(v);
+        for (int v = 0; v < num_nodes; v++) { // the children of a node tile it, in order
+            int pos = nodes[v].offset;
+            for (int c : children[v]) {
+                if (nodes[c].offset != pos || nodes[c].depth != nodes[v].depth + 1)
+                    return fail("the children of node " + std::to_string(v) + " do not tile it in order (or their depth is not parent + 1)");
+                pos += nodes[c].size;
+            }
+            if (!children[v].empty() && pos != nodes[v].offset + nodes[v].size)
+                return fail("the children of node " + std::to_string(v) + " do not cover it");
+        }
+        auto *T = new hmx_cluster_tree();
+        T->n    = n;
+        T->dim  = dim;
+        T->perm.assign(permutation, permutation + n);
+        T->permutation_is_local = permutation_is_local != 0;
+        // internal layout: root first, the children of a node contiguous
+        std::vector<int> id(num_nodes, -1), order;
+        order.reserve(num_nodes);
+        order.push_back(0);
+        id[0] = 0;
+        T->nodes.resize(num_nodes);
+        for (size_t q = 0; q < order.size(); q++) {
+            const int v = order[q];
+            hmx::ClusterNode &c = T->nodes[id[v]];
+            c.parent     = parent[v] < 0 ? -1 : id[parent[v]];
+            c.n_children = (int)children[v].size();
+            c.first_child = c.n_children ? (int)order.size() : -1;
+            c.depth = nodes[v].depth, c.offset = nodes[v].offset, c.size = nodes[v].size, c.rank = nodes[v].rank, c.counter = nodes[v].counter;
+            c.radius = nodes[v].radius;
+            for (int p = 0; p < 3; p++)
+                c.center[p] = nodes[v].center[p];
+            for (int ch : children[v]) {
+                id[ch] = (int)order.size();
+                order.push_back(ch);
+            }
+        }
+        for (int k = 0; k < num_partitions; k++) {
+            if (partition_nodes[k] < 0 || partition_nodes[k] >= num_nodes) {
+                delete T;
+                return fail("partition " + std::to_string(k) + " names a node that does not exist");
+            }
+            T->on_partition.push_back(id[partition_nodes[k]]);
+        }
+        int pos = 0; // the partition clusters tile the points in order (what the row distribution relies on)
+        for (int k = 0; k < num_partitions; k++) {
+            const hmx::ClusterNode &c = T->nodes[T->on_partition[k]];
+            if (c.offset != pos) {
+                delete T;
+                return fail("the partition clusters do not tile the points in order");
+            }
+            pos += c.size;
+        }
+        if (num_partitions > 0 && pos != n) {
+            delete T;
+            return fail("the partition clusters do not cover the points");
+        }
+        T->opt.maximal_leaf_size  = maximal_leaf_size;
+        T->opt.size_of_partition  = std::max(1, num_partitions);
+        T->opt.number_of_children = T->nodes[0].n_children;
+        *out = T;
+        return HMX_OK;
+    } catch (...) {
+        return fail("out of host memory");
+    }
 }
 void hmx_cluster_tree_destroy(hmx_cluster_tree *T) { delete T; }
 int hmx_cluster_tree_size(const hmx_cluster_tree *T) { return T ? T->n : 0; }

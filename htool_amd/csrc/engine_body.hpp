@@ -1355,7 +1355,9 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     std::vector<int64_t> visptr(nb, 0);
     int64_t ncross = 0, nvis = 0;
     double need = 0, estimate = 0;
-    constexpr int RANK_CAP = 4096;
+    // slots per block = the largest rank the reference itself accepts, q (M + N) <= M N (partialACA.hpp:84): no other cap, so a block fails
+    // into a dense leaf exactly when the reference's does (the slot table costs 8 bytes per possible cross: ~2 GB at N = 1e6)
+    constexpr int64_t RANK_CAP = INT32_MAX;
     // expected rank of an admissible block: grows like log(1/eps) for the asymptotically smooth kernels H-matrices are for
     const double rank_guess = getenv("HMX_POOL_RANK_GUESS") ? atof(getenv("HMX_POOL_RANK_GUESS"))
                               : (reqrank > 0 ? (double)reqrank : std::max(16.0, 8.0 + 3.0 * std::log10(1.0 / std::max(epsilon, 1e-16))));

@@ -154,7 +154,47 @@ class EngineT {
         return t;
     }
 
+    // htool's own Cluster -> hmx_cluster_tree, node for node (preorder walk): works for ANY tree, whatever built it -- a user's
+    // VirtualPartitioning (clustering/interfaces/virtual_partitioning.hpp:9-14), trees read from disk, given partitions
+    static hmx_cluster_tree *import_tree(const htool::Cluster<double> &root, int dim) {
+        std::vector<hmx_cluster_node> nodes;
+        std::map<const htool::Cluster<double> *, int32_t> index;
+        std::vector<const htool::Cluster<double> *> stack{&root};
+        while (!stack.empty()) { // preorder: a node, then its children's subtrees in order
+            const htool::Cluster<double> *c = stack.back();
+            stack.pop_back();
+            index[c] = (int32_t)nodes.size();
+            hmx_cluster_node nd;
+            nd.depth = c->get_depth(), nd.offset = c->get_offset(), nd.size = c->get_size(), nd.rank = c->get_rank(), nd.counter = c->get_counter();
+            nd.n_children = (int32_t)c->get_children().size();
+            nd.radius     = c->get_radius();
+            for (int p = 0; p < 3; p++)
+                nd.center[p] = p < (int)c->get_center().size() ? c->get_center()[p] : 0.;
+            nodes.push_back(nd);
+            for (size_t k = c->get_children().size(); k-- > 0;)
+                stack.push_back(c->get_children()[k].get());
+        }
+        std::vector<int32_t> parts;
+        for (const auto *c : root.get_clusters_on_partition())
+            parts.push_back(index.at(c));
+        std::vector<int32_t> perm(root.get_permutation().begin(), root.get_permutation().end());
+        hmx_cluster_tree *t = nullptr;
+        if (!ok(hmx_cluster_tree_from_nodes(root.get_size(), dim, perm.data(), (int)nodes.size(), nodes.data(), (int)parts.size(), parts.data(), root.get_maximal_leaf_size(), root.is_permutation_local() ? 1 : 0, &t), "cluster tree import"))
+            return nullptr;
+        return t;
+    }
+
   public:
+    // htool's cluster trees are taken as they are (no rebuild, no options to match)
+    EngineT(const htool::Cluster<double> &target, const htool::Cluster<double> &source, int dim) {
+        m_square       = (&target == &source);
+        m_htool_target = &target;
+        m_htool_source = &source;
+        m_target       = import_tree(target, dim);
+        m_source       = m_square ? m_target : import_tree(source, dim);
+    }
+    // the tree is REBUILT by hmx's own cluster-tree builder from the coordinates and the options the caller gave htool's
+    // ClusterTreeBuilder (an error is logged when the permutations differ)
     EngineT(const htool::Cluster<double> &target, int nt, const double *xt, const htool::Cluster<double> &source, int ns, const double *xs, int dim, const ClusterOptions &opt) {
         m_square       = (&target == &source);
         m_htool_target = &target;

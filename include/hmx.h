@@ -105,6 +105,14 @@ int hmx_cluster_tree_create(int n, int dim, const double *coords /* n*dim, AoS *
 int hmx_cluster_tree_create_ex(int n, int dim, const double *coords, const double *radii, const double *weights, int maximal_leaf_size,
                                int number_of_children, int size_of_partition, int direction, int splitting, int partitioning_n,
                                int is_complete, const int32_t *partition, int partition_kind, hmx_cluster_tree **out);
+/* An EXISTING cluster tree instead of a built one: whatever made it (a user's VirtualPartitioning,
+ * clustering/interfaces/virtual_partitioning.hpp:9-14 through ClusterTreeBuilder::set_partitioning_strategy, tree_builder.hpp:40; a tree
+ * read from disk; another library).  `nodes` is the preorder walk of htool's Cluster (preorder_tree_traversal: a node, then its children's
+ * subtrees in order) with the fields of Cluster (get_depth / get_offset / get_size / get_rank / get_counter / get_children().size() /
+ * get_radius / get_center), `permutation` Cluster::get_permutation() of the root, partition_nodes[k] the index (in `nodes`) of
+ * get_clusters_on_partition()[k].  Checked: the permutation is one, children tile their parent in order, partitions tile the points. */
+int hmx_cluster_tree_from_nodes(int n, int dim, const int32_t *permutation, int num_nodes, const hmx_cluster_node *nodes, int num_partitions,
+                                const int32_t *partition_nodes, int maximal_leaf_size, int permutation_is_local, hmx_cluster_tree **out);
 void hmx_cluster_tree_destroy(hmx_cluster_tree *);
 int hmx_cluster_tree_size(const hmx_cluster_tree *);            /* number of points                         */
 int hmx_cluster_tree_num_nodes(const hmx_cluster_tree *);

@@ -117,7 +117,68 @@ static int check_user_admissibility() {
     std::printf("user admissibility: htool_leaves=%zu (default condition %zu) hmx_leaves=%zu missing=%zu calls=%ld\n", nleaves, ndefault, E.number_of_leaves(), missing, mine.calls);
     return (missing == 0 && nleaves == E.number_of_leaves() && nleaves != ndefault && mine.calls > 0) ? 0 : 1;
 }
+// a user's partitioning strategy hmx has no builder for: cut the current cluster along the coordinate axis (depth mod 3) at the 40 %
+// quantile (uneven children).  The adaptor must take htool's tree as it is.
+class SkewedAxisPartitioning final : public VirtualPartitioning<double> {
+  public:
+    std::vector<std::pair<int, int>> compute_partitioning(Cluster<double> &c, int dim, const double *x, const double *, const double *, int nparts) override {
+        auto &perm     = c.get_permutation();
+        const int off = c.get_offset(), size = c.get_size(), axis = c.get_depth() % dim;
+        std::stable_sort(perm.begin() + off, perm.begin() + off + size, [&](int a, int b) { return x[dim * a + axis] < x[dim * b + axis]; });
+        std::vector<std::pair<int, int>> parts;
+        int pos = off;
+        for (int p = 0; p < nparts; p++) {
+            int len = p == nparts - 1 ? off + size - pos : std::max(1, (int)(0.4 * (off + size - pos)));
+            parts.emplace_back(pos, len);
+            pos += len;
+        }
+        return parts;
+    }
+};
+static int check_imported_tree() {
+    const int n = 2200;
+    std::vector<double> x(3 * n);
+    create_sphere(n, x.data());
+    ClusterTreeBuilder<double> ctb;
+    ctb.set_maximal_leaf_size(45);
+    ctb.set_partitioning_strategy(std::make_shared<SkewedAxisPartitioning>());
+    Cluster<double> T = ctb.create_cluster_tree(n, 3, x.data(), 2, 2);
+    Gen A(x);
+    HMatrixTreeBuilder<double> tb(1e-3, 10., 'N', 'N');
+    HMatrix<double> H = tb.sequential_build(A, T, T);
+    hmx_htool::Engine E(T, T, 3); // no options, no coordinates: the tree is imported node for node
+    E.setup_block_tree(10., 'N', 'N', 0, 0, -1, -1, 0);
+    size_t nleaves = 0, missing = 0;
+    std::vector<const HMatrix<double> *> st{&H};
+    while (!st.empty()) {
+        auto *c = st.back(); st.pop_back();
+        if (c->is_leaf()) {
+            nleaves++;
+            int64_t leaf = E.find_leaf(c->get_target_cluster().get_offset(), c->get_target_cluster().get_size(), c->get_source_cluster().get_offset(), c->get_source_cluster().get_size());
+            if (leaf < 0 || (c->is_low_rank() != E.leaf_is_admissible(leaf) && c->is_low_rank())) missing++;
+        }
+        for (auto &ch : c->get_children()) st.push_back(ch.get());
+    }
+    // the row-restricted block tree of partition 1 on the imported tree as well
+    HMatrix<double> H1 = tb.sequential_build(A, T, T, 1, 1);
+    hmx_htool::Engine E1(T, T, 3);
+    E1.setup_block_tree(10., 'N', 'N', 0, 0, 1, 1, 0);
+    size_t n1 = 0, missing1 = 0;
+    st = {&H1};
+    while (!st.empty()) {
+        auto *c = st.back(); st.pop_back();
+        if (c->is_leaf()) {
+            n1++;
+            if (E1.find_leaf(c->get_target_cluster().get_offset(), c->get_target_cluster().get_size(), c->get_source_cluster().get_offset(), c->get_source_cluster().get_size()) < 0) missing1++;
+        }
+        for (auto &ch : c->get_children()) st.push_back(ch.get());
+    }
+    std::printf("imported tree (user partitioning): htool_leaves=%zu hmx_leaves=%zu missing=%zu | partition 1: htool_leaves=%zu hmx_leaves=%zu missing=%zu\n", nleaves, E.number_of_leaves(), missing, n1, E1.number_of_leaves(), missing1);
+    return (missing == 0 && nleaves == E.number_of_leaves() && missing1 == 0 && n1 == E1.number_of_leaves()) ? 0 : 1;
+}
 int main() {
+    if (check_imported_tree() != 0)
+        return 4;
     if (check_complex() != 0)
         return 2;
     if (check_user_admissibility() != 0)

@@ -162,3 +162,36 @@ def test_user_admissibility_condition_on_local_block_trees():
     tb.set_admissibility_condition(lambda t, s, eta: False)
     dense = tb.build_local_block_tree(T, S, p["local"], p["local"]).leaves
     assert dense["admissible"].sum() == 0 and len(dense) != len(ref)
+
+
+def test_cluster_tree_from_nodes_round_trip_and_validation():
+    """hmx_cluster_tree_from_nodes: an existing tree given as its preorder node table (the route for a user's VirtualPartitioning,
+    clustering/interfaces/virtual_partitioning.hpp:9-14) gives the same block tree as the tree it was exported from; malformed tables
+    are refused (permutation, tiling of children, partitions)."""
+    import htool_amd as hm
+    n = 3000
+    x = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(60)
+    for children, parts in ((2, 4), (3, 3)):
+        T = b.create_cluster_tree(n, 3, x, children, parts)
+        ni, nr = T.nodes_int(), T.nodes_real()
+        part = T.get_clusters_on_partition()
+        depth = int(round(np.log(parts) / np.log(children)))
+        idx = [int(np.nonzero((ni[:, 0] == depth) & (ni[:, 1] == o) & (ni[:, 2] == s))[0][0]) for o, s in part]
+        T2 = hm.cluster_tree_from_nodes(T.get_permutation(), ni, nr, idx, 60, x)
+        assert np.array_equal(T2.nodes_int(), ni) and np.array_equal(T2.nodes_real(), nr)
+        assert np.array_equal(T2.get_clusters_on_partition(), part) and np.array_equal(T2.get_permutation(), T.get_permutation())
+        tb = hm.HMatrixTreeBuilder(1e-3, 10.0, "S", "L")
+        for rank in (-1, 1):
+            assert np.array_equal(tb.build_block_tree(T, T, rank, rank).leaves, tb.build_block_tree(T2, T2, rank, rank).leaves)
+    bad = T.get_permutation().copy()
+    bad[0] = bad[1]
+    with pytest.raises(hm.HmxError, match="permutation"):
+        hm.cluster_tree_from_nodes(bad, ni, nr, idx, 60, x)
+    ni_bad = ni.copy()
+    ni_bad[1, 2] -= 1  # first child no longer tiles the root with its siblings
+    with pytest.raises(hm.HmxError, match="children|tile|cover"):
+        hm.cluster_tree_from_nodes(T.get_permutation(), ni_bad, nr, idx, 60, x)
+    with pytest.raises(hm.HmxError, match="partition"):
+        hm.cluster_tree_from_nodes(T.get_permutation(), ni, nr, idx[:-1], 60, x)

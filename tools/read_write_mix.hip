@@ -30,7 +30,19 @@ __global__ __launch_bounds__(256) void rw(const d2 *__restrict__ in, double *__r
                 out[(((int64_t)blockIdx.x * 2654435761u + k * 40503u + wave) % (out_elems / 64)) * 64 + lane] = (s0 + s1) + (s2 + s3); // scattered 512-byte runs
             else if (MODE == 4)
                 __builtin_nontemporal_store((s0 + s1) + (s2 + s3), mine + k * 64 + lane); // contiguous per wave, non-temporal
-            else if (MODE == 6) // one fixed 512-byte run per wave, the runs `win` x 512 bytes apart
+            else if (MODE == 7) { // contiguous per wave, but only every 8th workgroup writes (8 runs each time): the same volume from 1/8 of the CUs
+                if ((blockIdx.x & 7) == 0)
+                    for (int q = 0; q < 8; q++)
+                        mine[(k * 8 + q) * 64 + lane] = (s0 + s1) + (s2 + s3);
+            } else if (MODE == 8) { // contiguous per wave, write-through to memory (sc0 sc1)
+                double v = (s0 + s1) + (s2 + s3);
+                double *pp = mine + k * 64 + lane;
+                asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(pp), "v"(v) : "memory");
+            } else if (MODE == 9) { // contiguous per wave, nt + sc1 (streaming)
+                double v = (s0 + s1) + (s2 + s3);
+                double *pp = mine + k * 64 + lane;
+                asm volatile("global_store_dwordx2 %0, %1, off nt sc1" ::"v"(pp), "v"(v) : "memory");
+            } else if (MODE == 6) // one fixed 512-byte run per wave, the runs `win` x 512 bytes apart
                 out[(((int64_t)blockIdx.x * 4 + wave) * win % (out_elems / 64)) * 64 + lane] = (s0 + s1) + (s2 + s3);
             else // contiguous per wave inside a window of `win` elements per wave (the whole grid writes 4096 * win * 8 bytes, again and again)
                 mine[(k % (win / 64)) * 64 + lane] = (s0 + s1) + (s2 + s3);
@@ -69,6 +81,9 @@ int main() {
         printf("every 2, window %.0f MB: contiguous-in-window %.0f GB/s\n", 4096.0 * win * 8 / 1e6, run(rw<5>, a, o, n, 2, oe, win));
     for (int stride : {1, 8, 128, 509, 512, 4096})
         printf("every 2, one fixed 512-byte run per wave, runs %d x 512 bytes apart: %.0f GB/s\n", stride, run(rw<6>, a, o, n, 2, oe, stride));
+    printf("every 2: same volume written by every 8th workgroup only: %.0f GB/s\n", run(rw<7>, a, o, n, 2, oe));
+    printf("every 2: contiguous, sc0 sc1 stores: %.0f GB/s\n", run(rw<8>, a, o, n, 2, oe));
+    printf("every 2: contiguous, nt sc1 stores: %.0f GB/s\n", run(rw<9>, a, o, n, 2, oe));
     printf("every 2: contiguous non-temporal store %.0f GB/s\n", run(rw<4>, a, o, n, 2, oe));
     return 0;
 }
