@@ -1191,8 +1191,9 @@ __global__ void combine_kernel(CombineArgs A) {
     A.Z[A.dst[e]] = (s0 + s1) + (s2 + s3);
 }
 
-// the same for entries with many partial sums (a mirrored low-rank leaf of 15 625 rows has one per 64-row range): one wave per
-// entry, lane l adds the partial sums l, l + 64, ..., then a fixed all-reduce over the lanes -- reproducible, and 64 loads in flight
+// fixed-order all-reduce over the 64 lanes without LDS (v_permlane32_swap, v_permlane16_swap, DPP row operations): every lane returns
+// the same sum, the order of the additions does not depend on anything but the lane layout -- used where one wave folds many partial
+// sums (combine_list_wave_kernel)
 __device__ __forceinline__ scalar wave_sum_dpp(scalar s) {
     scalar a = s, b = s;
     lane_swap32(a, b);
@@ -1206,21 +1207,6 @@ __device__ __forceinline__ scalar wave_sum_dpp(scalar s) {
     s += dpp_move<0x4E>(s);
     return s;
 }
-__global__ __launch_bounds__(256) void combine_wave_kernel(CombineArgs A) {
-    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (e >= A.n)
-        return;
-    const int lane  = threadIdx.x & 63;
-    const scalar *p = A.Z + A.src[e];
-    const int st = A.stride[e], cnt = A.count[e];
-    scalar s = scalar(0);
-    for (int k = lane; k < cnt; k += 64)
-        s += p[(int64_t)k * st];
-    s = wave_sum_dpp(s);
-    if (lane == 0)
-        A.Z[A.dst[e]] = s;
-}
-
 // Stage 2 (dense leaves: add_matrix_vector_product.hpp:18; low rank: add_lrmat_vector_product.hpp:17,
 // y += U a; final alpha/beta as openmp_internal_add_hmatrix_vector_product :134-136,168):
 // one workgroup per target row range, lane = row, the waves split the columns in 64-column chunks.

@@ -63,6 +63,20 @@ SCRIPT = textwrap.dedent('''
                 err = np.linalg.norm(y - ref) / np.linalg.norm(ref)
                 assert err < (1e-5 if dtype == np.float32 else 1e-13), (np.dtype(dtype).name, trans, fn.__name__, err)
                 hip.hipFree(dx); hip.hipFree(dy)
+        # the overlapped exchange (row-chunked expand stage, every chunk's rows exchanged on the side stream): with
+        # HMX_DIST_FORCE_COLLECTIVES=1 through the real RCCL (all-gather of the chunk bounds, grouped broadcasts, events)
+        ref = y0.copy()
+        hm.internal_add_hmatrix_vector_product("N", ab[0], H, xin, ab[1], ref)
+        for chunks in (2, 3, 0):
+            check(L.hmx_dist_set_overlap(D, chunks, None))
+            used = L.hmx_dist_overlap_chunks(D)
+            assert used == (chunks if os.environ.get("HMX_DIST_FORCE_COLLECTIVES") else 0), (chunks, used)
+            dx, dy = dev(xin), dev(y0)
+            check(L.hmx_dist_matvec_global_to_global(D, b"N", pa, dx, pb, dy, None))
+            assert hip.hipDeviceSynchronize() == 0
+            err = np.linalg.norm(host(dy, y0) - ref) / np.linalg.norm(ref)
+            assert err < (1e-5 if dtype == np.float32 else 1e-13), (np.dtype(dtype).name, "overlap", chunks, err)
+            hip.hipFree(dx); hip.hipFree(dy)
         L.hmx_dist_destroy(D)
         print("ok", np.dtype(dtype).name)
 ''') % ROOT
