@@ -1045,6 +1045,9 @@ struct ReduceArgs {
 #ifndef HMX_REDUCE_ROWS
 #define HMX_REDUCE_ROWS 1
 #endif
+#ifndef HMX_REDUCE_UNROLL_NARROW
+#define HMX_REDUCE_UNROLL_NARROW 16
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6)); // wave-uniform
@@ -1132,18 +1135,20 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
         }
         return;
     }
+    // rows in flight per wave: 8 for 16-byte loads (1 KiB per row and wave), 16 when a lane's pair is only 8 bytes (fp32: 512 B per row)
+    constexpr int RU = sizeof(scalar2) <= 8 ? HMX_REDUCE_UNROLL_NARROW : 8;
     for (int i0 = 0; i0 < len; i0 += 64) {
         const int nr    = (len - i0) < 64 ? (len - i0) : 64;
         const scalar xv = lane < nr ? xs[i0 + lane] : scalar(0);
         const scalar *p = src + (int64_t)i0 * wp;
         int j = 0;
-        for (; j + 8 <= nr; j += 8) {
-            scalar2 v[8];
+        for (; j + RU <= nr; j += RU) {
+            scalar2 v[RU];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < RU; u++)
                 v[u] = load_pair(p + (int64_t)(j + u) * wp, col0, col1, wp);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < RU; u++) {
                 const scalar xi = readlane_val(xv, j + u);
                 a0              = hmx_fma(v[u].x, xi, a0);
                 a1              = hmx_fma(v[u].y, xi, a1);
@@ -1945,9 +1950,9 @@ struct ExpandSymArgs {
     const scalar *xrow;  // the input at the TARGET positions of this operator: xrow[range_off + i]
     int herm;            // 'H' storage: the mirrored leaf is the conjugate transpose
 };
-// The wave's columns are walked in groups of eight, flattened over its 64-column tiles and software-pipelined: the loads of
-// group g + 1 are issued before group g is reduced, so the dependent chain of the eight-way reduction never leaves the wave
-// without loads in flight.
+// The wave's columns are walked in groups of eight (sixteen for 4-byte coefficients), flattened over its 64-column tiles and
+// software-pipelined: the loads of group g + 1 are issued before group g is reduced, so the dependent chain of the eight-way
+// reduction never leaves the wave without loads in flight.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
     const ExpandArgs &A = S.X;
@@ -1966,15 +1971,17 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
     // always eight loads, no branches (the compiler can then count them: s_waitcnt vmcnt(8) keeps the next group in flight while
     // this one is used): beyond the last column of the range the last column is read again -- its products meet the zero
     // coefficients of the lanes >= nc and its column sums are never stored
-    auto load_group = [&](scalar(&v)[8], int c0, int j) {
+    // (4-byte coefficients: groups of sixteen, reduced as two eights -- a wave's load is then only 256 bytes, sixteen are needed in flight)
+    constexpr int GS = sizeof(scalar) == 4 ? 16 : 8;
+    auto load_group = [&](scalar(&v)[GS], int c0, int j) {
         const int last    = C - c0 - j - 1; // >= 0
         const scalar *col = E + (int64_t)(c0 + j) * len + row;
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < GS; u++)
             v[u] = stream_load(col + (int64_t)(u < last ? u : last) * len);
     };
     auto advance = [&](int &c0, int &j) {
-        j += 8;
+        j += GS;
         if (j >= 64 || c0 + j >= C) {
             c0 += WAVES * 64;
             j = 0;
@@ -1989,15 +1996,20 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
         md  = lane < nc ? mdst[c0 + lane] : -1;
         mir = __any(md >= 0); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
     };
-    auto process = [&](const scalar(&v)[8], int j) {
+    auto process = [&](const scalar(&v)[GS], int jg) {
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-            acc = hmx_fma(v[u], readlane_val(z, (j + u) & 63), acc);
-        if (mir) {
+        for (int u = 0; u < GS; u++)
+            acc = hmx_fma(v[u], readlane_val(z, (jg + u) & 63), acc);
+        if (mir)
+#pragma unroll
+            for (int h = 0; h < GS; h += 8) {
+            const int j = jg + h;
+            if (j >= nc)
+                break;
             scalar p[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                p[u] = (herm ? hmx_conj(v[u]) : v[u]) * xr;
+                p[u] = (herm ? hmx_conj(v[h + u]) : v[h + u]) * xr;
             // every lane of lane group s = lane >> 3 now holds the sum of column j + s; lane 8 s + g keeps the one of group g = j / 8,
             // so that after the tile's last group an 8 x 8 transposition of the lane index (one ds_bpermute) puts the sum of
             // column c into lane c: ONE coalesced store per tile instead of eight 8-lane stores.  (What the stores cost is the write
@@ -2015,7 +2027,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
     // order inside a step: (tile setup, its own dependent loads) -> prefetch of the next group -> arithmetic on the current
     // one; the prefetch is unconditional (past the end it re-reads the current group) so that exactly eight newer loads are
     // outstanding whenever a group is consumed
-    scalar va[8], vb[8];
+    scalar va[GS], vb[GS];
     int c0 = wv * 64, j = 0;
     if (c0 < C)
         load_group(va, c0, 0);
@@ -2094,40 +2106,48 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSym
     scalar mine     = scalar(0);
     scalar *dst     = A.W + rb;
     // eight rows per reduction, the next eight already in flight (same pipelining as expand_sym_kernel)
-    // always eight loads, no branches: rows beyond the piece re-read its last row (their sums are never stored), lanes beyond
-    // the chunk read column 0 and multiply it with their zero coefficients
-    auto load_rows = [&](scalar2(&e)[8], int i0) {
+    // always GS loads, no branches: rows beyond the piece re-read its last row (their sums are never stored), lanes beyond
+    // the chunk read column 0 and multiply it with their zero coefficients.  GS = 8 rows per group, 16 when a lane's pair is only
+    // 8 bytes (fp32), reduced eight at a time.
+    constexpr int GS = sizeof(scalar2) <= 8 ? 16 : 8;
+    auto load_rows = [&](scalar2(&e)[GS], int i0) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < GS; u++) {
             const int i = i0 + u < len ? i0 + u : len - 1;
             e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
         }
     };
-    auto process = [&](const scalar2(&e)[8], int i0) {
-        scalar v[8];
+    auto process = [&](const scalar2(&e)[GS], int ig) {
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-            v[u] = herm ? hmx_fma(hmx_conj(e[u].x), c0, hmx_conj(e[u].y) * c1) : hmx_fma(e[u].x, c0, e[u].y * c1);
-        // as in expand_sym_kernel: lane 8 s + g keeps the sum of row 64 b + 8 g + s, one transposing ds_bpermute and ONE coalesced
-        // store per 64 rows
-        const scalar r = reduce8(v, lane);
-        const int g    = (i0 >> 3) & 7;
-        mine           = (lane & 7) == g ? r : mine;
-        if (g == 7 || i0 + 8 >= len) {
-            const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
-            const int i    = (i0 & ~63) + lane;
-            if (i < len)
-                dst[i] = t;
+        for (int h = 0; h < GS; h += 8) {
+            const int i0 = ig + h;
+            if (i0 >= len)
+                break;
+            scalar v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                v[u] = herm ? hmx_fma(hmx_conj(e[h + u].x), c0, hmx_conj(e[h + u].y) * c1) : hmx_fma(e[h + u].x, c0, e[h + u].y * c1);
+            // as in expand_sym_kernel: lane 8 s + g keeps the sum of row 64 b + 8 g + s, one transposing ds_bpermute and ONE coalesced
+            // store per 64 rows
+            const scalar r = reduce8(v, lane);
+            const int g    = (i0 >> 3) & 7;
+            mine           = (lane & 7) == g ? r : mine;
+            if (g == 7 || i0 + 8 >= len) {
+                const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
+                const int i    = (i0 & ~63) + lane;
+                if (i < len)
+                    dst[i] = t;
+            }
         }
     };
-    scalar2 ea[8], eb[8];
+    scalar2 ea[GS], eb[GS];
     load_rows(ea, 0);
-    for (int i0 = 0; i0 < len; i0 += 16) { // unconditional prefetches (clamped to the last row): exactly eight newer loads outstanding at every use
-        load_rows(eb, i0 + 8);
+    for (int i0 = 0; i0 < len; i0 += 2 * GS) { // unconditional prefetches (clamped to the last row): exactly GS newer loads outstanding at every use
+        load_rows(eb, i0 + GS);
         process(ea, i0);
-        load_rows(ea, i0 + 16);
-        if (i0 + 8 < len)
-            process(eb, i0 + 8);
+        load_rows(ea, i0 + 2 * GS);
+        if (i0 + GS < len)
+            process(eb, i0 + GS);
     }
 }
 
