@@ -411,7 +411,9 @@ static int build_streams(HMat &H) {
     // lines cost nothing measurable.)  The READERS gather: combine_list_kernel folds the partial a' of a leaf that spans several
     // ranges through a list of its column-group positions, sym_finish_kernel adds the contributions of an output row through a
     // level-major index array.  All in a fixed order: results are bit-reproducible.
-    std::vector<int32_t> s_mdst, s_coef, s_cnt, s_cd, s_clp, s_cc, s_ck, s_list, s_fidx;
+    std::vector<int32_t> s_mdst, s_coef, s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
+    std::unique_ptr<int32_t[]> s_fidx; // level-major, s_kmax x nT: left uninitialised (only the entries below count[j] are ever read)
+    size_t s_fidx_n = 0;
     std::vector<int64_t> s_rowbase;
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
@@ -440,24 +442,32 @@ static int build_streams(HMat &H) {
                 lptr[b] = LN;
                 LN += nrange[b];
             }
+        phase("  sym: setup");
         s_list.assign(LN, 0);
         std::vector<int64_t> single_slot(nb, -1);
         {
-            std::vector<int32_t> seen(nb, 0); // pairs of a leaf are consecutive in elr_* (leaf-major): position inside the leaf's list
-            for (size_t p = 0; p < elr_b.size(); p++) {
-                const int b = elr_b[p], r = elr_r[p];
-                if (!XL[b].mirror)
-                    continue;
-                const int64_t base = EWBASE + epad[r] + elr_c[p];
-                if (nrange[b] == 1)
-                    single_slot[b] = base;
-                else
-                    s_list[lptr[b] + seen[b]++] = (int32_t)base;
-                int32_t *dst = s_mdst.data() + E.colbase[r] + elr_c[p];
-                for (int k = 0; k < XL[b].rank; k++)
-                    dst[k] = (int32_t)(base + k);
-            }
+            // the pairs of a leaf are consecutive in elr_* (leaf-major) and cover consecutive ranges: position in the leaf's list = r - first range
+            std::vector<int32_t> first_range(nb, -1);
+            for (size_t p = 0; p < elr_b.size(); p++)
+                if (first_range[elr_b[p]] < 0)
+                    first_range[elr_b[p]] = elr_r[p];
+            parallel_for(elr_b.size(), [&](size_t lo, size_t hi) {
+                for (size_t p = lo; p < hi; p++) {
+                    const int b = elr_b[p], r = elr_r[p];
+                    if (!XL[b].mirror)
+                        continue;
+                    const int64_t base = EWBASE + epad[r] + elr_c[p];
+                    if (nrange[b] == 1)
+                        single_slot[b] = base;
+                    else
+                        s_list[lptr[b] + (r - first_range[b])] = (int32_t)base;
+                    int32_t *dst = s_mdst.data() + E.colbase[r] + elr_c[p];
+                    for (int k = 0; k < XL[b].rank; k++)
+                        dst[k] = (int32_t)(base + k);
+                }
+            });
         }
+        phase("  sym: lr columns");
         H.n_sym_combine_wave = 0;
         for (int pass = 0; pass < 2; pass++) // entries with many partial sums first (one wave each), then the rest (one thread each)
             for (int64_t b = 0; b < nb; b++)
@@ -471,6 +481,7 @@ static int build_streams(HMat &H) {
                     if (pass == 0)
                         H.n_sym_combine_wave += XL[b].rank;
                 }
+        phase("  sym: combine entries");
         parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
             for (size_t p = lo; p < hi; p++) {
                 const int b = rlr_b[p];
@@ -482,6 +493,7 @@ static int build_streams(HMat &H) {
                     dst[k] = (int32_t)(base + k);
             }
         });
+        phase("  sym: coef");
         // tasks of the second R sweep with at least one mirrored column: a contiguous piece of RW each
         const size_t ntask = R.task_range.size();
         s_rowbase.assign(ntask, -1);
@@ -505,6 +517,7 @@ static int build_streams(HMat &H) {
             for (int i = 0; i < R.len[r]; i++)
                 s_cnt[j0 + i]++;
         }
+        phase("  sym: tasks");
         // contributions per output row: dense mirrored columns (in EW) and task rows (in RW), numbered in layout order ("levels")
         for (size_t p = 0; p < ed_b.size() && !bad; p++) {
             const hmx_leaf &l = XL[ed_b[p]];
@@ -529,7 +542,9 @@ static int build_streams(HMat &H) {
             set_error("operator too large for 32-bit slots of the fused symmetric product (HMX_SYM_EXPANDED=1 selects the expanded layout)");
             return HMX_ERR_UNSUPPORTED;
         }
-        s_fidx.assign((size_t)H.s_kmax * H.nT, -1);
+        phase("  sym: dense count");
+        s_fidx_n = (size_t)H.s_kmax * H.nT;
+        s_fidx.reset(new int32_t[std::max<size_t>(s_fidx_n, 1)]);
         std::vector<int32_t> fill(H.nT, 0);
         for (size_t p = 0; p < ed_b.size(); p++) { // dense pairs first (leaf-major), then the tasks in launch order
             const int b = ed_b[p], r = ed_r[p];
@@ -551,6 +566,7 @@ static int build_streams(HMat &H) {
             for (int i = 0; i < R.len[r]; i++)
                 s_fidx[(size_t)(fill[j0 + i]++) * H.nT + (j0 + i)] = (int32_t)(s_rowbase[t] + i);
         }
+        phase("  sym: fidx fill");
         H.n_sym_combine = (int)s_cd.size();
         phase("fused symmetric slots");
     }
@@ -581,7 +597,9 @@ static int build_streams(HMat &H) {
         HMX_HIP(H.sc_count.upload(s_cc));
         HMX_HIP(H.sc_k.upload(s_ck));
         HMX_HIP(H.s_list.upload(s_list));
-        HMX_HIP(H.s_fidx.upload(s_fidx));
+        HMX_HIP(H.s_fidx.alloc(std::max<size_t>(s_fidx_n, 1)));
+        if (s_fidx_n)
+            HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
         HMX_HIP(H.SW.alloc(s_total + 1));
     } else {
         for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx})
