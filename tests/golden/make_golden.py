@@ -126,6 +126,13 @@ FULL_CASES = {
 }
 
 
+# BASELINE configs[3]: the N=1e6 operator row-partitioned over 8 ranks (DistributedOperator: rank k owns the block rows of partition
+# cluster k of the tree built with size_of_partition = 8).  One reference run per rank (target_partition_number = k): structure hash,
+# ranks and the rank-local product at sampled local rows -- what rank k of htool's MPI run computes before the Allgatherv.
+FULL_CASES.update({"full_ellipse_n1000000_p8_rank%d" % r: dict(n=1000000, geom="ellipse", leaf=100, eps=1e-4, eta=10, compressor="partialACA", mindepth=5, partitions=8, rank=r)
+                   for r in range(8)})
+
+
 def sample_rows(n):
     """SAMPLE distinct fixed rows, spread over the whole range (closed form: reproducible in the test)."""
     return np.unique((np.arange(SAMPLE, dtype=np.int64) * 2654435761 + 12345) % n)
@@ -144,7 +151,7 @@ def make_full(only):
             d = read_dump(tmp.name)
         leaves = np.ascontiguousarray(d["leaves"], dtype=np.int32)
         structure = np.ascontiguousarray(leaves[:, [0, 1, 2, 3, 5]])
-        rows = sample_rows(params["n"])
+        rows = sample_rows(len(np.asarray(d["yN"])))  # local rows of a row-restricted operator
         out = dict(
             perm_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(d["t_perm"], dtype=np.int32).tobytes()).digest(), dtype=np.uint8),
             structure_sha256=np.frombuffer(hashlib.sha256(structure.tobytes()).digest(), dtype=np.uint8),

@@ -2,7 +2,9 @@
 
 tests/golden/full_*.npz were written by htool (oracle/_ref/ref_driver, `python tests/golden/make_golden.py full`): N=1e5 ball and
 ellipse, N=1e6 ellipse with the bench's minimal block depth, the symmetric ('S','L', sympartialACA) N=1e5 operators and BASELINE
-config 5's shape (fp32, 'S','L', eps=1e-6, 16 right-hand sides) at N=1e5.  A fixture holds sha256 of the cluster permutation and of
+config 5's shape (fp32, 'S','L', eps=1e-6, 16 right-hand sides) at N=1e5, and BASELINE configs[3] rank by rank: the N=1e6 operator
+row-partitioned over 8 ranks (`full_ellipse_n1000000_p8_rank<k>`: what rank k of htool's DistributedOperator holds and multiplies
+before the Allgatherv), each rank's share built and multiplied on the one GPU a box has.  A fixture holds sha256 of the cluster permutation and of
 the leaf table's structure columns, the rank of every leaf, and the reference's products at 4096 fixed rows.  Here the engine
 builds the same operator on the GPU: permutation and block structure must hash equal, every rank must equal the reference's, and
 the sampled products must agree to 1e-10 (fp64; 2e-5 for the fp32 operator -- the fp32 floor SURVEY.md App. D states)."""
@@ -33,13 +35,15 @@ def test_full_size_matches_the_reference(name):
     x = hm.create_geometry(p["geom"], n)
     b = hm.ClusterTreeBuilder()
     b.set_maximal_leaf_size(p["leaf"])
-    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    parts, rank = p.get("partitions", 2), p.get("rank", -1)  # rank >= 0: the block rows of partition `rank` (DistributedOperator's local operator)
+    T = b.create_cluster_tree(n, 3, x, 2, parts)
     assert np.array_equal(_sha(np.asarray(T.get_permutation(), dtype=np.int32)), g["perm_sha256"]), "cluster permutation differs from the reference's"
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], sym, uplo)
     tb.set_low_rank_generator(p["compressor"])
     tb.set_minimal_target_depth(p.get("mindepth", 0))
     tb.set_minimal_source_depth(p.get("mindepth", 0))
-    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, dtype=np.float32 if f32 else np.float64)
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, rank, rank, dtype=np.float32 if f32 else np.float64)
+    nr = H.nb_rows()
     tab = np.asarray(H.leaf_table())
     assert len(tab) == int(g["nleaves"])
     assert np.array_equal(_sha(tab[:, [0, 1, 2, 3, 5]].astype(np.int32)), g["structure_sha256"]), "block structure differs from the reference's"
@@ -64,15 +68,15 @@ def test_full_size_matches_the_reference(name):
     def err(a, ref):
         return float(np.linalg.norm(a.astype(np.float64) - ref) / np.linalg.norm(ref))
 
-    y = np.zeros(n, dtype=dt)
+    y = np.zeros(nr, dtype=dt)
     hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y)
     e1 = err(y[rows], g["yN_a1b0"])
     al, be = float(g["alphabeta"][0]), float(g["alphabeta"][1])
-    y = hashed_vector(n, 3).astype(dt)
+    y = hashed_vector(nr, 3).astype(dt)
     hm.internal_add_hmatrix_vector_product("N", al, H, xin, be, y)
     e2 = err(y[rows], g["yN"])
     X = hashed_vector(n * mu, 5).astype(dt).reshape(n, mu)
-    Y = hashed_vector(n * mu, 6).astype(dt).reshape(n, mu)
+    Y = hashed_vector(nr * mu, 6).astype(dt).reshape(nr, mu)
     hm.internal_add_hmatrix_matrix_product_row_major("N", al, H, X, be, Y, mu)
     e3 = err(Y[rows], g["YNrm"])
     print("%s: relative error vs the reference at %d rows: %.2e (alpha=1, beta=0), %.2e (alpha=%g, beta=%g), %.2e (%d right-hand sides)" % (name, len(rows), e1, e2, al, be, e3, mu))
