@@ -235,6 +235,42 @@ MOCK_SCRIPT = textwrap.dedent('''
         for D in Ds:
             L.hmx_dist_destroy(D)
         print("ok", np.dtype(dtype).name)
+    # symmetric storage: the diagonal block of every rank is fused (mirrored contributions reach rows after the expand stage), so the
+    # operators cannot be chunked -- hmx_dist_set_overlap must make ALL ranks keep the single exchange, and the product stays right
+    tb = hm.HMatrixTreeBuilder(1e-6, 10.0, "S", "L"); tb.set_low_rank_generator("sympartialACA")
+    gen = hm.InvDistGenerator(3, x3, x3, 1e-5, 1.0)
+    Hfull = tb.build(gen, T, T)
+    Hloc = [tb.build(gen, T, T, k, k) for k in range(WORLD)]
+    Ds = []
+    for k in range(WORLD):
+        D = C.c_void_p()
+        check(L.hmx_dist_create(Hloc[k]._h, T._h, T._h, C.c_void_p(k + 1), k, WORLD, C.byref(api), C.byref(D)))
+        Ds.append(D)
+    xin, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    ab = np.array([1.5, 0.25])
+    pa, pb = C.c_void_p(ab.ctypes.data), C.c_void_p(ab.ctypes.data + ab.itemsize)
+    ref = y0.copy()
+    hm.internal_add_hmatrix_vector_product("N", ab[0], Hfull, xin, ab[1], ref)
+    errs, fails = [None] * WORLD, []
+    def sym_rank(k):
+        try:
+            check(L.hmx_dist_set_overlap(Ds[k], 3, None))
+            assert L.hmx_dist_overlap_chunks(Ds[k]) == 0
+            dx, dy = dev(xin), dev(y0)
+            check(L.hmx_dist_matvec_global_to_global(Ds[k], b"N", pa, dx, pb, dy, None))
+            assert hip.hipDeviceSynchronize() == 0
+            errs[k] = np.linalg.norm(host(dy, y0) - ref) / np.linalg.norm(ref)
+        except BaseException as e:
+            fails.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=sym_rank, args=(k,)) for k in range(WORLD)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not fails, fails
+    assert max(errs) < 1e-12, errs
+    for D in Ds:
+        L.hmx_dist_destroy(D)
+    print("ok symmetric")
     print("calls", calls)
     equal = len(set(int(p[1]) for p in parts)) == 1
     assert calls["all_reduce"] > 0 and calls["broadcast"] > 0 and calls["all_gather"] > 0, calls
@@ -254,5 +290,5 @@ def test_c_level_distributed_operator_multi_rank_with_mock_collectives(world):
     out = subprocess.run([sys.executable, "-c", MOCK_SCRIPT, str(world)], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HMX_NO_TORCH="1"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert out.stdout.count("ok ") == 2 and "calls" in out.stdout, out.stdout
+    assert out.stdout.count("ok ") == 3 and "calls" in out.stdout, out.stdout
     print(out.stdout)
