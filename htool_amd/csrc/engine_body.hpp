@@ -41,7 +41,9 @@ struct HMat {
     // compact symmetric storage, fused product (expand_sym_kernel / rowreduce_sym_kernel): slots in SW = [a' | partial a' | levels]
     bool sym_fused = false;
     DArr<int32_t> s_mdst, s_coef, s_count, s_list, s_fidx;
-    DArr<int64_t> s_task_rowbase;
+    DArr<int64_t> s_sub_ptr;
+    DArr<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order; // second R sweep: per row interval the (parts of) tasks inside it
+    int s_nint = 0;
     DArr<int32_t> sc_dst, sc_lp, sc_count, sc_k;
     int n_sym_combine = 0, n_sym_combine_wave = 0; // the first n_sym_combine_wave entries have >= 32 partial sums: one wave each
     int s_kmax        = 0;
@@ -406,7 +408,7 @@ static int build_streams(HMat &H) {
 
     // ---- fused symmetric product: slots of the mirrored partial results ----------------------------------------------------
     // W = [a' | EW | RW].  Every WRITER owns a contiguous, 128-byte aligned piece: expand_sym_kernel stores the column sums of a
-    // row range at EW[epad(range) + column] (E-column order), rowreduce_sym_kernel the rows of a task at RW[rowbase(task) + row].
+    // row range at EW[epad(range) + column] (E-column order); the second R sweep (rowsym_kernel) folds its row sums on chip.
     // (Scattered 8- to 72-byte writes into per-destination slots cost 10-20 % of those kernels in partial-line HBM writes; whole
     // lines cost nothing measurable.)  The READERS gather: combine_list_kernel folds the partial a' of a leaf that spans several
     // ranges through a list of its column-group positions, sym_finish_kernel adds the contributions of an output row through a
@@ -414,7 +416,8 @@ static int build_streams(HMat &H) {
     std::vector<int32_t> s_mdst, s_coef, s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
     std::unique_ptr<int32_t[]> s_fidx; // level-major, s_kmax x nT: left uninitialised (only the entries below count[j] are ever read)
     size_t s_fidx_n = 0;
-    std::vector<int64_t> s_rowbase;
+    std::vector<int64_t> s_sub_ptr;
+    std::vector<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order;
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
     int64_t s_total = 0;
@@ -494,10 +497,15 @@ static int build_streams(HMat &H) {
             }
         });
         phase("  sym: coef");
-        // tasks of the second R sweep with at least one mirrored column: a contiguous piece of RW each
+        // Second R sweep, owner-computes: the target rows are cut into intervals of SYM_IR rows and ONE workgroup per interval applies
+        // every (piece, chunk) task -- or the part of it -- whose rows lie in the interval, folds the row sums of its waves in LDS,
+        // adds the interval's dense mirrored contributions (EW, through the level index) and updates y once.  No partial row sums
+        // leave the chip (they were 76 MB per product at N=1e6, written and read again), no separate folding kernel.
         const size_t ntask = R.task_range.size();
-        s_rowbase.assign(ntask, -1);
-        int64_t RWN = 0;
+        const int IR       = SYM_IR;
+        const int nint     = (H.nT + IR - 1) / IR;
+        std::vector<int64_t> sub_count(nint + 1, 0);
+        std::vector<char> task_mirror(ntask, 0);
         for (size_t t = 0; t < ntask; t++) {
             const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
             const int w = std::min(cw, R.cols[r] - ch * cw);
@@ -512,13 +520,43 @@ static int build_streams(HMat &H) {
                 bad = true;
                 break;
             }
-            s_rowbase[t] = RWBASE + RWN;
-            RWN += (R.len[r] + 15) & ~15;
-            for (int i = 0; i < R.len[r]; i++)
-                s_cnt[j0 + i]++;
+            task_mirror[t] = 1;
+            for (int I = j0 / IR; I <= (j0 + R.len[r] - 1) / IR; I++)
+                sub_count[I + 1]++;
         }
+        for (int I = 0; I < nint; I++)
+            sub_count[I + 1] += sub_count[I];
+        s_sub_ptr = sub_count;
+        const int64_t nsub = sub_count[nint];
+        s_sub_task.assign(nsub, 0);
+        s_sub_row0.assign(nsub, 0);
+        s_sub_nrows.assign(nsub, 0);
+        s_sub_dst.assign(nsub, 0);
+        std::vector<double> int_work(nint, 0.0);
+        {
+            std::vector<int64_t> pos(sub_count.begin(), sub_count.end() - 1);
+            for (size_t t = 0; t < ntask && !bad; t++) { // launch order of the tasks = order inside every interval's list
+                if (!task_mirror[t])
+                    continue;
+                const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
+                const int w = std::min(cw, R.cols[r] - ch * cw);
+                const int j0 = R.off[r] + H.S0 - H.T0, j1 = j0 + R.len[r];
+                for (int I = j0 / IR; I <= (j1 - 1) / IR; I++) {
+                    const int lo = std::max(j0, I * IR), hi = std::min(j1, (I + 1) * IR);
+                    const int64_t q = pos[I]++;
+                    s_sub_task[q]  = (int32_t)t;
+                    s_sub_row0[q]  = lo - j0;
+                    s_sub_nrows[q] = hi - lo;
+                    s_sub_dst[q]   = lo - I * IR;
+                    int_work[I] += (double)(hi - lo) * w + 256;
+                }
+            }
+        }
+        s_int_order.resize(nint);
+        std::iota(s_int_order.begin(), s_int_order.end(), 0);
+        std::stable_sort(s_int_order.begin(), s_int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
         phase("  sym: tasks");
-        // contributions per output row: dense mirrored columns (in EW) and task rows (in RW), numbered in layout order ("levels")
+        // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
         for (size_t p = 0; p < ed_b.size() && !bad; p++) {
             const hmx_leaf &l = XL[ed_b[p]];
             if (!l.mirror)
@@ -535,7 +573,7 @@ static int build_streams(HMat &H) {
             set_error("symmetric storage needs the mirrored leaves' source clusters inside the target rows of the operator");
             return HMX_ERR_UNSUPPORTED;
         }
-        s_total = RWBASE + RWN;
+        s_total = RWBASE;
         for (int32_t c : s_cnt)
             H.s_kmax = std::max(H.s_kmax, (int)c);
         if (s_total >= (int64_t(1) << 31) - 1 || (int64_t)H.s_kmax * H.nT >= (int64_t(1) << 40)) {
@@ -546,7 +584,7 @@ static int build_streams(HMat &H) {
         s_fidx_n = (size_t)H.s_kmax * H.nT;
         s_fidx.reset(new int32_t[std::max<size_t>(s_fidx_n, 1)]);
         std::vector<int32_t> fill(H.nT, 0);
-        for (size_t p = 0; p < ed_b.size(); p++) { // dense pairs first (leaf-major), then the tasks in launch order
+        for (size_t p = 0; p < ed_b.size(); p++) { // leaf-major
             const int b = ed_b[p], r = ed_r[p];
             const hmx_leaf &l = XL[b];
             if (!l.mirror)
@@ -559,13 +597,7 @@ static int build_streams(HMat &H) {
                 s_fidx[(size_t)(fill[j0 + j]++) * H.nT + (j0 + j)] = (int32_t)(base + j);
             }
         }
-        for (size_t t = 0; t < ntask; t++) {
-            if (s_rowbase[t] < 0)
-                continue;
-            const int r = R.task_range[t], j0 = R.off[r] + H.S0 - H.T0;
-            for (int i = 0; i < R.len[r]; i++)
-                s_fidx[(size_t)(fill[j0 + i]++) * H.nT + (j0 + i)] = (int32_t)(s_rowbase[t] + i);
-        }
+        H.s_nint = nint;
         phase("  sym: fidx fill");
         H.n_sym_combine = (int)s_cd.size();
         phase("fused symmetric slots");
@@ -591,7 +623,12 @@ static int build_streams(HMat &H) {
         HMX_HIP(H.s_mdst.upload(s_mdst));
         HMX_HIP(H.s_coef.upload(s_coef));
         HMX_HIP(H.s_count.upload(s_cnt));
-        HMX_HIP(H.s_task_rowbase.upload(s_rowbase));
+        HMX_HIP(H.s_sub_ptr.upload(s_sub_ptr));
+        HMX_HIP(H.s_sub_task.upload(s_sub_task));
+        HMX_HIP(H.s_sub_row0.upload(s_sub_row0));
+        HMX_HIP(H.s_sub_nrows.upload(s_sub_nrows));
+        HMX_HIP(H.s_sub_dst.upload(s_sub_dst));
+        HMX_HIP(H.s_int_order.upload(s_int_order));
         HMX_HIP(H.sc_dst.upload(s_cd));
         HMX_HIP(H.sc_lp.upload(s_clp));
         HMX_HIP(H.sc_count.upload(s_cc));
@@ -604,7 +641,9 @@ static int build_streams(HMat &H) {
     } else {
         for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx})
             a->release();
-        H.s_task_rowbase.release();
+        for (auto *a : {&H.s_sub_task, &H.s_sub_row0, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
+            a->release();
+        H.s_sub_ptr.release();
         H.SW.release();
     }
     H.e_zidx_mirror.release();
@@ -853,15 +892,12 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
             }
             prof_mark(H, st, "combine_sym_kernel");
         }
-        if (ntasks > 0 && H.s_kmax > 0) {
-            RowReduceSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
-                               H.s_coef.d, H.s_task_rowbase.d, H.SW.d, ntasks, H.symmetry_for_leaves == 'H' ? 1 : 0};
-            hipLaunchKernelGGL(rowreduce_sym_kernel<1>, dim3(ntasks), dim3(64), 0, st, A);
-            prof_mark(H, st, "rowreduce_sym_kernel");
-        }
-        if (H.s_kmax > 0) {
-            hipLaunchKernelGGL(sym_finish_kernel, dim3((H.nT + 255) / 256), dim3(256), 0, st, H.nT, alpha, (const scalar *)H.SW.d, (const int32_t *)H.s_fidx.d, (const int32_t *)H.s_count.d, y);
-            prof_mark(H, st, "sym_finish_kernel");
+        if (H.s_nint > 0) {
+            RowSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d,
+                         H.s_int_order.d, H.s_sub_ptr.d, H.s_sub_task.d, H.s_sub_row0.d, H.s_sub_nrows.d, H.s_sub_dst.d,
+                         H.SW.d, H.s_fidx.d, H.s_count.d, y, alpha, H.nT, H.symmetry_for_leaves == 'H' ? 1 : 0};
+            hipLaunchKernelGGL(rowsym_kernel<SYM_WAVES>, dim3(H.s_nint), dim3(SYM_WAVES * 64), 0, st, A);
+            prof_mark(H, st, "rowsym_kernel");
         }
     } else if (H.E.nranges() > 0 && nchunks > 1) {
         // the same kernel over contiguous groups of row ranges: after group c its rows of y are final and `after_chunk` may start

@@ -2062,109 +2062,124 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
     }
 }
 
-// second sweep over the R-streams: per (source piece, column chunk) the rows sum_col Rs[i,col] a'[col] (conjugated for 'H'),
-// each written to its own output-level slot
-struct RowReduceSymArgs {
+// Second sweep over the R-streams, owner-computes: y_s += V^T a' (conjugated for 'H').  The target rows are cut into intervals of
+// SYM_IR rows; one workgroup per interval walks the (parts of) (source piece, column chunk) tasks whose rows lie in it -- an R-stream
+// chunk is row-major, so any row sub-range of a piece is one contiguous block -- wave w taking the sub-tasks w, w + WAVES, ... of the
+// interval's list.  Per sub-task: lane = column pair, eight (fp32: sixteen) rows per group with the next group's loads in flight,
+// reduce8 over the rows, and after 64 rows one transposing ds_bpermute that puts the sum of row i into lane i, which adds it to the
+// wave's slice of an LDS accumulator.  At the end the waves' slices are added in order, the interval's dense mirrored contributions
+// (column sums expand_sym_kernel left in EW, found through the level-major index) are added, and y is updated ONCE per row: no
+// partial row sums go through HBM, no folding kernel.  Fixed order everywhere: bit-reproducible.
+#ifndef HMX_SYM_IR
+#define HMX_SYM_IR 256
+#endif
+#ifndef HMX_SYM_WAVES
+#define HMX_SYM_WAVES 4
+#endif
+constexpr int SYM_IR    = HMX_SYM_IR; // rows per interval
+constexpr int SYM_WAVES = HMX_SYM_WAVES;
+struct RowSymArgs {
     const scalar *stream;
     const int32_t *task_range, *task_chunk;
     const int32_t *range_len, *range_cols, *range_cw;
     const int64_t *range_base, *range_colbase;
-    const int32_t *coef;         // per R column: slot of a'[col] in W, -1: not a mirrored column
-    const int64_t *task_rowbase; // per task: first slot of its rows in W (its own contiguous, 128-byte aligned piece), -1: no mirrored column in the chunk
-    scalar *W;
-    int ntasks;
+    const int32_t *coef;      // per R column: slot of a'[col] in W, -1: not a mirrored column
+    const int32_t *order;     // launch position -> interval (heaviest first)
+    const int64_t *sub_ptr;   // per interval: its sub-tasks [sub_ptr[I], sub_ptr[I + 1])
+    const int32_t *sub_task, *sub_row0, *sub_nrows, *sub_dst; // task, first row inside the piece, rows, first row inside the interval
+    const scalar *W;          // [a' | EW]
+    const int32_t *fidx;      // dense mirrored contributions of output row j: W[fidx[k * n + j]], k < count[j]
+    const int32_t *count;
+    scalar *y;
+    scalar alpha;
+    int n;                    // rows of the operator (stride of fidx)
     int herm;
 };
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void rowreduce_sym_kernel(RowReduceSymArgs A) {
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    if (task >= A.ntasks)
-        return;
-    const int64_t rb = A.task_rowbase[task];
-    if (rb < 0)
-        return;
-    const int lane = threadIdx.x & 63;
-    const int S = A.task_range[task], ch = A.task_chunk[task];
-    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-    int w = C - ch * cw;
-    w     = w > cw ? cw : w;
-    const int wp      = (w + 1) & ~1;
-    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
-    const bool active = col0 < wp;
-    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
-    const int64_t cb  = A.range_colbase[S] + ch * cw;
-    scalar c0 = scalar(0), c1 = scalar(0);
-    if (col0 < w) {
-        const int d = A.coef[cb + col0];
-        c0          = d >= 0 ? A.W[d] : scalar(0);
-    }
-    if (col1 < w) {
-        const int d = A.coef[cb + col1];
-        c1          = d >= 0 ? A.W[d] : scalar(0);
-    }
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_kernel(RowSymArgs A) {
+    __shared__ scalar acc[WAVES][SYM_IR];
+    const int I    = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int r = lane; r < SYM_IR; r += WAVE)
+        acc[wv][r] = scalar(0);
     const bool herm = A.herm != 0;
-    scalar mine     = scalar(0);
-    scalar *dst     = A.W + rb;
-    // eight rows per reduction, the next eight already in flight (same pipelining as expand_sym_kernel)
-    // always GS loads, no branches: rows beyond the piece re-read its last row (their sums are never stored), lanes beyond
-    // the chunk read column 0 and multiply it with their zero coefficients.  GS = 8 rows per group, 16 when a lane's pair is only
-    // 8 bytes (fp32), reduced eight at a time.
     constexpr int GS = sizeof(scalar2) <= 8 ? 16 : 8;
-    auto load_rows = [&](scalar2(&e)[GS], int i0) {
-#pragma unroll
-        for (int u = 0; u < GS; u++) {
-            const int i = i0 + u < len ? i0 + u : len - 1;
-            e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
+    for (int64_t q = A.sub_ptr[I] + wv; q < A.sub_ptr[I + 1]; q += WAVES) {
+        const int task = A.sub_task[q], row0 = A.sub_row0[q], len = A.sub_nrows[q];
+        scalar *dst = &acc[wv][A.sub_dst[q]];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        const int wp      = (w + 1) & ~1;
+        const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * wp;
+        const int64_t cb  = A.range_colbase[S] + ch * cw;
+        scalar c0 = scalar(0), c1 = scalar(0);
+        if (col0 < w) {
+            const int d = A.coef[cb + col0];
+            c0          = d >= 0 ? A.W[d] : scalar(0);
         }
-    };
-    auto process = [&](const scalar2(&e)[GS], int ig) {
+        if (col1 < w) {
+            const int d = A.coef[cb + col1];
+            c1          = d >= 0 ? A.W[d] : scalar(0);
+        }
+        scalar mine = scalar(0);
+        // always GS loads, no branches: rows beyond the sub-task re-read its last row (their sums are dropped), lanes beyond the
+        // chunk read column 0 and multiply it with their zero coefficients
+        auto load_rows = [&](scalar2(&e)[GS], int i0) {
 #pragma unroll
-        for (int h = 0; h < GS; h += 8) {
-            const int i0 = ig + h;
-            if (i0 >= len)
-                break;
-            scalar v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                v[u] = herm ? hmx_fma(hmx_conj(e[h + u].x), c0, hmx_conj(e[h + u].y) * c1) : hmx_fma(e[h + u].x, c0, e[h + u].y * c1);
-            // as in expand_sym_kernel: lane 8 s + g keeps the sum of row 64 b + 8 g + s, one transposing ds_bpermute and ONE coalesced
-            // store per 64 rows
-            const scalar r = reduce8(v, lane);
-            const int g    = (i0 >> 3) & 7;
-            mine           = (lane & 7) == g ? r : mine;
-            if (g == 7 || i0 + 8 >= len) {
-                const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
-                const int i    = (i0 & ~63) + lane;
-                if (i < len)
-                    dst[i] = t;
+            for (int u = 0; u < GS; u++) {
+                const int i = i0 + u < len ? i0 + u : len - 1;
+                e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
             }
+        };
+        auto process = [&](const scalar2(&e)[GS], int ig) {
+#pragma unroll
+            for (int h = 0; h < GS; h += 8) {
+                const int i0 = ig + h;
+                if (i0 >= len)
+                    break;
+                scalar v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = herm ? hmx_fma(hmx_conj(e[h + u].x), c0, hmx_conj(e[h + u].y) * c1) : hmx_fma(e[h + u].x, c0, e[h + u].y * c1);
+                // as in expand_sym_kernel: lane 8 s + g keeps the sum of row 64 b + 8 g + s; after 64 rows one transposing ds_bpermute
+                const scalar r = reduce8(v, lane);
+                const int g    = (i0 >> 3) & 7;
+                mine           = (lane & 7) == g ? r : mine;
+                if (g == 7 || i0 + 8 >= len) {
+                    const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
+                    const int i    = (i0 & ~63) + lane;
+                    if (i < len)
+                        dst[i] += t; // this wave's slice: no other wave touches it, the sub-tasks of a wave run one after the other
+                }
+            }
+        };
+        scalar2 ea[GS], eb[GS];
+        load_rows(ea, 0);
+        for (int i0 = 0; i0 < len; i0 += 2 * GS) { // unconditional prefetches (clamped to the last row): exactly GS newer loads outstanding at every use
+            load_rows(eb, i0 + GS);
+            process(ea, i0);
+            load_rows(ea, i0 + 2 * GS);
+            if (i0 + GS < len)
+                process(eb, i0 + GS);
         }
-    };
-    scalar2 ea[GS], eb[GS];
-    load_rows(ea, 0);
-    for (int i0 = 0; i0 < len; i0 += 2 * GS) { // unconditional prefetches (clamped to the last row): exactly GS newer loads outstanding at every use
-        load_rows(eb, i0 + GS);
-        process(ea, i0);
-        load_rows(ea, i0 + 2 * GS);
-        if (i0 + GS < len)
-            process(eb, i0 + GS);
     }
-}
-
-// y[j] += alpha * (contribution 0 + contribution 1 + ...): the mirrored contributions of output row j in their fixed layout order;
-// fidx is level-major (contribution k of row j at k * n + j), so the index loads are coalesced and neighbouring rows mostly read
-// neighbouring slots
-__global__ void sym_finish_kernel(int n, scalar alpha, const scalar *W, const int32_t *fidx, const int32_t *count, scalar *y) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n)
-        return;
-    const int cnt = count[j];
-    if (cnt == 0)
-        return;
-    scalar s = scalar(0);
-    for (int k = 0; k < cnt; k++)
-        s += W[fidx[(int64_t)k * n + j]];
-    y[j] += alpha * s;
+    __syncthreads();
+    for (int r = threadIdx.x; r < SYM_IR; r += WAVES * WAVE) {
+        const int j = I * SYM_IR + r;
+        if (j >= A.n)
+            break;
+        scalar sum = acc[0][r];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            sum += acc[k][r];
+        const int cnt = A.count[j];
+        for (int k = 0; k < cnt; k++)
+            sum += A.W[A.fidx[(int64_t)k * A.n + j]];
+        A.y[j] += A.alpha * sum;
+    }
 }
 
 // a'[dst] = sum_i W[list[lp + i] + k]: the partial column sums of a mirrored low-rank leaf that spans several row ranges, one list
