@@ -38,7 +38,7 @@ struct HMat {
     double build_epsilon = 0;  // accuracy the low-rank leaves were built with (LowRankMatrix::get_epsilon)
     bool has_mirror = false;   // the block tree has leaves_for_symmetry
     bool sym_expanded = false; // ... and they were laid out explicitly (no mirror pass needed)
-    // compact symmetric storage, fused product (expand_sym_kernel / rowreduce_sym_kernel): slots in SW = [a' | partial a' | levels]
+    // compact symmetric storage, fused product (expand_sym_kernel / rowsym_kernel): slots in SW = [a' | EW (column sums, E-column order)]
     bool sym_fused = false;
     DArr<int32_t> s_mdst, s_coef, s_count, s_list, s_fidx;
     DArr<int64_t> s_sub_ptr;
@@ -407,12 +407,11 @@ static int build_streams(HMat &H) {
     // transposed-pass destinations are derived from h_e_zidx on first use (ensure_transposed_indices)
 
     // ---- fused symmetric product: slots of the mirrored partial results ----------------------------------------------------
-    // W = [a' | EW | RW].  Every WRITER owns a contiguous, 128-byte aligned piece: expand_sym_kernel stores the column sums of a
-    // row range at EW[epad(range) + column] (E-column order); the second R sweep (rowsym_kernel) folds its row sums on chip.
-    // (Scattered 8- to 72-byte writes into per-destination slots cost 10-20 % of those kernels in partial-line HBM writes; whole
-    // lines cost nothing measurable.)  The READERS gather: combine_list_kernel folds the partial a' of a leaf that spans several
-    // ranges through a list of its column-group positions, sym_finish_kernel adds the contributions of an output row through a
-    // level-major index array.  All in a fixed order: results are bit-reproducible.
+    // W = [a' | EW].  expand_sym_kernel stores the column sums of a row range at EW[epad(range) + column] (E-column order: one
+    // contiguous, 128-byte aligned run per range).  combine_list_kernel folds the partial a' of a leaf that spans several ranges
+    // through a list of its column-group positions.  The second R sweep (rowsym_kernel) is owner-computes: one workgroup per interval
+    // of SYM_IR target rows applies every (part of a) task inside it, folds the row sums in LDS, adds the interval's dense mirrored
+    // column sums (EW, through a level-major index) and updates y once.  All in a fixed order: results are bit-reproducible.
     std::vector<int32_t> s_mdst, s_coef, s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
     std::unique_ptr<int32_t[]> s_fidx; // level-major, s_kmax x nT: left uninitialised (only the entries below count[j] are ever read)
     size_t s_fidx_n = 0;

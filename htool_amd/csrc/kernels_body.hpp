@@ -1939,9 +1939,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
 // sum_i E[i,c] x_t[i] (eight wave reductions at a time, reduce8).  For a dense leaf that is the leaf's contribution to an output
 // row; for a low-rank leaf B = U V it is a slice of a' = U^T x_t, and y_s += V^T a' needs a second sweep over the R-streams once
 // a' is complete (the one factor a streaming product must read twice: U-expand needs V x_s and V-expand needs U^T x_t, so with
-// one read of U the two V passes lie before and after it).  Nothing is accumulated with atomics: every partial result has
-// its own slot in W = [a' | partial a' | output levels] assigned at layout time, folded in a fixed order (combine_kernel for a',
-// sym_finish_kernel for the output rows), so results are bit-reproducible.
+// one read of U the two V passes lie before and after it).  Nothing is accumulated with atomics: the column sums have their own
+// slots in W = [a' | EW] assigned at layout time (E-column order: every row range writes one contiguous run), a' of a leaf spanning
+// several ranges is folded in a fixed order (combine_list_kernel), and the second sweep (rowsym_kernel) owns the output rows it
+// updates -- results are bit-reproducible.
 // ---------------------------------------------------------------------------------------------
 struct ExpandSymArgs {
     ExpandArgs X;
