@@ -6,7 +6,7 @@ import json
 import sys
 
 d = sys.argv[1]
-KEEP = ("reduce", "expand", "combine", "sym_finish", "read16", "copy16")
+KEEP = ("reduce", "expand", "combine", "rowsym", "read16", "copy16")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):

@@ -1,0 +1,48 @@
+"""Copies what tools/collect_profiles.sh left under gpurun_out/{r2_n1e6,r2_sym} into profiles/ (tracked) and rewrites profiles/traffic.json
+with the sha256 of the kernel sources the counters were measured on.  Run in the dev container right after the gpurun call."""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+os.chdir(ROOT)
+for tag, name in (("r2_n1e6", "r2_bench_n1e6"), ("r2_sym", "r2_bench_n1e6_sym")):
+    d = "gpurun_out/" + tag
+    shutil.copy(d + "/kernel_stats.csv", "profiles/%s_kernel_stats.csv" % name)
+    shutil.copy(d + "/under_rocprof.json", "profiles/%s_under_rocprof.json" % name)
+    shutil.copy(d + "/bench.json", "profiles/%s.json" % name)
+    f, w = json.load(open(d + "/pmc_FETCH_SIZE.json")), json.load(open(d + "/pmc_WRITE_SIZE.json"))
+    summ = {}
+    for k in sorted(set(f) | set(w)):
+        if "pack" in k or "copy16" in k:
+            continue
+        fs, ws = f.get(k, {}).get("FETCH_SIZE", {}), w.get(k, {}).get("WRITE_SIZE", {})
+        summ[k] = dict(FETCH_SIZE_KB_mean=fs.get("mean"), fetch_bytes_x2=2 * 1024 * fs["mean"] if fs else None, WRITE_SIZE_KB_mean=ws.get("mean"),
+                       write_bytes=1024 * ws["mean"] if ws else None, launches=fs.get("n"))
+    json.dump(summ, open("profiles/%s_pmc_summary.json" % name, "w"), indent=1, sort_keys=True)
+n, s = json.load(open("profiles/r2_bench_n1e6_pmc_summary.json")), json.load(open("profiles/r2_bench_n1e6_sym_pmc_summary.json"))
+
+
+def tot(x):
+    return x["fetch_bytes_x2"] + x["write_bytes"]
+
+
+def pick(d, sub):
+    return next(v for k, v in d.items() if sub in k)
+
+
+rec = dict(round=2, kernel_sources_sha256=bench.kernel_sources_hash(),
+           workload="bench.py N=1e6 ellipse eps=1e-4 (1 GPU): default (partialACA, 'N') and --sym S (sympartialACA, 'S','L', compact storage, fused product)",
+           method="rocprofv3 --kernel-trace --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE (tools/collect_profiles.sh, tools/pmc_summary.py); values in KB; "
+                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM): in the same runs the 8 GiB read16_kernel reports 4.194e6 KB = 1/2 of 8 GiB; WRITE_SIZE exact",
+           expand_kernel_hbm_bytes_per_launch=tot(pick(n, "expand_kernel")), expand_kernel_fetch_bytes=pick(n, "expand_kernel")["fetch_bytes_x2"],
+           expand_kernel_write_bytes=pick(n, "expand_kernel")["write_bytes"], reduce_kernel_hbm_bytes_per_launch=tot(pick(n, "reduce_kernel")),
+           expand_sym_kernel_hbm_bytes_per_launch=tot(pick(s, "expand_sym_kernel")), expand_sym_kernel_write_bytes=pick(s, "expand_sym_kernel")["write_bytes"],
+           rowsym_kernel_hbm_bytes_per_launch=tot(pick(s, "rowsym_kernel")), rowsym_kernel_write_bytes=pick(s, "rowsym_kernel")["write_bytes"],
+           sym_product_hbm_bytes_total=sum(tot(v) for k, v in s.items() if "read16" not in k))
+json.dump(rec, open("profiles/traffic.json", "w"), indent=1)
+print(json.dumps(rec, indent=1))
