@@ -319,10 +319,10 @@ static int build_streams(HMat &H) {
         R.colbase[r] = R.total_cols;
         const int C = R.cols[r], nch = (C + 127) / 128;
         if (C > 0) { // balanced chunks: nch chunks of width cw (even), the last one takes what is left
-            const int cw = (((C + nch - 1) / nch) + 1) & ~1;
+            const int cw = hmx_wp((C + nch - 1) / nch);
             R.cw[r]      = cw;
             const int wlast = C - (nch - 1) * cw;
-            R.elems += (int64_t)R.len[r] * ((int64_t)(nch - 1) * cw + ((wlast + 1) & ~1));
+            R.elems += (int64_t)R.len[r] * ((int64_t)(nch - 1) * cw + hmx_wp(wlast));
         }
         R.total_cols += C;
         for (int c = 0; c < nch; c++) {

@@ -913,13 +913,18 @@ __global__ void pack_lr_expand_kernel(PackLrArgs P, int64_t npairs) {
     }
 }
 
+// row pitch of an R-stream chunk of w columns: even (16-byte rows for 8-byte pairs); a multiple of 4 for 4-byte coefficients, whose
+// reduce stage reads 16 bytes = 4 columns per lane
+constexpr int HMX_WPAD = sizeof(scalar) == 4 ? 3 : 1;
+__host__ __device__ __forceinline__ int hmx_wp(int w) { return (w + HMX_WPAD) & ~HMX_WPAD; }
+
 __device__ __forceinline__ int64_t rstream_index(int64_t base, int len, int C, int cw, int i, int col) {
     // row-major, chunks of cw columns (cw even, <= 128, chosen per range so the chunks are balanced); the last
     // chunk may be narrower and is stored with its own row pitch rounded up to even
     const int ch = col / cw, within = col - ch * cw;
     int w        = C - ch * cw;
     w            = w > cw ? cw : w;
-    w            = (w + 1) & ~1;
+    w            = hmx_wp(w);
     return base + (int64_t)ch * len * cw + (int64_t)i * w + within;
 }
 
@@ -1045,6 +1050,62 @@ struct ReduceArgs {
 #ifndef HMX_REDUCE_ROWS
 #define HMX_REDUCE_ROWS 1
 #endif
+// 4-byte real coefficients: a chunk is at most 128 columns = 512 bytes per row, so with the 8-byte pair loads of the generic path a
+// wave-wide load moves at most 512 bytes (5.2 TB/s).  Here every lane loads 16 bytes = 4 adjacent columns and a wave-wide load covers
+// R = 256 / wp whole rows of the contiguous row-major chunk (lane l: row group 4 l / wp); the R partial sums of a column are folded
+// in a fixed tree at the end.  (Compiled for every coefficient type, called for float only.)
+__device__ __forceinline__ void reduce_rows_x4(const ReduceArgs &A, int lane, int S, int ch, int len, int w, int wp, int cw, const scalar *src, const scalar *xs) {
+    const int R = 256 / wp, hw = wp / 4; // rows per load (>= 2), lanes per row
+    const int g = lane / hw;
+    const bool lane_ok = g < R;
+    const scalar *p  = src + 4 * lane;
+    const scalar *xg = xs + g;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 8 * R <= len; j += 8 * R) {
+        hmx_f4v v[8];
+        float xi[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            v[u]  = lane_ok ? __builtin_nontemporal_load(reinterpret_cast<const hmx_f4v *>(p + (int64_t)(j + u * R) * wp)) : hmx_f4v{0.f, 0.f, 0.f, 0.f};
+            xi[u] = lane_ok ? (float)hmx_re(xg[j + u * R]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            a[0] = __builtin_fmaf(v[u].x, xi[u], a[0]);
+            a[1] = __builtin_fmaf(v[u].y, xi[u], a[1]);
+            a[2] = __builtin_fmaf(v[u].z, xi[u], a[2]);
+            a[3] = __builtin_fmaf(v[u].w, xi[u], a[3]);
+        }
+    }
+    for (; j < len; j += R) {
+        const bool ok  = lane_ok && j + g < len;
+        const float xi = ok ? (float)hmx_re(xg[j]) : 0.f;
+        const hmx_f4v v = ok ? __builtin_nontemporal_load(reinterpret_cast<const hmx_f4v *>(p + (int64_t)j * wp)) : hmx_f4v{0.f, 0.f, 0.f, 0.f};
+        a[0] = __builtin_fmaf(v.x, xi, a[0]);
+        a[1] = __builtin_fmaf(v.y, xi, a[1]);
+        a[2] = __builtin_fmaf(v.z, xi, a[2]);
+        a[3] = __builtin_fmaf(v.w, xi, a[3]);
+    }
+    for (int n = R; n > 1;) { // row groups 0..n-1 hold partial sums; fold the upper half onto the lower one
+        const int h = (n + 1) >> 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float t = __shfl(a[k], lane + h * hw, WAVE);
+            if (g + h < n)
+                a[k] += t;
+        }
+        n = h;
+    }
+    if (lane < hw) {
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        const int c0     = 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (c0 + k < w)
+                A.Z[A.out_idx[cb + c0 + k]] = scalar(a[k]);
+    }
+}
 #ifndef HMX_REDUCE_UNROLL_NARROW
 #define HMX_REDUCE_UNROLL_NARROW 16
 #endif
@@ -1058,7 +1119,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
-    const int wp      = (w + 1) & ~1;
+    const int wp      = hmx_wp(w);
     const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane); // the two columns of this lane
     const bool active = col0 < wp;
     const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
@@ -1068,6 +1129,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_kernel(ReduceArgs A) {
     // contiguous row-major array, so a wave-wide load covers R = floor(wave elements / wp) whole rows; lane l holds the
     // columns of row group g = EPL*l / wp.  R times fewer loads for the same bytes; the R partial sums of a column are
     // added in a fixed tree at the end.  HMX_REDUCE_ROWS=0 (compile time) keeps one row per load.
+    if (HMX_REDUCE_ROWS && sizeof(scalar) == 4) { // fp32: 16-byte loads for every chunk (wp <= 128 is a multiple of 4)
+        reduce_rows_x4(A, lane, S, ch, len, w, wp, cw, src, xs);
+        return;
+    }
     constexpr int EPL = HMX_SPLIT_COLS ? 1 : 2; // stream elements per lane and load
     if (HMX_REDUCE_ROWS && wp <= 32 * EPL) {
         const int R  = (64 * EPL) / wp;         // rows per load, >= 2
@@ -1388,7 +1453,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mu_kernel(ReduceArgs A, in
     const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
-    const int wp      = (w + 1) & ~1;
+    const int wp      = hmx_wp(w);
     const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
     const bool active = col0 < wp;
     const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
@@ -1550,7 +1615,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mus_kernel(ReduceArgs A, i
     const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
-    const int wp      = (w + 1) & ~1;
+    const int wp      = hmx_wp(w);
     const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
     const bool active = col0 < wp;
     const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
@@ -1742,7 +1807,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
     const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
-    const int wp      = (w + 1) & ~1;
+    const int wp      = hmx_wp(w);
     const int ntile   = (w + 15) >> 4; // <= 8 column tiles of 16
     const real *src   = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
     const real *xs    = A.x + (int64_t)A.range_off[S] * mu + cbase;
@@ -1894,7 +1959,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A)
     const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
     int w = C - ch * cw;
     w     = w > cw ? cw : w;
-    const int wp      = (w + 1) & ~1;
+    const int wp      = hmx_wp(w);
     const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
     const bool active = col0 < wp;
     const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
@@ -2112,7 +2177,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_kernel(RowSymArgs A) {
         const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
         int w = C - ch * cw;
         w     = w > cw ? cw : w;
-        const int wp      = (w + 1) & ~1;
+        const int wp      = hmx_wp(w);
         const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
         const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * wp;
         const int64_t cb  = A.range_colbase[S] + ch * cw;
