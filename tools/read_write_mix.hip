@@ -84,6 +84,17 @@ int main() {
     printf("every 2: same volume written by every 8th workgroup only: %.0f GB/s\n", run(rw<7>, a, o, n, 2, oe));
     printf("every 2: contiguous, sc0 sc1 stores: %.0f GB/s\n", run(rw<8>, a, o, n, 2, oe));
     printf("every 2: contiguous, nt sc1 stores: %.0f GB/s\n", run(rw<9>, a, o, n, 2, oe));
+    { // the written buffer in other kinds of device memory (the L2 treats them differently)
+        for (unsigned flag : {0x3u /* hipDeviceMallocUncached */, 0x1u /* hipDeviceMallocFinegrained */}) {
+            double *o2 = nullptr;
+            if (hipExtMallocWithFlags((void **)&o2, oe * 8, flag) != hipSuccess) {
+                printf("hipExtMallocWithFlags(0x%x) failed\n", flag);
+                continue;
+            }
+            printf("every 2, written buffer hipExtMallocWithFlags(0x%x): contiguous %.0f, scattered %.0f GB/s\n", flag, run(rw<2>, a, o2, n, 2, oe), run(rw<3>, a, o2, n, 2, oe));
+            hipFree(o2);
+        }
+    }
     printf("every 2: contiguous non-temporal store %.0f GB/s\n", run(rw<4>, a, o, n, 2, oe));
     return 0;
 }
