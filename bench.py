@@ -305,7 +305,7 @@ def main():
     # N > 1, single vector: the C-level DistributedOperator (one C call per step, its own RCCL communicator).  Every rank must take
     # the same path: the outcome of the set-up is agreed on over the process group before anything is timed.
     native, dist_info = None, dict(impl="python (torch.distributed)")
-    if part and mu == 1 and args.trans == "N" and args.dist_impl == "native":
+    if part and args.trans == "N" and args.dist_impl == "native":
         ok = 1
         try:
             comm = D.NativeCommunicator(backend="gloo" if os.environ.get("HMX_BENCH_BACKEND", "nccl") != "nccl" else "rccl")
@@ -324,7 +324,9 @@ def main():
         Yg = torch.zeros((n, mu), dtype=t_dt, device=dev)  # every rank receives the whole result (global-to-global contract)
 
     def step():
-        if mu > 1 and part:  # BASELINE config 5: row-partitioned multi-RHS product, all-gather of the mu-interleaved row slices
+        if mu > 1 and native is not None:  # BASELINE config 5: row-partitioned multi-RHS product, exchange of the mu-interleaved row slices
+            native.matmat_row_major_global_to_global("N", 1.0, Xmu, 0.0, Yg, mu)
+        elif mu > 1 and part:
             D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, Yg, mu)
         elif mu > 1:
             hm.internal_add_hmatrix_matrix_product_row_major(args.trans, 1.0, H, Xmu, 0.0, Ymu, mu)
@@ -348,7 +350,20 @@ def main():
     # of a step are captured once in a HIP graph (htool_amd.distributed.GraphedGlobalToGlobalProduct); the RCCL all-gather
     # is issued eagerly after each replay, so no graph ever holds a collective.  HMX_BENCH_NO_GRAPH=1: eager launches.
     graphed = False
-    if native is not None:
+    if native is not None and mu > 1:
+        # untimed: the native multi-RHS product must equal the torch.distributed layer's
+        Y_ref = torch.zeros_like(Yg)
+        D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, Y_ref, mu)
+        Yg.zero_()
+        step()
+        torch.cuda.synchronize()
+        good = torch.tensor([1 if torch.equal(Yg, Y_ref) else 0], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        if int(good.item()) == 0:
+            log("native distributed multi-RHS product differs from the torch.distributed layer: falling back")
+            native, dist_info = None, dict(impl="python (torch.distributed); native result mismatch")
+        del Y_ref
+    elif native is not None:
         # untimed: the result must equal the torch.distributed layer's, then the variants of the output exchange are tried for a few
         # steps each -- one exchange after the product, or the expand stage in 2 / 4 row chunks with every chunk's exchange on a side
         # stream under the next chunk's kernel (HMX_DIST_OVERLAP=<chunks> pins the choice) -- and the fastest becomes the timed region

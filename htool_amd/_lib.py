@@ -125,6 +125,7 @@ SYMBOLS = [
     ("hmx_dist_destroy", None, [_vp]),
     ("hmx_dist_matvec_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matvec_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
+    ("hmx_dist_matmat_row_major_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     ("hmx_dist_set_overlap", C.c_int, [_vp, C.c_int, _vp]),
     ("hmx_dist_overlap_chunks", C.c_int, [_vp]),
     ("hmx_dist_set_reduce_scatter", C.c_int, [_vp, _vp]),

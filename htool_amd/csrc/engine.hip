@@ -1000,6 +1000,83 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
     return HMX_OK;
 }
 
+// add_distributed_operator_matrix_product_row_major_global_to_global.hpp:18-85: X (n x mu) and Y (m x mu) row-major (mu fastest), whole
+// matrices replicated on every rank, partition numbering.  trans = 'N': the local slice of Y (its rows are contiguous: mu-interleaved),
+// product, exchange of the slices (MPI_Allgatherv :76); transposed: all-reduce of the whole matrix (:78).
+static int dist_local_matmat(hmx_dist &D, char trans, const void *alpha, const void *in, const void *beta, void *out, int mu, hipStream_t st) {
+    hmx_hmatrix *H = D.local;
+    if (H->d)
+        return hmx::f64::api_matmat_row_major(H->d, trans, *static_cast<const double *>(alpha), static_cast<const double *>(in), *static_cast<const double *>(beta), static_cast<double *>(out), mu, HMX_MEM_DEVICE, st);
+    if (H->s)
+        return hmx::f32::api_matmat_row_major(H->s, trans, *static_cast<const float *>(alpha), static_cast<const float *>(in), *static_cast<const float *>(beta), static_cast<float *>(out), mu, HMX_MEM_DEVICE, st);
+    if (H->z)
+        return hmx::z64::api_matmat_row_major(H->z, trans, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), mu, HMX_MEM_DEVICE, st);
+    return hmx::c32::api_matmat_row_major(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), mu, HMX_MEM_DEVICE, st);
+}
+int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const void *alpha, const void *X, const void *beta, void *Y, int mu, void *stream) {
+    if (!Dp || !alpha || !beta || !X || !Y || mu < 1) {
+        set_error("hmx_dist_matmat_row_major_global_to_global: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D    = *Dp;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t e = D.esz * (size_t)mu; // bytes per row
+    char *yb       = static_cast<char *>(Y);
+    const char *xb = static_cast<const char *>(X);
+    if (trans == 'N') {
+        const int off = D.t_off[D.rank], n = D.t_size[D.rank];
+        if (D.work.n < (size_t)n * e)
+            HMX_HIP(D.work.alloc((size_t)n * e));
+        HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
+        int rc = dist_local_matmat(D, 'N', alpha, X, beta, D.work.d, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        // the slices are mu-interleaved rows: the same exchange with mu times the counts
+        if (D.world == 1 && !D.force) {
+            HMX_HIP(hipMemcpyAsync(yb + (size_t)D.t_off[0] * e, D.work.d, (size_t)D.t_size[0] * e, hipMemcpyDeviceToDevice, st));
+            return HMX_OK;
+        }
+        bool equal = D.t_off[0] == 0;
+        for (int k = 1; k < D.world; k++)
+            equal = equal && D.t_size[k] == D.t_size[0];
+        if (equal && !(getenv("HMX_DIST_NO_ALLGATHER") && atoi(getenv("HMX_DIST_NO_ALLGATHER")))) {
+            HMX_NCCL(D.api.all_gather(D.work.d, yb, (size_t)D.t_size[0] * D.reals * mu, D.dtype, D.comm, st));
+            return HMX_OK;
+        }
+        HMX_NCCL(D.api.group_start());
+        for (int k = 0; k < D.world; k++)
+            HMX_NCCL(D.api.broadcast(D.work.d, yb + (size_t)D.t_off[k] * e, (size_t)D.t_size[k] * D.reals * mu, D.dtype, k, D.comm, st));
+        HMX_NCCL(D.api.group_end());
+        return HMX_OK;
+    }
+    const int off      = D.t_off[D.rank];
+    const size_t bytes = (size_t)D.ns * e;
+    if (D.work.n < bytes)
+        HMX_HIP(D.work.alloc(bytes));
+    HMX_HIP(hipMemsetAsync(D.work.d, 0, bytes, st));
+    const double zero[2] = {0.0, 0.0};
+    const float zerof[2] = {0.f, 0.f};
+    const void *bz       = D.dtype == 8 ? (const void *)zero : (const void *)zerof;
+    int rc = dist_local_matmat(D, trans, alpha, xb + (size_t)off * e, bz, D.work.d, mu, st);
+    if (rc != HMX_OK)
+        return rc;
+    if (D.world > 1 || D.force)
+        HMX_NCCL(D.api.all_reduce(D.work.d, D.work.d, (size_t)D.ns * D.reals * mu, D.dtype, 0 /* ncclSum */, D.comm, st));
+    hmx_hmatrix *H = D.local;
+    const int64_t n = (int64_t)D.ns * mu;
+    const unsigned g = (unsigned)((n + 255) / 256);
+    if (H->d)
+        hipLaunchKernelGGL(hmx::f64::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, 1.0, (const double *)D.work.d, *static_cast<const double *>(beta), static_cast<double *>(Y));
+    else if (H->s)
+        hipLaunchKernelGGL(hmx::f32::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, 1.0f, (const float *)D.work.d, *static_cast<const float *>(beta), static_cast<float *>(Y));
+    else if (H->z)
+        hipLaunchKernelGGL(hmx::z64::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, cplx<double>(1.0), ZP(D.work.d), zval(static_cast<const double *>(beta)), ZPM(Y));
+    else
+        hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, cplx<float>(1.0f), CP(D.work.d), cval(static_cast<const float *>(beta)), CPM(Y));
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
 int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, const void *x_local, const void *beta, void *y_local, void *stream) {
     if (!Dp || !alpha || !beta || !x_local || !y_local) {
         set_error("hmx_dist_matvec_local_to_local: invalid arguments");

@@ -515,6 +515,12 @@ class NativeDistributedOperator:
         check(self._L.hmx_dist_matvec_global_to_global(self._h, trans.encode(), pa, C.c_void_p(x.data_ptr()), pb, C.c_void_p(y.data_ptr()), self._stream(y)))
         return y
 
+    def matmat_row_major_global_to_global(self, trans, alpha, X, beta, Y, mu):
+        from ._lib import check
+        pa, pb = self._scalars(alpha, beta, Y.dtype)
+        check(self._L.hmx_dist_matmat_row_major_global_to_global(self._h, trans.encode(), pa, C.c_void_p(X.data_ptr()), pb, C.c_void_p(Y.data_ptr()), int(mu), self._stream(Y)))
+        return Y
+
     def matvec_local_to_local(self, trans, alpha, x_loc, beta, y_loc):
         from ._lib import check
         pa, pb = self._scalars(alpha, beta, y_loc.dtype)

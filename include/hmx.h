@@ -293,6 +293,10 @@ void hmx_dist_destroy(hmx_dist *);
  * type is the local operator's: pointers to double / float / interleaved complex accordingly, alpha / beta as in the matvec
  * entry points of that type but always passed by pointer here. */
 int hmx_dist_matvec_global_to_global(hmx_dist *, char trans, const void *alpha, const void *x, const void *beta, void *y, void *stream);
+/* The same for mu right-hand sides, X (n x mu) and Y (m x mu) row-major with mu fastest
+ * (distributed_operator/linalg/add_distributed_operator_matrix_product_row_major_global_to_global.hpp:18-85): the exchanged slices are
+ * mu-interleaved rows. */
+int hmx_dist_matmat_row_major_global_to_global(hmx_dist *, char trans, const void *alpha, const void *X, const void *beta, void *Y, int mu, void *stream);
 /* local slices in and out (the Krylov-side contract, local_to_local.hpp:19-89): all-gather of x, local product ('N');
  * local product into a zeroed global vector, all-reduce, slice (transposed). */
 int hmx_dist_matvec_local_to_local(hmx_dist *, char trans, const void *alpha, const void *x_local, const void *beta, void *y_local, void *stream);

@@ -232,6 +232,28 @@ MOCK_SCRIPT = textwrap.dedent('''
                 [t.join() for t in th]
                 assert not fails, fails
                 assert max(errs) < 1e-12, (np.dtype(dtype).name, trans, local, errs)
+        # row-major multi-RHS global-to-global products (mu = 3): exchange of mu-interleaved row slices / all-reduce of the whole matrix
+        mu = 3
+        X = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
+        Y0 = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
+        for trans in ("N", "T"):
+            ref = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, ab[0], Hfull, X, ab[1], ref, mu)
+            errs, fails = [None] * WORLD, []
+            def mm_rank(k):
+                try:
+                    dx, dy = dev(X), dev(Y0)
+                    check(L.hmx_dist_matmat_row_major_global_to_global(Ds[k], trans.encode(), pa, dx, pb, dy, mu, None))
+                    assert hip.hipDeviceSynchronize() == 0
+                    errs[k] = np.linalg.norm(host(dy, Y0) - ref) / np.linalg.norm(ref)
+                except BaseException as e:
+                    fails.append(e)
+                    barrier.abort()
+            th = [threading.Thread(target=mm_rank, args=(k,)) for k in range(WORLD)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not fails, fails
+            assert max(errs) < 1e-12, (np.dtype(dtype).name, "matmat", trans, errs)
         for D in Ds:
             L.hmx_dist_destroy(D)
         print("ok", np.dtype(dtype).name)
