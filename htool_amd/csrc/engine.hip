@@ -4,6 +4,7 @@
 // There is deliberately NO CPU fallback in this file: every entry point that computes needs a HIP
 // device and reports HMX_ERR_NO_DEVICE / HMX_ERR_HIP otherwise.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <cmath>
@@ -105,6 +106,14 @@ struct DeviceCache {
     }
 };
 
+// wall time this process spent inside hipMalloc (large allocations sporadically take seconds on this platform: tools/malloc_timing.hip);
+// bench.py reports it next to the build time
+static std::atomic<long long> g_malloc_ns{0};
+struct MallocTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~MallocTimer() { g_malloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 template <typename T>
 struct DArr { // device array with RAII
     T *d        = nullptr;
@@ -136,6 +145,7 @@ struct DArr { // device array with RAII
             return hipSuccess;
         }
         cap_               = bytes;
+        MallocTimer timer;
         const hipError_t e = hipMalloc((void **)&d, bytes);
         if (e != hipSuccess) { // out of memory: give the parked buffers back and try once more
             DeviceCache::get().trim();
@@ -706,6 +716,15 @@ struct hmx_dist {
             (void)hipStreamDestroy(side);
     }
 };
+// beta == 0 for the handle's coefficient type: the old output values are never read, so they need not be copied to the work buffer
+static bool dist_beta_is_zero(const hmx_dist &D, const void *beta) {
+    if (D.dtype == 8) {
+        const double *b = static_cast<const double *>(beta);
+        return b[0] == 0.0 && (D.reals == 1 || b[1] == 0.0);
+    }
+    const float *b = static_cast<const float *>(beta);
+    return b[0] == 0.f && (D.reals == 1 || b[1] == 0.f);
+}
 static int dist_api_from_library(hmx_rccl_api &api, void **reduce_scatter = nullptr) {
     void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h)
@@ -944,7 +963,8 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
         const int off = D.t_off[D.rank], n = D.t_size[D.rank];
         if (D.work.n < (size_t)n * e)
             HMX_HIP(D.work.alloc((size_t)n * e));
-        HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
+        if (!dist_beta_is_zero(D, beta))
+            HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
         if (D.nchunks > 1 && (D.world > 1 || D.force)) {
             // chunked expand stage on `st`, each chunk's exchange on the side stream under the next chunk's kernel
             DistChunkCtx ctx{&D, D.work.d, yb};
@@ -1027,7 +1047,8 @@ int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const v
         const int off = D.t_off[D.rank], n = D.t_size[D.rank];
         if (D.work.n < (size_t)n * e)
             HMX_HIP(D.work.alloc((size_t)n * e));
-        HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
+        if (!dist_beta_is_zero(D, beta))
+            HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
         int rc = dist_local_matmat(D, 'N', alpha, X, beta, D.work.d, mu, st);
         if (rc != HMX_OK)
             return rc;
@@ -1135,6 +1156,7 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
     return HMX_OK;
 }
 
+double hmx_device_malloc_seconds(void) { return 1e-9 * (double)g_malloc_ns.load(); }
 int hmx_device_trim_cache(void) {
     DeviceCache::get().trim();
     return HMX_OK;

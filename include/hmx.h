@@ -324,6 +324,9 @@ int hmx_hmatrix_set_profiling(hmx_hmatrix *, int enabled);
 /* libhmx recycles large device buffers inside the process (rebuilding operators would otherwise hit multi-second hipMalloc calls);
  * this returns every parked buffer to the driver.  HMX_CACHE_GB (default 48) bounds what is kept. */
 int hmx_device_trim_cache(void);
+/* Wall time (seconds) this process has spent inside hipMalloc on behalf of libhmx so far: large allocations sporadically take seconds
+ * on this platform, callers that time builds report it separately. */
+double hmx_device_malloc_seconds(void);
 
 /* Device bandwidth probe: plain 16 B/lane copy of `bytes` bytes, returns GB/s (read+write counted). */
 int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gbps);
