@@ -1464,6 +1464,19 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     H.staged_off.assign(nb, -1);
     HMX_HIP(H.d_staged_off.upload(H.staged_off));
 
+    DArr<int32_t> st_q, st_I1, st_I2; // state of suspended blocks (aca_kernel)
+    DArr<real> st_frob, st_aux;
+    if (!assembled && !use_cb) {
+        HMX_HIP(st_q.alloc(std::max<size_t>(nb, 1)));
+        HMX_HIP(st_I1.alloc(std::max<size_t>(nb, 1)));
+        HMX_HIP(st_I2.alloc(std::max<size_t>(nb, 1)));
+        HMX_HIP(st_frob.alloc(std::max<size_t>(nb, 1)));
+        HMX_HIP(st_aux.alloc(std::max<size_t>(nb, 1)));
+        for (auto *a : {&st_q, &st_I1, &st_I2})
+            HMX_HIP(a->zero());
+        for (auto *a : {&st_frob, &st_aux})
+            HMX_HIP(a->zero());
+    }
     phase("scratch upload");
     auto aca_args = [&](scalar *pool, unsigned long long pool_cap, const int32_t *order_dev) {
         AcaArgs A{};
@@ -1485,6 +1498,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         A.vis_ptr   = d_visptr.d;
         A.rank_out  = H.d_rank.d;
         A.swapped_out = H.d_swapped.d;
+        A.st_q = st_q.d; A.st_I1 = st_I1.d; A.st_I2 = st_I2.d; A.st_frob = st_frob.d; A.st_aux = st_aux.d;
         return A;
     };
     // Pool sizing from a SAMPLE of the blocks.  The a-priori rank guess has to be pessimistic (it decides whether the
@@ -1526,6 +1540,10 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             HMX_HIP(visited.zero());
             HMX_HIP(H.d_rank.zero());
             HMX_HIP(H.d_swapped.zero());
+            for (auto *a : {&st_q, &st_I1, &st_I2})
+                HMX_HIP(a->zero());
+            for (auto *a : {&st_frob, &st_aux})
+                HMX_HIP(a->zero());
         } else {
             (void)hipGetLastError();
         }
@@ -1713,36 +1731,179 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                 return rcp;
         }
     } else if (!order.empty()) {
-        AcaArgs A = aca_args(H.pool.d, cap, d_order.d);
-        // 1024-thread workgroups on a side stream for the largest blocks, concurrently with the rest in 256-thread workgroups
-        // (`order` is sorted by n1 + n2, largest first).  That shortens the critical path of a block (every iteration walks
-        // n1 + n2 entries) but lowers the throughput over many blocks: with ranks as expected it loses (N=1e6: 94 vs 79 ms,
-        // N=4e6 eps=1e-6: 0.37 vs 0.32 s), with a few very high-rank blocks it halves the time (Hermitian sign-discontinuous
-        // generator, ranks up to 646: 17.9 -> 8.7 s).  High ranks show up as an exhausted rank-estimated pool, so the retry
-        // with the full pool is the one that uses it.  HMX_ACA_BIG=<n1 + n2> forces the threshold for both attempts.
-        const int big_threshold = getenv("HMX_ACA_BIG") ? atoi(getenv("HMX_ACA_BIG")) : (full_pool ? 8192 : INT_MAX);
-        size_t nbig = 0;
-        while (nbig < order.size() && (int64_t)H.leaves[order[nbig]].t_size + H.leaves[order[nbig]].s_size >= big_threshold)
-            nbig++;
-        hipStream_t side = nullptr;
-        DEvent big_done;
-        if (nbig > 0) {
-            HMX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-            hipLaunchKernelGGL(aca_kernel<1024>, dim3((unsigned)nbig), dim3(1024), 0, side, A);
-            HMX_HIP(hipEventRecord(big_done, side));
-            if (getenv("HMX_ACA_SERIAL") && atoi(getenv("HMX_ACA_SERIAL"))) // diagnosis: the two launches one after the other
-                HMX_HIP(hipStreamSynchronize(side));
-        }
-        if (order.size() > nbig) {
-            A.order = d_order.d + nbig;
-            hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)(order.size() - nbig)), dim3(256), 0, 0, A);
-        }
-        if (nbig > 0) {
-            HMX_HIP(hipStreamWaitEvent(0, big_done, 0));
+        // Rounds: all blocks first; a block that finds the rank-estimated pool exhausted suspends with its state (aca_kernel), the pool
+        // grows (new allocation + device copy of the crosses written so far) and the suspended blocks continue where they stopped --
+        // nothing is computed twice, the blocks that had finished keep their crosses.
+        // Large blocks whose rank keeps growing leave the one-workgroup kernel after team_q iterations and continue with several workgroups
+        // each (aca_team_*_kernel, three launches per iteration over all such blocks).
+        // a zero row pivot and every growth round leave a grant unused: some slack over the exact need
+        const unsigned long long maxcap = (unsigned long long)std::max(1024.0, std::min(need + 2.0 * (double)nvis + 64.0 * 1048576.0, budget));
+        std::vector<int32_t> active     = order; // `order` is sorted by n1 + n2, largest first; so is every later list
+        DArr<int32_t> d_active;
+        std::vector<int32_t> round_ranks(nb, 0);
+        DArr<int32_t> t_status, t_need;
+        DArr<scalar> t_gamma;
+        DArr<unsigned long long> t_off;
+        DArr<unsigned int> t_counter;
+        DArr<real> t_paux;
+        auto since_phase = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - phase_t0).count(); };
+        auto grow_pool = [&]() -> int { // HMX_OK: grown; 1: the budget is used up
+            if (cap >= maxcap)
+                return 1;
+            const unsigned long long newcap = std::min<unsigned long long>(maxcap, std::max<unsigned long long>(2 * cap, cap + 1024));
+            DArr<scalar> bigger;
+            if (bigger.alloc(newcap) != hipSuccess) {
+                (void)hipGetLastError();
+                return 1;
+            }
+            HMX_HIP(hipMemcpy(bigger.d, H.pool.d, (size_t)cap * sizeof(scalar), hipMemcpyDeviceToDevice));
+            std::swap(bigger.d, H.pool.d);
+            std::swap(bigger.n, H.pool.n);
+            std::swap(bigger.cap_, H.pool.cap_);
+            std::swap(bigger.dev_, H.pool.dev_);
+            bigger.release();
+            const unsigned long long old = cap; // the grants that failed pushed the head beyond the old capacity: restart it there
+            HMX_HIP(hipMemcpy(head.d, &old, 8, hipMemcpyHostToDevice));
+            cap = newcap;
+            return HMX_OK;
+        };
+        // entries of a line per workgroup.  Fewer entries = more workgroups for the last few blocks, but every workgroup walks the whole history
+        // for its entries: 256 or a count adapted to the blocks left were slower than 1024 throughout (N=1e6 Hermitian case: 2.5-3.0 vs 1.9 s)
+        const int team_slice = getenv("HMX_ACA_TEAM_SLICE") ? std::max(64, atoi(getenv("HMX_ACA_TEAM_SLICE"))) : 1024;
+        auto run_team = [&](const std::vector<int32_t> &blocks, int round) -> int {
+            if (!t_status.d) {
+                HMX_HIP(t_status.alloc(nb));
+                HMX_HIP(t_need.alloc(nb));
+                HMX_HIP(t_gamma.alloc(nb));
+                HMX_HIP(t_off.alloc(nb));
+                HMX_HIP(t_counter.alloc(nb));
+                HMX_HIP(t_paux.alloc(nb));
+                HMX_HIP(t_need.zero());
+                HMX_HIP(t_counter.zero());
+            }
+            HMX_HIP(t_status.zero()); // every block in `blocks` is active (again); the entries of other blocks are not looked at
+            std::vector<int32_t> cur = blocks, st(nb);
+            int launches = 0;
+            // Tables for at most 64 workgroups per block, allocated once: hipFree waits for the whole device, and the side stream is busy with
+            // the small blocks meanwhile.  (Dealing the teams out to 2 / 4 / 8 streams so that launches overlap was measured on the N=1e6
+            // Hermitian case: 1.65 / 2.3 / 2.8 s for the team phase against 1.65 s on one stream -- the launches themselves become the cost.)
+            DArr<int32_t> d_block, d_G, d_wg0, d_wgteam, d_pidx;
+            DArr<real> d_pval;
+            DArr<scalar> d_pfrob;
+            HMX_HIP(d_block.alloc(cur.size()));
+            HMX_HIP(d_G.alloc(cur.size()));
+            HMX_HIP(d_wg0.alloc(cur.size()));
+            HMX_HIP(d_wgteam.alloc(64 * cur.size()));
+            HMX_HIP(d_pidx.alloc(64 * cur.size()));
+            HMX_HIP(d_pval.alloc(64 * cur.size()));
+            HMX_HIP(d_pfrob.alloc(64 * cur.size()));
+            while (!cur.empty()) {
+                std::vector<int32_t> team_G(cur.size()), team_wg0(cur.size()), wg_team;
+                for (size_t t = 0; t < cur.size(); t++) {
+                    const hmx_leaf &l = H.leaves[cur[t]];
+                    team_G[t]         = std::max(1, std::min(64, (std::max(l.t_size, l.s_size) + team_slice - 1) / team_slice));
+                    team_wg0[t]       = (int32_t)wg_team.size();
+                    wg_team.insert(wg_team.end(), (size_t)team_G[t], (int32_t)t);
+                }
+                HMX_HIP(hipMemcpy(d_block.d, cur.data(), cur.size() * 4, hipMemcpyHostToDevice));
+                HMX_HIP(hipMemcpy(d_G.d, team_G.data(), cur.size() * 4, hipMemcpyHostToDevice));
+                HMX_HIP(hipMemcpy(d_wg0.d, team_wg0.data(), cur.size() * 4, hipMemcpyHostToDevice));
+                HMX_HIP(hipMemcpy(d_wgteam.d, wg_team.data(), wg_team.size() * 4, hipMemcpyHostToDevice));
+                AcaTeamArgs T{};
+                T.A = aca_args(H.pool.d, cap, d_order.d);
+                T.wg_team = d_wgteam.d; T.team_block = d_block.d; T.team_wg0 = d_wg0.d; T.team_G = d_G.d;
+                T.status = t_status.d; T.need_dots = t_need.d; T.gamma = t_gamma.d; T.off = t_off.d; T.counter = t_counter.d;
+                T.pval = d_pval.d; T.pidx = d_pidx.d; T.pfrob = d_pfrob.d; T.paux = t_paux.d;
+                const dim3 grid((unsigned)wg_team.size()), wg(256);
+                for (;;) {
+                    for (int it = 0; it < 16; it++) {
+                        hipLaunchKernelGGL(aca_team_control_kernel<256>, grid, wg, 0, 0, T);
+                        hipLaunchKernelGGL(aca_team_row_kernel<256>, grid, wg, 0, 0, T);
+                        hipLaunchKernelGGL(aca_team_col_kernel<256>, grid, wg, 0, 0, T);
+                        launches += 3;
+                    }
+                    HMX_HIP(hipGetLastError());
+                    HMX_HIP(hipMemcpy(st.data(), t_status.d, nb * 4, hipMemcpyDeviceToHost));
+                    std::vector<int32_t> still;
+                    for (int32_t b : cur)
+                        if (st[b] == 0)
+                            still.push_back(b);
+                    if (still.size() * 2 <= cur.size()) { // fewer, smaller launches for the blocks that go on
+                        cur.swap(still);
+                        break;
+                    }
+                }
+            }
+            if (phase_timing)
+                fprintf(stderr, "[hmx build]   round %d (%.0f ms): %zu blocks continued by workgroup teams, %d launches\n", round, since_phase(), blocks.size(), launches);
+            return HMX_OK;
+        };
+        const bool team_ok = reqrank < 0 && !(getenv("HMX_ACA_TEAM") && atoi(getenv("HMX_ACA_TEAM")) == 0);
+        const int team_min = team_ok ? (getenv("HMX_ACA_TEAM_MIN") ? atoi(getenv("HMX_ACA_TEAM_MIN")) : 4096) : 0;
+        const int team_q   = getenv("HMX_ACA_TEAM_Q") ? atoi(getenv("HMX_ACA_TEAM_Q")) : 48;
+        hipStream_t side = nullptr; // the blocks below team_min, concurrently with the large ones and their teams
+        struct SideGuard {
+            hipStream_t &s;
+            ~SideGuard() {
+                if (s)
+                    (void)hipStreamDestroy(s);
+            }
+        } side_guard{side};
+        HMX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        for (int round = 0;; round++) {
+            AcaArgs A  = aca_args(H.pool.d, cap, round == 0 ? d_order.d : d_active.d);
+            A.team_min = team_min;
+            A.team_q   = team_q;
+            // `active` is sorted by n1 + n2, largest first: the blocks that may hand over to teams are a prefix.  They run on the null
+            // stream and their teams follow at once; everything smaller runs on the side stream meanwhile (one workgroup per block,
+            // dominated by its few high-rank blocks: the two overlap well).
+            size_t nbig = 0;
+            while (team_min > 0 && nbig < active.size() && (int64_t)H.leaves[active[nbig]].t_size + H.leaves[active[nbig]].s_size >= team_min)
+                nbig++;
+            HMX_HIP(hipDeviceSynchronize()); // uploads, pool growth and state resets on the null stream, before the side stream reads them
+            if (active.size() > nbig) {
+                AcaArgs S = A;
+                S.order += nbig;
+                hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)(active.size() - nbig)), dim3(256), 0, side, S);
+            }
+            if (nbig > 0) {
+                hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)nbig), dim3(256), 0, 0, A);
+                HMX_HIP(hipGetLastError());
+                HMX_HIP(hipMemcpy(round_ranks.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
+                std::vector<int32_t> handed;
+                for (size_t i = 0; i < nbig; i++)
+                    if (round_ranks[active[i]] == -3)
+                        handed.push_back(active[i]);
+                if (phase_timing)
+                    fprintf(stderr, "[hmx build]   round %d (%.0f ms): first %d iterations of the %zu blocks of %d rows + columns or more, pool %.2f GB\n", round, since_phase(), team_q, nbig,
+                            team_min, (double)cap * sizeof(scalar) / 1e9);
+                if (!handed.empty()) {
+                    const int rct = run_team(handed, round);
+                    if (rct != HMX_OK)
+                        return rct;
+                }
+            }
             HMX_HIP(hipStreamSynchronize(side));
-            (void)hipStreamDestroy(side);
+            HMX_HIP(hipGetLastError());
+            HMX_HIP(hipMemcpy(round_ranks.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
+            if (phase_timing)
+                fprintf(stderr, "[hmx build]   round %d (%.0f ms): one-workgroup kernel over the other %zu blocks done\n", round, since_phase(), active.size() - nbig);
+            std::vector<int32_t> suspended;
+            for (int32_t b : active)
+                if (round_ranks[b] == -2)
+                    suspended.push_back(b);
+            if (suspended.empty())
+                break;
+            if (phase_timing)
+                fprintf(stderr, "[hmx build]   round %d: %zu of %zu blocks suspended at a pool of %.2f GB\n", round, suspended.size(), active.size(), (double)cap * sizeof(scalar) / 1e9);
+            const int rcg = grow_pool();
+            if (rcg == 1)
+                break; // reported below as an exhausted pool
+            if (rcg != HMX_OK)
+                return rcg;
+            active.swap(suspended);
+            HMX_HIP(d_active.upload(active));
         }
-        HMX_HIP(hipGetLastError());
     }
     HMX_HIP(hipEventRecord(e1, 0));
     HMX_HIP(hipEventSynchronize(e1));
@@ -1759,8 +1920,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     int64_t false_pos = 0;
     for (int32_t b : order) {
         if (ranks[b] == -2) {
-            if (!full_pool)
-                return 1; // the rank estimate was too low: repeat with the whole budget
+            if (!full_pool && (assembled || use_cb))
+                return 1; // the rank estimate was too low: repeat with the whole budget (the device ACA has grown its pool by itself)
             set_error("hmx_hmatrix_compress: compression pool exhausted (not enough free HBM)");
             return HMX_ERR_HIP;
         }

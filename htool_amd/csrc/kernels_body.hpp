@@ -56,6 +56,9 @@ struct AcaArgs {
     const int64_t *vis_ptr;
     int32_t *rank_out;          // > 0 rank; 0 = compressor failed (dense fallback); -2 = pool exhausted
     int32_t *swapped_out;       // 1 when index "1" is the source side (sympartialACA.hpp:48-63)
+    int32_t *st_q, *st_I1, *st_I2; // per block: state of a suspended block (zero = fresh start): iterations completed, next row pivot, last column pivot
+    real *st_frob, *st_aux;
+    int team_min, team_q;       // blocks with n1 + n2 >= team_min hand over to the team kernels (rank -3) once team_q iterations are done; team_min = 0: never
 };
 
 template <int NT>
@@ -109,14 +112,129 @@ __device__ __forceinline__ void block_sum_group(V (&acc)[G], V *sbuf) {
     __syncthreads();
 }
 
+// One line of a cross (partialACA.hpp:93-99 the row, :112-118 the column): out[k] = A(line, k) - sum_j hist_j[coef_index] * hist_j[line_base + k],
+// j in history order, (x gamma for the column), and the pivot search over the entries not visited yet.  Every iteration of the ACA walks
+// the whole history of the block, so this is where a high-rank block spends its time: the coefficients and pool offsets of ACA_JT crosses
+// are staged in LDS, a thread keeps KR entries of the line in registers and the loop over the history has KR independent, unconditional
+// loads per cross (the index is clamped instead of predicated: no branch inside the loop, loads of several crosses stay in flight).
+// Histories longer than ACA_JT are applied tile after tile with the partial line parked in `out` (same sums, same order).
+constexpr int ACA_JT = 128;
+template <int NT, int KR, typename F>
+__device__ __forceinline__ void aca_cross_line(int k_lo, int n, int nq, const int64_t *cross, const scalar *pool, int64_t coef_index, int64_t line_base, scalar *out, F eval,
+                                               bool scale, scalar gamma, const unsigned char *vis, int skip, real &best, int &besti, scalar *s_coef, int64_t *s_offs) {
+    const int tid = threadIdx.x;
+    best          = -1;
+    besti         = -1;
+    int j0        = 0;
+    do {
+        const int tile = (nq - j0) < ACA_JT ? (nq - j0) : ACA_JT;
+        if (tid < tile) {
+            const int64_t o = cross[j0 + tid];
+            s_offs[tid]     = o + line_base;
+            s_coef[tid]     = -pool[o + coef_index];
+        }
+        __syncthreads();
+        const bool first = j0 == 0, last = j0 + tile >= nq;
+        for (int k0 = k_lo; k0 < n; k0 += KR * NT) { // the entries [k_lo, n) of the line
+            scalar v[KR];
+            int kk[KR];
+#pragma unroll
+            for (int r = 0; r < KR; r++) {
+                const int k = k0 + r * NT + tid;
+                kk[r]       = k < n ? k : n - 1;
+                v[r]        = first ? eval(kk[r]) : out[kk[r]];
+            }
+#pragma unroll 4
+            for (int jj = 0; jj < tile; jj++) {
+                const scalar coef = s_coef[jj];
+                const scalar *cj  = pool + s_offs[jj];
+#pragma unroll
+                for (int r = 0; r < KR; r++)
+                    v[r] = coef * cj[kk[r]] + v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < KR; r++) {
+                const int k = k0 + r * NT + tid;
+                if (k < n) {
+                    if (last) {
+                        if (scale)
+                            v[r] = v[r] * gamma;
+                        out[k] = v[r];
+                        if (!vis[k] && k != skip) {
+                            const real a = hmx_abs(v[r]);
+                            if (a >= best) { // k increases per thread: ">=" keeps the last maximum
+                                best  = a;
+                                besti = k;
+                            }
+                        }
+                    } else {
+                        out[k] = v[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        j0 += tile;
+    } while (j0 < nq);
+}
+
+// Error estimator, the sums of partialACA.hpp:141-147 for four crosses j0..j0+nj-1 of the history at once: acc[2g] = vv_j . r (over index 2),
+// acc[2g+1] = uu_j . c (over index 1), per-thread partial sums (k increasing); the new cross is loaded once, four independent streams.
+template <int NT>
+__device__ __forceinline__ void aca_dots4(const scalar *pool, const int64_t *cross, int j0, int nj, int n1, int n2, const scalar *u1, const scalar *u2, scalar (&acc)[8]) {
+    const int tid    = threadIdx.x;
+    const scalar *c0 = pool + cross[j0], *c1 = pool + cross[j0 + (nj > 1 ? 1 : 0)], *c2 = pool + cross[j0 + (nj > 2 ? 2 : 0)], *c3 = pool + cross[j0 + (nj > 3 ? 3 : 0)];
+    scalar a10 = 0, a11 = 0, a12 = 0, a13 = 0, a20 = 0, a21 = 0, a22 = 0, a23 = 0;
+    if (nj == 4) {
+#pragma unroll 2
+        for (int k = tid; k < n2; k += NT) {
+            const scalar x = u1[k];
+            a10 += hmx_conj(c0[n1 + k]) * x;
+            a11 += hmx_conj(c1[n1 + k]) * x;
+            a12 += hmx_conj(c2[n1 + k]) * x;
+            a13 += hmx_conj(c3[n1 + k]) * x;
+        }
+#pragma unroll 2
+        for (int k = tid; k < n1; k += NT) {
+            const scalar x = u2[k];
+            a20 += hmx_conj(c0[k]) * x;
+            a21 += hmx_conj(c1[k]) * x;
+            a22 += hmx_conj(c2[k]) * x;
+            a23 += hmx_conj(c3[k]) * x;
+        }
+    } else {
+        for (int k = tid; k < n2; k += NT) {
+            const scalar x = u1[k];
+            a10 += hmx_conj(c0[n1 + k]) * x;
+            if (nj > 1)
+                a11 += hmx_conj(c1[n1 + k]) * x;
+            if (nj > 2)
+                a12 += hmx_conj(c2[n1 + k]) * x;
+        }
+        for (int k = tid; k < n1; k += NT) {
+            const scalar x = u2[k];
+            a20 += hmx_conj(c0[k]) * x;
+            if (nj > 1)
+                a21 += hmx_conj(c1[k]) * x;
+            if (nj > 2)
+                a22 += hmx_conj(c2[k]) * x;
+        }
+    }
+    acc[0] = a10; acc[1] = a20; acc[2] = a11; acc[3] = a21; acc[4] = a12; acc[5] = a22; acc[6] = a13; acc[7] = a23;
+}
+
 // partialACA::copy_low_rank_approximation (hmatrix/lrmat/partialACA.hpp:42-184) and
 // sympartialACA (hmatrix/lrmat/sympartialACA.hpp:41-216) share this kernel: index "1" is the
 // row side unless symmetric pivoting asks for the larger-offset side.
+// A block that finds the pool exhausted SUSPENDS: it records (q, I1, frob, aux) in A.st_* and reports rank -2; the host grows the pool and
+// launches the suspended blocks again, which continue with their next iteration (crosses and visited flags are in global memory already).
 template <int NT>
 __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
     __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
     __shared__ scalar sbuf[(NT / WAVE) * 8];
+    __shared__ scalar s_coef[ACA_JT];
+    __shared__ int64_t s_offs[ACA_JT];
     __shared__ unsigned long long s_off;
 
     const int b      = A.order[blockIdx.x];
@@ -133,11 +251,25 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
     const int cap       = A.colcap[b];
     const int tid       = threadIdx.x;
 
-    int I1 = 0, I2 = 0, q = 0;
-    real frob = 0, aux = 0;
+    int I1 = A.st_I1[b], I2 = A.st_I2[b], q = A.st_q[b];
+    real frob = A.st_frob[b], aux = A.st_aux[b];
     const int reqrank = A.reqrank;
     const int minmn   = n1 < n2 ? n1 : n2;
     while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (q == 0 || sqrt(aux / frob) > (real)A.epsilon))) {
+        auto suspend = [&](int completed) { // before the next iteration has changed anything
+            if (tid == 0) {
+                A.st_q[b]    = completed;
+                A.st_I1[b]   = I1;
+                A.st_I2[b]   = I2;
+                A.st_frob[b] = frob;
+                A.st_aux[b]  = aux;
+            }
+        };
+        if (A.team_min > 0 && n1 + n2 >= A.team_min && q >= A.team_q) { // a large block whose rank keeps growing: several workgroups take over
+            suspend(q);
+            q = -3;
+            break;
+        }
         q += 1;
         if ((long long)q * ((long long)n1 + n2) > (long long)n1 * n2 || q > cap) { // not advantageous any more
             q = -1;
@@ -148,6 +280,7 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
         __syncthreads();
         const unsigned long long off = s_off;
         if (off + (unsigned long long)(n1 + n2) > A.pool_cap) {
+            suspend(q - 1);
             q = -2;
             break;
         }
@@ -155,24 +288,13 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
         scalar *u1 = A.pool + off + n1; // new vv (length n2)
         // ---- cross row: entries (I1, k), k over index 2 ------------------------------------------
         const double ax = p1x[I1], ay = p1y[I1], az = p1z[I1];
-        real best = -1;
-        int besti   = -1;
-        for (int k = tid; k < n2; k += NT) {
-            scalar v = swap ? eval_scalar(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_scalar(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]);
-            for (int j = 0; j < q - 1; j++) {
-                const scalar *cj  = A.pool + cross[j];
-                const scalar coef = -cj[I1];
-                v                 = coef * cj[n1 + k] + v;
-            }
-            u1[k] = v;
-            if (!vis2[k]) {
-                const real a = hmx_abs(v);
-                if (a >= best) { // k increases per thread: ">=" keeps the last maximum
-                    best  = a;
-                    besti = k;
-                }
-            }
-        }
+        real best;
+        int besti;
+        auto row_entry = [&](int k) { return swap ? eval_scalar(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_scalar(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]); };
+        if (n2 <= NT)
+            aca_cross_line<NT, 1>(0, n2, q - 1, cross, A.pool, I1, n1, u1, row_entry, false, scalar(1), vis2, -1, best, besti, s_coef, s_offs);
+        else
+            aca_cross_line<NT, 4>(0, n2, q - 1, cross, A.pool, I1, n1, u1, row_entry, false, scalar(1), vis2, -1, best, besti, s_coef, s_offs);
         block_argmax<NT>(best, besti, sval, sidx); // also makes u1 visible to the whole workgroup
         if (besti >= 0)
             I2 = besti;
@@ -183,25 +305,11 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
         if (hmx_abs(piv) > 1e-15) {
             // ---- cross column: entries (k, I2), k over index 1 -----------------------------------
             const double bx = p2x[I2], by = p2y[I2], bz = p2z[I2];
-            best  = -1.0;
-            besti = -1;
-            for (int k = tid; k < n1; k += NT) {
-                scalar v = swap ? eval_scalar(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_scalar(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz);
-                for (int j = 0; j < q - 1; j++) {
-                    const scalar *cj  = A.pool + cross[j];
-                    const scalar coef = -cj[n1 + I2];
-                    v                 = coef * cj[k] + v;
-                }
-                v     = v * gamma;
-                u2[k] = v;
-                if (!vis1[k] && k != I1) {
-                    const real a = hmx_abs(v);
-                    if (a >= best) {
-                        best  = a;
-                        besti = k;
-                    }
-                }
-            }
+            auto col_entry = [&](int k) { return swap ? eval_scalar(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_scalar(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz); };
+            if (n1 <= NT)
+                aca_cross_line<NT, 1>(0, n1, q - 1, cross, A.pool, (int64_t)n1 + I2, 0, u2, col_entry, true, gamma, vis1, I1, best, besti, s_coef, s_offs);
+            else
+                aca_cross_line<NT, 4>(0, n1, q - 1, cross, A.pool, (int64_t)n1 + I2, 0, u2, col_entry, true, gamma, vis1, I1, best, besti, s_coef, s_offs);
             block_argmax<NT>(best, besti, sval, sidx);
             const int nextI1 = besti >= 0 ? besti : I1;
             if (tid == 0) {
@@ -219,21 +327,17 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
                 aux             = hmx_abs(acc2[0]) * hmx_abs(acc2[1]);
                 scalar frob_aux = 0;
                 for (int j0 = 0; j0 < q - 1; j0 += 4) {
-                    scalar acc[8] = {};
-                    const int nj  = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
-                    for (int g = 0; g < nj; g++) {
-                        const scalar *cj = A.pool + cross[j0 + g];
-                        scalar a1 = 0, a2 = 0;
-                        for (int k = tid; k < n2; k += NT)
-                            a1 += hmx_conj(cj[n1 + k]) * u1[k];
-                        for (int k = tid; k < n1; k += NT)
-                            a2 += hmx_conj(cj[k]) * u2[k];
-                        acc[2 * g]     = a1;
-                        acc[2 * g + 1] = a2;
-                    }
+                    const int nj = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
+                    scalar acc[8];
+                    aca_dots4<NT>(A.pool, cross, j0, nj, n1, n2, u1, u2, acc);
                     block_sum_group<NT, 8>(acc, sbuf);
-                    for (int g = 0; g < nj; g++)
-                        frob_aux += acc[2 * g] * acc[2 * g + 1];
+                    frob_aux += acc[0] * acc[1];
+                    if (nj > 1)
+                        frob_aux += acc[2] * acc[3];
+                    if (nj > 2)
+                        frob_aux += acc[4] * acc[5];
+                    if (nj > 3)
+                        frob_aux += acc[6] * acc[7];
                 }
                 frob += aux + 2 * hmx_re(frob_aux);
             }
@@ -247,9 +351,264 @@ __global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
         }
     }
     if (tid == 0) {
-        A.rank_out[b]    = q > 0 ? q : (q == -2 ? -2 : 0);
+        A.rank_out[b]    = q > 0 ? q : (q <= -2 ? q : 0);
         A.swapped_out[b] = swap ? 1 : 0;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same iteration for a TEAM of G workgroups per block.  One workgroup streams some tens of GB/s: a 15 625 x 15 625 block of rank 476
+// walks 113 GB of its own history, seconds on one compute unit while the rest of the GPU has long finished.  So large blocks leave
+// aca_kernel after team_q iterations (rank -3, state in st_*) and continue here, three launches per iteration over all such blocks:
+//   aca_team_control_kernel  error estimator of the iteration just finished (the history crosses are dealt out to the workgroups, each sum is
+//                            complete in one workgroup exactly as in aca_kernel), stopping test, pool grant for the next iteration
+//   aca_team_row_kernel      the cross row, the workgroups share the entries; column pivot
+//   aca_team_col_kernel      the cross column; next row pivot
+// Row and column entries and the pivots are those of aca_kernel bit for bit (every entry sums its history in the same order, the pivot
+// rule is order independent); only the final sum of the estimator's products runs over per-workgroup partial sums.  The last workgroup
+// of a team to arrive (atomic counter, no spinning, so no co-residency is needed) does the team's scalar work.
+// ---------------------------------------------------------------------------------------------
+struct AcaTeamArgs {
+    AcaArgs A;
+    const int32_t *wg_team;    // workgroup -> team
+    const int32_t *team_block; // team -> block id
+    const int32_t *team_wg0;   // team -> its first workgroup
+    const int32_t *team_G;     // team -> workgroups
+    int32_t *status;           // block: 0 active, 1 finished, 2 suspended (pool exhausted)
+    int32_t *need_dots;        // block: an iteration has completed whose estimator is due
+    scalar *gamma;             // block: 1 / pivot of the iteration in progress
+    unsigned long long *off;   // block: pool grant of the iteration in progress (of the last one while need_dots)
+    unsigned int *counter;     // block: arrivals
+    real *pval;                // workgroup: partial pivot search
+    int32_t *pidx;
+    scalar *pfrob;             // workgroup: partial sum of the estimator's products
+    real *paux;                // block: |c.c||r.r|
+};
+
+struct AcaTeamBlock { // what every team kernel derives from its workgroup index
+    int t, b, g, G, n1, n2;
+    bool swap;
+    const double *p1x, *p1y, *p1z, *p2x, *p2y, *p2z;
+    unsigned char *vis1, *vis2;
+    int64_t *cross;
+};
+__device__ __forceinline__ bool aca_team_setup(const AcaTeamArgs &T, AcaTeamBlock &B) {
+    const AcaArgs &A = T.A;
+    B.t              = T.wg_team[blockIdx.x];
+    B.b              = T.team_block[B.t];
+    if (T.status[B.b] != 0)
+        return false;
+    B.g            = (int)blockIdx.x - T.team_wg0[B.t];
+    B.G            = T.team_G[B.t];
+    const int b    = B.b;
+    const int M    = A.t_size[b], N = A.s_size[b];
+    const int roff = A.t_off[b], coff = A.s_off[b];
+    B.swap         = A.symmetric_pivoting && !(roff >= coff);
+    B.n1           = B.swap ? N : M;
+    B.n2           = B.swap ? M : N;
+    B.p1x = B.swap ? A.sx + coff : A.tx + roff; B.p1y = B.swap ? A.sy + coff : A.ty + roff; B.p1z = B.swap ? A.sz + coff : A.tz + roff;
+    B.p2x = B.swap ? A.tx + roff : A.sx + coff; B.p2y = B.swap ? A.ty + roff : A.sy + coff; B.p2z = B.swap ? A.tz + roff : A.sz + coff;
+    B.vis1  = A.visited + A.vis_ptr[b];
+    B.vis2  = B.vis1 + B.n1;
+    B.cross = A.cross_off + A.colptr[b];
+    return true;
+}
+// true in the workgroup that arrives last: everything the other workgroups of the team wrote before arriving is visible to it
+__device__ __forceinline__ bool aca_team_arrive(unsigned int *counter, int G, int *s_last) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *s_last = atomicAdd(counter, 1u) == (unsigned)(G - 1);
+    __syncthreads();
+    const bool last = *s_last != 0;
+    if (last)
+        __threadfence();
+    return last;
+}
+// the share [lo, hi) of workgroup g in a line of n entries (whole wavefronts)
+__device__ __forceinline__ void aca_team_share(int n, int g, int G, int &lo, int &hi) {
+    const int per = (((n + G - 1) / G) + WAVE - 1) / WAVE * WAVE;
+    lo            = g * per < n ? g * per : n;
+    hi            = lo + per < n ? lo + per : n;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void aca_team_control_kernel(AcaTeamArgs T) {
+    __shared__ scalar sbuf[(NT / WAVE) * 8];
+    __shared__ int s_last;
+    AcaTeamBlock B;
+    if (!aca_team_setup(T, B))
+        return;
+    const AcaArgs &A = T.A;
+    const int tid = threadIdx.x, n1 = B.n1, n2 = B.n2, b = B.b;
+    const int q   = A.st_q[b]; // iterations completed
+    const bool dots = T.need_dots[B.b] != 0;
+    if (dots) {
+        const scalar *u2 = A.pool + T.off[B.b], *u1 = u2 + n1;
+        if (B.g == 0) {
+            scalar acc2[2] = {scalar(0), scalar(0)};
+            for (int k = tid; k < n1; k += NT)
+                acc2[0] += hmx_conj(u2[k]) * u2[k];
+            for (int k = tid; k < n2; k += NT)
+                acc2[1] += hmx_conj(u1[k]) * u1[k];
+            block_sum_group<NT, 2>(acc2, sbuf);
+            if (tid == 0)
+                T.paux[B.b] = hmx_abs(acc2[0]) * hmx_abs(acc2[1]);
+        }
+        scalar part = 0;
+        for (int j0 = 4 * B.g; j0 < q - 1; j0 += 4 * B.G) { // groups of four history crosses, dealt out round robin
+            const int nj = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
+            scalar acc[8];
+            aca_dots4<NT>(A.pool, B.cross, j0, nj, n1, n2, u1, u2, acc);
+            block_sum_group<NT, 8>(acc, sbuf);
+            part += acc[0] * acc[1];
+            if (nj > 1)
+                part += acc[2] * acc[3];
+            if (nj > 2)
+                part += acc[4] * acc[5];
+            if (nj > 3)
+                part += acc[6] * acc[7];
+        }
+        if (tid == 0)
+            T.pfrob[blockIdx.x] = part;
+    }
+    if (!aca_team_arrive(T.counter + B.b, B.G, &s_last) || tid != 0)
+        return;
+    // ---- the team's scalar work: estimator, stopping test (partialACA.hpp:78-84), grant for the next iteration --------------------------
+    real frob = A.st_frob[b], aux = A.st_aux[b];
+    if (dots) {
+        scalar frob_aux = 0;
+        for (int g = 0; g < B.G; g++)
+            frob_aux += T.pfrob[T.team_wg0[B.t] + g];
+        aux = T.paux[B.b];
+        frob += aux + 2 * hmx_re(frob_aux);
+        A.st_frob[b] = frob;
+        A.st_aux[b]  = aux;
+    }
+    T.need_dots[B.b] = 0;
+    T.counter[B.b]   = 0;
+    auto finish = [&](int rank) {
+        A.rank_out[b]    = rank;
+        A.swapped_out[b] = B.swap ? 1 : 0;
+        T.status[B.b]    = rank == -2 ? 2 : 1;
+    };
+    if (!(q == 0 || sqrt(aux / frob) > (real)A.epsilon)) {
+        finish(q);
+        return;
+    }
+    const int qn = q + 1;
+    if ((long long)qn * ((long long)n1 + n2) > (long long)n1 * n2 || qn > A.colcap[b]) { // not advantageous any more: the compressor fails
+        finish(0);
+        return;
+    }
+    const unsigned long long off = atomicAdd(A.pool_head, (unsigned long long)(n1 + n2));
+    if (off + (unsigned long long)(n1 + n2) > A.pool_cap) {
+        finish(-2);
+        return;
+    }
+    T.off[B.b] = off;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void aca_team_row_kernel(AcaTeamArgs T) {
+    __shared__ real sval[NT / WAVE];
+    __shared__ int sidx[NT / WAVE];
+    __shared__ scalar s_coef[ACA_JT];
+    __shared__ int64_t s_offs[ACA_JT];
+    __shared__ int s_last;
+    AcaTeamBlock B;
+    if (!aca_team_setup(T, B))
+        return;
+    const AcaArgs &A = T.A;
+    const int tid = threadIdx.x, n1 = B.n1, n2 = B.n2, b = B.b;
+    const int q   = A.st_q[b] + 1; // the iteration in progress
+    const int I1  = A.st_I1[b];
+    scalar *u1    = A.pool + T.off[B.b] + n1;
+    const double ax = B.p1x[I1], ay = B.p1y[I1], az = B.p1z[I1];
+    auto row_entry = [&](int k) { return B.swap ? eval_scalar(A.ks, B.p2x[k], B.p2y[k], B.p2z[k], ax, ay, az) : eval_scalar(A.ks, ax, ay, az, B.p2x[k], B.p2y[k], B.p2z[k]); };
+    int lo, hi;
+    aca_team_share(n2, B.g, B.G, lo, hi);
+    real best = -1;
+    int besti = -1;
+    if (lo < hi) {
+        if (hi - lo <= NT)
+            aca_cross_line<NT, 1>(lo, hi, q - 1, B.cross, A.pool, I1, n1, u1, row_entry, false, scalar(1), B.vis2, -1, best, besti, s_coef, s_offs);
+        else
+            aca_cross_line<NT, 4>(lo, hi, q - 1, B.cross, A.pool, I1, n1, u1, row_entry, false, scalar(1), B.vis2, -1, best, besti, s_coef, s_offs);
+    }
+    block_argmax<NT>(best, besti, sval, sidx);
+    if (tid == 0) {
+        T.pval[blockIdx.x] = best;
+        T.pidx[blockIdx.x] = besti;
+    }
+    if (!aca_team_arrive(T.counter + B.b, B.G, &s_last))
+        return;
+    best  = tid < B.G ? T.pval[T.team_wg0[B.t] + tid] : (real)-1;
+    besti = tid < B.G ? T.pidx[T.team_wg0[B.t] + tid] : -1;
+    block_argmax<NT>(best, besti, sval, sidx);
+    if (tid != 0)
+        return;
+    const int I2     = besti >= 0 ? besti : A.st_I2[b];
+    const scalar piv = u1[I2];
+    B.vis1[I1]       = 1;
+    T.counter[B.b]   = 0;
+    A.st_I2[b]       = I2;
+    if (hmx_abs(piv) > 1e-15) {
+        T.gamma[B.b] = scalar(1) / piv;
+    } else { // zero row: the crosses found so far are the approximation (none: the compressor fails)
+        A.rank_out[b]    = q - 1 > 0 ? q - 1 : 0;
+        A.swapped_out[b] = B.swap ? 1 : 0;
+        T.status[B.b]    = 1;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void aca_team_col_kernel(AcaTeamArgs T) {
+    __shared__ real sval[NT / WAVE];
+    __shared__ int sidx[NT / WAVE];
+    __shared__ scalar s_coef[ACA_JT];
+    __shared__ int64_t s_offs[ACA_JT];
+    __shared__ int s_last;
+    AcaTeamBlock B;
+    if (!aca_team_setup(T, B))
+        return;
+    const AcaArgs &A = T.A;
+    const int tid = threadIdx.x, n1 = B.n1, b = B.b;
+    const int q   = A.st_q[b] + 1;
+    const int I1 = A.st_I1[b], I2 = A.st_I2[b];
+    const unsigned long long off = T.off[B.b];
+    scalar *u2         = A.pool + off;
+    const scalar gamma = T.gamma[B.b];
+    const double bx = B.p2x[I2], by = B.p2y[I2], bz = B.p2z[I2];
+    auto col_entry = [&](int k) { return B.swap ? eval_scalar(A.ks, bx, by, bz, B.p1x[k], B.p1y[k], B.p1z[k]) : eval_scalar(A.ks, B.p1x[k], B.p1y[k], B.p1z[k], bx, by, bz); };
+    int lo, hi;
+    aca_team_share(n1, B.g, B.G, lo, hi);
+    real best = -1;
+    int besti = -1;
+    if (lo < hi) {
+        if (hi - lo <= NT)
+            aca_cross_line<NT, 1>(lo, hi, q - 1, B.cross, A.pool, (int64_t)n1 + I2, 0, u2, col_entry, true, gamma, B.vis1, I1, best, besti, s_coef, s_offs);
+        else
+            aca_cross_line<NT, 4>(lo, hi, q - 1, B.cross, A.pool, (int64_t)n1 + I2, 0, u2, col_entry, true, gamma, B.vis1, I1, best, besti, s_coef, s_offs);
+    }
+    block_argmax<NT>(best, besti, sval, sidx);
+    if (tid == 0) {
+        T.pval[blockIdx.x] = best;
+        T.pidx[blockIdx.x] = besti;
+    }
+    if (!aca_team_arrive(T.counter + B.b, B.G, &s_last))
+        return;
+    best  = tid < B.G ? T.pval[T.team_wg0[B.t] + tid] : (real)-1;
+    besti = tid < B.G ? T.pidx[T.team_wg0[B.t] + tid] : -1;
+    block_argmax<NT>(best, besti, sval, sidx);
+    if (tid != 0)
+        return;
+    B.vis2[I2]       = 1;
+    B.cross[q - 1]   = (int64_t)off;
+    A.st_I1[b]       = besti >= 0 ? besti : I1;
+    A.st_q[b]        = q;
+    T.need_dots[B.b] = 1;
+    T.counter[B.b]   = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

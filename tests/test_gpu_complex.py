@@ -64,6 +64,17 @@ def test_complex_compression_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", Z_CASES)
+def test_complex_workgroup_teams_build_the_same_operator(name, monkeypatch):
+    """The team kernels of the ACA (tests/test_gpu_parity.py::test_workgroup_teams_build_the_same_operator) for complex coefficients."""
+    monkeypatch.setenv("HMX_ACA_TEAM_MIN", "48")
+    monkeypatch.setenv("HMX_ACA_TEAM_Q", "2")
+    monkeypatch.setenv("HMX_ACA_TEAM_SLICE", "64")
+    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "3")
+    test_complex_compression_matches_reference(name)
+    test_complex_products_match_reference(name)
+
+
+@pytest.mark.parametrize("name", Z_CASES)
 def test_complex_products_match_reference(name):
     p, g = params(name), load(name)
     T, S, H = build_zengine(p)

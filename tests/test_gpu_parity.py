@@ -609,10 +609,11 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
             assert rel_err(Y, Ho.matmat_row_major(X, "T", 1.5, -0.5, Y0)) < 1e-12
 
 
-@pytest.mark.parametrize("name", ["ellipse_n3000_partial", "ball_n1500_eps1e-12", "ball_n1200_fullACA"])
+@pytest.mark.parametrize("name", ["ellipse_n3000_partial", "ball_n1500_eps1e-12", "ball_n1200_fullACA", "ball_n2000_symL_eta3"])
 def test_pool_estimate_too_low_is_retried(name, monkeypatch):
-    """The cross pool is sized from a rank estimate; when a block runs out of pool the compression is repeated with the
-    whole budget and gives the same operator."""
+    """The cross pool is sized from a rank estimate.  When the pool runs out, the blocks of the device ACA suspend, the pool grows and
+    they continue with their next iteration (several rounds with a guess of 1); fullACA / SVD repeat the compression with the whole
+    budget.  Either way the operator is the one the reference builds."""
     p, g = params(name), load(name)
     monkeypatch.setenv("HMX_POOL_RANK_GUESS", "1")
     T, S, H = build_engine(p)
@@ -622,6 +623,20 @@ def test_pool_estimate_too_low_is_retried(name, monkeypatch):
     y = y0.copy()
     hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
     assert rel_err(y, g["yN"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ACA_CASES)
+def test_workgroup_teams_build_the_same_operator(name, monkeypatch):
+    """Large blocks whose rank keeps growing are continued by teams of workgroups (aca_team_*_kernel, three launches per iteration).
+    Forced onto the fixtures here -- every block of 48 rows + columns or more after two iterations, 64 entries of a line per
+    workgroup, and a pool that runs out on the way: structure, ranks, factors and products are the reference's."""
+    monkeypatch.setenv("HMX_ACA_TEAM_MIN", "48")
+    monkeypatch.setenv("HMX_ACA_TEAM_Q", "2")
+    monkeypatch.setenv("HMX_ACA_TEAM_SLICE", "64")
+    test_compression_matches_reference(name)
+    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "3")
+    test_compression_matches_reference(name)
+    test_matvec_matches_reference(name)
 
 
 def test_trans_c_for_real_coefficients():
