@@ -228,8 +228,14 @@ __device__ __forceinline__ void aca_dots4(const scalar *pool, const int64_t *cro
 // row side unless symmetric pivoting asks for the larger-offset side.
 // A block that finds the pool exhausted SUSPENDS: it records (q, I1, frob, aux) in A.st_* and reports rank -2; the host grows the pool and
 // launches the suspended blocks again, which continue with their next iteration (crosses and visited flags are in global memory already).
+#undef HMX_ACA_OCCUPANCY
+#if HMX_COMPLEX
+#define HMX_ACA_OCCUPANCY
+#else
+#define HMX_ACA_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4))) // <= 128 registers: the many small blocks want workgroups in flight, not loads
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void aca_kernel(AcaArgs A) {
+__global__ __launch_bounds__(NT) HMX_ACA_OCCUPANCY void aca_kernel(AcaArgs A) {
     __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
     __shared__ scalar sbuf[(NT / WAVE) * 8];
