@@ -10,5 +10,5 @@ tb.set_minimal_target_depth(6); tb.set_minimal_source_depth(6)
 for rep in range(2):
     H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T)
     st = H.stats()
-    print(os.environ.get("HMX_ACA_BIG"), os.environ.get("HMX_ACA_SERIAL"), "ACA %.1f ms" % (1e3 * st["t_compress_s"]), flush=True)
+    print("team", os.environ.get("HMX_ACA_TEAM"), os.environ.get("HMX_ACA_TEAM_MIN"), os.environ.get("HMX_ACA_TEAM_Q"), "ACA %.1f ms" % (1e3 * st["t_compress_s"]), flush=True)
     del H
