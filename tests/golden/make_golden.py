@@ -123,6 +123,9 @@ FULL_CASES = {
     "full_ball_n100000_symL": dict(n=100000, geom="ball", leaf=100, eps=1e-4, eta=10, sym="S", uplo="L", compressor="sympartialACA"),
     # BASELINE config 5's shape at a size the reference builds here: fp32 coefficients, 'S','L', sympartialACA, eps=1e-6, 16 RHS
     "full_ellipse_n100000_f32_symL_mu16": dict(n=100000, geom="ellipse", leaf=100, eps=1e-6, eta=10, sym="S", uplo="L", compressor="sympartialACA", prec="f32", mu=16),
+    # the reference's Hermitian test generator (sign-discontinuous imaginary part, testing/generator_test.hpp:186-205): blocks that cross the
+    # discontinuity have ranks in the hundreds -- the case the ACA's pool growth and workgroup teams exist for
+    "full_ellipse_n100000_z64_hermL": dict(n=100000, geom="ellipse", leaf=100, eps=1e-4, eta=10, sym="H", uplo="L", compressor="sympartialACA", prec="z64", mindepth=3),
 }
 
 

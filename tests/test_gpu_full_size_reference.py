@@ -1,7 +1,8 @@
 """BASELINE.json's own sizes against the REFERENCE itself (north star: "<= 1e-10 relative error vs CPU reference" at N=1e6).
 
 tests/golden/full_*.npz were written by htool (oracle/_ref/ref_driver, `python tests/golden/make_golden.py full`): N=1e5 ball and
-ellipse, N=1e6 ellipse with the bench's minimal block depth, the symmetric ('S','L', sympartialACA) N=1e5 operators and BASELINE
+ellipse, N=1e6 ellipse with the bench's minimal block depth, the symmetric ('S','L', sympartialACA) N=1e5 operators, the complex
+Hermitian N=1e5 operator of the reference's sign-discontinuous test generator (ranks up to 490: the ACA's pool growth and workgroup teams) and BASELINE
 config 5's shape (fp32, 'S','L', eps=1e-6, 16 right-hand sides) at N=1e5, and BASELINE configs[3] rank by rank: the N=1e6 operator
 row-partitioned over 8 ranks (`full_ellipse_n1000000_p8_rank<k>`: what rank k of htool's DistributedOperator holds and multiplies
 before the Allgatherv), each rank's share built and multiplied on the one GPU a box has.  A fixture holds sha256 of the cluster permutation and of
@@ -15,7 +16,7 @@ import pytest
 
 import htool_amd as hm
 from helpers import MANIFEST, load
-from oracle.oracle import hashed_vector
+from oracle.oracle import hashed_vector, hashed_zvector
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +32,7 @@ def test_full_size_matches_the_reference(name):
     p, g = MANIFEST[name], load(name)
     n, mu = p["n"], p.get("mu", 2)
     f32 = p.get("prec") == "f32"
+    z64 = p.get("prec") == "z64"  # the reference's complex generators: (1 + i sgn) / (delta + r), sgn = sign(x_t[0] - x_s[0]) for 'H'
     sym, uplo = p.get("sym", "N"), p.get("uplo", "N")
     x = hm.create_geometry(p["geom"], n)
     b = hm.ClusterTreeBuilder()
@@ -42,7 +44,10 @@ def test_full_size_matches_the_reference(name):
     tb.set_low_rank_generator(p["compressor"])
     tb.set_minimal_target_depth(p.get("mindepth", 0))
     tb.set_minimal_source_depth(p.get("mindepth", 0))
-    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, rank, rank, dtype=np.float32 if f32 else np.float64)
+    gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 1.0, sym == "H") if z64 else hm.InvDistGenerator(3, x, x, 1e-5, 1.0)
+    dt = np.complex128 if z64 else (np.float32 if f32 else np.float64)
+    hashed = (lambda n, s: hashed_zvector(n, s).astype(dt)) if z64 else (lambda n, s: hashed_vector(n, s).astype(dt))
+    H = tb.build(gen, T, T, rank, rank, dtype=dt)
     nr = H.nb_rows()
     tab = np.asarray(H.leaf_table())
     assert len(tab) == int(g["nleaves"])
@@ -61,25 +66,27 @@ def test_full_size_matches_the_reference(name):
     else:
         assert ndiff == 0
     rows = g["rows"]
-    dt = np.float32 if f32 else np.float64
     tol = 2e-5 if f32 else 1e-10
-    xin = hashed_vector(n, 1).astype(dt)
+    xin = hashed(n, 1)
 
     def err(a, ref):
-        return float(np.linalg.norm(a.astype(np.float64) - ref) / np.linalg.norm(ref))
+        if z64 and not np.iscomplexobj(ref):  # stored as (re, im) pairs
+            ref = np.ascontiguousarray(ref).view(np.complex128).reshape(ref.shape[:-1])
+        return float(np.linalg.norm(a.astype(np.complex128 if z64 else np.float64) - ref) / np.linalg.norm(ref))
 
     y = np.zeros(nr, dtype=dt)
     hm.internal_add_hmatrix_vector_product("N", 1.0, H, xin, 0.0, y)
     e1 = err(y[rows], g["yN_a1b0"])
-    al, be = float(g["alphabeta"][0]), float(g["alphabeta"][1])
-    y = hashed_vector(nr, 3).astype(dt)
+    ab = g["alphabeta"]
+    al, be = (complex(ab[0], ab[2]), complex(ab[1], ab[3])) if z64 else (float(ab[0]), float(ab[1]))
+    y = hashed(nr, 3)
     hm.internal_add_hmatrix_vector_product("N", al, H, xin, be, y)
     e2 = err(y[rows], g["yN"])
-    X = hashed_vector(n * mu, 5).astype(dt).reshape(n, mu)
-    Y = hashed_vector(nr * mu, 6).astype(dt).reshape(nr, mu)
+    X = hashed(n * mu, 5).reshape(n, mu)
+    Y = hashed(nr * mu, 6).reshape(nr, mu)
     hm.internal_add_hmatrix_matrix_product_row_major("N", al, H, X, be, Y, mu)
     e3 = err(Y[rows], g["YNrm"])
-    print("%s: relative error vs the reference at %d rows: %.2e (alpha=1, beta=0), %.2e (alpha=%g, beta=%g), %.2e (%d right-hand sides)" % (name, len(rows), e1, e2, al, be, e3, mu))
+    print("%s: relative error vs the reference at %d rows: %.2e (alpha=1, beta=0), %.2e (alpha=%s, beta=%s), %.2e (%d right-hand sides)" % (name, len(rows), e1, e2, al, be, e3, mu))
     if ndiff == 0:
         assert e1 < tol and e2 < tol and e3 < tol
     else:  # some fp32 ranks moved by one: the products differ by what one cross of those blocks carries (below epsilon)
