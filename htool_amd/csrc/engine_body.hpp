@@ -1784,6 +1784,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             HMX_HIP(t_status.zero()); // every block in `blocks` is active (again); the entries of other blocks are not looked at
             std::vector<int32_t> cur = blocks, st(nb);
             int launches = 0;
+            double t_wait = 0, t_copy = 0;
             // Tables for at most 64 workgroups per block, allocated once: hipFree waits for the whole device, and the side stream is busy with
             // the small blocks meanwhile.  (Dealing the teams out to 2 / 4 / 8 streams so that launches overlap was measured on the N=1e6
             // Hermitian case: 1.65 / 2.3 / 2.8 s for the team phase against 1.65 s on one stream -- the launches themselves become the cost.)
@@ -1823,7 +1824,13 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                         launches += 3;
                     }
                     HMX_HIP(hipGetLastError());
+                    const auto tq0 = std::chrono::steady_clock::now();
+                    HMX_HIP(hipStreamSynchronize(0));
+                    const auto tq1 = std::chrono::steady_clock::now();
                     HMX_HIP(hipMemcpy(st.data(), t_status.d, nb * 4, hipMemcpyDeviceToHost));
+                    const auto tq2 = std::chrono::steady_clock::now();
+                    t_wait += std::chrono::duration<double, std::milli>(tq1 - tq0).count();
+                    t_copy += std::chrono::duration<double, std::milli>(tq2 - tq1).count();
                     std::vector<int32_t> still;
                     for (int32_t b : cur)
                         if (st[b] == 0)
@@ -1835,7 +1842,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                 }
             }
             if (phase_timing)
-                fprintf(stderr, "[hmx build]   round %d (%.0f ms): %zu blocks continued by workgroup teams, %d launches\n", round, since_phase(), blocks.size(), launches);
+                fprintf(stderr, "[hmx build]   round %d (%.0f ms): %zu blocks continued by workgroup teams, %d launches (host waited %.0f ms for the kernels, %.0f ms for status copies)\n", round, since_phase(), blocks.size(), launches, t_wait, t_copy);
             return HMX_OK;
         };
         const bool team_ok = reqrank < 0 && !(getenv("HMX_ACA_TEAM") && atoi(getenv("HMX_ACA_TEAM")) == 0);
