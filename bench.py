@@ -402,7 +402,7 @@ def main():
                 tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 trials[chunks] = float(tt.item()) / 10 * 1e3
-            best = min(trials, key=trials.get)
+            best = min(trials, key=trials.get) if trials else 0  # nothing could be timed (a pinned chunk count no rank supports): one exchange
             native.set_overlap(best, like=y)
             dist_info.update(overlap_chunks=best, overlap_trials_ms={str(k): v for k, v in trials.items()})
             log("output exchange variants (ms per step, 0 = one exchange after the product): %s -> %d" % (trials, best))
