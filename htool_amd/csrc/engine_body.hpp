@@ -1767,9 +1767,10 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             cap = newcap;
             return HMX_OK;
         };
-        // entries of a line per workgroup.  Fewer entries = more workgroups for the last few blocks, but every workgroup walks the whole history
-        // for its entries: 256 or a count adapted to the blocks left were slower than 1024 throughout (N=1e6 Hermitian case: 2.5-3.0 vs 1.9 s)
-        const int team_slice = getenv("HMX_ACA_TEAM_SLICE") ? std::max(64, atoi(getenv("HMX_ACA_TEAM_SLICE"))) : 1024;
+        // entries of a line per workgroup: 1024 while the launch has workgroups enough to fill the GPU, 256 when few blocks are left (a
+        // workgroup walks the whole history whatever its share, 16 loads in flight per thread either way: N=1e6 Hermitian case, team phase
+        // of the second round 1.63 s with 1024 throughout, 1.53 s with 256 throughout -- but the first round 0.92 instead of 0.75 s)
+        const int team_slice_env = getenv("HMX_ACA_TEAM_SLICE") && atoi(getenv("HMX_ACA_TEAM_SLICE")) > 0 ? std::max(64, atoi(getenv("HMX_ACA_TEAM_SLICE"))) : 0;
         auto run_team = [&](const std::vector<int32_t> &blocks, int round) -> int {
             if (!t_status.d) {
                 HMX_HIP(t_status.alloc(nb));
@@ -1799,6 +1800,13 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             HMX_HIP(d_pval.alloc(64 * cur.size()));
             HMX_HIP(d_pfrob.alloc(64 * cur.size()));
             while (!cur.empty()) {
+                int team_slice = team_slice_env;
+                if (team_slice == 0) { // (the kernels have a one-entry and a four-entry path per thread: shares of 257-512 entries would idle half of the latter)
+                    int64_t wgs = 0;
+                    for (int32_t b : cur)
+                        wgs += (std::max(H.leaves[b].t_size, H.leaves[b].s_size) + 1023) / 1024;
+                    team_slice = wgs >= 1536 ? 1024 : 256;
+                }
                 std::vector<int32_t> team_G(cur.size()), team_wg0(cur.size()), wg_team;
                 for (size_t t = 0; t < cur.size(); t++) {
                     const hmx_leaf &l = H.leaves[cur[t]];

@@ -144,7 +144,7 @@ __device__ __forceinline__ void aca_cross_line(int k_lo, int n, int nq, const in
                 kk[r]       = k < n ? k : n - 1;
                 v[r]        = first ? eval(kk[r]) : out[kk[r]];
             }
-#pragma unroll 4
+#pragma unroll(16 / KR) // 16 loads of the history in flight per thread
             for (int jj = 0; jj < tile; jj++) {
                 const scalar coef = s_coef[jj];
                 const scalar *cj  = pool + s_offs[jj];
