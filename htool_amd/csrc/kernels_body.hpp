@@ -144,13 +144,21 @@ __device__ __forceinline__ void aca_cross_line(int k_lo, int n, int nq, const in
                 kk[r]       = k < n ? k : n - 1;
                 v[r]        = first ? eval(kk[r]) : out[kk[r]];
             }
-#pragma unroll(16 / KR) // 16 loads of the history in flight per thread
-            for (int jj = 0; jj < tile; jj++) {
+            auto apply = [&](int jj) {
                 const scalar coef = s_coef[jj];
                 const scalar *cj  = pool + s_offs[jj];
 #pragma unroll
                 for (int r = 0; r < KR; r++)
                     v[r] = coef * cj[kk[r]] + v[r];
+            };
+            if (KR == 1) { // 16 loads of the history in flight per thread on either path
+#pragma unroll 16
+                for (int jj = 0; jj < tile; jj++)
+                    apply(jj);
+            } else {
+#pragma unroll 4
+                for (int jj = 0; jj < tile; jj++)
+                    apply(jj);
             }
 #pragma unroll
             for (int r = 0; r < KR; r++) {
