@@ -352,60 +352,71 @@ def main():
     # of a step are captured once in a HIP graph (htool_amd.distributed.GraphedGlobalToGlobalProduct); the RCCL all-gather
     # is issued eagerly after each replay, so no graph ever holds a collective.  HMX_BENCH_NO_GRAPH=1: eager launches.
     graphed = False
-    if native is not None and mu > 1:
-        # untimed: the native multi-RHS product must equal the torch.distributed layer's
-        Y_ref = torch.zeros_like(Yg)
-        D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, Y_ref, mu)
-        Yg.zero_()
-        step()
-        torch.cuda.synchronize()
-        good = torch.tensor([1 if torch.equal(Yg, Y_ref) else 0], device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(good, op=dist.ReduceOp.MIN)
-        if int(good.item()) == 0:
-            log("native distributed multi-RHS product differs from the torch.distributed layer: falling back")
-            native, dist_info = None, dict(impl="python (torch.distributed); native result mismatch")
-        del Y_ref
-    elif native is not None:
+    if native is not None:
         # untimed: the result must equal the torch.distributed layer's, then the variants of the output exchange are tried for a few
-        # steps each -- one exchange after the product, or the expand stage in 2 / 4 row chunks with every chunk's exchange on a side
-        # stream under the next chunk's kernel (HMX_DIST_OVERLAP=<chunks> pins the choice) -- and the fastest becomes the timed region
-        y_ref = torch.zeros_like(y)
-        D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, y_ref)
-        y.zero_()
-        step()
-        torch.cuda.synchronize()
-        good = torch.tensor([1 if torch.equal(y, y_ref) else 0], device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(good, op=dist.ReduceOp.MIN)
-        if int(good.item()) == 0:
+        # steps each and the fastest becomes the timed region: one exchange after the product or (single vector) the expand stage in
+        # 2 / 4 row chunks with every chunk's exchange on a side stream under the next chunk's kernel; each as an all-gather / grouped
+        # broadcasts or pairwise (grouped ncclSend / ncclRecv: one xGMI link per pair on a fully connected node).
+        # HMX_DIST_OVERLAP=<chunks> and HMX_DIST_P2P=0/1 pin the choice.
+        flag_dev = dev if backend == "nccl" else "cpu"
+        out = Yg if mu > 1 else y
+        ref = torch.zeros_like(out)
+        if mu > 1:
+            D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, ref, mu)
+        else:
+            D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, ref)
+
+        def reproduces():
+            out.zero_()
+            step()
+            torch.cuda.synchronize()
+            good = torch.tensor([1 if torch.equal(out, ref) else 0], device=flag_dev)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            return int(good.item()) == 1
+
+        if not reproduces():
             log("native distributed product differs from the torch.distributed layer: falling back")
             native, dist_info = None, dict(impl="python (torch.distributed); native result mismatch")
         else:
-            pinned = os.environ.get("HMX_DIST_OVERLAP")
+            pin_c, pin_p = os.environ.get("HMX_DIST_OVERLAP"), os.environ.get("HMX_DIST_P2P")
+            chunk_choices = [int(pin_c)] if pin_c is not None else ([0, 2, 4] if mu == 1 else [0])
+            p2p_choices = [bool(int(pin_p))] if pin_p is not None else [False, True]
             trials = {}
-            for chunks in ([int(pinned)] if pinned is not None else [0, 2, 4]):
-                used = native.set_overlap(chunks, like=y)
-                if chunks > 1 and used != chunks:
-                    continue  # some rank's operator cannot be chunked
-                y.zero_()
-                step()
-                torch.cuda.synchronize()
-                same = torch.tensor([1 if torch.equal(y, y_ref) else 0], device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                if int(same.item()) == 0:
-                    log("overlap with %d chunks does not reproduce the result: skipped" % chunks)
+            for p2p in p2p_choices:
+                try:
+                    native.set_point_to_point(p2p)
+                    p2p_ok = 1
+                except Exception as e:  # noqa: BLE001 -- no ncclSend / ncclRecv in this communicator
+                    log("point-to-point exchange unavailable (%r)" % (e,))
+                    p2p_ok = 0
+                agreed = torch.tensor([p2p_ok], device=flag_dev)
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+                if int(agreed.item()) == 0:
+                    native.set_point_to_point(False)
                     continue
-                fence()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    step()
-                fence()
-                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                trials[chunks] = float(tt.item()) / 10 * 1e3
-            best = min(trials, key=trials.get) if trials else 0  # nothing could be timed (a pinned chunk count no rank supports): one exchange
-            native.set_overlap(best, like=y)
-            dist_info.update(overlap_chunks=best, overlap_trials_ms={str(k): v for k, v in trials.items()})
-            log("output exchange variants (ms per step, 0 = one exchange after the product): %s -> %d" % (trials, best))
+                for chunks in chunk_choices:
+                    used = native.set_overlap(chunks, like=out)
+                    if chunks > 1 and used != chunks:
+                        continue  # some rank's operator cannot be chunked
+                    name = "%d%s" % (chunks, "+p2p" if p2p else "")
+                    if not reproduces():
+                        log("exchange variant %s does not reproduce the result: skipped" % name)
+                        continue
+                    fence()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        step()
+                    fence()
+                    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=flag_dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    trials[(chunks, p2p)] = float(tt.item()) / 10 * 1e3
+            best = min(trials, key=trials.get) if trials else (0, False)  # nothing could be timed (pinned to what no rank supports): the plain exchange
+            native.set_point_to_point(best[1])
+            native.set_overlap(best[0], like=out)
+            dist_info.update(overlap_chunks=best[0], point_to_point=bool(best[1]),
+                             exchange_trials_ms={"%d%s" % (c, "+p2p" if p else ""): v for (c, p), v in trials.items()})
+            log("output exchange variants (ms per step; chunks of the expand stage, +p2p = pairwise send/recv): %s -> %s" % (dist_info["exchange_trials_ms"], best))
+        del ref
     if native is None and part and mu == 1 and args.trans == "N" and not os.environ.get("HMX_BENCH_NO_GRAPH"):
         eager_step = step
         eager_step()

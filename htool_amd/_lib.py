@@ -129,6 +129,7 @@ SYMBOLS = [
     ("hmx_dist_set_overlap", C.c_int, [_vp, C.c_int, _vp]),
     ("hmx_dist_overlap_chunks", C.c_int, [_vp]),
     ("hmx_dist_set_reduce_scatter", C.c_int, [_vp, _vp]),
+    ("hmx_dist_set_point_to_point", C.c_int, [_vp, _vp, _vp, C.c_int]),
     ("hmx_hmatrix_last_kernel_times", C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     ("hmx_hmatrix_set_profiling", C.c_int, [_vp, C.c_int]),
     ("hmx_device_trim_cache", C.c_int, []),

@@ -698,6 +698,10 @@ struct hmx_dist {
     DArr<char> work, work2;
     bool force = false; // HMX_DIST_FORCE_COLLECTIVES=1: call RCCL even with one rank (tests)
     int (*reduce_scatter)(const void *, void *, size_t, int, int, void *, void *) = nullptr; // ncclReduceScatter, when available
+    // point-to-point exchange of the output slices (hmx_dist_set_point_to_point): ncclSend / ncclRecv, and whether they are in use
+    int (*send)(const void *, size_t, int, int, void *, void *) = nullptr;
+    int (*recv)(void *, size_t, int, int, void *, void *)       = nullptr;
+    bool p2p = false;
     // overlap of the output exchange with the expand stage (hmx_dist_set_overlap): row chunks, side stream, one event per chunk
     int overlap = 0;                  // requested number of chunks (0 / 1: off)
     int nchunks = 0;                  // chunks in use (the same on every rank)
@@ -725,7 +729,7 @@ static bool dist_beta_is_zero(const hmx_dist &D, const void *beta) {
     const float *b = static_cast<const float *>(beta);
     return b[0] == 0.f && (D.reals == 1 || b[1] == 0.f);
 }
-static int dist_api_from_library(hmx_rccl_api &api, void **reduce_scatter = nullptr) {
+static int dist_api_from_library(hmx_rccl_api &api, void **reduce_scatter = nullptr, void **send = nullptr, void **recv = nullptr) {
     void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h)
         h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -740,6 +744,10 @@ static int dist_api_from_library(hmx_rccl_api &api, void **reduce_scatter = null
     api.group_end   = reinterpret_cast<decltype(api.group_end)>(dlsym(h, "ncclGroupEnd"));
     if (reduce_scatter)
         *reduce_scatter = dlsym(h, "ncclReduceScatter");
+    if (send)
+        *send = dlsym(h, "ncclSend");
+    if (recv)
+        *recv = dlsym(h, "ncclRecv");
     if (!api.all_gather || !api.all_reduce || !api.broadcast || !api.group_start || !api.group_end) {
         set_error("hmx_dist_create: librccl.so lacks a collective entry point");
         return HMX_ERR_UNSUPPORTED;
@@ -754,22 +762,48 @@ static int dist_api_from_library(hmx_rccl_api &api, void **reduce_scatter = null
             return HMX_ERR_HIP;                                                         \
         }                                                                               \
     } while (0)
-// out[off_k : off_k + size_k] = rank k's slice (MPI_Allgatherv)
-static int dist_gather_slices(hmx_dist &D, const std::vector<int> &off, const std::vector<int> &size, const char *local, char *out, hipStream_t st) {
+// Point-to-point form of the slice exchange: every rank sends rows [lo_r, hi_r) of its slice straight to every peer and receives
+// each peer's rows in place, one grouped ncclSend / ncclRecv per pair.  On the fully connected xGMI mesh of an 8-GPU node every
+// pair has its own link, so a 1 MB slice crosses ONE link once, where a ring all-gather forwards it over seven hops in turn.
+// `per` = elements per row (mu for the multi-RHS products).
+static int dist_exchange_p2p(hmx_dist &D, const std::vector<int> &off, const int32_t *lo, const int32_t *hi, int stride, const char *local, char *out, size_t per, hipStream_t st) {
+    const int r = D.rank;
+    const int mylo = lo[(size_t)r * stride], myhi = hi[(size_t)r * stride];
+    if (myhi > mylo)
+        HMX_HIP(hipMemcpyAsync(out + (size_t)(off[r] + mylo) * per * D.esz, local + (size_t)mylo * per * D.esz, (size_t)(myhi - mylo) * per * D.esz, hipMemcpyDeviceToDevice, st));
+    HMX_NCCL(D.api.group_start());
+    for (int k = 0; k < D.world; k++) {
+        if (k == r)
+            continue;
+        if (myhi > mylo)
+            HMX_NCCL(D.send(local + (size_t)mylo * per * D.esz, (size_t)(myhi - mylo) * per * D.reals, D.dtype, k, D.comm, st));
+        const int klo = lo[(size_t)k * stride], khi = hi[(size_t)k * stride];
+        if (khi > klo)
+            HMX_NCCL(D.recv(out + (size_t)(off[k] + klo) * per * D.esz, (size_t)(khi - klo) * per * D.reals, D.dtype, k, D.comm, st));
+    }
+    HMX_NCCL(D.api.group_end());
+    return HMX_OK;
+}
+// out[off_k : off_k + size_k] = rank k's slice (MPI_Allgatherv); `per` elements per row
+static int dist_gather_slices(hmx_dist &D, const std::vector<int> &off, const std::vector<int> &size, const char *local, char *out, hipStream_t st, size_t per = 1) {
     if (D.world == 1 && !D.force) {
-        HMX_HIP(hipMemcpyAsync(out + (size_t)off[0] * D.esz, local, (size_t)size[0] * D.esz, hipMemcpyDeviceToDevice, st));
+        HMX_HIP(hipMemcpyAsync(out + (size_t)off[0] * per * D.esz, local, (size_t)size[0] * per * D.esz, hipMemcpyDeviceToDevice, st));
         return HMX_OK;
+    }
+    if (D.p2p) {
+        std::vector<int32_t> lo(D.world, 0), hi(size.begin(), size.end());
+        return dist_exchange_p2p(D, off, lo.data(), hi.data(), 1, local, out, per, st);
     }
     bool equal = off[0] == 0;
     for (int k = 1; k < D.world; k++)
         equal = equal && size[k] == size[0];
     if (equal && !(getenv("HMX_DIST_NO_ALLGATHER") && atoi(getenv("HMX_DIST_NO_ALLGATHER")))) {
-        HMX_NCCL(D.api.all_gather(local, out, (size_t)size[0] * D.reals, D.dtype, D.comm, st));
+        HMX_NCCL(D.api.all_gather(local, out, (size_t)size[0] * D.reals * per, D.dtype, D.comm, st));
         return HMX_OK;
     }
     HMX_NCCL(D.api.group_start());
     for (int k = 0; k < D.world; k++)
-        HMX_NCCL(D.api.broadcast(local, out + (size_t)off[k] * D.esz, (size_t)size[k] * D.reals, D.dtype, k, D.comm, st));
+        HMX_NCCL(D.api.broadcast(local, out + (size_t)off[k] * per * D.esz, (size_t)size[k] * D.reals * per, D.dtype, k, D.comm, st));
     HMX_NCCL(D.api.group_end());
     return HMX_OK;
 }
@@ -809,6 +843,8 @@ static int dist_chunk_bounds(hmx_dist &D, int nchunks, int *n, int32_t *b) {
 // of different ranks have different sizes and are not adjacent in `out`, so this is not an ncclAllGather)
 static int dist_gather_chunk(hmx_dist &D, int c, const char *local, char *out, hipStream_t st) {
     const int nb = D.nchunks + 1;
+    if (D.p2p)
+        return dist_exchange_p2p(D, D.t_off, D.bounds.data() + c, D.bounds.data() + c + 1, nb, local, out, 1, st);
     HMX_NCCL(D.api.group_start());
     for (int k = 0; k < D.world; k++) {
         const int lo = D.bounds[(size_t)k * nb + c], hi = D.bounds[(size_t)k * nb + c + 1];
@@ -906,6 +942,24 @@ int hmx_dist_set_reduce_scatter(hmx_dist *D, int (*fn)(const void *, void *, siz
     return HMX_OK;
 }
 
+/* Point-to-point exchange of the output slices (ncclSend / ncclRecv shapes); see include/hmx.h */
+int hmx_dist_set_point_to_point(hmx_dist *D, int (*send)(const void *, size_t, int, int, void *, void *), int (*recv)(void *, size_t, int, int, void *, void *), int enable) {
+    if (!D) {
+        set_error("hmx_dist_set_point_to_point: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    if (send && recv) {
+        D->send = send;
+        D->recv = recv;
+    }
+    if (enable && (!D->send || !D->recv)) {
+        set_error("hmx_dist_set_point_to_point: no ncclSend / ncclRecv entry points (give them, or create the operator with a NULL collective table)");
+        return HMX_ERR_UNSUPPORTED;
+    }
+    D->p2p = enable != 0;
+    return HMX_OK;
+}
+
 int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank, int world_size, const hmx_rccl_api *api, hmx_dist **out) {
     if (!local || !target || !source || !out || world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !nccl_comm)) {
         set_error("hmx_dist_create: invalid arguments");
@@ -924,13 +978,15 @@ int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hm
     if (api) {
         D->api = *api;
     } else if (world_size > 1 || D->force) {
-        void *rs     = nullptr;
-        const int rc = dist_api_from_library(D->api, &rs);
+        void *rs = nullptr, *sd = nullptr, *rv = nullptr;
+        const int rc = dist_api_from_library(D->api, &rs, &sd, &rv);
         if (rc != HMX_OK) {
             delete D;
             return rc;
         }
         D->reduce_scatter = reinterpret_cast<decltype(D->reduce_scatter)>(rs);
+        D->send           = reinterpret_cast<decltype(D->send)>(sd);
+        D->recv           = reinterpret_cast<decltype(D->recv)>(rv);
     }
     for (int k = 0; k < world_size; k++) {
         D->t_off.push_back(target->nodes[target->on_partition[k]].offset);
@@ -1053,22 +1109,7 @@ int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const v
         if (rc != HMX_OK)
             return rc;
         // the slices are mu-interleaved rows: the same exchange with mu times the counts
-        if (D.world == 1 && !D.force) {
-            HMX_HIP(hipMemcpyAsync(yb + (size_t)D.t_off[0] * e, D.work.d, (size_t)D.t_size[0] * e, hipMemcpyDeviceToDevice, st));
-            return HMX_OK;
-        }
-        bool equal = D.t_off[0] == 0;
-        for (int k = 1; k < D.world; k++)
-            equal = equal && D.t_size[k] == D.t_size[0];
-        if (equal && !(getenv("HMX_DIST_NO_ALLGATHER") && atoi(getenv("HMX_DIST_NO_ALLGATHER")))) {
-            HMX_NCCL(D.api.all_gather(D.work.d, yb, (size_t)D.t_size[0] * D.reals * mu, D.dtype, D.comm, st));
-            return HMX_OK;
-        }
-        HMX_NCCL(D.api.group_start());
-        for (int k = 0; k < D.world; k++)
-            HMX_NCCL(D.api.broadcast(D.work.d, yb + (size_t)D.t_off[k] * e, (size_t)D.t_size[k] * D.reals * mu, D.dtype, k, D.comm, st));
-        HMX_NCCL(D.api.group_end());
-        return HMX_OK;
+        return dist_gather_slices(D, D.t_off, D.t_size, D.work.d, yb, st, (size_t)mu);
     }
     const int off      = D.t_off[D.rank];
     const size_t bytes = (size_t)D.ns * e;

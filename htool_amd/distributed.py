@@ -374,6 +374,7 @@ class NativeCommunicator:
         self.comm = C.c_void_p(self.rank + 1)
         self.api = _RcclApi()
         self.reduce_scatter = None
+        self.send = self.recv = None  # ncclSend / ncclRecv (hmx_dist_set_point_to_point)
         self._keep = []
         if backend == "rccl":
             path = lib_path or os.environ.get("HMX_RCCL_LIB")
@@ -401,6 +402,7 @@ class NativeCommunicator:
                                ("group_start", "ncclGroupStart"), ("group_end", "ncclGroupEnd")):
                 setattr(self.api, field, C.cast(getattr(self.lib, sym), C.c_void_p).value)
             self.reduce_scatter = C.cast(self.lib.ncclReduceScatter, C.c_void_p)
+            self.send, self.recv = C.cast(self.lib.ncclSend, C.c_void_p), C.cast(self.lib.ncclRecv, C.c_void_p)
         else:
             self._make_host_staged_table()
 
@@ -458,10 +460,36 @@ class NativeCommunicator:
             store(recv, out)
             return 0
 
+        # ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd: posted at the group's end (batch_isend_irecv), so that every rank
+        # can name all its sends before any receive completes
+        pending = []
+
+        def send(buf, count, dt, peer, comm, stream):
+            hip.hipStreamSynchronize(stream)
+            pending.append((dist.isend, fetch(buf, count, dt), peer, None))
+            return 0
+
+        def recv(buf, count, dt, peer, comm, stream):
+            pending.append((dist.irecv, torch.empty(count, dtype=torch.float64 if dt == 8 else torch.float32), peer, buf))
+            return 0
+
+        def group_end():
+            if pending:
+                ops = [dist.P2POp(op, t, dist.get_global_rank(group, peer) if group is not None else peer, group) for op, t, peer, _ in pending]
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                for op, t, _, buf in pending:
+                    if buf is not None:
+                        store(buf, t)
+                del pending[:]
+            return 0
+
         AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
         AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+        SR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
         GR = C.CFUNCTYPE(C.c_int)
-        fns = [AG(all_gather), AR(all_reduce), AR(broadcast), GR(lambda: 0), GR(lambda: 0), AR(reduce_scatter)]
+        fns = [AG(all_gather), AR(all_reduce), AR(broadcast), GR(lambda: 0), GR(group_end), AR(reduce_scatter), SR(send), SR(recv)]
+        self.send, self.recv = C.cast(fns[6], C.c_void_p), C.cast(fns[7], C.c_void_p)
         self._keep = fns
         for field, f in zip(("all_gather", "all_reduce", "broadcast", "group_start", "group_end"), fns):
             setattr(self.api, field, C.cast(f, C.c_void_p).value)
@@ -481,6 +509,8 @@ class NativeDistributedOperator:
                                       C.byref(communicator.api), C.byref(self._h)))
         if communicator.reduce_scatter is not None:
             check(self._L.hmx_dist_set_reduce_scatter(self._h, communicator.reduce_scatter))
+        if communicator.send is not None:  # known, not in use: set_point_to_point(True) switches the slice exchange over
+            check(self._L.hmx_dist_set_point_to_point(self._h, communicator.send, communicator.recv, 0))
         self._scal = {}
 
     def __del__(self):
@@ -508,6 +538,12 @@ class NativeDistributedOperator:
         st = self._stream(like) if like is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(self._L.hmx_dist_set_overlap(self._h, int(chunks), st))
         return int(self._L.hmx_dist_overlap_chunks(self._h))
+
+    def set_point_to_point(self, enable):
+        """Output slices exchanged pairwise (grouped ncclSend / ncclRecv) instead of all-gather / grouped broadcasts
+        (hmx_dist_set_point_to_point); every rank must choose the same."""
+        from ._lib import check
+        check(self._L.hmx_dist_set_point_to_point(self._h, None, None, 1 if enable else 0))
 
     def matvec_global_to_global(self, trans, alpha, x, beta, y):
         from ._lib import check

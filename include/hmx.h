@@ -315,6 +315,16 @@ int hmx_dist_overlap_chunks(const hmx_dist *);
  * Without it, or with unequal partitions, that product uses all-reduce + slice. */
 int hmx_dist_set_reduce_scatter(hmx_dist *, int (*reduce_scatter)(const void *send, void *recv, size_t recvcount, int datatype, int op, void *comm, void *stream));
 
+/* Point-to-point exchange of the output slices of the trans = 'N' global-to-global products (single vector, chunked / overlapped,
+ * multi-RHS) instead of ncclAllGather / grouped ncclBroadcast: every rank sends its rows straight to each peer and receives each
+ * peer's rows in place, one grouped ncclSend / ncclRecv per pair (MPI_Allgatherv of global_to_global.hpp:76 as the pairwise
+ * exchange it is).  An 8-GPU MI355X node is a full xGMI mesh: every pair has its own link, so a slice crosses one link once where
+ * a ring forwards it seven times in turn.  `send` / `recv` have the argument shapes of ncclSend / ncclRecv (rccl.h); NULL keeps
+ * the ones already known (taken from librccl.so when the operator was created with a NULL collective table).  enable != 0 on
+ * EVERY rank or on none.  Results are identical either way. */
+int hmx_dist_set_point_to_point(hmx_dist *, int (*send)(const void *buf, size_t count, int datatype, int peer, void *comm, void *stream),
+                                int (*recv)(void *buf, size_t count, int datatype, int peer, void *comm, void *stream), int enable);
+
 /* Timing hooks for bench.py: average duration (ms) of the last matvec's kernels measured with HIP
  * events on the launch stream; names[i] is a static string. */
 int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *, int max, const char **names, float *ms);

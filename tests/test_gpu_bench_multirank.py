@@ -38,8 +38,8 @@ def test_bench_two_ranks_one_gpu(extra):
 def test_bench_starts_its_own_ranks(impl):
     """`python bench.py --gpus 2` WITHOUT a launcher: bench.py starts the two ranks itself (fresh children, before anything touches the
     GPU), rank 0's JSON line comes out of the parent.  native: the step is one hmx_dist_* call per product (here over host-staged gloo
-    collectives, since the two ranks share the box's one GPU), the exchange variants (0 / 2 / 4 row chunks on the side stream) are tried and
-    reported; python: the torch.distributed layer."""
+    collectives, since the two ranks share the box's one GPU), the exchange variants (0 / 2 / 4 row chunks on the side stream, all-gather /
+    broadcasts or pairwise send / recv) are tried and reported; python: the torch.distributed layer."""
     env = dict(os.environ, HMX_BENCH_SAME_DEVICE="1", HMX_BENCH_BACKEND="gloo", HMX_BENCH_N="200000")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -53,6 +53,7 @@ def test_bench_starts_its_own_ranks(impl):
     assert len(d["dist"]["per_rank_local_ms"]) == 2 and len(d["dist"]["per_rank_GB"]) == 2
     if impl == "native":
         assert d["dist"]["impl"].startswith("native"), d["dist"]
-        assert set(d["dist"]["overlap_trials_ms"]) >= {"0", "2"}, d["dist"]
+        # exchange variants: 0 / 2 / 4 row chunks, each as all-gather / broadcasts and pairwise (send / recv)
+        assert set(d["dist"]["exchange_trials_ms"]) >= {"0", "2", "0+p2p", "2+p2p"}, d["dist"]
     else:
         assert d["dist"]["impl"].startswith("python")

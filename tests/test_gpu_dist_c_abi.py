@@ -162,6 +162,40 @@ MOCK_SCRIPT = textwrap.dedent('''
         assert hip.hipMemcpy(recv, acc.ctypes.data, nbytes, 1) == 0
         barrier.wait()
         return 0
+    # ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd: the copies happen at the group's end, when every rank has posted
+    tl = threading.local()
+    mail, pend = {}, [[] for _ in range(WORLD)]
+    def send(buf, count, dtype, peer, comm, stream):
+        r = comm - 1
+        tl.rank, tl.posted = r, True
+        calls["send"] = calls.get("send", 0) + (r == 0)
+        hip.hipStreamSynchronize(stream)
+        mail[(r, peer)] = (buf, count * ESZ[dtype])
+        return 0
+    def recv(buf, count, dtype, peer, comm, stream):
+        r = comm - 1
+        tl.rank, tl.posted = r, True
+        pend[r].append((peer, buf, count * ESZ[dtype]))
+        return 0
+    def group_end():
+        if not getattr(tl, "posted", False):
+            return 0  # a group of broadcasts: they were carried out one by one
+        r = tl.rank
+        barrier.wait()
+        for peer, buf, nbytes in pend[r]:
+            src, nb = mail[(peer, r)]
+            assert nb == nbytes, (peer, r, nb, nbytes)
+            assert hip.hipMemcpy(buf, src, nbytes, 3) == 0
+        hip.hipStreamSynchronize(None)
+        barrier.wait()
+        del pend[r][:]
+        for key in [k for k in mail if k[0] == r]:
+            del mail[key]
+        tl.posted = False
+        barrier.wait()
+        return 0
+    SR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    send_fn, recv_fn = SR(send), SR(recv)
     AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
     RS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
     rs_fn = RS(reduce_scatter)
@@ -170,7 +204,7 @@ MOCK_SCRIPT = textwrap.dedent('''
     GR = C.CFUNCTYPE(C.c_int)
     class Api(C.Structure):
         _fields_ = [("all_gather", AG), ("all_reduce", AR), ("broadcast", BC), ("group_start", GR), ("group_end", GR)]
-    api = Api(AG(all_gather), AR(all_reduce), BC(broadcast), GR(lambda: 0), GR(lambda: 0))
+    api = Api(AG(all_gather), AR(all_reduce), BC(broadcast), GR(lambda: 0), GR(group_end))
 
     def dev(a):
         p = C.c_void_p()
@@ -205,7 +239,10 @@ MOCK_SCRIPT = textwrap.dedent('''
         y0 = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
         ab = np.array([1.5 - (0.5j if cplx else 0), 0.25 + (1j if cplx else 0)], dtype=dtype)
         pa, pb = C.c_void_p(ab.ctypes.data), C.c_void_p(ab.ctypes.data + ab.itemsize)
-        for trans, overlap in (("N", 0), ("T", 0), ("N", 3), ("N", 2)):
+        # p2p: the output slices exchanged pairwise (grouped send / recv) instead of all-gather / grouped broadcasts
+        for trans, overlap, p2p in (("N", 0, 0), ("T", 0, 0), ("N", 3, 0), ("N", 2, 0), ("N", 0, 1), ("N", 3, 1), ("T", 0, 1)):
+            for D in Ds:
+                check(L.hmx_dist_set_point_to_point(D, C.cast(send_fn, C.c_void_p), C.cast(recv_fn, C.c_void_p), p2p))
             ref = y0.copy()
             hm.internal_add_hmatrix_vector_product(trans, ab[0], Hfull, xin, ab[1], ref)
             for local in ((False, True) if overlap == 0 else (False,)):
@@ -236,7 +273,9 @@ MOCK_SCRIPT = textwrap.dedent('''
         mu = 3
         X = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
         Y0 = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
-        for trans in ("N", "T"):
+        for trans, p2p in (("N", 0), ("T", 0), ("N", 1)):
+            for D in Ds:
+                check(L.hmx_dist_set_point_to_point(D, None, None, p2p))
             ref = Y0.copy()
             hm.internal_add_hmatrix_matrix_product_row_major(trans, ab[0], Hfull, X, ab[1], ref, mu)
             errs, fails = [None] * WORLD, []
@@ -295,7 +334,7 @@ MOCK_SCRIPT = textwrap.dedent('''
     print("ok symmetric")
     print("calls", calls)
     equal = len(set(int(p[1]) for p in parts)) == 1
-    assert calls["all_reduce"] > 0 and calls["broadcast"] > 0 and calls["all_gather"] > 0, calls
+    assert calls["all_reduce"] > 0 and calls["broadcast"] > 0 and calls["all_gather"] > 0 and calls.get("send", 0) > 0, calls
     assert (calls.get("reduce_scatter", 0) > 0) == equal, calls  # transposed local-to-local: reduce-scatter for equal parts
 ''') % ROOT
 
