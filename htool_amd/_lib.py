@@ -134,6 +134,7 @@ SYMBOLS = [
     ("hmx_hmatrix_set_profiling", C.c_int, [_vp, C.c_int]),
     ("hmx_device_trim_cache", C.c_int, []),
     ("hmx_device_malloc_seconds", C.c_double, []),
+    ("hmx_device_reserve", C.c_int, [C.c_int, C.c_int64]),
     ("hmx_device_copy_bandwidth", C.c_int, [C.c_int, C.c_int64, C.c_int, _dp]),
     ("hmx_device_read_bandwidth", C.c_int, [C.c_int, C.c_int64, C.c_int, _dp]),
 ]

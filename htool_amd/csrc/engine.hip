@@ -4,6 +4,7 @@
 // There is deliberately NO CPU fallback in this file: every entry point that computes needs a HIP
 // device and reports HMX_ERR_NO_DEVICE / HMX_ERR_HIP otherwise.
 #include <algorithm>
+#include <map>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -106,6 +107,109 @@ struct DeviceCache {
     }
 };
 
+// hmx_device_reserve(): one slab per call, taken from the driver once; every later device array of >= 1 MiB is carved out of a slab
+// (first fit over an offset-ordered free list, 2 MiB granularity, neighbours coalesced on release) before hipMalloc is asked.
+// On this platform hipMalloc stalls for seconds when memory was released shortly before -- by this process or by the one that ran
+// before it (tools/malloc_after_exit.hip: ~25 ms per GB until the driver has scrubbed what came back) -- and an operator build
+// allocates its two largest arrays (cross pool, streams) right where that hurts; a caller that builds operators repeatedly, or
+// times a build, pays once and outside.  Released ranges become reusable after a device-wide synchronisation, like hipFree.
+struct DeviceSlabs {
+    struct Slab {
+        char *base;
+        size_t bytes;
+        int device;
+        std::map<size_t, size_t> free_at; // offset -> size
+        size_t in_use = 0;
+    };
+    std::mutex mu;
+    std::vector<Slab> slabs;
+    static constexpr size_t GRAIN = size_t(2) << 20;
+    static DeviceSlabs &get() {
+        static DeviceSlabs s;
+        return s;
+    }
+    hipError_t reserve(int dev, size_t bytes) {
+        bytes = (bytes + GRAIN - 1) / GRAIN * GRAIN;
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+            return e;
+        std::lock_guard<std::mutex> lock(mu);
+        Slab s{static_cast<char *>(p), bytes, dev, {}, 0};
+        s.free_at[0] = bytes;
+        slabs.push_back(std::move(s));
+        return hipSuccess;
+    }
+    void *take(int dev, size_t bytes, size_t *got) {
+        const size_t need = (bytes + GRAIN - 1) / GRAIN * GRAIN;
+        std::lock_guard<std::mutex> lock(mu);
+        for (Slab &s : slabs) {
+            if (s.device != dev)
+                continue;
+            for (auto it = s.free_at.begin(); it != s.free_at.end(); ++it)
+                if (it->second >= need) {
+                    const size_t off = it->first, rest = it->second - need;
+                    s.free_at.erase(it);
+                    if (rest)
+                        s.free_at[off + need] = rest;
+                    s.in_use += need;
+                    *got = need;
+                    return s.base + off;
+                }
+        }
+        return nullptr;
+    }
+    // true when p belongs to a slab (and is free again afterwards)
+    bool give_back(void *p, size_t bytes) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (Slab &s : slabs) {
+            char *c = static_cast<char *>(p);
+            if (c < s.base || c >= s.base + s.bytes)
+                continue;
+            size_t off = (size_t)(c - s.base), len = bytes;
+            s.in_use -= len;
+            auto next = s.free_at.lower_bound(off);
+            if (next != s.free_at.end() && off + len == next->first) { // merge with the range after
+                len += next->second;
+                next = s.free_at.erase(next);
+            }
+            if (next != s.free_at.begin()) { // ... and with the one before
+                auto prev = std::prev(next);
+                if (prev->first + prev->second == off) {
+                    off = prev->first;
+                    len += prev->second;
+                    s.free_at.erase(prev);
+                }
+            }
+            s.free_at[off] = len;
+            return true;
+        }
+        return false;
+    }
+    bool owns(const void *p) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Slab &s : slabs)
+            if (static_cast<const char *>(p) >= s.base && static_cast<const char *>(p) < s.base + s.bytes)
+                return true;
+        return false;
+    }
+    // slabs nothing is carved out of go back to the driver
+    size_t release_idle() {
+        std::lock_guard<std::mutex> lock(mu);
+        size_t kept = 0;
+        for (size_t i = 0; i < slabs.size();) {
+            if (slabs[i].in_use == 0) {
+                (void)hipFree(slabs[i].base);
+                slabs.erase(slabs.begin() + i);
+            } else {
+                kept += slabs[i].bytes;
+                i++;
+            }
+        }
+        return kept;
+    }
+};
+
 // wall time this process spent inside hipMalloc (large allocations sporadically take seconds on this platform: tools/malloc_timing.hip);
 // bench.py reports it next to the build time
 static std::atomic<long long> g_malloc_ns{0};
@@ -120,13 +224,24 @@ struct DArr { // device array with RAII
     size_t n    = 0;
     size_t cap_ = 0; // bytes actually owned (>= n * sizeof(T) when the buffer came from the cache)
     int dev_    = 0; // device the buffer lives on (current device at alloc time)
+    bool plain_ = false; // never from a reserved slab (buffers handed to RCCL: their allocation is what peers map)
     DArr() {}
     DArr(const DArr &)            = delete;
     DArr &operator=(const DArr &) = delete;
     ~DArr() { release(); }
     void release() {
-        if (d && !DeviceCache::get().park(d, cap_, dev_))
+        if (d && DeviceSlabs::get().owns(d)) { // a range of a reserved slab: reusable once nothing on the device can still touch it
+            int cur = dev_;
+            (void)hipGetDevice(&cur);
+            if (cur != dev_)
+                (void)hipSetDevice(dev_);
+            (void)hipDeviceSynchronize();
+            if (cur != dev_)
+                (void)hipSetDevice(cur);
+            (void)DeviceSlabs::get().give_back(d, cap_);
+        } else if (d && !DeviceCache::get().park(d, cap_, dev_)) {
             (void)hipFree(d);
+        }
         d    = nullptr;
         n    = 0;
         cap_ = 0;
@@ -144,6 +259,12 @@ struct DArr { // device array with RAII
             cap_ = got;
             return hipSuccess;
         }
+        if (bytes >= (size_t(1) << 20) && !plain_)
+            if (void *p = DeviceSlabs::get().take(dev_, bytes, &got)) {
+                d    = static_cast<T *>(p);
+                cap_ = got;
+                return hipSuccess;
+            }
         cap_               = bytes;
         MallocTimer timer;
         const hipError_t e = hipMalloc((void **)&d, bytes);
@@ -970,6 +1091,7 @@ int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hm
         return HMX_ERR_INVALID;
     }
     auto *D  = new hmx_dist();
+    D->work.plain_ = D->work2.plain_ = true;
     D->local = local;
     D->comm  = nccl_comm;
     D->rank  = rank;
@@ -1200,6 +1322,22 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
 double hmx_device_malloc_seconds(void) { return 1e-9 * (double)g_malloc_ns.load(); }
 int hmx_device_trim_cache(void) {
     DeviceCache::get().trim();
+    (void)DeviceSlabs::get().release_idle();
+    return HMX_OK;
+}
+int hmx_device_reserve(int device_id, int64_t bytes) {
+    const int rc = ensure_device(device_id);
+    if (rc != HMX_OK)
+        return rc;
+    if (bytes <= 0) {
+        set_error("hmx_device_reserve: bytes must be positive");
+        return HMX_ERR_INVALID;
+    }
+    if (DeviceSlabs::get().reserve(device_id, (size_t)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hmx_device_reserve: hipMalloc of the slab failed");
+        return HMX_ERR_HIP;
+    }
     return HMX_OK;
 }
 

@@ -334,6 +334,12 @@ int hmx_hmatrix_set_profiling(hmx_hmatrix *, int enabled);
 /* libhmx recycles large device buffers inside the process (rebuilding operators would otherwise hit multi-second hipMalloc calls);
  * this returns every parked buffer to the driver.  HMX_CACHE_GB (default 48) bounds what is kept. */
 int hmx_device_trim_cache(void);
+/* Takes `bytes` of device memory from the driver ONCE; device arrays of 1 MiB and more that libhmx allocates afterwards (cross pool,
+ * streams, views, work vectors) are carved out of such slabs before hipMalloc is asked, and return to them when released.  For callers
+ * that build operators repeatedly or time a build: on this platform hipMalloc stalls for seconds while the driver scrubs memory that
+ * was released shortly before, by this or by the previous process.  May be called several times (one more slab each);
+ * hmx_device_trim_cache frees the slabs nothing lives in. */
+int hmx_device_reserve(int device_id, int64_t bytes);
 /* Wall time (seconds) this process has spent inside hipMalloc on behalf of libhmx so far: large allocations sporadically take seconds
  * on this platform, callers that time builds report it separately. */
 double hmx_device_malloc_seconds(void);
