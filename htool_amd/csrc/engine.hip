@@ -193,6 +193,14 @@ struct DeviceSlabs {
                 return true;
         return false;
     }
+    size_t free_bytes(int dev) {
+        std::lock_guard<std::mutex> lock(mu);
+        size_t f = 0;
+        for (const Slab &s : slabs)
+            if (s.device == dev)
+                f += s.bytes - s.in_use;
+        return f;
+    }
     // slabs nothing is carved out of go back to the driver
     size_t release_idle() {
         std::lock_guard<std::mutex> lock(mu);
@@ -283,6 +291,17 @@ struct DArr { // device array with RAII
     }
     hipError_t zero() { return n ? hipMemset(d, 0, n * sizeof(T)) : hipSuccess; }
 };
+
+// free device memory as the library sees it: what the driver has left plus what is free inside the reserved slabs
+static hipError_t hmx_mem_info(size_t *free_b, size_t *total_b) {
+    const hipError_t e = hipMemGetInfo(free_b, total_b);
+    if (e != hipSuccess)
+        return e;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    *free_b += DeviceSlabs::get().free_bytes(dev);
+    return hipSuccess;
+}
 
 struct DEvent { // hipEvent_t with RAII, so error returns between create and destroy do not leak it
     hipEvent_t e = nullptr;

@@ -1101,7 +1101,7 @@ static HMat *ensure_transposed_operator(HMat &H) {
         return nullptr;
     size_t free_b = 0, total_b = 0;
     // a fused symmetric owner holds the stored triangle only, its transposed view the whole operator
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < (H.sym_fused ? 2.3 : 1.15) * (double)H.stats.stream_bytes) {
+    if (hmx_mem_info(&free_b, &total_b) != hipSuccess || (double)free_b < (H.sym_fused ? 2.3 : 1.15) * (double)H.stats.stream_bytes) {
         H.T_op_failed = true; // not enough HBM for a second layout
         return nullptr;
     }
@@ -1146,7 +1146,7 @@ static HMat *ensure_expanded_view(HMat &H) {
     if (!H.sym_fused || H.factors_released || H.X_op_failed || H.view_of || (getenv("HMX_SYM_NO_VIEW") && atoi(getenv("HMX_SYM_NO_VIEW"))))
         return nullptr;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 2.3 * (double)H.stats.stream_bytes) {
+    if (hmx_mem_info(&free_b, &total_b) != hipSuccess || (double)free_b < 2.3 * (double)H.stats.stream_bytes) {
         H.X_op_failed = true;
         return nullptr;
     }
@@ -1440,7 +1440,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         return sa != sb ? sa > sb : a < b;
     });
     size_t free_b = 0, total_b = 0;
-    HMX_HIP(hipMemGetInfo(&free_b, &total_b));
+    HMX_HIP(hmx_mem_info(&free_b, &total_b));
     const double budget        = 0.40 * (double)free_b / sizeof(scalar);
     unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : 1.25 * estimate));
     phase("host scratch tables");
@@ -1567,7 +1567,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             largest       = std::max(largest, need_elems[b]);
         }
         size_t free2 = 0, total2 = 0;
-        HMX_HIP(hipMemGetInfo(&free2, &total2));
+        HMX_HIP(hmx_mem_info(&free2, &total2));
         int64_t total_need = 0;
         for (int32_t b : order)
             total_need += need_elems[b];
@@ -2023,7 +2023,7 @@ static int api_recompress(HMat *Hp, double epsilon) {
         return HMX_OK;
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return need[a] != need[b] ? need[a] > need[b] : a < b; });
     size_t free_b = 0, total_b = 0;
-    HMX_HIP(hipMemGetInfo(&free_b, &total_b));
+    HMX_HIP(hmx_mem_info(&free_b, &total_b));
     int64_t total_need = 0;
     for (int32_t b : order)
         total_need += need[b];
