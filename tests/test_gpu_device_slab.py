@@ -75,3 +75,42 @@ SCRIPT = textwrap.dedent('''
 def test_device_slab_allocations():
     out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=900, env=dict(os.environ, HMX_NO_TORCH="1"))
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+BUDGET_SCRIPT = textwrap.dedent('''
+    import ctypes as C, os, sys
+    import numpy as np
+    os.environ["HMX_NO_TORCH"] = "1"
+    sys.path.insert(0, %r)
+    import htool_amd as hm
+    from htool_amd._lib import lib, check
+    L = lib()
+    check(L.hmx_device_init(0))
+    hip = C.CDLL("libamdhip64.so")
+    fr, tot = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0
+    check(L.hmx_device_reserve(0, fr.value - (3 << 30)))  # the driver keeps 3 GB: the cross pool's budget must come from the slab
+    n = 60000
+    x = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(50)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    tb = hm.HMatrixTreeBuilder(1e-8, 10.0, "N", "N"); tb.set_low_rank_generator("partialACA")
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T)
+    assert H.stats()["stream_bytes"] > 2.5e9  # more than the driver has left
+    u = np.random.default_rng(0).standard_normal(n)
+    y = np.zeros(n)
+    hm.add_hmatrix_vector_product("N", 1.0, H, u, 0.0, y)
+    rows = np.arange(0, n, n // 16)
+    exact = np.array([(1.0 / (1e-5 + np.sqrt(((x[i][None, :] - x) ** 2).sum(-1)))) @ u for i in rows])
+    assert np.linalg.norm(y[rows] - exact) / np.linalg.norm(exact) < 1e-7
+    yt = np.zeros(n)
+    hm.internal_add_hmatrix_vector_product("T", 1.0, H, u, 0.0, yt)  # the transposed layout is sized from the same free-memory figure
+    print("ok")
+''') % ROOT
+
+
+def test_memory_budgets_count_the_slab():
+    """With nearly all of HBM in a reserved slab the driver reports almost nothing free: the library's budgets (cross pool, views) must be
+    computed from driver + slab (a 185 GB slab once made the N=1e6 ball fail with "compression pool exhausted")."""
+    out = subprocess.run([sys.executable, "-c", BUDGET_SCRIPT], capture_output=True, text=True, timeout=900, env=dict(os.environ, HMX_NO_TORCH="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
