@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libhmx.so")
 
 HMX_MEM_HOST, HMX_MEM_DEVICE = 0, 1
 HMX_PREC_F64, HMX_PREC_F32, HMX_PREC_Z64, HMX_PREC_C32 = 0, 1, 2, 3
+HMX_NUMBERING_PARTITION, HMX_NUMBERING_USER = 0, 1
 COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
 DIRECTIONS = {"largest_extent": 0, "bounding_box": 1}
 SPLITTINGS = {"regular": 0, "geometric": 1}
@@ -126,6 +127,9 @@ SYMBOLS = [
     ("hmx_dist_matvec_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matvec_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matmat_row_major_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("hmx_dist_matmat_row_major_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("hmx_dist_matmat_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    ("hmx_dist_matmat_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_dist_set_overlap", C.c_int, [_vp, C.c_int, _vp]),
     ("hmx_dist_overlap_chunks", C.c_int, [_vp]),
     ("hmx_dist_set_reduce_scatter", C.c_int, [_vp, _vp]),

@@ -832,6 +832,12 @@ struct hmx_dist {
     hmx_rccl_api api{};
     std::vector<int> t_off, t_size, s_off, s_size; // partitions of the target / source cluster trees
     int nt = 0, ns = 0;
+    // user numbering <-> partition numbering (PartitionFromCluster::global_to_partition_numbering / local_to_local_partition_numbering,
+    // distributed_operator/implementations/partition_from_cluster.hpp:27-39): the trees' permutations, uploaded on first use
+    std::vector<int32_t> t_perm, s_perm;
+    bool t_perm_local = false, s_perm_local = false;
+    DArr<int32_t> d_t_perm, d_s_perm;
+    DArr<char> cm_in, cm_out; // row-major partition-numbering copies of the column-major front ends' operands
     size_t esz = 8;     // bytes per coefficient
     int dtype  = 8;     // ncclFloat64 / ncclFloat32 of the underlying real type
     int reals  = 1;     // real numbers per coefficient (2 for complex)
@@ -1001,16 +1007,106 @@ struct DistChunkCtx {
     char *out;
 };
 // called on the host right after chunk c of the expand stage was launched on the caller's stream: its exchange goes to the side stream
-static void dist_after_chunk(void *user, int c, int, int) {
+static void dist_after_chunk(void *user, int c, int row_lo, int row_hi) {
     DistChunkCtx &X = *static_cast<DistChunkCtx *>(user);
     hmx_dist &D     = *X.D;
     if (D.cb_rc != HMX_OK)
         return;
+    // the rows this chunk really covered must be the ones every rank was told at hmx_dist_set_overlap: a re-laid-out local operator
+    // (recompress, release_factors with a view, a new build) recomputes its chunk plan, and peers would receive stale row ranges
+    const int nb = D.nchunks + 1;
+    if (c < 0 || c >= D.nchunks || row_lo != D.bounds[(size_t)D.rank * nb + c] || row_hi != D.bounds[(size_t)D.rank * nb + c + 1]) {
+        set_error("hmx_dist_matvec_global_to_global: the local operator was re-laid out since hmx_dist_set_overlap (chunk rows differ); call it again");
+        D.cb_rc = HMX_ERR_STATE;
+        return;
+    }
     if (hipEventRecord(D.chunk_ev[c], D.cur_stream) != hipSuccess || hipStreamWaitEvent(D.side, D.chunk_ev[c], 0) != hipSuccess) {
         D.cb_rc = HMX_ERR_HIP;
         return;
     }
     D.cb_rc = dist_gather_chunk(D, c, X.local, X.out, D.side);
+}
+
+
+// ---- column-major / user-numbering front ends of the distributed products: pure data movement, one kernel per element size --------
+// rm[i][c] = cm[(perm ? perm[i] - base : i) + ld * c]  (user_to_cluster per column + transpose,
+// add_distributed_operator_matrix_product_global_to_global.hpp:158-171; `perm == nullptr`: partition numbering, transpose only)
+template <typename E>
+__global__ void dist_cm_to_rm_kernel(int n, int mu, const int32_t *perm, int base, const E *cm, int64_t ld, E *rm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)n * mu) {
+        const int i = (int)(e / mu), c = (int)(e - (int64_t)i * mu);
+        rm[e]       = cm[(int64_t)(perm ? perm[i] - base : i) + ld * c];
+    }
+}
+template <typename E>
+__global__ void dist_rm_to_cm_kernel(int n, int mu, const int32_t *perm, int base, const E *rm, E *cm, int64_t ld) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)n * mu) {
+        const int i = (int)(e / mu), c = (int)(e - (int64_t)i * mu);
+        cm[(int64_t)(perm ? perm[i] - base : i) + ld * c] = rm[e];
+    }
+}
+static int dist_cm_to_rm(hmx_dist &D, int n, int mu, const int32_t *perm, int base, const void *cm, int64_t ld, void *rm, hipStream_t st) {
+    const int64_t t = (int64_t)n * mu;
+    if (t == 0)
+        return HMX_OK;
+    const dim3 g((unsigned)((t + 255) / 256)), b(256);
+    if (D.esz == 4)
+        hipLaunchKernelGGL(dist_cm_to_rm_kernel<float>, g, b, 0, st, n, mu, perm, base, (const float *)cm, ld, (float *)rm);
+    else if (D.esz == 8)
+        hipLaunchKernelGGL(dist_cm_to_rm_kernel<double>, g, b, 0, st, n, mu, perm, base, (const double *)cm, ld, (double *)rm);
+    else
+        hipLaunchKernelGGL(dist_cm_to_rm_kernel<double2>, g, b, 0, st, n, mu, perm, base, (const double2 *)cm, ld, (double2 *)rm);
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+static int dist_rm_to_cm(hmx_dist &D, int n, int mu, const int32_t *perm, int base, const void *rm, void *cm, int64_t ld, hipStream_t st) {
+    const int64_t t = (int64_t)n * mu;
+    if (t == 0)
+        return HMX_OK;
+    const dim3 g((unsigned)((t + 255) / 256)), b(256);
+    if (D.esz == 4)
+        hipLaunchKernelGGL(dist_rm_to_cm_kernel<float>, g, b, 0, st, n, mu, perm, base, (const float *)rm, (float *)cm, ld);
+    else if (D.esz == 8)
+        hipLaunchKernelGGL(dist_rm_to_cm_kernel<double>, g, b, 0, st, n, mu, perm, base, (const double *)rm, (double *)cm, ld);
+    else
+        hipLaunchKernelGGL(dist_rm_to_cm_kernel<double2>, g, b, 0, st, n, mu, perm, base, (const double2 *)rm, (double2 *)cm, ld);
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+// y[0..n) = beta * y + w, n coefficients of the operator's type (the epilogue of the transposed products)
+static int dist_add_scaled(hmx_dist &D, int64_t n, const void *w, const void *beta, void *y, hipStream_t st) {
+    if (n == 0)
+        return HMX_OK;
+    if (n > 0x7fffffff) {
+        set_error("hmx_dist: more than 2^31 coefficients in one distributed multi-RHS vector");
+        return HMX_ERR_UNSUPPORTED;
+    }
+    hmx_hmatrix *H = D.local;
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (H->d)
+        hipLaunchKernelGGL(hmx::f64::axpby_kernel, g, b, 0, st, (int)n, 1.0, (const double *)w, *static_cast<const double *>(beta), static_cast<double *>(y));
+    else if (H->s)
+        hipLaunchKernelGGL(hmx::f32::axpby_kernel, g, b, 0, st, (int)n, 1.0f, (const float *)w, *static_cast<const float *>(beta), static_cast<float *>(y));
+    else if (H->z)
+        hipLaunchKernelGGL(hmx::z64::axpby_kernel, g, b, 0, st, (int)n, cplx<double>(1.0), ZP(w), zval(static_cast<const double *>(beta)), ZPM(y));
+    else
+        hipLaunchKernelGGL(hmx::c32::axpby_kernel, g, b, 0, st, (int)n, cplx<float>(1.0f), CP(w), cval(static_cast<const float *>(beta)), CPM(y));
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+static int dist_device_perms(hmx_dist &D) {
+    if (!D.d_t_perm.d && !D.t_perm.empty())
+        HMX_HIP(D.d_t_perm.upload(D.t_perm));
+    if (!D.d_s_perm.d && !D.s_perm.empty())
+        HMX_HIP(D.d_s_perm.upload(D.s_perm));
+    return HMX_OK;
+}
+static const void *dist_zero(const hmx_dist &D) {
+    static const double zero[2] = {0.0, 0.0};
+    static const float zerof[2] = {0.f, 0.f};
+    return D.dtype == 8 ? (const void *)zero : (const void *)zerof;
 }
 
 extern "C" {
@@ -1137,6 +1233,8 @@ int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hm
     }
     D->nt = target->n;
     D->ns = source->n;
+    D->t_perm = target->perm, D->s_perm = source->perm;
+    D->t_perm_local = target->permutation_is_local, D->s_perm_local = source->permutation_is_local;
     const int prec = hmx_hmatrix_precision(local);
     D->esz   = prec == HMX_PREC_F64 ? 8 : (prec == HMX_PREC_F32 ? 4 : (prec == HMX_PREC_Z64 ? 16 : 8));
     D->dtype = (prec == HMX_PREC_F64 || prec == HMX_PREC_Z64) ? 8 : 7; // ncclFloat64 : ncclFloat32
@@ -1171,6 +1269,9 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
             HMX_HIP(hipStreamWaitEvent(D.side, D.join_ev, 0));
             int used = 0;
             int rc   = dist_local_product_chunked(D, alpha, x, beta, D.work.d, st, D.nchunks, dist_after_chunk, &ctx, &used);
+            // whatever happened, exchanges already enqueued on the side stream read D.work and write y: the caller's stream joins them
+            // before this function returns, so that a failed call leaves nothing running behind the caller's back
+            const hipError_t j1 = hipEventRecord(D.join_ev, D.side), j2 = hipStreamWaitEvent(st, D.join_ev, 0);
             if (rc != HMX_OK)
                 return rc;
             if (D.cb_rc != HMX_OK)
@@ -1179,8 +1280,8 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
                 set_error("hmx_dist_matvec_global_to_global: the local operator changed since hmx_dist_set_overlap");
                 return HMX_ERR_STATE;
             }
-            HMX_HIP(hipEventRecord(D.join_ev, D.side));
-            HMX_HIP(hipStreamWaitEvent(st, D.join_ev, 0));
+            HMX_HIP(j1);
+            HMX_HIP(j2);
             return HMX_OK;
         }
         int rc = dist_local_product(D, 'N', alpha, x, beta, D.work.d, st);
@@ -1336,6 +1437,137 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
         hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<float>(1.0f), CP(w), cval(static_cast<const float *>(beta)), CPM(y_local));
     HMX_HIP(hipGetLastError());
     return HMX_OK;
+}
+
+
+// internal_add_distributed_operator_matrix_product_row_major_local_to_local (distributed_operator/linalg/
+// add_distributed_operator_matrix_product_row_major_local_to_local.hpp:19-95; what HPDDMOperator::GMV calls for mu != 1,
+// wrappers/wrapper_hpddm.hpp:126): local row slices in and out, mu-interleaved rows, partition numbering.
+// trans = 'N': local_to_global of X (MPI_Allgatherv, linalg/utility.hpp:11-28) then the local product straight into Y_local;
+// transposed: the local product into a zeroed global matrix, then MPI_Alltoallv + p axpys (:64-93) = a reduce-scatter of
+// mu * n rows (ncclReduceScatter on equal partitions, otherwise all-reduce + slice), Y_local = beta * Y_local + slice.
+int hmx_dist_matmat_row_major_local_to_local(hmx_dist *Dp, char trans, const void *alpha, const void *X_local, const void *beta, void *Y_local, int mu, void *stream) {
+    if (!Dp || !alpha || !beta || !X_local || !Y_local || mu < 1) {
+        set_error("hmx_dist_matmat_row_major_local_to_local: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D    = *Dp;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t e = D.esz * (size_t)mu; // bytes per row
+    const size_t bytes = (size_t)D.ns * e;
+    if (D.work2.n < bytes)
+        HMX_HIP(D.work2.alloc(bytes));
+    if (trans == 'N') {
+        int rc = dist_gather_slices(D, D.s_off, D.s_size, static_cast<const char *>(X_local), D.work2.d, st, (size_t)mu);
+        if (rc != HMX_OK)
+            return rc;
+        return dist_local_matmat(D, 'N', alpha, D.work2.d, beta, Y_local, mu, st);
+    }
+    HMX_HIP(hipMemsetAsync(D.work2.d, 0, bytes, st));
+    int rc = dist_local_matmat(D, trans, alpha, X_local, dist_zero(D), D.work2.d, mu, st);
+    if (rc != HMX_OK)
+        return rc;
+    const int off = D.s_off[D.rank], n = D.s_size[D.rank];
+    const char *w = D.work2.d + (size_t)off * e;
+    if (D.world > 1 || D.force) {
+        bool equal = D.s_off[0] == 0 && D.reduce_scatter != nullptr && !(getenv("HMX_DIST_NO_REDUCE_SCATTER") && atoi(getenv("HMX_DIST_NO_REDUCE_SCATTER")));
+        for (int k = 1; k < D.world && equal; k++)
+            equal = D.s_size[k] == D.s_size[0] && D.s_off[k] == k * D.s_size[0];
+        if (equal) {
+            if (D.work.n < (size_t)n * e)
+                HMX_HIP(D.work.alloc((size_t)n * e));
+            HMX_NCCL(D.reduce_scatter(D.work2.d, D.work.d, (size_t)n * D.reals * mu, D.dtype, 0, D.comm, st));
+            w = D.work.d;
+        } else {
+            HMX_NCCL(D.api.all_reduce(D.work2.d, D.work2.d, (size_t)D.ns * D.reals * mu, D.dtype, 0, D.comm, st));
+        }
+    }
+    return dist_add_scaled(D, (int64_t)n * mu, w, beta, Y_local, st);
+}
+
+// add_distributed_operator_matrix_product_global_to_global / internal_add_... (distributed_operator/linalg/
+// add_distributed_operator_matrix_product_global_to_global.hpp:132-279 / :18-117): column-major X (n x mu) and Y (m x mu), whole
+// matrices replicated on every rank; numbering = 1: USER numbering (every column through global_to_partition_numbering on the way in,
+// partition_to_global_numbering on the way out, :158-171,263-276), 0: partition numbering (transposition only).  The operands are
+// brought to the row-major layout by one kernel each way, then the row-major product above runs; for a transposed product only this
+// rank's rows of X are converted (:165-169).  mu = 1 is the user-numbering vector product
+// (add_distributed_operator_vector_product_global_to_global.hpp:97-118).
+int hmx_dist_matmat_global_to_global(hmx_dist *Dp, char trans, const void *alpha, const void *X, const void *beta, void *Y, int mu, int numbering, void *stream) {
+    if (!Dp || !alpha || !beta || !X || !Y || mu < 1 || (numbering != 0 && numbering != 1)) {
+        set_error("hmx_dist_matmat_global_to_global: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D    = *Dp;
+    hipStream_t st = (hipStream_t)stream;
+    int rc         = numbering ? dist_device_perms(D) : HMX_OK;
+    if (rc != HMX_OK)
+        return rc;
+    const bool N    = trans == 'N';
+    const int nin = N ? D.ns : D.nt, nout = N ? D.nt : D.ns;
+    const int32_t *pin = numbering ? (N ? D.d_s_perm.d : D.d_t_perm.d) : nullptr, *pout = numbering ? (N ? D.d_t_perm.d : D.d_s_perm.d) : nullptr;
+    const size_t e = D.esz * (size_t)mu;
+    if (D.cm_in.n < (size_t)nin * e)
+        HMX_HIP(D.cm_in.alloc((size_t)nin * e));
+    if (D.cm_out.n < (size_t)nout * e)
+        HMX_HIP(D.cm_out.alloc((size_t)nout * e));
+    // rows of X the product reads: all of them for 'N', this rank's slice of the target partition otherwise
+    const int lo = N ? 0 : D.t_off[D.rank], cnt = N ? nin : D.t_size[D.rank];
+    rc = dist_cm_to_rm(D, cnt, mu, pin ? pin + lo : nullptr, 0, numbering ? X : (const void *)(static_cast<const char *>(X) + (size_t)lo * D.esz), nin, D.cm_in.d + (size_t)lo * e, st);
+    if (rc != HMX_OK)
+        return rc;
+    if (!dist_beta_is_zero(D, beta)) {
+        rc = dist_cm_to_rm(D, nout, mu, pout, 0, Y, nout, D.cm_out.d, st);
+        if (rc != HMX_OK)
+            return rc;
+    }
+    rc = hmx_dist_matmat_row_major_global_to_global(Dp, trans, alpha, D.cm_in.d, beta, D.cm_out.d, mu, stream);
+    if (rc != HMX_OK)
+        return rc;
+    return dist_rm_to_cm(D, nout, mu, pout, 0, D.cm_out.d, Y, nout, st);
+}
+
+// add_distributed_operator_matrix_product_local_to_local / internal_add_... (distributed_operator/linalg/
+// add_distributed_operator_matrix_product_local_to_local.hpp:66-120 / :20-49): column-major local slices X_local (n_k x mu) and
+// Y_local (m_k x mu); numbering = 1: the rank's LOCAL user numbering (local_to_local_partition_numbering /
+// local_partition_to_local_numbering per column, :91-117 -- needs a cluster tree whose permutation is local to the partitions,
+// clustering/cluster_node.hpp:124-146), 0: partition numbering.  mu = 1 with numbering = 1 is
+// add_distributed_operator_vector_product_local_to_local (..._vector_product_local_to_local.hpp:99-125).
+int hmx_dist_matmat_local_to_local(hmx_dist *Dp, char trans, const void *alpha, const void *X_local, const void *beta, void *Y_local, int mu, int numbering, void *stream) {
+    if (!Dp || !alpha || !beta || !X_local || !Y_local || mu < 1 || (numbering != 0 && numbering != 1)) {
+        set_error("hmx_dist_matmat_local_to_local: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D    = *Dp;
+    hipStream_t st = (hipStream_t)stream;
+    if (numbering && !(D.t_perm_local && D.s_perm_local)) {
+        set_error("hmx_dist_matmat_local_to_local: permutation is not local to partition, local numbering cannot be used"); // cluster_node.hpp:126,138
+        return HMX_ERR_INVALID;
+    }
+    int rc = numbering ? dist_device_perms(D) : HMX_OK;
+    if (rc != HMX_OK)
+        return rc;
+    const bool N    = trans == 'N';
+    const int in_off = N ? D.s_off[D.rank] : D.t_off[D.rank], nin = N ? D.s_size[D.rank] : D.t_size[D.rank];
+    const int out_off = N ? D.t_off[D.rank] : D.s_off[D.rank], nout = N ? D.t_size[D.rank] : D.s_size[D.rank];
+    const int32_t *pin = numbering ? (N ? D.d_s_perm.d : D.d_t_perm.d) + in_off : nullptr, *pout = numbering ? (N ? D.d_t_perm.d : D.d_s_perm.d) + out_off : nullptr;
+    const size_t e = D.esz * (size_t)mu;
+    if (D.cm_in.n < (size_t)nin * e)
+        HMX_HIP(D.cm_in.alloc((size_t)nin * e));
+    if (D.cm_out.n < (size_t)nout * e)
+        HMX_HIP(D.cm_out.alloc((size_t)nout * e));
+    rc = dist_cm_to_rm(D, nin, mu, pin, in_off, X_local, nin, D.cm_in.d, st);
+    if (rc != HMX_OK)
+        return rc;
+    if (!dist_beta_is_zero(D, beta)) {
+        rc = dist_cm_to_rm(D, nout, mu, pout, out_off, Y_local, nout, D.cm_out.d, st);
+        if (rc != HMX_OK)
+            return rc;
+    }
+    rc = mu == 1 ? hmx_dist_matvec_local_to_local(Dp, trans, alpha, D.cm_in.d, beta, D.cm_out.d, stream)
+                 : hmx_dist_matmat_row_major_local_to_local(Dp, trans, alpha, D.cm_in.d, beta, D.cm_out.d, mu, stream);
+    if (rc != HMX_OK)
+        return rc;
+    return dist_rm_to_cm(D, nout, mu, pout, out_off, D.cm_out.d, Y_local, nout, st);
 }
 
 double hmx_device_malloc_seconds(void) { return 1e-9 * (double)g_malloc_ns.load(); }

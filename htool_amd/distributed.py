@@ -10,6 +10,11 @@ Mirror of the reference's MPI layer for the hot path (paths relative to htool's 
   internal_add_..._global_to_global         distributed_operator/linalg/add_distributed_operator_vector_product_global_to_global.hpp:18-85
   add_..._global_to_global                  same file :97-118
   internal_add_..._local_to_local           distributed_operator/linalg/add_distributed_operator_vector_product_local_to_local.hpp:19-89
+  add_..._local_to_local                    same file :99-125
+  ..._matrix_product_row_major_{global_to_global,local_to_local}   linalg/add_distributed_operator_matrix_product_row_major_*.hpp
+  ..._matrix_product_{global_to_global,local_to_local} (column-major, user and partition numbering)
+                                            linalg/add_distributed_operator_matrix_product_{global_to_global,local_to_local}.hpp
+  ..._vector_sub_product_global_to_local    linalg/add_distributed_operator_vector_sub_product_global_to_local.hpp:11-21
 
 One process per GPU; rank k owns the block rows of partition cluster k.  The MPI collectives map to
   MPI_Allgatherv (trans='N', C1/C3)  -> all_gather_into_tensor on a max-size padded buffer (RCCL has no allgatherv;
@@ -66,6 +71,28 @@ class PartitionFromCluster:
     def partition_to_global_numbering(self, x, out=None):
         out = torch.empty_like(x) if out is None else out
         out.index_copy_(0, self._perm_on(x.device), x)
+        return out
+
+    def is_renumbering_local(self):
+        return bool(self._cluster.is_permutation_local())
+
+    def _local_perm_on(self, k, device):
+        """perm[off_k + i] - off_k, i < size_k: positions inside partition k (local_to_local_cluster, cluster_node.hpp:136-146)."""
+        if not self.is_renumbering_local():
+            raise ValueError("Permutation is not local to partition, local numbering cannot be used")  # cluster_node.hpp:126,138
+        key = ("loc", k, str(device))
+        if key not in self._perm_dev:
+            off, n = self.get_offset_of_partition(k), self.get_size_of_partition(k)
+            self._perm_dev[key] = (self._perm[off:off + n] - off).to(device)
+        return self._perm_dev[key]
+
+    def local_to_local_partition_numbering(self, k, x):
+        """Rows of partition k from the rank's local user numbering to partition numbering (partition_from_cluster.hpp:34-36)."""
+        return x.index_select(0, self._local_perm_on(k, x.device))
+
+    def local_partition_to_local_numbering(self, k, x, out=None):
+        out = torch.empty_like(x) if out is None else out
+        out.index_copy_(0, self._local_perm_on(k, x.device), x)
         return out
 
 
@@ -563,6 +590,46 @@ class NativeDistributedOperator:
         check(self._L.hmx_dist_matvec_local_to_local(self._h, trans.encode(), pa, C.c_void_p(x_loc.data_ptr()), pb, C.c_void_p(y_loc.data_ptr()), self._stream(y_loc)))
         return y_loc
 
+    def matmat_row_major_local_to_local(self, trans, alpha, X_loc, beta, Y_loc, mu):
+        """hmx_dist_matmat_row_major_local_to_local: the Krylov-side block product (HPDDMOperator::GMV for mu != 1)."""
+        from ._lib import check
+        pa, pb = self._scalars(alpha, beta, Y_loc.dtype)
+        check(self._L.hmx_dist_matmat_row_major_local_to_local(self._h, trans.encode(), pa, C.c_void_p(X_loc.data_ptr()), pb, C.c_void_p(Y_loc.data_ptr()), int(mu), self._stream(Y_loc)))
+        return Y_loc
+
+    @staticmethod
+    def _column_major(M, name):
+        """(pointer, mu) of a column-major n x mu device matrix: a 1-D tensor (mu = 1) or the transpose of a contiguous mu x n tensor."""
+        if M.dim() == 1:
+            if not M.is_contiguous():
+                raise ValueError(name + " must be contiguous")
+            return M.data_ptr(), 1
+        if M.dim() != 2 or not M.T.is_contiguous():
+            raise ValueError(name + " must be column-major (the transpose of a contiguous mu x n tensor)")
+        return M.data_ptr(), int(M.shape[1])
+
+    def matmat_global_to_global(self, trans, alpha, X, beta, Y, user_numbering=True):
+        """hmx_dist_matmat_global_to_global: column-major X (n x mu), Y (m x mu), user or partition numbering."""
+        from ._lib import check
+        px, mu = self._column_major(X, "X")
+        py, mu_y = self._column_major(Y, "Y")
+        if mu != mu_y:
+            raise ValueError("X and Y must have the same number of columns")
+        pa, pb = self._scalars(alpha, beta, Y.dtype)
+        check(self._L.hmx_dist_matmat_global_to_global(self._h, trans.encode(), pa, C.c_void_p(px), pb, C.c_void_p(py), mu, 1 if user_numbering else 0, self._stream(Y)))
+        return Y
+
+    def matmat_local_to_local(self, trans, alpha, X_loc, beta, Y_loc, user_numbering=True):
+        """hmx_dist_matmat_local_to_local: column-major local slices, the rank's local user numbering or partition numbering."""
+        from ._lib import check
+        px, mu = self._column_major(X_loc, "X_loc")
+        py, mu_y = self._column_major(Y_loc, "Y_loc")
+        if mu != mu_y:
+            raise ValueError("X_loc and Y_loc must have the same number of columns")
+        pa, pb = self._scalars(alpha, beta, Y_loc.dtype)
+        check(self._L.hmx_dist_matmat_local_to_local(self._h, trans.encode(), pa, C.c_void_p(px), pb, C.c_void_p(py), mu, 1 if user_numbering else 0, self._stream(Y_loc)))
+        return Y_loc
+
 
 class DefaultApproximationBuilder:
     """Builds this rank's block rows on its GPU and wires them into a DistributedOperator
@@ -612,6 +679,122 @@ def internal_add_distributed_operator_matrix_product_row_major_global_to_global(
         if beta != 0:
             Y.add_(Y_old, alpha=beta)
     return Y
+
+
+def internal_add_distributed_operator_matrix_product_row_major_local_to_local(trans, alpha, A, X_loc, beta, Y_loc, mu):
+    """Multi-RHS Krylov-side contract: what HPDDMOperator::GMV calls for mu != 1 (wrappers/wrapper_hpddm.hpp:126).  Local row
+    slices in and out, row-major (mu fastest), partition numbering
+    (distributed_operator/linalg/add_distributed_operator_matrix_product_row_major_local_to_local.hpp:19-95).
+    trans='N': local-to-local operators on the local rows, all-gather of the mu-interleaved rows of X (local_to_global,
+    linalg/utility.hpp:11-28), global-to-local operators.  trans!='N': local product into a zeroed global matrix, then the
+    reference's MPI_Alltoallv + p axpys (:64-93) as one reduce-scatter (DistributedOperator._reduce_scatter_slices)."""
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    if trans == "N":
+        apply_beta = True
+        for op in A.local_to_local_operators:
+            op.add_matrix_product_row_major(trans, alpha, X_loc, beta if apply_beta else 1.0, Y_loc, mu)
+            apply_beta = False
+        if A.global_to_local_operators:
+            X = torch.empty((in_part.get_global_size(), mu), dtype=X_loc.dtype, device=X_loc.device)
+            A._gather_slices(X_loc, in_part, X)
+            for op in A.global_to_local_operators:
+                op.add_matrix_product_row_major(trans, alpha, X, beta if apply_beta else 1.0, Y_loc, mu)
+                apply_beta = False
+    else:
+        if beta != 1:
+            Y_loc.mul_(beta)
+        for op in A.local_to_local_operators:
+            op.add_matrix_product_row_major(trans, alpha, X_loc, 1.0, Y_loc, mu)
+        if A.global_to_local_operators:
+            buf = torch.zeros((out_part.get_global_size(), mu), dtype=X_loc.dtype, device=X_loc.device)
+            for op in A.global_to_local_operators:
+                op.add_matrix_product_row_major(trans, alpha, X_loc, 1.0, buf, mu)
+            Y_loc.add_(A._reduce_scatter_slices(buf, out_part))
+    return Y_loc
+
+
+def _rows_by_mu(M):
+    """A column-major n x mu matrix as the library sees it: any 2-D tensor of shape (n, mu) (or a vector: mu = 1)."""
+    return M.reshape(-1, 1) if M.dim() == 1 else M
+
+
+def internal_add_distributed_operator_matrix_product_global_to_global(trans, alpha, A, X, beta, Y):
+    """Column-major multi-RHS product in partition numbering: transposition to the row-major layout, row-major product,
+    transposition back (distributed_operator/linalg/add_distributed_operator_matrix_product_global_to_global.hpp:18-117).
+    X (n x mu) and Y (m x mu) are 2-D tensors of those shapes with any strides (column-major = the transpose of a contiguous
+    mu x n tensor); Y is updated in place."""
+    X2, Y2 = _rows_by_mu(X), _rows_by_mu(Y)
+    mu = X2.shape[1]
+    Xr = X2.contiguous()
+    Yr = Y2.contiguous().clone() if beta != 0 else torch.zeros(Y2.shape, dtype=Y2.dtype, device=Y2.device)
+    internal_add_distributed_operator_matrix_product_row_major_global_to_global(trans, alpha, A, Xr, beta, Yr, mu)
+    Y2.copy_(Yr)
+    return Y
+
+
+def add_distributed_operator_matrix_product_global_to_global(trans, alpha, A, X, beta, Y):
+    """The same in USER numbering: every column through global_to_partition_numbering on the way in and
+    partition_to_global_numbering on the way out (same file :132-279)."""
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    X2, Y2 = _rows_by_mu(X), _rows_by_mu(Y)
+    mu = X2.shape[1]
+    Xr = in_part.global_to_partition_numbering(X2).contiguous()
+    Yr = out_part.global_to_partition_numbering(Y2).contiguous() if beta != 0 else torch.zeros(Y2.shape, dtype=Y2.dtype, device=Y2.device)
+    internal_add_distributed_operator_matrix_product_row_major_global_to_global(trans, alpha, A, Xr, beta, Yr, mu)
+    Y2.copy_(out_part.partition_to_global_numbering(Yr))
+    return Y
+
+
+def internal_add_distributed_operator_matrix_product_local_to_local(trans, alpha, A, X_loc, beta, Y_loc):
+    """Column-major local slices, partition numbering
+    (distributed_operator/linalg/add_distributed_operator_matrix_product_local_to_local.hpp:20-49)."""
+    X2, Y2 = _rows_by_mu(X_loc), _rows_by_mu(Y_loc)
+    mu = X2.shape[1]
+    Xr = X2.contiguous()
+    Yr = Y2.contiguous().clone() if beta != 0 else torch.zeros(Y2.shape, dtype=Y2.dtype, device=Y2.device)
+    internal_add_distributed_operator_matrix_product_row_major_local_to_local(trans, alpha, A, Xr, beta, Yr, mu)
+    Y2.copy_(Yr)
+    return Y_loc
+
+
+def add_distributed_operator_matrix_product_local_to_local(trans, alpha, A, X_loc, beta, Y_loc):
+    """Column-major local slices in the rank's LOCAL user numbering (same file :66-120): needs cluster trees whose permutation
+    is local to the partitions (create_cluster_tree_from_local_partition)."""
+    rank = A.rank()
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    X2, Y2 = _rows_by_mu(X_loc), _rows_by_mu(Y_loc)
+    mu = X2.shape[1]
+    Xr = in_part.local_to_local_partition_numbering(rank, X2).contiguous()
+    Yr = out_part.local_to_local_partition_numbering(rank, Y2).contiguous() if beta != 0 else torch.zeros(Y2.shape, dtype=Y2.dtype, device=Y2.device)
+    internal_add_distributed_operator_matrix_product_row_major_local_to_local(trans, alpha, A, Xr, beta, Yr, mu)
+    Y2.copy_(out_part.local_partition_to_local_numbering(rank, Yr))
+    return Y_loc
+
+
+def add_distributed_operator_vector_product_local_to_local(trans, alpha, A, x_loc, beta, y_loc):
+    """Local slices in the rank's local user numbering
+    (distributed_operator/linalg/add_distributed_operator_vector_product_local_to_local.hpp:99-125)."""
+    rank = A.rank()
+    in_part = A.source_partition if trans == "N" else A.target_partition
+    out_part = A.target_partition if trans == "N" else A.source_partition
+    xp = in_part.local_to_local_partition_numbering(rank, x_loc)
+    yp = out_part.local_to_local_partition_numbering(rank, y_loc) if beta != 0 else torch.zeros_like(y_loc)
+    internal_add_distributed_operator_vector_product_local_to_local(trans, alpha, A, xp, beta, yp)
+    out_part.local_partition_to_local_numbering(rank, yp, out=y_loc)
+    return y_loc
+
+
+def internal_add_distributed_operator_vector_sub_product_global_to_local(A, X, Y_loc, mu, offset, size):
+    """Y_loc += A_loc * (X zero-extended): X holds rows [offset, offset + size) of the source partition numbering, row-major
+    with mu columns (distributed_operator/linalg/add_distributed_operator_vector_sub_product_global_to_local.hpp:11-21)."""
+    for op in A.global_to_local_operators:
+        op.add_sub_matrix_product_to_local(X, Y_loc, mu, offset, size)
+    for op in A.local_to_local_operators:
+        op.add_sub_matrix_product_to_local(X, Y_loc, mu, offset, size)
+    return Y_loc
 
 
 class DefaultLocalApproximationBuilder:

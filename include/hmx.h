@@ -301,6 +301,26 @@ int hmx_dist_matmat_row_major_global_to_global(hmx_dist *, char trans, const voi
  * local product into a zeroed global vector, all-reduce, slice (transposed). */
 int hmx_dist_matvec_local_to_local(hmx_dist *, char trans, const void *alpha, const void *x_local, const void *beta, void *y_local, void *stream);
 
+/* The same contract for mu right-hand sides: X_local (n_k x mu) and Y_local (m_k x mu) row-major with mu fastest, partition numbering
+ * (distributed_operator/linalg/add_distributed_operator_matrix_product_row_major_local_to_local.hpp:19-95 -- what HPDDMOperator::GMV
+ * calls for mu != 1, wrappers/wrapper_hpddm.hpp:126).  'N': all-gather of the mu-interleaved rows of X (local_to_global,
+ * linalg/utility.hpp:11-28), local product; transposed: local product into a zeroed global matrix, then the reference's
+ * MPI_Alltoallv + p axpys (:64-93) as one reduce-scatter (ncclReduceScatter on equal partitions, all-reduce + slice otherwise). */
+int hmx_dist_matmat_row_major_local_to_local(hmx_dist *, char trans, const void *alpha, const void *X_local, const void *beta, void *Y_local, int mu, void *stream);
+/* Column-major front ends (device pointers): X (n x mu) and Y (m x mu) stored column by column.
+ *   numbering = HMX_NUMBERING_USER:      add_distributed_operator_matrix_product_global_to_global (distributed_operator/linalg/
+ *       add_distributed_operator_matrix_product_global_to_global.hpp:132-279) resp. add_distributed_operator_matrix_product_local_to_local
+ *       (..._matrix_product_local_to_local.hpp:66-120): every column is permuted between user and partition numbering
+ *       (global_to_partition_numbering / local_to_local_partition_numbering) and the operands are transposed to the row-major layout
+ *       -- one kernel each way on the device --, then the row-major product runs.  The local form needs cluster trees whose
+ *       permutation is local to the partitions (create_cluster_tree_from_local_partition, or one partition).
+ *   numbering = HMX_NUMBERING_PARTITION: the internal_ variants of the same files (:18-117 resp. :20-49): transposition only.
+ * mu = 1 with user numbering is add_distributed_operator_vector_product_global_to_global (..._vector_product_global_to_global.hpp:97-118)
+ * resp. add_distributed_operator_vector_product_local_to_local (..._vector_product_local_to_local.hpp:99-125). */
+typedef enum { HMX_NUMBERING_PARTITION = 0, HMX_NUMBERING_USER = 1 } hmx_numbering;
+int hmx_dist_matmat_global_to_global(hmx_dist *, char trans, const void *alpha, const void *X, const void *beta, void *Y, int mu, int numbering, void *stream);
+int hmx_dist_matmat_local_to_local(hmx_dist *, char trans, const void *alpha, const void *X_local, const void *beta, void *Y_local, int mu, int numbering, void *stream);
+
 /* Overlap of the output exchange with the computation ("all via RCCL on a side HIP stream; overlap by chunking the
  * output range").  chunks >= 2: the expand stage of a trans = 'N' global-to-global product runs in that many row chunks on the
  * caller's stream; an event after each chunk hands its rows to a side stream, where they are exchanged (grouped ncclBroadcast,

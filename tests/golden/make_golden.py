@@ -104,6 +104,16 @@ CASES = {
     # text rank 0 prints for the operators whose per-rank leaf tables are the *_p4_rank* / *_p2_symL_rank* fixtures above
     "distinfo_ellipse_n4000_p4": ("distinfo", dict(n=4000, geom="ellipse", leaf=100, partitions=4, eps=1e-4, compressor="partialACA")),
     "distinfo_ball_n2000_p2_symL": ("distinfo", dict(n=2000, geom="ball", leaf=50, partitions=2, eps=1e-3, sym="S", uplo="L", compressor="sympartialACA")),
+    # EVERY product family of htool's DistributedOperator run under MPI (oracle/_ref/dist_products, world = partitions): vector /
+    # row-major / column-major, global-to-global / local-to-local, user / partition numbering, sub product; one fixture holds the
+    # outputs of all ranks (keys r<k>_<name>).  given=local: a cluster tree from a local partition, so that the local user numbering
+    # of the add_*_local_to_local families exists (test_distributed_operator.hpp:520-537 builds its trees the same way)
+    "distprod_ellipse_n2000_p2": ("distprod", dict(n=2000, geom="ellipse", leaf=50, partitions=2, eps=1e-6, compressor="partialACA", mu=5, given="local")),
+    "distprod_ellipse_n2400_p4": ("distprod", dict(n=2400, geom="ellipse", leaf=50, partitions=4, eps=1e-6, compressor="partialACA", mu=3, given="local")),
+    "distprod_ball_n1500_p2_symL": ("distprod", dict(n=1500, geom="ball", leaf=40, partitions=2, eps=1e-5, sym="S", uplo="L", compressor="sympartialACA", mu=5, given="local")),
+    "distprod_ball_n1500_c3_p3": ("distprod", dict(n=1500, geom="ball", leaf=40, children=3, partitions=3, eps=1e-5, compressor="partialACA", mu=4)),
+    "distprod_ellipse_n2000_p2_blockdiag": ("distprod", dict(n=2000, geom="ellipse", leaf=50, partitions=2, eps=1e-6, compressor="partialACA", mu=5, given="local", local=1)),
+    "distprod_ball_n1200_p2_z64_hermL": ("distprod", dict(n=1200, geom="ball", leaf=40, partitions=2, eps=1e-5, sym="H", uplo="L", compressor="sympartialACA", mu=3, given="local", prec="z64")),
     # the reference's own compressor test block (500 x 100, two disks at distance d)
     **{"lrmat_d%d" % d: ("lrmat", dict(distance=d, eps=1e-4)) for d in (15, 20, 30, 40)},
 }
@@ -202,6 +212,27 @@ def main():
                 print(" ".join(cmd))
                 subprocess.check_call(cmd, env=dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs")))
                 np.savez_compressed(os.path.join(HERE, name + ".npz"), information=np.fromfile(os.path.join(tmp, "info.txt"), dtype=np.uint8))
+            manifest[name] = dict(mode=mode, **params)
+            continue
+        if mode == "distprod":
+            with tempfile.TemporaryDirectory() as tmp:
+                exe = os.path.join(ROOT, "oracle", "_ref", "dist_products")
+                world = params["partitions"]
+                cmd = ["/opt/conda/bin/mpiexec", "-n", str(world), exe] + ["%s=%s" % (k, v) for k, v in params.items()] + ["out=" + tmp + "/dp"]
+                print(" ".join(cmd))
+                subprocess.check_call(cmd, env=dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs"), OMP_NUM_THREADS="1"))
+                d = {}
+                for r in range(world):
+                    dr = read_dump(tmp + "/dp.rank%d" % r)
+                    for k, v in dr.items():
+                        if params.get("prec") == "z64" and v.dtype == np.float64 and v.ndim >= 2 and v.shape[-1] == 2 and k not in ("alpha_beta",):
+                            v = np.ascontiguousarray(v).view(np.complex128).reshape(v.shape[:-1])
+                        if k in ("perm", "partition", "alpha_beta", "sub_offset_size"):
+                            if r == 0:
+                                d[k] = v
+                        else:
+                            d["r%d_%s" % (r, k)] = v
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
             manifest[name] = dict(mode=mode, **params)
             continue
         if mode == "io":

@@ -174,3 +174,70 @@ def test_distributed_layer_on_gpu_several_ranks_sharing_the_device(world, tmp_pa
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "multi-rank ok" in out.stdout
+
+
+FAMILIES_SCRIPT = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    sys.path.insert(0, os.path.join(%r, "tests"))
+    import htool_amd as hm
+    from htool_amd import distributed as D
+    from helpers import load, MANIFEST
+    import test_distributed_gloo as G
+    case = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)  # every rank on the box's single GPU; gloo carries the collectives
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    p, g = MANIFEST[case], load(case)
+    assert world == p["partitions"]
+    x, T, To = G.distprod_cluster_tree(p, world)
+    assert np.array_equal(T.get_permutation(), g["perm"])
+    cplx = p.get("prec") == "z64"
+    sym = p.get("sym", "N")
+    tb = hm.HMatrixTreeBuilder(p["eps"], 10.0, sym, p.get("uplo", "N"))
+    tb.set_low_rank_generator(p["compressor"])
+    gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 0.5 if cplx else 0.0, sym == "H")
+    dtype = np.complex128 if cplx else np.float64
+    block_diagonal = bool(p.get("local", 0))
+    B = (D.DefaultLocalApproximationBuilder if block_diagonal else D.DefaultApproximationBuilder)(gen, T, T, tb, dtype=dtype)
+    lt = np.asarray(B.hmatrix.leaf_table())
+    assert np.array_equal(lt[:, :5], g["r%%d_leaves" %% rank]), "this rank's blocks / ranks differ from htool's under MPI"
+    native = None
+    if not block_diagonal:  # hmx_dist_*: the same products as one C call each, collectives host-staged over gloo
+        comm = D.NativeCommunicator(backend="gloo")
+        native = D.NativeDistributedOperator(B.hmatrix, T, T, comm)
+    errs = G.run_distprod_families(B.distributed_operator, rank, world, g, p, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev), native=native)
+    bad = sorted((k, float(v)) for k, v in errs.items() if not v < 1e-10)
+    assert not bad, bad
+    assert native is None or sum(k.startswith("native_") for k in errs) >= 12, sorted(errs)
+    if rank == 0:
+        print("families ok", len(errs), "max", max(errs.values()))
+    dist.destroy_process_group()
+''') % (ROOT, ROOT)
+
+
+@pytest.mark.parametrize("case", ["distprod_ellipse_n2000_p2", "distprod_ellipse_n2400_p4", "distprod_ball_n1500_p2_symL", "distprod_ball_n1500_c3_p3",
+                                  "distprod_ellipse_n2000_p2_blockdiag", "distprod_ball_n1200_p2_z64_hermL"])
+def test_every_product_family_on_the_gpu_matches_the_reference_under_mpi(case, tmp_path):
+    """SURVEY.md 8(f)1 on the HIP engine: `world` processes share the box's GPU (gloo carries the collectives), every rank holds
+    its block rows on the device; every product family of distributed_operator/linalg/ -- through the torch.distributed layer AND
+    through the C-level hmx_dist_* entry points (row-major local-to-local multi-RHS = what HPDDMOperator::GMV calls, the column-major
+    front ends in both numberings) -- against the outputs htool itself produced under mpiexec -n world (tests/golden/distprod_*)."""
+    import socket
+    from helpers import MANIFEST
+    world = MANIFEST[case]["partitions"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "families.py"
+    script.write_text(FAMILIES_SCRIPT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), case]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "families ok" in out.stdout
