@@ -6,6 +6,10 @@
 // tests/test_gpu_adaptor_end_to_end.py with `mpiexec -n {1,2}` (all ranks share device 0 there).
 #include <htool/clustering/tree_builder/tree_builder.hpp>
 #include <htool/distributed_operator/distributed_operator.hpp>
+#include <htool/matrix/linalg/transpose.hpp> // used, but not included, by the matrix-product headers
+#include <htool/distributed_operator/linalg/add_distributed_operator_matrix_product_global_to_global.hpp>
+#include <htool/distributed_operator/linalg/add_distributed_operator_matrix_product_row_major_global_to_global.hpp>
+#include <htool/distributed_operator/linalg/add_distributed_operator_matrix_product_row_major_local_to_local.hpp>
 #include <htool/distributed_operator/linalg/add_distributed_operator_vector_product_global_to_global.hpp>
 #include <htool/distributed_operator/linalg/add_distributed_operator_vector_product_local_to_local.hpp>
 #include <htool/distributed_operator/utility.hpp>
@@ -97,6 +101,36 @@ int main(int argc, char **argv) {
             if (rankWorld == 0)
                 std::printf("np=%d sym=%c trans=%c local_to_local,   GPU local operator vs htool: %.3e %s\n", sizeWorld, sym, trans, emax, emax < 1e-10 ? "ok" : "FAIL");
             failures += !(emax < 1e-10);
+            // mu = 5: the Krylov-side block product (HPDDMOperator::GMV calls exactly this for mu != 1, wrappers/wrapper_hpddm.hpp:126),
+            // the row-major global-to-global product and the column-major user-numbering front end
+            const int mu = 5;
+            Matrix<double> Xl(mu, sz), Ylr(mu, sz), Yl(mu, sz), Xg(mu, n), Ygr(mu, n), Yg(mu, n), Xc(n, mu), Ycr(n, mu), Yc(n, mu);
+            for (int i = 0; i < n; i++)
+                for (int c = 0; c < mu; c++) {
+                    Xg(c, i) = Xc(i, c) = std::sin(0.37 * i + 0.61 * c) + 0.1;
+                    Ygr(c, i) = Yg(c, i) = Ycr(i, c) = Yc(i, c) = std::cos(0.11 * i - 0.3 * c);
+                    if (i >= off && i < off + sz) {
+                        Xl(c, i - off)  = Xg(c, i);
+                        Ylr(c, i - off) = Yl(c, i - off) = Ygr(c, i);
+                    }
+                }
+            internal_add_distributed_operator_matrix_product_row_major_local_to_local(trans, 1.5, reference.distributed_operator, Xl, 0.5, Ylr, work);
+            internal_add_distributed_operator_matrix_product_row_major_local_to_local(trans, 1.5, device.distributed_operator, Xl, 0.5, Yl, work);
+            internal_add_distributed_operator_matrix_product_row_major_global_to_global(trans, 1.5, reference.distributed_operator, Xg, 0.5, Ygr, work);
+            internal_add_distributed_operator_matrix_product_row_major_global_to_global(trans, 1.5, device.distributed_operator, Xg, 0.5, Yg, work);
+            add_distributed_operator_matrix_product_global_to_global(trans, 1.5, reference.distributed_operator, Xc, 0.5, Ycr, work);
+            add_distributed_operator_matrix_product_global_to_global(trans, 1.5, device.distributed_operator, Xc, 0.5, Yc, work);
+            auto relm = [](const Matrix<double> &a, const Matrix<double> &b) {
+                return rel(std::vector<double>(a.data(), a.data() + (size_t)a.nb_rows() * a.nb_cols()), std::vector<double>(b.data(), b.data() + (size_t)b.nb_rows() * b.nb_cols()));
+            };
+            double em[3] = {relm(Yl, Ylr), relm(Yg, Ygr), relm(Yc, Ycr)}, emx[3];
+            MPI_Allreduce(em, emx, 3, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD);
+            const char *names[3] = {"row-major local_to_local mu=5", "row-major global_to_global mu=5", "column-major global_to_global mu=5 (user numbering)"};
+            for (int k = 0; k < 3; k++) {
+                if (rankWorld == 0)
+                    std::printf("np=%d sym=%c trans=%c %s, GPU local operator vs htool: %.3e %s\n", sizeWorld, sym, trans, names[k], emx[k], emx[k] < 1e-10 ? "ok" : "FAIL");
+                failures += !(emx[k] < 1e-10);
+            }
         }
     }
     if (rankWorld == 0)

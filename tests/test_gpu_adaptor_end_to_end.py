@@ -37,4 +37,4 @@ def test_reference_distributed_operator_with_device_local_operator(np_):
     out = subprocess.run([MPIEXEC, "-n", str(np_), MPI_EXE], capture_output=True, text=True, timeout=900, env=env)
     print(out.stdout)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 9
+    assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 20
