@@ -81,14 +81,42 @@ def spawn_ranks_if_needed(args):
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    rcs = [p.wait() for p in procs]
+    procs, out0 = [], None
+    import tempfile
+    with tempfile.TemporaryFile() as cap:  # rank 0's stdout (the JSON line); a pipe nobody drains while we poll could fill up
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=cap if r == 0 else subprocess.DEVNULL))
+        # supervise: the first rank that fails (OOM, RCCL initialisation) takes the others down instead of leaving them in a collective
+        # for ever; an overall limit bounds a hang (HMX_BENCH_SPAWN_TIMEOUT seconds, default 3600)
+        deadline = time.time() + float(os.environ.get("HMX_BENCH_SPAWN_TIMEOUT", 3600))
+        failed = None
+        while True:
+            rcs = [p.poll() for p in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad or time.time() > deadline:
+                failed = ("rank %d exited with code %s" % (bad[0], rcs[bad[0]])) if bad else "time limit reached"
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                t_kill = time.time() + 10
+                while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                    time.sleep(0.1)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.2)
+        rcs = [p.wait() for p in procs]
+        cap.seek(0)
+        out0 = cap.read()
+    if failed:
+        print("bench.py: %s; remaining ranks stopped" % failed, file=sys.stderr)
+        sys.exit(1)
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     sys.exit(max(abs(rc) for rc in rcs))
@@ -209,6 +237,58 @@ def reference_baseline(log, n, geom, eps, eta, leaf, depth):
                     build_s=best["build_s"], matvec_s=best["matvec_s"], n=size)
     except Exception as e:
         log("reference driver failed: %r" % (e,))
+        return None
+
+
+def reference_mpi_baseline(log, world, n, geom, eps, eta, leaf, depth):
+    """htool's own MPI + OpenMP CPU path next to the multi-GPU numbers: oracle/_ref/dist_bench (the real headers + MPICH + MKL,
+    built in the dev container) under `mpiexec -n world`, cores / world OpenMP threads per rank, on THE SAME configuration --
+    every rank builds its block rows (openmp_build), the product is internal_add_distributed_operator_vector_product_global_to_global
+    (openmp leaf loop per rank + MPI_Allgatherv), best of 5, maximum over the ranks.  Time-boxed (HMX_BENCH_REF_TIMEOUT, default
+    240 s; falls back to the N=1e5 operator).  Started as a child process by rank 0 AFTER its process group is gone."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "dist_bench")
+    mpiexec = os.environ.get("HMX_BENCH_MPIEXEC", "/opt/conda/bin/mpiexec")
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        log("no oracle/_ref/dist_bench or mpiexec here: no reference-mpi baseline")
+        return None
+    budget = float(os.environ.get("HMX_BENCH_REF_TIMEOUT", 240))
+    threads = max(1, (os.cpu_count() or world) // world)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(nn, dd, timeout):
+        t0 = time.time()
+        out = subprocess.run([mpiexec, "-n", str(world), exe, "n=%d" % nn, "geom=%s" % geom, "eps=%g" % eps, "eta=%g" % eta, "leaf=%d" % leaf,
+                              "mindepth=%d" % dd, "compressor=partialACA", "reps=5"], capture_output=True, text=True, timeout=timeout, env=env)
+        m = re.search(r"ranks=(\d+) threads=(\d+) n=\d+ cgen=(\d+) build=([0-9.]+)s matvec=([0-9.]+)s", out.stdout)
+        if not m:
+            log("reference-mpi produced no timing: %s" % (out.stdout[-200:] + out.stderr[-300:]))
+            return None
+        log("reference (htool, MPI x OpenMP = %s x %s) N=%d: build %.2fs, product %.5fs (%.1fs wall)" % (m.group(1), m.group(2), nn, float(m.group(4)), float(m.group(5)), time.time() - t0))
+        return dict(ranks=int(m.group(1)), threads=int(m.group(2)), cgen=int(m.group(3)), build_s=float(m.group(4)), matvec_s=float(m.group(5)))
+
+    try:
+        size, r = n, None
+        try:
+            r = run(n, depth, budget)
+        except subprocess.TimeoutExpired:
+            log("reference-mpi at N=%d did not finish in the time box" % n)
+        if r is None and n > 100000:
+            size = 100000
+            r = run(size, 0, 120)
+        if r is None:
+            return None
+        return dict(value=8.0 * (r["cgen"] + world * size + size) / r["matvec_s"] / 1e9, unit="GB/s", cores=r["ranks"] * r["threads"], kind="reference-mpi",
+                    sample="htool itself: DistributedOperator over %d MPI ranks x %d OpenMP threads (internal_add_distributed_operator_vector_product_global_to_global, "
+                           "MKL sequential BLAS, MPICH) on the %s: N=%d %s, eps=%g, eta=%g, leaf %d, min block depth %d; best of 5 products, max over ranks"
+                           % (r["ranks"], r["threads"], "same configuration" if size == n else "configs[1] operator (the N=%d run did not fit the time box)" % n,
+                              size, geom, eps, eta, leaf, depth if size == n else 0),
+                    build_s=r["build_s"], matvec_s=r["matvec_s"], n=size, mpi_ranks=r["ranks"], omp_threads_per_rank=r["threads"])
+    except Exception as e:  # noqa: BLE001
+        log("reference-mpi failed: %r" % (e,))
         return None
 
 
@@ -333,7 +413,8 @@ def main():
         if int(flag.item()) == 0:
             native = None
         else:
-            dist_info = dict(impl="native (hmx_dist_*, one C call per step)", rccl_ranks=world, communicator=comm.backend)
+            # the number of ranks as the COMMUNICATOR reports it (ncclCommCount), not what the launcher said
+            dist_info = dict(impl="native (hmx_dist_*, one C call per step)", rccl_ranks=comm.count(), communicator=comm.backend)
 
     if mu > 1 and part:
         Yg = torch.zeros((n, mu), dtype=t_dt, device=dev)  # every rank receives the whole result (global-to-global contract)
@@ -395,6 +476,20 @@ def main():
             chunk_choices = [int(pin_c)] if pin_c is not None else ([0, 2, 4] if mu == 1 else [0])
             p2p_choices = [bool(int(pin_p))] if pin_p is not None else [False, True]
             trials = {}
+
+            def time_variant(key, name):
+                if not reproduces():
+                    log("exchange variant %s does not reproduce the result: skipped" % name)
+                    return
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                fence()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=flag_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                trials[key] = float(tt.item()) / 10 * 1e3
+
             for p2p in p2p_choices:
                 try:
                     native.set_point_to_point(p2p)
@@ -411,24 +506,26 @@ def main():
                     used = native.set_overlap(chunks, like=out)
                     if chunks > 1 and used != chunks:
                         continue  # some rank's operator cannot be chunked
-                    name = "%d%s" % (chunks, "+p2p" if p2p else "")
-                    if not reproduces():
-                        log("exchange variant %s does not reproduce the result: skipped" % name)
-                        continue
-                    fence()
-                    t0 = time.perf_counter()
-                    for _ in range(10):
-                        step()
-                    fence()
-                    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=flag_dev)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    trials[(chunks, p2p)] = float(tt.item()) / 10 * 1e3
-            best = min(trials, key=trials.get) if trials else (0, False)  # nothing could be timed (pinned to what no rank supports): the plain exchange
+                    time_variant((chunks, p2p, False), "%d%s" % (chunks, "+p2p" if p2p else ""))
+            # the north star's wording: ncclAllReduce of the zero-padded output vector (single vector; p times the bytes)
+            if mu == 1 and os.environ.get("HMX_DIST_ALLREDUCE", "1") != "0":
+                native.set_point_to_point(False)
+                native.set_overlap(0, like=out)
+                native.set_output_collective(True)
+                time_variant((0, False, True), "allreduce")
+                native.set_output_collective(False)
+            if os.environ.get("HMX_DIST_ALLREDUCE") == "only" and (0, False, True) in trials:
+                trials = {(0, False, True): trials[(0, False, True)]}
+            best = min(trials, key=trials.get) if trials else (0, False, False)  # nothing could be timed (pinned to what no rank supports): the plain exchange
             native.set_point_to_point(best[1])
             native.set_overlap(best[0], like=out)
-            dist_info.update(overlap_chunks=best[0], point_to_point=bool(best[1]),
-                             exchange_trials_ms={"%d%s" % (c, "+p2p" if p else ""): v for (c, p), v in trials.items()})
-            log("output exchange variants (ms per step; chunks of the expand stage, +p2p = pairwise send/recv): %s -> %s" % (dist_info["exchange_trials_ms"], best))
+            native.set_output_collective(best[2])
+
+            def vname(k):
+                return "allreduce" if k[2] else "%d%s" % (k[0], "+p2p" if k[1] else "")
+            dist_info.update(overlap_chunks=best[0], point_to_point=bool(best[1]), output_collective="allreduce" if best[2] else "exchange of the slices",
+                             exchange_trials_ms={vname(k): v for k, v in trials.items()})
+            log("output exchange variants (ms per step; chunks of the expand stage, +p2p = pairwise send/recv, allreduce = zero-padded vector): %s -> %s" % (dist_info["exchange_trials_ms"], vname(best)))
         del ref
     if native is None and part and mu == 1 and args.trans == "N" and not os.environ.get("HMX_BENCH_NO_GRAPH"):
         eager_step = step
@@ -513,8 +610,23 @@ def main():
         mine = torch.tensor([sum(kern_ms.values()), esz * (st["cgen_dense"] + st["cgen_lowrank"] + n + H.nb_rows()) / 1e9], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        dist_info.update(per_rank_local_ms=[float(t[0]) for t in allr], per_rank_GB=[float(t[1]) for t in allr],
-                         exposed_exchange_ms=ms_per_step - max(float(t[0]) for t in allr))
+        dist_info.update(per_rank_local_ms=[float(t[0]) for t in allr], per_rank_GB=[float(t[1]) for t in allr])
+        # what the exchange adds to a step, MEASURED: HIP events on the launch stream inside hmx_dist_matvec_global_to_global (start /
+        # last local kernel done / whole result there), on the variant that was timed; maximum over the ranks of the per-rank means
+        if native is not None and mu == 1:
+            native.set_profiling(True)
+            loc, exp = [], []
+            for _ in range(nprof):
+                step()
+                a, b = native.last_exchange_ms()
+                loc.append(a)
+                exp.append(b)
+            native.set_profiling(False)
+            ev = torch.tensor([float(np.mean(loc)), float(np.mean(exp))], dtype=torch.float64, device=dev)
+            dist.all_reduce(ev, op=dist.ReduceOp.MAX)
+            dist_info.update(local_ms_events=float(ev[0]), exposed_exchange_ms=float(ev[1]), exposed_exchange_method="HIP events around the non-local part of the product (hmx_dist_last_exchange_ms), max over ranks")
+        else:
+            dist_info.update(exposed_exchange_ms=None, exposed_exchange_method="not measured on this path")
     # user numbering (permutations on the device) and host vectors (two PCIe copies per product): reported, never `value`
     extras = {}
     if not use_dist and mu == 1 and args.trans == "N" and not emu:
@@ -574,6 +686,13 @@ def main():
                 out["cpu_baseline"] = ref
         except Exception as e:  # the baseline is a reported number, never the product path
             out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
+    if use_dist:
+        dist.destroy_process_group()
+    if rank == 0 and world > 1 and not args.no_cpu_baseline and not args.no_reference and args.dtype == "f64" and args.sym == "N":
+        # next to the multi-GPU numbers: htool's own MPI + OpenMP path on this box's host cores (the other ranks have finished)
+        ref = reference_mpi_baseline(log, world, n, args.geom, args.eps, args.eta, args.leaf, d)
+        if ref is not None:
+            out["cpu_baseline"] = ref
     if rank == 0:
         def clean(o):  # strict JSON: no NaN / Infinity
             if isinstance(o, dict):
@@ -584,8 +703,6 @@ def main():
                 return None
             return o
         os.write(json_fd, (json.dumps(clean(out)) + "\n").encode())
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

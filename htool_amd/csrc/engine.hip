@@ -201,6 +201,16 @@ struct DeviceSlabs {
                 f += s.bytes - s.in_use;
         return f;
     }
+    // the largest single array a slab of this device can still hold (free ranges do not join across slabs or across used ranges)
+    size_t largest_hole(int dev) {
+        std::lock_guard<std::mutex> lock(mu);
+        size_t f = 0;
+        for (const Slab &s : slabs)
+            if (s.device == dev)
+                for (const auto &r : s.free_at)
+                    f = std::max(f, r.second);
+        return f;
+    }
     // slabs nothing is carved out of go back to the driver
     size_t release_idle() {
         std::lock_guard<std::mutex> lock(mu);
@@ -243,10 +253,13 @@ struct DArr { // device array with RAII
             (void)hipGetDevice(&cur);
             if (cur != dev_)
                 (void)hipSetDevice(dev_);
-            (void)hipDeviceSynchronize();
+            const hipError_t se = hipDeviceSynchronize();
             if (cur != dev_)
                 (void)hipSetDevice(cur);
-            (void)DeviceSlabs::get().give_back(d, cap_);
+            if (se == hipSuccess)
+                (void)DeviceSlabs::get().give_back(d, cap_);
+            else // e.g. a stream capture in progress: what cannot be proven idle is not handed out again (the range stays taken)
+                (void)hipGetLastError();
         } else if (d && !DeviceCache::get().park(d, cap_, dev_)) {
             (void)hipFree(d);
         }
@@ -276,8 +289,9 @@ struct DArr { // device array with RAII
         cap_               = bytes;
         MallocTimer timer;
         const hipError_t e = hipMalloc((void **)&d, bytes);
-        if (e != hipSuccess) { // out of memory: give the parked buffers back and try once more
+        if (e != hipSuccess) { // out of memory: give the parked buffers and the slabs nothing lives in back and try once more
             DeviceCache::get().trim();
+            (void)DeviceSlabs::get().release_idle();
             (void)hipGetLastError();
             return hipMalloc((void **)&d, bytes);
         }
@@ -300,6 +314,18 @@ static hipError_t hmx_mem_info(size_t *free_b, size_t *total_b) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     *free_b += DeviceSlabs::get().free_bytes(dev);
+    return hipSuccess;
+}
+// ... and the largest SINGLE array that can still be allocated: no allocation spans the driver's memory and a slab, or two holes of a
+// slab, so budgets for one array (cross pool, scratch) are capped by this, not by the sum above
+static hipError_t hmx_mem_largest(size_t *largest_b) {
+    size_t free_b = 0, total_b = 0;
+    const hipError_t e = hipMemGetInfo(&free_b, &total_b);
+    if (e != hipSuccess)
+        return e;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    *largest_b = std::max(free_b, DeviceSlabs::get().largest_hole(dev));
     return hipSuccess;
 }
 
@@ -857,11 +883,21 @@ struct hmx_dist {
     hipEvent_t join_ev = nullptr;
     hipStream_t cur_stream = nullptr; // the caller's stream of the product in progress (after_chunk callback)
     int cb_rc = 0;
+    // trans = 'N' output exchange as the north star words it: ncclAllReduce of the zero-padded output vector (hmx_dist_set_output_collective)
+    bool allreduce_out = false;
+    // hmx_dist_set_profiling: events on the caller's stream around the part of a global-to-global product that is NOT local computation
+    // -- start of the product, last local kernel enqueued, exchange complete -- so that the exposed exchange time is measured, not derived
+    bool profiling = false;
+    hipEvent_t prof_ev[3] = {nullptr, nullptr, nullptr};
+    bool prof_valid = false;
     ~hmx_dist() {
         for (auto e : chunk_ev)
             (void)hipEventDestroy(e);
         if (join_ev)
             (void)hipEventDestroy(join_ev);
+        for (auto e : prof_ev)
+            if (e)
+                (void)hipEventDestroy(e);
         if (side)
             (void)hipStreamDestroy(side);
     }
@@ -1196,6 +1232,49 @@ int hmx_dist_set_point_to_point(hmx_dist *D, int (*send)(const void *, size_t, i
     return HMX_OK;
 }
 
+/* trans = 'N' global-to-global products: how the disjoint output slices reach every rank.  0 (default): exchange of the slices
+ * (MPI_Allgatherv of global_to_global.hpp:76: ncclAllGather / grouped broadcasts / pairwise send-recv); 1: ncclAllReduce of the
+ * zero-padded length-N output vector, the north star's wording (p times the bytes; not combined with the chunked overlap). */
+int hmx_dist_set_output_collective(hmx_dist *D, int all_reduce) {
+    if (!D) {
+        set_error("hmx_dist_set_output_collective: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    D->allreduce_out = all_reduce != 0;
+    return HMX_OK;
+}
+/* Events on the caller's stream around the non-local part of hmx_dist_matvec_global_to_global (trans = 'N'). */
+int hmx_dist_set_profiling(hmx_dist *D, int enabled) {
+    if (!D) {
+        set_error("hmx_dist_set_profiling: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    D->profiling  = enabled != 0;
+    D->prof_valid = false;
+    if (D->profiling)
+        for (auto &e : D->prof_ev)
+            if (!e)
+                HMX_HIP(hipEventCreate(&e));
+    return HMX_OK;
+}
+/* local_ms: start of the last profiled product -> its last local kernel done; exposed_ms: from there until the caller's stream has
+ * the whole result (what the exchange adds to the step once whatever overlapped with the local kernels is taken out).  Synchronises
+ * on the last event. */
+int hmx_dist_last_exchange_ms(hmx_dist *D, float *local_ms, float *exposed_ms) {
+    if (!D || !local_ms || !exposed_ms) {
+        set_error("hmx_dist_last_exchange_ms: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    if (!D->prof_valid) {
+        set_error("hmx_dist_last_exchange_ms: no profiled trans = 'N' global-to-global product yet (hmx_dist_set_profiling)");
+        return HMX_ERR_STATE;
+    }
+    HMX_HIP(hipEventSynchronize(D->prof_ev[2]));
+    HMX_HIP(hipEventElapsedTime(local_ms, D->prof_ev[0], D->prof_ev[1]));
+    HMX_HIP(hipEventElapsedTime(exposed_ms, D->prof_ev[1], D->prof_ev[2]));
+    return HMX_OK;
+}
+
 int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank, int world_size, const hmx_rccl_api *api, hmx_dist **out) {
     if (!local || !target || !source || !out || world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !nccl_comm)) {
         set_error("hmx_dist_create: invalid arguments");
@@ -1254,6 +1333,30 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
     const size_t e = D.esz;
     char *yb       = static_cast<char *>(y);
     const char *xb = static_cast<const char *>(x);
+    D.prof_valid = false;
+    if (D.profiling && trans == 'N')
+        HMX_HIP(hipEventRecord(D.prof_ev[0], st));
+    if (trans == 'N' && D.allreduce_out && (D.world > 1 || D.force)) {
+        // the north star's wording of the exchange: every rank puts alpha * A_loc x into its rows of a zeroed length-N vector, ncclAllReduce
+        // sums the vectors (p times the bytes of the all-gather for the same result), then y = beta * y + that
+        const int off = D.t_off[D.rank];
+        const size_t bytes = (size_t)D.nt * e;
+        if (D.work.n < bytes)
+            HMX_HIP(D.work.alloc(bytes));
+        HMX_HIP(hipMemsetAsync(D.work.d, 0, bytes, st));
+        int rc = dist_local_product(D, 'N', alpha, x, dist_zero(D), D.work.d + (size_t)off * e, st);
+        if (rc != HMX_OK)
+            return rc;
+        if (D.profiling)
+            HMX_HIP(hipEventRecord(D.prof_ev[1], st));
+        HMX_NCCL(D.api.all_reduce(D.work.d, D.work.d, (size_t)D.nt * D.reals, D.dtype, 0 /* ncclSum */, D.comm, st));
+        rc = dist_add_scaled(D, D.nt, D.work.d, beta, y, st);
+        if (rc == HMX_OK && D.profiling) {
+            HMX_HIP(hipEventRecord(D.prof_ev[2], st));
+            D.prof_valid = true;
+        }
+        return rc;
+    }
     if (trans == 'N') { // local = beta * y_slice + alpha * A_loc x ; all-gather of the slices
         const int off = D.t_off[D.rank], n = D.t_size[D.rank];
         if (D.work.n < (size_t)n * e)
@@ -1269,6 +1372,8 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
             HMX_HIP(hipStreamWaitEvent(D.side, D.join_ev, 0));
             int used = 0;
             int rc   = dist_local_product_chunked(D, alpha, x, beta, D.work.d, st, D.nchunks, dist_after_chunk, &ctx, &used);
+            if (D.profiling)
+                (void)hipEventRecord(D.prof_ev[1], st); // the last local kernel is enqueued: what `st` waits for from here on is exchange
             // whatever happened, exchanges already enqueued on the side stream read D.work and write y: the caller's stream joins them
             // before this function returns, so that a failed call leaves nothing running behind the caller's back
             const hipError_t j1 = hipEventRecord(D.join_ev, D.side), j2 = hipStreamWaitEvent(st, D.join_ev, 0);
@@ -1282,12 +1387,23 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
             }
             HMX_HIP(j1);
             HMX_HIP(j2);
+            if (D.profiling) {
+                HMX_HIP(hipEventRecord(D.prof_ev[2], st));
+                D.prof_valid = true;
+            }
             return HMX_OK;
         }
         int rc = dist_local_product(D, 'N', alpha, x, beta, D.work.d, st);
         if (rc != HMX_OK)
             return rc;
-        return dist_gather_slices(D, D.t_off, D.t_size, D.work.d, yb, st);
+        if (D.profiling)
+            HMX_HIP(hipEventRecord(D.prof_ev[1], st));
+        rc = dist_gather_slices(D, D.t_off, D.t_size, D.work.d, yb, st);
+        if (rc == HMX_OK && D.profiling) {
+            HMX_HIP(hipEventRecord(D.prof_ev[2], st));
+            D.prof_valid = true;
+        }
+        return rc;
     }
     // transposed: every rank contributes alpha * A_loc^T x_slice to the whole vector; all-reduce; beta * y_old added once
     const int off = D.t_off[D.rank];

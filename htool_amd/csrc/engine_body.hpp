@@ -1441,7 +1441,9 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     });
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hmx_mem_info(&free_b, &total_b));
-    const double budget        = 0.40 * (double)free_b / sizeof(scalar);
+    size_t largest_b = 0;
+    HMX_HIP(hmx_mem_largest(&largest_b)); // the pool is ONE array: it must fit the driver's free memory or one hole of a reserved slab
+    const double budget        = std::min(0.40 * (double)free_b, 0.95 * (double)largest_b) / sizeof(scalar);
     unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : 1.25 * estimate));
     phase("host scratch tables");
     DArr<unsigned long long> head;
@@ -1568,6 +1570,11 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         }
         size_t free2 = 0, total2 = 0;
         HMX_HIP(hmx_mem_info(&free2, &total2));
+        {
+            size_t one = 0;
+            HMX_HIP(hmx_mem_largest(&one));
+            free2 = std::min(free2, (size_t)(1.9 * (double)one)); // the scratch slab (0.5 * free2 below) is one array
+        }
         int64_t total_need = 0;
         for (int32_t b : order)
             total_need += need_elems[b];
@@ -2024,6 +2031,11 @@ static int api_recompress(HMat *Hp, double epsilon) {
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return need[a] != need[b] ? need[a] > need[b] : a < b; });
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hmx_mem_info(&free_b, &total_b));
+    {
+        size_t one = 0;
+        HMX_HIP(hmx_mem_largest(&one));
+        free_b = std::min(free_b, (size_t)(1.9 * (double)one)); // the scratch slab (0.5 * free_b below) is one array
+    }
     int64_t total_need = 0;
     for (int32_t b : order)
         total_need += need[b];

@@ -433,6 +433,17 @@ class NativeCommunicator:
         else:
             self._make_host_staged_table()
 
+    def count(self):
+        """Number of ranks AS THE COMMUNICATOR REPORTS IT (ncclCommCount on the native RCCL communicator; the process group's size
+        for the host-staged table)."""
+        if self.backend != "rccl":
+            return self.world
+        n = C.c_int(-1)
+        self.lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        if self.lib.ncclCommCount(self.comm, C.byref(n)) != 0:
+            raise RuntimeError("ncclCommCount failed")
+        return int(n.value)
+
     def destroy(self):
         if self.backend == "rccl" and self.comm:
             self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
@@ -565,6 +576,24 @@ class NativeDistributedOperator:
         st = self._stream(like) if like is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(self._L.hmx_dist_set_overlap(self._h, int(chunks), st))
         return int(self._L.hmx_dist_overlap_chunks(self._h))
+
+    def set_output_collective(self, all_reduce):
+        """trans='N' global-to-global products: exchange of the output slices (False, default) or ncclAllReduce of the zero-padded
+        output vector (True): hmx_dist_set_output_collective.  Every rank must choose the same."""
+        from ._lib import check
+        check(self._L.hmx_dist_set_output_collective(self._h, 1 if all_reduce else 0))
+
+    def set_profiling(self, on):
+        from ._lib import check
+        check(self._L.hmx_dist_set_profiling(self._h, 1 if on else 0))
+
+    def last_exchange_ms(self):
+        """(local_ms, exposed_ms) of the last profiled trans='N' global-to-global product: HIP events on the caller's stream
+        (hmx_dist_last_exchange_ms)."""
+        from ._lib import check
+        a, b = C.c_float(0), C.c_float(0)
+        check(self._L.hmx_dist_last_exchange_ms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
 
     def set_point_to_point(self, enable):
         """Output slices exchanged pairwise (grouped ncclSend / ncclRecv) instead of all-gather / grouped broadcasts

@@ -345,6 +345,18 @@ int hmx_dist_set_reduce_scatter(hmx_dist *, int (*reduce_scatter)(const void *se
 int hmx_dist_set_point_to_point(hmx_dist *, int (*send)(const void *buf, size_t count, int datatype, int peer, void *comm, void *stream),
                                 int (*recv)(void *buf, size_t count, int datatype, int peer, void *comm, void *stream), int enable);
 
+/* How the disjoint output slices of a trans = 'N' global-to-global product reach every rank: 0 (default) = exchange of the slices
+ * (MPI_Allgatherv of global_to_global.hpp:76: ncclAllGather, grouped ncclBroadcast or pairwise send / recv); 1 = ncclAllReduce of the
+ * zero-padded length-N output vector ("RCCL all-reduce of the output vector": p times the bytes for the same result; single exchange,
+ * not chunked).  Every rank must choose the same. */
+int hmx_dist_set_output_collective(hmx_dist *, int all_reduce);
+/* Exposed exchange time, measured: with profiling on, hmx_dist_matvec_global_to_global (trans = 'N') records events on the caller's
+ * stream at its start, after its last local kernel and when the whole result is there.  hmx_dist_last_exchange_ms returns
+ * local_ms = start -> last local kernel done and exposed_ms = from there to the end (the exchange minus whatever ran under the local
+ * kernels on the side stream); it synchronises on the last event. */
+int hmx_dist_set_profiling(hmx_dist *, int enabled);
+int hmx_dist_last_exchange_ms(hmx_dist *, float *local_ms, float *exposed_ms);
+
 /* Timing hooks for bench.py: average duration (ms) of the last matvec's kernels measured with HIP
  * events on the launch stream; names[i] is a static string. */
 int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *, int max, const char **names, float *ms);

@@ -146,6 +146,14 @@ FULL_CASES.update({"full_ellipse_n1000000_p8_rank%d" % r: dict(n=1000000, geom="
                    for r in range(8)})
 
 
+# BASELINE configs[4] at its own size: N=4e6 fp32, 'S','L', sympartialACA, eps=1e-6, 16 right-hand sides, row-partitioned over 8 ranks
+# (minimal depth 7: N / 2^7 <= 46340).  Three of the eight per-rank operators -- the first, a middle one and the last -- as htool builds
+# and multiplies them (5 GB each).  And configs[0]'s literal workload: N=5000 points in the unit ball, eps=1e-3, partialACA.
+FULL_CASES.update({"full_ellipse_n4000000_f32_symL_p8_rank%d" % r: dict(n=4000000, geom="ellipse", leaf=100, eps=1e-6, eta=10, sym="S", uplo="L", compressor="sympartialACA",
+                                                                        prec="f32", mu=16, mindepth=7, partitions=8, rank=r) for r in (0, 3, 7)})
+FULL_CASES["full_ball_n5000_eps1e-3"] = dict(n=5000, geom="ball", leaf=100, eps=1e-3, eta=10, compressor="partialACA")
+
+
 def sample_rows(n):
     """SAMPLE distinct fixed rows, spread over the whole range (closed form: reproducible in the test)."""
     return np.unique((np.arange(SAMPLE, dtype=np.int64) * 2654435761 + 12345) % n)

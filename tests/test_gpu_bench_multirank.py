@@ -55,5 +55,16 @@ def test_bench_starts_its_own_ranks(impl):
         assert d["dist"]["impl"].startswith("native"), d["dist"]
         # exchange variants: 0 / 2 / 4 row chunks, each as all-gather / broadcasts and pairwise (send / recv)
         assert set(d["dist"]["exchange_trials_ms"]) >= {"0", "2", "0+p2p", "2+p2p"}, d["dist"]
+        # ... and the north star's wording of the exchange, ncclAllReduce of the zero-padded output vector, as one more variant
+        assert "allreduce" in d["dist"]["exchange_trials_ms"], d["dist"]
+        # the number of ranks comes from the communicator, the exposed exchange time from HIP events around the non-local part
+        assert d["dist"]["rccl_ranks"] == 2
+        assert d["dist"]["exposed_exchange_ms"] is not None and d["dist"]["exposed_exchange_ms"] >= 0 and "HIP events" in d["dist"]["exposed_exchange_method"]
+        assert d["dist"]["local_ms_events"] > 0
+        # next to the multi-rank number: htool's own MPI + OpenMP path on this box's host cores, same configuration, cores stated
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dist_bench")) and os.path.exists("/opt/conda/bin/mpiexec"):
+            cb = d["cpu_baseline"]
+            assert cb["kind"] == "reference-mpi" and cb["mpi_ranks"] == 2 and cb["cores"] == 2 * cb["omp_threads_per_rank"] and cb["value"] > 0, cb
+            assert cb["n"] == 200000, cb
     else:
         assert d["dist"]["impl"].startswith("python")

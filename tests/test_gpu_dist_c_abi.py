@@ -240,9 +240,12 @@ MOCK_SCRIPT = textwrap.dedent('''
         ab = np.array([1.5 - (0.5j if cplx else 0), 0.25 + (1j if cplx else 0)], dtype=dtype)
         pa, pb = C.c_void_p(ab.ctypes.data), C.c_void_p(ab.ctypes.data + ab.itemsize)
         # p2p: the output slices exchanged pairwise (grouped send / recv) instead of all-gather / grouped broadcasts
-        for trans, overlap, p2p in (("N", 0, 0), ("T", 0, 0), ("N", 3, 0), ("N", 2, 0), ("N", 0, 1), ("N", 3, 1), ("T", 0, 1)):
+        # last field: the trans = 'N' output exchange as ncclAllReduce of the zero-padded vector (hmx_dist_set_output_collective)
+        for trans, overlap, p2p, allred in (("N", 0, 0, 0), ("T", 0, 0, 0), ("N", 3, 0, 0), ("N", 2, 0, 0), ("N", 0, 1, 0), ("N", 3, 1, 0), ("T", 0, 1, 0), ("N", 0, 0, 1)):
             for D in Ds:
                 check(L.hmx_dist_set_point_to_point(D, C.cast(send_fn, C.c_void_p), C.cast(recv_fn, C.c_void_p), p2p))
+                check(L.hmx_dist_set_output_collective(D, allred))
+                check(L.hmx_dist_set_profiling(D, 1))
             ref = y0.copy()
             hm.internal_add_hmatrix_vector_product(trans, ab[0], Hfull, xin, ab[1], ref)
             for local in ((False, True) if overlap == 0 else (False,)):
@@ -258,6 +261,10 @@ MOCK_SCRIPT = textwrap.dedent('''
                         assert L.hmx_dist_overlap_chunks(Ds[k]) == overlap
                         check(fn(Ds[k], trans.encode(), pa, dx, pb, dy, None))
                         assert hip.hipDeviceSynchronize() == 0
+                        if trans == "N" and not local:  # measured: local part and exposed exchange of this product (HIP events)
+                            lm, em = C.c_float(-1), C.c_float(-1)
+                            check(L.hmx_dist_last_exchange_ms(Ds[k], C.byref(lm), C.byref(em)))
+                            assert lm.value > 0 and em.value >= 0, (lm.value, em.value)
                         y = host(dy, yi)
                         want = ref[off:off + sz] if local else ref
                         errs[k] = np.linalg.norm(y - want) / np.linalg.norm(want)
@@ -269,6 +276,9 @@ MOCK_SCRIPT = textwrap.dedent('''
                 [t.join() for t in th]
                 assert not fails, fails
                 assert max(errs) < 1e-12, (np.dtype(dtype).name, trans, local, errs)
+        for D in Ds:
+            check(L.hmx_dist_set_output_collective(D, 0))
+            check(L.hmx_dist_set_profiling(D, 0))
         # row-major multi-RHS global-to-global products (mu = 3): exchange of mu-interleaved row slices / all-reduce of the whole matrix
         mu = 3
         X = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
@@ -293,6 +303,53 @@ MOCK_SCRIPT = textwrap.dedent('''
             [t.join() for t in th]
             assert not fails, fails
             assert max(errs) < 1e-12, (np.dtype(dtype).name, "matmat", trans, errs)
+        # row-major multi-RHS LOCAL-TO-LOCAL product (HPDDMOperator::GMV's call for mu != 1): all-gather of the mu-interleaved rows of X /
+        # reduce-scatter of mu * n rows; against the rows of the whole operator's product and against mu single-vector local-to-local products
+        for trans in ("N", "T"):
+            ref = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, ab[0], Hfull, X, ab[1], ref, mu)
+            errs, fails = [None] * WORLD, []
+            def l2l_rank(k):
+                try:
+                    off, sz = int(parts[k][0]), int(parts[k][1])
+                    Xl, Yl = np.ascontiguousarray(X[off:off + sz]), np.ascontiguousarray(Y0[off:off + sz])
+                    dx, dy = dev(Xl), dev(Yl)
+                    check(L.hmx_dist_matmat_row_major_local_to_local(Ds[k], trans.encode(), pa, dx, pb, dy, mu, None))
+                    assert hip.hipDeviceSynchronize() == 0
+                    got = host(dy, Yl)
+                    e1 = np.linalg.norm(got - ref[off:off + sz]) / np.linalg.norm(ref[off:off + sz])
+                    cols = np.empty_like(Yl)
+                    for c in range(mu):  # the same through mu single-vector products
+                        dxc, dyc = dev(np.ascontiguousarray(Xl[:, c])), dev(np.ascontiguousarray(Yl[:, c]))
+                        check(L.hmx_dist_matvec_local_to_local(Ds[k], trans.encode(), pa, dxc, pb, dyc, None))
+                        assert hip.hipDeviceSynchronize() == 0
+                        cols[:, c] = host(dyc, np.ascontiguousarray(Yl[:, c]))
+                    errs[k] = max(e1, np.linalg.norm(got - cols) / np.linalg.norm(cols))
+                except BaseException as e:
+                    fails.append(e)
+                    barrier.abort()
+            th = [threading.Thread(target=l2l_rank, args=(k,)) for k in range(WORLD)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not fails, fails
+            assert max(errs) < 1e-12, (np.dtype(dtype).name, "matmat l2l", trans, errs)
+            # column-major front end, partition numbering (transposition on the device around the same product)
+            errs, fails = [None] * WORLD, []
+            def cm_rank(k):
+                try:
+                    dx, dy = dev(np.asfortranarray(X).ravel("K")), dev(np.asfortranarray(Y0).ravel("K"))
+                    check(L.hmx_dist_matmat_global_to_global(Ds[k], trans.encode(), pa, dx, pb, dy, mu, 0, None))
+                    assert hip.hipDeviceSynchronize() == 0
+                    got = host(dy, np.asfortranarray(Y0).ravel("K")).reshape(mu, n).T
+                    errs[k] = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+                except BaseException as e:
+                    fails.append(e)
+                    barrier.abort()
+            th = [threading.Thread(target=cm_rank, args=(k,)) for k in range(WORLD)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not fails, fails
+            assert max(errs) < 1e-12, (np.dtype(dtype).name, "column-major g2g", trans, errs)
         for D in Ds:
             L.hmx_dist_destroy(D)
         print("ok", np.dtype(dtype).name)
