@@ -57,8 +57,8 @@ struct Abi<double> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const double *U, const double *V) { return hmx_hmatrix_set_block_lowrank(h, leaf, r, U, V); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const double *D) { return hmx_hmatrix_set_block_dense(h, leaf, D); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, double *U, double *V) { return hmx_hmatrix_get_block(h, leaf, U, V); }
-    static int matvec(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out) { return hmx_hmatrix_matvec(h, tr, a, in, b, out, HMX_MEM_HOST, nullptr); }
-    static int matmat(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out, int mu) { return hmx_hmatrix_matmat_row_major(h, tr, a, in, b, out, mu, HMX_MEM_HOST, nullptr); }
+    static int matvec(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec(h, tr, a, in, b, out, mem, stream); }
+    static int matmat(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major(h, tr, a, in, b, out, mu, mem, stream); }
 };
 template <>
 struct Abi<float> {
@@ -68,8 +68,8 @@ struct Abi<float> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const float *U, const float *V) { return hmx_hmatrix_set_block_lowrank_s(h, leaf, r, U, V); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const float *D) { return hmx_hmatrix_set_block_dense_s(h, leaf, D); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, float *U, float *V) { return hmx_hmatrix_get_block_s(h, leaf, U, V); }
-    static int matvec(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out) { return hmx_hmatrix_matvec_s(h, tr, a, in, b, out, HMX_MEM_HOST, nullptr); }
-    static int matmat(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out, int mu) { return hmx_hmatrix_matmat_row_major_s(h, tr, a, in, b, out, mu, HMX_MEM_HOST, nullptr); }
+    static int matvec(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec_s(h, tr, a, in, b, out, mem, stream); }
+    static int matmat(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major_s(h, tr, a, in, b, out, mu, mem, stream); }
 };
 template <>
 struct Abi<std::complex<double>> {
@@ -82,8 +82,8 @@ struct Abi<std::complex<double>> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const Z *U, const Z *V) { return hmx_hmatrix_set_block_lowrank_z(h, leaf, r, p(U), p(V)); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const Z *D) { return hmx_hmatrix_set_block_dense_z(h, leaf, p(D)); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, Z *U, Z *V) { return hmx_hmatrix_get_block_z(h, leaf, p(U), p(V)); }
-    static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out) { return hmx_hmatrix_matvec_z(h, tr, p(&a), p(in), p(&b), p(out), HMX_MEM_HOST, nullptr); }
-    static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu) { return hmx_hmatrix_matmat_row_major_z(h, tr, p(&a), p(in), p(&b), p(out), mu, HMX_MEM_HOST, nullptr); }
+    static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec_z(h, tr, p(&a), p(in), p(&b), p(out), mem, stream); }
+    static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major_z(h, tr, p(&a), p(in), p(&b), p(out), mu, mem, stream); }
 };
 template <>
 struct Abi<std::complex<float>> {
@@ -96,8 +96,8 @@ struct Abi<std::complex<float>> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const Z *U, const Z *V) { return hmx_hmatrix_set_block_lowrank_c(h, leaf, r, p(U), p(V)); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const Z *D) { return hmx_hmatrix_set_block_dense_c(h, leaf, p(D)); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, Z *U, Z *V) { return hmx_hmatrix_get_block_c(h, leaf, p(U), p(V)); }
-    static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out) { return hmx_hmatrix_matvec_c(h, tr, p(&a), p(in), p(&b), p(out), HMX_MEM_HOST, nullptr); }
-    static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu) { return hmx_hmatrix_matmat_row_major_c(h, tr, p(&a), p(in), p(&b), p(out), mu, HMX_MEM_HOST, nullptr); }
+    static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec_c(h, tr, p(&a), p(in), p(&b), p(out), mem, stream); }
+    static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major_c(h, tr, p(&a), p(in), p(&b), p(out), mu, mem, stream); }
 };
 
 struct ClusterOptions { // the arguments the caller gave to htool's ClusterTreeBuilder
@@ -397,6 +397,15 @@ class GlobalToLocalHmxT final : public htool::VirtualGlobalToLocalOperator<T> {
     void add_matrix_product_row_major(char trans, T alpha, const T *const in, T beta, T *const out, int mu) const override {
         ok(Abi<T>::matmat(m_engine.hmatrix(), trans, alpha, in, beta, out, mu), "matmat");
     }
+    // For callers that already hold their vectors in device memory (a GPU Krylov solver, another HIP library): the same products on
+    // DEVICE pointers, enqueued on `stream` (a hipStream_t) -- no host staging, no PCIe copies.  Not part of htool's interface
+    // (its contract is host pointers); `in` / `out` have the sizes add_vector_product / add_matrix_product_row_major document.
+    bool add_vector_product_device(char trans, T alpha, const T *d_in, T beta, T *d_out, void *stream = nullptr) const {
+        return ok(Abi<T>::matvec(m_engine.hmatrix(), trans, alpha, d_in, beta, d_out, HMX_MEM_DEVICE, stream), "matvec (device pointers)");
+    }
+    bool add_matrix_product_row_major_device(char trans, T alpha, const T *d_in, T beta, T *d_out, int mu, void *stream = nullptr) const {
+        return ok(Abi<T>::matmat(m_engine.hmatrix(), trans, alpha, d_in, beta, d_out, mu, HMX_MEM_DEVICE, stream), "matmat (device pointers)");
+    }
     void add_sub_matrix_product_to_local(const T *const in, T *const out, int mu, int offset, int size) const override {
         // restricted_operator.hpp:170-193: zero-extend the sub-vector to the whole source range
         std::vector<T> temp((size_t)m_source_size * mu, T(0));
@@ -431,6 +440,15 @@ class LocalToLocalHmxT final : public htool::VirtualLocalToLocalOperator<T> {
     }
     void add_matrix_product_row_major(char trans, T alpha, const T *const in, T beta, T *const out, int mu) const override {
         ok(Abi<T>::matmat(m_engine.hmatrix(), trans, alpha, in, beta, out, mu), "matmat");
+    }
+    // For callers that already hold their vectors in device memory (a GPU Krylov solver, another HIP library): the same products on
+    // DEVICE pointers, enqueued on `stream` (a hipStream_t) -- no host staging, no PCIe copies.  Not part of htool's interface
+    // (its contract is host pointers); `in` / `out` have the sizes add_vector_product / add_matrix_product_row_major document.
+    bool add_vector_product_device(char trans, T alpha, const T *d_in, T beta, T *d_out, void *stream = nullptr) const {
+        return ok(Abi<T>::matvec(m_engine.hmatrix(), trans, alpha, d_in, beta, d_out, HMX_MEM_DEVICE, stream), "matvec (device pointers)");
+    }
+    bool add_matrix_product_row_major_device(char trans, T alpha, const T *d_in, T beta, T *d_out, int mu, void *stream = nullptr) const {
+        return ok(Abi<T>::matmat(m_engine.hmatrix(), trans, alpha, d_in, beta, d_out, mu, HMX_MEM_DEVICE, stream), "matmat (device pointers)");
     }
     // local_to_local_operators/hmatrix.hpp:33-51: `in` holds rows [offset, offset + size) of the GLOBAL source numbering; the part
     // inside the local source cluster is zero-extended to the cluster and multiplied.  (For mu > 1 the reference advances `in` by

@@ -21,6 +21,12 @@
 #include <htool/testing/geometry.hpp>
 
 #include "hmx/htool_adaptor.hpp"
+extern "C" { // the HIP runtime entry points this check needs (libamdhip64, which libhmx.so links)
+int hipMalloc(void **, size_t);
+int hipFree(void *);
+int hipMemcpy(void *, const void *, size_t, int /* 1 = host to device, 2 = device to host */);
+int hipDeviceSynchronize(void);
+}
 
 #include <cmath>
 #include <complex>
@@ -156,6 +162,32 @@ int main() {
         hmx_htool::GlobalToLocalHmx op(El, n);
         op.add_vector_product('N', 1., xin_cluster.data(), 0., yl.data());
         report("(e) GlobalToLocalHmx (row slab of partition 1) vs htool's restricted H-matrix", rel(yl, ylref), 1e-10);
+        { // the same product on DEVICE pointers (add_vector_product_device / add_matrix_product_row_major_device): no host staging
+            void *d_in = nullptr, *d_out = nullptr;
+            if (hipMalloc(&d_in, n * sizeof(double)) != 0 || hipMalloc(&d_out, nloc * sizeof(double)) != 0)
+                return 4;
+            std::vector<double> yd(nloc, 0.);
+            hipMemcpy(d_in, xin_cluster.data(), n * sizeof(double), 1);
+            hipMemcpy(d_out, yd.data(), nloc * sizeof(double), 1);
+            const bool okd = op.add_vector_product_device('N', 1., static_cast<const double *>(d_in), 0., static_cast<double *>(d_out));
+            hipDeviceSynchronize();
+            hipMemcpy(yd.data(), d_out, nloc * sizeof(double), 2);
+            report("(e) ... on device pointers: identical to the host-pointer product", okd && yd == yl ? 0. : 1., 1e-300);
+            const int mu = 3;
+            std::vector<double> Xm((size_t)n * mu), Ym((size_t)nloc * mu, 0.), Yd((size_t)nloc * mu, 0.);
+            for (size_t i = 0; i < Xm.size(); i++)
+                Xm[i] = std::sin(0.013 * (double)i) + 0.2;
+            op.add_matrix_product_row_major('N', 1., Xm.data(), 0., Ym.data(), mu);
+            void *d_X = nullptr, *d_Y = nullptr;
+            if (hipMalloc(&d_X, Xm.size() * sizeof(double)) != 0 || hipMalloc(&d_Y, Yd.size() * sizeof(double)) != 0)
+                return 4;
+            hipMemcpy(d_X, Xm.data(), Xm.size() * sizeof(double), 1);
+            const bool okm = op.add_matrix_product_row_major_device('N', 1., static_cast<const double *>(d_X), 0., static_cast<double *>(d_Y), mu);
+            hipDeviceSynchronize();
+            hipMemcpy(Yd.data(), d_Y, Yd.size() * sizeof(double), 2);
+            report("(e) ... row-major multi-RHS on device pointers: identical to the host-pointer product", okm && Yd == Ym ? 0. : 1., 1e-300);
+            hipFree(d_in), hipFree(d_out), hipFree(d_X), hipFree(d_Y);
+        }
 
         // (e') the block-diagonal operator of partition 1 (DefaultLocalApproximationBuilder) as a VirtualLocalToLocalOperator
         const Cluster<double> &part = T.get_cluster_on_partition(1);

@@ -20,7 +20,7 @@ def test_reference_with_adaptor_on_device():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=env)
     print(out.stdout)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 11
+    assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 13
 
 
 MPI_EXE = os.path.join(ROOT, "oracle", "_ref", "distributed_device_check")

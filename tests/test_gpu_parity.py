@@ -434,6 +434,40 @@ def test_symmetric_storage_layouts(name, layout, monkeypatch):
     assert rel_err(Y, g["YNrm"]) < 1e-10
 
 
+@pytest.mark.parametrize("sym,trans", [("N", "N"), ("N", "T"), ("S", "N")])
+def test_sixteen_rhs_mfma_path_against_the_oracle(sym, trans):
+    """The fp64 mu = 16 product (v_mfma_f64_16x16x4 kernels; compact symmetric storage included) against the CPU oracle's
+    restatement of openmp_internal_add_hmatrix_matrix_product_row_major (hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:
+    112-178) on the operator the oracle itself compressed: same leaves, same ranks, products to 1e-12 -- not the engine against
+    itself."""
+    from oracle import oracle as O
+    n, mu = 4000, 16
+    x = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(80)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    comp = "sympartialACA" if sym == "S" else "partialACA"
+    tb = hm.HMatrixTreeBuilder(1e-6, 10.0, sym, "L" if sym == "S" else "N")
+    tb.set_low_rank_generator(comp)
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T)
+    To = O.ClusterTree(x, 80, 2, 2)
+    Ho = O.HMatrix(To, To, eps=1e-6, eta=10.0, sym=sym, uplo="L" if sym == "S" else "N", compressor=comp)
+    assert np.array_equal(np.asarray(H.leaf_table()), Ho.leaves)
+    X = O.hashed_vector(n * mu, 31).reshape(n, mu)
+    Y0 = O.hashed_vector(n * mu, 32).reshape(n, mu)
+    Y = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.5, H, X, 0.5, Y, mu)
+    ref = Ho.matmat_row_major(X, trans, 1.5, 0.5, Y0)
+    assert rel_err(Y, ref) < 1e-12, rel_err(Y, ref)
+    names = [k for k, _ in H.last_kernel_times()] if hasattr(H, "last_kernel_times") else []
+    H.set_profiling(True)
+    Y = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.5, H, X, 0.5, Y, mu)
+    names = [k for k, _ in H.last_kernel_times()]
+    H.set_profiling(False)
+    assert any("mfma16" in k for k in names), names  # the matrix-core kernels are what ran
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-5)])
 def test_sixteen_rhs_mfma_path(dtype, tol, monkeypatch):
     """mu = 16 runs on the matrix cores (v_mfma_f64_16x16x4 / v_mfma_f32_16x16x4).  Checked against 16 separate
