@@ -124,6 +124,7 @@ SYMBOLS = [
     ("hmx_hmatrix_matmat_user_c", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_dist_create", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     ("hmx_dist_destroy", None, [_vp]),
+    ("hmx_dist_add_local_to_local_operator", C.c_int, [_vp, _vp]),
     ("hmx_dist_matvec_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matvec_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matmat_row_major_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),

@@ -852,7 +852,8 @@ int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gb
 } // extern "C" (reopened below)
 #include <dlfcn.h>
 struct hmx_dist {
-    hmx_hmatrix *local = nullptr;
+    hmx_hmatrix *local = nullptr; // the global-to-local operator (the rank's block rows), may be absent
+    hmx_hmatrix *diag  = nullptr; // a local-to-local operator (hmx_dist_add_local_to_local_operator: the block-diagonal H-matrix of partition `rank`)
     void *comm         = nullptr;
     int rank = 0, world = 1;
     hmx_rccl_api api{};
@@ -989,9 +990,8 @@ static int dist_gather_slices(hmx_dist &D, const std::vector<int> &off, const st
     HMX_NCCL(D.api.group_end());
     return HMX_OK;
 }
-// the local operator's product on device pointers, whatever its coefficient type
-static int dist_local_product(hmx_dist &D, char trans, const void *alpha, const void *in, const void *beta, void *out, hipStream_t st) {
-    hmx_hmatrix *H = D.local;
+// one operator's product on device pointers, whatever its coefficient type
+static int dist_op_product(hmx_hmatrix *H, char trans, const void *alpha, const void *in, const void *beta, void *out, hipStream_t st) {
     if (H->d)
         return hmx::f64::api_matvec(H->d, trans, *static_cast<const double *>(alpha), static_cast<const double *>(in), *static_cast<const double *>(beta), static_cast<double *>(out), HMX_MEM_DEVICE, st);
     if (H->s)
@@ -999,6 +999,47 @@ static int dist_local_product(hmx_dist &D, char trans, const void *alpha, const 
     if (H->z)
         return hmx::z64::api_matvec(H->z, trans, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), HMX_MEM_DEVICE, st);
     HMX_GUARD(hmx::c32::api_matvec(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), HMX_MEM_DEVICE, st));
+}
+static int dist_op_matmat(hmx_hmatrix *H, char trans, const void *alpha, const void *in, const void *beta, void *out, int mu, hipStream_t st) {
+    if (H->d)
+        return hmx::f64::api_matmat_row_major(H->d, trans, *static_cast<const double *>(alpha), static_cast<const double *>(in), *static_cast<const double *>(beta), static_cast<double *>(out), mu, HMX_MEM_DEVICE, st);
+    if (H->s)
+        return hmx::f32::api_matmat_row_major(H->s, trans, *static_cast<const float *>(alpha), static_cast<const float *>(in), *static_cast<const float *>(beta), static_cast<float *>(out), mu, HMX_MEM_DEVICE, st);
+    if (H->z)
+        return hmx::z64::api_matmat_row_major(H->z, trans, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), mu, HMX_MEM_DEVICE, st);
+    return hmx::c32::api_matmat_row_major(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), mu, HMX_MEM_DEVICE, st);
+}
+static const void *dist_one(const hmx_dist &D) {
+    static const double one[2] = {1.0, 0.0};
+    static const float onef[2] = {1.f, 0.f};
+    return D.dtype == 8 ? (const void *)one : (const void *)onef;
+}
+// ALL operators of this rank (the loops of global_to_global.hpp:63-72 over the global-to-local and the local-to-local operators,
+// beta for the first, 1 for the rest), mu right-hand sides (mu = 1: the vector kernels):
+//   trans = 'N': `in` = the whole input in the source numbering, `out` = this rank's slice of the target numbering;
+//   otherwise  : `in` = this rank's slice of the target numbering, `out` = the whole output in the source numbering
+// -- the local-to-local operator sees the rank's slice of either.
+static int dist_local_matmat(hmx_dist &D, char trans, const void *alpha, const void *in, const void *beta, void *out, int mu, hipStream_t st) {
+    const size_t row = D.esz * (size_t)mu;
+    bool first = true;
+    if (D.local) {
+        const int rc = mu == 1 ? dist_op_product(D.local, trans, alpha, in, beta, out, st) : dist_op_matmat(D.local, trans, alpha, in, beta, out, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        first = false;
+    }
+    if (D.diag) {
+        const void *in2 = trans == 'N' ? static_cast<const void *>(static_cast<const char *>(in) + (size_t)D.s_off[D.rank] * row) : in;
+        void *out2      = trans == 'N' ? out : static_cast<void *>(static_cast<char *>(out) + (size_t)D.s_off[D.rank] * row);
+        const void *b2  = first ? beta : dist_one(D);
+        const int rc    = mu == 1 ? dist_op_product(D.diag, trans, alpha, in2, b2, out2, st) : dist_op_matmat(D.diag, trans, alpha, in2, b2, out2, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+    }
+    return HMX_OK;
+}
+static int dist_local_product(hmx_dist &D, char trans, const void *alpha, const void *in, const void *beta, void *out, hipStream_t st) {
+    return dist_local_matmat(D, trans, alpha, in, beta, out, 1, st);
 }
 // chunked local product (trans = 'N'), whatever the coefficient type
 static int dist_local_product_chunked(hmx_dist &D, const void *alpha, const void *in, const void *beta, void *out, hipStream_t st, int nchunks, void (*after)(void *, int, int, int), void *user, int *used) {
@@ -1013,6 +1054,12 @@ static int dist_local_product_chunked(hmx_dist &D, const void *alpha, const void
 }
 static int dist_chunk_bounds(hmx_dist &D, int nchunks, int *n, int32_t *b) {
     hmx_hmatrix *H = D.local;
+    if (!H || D.diag) { // the chunked expand stage exists for ONE operator: with a local-to-local operator registered the exchange stays whole
+        *n   = 1;
+        b[0] = 0;
+        b[1] = D.t_size[D.rank];
+        return HMX_OK;
+    }
     if (H->d)
         return hmx::f64::api_chunk_bounds(H->d, nchunks, n, b);
     if (H->s)
@@ -1119,7 +1166,7 @@ static int dist_add_scaled(hmx_dist &D, int64_t n, const void *w, const void *be
         set_error("hmx_dist: more than 2^31 coefficients in one distributed multi-RHS vector");
         return HMX_ERR_UNSUPPORTED;
     }
-    hmx_hmatrix *H = D.local;
+    hmx_hmatrix *H = D.local ? D.local : D.diag;
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
     if (H->d)
         hipLaunchKernelGGL(hmx::f64::axpby_kernel, g, b, 0, st, (int)n, 1.0, (const double *)w, *static_cast<const double *>(beta), static_cast<double *>(y));
@@ -1275,8 +1322,13 @@ int hmx_dist_last_exchange_ms(hmx_dist *D, float *local_ms, float *exposed_ms) {
     return HMX_OK;
 }
 
+static void dist_set_precision(hmx_dist &D, int prec) {
+    D.esz   = prec == HMX_PREC_F64 ? 8 : (prec == HMX_PREC_F32 ? 4 : (prec == HMX_PREC_Z64 ? 16 : 8));
+    D.dtype = (prec == HMX_PREC_F64 || prec == HMX_PREC_Z64) ? 8 : 7; // ncclFloat64 : ncclFloat32
+    D.reals = (prec == HMX_PREC_Z64 || prec == HMX_PREC_C32) ? 2 : 1;
+}
 int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank, int world_size, const hmx_rccl_api *api, hmx_dist **out) {
-    if (!local || !target || !source || !out || world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !nccl_comm)) {
+    if (!target || !source || !out || world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !nccl_comm)) {
         set_error("hmx_dist_create: invalid arguments");
         return HMX_ERR_INVALID;
     }
@@ -1314,11 +1366,29 @@ int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hm
     D->ns = source->n;
     D->t_perm = target->perm, D->s_perm = source->perm;
     D->t_perm_local = target->permutation_is_local, D->s_perm_local = source->permutation_is_local;
-    const int prec = hmx_hmatrix_precision(local);
-    D->esz   = prec == HMX_PREC_F64 ? 8 : (prec == HMX_PREC_F32 ? 4 : (prec == HMX_PREC_Z64 ? 16 : 8));
-    D->dtype = (prec == HMX_PREC_F64 || prec == HMX_PREC_Z64) ? 8 : 7; // ncclFloat64 : ncclFloat32
-    D->reals = (prec == HMX_PREC_Z64 || prec == HMX_PREC_C32) ? 2 : 1;
-    *out     = D;
+    if (local)
+        dist_set_precision(*D, hmx_hmatrix_precision(local));
+    *out = D;
+    return HMX_OK;
+}
+/* DistributedOperator::add_local_to_local_operator (distributed_operator/distributed_operator.hpp:50-53) with a LocalToLocalHMatrix
+ * (implementations/local_to_local_operators/hmatrix.hpp:15-56): the H-matrix on (target partition rank) x (source partition rank), built
+ * on a block tree from hmx_block_tree_create_local -- DefaultLocalApproximationBuilder's block-diagonal operator (utility.hpp:64-88).
+ * Every product then adds its contribution on the rank's slices, after the global-to-local operator's (which may be absent: create the
+ * hmx_dist with local = NULL).  One of each kind at most; same coefficient type. */
+int hmx_dist_add_local_to_local_operator(hmx_dist *D, hmx_hmatrix *diag) {
+    if (!D || !diag) {
+        set_error("hmx_dist_add_local_to_local_operator: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    const int prec = hmx_hmatrix_precision(diag);
+    if (D->local && hmx_hmatrix_precision(D->local) != prec) {
+        set_error("hmx_dist_add_local_to_local_operator: the operators of one DistributedOperator have one coefficient type");
+        return HMX_ERR_INVALID;
+    }
+    D->diag = diag;
+    dist_set_precision(*D, prec);
+    D->nchunks = 0; // see dist_chunk_bounds
     return HMX_OK;
 }
 void hmx_dist_destroy(hmx_dist *D) { delete D; }
@@ -1330,6 +1400,10 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
     }
     hmx_dist &D    = *Dp;
     hipStream_t st = (hipStream_t)stream;
+    if (!D.local && !D.diag) {
+        set_error("hmx_dist: no operator registered");
+        return HMX_ERR_STATE;
+    }
     const size_t e = D.esz;
     char *yb       = static_cast<char *>(y);
     const char *xb = static_cast<const char *>(x);
@@ -1420,33 +1494,12 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
     if (D.world > 1 || D.force)
         HMX_NCCL(D.api.all_reduce(D.work.d, D.work.d, (size_t)D.ns * D.reals, D.dtype, 0 /* ncclSum */, D.comm, st));
     // y = beta * y + work
-    hmx_hmatrix *H = D.local;
-    const int n    = D.ns;
-    if (H->d)
-        hipLaunchKernelGGL(hmx::f64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0, (const double *)D.work.d, *static_cast<const double *>(beta), static_cast<double *>(y));
-    else if (H->s)
-        hipLaunchKernelGGL(hmx::f32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0f, (const float *)D.work.d, *static_cast<const float *>(beta), static_cast<float *>(y));
-    else if (H->z)
-        hipLaunchKernelGGL(hmx::z64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<double>(1.0), ZP(D.work.d), zval(static_cast<const double *>(beta)), ZPM(y));
-    else
-        hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<float>(1.0f), CP(D.work.d), cval(static_cast<const float *>(beta)), CPM(y));
-    HMX_HIP(hipGetLastError());
-    return HMX_OK;
+    return dist_add_scaled(D, D.ns, D.work.d, beta, y, st);
 }
 
 // add_distributed_operator_matrix_product_row_major_global_to_global.hpp:18-85: X (n x mu) and Y (m x mu) row-major (mu fastest), whole
 // matrices replicated on every rank, partition numbering.  trans = 'N': the local slice of Y (its rows are contiguous: mu-interleaved),
 // product, exchange of the slices (MPI_Allgatherv :76); transposed: all-reduce of the whole matrix (:78).
-static int dist_local_matmat(hmx_dist &D, char trans, const void *alpha, const void *in, const void *beta, void *out, int mu, hipStream_t st) {
-    hmx_hmatrix *H = D.local;
-    if (H->d)
-        return hmx::f64::api_matmat_row_major(H->d, trans, *static_cast<const double *>(alpha), static_cast<const double *>(in), *static_cast<const double *>(beta), static_cast<double *>(out), mu, HMX_MEM_DEVICE, st);
-    if (H->s)
-        return hmx::f32::api_matmat_row_major(H->s, trans, *static_cast<const float *>(alpha), static_cast<const float *>(in), *static_cast<const float *>(beta), static_cast<float *>(out), mu, HMX_MEM_DEVICE, st);
-    if (H->z)
-        return hmx::z64::api_matmat_row_major(H->z, trans, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), mu, HMX_MEM_DEVICE, st);
-    return hmx::c32::api_matmat_row_major(H->c, trans, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), mu, HMX_MEM_DEVICE, st);
-}
 int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const void *alpha, const void *X, const void *beta, void *Y, int mu, void *stream) {
     if (!Dp || !alpha || !beta || !X || !Y || mu < 1) {
         set_error("hmx_dist_matmat_row_major_global_to_global: invalid arguments");
@@ -1454,6 +1507,10 @@ int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const v
     }
     hmx_dist &D    = *Dp;
     hipStream_t st = (hipStream_t)stream;
+    if (!D.local && !D.diag) {
+        set_error("hmx_dist: no operator registered");
+        return HMX_ERR_STATE;
+    }
     const size_t e = D.esz * (size_t)mu; // bytes per row
     char *yb       = static_cast<char *>(Y);
     const char *xb = static_cast<const char *>(X);
@@ -1482,19 +1539,7 @@ int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const v
         return rc;
     if (D.world > 1 || D.force)
         HMX_NCCL(D.api.all_reduce(D.work.d, D.work.d, (size_t)D.ns * D.reals * mu, D.dtype, 0 /* ncclSum */, D.comm, st));
-    hmx_hmatrix *H = D.local;
-    const int64_t n = (int64_t)D.ns * mu;
-    const unsigned g = (unsigned)((n + 255) / 256);
-    if (H->d)
-        hipLaunchKernelGGL(hmx::f64::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, 1.0, (const double *)D.work.d, *static_cast<const double *>(beta), static_cast<double *>(Y));
-    else if (H->s)
-        hipLaunchKernelGGL(hmx::f32::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, 1.0f, (const float *)D.work.d, *static_cast<const float *>(beta), static_cast<float *>(Y));
-    else if (H->z)
-        hipLaunchKernelGGL(hmx::z64::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, cplx<double>(1.0), ZP(D.work.d), zval(static_cast<const double *>(beta)), ZPM(Y));
-    else
-        hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3(g), dim3(256), 0, st, (int)n, cplx<float>(1.0f), CP(D.work.d), cval(static_cast<const float *>(beta)), CPM(Y));
-    HMX_HIP(hipGetLastError());
-    return HMX_OK;
+    return dist_add_scaled(D, (int64_t)D.ns * mu, D.work.d, beta, Y, st);
 }
 
 int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, const void *x_local, const void *beta, void *y_local, void *stream) {
@@ -1505,6 +1550,12 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
     hmx_dist &D    = *Dp;
     hipStream_t st = (hipStream_t)stream;
     const size_t e = D.esz;
+    if (!D.local && !D.diag) {
+        set_error("hmx_dist: no operator registered");
+        return HMX_ERR_STATE;
+    }
+    if (!D.local) // local-to-local operators only (local_to_local.hpp:27-31): local slices in and out, nothing to exchange
+        return dist_op_product(D.diag, trans, alpha, x_local, beta, y_local, st);
     if (trans == 'N') { // all-gather of x, then the local product straight into the local slice
         const size_t bytes = (size_t)D.ns * e;
         if (D.work2.n < bytes)
@@ -1542,17 +1593,7 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
             HMX_NCCL(D.api.all_reduce(D.work2.d, D.work2.d, (size_t)D.ns * D.reals, D.dtype, 0, D.comm, st));
         }
     }
-    hmx_hmatrix *H = D.local;
-    if (H->d)
-        hipLaunchKernelGGL(hmx::f64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0, (const double *)w, *static_cast<const double *>(beta), static_cast<double *>(y_local));
-    else if (H->s)
-        hipLaunchKernelGGL(hmx::f32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, 1.0f, (const float *)w, *static_cast<const float *>(beta), static_cast<float *>(y_local));
-    else if (H->z)
-        hipLaunchKernelGGL(hmx::z64::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<double>(1.0), ZP(w), zval(static_cast<const double *>(beta)), ZPM(y_local));
-    else
-        hipLaunchKernelGGL(hmx::c32::axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, cplx<float>(1.0f), CP(w), cval(static_cast<const float *>(beta)), CPM(y_local));
-    HMX_HIP(hipGetLastError());
-    return HMX_OK;
+    return dist_add_scaled(D, n, w, beta, y_local, st);
 }
 
 
@@ -1569,6 +1610,12 @@ int hmx_dist_matmat_row_major_local_to_local(hmx_dist *Dp, char trans, const voi
     }
     hmx_dist &D    = *Dp;
     hipStream_t st = (hipStream_t)stream;
+    if (!D.local && !D.diag) {
+        set_error("hmx_dist: no operator registered");
+        return HMX_ERR_STATE;
+    }
+    if (!D.local) // local-to-local operators only: nothing to exchange
+        return dist_op_matmat(D.diag, trans, alpha, X_local, beta, Y_local, mu, st);
     const size_t e = D.esz * (size_t)mu; // bytes per row
     const size_t bytes = (size_t)D.ns * e;
     if (D.work2.n < bytes)

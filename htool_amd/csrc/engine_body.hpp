@@ -51,6 +51,22 @@ struct HMat {
     std::vector<int64_t> staged_off;
     std::vector<int32_t> perm_t, perm_s; // full permutations (cluster -> user)
     bool t_root_is_tree_root = false, perm_local = false;
+    // the cluster trees' nodes as (offset, size, first child, number of children), GLOBAL cluster positions: the R-stream pieces of a
+    // source cluster larger than SR_MAX follow the tree (its descendants of at most SR_MAX rows), so that the pieces of ALL cluster
+    // levels nest inside "windows" (the tree nodes of at most SR_MAX rows whose parent is larger) -- what lets one workgroup keep a
+    // window's rows of a multi-RHS input on chip for every task over them (reduce_win_* kernels)
+    struct TreeNode {
+        int32_t off, size, first_child, n_children;
+    };
+    std::vector<TreeNode> tree_t, tree_s;
+    // windows of the source rows (root-local offsets) and, per window, its (range piece, column chunk) tasks dealt to SPLITS x WAVES bins
+    std::vector<int32_t> win_off, win_len;
+    DArr<int32_t> d_win_off, d_win_len, d_win_order, d_win_bin_ptr, d_win_bin_task;
+    int n_win = 0, n_win_groups = 0; // n_win_groups = n_win * WIN_SPLITS workgroups
+    // groups of consecutive row ranges whose column lists share a prefix (expand_grp_* kernels: the prefix's operand rows staged once)
+    DArr<int32_t> d_grp_first, d_grp_count, d_grp_prefix, d_grp_order;
+    int n_grp = 0;
+    double grp_shared_frac = 0; // share of the E columns that lie in a common prefix
 
     // generator
     // host generator: VirtualGenerator::copy_submatrix semantics (user numbering, column-major output)
@@ -208,14 +224,59 @@ static int build_streams(HMat &H) {
     R.off.clear();
     R.len.clear();
     std::vector<int32_t> scluster_first(sclusters.size() + 1, 0);
-    for (size_t c = 0; c < sclusters.size(); c++) {
-        std::vector<int> bp{sclusters[c].first, sclusters[c].first + sclusters[c].second};
-        std::vector<int32_t> o, ln;
-        make_ranges(bp, SR_MAX, H.S0, o, ln);
-        scluster_first[c] = (int32_t)R.off.size();
-        R.off.insert(R.off.end(), o.begin(), o.end());
-        R.len.insert(R.len.end(), ln.begin(), ln.end());
-    }
+    // Pieces of a source cluster larger than SR_MAX: its descendants of at most SR_MAX rows in the source cluster tree (when the
+    // tree is known and cuts reasonably: binary trees halve, so pieces are SR_MAX / 2 ... SR_MAX rows), otherwise steps of SR_MAX rows
+    // from the cluster's start.  Along the tree the pieces of every cluster level nest inside the same windows (below).
+    const bool want_tree_pieces = !(getenv("HMX_R_TREE_PIECES") && !atoi(getenv("HMX_R_TREE_PIECES")));
+    std::map<std::pair<int, int>, int> node_of;
+    if (want_tree_pieces)
+        for (size_t v = 0; v < H.tree_s.size(); v++)
+            node_of[{H.tree_s[v].off, H.tree_s[v].size}] = (int)v; // same (offset, size) more than once (single-child root): the deepest
+    auto cut_pieces = [&](bool along_tree) -> bool { // false: the tree cannot be used (then called again without it)
+        R.off.clear();
+        R.len.clear();
+        int64_t n_cut = 0, n_pieces = 0, rows = 0;
+        for (size_t c = 0; c < sclusters.size(); c++) {
+            std::vector<int32_t> o, ln;
+            if (along_tree && sclusters[c].second > SR_MAX) {
+                auto it = node_of.find({sclusters[c].first, sclusters[c].second});
+                if (it == node_of.end())
+                    return false; // a source cluster that is no node of the tree: not the tree the blocks came from
+                std::vector<int> stack{it->second};
+                while (!stack.empty()) { // depth first, children in order: pieces come out by increasing offset
+                    const HMat::TreeNode nd = H.tree_s[stack.back()];
+                    stack.pop_back();
+                    if (nd.size <= SR_MAX) {
+                        o.push_back(nd.off - H.S0);
+                        ln.push_back(nd.size);
+                    } else if (nd.n_children == 0) { // a leaf cluster larger than SR_MAX (maximal_leaf_size > SR_MAX): steps of SR_MAX rows
+                        std::vector<int> bp{nd.off, nd.off + nd.size};
+                        std::vector<int32_t> o2, l2;
+                        make_ranges(bp, SR_MAX, H.S0, o2, l2);
+                        o.insert(o.end(), o2.begin(), o2.end());
+                        ln.insert(ln.end(), l2.begin(), l2.end());
+                    } else {
+                        for (int k = nd.n_children - 1; k >= 0; k--)
+                            stack.push_back(nd.first_child + k);
+                    }
+                }
+                n_cut++;
+                n_pieces += (int64_t)o.size();
+                rows += sclusters[c].second;
+            } else {
+                std::vector<int> bp{sclusters[c].first, sclusters[c].first + sclusters[c].second};
+                make_ranges(bp, SR_MAX, H.S0, o, ln);
+            }
+            scluster_first[c] = (int32_t)R.off.size();
+            R.off.insert(R.off.end(), o.begin(), o.end());
+            R.len.insert(R.len.end(), ln.begin(), ln.end());
+        }
+        // trees with many children per node cut into slivers: then the fixed steps are the better pieces (and there are no windows)
+        return !(along_tree && n_cut > 0 && (double)rows / (double)n_pieces < 0.35 * SR_MAX);
+    };
+    bool tree_pieces = want_tree_pieces && !H.tree_s.empty() && cut_pieces(true);
+    if (!tree_pieces)
+        (void)cut_pieces(false);
     scluster_first[sclusters.size()] = (int32_t)R.off.size();
     // position -> range lookup
     std::vector<int32_t> t_pos2range(H.nT + 1, -1);
@@ -238,7 +299,17 @@ static int build_streams(HMat &H) {
     H.stats = hmx_stats{};
     H.stats.rank_min = 1 << 30;
     double rank_sum  = 0;
-    for (int64_t b = 0; b < nb; b++) {
+    // Columns are given out leaf by leaf in the order of DECREASING target cluster size (ties: the leaves' own order): the leaves that
+    // reach a row range form a chain of nested target clusters, so two neighbouring ranges then share a PREFIX of their column lists --
+    // the leaves whose target cluster contains both (expand_grp_* kernels stage that prefix's operand rows once for the group).
+    // HMX_E_GROUPS=0: the leaves' own order, no groups.
+    const bool want_groups = !(getenv("HMX_E_GROUPS") && !atoi(getenv("HMX_E_GROUPS")));
+    std::vector<int64_t> border(nb);
+    std::iota(border.begin(), border.end(), (int64_t)0);
+    if (want_groups)
+        std::stable_sort(border.begin(), border.end(), [&](int64_t a, int64_t b) { return XL[a].t_size > XL[b].t_size; });
+    for (int64_t ib = 0; ib < nb; ib++) {
+        const int64_t b   = border[ib];
         const hmx_leaf &l = XL[b];
         const bool lr     = XK[b] == LK_LOWRANK;
         if (lr && l.rank <= 0)
@@ -351,6 +422,111 @@ static int build_streams(HMat &H) {
         R.task_range.swap(tr);
         R.task_chunk.swap(tc);
     }
+    // ---- windows of the source rows (multi-RHS reduce stage with the input rows on chip) ---------------------------------------------
+    // A window = a node of the source tree with at most SR_MAX rows whose parent has more: the windows tile the source rows, and with
+    // pieces cut along the tree every piece of every cluster level lies inside exactly one of them.  One workgroup per (window, split)
+    // keeps the window's rows of X in LDS and runs the window's tasks, dealt heaviest first to WIN_SPLITS x WIN_WAVES bins.
+    H.n_win = H.n_win_groups = 0;
+    H.win_off.clear();
+    H.win_len.clear();
+    if (tree_pieces && SR_MAX <= WIN_ROWS && !R.task_range.empty() && !(getenv("HMX_MU_WINDOW") && !atoi(getenv("HMX_MU_WINDOW")))) {
+        std::vector<std::pair<int32_t, int32_t>> wins; // (root-local offset, rows)
+        {
+            std::vector<std::pair<int, int>> stack; // (node, parent size)
+            // start from every node that is not somebody's child: the root(s)
+            std::vector<char> is_child(H.tree_s.size(), 0);
+            for (const auto &nd : H.tree_s)
+                for (int k = 0; k < nd.n_children; k++)
+                    is_child[nd.first_child + k] = 1;
+            for (size_t v = 0; v < H.tree_s.size(); v++)
+                if (!is_child[v])
+                    stack.emplace_back((int)v, INT32_MAX);
+            while (!stack.empty()) {
+                const int v = stack.back().first;
+                stack.pop_back();
+                const HMat::TreeNode nd = H.tree_s[v];
+                if (nd.off + nd.size <= H.S0 || nd.off >= H.S0 + H.nS)
+                    continue; // outside this operator's source rows
+                if (nd.size <= SR_MAX || nd.n_children == 0) {
+                    if (nd.off >= H.S0 && nd.off + nd.size <= H.S0 + H.nS)
+                        wins.emplace_back(nd.off - H.S0, nd.size);
+                    continue;
+                }
+                for (int k = 0; k < nd.n_children; k++)
+                    stack.emplace_back(nd.first_child + k, nd.size);
+            }
+        }
+        std::sort(wins.begin(), wins.end());
+        // every piece must lie inside one window (true along the tree; checked, the window kernels are simply not used otherwise)
+        std::vector<int32_t> win_of_range(R.nranges(), -1);
+        bool nested = !wins.empty();
+        for (int r = 0; r < R.nranges() && nested; r++) {
+            auto it = std::upper_bound(wins.begin(), wins.end(), std::make_pair(R.off[r], INT32_MAX));
+            if (it == wins.begin()) {
+                nested = false;
+                break;
+            }
+            --it;
+            if (R.off[r] + R.len[r] > it->first + it->second || it->second > SR_MAX)
+                nested = false;
+            win_of_range[r] = (int32_t)(it - wins.begin());
+        }
+        if (nested) {
+            const int nw = (int)wins.size();
+            constexpr int BINS = WIN_SPLITS;
+            std::vector<std::vector<int32_t>> tasks_of(nw);
+            std::vector<int64_t> win_work(nw, 0);
+            auto work = [&](int t) {
+                const int r = R.task_range[t], c = R.task_chunk[t];
+                const int w = std::min<int>(R.cols[r] - c * R.cw[r], R.cw[r]);
+                return (int64_t)R.len[r] * w;
+            };
+            for (int t = 0; t < (int)R.task_range.size(); t++) {
+                tasks_of[win_of_range[R.task_range[t]]].push_back(t);
+                win_work[win_of_range[R.task_range[t]]] += work(t);
+            }
+            std::vector<int32_t> bin_ptr((size_t)nw * BINS + 1, 0), bin_task;
+            bin_task.reserve(R.task_range.size());
+            for (int w = 0; w < nw; w++) {
+                auto &tl = tasks_of[w];
+                std::stable_sort(tl.begin(), tl.end(), [&](int a, int b) { return work(a) > work(b); });
+                // the window's tasks to its WIN_SPLITS workgroups, longest first to the one with the least work so far; inside a
+                // workgroup the waves pull the tasks from the list in this order
+                std::vector<std::vector<int32_t>> bins(BINS);
+                int64_t load[BINS] = {0};
+                for (int t : tl) {
+                    int best = 0;
+                    for (int b = 1; b < BINS; b++)
+                        if (load[b] < load[best])
+                            best = b;
+                    bins[best].push_back(t);
+                    load[best] += work(t) + 2048; // a fixed cost per task: set-up and the write of its results
+                }
+                for (int b = 0; b < BINS; b++) {
+                    bin_task.insert(bin_task.end(), bins[b].begin(), bins[b].end());
+                    bin_ptr[(size_t)w * BINS + b + 1] = (int32_t)bin_task.size();
+                }
+            }
+            std::vector<int32_t> order((size_t)nw * WIN_SPLITS);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return win_work[a / WIN_SPLITS] > win_work[b / WIN_SPLITS]; });
+            H.win_off.resize(nw);
+            H.win_len.resize(nw);
+            for (int w = 0; w < nw; w++) {
+                H.win_off[w] = wins[w].first;
+                H.win_len[w] = wins[w].second;
+            }
+            if (bin_task.empty())
+                bin_task.push_back(0);
+            HMX_HIP(H.d_win_off.upload(H.win_off));
+            HMX_HIP(H.d_win_len.upload(H.win_len));
+            HMX_HIP(H.d_win_order.upload(order));
+            HMX_HIP(H.d_win_bin_ptr.upload(bin_ptr));
+            HMX_HIP(H.d_win_bin_task.upload(bin_task));
+            H.n_win        = nw;
+            H.n_win_groups = nw * WIN_SPLITS;
+        }
+    }
     if (E.total_cols >= (int64_t(1) << 31) || R.total_cols >= (int64_t(1) << 31) || (int64_t)H.nS + A_total + P_total + 2 >= (int64_t(1) << 31)) {
         set_error("operator too large for 32-bit column indices");
         return HMX_ERR_UNSUPPORTED;
@@ -378,6 +554,76 @@ static int build_streams(HMat &H) {
     };
     fill_e(elr_b, elr_r, elr_c, true);
     fill_e(ed_b, ed_r, ed_c, false);
+    // ---- groups of E_GW consecutive row ranges and the column prefix they share (expand_grp_* kernels) ----------------------------------
+    // The prefix is taken from the index arrays themselves (longest common prefix of the ranges' operand indices), so it is right whatever
+    // order the columns came in; the ordering above only makes it long.  Of the E_GW possible alignments of the groups the one with the
+    // most shared columns is used.
+    H.n_grp           = 0;
+    H.grp_shared_frac = 0;
+    if (want_groups && E.nranges() > 0 && !mirror_flags) {
+        constexpr int GW = E_GW;
+        const int nr = E.nranges();
+        auto lcp = [&](int r0, int r1) { // columns of r0 .. r1 - 1 that agree from the start
+            int p = E.cols[r0];
+            const int32_t *z0 = H.h_e_zidx.data() + E.colbase[r0];
+            for (int r = r0 + 1; r < r1; r++) {
+                const int32_t *z = H.h_e_zidx.data() + E.colbase[r];
+                const int lim    = std::min(p, (int)E.cols[r]);
+                int q = 0;
+                while (q < lim && z[q] == z0[q])
+                    q++;
+                p = q;
+            }
+            return r1 - r0 > 1 ? p : 0;
+        };
+        int best_shift = 0;
+        int64_t best   = -1;
+        std::vector<int64_t> shared_of(GW, 0);
+        parallel_for((size_t)GW, [&](size_t lo, size_t hi) {
+            for (size_t sh = lo; sh < hi; sh++) {
+                int64_t tot = 0;
+                for (int r0 = sh ? (int)sh - GW : 0; r0 < nr; r0 += GW) {
+                    const int a = std::max(r0, 0), b = std::min(r0 + GW, nr);
+                    tot += (int64_t)lcp(a, b) * (b - a - 1);
+                }
+                shared_of[sh] = tot;
+            }
+        });
+        for (int sh = 0; sh < GW; sh++)
+            if (shared_of[sh] > best) {
+                best       = shared_of[sh];
+                best_shift = sh;
+            }
+        std::vector<int32_t> gfirst, gcount, gprefix;
+        int64_t shared = 0;
+        for (int r0 = best_shift ? best_shift - GW : 0; r0 < nr; r0 += GW) {
+            const int a = std::max(r0, 0), b = std::min(r0 + GW, nr);
+            gfirst.push_back(a);
+            gcount.push_back(b - a);
+            gprefix.push_back(lcp(a, b));
+            shared += (int64_t)gprefix.back() * (b - a);
+        }
+        std::vector<int32_t> gorder(gfirst.size());
+        std::iota(gorder.begin(), gorder.end(), 0);
+        auto gwork = [&](int g) {
+            int64_t w = 0;
+            for (int r = gfirst[g]; r < gfirst[g] + gcount[g]; r++)
+                w += (int64_t)E.len[r] * E.cols[r];
+            return w;
+        };
+        std::vector<int64_t> gw(gfirst.size());
+        for (size_t g = 0; g < gfirst.size(); g++)
+            gw[g] = gwork((int)g);
+        std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return gw[a] > gw[b]; });
+        HMX_HIP(H.d_grp_first.upload(gfirst));
+        HMX_HIP(H.d_grp_count.upload(gcount));
+        HMX_HIP(H.d_grp_prefix.upload(gprefix));
+        HMX_HIP(H.d_grp_order.upload(gorder));
+        H.n_grp           = (int)gfirst.size();
+        H.grp_shared_frac = E.total_cols ? (double)shared / (double)E.total_cols : 0;
+        if (phase_timing)
+            fprintf(stderr, "[hmx build]   %d groups of %d row ranges (alignment %d): %.1f %% of the E columns in a shared prefix\n", H.n_grp, GW, best_shift, 100 * H.grp_shared_frac);
+    }
     std::vector<int32_t> h_outidx(R.total_cols, 0);
     H.h_r_aidx.assign(R.total_cols, 0);
     H.h_r_mirrorflag.assign(mirror_flags ? R.total_cols : 0, 0);
@@ -942,9 +1188,27 @@ static bool mu_scalar_operands(bool reduce_stage) {
     const int v   = e ? atoi(e) : -1;
     return v < 0 ? (reduce_stage && sizeof(scalar) == 4) : v != 0;
 }
+// The multi-RHS reduce stage with a window of X in LDS (reduce_win_* kernels): when the layout has windows (pieces cut along the
+// source tree) -- by default for the matrix-core kernel (groups of 16 real right-hand sides); HMX_MU_WINDOW=1 for every type and
+// group size, =0 never (then the layout does not build the window lists either).
+static bool mu_window(const HMat &H, bool mfma) {
+    if (H.n_win_groups <= 0)
+        return false;
+    const char *e = getenv("HMX_MU_WINDOW");
+    // measured at N = 1e6 (tools/ab_mu.sh, gpurun_out/r3_ab_mu*): fp64 mu = 16 on the matrix cores 1.68 against 1.75 ms, and the expand
+    // stage that follows gains another 0.1 ms; the VALU form loses (complex double mu = 8: 3.07 against 2.63 ms, fp32 mu = 16: 1.08
+    // against 0.80 ms with the scalar-operand kernel) -- its operand reads come from the same LDS pipe either way
+    return e ? atoi(e) != 0 : mfma;
+}
+static WinArgs win_args(const HMat &H) { return WinArgs{H.d_win_off.d, H.d_win_len.d, H.d_win_order.d, H.d_win_bin_ptr.d, H.d_win_bin_task.d, H.n_win_groups}; }
 template <int MU>
 static void launch_mu(HMat &H, ReduceArgs &RA, ExpandArgs &XA, int mu, int cbase, hipStream_t st) {
     constexpr int RW = 4;
+    if (MU >= 4 && mu_window(H, false)) {
+        hipLaunchKernelGGL((reduce_win_mu_kernel<WIN_WAVES, MU>), dim3(H.n_win_groups), dim3(WIN_WAVES * 64), 0, st, RA, win_args(H), mu, cbase);
+        prof_mark(H, st, "reduce_win_mu_kernel");
+        return;
+    }
 #if !HMX_COMPLEX
     if (mu_scalar_operands(true) && MU >= 4) {
         static const int rw = getenv("HMX_REDUCE_MU_WAVES") ? atoi(getenv("HMX_REDUCE_MU_WAVES")) : RW;
@@ -1012,6 +1276,11 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     for_groups([&](int g, int c) {
 #if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
+            if (mu_window(H, true)) {
+                hipLaunchKernelGGL((reduce_win_mfma16_kernel<WIN_WAVES>), dim3(H.n_win_groups), dim3(WIN_WAVES * 64), 0, st, RA, win_args(H), mu, c);
+                prof_mark(H, st, "reduce_win_mfma16_kernel");
+                return;
+            }
             if (RA.ntasks > 0)
                 hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
             prof_mark(H, st, "reduce_mfma16_kernel");
@@ -1038,6 +1307,13 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     for_groups([&](int g, int c) {
 #if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
+            // groups of sibling row ranges with the shared operand rows staged once (HMX_MU_GROUPS=0: one workgroup per range)
+            if (H.n_grp > 0 && H.grp_shared_frac > 0.15 && !(getenv("HMX_MU_GROUPS") && !atoi(getenv("HMX_MU_GROUPS")))) {
+                GroupArgs GA{H.d_grp_first.d, H.d_grp_count.d, H.d_grp_prefix.d, H.d_grp_order.d, H.n_grp};
+                hipLaunchKernelGGL((expand_grp_mfma16_kernel<E_GW>), dim3(H.n_grp), dim3(E_GW * 64), 0, st, XA, GA, mu, c);
+                prof_mark(H, st, "expand_grp_mfma16_kernel");
+                return;
+            }
             if (XA.nranges > 0)
                 hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
             prof_mark(H, st, "expand_mfma16_kernel");
@@ -1116,6 +1392,7 @@ static HMat *ensure_transposed_operator(HMat &H) {
     T->kind = H.kind;
     T->T0 = H.S0, T->nT = H.nS, T->S0 = H.T0, T->nS = H.nT;
     T->nT_total = H.nS_total, T->nS_total = H.nT_total;
+    T->tree_t = H.tree_s, T->tree_s = H.tree_t;
     T->symmetry_for_leaves = H.symmetry_for_leaves;
     T->uplo_for_leaves     = H.uplo_for_leaves == 'L' ? 'U' : (H.uplo_for_leaves == 'U' ? 'L' : 'N');
     T->build_epsilon       = H.build_epsilon;
@@ -1158,6 +1435,7 @@ static HMat *ensure_expanded_view(HMat &H) {
     X->kind            = H.kind;
     X->T0 = H.T0, X->nT = H.nT, X->S0 = H.S0, X->nS = H.nS;
     X->nT_total = H.nT_total, X->nS_total = H.nS_total;
+    X->tree_t = H.tree_t, X->tree_s = H.tree_s; // symmetric storage: one cluster tree on both sides
     X->symmetry_for_leaves = H.symmetry_for_leaves;
     X->uplo_for_leaves     = H.uplo_for_leaves;
     X->build_epsilon       = H.build_epsilon;
@@ -1288,6 +1566,13 @@ static int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
     H->uplo_for_leaves     = bt->uplo_for_leaves;
     H->perm_t              = bt->target->perm;
     H->perm_s              = bt->source->perm;
+    auto copy_tree = [](const hmx_cluster_tree &T, std::vector<HMat::TreeNode> &out) {
+        out.resize(T.nodes.size());
+        for (size_t v = 0; v < T.nodes.size(); v++)
+            out[v] = HMat::TreeNode{T.nodes[v].offset, T.nodes[v].size, T.nodes[v].first_child, T.nodes[v].n_children};
+    };
+    copy_tree(*bt->target, H->tree_t);
+    copy_tree(*bt->source, H->tree_s);
     H->t_root_is_tree_root = (H->T0 == 0 && H->nT == bt->target->n);
     H->perm_local          = bt->target->permutation_is_local;
     for (auto &l : H->leaves)

@@ -1731,7 +1731,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
 // covers R = floor(wave elements / wp) whole rows of the contiguous row-major chunk, lane l works on row group EPL*l / wp and
 // reads ITS row's MU operands from the wave-private LDS tile (R distinct rows per ds_read instead of one broadcast row:
 // the same LDS time for R rows of stream).  The R partial sums per column are folded in a fixed tree at the end.
-template <int MU>
+// STAGED = false: `xt` already holds the operand rows of the WHOLE piece (a window of X kept in LDS by the workgroup, reduce_win_mu_kernel):
+// nothing is staged, row i of the piece is xt[i].
+template <int MU, bool STAGED = true>
 __device__ __forceinline__ void reduce_mu_narrow(const ReduceArgs &A, scalar (*xt)[MU], int lane, int S, int ch, int len, int w, int wp, int cw,
                                                  const scalar *src, const scalar *xs, int mu, int cbase) {
     constexpr int EPL = HMX_SPLIT_COLS ? 1 : 2;
@@ -1744,13 +1746,16 @@ __device__ __forceinline__ void reduce_mu_narrow(const ReduceArgs &A, scalar (*x
         a0[c] = a1[c] = scalar(0);
     for (int i0 = 0; i0 < len; i0 += 64) {
         const int nr = (len - i0) < 64 ? (len - i0) : 64;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < nr) {
+        if (STAGED) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nr) {
 #pragma unroll
-            for (int c = 0; c < MU; c++)
-                xt[lane][c] = xs[(int64_t)(i0 + lane) * mu + c];
+                for (int c = 0; c < MU; c++)
+                    xt[lane][c] = xs[(int64_t)(i0 + lane) * mu + c];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        scalar(*const xrow)[MU] = STAGED ? xt : xt + i0;
         const scalar *p = src + (int64_t)i0 * wp + e0;
         for (int j = 0; j < nr; j += 4 * R) {
 #if HMX_SPLIT_COLS
@@ -1771,7 +1776,7 @@ __device__ __forceinline__ void reduce_mu_narrow(const ReduceArgs &A, scalar (*x
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (ok[u]) { // masked lanes do not touch their sums (no 0 * inf)
-                    const scalar *xr = xt[j + u * R + g];
+                    const scalar *xr = xrow[j + u * R + g];
 #pragma unroll
                     for (int c = 0; c < MU; c++) {
 #if HMX_SPLIT_COLS
@@ -1903,6 +1908,108 @@ __global__ void combine_mu_kernel(CombineArgs A, int mu) {
     for (int k = 0; k < cnt; k++)
         s += p[(int64_t)k * st * mu];
     A.Z[(int64_t)A.dst[e] * mu + c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-RHS reduce stage with the input rows ON CHIP.  In reduce_mu_kernel / reduce_mfma16_kernel every (piece, chunk) task fetches
+// its rows of X itself; the pieces of all cluster levels cover the same rows, so at N = 1e6 a row of X is fetched ~15 times (2.0 GB
+// on a 7.2 GB stream for 16 fp64 right-hand sides: profiles/r2_bench_n1e6_mu16*).  Here the source rows are tiled by WINDOWS (nodes of the
+// source cluster tree of at most 512 rows; the pieces are cut along the same tree, so every piece lies inside one window), one
+// workgroup per (window, split) copies the window's rows of X to LDS once -- one contiguous block of memory -- and its waves run
+// the window's tasks from the list dealt to them at layout time.  Same arithmetic per task as the per-task kernels.
+// ---------------------------------------------------------------------------------------------
+struct WinArgs {
+    const int32_t *win_off, *win_len; // window: first source row (root-local), rows (<= WIN_ROWS)
+    const int32_t *order;             // launch position -> (window, split), heaviest windows first
+    const int32_t *bin_ptr, *bin_task; // tasks of (window, split) g, heaviest first: bin_task[bin_ptr[g] .. bin_ptr[g + 1]); the waves pull them one by one
+    int ngroups;
+};
+
+template <int WAVES, int MU>
+__global__ __launch_bounds__(WAVES *WAVE, 4) void reduce_win_mu_kernel(ReduceArgs A, WinArgs Wn, int mu, int cbase) {
+    __shared__ __attribute__((aligned(16))) scalar xw[WIN_ROWS][MU];
+    __shared__ int next_task;
+    const int g    = Wn.order[blockIdx.x];
+    if (threadIdx.x == 0)
+        next_task = Wn.bin_ptr[g];
+    const int win  = g / WIN_SPLITS;
+    const int woff = Wn.win_off[win], wlen = Wn.win_len[win];
+    {
+        const scalar *xs = A.x + (int64_t)woff * mu + cbase;
+        for (int e = threadIdx.x; e < wlen * MU; e += WAVES * WAVE) {
+            const int i = e / MU, c = e - i * MU;
+            xw[i][c]    = xs[(int64_t)i * mu + c];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int q1   = Wn.bin_ptr[g + 1];
+    for (;;) { // the waves pull the tasks of this (window, split) heaviest first: no wave waits for another one's long task
+        int q = 0;
+        if (lane == 0)
+            q = atomicAdd(&next_task, 1);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= q1)
+            break;
+        const int task = Wn.bin_task[q];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        const int wp      = hmx_wp(w);
+        const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+        const bool active = col0 < wp;
+        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+        scalar(*const xr)[MU] = xw + (A.range_off[S] - woff); // this piece's rows of the window
+        if (HMX_REDUCE_ROWS && wp <= (HMX_SPLIT_COLS ? 32 : 64)) {
+            reduce_mu_narrow<MU, false>(A, xr, lane, S, ch, len, w, wp, cw, src, nullptr, mu, cbase);
+            continue;
+        }
+        scalar a0[MU], a1[MU];
+#pragma unroll
+        for (int c = 0; c < MU; c++)
+            a0[c] = a1[c] = scalar(0);
+        int j = 0;
+        for (; j + 4 <= len; j += 4) {
+            scalar2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                v[u] = load_pair(src + (int64_t)(j + u) * wp, col0, col1, wp);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int c = 0; c < MU; c++) {
+                    const scalar xi = xr[j + u][c];
+                    a0[c]           = hmx_fma(v[u].x, xi, a0[c]);
+                    a1[c]           = hmx_fma(v[u].y, xi, a1[c]);
+                }
+            }
+        }
+        for (; j < len; j++) {
+            const scalar2 v = load_pair(src + (int64_t)j * wp, col0, col1, wp);
+#pragma unroll
+            for (int c = 0; c < MU; c++) {
+                const scalar xi = xr[j][c];
+                a0[c]           = hmx_fma(v.x, xi, a0[c]);
+                a1[c]           = hmx_fma(v.y, xi, a1[c]);
+            }
+        }
+        if (active) {
+            const int64_t cb = A.range_colbase[S] + ch * cw;
+            if (col0 < w) {
+                scalar *dst = A.Z + (int64_t)A.out_idx[cb + col0] * mu + cbase;
+#pragma unroll
+                for (int c = 0; c < MU; c++)
+                    dst[c] = a0[c];
+            }
+            if (col1 < w) {
+                scalar *dst = A.Z + (int64_t)A.out_idx[cb + col1] * mu + cbase;
+#pragma unroll
+                for (int c = 0; c < MU; c++)
+                    dst[c] = a1[c];
+            }
+        }
+    }
 }
 
 template <int WAVES, int MU>
@@ -2169,6 +2276,122 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16_kernel(ExpandArgs A
     }
 }
 
+// expand_mfma16_kernel for GROUPS of sibling row ranges.  A low-rank leaf of m rows reaches m / 64 row ranges and every one of them
+// fetches the leaf's rows of `a` again (at N = 1e6 a range has 890 low-rank columns, 16 fp64 right-hand sides: 114 KB of gathered
+// rows per 430 KB of U slices; summed over the ranges every row of `a` is fetched 4.6 times).  The layout orders the columns of a
+// range by decreasing target cluster, so consecutive ranges share a PREFIX of their column lists (the leaves whose target cluster
+// contains all of them).  One workgroup takes GW consecutive ranges, one wave each: the common prefix is walked in lock step, its
+// operand rows staged ONCE per 64 columns in LDS (double buffered: the next tile's gather is in flight under the MFMAs of the current
+// one), then every wave finishes its private columns alone with the operand straight from memory as before.  A wave owns its rows: no
+// reduction over the waves at the end.
+struct GroupArgs {
+    const int32_t *first, *count, *prefix; // group: first range, ranges (<= GW), columns common to all of them (a prefix of each list)
+    const int32_t *order;                  // launch position -> group (heaviest first)
+    int ngroups;
+};
+template <int GW>
+__global__ __launch_bounds__(GW *WAVE) void expand_grp_mfma16_kernel(ExpandArgs A, GroupArgs Gp, int mu, int cbase) {
+    static_assert(GW == 4, "the staging below deals 64 x 16 values to 256 threads");
+    __shared__ __attribute__((aligned(16))) real zt[2][64][16];
+    const int g  = Gp.order[blockIdx.x];
+    const int r0 = Gp.first[g], cnt = Gp.count[g], P = Gp.prefix[g];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool have = wv < cnt;
+    const int R     = r0 + (have ? wv : 0);
+    const int len = have ? A.range_len[R] : 0, C = have ? A.range_cols[R] : 0;
+    const real *E        = A.stream + A.range_base[R];
+    const int32_t *zidx0 = A.z_idx + A.range_colbase[r0]; // the common columns: the first range's list serves all
+    const int m = lane & 15, kk = lane >> 4;              // A: row m of the tile, column kk of the group; B: column kk, rhs m
+    acc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    constexpr int G = 4; // four groups of 4 columns per step, as in expand_mfma16_kernel
+    // ---- common prefix: tiles of 64 columns, operand rows through LDS ----
+    const int ntile = (P + 63) >> 6;
+    const int srow = threadIdx.x >> 2, sq = (threadIdx.x & 3) * 4; // this thread's share of a tile: 4 right-hand sides of one column
+    real pre[4] = {0, 0, 0, 0};
+    auto fetch = [&](int tile) {
+        const int col = tile * 64 + srow;
+        if (col < P) {
+            const real *zr = expand_operand(A, zidx0[col], mu) + cbase + sq;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                pre[k] = zr[k];
+        }
+    };
+    if (ntile > 0)
+        fetch(0);
+    for (int i = 0; i < ntile; i++) {
+        real(*buf)[16] = zt[i & 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            buf[srow][sq + k] = pre[k];
+        __syncthreads(); // one barrier per tile: the other buffer was last read in step i - 1, which every wave has left
+        if (i + 1 < ntile)
+            fetch(i + 1);
+        const int nc = (P - 64 * i) < 64 ? (P - 64 * i) : 64;
+        if (have)
+            for (int c0 = 0; c0 < nc; c0 += 4 * G) {
+                real b[G], a[G][4];
+#pragma unroll
+                for (int gq = 0; gq < G; gq++) {
+                    const int col  = c0 + 4 * gq + kk;
+                    const bool cok = col < nc;
+                    b[gq]          = cok ? buf[col][m] : real(0);
+                    const real *cp = E + (int64_t)(64 * i + (cok ? col : 0)) * len;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int row = 16 * t + m;
+                        a[gq][t]      = (cok && row < len) ? stream_load(cp + row) : real(0);
+                    }
+                }
+#pragma unroll
+                for (int gq = 0; gq < G; gq++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        acc[t] = mfma16(a[gq][t], b[gq], acc[t]);
+            }
+    }
+    if (!have)
+        return;
+    // ---- private columns: this wave alone, operand rows straight from memory ----
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    for (int c0 = P; c0 < C; c0 += 4 * G) {
+        real b[G], a[G][4];
+#pragma unroll
+        for (int gq = 0; gq < G; gq++) {
+            const int col  = c0 + 4 * gq + kk;
+            const bool cok = col < C;
+            b[gq]          = cok ? expand_operand(A, zidx[col], mu)[cbase + m] : real(0);
+            const real *cp = E + (int64_t)(cok ? col : 0) * len;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int row = 16 * t + m;
+                a[gq][t]      = (cok && row < len) ? stream_load(cp + row) : real(0);
+            }
+        }
+#pragma unroll
+        for (int gq = 0; gq < G; gq++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                acc[t] = mfma16(a[gq][t], b[gq], acc[t]);
+    }
+    // accumulator tile t, register j of lane l = (row 16 t + mfma16_row, rhs l & 15): the wave owns these rows
+    // (16-byte loads of row pairs were tried here as in the reduce stage: slower, 2.47 against 2.36 ms -- a column starts at an odd
+    // multiple of 8 bytes whenever the range has an odd number of rows, and half the pairs then straddle a 128-byte line)
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = 16 * t + mfma16_row(real(0), lane, j);
+            if (row < len) {
+                real *yo = A.y + (int64_t)(A.range_off[R] + row) * mu + cbase + m;
+                *yo      = A.beta == real(0) ? A.alpha * acc[t][j] : A.alpha * acc[t][j] + A.beta * (*yo);
+            }
+        }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A, int mu, int cbase) {
     const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2221,6 +2444,83 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
                 if (col < w)
                     A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
             }
+}
+
+// reduce_mfma16_kernel with the window's rows of X in LDS (see reduce_win_mu_kernel): the B operand of a step (4 rows x 16
+// right-hand sides) is one conflict-free ds_read per lane instead of a global load that, summed over the tasks, re-fetches X ~15 times.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE, 4) void reduce_win_mfma16_kernel(ReduceArgs A, WinArgs Wn, int mu, int cbase) {
+    __shared__ __attribute__((aligned(16))) real xw[WIN_ROWS][16];
+    __shared__ int next_task;
+    const int g    = Wn.order[blockIdx.x];
+    if (threadIdx.x == 0)
+        next_task = Wn.bin_ptr[g];
+    const int win  = g / WIN_SPLITS;
+    const int woff = Wn.win_off[win], wlen = Wn.win_len[win];
+    {
+        const real *xs = A.x + (int64_t)woff * mu + cbase;
+        for (int e = threadIdx.x; e < wlen * 16; e += WAVES * WAVE)
+            xw[e >> 4][e & 15] = xs[(int64_t)(e >> 4) * mu + (e & 15)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, rhs m
+    const int q1 = Wn.bin_ptr[g + 1];
+    for (;;) {
+        int q = 0;
+        if (lane == 0)
+            q = atomicAdd(&next_task, 1);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= q1)
+            break;
+        const int task = Wn.bin_task[q];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        const int wp    = hmx_wp(w);
+        const int ntile = 2 * ((w + 31) >> 5); // column tiles of 16 in use, in pairs (<= 8)
+        const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+        const real(*xr)[16] = xw + (A.range_off[S] - woff);
+        acc4 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            acc[t] = acc4{0, 0, 0, 0};
+        for (int i0 = 0; i0 < len; i0 += 8) {
+            real b[2], a[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int row  = i0 + 4 * h + kk;
+                const bool rok = row < len;
+                b[h]           = rok ? xr[row][m] : real(0);
+                const real *rp = src + (int64_t)(rok ? row : 0) * wp;
+#pragma unroll
+                for (int pr = 0; pr < 4; pr++) { // tile 2 pr: the even columns of [32 pr, 32 pr + 32), tile 2 pr + 1: the odd ones -- one 16-byte load feeds both
+                    const int col = 32 * pr + 2 * m;
+                    if (2 * pr < ntile)
+                        stream_load2(rp + col, rok ? w - col : 0, a[h][2 * pr], a[h][2 * pr + 1]);
+                    else
+                        a[h][2 * pr] = a[h][2 * pr + 1] = real(0);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    if (t < ntile)
+                        acc[t] = mfma16(a[h][t], b[h], acc[t]);
+        }
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (t < ntile)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int col = 32 * (t >> 1) + 2 * mfma16_row(real(0), lane, j) + (t & 1);
+                    if (col < w)
+                        A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
+                }
+    }
 }
 
 #endif // !HMX_COMPLEX

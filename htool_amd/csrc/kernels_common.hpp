@@ -20,6 +20,11 @@
 namespace hmx {
 
 constexpr int WAVE = 64;
+// multi-RHS reduce stage with a window of the input in LDS (reduce_win_* kernels): rows per window at most, workgroups per window,
+// waves per workgroup
+constexpr int WIN_ROWS = 512, WIN_SPLITS = 2, WIN_WAVES = 8;
+// row ranges per workgroup in the grouped multi-RHS expand stage (expand_grp_* kernels), one wave each
+constexpr int E_GW = 4;
 
 struct KernelSpec { // device-evaluable generator
     int kind;
@@ -191,6 +196,8 @@ __device__ __forceinline__ void lane_swap16(T &a, T &b) {
 #define HMX_NT 1
 #endif
 typedef double hmx_d2 __attribute__((ext_vector_type(2)));
+typedef double hmx_d2u __attribute__((ext_vector_type(2), aligned(8))); // two adjacent doubles at an 8-byte aligned address (global_load_dwordx4 needs no more)
+typedef float hmx_f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float hmx_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double stream_load(const double *p) {
 #if HMX_NT
@@ -264,6 +271,26 @@ __device__ __forceinline__ cplx2<float> stream_load(const cplx2<float> *p) { // 
 // (cdna_hip_programming.md section 3: the f64 form does NOT use the f32 row map).
 typedef double hmx_d4 __attribute__((ext_vector_type(4)));
 typedef float hmx_f4 __attribute__((ext_vector_type(4)));
+// two adjacent stream elements p[0], p[1] with one load when both are wanted (n = how many of them exist: 0, 1 or 2): halves the number of
+// load instructions of the MFMA kernels, whose 16-row / 16-column tiles otherwise fetch 8 bytes per lane
+__device__ __forceinline__ void stream_load2(const double *p, int n, double &a, double &b) {
+    if (n >= 2) {
+        const hmx_d2u v = __builtin_nontemporal_load(reinterpret_cast<const hmx_d2u *>(p));
+        a = v.x, b = v.y;
+    } else {
+        a = n == 1 ? __builtin_nontemporal_load(p) : 0.0;
+        b = 0.0;
+    }
+}
+__device__ __forceinline__ void stream_load2(const float *p, int n, float &a, float &b) {
+    if (n >= 2) {
+        const hmx_f2u v = __builtin_nontemporal_load(reinterpret_cast<const hmx_f2u *>(p));
+        a = v.x, b = v.y;
+    } else {
+        a = n == 1 ? __builtin_nontemporal_load(p) : 0.f;
+        b = 0.f;
+    }
+}
 template <typename T> struct Acc4;
 template <> struct Acc4<double> { typedef hmx_d4 type; };
 template <> struct Acc4<float> { typedef hmx_f4 type; };

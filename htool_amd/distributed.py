@@ -538,13 +538,18 @@ class NativeDistributedOperator:
     """hmx_dist_* (include/hmx.h): the row-restricted H-matrix of this rank + a communicator; products take torch tensors on the
     device, partition numbering.  set_overlap(chunks) is collective (hmx_dist_set_overlap)."""
 
-    def __init__(self, hmatrix, target_cluster, source_cluster, communicator):
+    def __init__(self, hmatrix, target_cluster, source_cluster, communicator, block_diagonal_hmatrix=None):
+        """hmatrix: the rank's row-restricted H-matrix (global-to-local operator) or None; block_diagonal_hmatrix: an H-matrix on
+        (target partition rank) x (source partition rank) registered as a local-to-local operator
+        (hmx_dist_add_local_to_local_operator; DefaultLocalApproximationBuilder's operator)."""
         from ._lib import check, lib
-        self.hmatrix, self.comm = hmatrix, communicator
+        self.hmatrix, self.comm, self.block_diagonal_hmatrix = hmatrix, communicator, block_diagonal_hmatrix
         self._L = lib()
         self._h = C.c_void_p()
-        check(self._L.hmx_dist_create(hmatrix._h, target_cluster._h, source_cluster._h, communicator.comm, communicator.rank, communicator.world,
+        check(self._L.hmx_dist_create(hmatrix._h if hmatrix is not None else None, target_cluster._h, source_cluster._h, communicator.comm, communicator.rank, communicator.world,
                                       C.byref(communicator.api), C.byref(self._h)))
+        if block_diagonal_hmatrix is not None:
+            check(self._L.hmx_dist_add_local_to_local_operator(self._h, block_diagonal_hmatrix._h))
         if communicator.reduce_scatter is not None:
             check(self._L.hmx_dist_set_reduce_scatter(self._h, communicator.reduce_scatter))
         if communicator.send is not None:  # known, not in use: set_point_to_point(True) switches the slice exchange over

@@ -289,6 +289,14 @@ typedef struct hmx_dist hmx_dist;
 int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hmx_cluster_tree *source, void *nccl_comm, int rank,
                     int world_size, const hmx_rccl_api *api, hmx_dist **out);
 void hmx_dist_destroy(hmx_dist *);
+/* DistributedOperator::add_local_to_local_operator (distributed_operator/distributed_operator.hpp:50-53) with a LocalToLocalHMatrix
+ * (implementations/local_to_local_operators/hmatrix.hpp:15-56): `diag` = the H-matrix on (target partition rank) x (source partition
+ * rank), built on a block tree from hmx_block_tree_create_local -- the block-diagonal operator of DefaultLocalApproximationBuilder
+ * (distributed_operator/utility.hpp:64-88).  Every product adds its contribution on the rank's slices after the global-to-local
+ * operator's, beta applied once (global_to_global.hpp:63-72, local_to_local.hpp:27-59).  hmx_dist_create accepts local = NULL for
+ * an operator that consists of local-to-local operators only (its local-to-local products then exchange nothing).  Kept by
+ * reference; same coefficient type as `local`. */
+int hmx_dist_add_local_to_local_operator(hmx_dist *, hmx_hmatrix *diag);
 /* y = alpha * op(A) * x + beta * y, x and y whole vectors replicated on every rank (global_to_global.hpp:18-85); the coefficient
  * type is the local operator's: pointers to double / float / interleaved complex accordingly, alpha / beta as in the matvec
  * entry points of that type but always passed by pointer here. */

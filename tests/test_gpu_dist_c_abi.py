@@ -350,7 +350,51 @@ MOCK_SCRIPT = textwrap.dedent('''
             [t.join() for t in th]
             assert not fails, fails
             assert max(errs) < 1e-12, (np.dtype(dtype).name, "column-major g2g", trans, errs)
-        for D in Ds:
+        # a DistributedOperator with BOTH kinds of operators (distributed_operator.hpp:47-53): the rank's block rows as global-to-local
+        # operator plus its block-diagonal H-matrix as local-to-local operator -- every product is the sum of the two operators' products
+        Hdiag = [tb.build(gen, T, T, dtype=dtype, local_partitions=(k, k)) for k in range(WORLD)]
+        Dd = []
+        for k in range(WORLD):
+            D = C.c_void_p()
+            check(L.hmx_dist_create(None, T._h, T._h, C.c_void_p(k + 1), k, WORLD, C.byref(api), C.byref(D)))
+            check(L.hmx_dist_add_local_to_local_operator(D, Hdiag[k]._h))
+            Dd.append(D)
+            check(L.hmx_dist_add_local_to_local_operator(Ds[k], Hdiag[k]._h))
+        one = np.array([1.0, 0.0], dtype=dtype)
+        p1, p0 = C.c_void_p(one.ctypes.data), C.c_void_p(one.ctypes.data + one.itemsize)
+        for trans in ("N", "T"):
+            outs, fails = {}, []
+            def both_rank(k):
+                try:
+                    res = []
+                    for Dk in (Dd[k], None, Ds[k]):  # block-diagonal only, (rows only: from the whole operator below), both
+                        if Dk is None:
+                            continue
+                        dx, dy = dev(xin), dev(np.zeros_like(y0))
+                        check(L.hmx_dist_matvec_global_to_global(Dk, trans.encode(), p1, dx, p0, dy, None))
+                        assert hip.hipDeviceSynchronize() == 0
+                        res.append(host(dy, y0))
+                    outs[k] = res
+                except BaseException as e:
+                    fails.append(e)
+                    barrier.abort()
+            th = [threading.Thread(target=both_rank, args=(k,)) for k in range(WORLD)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not fails, fails
+            rows = np.zeros_like(y0)
+            hm.internal_add_hmatrix_vector_product(trans, 1.0, Hfull, xin, 0.0, rows)
+            diag = np.zeros_like(y0)
+            for k in range(WORLD):
+                off, sz = int(parts[k][0]), int(parts[k][1])
+                yk = np.zeros(sz, dtype=dtype)
+                hm.internal_add_hmatrix_vector_product(trans, 1.0, Hdiag[k], np.ascontiguousarray(xin[off:off + sz]), 0.0, yk)
+                diag[off:off + sz] = yk
+            for k in range(WORLD):
+                e1 = np.linalg.norm(outs[k][0] - diag) / np.linalg.norm(diag)
+                e2 = np.linalg.norm(outs[k][1] - (rows + diag)) / np.linalg.norm(rows + diag)
+                assert e1 < 1e-12 and e2 < 1e-12, (np.dtype(dtype).name, "two operators", trans, k, e1, e2)
+        for D in Ds + Dd:
             L.hmx_dist_destroy(D)
         print("ok", np.dtype(dtype).name)
     # symmetric storage: the diagonal block of every rank is fused (mirrored contributions reach rows after the expand stage), so the

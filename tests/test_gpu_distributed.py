@@ -206,10 +206,10 @@ FAMILIES_SCRIPT = textwrap.dedent('''
     B = (D.DefaultLocalApproximationBuilder if block_diagonal else D.DefaultApproximationBuilder)(gen, T, T, tb, dtype=dtype)
     lt = np.asarray(B.hmatrix.leaf_table())
     assert np.array_equal(lt[:, :5], g["r%%d_leaves" %% rank]), "this rank's blocks / ranks differ from htool's under MPI"
-    native = None
-    if not block_diagonal:  # hmx_dist_*: the same products as one C call each, collectives host-staged over gloo
-        comm = D.NativeCommunicator(backend="gloo")
-        native = D.NativeDistributedOperator(B.hmatrix, T, T, comm)
+    # hmx_dist_*: the same products as one C call each, collectives host-staged over gloo; the block-diagonal operator is registered
+    # as a local-to-local operator of a DistributedOperator without global-to-local operator (hmx_dist_add_local_to_local_operator)
+    comm = D.NativeCommunicator(backend="gloo")
+    native = D.NativeDistributedOperator(None, T, T, comm, block_diagonal_hmatrix=B.hmatrix) if block_diagonal else D.NativeDistributedOperator(B.hmatrix, T, T, comm)
     errs = G.run_distprod_families(B.distributed_operator, rank, world, g, p, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev), native=native)
     bad = sorted((k, float(v)) for k, v in errs.items() if not v < 1e-10)
     assert not bad, bad
