@@ -1276,14 +1276,20 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     for_groups([&](int g, int c) {
 #if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
-            if (mu_window(H, true)) {
+            // stream tile through LDS (whole-row loads, HMX_MFMA_STAGE=1: the default) | window of X in LDS (HMX_MU_WINDOW=1) | neither
+            static const int staged = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;
+            if (mu_window(H, !staged)) {
                 hipLaunchKernelGGL((reduce_win_mfma16_kernel<WIN_WAVES>), dim3(H.n_win_groups), dim3(WIN_WAVES * 64), 0, st, RA, win_args(H), mu, c);
                 prof_mark(H, st, "reduce_win_mfma16_kernel");
                 return;
             }
-            if (RA.ntasks > 0)
-                hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
-            prof_mark(H, st, "reduce_mfma16_kernel");
+            if (RA.ntasks > 0) {
+                if (staged)
+                    hipLaunchKernelGGL((reduce_mfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
+                else
+                    hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
+            }
+            prof_mark(H, st, staged ? "reduce_mfma16s_kernel" : "reduce_mfma16_kernel");
             return;
         }
 #endif
@@ -1308,15 +1314,22 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
 #if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
             // groups of sibling row ranges with the shared operand rows staged once (HMX_MU_GROUPS=0: one workgroup per range)
-            if (H.n_grp > 0 && H.grp_shared_frac > 0.15 && !(getenv("HMX_MU_GROUPS") && !atoi(getenv("HMX_MU_GROUPS")))) {
+            static const int stg = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;
+            static const int grp = getenv("HMX_MU_GROUPS") ? atoi(getenv("HMX_MU_GROUPS")) : -1; // 1: always, 0: never, unset: only without staging
+            if (H.n_grp > 0 && H.grp_shared_frac > 0.15 && (grp > 0 || (grp < 0 && !stg))) {
                 GroupArgs GA{H.d_grp_first.d, H.d_grp_count.d, H.d_grp_prefix.d, H.d_grp_order.d, H.n_grp};
                 hipLaunchKernelGGL((expand_grp_mfma16_kernel<E_GW>), dim3(H.n_grp), dim3(E_GW * 64), 0, st, XA, GA, mu, c);
                 prof_mark(H, st, "expand_grp_mfma16_kernel");
                 return;
             }
-            if (XA.nranges > 0)
-                hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
-            prof_mark(H, st, "expand_mfma16_kernel");
+            static const int staged = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1; // stream tile through LDS (whole-column loads)
+            if (XA.nranges > 0) {
+                if (staged)
+                    hipLaunchKernelGGL((expand_mfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
+                else
+                    hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
+            }
+            prof_mark(H, st, staged ? "expand_mfma16s_kernel" : "expand_mfma16_kernel");
             return;
         }
 #endif

@@ -2222,6 +2222,64 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mus_kernel(ExpandArgs A, i
 // ---------------------------------------------------------------------------------------------
 typedef Acc4<real>::type acc4;
 
+// One step = 16 columns of a row range (<= 64 rows): the A operands of its 4 x 4 MFMAs (row tile t, column group g) and the 4 B operands.
+struct MfmaStep {
+    real a[4][4], b[4];
+};
+// Loads WITHOUT branches: rows beyond the range re-read its last row (they only reach accumulator rows that are never stored), columns
+// beyond the last one re-read the last column and get a zero operand (and a zero coefficient).  Nothing here depends on a load that is
+// still in flight, so the loads of the next step can be issued before the MFMAs of the current one (the first version of these kernels
+// fetched the operand index of every column group right before its loads: s_waitcnt vmcnt(0) four times per step, and every load
+// behind an exec-mask branch).  `zi` = operand index of column (tile start + lane), fetched once per 64 columns.
+__device__ __forceinline__ void mfma_step_load(MfmaStep &S, const ExpandArgs &A, const real *E, int len, int C, int c, int zi_lane_base, int zi, int mu, int cbase, int m, int kk) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int col  = c + 4 * g + kk;
+        const bool cok = col < C;
+        const int zc   = __shfl(zi, zi_lane_base + 4 * g + kk, WAVE); // the index lane (zi_lane_base + 4 g + kk) holds: no memory access
+        const real bv  = expand_operand(A, zc, mu)[cbase + m];
+        S.b[g]         = cok ? bv : real(0);
+        const real *cp = E + (int64_t)(cok ? col : C - 1) * len;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int row = 16 * t + m;
+            const real v  = stream_load(cp + (row < len ? row : len - 1));
+            S.a[g][t]     = cok ? v : real(0);
+        }
+    }
+}
+__device__ __forceinline__ void mfma_step_apply(const MfmaStep &S, acc4 (&acc)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            acc[t] = mfma16(S.a[g][t], S.b[g], acc[t]);
+}
+// The columns [c_lo, c_hi) of one range for ONE wave, in tiles of 64 columns (4 steps), double buffered.
+__device__ __forceinline__ void mfma_expand_columns(const ExpandArgs &A, const real *E, const int32_t *zidx, int len, int C, int c_lo, int c_hi, int tile_stride, int mu, int cbase,
+                                                    int lane, acc4 (&acc)[4]) {
+    const int m = lane & 15, kk = lane >> 4; // A: row m of the tile, column kk of the group; B: column kk, rhs m
+    for (int t0 = c_lo; t0 < c_hi; t0 += tile_stride) {
+        const int tend = (t0 + 64) < c_hi ? (t0 + 64) : c_hi;
+        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1]; // columns beyond the range: any valid index (their operand is zeroed)
+        MfmaStep S0, S1;
+        mfma_step_load(S0, A, E, len, C, t0, 0, zi, mu, cbase, m, kk);
+        if (t0 + 16 < tend)
+            mfma_step_load(S1, A, E, len, C, t0 + 16, 16, zi, mu, cbase, m, kk);
+        mfma_step_apply(S0, acc);
+        if (t0 + 32 < tend)
+            mfma_step_load(S0, A, E, len, C, t0 + 32, 32, zi, mu, cbase, m, kk);
+        if (t0 + 16 < tend)
+            mfma_step_apply(S1, acc);
+        if (t0 + 48 < tend)
+            mfma_step_load(S1, A, E, len, C, t0 + 48, 48, zi, mu, cbase, m, kk);
+        if (t0 + 32 < tend)
+            mfma_step_apply(S0, acc);
+        if (t0 + 48 < tend)
+            mfma_step_apply(S1, acc);
+    }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16_kernel(ExpandArgs A, int mu, int cbase) {
     __shared__ __attribute__((aligned(16))) real red[WAVES][WAVE][16];
@@ -2230,34 +2288,119 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16_kernel(ExpandArgs A
     const int len = A.range_len[R], C = A.range_cols[R];
     const real *E       = A.stream + A.range_base[R];
     const int32_t *zidx = A.z_idx + A.range_colbase[R];
-    const int m = lane & 15, kk = lane >> 4; // A: row m of the tile, column kk of the group; B: column kk, rhs m
+    const int m = lane & 15;
     acc4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
         acc[t] = acc4{0, 0, 0, 0};
-    // four groups of 4 columns per step: all 22 loads of a step are issued before its 16 MFMAs
-    constexpr int G = 4;
-    for (int c0 = wv * 4 * G; c0 < C; c0 += WAVES * 4 * G) {
-        real b[G], a[G][4];
+    // wave w takes the 64-column tiles w, w + WAVES, ...
+    if (C > 0)
+        mfma_expand_columns(A, E, zidx, len, C, wv * 64, C, WAVES * 64, mu, cbase, lane, acc);
+    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, rhs l & 15): stage as [row][rhs]
+    __syncthreads();
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int col  = c0 + 4 * g + kk;
-            const bool cok = col < C;
-            b[g]           = cok ? expand_operand(A, zidx[col], mu)[cbase + m] : real(0);
-            const real *cp = E + (int64_t)(cok ? col : 0) * len;
+    for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int row = 16 * t + m;
-                a[g][t]       = (cok && row < len) ? stream_load(cp + row) : real(0);
-            }
+        for (int j = 0; j < 4; j++)
+            red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 16; e += WAVES * WAVE) {
+        const int i = e >> 4, c = e & 15;
+        real s = red[0][i][c];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++)
+            s += red[w][i][c];
+        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+// expand_mfma16_kernel with the stream tile STAGED THROUGH LDS.  In the kernel above every lane fetches its own MFMA operand element:
+// one load instruction of a wave is four 128-byte pieces of four different columns (16 rows x 8 bytes each, and a column of a 61-row
+// range starts at an odd multiple of 8 bytes, so most pieces straddle two lines) -- the kernel moves its bytes at 5 TB/s where the
+// single-vector expand_kernel, whose loads are whole columns (lane = row: 488 contiguous bytes), reaches 6.5 TB/s.  Here the loads
+// are those of expand_kernel -- 16 whole columns per step, the next step's 16 in flight under the current step's MFMAs -- and the
+// 64 x 16 tile goes through a wave-private LDS buffer (80-element column pitch: the operand reads 16 rows x 4 columns are free of bank
+// conflicts) to reach the lanes in operand layout.  LDS traffic is 16 bytes per streamed 8, a quarter of the pipe.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs A, int mu, int cbase) {
+    constexpr int PITCH = 80; // 64 rows + 16: consecutive tile columns are 32 banks apart, so the 64-bit operand reads (16 rows x 4 columns) do not conflict
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 16 * PITCH > WAVES * WAVE * 16 ? WAVES * 16 * PITCH : WAVES * WAVE * 16];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const real *E       = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4;
+    real(*tile)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 16 * PITCH);
+    const int row      = lane < len ? lane : len - 1; // idle lanes re-read the last row: their tile rows only reach accumulator rows that are never stored
+    acc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    auto load_cols = [&](real(&v)[16], int c) { // 16 whole columns, clamped to the last one (zero operand there)
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int col = c + u < C ? c + u : C - 1;
+            v[u]          = stream_load(E + (int64_t)col * len + row);
         }
+    };
+    auto operands = [&](real(&b)[4], int c, int zi, int base) {
 #pragma unroll
-        for (int g = 0; g < G; g++)
+        for (int g = 0; g < 4; g++) {
+            const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
+            const real bv = expand_operand(A, zc, mu)[cbase + m];
+            b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
+        }
+    };
+    auto apply = [&](const real(&v)[16], const real(&b)[4]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            tile[u][lane] = v[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        real a[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                a[g][t] = tile[4 * g + kk][16 * t + m];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 acc[t] = mfma16(a[g][t], b[g], acc[t]);
+    };
+    // wave w takes the 64-column tiles w, w + WAVES, ...; inside a tile four steps of 16 columns, loads one step ahead
+    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
+        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
+        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        real v0[16], v1[16], b0[4], b1[4];
+        load_cols(v0, t0);
+        operands(b0, t0, zi, 0);
+        if (t0 + 16 < tend) {
+            load_cols(v1, t0 + 16);
+            operands(b1, t0 + 16, zi, 16);
+        }
+        apply(v0, b0);
+        if (t0 + 32 < tend) {
+            load_cols(v0, t0 + 32);
+            operands(b0, t0 + 32, zi, 32);
+        }
+        if (t0 + 16 < tend)
+            apply(v1, b1);
+        if (t0 + 48 < tend) {
+            load_cols(v1, t0 + 48);
+            operands(b1, t0 + 48, zi, 48);
+        }
+        if (t0 + 32 < tend)
+            apply(v0, b0);
+        if (t0 + 48 < tend)
+            apply(v1, b1);
     }
-    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, rhs l & 15): stage as [row][rhs]
+    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, rhs l & 15): stage as [row][rhs] (the tile buffers are done with)
+    real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -2306,7 +2449,6 @@ __global__ __launch_bounds__(GW *WAVE) void expand_grp_mfma16_kernel(ExpandArgs 
 #pragma unroll
     for (int t = 0; t < 4; t++)
         acc[t] = acc4{0, 0, 0, 0};
-    constexpr int G = 4; // four groups of 4 columns per step, as in expand_mfma16_kernel
     // ---- common prefix: tiles of 64 columns, operand rows through LDS ----
     const int ntile = (P + 63) >> 6;
     const int srow = threadIdx.x >> 2, sq = (threadIdx.x & 3) * 4; // this thread's share of a tile: 4 right-hand sides of one column
@@ -2331,52 +2473,45 @@ __global__ __launch_bounds__(GW *WAVE) void expand_grp_mfma16_kernel(ExpandArgs 
         if (i + 1 < ntile)
             fetch(i + 1);
         const int nc = (P - 64 * i) < 64 ? (P - 64 * i) : 64;
-        if (have)
-            for (int c0 = 0; c0 < nc; c0 += 4 * G) {
-                real b[G], a[G][4];
+        if (have) { // the tile's (up to) four steps, double buffered, loads without branches (see mfma_step_load)
+            auto load = [&](MfmaStep &S, int c0) {
 #pragma unroll
-                for (int gq = 0; gq < G; gq++) {
+                for (int gq = 0; gq < 4; gq++) {
                     const int col  = c0 + 4 * gq + kk;
                     const bool cok = col < nc;
-                    b[gq]          = cok ? buf[col][m] : real(0);
+                    const real bv  = buf[cok ? col : 0][m];
+                    S.b[gq]        = cok ? bv : real(0);
                     const real *cp = E + (int64_t)(64 * i + (cok ? col : 0)) * len;
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const int row = 16 * t + m;
-                        a[gq][t]      = (cok && row < len) ? stream_load(cp + row) : real(0);
+                        const real v  = stream_load(cp + (row < len ? row : len - 1));
+                        S.a[gq][t]    = cok ? v : real(0);
                     }
                 }
-#pragma unroll
-                for (int gq = 0; gq < G; gq++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[t] = mfma16(a[gq][t], b[gq], acc[t]);
-            }
+            };
+            MfmaStep S0, S1;
+            load(S0, 0);
+            if (16 < nc)
+                load(S1, 16);
+            mfma_step_apply(S0, acc);
+            if (32 < nc)
+                load(S0, 32);
+            if (16 < nc)
+                mfma_step_apply(S1, acc);
+            if (48 < nc)
+                load(S1, 48);
+            if (32 < nc)
+                mfma_step_apply(S0, acc);
+            if (48 < nc)
+                mfma_step_apply(S1, acc);
+        }
     }
     if (!have)
         return;
     // ---- private columns: this wave alone, operand rows straight from memory ----
-    const int32_t *zidx = A.z_idx + A.range_colbase[R];
-    for (int c0 = P; c0 < C; c0 += 4 * G) {
-        real b[G], a[G][4];
-#pragma unroll
-        for (int gq = 0; gq < G; gq++) {
-            const int col  = c0 + 4 * gq + kk;
-            const bool cok = col < C;
-            b[gq]          = cok ? expand_operand(A, zidx[col], mu)[cbase + m] : real(0);
-            const real *cp = E + (int64_t)(cok ? col : 0) * len;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int row = 16 * t + m;
-                a[gq][t]      = (cok && row < len) ? stream_load(cp + row) : real(0);
-            }
-        }
-#pragma unroll
-        for (int gq = 0; gq < G; gq++)
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                acc[t] = mfma16(a[gq][t], b[gq], acc[t]);
-    }
+    if (P < C)
+        mfma_expand_columns(A, E, A.z_idx + A.range_colbase[R], len, C, P, C, 64, mu, cbase, lane, acc);
     // accumulator tile t, register j of lane l = (row 16 t + mfma16_row, rhs l & 15): the wave owns these rows
     // (16-byte loads of row pairs were tried here as in the reduce stage: slower, 2.47 against 2.36 ms -- a column starts at an odd
     // multiple of 8 bytes whenever the range has an odd number of rows, and half the pairs then straddle a 128-byte line)
@@ -2433,6 +2568,92 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
             for (int t = 0; t < 8; t++)
                 if (t < ntile)
                     acc[t] = mfma16(a[h][t], b[h], acc[t]);
+    }
+    const int64_t cb = A.range_colbase[S] + ch * cw;
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        if (t < ntile)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int col = 16 * t + mfma16_row(real(0), lane, j);
+                if (col < w)
+                    A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
+            }
+}
+
+// reduce_mfma16_kernel with the stream tile staged through LDS, as expand_mfma16s_kernel: the loads are those of the single-vector
+// reduce_kernel (a lane fetches two adjacent columns, a wave one whole row of the chunk: up to 1 KiB contiguous), eight rows per step
+// with the next eight in flight, and the 8 x 128 tile reaches the lanes in operand layout through a wave-private LDS buffer
+// (144-element row pitch: rows 32 banks apart).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs A, int mu, int cbase) {
+    constexpr int PITCH = 144;
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 8 * PITCH];
+    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES + wv;
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp    = hmx_wp(w);
+    const int ntile = (w + 15) >> 4; // <= 8 column tiles of 16
+    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const real *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
+    const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, rhs m
+    real(*tile)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 8 * PITCH);
+    const int c2       = 2 * lane < wp ? 2 * lane : 0; // lanes beyond the chunk re-read its first pair (their tile columns are never used)
+    acc4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    auto load_rows = [&](scalar2 (&v)[8], int i0) { // 8 whole rows, clamped to the last one (its operand is zero there)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = i0 + u < len ? i0 + u : len - 1;
+            v[u]          = stream_load(reinterpret_cast<const scalar2 *>(src + (int64_t)row * wp + c2));
+        }
+    };
+    auto operands = [&](real(&b)[2], int i0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int row = i0 + 4 * h + kk;
+            const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + m];
+            b[h]          = row < len ? bv : real(0);
+        }
+    };
+    auto apply = [&](const scalar2 (&v)[8], const real(&b)[2]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            *reinterpret_cast<scalar2 *>(&tile[u][2 * lane]) = v[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (t < ntile)
+                    acc[t] = mfma16(tile[4 * h + kk][16 * t + m], b[h], acc[t]);
+    };
+    scalar2 v0[8], v1[8];
+    real b0[2], b1[2];
+    load_rows(v0, 0);
+    operands(b0, 0);
+    for (int i0 = 0; i0 < len; i0 += 16) {
+        if (i0 + 8 < len) {
+            load_rows(v1, i0 + 8);
+            operands(b1, i0 + 8);
+        }
+        apply(v0, b0);
+        if (i0 + 16 < len) {
+            load_rows(v0, i0 + 16);
+            operands(b0, i0 + 16);
+        }
+        if (i0 + 8 < len)
+            apply(v1, b1);
     }
     const int64_t cb = A.range_colbase[S] + ch * cw;
 #pragma unroll
