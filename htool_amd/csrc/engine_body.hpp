@@ -302,55 +302,170 @@ static int build_streams(HMat &H) {
     // Columns are given out leaf by leaf in the order of DECREASING target cluster size (ties: the leaves' own order): the leaves that
     // reach a row range form a chain of nested target clusters, so two neighbouring ranges then share a PREFIX of their column lists --
     // the leaves whose target cluster contains both (expand_grp_* kernels stage that prefix's operand rows once for the group).
-    // HMX_E_GROUPS=0: the leaves' own order, no groups.
-    const bool want_groups = !(getenv("HMX_E_GROUPS") && !atoi(getenv("HMX_E_GROUPS")));
+    // Off by default since the matrix-core kernels stage their stream tiles through LDS (expand_mfma16s_kernel is faster than the grouped
+    // kernel, and sorting the leaves + finding the prefixes costs ~80 ms of host time at N = 1e6); HMX_E_GROUPS=1 turns it on.
+    const bool want_groups = getenv("HMX_E_GROUPS") && atoi(getenv("HMX_E_GROUPS"));
     std::vector<int64_t> border(nb);
     std::iota(border.begin(), border.end(), (int64_t)0);
     if (want_groups)
         std::stable_sort(border.begin(), border.end(), [&](int64_t a, int64_t b) { return XL[a].t_size > XL[b].t_size; });
-    for (int64_t ib = 0; ib < nb; ib++) {
-        const int64_t b   = border[ib];
-        const hmx_leaf &l = XL[b];
-        const bool lr     = XK[b] == LK_LOWRANK;
-        if (lr && l.rank <= 0)
-            continue; // rank-0 low-rank block: contributes nothing (add_lrmat_vector_product.hpp:11)
-        const int ncols = lr ? l.rank : l.s_size;
-        int ra, rb;
-        range_span(t_pos2range, E, l.t_offset - H.T0, l.t_offset - H.T0 + l.t_size, ra, rb);
-        for (int r = ra; r < rb; r++) {
-            (lr ? elr_b : ed_b).push_back((int32_t)b);
-            (lr ? elr_r : ed_r).push_back(r);
-            (lr ? elr_c : ed_c).push_back(E.cols[r]);
-            E.cols[r] += ncols;
+    // Two passes over the leaves (in `border` order), each split over a few threads: pass 1 counts, per thread and per range, the
+    // columns its leaves add (and the pairs, ranks and partial slots); a prefix over the threads turns the counts into each thread's
+    // starting column per range and starting position in the pair lists; pass 2 writes the pairs.  The result is what the one-thread
+    // loop gives (columns in `border` order, pair lists leaf-major in that order) -- 58 ms of a 320 ms build at N = 1e6 before.
+    {
+        const int nre = E.nranges(), nrr = R.nranges();
+        const size_t NT = getenv("HMX_LAYOUT_THREADS") ? (size_t)std::max(1, atoi(getenv("HMX_LAYOUT_THREADS")))
+                                                       : std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)nb / 16384 + 1});
+        struct Part {
+            std::vector<int32_t> ecnt, rcnt; // columns this part adds to every E range / R piece
+            int64_t n_elr = 0, n_ed = 0, n_rlr = 0, a = 0, p = 0;
+            int64_t n_lowrank = 0, n_dense = 0, cgen_lr = 0, cgen_d = 0;
+            int rank_min = 1 << 30, rank_max = 0;
+            double rank_sum = 0;
+        };
+        std::vector<Part> part(NT);
+        auto leaf_spans = [&](int64_t b, bool &skip, bool &lr, int &ncols, int &ra, int &rb, int &sa, int &sb) {
+            const hmx_leaf &l = XL[b];
+            lr   = XK[b] == LK_LOWRANK;
+            skip = lr && l.rank <= 0; // rank-0 low-rank block: contributes nothing (add_lrmat_vector_product.hpp:11)
+            if (skip)
+                return;
+            ncols = lr ? l.rank : l.s_size;
+            range_span(t_pos2range, E, l.t_offset - H.T0, l.t_offset - H.T0 + l.t_size, ra, rb);
+            sa = sb = 0;
+            if (lr) {
+                const size_t sc = std::lower_bound(sclusters.begin(), sclusters.end(), std::make_pair((int)l.s_offset, (int)l.s_size)) - sclusters.begin();
+                sa = scluster_first[sc], sb = scluster_first[sc + 1];
+            }
+        };
+        auto run_parts = [&](auto &&fn) {
+            if (NT == 1) {
+                fn((size_t)0);
+                return;
+            }
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < NT; t++)
+                th.emplace_back([&, t] { fn(t); });
+            for (auto &x : th)
+                x.join();
+        };
+        run_parts([&](size_t t) {
+            Part &P = part[t];
+            P.ecnt.assign(nre, 0);
+            P.rcnt.assign(nrr, 0);
+            for (int64_t ib = nb * (int64_t)t / (int64_t)NT; ib < nb * (int64_t)(t + 1) / (int64_t)NT; ib++) {
+                const int64_t b = border[ib];
+                bool skip, lr;
+                int ncols, ra, rb, sa, sb;
+                leaf_spans(b, skip, lr, ncols, ra, rb, sa, sb);
+                if (skip)
+                    continue;
+                const hmx_leaf &l = XL[b];
+                for (int r = ra; r < rb; r++)
+                    P.ecnt[r] += ncols;
+                (lr ? P.n_elr : P.n_ed) += rb - ra;
+                if (lr) {
+                    P.a += l.rank;
+                    if (sb - sa > 1)
+                        P.p += (int64_t)(sb - sa) * l.rank;
+                    for (int r = sa; r < sb; r++)
+                        P.rcnt[r] += l.rank;
+                    P.n_rlr += sb - sa;
+                    if (b < nb_real) { // statistics describe the stored leaves (htool's definitions), not the mirrored copies
+                        P.n_lowrank++;
+                        P.cgen_lr += (int64_t)l.rank * (l.t_size + l.s_size);
+                        P.rank_min = std::min(P.rank_min, (int)l.rank);
+                        P.rank_max = std::max(P.rank_max, (int)l.rank);
+                        P.rank_sum += l.rank;
+                    }
+                } else if (b < nb_real) {
+                    P.n_dense++;
+                    P.cgen_d += (int64_t)l.t_size * l.s_size;
+                }
+            }
+        });
+        // exclusive prefix over the parts, per range: ecnt / rcnt become each part's first column
+        parallel_for((size_t)nre, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; r++) {
+                int32_t run = 0;
+                for (size_t t = 0; t < NT; t++) {
+                    const int32_t c = part[t].ecnt[r];
+                    part[t].ecnt[r] = run;
+                    run += c;
+                }
+                E.cols[r] = run;
+            }
+        });
+        parallel_for((size_t)nrr, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; r++) {
+                int32_t run = 0;
+                for (size_t t = 0; t < NT; t++) {
+                    const int32_t c = part[t].rcnt[r];
+                    part[t].rcnt[r] = run;
+                    run += c;
+                }
+                R.cols[r] = run;
+            }
+        });
+        std::vector<int64_t> o_elr(NT + 1, 0), o_ed(NT + 1, 0), o_rlr(NT + 1, 0), o_a(NT + 1, 0), o_p(NT + 1, 0);
+        for (size_t t = 0; t < NT; t++) {
+            o_elr[t + 1] = o_elr[t] + part[t].n_elr;
+            o_ed[t + 1]  = o_ed[t] + part[t].n_ed;
+            o_rlr[t + 1] = o_rlr[t] + part[t].n_rlr;
+            o_a[t + 1]   = o_a[t] + part[t].a;
+            o_p[t + 1]   = o_p[t] + part[t].p;
+            H.stats.n_lowrank += part[t].n_lowrank;
+            H.stats.n_dense += part[t].n_dense;
+            H.stats.cgen_lowrank += part[t].cgen_lr;
+            H.stats.cgen_dense += part[t].cgen_d;
+            H.stats.rank_min = std::min(H.stats.rank_min, part[t].rank_min);
+            H.stats.rank_max = std::max(H.stats.rank_max, part[t].rank_max);
+            rank_sum += part[t].rank_sum;
         }
-        if (lr) {
-            aoff[b] = A_total;
-            A_total += l.rank;
-            const size_t sc = std::lower_bound(sclusters.begin(), sclusters.end(), std::make_pair((int)l.s_offset, (int)l.s_size)) - sclusters.begin();
-            const int sa = scluster_first[sc], sb = scluster_first[sc + 1];
-            ns_of[b]   = sb - sa;
-            s_first[b] = sa;
-            if (sb - sa > 1) {
-                poff[b] = P_total;
-                P_total += (int64_t)(sb - sa) * l.rank;
+        A_total = o_a[NT];
+        P_total = o_p[NT];
+        elr_b.resize(o_elr[NT]), elr_r.resize(o_elr[NT]), elr_c.resize(o_elr[NT]);
+        ed_b.resize(o_ed[NT]), ed_r.resize(o_ed[NT]), ed_c.resize(o_ed[NT]);
+        rlr_b.resize(o_rlr[NT]), rlr_r.resize(o_rlr[NT]), rlr_c.resize(o_rlr[NT]);
+        run_parts([&](size_t t) {
+            Part &P = part[t];
+            int64_t q_elr = o_elr[t], q_ed = o_ed[t], q_rlr = o_rlr[t], a_run = o_a[t], p_run = o_p[t];
+            for (int64_t ib = nb * (int64_t)t / (int64_t)NT; ib < nb * (int64_t)(t + 1) / (int64_t)NT; ib++) {
+                const int64_t b = border[ib];
+                bool skip, lr;
+                int ncols, ra, rb, sa, sb;
+                leaf_spans(b, skip, lr, ncols, ra, rb, sa, sb);
+                if (skip)
+                    continue;
+                const hmx_leaf &l = XL[b];
+                for (int r = ra; r < rb; r++) {
+                    int64_t &q = lr ? q_elr : q_ed;
+                    (lr ? elr_b : ed_b)[q] = (int32_t)b;
+                    (lr ? elr_r : ed_r)[q] = r;
+                    (lr ? elr_c : ed_c)[q] = P.ecnt[r];
+                    q++;
+                    P.ecnt[r] += ncols;
+                }
+                if (lr) {
+                    aoff[b] = a_run;
+                    a_run += l.rank;
+                    ns_of[b]   = sb - sa;
+                    s_first[b] = sa;
+                    if (sb - sa > 1) {
+                        poff[b] = p_run;
+                        p_run += (int64_t)(sb - sa) * l.rank;
+                    }
+                    for (int r = sa; r < sb; r++) {
+                        rlr_b[q_rlr] = (int32_t)b;
+                        rlr_r[q_rlr] = r;
+                        rlr_c[q_rlr] = P.rcnt[r];
+                        q_rlr++;
+                        P.rcnt[r] += l.rank;
+                    }
+                }
             }
-            for (int r = sa; r < sb; r++) {
-                rlr_b.push_back((int32_t)b);
-                rlr_r.push_back(r);
-                rlr_c.push_back(R.cols[r]);
-                R.cols[r] += l.rank;
-            }
-            if (b < nb_real) { // statistics describe the stored leaves (htool's definitions), not the mirrored copies
-                H.stats.n_lowrank++;
-                H.stats.cgen_lowrank += (int64_t)l.rank * (l.t_size + l.s_size);
-                H.stats.rank_min = std::min(H.stats.rank_min, l.rank);
-                H.stats.rank_max = std::max(H.stats.rank_max, l.rank);
-                rank_sum += l.rank;
-            }
-        } else if (b < nb_real) {
-            H.stats.n_dense++;
-            H.stats.cgen_dense += (int64_t)l.t_size * l.s_size;
-        }
+        });
     }
     if (H.stats.n_lowrank == 0)
         H.stats.rank_min = 0;
