@@ -1374,7 +1374,11 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     const bool use_mfma = false; // complex groups stay on the VALU kernels, at most 8 right-hand sides per pass (registers, LDS)
     constexpr int GMAX  = 8;
 #else
-    const bool mfma_ok  = sizeof(scalar) == 8 || (getenv("HMX_MFMA_F32") && atoi(getenv("HMX_MFMA_F32")));
+    // Round 3, with the stream tiles staged through LDS (HMX_MFMA_STAGE, the default): fp32 groups of 16 go to the matrix cores as well --
+    // N = 1e6, eps = 1e-4 (mean rank 8.9): 2.16 against 2.14 ms, config 5 (N = 4e6, eps = 1e-6, mean rank 14.3) 15.9 against 17.8 ms,
+    // its per-rank share of an 8-GPU run 2.30 against 2.38 ms (gpurun_out/r3_ab_cfg5.log).  HMX_MFMA_F32=0: VALU kernels for fp32.
+    static const int stage_default = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;
+    const bool mfma_ok  = sizeof(scalar) == 8 || (getenv("HMX_MFMA_F32") ? atoi(getenv("HMX_MFMA_F32")) != 0 : stage_default != 0);
     const bool use_mfma = mfma_ok && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")));
     constexpr int GMAX  = 16;
 #endif

@@ -2038,13 +2038,15 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, in
         __builtin_amdgcn_wave_barrier();
         const scalar *col = E + (int64_t)c0 * len + row;
         int j = 0;
-        for (; j + 8 <= nc; j += 8) {
-            scalar v[8];
+        // columns in flight per wave: 16 for 4-byte coefficients (a wave's load is only 256 bytes then), 8 otherwise -- as in expand_kernel
+        constexpr int EU = sizeof(scalar) == 4 ? 16 : 8;
+        for (; j + EU <= nc; j += EU) {
+            scalar v[EU];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < EU; u++)
                 v[u] = stream_load(col + (int64_t)(j + u) * len);
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < EU; u++)
 #pragma unroll
                 for (int c = 0; c < MU; c++)
                     acc[c] = hmx_fma(v[u], zt[wv][j + u][c], acc[c]);
@@ -2110,13 +2112,14 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mus_kernel(ReduceArgs A, i
     for (int c = 0; c < MU; c++)
         a0[c] = a1[c] = scalar(0);
     int i = 0;
-    for (; i + 4 <= len; i += 4) {
-        scalar2 v[4];
+    constexpr int RU = sizeof(scalar2) <= 8 ? 8 : 4; // rows in flight: a wave's load of 4-byte pairs is at most 512 bytes
+    for (; i + RU <= len; i += RU) {
+        scalar2 v[RU];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < RU; u++)
             v[u] = load_pair(src + (int64_t)(i + u) * wp, col0, col1, wp);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < RU; u++) {
             uniform_ptr xr = xs + (int64_t)(i + u) * mu;
 #pragma unroll
             for (int c = 0; c < MU; c++) {
