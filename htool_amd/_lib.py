@@ -131,6 +131,7 @@ SYMBOLS = [
     ("hmx_dist_matmat_row_major_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     ("hmx_dist_matmat_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_dist_matmat_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    ("hmx_dist_gmv", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     ("hmx_dist_set_output_collective", C.c_int, [_vp, C.c_int]),
     ("hmx_dist_set_profiling", C.c_int, [_vp, C.c_int]),
     ("hmx_dist_last_exchange_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

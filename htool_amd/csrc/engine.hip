@@ -1130,6 +1130,16 @@ __global__ void dist_rm_to_cm_kernel(int n, int mu, const int32_t *perm, int bas
         cm[(int64_t)(perm ? perm[i] - base : i) + ld * c] = rm[e];
     }
 }
+template <typename E>
+__global__ void dist_zero_tail_kernel(E *out, int64_t ld, int first, int rows, int mu) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (int64_t)rows * mu) {
+        const int c = (int)(e / rows), i = (int)(e - (int64_t)c * rows);
+        E z;
+        memset(&z, 0, sizeof(E));
+        out[(int64_t)c * ld + first + i] = z;
+    }
+}
 static int dist_cm_to_rm(hmx_dist &D, int n, int mu, const int32_t *perm, int base, const void *cm, int64_t ld, void *rm, hipStream_t st) {
     const int64_t t = (int64_t)n * mu;
     if (t == 0)
@@ -1731,6 +1741,58 @@ int hmx_dist_matmat_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
     if (rc != HMX_OK)
         return rc;
     return dist_rm_to_cm(D, nout, mu, pout, out_off, D.cm_out.d, Y_local, nout, st);
+}
+
+// HPDDMOperator::GMV (wrappers/wrapper_hpddm.hpp:102-142) up to HPDDM's own overlap exchange: `in` and `out` are column-major with
+// leading dimension `dof` (the local size INCLUDING the overlap HPDDM keeps behind the first local_size rows), mu columns.  As there:
+// the first local_size rows of every column are brought to the row-major layout (:108-116), the local-to-local product with alpha = 1,
+// beta = 0 runs (vector kernel for mu = 1, :118-125), the result is transposed back and rows [local_size, dof) of every column of `out`
+// are set to zero (:128-138).  The caller then does what GMV does last: this->exchange(out, mu).
+int hmx_dist_gmv(hmx_dist *Dp, const void *in, void *out, int mu, int dof, void *stream) {
+    if (!Dp || !in || !out || mu < 1) {
+        set_error("hmx_dist_gmv: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D    = *Dp;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_in = D.s_size[D.rank], n_out = D.t_size[D.rank];
+    if (n_in != n_out || dof < n_out) {
+        set_error("hmx_dist_gmv: GMV works on one local size (square operator, same partition on both sides) and dof >= local size");
+        return HMX_ERR_INVALID;
+    }
+    const size_t e = D.esz * (size_t)mu;
+    if (D.cm_in.n < (size_t)n_in * e)
+        HMX_HIP(D.cm_in.alloc((size_t)n_in * e));
+    if (D.cm_out.n < (size_t)n_out * e)
+        HMX_HIP(D.cm_out.alloc((size_t)n_out * e));
+    int rc = HMX_OK;
+    const void *xin = in;
+    if (mu != 1) {
+        rc = dist_cm_to_rm(D, n_in, mu, nullptr, 0, in, dof, D.cm_in.d, st);
+        if (rc != HMX_OK)
+            return rc;
+        xin = D.cm_in.d;
+    }
+    rc = mu == 1 ? hmx_dist_matvec_local_to_local(Dp, 'N', dist_one(D), xin, dist_zero(D), D.cm_out.d, stream)
+                 : hmx_dist_matmat_row_major_local_to_local(Dp, 'N', dist_one(D), xin, dist_zero(D), D.cm_out.d, mu, stream);
+    if (rc != HMX_OK)
+        return rc;
+    rc = dist_rm_to_cm(D, n_out, mu, nullptr, 0, D.cm_out.d, out, dof, st);
+    if (rc != HMX_OK)
+        return rc;
+    const int tail = dof - n_out;
+    if (tail > 0) {
+        const int64_t t = (int64_t)tail * mu;
+        const dim3 g((unsigned)((t + 255) / 256)), b(256);
+        if (D.esz == 4)
+            hipLaunchKernelGGL(dist_zero_tail_kernel<float>, g, b, 0, st, (float *)out, (int64_t)dof, n_out, tail, mu);
+        else if (D.esz == 8)
+            hipLaunchKernelGGL(dist_zero_tail_kernel<double>, g, b, 0, st, (double *)out, (int64_t)dof, n_out, tail, mu);
+        else
+            hipLaunchKernelGGL(dist_zero_tail_kernel<double2>, g, b, 0, st, (double2 *)out, (int64_t)dof, n_out, tail, mu);
+        HMX_HIP(hipGetLastError());
+    }
+    return HMX_OK;
 }
 
 double hmx_device_malloc_seconds(void) { return 1e-9 * (double)g_malloc_ns.load(); }

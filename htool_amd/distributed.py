@@ -631,6 +631,13 @@ class NativeDistributedOperator:
         check(self._L.hmx_dist_matmat_row_major_local_to_local(self._h, trans.encode(), pa, C.c_void_p(X_loc.data_ptr()), pb, C.c_void_p(Y_loc.data_ptr()), int(mu), self._stream(Y_loc)))
         return Y_loc
 
+    def gmv(self, x, y, mu, dof):
+        """hmx_dist_gmv: HPDDMOperator::GMV's body (wrappers/wrapper_hpddm.hpp:102-142) without HPDDM's overlap exchange.  x, y: 1-D device
+        tensors of dof * mu coefficients, column-major with leading dimension dof."""
+        from ._lib import check
+        check(self._L.hmx_dist_gmv(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), int(mu), int(dof), self._stream(y)))
+        return y
+
     @staticmethod
     def _column_major(M, name):
         """(pointer, mu) of a column-major n x mu device matrix: a 1-D tensor (mu = 1) or the transpose of a contiguous mu x n tensor."""
@@ -746,6 +753,24 @@ def internal_add_distributed_operator_matrix_product_row_major_local_to_local(tr
                 op.add_matrix_product_row_major(trans, alpha, X_loc, 1.0, buf, mu)
             Y_loc.add_(A._reduce_scatter_slices(buf, out_part))
     return Y_loc
+
+
+def hpddm_gmv(A, x, y, mu, dof):
+    """HPDDMOperator::GMV (wrappers/wrapper_hpddm.hpp:102-142) up to HPDDM's own overlap exchange, over the torch.distributed layer:
+    x, y are 1-D tensors of dof * mu coefficients, column-major with leading dimension dof (local size + overlap); the first local_size
+    rows of every column go through the local-to-local product (alpha = 1, beta = 0), the overlap rows of y are zeroed."""
+    n = A.target_partition.get_size_of_partition(A.rank())
+    X, Y = x.view(mu, dof), y.view(mu, dof)
+    if mu == 1:
+        out = torch.zeros(n, dtype=y.dtype, device=y.device)
+        internal_add_distributed_operator_vector_product_local_to_local("N", 1.0, A, X[0, :n].contiguous(), 0.0, out)
+        Y[0, :n] = out
+    else:
+        out = torch.zeros((n, mu), dtype=y.dtype, device=y.device)
+        internal_add_distributed_operator_matrix_product_row_major_local_to_local("N", 1.0, A, X[:, :n].t().contiguous(), 0.0, out, mu)
+        Y[:, :n] = out.t()
+    Y[:, n:] = 0
+    return y
 
 
 def _rows_by_mu(M):

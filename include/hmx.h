@@ -329,6 +329,13 @@ typedef enum { HMX_NUMBERING_PARTITION = 0, HMX_NUMBERING_USER = 1 } hmx_numberi
 int hmx_dist_matmat_global_to_global(hmx_dist *, char trans, const void *alpha, const void *X, const void *beta, void *Y, int mu, int numbering, void *stream);
 int hmx_dist_matmat_local_to_local(hmx_dist *, char trans, const void *alpha, const void *X_local, const void *beta, void *Y_local, int mu, int numbering, void *stream);
 
+/* HPDDMOperator::GMV (wrappers/wrapper_hpddm.hpp:102-142), the body of the Krylov-side callback up to HPDDM's own overlap exchange:
+ * `in` / `out` are DEVICE pointers, column-major with leading dimension `dof` (HPDDM's local size including the overlap that follows the
+ * first local_size rows), mu columns.  The first local_size rows of every column are transposed to the row-major layout (:108-116), the
+ * local-to-local product with alpha = 1, beta = 0 runs (:118-125), the result is transposed back and rows [local_size, dof) of `out`
+ * are zeroed (:128-138).  What remains for the caller is GMV's last statement, this->exchange(out, mu). */
+int hmx_dist_gmv(hmx_dist *, const void *in, void *out, int mu, int dof, void *stream);
+
 /* Overlap of the output exchange with the computation ("all via RCCL on a side HIP stream; overlap by chunking the
  * output range").  chunks >= 2: the expand stage of a trans = 'N' global-to-global product runs in that many row chunks on the
  * caller's stream; an event after each chunk hands its rows to a side stream, where they are exchanged (grouped ncclBroadcast,

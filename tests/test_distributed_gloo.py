@@ -371,6 +371,24 @@ def run_distprod_families(A, rank, world, g, p, mk, native=None):
                 yl = mk(y0[off:off + sz].copy())
                 native.matmat_local_to_local(t, alpha, mk(xin[off:off + sz].copy()), beta, yl, user_numbering=True)
                 errs["native_l2l_user_" + t] = rel_err(yl.cpu().numpy(), ref("l2l_user_" + t, rank))
+    # HPDDMOperator::GMV's body (wrappers/wrapper_hpddm.hpp:102-142): column-major with leading dimension dof = local size + overlap,
+    # alpha = 1, beta = 0, overlap rows of the output zeroed; expected = the reference's beta = 0 row-major product / alpha
+    dof = sz + 7
+    want = ref("l2l_rm_beta0_N", rank) / alpha
+    for m_ in (mu, 1):
+        xg = np.zeros((m_, dof), dtype=X.dtype)
+        xg[:, :sz] = X[off:off + sz, :m_].T
+        for name, fn in (("gmv_mu%d" % m_, lambda x_, y_: D.hpddm_gmv(A, x_, y_, m_, dof)),) + ((("native_gmv_mu%d" % m_, lambda x_, y_: native.gmv(x_, y_, m_, dof)),) if native is not None else ()):
+            yg = mk(np.full(m_ * dof, 7.0, dtype=X.dtype))
+            fn(mk(xg.ravel().copy()), yg)
+            Yg = yg.cpu().numpy().reshape(m_, dof)
+            if m_ == mu:
+                errs[name] = rel_err(Yg[:, :sz].T, want)
+            else:  # mu = 1: the vector kernel; compare with column 0 of a separate single-vector product
+                y1 = mk(np.zeros(sz, dtype=X.dtype))
+                D.internal_add_distributed_operator_vector_product_local_to_local("N", 1.0, A, mk(np.ascontiguousarray(X[off:off + sz, 0])), 0.0, y1)
+                errs[name] = rel_err(Yg[0, :sz], y1.cpu().numpy())
+            assert not Yg[:, sz:].any(), name + ": overlap rows of the output must be zero"
     # sub product: the rows of one partition after the other, accumulating (as solvers/geneo/coarse_operator_builder.hpp:99 calls it);
     # then a range that overlaps the partitions partially, mu = 1
     Yl = mk(np.ascontiguousarray(Y0[off:off + sz]))
