@@ -350,6 +350,14 @@ MOCK_SCRIPT = textwrap.dedent('''
             [t.join() for t in th]
             assert not fails, fails
             assert max(errs) < 1e-12, (np.dtype(dtype).name, "column-major g2g", trans, errs)
+        # error behaviour of the front ends: the local USER numbering needs a permutation that is local to the partitions
+        # (cluster_node.hpp:126,138 log exactly this); create_cluster_tree with several partitions does not give one.  Refused before
+        # anything is exchanged, so one rank may ask alone.
+        dxe, dye = dev(np.ascontiguousarray(X[:int(parts[0][1])])), dev(np.ascontiguousarray(Y0[:int(parts[0][1])]))
+        rc = L.hmx_dist_matmat_local_to_local(Ds[0], b"N", pa, dxe, pb, dye, mu, 1, None)
+        assert rc == -1 and b"not local" in L.hmx_last_error(), (rc, L.hmx_last_error())
+        assert L.hmx_dist_matmat_global_to_global(Ds[0], b"N", pa, dxe, pb, dye, mu, 7, None) == -1  # no such numbering
+        assert L.hmx_dist_gmv(Ds[0], dxe, dye, mu, int(parts[0][1]) - 1, None) == -1                  # dof below the local size
         # a DistributedOperator with BOTH kinds of operators (distributed_operator.hpp:47-53): the rank's block rows as global-to-local
         # operator plus its block-diagonal H-matrix as local-to-local operator -- every product is the sum of the two operators' products
         Hdiag = [tb.build(gen, T, T, dtype=dtype, local_partitions=(k, k)) for k in range(WORLD)]
