@@ -544,7 +544,8 @@ static int build_streams(HMat &H) {
     H.n_win = H.n_win_groups = 0;
     H.win_off.clear();
     H.win_len.clear();
-    if (tree_pieces && SR_MAX <= WIN_ROWS && !R.task_range.empty() && !(getenv("HMX_MU_WINDOW") && !atoi(getenv("HMX_MU_WINDOW")))) {
+    // (the window lists are only built when the window kernels are asked for, HMX_MU_WINDOW=1: the staged matrix-core kernels are the default)
+    if (tree_pieces && SR_MAX <= WIN_ROWS && !R.task_range.empty() && getenv("HMX_MU_WINDOW") && atoi(getenv("HMX_MU_WINDOW"))) {
         std::vector<std::pair<int32_t, int32_t>> wins; // (root-local offset, rows)
         {
             std::vector<std::pair<int, int>> stack; // (node, parent size)
@@ -1309,7 +1310,7 @@ static bool mu_scalar_operands(bool reduce_stage) {
 static bool mu_window(const HMat &H, bool mfma) {
     if (H.n_win_groups <= 0)
         return false;
-    const char *e = getenv("HMX_MU_WINDOW");
+    const char *e = getenv("HMX_MU_WINDOW"); // the layout builds the window lists only when this is set to 1
     // measured at N = 1e6 (tools/ab_mu.sh, gpurun_out/r3_ab_mu*): fp64 mu = 16 on the matrix cores 1.68 against 1.75 ms, and the expand
     // stage that follows gains another 0.1 ms; the VALU form loses (complex double mu = 8: 3.07 against 2.63 ms, fp32 mu = 16: 1.08
     // against 0.80 ms with the scalar-operand kernel) -- its operand reads come from the same LDS pipe either way
