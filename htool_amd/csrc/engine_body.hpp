@@ -1394,6 +1394,15 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         }
     };
     for_groups([&](int g, int c) {
+#if HMX_COMPLEX
+        // groups of 8 complex right-hand sides: two real MFMAs per complex tile, stream tiles staged through LDS (HMX_NO_MFMA=1: VALU kernels)
+        if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
+            if (RA.ntasks > 0)
+                hipLaunchKernelGGL((reduce_zmfma8s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
+            prof_mark(H, st, "reduce_zmfma8s_kernel");
+            return;
+        }
+#endif
 #if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
             // stream tile through LDS (whole-row loads, HMX_MFMA_STAGE=1: the default) | window of X in LDS (HMX_MU_WINDOW=1) | neither
@@ -1431,6 +1440,14 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         prof_mark(H, st, "combine_mu_kernel");
     }
     for_groups([&](int g, int c) {
+#if HMX_COMPLEX
+        if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
+            if (XA.nranges > 0)
+                hipLaunchKernelGGL((expand_zmfma8s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
+            prof_mark(H, st, "expand_zmfma8s_kernel");
+            return;
+        }
+#endif
 #if !HMX_COMPLEX
         if (g == 16 && use_mfma) {
             // groups of sibling row ranges with the shared operand rows staged once (HMX_MU_GROUPS=0: one workgroup per range)

@@ -2749,6 +2749,207 @@ __global__ __launch_bounds__(WAVES *WAVE, 4) void reduce_win_mfma16_kernel(Reduc
 
 #endif // !HMX_COMPLEX
 
+#if HMX_COMPLEX
+// ---------------------------------------------------------------------------------------------
+// Groups of 8 COMPLEX right-hand sides on the matrix cores (matrix/linalg/add_matrix_matrix_product_row_major.hpp:49-84,113-139: the
+// complex gemm of the leaf products).  A row of 8 complex operands is 16 reals (re0, im0, re1, im1, ...): with n = 2 rhs + part as the
+// MFMA's free index,
+//     [Y_re | Y_im interleaved] += E_re * Z  +  E_im * Z',        Z'[n] = n even ? -Z[n + 1] : Z[n - 1]
+// i.e. TWO real 16x16x4 MFMAs per complex tile; Z' is the operand register of the neighbouring lane (DPP quad_perm [1,0,3,2]) with the
+// sign of the even lanes flipped, and the accumulator rows come out as interleaved complex numbers.  The stream tiles are staged through
+// LDS as in expand_mfma16s_kernel / reduce_mfma16s_kernel (whole-column / whole-row loads, the next step in flight), real and imaginary
+// parts in two planes.
+// ---------------------------------------------------------------------------------------------
+typedef Acc4<real>::type zacc4;
+__device__ __forceinline__ real zmfma_swapped(real b, int lane) {
+    const real o = hmx_shfl_xor(b, 1);
+    return (lane & 1) ? o : -o;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs A, int mu, int cbase) {
+    constexpr int PITCH = 80, STEP = 8; // 8 columns per step: two planes of 8 x 80 reals per wave
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 2 * STEP * PITCH > WAVES * WAVE * 16 ? WAVES * 2 * STEP * PITCH : WAVES * WAVE * 16];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4;
+    real(*tre)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 2 * STEP * PITCH);
+    real(*tim)[PITCH] = tre + STEP;
+    const int row     = lane < len ? lane : len - 1;
+    zacc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = zacc4{0, 0, 0, 0};
+    auto load_cols = [&](scalar(&v)[STEP], int c) {
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            const int col = c + u < C ? c + u : C - 1;
+            v[u]          = stream_load(E + (int64_t)col * len + row);
+        }
+    };
+    auto operands = [&](real(&b)[2], real(&bs)[2], int c, int zi, int base) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int zc   = __shfl(zi, base + 4 * g + kk, WAVE);
+            const real *zr = reinterpret_cast<const real *>(expand_operand(A, zc, mu) + cbase);
+            const real bv  = (c + 4 * g + kk < C) ? zr[m] : real(0);
+            b[g]           = bv;
+            bs[g]          = zmfma_swapped(bv, lane);
+        }
+    };
+    auto apply = [&](const scalar(&v)[STEP], const real(&b)[2], const real(&bs)[2]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            tre[u][lane] = v[u].re;
+            tim[u][lane] = v[u].im;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                acc[t] = mfma16(tre[4 * g + kk][16 * t + m], b[g], acc[t]);
+                acc[t] = mfma16(tim[4 * g + kk][16 * t + m], bs[g], acc[t]);
+            }
+    };
+    // wave w takes the 64-column tiles w, w + WAVES, ...; inside a tile eight steps of 8 columns, loads one step ahead
+    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
+        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
+        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        scalar v0[STEP], v1[STEP];
+        real b0[2], s0[2], b1[2], s1[2];
+        load_cols(v0, t0);
+        operands(b0, s0, t0, zi, 0);
+        for (int c = t0; c < tend; c += 2 * STEP) {
+            if (c + STEP < tend) {
+                load_cols(v1, c + STEP);
+                operands(b1, s1, c + STEP, zi, c + STEP - t0);
+            }
+            apply(v0, b0, s0);
+            if (c + 2 * STEP < tend) {
+                load_cols(v0, c + 2 * STEP);
+                operands(b0, s0, c + 2 * STEP, zi, c + 2 * STEP - t0);
+            }
+            if (c + STEP < tend)
+                apply(v1, b1, s1);
+        }
+    }
+    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, real column l & 15 = 2 rhs + part): stage as [row][16 reals]
+    real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 8; e += WAVES * WAVE) {
+        const int i = e >> 3, c = e & 7;
+        scalar s(red[0][i][2 * c], red[0][i][2 * c + 1]);
+#pragma unroll
+        for (int w = 1; w < WAVES; w++)
+            s += scalar(red[w][i][2 * c], red[w][i][2 * c + 1]);
+        scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs A, int mu, int cbase) {
+    constexpr int PITCH = 144, STEP = 4; // 4 rows per step (one MFMA k-step): two planes of 4 x 144 reals per wave
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 2 * STEP * PITCH];
+    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES + wv;
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp      = hmx_wp(w);
+    const int ntile   = (w + 15) >> 4; // <= 8 column tiles of 16
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const real *xs    = reinterpret_cast<const real *>(A.x + (int64_t)A.range_off[S] * mu + cbase);
+    const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, real column m = 2 rhs + part
+    real(*tre)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 2 * STEP * PITCH);
+    real(*tim)[PITCH] = tre + STEP;
+    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+    zacc4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        acc[t] = zacc4{0, 0, 0, 0};
+    auto load_rows = [&](scalar2(&v)[STEP], int i0) {
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            const int row = i0 + u < len ? i0 + u : len - 1;
+            v[u]          = load_pair(src + (int64_t)row * wp, col0, col1, wp);
+        }
+    };
+    auto operands = [&](real &b, real &bs, int i0) {
+        const int row = i0 + kk;
+        const real bv = xs[(int64_t)(row < len ? row : len - 1) * 2 * mu + m];
+        b             = row < len ? bv : real(0);
+        bs            = zmfma_swapped(b, lane);
+    };
+    auto apply = [&](const scalar2(&v)[STEP], real b, real bs) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            if (col0 < wp) {
+                tre[u][col0] = v[u].x.re;
+                tim[u][col0] = v[u].x.im;
+            }
+            if (col1 < wp) {
+                tre[u][col1] = v[u].y.re;
+                tim[u][col1] = v[u].y.im;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (t < ntile) {
+                acc[t] = mfma16(tre[kk][16 * t + m], b, acc[t]);
+                acc[t] = mfma16(tim[kk][16 * t + m], bs, acc[t]);
+            }
+    };
+    scalar2 v0[STEP], v1[STEP];
+    real b0, s0, b1, s1;
+    load_rows(v0, 0);
+    operands(b0, s0, 0);
+    for (int i0 = 0; i0 < len; i0 += 2 * STEP) {
+        if (i0 + STEP < len) {
+            load_rows(v1, i0 + STEP);
+            operands(b1, s1, i0 + STEP);
+        }
+        apply(v0, b0, s0);
+        if (i0 + 2 * STEP < len) {
+            load_rows(v0, i0 + 2 * STEP);
+            operands(b0, s0, i0 + 2 * STEP);
+        }
+        if (i0 + STEP < len)
+            apply(v1, b1, s1);
+    }
+    const int64_t cb = A.range_colbase[S] + ch * cw;
+    real *Zr         = reinterpret_cast<real *>(A.Z);
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        if (t < ntile)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int col = 16 * t + mfma16_row(real(0), lane, j);
+                if (col < w)
+                    Zr[((int64_t)A.out_idx[cb + col] * mu + cbase) * 2 + m] = acc[t][j];
+            }
+}
+#endif // HMX_COMPLEX
+
 // ---------------------------------------------------------------------------------------------
 // Transposed / mirrored passes (trans = 'T', and the symmetric mirror pass
 // add_hmatrix_vector_product.hpp:97-103,154-163).  Same streams, read in the "wrong" orientation:

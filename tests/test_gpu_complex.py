@@ -140,6 +140,47 @@ def test_complex_against_oracle_other_size(sym, uplo, trans_list, mu):
             assert rel_err(Y, Ho.matmat_row_major(X, trans, alpha, beta, Y0)) < 1e-11
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-5)])
+def test_eight_complex_rhs_on_the_matrix_cores(dtype, tol, monkeypatch):
+    """Groups of 8 complex right-hand sides run as two real MFMAs per complex tile (expand_zmfma8s_kernel / reduce_zmfma8s_kernel:
+    matrix/linalg/add_matrix_matrix_product_row_major.hpp:49-84,113-139 is the reference's complex gemm).  mu = 11 = 8 + 2 + 1 against the
+    CPU oracle on the operator the oracle itself compressed (complex double; complex float against the VALU kernels, HMX_NO_MFMA=1),
+    trans N / T / C, alpha / beta complex; and the matrix-core kernels are what ran."""
+    from oracle import oracle as O
+    n, eps, mu = 4000, 1e-5, 11
+    x3 = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(80)
+    T = b.create_cluster_tree(n, 3, x3, 2, 2)
+    tb = hm.HMatrixTreeBuilder(eps, 10.0, "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    H = tb.build(hm.InvDistGenerator(3, x3, x3, 1e-5, 1.0, 0.7, -0.4, False), T, T, dtype=dtype)
+    rng = np.random.default_rng(3)
+    alpha, beta = 1.5 - 0.5j, -0.3 + 0.8j
+    Ho = None
+    if dtype == np.complex128:
+        To = O.ClusterTree(x3, 80, 2, 2)
+        Ho = O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=0.7, cim=-0.4, eps=eps, eta=10.0, compressor="partialACA", parallel=True)
+        assert np.array_equal(H.leaf_table(), Ho.leaves)
+    for trans in "NTC":
+        X = (rng.standard_normal((n, mu)) + 1j * rng.standard_normal((n, mu))).astype(dtype)
+        Y0 = (rng.standard_normal((n, mu)) + 1j * rng.standard_normal((n, mu))).astype(dtype)
+        H.set_profiling(True)
+        Y = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, mu)
+        names = [k for k, _ in H.last_kernel_times()]
+        H.set_profiling(False)
+        assert any("zmfma8s" in k for k in names), names
+        if Ho is not None:
+            ref = Ho.matmat_row_major(X, trans, alpha, beta, Y0)
+        else:
+            monkeypatch.setenv("HMX_NO_MFMA", "1")
+            ref = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, ref, mu)
+            monkeypatch.delenv("HMX_NO_MFMA")
+        assert rel_err(Y, ref) < tol, (trans, rel_err(Y, ref))
+
+
 @pytest.mark.parametrize("name", ["ball_n2000_z64_hermU", "ellipse_n3000_z64_symL", "ball_n2000_z64_p2_rank1"])
 def test_complex_upload_download_roundtrip(name, tmp_path):
     """Blocks compressed by the CPU oracle, uploaded through hmx_hmatrix_set_block_*_z, multiplied on the device: equal to
