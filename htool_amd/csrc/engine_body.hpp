@@ -1384,21 +1384,40 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     constexpr int GMAX  = 16;
 #endif
     // stage 1 for every group of right-hand sides, then the partial sums, then stage 2
+    // Groups of right-hand sides, one sweep over the streams each.  The staged matrix-core kernels take RAGGED groups (missing right-hand
+    // sides are zero operands, their results are not stored): 9 ... 15 real right-hand sides are one group of 16 instead of 8 + 4 + 2 + 1
+    // (four sweeps), 5 ... 7 complex ones one group of 8.  fn(kernel width, first column, right-hand sides in the group).
+    // (only the staged kernels know about ragged groups: not with the window / grouped variants switched on)
+    static const int stage_on = (getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1) && !(getenv("HMX_MU_WINDOW") && atoi(getenv("HMX_MU_WINDOW"))) &&
+                                !(getenv("HMX_MU_GROUPS") && atoi(getenv("HMX_MU_GROUPS")) > 0);
+    const bool no_mfma        = getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA"));
+    (void)no_mfma;
     auto for_groups = [&](auto &&fn) {
         int c = 0;
         while (c < mu) {
             const int left = mu - c;
-            const int g    = (left >= 16 && GMAX >= 16) ? 16 : (left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1)));
-            fn(g, c);
-            c += g;
+            int g          = (left >= 16 && GMAX >= 16) ? 16 : (left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1)));
+            int n          = g;
+            // ... and so are 3, 5, 6, 7: one ragged sweep (3.7 ms at N = 1e6 fp64) instead of two or three exact ones (2 + 1: 7.8 ms)
+            const bool odd_tail = left == 3 || (left >= 5 && left < 8);
+#if HMX_COMPLEX
+            if (stage_on && !no_mfma && odd_tail)
+                g = 8, n = left;
+#else
+            if (stage_on && use_mfma && ((left >= 9 && left < 16) || odd_tail))
+                g = 16, n = left;
+#endif
+            fn(g, c, n);
+            c += n;
         }
     };
-    for_groups([&](int g, int c) {
+    for_groups([&](int g, int c, int nrhs) {
+        (void)nrhs;
 #if HMX_COMPLEX
         // groups of 8 complex right-hand sides: two real MFMAs per complex tile, stream tiles staged through LDS (HMX_NO_MFMA=1: VALU kernels)
         if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
             if (RA.ntasks > 0)
-                hipLaunchKernelGGL((reduce_zmfma8s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
+                hipLaunchKernelGGL((reduce_zmfma8s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
             prof_mark(H, st, "reduce_zmfma8s_kernel");
             return;
         }
@@ -1414,7 +1433,7 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
             }
             if (RA.ntasks > 0) {
                 if (staged)
-                    hipLaunchKernelGGL((reduce_mfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
+                    hipLaunchKernelGGL((reduce_mfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
                 else
                     hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
             }
@@ -1439,11 +1458,12 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         hipLaunchKernelGGL(combine_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, mu);
         prof_mark(H, st, "combine_mu_kernel");
     }
-    for_groups([&](int g, int c) {
+    for_groups([&](int g, int c, int nrhs) {
+        (void)nrhs;
 #if HMX_COMPLEX
         if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
             if (XA.nranges > 0)
-                hipLaunchKernelGGL((expand_zmfma8s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
+                hipLaunchKernelGGL((expand_zmfma8s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
             prof_mark(H, st, "expand_zmfma8s_kernel");
             return;
         }
@@ -1462,7 +1482,7 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
             static const int staged = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1; // stream tile through LDS (whole-column loads)
             if (XA.nranges > 0) {
                 if (staged)
-                    hipLaunchKernelGGL((expand_mfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
+                    hipLaunchKernelGGL((expand_mfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
                 else
                     hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
             }

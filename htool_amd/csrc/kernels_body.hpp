@@ -2326,7 +2326,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16_kernel(ExpandArgs A
 // 64 x 16 tile goes through a wave-private LDS buffer (80-element column pitch: the operand reads 16 rows x 4 columns are free of bank
 // conflicts) to reach the lanes in operand layout.  LDS traffic is 16 bytes per streamed 8, a quarter of the pipe.
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs A, int mu, int cbase) {
+__global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs A, int mu, int cbase, int nrhs) {
     constexpr int PITCH = 80; // 64 rows + 16: consecutive tile columns are 32 banks apart, so the 64-bit operand reads (16 rows x 4 columns) do not conflict
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 16 * PITCH > WAVES * WAVE * 16 ? WAVES * 16 * PITCH : WAVES * WAVE * 16];
     const int R = A.order[blockIdx.x];
@@ -2352,8 +2352,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
-            const real bv = expand_operand(A, zc, mu)[cbase + m];
-            b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
+            const real bv = expand_operand(A, zc, mu)[cbase + (m < nrhs ? m : 0)]; // nrhs < 16: a ragged last group, the missing right-hand sides are zeros
+            b[g]          = (c + 4 * g + kk < C && m < nrhs) ? bv : real(0);
         }
     };
     auto apply = [&](const real(&v)[16], const real(&b)[4]) {
@@ -2413,6 +2413,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
     __syncthreads();
     for (int e = threadIdx.x; e < len * 16; e += WAVES * WAVE) {
         const int i = e >> 4, c = e & 15;
+        if (c >= nrhs)
+            continue;
         real s = red[0][i][c];
 #pragma unroll
         for (int w = 1; w < WAVES; w++)
@@ -2589,7 +2591,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
 // with the next eight in flight, and the 8 x 128 tile reaches the lanes in operand layout through a wave-private LDS buffer
 // (144-element row pitch: rows 32 banks apart).
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs A, int mu, int cbase) {
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
     constexpr int PITCH = 144;
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 8 * PITCH];
     const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2623,8 +2625,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int row = i0 + 4 * h + kk;
-            const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + m];
-            b[h]          = row < len ? bv : real(0);
+            const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + (m < nrhs ? m : 0)];
+            b[h]          = (row < len && m < nrhs) ? bv : real(0);
         }
     };
     auto apply = [&](const scalar2 (&v)[8], const real(&b)[2]) {
@@ -2665,7 +2667,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int col = 16 * t + mfma16_row(real(0), lane, j);
-                if (col < w)
+                if (col < w && m < nrhs)
                     A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
             }
 }
@@ -2767,7 +2769,7 @@ __device__ __forceinline__ real zmfma_swapped(real b, int lane) {
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs A, int mu, int cbase) {
+__global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs A, int mu, int cbase, int nrhs) {
     constexpr int PITCH = 80, STEP = 8; // 8 columns per step: two planes of 8 x 80 reals per wave
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 2 * STEP * PITCH > WAVES * WAVE * 16 ? WAVES * 2 * STEP * PITCH : WAVES * WAVE * 16];
     const int R = A.order[blockIdx.x];
@@ -2795,7 +2797,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs 
         for (int g = 0; g < 2; g++) {
             const int zc   = __shfl(zi, base + 4 * g + kk, WAVE);
             const real *zr = reinterpret_cast<const real *>(expand_operand(A, zc, mu) + cbase);
-            const real bv  = (c + 4 * g + kk < C) ? zr[m] : real(0);
+            const real zv  = zr[m < 2 * nrhs ? m : 0]; // nrhs < 8: a ragged last group, the missing right-hand sides are zeros
+            const real bv  = (c + 4 * g + kk < C && m < 2 * nrhs) ? zv : real(0);
             b[g]           = bv;
             bs[g]          = zmfma_swapped(bv, lane);
         }
@@ -2850,6 +2853,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs 
     __syncthreads();
     for (int e = threadIdx.x; e < len * 8; e += WAVES * WAVE) {
         const int i = e >> 3, c = e & 7;
+        if (c >= nrhs)
+            continue;
         scalar s(red[0][i][2 * c], red[0][i][2 * c + 1]);
 #pragma unroll
         for (int w = 1; w < WAVES; w++)
@@ -2860,7 +2865,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs 
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs A, int mu, int cbase) {
+__global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
     constexpr int PITCH = 144, STEP = 4; // 4 rows per step (one MFMA k-step): two planes of 4 x 144 reals per wave
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 2 * STEP * PITCH];
     const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2893,8 +2898,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs 
     };
     auto operands = [&](real &b, real &bs, int i0) {
         const int row = i0 + kk;
-        const real bv = xs[(int64_t)(row < len ? row : len - 1) * 2 * mu + m];
-        b             = row < len ? bv : real(0);
+        const real bv = xs[(int64_t)(row < len ? row : len - 1) * 2 * mu + (m < 2 * nrhs ? m : 0)];
+        b             = (row < len && m < 2 * nrhs) ? bv : real(0);
         bs            = zmfma_swapped(b, lane);
     };
     auto apply = [&](const scalar2(&v)[STEP], real b, real bs) {
@@ -2944,7 +2949,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int col = 16 * t + mfma16_row(real(0), lane, j);
-                if (col < w)
+                if (col < w && m < 2 * nrhs)
                     Zr[((int64_t)A.out_idx[cb + col] * mu + cbase) * 2 + m] = acc[t][j];
             }
 }
