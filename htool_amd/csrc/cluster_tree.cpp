@@ -10,8 +10,12 @@
 // std::sort on the same comparison outcomes, so permutation, radii and centres match bit for bit.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -33,10 +37,33 @@ struct Builder {
     const double *x, *radii, *w;
     ClusterTreeOptions opt;
     std::vector<int32_t> &perm;
-    std::vector<double> key; // projection of point id on the current direction
+    std::vector<double> key; // projection of point id on the current direction (only filled when a slice falls back to the reference's sort)
+    // The points' coordinates in the order of the CURRENT permutation, xs[dim * position + p]: every pass over a cluster (centre, radius,
+    // covariance, projections) then streams contiguous memory instead of gathering x[perm[...]] from all over the array -- below the top
+    // levels that gather was the whole cost of the tree (a slice of 31 250 points touches 2 MB of cache lines spread over 24 MB).
+    // The values and the order they are accumulated in are unchanged, so every node is bit-identical to the gathered form.
+    std::vector<double> xs;
+    // scratch of order_along, one slot per POSITION (slices of one level are disjoint, so the nodes of a level share the arrays): allocated
+    // once -- fresh buffers per call cost the top levels more in page faults than the sort itself
+    typedef std::pair<double, int> KeyPos;
+    std::vector<KeyPos> sk_a, sk_b;
+    std::vector<int32_t> sk_ids;
+    std::vector<double> sk_x;
 
     Builder(int n_, int dim_, const double *x_, const double *r_, const double *w_, const ClusterTreeOptions &o, std::vector<int32_t> &p)
-        : n(n_), dim(dim_), x(x_), radii(r_), w(w_), opt(o), perm(p), key(n_) {}
+        : n(n_), dim(dim_), x(x_), radii(r_), w(w_), opt(o), perm(p) {}
+    void gather_xs(int off, int size) { // after the permutation of a slice was set from outside
+        if (xs.empty()) {
+            xs.resize((size_t)n * dim);
+            sk_a.resize(n);
+            sk_b.resize(n);
+            sk_ids.resize(n);
+            sk_x.resize((size_t)n * dim);
+        }
+        for (int j = off; j < off + size; j++)
+            for (int p = 0; p < dim; p++)
+                xs[(size_t)dim * j + p] = x[(size_t)dim * perm[j] + p];
+    }
 
     // tree_builder.hpp:210-233 -- weighted mean, accumulate j then p, multiply by 1/total
     void centroid(int off, int size, double *c) const {
@@ -45,11 +72,11 @@ struct Builder {
             total += w ? w[perm[off + j]] : 1.0;
         for (int p = 0; p < dim; p++)
             c[p] = 0;
+        const double *xo = xs.data() + (size_t)dim * off;
         for (int j = 0; j < size; j++) {
-            const int id     = perm[off + j];
-            const double wid = w ? w[id] : 1.0;
+            const double wid = w ? w[perm[off + j]] : 1.0;
             for (int p = 0; p < dim; p++)
-                c[p] += wid * x[dim * id + p];
+                c[p] += wid * xo[dim * j + p];
         }
         const double inv = 1.0 / total;
         for (int p = 0; p < dim; p++)
@@ -57,15 +84,31 @@ struct Builder {
     }
     // tree_builder.hpp:236-253 -- max_j( sqrt(|sum u^2|) + radii_j )
     double bounding_radius(int off, int size, const double *c) const {
-        double r = 0;
+        if (size >= psort_min && psort_threads > 1) { // a maximum does not depend on the order it is taken in
+            std::vector<double> part(psort_threads, 0.0);
+            in_chunks(size, [&](int lo, int hi, int t) { part[t] = radius_of(off + lo, hi - lo, c); });
+            return *std::max_element(part.begin(), part.end());
+        }
+        return radius_of(off, size, c);
+    }
+    template <typename F>
+    void in_chunks(int size, F &&body) const {
+        std::vector<std::thread> th;
+        for (int t = 0; t < psort_threads; t++)
+            th.emplace_back([&, t] { body((int)((int64_t)size * t / psort_threads), (int)((int64_t)size * (t + 1) / psort_threads), t); });
+        for (auto &x_ : th)
+            x_.join();
+    }
+    double radius_of(int off, int size, const double *c) const {
+        double r         = 0;
+        const double *xo = xs.data() + (size_t)dim * off;
         for (int j = 0; j < size; j++) {
-            const int id = perm[off + j];
-            double s     = 0;
+            double s = 0;
             for (int p = 0; p < dim; p++) {
-                const double u = x[dim * id + p] - c[p];
+                const double u = xo[dim * j + p] - c[p];
                 s              = s + u * u;
             }
-            r = std::max(r, std::sqrt(std::fabs(s)) + (radii ? radii[id] : 0.0));
+            r = std::max(r, std::sqrt(std::fabs(s)) + (radii ? radii[perm[off + j]] : 0.0));
         }
         return r;
     }
@@ -74,12 +117,12 @@ struct Builder {
     // ComputeLargestExtent (partitioning.hpp:160-193) + solve_EVP_2/3 (misc/evp.hpp:13-159)
     Frame principal_axes(const ClusterNode &c) const {
         double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const double *xo = xs.data() + (size_t)dim * c.offset;
         for (int j = 0; j < c.size; j++) {
-            const int id     = perm[c.offset + j];
-            const double wid = w ? w[id] : 1.0;
+            const double wid = w ? w[perm[c.offset + j]] : 1.0;
             double u[3];
             for (int p = 0; p < dim; p++)
-                u[p] = x[dim * id + p] - c.center[p];
+                u[p] = xo[dim * j + p] - c.center[p];
             for (int p = 0; p < dim; p++)
                 for (int q = 0; q < dim; q++)
                     cov[p + dim * q] += wid * u[p] * u[q];
@@ -208,10 +251,10 @@ struct Builder {
             lo[p] = std::numeric_limits<double>::max();
             hi[p] = std::numeric_limits<double>::min();
         }
+        const double *xo = xs.data() + (size_t)dim * c.offset;
         for (int j = 0; j < c.size; j++) {
-            const int id = perm[c.offset + j];
             for (int p = 0; p < dim; p++) {
-                const double v = x[dim * id + p];
+                const double v = xo[dim * j + p];
                 if (lo[p] > v)
                     lo[p] = v;
                 if (hi[p] < v)
@@ -233,17 +276,99 @@ struct Builder {
 
     // ---- ordering + splitting -----------------------------------------------------------------
     // partitioning.hpp:27-31: sort the slice by projection on `dir` with the unstable std::sort.
+    //
+    // htool sorts the point numbers with a comparator that looks the keys up (`key[a] < key[b]`).  When all keys of the slice are DISTINCT
+    // the ascending order is unique, whatever algorithm produces it: here (key, position) pairs are sorted -- contiguous 16-byte records, in
+    // chunks on several threads + merges for the large slices of the top levels, where few nodes leave most cores idle -- and the permutation
+    // and the ordered coordinates are rewritten from the result.  If two keys compare equal (duplicate points, a degenerate direction) the
+    // outcome of an unstable sort depends on its comparison sequence, and the slice is sorted again exactly as the reference does it.
     void order_along(int off, int size, const double *dir) {
-        for (int j = 0; j < size; j++) {
-            const int id = perm[off + j];
-            double c     = 0.0;
-            for (int p = 0; p < dim; p++)
-                c = c + x[dim * id + p] * dir[p];
-            key[id] = c;
+        if (size <= 0)
+            return;
+        const bool wide = size >= psort_min && psort_threads > 1;
+        KeyPos *a       = sk_a.data() + off;
+        const double *xo = xs.data() + (size_t)dim * off;
+        auto keys        = [&](int lo, int hi, int) {
+            for (int j = lo; j < hi; j++) {
+                double c = 0.0;
+                for (int p = 0; p < dim; p++)
+                    c = c + xo[dim * j + p] * dir[p];
+                a[j] = KeyPos(c, j);
+            }
+        };
+        if (wide)
+            in_chunks(size, keys);
+        else
+            keys(0, size, 0);
+        auto by_key = [](const KeyPos &u, const KeyPos &v) { return u.first < v.first; };
+        if (wide) {
+            const int nt = std::max(2, std::min(psort_threads, size / std::max(1, psort_min / 4)));
+            std::vector<int> cut(nt + 1);
+            for (int t = 0; t <= nt; t++)
+                cut[t] = (int)((int64_t)size * t / nt);
+            {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; t++)
+                    th.emplace_back([&, t] { std::sort(a + cut[t], a + cut[t + 1], by_key); });
+                for (auto &x_ : th)
+                    x_.join();
+            }
+            KeyPos *src = a, *dst = sk_b.data() + off;
+            for (int width = 1; width < nt; width *= 2) { // rounds of pairwise merges into the other buffer, the pairs of a round in parallel
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; t += 2 * width)
+                    th.emplace_back([&, t, src, dst] {
+                        const int lo = cut[t], mid = cut[std::min(t + width, nt)], hi = cut[std::min(t + 2 * width, nt)];
+                        std::merge(src + lo, src + mid, src + mid, src + hi, dst + lo, by_key);
+                    });
+                for (auto &x_ : th)
+                    x_.join();
+                std::swap(src, dst);
+            }
+            a = src;
+        } else {
+            std::sort(a, a + size, by_key);
         }
-        const double *k = key.data();
-        std::sort(perm.begin() + off, perm.begin() + off + size, [k](int a, int b) { return k[a] < k[b]; });
+        bool distinct = true;
+        for (int j = 1; j < size && distinct; j++)
+            distinct = a[j - 1].first < a[j].first; // false for equal keys and for unordered ones (NaN)
+        if (!distinct) {                            // the reference's own call decides the order of equal keys
+            std::call_once(key_once, [&] { key.resize(n); });
+            for (int j = 0; j < size; j++) {
+                double c = 0.0;
+                for (int p = 0; p < dim; p++)
+                    c = c + xo[dim * j + p] * dir[p];
+                key[perm[off + j]] = c;
+            }
+            const double *k = key.data();
+            std::sort(perm.begin() + off, perm.begin() + off + size, [k](int u, int v) { return k[u] < k[v]; });
+            gather_xs(off, size);
+            return;
+        }
+        int32_t *ids = sk_ids.data() + off;
+        double *xc   = sk_x.data() + (size_t)dim * off, *xw = xs.data() + (size_t)dim * off;
+        auto save    = [&](int lo, int hi, int) {
+            std::copy(perm.begin() + off + lo, perm.begin() + off + hi, ids + lo);
+            std::copy(xw + (size_t)dim * lo, xw + (size_t)dim * hi, xc + (size_t)dim * lo);
+        };
+        auto rewrite = [&](int lo, int hi, int) {
+            for (int j = lo; j < hi; j++) {
+                const int from = a[j].second;
+                perm[off + j]  = ids[from];
+                for (int p = 0; p < dim; p++)
+                    xw[dim * j + p] = xc[(size_t)dim * from + p];
+            }
+        };
+        if (wide) {
+            in_chunks(size, save);
+            in_chunks(size, rewrite);
+        } else {
+            save(0, size, 0);
+            rewrite(0, size, 0);
+        }
     }
+    int psort_min = 1 << 16, psort_threads = 1;
+    std::once_flag key_once;
     // RegularSplitting (partitioning.hpp:234-249)
     static Parts even_parts(int off, int size, int k) {
         Parts parts(k);
@@ -259,29 +384,29 @@ struct Builder {
         if (size <= k)
             return parts;
         parts.assign(k, {0, 0});
-        auto proj_from = [&](int id, const double *origin) {
+        auto proj_from = [&](int pos, const double *origin) { // pos: position in the permutation
             double s = 0.0;
             for (int p = 0; p < dim; p++)
-                s = s + dir[p] * (x[dim * id + p] - origin[p]);
+                s = s + dir[p] * (xs[(size_t)dim * pos + p] - origin[p]);
             return s;
         };
         double origin[3];
         for (int p = 0; p < dim; p++)
-            origin[p] = x[dim * perm[off] + p];
-        const double span = proj_from(perm[off + size - 1], origin);
+            origin[p] = xs[(size_t)dim * off + p];
+        const double span = proj_from(off + size - 1, origin);
         const double step = span / k;
         int cursor        = off;
         std::vector<int> offs(k, 0), sizes(k, 0);
         for (int p = 0; p < k - 1; p++) {
             int hit = cursor;
-            while (hit < off + size && !(proj_from(perm[hit], origin) > step))
+            while (hit < off + size && !(proj_from(hit, origin) > step))
                 hit++;
             if (hit != n) {
                 offs[p]  = cursor;
                 sizes[p] = hit - cursor;
                 cursor   = hit;
                 for (int q = 0; q < dim; q++)
-                    origin[q] = x[dim * perm[hit] + q];
+                    origin[q] = xs[(size_t)dim * hit + q];
             } else {
                 break;
             }
@@ -414,14 +539,19 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
         set_error("hmx_cluster_tree_create: invalid partition arguments");
         return HMX_ERR_INVALID;
     }
-    T.n   = n;
-    T.dim = dim;
-    T.opt = opt;
+    const auto t_start = std::chrono::steady_clock::now();
+    T.n                = n;
+    T.dim              = dim;
+    T.opt              = opt;
     T.perm.resize(n);
     std::iota(T.perm.begin(), T.perm.end(), 0);
     T.nodes.clear();
     T.on_partition.clear();
     Builder B(n, dim, coords, radii, weights, opt, T.perm);
+    B.psort_threads = std::min(32, (int)std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = std::getenv("HMX_TREE_PSORT_MIN")) // smallest slice handled in chunks on several threads (tests lower it; a huge value disables it)
+        B.psort_min = std::max(2, std::atoi(e));
+    B.gather_xs(0, n);
 
     ClusterNode root;
     root.size = n;
@@ -481,6 +611,7 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
                 return HMX_ERR_INVALID;
             }
             T.permutation_is_local = local;
+            B.gather_xs(0, n); // the permutation now groups the points by part
         }
         level.clear();
         T.nodes[0].first_child = 1;
@@ -502,10 +633,15 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
         if (sp == 1)
             T.permutation_is_local = true; // tree_builder.hpp:143-145
     }
+    const bool level_timing = std::getenv("HMX_BUILD_TIMING") && std::atoi(std::getenv("HMX_BUILD_TIMING"));
+    if (level_timing)
+        fprintf(stderr, "[hmx tree] root, partition: %.1f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+    auto t_level = std::chrono::steady_clock::now();
     while (!level.empty()) {
         // split every node of this level concurrently: slices of the permutation are disjoint
         std::vector<Parts> parts(level.size());
         std::vector<std::vector<ClusterNode>> kids(level.size());
+        B.psort_threads = std::min(32, hw / (int)std::min<size_t>(level.size(), (size_t)hw)); // the cores the level's nodes leave idle
         parallel_for((int)level.size(), hw, [&](int li) {
             const ClusterNode c = T.nodes[level[li]];
             const bool above    = (c.depth == partition_depth - 1);
@@ -535,6 +671,11 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
                 }
             }
         });
+        if (level_timing) {
+            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_level).count();
+            fprintf(stderr, "[hmx tree] level of %zu nodes (%d rows in the first): %.1f ms\n", level.size(), T.nodes[level[0]].size, 1e3 * t);
+            t_level = std::chrono::steady_clock::now();
+        }
         std::vector<int> next;
         for (size_t li = 0; li < level.size(); li++) {
             if (kids[li].empty())

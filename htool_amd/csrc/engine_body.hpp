@@ -217,10 +217,12 @@ static int build_streams(HMat &H) {
         if (XK[b] == LK_LOWRANK && l.rank > 0)
             sclusters.emplace_back(l.s_offset, l.s_size);
     }
+    phase("  copies, breakpoints");
     std::sort(sclusters.begin(), sclusters.end());
     sclusters.erase(std::unique(sclusters.begin(), sclusters.end()), sclusters.end());
     StreamSet &E = H.E, &R = H.R;
     make_ranges(tbp, TR_MAX, H.T0, E.off, E.len);
+    phase("  source clusters, row ranges");
     R.off.clear();
     R.len.clear();
     std::vector<int32_t> scluster_first(sclusters.size() + 1, 0);
@@ -278,6 +280,7 @@ static int build_streams(HMat &H) {
     if (!tree_pieces)
         (void)cut_pieces(false);
     scluster_first[sclusters.size()] = (int32_t)R.off.size();
+    phase("  pieces");
     // position -> range lookup
     std::vector<int32_t> t_pos2range(H.nT + 1, -1);
     for (int r = 0; r < E.nranges(); r++)
@@ -385,6 +388,7 @@ static int build_streams(HMat &H) {
                 }
             }
         });
+        phase("  pair pass 1");
         // exclusive prefix over the parts, per range: ecnt / rcnt become each part's first column
         parallel_for((size_t)nre, [&](size_t lo, size_t hi) {
             for (size_t r = lo; r < hi; r++) {
@@ -428,6 +432,7 @@ static int build_streams(HMat &H) {
         elr_b.resize(o_elr[NT]), elr_r.resize(o_elr[NT]), elr_c.resize(o_elr[NT]);
         ed_b.resize(o_ed[NT]), ed_r.resize(o_ed[NT]), ed_c.resize(o_ed[NT]);
         rlr_b.resize(o_rlr[NT]), rlr_r.resize(o_rlr[NT]), rlr_c.resize(o_rlr[NT]);
+        phase("  prefix, resize");
         run_parts([&](size_t t) {
             Part &P = part[t];
             int64_t q_elr = o_elr[t], q_ed = o_ed[t], q_rlr = o_rlr[t], a_run = o_a[t], p_run = o_p[t];
@@ -740,6 +745,7 @@ static int build_streams(HMat &H) {
         if (phase_timing)
             fprintf(stderr, "[hmx build]   %d groups of %d row ranges (alignment %d): %.1f %% of the E columns in a shared prefix\n", H.n_grp, GW, best_shift, 100 * H.grp_shared_frac);
     }
+    phase("  e index");
     std::vector<int32_t> h_outidx(R.total_cols, 0);
     H.h_r_aidx.assign(R.total_cols, 0);
     H.h_r_mirrorflag.assign(mirror_flags ? R.total_cols : 0, 0);
@@ -756,6 +762,7 @@ static int build_streams(HMat &H) {
             }
         }
     });
+    phase("  r index");
     std::vector<int32_t> cd, cs, cst, cc;
     for (int64_t b = 0; b < nb; b++)
         if (poff[b] >= 0)

@@ -103,6 +103,35 @@ def test_larger_tree_matches_oracle():
         assert np.array_equal(np.stack([a["t_offset"], a["t_size"], a["s_offset"], a["s_size"]], axis=1), Ho.leaves[:, :4])
 
 
+def test_chunked_sort_of_large_slices_gives_the_reference_order(monkeypatch):
+    """The top levels of the tree sort their slices in chunks on several threads (cluster_tree.cpp order_along).  With distinct keys the
+    ascending order is unique; with EQUAL keys (duplicate points, points sharing a coordinate) the slice falls back to the reference's own
+    std::sort call, so the permutation is the same with the chunked path off, at its default threshold and forced onto every slice above
+    2000 points -- and the same as the oracle's restatement of htool."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    n = 150000
+    for ties in (False, True):
+        x = rng.random((n, 3))
+        if ties:
+            x[n // 3:n // 3 + 4000] = x[:4000]
+            x[-3000:, 0] = 0.25
+        got = []
+        for knob in ("1000000000", None, "2000"):
+            if knob is None:
+                monkeypatch.delenv("HMX_TREE_PSORT_MIN", raising=False)
+            else:
+                monkeypatch.setenv("HMX_TREE_PSORT_MIN", knob)
+            b = hm.ClusterTreeBuilder()
+            b.set_maximal_leaf_size(100)
+            T = b.create_cluster_tree(n, 3, x, 2, 2)
+            got.append((np.array(T.get_permutation()), np.array(T.nodes_int()), np.array(T.nodes_real())))
+        for g in got[1:]:
+            assert all(np.array_equal(a, b_) for a, b_ in zip(got[0], g))
+        To = O.ClusterTree(x, 100, 2, 2)
+        assert np.array_equal(got[2][0], To.perm) and np.array_equal(got[2][1], To.nodes_int) and np.array_equal(got[2][2], To.nodes_real)
+
+
 def test_invalid_arguments_are_reported():
     x = hm.create_geometry("disk", 100)
     b = hm.ClusterTreeBuilder()
