@@ -333,7 +333,9 @@ def main():
 
     n = args.n
     t0 = time.time()
-    x = hm.create_geometry(args.geom, n)
+    x = hm.create_geometry(args.geom, n)  # the synthetic input itself: not part of the tree build
+    t_geom = time.time() - t0
+    t0 = time.time()
     ctb = hm.ClusterTreeBuilder()
     ctb.set_maximal_leaf_size(args.leaf)
     # single GPU: HMatrixBuilder's default of 2 partitions (hmatrix/utility.hpp:23), whole operator on the GPU
@@ -382,7 +384,7 @@ def main():
     t_build = time.time() - t0
     t_malloc = hm.lib().hmx_device_malloc_seconds() - malloc0
     st = H.stats()
-    log("cluster tree %.1fs, device build %.1fs (ACA %.2fs, pack+assemble %.2fs): %d dense + %d low-rank leaves, rank %d/%.2f/%d, "
+    log("cluster tree %.2fs, device build %.2fs (ACA %.2fs, pack+assemble %.2fs): %d dense + %d low-rank leaves, rank %d/%.2f/%d, "
         "C_gen %.3e + %.3e, %.2f GB in HBM" % (t_tree, t_build, st["t_compress_s"], st["t_pack_s"], st["n_dense"], st["n_lowrank"],
                                                st["rank_min"], st["rank_mean"], st["rank_max"], st["cgen_dense"], st["cgen_lowrank"],
                                                st["stream_bytes"] / 1e9))
@@ -669,7 +671,7 @@ def main():
                            parallelism=("row-partition x%d + all-gather%s" % (world, ", local kernels replayed from a HIP graph" if graphed else (", hmx_dist_* (C)" if native is not None else ""))) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
-                           build_s=dict(cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
+                           build_s=dict(geometry=t_geom, cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
                roofline=roofline, compress=compress)
     if use_dist:
         out["dist"] = dist_info

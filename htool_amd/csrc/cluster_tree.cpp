@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -42,27 +43,36 @@ struct Builder {
     // covariance, projections) then streams contiguous memory instead of gathering x[perm[...]] from all over the array -- below the top
     // levels that gather was the whole cost of the tree (a slice of 31 250 points touches 2 MB of cache lines spread over 24 MB).
     // The values and the order they are accumulated in are unchanged, so every node is bit-identical to the gathered form.
-    std::vector<double> xs;
+    std::unique_ptr<double[]> xs;
     // scratch of order_along, one slot per POSITION (slices of one level are disjoint, so the nodes of a level share the arrays): allocated
-    // once -- fresh buffers per call cost the top levels more in page faults than the sort itself
-    typedef std::pair<double, int> KeyPos;
-    std::vector<KeyPos> sk_a, sk_b;
-    std::vector<int32_t> sk_ids;
-    std::vector<double> sk_x;
+    // once, not initialised -- fresh (zeroed) buffers per call cost the top levels more in page faults than the sort itself
+    struct KeyPos {
+        double first;
+        int second;
+    };
+    std::unique_ptr<KeyPos[]> sk_a, sk_b;
+    std::unique_ptr<int32_t[]> sk_ids;
+    std::unique_ptr<double[]> sk_x;
 
     Builder(int n_, int dim_, const double *x_, const double *r_, const double *w_, const ClusterTreeOptions &o, std::vector<int32_t> &p)
         : n(n_), dim(dim_), x(x_), radii(r_), w(w_), opt(o), perm(p) {}
     void gather_xs(int off, int size) { // after the permutation of a slice was set from outside
-        if (xs.empty()) {
-            xs.resize((size_t)n * dim);
-            sk_a.resize(n);
-            sk_b.resize(n);
-            sk_ids.resize(n);
-            sk_x.resize((size_t)n * dim);
+        if (!xs) {
+            xs.reset(new double[(size_t)n * dim]);
+            sk_a.reset(new KeyPos[n]);
+            sk_b.reset(new KeyPos[n]);
+            sk_ids.reset(new int32_t[n]);
+            sk_x.reset(new double[(size_t)n * dim]);
         }
-        for (int j = off; j < off + size; j++)
-            for (int p = 0; p < dim; p++)
-                xs[(size_t)dim * j + p] = x[(size_t)dim * perm[j] + p];
+        auto copy = [&](int lo, int hi, int) {
+            for (int j = off + lo; j < off + hi; j++)
+                for (int p = 0; p < dim; p++)
+                    xs[(size_t)dim * j + p] = x[(size_t)dim * perm[j] + p];
+        };
+        if (size >= psort_min && psort_threads > 1)
+            in_chunks(size, copy);
+        else
+            copy(0, size, 0);
     }
 
     // tree_builder.hpp:210-233 -- weighted mean, accumulate j then p, multiply by 1/total
@@ -72,7 +82,7 @@ struct Builder {
             total += w ? w[perm[off + j]] : 1.0;
         for (int p = 0; p < dim; p++)
             c[p] = 0;
-        const double *xo = xs.data() + (size_t)dim * off;
+        const double *xo = xs.get() + (size_t)dim * off;
         for (int j = 0; j < size; j++) {
             const double wid = w ? w[perm[off + j]] : 1.0;
             for (int p = 0; p < dim; p++)
@@ -92,16 +102,19 @@ struct Builder {
         return radius_of(off, size, c);
     }
     template <typename F>
-    void in_chunks(int size, F &&body) const {
+    void in_chunks(int size, F &&body) const { // chunks of at least half the smallest wide slice: a thread costs as much as ~10^4 points
+        const int nt = chunks_of(size);
         std::vector<std::thread> th;
-        for (int t = 0; t < psort_threads; t++)
-            th.emplace_back([&, t] { body((int)((int64_t)size * t / psort_threads), (int)((int64_t)size * (t + 1) / psort_threads), t); });
+        for (int t = 1; t < nt; t++)
+            th.emplace_back([&, t] { body((int)((int64_t)size * t / nt), (int)((int64_t)size * (t + 1) / nt), t); });
+        body(0, (int)((int64_t)size / nt), 0);
         for (auto &x_ : th)
             x_.join();
     }
+    int chunks_of(int size) const { return std::max(1, std::min(psort_threads, size / std::max(1, psort_min / 2))); }
     double radius_of(int off, int size, const double *c) const {
         double r         = 0;
-        const double *xo = xs.data() + (size_t)dim * off;
+        const double *xo = xs.get() + (size_t)dim * off;
         for (int j = 0; j < size; j++) {
             double s = 0;
             for (int p = 0; p < dim; p++) {
@@ -117,7 +130,7 @@ struct Builder {
     // ComputeLargestExtent (partitioning.hpp:160-193) + solve_EVP_2/3 (misc/evp.hpp:13-159)
     Frame principal_axes(const ClusterNode &c) const {
         double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const double *xo = xs.data() + (size_t)dim * c.offset;
+        const double *xo = xs.get() + (size_t)dim * c.offset;
         for (int j = 0; j < c.size; j++) {
             const double wid = w ? w[perm[c.offset + j]] : 1.0;
             double u[3];
@@ -251,7 +264,7 @@ struct Builder {
             lo[p] = std::numeric_limits<double>::max();
             hi[p] = std::numeric_limits<double>::min();
         }
-        const double *xo = xs.data() + (size_t)dim * c.offset;
+        const double *xo = xs.get() + (size_t)dim * c.offset;
         for (int j = 0; j < c.size; j++) {
             for (int p = 0; p < dim; p++) {
                 const double v = xo[dim * j + p];
@@ -286,14 +299,15 @@ struct Builder {
         if (size <= 0)
             return;
         const bool wide = size >= psort_min && psort_threads > 1;
-        KeyPos *a       = sk_a.data() + off;
-        const double *xo = xs.data() + (size_t)dim * off;
+        KeyPos *a       = sk_a.get() + off;
+        const double *xo = xs.get() + (size_t)dim * off;
         auto keys        = [&](int lo, int hi, int) {
             for (int j = lo; j < hi; j++) {
                 double c = 0.0;
                 for (int p = 0; p < dim; p++)
                     c = c + xo[dim * j + p] * dir[p];
-                a[j] = KeyPos(c, j);
+                a[j].first  = c;
+                a[j].second = j;
             }
         };
         if (wide)
@@ -302,7 +316,7 @@ struct Builder {
             keys(0, size, 0);
         auto by_key = [](const KeyPos &u, const KeyPos &v) { return u.first < v.first; };
         if (wide) {
-            const int nt = std::max(2, std::min(psort_threads, size / std::max(1, psort_min / 4)));
+            const int nt = std::max(2, chunks_of(size));
             std::vector<int> cut(nt + 1);
             for (int t = 0; t <= nt; t++)
                 cut[t] = (int)((int64_t)size * t / nt);
@@ -313,7 +327,7 @@ struct Builder {
                 for (auto &x_ : th)
                     x_.join();
             }
-            KeyPos *src = a, *dst = sk_b.data() + off;
+            KeyPos *src = a, *dst = sk_b.get() + off;
             for (int width = 1; width < nt; width *= 2) { // rounds of pairwise merges into the other buffer, the pairs of a round in parallel
                 std::vector<std::thread> th;
                 for (int t = 0; t < nt; t += 2 * width)
@@ -345,8 +359,8 @@ struct Builder {
             gather_xs(off, size);
             return;
         }
-        int32_t *ids = sk_ids.data() + off;
-        double *xc   = sk_x.data() + (size_t)dim * off, *xw = xs.data() + (size_t)dim * off;
+        int32_t *ids = sk_ids.get() + off;
+        double *xc   = sk_x.get() + (size_t)dim * off, *xw = xs.get() + (size_t)dim * off;
         auto save    = [&](int lo, int hi, int) {
             std::copy(perm.begin() + off + lo, perm.begin() + off + hi, ids + lo);
             std::copy(xw + (size_t)dim * lo, xw + (size_t)dim * hi, xc + (size_t)dim * lo);
@@ -510,7 +524,7 @@ struct Builder {
 
 template <typename F>
 void parallel_for(int count, int max_threads, F &&body) {
-    const int nt = std::max(1, std::min(max_threads, count));
+    const int nt = std::max(1, std::min({max_threads, count, 64})); // starting a thread costs ~30 us: 256 of them per level were most of the lower levels' time
     if (nt == 1) {
         for (int i = 0; i < count; i++)
             body(i);
