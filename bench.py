@@ -671,7 +671,8 @@ def main():
                            parallelism=("row-partition x%d + all-gather%s" % (world, ", local kernels replayed from a HIP graph" if graphed else (", hmx_dist_* (C)" if native is not None else ""))) if part else "single GPU",
                            n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
                            algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
-                           build_s=dict(geometry=t_geom, cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"])),
+                           build_s=dict(geometry=t_geom, cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"],
+                                        **{k: round(v, 4) for k, v in getattr(H, "_build_walltimes", {}).items()})),
                roofline=roofline, compress=compress)
     if use_dist:
         out["dist"] = dist_info

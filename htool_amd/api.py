@@ -579,8 +579,10 @@ class HMatrixTreeBuilder:
         prec = [k for k, v in _PREC.items() if np.dtype(v["np"]) == np.dtype(dtype)]
         if not prec:
             raise HmxError("dtype must be float64, float32, complex128 or complex64")
+        t_create = time.perf_counter()
         check(getattr(lib(), "hmx_hmatrix_create" + _PREC[prec[0]]["sfx"])(bt, device, C.byref(h)))
         H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
+        t_create = time.perf_counter() - t_create
         H._tree_parameters = dict(eta=self._eta, epsilon=self._eps, min_target_depth=self._mint, min_source_depth=self._mins)
         H._block_tree_walltime = t_bt
         if isinstance(generator, VirtualGenerator):
@@ -592,12 +594,17 @@ class HMatrixTreeBuilder:
                                "subclass (evaluated on the host through a callback)")
             params = np.array([generator.delta, generator.scale, generator.cre, generator.cim, float(generator.hermitian)], dtype=np.float64)
             check(lib().hmx_hmatrix_set_kernel(h, 0, _dp(params), 5, generator.dim, _dp(generator.xt), _dp(generator.xs)))
+        H._build_walltimes = dict(block_tree=t_bt, create=t_create)
         if compress:
+            t_c = time.perf_counter()
             check(lib().hmx_hmatrix_compress(h, _lib.COMPRESSORS[self._compressor], self._eps, self._reqrank))
             if getattr(generator, "_callback_error", None) is not None:  # raised inside copy_submatrix during the build
                 err, generator._callback_error = generator._callback_error, None
                 raise err
+            H._build_walltimes["compress_call"] = time.perf_counter() - t_c
+            t_c = time.perf_counter()
             H.refresh_leaves()
+            H._build_walltimes["refresh_leaves"] = time.perf_counter() - t_c
             if self._recompressed:
                 H.recompress()
         return H

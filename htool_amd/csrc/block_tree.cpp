@@ -7,7 +7,11 @@
 // preorder (children in creation order), which is also the order of m_admissible_tasks / m_dense_tasks.
 // Integer results are bit-exact with the reference (tests/test_host_structure.py).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <thread>
 
 #include "hmx_host.hpp"
 
@@ -25,6 +29,11 @@ struct Walker {
     hmx_block_tree &bt;
     const hmx_cluster_tree &T, &S;
     std::vector<BNode> arena;
+    // Sub-trees are independent of each other: the first walk stops at recursion depth `defer_depth` (below the partition level, where
+    // all descendants keep their target's rank) and leaves those nodes to be expanded by one walker each, on several threads.
+    int defer_depth = -1;
+    std::vector<int> deferred;        // arena ids, in creation order
+    std::vector<int> depth_of{};      // recursion depth per arena id (only kept while deferring)
 
     explicit Walker(hmx_block_tree &b) : bt(b), T(*b.target), S(*b.source) {}
     const ClusterNode &tn(int v) const { return T.nodes[v]; }
@@ -87,6 +96,14 @@ struct Walker {
     void child(int parent, int t, int s) {
         const int c = make(t, s);
         arena[parent].children.push_back(c);
+        if (defer_depth >= 0) {
+            depth_of.resize(arena.size(), 0);
+            depth_of[c] = depth_of[parent] + 1;
+            if (depth_of[c] >= defer_depth && tn(t).rank >= 0) {
+                deferred.push_back(c);
+                return;
+            }
+        }
         descend(c);
     }
 
@@ -175,9 +192,40 @@ int build_block_tree(hmx_block_tree &bt) {
     const int t_start = bt.target_root_partition >= 0 ? T.on_partition[bt.target_root_partition] : 0;
     const int s_start = bt.source_root_partition >= 0 ? S.on_partition[bt.source_root_partition] : 0;
     Walker W(bt);
+    // a user-supplied admissibility condition is a callback into the caller's code (Python, through ctypes): one thread
+    const int hw      = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int threads = bt.admissibility ? 1 : std::min(hw, 32);
+    if (threads > 1 && (int64_t)T.nodes.size() + (int64_t)S.nodes.size() > 4096)
+        W.defer_depth = 6;
+    if (const char *e = std::getenv("HMX_BT_DEFER_DEPTH")) // tests: sub-trees from this recursion depth on small trees too (-1: one walk)
+        W.defer_depth = bt.admissibility ? -1 : std::atoi(e);
+    if (W.defer_depth >= 0)
+        W.depth_of.assign(1, 0);
     const int root = W.make(t_start, s_start);
     W.arena[root].symmetric = false; // the root is flagged after re-rooting (tree_builder.hpp:408-410)
     W.descend(root);
+    // the deferred sub-trees, each in its own arena
+    std::vector<std::unique_ptr<Walker>> sub(W.deferred.size());
+    std::vector<int> sub_of(W.deferred.empty() ? 0 : W.arena.size(), -1);
+    for (size_t k = 0; k < W.deferred.size(); k++)
+        sub_of[W.deferred[k]] = (int)k;
+    if (!W.deferred.empty()) {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t k = next.fetch_add(1); k < sub.size(); k = next.fetch_add(1)) {
+                sub[k].reset(new Walker(bt));
+                const BNode &b = W.arena[W.deferred[k]];
+                const int r    = sub[k]->make(b.t, b.s);
+                sub[k]->descend(r);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < std::min<int>(std::max(threads, 2), (int)sub.size()); t++)
+            th.emplace_back(work);
+        work();
+        for (auto &x : th)
+            x.join();
+    }
 
     // reset_root_of_block_tree (tree_builder.hpp:533-566): when the root's target cluster is not the
     // requested partition, the new root adopts every node whose target cluster has that rank, in the
@@ -227,30 +275,74 @@ int build_block_tree(hmx_block_tree &bt) {
         int id;
         bool sym_anc;
     };
-    std::vector<Item> stack{{root, W.arena[root].symmetric}};
-    while (!stack.empty()) {
-        const Item it = stack.back();
-        stack.pop_back();
-        const BNode &b = W.arena[it.id];
-        if (b.children.empty()) {
-            if (b.kind == 0)
-                continue; // pruned interior node without leaves
-            const ClusterNode &t = T.nodes[b.t], &s = S.nodes[b.s];
-            hmx_leaf l;
-            l.t_offset   = t.offset;
-            l.t_size     = t.size;
-            l.s_offset   = s.offset;
-            l.s_size     = s.size;
-            l.admissible = b.kind == 1;
-            l.mirror     = (it.sym_anc && t.offset != s.offset) ? 1 : 0;
-            l.symmetric  = b.symmetric ? 1 : 0;
-            l.rank       = b.kind == 1 ? 0 : -1;
-            bt.leaves.push_back(l);
-            continue;
+    // walks one arena from `start`; a deferred node of the first walk is only recorded (position in the list so far + inherited flag)
+    struct Hole {
+        size_t at;
+        int sub;
+        bool sym_anc;
+    };
+    std::vector<Hole> holes;
+    auto emit = [&](const Walker &A, int start, bool start_flag, std::vector<hmx_leaf> &out, bool first_walk) {
+        std::vector<Item> stack{{start, start_flag}};
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            const BNode &b = A.arena[it.id];
+            if (first_walk && !sub_of.empty() && sub_of[it.id] >= 0) {
+                holes.push_back({out.size(), sub_of[it.id], it.sym_anc});
+                continue;
+            }
+            if (b.children.empty()) {
+                if (b.kind == 0)
+                    continue; // pruned interior node without leaves
+                const ClusterNode &t = T.nodes[b.t], &s = S.nodes[b.s];
+                hmx_leaf l;
+                l.t_offset   = t.offset;
+                l.t_size     = t.size;
+                l.s_offset   = s.offset;
+                l.s_size     = s.size;
+                l.admissible = b.kind == 1;
+                l.mirror     = (it.sym_anc && t.offset != s.offset) ? 1 : 0;
+                l.symmetric  = b.symmetric ? 1 : 0;
+                l.rank       = b.kind == 1 ? 0 : -1;
+                out.push_back(l);
+                continue;
+            }
+            for (int c = (int)b.children.size() - 1; c >= 0; c--)
+                stack.push_back({b.children[c], it.sym_anc || b.symmetric});
         }
-        for (int c = (int)b.children.size() - 1; c >= 0; c--)
-            stack.push_back({b.children[c], it.sym_anc || b.symmetric});
+    };
+    if (sub.empty()) {
+        emit(W, root, W.arena[root].symmetric, bt.leaves, false);
+        return HMX_OK;
     }
+    std::vector<hmx_leaf> upper;
+    emit(W, root, W.arena[root].symmetric, upper, true);
+    std::vector<std::vector<hmx_leaf>> part(holes.size());
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t k = next.fetch_add(1); k < holes.size(); k = next.fetch_add(1))
+                emit(*sub[holes[k].sub], 0, holes[k].sym_anc, part[k], false);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < std::min<int>(threads, (int)holes.size()); t++)
+            th.emplace_back(work);
+        work();
+        for (auto &x : th)
+            x.join();
+    }
+    size_t total = upper.size();
+    for (auto &v : part)
+        total += v.size();
+    bt.leaves.reserve(total);
+    size_t done = 0;
+    for (size_t k = 0; k < holes.size(); k++) {
+        bt.leaves.insert(bt.leaves.end(), upper.begin() + done, upper.begin() + holes[k].at);
+        done = holes[k].at;
+        bt.leaves.insert(bt.leaves.end(), part[k].begin(), part[k].end());
+    }
+    bt.leaves.insert(bt.leaves.end(), upper.begin() + done, upper.end());
     return HMX_OK;
 }
 

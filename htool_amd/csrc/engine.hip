@@ -4,6 +4,7 @@
 // There is deliberately NO CPU fallback in this file: every entry point that computes needs a HIP
 // device and reports HMX_ERR_NO_DEVICE / HMX_ERR_HIP otherwise.
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <atomic>
 #include <chrono>
@@ -236,6 +237,24 @@ struct MallocTimer {
     ~MallocTimer() { g_malloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// std::vector whose resize() leaves the new elements uninitialised: the large host index arrays are written completely (by several
+// threads) right after they are sized, and zero-filling 150 MB first costs as much as filling it
+template <typename T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        typedef DefaultInitAlloc<U> other;
+    };
+    template <typename U, typename... Args>
+    void construct(U *p, Args &&...args) {
+        if constexpr (sizeof...(Args) == 0)
+            ::new ((void *)p) U;
+        else
+            ::new ((void *)p) U(std::forward<Args>(args)...);
+    }
+};
+typedef std::vector<int32_t, DefaultInitAlloc<int32_t>> hvec32;
+
 template <typename T>
 struct DArr { // device array with RAII
     T *d        = nullptr;
@@ -297,7 +316,8 @@ struct DArr { // device array with RAII
         }
         return e;
     }
-    hipError_t upload(const std::vector<T> &h) {
+    template <typename A>
+    hipError_t upload(const std::vector<T, A> &h) {
         hipError_t e = alloc(h.size());
         if (e != hipSuccess || h.empty())
             return e;

@@ -92,7 +92,7 @@ struct HMat {
     StreamSet E, R;
     DArr<int32_t> e_zidx, e_zidx_mirror, e_tdst, e_tdst_mirror;
     DArr<int32_t> r_outidx, r_tcoef, r_tcoef_mirror;
-    std::vector<int32_t> h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag;
+    hvec32 h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag;
     DArr<int32_t> c_dst, c_src, c_stride, c_count;
     int n_combine       = 0;
     int64_t A_total     = 0, P_total = 0;
@@ -208,14 +208,48 @@ static int build_streams(HMat &H) {
     // R ranges are per DISTINCT source cluster of the low-rank leaves (cut into pieces of <= SR_MAX rows): a
     // block is reduced over ceil(n/SR_MAX) pieces of its own cluster instead of over every leaf cluster below
     // it, so blocks up to SR_MAX columns need no partial sums at all and the largest ones a few dozen.
-    std::vector<int> tbp{H.T0, H.T0 + H.nT};
+    // row breakpoints: marks over the local rows, read back in order (no sort of 2 x leaves numbers); the distinct source clusters of the
+    // low-rank leaves: sorted + deduplicated per slice of the leaf list on a few threads, then once more over the survivors
+    std::vector<int> tbp;
     std::vector<std::pair<int, int>> sclusters;
-    for (int64_t b = 0; b < nb; b++) {
-        const hmx_leaf &l = XL[b];
-        tbp.push_back(l.t_offset);
-        tbp.push_back(l.t_offset + l.t_size);
-        if (XK[b] == LK_LOWRANK && l.rank > 0)
-            sclusters.emplace_back(l.s_offset, l.s_size);
+    {
+        std::vector<char> mark((size_t)H.nT + 1, 0);
+        mark[0] = mark[H.nT] = 1;
+        std::vector<int> outside;
+        const size_t NS = std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)nb / 32768 + 1});
+        std::vector<std::vector<std::pair<int, int>>> sc(NS);
+        std::vector<std::thread> th;
+        auto slice = [&](size_t t) {
+            auto &v = sc[t];
+            for (int64_t b = nb * (int64_t)t / (int64_t)NS; b < nb * (int64_t)(t + 1) / (int64_t)NS; b++) {
+                const hmx_leaf &l = XL[b];
+                if (XK[b] == LK_LOWRANK && l.rank > 0)
+                    v.emplace_back(l.s_offset, l.s_size);
+            }
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+        };
+        for (size_t t = 1; t < NS; t++)
+            th.emplace_back(slice, t);
+        for (int64_t b = 0; b < nb; b++) { // meanwhile, on this thread
+            const hmx_leaf &l = XL[b];
+            const int64_t lo = (int64_t)l.t_offset - H.T0, hi = lo + l.t_size;
+            if (lo >= 0 && hi <= H.nT)
+                mark[lo] = mark[hi] = 1;
+            else {
+                outside.push_back(l.t_offset);
+                outside.push_back(l.t_offset + l.t_size);
+            }
+        }
+        slice(0);
+        for (auto &x : th)
+            x.join();
+        for (int64_t i = 0; i <= H.nT; i++)
+            if (mark[i])
+                tbp.push_back(H.T0 + (int)i);
+        tbp.insert(tbp.end(), outside.begin(), outside.end());
+        for (auto &v : sc)
+            sclusters.insert(sclusters.end(), v.begin(), v.end());
     }
     phase("  copies, breakpoints");
     std::sort(sclusters.begin(), sclusters.end());
@@ -656,8 +690,8 @@ static int build_streams(HMat &H) {
     phase("bases, task order");
     const int64_t zA = H.nS, zP = H.nS + A_total;
     H.zero_slot      = H.nS + A_total + P_total;
-    H.h_e_zidx.assign(E.total_cols, 0);
-    H.h_e_mirrorflag.assign(mirror_flags ? E.total_cols : 0, 0);
+    H.h_e_zidx.resize(E.total_cols); // every column belongs to exactly one (leaf, range) pair: written completely below
+    H.h_e_mirrorflag.resize(mirror_flags ? E.total_cols : 0);
     auto fill_e = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
         parallel_for(pb.size(), [&](size_t lo, size_t hi) { // every (leaf, range) pair owns its own columns
             for (size_t p = lo; p < hi; p++) {
@@ -668,8 +702,8 @@ static int build_streams(HMat &H) {
                 int32_t *dst      = H.h_e_zidx.data() + E.colbase[r] + pc[p];
                 for (int j = 0; j < ncols; j++)
                     dst[j] = (int32_t)(z0 + j);
-                if (mirror_flags && l.mirror)
-                    std::fill_n(H.h_e_mirrorflag.data() + E.colbase[r] + pc[p], ncols, 1);
+                if (mirror_flags)
+                    std::fill_n(H.h_e_mirrorflag.data() + E.colbase[r] + pc[p], ncols, l.mirror ? 1 : 0);
             }
         });
     };
@@ -746,9 +780,9 @@ static int build_streams(HMat &H) {
             fprintf(stderr, "[hmx build]   %d groups of %d row ranges (alignment %d): %.1f %% of the E columns in a shared prefix\n", H.n_grp, GW, best_shift, 100 * H.grp_shared_frac);
     }
     phase("  e index");
-    std::vector<int32_t> h_outidx(R.total_cols, 0);
-    H.h_r_aidx.assign(R.total_cols, 0);
-    H.h_r_mirrorflag.assign(mirror_flags ? R.total_cols : 0, 0);
+    hvec32 h_outidx(R.total_cols);
+    H.h_r_aidx.resize(R.total_cols);
+    H.h_r_mirrorflag.resize(mirror_flags ? R.total_cols : 0);
     parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++) {
             const int b = rlr_b[p], r = rlr_r[p];
@@ -757,8 +791,8 @@ static int build_streams(HMat &H) {
             for (int k = 0; k < l.rank; k++) {
                 H.h_r_aidx[cb + k] = (int32_t)(aoff[b] + k);
                 h_outidx[cb + k]   = ns_of[b] == 1 ? (int32_t)(zA + aoff[b] + k) : (int32_t)(zP + poff[b] + (int64_t)(r - s_first[b]) * l.rank + k);
-                if (mirror_flags && l.mirror)
-                    H.h_r_mirrorflag[cb + k] = 1;
+                if (mirror_flags)
+                    H.h_r_mirrorflag[cb + k] = l.mirror ? 1 : 0;
             }
         }
     });
@@ -1897,10 +1931,41 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         need += (double)qmax * (double)(M + N);
         estimate += std::min((double)qmax, rank_guess) * (double)(M + N);
     }
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        const int64_t sa = (int64_t)H.leaves[a].t_size + H.leaves[a].s_size, sb = (int64_t)H.leaves[b].t_size + H.leaves[b].s_size;
-        return sa != sb ? sa > sb : a < b;
-    });
+    { // largest blocks (rows + columns) first, leaf order inside a size: `order` is in leaf order and the sizes take a few dozen distinct
+      // values (two per level of the trees), so one counting pass per distinct size class replaces the comparison sort
+        std::map<int64_t, int64_t, std::greater<int64_t>> count;
+        std::vector<int64_t> size_of(order.size());
+        for (size_t k = 0; k < order.size(); k++)
+            size_of[k] = (int64_t)H.leaves[order[k]].t_size + H.leaves[order[k]].s_size;
+        if (order.size() > 0) {
+            // consecutive leaves mostly share their size: the map is only consulted where a run ends
+            int64_t last = -1;
+            int64_t *slot = nullptr;
+            for (size_t k = 0; k < order.size(); k++) {
+                if (size_of[k] != last) {
+                    last = size_of[k];
+                    slot = &count[last];
+                }
+                ++*slot;
+            }
+            int64_t run = 0;
+            for (auto &kv : count) {
+                const int64_t c = kv.second;
+                kv.second       = run;
+                run += c;
+            }
+            std::vector<int32_t> sorted(order.size());
+            last = -1;
+            for (size_t k = 0; k < order.size(); k++) {
+                if (size_of[k] != last) {
+                    last = size_of[k];
+                    slot = &count[last];
+                }
+                sorted[(*slot)++] = order[k];
+            }
+            order.swap(sorted);
+        }
+    }
     size_t free_b = 0, total_b = 0;
     HMX_HIP(hmx_mem_info(&free_b, &total_b));
     size_t largest_b = 0;
