@@ -132,6 +132,27 @@ def test_chunked_sort_of_large_slices_gives_the_reference_order(monkeypatch):
         assert np.array_equal(got[2][0], To.perm) and np.array_equal(got[2][1], To.nodes_int) and np.array_equal(got[2][2], To.nodes_real)
 
 
+def test_block_tree_sub_trees_on_threads_give_the_same_leaf_list(monkeypatch):
+    """block_tree.cpp expands the sub-trees below a recursion depth on their own threads and splices their leaves back in preorder: the leaf
+    list (order, mirror / symmetric flags) must not depend on where the first walk stops -- whole operator, one row partition (re-rooted
+    block tree), symmetric storage, block-diagonal (local) trees."""
+    x = hm.create_geometry("ellipse", 30000)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(50)
+    T = b.create_cluster_tree(30000, 3, x, 2, 4)
+    cases = [("N", "N", -1, -1), ("N", "N", 2, -1), ("S", "L", -1, -1), ("S", "U", 1, 1), ("S", "L", 3, -1)]
+    for sym, uplo, part, psym in cases:
+        got = []
+        for depth in ("-1", "0", "2", "5"):
+            monkeypatch.setenv("HMX_BT_DEFER_DEPTH", depth)
+            tb = hm.HMatrixTreeBuilder(1e-3, 10.0, sym, uplo)
+            got.append(np.array(tb.build_block_tree(T, T, part, psym).leaves))
+        assert len(got[0]) > 100
+        for g in got[1:]:
+            assert g.tobytes() == got[0].tobytes(), (sym, uplo, part, psym)
+    monkeypatch.delenv("HMX_BT_DEFER_DEPTH")
+
+
 def test_invalid_arguments_are_reported():
     x = hm.create_geometry("disk", 100)
     b = hm.ClusterTreeBuilder()
