@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmx.so")
+LIB_PATH = os.environ.get("HMX_LIB_PATH") or os.path.join(_HERE, "libhmx.so")  # HMX_LIB_PATH: another build of the same ABI (A/B runs)
 
 HMX_MEM_HOST, HMX_MEM_DEVICE = 0, 1
 HMX_PREC_F64, HMX_PREC_F32, HMX_PREC_Z64, HMX_PREC_C32 = 0, 1, 2, 3
