@@ -139,13 +139,17 @@ static int build_streams(HMat &H) {
     Timer tim;
     const bool phase_timing = getenv("HMX_BUILD_TIMING") && atoi(getenv("HMX_BUILD_TIMING"));
     double phase_last       = 0;
-    auto phase              = [&](const char *name) {
+    auto phase_nosync       = [&](const char *name) { // host phases that run while the pack kernels are in flight
         if (!phase_timing)
             return;
-        (void)hipDeviceSynchronize();
         const double t = tim.s();
         fprintf(stderr, "[hmx build]   layout: %-20s %8.1f ms\n", name, 1e3 * (t - phase_last));
         phase_last = t;
+    };
+    auto phase = [&](const char *name) {
+        if (phase_timing)
+            (void)hipDeviceSynchronize();
+        phase_nosync(name);
     };
     const int64_t nb_real = (int64_t)H.leaves.size();
     constexpr int TR_MAX = 64;
@@ -528,10 +532,12 @@ static int build_streams(HMat &H) {
     // address order inside a class (neighbouring workgroups stream neighbouring memory)
     const int sort_mode = getenv("HMX_SORT_TASKS") ? atoi(getenv("HMX_SORT_TASKS")) : 1;
     auto weight_class = [](int64_t w) { int c = 0; while (w > 1) { w >>= 1; c++; } return c; };
-    if (sort_mode == 1)
-        std::stable_sort(E.task_range.begin(), E.task_range.end(), [&](int a, int b) { return (int64_t)E.len[a] * E.cols[a] > (int64_t)E.len[b] * E.cols[b]; });
-    else if (sort_mode == 2)
-        std::stable_sort(E.task_range.begin(), E.task_range.end(), [&](int a, int b) { return weight_class((int64_t)E.len[a] * E.cols[a]) > weight_class((int64_t)E.len[b] * E.cols[b]); });
+    if (sort_mode == 1 || sort_mode == 2) {
+        std::vector<int64_t> wk(E.nranges());
+        for (int r = 0; r < E.nranges(); r++)
+            wk[r] = sort_mode == 2 ? (int64_t)weight_class((int64_t)E.len[r] * E.cols[r]) : (int64_t)E.len[r] * E.cols[r];
+        std::stable_sort(E.task_range.begin(), E.task_range.end(), [&](int a, int b) { return wk[a] > wk[b]; });
+    }
     E.task_chunk.clear();
     R.base.assign(R.nranges(), 0);
     R.colbase.assign(R.nranges(), 0);
@@ -564,10 +570,10 @@ static int build_streams(HMat &H) {
             w     = std::min(w, (int)R.cw[r]);
             return (int64_t)R.len[r] * w;
         };
-        if (sort_mode == 2)
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return weight_class(work(a)) > weight_class(work(b)); });
-        else
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return work(a) > work(b); });
+        std::vector<int64_t> wk(ord.size()); // the key once per task, not once per comparison
+        for (size_t t = 0; t < ord.size(); t++)
+            wk[t] = sort_mode == 2 ? (int64_t)weight_class(work((int)t)) : work((int)t);
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return wk[a] > wk[b]; });
         std::vector<int32_t> tr(ord.size()), tc(ord.size());
         for (size_t k = 0; k < ord.size(); k++) {
             tr[k] = R.task_range[ord[k]];
@@ -688,6 +694,98 @@ static int build_streams(HMat &H) {
     }
     // ---- index arrays -------------------------------------------------------------------------------
     phase("bases, task order");
+    // ---- upload metadata, allocate streams ------------------------------------------------------------
+    // Order since round 3: what the pack kernels need goes first, the pack kernels are launched, and the HOST work they do not depend on
+    // (the index arrays of the product kernels, the slots of the fused symmetric product) runs while they fill the streams.
+    if (!H.sym_fused) {
+        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx})
+            a->release();
+        for (auto *a : {&H.s_sub_task, &H.s_sub_row0, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
+            a->release();
+        H.s_sub_ptr.release();
+        H.SW.release();
+    }
+    H.e_zidx_mirror.release();
+    H.e_tdst.release();
+    H.e_tdst_mirror.release();
+    H.r_tcoef.release();
+    H.r_tcoef_mirror.release();
+    HMX_HIP(E.upload_meta());
+    HMX_HIP(R.upload_meta());
+    HMX_HIP(E.stream.alloc(std::max<int64_t>(E.elems, 1)));
+    HMX_HIP(R.stream.alloc(std::max<int64_t>(R.elems, 1)));
+    HMX_HIP(R.stream.zero()); // padded odd-width chunks keep a zero column
+    // ---- pack ---------------------------------------------------------------------------------------------
+    std::vector<int32_t> ranks(nb), symu(nb, 0);
+    for (int64_t b = 0; b < nb; b++) {
+        ranks[b] = XL[b].rank;
+        if (XL[b].symmetric && XK[b] == LK_DENSE_STAGED && !SRC.dense_stage.d) // uploaded symmetric leaf: one triangle is valid
+            symu[b] = H.uplo_for_leaves == 'L' ? 1 : (H.uplo_for_leaves == 'U' ? 2 : 0);
+    }
+    HMX_HIP(H.d_rank.upload(ranks));
+    HMX_HIP(H.d_sym_uplo.upload(symu));
+    {
+        std::vector<int32_t> a(nb), bb(nb), c(nb), d(nb);
+        for (int64_t i = 0; i < nb; i++) {
+            a[i]  = XL[i].t_offset;
+            bb[i] = XL[i].t_size;
+            c[i]  = XL[i].s_offset;
+            d[i]  = XL[i].s_size;
+        }
+        HMX_HIP(H.d_t_off.upload(a));
+        HMX_HIP(H.d_t_size.upload(bb));
+        HMX_HIP(H.d_s_off.upload(c));
+        HMX_HIP(H.d_s_size.upload(d));
+        HMX_HIP(H.d_colptr.upload(xcolptr));
+        HMX_HIP(H.d_swapped.upload(xswapped));
+        HMX_HIP(H.d_staged_off.upload(xstaged));
+        HMX_HIP(H.d_transposed.upload(xtransposed));
+        HMX_HIP(H.d_conj.upload(xconj));
+    }
+    phase("uploads, allocations");
+    DEvent e0, e1;
+    DArr<int32_t> pk[9]; // pair lists of the three launches: all uploaded BEFORE the first launch (a blocking copy waits for the kernels
+                         // already queued on its stream), alive until the kernels are done
+    if (!elr_b.empty()) {
+        HMX_HIP(pk[0].upload(elr_b));
+        HMX_HIP(pk[1].upload(elr_r));
+        HMX_HIP(pk[2].upload(elr_c));
+    }
+    if (!rlr_b.empty()) {
+        HMX_HIP(pk[3].upload(rlr_b));
+        HMX_HIP(pk[4].upload(rlr_r));
+        HMX_HIP(pk[5].upload(rlr_c));
+    }
+    if (!ed_b.empty()) {
+        HMX_HIP(pk[6].upload(ed_b));
+        HMX_HIP(pk[7].upload(ed_r));
+        HMX_HIP(pk[8].upload(ed_c));
+    }
+    HMX_HIP(hipEventRecord(e0, 0));
+    if (!elr_b.empty()) {
+        PackLrArgs P{SRC.pool.d, SRC.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
+                     pk[0].d, pk[1].d, pk[2].d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0, H.d_conj.d};
+        hipLaunchKernelGGL(pack_lr_expand_kernel, dim3((unsigned)elr_b.size()), dim3(256), 0, 0, P, (int64_t)elr_b.size());
+        HMX_HIP(hipGetLastError());
+    }
+    if (!rlr_b.empty()) {
+        PackLrArgs P{SRC.pool.d, SRC.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
+                     pk[3].d, pk[4].d, pk[5].d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0, H.d_conj.d};
+        hipLaunchKernelGGL(pack_lr_reduce_kernel, dim3((unsigned)rlr_b.size()), dim3(256), 0, 0, P, (int64_t)rlr_b.size());
+        HMX_HIP(hipGetLastError());
+    }
+    if (!ed_b.empty()) {
+        // row / column coordinates of THIS layout: a transposed view's rows are the owner's source points
+        const DArr<double> &rx = tv ? SRC.sx : SRC.tx, &ry = tv ? SRC.sy : SRC.ty, &rz = tv ? SRC.sz : SRC.tz;
+        const DArr<double> &cx = tv ? SRC.tx : SRC.sx, &cy = tv ? SRC.ty : SRC.sy, &cz = tv ? SRC.tz : SRC.sz;
+        PackDenseArgs P{SRC.ks, rx.d, ry.d, rz.d, cx.d, cy.d, cz.d, pk[6].d, pk[7].d, pk[8].d, E.d_off.d, E.d_len.d, E.d_base.d,
+                        H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.d_conj.d,
+                        SRC.dense_stage.d ? SRC.dense_stage.d : SRC.pool.d, E.stream.d, H.T0, herm};
+        hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)ed_b.size()), dim3(256), 0, 0, P, (int64_t)ed_b.size());
+        HMX_HIP(hipGetLastError());
+    }
+    HMX_HIP(hipEventRecord(e1, 0));
+    phase_nosync("pack kernels launched");
     const int64_t zA = H.nS, zP = H.nS + A_total;
     H.zero_slot      = H.nS + A_total + P_total;
     H.h_e_zidx.resize(E.total_cols); // every column belongs to exactly one (leaf, range) pair: written completely below
@@ -779,7 +877,7 @@ static int build_streams(HMat &H) {
         if (phase_timing)
             fprintf(stderr, "[hmx build]   %d groups of %d row ranges (alignment %d): %.1f %% of the E columns in a shared prefix\n", H.n_grp, GW, best_shift, 100 * H.grp_shared_frac);
     }
-    phase("  e index");
+    phase_nosync("  e index");
     hvec32 h_outidx(R.total_cols);
     H.h_r_aidx.resize(R.total_cols);
     H.h_r_mirrorflag.resize(mirror_flags ? R.total_cols : 0);
@@ -796,7 +894,7 @@ static int build_streams(HMat &H) {
             }
         }
     });
-    phase("  r index");
+    phase_nosync("  r index");
     std::vector<int32_t> cd, cs, cst, cc;
     for (int64_t b = 0; b < nb; b++)
         if (poff[b] >= 0)
@@ -815,7 +913,8 @@ static int build_streams(HMat &H) {
     // through a list of its column-group positions.  The second R sweep (rowsym_kernel) is owner-computes: one workgroup per interval
     // of SYM_IR target rows applies every (part of a) task inside it, folds the row sums in LDS, adds the interval's dense mirrored
     // column sums (EW, through a level-major index) and updates y once.  All in a fixed order: results are bit-reproducible.
-    std::vector<int32_t> s_mdst, s_coef, s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
+    hvec32 s_mdst, s_coef;
+    std::vector<int32_t> s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
     std::unique_ptr<int32_t[]> s_fidx; // level-major, s_kmax x nT: left uninitialised (only the entries below count[j] are ever read)
     size_t s_fidx_n = 0;
     std::vector<int64_t> s_sub_ptr;
@@ -824,8 +923,10 @@ static int build_streams(HMat &H) {
     H.s_kmax        = 0;
     int64_t s_total = 0;
     if (H.sym_fused) {
-        s_mdst.assign(E.total_cols, -1);
-        s_coef.assign(R.total_cols, -1);
+        s_mdst.resize(E.total_cols); // sized without initialisation, filled by several threads
+        s_coef.resize(R.total_cols);
+        parallel_for(s_mdst.size(), [&](size_t lo, size_t hi) { std::fill(s_mdst.begin() + lo, s_mdst.begin() + hi, -1); });
+        parallel_for(s_coef.size(), [&](size_t lo, size_t hi) { std::fill(s_coef.begin() + lo, s_coef.begin() + hi, -1); });
         s_cnt.assign(H.nT, 0);
         bool bad = false;
         std::vector<int64_t> epad(E.nranges());
@@ -847,7 +948,7 @@ static int build_streams(HMat &H) {
                 lptr[b] = LN;
                 LN += nrange[b];
             }
-        phase("  sym: setup");
+        phase_nosync("  sym: setup");
         s_list.assign(LN, 0);
         std::vector<int64_t> single_slot(nb, -1);
         {
@@ -872,8 +973,16 @@ static int build_streams(HMat &H) {
                 }
             });
         }
-        phase("  sym: lr columns");
+        phase_nosync("  sym: lr columns");
         H.n_sym_combine_wave = 0;
+        {
+            size_t entries = 0;
+            for (int64_t b = 0; b < nb; b++)
+                if (lptr[b] >= 0)
+                    entries += (size_t)XL[b].rank;
+            for (auto *v : {&s_cd, &s_clp, &s_cc, &s_ck})
+                v->reserve(entries);
+        }
         for (int pass = 0; pass < 2; pass++) // entries with many partial sums first (one wave each), then the rest (one thread each)
             for (int64_t b = 0; b < nb; b++)
                 if (lptr[b] >= 0 && (nrange[b] >= 32) == (pass == 0)) {
@@ -886,7 +995,7 @@ static int build_streams(HMat &H) {
                     if (pass == 0)
                         H.n_sym_combine_wave += XL[b].rank;
                 }
-        phase("  sym: combine entries");
+        phase_nosync("  sym: combine entries");
         parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
             for (size_t p = lo; p < hi; p++) {
                 const int b = rlr_b[p];
@@ -898,7 +1007,7 @@ static int build_streams(HMat &H) {
                     dst[k] = (int32_t)(base + k);
             }
         });
-        phase("  sym: coef");
+        phase_nosync("  sym: coef");
         // Second R sweep, owner-computes: the target rows are cut into intervals of SYM_IR rows and ONE workgroup per interval applies
         // every (piece, chunk) task -- or the part of it -- whose rows lie in the interval, folds the row sums of its waves in LDS,
         // adds the interval's dense mirrored contributions (EW, through the level index) and updates y once.  No partial row sums
@@ -957,7 +1066,7 @@ static int build_streams(HMat &H) {
         s_int_order.resize(nint);
         std::iota(s_int_order.begin(), s_int_order.end(), 0);
         std::stable_sort(s_int_order.begin(), s_int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
-        phase("  sym: tasks");
+        phase_nosync("  sym: tasks");
         // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
         for (size_t p = 0; p < ed_b.size() && !bad; p++) {
             const hmx_leaf &l = XL[ed_b[p]];
@@ -982,36 +1091,38 @@ static int build_streams(HMat &H) {
             set_error("operator too large for 32-bit slots of the fused symmetric product (HMX_SYM_EXPANDED=1 selects the expanded layout)");
             return HMX_ERR_UNSUPPORTED;
         }
-        phase("  sym: dense count");
+        phase_nosync("  sym: dense count");
         s_fidx_n = (size_t)H.s_kmax * H.nT;
         s_fidx.reset(new int32_t[std::max<size_t>(s_fidx_n, 1)]);
         std::vector<int32_t> fill(H.nT, 0);
-        for (size_t p = 0; p < ed_b.size(); p++) { // leaf-major
-            const int b = ed_b[p], r = ed_r[p];
-            const hmx_leaf &l = XL[b];
-            if (!l.mirror)
-                continue;
-            const int j0       = l.s_offset - H.T0;
-            const int64_t base = EWBASE + epad[r] + ed_c[p];
-            int32_t *dst       = s_mdst.data() + E.colbase[r] + ed_c[p];
-            for (int j = 0; j < l.s_size; j++) {
-                dst[j]                                               = (int32_t)(base + j);
-                s_fidx[(size_t)(fill[j0 + j]++) * H.nT + (j0 + j)] = (int32_t)(base + j);
+        // every thread owns an interval of the mirrored columns and walks ALL pairs (leaf-major), clipped to its interval: the levels of a
+        // column are numbered in the pairs' order, as the one-thread loop numbers them
+        parallel_for((size_t)H.nT, [&](size_t clo, size_t chi) {
+            for (size_t p = 0; p < ed_b.size(); p++) {
+                const int b = ed_b[p], r = ed_r[p];
+                const hmx_leaf &l = XL[b];
+                if (!l.mirror)
+                    continue;
+                const int j0 = l.s_offset - H.T0;
+                const int ja = std::max(0, (int)clo - j0), jb = std::min((int)l.s_size, (int)chi - j0);
+                if (ja >= jb)
+                    continue;
+                const int64_t base = EWBASE + epad[r] + ed_c[p];
+                int32_t *dst       = s_mdst.data() + E.colbase[r] + ed_c[p];
+                for (int j = ja; j < jb; j++) {
+                    dst[j]                                               = (int32_t)(base + j);
+                    s_fidx[(size_t)(fill[j0 + j]++) * H.nT + (j0 + j)] = (int32_t)(base + j);
+                }
             }
-        }
+        });
         H.s_nint = nint;
-        phase("  sym: fidx fill");
+        phase_nosync("  sym: fidx fill");
         H.n_sym_combine = (int)s_cd.size();
-        phase("fused symmetric slots");
+        phase_nosync("fused symmetric slots");
     }
 
-    phase("index arrays");
-    // ---- upload metadata, allocate streams ------------------------------------------------------------
-    HMX_HIP(E.upload_meta());
-    HMX_HIP(R.upload_meta());
-    HMX_HIP(E.stream.alloc(std::max<int64_t>(E.elems, 1)));
-    HMX_HIP(R.stream.alloc(std::max<int64_t>(R.elems, 1)));
-    HMX_HIP(R.stream.zero()); // padded odd-width chunks keep a zero column
+    phase_nosync("index arrays");
+    // ---- uploads of the index arrays (the first one waits for the pack kernels: same stream) ----------------------------------------
     HMX_HIP(H.e_zidx.upload(H.h_e_zidx));
     HMX_HIP(H.r_outidx.upload(h_outidx));
     HMX_HIP(H.c_dst.upload(cd));
@@ -1040,92 +1151,14 @@ static int build_streams(HMat &H) {
         if (s_fidx_n)
             HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
         HMX_HIP(H.SW.alloc(s_total + 1));
-    } else {
-        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx})
-            a->release();
-        for (auto *a : {&H.s_sub_task, &H.s_sub_row0, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
-            a->release();
-        H.s_sub_ptr.release();
-        H.SW.release();
     }
-    H.e_zidx_mirror.release();
-    H.e_tdst.release();
-    H.e_tdst_mirror.release();
-    H.r_tcoef.release();
-    H.r_tcoef_mirror.release();
-
-    // ---- pack ---------------------------------------------------------------------------------------------
-    std::vector<int32_t> ranks(nb), symu(nb, 0);
-    for (int64_t b = 0; b < nb; b++) {
-        ranks[b] = XL[b].rank;
-        if (XL[b].symmetric && XK[b] == LK_DENSE_STAGED && !SRC.dense_stage.d) // uploaded symmetric leaf: one triangle is valid
-            symu[b] = H.uplo_for_leaves == 'L' ? 1 : (H.uplo_for_leaves == 'U' ? 2 : 0);
-    }
-    HMX_HIP(H.d_rank.upload(ranks));
-    HMX_HIP(H.d_sym_uplo.upload(symu));
-    {
-        std::vector<int32_t> a(nb), bb(nb), c(nb), d(nb);
-        for (int64_t i = 0; i < nb; i++) {
-            a[i]  = XL[i].t_offset;
-            bb[i] = XL[i].t_size;
-            c[i]  = XL[i].s_offset;
-            d[i]  = XL[i].s_size;
-        }
-        HMX_HIP(H.d_t_off.upload(a));
-        HMX_HIP(H.d_t_size.upload(bb));
-        HMX_HIP(H.d_s_off.upload(c));
-        HMX_HIP(H.d_s_size.upload(d));
-        HMX_HIP(H.d_colptr.upload(xcolptr));
-        HMX_HIP(H.d_swapped.upload(xswapped));
-        HMX_HIP(H.d_staged_off.upload(xstaged));
-        HMX_HIP(H.d_transposed.upload(xtransposed));
-        HMX_HIP(H.d_conj.upload(xconj));
-    }
-    phase("uploads, allocations");
-    DEvent e0, e1;
-    HMX_HIP(hipEventRecord(e0, 0));
-    {
-        DArr<int32_t> pb, pr, pc;
-        if (!elr_b.empty()) {
-            HMX_HIP(pb.upload(elr_b));
-            HMX_HIP(pr.upload(elr_r));
-            HMX_HIP(pc.upload(elr_c));
-            PackLrArgs P{SRC.pool.d, SRC.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d, E.d_cols.d, E.d_cw.d, E.stream.d, H.T0, H.d_conj.d};
-            hipLaunchKernelGGL(pack_lr_expand_kernel, dim3((unsigned)elr_b.size()), dim3(256), 0, 0, P, (int64_t)elr_b.size());
-            HMX_HIP(hipGetLastError());
-            HMX_HIP(hipDeviceSynchronize());
-        }
-        if (!rlr_b.empty()) {
-            HMX_HIP(pb.upload(rlr_b));
-            HMX_HIP(pr.upload(rlr_r));
-            HMX_HIP(pc.upload(rlr_c));
-            PackLrArgs P{SRC.pool.d, SRC.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
-                         pb.d, pr.d, pc.d, R.d_off.d, R.d_len.d, R.d_base.d, R.d_cols.d, R.d_cw.d, R.stream.d, H.S0, H.d_conj.d};
-            hipLaunchKernelGGL(pack_lr_reduce_kernel, dim3((unsigned)rlr_b.size()), dim3(256), 0, 0, P, (int64_t)rlr_b.size());
-            HMX_HIP(hipGetLastError());
-            HMX_HIP(hipDeviceSynchronize());
-        }
-        if (!ed_b.empty()) {
-            HMX_HIP(pb.upload(ed_b));
-            HMX_HIP(pr.upload(ed_r));
-            HMX_HIP(pc.upload(ed_c));
-            // row / column coordinates of THIS layout: a transposed view's rows are the owner's source points
-            const DArr<double> &rx = tv ? SRC.sx : SRC.tx, &ry = tv ? SRC.sy : SRC.ty, &rz = tv ? SRC.sz : SRC.tz;
-            const DArr<double> &cx = tv ? SRC.tx : SRC.sx, &cy = tv ? SRC.ty : SRC.sy, &cz = tv ? SRC.tz : SRC.sz;
-            PackDenseArgs P{SRC.ks, rx.d, ry.d, rz.d, cx.d, cy.d, cz.d, pb.d, pr.d, pc.d, E.d_off.d, E.d_len.d, E.d_base.d,
-                            H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d, H.d_staged_off.d, H.d_sym_uplo.d, H.d_transposed.d, H.d_conj.d,
-                            SRC.dense_stage.d ? SRC.dense_stage.d : SRC.pool.d, E.stream.d, H.T0, herm};
-            hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)ed_b.size()), dim3(256), 0, 0, P, (int64_t)ed_b.size());
-            HMX_HIP(hipGetLastError());
-            HMX_HIP(hipDeviceSynchronize());
-        }
-    }
-    HMX_HIP(hipEventRecord(e1, 0));
     HMX_HIP(hipEventSynchronize(e1));
+    HMX_HIP(hipDeviceSynchronize()); // an error of the pack kernels surfaces here
     float ms = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    phase("pack kernels");
+    for (auto &a : pk)
+        a.release();
+    phase("uploads of the index arrays");
     H.stats.t_pack_s     = tim.s();
     H.stats.t_assemble_s = ms * 1e-3;
     H.stats.stream_bytes = (E.elems + R.elems) * (int64_t)sizeof(scalar);
