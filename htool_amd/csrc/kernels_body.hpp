@@ -2337,6 +2337,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
     const int m = lane & 15, kk = lane >> 4;
     real(*tile)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 16 * PITCH);
     const int row      = lane < len ? lane : len - 1; // idle lanes re-read the last row: their tile rows only reach accumulator rows that are never stored
+    // nrhs < 16, a ragged last group: operand column m of the MFMA only reaches result column m, and the columns >= nrhs are never stored, so
+    // their lanes just read a valid element (the group's first right-hand side).  NOT a select on the loaded value: the compiler then moves the
+    // load under an exec-mask branch with a vmcnt(0) behind it (fp32 config 5: 8.4 -> 12.2 ms for this kernel)
+    const int mo = cbase + (m < nrhs ? m : 0);
     acc4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -2352,8 +2356,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
-            const real bv = expand_operand(A, zc, mu)[cbase + (m < nrhs ? m : 0)]; // nrhs < 16: a ragged last group, the missing right-hand sides are zeros
-            b[g]          = (c + 4 * g + kk < C && m < nrhs) ? bv : real(0);
+            const real bv = expand_operand(A, zc, mu)[mo];
+            b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
         }
     };
     auto apply = [&](const real(&v)[16], const real(&b)[4]) {
@@ -2610,6 +2614,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
     const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, rhs m
     real(*tile)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 8 * PITCH);
     const int c2       = 2 * lane < wp ? 2 * lane : 0; // lanes beyond the chunk re-read its first pair (their tile columns are never used)
+    const int mo       = m < nrhs ? m : 0;             // ragged group: see expand_mfma16s_kernel (xs already points at the group's first right-hand side)
     acc4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++)
@@ -2625,8 +2630,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int row = i0 + 4 * h + kk;
-            const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + (m < nrhs ? m : 0)];
-            b[h]          = (row < len && m < nrhs) ? bv : real(0);
+            const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + mo];
+            b[h]          = row < len ? bv : real(0);
         }
     };
     auto apply = [&](const scalar2 (&v)[8], const real(&b)[2]) {
@@ -2661,6 +2666,16 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
             apply(v1, b1);
     }
     const int64_t cb = A.range_colbase[S] + ch * cw;
+    // destinations first: the chunk's (<= 128) indices in two coalesced loads, handed to the lanes by shuffles.  With the index fetched
+    // under each store's own predicate the compiler emits load -> vmcnt(0) -> store thirty-two times in a row (and it moves plain
+    // unpredicated index loads back under the predicates; a shuffle cannot be moved into divergent code)
+    const int32_t ilo = A.out_idx[cb + (lane < w ? lane : 0)], ihi = A.out_idx[cb + (64 + lane < w ? 64 + lane : 0)];
+    int32_t dst[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            dst[t][j] = __shfl(t < 4 ? ilo : ihi, 16 * (t & 3) + mfma16_row(real(0), lane, j), WAVE);
 #pragma unroll
     for (int t = 0; t < 8; t++)
         if (t < ntile)
@@ -2668,7 +2683,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
             for (int j = 0; j < 4; j++) {
                 const int col = 16 * t + mfma16_row(real(0), lane, j);
                 if (col < w && m < nrhs)
-                    A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
+                    A.Z[(int64_t)dst[t][j] * mu + cbase + m] = acc[t][j];
             }
 }
 
@@ -2781,6 +2796,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs 
     real(*tre)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 2 * STEP * PITCH);
     real(*tim)[PITCH] = tre + STEP;
     const int row     = lane < len ? lane : len - 1;
+    const int mo      = m < 2 * nrhs ? m : 0; // ragged group: see expand_mfma16s_kernel
     zacc4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -2797,8 +2813,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs 
         for (int g = 0; g < 2; g++) {
             const int zc   = __shfl(zi, base + 4 * g + kk, WAVE);
             const real *zr = reinterpret_cast<const real *>(expand_operand(A, zc, mu) + cbase);
-            const real zv  = zr[m < 2 * nrhs ? m : 0]; // nrhs < 8: a ragged last group, the missing right-hand sides are zeros
-            const real bv  = (c + 4 * g + kk < C && m < 2 * nrhs) ? zv : real(0);
+            const real zv  = zr[mo]; // nrhs < 8, a ragged last group: see expand_mfma16s_kernel (lanes of the missing right-hand sides read a valid pair)
+            const real bv  = (c + 4 * g + kk < C) ? zv : real(0);
             b[g]           = bv;
             bs[g]          = zmfma_swapped(bv, lane);
         }
@@ -2885,6 +2901,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs 
     real(*tre)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 2 * STEP * PITCH);
     real(*tim)[PITCH] = tre + STEP;
     const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+    const int mo   = m < 2 * nrhs ? m : 0; // ragged group: see expand_mfma16s_kernel
     zacc4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++)
@@ -2898,8 +2915,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs 
     };
     auto operands = [&](real &b, real &bs, int i0) {
         const int row = i0 + kk;
-        const real bv = xs[(int64_t)(row < len ? row : len - 1) * 2 * mu + (m < 2 * nrhs ? m : 0)];
-        b             = (row < len && m < 2 * nrhs) ? bv : real(0);
+        const real bv = xs[(int64_t)(row < len ? row : len - 1) * 2 * mu + mo];
+        b             = row < len ? bv : real(0);
         bs            = zmfma_swapped(b, lane);
     };
     auto apply = [&](const scalar2(&v)[STEP], real b, real bs) {
@@ -2943,6 +2960,14 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs 
     }
     const int64_t cb = A.range_colbase[S] + ch * cw;
     real *Zr         = reinterpret_cast<real *>(A.Z);
+    // destinations first, two coalesced loads + shuffles: see reduce_mfma16s_kernel
+    const int32_t ilo = A.out_idx[cb + (lane < w ? lane : 0)], ihi = A.out_idx[cb + (64 + lane < w ? 64 + lane : 0)];
+    int32_t dst[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            dst[t][j] = __shfl(t < 4 ? ilo : ihi, 16 * (t & 3) + mfma16_row(real(0), lane, j), WAVE);
 #pragma unroll
     for (int t = 0; t < 8; t++)
         if (t < ntile)
@@ -2950,7 +2975,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs 
             for (int j = 0; j < 4; j++) {
                 const int col = 16 * t + mfma16_row(real(0), lane, j);
                 if (col < w && m < 2 * nrhs)
-                    Zr[((int64_t)A.out_idx[cb + col] * mu + cbase) * 2 + m] = acc[t][j];
+                    Zr[((int64_t)dst[t][j] * mu + cbase) * 2 + m] = acc[t][j];
             }
 }
 #endif // HMX_COMPLEX

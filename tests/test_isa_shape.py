@@ -1,0 +1,56 @@
+"""Shape of the compiled multi-RHS matrix-core kernels (gfx950 code object inside libhmx.so), checked without a GPU.
+
+These kernels are bound by how their stream loads are issued.  Twice in round 3 a source change that looked harmless made
+the compiler move operand loads under exec-mask branches with an `s_waitcnt vmcnt(0)` behind each of them -- same registers, same LDS, 45 %
+more time on the fp32 expand stage of config 5.  The counts below are what the kernels have when the loads are issued back to back."""
+import collections
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "htool_amd", "libhmx.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def code_object(tmp_path):
+    data = open(LIB, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0, "no offload bundle in libhmx.so"
+    off = i + 24
+    n = struct.unpack_from("<Q", data, off)[0]
+    off += 8
+    for _ in range(n):
+        o, s, l = struct.unpack_from("<QQQ", data, off)
+        off += 24
+        name = data[off:off + l].decode()
+        off += l
+        if "gfx950" in name:
+            p = tmp_path / "hmx_gfx950.co"
+            p.write_bytes(data[i + o:i + o + s])
+            return str(p)
+    raise AssertionError("no gfx950 code object in libhmx.so")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="llvm-objdump not installed")
+def test_staged_matrix_core_kernels_issue_their_loads_back_to_back(tmp_path):
+    co = code_object(tmp_path)
+    syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", co], capture_output=True, text=True, check=True).stdout
+    names = sorted(set(re.findall(r"FUNC.* (\S*(?:mfma16s|zmfma8s)_kernel\S*)$", syms, flags=re.M)))
+    assert len(names) == 8, names  # expand + reduce, real (f64, f32) and complex (z64, c32)
+    for sym in names:
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, co], capture_output=True, text=True, check=True).stdout
+        ops = collections.Counter(l.split()[0] for l in asm.split("\n") if l.startswith("\t"))
+        drained = sum(1 for l in asm.split("\n") if "s_waitcnt vmcnt(0)" in l)
+        assert ops["v_mfma_f64_16x16x4_f64"] + ops["v_mfma_f32_16x16x4_f32"] >= 32, sym
+        assert ops["scratch_load_dword"] + ops["scratch_store_dword"] == 0, sym
+        if "expand" in sym:
+            # the loop has no divergent branch at all: the three are the tile loop's tail and the write-out of the rows
+            assert ops["s_cbranch_execz"] <= 4 and drained <= 8, (sym, ops["s_cbranch_execz"], drained)
+        else:
+            # reduce stage: the 32 (64 for complex double) predicated stores of the write-out are branches, but the loop waits for
+            # nothing but its own tile, and the destinations are fetched before the stores
+            assert drained <= 12, (sym, drained)
