@@ -561,6 +561,19 @@ static int build_streams(HMat &H) {
             R.task_chunk.push_back(c);
         }
     }
+    if (phase_timing) { // where the R-stream's coefficients sit, by chunk width (narrow chunks: few coefficients per row of the chunk)
+        int64_t by_width[5] = {0, 0, 0, 0, 0}, tasks[5] = {0, 0, 0, 0, 0};
+        for (size_t t = 0; t < R.task_range.size(); t++) {
+            const int r = R.task_range[t], w = std::min<int>(R.cols[r] - R.task_chunk[t] * R.cw[r], R.cw[r]);
+            const int k = w <= 8 ? 0 : (w <= 16 ? 1 : (w <= 32 ? 2 : (w <= 64 ? 3 : 4)));
+            by_width[k] += (int64_t)R.len[r] * w;
+            tasks[k]++;
+        }
+        fprintf(stderr, "[hmx build]   R-stream coefficients by chunk width <= 8 / 16 / 32 / 64 / 128: %.1f / %.1f / %.1f / %.1f / %.1f %% (%lld / %lld / %lld / %lld / %lld tasks)\n",
+                100.0 * by_width[0] / std::max<int64_t>(R.elems, 1), 100.0 * by_width[1] / std::max<int64_t>(R.elems, 1), 100.0 * by_width[2] / std::max<int64_t>(R.elems, 1),
+                100.0 * by_width[3] / std::max<int64_t>(R.elems, 1), 100.0 * by_width[4] / std::max<int64_t>(R.elems, 1), (long long)tasks[0], (long long)tasks[1], (long long)tasks[2],
+                (long long)tasks[3], (long long)tasks[4]);
+    }
     if (sort_mode) { // longest tasks first: shorter kernel tail (-8 % on reduce_kernel)
         std::vector<int> ord(R.task_range.size());
         std::iota(ord.begin(), ord.end(), 0);
