@@ -1849,9 +1849,7 @@ static int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
         delete H;
         return HMX_ERR_HIP;
     }
-    H->staged_U.resize(nb);
-    H->staged_V.resize(nb);
-    H->staged_D.resize(nb);
+    // staged_U / V / D (one std::vector per leaf, for blocks uploaded through set_block_*) are sized on first use: ensure_staged
     *out = H;
     return HMX_OK;
 }
@@ -1869,13 +1867,15 @@ static int api_set_kernel(HMat *H, int kernel, const double *params, int nparams
     auto soa = [&](const double *xyz, const std::vector<int32_t> &perm, DArr<double> &X, DArr<double> &Y, DArr<double> &Zc) -> hipError_t {
         const size_t n = perm.size();
         std::vector<double> x(n), y(n), z(n, 0.0);
-        for (size_t i = 0; i < n; i++) {
-            const double *p = xyz + (size_t)dim * perm[i];
-            x[i]            = p[0];
-            y[i]            = p[1];
-            if (dim == 3)
-                z[i] = p[2];
-        }
+        parallel_for(n, [&](size_t lo, size_t hi) { // a gather through the permutation: cache misses, spread over a few threads
+            for (size_t i = lo; i < hi; i++) {
+                const double *p = xyz + (size_t)dim * perm[i];
+                x[i]            = p[0];
+                y[i]            = p[1];
+                if (dim == 3)
+                    z[i] = p[2];
+            }
+        });
         hipError_t e;
         if ((e = X.upload(x)) != hipSuccess) return e;
         if ((e = Y.upload(y)) != hipSuccess) return e;
@@ -2663,12 +2663,21 @@ static int api_recompress(HMat *Hp, double epsilon) {
     return rc;
 }
 
+static void ensure_staged(HMat &H) {
+    const size_t nb = H.leaves.size();
+    if (H.staged_U.size() != nb) {
+        H.staged_U.resize(nb);
+        H.staged_V.resize(nb);
+        H.staged_D.resize(nb);
+    }
+}
 static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const scalar *U, const scalar *V) {
     if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || rank < 0 || (rank > 0 && (!U || !V))) {
         set_error("hmx_hmatrix_set_block_lowrank: invalid arguments");
         return HMX_ERR_INVALID;
     }
     const hmx_leaf &l = H->leaves[leaf];
+    ensure_staged(*H);
     H->staged_U[leaf].assign(U, U + (size_t)l.t_size * rank);
     // V arrives r x N column-major; keep it k-major (row k contiguous) like a cross
     H->staged_V[leaf].resize((size_t)l.s_size * rank);
@@ -2687,6 +2696,7 @@ static int api_set_block_dense(HMat *H, int64_t leaf, const scalar *D) {
         return HMX_ERR_INVALID;
     }
     const hmx_leaf &l = H->leaves[leaf];
+    ensure_staged(*H);
     H->staged_D[leaf].assign(D, D + (size_t)l.t_size * l.s_size);
     H->staged_U[leaf].clear();
     H->staged_V[leaf].clear();
@@ -2703,6 +2713,7 @@ static int api_finalize(HMat *Hp) {
     const size_t nb = H.leaves.size();
     // every leaf needs a payload
     int64_t total = 0, ncross = 0;
+    ensure_staged(H);
     for (size_t b = 0; b < nb; b++) {
         if (H.kind[b] == LK_PENDING || H.kind[b] == LK_DENSE_GEN) {
             if (H.has_kernel && !H.leaves[b].admissible) { // dense leaves may be left to the device generator
