@@ -2596,8 +2596,17 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A
 // (144-element row pitch: rows 32 banks apart).
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
-    constexpr int PITCH = 144;
-    __shared__ __attribute__((aligned(16))) real lds[WAVES * 8 * PITCH];
+    // Rows per wave-wide load: a chunk of <= 64 (<= 32) columns puts 2 (4) consecutive rows into one load instruction -- the chunk is a
+    // contiguous row-major block, lane l reads the column pair 2 (l mod LPR) of row l / LPR -- instead of leaving half (three quarters) of
+    // the lanes idle; a step is then 16 (32) rows and 4 (8) k-steps over 4 (2) column tiles: the same 16 MFMAs per 8 loads.  On one
+    // rank's share of a row-partitioned operator up to half of the R-stream sits in such chunks (few leaves share a source cluster).
+    // Tile pitch per variant: 144 / 80 / 48 elements (= 16 mod 32: the operand reads of 4 rows x 16 columns do not conflict).
+    // fp32 only: measured on one box (profiles/r3_ab_rpl.log), fp32 reduce stage -8 % on the whole N = 1e6 operator and -4 % on one rank's
+    // share of config 5; the fp64 stage does not gain from the 2-row form (a row of 64 fp64 columns already is a 512-byte load) and loses 3 %.
+    constexpr int RPL_MAX = sizeof(real) == 8 ? 1 : 4;
+    constexpr int TILE    = RPL_MAX == 4 ? 32 * 48 : 8 * 144;
+    static_assert(TILE >= 8 * 144, "tile buffer");
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * TILE];
     const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.x * WAVES + wv;
     if (task >= A.ntasks)
@@ -2612,59 +2621,70 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
     const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
     const real *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
     const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, rhs m
-    real(*tile)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 8 * PITCH);
-    const int c2       = 2 * lane < wp ? 2 * lane : 0; // lanes beyond the chunk re-read its first pair (their tile columns are never used)
-    const int mo       = m < nrhs ? m : 0;             // ragged group: see expand_mfma16s_kernel (xs already points at the group's first right-hand side)
+    real *tile   = lds + wv * TILE;
+    const int mo = m < nrhs ? m : 0; // ragged group: see expand_mfma16s_kernel (xs already points at the group's first right-hand side)
     acc4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++)
         acc[t] = acc4{0, 0, 0, 0};
-    auto load_rows = [&](scalar2 (&v)[8], int i0) { // 8 whole rows, clamped to the last one (its operand is zero there)
+    auto sweep = [&](auto rpl_c) {
+        constexpr int RPL = decltype(rpl_c)::value, LPR = 64 / RPL, RS = 8 * RPL, KS = 2 * RPL, NT = 8 / RPL;
+        constexpr int PITCH = RPL == 1 ? 144 : (RPL == 2 ? 80 : 48);
+        const int rl = lane / LPR, lr = lane % LPR;
+        const int c2 = 2 * lr < wp ? 2 * lr : 0; // lanes beyond the chunk re-read its first pair (their tile columns are never used)
+        auto load_rows = [&](scalar2(&v)[8], int i0) { // 8 loads of RPL whole rows each, clamped to the last row (its operand is zero there)
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int row = i0 + u < len ? i0 + u : len - 1;
-            v[u]          = stream_load(reinterpret_cast<const scalar2 *>(src + (int64_t)row * wp + c2));
+            for (int u = 0; u < 8; u++) {
+                const int row = i0 + u * RPL + rl < len ? i0 + u * RPL + rl : len - 1;
+                v[u]          = stream_load(reinterpret_cast<const scalar2 *>(src + (int64_t)row * wp + c2));
+            }
+        };
+        auto operands = [&](real(&b)[KS], int i0) {
+#pragma unroll
+            for (int h = 0; h < KS; h++) {
+                const int row = i0 + 4 * h + kk;
+                const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + mo];
+                b[h]          = row < len ? bv : real(0);
+            }
+        };
+        auto apply = [&](const scalar2(&v)[8], const real(&b)[KS]) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                *reinterpret_cast<scalar2 *>(&tile[(u * RPL + rl) * PITCH + 2 * lr]) = v[u];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < KS; h++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    if (t < ntile)
+                        acc[t] = mfma16(tile[(4 * h + kk) * PITCH + 16 * t + m], b[h], acc[t]);
+        };
+        scalar2 v0[8], v1[8];
+        real b0[KS], b1[KS];
+        load_rows(v0, 0);
+        operands(b0, 0);
+        for (int i0 = 0; i0 < len; i0 += 2 * RS) {
+            if (i0 + RS < len) {
+                load_rows(v1, i0 + RS);
+                operands(b1, i0 + RS);
+            }
+            apply(v0, b0);
+            if (i0 + 2 * RS < len) {
+                load_rows(v0, i0 + 2 * RS);
+                operands(b0, i0 + 2 * RS);
+            }
+            if (i0 + RS < len)
+                apply(v1, b1);
         }
     };
-    auto operands = [&](real(&b)[2], int i0) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int row = i0 + 4 * h + kk;
-            const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + mo];
-            b[h]          = row < len ? bv : real(0);
-        }
-    };
-    auto apply = [&](const scalar2 (&v)[8], const real(&b)[2]) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            *reinterpret_cast<scalar2 *>(&tile[u][2 * lane]) = v[u];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int t = 0; t < 8; t++)
-                if (t < ntile)
-                    acc[t] = mfma16(tile[4 * h + kk][16 * t + m], b[h], acc[t]);
-    };
-    scalar2 v0[8], v1[8];
-    real b0[2], b1[2];
-    load_rows(v0, 0);
-    operands(b0, 0);
-    for (int i0 = 0; i0 < len; i0 += 16) {
-        if (i0 + 8 < len) {
-            load_rows(v1, i0 + 8);
-            operands(b1, i0 + 8);
-        }
-        apply(v0, b0);
-        if (i0 + 16 < len) {
-            load_rows(v0, i0 + 16);
-            operands(b0, i0 + 16);
-        }
-        if (i0 + 8 < len)
-            apply(v1, b1);
-    }
+    if (RPL_MAX >= 4 && wp <= 32)
+        sweep(std::integral_constant<int, (RPL_MAX >= 4 ? 4 : 1)>{});
+    else if (RPL_MAX >= 2 && wp <= 64)
+        sweep(std::integral_constant<int, (RPL_MAX >= 2 ? 2 : 1)>{});
+    else
+        sweep(std::integral_constant<int, 1>{});
     const int64_t cb = A.range_colbase[S] + ch * cw;
     // destinations first: the chunk's (<= 128) indices in two coalesced loads, handed to the lanes by shuffles.  With the index fetched
     // under each store's own predicate the compiler emits load -> vmcnt(0) -> store thirty-two times in a row (and it moves plain
