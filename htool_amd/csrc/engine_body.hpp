@@ -1520,7 +1520,15 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
             }
             if (RA.ntasks > 0) {
                 if (staged)
-                    hipLaunchKernelGGL((reduce_mfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
+                {
+                    static const int rw = getenv("HMX_MFMA_REDUCE_WAVES") ? atoi(getenv("HMX_MFMA_REDUCE_WAVES")) : 4; // tasks (= waves) per workgroup (A/B runs)
+                    if (rw == 1)
+                        hipLaunchKernelGGL((reduce_mfma16s_kernel<1>), dim3(RA.ntasks), dim3(64), 0, st, RA, mu, c, nrhs);
+                    else if (rw == 2)
+                        hipLaunchKernelGGL((reduce_mfma16s_kernel<2>), dim3((RA.ntasks + 1) / 2), dim3(128), 0, st, RA, mu, c, nrhs);
+                    else
+                        hipLaunchKernelGGL((reduce_mfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
+                }
                 else
                     hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
             }
@@ -1569,7 +1577,15 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
             static const int staged = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1; // stream tile through LDS (whole-column loads)
             if (XA.nranges > 0) {
                 if (staged)
-                    hipLaunchKernelGGL((expand_mfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
+                {
+                    static const int xw = getenv("HMX_MFMA_EXPAND_WAVES") ? atoi(getenv("HMX_MFMA_EXPAND_WAVES")) : 4; // waves per row range (A/B runs)
+                    if (xw == 2)
+                        hipLaunchKernelGGL((expand_mfma16s_kernel<2>), dim3(XA.nranges), dim3(128), 0, st, XA, mu, c, nrhs);
+                    else if (xw == 8)
+                        hipLaunchKernelGGL((expand_mfma16s_kernel<8>), dim3(XA.nranges), dim3(512), 0, st, XA, mu, c, nrhs);
+                    else
+                        hipLaunchKernelGGL((expand_mfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
+                }
                 else
                     hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
             }
