@@ -82,7 +82,7 @@ while time.time() - t0 < budget:
         e = rel(y, ref)
         worst = max(worst, e if not single else 0.0)
         assert e < tol, ("matvec", trans, e, cfg)
-        mu = int(rng.choice([2, 5, 16, 19]))
+        mu = int(rng.choice([2, 3, 5, 7, 8, 11, 16, 19]))
         X = (rng.standard_normal((nin, mu)) + (1j * rng.standard_normal((nin, mu)) if cplx else 0)).astype(dt)
         Y0 = (rng.standard_normal((nout, mu)) + (1j * rng.standard_normal((nout, mu)) if cplx else 0)).astype(dt)
         Y = Y0.copy()
