@@ -39,7 +39,7 @@ def code_object(tmp_path):
 def test_staged_matrix_core_kernels_issue_their_loads_back_to_back(tmp_path):
     co = code_object(tmp_path)
     syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", co], capture_output=True, text=True, check=True).stdout
-    names = sorted(set(re.findall(r"FUNC.* (\S*(?:mfma16s|zmfma8s)_kernel\S*)$", syms, flags=re.M)))
+    names = sorted(set(re.findall(r"FUNC.* (\S*(?:mfma16s|zmfma8s)_kernelILi4E\S*)$", syms, flags=re.M)))  # the default: 4 waves per workgroup
     assert len(names) == 8, names  # expand + reduce, real (f64, f32) and complex (z64, c32)
     for sym in names:
         asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, co], capture_output=True, text=True, check=True).stdout
@@ -54,3 +54,32 @@ def test_staged_matrix_core_kernels_issue_their_loads_back_to_back(tmp_path):
             # reduce stage: the 32 (64 for complex double) predicated stores of the write-out are branches, but the loop waits for
             # nothing but its own tile, and the destinations are fetched before the stores
             assert drained <= 12, (sym, drained)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="llvm-objdump not installed")
+def test_single_vector_kernels_keep_their_occupancy_and_load_shape(tmp_path):
+    """The headline kernels: registers (eight waves per SIMD for the expand stage, at least seven for the reduce stage), no scratch, the
+    stream loads of the main loops as wide as they were tuned to be (fp64: 16-byte loads in the reduce stage, one 8-byte column entry per
+    lane in the expand stage)."""
+    co = code_object(tmp_path)
+    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    meta = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1)) for k in ("vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+    checked = 0
+    for name, m in meta.items():
+        if re.search(r"3(f64|f32|z64|c32)13expand_kernelILi\d", name):
+            assert m["private_segment_fixed_size"] == 0 and m["vgpr_count"] <= 64, (name, m)  # 8 waves per SIMD
+            checked += 1
+        if re.search(r"3(f64|f32)13reduce_kernelILi\d", name):
+            assert m["private_segment_fixed_size"] == 0 and m["vgpr_count"] <= 72, (name, m)  # 7 waves per SIMD
+            checked += 1
+        if re.search(r"3f64(17expand_sym_kernel|13rowsym_kernel)", name):
+            assert m["private_segment_fixed_size"] == 0, (name, m)
+            checked += 1
+    assert checked >= 20, checked
+    for sym, op, least in (("_ZN3hmx3f6413reduce_kernelILi1EEEvNS0_10ReduceArgsE", "global_load_dwordx4", 8), ("_ZN3hmx3f6413expand_kernelILi4EEEvNS0_10ExpandArgsE", "global_load_dwordx2", 8)):
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, co], capture_output=True, text=True, check=True).stdout
+        ops = collections.Counter(l.split()[0] for l in asm.split("\n") if l.startswith("\t"))
+        assert ops[op] >= least, (sym, op, ops[op])
