@@ -452,7 +452,7 @@ def main():
     graphed = False
     if native is not None:
         # untimed: the result must equal the torch.distributed layer's, then the variants of the output exchange are tried for a few
-        # steps each and the fastest becomes the timed region: one exchange after the product or (single vector) the expand stage in
+        # steps each and the fastest becomes the timed region: one exchange after the product or the expand stage in
         # 2 / 4 row chunks with every chunk's exchange on a side stream under the next chunk's kernel; each as an all-gather / grouped
         # broadcasts or pairwise (grouped ncclSend / ncclRecv: one xGMI link per pair on a fully connected node).
         # HMX_DIST_OVERLAP=<chunks> and HMX_DIST_P2P=0/1 pin the choice.
@@ -477,7 +477,7 @@ def main():
             native, dist_info = None, dict(impl="python (torch.distributed); native result mismatch")
         else:
             pin_c, pin_p = os.environ.get("HMX_DIST_OVERLAP"), os.environ.get("HMX_DIST_P2P")
-            chunk_choices = [int(pin_c)] if pin_c is not None else ([0, 2, 4] if mu == 1 else [0])
+            chunk_choices = [int(pin_c)] if pin_c is not None else [0, 2, 4]
             p2p_choices = [bool(int(pin_p))] if pin_p is not None else [False, True]
             trials = {}
 
@@ -508,6 +508,12 @@ def main():
                     continue
                 for chunks in chunk_choices:
                     used = native.set_overlap(chunks, like=out)
+                    if mu > 1 and chunks > 1:
+                        # several right-hand sides: the row chunks of THEIR layout are agreed on inside the first product (the expanded
+                        # view of a compact symmetric operator can be chunked where its fused single-vector product cannot)
+                        step()
+                        torch.cuda.synchronize()
+                        used = native.overlap_chunks_multi()
                     if chunks > 1 and used != chunks:
                         continue  # some rank's operator cannot be chunked
                     time_variant((chunks, p2p, False), "%d%s" % (chunks, "+p2p" if p2p else ""))

@@ -137,6 +137,7 @@ SYMBOLS = [
     ("hmx_dist_last_exchange_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("hmx_dist_set_overlap", C.c_int, [_vp, C.c_int, _vp]),
     ("hmx_dist_overlap_chunks", C.c_int, [_vp]),
+    ("hmx_dist_overlap_chunks_multi", C.c_int, [_vp]),
     ("hmx_dist_set_reduce_scatter", C.c_int, [_vp, _vp]),
     ("hmx_dist_set_point_to_point", C.c_int, [_vp, _vp, _vp, C.c_int]),
     ("hmx_hmatrix_last_kernel_times", C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),

@@ -899,6 +899,11 @@ struct hmx_dist {
     int overlap = 0;                  // requested number of chunks (0 / 1: off)
     int nchunks = 0;                  // chunks in use (the same on every rank)
     std::vector<int32_t> bounds;      // [rank][chunk]: first local row of chunk c on rank k; (nchunks + 1) entries per rank
+    // the same for products with several right-hand sides: their expand stage may run on another layout (the expanded view of a compact
+    // symmetric operator), whose row chunks are others; exchanged at the first such product after hmx_dist_set_overlap
+    int nchunks_mu = 0;
+    bool mu_bounds_known = false;
+    std::vector<int32_t> bounds_mu;
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> chunk_ev;
     hipEvent_t join_ev = nullptr;
@@ -1088,18 +1093,48 @@ static int dist_chunk_bounds(hmx_dist &D, int nchunks, int *n, int32_t *b) {
         return hmx::z64::api_chunk_bounds(H->z, nchunks, n, b);
     return hmx::c32::api_chunk_bounds(H->c, nchunks, n, b);
 }
+static int dist_chunk_bounds_mu(hmx_dist &D, int nchunks, int *n, int32_t *b) {
+    hmx_hmatrix *H = D.local;
+    if (!H || D.diag) {
+        *n   = 1;
+        b[0] = 0;
+        b[1] = D.t_size[D.rank];
+        return HMX_OK;
+    }
+    if (H->d)
+        return hmx::f64::api_chunk_bounds_mu(H->d, nchunks, n, b);
+    if (H->s)
+        return hmx::f32::api_chunk_bounds_mu(H->s, nchunks, n, b);
+    if (H->z)
+        return hmx::z64::api_chunk_bounds_mu(H->z, nchunks, n, b);
+    return hmx::c32::api_chunk_bounds_mu(H->c, nchunks, n, b);
+}
+static int dist_local_matmat_chunked(hmx_dist &D, const void *alpha, const void *in, const void *beta, void *out, int mu, hipStream_t st, int nchunks, void (*after)(void *, int, int, int),
+                                     void *user, int *used) {
+    hmx_hmatrix *H = D.local;
+    if (H->d)
+        return hmx::f64::api_matmat_chunked(H->d, *static_cast<const double *>(alpha), static_cast<const double *>(in), *static_cast<const double *>(beta), static_cast<double *>(out), mu, st, nchunks,
+                                            after, user, used);
+    if (H->s)
+        return hmx::f32::api_matmat_chunked(H->s, *static_cast<const float *>(alpha), static_cast<const float *>(in), *static_cast<const float *>(beta), static_cast<float *>(out), mu, st, nchunks, after,
+                                            user, used);
+    if (H->z)
+        return hmx::z64::api_matmat_chunked(H->z, zval(static_cast<const double *>(alpha)), ZP(in), zval(static_cast<const double *>(beta)), ZPM(out), mu, st, nchunks, after, user, used);
+    return hmx::c32::api_matmat_chunked(H->c, cval(static_cast<const float *>(alpha)), CP(in), cval(static_cast<const float *>(beta)), CPM(out), mu, st, nchunks, after, user, used);
+}
 // rows [bounds[k][c], bounds[k][c + 1]) of every rank k's slice -> their place in `out`: one grouped broadcast per rank (the chunks
-// of different ranks have different sizes and are not adjacent in `out`, so this is not an ncclAllGather)
-static int dist_gather_chunk(hmx_dist &D, int c, const char *local, char *out, hipStream_t st) {
-    const int nb = D.nchunks + 1;
+// of different ranks have different sizes and are not adjacent in `out`, so this is not an ncclAllGather).  `per`: right-hand sides
+// (the rows of a row-major matrix are mu-interleaved: the same exchange with mu times the counts); `bounds`, `nchunks`: D.bounds / D.bounds_mu
+static int dist_gather_chunk(hmx_dist &D, const std::vector<int32_t> &bounds, int nchunks, int c, const char *local, char *out, size_t per, hipStream_t st) {
+    const int nb = nchunks + 1;
     if (D.p2p)
-        return dist_exchange_p2p(D, D.t_off, D.bounds.data() + c, D.bounds.data() + c + 1, nb, local, out, 1, st);
+        return dist_exchange_p2p(D, D.t_off, bounds.data() + c, bounds.data() + c + 1, nb, local, out, per, st);
     HMX_NCCL(D.api.group_start());
     for (int k = 0; k < D.world; k++) {
-        const int lo = D.bounds[(size_t)k * nb + c], hi = D.bounds[(size_t)k * nb + c + 1];
+        const int lo = bounds[(size_t)k * nb + c], hi = bounds[(size_t)k * nb + c + 1];
         if (hi <= lo)
             continue;
-        HMX_NCCL(D.api.broadcast(local + (size_t)(k == D.rank ? lo : 0) * D.esz, out + (size_t)(D.t_off[k] + lo) * D.esz, (size_t)(hi - lo) * D.reals, D.dtype, k, D.comm, st));
+        HMX_NCCL(D.api.broadcast(local + (size_t)(k == D.rank ? lo : 0) * D.esz * per, out + (size_t)(D.t_off[k] + lo) * D.esz * per, (size_t)(hi - lo) * D.reals * per, D.dtype, k, D.comm, st));
     }
     HMX_NCCL(D.api.group_end());
     return HMX_OK;
@@ -1108,6 +1143,9 @@ struct DistChunkCtx {
     hmx_dist *D;
     const char *local;
     char *out;
+    size_t per                         = 1;       // right-hand sides
+    const std::vector<int32_t> *bounds = nullptr; // D.bounds or D.bounds_mu
+    int nchunks                        = 0;
 };
 // called on the host right after chunk c of the expand stage was launched on the caller's stream: its exchange goes to the side stream
 static void dist_after_chunk(void *user, int c, int row_lo, int row_hi) {
@@ -1117,9 +1155,10 @@ static void dist_after_chunk(void *user, int c, int row_lo, int row_hi) {
         return;
     // the rows this chunk really covered must be the ones every rank was told at hmx_dist_set_overlap: a re-laid-out local operator
     // (recompress, release_factors with a view, a new build) recomputes its chunk plan, and peers would receive stale row ranges
-    const int nb = D.nchunks + 1;
-    if (c < 0 || c >= D.nchunks || row_lo != D.bounds[(size_t)D.rank * nb + c] || row_hi != D.bounds[(size_t)D.rank * nb + c + 1]) {
-        set_error("hmx_dist_matvec_global_to_global: the local operator was re-laid out since hmx_dist_set_overlap (chunk rows differ); call it again");
+    const std::vector<int32_t> &B = *X.bounds;
+    const int nb                  = X.nchunks + 1;
+    if (c < 0 || c >= X.nchunks || row_lo != B[(size_t)D.rank * nb + c] || row_hi != B[(size_t)D.rank * nb + c + 1]) {
+        set_error("hmx_dist (overlapped product): the local operator was re-laid out since hmx_dist_set_overlap (chunk rows differ); call it again");
         D.cb_rc = HMX_ERR_STATE;
         return;
     }
@@ -1127,7 +1166,7 @@ static void dist_after_chunk(void *user, int c, int row_lo, int row_hi) {
         D.cb_rc = HMX_ERR_HIP;
         return;
     }
-    D.cb_rc = dist_gather_chunk(D, c, X.local, X.out, D.side);
+    D.cb_rc = dist_gather_chunk(D, B, X.nchunks, c, X.local, X.out, X.per, D.side);
 }
 
 
@@ -1229,21 +1268,13 @@ extern "C" {
 // computes; the caller's stream then waits for the last exchange.  COLLECTIVE: every rank calls it with the same value (the ranks
 // exchange their chunk boundaries; an operator that cannot be chunked -- fused symmetric storage -- makes all ranks fall back to one
 // exchange after the product).  chunks <= 1 switches it off (the default: hmx_dist_create is not collective, this function is).
-int hmx_dist_set_overlap(hmx_dist *Dp, int chunks, void *stream) {
-    if (!Dp) {
-        set_error("hmx_dist_set_overlap: NULL handle");
-        return HMX_ERR_INVALID;
-    }
-    hmx_dist &D = *Dp;
-    D.overlap   = chunks > 1 ? chunks : 0;
-    D.nchunks   = 0;
-    if (!D.overlap || (D.world == 1 && !D.force))
-        return HMX_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const int nb   = chunks + 1;
+// every rank's chunk bounds of one layout (multi = false: the single-vector product's, true: the multi-RHS product's), agreed on by all
+// ranks: *nchunks_out = chunks when every rank can chunk its product that way, 0 otherwise (the collectives must match)
+static int dist_exchange_bounds(hmx_dist &D, int chunks, bool multi, hipStream_t st, int *nchunks_out, std::vector<int32_t> &bounds) {
+    const int nb = chunks + 1;
     std::vector<int32_t> mine(nb, 0);
-    int n = 1;
-    int rc = dist_chunk_bounds(D, chunks, &n, mine.data());
+    int n  = 1;
+    int rc = multi ? dist_chunk_bounds_mu(D, chunks, &n, mine.data()) : dist_chunk_bounds(D, chunks, &n, mine.data());
     if (rc != HMX_OK)
         return rc;
     // every rank sends (n, bounds[0..chunks]) as doubles (exact; the mock communicators of the tests only know float types)
@@ -1262,15 +1293,15 @@ int hmx_dist_set_overlap(hmx_dist *Dp, int chunks, void *stream) {
     bool all_chunked = true;
     for (int k = 0; k < D.world; k++)
         all_chunked = all_chunked && (int)recv[(size_t)k * (nb + 1)] == chunks;
-    if (!all_chunked) { // some rank cannot chunk its product: nobody does (the collectives must match)
-        D.nchunks = 0;
+    if (!all_chunked) { // some rank cannot chunk its product: nobody does
+        *nchunks_out = 0;
         return HMX_OK;
     }
-    D.nchunks = chunks;
-    D.bounds.assign((size_t)nb * D.world, 0);
+    *nchunks_out = chunks;
+    bounds.assign((size_t)nb * D.world, 0);
     for (int k = 0; k < D.world; k++)
         for (int c = 0; c < nb; c++)
-            D.bounds[(size_t)k * nb + c] = (int32_t)recv[(size_t)k * (nb + 1) + 1 + c];
+            bounds[(size_t)k * nb + c] = (int32_t)recv[(size_t)k * (nb + 1) + 1 + c];
     if (!D.side)
         HMX_HIP(hipStreamCreateWithFlags(&D.side, hipStreamNonBlocking));
     while ((int)D.chunk_ev.size() < chunks) {
@@ -1282,7 +1313,22 @@ int hmx_dist_set_overlap(hmx_dist *Dp, int chunks, void *stream) {
         HMX_HIP(hipEventCreateWithFlags(&D.join_ev, hipEventDisableTiming));
     return HMX_OK;
 }
+int hmx_dist_set_overlap(hmx_dist *Dp, int chunks, void *stream) {
+    if (!Dp) {
+        set_error("hmx_dist_set_overlap: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    hmx_dist &D       = *Dp;
+    D.overlap         = chunks > 1 ? chunks : 0;
+    D.nchunks         = 0;
+    D.nchunks_mu      = 0;
+    D.mu_bounds_known = false; // exchanged by the first product with several right-hand sides (its layout may have to be built first)
+    if (!D.overlap || (D.world == 1 && !D.force))
+        return HMX_OK;
+    return dist_exchange_bounds(D, chunks, false, (hipStream_t)stream, &D.nchunks, D.bounds);
+}
 int hmx_dist_overlap_chunks(const hmx_dist *D) { return D ? D->nchunks : 0; }
+int hmx_dist_overlap_chunks_multi(const hmx_dist *D) { return (D && D->mu_bounds_known) ? D->nchunks_mu : 0; }
 /* ncclReduceScatter for the transposed local-to-local product when the communicator table was given by the caller */
 int hmx_dist_set_reduce_scatter(hmx_dist *D, int (*fn)(const void *, void *, size_t, int, int, void *, void *)) {
     if (!D)
@@ -1469,7 +1515,7 @@ int hmx_dist_matvec_global_to_global(hmx_dist *Dp, char trans, const void *alpha
             HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
         if (D.nchunks > 1 && (D.world > 1 || D.force)) {
             // chunked expand stage on `st`, each chunk's exchange on the side stream under the next chunk's kernel
-            DistChunkCtx ctx{&D, D.work.d, yb};
+            DistChunkCtx ctx{&D, D.work.d, yb, 1, &D.bounds, D.nchunks};
             D.cur_stream = st;
             D.cb_rc      = HMX_OK;
             HMX_HIP(hipEventRecord(D.join_ev, st)); // the side stream must not run ahead of what `st` did to y before this call
@@ -1550,6 +1596,38 @@ int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const v
             HMX_HIP(D.work.alloc((size_t)n * e));
         if (!dist_beta_is_zero(D, beta))
             HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
+        if (D.overlap > 1 && mu > 1 && (D.world > 1 || D.force) && D.local && !D.diag) {
+            // expand stage in row chunks on `st`, every chunk's (mu-interleaved) rows exchanged on the side stream under the next chunk's
+            // kernels -- hmx_dist_matvec_global_to_global's scheme; the chunk rows of the multi-RHS layout are agreed on at the first call
+            if (!D.mu_bounds_known) {
+                const int rc0 = dist_exchange_bounds(D, D.overlap, true, st, &D.nchunks_mu, D.bounds_mu);
+                if (rc0 != HMX_OK)
+                    return rc0;
+                D.mu_bounds_known = true;
+            }
+            if (D.nchunks_mu > 1) {
+                DistChunkCtx ctx{&D, D.work.d, yb, (size_t)mu, &D.bounds_mu, D.nchunks_mu};
+                D.cur_stream = st;
+                D.cb_rc      = HMX_OK;
+                HMX_HIP(hipEventRecord(D.join_ev, st));
+                HMX_HIP(hipStreamWaitEvent(D.side, D.join_ev, 0));
+                int used = 0;
+                int rc   = dist_local_matmat_chunked(D, alpha, X, beta, D.work.d, mu, st, D.nchunks_mu, dist_after_chunk, &ctx, &used);
+                // exchanges already enqueued on the side stream read D.work and write Y: the caller's stream joins them on every exit path
+                const hipError_t j1 = hipEventRecord(D.join_ev, D.side), j2 = hipStreamWaitEvent(st, D.join_ev, 0);
+                if (rc != HMX_OK)
+                    return rc;
+                if (D.cb_rc != HMX_OK)
+                    return D.cb_rc;
+                if (used != D.nchunks_mu) {
+                    set_error("hmx_dist_matmat_row_major_global_to_global: the local operator changed since hmx_dist_set_overlap");
+                    return HMX_ERR_STATE;
+                }
+                HMX_HIP(j1);
+                HMX_HIP(j2);
+                return HMX_OK;
+            }
+        }
         int rc = dist_local_matmat(D, 'N', alpha, X, beta, D.work.d, mu, st);
         if (rc != HMX_OK)
             return rc;

@@ -1447,7 +1447,8 @@ static void launch_mu_expand(HMat &H, ExpandArgs &XA, int mu, int cbase, hipStre
 }
 
 // Fused multi-RHS forward pass (trans='N', no mirror leaves): Y = alpha * H * X + beta * Y, X and Y row-major.
-static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
+static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st, int nchunks = 0, after_chunk_fn after_chunk = nullptr,
+                          void *after_user = nullptr) {
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
         HMX_HIP(H.Zmu.alloc(need));
@@ -1553,7 +1554,7 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         hipLaunchKernelGGL(combine_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, mu);
         prof_mark(H, st, "combine_mu_kernel");
     }
-    for_groups([&](int g, int c, int nrhs) {
+    auto expand_group = [&](int g, int c, int nrhs) {
         (void)nrhs;
 #if HMX_COMPLEX
         if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
@@ -1602,7 +1603,26 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         case 2: launch_mu_expand<2>(H, XA, mu, c, st); break;
         default: launch_mu_expand<1>(H, XA, mu, c, st); break;
         }
-    });
+    };
+    if (nchunks > 1 && H.E.nranges() > 1 && H.n_grp == 0) {
+        // the expand stage over contiguous groups of row ranges, all groups of right-hand sides per chunk: after chunk c its rows of Y are
+        // final and `after_chunk` may start sending them while chunk c + 1 computes (as run_forward does for one vector)
+        const int rc = ensure_expand_chunks(H, nchunks);
+        if (rc != HMX_OK)
+            return rc;
+        for (int c = 0; c < H.chunk_plan_n; c++) {
+            XA.order   = H.d_chunk_order.d + H.chunk_first[c];
+            XA.nranges = H.chunk_count[c];
+            if (XA.nranges > 0)
+                for_groups(expand_group);
+            if (after_chunk)
+                after_chunk(after_user, c, H.chunk_row_lo[c], H.chunk_row_hi[c]);
+        }
+    } else {
+        for_groups(expand_group);
+        if (after_chunk)
+            after_chunk(after_user, 0, 0, H.nT);
+    }
     HMX_HIP(hipGetLastError());
     return HMX_OK;
 }
@@ -3106,6 +3126,71 @@ static int api_chunk_bounds(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) 
     for (int c = 0; c < H.chunk_plan_n; c++)
         bounds[c] = H.chunk_row_lo[c];
     bounds[H.chunk_plan_n] = H.nT;
+    return HMX_OK;
+}
+
+static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, scalar beta, scalar *dout, int mu, hipStream_t st);
+// The layout a trans = 'N' product with several right-hand sides runs on: the operator's own streams, or (compact symmetric storage) its
+// expanded view -- same rows, its own row ranges.  nullptr: no fused multi-RHS path (one pass per right-hand side).
+static HMat *matmat_layout_n(HMat &H) {
+    if (!(H.finalized && (!H.has_mirror || H.sym_expanded || H.sym_fused) && !getenv("HMX_NO_FUSED_MU")))
+        return nullptr;
+    return H.sym_fused ? ensure_expanded_view(H) : &H;
+}
+// api_matvec_chunked for mu right-hand sides (row-major, device pointers, trans = 'N'): after_chunk(user, c, row_lo, row_hi) is called on the
+// host right after the expand kernels of row chunk c (all groups of right-hand sides) were launched on `stream`.
+static int api_matmat_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, void *stream, int nchunks, after_chunk_fn after_chunk, void *user, int *used) {
+    if (!Hp || !in || !out || mu < 1) {
+        set_error("hmx_hmatrix_matmat_row_major (chunked): invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!H.finalized) {
+        set_error("hmx_hmatrix_matmat_row_major: operator not built (call hmx_hmatrix_compress or hmx_hmatrix_finalize first)");
+        return HMX_ERR_STATE;
+    }
+    HMat *F = nchunks > 1 ? matmat_layout_n(H) : nullptr;
+    if (!F || F->E.nranges() <= 1 || F->n_grp != 0) {
+        const int rc = matmat_device(H, 'N', alpha, in, beta, out, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        if (after_chunk)
+            after_chunk(user, 0, 0, H.nT);
+        if (used)
+            *used = 1;
+        return HMX_OK;
+    }
+    F->ev_names.clear();
+    const bool prof = F->profiling;
+    F->profiling    = false; // per-kernel events make no sense with interleaved collectives
+    const int rc    = run_forward_mu(*F, in, alpha, beta, out, mu, st, nchunks, after_chunk, user);
+    F->profiling    = prof;
+    if (used)
+        *used = F->chunk_plan_n;
+    return rc;
+}
+// row bounds of the chunks api_matmat_chunked will use (they differ from the single-vector ones when the product runs on the expanded view)
+static int api_chunk_bounds_mu(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) {
+    if (!Hp || !n_out || !bounds)
+        return HMX_ERR_INVALID;
+    HMat &H = *Hp;
+    HMX_HIP(hipSetDevice(H.device));
+    HMat *F = (nchunks > 1 && H.finalized) ? matmat_layout_n(H) : nullptr;
+    if (!F || F->E.nranges() <= 1 || F->n_grp != 0) {
+        *n_out    = 1;
+        bounds[0] = 0;
+        bounds[1] = H.nT;
+        return HMX_OK;
+    }
+    const int rc = ensure_expand_chunks(*F, nchunks);
+    if (rc != HMX_OK)
+        return rc;
+    *n_out = F->chunk_plan_n;
+    for (int c = 0; c < F->chunk_plan_n; c++)
+        bounds[c] = F->chunk_row_lo[c];
+    bounds[F->chunk_plan_n] = H.nT;
     return HMX_OK;
 }
 

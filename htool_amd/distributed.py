@@ -582,6 +582,11 @@ class NativeDistributedOperator:
         check(self._L.hmx_dist_set_overlap(self._h, int(chunks), st))
         return int(self._L.hmx_dist_overlap_chunks(self._h))
 
+    def overlap_chunks_multi(self):
+        """Row chunks in use for trans='N' products with SEVERAL right-hand sides (hmx_dist_overlap_chunks_multi): agreed on inside the first
+        such product after set_overlap; 0 before that, or when some rank's multi-RHS layout cannot be chunked."""
+        return int(self._L.hmx_dist_overlap_chunks_multi(self._h))
+
     def set_output_collective(self, all_reduce):
         """trans='N' global-to-global products: exchange of the output slices (False, default) or ncclAllReduce of the zero-padded
         output vector (True): hmx_dist_set_output_collective.  Every rank must choose the same."""

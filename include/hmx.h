@@ -345,6 +345,13 @@ int hmx_dist_gmv(hmx_dist *, const void *in, void *out, int mu, int dof, void *s
  * all ranks keep the single exchange after the product; hmx_dist_overlap_chunks tells.  chunks <= 1: off (the default). */
 int hmx_dist_set_overlap(hmx_dist *, int chunks, void *stream);
 int hmx_dist_overlap_chunks(const hmx_dist *);
+/* The same for hmx_dist_matmat_row_major_global_to_global with mu > 1, trans = 'N' (BASELINE configs[4]: 16 right-hand sides on 8 GPUs
+ * exchange 32 MB per rank and product): the expand kernels of ALL groups of right-hand sides run chunk by chunk, the chunk's
+ * mu-interleaved rows are exchanged on the side stream.  The row chunks are those of the layout the multi-RHS product runs on (the
+ * expanded view of a compact symmetric operator is chunkable where its fused single-vector product is not); the ranks agree on them
+ * inside the FIRST such product after hmx_dist_set_overlap (collective, like the product itself).  hmx_dist_overlap_chunks_multi:
+ * the chunks in use for multi-RHS products (0: not yet exchanged, or some rank cannot chunk). */
+int hmx_dist_overlap_chunks_multi(const hmx_dist *);
 /* ncclReduceScatter (same argument shapes as rccl.h) for the transposed local-to-local product (MPI_Alltoallv + axpys of
  * local_to_local.hpp:77) when the collective table was given by the caller; with a NULL table it is taken from librccl.so.
  * Without it, or with unequal partitions, that product uses all-reduce + slice. */

@@ -280,29 +280,40 @@ MOCK_SCRIPT = textwrap.dedent('''
             check(L.hmx_dist_set_output_collective(D, 0))
             check(L.hmx_dist_set_profiling(D, 0))
         # row-major multi-RHS global-to-global products (mu = 3): exchange of mu-interleaved row slices / all-reduce of the whole matrix
+        # last field: the overlapped exchange for several right-hand sides (expand stage of ALL groups of right-hand sides in row chunks,
+        # every chunk's mu-interleaved rows exchanged on the side stream; mu = 19: two groups, 16 + a ragged 3)
+        for mu, variants in ((3, (("N", 0, 0), ("T", 0, 0), ("N", 1, 0), ("N", 0, 3), ("N", 1, 2))), (19, (("N", 0, 2), ("N", 0, 0)))):
+            X = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
+            Y0 = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
+            for trans, p2p, overlap in variants:
+                for D in Ds:
+                    check(L.hmx_dist_set_point_to_point(D, None, None, p2p))
+                ref = Y0.copy()
+                hm.internal_add_hmatrix_matrix_product_row_major(trans, ab[0], Hfull, X, ab[1], ref, mu)
+                errs, fails = [None] * WORLD, []
+                def mm_rank(k):
+                    try:
+                        dx, dy = dev(X), dev(Y0)
+                        check(L.hmx_dist_set_overlap(Ds[k], overlap, None))
+                        for rep in range(2):  # the second call reuses the chunk rows agreed on by the first
+                            dy = dev(Y0)
+                            check(L.hmx_dist_matmat_row_major_global_to_global(Ds[k], trans.encode(), pa, dx, pb, dy, mu, None))
+                            assert hip.hipDeviceSynchronize() == 0
+                        assert L.hmx_dist_overlap_chunks_multi(Ds[k]) == overlap, (L.hmx_dist_overlap_chunks_multi(Ds[k]), overlap)
+                        errs[k] = np.linalg.norm(host(dy, Y0) - ref) / np.linalg.norm(ref)
+                    except BaseException as e:
+                        fails.append(e)
+                        barrier.abort()
+                th = [threading.Thread(target=mm_rank, args=(k,)) for k in range(WORLD)]
+                [t.start() for t in th]
+                [t.join() for t in th]
+                assert not fails, fails
+                assert max(errs) < 1e-12, (np.dtype(dtype).name, "matmat", trans, mu, overlap, errs)
+        for D in Ds:
+            check(L.hmx_dist_set_overlap(D, 0, None))
         mu = 3
         X = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
         Y0 = (rng.standard_normal((n, mu)) + (1j * rng.standard_normal((n, mu)) if cplx else 0)).astype(dtype)
-        for trans, p2p in (("N", 0), ("T", 0), ("N", 1)):
-            for D in Ds:
-                check(L.hmx_dist_set_point_to_point(D, None, None, p2p))
-            ref = Y0.copy()
-            hm.internal_add_hmatrix_matrix_product_row_major(trans, ab[0], Hfull, X, ab[1], ref, mu)
-            errs, fails = [None] * WORLD, []
-            def mm_rank(k):
-                try:
-                    dx, dy = dev(X), dev(Y0)
-                    check(L.hmx_dist_matmat_row_major_global_to_global(Ds[k], trans.encode(), pa, dx, pb, dy, mu, None))
-                    assert hip.hipDeviceSynchronize() == 0
-                    errs[k] = np.linalg.norm(host(dy, Y0) - ref) / np.linalg.norm(ref)
-                except BaseException as e:
-                    fails.append(e)
-                    barrier.abort()
-            th = [threading.Thread(target=mm_rank, args=(k,)) for k in range(WORLD)]
-            [t.start() for t in th]
-            [t.join() for t in th]
-            assert not fails, fails
-            assert max(errs) < 1e-12, (np.dtype(dtype).name, "matmat", trans, errs)
         # row-major multi-RHS LOCAL-TO-LOCAL product (HPDDMOperator::GMV's call for mu != 1): all-gather of the mu-interleaved rows of X /
         # reduce-scatter of mu * n rows; against the rows of the whole operator's product and against mu single-vector local-to-local products
         for trans in ("N", "T"):
@@ -434,6 +445,30 @@ MOCK_SCRIPT = textwrap.dedent('''
             fails.append(e)
             barrier.abort()
     th = [threading.Thread(target=sym_rank, args=(k,)) for k in range(WORLD)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not fails, fails
+    assert max(errs) < 1e-12, errs
+    # ... but the product with SEVERAL right-hand sides runs on the expanded view of every rank's operator, which has an expand stage like
+    # any other: it is chunked (its own row chunks, agreed on inside the first product) and the chunks' rows are exchanged on the side stream
+    mu = 5
+    X, Y0 = rng.standard_normal((n, mu)), rng.standard_normal((n, mu))
+    ref = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major("N", ab[0], Hfull, X, ab[1], ref, mu)
+    errs, fails = [None] * WORLD, []
+    def sym_mm_rank(k):
+        try:
+            dx = dev(X)
+            for rep in range(2):
+                dy = dev(Y0)
+                check(L.hmx_dist_matmat_row_major_global_to_global(Ds[k], b"N", pa, dx, pb, dy, mu, None))
+                assert hip.hipDeviceSynchronize() == 0
+            assert L.hmx_dist_overlap_chunks(Ds[k]) == 0 and L.hmx_dist_overlap_chunks_multi(Ds[k]) == 3
+            errs[k] = np.linalg.norm(host(dy, Y0) - ref) / np.linalg.norm(ref)
+        except BaseException as e:
+            fails.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=sym_mm_rank, args=(k,)) for k in range(WORLD)]
     [t.start() for t in th]
     [t.join() for t in th]
     assert not fails, fails
