@@ -1494,6 +1494,11 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
 #else
             if (stage_on && use_mfma && ((left >= 9 && left < 16) || odd_tail))
                 g = 16, n = left;
+            // 17 and more: sweeps of up to 32 right-hand sides (every tile element read from LDS feeds two MFMAs; the sweep is matrix-core
+            // bound at ~1.2 x the time of a 16-wide one).  HMX_MFMA_WIDE=0: sweeps of 16.
+            static const int wide = getenv("HMX_MFMA_WIDE") ? atoi(getenv("HMX_MFMA_WIDE")) : 1;
+            if (stage_on && use_mfma && wide && left > 16)
+                g = 32, n = left < 32 ? left : 32;
 #endif
             fn(g, c, n);
             c += n;
@@ -1511,6 +1516,12 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         }
 #endif
 #if !HMX_COMPLEX
+        if (g == 32) { // only chosen with the staged matrix-core kernels (for_groups)
+            if (RA.ntasks > 0)
+                hipLaunchKernelGGL((reduce_mfma32s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
+            prof_mark(H, st, "reduce_mfma32s_kernel");
+            return;
+        }
         if (g == 16 && use_mfma) {
             // stream tile through LDS (whole-row loads, HMX_MFMA_STAGE=1: the default) | window of X in LDS (HMX_MU_WINDOW=1) | neither
             static const int staged = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;
@@ -1565,6 +1576,12 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         }
 #endif
 #if !HMX_COMPLEX
+        if (g == 32) {
+            if (XA.nranges > 0)
+                hipLaunchKernelGGL((expand_mfma32s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
+            prof_mark(H, st, "expand_mfma32s_kernel");
+            return;
+        }
         if (g == 16 && use_mfma) {
             // groups of sibling row ranges with the shared operand rows staged once (HMX_MU_GROUPS=0: one workgroup per range)
             static const int stg = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;

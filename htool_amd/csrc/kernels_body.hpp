@@ -2428,6 +2428,119 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
     }
 }
 
+// expand_mfma16s_kernel for groups of up to 32 right-hand sides: every tile element read from LDS feeds two MFMAs (operand sets m and
+// 16 + m), so a sweep over the E-stream serves twice the columns -- at 32 right-hand sides the product needs 8 flops per streamed byte
+// and the matrix cores, not HBM, set the pace (fp64: 82 % of their peak at full HBM speed).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))) void expand_mfma32s_kernel(ExpandArgs A, int mu, int cbase, int nrhs) {
+    constexpr int PITCH = 80; // 64 rows + 16: consecutive tile columns are 32 banks apart, so the 64-bit operand reads (16 rows x 4 columns) do not conflict
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 16 * PITCH > WAVES * WAVE * 16 ? WAVES * 16 * PITCH : WAVES * WAVE * 16];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const real *E       = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4;
+    real(*tile)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 16 * PITCH);
+    const int row      = lane < len ? lane : len - 1; // idle lanes re-read the last row: their tile rows only reach accumulator rows that are never stored
+    // nrhs < 16, a ragged last group: operand column m of the MFMA only reaches result column m, and the columns >= nrhs are never stored, so
+    // their lanes just read a valid element (the group's first right-hand side).  NOT a select on the loaded value: the compiler then moves the
+    // load under an exec-mask branch with a vmcnt(0) behind it (fp32 config 5: 8.4 -> 12.2 ms for this kernel)
+    const int mo = cbase + (m < nrhs ? m : 0), mo2 = cbase + (16 + m < nrhs ? 16 + m : 0);
+    acc4 acc[4], acc2[4]; // right-hand sides 0..15 and 16..31 of the group
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc2[t] = acc4{0, 0, 0, 0};
+    auto load_cols = [&](real(&v)[16], int c) { // 16 whole columns, clamped to the last one (zero operand there)
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int col = c + u < C ? c + u : C - 1;
+            v[u]          = stream_load(E + (int64_t)col * len + row);
+        }
+    };
+    auto operands = [&](real(&b)[8], int c, int zi, int base) { // b[g]: right-hand side m, b[4 + g]: right-hand side 16 + m of operand row g
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int zc   = __shfl(zi, base + 4 * g + kk, WAVE);
+            const real *zr = expand_operand(A, zc, mu);
+            const real bv = zr[mo], bw = zr[mo2];
+            b[g]     = (c + 4 * g + kk < C) ? bv : real(0);
+            b[4 + g] = (c + 4 * g + kk < C) ? bw : real(0);
+        }
+    };
+    auto apply = [&](const real(&v)[16], const real(&b)[8]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            tile[u][lane] = v[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            real a[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                a[t] = tile[4 * g + kk][16 * t + m];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                acc[t]  = mfma16(a[t], b[g], acc[t]); // the tile element is read from LDS once for both halves of the group
+                acc2[t] = mfma16(a[t], b[4 + g], acc2[t]);
+            }
+        }
+    };
+    // wave w takes the 64-column tiles w, w + WAVES, ...; inside a tile four steps of 16 columns, loads one step ahead
+    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
+        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
+        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        real v0[16], v1[16], b0[8], b1[8];
+        load_cols(v0, t0);
+        operands(b0, t0, zi, 0);
+        if (t0 + 16 < tend) {
+            load_cols(v1, t0 + 16);
+            operands(b1, t0 + 16, zi, 16);
+        }
+        apply(v0, b0);
+        if (t0 + 32 < tend) {
+            load_cols(v0, t0 + 32);
+            operands(b0, t0 + 32, zi, 32);
+        }
+        if (t0 + 16 < tend)
+            apply(v1, b1);
+        if (t0 + 48 < tend) {
+            load_cols(v1, t0 + 48);
+            operands(b1, t0 + 48, zi, 48);
+        }
+        if (t0 + 32 < tend)
+            apply(v0, b0);
+        if (t0 + 48 < tend)
+            apply(v1, b1);
+    }
+    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, rhs l & 15): stage as [row][rhs] (the tile buffers are done with),
+    // first the right-hand sides 0..15, then 16..31 through the same buffer
+    real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = half ? acc2[t][j] : acc[t][j];
+        __syncthreads();
+        for (int e = threadIdx.x; e < len * 16; e += WAVES * WAVE) {
+            const int i = e >> 4, c = 16 * half + (e & 15);
+            if (c >= nrhs)
+                continue;
+            real s = red[0][i][e & 15];
+#pragma unroll
+            for (int w = 1; w < WAVES; w++)
+                s += red[w][i][e & 15];
+            real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+            *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        }
+    }
+}
+
 // expand_mfma16_kernel for GROUPS of sibling row ranges.  A low-rank leaf of m rows reaches m / 64 row ranges and every one of them
 // fetches the leaf's rows of `a` again (at N = 1e6 a range has 890 low-rank columns, 16 fp64 right-hand sides: 114 KB of gathered
 // rows per 430 KB of U slices; summed over the ranges every row of `a` is fetched 4.6 times).  The layout orders the columns of a
@@ -2705,6 +2818,108 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
                 if (col < w && m < nrhs)
                     A.Z[(int64_t)dst[t][j] * mu + cbase + m] = acc[t][j];
             }
+}
+
+// reduce_mfma16s_kernel for groups of up to 32 right-hand sides.  Sixteen accumulator tiles (8 column tiles x 2 operand sets) do not fit
+// the registers, so a task walks its rows once per HALF of its (<= 128) columns -- the halves are different coefficients, nothing is read
+// twice -- with 2 rows per wave-wide load (64 columns x 2 rows: every lane busy), 4 column tiles and both operand sets per k-step.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))) void reduce_mfma32s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
+    constexpr int PITCH = 80, RS = 16, KS = 4; // 16 rows per step = 4 k-steps, tile pitch 80 (= 16 mod 32: conflict-free operand reads)
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * RS * PITCH];
+    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES + wv;
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp    = hmx_wp(w);
+    const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const real *xs  = A.x + (int64_t)A.range_off[S] * mu + cbase;
+    const int m = lane & 15, kk = lane >> 4;
+    real *tile   = lds + wv * RS * PITCH;
+    const int mo = m < nrhs ? m : 0, mo2 = 16 + m < nrhs ? 16 + m : 0; // ragged group: see expand_mfma16s_kernel
+    const int rl = lane >> 5, lr = lane & 31;                          // row of the load, column pair in the row
+    const int64_t cb = A.range_colbase[S] + ch * cw;
+    for (int c0 = 0; c0 < w; c0 += 64) { // columns [c0, c0 + 64) of the chunk
+        const int wh    = w - c0 < 64 ? w - c0 : 64;
+        const int ntile = (wh + 15) >> 4;
+        const int c2    = c0 + 2 * lr < wp ? c0 + 2 * lr : c0; // lanes beyond the chunk re-read the half's first pair (their tile columns are never used)
+        acc4 acc[4], acc2[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            acc[t] = acc2[t] = acc4{0, 0, 0, 0};
+        auto load_rows = [&](scalar2(&v)[8], int i0) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = i0 + 2 * u + rl < len ? i0 + 2 * u + rl : len - 1;
+                v[u]          = stream_load(reinterpret_cast<const scalar2 *>(src + (int64_t)row * wp + c2));
+            }
+        };
+        auto operands = [&](real(&b)[2 * KS], int i0) {
+#pragma unroll
+            for (int h = 0; h < KS; h++) {
+                const int row  = i0 + 4 * h + kk;
+                const real *xr = xs + (int64_t)(row < len ? row : len - 1) * mu;
+                const real bv = xr[mo], bw = xr[mo2];
+                b[h]      = row < len ? bv : real(0);
+                b[KS + h] = row < len ? bw : real(0);
+            }
+        };
+        auto apply = [&](const scalar2(&v)[8], const real(&b)[2 * KS]) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                *reinterpret_cast<scalar2 *>(&tile[(2 * u + rl) * PITCH + 2 * lr]) = v[u];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < KS; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < ntile) {
+                        const real a = tile[(4 * h + kk) * PITCH + 16 * t + m];
+                        acc[t]       = mfma16(a, b[h], acc[t]);
+                        acc2[t]      = mfma16(a, b[KS + h], acc2[t]);
+                    }
+        };
+        scalar2 v0[8], v1[8];
+        real b0[2 * KS], b1[2 * KS];
+        load_rows(v0, 0);
+        operands(b0, 0);
+        for (int i0 = 0; i0 < len; i0 += 2 * RS) {
+            if (i0 + RS < len) {
+                load_rows(v1, i0 + RS);
+                operands(b1, i0 + RS);
+            }
+            apply(v0, b0);
+            if (i0 + 2 * RS < len) {
+                load_rows(v0, i0 + 2 * RS);
+                operands(b0, i0 + 2 * RS);
+            }
+            if (i0 + RS < len)
+                apply(v1, b1);
+        }
+        // destinations of the half's columns: one coalesced load, handed out by shuffles (see reduce_mfma16s_kernel)
+        const int32_t ih = A.out_idx[cb + (c0 + lane < w ? c0 + lane : 0)];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (t < ntile)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int cl      = 16 * t + mfma16_row(real(0), lane, j);
+                    const int32_t dst = __shfl(ih, cl, WAVE);
+                    if (c0 + cl < w) {
+                        if (m < nrhs)
+                            A.Z[(int64_t)dst * mu + cbase + m] = acc[t][j];
+                        if (16 + m < nrhs)
+                            A.Z[(int64_t)dst * mu + cbase + 16 + m] = acc2[t][j];
+                    }
+                }
+    }
 }
 
 // reduce_mfma16_kernel with the window's rows of X in LDS (see reduce_win_mu_kernel): the B operand of a step (4 rows x 16

@@ -468,6 +468,57 @@ def test_sixteen_rhs_mfma_path_against_the_oracle(sym, trans):
     assert any("mfma16" in k for k in names), names  # the matrix-core kernels are what ran
 
 
+@pytest.mark.parametrize("mu", [17, 23, 32, 40, 70])
+@pytest.mark.parametrize("sym,trans,f32", [("N", "N", False), ("S", "N", False), ("N", "T", False), ("N", "N", True)])
+def test_sweeps_of_32_right_hand_sides_against_the_oracle(mu, sym, trans, f32, monkeypatch):
+    """More than 16 right-hand sides: sweeps of up to 32 (expand_mfma32s_kernel / reduce_mfma32s_kernel: every tile element feeds two
+    MFMAs; 17 ... 31 as one ragged sweep, 40 = 32 + 8, 70 = 32 + 32 + 6) against the oracle's row-major product on the operator the
+    oracle compressed, and against the 16-wide sweeps (HMX_MFMA_WIDE=0) -- bitwise where those run on the matrix cores for every column
+    (23 = 16 + ragged 7, 32, 70): each result column is then the same sum in the same order."""
+    from oracle import oracle as O
+    n = 3000
+    x = hm.create_geometry("ball", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(70)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    comp = "sympartialACA" if sym == "S" else "partialACA"
+    tb = hm.HMatrixTreeBuilder(1e-6, 10.0, sym, "L" if sym == "S" else "N")
+    tb.set_low_rank_generator(comp)
+    dt = np.float32 if f32 else np.float64
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, dtype=dt)
+    To = O.ClusterTree(x, 70, 2, 2)
+    Ho = O.HMatrix(To, To, eps=1e-6, eta=10.0, sym=sym, uplo="L" if sym == "S" else "N", compressor=comp, f32=f32)
+    X = O.hashed_vector(n * mu, 41).reshape(n, mu).astype(dt)
+    Y0 = O.hashed_vector(n * mu, 42).reshape(n, mu).astype(dt)
+    H.set_profiling(True)
+    Y = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.5, H, X, 0.5, Y, mu)
+    names = [k for k, _ in H.last_kernel_times()]
+    H.set_profiling(False)
+    assert any("mfma32s" in k for k in names), names
+    ref = Ho.matmat_row_major(X.astype(np.float64), trans, 1.5, 0.5, Y0.astype(np.float64))
+    assert rel_err(Y, ref) < (5e-4 if f32 else 1e-12), rel_err(Y, ref)
+    monkeypatch.setenv("HMX_MFMA_WIDE", "0")  # read once per process: a fresh process for the 16-wide sweeps
+    import subprocess, sys, os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "Y.npy"), Y)
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r); import htool_amd as hm; from oracle import oracle as O\n"
+            "n, mu = %d, %d\n"
+            "x = hm.create_geometry('ball', n); b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(70); T = b.create_cluster_tree(n, 3, x, 2, 2)\n"
+            "tb = hm.HMatrixTreeBuilder(1e-6, 10.0, %r, %r); tb.set_low_rank_generator(%r)\n"
+            "H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, dtype=np.%s)\n"
+            "X = O.hashed_vector(n * mu, 41).reshape(n, mu).astype(np.%s); Y = O.hashed_vector(n * mu, 42).reshape(n, mu).astype(np.%s)\n"
+            "H.set_profiling(True); hm.internal_add_hmatrix_matrix_product_row_major(%r, 1.5, H, X, 0.5, Y, mu)\n"
+            "assert not any('mfma32s' in k for k, _ in H.last_kernel_times())\n"
+            "W = np.load(%r); bitwise = %r\n"
+            "assert (np.array_equal(Y, W) if bitwise else np.linalg.norm(Y - W) <= %g * np.linalg.norm(W)), float(np.abs(Y - W).max())\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, mu, sym, "L" if sym == "S" else "N", comp, dt.__name__, dt.__name__, dt.__name__, trans,
+             os.path.join(d, "Y.npy"), mu in (23, 32, 70), 1e-5 if f32 else 1e-13)  # 17 = 16 + 1, 40 = 32 + 8: the 16-wide run finishes on the VALU kernels
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ))
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-5)])
 def test_sixteen_rhs_mfma_path(dtype, tol, monkeypatch):
     """mu = 16 runs on the matrix cores (v_mfma_f64_16x16x4 / v_mfma_f32_16x16x4).  Checked against 16 separate
