@@ -1480,7 +1480,9 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
                                 !(getenv("HMX_MU_GROUPS") && atoi(getenv("HMX_MU_GROUPS")) > 0);
     const bool no_mfma        = getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA"));
     (void)no_mfma;
-    auto for_groups = [&](auto &&fn) {
+    // (the two stages need not cut the right-hand sides into the same groups: stage 2 starts when all of stage 1 is done)
+    auto for_groups = [&](auto &&fn, bool expand_stage = false) {
+        (void)expand_stage;
         int c = 0;
         while (c < mu) {
             const int left = mu - c;
@@ -1491,6 +1493,10 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
 #if HMX_COMPLEX
             if (stage_on && !no_mfma && odd_tail)
                 g = 8, n = left;
+            // expand stage: 9 and more complex right-hand sides in sweeps of up to 16 (expand_zmfma16s_kernel; HMX_MFMA_WIDE=0: sweeps of 8)
+            static const int zwide = getenv("HMX_MFMA_WIDE") ? atoi(getenv("HMX_MFMA_WIDE")) : 1;
+            if (expand_stage && stage_on && !no_mfma && zwide && left > 8)
+                g = 16, n = left < 16 ? left : 16;
 #else
             if (stage_on && use_mfma && ((left >= 9 && left < 16) || odd_tail))
                 g = 16, n = left;
@@ -1568,6 +1574,12 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     auto expand_group = [&](int g, int c, int nrhs) {
         (void)nrhs;
 #if HMX_COMPLEX
+        if (g == 16) { // only chosen with the staged matrix-core kernels (for_groups)
+            if (XA.nranges > 0)
+                hipLaunchKernelGGL((expand_zmfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
+            prof_mark(H, st, "expand_zmfma16s_kernel");
+            return;
+        }
         if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
             if (XA.nranges > 0)
                 hipLaunchKernelGGL((expand_zmfma8s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
@@ -1631,12 +1643,12 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
             XA.order   = H.d_chunk_order.d + H.chunk_first[c];
             XA.nranges = H.chunk_count[c];
             if (XA.nranges > 0)
-                for_groups(expand_group);
+                for_groups(expand_group, true);
             if (after_chunk)
                 after_chunk(after_user, c, H.chunk_row_lo[c], H.chunk_row_hi[c]);
         }
     } else {
-        for_groups(expand_group);
+        for_groups(expand_group, true);
         if (after_chunk)
             after_chunk(after_user, 0, 0, H.nT);
     }

@@ -3115,6 +3115,116 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_zmfma8s_kernel(ExpandArgs 
     }
 }
 
+// expand_zmfma8s_kernel for groups of up to 16 complex right-hand sides: the (re, im) planes of a tile element are read from LDS once and
+// feed four MFMAs (two operand sets), as expand_mfma32s_kernel does for real coefficients.  The reduce stage keeps its sweeps of 8 (the two
+// stages need not cut the right-hand sides into the same groups: stage 2 starts when all of stage 1 is done).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))) void expand_zmfma16s_kernel(ExpandArgs A, int mu, int cbase, int nrhs) {
+    constexpr int PITCH = 80, STEP = 8; // 8 columns per step: two planes of 8 x 80 reals per wave
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 2 * STEP * PITCH > WAVES * WAVE * 16 ? WAVES * 2 * STEP * PITCH : WAVES * WAVE * 16];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4;
+    real(*tre)[PITCH] = reinterpret_cast<real(*)[PITCH]>(lds + wv * 2 * STEP * PITCH);
+    real(*tim)[PITCH] = tre + STEP;
+    const int row     = lane < len ? lane : len - 1;
+    const int mo      = m < 2 * nrhs ? m : 0;                  // ragged group: see expand_mfma16s_kernel
+    const int mo2     = 16 + (m < 2 * (nrhs - 8) ? m : 0);     // right-hand sides 8..15 of the group (nrhs > 8 here)
+    zacc4 acc[4], acc2[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc2[t] = zacc4{0, 0, 0, 0};
+    auto load_cols = [&](scalar(&v)[STEP], int c) {
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            const int col = c + u < C ? c + u : C - 1;
+            v[u]          = stream_load(E + (int64_t)col * len + row);
+        }
+    };
+    auto operands = [&](real(&b)[4], real(&bs)[4], int c, int zi, int base) { // [g]: right-hand sides 0..7, [2 + g]: 8..15
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int zc   = __shfl(zi, base + 4 * g + kk, WAVE);
+            const real *zr = reinterpret_cast<const real *>(expand_operand(A, zc, mu) + cbase);
+            const real zv = zr[mo], zw = zr[mo2];
+            const real bv = (c + 4 * g + kk < C) ? zv : real(0), bw = (c + 4 * g + kk < C) ? zw : real(0);
+            b[g]      = bv;
+            bs[g]     = zmfma_swapped(bv, lane);
+            b[2 + g]  = bw;
+            bs[2 + g] = zmfma_swapped(bw, lane);
+        }
+    };
+    auto apply = [&](const scalar(&v)[STEP], const real(&b)[4], const real(&bs)[4]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            tre[u][lane] = v[u].re;
+            tim[u][lane] = v[u].im;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const real are = tre[4 * g + kk][16 * t + m], aim = tim[4 * g + kk][16 * t + m]; // read once for both halves of the group
+                acc[t]  = mfma16(are, b[g], acc[t]);
+                acc[t]  = mfma16(aim, bs[g], acc[t]);
+                acc2[t] = mfma16(are, b[2 + g], acc2[t]);
+                acc2[t] = mfma16(aim, bs[2 + g], acc2[t]);
+            }
+    };
+    // wave w takes the 64-column tiles w, w + WAVES, ...; inside a tile eight steps of 8 columns, loads one step ahead
+    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
+        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
+        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        scalar v0[STEP], v1[STEP];
+        real b0[4], s0[4], b1[4], s1[4];
+        load_cols(v0, t0);
+        operands(b0, s0, t0, zi, 0);
+        for (int c = t0; c < tend; c += 2 * STEP) {
+            if (c + STEP < tend) {
+                load_cols(v1, c + STEP);
+                operands(b1, s1, c + STEP, zi, c + STEP - t0);
+            }
+            apply(v0, b0, s0);
+            if (c + 2 * STEP < tend) {
+                load_cols(v0, c + 2 * STEP);
+                operands(b0, s0, c + 2 * STEP, zi, c + 2 * STEP - t0);
+            }
+            if (c + STEP < tend)
+                apply(v1, b1, s1);
+        }
+    }
+    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, real column l & 15 = 2 rhs + part): stage as [row][16 reals],
+    // first the right-hand sides 0..7, then 8..15 through the same buffer
+    real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = half ? acc2[t][j] : acc[t][j];
+        __syncthreads();
+        for (int e = threadIdx.x; e < len * 8; e += WAVES * WAVE) {
+            const int i = e >> 3, cl = e & 7, c = 8 * half + cl;
+            if (c >= nrhs)
+                continue;
+            scalar s(red[0][i][2 * cl], red[0][i][2 * cl + 1]);
+#pragma unroll
+            for (int w = 1; w < WAVES; w++)
+                s += scalar(red[w][i][2 * cl], red[w][i][2 * cl + 1]);
+            scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+            *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        }
+    }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
     constexpr int PITCH = 144, STEP = 4; // 4 rows per step (one MFMA k-step): two planes of 4 x 144 reals per wave

@@ -140,14 +140,16 @@ def test_complex_against_oracle_other_size(sym, uplo, trans_list, mu):
             assert rel_err(Y, Ho.matmat_row_major(X, trans, alpha, beta, Y0)) < 1e-11
 
 
+@pytest.mark.parametrize("mu", [11, 16, 21])
 @pytest.mark.parametrize("dtype,tol", [(np.complex128, 1e-11), (np.complex64, 2e-5)])
-def test_eight_complex_rhs_on_the_matrix_cores(dtype, tol, monkeypatch):
+def test_eight_complex_rhs_on_the_matrix_cores(dtype, tol, mu, monkeypatch):
     """Groups of 8 complex right-hand sides run as two real MFMAs per complex tile (expand_zmfma8s_kernel / reduce_zmfma8s_kernel:
     matrix/linalg/add_matrix_matrix_product_row_major.hpp:49-84,113-139 is the reference's complex gemm).  mu = 11 = 8 + 2 + 1 against the
     CPU oracle on the operator the oracle itself compressed (complex double; complex float against the VALU kernels, HMX_NO_MFMA=1),
-    trans N / T / C, alpha / beta complex; and the matrix-core kernels are what ran."""
+    trans N / T / C, alpha / beta complex; and the matrix-core kernels are what ran.  More than 8 right-hand sides: the expand stage runs
+    sweeps of up to 16 (expand_zmfma16s_kernel: 11 = one ragged sweep, 21 = 16 + ragged 5), the reduce stage keeps its sweeps of 8."""
     from oracle import oracle as O
-    n, eps, mu = 4000, 1e-5, 11
+    n, eps = 4000, 1e-5
     x3 = hm.create_geometry("ball", n)
     b = hm.ClusterTreeBuilder()
     b.set_maximal_leaf_size(80)
@@ -170,7 +172,7 @@ def test_eight_complex_rhs_on_the_matrix_cores(dtype, tol, monkeypatch):
         hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, mu)
         names = [k for k, _ in H.last_kernel_times()]
         H.set_profiling(False)
-        assert any("zmfma8s" in k for k in names), names
+        assert any("reduce_zmfma8s" in k for k in names) and any("expand_zmfma16s" in k for k in names), names
         if Ho is not None:
             ref = Ho.matmat_row_major(X, trans, alpha, beta, Y0)
         else:
