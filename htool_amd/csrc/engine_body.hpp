@@ -1493,9 +1493,9 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
 #if HMX_COMPLEX
             if (stage_on && !no_mfma && odd_tail)
                 g = 8, n = left;
-            // expand stage: 9 and more complex right-hand sides in sweeps of up to 16 (expand_zmfma16s_kernel; HMX_MFMA_WIDE=0: sweeps of 8)
+            // 9 and more complex right-hand sides in sweeps of up to 16 (expand_zmfma16s_kernel / reduce_zmfma16s_kernel; HMX_MFMA_WIDE=0: sweeps of 8)
             static const int zwide = getenv("HMX_MFMA_WIDE") ? atoi(getenv("HMX_MFMA_WIDE")) : 1;
-            if (expand_stage && stage_on && !no_mfma && zwide && left > 8)
+            if (stage_on && !no_mfma && zwide && left > 8)
                 g = 16, n = left < 16 ? left : 16;
 #else
             if (stage_on && use_mfma && ((left >= 9 && left < 16) || odd_tail))
@@ -1513,6 +1513,12 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     for_groups([&](int g, int c, int nrhs) {
         (void)nrhs;
 #if HMX_COMPLEX
+        if (g == 16) { // only chosen with the staged matrix-core kernels (for_groups)
+            if (RA.ntasks > 0)
+                hipLaunchKernelGGL((reduce_zmfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
+            prof_mark(H, st, "reduce_zmfma16s_kernel");
+            return;
+        }
         // groups of 8 complex right-hand sides: two real MFMAs per complex tile, stream tiles staged through LDS (HMX_NO_MFMA=1: VALU kernels)
         if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
             if (RA.ntasks > 0)

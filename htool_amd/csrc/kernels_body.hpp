@@ -3323,6 +3323,132 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_zmfma8s_kernel(ReduceArgs 
                     Zr[((int64_t)dst[t][j] * mu + cbase) * 2 + m] = acc[t][j];
             }
 }
+
+// reduce_zmfma8s_kernel for groups of up to 16 complex right-hand sides (as reduce_mfma32s_kernel for real coefficients): sixteen
+// accumulator tiles do not fit the registers, so a task walks its rows once per HALF of its (<= 128) columns with both operand sets per
+// k-step.  Complex double (columns lane / lane + 64 of a row are separate loads anyway): a pass issues the one load of its half, 4 rows
+// = one k-step per step.  Complex float (two adjacent columns per 16-byte load): 2 rows per wave-wide load, 8 rows = two k-steps per step.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))) void reduce_zmfma16s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
+    constexpr int PITCH = 80, RPL = HMX_SPLIT_COLS ? 1 : 2, RS = 4 * RPL, KS = RPL; // rows per load / per step, k-steps per step
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 2 * RS * PITCH];
+    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * WAVES + wv;
+    if (task >= A.ntasks)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int S = A.task_range[task], ch = A.task_chunk[task];
+    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+    int w = C - ch * cw;
+    w     = w > cw ? cw : w;
+    const int wp      = hmx_wp(w);
+    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
+    const real *xs    = reinterpret_cast<const real *>(A.x + (int64_t)A.range_off[S] * mu + cbase);
+    const int m = lane & 15, kk = lane >> 4;
+    real *tre = lds + wv * 2 * RS * PITCH, *tim = tre + RS * PITCH;
+    const int mo  = m < 2 * nrhs ? m : 0;              // ragged group: see expand_mfma16s_kernel
+    const int mo2 = 16 + (m < 2 * (nrhs - 8) ? m : 0); // right-hand sides 8..15 (nrhs > 8 here)
+    const int64_t cb = A.range_colbase[S] + ch * cw;
+    real *Zr         = reinterpret_cast<real *>(A.Z);
+    for (int c0 = 0; c0 < w; c0 += 64) { // columns [c0, c0 + 64) of the chunk
+        const int wh    = w - c0 < 64 ? w - c0 : 64;
+        const int ntile = (wh + 15) >> 4;
+#if HMX_SPLIT_COLS
+        typedef scalar loaded; // one column per lane
+        const int rl = 0, lc = lane;
+        const int cl = c0 + lane < wp ? c0 + lane : c0;
+#else
+        typedef scalar2 loaded; // two adjacent columns per lane, 32 lanes per row
+        const int rl = lane >> 5, lc = 2 * (lane & 31);
+        const int cl = c0 + lc < wp ? c0 + lc : c0;
+#endif
+        zacc4 acc[4], acc2[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            acc[t] = acc2[t] = zacc4{0, 0, 0, 0};
+        auto load_rows = [&](loaded(&v)[4], int i0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = i0 + u * RPL + rl < len ? i0 + u * RPL + rl : len - 1;
+                v[u]          = stream_load(reinterpret_cast<const loaded *>(src + (int64_t)row * wp + cl));
+            }
+        };
+        auto operands = [&](real(&b)[2 * KS], real(&bs)[2 * KS], int i0) { // [h]: right-hand sides 0..7, [KS + h]: 8..15 of k-step h
+#pragma unroll
+            for (int h = 0; h < KS; h++) {
+                const int row  = i0 + 4 * h + kk;
+                const real *xr = xs + (int64_t)(row < len ? row : len - 1) * 2 * mu;
+                const real bv = xr[mo], bw = xr[mo2];
+                b[h]       = row < len ? bv : real(0);
+                b[KS + h]  = row < len ? bw : real(0);
+                bs[h]      = zmfma_swapped(b[h], lane);
+                bs[KS + h] = zmfma_swapped(b[KS + h], lane);
+            }
+        };
+        auto apply = [&](const loaded(&v)[4], const real(&b)[2 * KS], const real(&bs)[2 * KS]) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = u * RPL + rl;
+#if HMX_SPLIT_COLS
+                tre[r * PITCH + lc] = v[u].re;
+                tim[r * PITCH + lc] = v[u].im;
+#else
+                tre[r * PITCH + lc]     = v[u].x.re;
+                tim[r * PITCH + lc]     = v[u].x.im;
+                tre[r * PITCH + lc + 1] = v[u].y.re;
+                tim[r * PITCH + lc + 1] = v[u].y.im;
+#endif
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < KS; h++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < ntile) {
+                        const real are = tre[(4 * h + kk) * PITCH + 16 * t + m], aim = tim[(4 * h + kk) * PITCH + 16 * t + m];
+                        acc[t]  = mfma16(are, b[h], acc[t]);
+                        acc[t]  = mfma16(aim, bs[h], acc[t]);
+                        acc2[t] = mfma16(are, b[KS + h], acc2[t]);
+                        acc2[t] = mfma16(aim, bs[KS + h], acc2[t]);
+                    }
+        };
+        loaded v0[4], v1[4];
+        real b0[2 * KS], s0[2 * KS], b1[2 * KS], s1[2 * KS];
+        load_rows(v0, 0);
+        operands(b0, s0, 0);
+        for (int i0 = 0; i0 < len; i0 += 2 * RS) {
+            if (i0 + RS < len) {
+                load_rows(v1, i0 + RS);
+                operands(b1, s1, i0 + RS);
+            }
+            apply(v0, b0, s0);
+            if (i0 + 2 * RS < len) {
+                load_rows(v0, i0 + 2 * RS);
+                operands(b0, s0, i0 + 2 * RS);
+            }
+            if (i0 + RS < len)
+                apply(v1, b1, s1);
+        }
+        // destinations of the half's columns: one coalesced load, handed out by shuffles (see reduce_mfma16s_kernel)
+        const int32_t ih = A.out_idx[cb + (c0 + lane < w ? c0 + lane : 0)];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (t < ntile)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int col     = 16 * t + mfma16_row(real(0), lane, j);
+                    const int32_t dst = __shfl(ih, col, WAVE);
+                    if (c0 + col < w) {
+                        if (m < 2 * nrhs)
+                            Zr[((int64_t)dst * mu + cbase) * 2 + m] = acc[t][j];
+                        if (m < 2 * (nrhs - 8))
+                            Zr[((int64_t)dst * mu + cbase) * 2 + 16 + m] = acc2[t][j];
+                    }
+                }
+    }
+}
 #endif // HMX_COMPLEX
 
 // ---------------------------------------------------------------------------------------------

@@ -147,7 +147,7 @@ def test_eight_complex_rhs_on_the_matrix_cores(dtype, tol, mu, monkeypatch):
     matrix/linalg/add_matrix_matrix_product_row_major.hpp:49-84,113-139 is the reference's complex gemm).  mu = 11 = 8 + 2 + 1 against the
     CPU oracle on the operator the oracle itself compressed (complex double; complex float against the VALU kernels, HMX_NO_MFMA=1),
     trans N / T / C, alpha / beta complex; and the matrix-core kernels are what ran.  More than 8 right-hand sides: the expand stage runs
-    sweeps of up to 16 (expand_zmfma16s_kernel: 11 = one ragged sweep, 21 = 16 + ragged 5), the reduce stage keeps its sweeps of 8."""
+    sweeps of up to 16 in both stages (expand_zmfma16s_kernel / reduce_zmfma16s_kernel: 11 = one ragged sweep, 21 = 16 + ragged 5)."""
     from oracle import oracle as O
     n, eps = 4000, 1e-5
     x3 = hm.create_geometry("ball", n)
@@ -172,7 +172,8 @@ def test_eight_complex_rhs_on_the_matrix_cores(dtype, tol, mu, monkeypatch):
         hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, mu)
         names = [k for k, _ in H.last_kernel_times()]
         H.set_profiling(False)
-        assert any("reduce_zmfma8s" in k for k in names) and any("expand_zmfma16s" in k for k in names), names
+        assert any("reduce_zmfma16s" in k for k in names) and any("expand_zmfma16s" in k for k in names), names
+        assert (mu > 16) == any("zmfma8s" in k for k in names), names  # 21 = 16 + a ragged sweep of 8
         if Ho is not None:
             ref = Ho.matmat_row_major(X, trans, alpha, beta, Y0)
         else:

@@ -40,7 +40,7 @@ def test_staged_matrix_core_kernels_issue_their_loads_back_to_back(tmp_path):
     co = code_object(tmp_path)
     syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", co], capture_output=True, text=True, check=True).stdout
     names = sorted(set(re.findall(r"FUNC.* (\S*3(?:f64|f32)21(?:expand|reduce)_mfma(?:16|32)s_kernelILi4E\S*|\S*3(?:z64|c32)2[12](?:expand|reduce)_zmfma(?:8|16)s_kernelILi4E\S*)$", syms, flags=re.M)))
-    assert len(names) == 14, names  # expand + reduce: 16- and 32-wide real (f64, f32), 8-wide complex (z64, c32) + the 16-wide complex expand stage; 4 waves per workgroup (the default)
+    assert len(names) == 16, names  # expand + reduce: 16- and 32-wide real (f64, f32), 8- and 16-wide complex (z64, c32); 4 waves per workgroup (the default)
     for sym in names:
         asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, co], capture_output=True, text=True, check=True).stdout
         ops = collections.Counter(l.split()[0] for l in asm.split("\n") if l.startswith("\t"))
