@@ -1456,11 +1456,10 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                   H.r_outidx.d, X, H.Zmu.d, (int)H.R.task_range.size()};
     ExpandArgs XA{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges(), X, H.nS};
-    // groups of 16 right-hand sides go to the matrix cores (HMX_NO_MFMA=1: VALU kernels, for A/B comparison)
-    // Measured at N=1e6, mu=16: fp64 4.34 ms (MFMA) vs 4.72 ms (VALU); fp32 2.68 ms (MFMA: 64-byte row segments) vs 2.28 ms
-    // (VALU) -- so the matrix cores take the fp64 groups only unless HMX_MFMA_F32=1.
+    // groups of 16 (and, beyond 16, of 32) right-hand sides go to the matrix cores (HMX_NO_MFMA=1: VALU kernels, for A/B comparison)
+    // Round 2, unstaged kernels at N=1e6, mu=16: fp64 4.34 ms (MFMA) vs 4.72 ms (VALU); fp32 2.68 ms (MFMA: 64-byte row segments) vs 2.28 ms (VALU).
 #if HMX_COMPLEX
-    const bool use_mfma = false; // complex groups stay on the VALU kernels, at most 8 right-hand sides per pass (registers, LDS)
+    const bool use_mfma = false; // (the real-valued MFMA kernels) complex groups have their own: *_zmfma8s / *_zmfma16s, chosen in for_groups below; GMAX bounds the VALU kernels
     constexpr int GMAX  = 8;
 #else
     // Round 3, with the stream tiles staged through LDS (HMX_MFMA_STAGE, the default): fp32 groups of 16 go to the matrix cores as well --
