@@ -1,467 +1,29 @@
-// engine.hip -- device side of libhmx: owns the HBM-resident operator, runs compression, packing and
-// the H-matvec.  Host orchestration + C ABI (include/hmx.h); kernels are in kernels.hpp.
+// engine.hip -- the C ABI (include/hmx.h) of the device side of libhmx and the DistributedOperator layer over RCCL.  The engine
+// that owns the HBM-resident operator (compression, packing, H-matvec) is engine_body.hpp + kernels_body.hpp, compiled once per
+// coefficient type in engine_inst.hip; this file dispatches on the type a handle holds.
 //
 // There is deliberately NO CPU fallback in this file: every entry point that computes needs a HIP
 // device and reports HMX_ERR_NO_DEVICE / HMX_ERR_HIP otherwise.
-#include <algorithm>
-#include <functional>
-#include <map>
-#include <atomic>
-#include <chrono>
-#include <thread>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <mutex>
-#include <new>
-#include <stdexcept>
-#include <numeric>
-#include <string>
-#include <vector>
-
-#include "hmx_host.hpp"
+#include "engine_common.hpp"
 #include "kernels_common.hpp"
 
 namespace hmx {
-
-#define HMX_HIP(call)                                                                                         \
-    do {                                                                                                      \
-        hipError_t e_ = (call);                                                                               \
-        if (e_ != hipSuccess) {                                                                               \
-            set_error(std::string(#call) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
-            return HMX_ERR_HIP;                                                                               \
-        }                                                                                                     \
-    } while (0)
-
-// Large device buffers are recycled inside the process: after big frees the runtime's next large hipMalloc can take seconds
-// (tools/malloc_timing.hip, tools/build_timing.py rep 1), which hurts callers that rebuild operators (parameter sweeps, time
-// stepping).  release() parks buffers >= 64 MiB in a per-device free list (at most HMX_CACHE_GB, default 48, in total), alloc()
-// takes the smallest parked buffer that fits with at most 25 % waste.  hmx_device_trim_cache() returns everything to the driver.
-struct DeviceCache {
-    struct Entry {
-        void *p;
-        size_t bytes;
-        int device;
-    };
-    std::mutex mu;
-    std::vector<Entry> parked;
-    size_t total = 0;
-    static DeviceCache &get() {
-        static DeviceCache c;
-        return c;
-    }
-    static size_t limit() {
-        static const size_t l = (size_t)((getenv("HMX_CACHE_GB") ? atof(getenv("HMX_CACHE_GB")) : 48.0) * 1073741824.0);
-        return l;
-    }
-    void *take(size_t bytes, size_t *got) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lock(mu);
-        int best = -1;
-        for (size_t i = 0; i < parked.size(); i++)
-            if (parked[i].device == dev && parked[i].bytes >= bytes && parked[i].bytes <= bytes + bytes / 4 && (best < 0 || parked[i].bytes < parked[best].bytes))
-                best = (int)i;
-        if (best < 0)
-            return nullptr;
-        void *p = parked[best].p;
-        *got    = parked[best].bytes;
-        total -= parked[best].bytes;
-        parked.erase(parked.begin() + best);
-        return p;
-    }
-    // `dev` is the device the buffer was allocated on (recorded by DArr, not the caller's current device).  hipFree used to
-    // synchronise implicitly; a parked buffer can be handed out again at once, so work still in flight on ANY stream of the owning
-    // device (a caller's non-blocking stream, a graph launch) is waited for first.  Large releases are rare (operator teardown,
-    // buffer growth), so the device-wide wait costs nothing that matters.
-    bool park(void *p, size_t bytes, int dev) {
-        if (bytes < (size_t(64) << 20) || bytes > limit())
-            return false;
-        int cur = dev;
-        (void)hipGetDevice(&cur);
-        if (cur != dev)
-            (void)hipSetDevice(dev);
-        const hipError_t se = hipDeviceSynchronize();
-        if (cur != dev)
-            (void)hipSetDevice(cur);
-        if (se != hipSuccess) { // e.g. a stream capture in progress: do not recycle what cannot be proven idle
-            (void)hipGetLastError();
-            return false;
-        }
-        std::lock_guard<std::mutex> lock(mu);
-        while (total + bytes > limit() && !parked.empty()) { // evict the oldest
-            (void)hipFree(parked.front().p);
-            total -= parked.front().bytes;
-            parked.erase(parked.begin());
-        }
-        parked.push_back({p, bytes, dev});
-        total += bytes;
-        return true;
-    }
-    void trim() {
-        std::lock_guard<std::mutex> lock(mu);
-        for (auto &e : parked)
-            (void)hipFree(e.p);
-        parked.clear();
-        total = 0;
-    }
-};
-
-// hmx_device_reserve(): one slab per call, taken from the driver once; every later device array of >= 1 MiB is carved out of a slab
-// (first fit over an offset-ordered free list, 2 MiB granularity, neighbours coalesced on release) before hipMalloc is asked.
-// On this platform hipMalloc stalls for seconds when memory was released shortly before -- by this process or by the one that ran
-// before it (tools/malloc_after_exit.hip: ~25 ms per GB until the driver has scrubbed what came back) -- and an operator build
-// allocates its two largest arrays (cross pool, streams) right where that hurts; a caller that builds operators repeatedly, or
-// times a build, pays once and outside.  Released ranges become reusable after a device-wide synchronisation, like hipFree.
-struct DeviceSlabs {
-    struct Slab {
-        char *base;
-        size_t bytes;
-        int device;
-        std::map<size_t, size_t> free_at; // offset -> size
-        size_t in_use = 0;
-    };
-    std::mutex mu;
-    std::vector<Slab> slabs;
-    static constexpr size_t GRAIN = size_t(2) << 20;
-    static DeviceSlabs &get() {
-        static DeviceSlabs s;
-        return s;
-    }
-    hipError_t reserve(int dev, size_t bytes) {
-        bytes = (bytes + GRAIN - 1) / GRAIN * GRAIN;
-        void *p = nullptr;
-        const hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess)
-            return e;
-        std::lock_guard<std::mutex> lock(mu);
-        Slab s{static_cast<char *>(p), bytes, dev, {}, 0};
-        s.free_at[0] = bytes;
-        slabs.push_back(std::move(s));
-        return hipSuccess;
-    }
-    void *take(int dev, size_t bytes, size_t *got) {
-        const size_t need = (bytes + GRAIN - 1) / GRAIN * GRAIN;
-        std::lock_guard<std::mutex> lock(mu);
-        for (Slab &s : slabs) {
-            if (s.device != dev)
-                continue;
-            for (auto it = s.free_at.begin(); it != s.free_at.end(); ++it)
-                if (it->second >= need) {
-                    const size_t off = it->first, rest = it->second - need;
-                    s.free_at.erase(it);
-                    if (rest)
-                        s.free_at[off + need] = rest;
-                    s.in_use += need;
-                    *got = need;
-                    return s.base + off;
-                }
-        }
-        return nullptr;
-    }
-    // true when p belongs to a slab (and is free again afterwards)
-    bool give_back(void *p, size_t bytes) {
-        std::lock_guard<std::mutex> lock(mu);
-        for (Slab &s : slabs) {
-            char *c = static_cast<char *>(p);
-            if (c < s.base || c >= s.base + s.bytes)
-                continue;
-            size_t off = (size_t)(c - s.base), len = bytes;
-            s.in_use -= len;
-            auto next = s.free_at.lower_bound(off);
-            if (next != s.free_at.end() && off + len == next->first) { // merge with the range after
-                len += next->second;
-                next = s.free_at.erase(next);
-            }
-            if (next != s.free_at.begin()) { // ... and with the one before
-                auto prev = std::prev(next);
-                if (prev->first + prev->second == off) {
-                    off = prev->first;
-                    len += prev->second;
-                    s.free_at.erase(prev);
-                }
-            }
-            s.free_at[off] = len;
-            return true;
-        }
-        return false;
-    }
-    bool owns(const void *p) {
-        std::lock_guard<std::mutex> lock(mu);
-        for (const Slab &s : slabs)
-            if (static_cast<const char *>(p) >= s.base && static_cast<const char *>(p) < s.base + s.bytes)
-                return true;
-        return false;
-    }
-    size_t free_bytes(int dev) {
-        std::lock_guard<std::mutex> lock(mu);
-        size_t f = 0;
-        for (const Slab &s : slabs)
-            if (s.device == dev)
-                f += s.bytes - s.in_use;
-        return f;
-    }
-    // the largest single array a slab of this device can still hold (free ranges do not join across slabs or across used ranges)
-    size_t largest_hole(int dev) {
-        std::lock_guard<std::mutex> lock(mu);
-        size_t f = 0;
-        for (const Slab &s : slabs)
-            if (s.device == dev)
-                for (const auto &r : s.free_at)
-                    f = std::max(f, r.second);
-        return f;
-    }
-    // slabs nothing is carved out of go back to the driver
-    size_t release_idle() {
-        std::lock_guard<std::mutex> lock(mu);
-        size_t kept = 0;
-        for (size_t i = 0; i < slabs.size();) {
-            if (slabs[i].in_use == 0) {
-                (void)hipFree(slabs[i].base);
-                slabs.erase(slabs.begin() + i);
-            } else {
-                kept += slabs[i].bytes;
-                i++;
-            }
-        }
-        return kept;
-    }
-};
-
-// wall time this process spent inside hipMalloc (large allocations sporadically take seconds on this platform: tools/malloc_timing.hip);
-// bench.py reports it next to the build time
-static std::atomic<long long> g_malloc_ns{0};
-struct MallocTimer {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    ~MallocTimer() { g_malloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
-};
-
-// std::vector whose resize() leaves the new elements uninitialised: the large host index arrays are written completely (by several
-// threads) right after they are sized, and zero-filling 150 MB first costs as much as filling it
-template <typename T>
-struct DefaultInitAlloc : std::allocator<T> {
-    template <typename U>
-    struct rebind {
-        typedef DefaultInitAlloc<U> other;
-    };
-    template <typename U, typename... Args>
-    void construct(U *p, Args &&...args) {
-        if constexpr (sizeof...(Args) == 0)
-            ::new ((void *)p) U;
-        else
-            ::new ((void *)p) U(std::forward<Args>(args)...);
-    }
-};
-typedef std::vector<int32_t, DefaultInitAlloc<int32_t>> hvec32;
-
-template <typename T>
-struct DArr { // device array with RAII
-    T *d        = nullptr;
-    size_t n    = 0;
-    size_t cap_ = 0; // bytes actually owned (>= n * sizeof(T) when the buffer came from the cache)
-    int dev_    = 0; // device the buffer lives on (current device at alloc time)
-    bool plain_ = false; // never from a reserved slab (buffers handed to RCCL: their allocation is what peers map)
-    DArr() {}
-    DArr(const DArr &)            = delete;
-    DArr &operator=(const DArr &) = delete;
-    ~DArr() { release(); }
-    void release() {
-        if (d && DeviceSlabs::get().owns(d)) { // a range of a reserved slab: reusable once nothing on the device can still touch it
-            int cur = dev_;
-            (void)hipGetDevice(&cur);
-            if (cur != dev_)
-                (void)hipSetDevice(dev_);
-            const hipError_t se = hipDeviceSynchronize();
-            if (cur != dev_)
-                (void)hipSetDevice(cur);
-            if (se == hipSuccess)
-                (void)DeviceSlabs::get().give_back(d, cap_);
-            else // e.g. a stream capture in progress: what cannot be proven idle is not handed out again (the range stays taken)
-                (void)hipGetLastError();
-        } else if (d && !DeviceCache::get().park(d, cap_, dev_)) {
-            (void)hipFree(d);
-        }
-        d    = nullptr;
-        n    = 0;
-        cap_ = 0;
-    }
-    hipError_t alloc(size_t count) {
-        release();
-        n = count;
-        if (count == 0)
-            return hipSuccess;
-        const size_t bytes = count * sizeof(T);
-        size_t got         = 0;
-        (void)hipGetDevice(&dev_);
-        if (void *p = DeviceCache::get().take(bytes, &got)) {
-            d    = static_cast<T *>(p);
-            cap_ = got;
-            return hipSuccess;
-        }
-        if (bytes >= (size_t(1) << 20) && !plain_)
-            if (void *p = DeviceSlabs::get().take(dev_, bytes, &got)) {
-                d    = static_cast<T *>(p);
-                cap_ = got;
-                return hipSuccess;
-            }
-        cap_               = bytes;
-        MallocTimer timer;
-        const hipError_t e = hipMalloc((void **)&d, bytes);
-        if (e != hipSuccess) { // out of memory: give the parked buffers and the slabs nothing lives in back and try once more
-            DeviceCache::get().trim();
-            (void)DeviceSlabs::get().release_idle();
-            (void)hipGetLastError();
-            return hipMalloc((void **)&d, bytes);
-        }
-        return e;
-    }
-    template <typename A>
-    hipError_t upload(const std::vector<T, A> &h) {
-        hipError_t e = alloc(h.size());
-        if (e != hipSuccess || h.empty())
-            return e;
-        return hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-    hipError_t zero() { return n ? hipMemset(d, 0, n * sizeof(T)) : hipSuccess; }
-};
-
-// free device memory as the library sees it: what the driver has left plus what is free inside the reserved slabs
-static hipError_t hmx_mem_info(size_t *free_b, size_t *total_b) {
-    const hipError_t e = hipMemGetInfo(free_b, total_b);
-    if (e != hipSuccess)
-        return e;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    *free_b += DeviceSlabs::get().free_bytes(dev);
-    return hipSuccess;
-}
-// ... and the largest SINGLE array that can still be allocated: no allocation spans the driver's memory and a slab, or two holes of a
-// slab, so budgets for one array (cross pool, scratch) are capped by this, not by the sum above
-static hipError_t hmx_mem_largest(size_t *largest_b) {
-    size_t free_b = 0, total_b = 0;
-    const hipError_t e = hipMemGetInfo(&free_b, &total_b);
-    if (e != hipSuccess)
-        return e;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    *largest_b = std::max(free_b, DeviceSlabs::get().largest_hole(dev));
-    return hipSuccess;
-}
-
-struct DEvent { // hipEvent_t with RAII, so error returns between create and destroy do not leak it
-    hipEvent_t e = nullptr;
-    DEvent() { (void)hipEventCreate(&e); }
-    DEvent(const DEvent &)            = delete;
-    DEvent &operator=(const DEvent &) = delete;
-    ~DEvent() {
-        if (e)
-            (void)hipEventDestroy(e);
-    }
-    operator hipEvent_t() const { return e; }
-};
-
-// One family of streams (E = expand over target ranges, R = reduce over source ranges)
-enum LeafKind { LK_PENDING = 0, LK_DENSE_GEN = 1, LK_DENSE_STAGED = 2, LK_LOWRANK = 3 };
-
-
-static int ensure_device(int device) {
-    int count     = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) {
-        set_error("no HIP device available: libhmx has no CPU path (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) + ")");
-        return HMX_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= count) {
-        set_error("device id out of range");
-        return HMX_ERR_INVALID;
-    }
-    HMX_HIP(hipSetDevice(device));
-    return HMX_OK;
-}
-
-// split [lo,hi) at the sorted breakpoints, then cut pieces longer than maxlen evenly
-static void make_ranges(std::vector<int> &bp, int maxlen, int origin, std::vector<int32_t> &off, std::vector<int32_t> &len) {
-    std::sort(bp.begin(), bp.end());
-    bp.erase(std::unique(bp.begin(), bp.end()), bp.end());
-    off.clear();
-    len.clear();
-    for (size_t k = 0; k + 1 < bp.size(); k++) {
-        const int a = bp[k], L = bp[k + 1] - bp[k];
-        const int pieces = (L + maxlen - 1) / maxlen;
-        for (int p = 0; p < pieces; p++) {
-            const int s = a + (int)((int64_t)L * p / pieces), e = a + (int)((int64_t)L * (p + 1) / pieces);
-            off.push_back(s - origin);
-            len.push_back(e - s);
-        }
-    }
-}
-
-// host loops over millions of (leaf, range) pairs with disjoint outputs: split over a few threads
-template <typename F>
-static void parallel_for(size_t n, F &&body) {
-    const size_t nt = std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), n / 65536 + 1});
-    if (nt <= 1) {
-        body((size_t)0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; t++)
-        th.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt); });
-    for (auto &x : th)
-        x.join();
-}
-
-struct Timer {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    double s() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-};
-
-// Compute the stream layout from the final leaf kinds/ranks and move the data into it.
-
-#define HMX_COMPLEX 0
-#define HMX_SPLIT_COLS 0
 namespace f64 {
-using real    = double;
-using scalar  = double;
-using scalar2 = double2;
-#include "kernels_body.hpp"
-#include "engine_body.hpp"
+using scalar = double;
+#include "engine_api.hpp"
 } // namespace f64
 namespace f32 {
-using real    = float;
-using scalar  = float;
-using scalar2 = float2;
-#include "kernels_body.hpp"
-#include "engine_body.hpp"
+using scalar = float;
+#include "engine_api.hpp"
 } // namespace f32
-#undef HMX_COMPLEX
-#define HMX_COMPLEX 1
-#undef HMX_SPLIT_COLS
-#define HMX_SPLIT_COLS 1
-#undef HMX_COL0
-#undef HMX_COL1
-namespace z64 { // htool's HMatrix<std::complex<double>, double>
-using real    = double;
-using scalar  = cplx<double>;
-using scalar2 = cplx2<double>;
-#include "kernels_body.hpp"
-#include "engine_body.hpp"
+namespace z64 {
+using scalar = cplx<double>;
+#include "engine_api.hpp"
 } // namespace z64
-#undef HMX_SPLIT_COLS
-#define HMX_SPLIT_COLS 0
-#undef HMX_COL0
-#undef HMX_COL1
-namespace c32 { // HMatrix<std::complex<float>, double>
-using real    = float;
-using scalar  = cplx<float>;
-using scalar2 = cplx2<float>;
-#include "kernels_body.hpp"
-#include "engine_body.hpp"
+namespace c32 {
+using scalar = cplx<float>;
+#include "engine_api.hpp"
 } // namespace c32
-#undef HMX_COMPLEX
-#undef HMX_SPLIT_COLS
-
 } // namespace hmx
 
 using namespace hmx;
@@ -473,10 +35,10 @@ struct hmx_hmatrix {
     hmx::z64::HMat *z = nullptr;
     hmx::c32::HMat *c = nullptr;
     ~hmx_hmatrix() {
-        delete d;
-        delete s;
-        delete z;
-        delete c;
+        hmx::f64::api_destroy(d);
+        hmx::f32::api_destroy(s);
+        hmx::z64::api_destroy(z);
+        hmx::c32::api_destroy(c);
     }
 };
 
@@ -626,7 +188,7 @@ void hmx_hmatrix_destroy(hmx_hmatrix *H) {
     if (!H)
         return;
     // products are asynchronous on the caller's stream: nothing of this operator may be freed or recycled while one is in flight
-    const int dev = H->d ? H->d->device : (H->s ? H->s->device : (H->z ? H->z->device : (H->c ? H->c->device : -1)));
+    const int dev = H->d ? hmx::f64::api_device_of(H->d) : (H->s ? hmx::f32::api_device_of(H->s) : (H->z ? hmx::z64::api_device_of(H->z) : (H->c ? hmx::c32::api_device_of(H->c) : -1)));
     int cur       = 0;
     if (dev >= 0 && hipGetDevice(&cur) == hipSuccess) {
         if (cur != dev)
@@ -804,8 +366,8 @@ int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, 
         set_error(std::string("hmx_hmatrix_load: cannot open ") + path);
         return HMX_ERR_INVALID;
     }
-    hmx::f64::HmxFileHeader hd; // same layout in both instantiations
-    if (fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, hmx::f64::HMX_FILE_MAGIC, 8) != 0 || (hd.elem_size != 4 && hd.elem_size != 8 && hd.elem_size != 16)) {
+    hmx::HmxFileHeader hd;
+    if (fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, hmx::HMX_FILE_MAGIC, 8) != 0 || (hd.elem_size != 4 && hd.elem_size != 8 && hd.elem_size != 16)) {
         fclose(f);
         set_error(std::string("hmx_hmatrix_load: ") + path + " is not an hmx operator file");
         return HMX_ERR_INVALID;
@@ -819,17 +381,11 @@ int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, 
     if (hd.elem_size == 8 && !hd.reserved) {
         rc = hmx::f64::api_load(bt, device_id, f, hd, &d);
     } else if (hd.elem_size == 4) {
-        hmx::f32::HmxFileHeader hs;
-        std::memcpy(&hs, &hd, sizeof hs);
-        rc = hmx::f32::api_load(bt, device_id, f, hs, &s);
+        rc = hmx::f32::api_load(bt, device_id, f, hd, &s);
     } else if (hd.elem_size == 16) {
-        hmx::z64::HmxFileHeader hs;
-        std::memcpy(&hs, &hd, sizeof hs);
-        rc = hmx::z64::api_load(bt, device_id, f, hs, &z);
+        rc = hmx::z64::api_load(bt, device_id, f, hd, &z);
     } else {
-        hmx::c32::HmxFileHeader hs;
-        std::memcpy(&hs, &hd, sizeof hs);
-        rc = hmx::c32::api_load(bt, device_id, f, hs, &c);
+        rc = hmx::c32::api_load(bt, device_id, f, hd, &c);
     }
     } catch (...) { // a corrupt size field: std::bad_alloc / std::length_error from a host buffer
         set_error(std::string("hmx_hmatrix_load: ") + path + " is corrupt (allocation failed)");
@@ -1236,15 +792,14 @@ static int dist_add_scaled(hmx_dist &D, int64_t n, const void *w, const void *be
         return HMX_ERR_UNSUPPORTED;
     }
     hmx_hmatrix *H = D.local ? D.local : D.diag;
-    const dim3 g((unsigned)((n + 255) / 256)), b(256);
     if (H->d)
-        hipLaunchKernelGGL(hmx::f64::axpby_kernel, g, b, 0, st, (int)n, 1.0, (const double *)w, *static_cast<const double *>(beta), static_cast<double *>(y));
+        hmx::f64::api_axpby(n, (const double *)w, *static_cast<const double *>(beta), static_cast<double *>(y), st);
     else if (H->s)
-        hipLaunchKernelGGL(hmx::f32::axpby_kernel, g, b, 0, st, (int)n, 1.0f, (const float *)w, *static_cast<const float *>(beta), static_cast<float *>(y));
+        hmx::f32::api_axpby(n, (const float *)w, *static_cast<const float *>(beta), static_cast<float *>(y), st);
     else if (H->z)
-        hipLaunchKernelGGL(hmx::z64::axpby_kernel, g, b, 0, st, (int)n, cplx<double>(1.0), ZP(w), zval(static_cast<const double *>(beta)), ZPM(y));
+        hmx::z64::api_axpby(n, ZP(w), zval(static_cast<const double *>(beta)), ZPM(y), st);
     else
-        hipLaunchKernelGGL(hmx::c32::axpby_kernel, g, b, 0, st, (int)n, cplx<float>(1.0f), CP(w), cval(static_cast<const float *>(beta)), CPM(y));
+        hmx::c32::api_axpby(n, CP(w), cval(static_cast<const float *>(beta)), CPM(y), st);
     HMX_HIP(hipGetLastError());
     return HMX_OK;
 }

@@ -1275,7 +1275,6 @@ static int ensure_expand_chunks(HMat &H, int nchunks) {
     return HMX_OK;
 }
 
-typedef void (*after_chunk_fn)(void *user, int chunk, int row_lo, int row_hi);
 static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st, bool sym_fused = false,
                        int nchunks = 0, after_chunk_fn after_chunk = nullptr, void *after_user = nullptr) {
     // Z[x region] <- x.  x_shift != 0 (mirror pass of a transposed product): the input is indexed by target
@@ -1871,7 +1870,7 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
 }
 
 
-static int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
+int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
     if (!bt || !out) {
         set_error("hmx_hmatrix_create: NULL argument");
         return HMX_ERR_INVALID;
@@ -1925,7 +1924,7 @@ static int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
 }
 
 
-static int api_set_kernel(HMat *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc) {
+int api_set_kernel(HMat *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc) {
     if (!H || !params || !tc || !sc || kernel != HMX_KERNEL_INV_DIST || nparams < 2 || (dim != 2 && dim != 3)) {
         set_error("hmx_hmatrix_set_kernel: invalid arguments");
         return HMX_ERR_INVALID;
@@ -1957,7 +1956,7 @@ static int api_set_kernel(HMat *H, int kernel, const double *params, int nparams
     return HMX_OK;
 }
 
-static int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, const int32_t *, scalar *), void *user) {
+int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, const int32_t *, scalar *), void *user) {
     if (!H || !fn) {
         set_error("hmx_hmatrix_set_callback: invalid arguments");
         return HMX_ERR_INVALID;
@@ -1969,7 +1968,7 @@ static int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t 
 }
 
 static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqrank, bool full_pool);
-static int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
+int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
     // The cross pool is first sized from a rank estimate (allocations beyond a few tens of GB take seconds on this
     // platform: tools/malloc_timing.hip); if a block runs out of pool the compression is repeated with the full budget.
     int rc = api_compress_impl(Hp, compressor, epsilon, reqrank, false);
@@ -2643,7 +2642,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
 
 // recompression(hmatrix) (hmatrix/utils/recompression.hpp:8-31): SVD recompression of every low-rank leaf with the
 // accuracy the operator was built with (LowRankMatrix::get_epsilon), then the streams are laid out again.
-static int api_recompress(HMat *Hp, double epsilon) {
+int api_recompress(HMat *Hp, double epsilon) {
     if (!Hp) {
         set_error("hmx_hmatrix_recompress: NULL handle");
         return HMX_ERR_INVALID;
@@ -2741,7 +2740,7 @@ static void ensure_staged(HMat &H) {
         H.staged_D.resize(nb);
     }
 }
-static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const scalar *U, const scalar *V) {
+int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const scalar *U, const scalar *V) {
     if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || rank < 0 || (rank > 0 && (!U || !V))) {
         set_error("hmx_hmatrix_set_block_lowrank: invalid arguments");
         return HMX_ERR_INVALID;
@@ -2760,7 +2759,7 @@ static int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const scalar *
     H->finalized         = false;
     return HMX_OK;
 }
-static int api_set_block_dense(HMat *H, int64_t leaf, const scalar *D) {
+int api_set_block_dense(HMat *H, int64_t leaf, const scalar *D) {
     if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || !D) {
         set_error("hmx_hmatrix_set_block_dense: invalid arguments");
         return HMX_ERR_INVALID;
@@ -2775,7 +2774,7 @@ static int api_set_block_dense(HMat *H, int64_t leaf, const scalar *D) {
     H->finalized         = false;
     return HMX_OK;
 }
-static int api_finalize(HMat *Hp) {
+int api_finalize(HMat *Hp) {
     if (!Hp)
         return HMX_ERR_INVALID;
     HMat &H = *Hp;
@@ -2832,7 +2831,7 @@ static int api_finalize(HMat *Hp) {
     return build_streams(H);
 }
 
-static int api_leaf_ranks(const HMat *H, int32_t *rank) {
+int api_leaf_ranks(const HMat *H, int32_t *rank) {
     if (!H || !rank)
         return HMX_ERR_INVALID;
     for (size_t b = 0; b < H->leaves.size(); b++)
@@ -2840,7 +2839,7 @@ static int api_leaf_ranks(const HMat *H, int32_t *rank) {
     return HMX_OK;
 }
 
-static int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V) {
+int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V) {
     HMat *H = const_cast<HMat *>(Hc);
     if (!H || leaf < 0 || leaf >= (int64_t)H->leaves.size() || !U_or_D) {
         set_error("hmx_hmatrix_get_block: invalid arguments");
@@ -2902,21 +2901,9 @@ static int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V
     return HMX_OK;
 }
 
-// ---- binary dump of the compressed operator (no counterpart in the reference) ---------------------------
-// Layout: HmxFileHeader, hmx_leaf[nleaves] (ranks filled in), then per leaf in htool's leaf order either
-// U (M x r, column-major) followed by V (r x N, column-major) -- LowRankMatrix' own layout (lrmat.hpp:15-128) -- or the
-// dense block (M x N, column-major).  Loading goes through set_block_* + finalize, i.e. the upload path.
-struct HmxFileHeader {
-    char magic[8];
-    int32_t elem_size, reserved;
-    int64_t nleaves;
-    int32_t T0, nT, S0, nS;
-    int32_t symmetry, uplo;
-    double epsilon;
-};
-static const char HMX_FILE_MAGIC[8] = {'H', 'M', 'X', 'B', 'I', 'N', '1', '\0'};
+// ---- binary dump of the compressed operator: HmxFileHeader and the layout are described in engine_common.hpp ----------------
 
-static int api_save(const HMat *Hc, const char *path) {
+int api_save(const HMat *Hc, const char *path) {
     HMat *H = const_cast<HMat *>(Hc);
     if (!H || !path) {
         set_error("hmx_hmatrix_save: invalid arguments");
@@ -2985,7 +2972,7 @@ static int api_save(const HMat *Hc, const char *path) {
 }
 
 // `f` is positioned just behind the header (engine.hip reads it to pick the precision)
-static int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxFileHeader &hd, HMat **out) {
+int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxFileHeader &hd, HMat **out) {
     HMat *H = nullptr;
     int rc  = api_create(bt, device_id, &H);
     if (rc != HMX_OK)
@@ -3030,7 +3017,7 @@ static int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxF
 // Give the compression pool (the ACA crosses / uploaded blocks the streams were packed from) back: products only need the
 // streams.  Afterwards low-rank blocks can no longer be downloaded, saved or recompressed, and a transposed product that has not
 // built its layout yet uses the in-place passes.  with_transposed != 0 builds the transposed layout first.
-static int api_release_factors(HMat *Hp, int with_transposed) {
+int api_release_factors(HMat *Hp, int with_transposed) {
     if (!Hp || !Hp->finalized) {
         set_error("hmx_hmatrix_release_factors: operator not built");
         return HMX_ERR_STATE;
@@ -3051,7 +3038,7 @@ static int api_release_factors(HMat *Hp, int with_transposed) {
     return HMX_OK;
 }
 
-static int api_stats(const HMat *H, hmx_stats *out) {
+int api_stats(const HMat *H, hmx_stats *out) {
     if (!H || !out)
         return HMX_ERR_INVALID;
     *out = H->stats;
@@ -3079,7 +3066,7 @@ static int with_buffers(HMat &H, char trans, const scalar *in, scalar *out, int 
     return HMX_OK;
 }
 
-static int api_matvec(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mem, void *stream) {
+int api_matvec(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mem, void *stream) {
     if (!Hp || !in || !out) {
         set_error("hmx_hmatrix_matvec: NULL argument");
         return HMX_ERR_INVALID;
@@ -3108,7 +3095,7 @@ static int api_matvec(HMat *Hp, char trans, scalar alpha, const scalar *in, scal
 // the host right after chunk c was LAUNCHED on `stream`: rows [row_lo, row_hi) of `out` are final once the stream reaches that point.
 // Returns the number of chunks used through *used (1: the operator could not be chunked -- fused symmetric storage adds to rows after
 // the expand stage -- and after_chunk was called once, for all rows, after the whole product).
-static int api_matvec_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, scalar *out, void *stream, int nchunks, after_chunk_fn after_chunk, void *user, int *used) {
+int api_matvec_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, scalar *out, void *stream, int nchunks, after_chunk_fn after_chunk, void *user, int *used) {
     if (!Hp || !in || !out) {
         set_error("hmx_hmatrix_matvec (chunked): NULL argument");
         return HMX_ERR_INVALID;
@@ -3141,7 +3128,7 @@ static int api_matvec_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar b
     return rc;
 }
 // row bounds of the chunks api_matvec_chunked will use (bounds[0..n]; n returned through *n_out; n = 1 when the operator is not chunkable)
-static int api_chunk_bounds(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) {
+int api_chunk_bounds(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) {
     if (!Hp || !n_out || !bounds)
         return HMX_ERR_INVALID;
     HMat &H = *Hp;
@@ -3173,7 +3160,7 @@ static HMat *matmat_layout_n(HMat &H) {
 }
 // api_matvec_chunked for mu right-hand sides (row-major, device pointers, trans = 'N'): after_chunk(user, c, row_lo, row_hi) is called on the
 // host right after the expand kernels of row chunk c (all groups of right-hand sides) were launched on `stream`.
-static int api_matmat_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, void *stream, int nchunks, after_chunk_fn after_chunk, void *user, int *used) {
+int api_matmat_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, void *stream, int nchunks, after_chunk_fn after_chunk, void *user, int *used) {
     if (!Hp || !in || !out || mu < 1) {
         set_error("hmx_hmatrix_matmat_row_major (chunked): invalid arguments");
         return HMX_ERR_INVALID;
@@ -3206,7 +3193,7 @@ static int api_matmat_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar b
     return rc;
 }
 // row bounds of the chunks api_matmat_chunked will use (they differ from the single-vector ones when the product runs on the expanded view)
-static int api_chunk_bounds_mu(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) {
+int api_chunk_bounds_mu(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) {
     if (!Hp || !n_out || !bounds)
         return HMX_ERR_INVALID;
     HMat &H = *Hp;
@@ -3228,7 +3215,7 @@ static int api_chunk_bounds_mu(HMat *Hp, int nchunks, int *n_out, int32_t *bound
     return HMX_OK;
 }
 
-static int api_matvec_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mem, void *stream) {
+int api_matvec_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mem, void *stream) {
     if (!Hp || !in || !out) {
         set_error("hmx_hmatrix_matvec_user: NULL argument");
         return HMX_ERR_INVALID;
@@ -3357,7 +3344,7 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
 }
 
 
-static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
+int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
     if (!Hp || !in || !out || mu < 1) {
         set_error("hmx_hmatrix_matmat_row_major: invalid arguments");
         return HMX_ERR_INVALID;
@@ -3385,7 +3372,7 @@ static int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar
 // add_hmatrix_matrix_product (hmatrix/linalg/add_hmatrix_matrix_product.hpp:26-77,176-205): column-major B (n x mu) and C (m x mu)
 // in USER numbering; every column is permuted to cluster numbering and the operands are transposed to row-major (one gather
 // kernel each way), the fused row-major product runs, the result is transposed and permuted back.
-static int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
+int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream) {
     if (!Hp || !in || !out || mu < 1) {
         set_error("hmx_hmatrix_matmat_user: invalid arguments");
         return HMX_ERR_INVALID;
@@ -3430,13 +3417,13 @@ static int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in,
     return HMX_OK;
 }
 
-static int api_set_profiling(HMat *H, int enabled) {
+int api_set_profiling(HMat *H, int enabled) {
     if (!H)
         return HMX_ERR_INVALID;
     H->profiling = enabled != 0;
     return HMX_OK;
 }
-static int api_last_kernel_times(const HMat *H, int max, const char **names, float *ms) {
+int api_last_kernel_times(const HMat *H, int max, const char **names, float *ms) {
     if (!H)
         return 0;
     int n = std::min<int>(max, (int)H->last_ms.size());
@@ -3448,3 +3435,9 @@ static int api_last_kernel_times(const HMat *H, int max, const char **names, flo
 }
 
 
+
+int api_device_of(const HMat *H) { return H ? H->device : -1; }
+void api_destroy(HMat *H) { delete H; }
+void api_axpby(int64_t n, const scalar *w, scalar beta, scalar *y, hipStream_t st) {
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int)n, scalar(1), w, beta, y);
+}

@@ -299,7 +299,7 @@ __device__ __forceinline__ hmx_f4 mfma16(float a, float b, hmx_f4 c) { return __
 __device__ __forceinline__ int mfma16_row(double, int lane, int reg) { return (lane >> 4) + 4 * reg; }
 __device__ __forceinline__ int mfma16_row(float, int lane, int reg) { return 4 * (lane >> 4) + reg; }
 
-__global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
+static __global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
     int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride)
@@ -308,7 +308,7 @@ __global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restric
 
 // read-only probe: every workgroup streams its own contiguous chunk with 16-byte non-temporal loads (four in flight per lane)
 // and keeps running sums -- the access pattern of the stream kernels without any of their arithmetic or gathers
-__global__ __launch_bounds__(256) void read16_kernel(const double2 *__restrict__ in, double *__restrict__ out, int64_t n) {
+static __global__ __launch_bounds__(256) void read16_kernel(const double2 *__restrict__ in, double *__restrict__ out, int64_t n) {
     const int64_t per = n / gridDim.x;
     const double2 *p  = in + per * blockIdx.x;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;

@@ -16,33 +16,46 @@ LIB = os.path.join(ROOT, "htool_amd", "libhmx.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def code_object(tmp_path):
+def code_objects(tmp_path):
+    """Every gfx950 code object in libhmx.so: one offload bundle per translation unit (the engine is compiled once per coefficient type)."""
     data = open(LIB, "rb").read()
-    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    out, i = [], data.find(b"__CLANG_OFFLOAD_BUNDLE__")
     assert i >= 0, "no offload bundle in libhmx.so"
-    off = i + 24
-    n = struct.unpack_from("<Q", data, off)[0]
-    off += 8
-    for _ in range(n):
-        o, s, l = struct.unpack_from("<QQQ", data, off)
-        off += 24
-        name = data[off:off + l].decode()
-        off += l
-        if "gfx950" in name:
-            p = tmp_path / "hmx_gfx950.co"
-            p.write_bytes(data[i + o:i + o + s])
-            return str(p)
-    raise AssertionError("no gfx950 code object in libhmx.so")
+    while i >= 0:
+        off = i + 24
+        n = struct.unpack_from("<Q", data, off)[0]
+        off += 8
+        for _ in range(n):
+            o, s, l = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            name = data[off:off + l].decode()
+            off += l
+            if "gfx950" in name and s > 0:
+                p = tmp_path / ("hmx_gfx950_%d.co" % len(out))
+                p.write_bytes(data[i + o:i + o + s])
+                out.append(str(p))
+        i = data.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 24)
+    assert out, "no gfx950 code object in libhmx.so"
+    return out
+
+
+def kernel_symbols(cos):
+    """kernel name -> code object that defines it"""
+    where = {}
+    for co in cos:
+        syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", co], capture_output=True, text=True, check=True).stdout
+        for name in re.findall(r"FUNC\s+\S+\s+\S+\s+\d+\s+(\S+)$", syms, flags=re.M):
+            where[name] = co
+    return where
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="llvm-objdump not installed")
 def test_staged_matrix_core_kernels_issue_their_loads_back_to_back(tmp_path):
-    co = code_object(tmp_path)
-    syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", co], capture_output=True, text=True, check=True).stdout
-    names = sorted(set(re.findall(r"FUNC.* (\S*3(?:f64|f32)21(?:expand|reduce)_mfma(?:16|32)s_kernelILi4E\S*|\S*3(?:z64|c32)2[12](?:expand|reduce)_zmfma(?:8|16)s_kernelILi4E\S*)$", syms, flags=re.M)))
+    where = kernel_symbols(code_objects(tmp_path))
+    names = sorted(n for n in where if re.fullmatch(r"\S*3(?:f64|f32)21(?:expand|reduce)_mfma(?:16|32)s_kernelILi4E\S*|\S*3(?:z64|c32)2[12](?:expand|reduce)_zmfma(?:8|16)s_kernelILi4E\S*", n))
     assert len(names) == 16, names  # expand + reduce: 16- and 32-wide real (f64, f32), 8- and 16-wide complex (z64, c32); 4 waves per workgroup (the default)
     for sym in names:
-        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, co], capture_output=True, text=True, check=True).stdout
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, where[sym]], capture_output=True, text=True, check=True).stdout
         ops = collections.Counter(l.split()[0] for l in asm.split("\n") if l.startswith("\t"))
         drained = sum(1 for l in asm.split("\n") if "s_waitcnt vmcnt(0)" in l)
         assert ops["v_mfma_f64_16x16x4_f64"] + ops["v_mfma_f32_16x16x4_f32"] >= 32, sym
@@ -61,12 +74,14 @@ def test_single_vector_kernels_keep_their_occupancy_and_load_shape(tmp_path):
     """The headline kernels: registers (eight waves per SIMD for the expand stage, at least seven for the reduce stage), no scratch, the
     stream loads of the main loops as wide as they were tuned to be (fp64: 16-byte loads in the reduce stage, one 8-byte column entry per
     lane in the expand stage)."""
-    co = code_object(tmp_path)
-    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    cos = code_objects(tmp_path)
+    where = kernel_symbols(cos)
     meta = {}
-    for blk in notes.split("- .agpr_count:")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-        meta[name] = {k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1)) for k in ("vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+    for co in cos:
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            meta[name] = {k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1)) for k in ("vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
     checked = 0
     for name, m in meta.items():
         if re.search(r"3(f64|f32|z64|c32)13expand_kernelILi\d", name):
@@ -80,6 +95,6 @@ def test_single_vector_kernels_keep_their_occupancy_and_load_shape(tmp_path):
             checked += 1
     assert checked >= 20, checked
     for sym, op, least in (("_ZN3hmx3f6413reduce_kernelILi1EEEvNS0_10ReduceArgsE", "global_load_dwordx4", 8), ("_ZN3hmx3f6413expand_kernelILi4EEEvNS0_10ExpandArgsE", "global_load_dwordx2", 8)):
-        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, co], capture_output=True, text=True, check=True).stdout
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, where[sym]], capture_output=True, text=True, check=True).stdout
         ops = collections.Counter(l.split()[0] for l in asm.split("\n") if l.startswith("\t"))
         assert ops[op] >= least, (sym, op, ops[op])
