@@ -28,6 +28,33 @@ using scalar = cplx<float>;
 
 using namespace hmx;
 
+// bandwidth probes of hmx_device_copy_bandwidth / hmx_device_read_bandwidth (and the one-workgroup launch of hmx_device_init)
+namespace hmx {
+static __global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
+    int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = in[i];
+}
+
+// read-only probe: every workgroup streams its own contiguous chunk with 16-byte non-temporal loads (four in flight per lane)
+// and keeps running sums -- the access pattern of the stream kernels without any of their arithmetic or gathers
+static __global__ __launch_bounds__(256) void read16_kernel(const double2 *__restrict__ in, double *__restrict__ out, int64_t n) {
+    const int64_t per = n / gridDim.x;
+    const double2 *p  = in + per * blockIdx.x;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t i = threadIdx.x; i + 3 * 256 < per; i += 4 * 256) {
+        const double2 a = stream_load(p + i), b = stream_load(p + i + 256), c = stream_load(p + i + 512), d = stream_load(p + i + 768);
+        s0 += a.x + a.y;
+        s1 += b.x + b.y;
+        s2 += c.x + c.y;
+        s3 += d.x + d.y;
+    }
+    out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = (s0 + s1) + (s2 + s3);
+}
+
+} // namespace hmx
+
 // The opaque handle of the C ABI: one of the four instantiations
 struct hmx_hmatrix {
     hmx::f64::HMat *d = nullptr;

@@ -52,21 +52,11 @@ struct HMat {
     std::vector<int32_t> perm_t, perm_s; // full permutations (cluster -> user)
     bool t_root_is_tree_root = false, perm_local = false;
     // the cluster trees' nodes as (offset, size, first child, number of children), GLOBAL cluster positions: the R-stream pieces of a
-    // source cluster larger than SR_MAX follow the tree (its descendants of at most SR_MAX rows), so that the pieces of ALL cluster
-    // levels nest inside "windows" (the tree nodes of at most SR_MAX rows whose parent is larger) -- what lets one workgroup keep a
-    // window's rows of a multi-RHS input on chip for every task over them (reduce_win_* kernels)
+    // source cluster larger than SR_MAX follow the tree (its descendants of at most SR_MAX rows), so the pieces of all cluster levels nest
     struct TreeNode {
         int32_t off, size, first_child, n_children;
     };
     std::vector<TreeNode> tree_t, tree_s;
-    // windows of the source rows (root-local offsets) and, per window, its (range piece, column chunk) tasks dealt to SPLITS x WAVES bins
-    std::vector<int32_t> win_off, win_len;
-    DArr<int32_t> d_win_off, d_win_len, d_win_order, d_win_bin_ptr, d_win_bin_task;
-    int n_win = 0, n_win_groups = 0; // n_win_groups = n_win * WIN_SPLITS workgroups
-    // groups of consecutive row ranges whose column lists share a prefix (expand_grp_* kernels: the prefix's operand rows staged once)
-    DArr<int32_t> d_grp_first, d_grp_count, d_grp_prefix, d_grp_order;
-    int n_grp = 0;
-    double grp_shared_frac = 0; // share of the E columns that lie in a common prefix
 
     // generator
     // host generator: VirtualGenerator::copy_submatrix semantics (user numbering, column-major output)
@@ -340,20 +330,11 @@ static int build_streams(HMat &H) {
     H.stats = hmx_stats{};
     H.stats.rank_min = 1 << 30;
     double rank_sum  = 0;
-    // Columns are given out leaf by leaf in the order of DECREASING target cluster size (ties: the leaves' own order): the leaves that
-    // reach a row range form a chain of nested target clusters, so two neighbouring ranges then share a PREFIX of their column lists --
-    // the leaves whose target cluster contains both (expand_grp_* kernels stage that prefix's operand rows once for the group).
-    // Off by default since the matrix-core kernels stage their stream tiles through LDS (expand_mfma16s_kernel is faster than the grouped
-    // kernel, and sorting the leaves + finding the prefixes costs ~80 ms of host time at N = 1e6); HMX_E_GROUPS=1 turns it on.
-    const bool want_groups = getenv("HMX_E_GROUPS") && atoi(getenv("HMX_E_GROUPS"));
-    std::vector<int64_t> border(nb);
-    std::iota(border.begin(), border.end(), (int64_t)0);
-    if (want_groups)
-        std::stable_sort(border.begin(), border.end(), [&](int64_t a, int64_t b) { return XL[a].t_size > XL[b].t_size; });
-    // Two passes over the leaves (in `border` order), each split over a few threads: pass 1 counts, per thread and per range, the
+    // columns are given out leaf by leaf in the leaves' own order
+    // Two passes over the leaves (in their own order), each split over a few threads: pass 1 counts, per thread and per range, the
     // columns its leaves add (and the pairs, ranks and partial slots); a prefix over the threads turns the counts into each thread's
     // starting column per range and starting position in the pair lists; pass 2 writes the pairs.  The result is what the one-thread
-    // loop gives (columns in `border` order, pair lists leaf-major in that order) -- 58 ms of a 320 ms build at N = 1e6 before.
+    // loop gives (columns in leaf order, pair lists leaf-major) -- 58 ms of a 320 ms build at N = 1e6 before.
     {
         const int nre = E.nranges(), nrr = R.nranges();
         const size_t NT = getenv("HMX_LAYOUT_THREADS") ? (size_t)std::max(1, atoi(getenv("HMX_LAYOUT_THREADS")))
@@ -396,7 +377,7 @@ static int build_streams(HMat &H) {
             P.ecnt.assign(nre, 0);
             P.rcnt.assign(nrr, 0);
             for (int64_t ib = nb * (int64_t)t / (int64_t)NT; ib < nb * (int64_t)(t + 1) / (int64_t)NT; ib++) {
-                const int64_t b = border[ib];
+                const int64_t b = ib;
                 bool skip, lr;
                 int ncols, ra, rb, sa, sb;
                 leaf_spans(b, skip, lr, ncols, ra, rb, sa, sb);
@@ -475,7 +456,7 @@ static int build_streams(HMat &H) {
             Part &P = part[t];
             int64_t q_elr = o_elr[t], q_ed = o_ed[t], q_rlr = o_rlr[t], a_run = o_a[t], p_run = o_p[t];
             for (int64_t ib = nb * (int64_t)t / (int64_t)NT; ib < nb * (int64_t)(t + 1) / (int64_t)NT; ib++) {
-                const int64_t b = border[ib];
+                const int64_t b = ib;
                 bool skip, lr;
                 int ncols, ra, rb, sa, sb;
                 leaf_spans(b, skip, lr, ncols, ra, rb, sa, sb);
@@ -594,112 +575,6 @@ static int build_streams(HMat &H) {
         }
         R.task_range.swap(tr);
         R.task_chunk.swap(tc);
-    }
-    // ---- windows of the source rows (multi-RHS reduce stage with the input rows on chip) ---------------------------------------------
-    // A window = a node of the source tree with at most SR_MAX rows whose parent has more: the windows tile the source rows, and with
-    // pieces cut along the tree every piece of every cluster level lies inside exactly one of them.  One workgroup per (window, split)
-    // keeps the window's rows of X in LDS and runs the window's tasks, dealt heaviest first to WIN_SPLITS x WIN_WAVES bins.
-    H.n_win = H.n_win_groups = 0;
-    H.win_off.clear();
-    H.win_len.clear();
-    // (the window lists are only built when the window kernels are asked for, HMX_MU_WINDOW=1: the staged matrix-core kernels are the default)
-    if (tree_pieces && SR_MAX <= WIN_ROWS && !R.task_range.empty() && getenv("HMX_MU_WINDOW") && atoi(getenv("HMX_MU_WINDOW"))) {
-        std::vector<std::pair<int32_t, int32_t>> wins; // (root-local offset, rows)
-        {
-            std::vector<std::pair<int, int>> stack; // (node, parent size)
-            // start from every node that is not somebody's child: the root(s)
-            std::vector<char> is_child(H.tree_s.size(), 0);
-            for (const auto &nd : H.tree_s)
-                for (int k = 0; k < nd.n_children; k++)
-                    is_child[nd.first_child + k] = 1;
-            for (size_t v = 0; v < H.tree_s.size(); v++)
-                if (!is_child[v])
-                    stack.emplace_back((int)v, INT32_MAX);
-            while (!stack.empty()) {
-                const int v = stack.back().first;
-                stack.pop_back();
-                const HMat::TreeNode nd = H.tree_s[v];
-                if (nd.off + nd.size <= H.S0 || nd.off >= H.S0 + H.nS)
-                    continue; // outside this operator's source rows
-                if (nd.size <= SR_MAX || nd.n_children == 0) {
-                    if (nd.off >= H.S0 && nd.off + nd.size <= H.S0 + H.nS)
-                        wins.emplace_back(nd.off - H.S0, nd.size);
-                    continue;
-                }
-                for (int k = 0; k < nd.n_children; k++)
-                    stack.emplace_back(nd.first_child + k, nd.size);
-            }
-        }
-        std::sort(wins.begin(), wins.end());
-        // every piece must lie inside one window (true along the tree; checked, the window kernels are simply not used otherwise)
-        std::vector<int32_t> win_of_range(R.nranges(), -1);
-        bool nested = !wins.empty();
-        for (int r = 0; r < R.nranges() && nested; r++) {
-            auto it = std::upper_bound(wins.begin(), wins.end(), std::make_pair(R.off[r], INT32_MAX));
-            if (it == wins.begin()) {
-                nested = false;
-                break;
-            }
-            --it;
-            if (R.off[r] + R.len[r] > it->first + it->second || it->second > SR_MAX)
-                nested = false;
-            win_of_range[r] = (int32_t)(it - wins.begin());
-        }
-        if (nested) {
-            const int nw = (int)wins.size();
-            constexpr int BINS = WIN_SPLITS;
-            std::vector<std::vector<int32_t>> tasks_of(nw);
-            std::vector<int64_t> win_work(nw, 0);
-            auto work = [&](int t) {
-                const int r = R.task_range[t], c = R.task_chunk[t];
-                const int w = std::min<int>(R.cols[r] - c * R.cw[r], R.cw[r]);
-                return (int64_t)R.len[r] * w;
-            };
-            for (int t = 0; t < (int)R.task_range.size(); t++) {
-                tasks_of[win_of_range[R.task_range[t]]].push_back(t);
-                win_work[win_of_range[R.task_range[t]]] += work(t);
-            }
-            std::vector<int32_t> bin_ptr((size_t)nw * BINS + 1, 0), bin_task;
-            bin_task.reserve(R.task_range.size());
-            for (int w = 0; w < nw; w++) {
-                auto &tl = tasks_of[w];
-                std::stable_sort(tl.begin(), tl.end(), [&](int a, int b) { return work(a) > work(b); });
-                // the window's tasks to its WIN_SPLITS workgroups, longest first to the one with the least work so far; inside a
-                // workgroup the waves pull the tasks from the list in this order
-                std::vector<std::vector<int32_t>> bins(BINS);
-                int64_t load[BINS] = {0};
-                for (int t : tl) {
-                    int best = 0;
-                    for (int b = 1; b < BINS; b++)
-                        if (load[b] < load[best])
-                            best = b;
-                    bins[best].push_back(t);
-                    load[best] += work(t) + 2048; // a fixed cost per task: set-up and the write of its results
-                }
-                for (int b = 0; b < BINS; b++) {
-                    bin_task.insert(bin_task.end(), bins[b].begin(), bins[b].end());
-                    bin_ptr[(size_t)w * BINS + b + 1] = (int32_t)bin_task.size();
-                }
-            }
-            std::vector<int32_t> order((size_t)nw * WIN_SPLITS);
-            std::iota(order.begin(), order.end(), 0);
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return win_work[a / WIN_SPLITS] > win_work[b / WIN_SPLITS]; });
-            H.win_off.resize(nw);
-            H.win_len.resize(nw);
-            for (int w = 0; w < nw; w++) {
-                H.win_off[w] = wins[w].first;
-                H.win_len[w] = wins[w].second;
-            }
-            if (bin_task.empty())
-                bin_task.push_back(0);
-            HMX_HIP(H.d_win_off.upload(H.win_off));
-            HMX_HIP(H.d_win_len.upload(H.win_len));
-            HMX_HIP(H.d_win_order.upload(order));
-            HMX_HIP(H.d_win_bin_ptr.upload(bin_ptr));
-            HMX_HIP(H.d_win_bin_task.upload(bin_task));
-            H.n_win        = nw;
-            H.n_win_groups = nw * WIN_SPLITS;
-        }
     }
     if (E.total_cols >= (int64_t(1) << 31) || R.total_cols >= (int64_t(1) << 31) || (int64_t)H.nS + A_total + P_total + 2 >= (int64_t(1) << 31)) {
         set_error("operator too large for 32-bit column indices");
@@ -820,76 +695,6 @@ static int build_streams(HMat &H) {
     };
     fill_e(elr_b, elr_r, elr_c, true);
     fill_e(ed_b, ed_r, ed_c, false);
-    // ---- groups of E_GW consecutive row ranges and the column prefix they share (expand_grp_* kernels) ----------------------------------
-    // The prefix is taken from the index arrays themselves (longest common prefix of the ranges' operand indices), so it is right whatever
-    // order the columns came in; the ordering above only makes it long.  Of the E_GW possible alignments of the groups the one with the
-    // most shared columns is used.
-    H.n_grp           = 0;
-    H.grp_shared_frac = 0;
-    if (want_groups && E.nranges() > 0 && !mirror_flags) {
-        constexpr int GW = E_GW;
-        const int nr = E.nranges();
-        auto lcp = [&](int r0, int r1) { // columns of r0 .. r1 - 1 that agree from the start
-            int p = E.cols[r0];
-            const int32_t *z0 = H.h_e_zidx.data() + E.colbase[r0];
-            for (int r = r0 + 1; r < r1; r++) {
-                const int32_t *z = H.h_e_zidx.data() + E.colbase[r];
-                const int lim    = std::min(p, (int)E.cols[r]);
-                int q = 0;
-                while (q < lim && z[q] == z0[q])
-                    q++;
-                p = q;
-            }
-            return r1 - r0 > 1 ? p : 0;
-        };
-        int best_shift = 0;
-        int64_t best   = -1;
-        std::vector<int64_t> shared_of(GW, 0);
-        parallel_for((size_t)GW, [&](size_t lo, size_t hi) {
-            for (size_t sh = lo; sh < hi; sh++) {
-                int64_t tot = 0;
-                for (int r0 = sh ? (int)sh - GW : 0; r0 < nr; r0 += GW) {
-                    const int a = std::max(r0, 0), b = std::min(r0 + GW, nr);
-                    tot += (int64_t)lcp(a, b) * (b - a - 1);
-                }
-                shared_of[sh] = tot;
-            }
-        });
-        for (int sh = 0; sh < GW; sh++)
-            if (shared_of[sh] > best) {
-                best       = shared_of[sh];
-                best_shift = sh;
-            }
-        std::vector<int32_t> gfirst, gcount, gprefix;
-        int64_t shared = 0;
-        for (int r0 = best_shift ? best_shift - GW : 0; r0 < nr; r0 += GW) {
-            const int a = std::max(r0, 0), b = std::min(r0 + GW, nr);
-            gfirst.push_back(a);
-            gcount.push_back(b - a);
-            gprefix.push_back(lcp(a, b));
-            shared += (int64_t)gprefix.back() * (b - a);
-        }
-        std::vector<int32_t> gorder(gfirst.size());
-        std::iota(gorder.begin(), gorder.end(), 0);
-        auto gwork = [&](int g) {
-            int64_t w = 0;
-            for (int r = gfirst[g]; r < gfirst[g] + gcount[g]; r++)
-                w += (int64_t)E.len[r] * E.cols[r];
-            return w;
-        };
-        std::vector<int64_t> gw(gfirst.size());
-        for (size_t g = 0; g < gfirst.size(); g++)
-            gw[g] = gwork((int)g);
-        std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return gw[a] > gw[b]; });
-        HMX_HIP(H.d_grp_first.upload(gfirst));
-        HMX_HIP(H.d_grp_count.upload(gcount));
-        HMX_HIP(H.d_grp_prefix.upload(gprefix));
-        HMX_HIP(H.d_grp_order.upload(gorder));
-        H.n_grp           = (int)gfirst.size();
-        H.grp_shared_frac = E.total_cols ? (double)shared / (double)E.total_cols : 0;
-        if (phase_timing)
-            fprintf(stderr, "[hmx build]   %d groups of %d row ranges (alignment %d): %.1f %% of the E columns in a shared prefix\n", H.n_grp, GW, best_shift, 100 * H.grp_shared_frac);
-    }
     phase_nosync("  e index");
     hvec32 h_outidx(R.total_cols);
     H.h_r_aidx.resize(R.total_cols);
@@ -1290,7 +1095,7 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         nx  = 0;
         prof_mark(H, st, "copy_x");
     }
-    static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 1; // tuning knobs: one wave per workgroup frees its slot as soon as its task ends
+    static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 1; // 1 (default: one wave per workgroup frees its slot as soon as its task ends) or 4
     // expand: 4 waves per row range; when there are too few ranges to fill the chip more than once (<= 4096: the per-rank share
     // of an 8-GPU run, or N ~ 1e5) 8 waves per range shorten the tail of the heavy ranges (-5 %), at full size they cost 2 %
     static const int EW_env = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 0;
@@ -1300,10 +1105,8 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         ReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                      H.r_outidx.d, xin, H.Z.d, ntasks};
         switch (RW) {
-        case 1: hipLaunchKernelGGL(reduce_kernel<1>, dim3(ntasks), dim3(64), 0, st, A); break;
-        case 2: hipLaunchKernelGGL(reduce_kernel<2>, dim3((ntasks + 1) / 2), dim3(128), 0, st, A); break;
-        case 8: hipLaunchKernelGGL(reduce_kernel<8>, dim3((ntasks + 7) / 8), dim3(512), 0, st, A); break;
-        default: hipLaunchKernelGGL(reduce_kernel<4>, dim3((ntasks + 3) / 4), dim3(256), 0, st, A); break;
+        case 4: hipLaunchKernelGGL(reduce_kernel<4>, dim3((ntasks + 3) / 4), dim3(256), 0, st, A); break;
+        default: hipLaunchKernelGGL(reduce_kernel<1>, dim3(ntasks), dim3(64), 0, st, A); break;
         }
         prof_mark(H, st, "reduce_kernel");
     }
@@ -1320,8 +1123,6 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
                             H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0};
             const size_t lds = 0;
             switch (EW) {
-            case 1: hipLaunchKernelGGL(expand_sym_kernel<1>, dim3(H.E.nranges()), dim3(64), lds, st, X); break;
-            case 2: hipLaunchKernelGGL(expand_sym_kernel<2>, dim3(H.E.nranges()), dim3(128), lds, st, X); break;
             case 8: hipLaunchKernelGGL(expand_sym_kernel<8>, dim3(H.E.nranges()), dim3(512), lds, st, X); break;
             default: hipLaunchKernelGGL(expand_sym_kernel<4>, dim3(H.E.nranges()), dim3(256), lds, st, X); break;
             }
@@ -1357,8 +1158,6 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
             if (cnt > 0) {
                 ExpandArgs X{H.E.stream.d, H.d_chunk_order.d + H.chunk_first[c], H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, cnt, xin, nx};
                 switch (EW) {
-                case 1: hipLaunchKernelGGL(expand_kernel<1>, dim3(cnt), dim3(64), 0, st, X); break;
-                case 2: hipLaunchKernelGGL(expand_kernel<2>, dim3(cnt), dim3(128), 0, st, X); break;
                 case 8: hipLaunchKernelGGL(expand_kernel<8>, dim3(cnt), dim3(512), 0, st, X); break;
                 default: hipLaunchKernelGGL(expand_kernel<4>, dim3(cnt), dim3(256), 0, st, X); break;
                 }
@@ -1370,8 +1169,6 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
     } else if (H.E.nranges() > 0) {
         ExpandArgs X{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx};
         switch (EW) {
-        case 1: hipLaunchKernelGGL(expand_kernel<1>, dim3(H.E.nranges()), dim3(64), 0, st, X); break;
-        case 2: hipLaunchKernelGGL(expand_kernel<2>, dim3(H.E.nranges()), dim3(128), 0, st, X); break;
         case 8: hipLaunchKernelGGL(expand_kernel<8>, dim3(H.E.nranges()), dim3(512), 0, st, X); break;
         default: hipLaunchKernelGGL(expand_kernel<4>, dim3(H.E.nranges()), dim3(256), 0, st, X); break;
         }
@@ -1381,45 +1178,22 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
     return HMX_OK;
 }
 
-// Wave-uniform operand of the multi-RHS VALU kernels through the scalar cache instead of LDS (real coefficient types).
-// Measured at N=1e6, mu=16, fp32: reduce 0.85 ms (scalar) vs 0.98 ms (LDS); expand 1.22 ms (scalar: the gathered coefficient
-// rows miss the scalar cache) vs 1.14 ms (LDS); fp64 1.71 / 1.67 ms and 2.71 / 2.86 ms with the MFMA kernels at 1.64 / 2.53 ms.
-// Default: scalar operands in the fp32 reduce stage only.  HMX_MU_SCALAR=0: never, =1: both stages (A/B comparison).
-static bool mu_scalar_operands(bool reduce_stage) {
+// Wave-uniform operand of the multi-RHS VALU reduce kernel through the scalar cache instead of LDS (real coefficient types).
+// Measured at N=1e6, mu=16, fp32: reduce 0.85 ms (scalar) vs 0.98 ms (LDS); the same trick in the expand stage lost (1.22 vs 1.14 ms: the
+// gathered coefficient rows miss the scalar cache) and was removed.  Default: fp32 only.  HMX_MU_SCALAR=0 / 1: never / also for fp64.
+static bool mu_scalar_operands() {
     const char *e = getenv("HMX_MU_SCALAR");
     const int v   = e ? atoi(e) : -1;
-    return v < 0 ? (reduce_stage && sizeof(scalar) == 4) : v != 0;
+    return v < 0 ? sizeof(scalar) == 4 : v != 0;
 }
-// The multi-RHS reduce stage with a window of X in LDS (reduce_win_* kernels): when the layout has windows (pieces cut along the
-// source tree) -- by default for the matrix-core kernel (groups of 16 real right-hand sides); HMX_MU_WINDOW=1 for every type and
-// group size, =0 never (then the layout does not build the window lists either).
-static bool mu_window(const HMat &H, bool mfma) {
-    if (H.n_win_groups <= 0)
-        return false;
-    const char *e = getenv("HMX_MU_WINDOW"); // the layout builds the window lists only when this is set to 1
-    // measured at N = 1e6 (tools/ab_mu.sh, gpurun_out/r3_ab_mu*): fp64 mu = 16 on the matrix cores 1.68 against 1.75 ms, and the expand
-    // stage that follows gains another 0.1 ms; the VALU form loses (complex double mu = 8: 3.07 against 2.63 ms, fp32 mu = 16: 1.08
-    // against 0.80 ms with the scalar-operand kernel) -- its operand reads come from the same LDS pipe either way
-    return e ? atoi(e) != 0 : mfma;
-}
-static WinArgs win_args(const HMat &H) { return WinArgs{H.d_win_off.d, H.d_win_len.d, H.d_win_order.d, H.d_win_bin_ptr.d, H.d_win_bin_task.d, H.n_win_groups}; }
 template <int MU>
-static void launch_mu(HMat &H, ReduceArgs &RA, ExpandArgs &XA, int mu, int cbase, hipStream_t st) {
+static void launch_mu(HMat &H, ReduceArgs &RA, int mu, int cbase, hipStream_t st) {
     constexpr int RW = 4;
-    if (MU >= 4 && mu_window(H, false)) {
-        hipLaunchKernelGGL((reduce_win_mu_kernel<WIN_WAVES, MU>), dim3(H.n_win_groups), dim3(WIN_WAVES * 64), 0, st, RA, win_args(H), mu, cbase);
-        prof_mark(H, st, "reduce_win_mu_kernel");
-        return;
-    }
 #if !HMX_COMPLEX
-    if (mu_scalar_operands(true) && MU >= 4) {
-        static const int rw = getenv("HMX_REDUCE_MU_WAVES") ? atoi(getenv("HMX_REDUCE_MU_WAVES")) : RW;
-        if (RA.ntasks > 0) {
-            if (rw == 1)
-                hipLaunchKernelGGL((reduce_mus_kernel<1, MU>), dim3(RA.ntasks), dim3(64), 0, st, RA, mu, cbase);
-            else
+    if (MU >= 4 && mu_scalar_operands()) {
+        if constexpr (MU >= 4)
+            if (RA.ntasks > 0)
                 hipLaunchKernelGGL((reduce_mus_kernel<RW, MU>), dim3((RA.ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, RA, mu, cbase);
-        }
         prof_mark(H, st, "reduce_mus_kernel");
         return;
     }
@@ -1427,19 +1201,10 @@ static void launch_mu(HMat &H, ReduceArgs &RA, ExpandArgs &XA, int mu, int cbase
     if (RA.ntasks > 0)
         hipLaunchKernelGGL((reduce_mu_kernel<RW, MU>), dim3((RA.ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, RA, mu, cbase);
     prof_mark(H, st, "reduce_mu_kernel");
-    (void)XA;
 }
 template <int MU>
 static void launch_mu_expand(HMat &H, ExpandArgs &XA, int mu, int cbase, hipStream_t st) {
     constexpr int EW = 4;
-#if !HMX_COMPLEX
-    if (mu_scalar_operands(false) && MU >= 4) {
-        if (XA.nranges > 0)
-            hipLaunchKernelGGL((expand_mus_kernel<EW, MU>), dim3(XA.nranges), dim3(EW * 64), 0, st, XA, mu, cbase);
-        prof_mark(H, st, "expand_mus_kernel");
-        return;
-    }
-#endif
     if (XA.nranges > 0)
         hipLaunchKernelGGL((expand_mu_kernel<EW, MU>), dim3(XA.nranges), dim3(EW * 64), 0, st, XA, mu, cbase);
     prof_mark(H, st, "expand_mu_kernel");
@@ -1455,118 +1220,79 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                   H.r_outidx.d, X, H.Zmu.d, (int)H.R.task_range.size()};
     ExpandArgs XA{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges(), X, H.nS};
-    // groups of 16 (and, beyond 16, of 32) right-hand sides go to the matrix cores (HMX_NO_MFMA=1: VALU kernels, for A/B comparison)
-    // Round 2, unstaged kernels at N=1e6, mu=16: fp64 4.34 ms (MFMA) vs 4.72 ms (VALU); fp32 2.68 ms (MFMA: 64-byte row segments) vs 2.28 ms (VALU).
+    // Groups of right-hand sides, one sweep over the streams each.  Real coefficients: groups of 16 and, beyond 16, of up to 32 run on the
+    // matrix cores with the stream tiles staged through LDS (*_mfma16s / *_mfma32s); complex: groups of 8 / up to 16 (*_zmfma8s / *_zmfma16s).
+    // Those kernels take RAGGED groups (missing right-hand sides are operands nobody stores the results of): 9 ... 15 real right-hand
+    // sides are one group of 16 instead of 8 + 4 + 2 + 1 (four sweeps), 3 and 5 ... 7 likewise.  Exact groups of 8, 4, 2, 1 run the VALU
+    // kernels.  HMX_NO_MFMA=1: VALU kernels throughout (A/B comparison; fp32: HMX_MFMA_F32=0), HMX_MFMA_WIDE=0: no sweeps of 32 (complex: 16).
+    const bool no_mfma = getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA"));
 #if HMX_COMPLEX
-    const bool use_mfma = false; // (the real-valued MFMA kernels) complex groups have their own: *_zmfma8s / *_zmfma16s, chosen in for_groups below; GMAX bounds the VALU kernels
-    constexpr int GMAX  = 8;
+    const bool use_mfma = !no_mfma;
+    constexpr int GMAX  = 8; // widest VALU kernel
 #else
-    // Round 3, with the stream tiles staged through LDS (HMX_MFMA_STAGE, the default): fp32 groups of 16 go to the matrix cores as well --
-    // N = 1e6, eps = 1e-4 (mean rank 8.9): 2.16 against 2.14 ms, config 5 (N = 4e6, eps = 1e-6, mean rank 14.3) 15.9 against 17.8 ms,
-    // its per-rank share of an 8-GPU run 2.30 against 2.38 ms (gpurun_out/r3_ab_cfg5.log).  HMX_MFMA_F32=0: VALU kernels for fp32.
-    static const int stage_default = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;
-    const bool mfma_ok  = sizeof(scalar) == 8 || (getenv("HMX_MFMA_F32") ? atoi(getenv("HMX_MFMA_F32")) != 0 : stage_default != 0);
-    const bool use_mfma = mfma_ok && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")));
+    const bool use_mfma = !no_mfma && (sizeof(scalar) == 8 || !(getenv("HMX_MFMA_F32") && atoi(getenv("HMX_MFMA_F32")) == 0));
     constexpr int GMAX  = 16;
 #endif
-    // stage 1 for every group of right-hand sides, then the partial sums, then stage 2
-    // Groups of right-hand sides, one sweep over the streams each.  The staged matrix-core kernels take RAGGED groups (missing right-hand
-    // sides are zero operands, their results are not stored): 9 ... 15 real right-hand sides are one group of 16 instead of 8 + 4 + 2 + 1
-    // (four sweeps), 5 ... 7 complex ones one group of 8.  fn(kernel width, first column, right-hand sides in the group).
-    // (only the staged kernels know about ragged groups: not with the window / grouped variants switched on)
-    static const int stage_on = (getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1) && !(getenv("HMX_MU_WINDOW") && atoi(getenv("HMX_MU_WINDOW"))) &&
-                                !(getenv("HMX_MU_GROUPS") && atoi(getenv("HMX_MU_GROUPS")) > 0);
-    const bool no_mfma        = getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA"));
-    (void)no_mfma;
-    // (the two stages need not cut the right-hand sides into the same groups: stage 2 starts when all of stage 1 is done)
-    auto for_groups = [&](auto &&fn, bool expand_stage = false) {
-        (void)expand_stage;
+    static const int wide = getenv("HMX_MFMA_WIDE") ? atoi(getenv("HMX_MFMA_WIDE")) : 1;
+    // fn(kernel width, first column, right-hand sides in the group); the two stages need not cut the right-hand sides into the same
+    // groups (stage 2 starts when all of stage 1 is done), but they do
+    auto for_groups = [&](auto &&fn) {
         int c = 0;
         while (c < mu) {
             const int left = mu - c;
             int g          = (left >= 16 && GMAX >= 16) ? 16 : (left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1)));
             int n          = g;
-            // ... and so are 3, 5, 6, 7: one ragged sweep (3.7 ms at N = 1e6 fp64) instead of two or three exact ones (2 + 1: 7.8 ms)
             const bool odd_tail = left == 3 || (left >= 5 && left < 8);
 #if HMX_COMPLEX
-            if (stage_on && !no_mfma && odd_tail)
+            if (use_mfma && odd_tail)
                 g = 8, n = left;
-            // 9 and more complex right-hand sides in sweeps of up to 16 (expand_zmfma16s_kernel / reduce_zmfma16s_kernel; HMX_MFMA_WIDE=0: sweeps of 8)
-            static const int zwide = getenv("HMX_MFMA_WIDE") ? atoi(getenv("HMX_MFMA_WIDE")) : 1;
-            if (stage_on && !no_mfma && zwide && left > 8)
+            if (use_mfma && wide && left > 8)
                 g = 16, n = left < 16 ? left : 16;
 #else
-            if (stage_on && use_mfma && ((left >= 9 && left < 16) || odd_tail))
+            if (use_mfma && ((left >= 9 && left < 16) || odd_tail))
                 g = 16, n = left;
-            // 17 and more: sweeps of up to 32 right-hand sides (every tile element read from LDS feeds two MFMAs; the sweep is matrix-core
-            // bound at ~1.2 x the time of a 16-wide one).  HMX_MFMA_WIDE=0: sweeps of 16.
-            static const int wide = getenv("HMX_MFMA_WIDE") ? atoi(getenv("HMX_MFMA_WIDE")) : 1;
-            if (stage_on && use_mfma && wide && left > 16)
+            if (use_mfma && wide && left > 16)
                 g = 32, n = left < 32 ? left : 32;
 #endif
             fn(g, c, n);
             c += n;
         }
     };
+    // stage 1 for every group of right-hand sides, then the partial sums, then stage 2
     for_groups([&](int g, int c, int nrhs) {
-        (void)nrhs;
+        constexpr int W = 4; // tasks (= waves) per workgroup
+        const dim3 grid((unsigned)((RA.ntasks + W - 1) / W)), wg(W * 64);
 #if HMX_COMPLEX
-        if (g == 16) { // only chosen with the staged matrix-core kernels (for_groups)
-            if (RA.ntasks > 0)
-                hipLaunchKernelGGL((reduce_zmfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
-            prof_mark(H, st, "reduce_zmfma16s_kernel");
-            return;
-        }
-        // groups of 8 complex right-hand sides: two real MFMAs per complex tile, stream tiles staged through LDS (HMX_NO_MFMA=1: VALU kernels)
-        if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
-            if (RA.ntasks > 0)
-                hipLaunchKernelGGL((reduce_zmfma8s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
-            prof_mark(H, st, "reduce_zmfma8s_kernel");
-            return;
-        }
-#endif
-#if !HMX_COMPLEX
-        if (g == 32) { // only chosen with the staged matrix-core kernels (for_groups)
-            if (RA.ntasks > 0)
-                hipLaunchKernelGGL((reduce_mfma32s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
-            prof_mark(H, st, "reduce_mfma32s_kernel");
-            return;
-        }
-        if (g == 16 && use_mfma) {
-            // stream tile through LDS (whole-row loads, HMX_MFMA_STAGE=1: the default) | window of X in LDS (HMX_MU_WINDOW=1) | neither
-            static const int staged = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;
-            if (mu_window(H, !staged)) {
-                hipLaunchKernelGGL((reduce_win_mfma16_kernel<WIN_WAVES>), dim3(H.n_win_groups), dim3(WIN_WAVES * 64), 0, st, RA, win_args(H), mu, c);
-                prof_mark(H, st, "reduce_win_mfma16_kernel");
-                return;
-            }
+        if (use_mfma && (g == 16 || g == 8)) {
             if (RA.ntasks > 0) {
-                if (staged)
-                {
-                    static const int rw = getenv("HMX_MFMA_REDUCE_WAVES") ? atoi(getenv("HMX_MFMA_REDUCE_WAVES")) : 4; // tasks (= waves) per workgroup (A/B runs)
-                    if (rw == 1)
-                        hipLaunchKernelGGL((reduce_mfma16s_kernel<1>), dim3(RA.ntasks), dim3(64), 0, st, RA, mu, c, nrhs);
-                    else if (rw == 2)
-                        hipLaunchKernelGGL((reduce_mfma16s_kernel<2>), dim3((RA.ntasks + 1) / 2), dim3(128), 0, st, RA, mu, c, nrhs);
-                    else
-                        hipLaunchKernelGGL((reduce_mfma16s_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c, nrhs);
-                }
+                if (g == 16)
+                    hipLaunchKernelGGL((reduce_zmfma16s_kernel<W>), grid, wg, 0, st, RA, mu, c, nrhs);
                 else
-                    hipLaunchKernelGGL((reduce_mfma16_kernel<4>), dim3((RA.ntasks + 3) / 4), dim3(256), 0, st, RA, mu, c);
+                    hipLaunchKernelGGL((reduce_zmfma8s_kernel<W>), grid, wg, 0, st, RA, mu, c, nrhs);
             }
-            prof_mark(H, st, staged ? "reduce_mfma16s_kernel" : "reduce_mfma16_kernel");
+            prof_mark(H, st, g == 16 ? "reduce_zmfma16s_kernel" : "reduce_zmfma8s_kernel");
+            return;
+        }
+#else
+        if (use_mfma && (g == 32 || g == 16)) {
+            if (RA.ntasks > 0) {
+                if (g == 32)
+                    hipLaunchKernelGGL((reduce_mfma32s_kernel<W>), grid, wg, 0, st, RA, mu, c, nrhs);
+                else
+                    hipLaunchKernelGGL((reduce_mfma16s_kernel<W>), grid, wg, 0, st, RA, mu, c, nrhs);
+            }
+            prof_mark(H, st, g == 32 ? "reduce_mfma32s_kernel" : "reduce_mfma16s_kernel");
             return;
         }
 #endif
-        (void)use_mfma;
         switch (g) {
 #if !HMX_COMPLEX
-        case 16: launch_mu<16>(H, RA, XA, mu, c, st); break;
+        case 16: launch_mu<16>(H, RA, mu, c, st); break;
 #endif
-        case 8: launch_mu<8>(H, RA, XA, mu, c, st); break;
-        case 4: launch_mu<4>(H, RA, XA, mu, c, st); break;
-        case 2: launch_mu<2>(H, RA, XA, mu, c, st); break;
-        default: launch_mu<1>(H, RA, XA, mu, c, st); break;
+        case 8: launch_mu<8>(H, RA, mu, c, st); break;
+        case 4: launch_mu<4>(H, RA, mu, c, st); break;
+        case 2: launch_mu<2>(H, RA, mu, c, st); break;
+        default: launch_mu<1>(H, RA, mu, c, st); break;
         }
     });
     if (H.n_combine > 0) {
@@ -1576,54 +1302,28 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         prof_mark(H, st, "combine_mu_kernel");
     }
     auto expand_group = [&](int g, int c, int nrhs) {
-        (void)nrhs;
+        constexpr int W = 4; // waves per row range
+        const dim3 grid((unsigned)XA.nranges), wg(W * 64);
 #if HMX_COMPLEX
-        if (g == 16) { // only chosen with the staged matrix-core kernels (for_groups)
-            if (XA.nranges > 0)
-                hipLaunchKernelGGL((expand_zmfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
-            prof_mark(H, st, "expand_zmfma16s_kernel");
-            return;
-        }
-        if (g == 8 && !(getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA")))) {
-            if (XA.nranges > 0)
-                hipLaunchKernelGGL((expand_zmfma8s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
-            prof_mark(H, st, "expand_zmfma8s_kernel");
-            return;
-        }
-#endif
-#if !HMX_COMPLEX
-        if (g == 32) {
-            if (XA.nranges > 0)
-                hipLaunchKernelGGL((expand_mfma32s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
-            prof_mark(H, st, "expand_mfma32s_kernel");
-            return;
-        }
-        if (g == 16 && use_mfma) {
-            // groups of sibling row ranges with the shared operand rows staged once (HMX_MU_GROUPS=0: one workgroup per range)
-            static const int stg = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1;
-            static const int grp = getenv("HMX_MU_GROUPS") ? atoi(getenv("HMX_MU_GROUPS")) : -1; // 1: always, 0: never, unset: only without staging
-            if (H.n_grp > 0 && H.grp_shared_frac > 0.15 && (grp > 0 || (grp < 0 && !stg))) {
-                GroupArgs GA{H.d_grp_first.d, H.d_grp_count.d, H.d_grp_prefix.d, H.d_grp_order.d, H.n_grp};
-                hipLaunchKernelGGL((expand_grp_mfma16_kernel<E_GW>), dim3(H.n_grp), dim3(E_GW * 64), 0, st, XA, GA, mu, c);
-                prof_mark(H, st, "expand_grp_mfma16_kernel");
-                return;
-            }
-            static const int staged = getenv("HMX_MFMA_STAGE") ? atoi(getenv("HMX_MFMA_STAGE")) : 1; // stream tile through LDS (whole-column loads)
+        if (use_mfma && (g == 16 || g == 8)) {
             if (XA.nranges > 0) {
-                if (staged)
-                {
-                    static const int xw = getenv("HMX_MFMA_EXPAND_WAVES") ? atoi(getenv("HMX_MFMA_EXPAND_WAVES")) : 4; // waves per row range (A/B runs)
-                    if (xw == 2)
-                        hipLaunchKernelGGL((expand_mfma16s_kernel<2>), dim3(XA.nranges), dim3(128), 0, st, XA, mu, c, nrhs);
-                    else if (xw == 8)
-                        hipLaunchKernelGGL((expand_mfma16s_kernel<8>), dim3(XA.nranges), dim3(512), 0, st, XA, mu, c, nrhs);
-                    else
-                        hipLaunchKernelGGL((expand_mfma16s_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c, nrhs);
-                }
+                if (g == 16)
+                    hipLaunchKernelGGL((expand_zmfma16s_kernel<W>), grid, wg, 0, st, XA, mu, c, nrhs);
                 else
-                    hipLaunchKernelGGL((expand_mfma16_kernel<4>), dim3(XA.nranges), dim3(256), 0, st, XA, mu, c);
+                    hipLaunchKernelGGL((expand_zmfma8s_kernel<W>), grid, wg, 0, st, XA, mu, c, nrhs);
             }
-            prof_mark(H, st, staged ? "expand_mfma16s_kernel" : "expand_mfma16_kernel");
+            prof_mark(H, st, g == 16 ? "expand_zmfma16s_kernel" : "expand_zmfma8s_kernel");
+            return;
+        }
+#else
+        if (use_mfma && (g == 32 || g == 16)) {
+            if (XA.nranges > 0) {
+                if (g == 32)
+                    hipLaunchKernelGGL((expand_mfma32s_kernel<W>), grid, wg, 0, st, XA, mu, c, nrhs);
+                else
+                    hipLaunchKernelGGL((expand_mfma16s_kernel<W>), grid, wg, 0, st, XA, mu, c, nrhs);
+            }
+            prof_mark(H, st, g == 32 ? "expand_mfma32s_kernel" : "expand_mfma16s_kernel");
             return;
         }
 #endif
@@ -1637,7 +1337,7 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
         default: launch_mu_expand<1>(H, XA, mu, c, st); break;
         }
     };
-    if (nchunks > 1 && H.E.nranges() > 1 && H.n_grp == 0) {
+    if (nchunks > 1 && H.E.nranges() > 1) {
         // the expand stage over contiguous groups of row ranges, all groups of right-hand sides per chunk: after chunk c its rows of Y are
         // final and `after_chunk` may start sending them while chunk c + 1 computes (as run_forward does for one vector)
         const int rc = ensure_expand_chunks(H, nchunks);
@@ -1647,12 +1347,12 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
             XA.order   = H.d_chunk_order.d + H.chunk_first[c];
             XA.nranges = H.chunk_count[c];
             if (XA.nranges > 0)
-                for_groups(expand_group, true);
+                for_groups(expand_group);
             if (after_chunk)
                 after_chunk(after_user, c, H.chunk_row_lo[c], H.chunk_row_hi[c]);
         }
     } else {
-        for_groups(expand_group, true);
+        for_groups(expand_group);
         if (after_chunk)
             after_chunk(after_user, 0, 0, H.nT);
     }
@@ -3173,7 +2873,7 @@ int api_matmat_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, sc
         return HMX_ERR_STATE;
     }
     HMat *F = nchunks > 1 ? matmat_layout_n(H) : nullptr;
-    if (!F || F->E.nranges() <= 1 || F->n_grp != 0) {
+    if (!F || F->E.nranges() <= 1) {
         const int rc = matmat_device(H, 'N', alpha, in, beta, out, mu, st);
         if (rc != HMX_OK)
             return rc;
@@ -3199,7 +2899,7 @@ int api_chunk_bounds_mu(HMat *Hp, int nchunks, int *n_out, int32_t *bounds) {
     HMat &H = *Hp;
     HMX_HIP(hipSetDevice(H.device));
     HMat *F = (nchunks > 1 && H.finalized) ? matmat_layout_n(H) : nullptr;
-    if (!F || F->E.nranges() <= 1 || F->n_grp != 0) {
+    if (!F || F->E.nranges() <= 1) {
         *n_out    = 1;
         bounds[0] = 0;
         bounds[1] = H.nT;

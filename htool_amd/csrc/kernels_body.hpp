@@ -1731,9 +1731,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_kernel(ExpandArgs A) {
 // covers R = floor(wave elements / wp) whole rows of the contiguous row-major chunk, lane l works on row group EPL*l / wp and
 // reads ITS row's MU operands from the wave-private LDS tile (R distinct rows per ds_read instead of one broadcast row:
 // the same LDS time for R rows of stream).  The R partial sums per column are folded in a fixed tree at the end.
-// STAGED = false: `xt` already holds the operand rows of the WHOLE piece (a window of X kept in LDS by the workgroup, reduce_win_mu_kernel):
-// nothing is staged, row i of the piece is xt[i].
-template <int MU, bool STAGED = true>
+template <int MU>
 __device__ __forceinline__ void reduce_mu_narrow(const ReduceArgs &A, scalar (*xt)[MU], int lane, int S, int ch, int len, int w, int wp, int cw,
                                                  const scalar *src, const scalar *xs, int mu, int cbase) {
     constexpr int EPL = HMX_SPLIT_COLS ? 1 : 2;
@@ -1746,7 +1744,7 @@ __device__ __forceinline__ void reduce_mu_narrow(const ReduceArgs &A, scalar (*x
         a0[c] = a1[c] = scalar(0);
     for (int i0 = 0; i0 < len; i0 += 64) {
         const int nr = (len - i0) < 64 ? (len - i0) : 64;
-        if (STAGED) {
+        {
             __builtin_amdgcn_wave_barrier();
             if (lane < nr) {
 #pragma unroll
@@ -1755,7 +1753,7 @@ __device__ __forceinline__ void reduce_mu_narrow(const ReduceArgs &A, scalar (*x
             }
             __builtin_amdgcn_wave_barrier();
         }
-        scalar(*const xrow)[MU] = STAGED ? xt : xt + i0;
+        scalar(*const xrow)[MU] = xt;
         const scalar *p = src + (int64_t)i0 * wp + e0;
         for (int j = 0; j < nr; j += 4 * R) {
 #if HMX_SPLIT_COLS
@@ -1910,108 +1908,6 @@ __global__ void combine_mu_kernel(CombineArgs A, int mu) {
     A.Z[(int64_t)A.dst[e] * mu + c] = s;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Multi-RHS reduce stage with the input rows ON CHIP.  In reduce_mu_kernel / reduce_mfma16_kernel every (piece, chunk) task fetches
-// its rows of X itself; the pieces of all cluster levels cover the same rows, so at N = 1e6 a row of X is fetched ~15 times (2.0 GB
-// on a 7.2 GB stream for 16 fp64 right-hand sides: profiles/r2_bench_n1e6_mu16*).  Here the source rows are tiled by WINDOWS (nodes of the
-// source cluster tree of at most 512 rows; the pieces are cut along the same tree, so every piece lies inside one window), one
-// workgroup per (window, split) copies the window's rows of X to LDS once -- one contiguous block of memory -- and its waves run
-// the window's tasks from the list dealt to them at layout time.  Same arithmetic per task as the per-task kernels.
-// ---------------------------------------------------------------------------------------------
-struct WinArgs {
-    const int32_t *win_off, *win_len; // window: first source row (root-local), rows (<= WIN_ROWS)
-    const int32_t *order;             // launch position -> (window, split), heaviest windows first
-    const int32_t *bin_ptr, *bin_task; // tasks of (window, split) g, heaviest first: bin_task[bin_ptr[g] .. bin_ptr[g + 1]); the waves pull them one by one
-    int ngroups;
-};
-
-template <int WAVES, int MU>
-__global__ __launch_bounds__(WAVES *WAVE, 4) void reduce_win_mu_kernel(ReduceArgs A, WinArgs Wn, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) scalar xw[WIN_ROWS][MU];
-    __shared__ int next_task;
-    const int g    = Wn.order[blockIdx.x];
-    if (threadIdx.x == 0)
-        next_task = Wn.bin_ptr[g];
-    const int win  = g / WIN_SPLITS;
-    const int woff = Wn.win_off[win], wlen = Wn.win_len[win];
-    {
-        const scalar *xs = A.x + (int64_t)woff * mu + cbase;
-        for (int e = threadIdx.x; e < wlen * MU; e += WAVES * WAVE) {
-            const int i = e / MU, c = e - i * MU;
-            xw[i][c]    = xs[(int64_t)i * mu + c];
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int q1   = Wn.bin_ptr[g + 1];
-    for (;;) { // the waves pull the tasks of this (window, split) heaviest first: no wave waits for another one's long task
-        int q = 0;
-        if (lane == 0)
-            q = atomicAdd(&next_task, 1);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= q1)
-            break;
-        const int task = Wn.bin_task[q];
-        const int S = A.task_range[task], ch = A.task_chunk[task];
-        const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-        int w = C - ch * cw;
-        w     = w > cw ? cw : w;
-        const int wp      = hmx_wp(w);
-        const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
-        const bool active = col0 < wp;
-        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
-        scalar(*const xr)[MU] = xw + (A.range_off[S] - woff); // this piece's rows of the window
-        if (HMX_REDUCE_ROWS && wp <= (HMX_SPLIT_COLS ? 32 : 64)) {
-            reduce_mu_narrow<MU, false>(A, xr, lane, S, ch, len, w, wp, cw, src, nullptr, mu, cbase);
-            continue;
-        }
-        scalar a0[MU], a1[MU];
-#pragma unroll
-        for (int c = 0; c < MU; c++)
-            a0[c] = a1[c] = scalar(0);
-        int j = 0;
-        for (; j + 4 <= len; j += 4) {
-            scalar2 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                v[u] = load_pair(src + (int64_t)(j + u) * wp, col0, col1, wp);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-#pragma unroll
-                for (int c = 0; c < MU; c++) {
-                    const scalar xi = xr[j + u][c];
-                    a0[c]           = hmx_fma(v[u].x, xi, a0[c]);
-                    a1[c]           = hmx_fma(v[u].y, xi, a1[c]);
-                }
-            }
-        }
-        for (; j < len; j++) {
-            const scalar2 v = load_pair(src + (int64_t)j * wp, col0, col1, wp);
-#pragma unroll
-            for (int c = 0; c < MU; c++) {
-                const scalar xi = xr[j][c];
-                a0[c]           = hmx_fma(v.x, xi, a0[c]);
-                a1[c]           = hmx_fma(v.y, xi, a1[c]);
-            }
-        }
-        if (active) {
-            const int64_t cb = A.range_colbase[S] + ch * cw;
-            if (col0 < w) {
-                scalar *dst = A.Z + (int64_t)A.out_idx[cb + col0] * mu + cbase;
-#pragma unroll
-                for (int c = 0; c < MU; c++)
-                    dst[c] = a0[c];
-            }
-            if (col1 < w) {
-                scalar *dst = A.Z + (int64_t)A.out_idx[cb + col1] * mu + cbase;
-#pragma unroll
-                for (int c = 0; c < MU; c++)
-                    dst[c] = a1[c];
-            }
-        }
-    }
-}
-
 template <int WAVES, int MU>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_mu_kernel(ExpandArgs A, int mu, int cbase) {
     __shared__ __attribute__((aligned(16))) scalar zt[WAVES][WAVE][MU]; // coefficient tiles, reused for the final reduction
@@ -2156,65 +2052,6 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mus_kernel(ReduceArgs A, i
     }
 }
 
-template <int WAVES, int MU>
-__global__ __launch_bounds__(WAVES *WAVE) void expand_mus_kernel(ExpandArgs A, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) scalar zt[WAVES][WAVE][MU]; // final reduction over the waves only
-    const int R = A.order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int len = A.range_len[R], C = A.range_cols[R];
-    const scalar *E   = A.stream + A.range_base[R];
-    uniform_ptr Zu = (uniform_ptr)A.Z, Xu = (uniform_ptr)A.x;
-    const bool active = lane < len;
-    const int row     = active ? lane : 0;
-    scalar acc[MU];
-#pragma unroll
-    for (int c = 0; c < MU; c++)
-        acc[c] = scalar(0);
-    // 64-column tiles per wave as in expand_mu_kernel; the tile's coefficient indices are one coalesced vector load and
-    // reach the scalar unit through v_readlane, so each column costs one s_load of its MU coefficients
-    for (int c0 = wv * 64; c0 < C; c0 += WAVES * 64) {
-        const int nc   = (C - c0) < 64 ? (C - c0) : 64;
-        const int zi_v = lane < nc ? A.z_idx[A.range_colbase[R] + c0 + lane] : 0;
-        const scalar *col = E + (int64_t)c0 * len + row;
-        int j = 0;
-        for (; j + 8 <= nc; j += 8) {
-            scalar v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                v[u] = stream_load(col + (int64_t)(j + u) * len);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int zi   = __builtin_amdgcn_readlane(zi_v, j + u);
-                uniform_ptr zr = (zi < A.nx ? Xu : Zu) + (int64_t)zi * mu + cbase;
-#pragma unroll
-                for (int c = 0; c < MU; c++)
-                    acc[c] = hmx_fma(v[u], zr[c], acc[c]);
-            }
-        }
-        for (; j < nc; j++) {
-            const scalar v = col[(int64_t)j * len];
-            const int zi   = __builtin_amdgcn_readlane(zi_v, j);
-            uniform_ptr zr = (zi < A.nx ? Xu : Zu) + (int64_t)zi * mu + cbase;
-#pragma unroll
-            for (int c = 0; c < MU; c++)
-                acc[c] = hmx_fma(v, zr[c], acc[c]);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < MU; c++)
-        zt[wv][lane][c] = active ? acc[c] : scalar(0);
-    __syncthreads();
-    for (int e = threadIdx.x; e < len * MU; e += WAVES * WAVE) {
-        const int i = e / MU, c = e - i * MU;
-        scalar s = zt[0][i][c];
-#pragma unroll
-        for (int k = 1; k < WAVES; k++)
-            s += zt[k][i][c];
-        scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
-        *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // 16 right-hand sides on the matrix cores.  With mu = 16 the leaf products are real GEMMs
 // (K7-K9 of SURVEY.md 2.2: [rows x cols] x [cols x 16]); the VALU kernels above then spend their time re-reading the
@@ -2225,100 +2062,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mus_kernel(ExpandArgs A, i
 // ---------------------------------------------------------------------------------------------
 typedef Acc4<real>::type acc4;
 
-// One step = 16 columns of a row range (<= 64 rows): the A operands of its 4 x 4 MFMAs (row tile t, column group g) and the 4 B operands.
-struct MfmaStep {
-    real a[4][4], b[4];
-};
-// Loads WITHOUT branches: rows beyond the range re-read its last row (they only reach accumulator rows that are never stored), columns
-// beyond the last one re-read the last column and get a zero operand (and a zero coefficient).  Nothing here depends on a load that is
-// still in flight, so the loads of the next step can be issued before the MFMAs of the current one (the first version of these kernels
-// fetched the operand index of every column group right before its loads: s_waitcnt vmcnt(0) four times per step, and every load
-// behind an exec-mask branch).  `zi` = operand index of column (tile start + lane), fetched once per 64 columns.
-__device__ __forceinline__ void mfma_step_load(MfmaStep &S, const ExpandArgs &A, const real *E, int len, int C, int c, int zi_lane_base, int zi, int mu, int cbase, int m, int kk) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int col  = c + 4 * g + kk;
-        const bool cok = col < C;
-        const int zc   = __shfl(zi, zi_lane_base + 4 * g + kk, WAVE); // the index lane (zi_lane_base + 4 g + kk) holds: no memory access
-        const real bv  = expand_operand(A, zc, mu)[cbase + m];
-        S.b[g]         = cok ? bv : real(0);
-        const real *cp = E + (int64_t)(cok ? col : C - 1) * len;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int row = 16 * t + m;
-            const real v  = stream_load(cp + (row < len ? row : len - 1));
-            S.a[g][t]     = cok ? v : real(0);
-        }
-    }
-}
-__device__ __forceinline__ void mfma_step_apply(const MfmaStep &S, acc4 (&acc)[4]) {
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            acc[t] = mfma16(S.a[g][t], S.b[g], acc[t]);
-}
-// The columns [c_lo, c_hi) of one range for ONE wave, in tiles of 64 columns (4 steps), double buffered.
-__device__ __forceinline__ void mfma_expand_columns(const ExpandArgs &A, const real *E, const int32_t *zidx, int len, int C, int c_lo, int c_hi, int tile_stride, int mu, int cbase,
-                                                    int lane, acc4 (&acc)[4]) {
-    const int m = lane & 15, kk = lane >> 4; // A: row m of the tile, column kk of the group; B: column kk, rhs m
-    for (int t0 = c_lo; t0 < c_hi; t0 += tile_stride) {
-        const int tend = (t0 + 64) < c_hi ? (t0 + 64) : c_hi;
-        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1]; // columns beyond the range: any valid index (their operand is zeroed)
-        MfmaStep S0, S1;
-        mfma_step_load(S0, A, E, len, C, t0, 0, zi, mu, cbase, m, kk);
-        if (t0 + 16 < tend)
-            mfma_step_load(S1, A, E, len, C, t0 + 16, 16, zi, mu, cbase, m, kk);
-        mfma_step_apply(S0, acc);
-        if (t0 + 32 < tend)
-            mfma_step_load(S0, A, E, len, C, t0 + 32, 32, zi, mu, cbase, m, kk);
-        if (t0 + 16 < tend)
-            mfma_step_apply(S1, acc);
-        if (t0 + 48 < tend)
-            mfma_step_load(S1, A, E, len, C, t0 + 48, 48, zi, mu, cbase, m, kk);
-        if (t0 + 32 < tend)
-            mfma_step_apply(S0, acc);
-        if (t0 + 48 < tend)
-            mfma_step_apply(S1, acc);
-    }
-}
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16_kernel(ExpandArgs A, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) real red[WAVES][WAVE][16];
-    const int R = A.order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int len = A.range_len[R], C = A.range_cols[R];
-    const real *E       = A.stream + A.range_base[R];
-    const int32_t *zidx = A.z_idx + A.range_colbase[R];
-    const int m = lane & 15;
-    acc4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-        acc[t] = acc4{0, 0, 0, 0};
-    // wave w takes the 64-column tiles w, w + WAVES, ...
-    if (C > 0)
-        mfma_expand_columns(A, E, zidx, len, C, wv * 64, C, WAVES * 64, mu, cbase, lane, acc);
-    // accumulator tile t, register j of lane l = (row 16t + mfma16_row, rhs l & 15): stage as [row][rhs]
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = acc[t][j];
-    __syncthreads();
-    for (int e = threadIdx.x; e < len * 16; e += WAVES * WAVE) {
-        const int i = e >> 4, c = e & 15;
-        real s = red[0][i][c];
-#pragma unroll
-        for (int w = 1; w < WAVES; w++)
-            s += red[w][i][c];
-        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
-        *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
-    }
-}
-
-// expand_mfma16_kernel with the stream tile STAGED THROUGH LDS.  In the kernel above every lane fetches its own MFMA operand element:
+// The stream tile is STAGED THROUGH LDS.  In the first version of this kernel (round 2) every lane fetched its own MFMA operand element:
 // one load instruction of a wave is four 128-byte pieces of four different columns (16 rows x 8 bytes each, and a column of a 61-row
 // range starts at an odd multiple of 8 bytes, so most pieces straddle two lines) -- the kernel moves its bytes at 5 TB/s where the
 // single-vector expand_kernel, whose loads are whole columns (lane = row: 488 contiguous bytes), reaches 6.5 TB/s.  Here the loads
@@ -2541,169 +2285,7 @@ __global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))
     }
 }
 
-// expand_mfma16_kernel for GROUPS of sibling row ranges.  A low-rank leaf of m rows reaches m / 64 row ranges and every one of them
-// fetches the leaf's rows of `a` again (at N = 1e6 a range has 890 low-rank columns, 16 fp64 right-hand sides: 114 KB of gathered
-// rows per 430 KB of U slices; summed over the ranges every row of `a` is fetched 4.6 times).  The layout orders the columns of a
-// range by decreasing target cluster, so consecutive ranges share a PREFIX of their column lists (the leaves whose target cluster
-// contains all of them).  One workgroup takes GW consecutive ranges, one wave each: the common prefix is walked in lock step, its
-// operand rows staged ONCE per 64 columns in LDS (double buffered: the next tile's gather is in flight under the MFMAs of the current
-// one), then every wave finishes its private columns alone with the operand straight from memory as before.  A wave owns its rows: no
-// reduction over the waves at the end.
-struct GroupArgs {
-    const int32_t *first, *count, *prefix; // group: first range, ranges (<= GW), columns common to all of them (a prefix of each list)
-    const int32_t *order;                  // launch position -> group (heaviest first)
-    int ngroups;
-};
-template <int GW>
-__global__ __launch_bounds__(GW *WAVE) void expand_grp_mfma16_kernel(ExpandArgs A, GroupArgs Gp, int mu, int cbase) {
-    static_assert(GW == 4, "the staging below deals 64 x 16 values to 256 threads");
-    __shared__ __attribute__((aligned(16))) real zt[2][64][16];
-    const int g  = Gp.order[blockIdx.x];
-    const int r0 = Gp.first[g], cnt = Gp.count[g], P = Gp.prefix[g];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool have = wv < cnt;
-    const int R     = r0 + (have ? wv : 0);
-    const int len = have ? A.range_len[R] : 0, C = have ? A.range_cols[R] : 0;
-    const real *E        = A.stream + A.range_base[R];
-    const int32_t *zidx0 = A.z_idx + A.range_colbase[r0]; // the common columns: the first range's list serves all
-    const int m = lane & 15, kk = lane >> 4;              // A: row m of the tile, column kk of the group; B: column kk, rhs m
-    acc4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-        acc[t] = acc4{0, 0, 0, 0};
-    // ---- common prefix: tiles of 64 columns, operand rows through LDS ----
-    const int ntile = (P + 63) >> 6;
-    const int srow = threadIdx.x >> 2, sq = (threadIdx.x & 3) * 4; // this thread's share of a tile: 4 right-hand sides of one column
-    real pre[4] = {0, 0, 0, 0};
-    auto fetch = [&](int tile) {
-        const int col = tile * 64 + srow;
-        if (col < P) {
-            const real *zr = expand_operand(A, zidx0[col], mu) + cbase + sq;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                pre[k] = zr[k];
-        }
-    };
-    if (ntile > 0)
-        fetch(0);
-    for (int i = 0; i < ntile; i++) {
-        real(*buf)[16] = zt[i & 1];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            buf[srow][sq + k] = pre[k];
-        __syncthreads(); // one barrier per tile: the other buffer was last read in step i - 1, which every wave has left
-        if (i + 1 < ntile)
-            fetch(i + 1);
-        const int nc = (P - 64 * i) < 64 ? (P - 64 * i) : 64;
-        if (have) { // the tile's (up to) four steps, double buffered, loads without branches (see mfma_step_load)
-            auto load = [&](MfmaStep &S, int c0) {
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int col  = c0 + 4 * gq + kk;
-                    const bool cok = col < nc;
-                    const real bv  = buf[cok ? col : 0][m];
-                    S.b[gq]        = cok ? bv : real(0);
-                    const real *cp = E + (int64_t)(64 * i + (cok ? col : 0)) * len;
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int row = 16 * t + m;
-                        const real v  = stream_load(cp + (row < len ? row : len - 1));
-                        S.a[gq][t]    = cok ? v : real(0);
-                    }
-                }
-            };
-            MfmaStep S0, S1;
-            load(S0, 0);
-            if (16 < nc)
-                load(S1, 16);
-            mfma_step_apply(S0, acc);
-            if (32 < nc)
-                load(S0, 32);
-            if (16 < nc)
-                mfma_step_apply(S1, acc);
-            if (48 < nc)
-                load(S1, 48);
-            if (32 < nc)
-                mfma_step_apply(S0, acc);
-            if (48 < nc)
-                mfma_step_apply(S1, acc);
-        }
-    }
-    if (!have)
-        return;
-    // ---- private columns: this wave alone, operand rows straight from memory ----
-    if (P < C)
-        mfma_expand_columns(A, E, A.z_idx + A.range_colbase[R], len, C, P, C, 64, mu, cbase, lane, acc);
-    // accumulator tile t, register j of lane l = (row 16 t + mfma16_row, rhs l & 15): the wave owns these rows
-    // (16-byte loads of row pairs were tried here as in the reduce stage: slower, 2.47 against 2.36 ms -- a column starts at an odd
-    // multiple of 8 bytes whenever the range has an odd number of rows, and half the pairs then straddle a 128-byte line)
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int row = 16 * t + mfma16_row(real(0), lane, j);
-            if (row < len) {
-                real *yo = A.y + (int64_t)(A.range_off[R] + row) * mu + cbase + m;
-                *yo      = A.beta == real(0) ? A.alpha * acc[t][j] : A.alpha * acc[t][j] + A.beta * (*yo);
-            }
-        }
-}
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16_kernel(ReduceArgs A, int mu, int cbase) {
-    const int wv   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = blockIdx.x * WAVES + wv;
-    if (task >= A.ntasks)
-        return;
-    const int lane = threadIdx.x & 63;
-    const int S = A.task_range[task], ch = A.task_chunk[task];
-    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-    int w = C - ch * cw;
-    w     = w > cw ? cw : w;
-    const int wp      = hmx_wp(w);
-    const int ntile   = (w + 15) >> 4; // <= 8 column tiles of 16
-    const real *src   = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
-    const real *xs    = A.x + (int64_t)A.range_off[S] * mu + cbase;
-    const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, rhs m
-    acc4 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++)
-        acc[t] = acc4{0, 0, 0, 0};
-    // two 4-row steps per iteration: 16 stream loads + 2 operand loads in flight before the MFMAs
-    for (int i0 = 0; i0 < len; i0 += 8) {
-        real b[2], a[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int row  = i0 + 4 * h + kk;
-            const bool rok = row < len;
-            b[h]           = rok ? xs[(int64_t)row * mu + m] : real(0);
-            const real *rp = src + (int64_t)(rok ? row : 0) * wp;
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int col = 16 * t + m;
-                a[h][t]       = (t < ntile && rok && col < w) ? stream_load(rp + col) : real(0);
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int t = 0; t < 8; t++)
-                if (t < ntile)
-                    acc[t] = mfma16(a[h][t], b[h], acc[t]);
-    }
-    const int64_t cb = A.range_colbase[S] + ch * cw;
-#pragma unroll
-    for (int t = 0; t < 8; t++)
-        if (t < ntile)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int col = 16 * t + mfma16_row(real(0), lane, j);
-                if (col < w)
-                    A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
-            }
-}
-
-// reduce_mfma16_kernel with the stream tile staged through LDS, as expand_mfma16s_kernel: the loads are those of the single-vector
+// The reduce stage on the matrix cores, stream tile staged through LDS as in expand_mfma16s_kernel: the loads are those of the single-vector
 // reduce_kernel (a lane fetches two adjacent columns, a wave one whole row of the chunk: up to 1 KiB contiguous), eight rows per step
 // with the next eight in flight, and the 8 x 128 tile reaches the lanes in operand layout through a wave-private LDS buffer
 // (144-element row pitch: rows 32 banks apart).
@@ -2918,83 +2500,6 @@ __global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))
                         if (16 + m < nrhs)
                             A.Z[(int64_t)dst * mu + cbase + 16 + m] = acc2[t][j];
                     }
-                }
-    }
-}
-
-// reduce_mfma16_kernel with the window's rows of X in LDS (see reduce_win_mu_kernel): the B operand of a step (4 rows x 16
-// right-hand sides) is one conflict-free ds_read per lane instead of a global load that, summed over the tasks, re-fetches X ~15 times.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE, 4) void reduce_win_mfma16_kernel(ReduceArgs A, WinArgs Wn, int mu, int cbase) {
-    __shared__ __attribute__((aligned(16))) real xw[WIN_ROWS][16];
-    __shared__ int next_task;
-    const int g    = Wn.order[blockIdx.x];
-    if (threadIdx.x == 0)
-        next_task = Wn.bin_ptr[g];
-    const int win  = g / WIN_SPLITS;
-    const int woff = Wn.win_off[win], wlen = Wn.win_len[win];
-    {
-        const real *xs = A.x + (int64_t)woff * mu + cbase;
-        for (int e = threadIdx.x; e < wlen * 16; e += WAVES * WAVE)
-            xw[e >> 4][e & 15] = xs[(int64_t)(e >> 4) * mu + (e & 15)];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int m = lane & 15, kk = lane >> 4; // A: column m of the tile, row kk of the step; B: row kk, rhs m
-    const int q1 = Wn.bin_ptr[g + 1];
-    for (;;) {
-        int q = 0;
-        if (lane == 0)
-            q = atomicAdd(&next_task, 1);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= q1)
-            break;
-        const int task = Wn.bin_task[q];
-        const int S = A.task_range[task], ch = A.task_chunk[task];
-        const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-        int w = C - ch * cw;
-        w     = w > cw ? cw : w;
-        const int wp    = hmx_wp(w);
-        const int ntile = 2 * ((w + 31) >> 5); // column tiles of 16 in use, in pairs (<= 8)
-        const real *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
-        const real(*xr)[16] = xw + (A.range_off[S] - woff);
-        acc4 acc[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-            acc[t] = acc4{0, 0, 0, 0};
-        for (int i0 = 0; i0 < len; i0 += 8) {
-            real b[2], a[2][8];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int row  = i0 + 4 * h + kk;
-                const bool rok = row < len;
-                b[h]           = rok ? xr[row][m] : real(0);
-                const real *rp = src + (int64_t)(rok ? row : 0) * wp;
-#pragma unroll
-                for (int pr = 0; pr < 4; pr++) { // tile 2 pr: the even columns of [32 pr, 32 pr + 32), tile 2 pr + 1: the odd ones -- one 16-byte load feeds both
-                    const int col = 32 * pr + 2 * m;
-                    if (2 * pr < ntile)
-                        stream_load2(rp + col, rok ? w - col : 0, a[h][2 * pr], a[h][2 * pr + 1]);
-                    else
-                        a[h][2 * pr] = a[h][2 * pr + 1] = real(0);
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int t = 0; t < 8; t++)
-                    if (t < ntile)
-                        acc[t] = mfma16(a[h][t], b[h], acc[t]);
-        }
-        const int64_t cb = A.range_colbase[S] + ch * cw;
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-            if (t < ntile)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int col = 32 * (t >> 1) + 2 * mfma16_row(real(0), lane, j) + (t & 1);
-                    if (col < w)
-                        A.Z[(int64_t)A.out_idx[cb + col] * mu + cbase + m] = acc[t][j];
                 }
     }
 }

@@ -20,11 +20,6 @@
 namespace hmx {
 
 constexpr int WAVE = 64;
-// multi-RHS reduce stage with a window of the input in LDS (reduce_win_* kernels): rows per window at most, workgroups per window,
-// waves per workgroup
-constexpr int WIN_ROWS = 512, WIN_SPLITS = 2, WIN_WAVES = 8;
-// row ranges per workgroup in the grouped multi-RHS expand stage (expand_grp_* kernels), one wave each
-constexpr int E_GW = 4;
 
 struct KernelSpec { // device-evaluable generator
     int kind;
@@ -298,28 +293,5 @@ __device__ __forceinline__ hmx_d4 mfma16(double a, double b, hmx_d4 c) { return 
 __device__ __forceinline__ hmx_f4 mfma16(float a, float b, hmx_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int mfma16_row(double, int lane, int reg) { return (lane >> 4) + 4 * reg; }
 __device__ __forceinline__ int mfma16_row(float, int lane, int reg) { return 4 * (lane >> 4) + reg; }
-
-static __global__ void copy16_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n) {
-    int64_t i            = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride)
-        out[i] = in[i];
-}
-
-// read-only probe: every workgroup streams its own contiguous chunk with 16-byte non-temporal loads (four in flight per lane)
-// and keeps running sums -- the access pattern of the stream kernels without any of their arithmetic or gathers
-static __global__ __launch_bounds__(256) void read16_kernel(const double2 *__restrict__ in, double *__restrict__ out, int64_t n) {
-    const int64_t per = n / gridDim.x;
-    const double2 *p  = in + per * blockIdx.x;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int64_t i = threadIdx.x; i + 3 * 256 < per; i += 4 * 256) {
-        const double2 a = stream_load(p + i), b = stream_load(p + i + 256), c = stream_load(p + i + 512), d = stream_load(p + i + 768);
-        s0 += a.x + a.y;
-        s1 += b.x + b.y;
-        s2 += c.x + c.y;
-        s3 += d.x + d.y;
-    }
-    out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = (s0 + s1) + (s2 + s3);
-}
 
 } // namespace hmx
