@@ -59,6 +59,11 @@ def parse():
     ap.add_argument("--cpu-sample-frac", type=float, default=1.0 / 16)
     ap.add_argument("--dist-impl", default=os.environ.get("HMX_BENCH_DIST_IMPL", "native"), choices=["native", "python"],
                     help="N > 1: hmx_dist_* through one C call per step (native) or the torch.distributed layer (python)")
+    ap.add_argument("--generator", default="device", choices=["device", "callback"],
+                    help="device: the built-in kernel evaluated on the GPU; callback: the same function as a USER's VirtualGenerator in compiled host code "
+                         "(examples/host_generator.c through hmx_hmatrix_set_callback) -- the literal drop-in route of examples/use_hmatrix.cpp")
+    ap.add_argument("--callback-threads", type=int, default=0, help="host threads that call the generator (0: all cores, at most 64)")
+    ap.add_argument("--no-callback-build", action="store_true", help="do not time a second build of the operator through the host-generator route")
     ap.add_argument("--no-reference", action="store_true", help="skip the timing of htool itself (oracle/_ref/ref_driver) on the host cores")
     return ap.parse_args()
 
@@ -130,6 +135,21 @@ def kernel_sources_hash():
         with open(os.path.join(ROOT, "htool_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def host_generator(hm, x, np_dt, cplx, herm, threads):
+    """examples/host_generator.c (examples/libhostgen.so, built by __graft_entry__.build()) as an htool_amd.NativeGenerator"""
+    import ctypes as C
+
+    class InvDist(C.Structure):
+        _fields_ = [("dim", C.c_int32), ("pad", C.c_int32), ("target", C.c_void_p), ("source", C.c_void_p), ("delta", C.c_double), ("scale", C.c_double),
+                    ("cre", C.c_double), ("cim", C.c_double), ("hermitian", C.c_int32), ("pad2", C.c_int32)]
+    lib = C.CDLL(os.path.join(ROOT, "examples", "libhostgen.so"))
+    xc = np.ascontiguousarray(x, dtype=np.float64)
+    g = InvDist(3, 0, xc.ctypes.data, xc.ctypes.data, 1e-5, 1.0, 1.0, 1.0 if cplx else 0.0, int(bool(herm)), 0)
+    fn = {np.dtype(np.float64): lib.hostgen_inv_dist_f64, np.dtype(np.float32): lib.hostgen_inv_dist_f32,
+          np.dtype(np.complex128): lib.hostgen_inv_dist_z64, np.dtype(np.complex64): lib.hostgen_inv_dist_c32}[np.dtype(np_dt)]
+    return hm.NativeGenerator(fn, C.addressof(g), threads=threads, keep=(lib, g, xc))
 
 
 def minimal_depth(n):
@@ -372,6 +392,8 @@ def main():
     t_dt = {"f64": torch.float64, "f32": torch.float32, "z64": torch.complex128, "c32": torch.complex64}[args.dtype]
     esz = float(np.dtype(np_dt).itemsize)
     malloc0 = hm.lib().hmx_device_malloc_seconds()
+    if args.generator == "callback":
+        gen = host_generator(hm, x, np_dt, cplx, args.sym == "H", args.callback_threads)
     H = tb.build(gen, T, T, brank, brank, device=local_rank, dtype=np_dt)
     if args.recompress:
         tr = time.time()
@@ -670,6 +692,27 @@ def main():
                     # timed build no longer pays) + the device build; and the operator's stored coefficients per second of all that
                     device_init_s=t_init, device_total_with_reserve_s=t_build + t_res, end_to_end_s=t_tree + t_init + t_res + t_build,
                     entries_per_s_end_to_end=(st["cgen_dense"] + st["cgen_lowrank"]) / (t_tree + t_init + t_res + t_build))
+
+    compress["generator"] = args.generator
+    if args.generator == "callback":
+        compress["callback_build_s"] = t_build
+        compress["callback_threads"] = args.callback_threads if args.callback_threads > 0 else min(64, os.cpu_count() or 1)
+    elif rank == 0 and world == 1 and not emu and not args.no_callback_build and os.path.exists(os.path.join(ROOT, "examples", "libhostgen.so")):
+        # the literal drop-in route next to the device-kernel build: the SAME operator built again from a user's host generator (compiled code
+        # libhmx knows nothing about, called on all cores; lock-step ACA and every product on the device), timed, compared, dropped
+        try:
+            t0 = time.time()
+            Hc = tb.build(host_generator(hm, x, np_dt, cplx, args.sym == "H", args.callback_threads), T, T, brank, brank, device=local_rank, dtype=np_dt)
+            torch.cuda.synchronize()
+            compress["callback_build_s"] = time.time() - t0
+            compress["callback_threads"] = args.callback_threads if args.callback_threads > 0 else min(64, os.cpu_count() or 1)
+            compress["callback_ranks_equal_device_build"] = bool(np.array_equal(Hc.leaf_table(), H.leaf_table()))
+            stc = Hc.stats()
+            compress["callback_entries_per_s"] = (stc["cgen_dense"] + stc["cgen_lowrank"]) / compress["callback_build_s"]
+            del Hc
+        except Exception as e:  # noqa: BLE001 -- a reported extra, never the product path
+            compress["callback_build_s"] = None
+            compress["callback_error"] = repr(e)
 
     out = dict(metric="hmatvec_effective_throughput", value=value, unit="GB/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None, dtype=args.dtype, data="synthetic",

@@ -104,6 +104,7 @@ SYMBOLS = [
     ("hmx_hmatrix_set_kernel", C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
     ("hmx_hmatrix_set_callback", C.c_int, [_vp, GENERATOR_FN, _vp]),
     ("hmx_hmatrix_set_callback_s", C.c_int, [_vp, GENERATOR_FN_S, _vp]),
+    ("hmx_hmatrix_set_callback_threads", C.c_int, [_vp, C.c_int]),
     ("hmx_hmatrix_compress", C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
     ("hmx_hmatrix_recompress", C.c_int, [_vp, C.c_double]),
     ("hmx_hmatrix_set_block_lowrank", C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp]),

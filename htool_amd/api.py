@@ -236,7 +236,14 @@ class VirtualGenerator:
     """User-defined generator, mirror of htool's VirtualGenerator (hmatrix/interfaces/virtual_generator.hpp:17-31):
     subclass and implement copy_submatrix(M, N, rows, cols) -> array of shape (M, N) holding A[rows[j], cols[k]]
     (rows / cols are numpy int32 arrays in USER numbering).  The generator runs on the host; the engine calls it for
-    one cross row / column per block and ACA iteration and for the dense leaves, everything else runs on the GPU."""
+    one cross row / column per block and ACA iteration and for the dense leaves, everything else runs on the GPU.
+
+    A Python generator is called from the calling thread only (htool does the same for its Python interface:
+    HTOOL_WITH_PYTHON_INTERFACE, hmatrix/tree_builder/tree_builder.hpp:606).  `parallel = True` on the subclass lets the
+    engine call copy_submatrix from all host threads -- worth it only when it spends its time in code that releases the
+    GIL.  NativeGenerator wraps a C function pointer instead, which runs on all cores like a C++ VirtualGenerator."""
+
+    parallel = False
 
     def copy_submatrix(self, M, N, rows, cols):
         raise NotImplementedError
@@ -263,6 +270,21 @@ class VirtualGenerator:
             else:
                 np.ctypeslib.as_array(out, shape=(N, M))[:] = block.T  # column-major M x N
         return fn_t(trampoline)
+
+
+class NativeGenerator:
+    """A VirtualGenerator that is compiled code: `function` is the address of (or a ctypes pointer to) a C function
+    void f(void *user, int M, int N, const int32_t *rows, const int32_t *cols, T *out) with copy_submatrix semantics
+    (hmatrix/interfaces/virtual_generator.hpp:24: column-major M x N block of user-numbered rows / cols; T = the
+    operator's real type, complex entries interleaved), `user` its first argument.  It is called concurrently from
+    `threads` host threads (0: all cores), as htool calls a C++ generator from its OpenMP build loop.  `keep` holds
+    whatever must outlive the build (the ctypes library, coordinate arrays)."""
+
+    def __init__(self, function, user=None, threads=0, keep=None):
+        self.function = C.cast(function, C.c_void_p)
+        self.user = C.cast(user, C.c_void_p) if user is not None else None
+        self.threads = threads
+        self.keep = keep
 
 
 # coefficient types: htool's HMatrix<double>, <float>, <std::complex<double>>, <std::complex<float>>
@@ -585,9 +607,15 @@ class HMatrixTreeBuilder:
         t_create = time.perf_counter() - t_create
         H._tree_parameters = dict(eta=self._eta, epsilon=self._eps, min_target_depth=self._mint, min_source_depth=self._mins)
         H._block_tree_walltime = t_bt
-        if isinstance(generator, VirtualGenerator):
+        if isinstance(generator, NativeGenerator):
+            H._callback = generator  # keeps the library and the user data alive as long as the operator
+            fn_t = _lib.GENERATOR_FN_S if H.prec in (_lib.HMX_PREC_F32, _lib.HMX_PREC_C32) else _lib.GENERATOR_FN
+            check(_fn(H, "hmx_hmatrix_set_callback")(h, C.cast(generator.function, fn_t), generator.user))
+            check(lib().hmx_hmatrix_set_callback_threads(h, int(generator.threads)))
+        elif isinstance(generator, VirtualGenerator):
             H._callback = generator._as_callback(H.prec)  # keep the ctypes thunk alive as long as the operator
             check(_fn(H, "hmx_hmatrix_set_callback")(h, H._callback, None))
+            check(lib().hmx_hmatrix_set_callback_threads(h, 0 if generator.parallel else 1))
         elif generator is not None:
             if not isinstance(generator, InvDistGenerator):
                 raise HmxError("generator must be an InvDistGenerator (evaluated on the device) or a VirtualGenerator "

@@ -240,6 +240,7 @@ int hmx_hmatrix_set_callback_s(hmx_hmatrix *H, hmx_generator_fn_s fn, void *user
     HMX_NEED(H, s, "hmx_hmatrix_set_callback_s");
     HMX_GUARD(hmx::f32::api_set_callback(H->s, fn, user));
 }
+int hmx_hmatrix_set_callback_threads(hmx_hmatrix *H, int threads) { HMX_ALL(H, api_set_callback_threads, threads); }
 int hmx_hmatrix_compress(hmx_hmatrix *H, int compressor, double epsilon, int reqrank) {
     HMX_ALL(H, api_compress, compressor, epsilon, reqrank);
 }

@@ -62,6 +62,7 @@ struct HMat {
     // host generator: VirtualGenerator::copy_submatrix semantics (user numbering, column-major output)
     void (*callback)(void *, int, int, const int32_t *, const int32_t *, scalar *) = nullptr;
     void *callback_user = nullptr;
+    int callback_threads = 0; // host threads that may call the generator concurrently: 0 = all cores (HMX_CALLBACK_THREADS), 1 = the calling thread only
     DArr<scalar> dense_stage; // dense leaves evaluated by the host generator (pack_dense reads them from here)
     bool has_kernel = false;
     KernelSpec ks{};
@@ -1624,6 +1625,14 @@ int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
 }
 
 
+int api_set_callback_threads(HMat *H, int threads) {
+    if (!H || threads < 0) {
+        set_error("hmx_hmatrix_set_callback_threads: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    H->callback_threads = threads;
+    return HMX_OK;
+}
 int api_set_kernel(HMat *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc) {
     if (!H || !params || !tc || !sc || kernel != HMX_KERNEL_INV_DIST || nparams < 2 || (dim != 2 && dim != 3)) {
         set_error("hmx_hmatrix_set_kernel: invalid arguments");
@@ -1664,6 +1673,237 @@ int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, cons
     H->callback      = fn;
     H->callback_user = user;
     H->has_kernel    = false;
+    return HMX_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Host generator on all cores.  The reference compresses the admissible blocks and assembles the dense ones from an OpenMP
+// `parallel for` (HMatrixTreeBuilder::openmp_compute_blocks, hmatrix/tree_builder/tree_builder.hpp:603-648), i.e. the user's
+// VirtualGenerator::copy_submatrix runs on every core unless HTOOL_WITH_PYTHON_INTERFACE is defined (:606).  Here the generator
+// threads are LANES: a lane owns a HIP stream and two slots (pinned host buffer + device buffer + an event), so that it evaluates
+// the generator for one slot while the other slot's upload, kernel and (for the ACA) packed result copy are in flight.
+//   * ACA: the admissible blocks are cut into batches (largest blocks first); a slot takes a batch and runs the lock-step iteration on
+//     it -- evaluate one line per active block into pinned memory, one H2D copy, one aca_cb_*_kernel launch over the batch, one packed
+//     D2H copy of (status, I1, I2) -- until the batch is done, then takes the next batch.  Batches progress independently, so the
+//     GPU always has other lanes' launches to run while this one's host thread is inside the generator.
+//   * dense leaves / assembled blocks: panels of whole columns, evaluated into pinned memory and copied to their place.
+// hmx_hmatrix_set_callback_threads(H, 1) (or HMX_CALLBACK_THREADS=1) keeps every call on the calling thread.
+// ---------------------------------------------------------------------------------------------
+struct CbSlot {
+    scalar *h_buf = nullptr, *d_buf = nullptr;
+    size_t cap = 0; // entries
+    CbItem *h_items = nullptr, *d_items = nullptr;
+    CbResult *h_res = nullptr, *d_res = nullptr;
+    size_t cap_blocks = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    // the batch in progress (ACA)
+    std::vector<int32_t> active, I1, I2;
+    bool row_phase = true;
+    hipError_t ensure(size_t entries, size_t blocks) {
+        hipError_t e;
+        if (entries > cap) {
+            if (h_buf)
+                (void)hipHostFree(h_buf);
+            if (d_buf)
+                (void)hipFree(d_buf);
+            h_buf = d_buf = nullptr;
+            cap   = 0;
+            const size_t want = std::max(entries, (size_t)(1 << 20) / sizeof(scalar));
+            if ((e = hipHostMalloc((void **)&h_buf, want * sizeof(scalar), hipHostMallocDefault)) != hipSuccess)
+                return e;
+            if ((e = hipMalloc((void **)&d_buf, want * sizeof(scalar))) != hipSuccess)
+                return e;
+            cap = want;
+        }
+        if (blocks > cap_blocks) {
+            if (h_items)
+                (void)hipHostFree(h_items);
+            if (d_items)
+                (void)hipFree(d_items);
+            h_items = d_items = nullptr;
+            h_res = d_res = nullptr;
+            cap_blocks    = 0;
+            // items and results share one allocation each (both 16 bytes per position)
+            if ((e = hipHostMalloc((void **)&h_items, blocks * (sizeof(CbItem) + sizeof(CbResult)), hipHostMallocDefault)) != hipSuccess)
+                return e;
+            if ((e = hipMalloc((void **)&d_items, blocks * (sizeof(CbItem) + sizeof(CbResult)))) != hipSuccess)
+                return e;
+            h_res      = reinterpret_cast<CbResult *>(h_items + blocks);
+            d_res      = reinterpret_cast<CbResult *>(d_items + blocks);
+            cap_blocks = blocks;
+        }
+        if (!done && (e = hipEventCreateWithFlags(&done, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess)
+            return e;
+        return hipSuccess;
+    }
+    hipError_t wait() {
+        if (!pending)
+            return hipSuccess;
+        pending = false;
+        return hipEventSynchronize(done);
+    }
+    void destroy() {
+        if (h_buf)
+            (void)hipHostFree(h_buf);
+        if (d_buf)
+            (void)hipFree(d_buf);
+        if (h_items)
+            (void)hipHostFree(h_items);
+        if (d_items)
+            (void)hipFree(d_items);
+        if (done)
+            (void)hipEventDestroy(done);
+        h_buf = d_buf = nullptr;
+        h_items = d_items = nullptr;
+        done              = nullptr;
+        cap = cap_blocks = 0;
+    }
+};
+struct CbLane {
+    hipStream_t st = nullptr;
+    CbSlot slot[2];
+};
+struct CbLanes {
+    int device = 0;
+    std::vector<CbLane> lanes;
+    std::mutex mu;
+    std::string error; // first failure of any lane
+    std::atomic<bool> failed{false};
+    explicit CbLanes(int dev, int n) : device(dev), lanes((size_t)std::max(1, n)) {}
+    CbLanes(const CbLanes &)            = delete;
+    CbLanes &operator=(const CbLanes &) = delete;
+    ~CbLanes() {
+        (void)hipSetDevice(device);
+        for (auto &L : lanes) {
+            if (L.st)
+                (void)hipStreamSynchronize(L.st);
+            for (auto &S : L.slot)
+                S.destroy();
+            if (L.st)
+                (void)hipStreamDestroy(L.st);
+        }
+    }
+    void fail(const std::string &what) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (error.empty())
+            error = what;
+        failed = true;
+    }
+    // fn(lane index) on every lane, each on its own thread (one lane: the calling thread); false when a lane reported an error
+    template <typename F>
+    bool run(F &&fn) {
+        auto body = [&](int t) {
+            try {
+                if (hipSetDevice(device) != hipSuccess) {
+                    fail("hipSetDevice failed in a generator thread");
+                    return;
+                }
+                if (!lanes[t].st && hipStreamCreateWithFlags(&lanes[t].st, hipStreamNonBlocking) != hipSuccess) {
+                    fail("hipStreamCreate failed in a generator thread");
+                    return;
+                }
+                fn(t);
+            } catch (const std::exception &e) {
+                fail(std::string("exception in a generator thread: ") + e.what());
+            } catch (...) {
+                fail("exception in a generator thread");
+            }
+        };
+        if (lanes.size() == 1) {
+            body(0);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < lanes.size(); t++)
+                th.emplace_back(body, (int)t);
+            for (auto &x : th)
+                x.join();
+        }
+        return !failed;
+    }
+};
+#define HMX_LANE_HIP(LN, call)                                                                                          \
+    do {                                                                                                                \
+        const hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                         \
+            (LN).fail(std::string(#call) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+            return;                                                                                                     \
+        }                                                                                                               \
+    } while (0)
+
+static int callback_thread_count(const HMat &H) {
+    int n = H.callback_threads;
+    if (n <= 0) {
+        const char *e = getenv("HMX_CALLBACK_THREADS");
+        n             = e && atoi(e) > 0 ? atoi(e) : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    }
+    return std::max(1, std::min(n, 256));
+}
+
+// Blocks assembled by the host generator into device memory: block `blocks[k]` (M x N, column-major, HMatrix::compute_dense_data's
+// layout, hmatrix/hmatrix.hpp:222-226) goes to dest + dst_off[blocks[k]]; the offsets must be the running total of the block sizes in
+// the order of `blocks`, so that whatever a slot evaluated in one go is one contiguous copy.  Large blocks are cut into panels of whole
+// columns (a panel of a column-major block is contiguous).
+static int cb_fill_blocks(HMat &H, CbLanes &LN, const std::vector<int32_t> &blocks, const std::vector<int64_t> &dst_off, scalar *dest) {
+    struct Unit {
+        int32_t b, c0, nc;
+        int64_t dst;
+    };
+    constexpr int64_t PANEL = (int64_t(1) << 20) / (int64_t)sizeof(scalar); // entries per slot fill (1 MiB)
+    std::vector<Unit> units;
+    std::vector<size_t> group_first{0}; // groups of consecutive units of at most PANEL entries (a single column may exceed it)
+    int64_t in_group = 0;
+    for (int32_t b : blocks) {
+        const hmx_leaf &l = H.leaves[b];
+        const int64_t M = l.t_size, N = l.s_size;
+        const int64_t step = M * N <= PANEL ? N : std::max<int64_t>(1, PANEL / M);
+        for (int64_t c0 = 0; c0 < N; c0 += step) {
+            const int64_t nc = std::min(step, N - c0), ent = M * nc;
+            if (in_group > 0 && in_group + ent > PANEL) {
+                group_first.push_back(units.size());
+                in_group = 0;
+            }
+            units.push_back(Unit{b, (int32_t)c0, (int32_t)nc, dst_off[b] + M * c0});
+            in_group += ent;
+        }
+    }
+    group_first.push_back(units.size());
+    const size_t ngroups = group_first.size() - 1;
+    std::atomic<size_t> next{0};
+    const bool ok = LN.run([&](int t) {
+        CbLane &L = LN.lanes[t];
+        for (int s = 0;; s ^= 1) {
+            if (LN.failed)
+                break;
+            const size_t g = next.fetch_add(1);
+            if (g >= ngroups)
+                break;
+            CbSlot &S = L.slot[s];
+            HMX_LANE_HIP(LN, S.wait()); // the copy that last read this slot's pinned buffer
+            const size_t u0 = group_first[g], u1 = group_first[g + 1];
+            if (u0 == u1)
+                continue;
+            const int64_t base = units[u0].dst;
+            const Unit &last   = units[u1 - 1];
+            const int64_t tot  = last.dst + (int64_t)H.leaves[last.b].t_size * last.nc - base;
+            HMX_LANE_HIP(LN, S.ensure((size_t)tot, 1));
+            for (size_t u = u0; u < u1; u++) {
+                const Unit &U     = units[u];
+                const hmx_leaf &l = H.leaves[U.b];
+                H.callback(H.callback_user, l.t_size, U.nc, H.perm_t.data() + l.t_offset, H.perm_s.data() + l.s_offset + U.c0, S.h_buf + (U.dst - base));
+            }
+            HMX_LANE_HIP(LN, hipMemcpyAsync(dest + base, S.h_buf, (size_t)tot * sizeof(scalar), hipMemcpyHostToDevice, L.st));
+            HMX_LANE_HIP(LN, hipEventRecord(S.done, L.st));
+            S.pending = true;
+        }
+        for (auto &S : L.slot)
+            HMX_LANE_HIP(LN, S.wait());
+    });
+    if (!ok) {
+        set_error("hmx_hmatrix_compress (host generator): " + LN.error);
+        return HMX_ERR_HIP;
+    }
     return HMX_OK;
 }
 
@@ -1895,6 +2135,33 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     }
     HMX_HIP(H.pool.alloc(cap));
     phase("pool allocation");
+    // a zero row pivot and every growth round leave a grant unused: some slack over the exact need
+    const unsigned long long maxcap = (unsigned long long)std::max(1024.0, std::min(need + 2.0 * (double)nvis + 64.0 * 1048576.0, budget));
+    auto grow_pool = [&]() -> int { // HMX_OK: grown; 1: the budget is used up
+        if (cap >= maxcap)
+            return 1;
+        const unsigned long long newcap = std::min<unsigned long long>(maxcap, std::max<unsigned long long>(2 * cap, cap + 1024));
+        DArr<scalar> bigger;
+        if (bigger.alloc(newcap) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        HMX_HIP(hipMemcpy(bigger.d, H.pool.d, (size_t)cap * sizeof(scalar), hipMemcpyDeviceToDevice));
+        std::swap(bigger.d, H.pool.d);
+        std::swap(bigger.n, H.pool.n);
+        std::swap(bigger.cap_, H.pool.cap_);
+        std::swap(bigger.dev_, H.pool.dev_);
+        bigger.release();
+        const unsigned long long old = cap; // the grants that failed pushed the head beyond the old capacity: restart it there
+        HMX_HIP(hipMemcpy(head.d, &old, 8, hipMemcpyHostToDevice));
+        cap = newcap;
+        return HMX_OK;
+    };
+    // the host generator's threads (lanes: stream + two pinned / device slot pairs each), shared by the ACA and the assembly of dense blocks
+    std::unique_ptr<CbLanes> cb_lanes;
+    if (use_cb)
+        cb_lanes.reset(new CbLanes(H.device, callback_thread_count(H)));
+    const auto wall0 = std::chrono::steady_clock::now();
     DEvent e0, e1;
     HMX_HIP(hipEventRecord(e0, 0));
     if (!order.empty() && assembled) {
@@ -1949,12 +2216,11 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                     preoff[order[k]] = tot;
                     tot += (int64_t)H.leaves[order[k]].t_size * H.leaves[order[k]].s_size;
                 }
-                std::vector<scalar> host(std::max<int64_t>(tot, 1));
-                for (size_t k = pos; k < end; k++) {
-                    const hmx_leaf &l = H.leaves[order[k]];
-                    gen(l.t_size, l.s_size, l.t_offset, l.s_offset, host.data() + preoff[order[k]]);
-                }
-                HMX_HIP(pre.upload(host));
+                HMX_HIP(pre.alloc(std::max<int64_t>(tot, 1)));
+                HMX_HIP(hipDeviceSynchronize());
+                const int rcf = cb_fill_blocks(H, *cb_lanes, std::vector<int32_t>(order.begin() + pos, order.begin() + end), preoff, pre.d);
+                if (rcf != HMX_OK)
+                    return rcf;
                 HMX_HIP(d_preoff.upload(preoff));
                 D.pre     = pre.d;
                 D.pre_off = d_preoff.d;
@@ -1984,13 +2250,14 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             pos = end;
         }
     } else if (!order.empty() && use_cb) {
-        // lock-step ACA: the generator runs on the host, everything else on the device (aca_cb_*_kernel)
-        DArr<int32_t> dI1, dI2, dq, dstatus, dactive;
+        // lock-step ACA: the generator runs on the host (on all cores: "Host generator on all cores" above), everything else on the
+        // device (aca_cb_*_kernel).  A block that finds the pool exhausted is parked with its row pivot; when the lanes have drained, the
+        // pool grows and the parked blocks continue with that row -- nothing is computed twice.
+        DArr<int32_t> dI1, dI2, dq;
         DArr<real> dfrob, daux;
-        DArr<scalar> dgamma, dbuf;
+        DArr<scalar> dgamma;
         DArr<unsigned long long> dcur;
-        DArr<int64_t> dbufoff;
-        for (auto *a : {&dI1, &dI2, &dq, &dstatus}) {
+        for (auto *a : {&dI1, &dI2, &dq}) {
             HMX_HIP(a->alloc(nb));
             HMX_HIP(a->zero());
         }
@@ -2001,83 +2268,173 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         HMX_HIP(dgamma.alloc(nb));
         HMX_HIP(dgamma.zero());
         HMX_HIP(dcur.alloc(nb));
-        std::vector<int32_t> status(nb, 1), I1(nb, 0), I2(nb, 0), active = order;
-        for (int32_t b : order)
-            status[b] = 0;
+        HMX_HIP(hipDeviceSynchronize()); // the lanes' streams do not wait for the null stream
         const bool sympiv = compressor == HMX_SYMPARTIAL_ACA;
-        std::vector<int64_t> bufoff(nb, 0);
-        std::vector<scalar> hostbuf;
-        AcaCbArgs A{};
-        A.t_off = H.d_t_off.d; A.t_size = H.d_t_size.d; A.s_off = H.d_s_off.d; A.s_size = H.d_s_size.d;
-        A.symmetric_pivoting = sympiv;
-        A.epsilon = epsilon; A.reqrank = reqrank;
-        A.pool = H.pool.d; A.pool_head = head.d; A.pool_cap = cap;
-        A.colptr = H.d_colptr.d; A.colcap = d_colcap.d; A.cross_off = H.d_cross_off.d;
-        A.visited = visited.d; A.vis_ptr = d_visptr.d;
-        A.I1 = dI1.d; A.I2 = dI2.d; A.q = dq.d; A.status = dstatus.d;
-        A.frob = dfrob.d; A.aux = daux.d; A.gamma = dgamma.d; A.cur_off = dcur.d;
-        A.rank_out = H.d_rank.d; A.swapped_out = H.d_swapped.d;
-        auto phase = [&](bool row_phase) -> int {
-            int64_t tot = 0;
-            for (int32_t b : active) {
-                const hmx_leaf &l = H.leaves[b];
-                const bool sw = sympiv && !(l.t_offset >= l.s_offset);
-                const int n1 = sw ? l.s_size : l.t_size, n2 = sw ? l.t_size : l.s_size;
-                bufoff[b] = tot;
-                tot += row_phase ? n2 : n1;
-            }
-            hostbuf.resize(std::max<int64_t>(tot, 1));
-            for (int32_t b : active) {
-                const hmx_leaf &l = H.leaves[b];
-                const bool sw = sympiv && !(l.t_offset >= l.s_offset);
-                scalar *out = hostbuf.data() + bufoff[b];
-                if (row_phase) { // entries (I1, k), k over index 2
-                    if (!sw)
-                        gen(1, l.s_size, l.t_offset + I1[b], l.s_offset, out);
-                    else
-                        gen(l.t_size, 1, l.t_offset, l.s_offset + I1[b], out);
-                } else { // entries (k, I2), k over index 1
-                    if (!sw)
-                        gen(l.t_size, 1, l.t_offset, l.s_offset + I2[b], out);
-                    else
-                        gen(1, l.s_size, l.t_offset + I2[b], l.s_offset, out);
-                }
-            }
-            HMX_HIP(dbuf.upload(hostbuf));
-            HMX_HIP(dbufoff.upload(bufoff));
-            HMX_HIP(dactive.upload(active));
-            A.active = dactive.d; A.buf = dbuf.d; A.buf_off = dbufoff.d;
-            if (row_phase)
-                hipLaunchKernelGGL(aca_cb_row_kernel<256>, dim3((unsigned)active.size()), dim3(256), 0, 0, A);
-            else
-                hipLaunchKernelGGL(aca_cb_col_kernel<256>, dim3((unsigned)active.size()), dim3(256), 0, 0, A);
-            HMX_HIP(hipGetLastError());
-            HMX_HIP(hipMemcpy(status.data(), dstatus.d, nb * 4, hipMemcpyDeviceToHost));
-            HMX_HIP(hipMemcpy(I1.data(), dI1.d, nb * 4, hipMemcpyDeviceToHost));
-            HMX_HIP(hipMemcpy(I2.data(), dI2.d, nb * 4, hipMemcpyDeviceToHost));
-            std::vector<int32_t> still;
-            for (int32_t b : active)
-                if (status[b] == 0)
-                    still.push_back(b);
-            active.swap(still);
-            return HMX_OK;
+        // entries of the longer side of a block: what one phase of the iteration evaluates at most
+        auto line_len = [&](int32_t b) { return (int64_t)std::max(H.leaves[b].t_size, H.leaves[b].s_size); };
+        // batch size: small enough that ~4 batches per slot exist (the tail of a lane is one batch), large enough that a phase is worth
+        // a launch; at most CB_BATCH_BLOCKS blocks and CB_BATCH_ENTRIES entries per phase
+        constexpr size_t CB_BATCH_BLOCKS   = 2048;
+        const int64_t CB_BATCH_ENTRIES     = (int64_t(4) << 20) / (int64_t)sizeof(scalar);
+        struct Todo {
+            int32_t b, I1;
         };
-        // status was initialised to "active" for the admissible leaves only
-        {
-            std::vector<int32_t> st0(nb, 1);
-            for (int32_t b : order)
-                st0[b] = 0;
-            HMX_HIP(hipMemcpy(dstatus.d, st0.data(), nb * 4, hipMemcpyHostToDevice));
-        }
-        while (!active.empty()) {
-            int rcp = phase(true);
-            if (rcp != HMX_OK)
-                return rcp;
-            if (active.empty())
+        std::vector<Todo> todo;
+        todo.reserve(order.size());
+        for (int32_t b : order)
+            todo.push_back(Todo{b, 0});
+        std::vector<Todo> parked;
+        std::mutex parked_mu;
+        for (int round = 0;; round++) {
+            int64_t total_entries = 0;
+            for (const Todo &t : todo)
+                total_entries += line_len(t.b);
+            const int64_t per_batch = std::max<int64_t>(1, std::min<int64_t>(CB_BATCH_ENTRIES, total_entries / (8 * (int64_t)cb_lanes->lanes.size()) + 1));
+            std::vector<size_t> batch_first{0};
+            {
+                int64_t ent = 0;
+                size_t cnt  = 0;
+                for (size_t k = 0; k < todo.size(); k++) {
+                    const int64_t e = line_len(todo[k].b);
+                    if (cnt > 0 && (ent + e > per_batch || cnt >= CB_BATCH_BLOCKS)) {
+                        batch_first.push_back(k);
+                        ent = 0;
+                        cnt = 0;
+                    }
+                    ent += e;
+                    cnt++;
+                }
+                batch_first.push_back(todo.size());
+            }
+            const size_t nbatches = batch_first.size() - 1;
+            std::atomic<size_t> next_batch{0};
+            AcaCbArgs A0{};
+            A0.t_off = H.d_t_off.d; A0.t_size = H.d_t_size.d; A0.s_off = H.d_s_off.d; A0.s_size = H.d_s_size.d;
+            A0.symmetric_pivoting = sympiv;
+            A0.epsilon = epsilon; A0.reqrank = reqrank;
+            A0.pool = H.pool.d; A0.pool_head = head.d; A0.pool_cap = cap;
+            A0.colptr = H.d_colptr.d; A0.colcap = d_colcap.d; A0.cross_off = H.d_cross_off.d;
+            A0.visited = visited.d; A0.vis_ptr = d_visptr.d;
+            A0.I1 = dI1.d; A0.I2 = dI2.d; A0.q = dq.d;
+            A0.frob = dfrob.d; A0.aux = daux.d; A0.gamma = dgamma.d; A0.cur_off = dcur.d;
+            A0.rank_out = H.d_rank.d; A0.swapped_out = H.d_swapped.d;
+            CbLanes &LN = *cb_lanes;
+            const bool ok = LN.run([&](int t) {
+                CbLane &L = LN.lanes[t];
+                for (auto &S : L.slot) {
+                    S.active.clear();
+                    S.pending = false;
+                }
+                for (;;) {
+                    bool any = false;
+                    for (auto &S : L.slot) {
+                        if (LN.failed)
+                            return;
+                        if (S.pending) { // digest the phase that was in flight
+                            HMX_LANE_HIP(LN, S.wait());
+                            size_t w = 0;
+                            for (size_t i = 0; i < S.active.size(); i++) {
+                                const CbResult r = S.h_res[i];
+                                if (r.status == CB_ACTIVE) {
+                                    S.active[w] = S.active[i];
+                                    S.I1[w]     = r.I1;
+                                    S.I2[w]     = r.I2;
+                                    w++;
+                                } else if (r.status == CB_SUSPENDED) {
+                                    std::lock_guard<std::mutex> lock(parked_mu);
+                                    parked.push_back(Todo{S.active[i], S.I1[i]});
+                                }
+                            }
+                            S.active.resize(w);
+                            S.I1.resize(w);
+                            S.I2.resize(w);
+                            S.row_phase = !S.row_phase;
+                        }
+                        if (S.active.empty()) { // next batch
+                            const size_t k = next_batch.fetch_add(1);
+                            if (k >= nbatches)
+                                continue;
+                            const size_t k0 = batch_first[k], k1 = batch_first[k + 1];
+                            S.active.resize(k1 - k0);
+                            S.I1.resize(k1 - k0);
+                            S.I2.assign(k1 - k0, 0);
+                            for (size_t i = k0; i < k1; i++) {
+                                S.active[i - k0] = todo[i].b;
+                                S.I1[i - k0]     = todo[i].I1;
+                            }
+                            S.row_phase = true;
+                        }
+                        // evaluate this phase's lines, then upload + kernel + result copy on the lane's stream
+                        int64_t tot = 0;
+                        for (int32_t b : S.active) {
+                            const hmx_leaf &l = H.leaves[b];
+                            const bool sw     = sympiv && !(l.t_offset >= l.s_offset);
+                            tot += (S.row_phase != sw) ? l.s_size : l.t_size; // row phase: index 2 runs over the source side unless swapped
+                        }
+                        HMX_LANE_HIP(LN, S.ensure((size_t)tot, std::max(S.active.size(), CB_BATCH_BLOCKS)));
+                        int64_t pos = 0;
+                        for (size_t i = 0; i < S.active.size(); i++) {
+                            const int32_t b   = S.active[i];
+                            const hmx_leaf &l = H.leaves[b];
+                            const bool sw     = sympiv && !(l.t_offset >= l.s_offset);
+                            scalar *out       = S.h_buf + pos;
+                            S.h_items[i]      = CbItem{pos, b, 0};
+                            if (S.row_phase) { // entries (I1, k), k over index 2
+                                if (!sw)
+                                    gen(1, l.s_size, l.t_offset + S.I1[i], l.s_offset, out);
+                                else
+                                    gen(l.t_size, 1, l.t_offset, l.s_offset + S.I1[i], out);
+                                pos += sw ? l.t_size : l.s_size;
+                            } else { // entries (k, I2), k over index 1
+                                if (!sw)
+                                    gen(l.t_size, 1, l.t_offset, l.s_offset + S.I2[i], out);
+                                else
+                                    gen(1, l.s_size, l.t_offset + S.I2[i], l.s_offset, out);
+                                pos += sw ? l.s_size : l.t_size;
+                            }
+                        }
+                        const size_t na = S.active.size();
+                        HMX_LANE_HIP(LN, hipMemcpyAsync(S.d_buf, S.h_buf, (size_t)tot * sizeof(scalar), hipMemcpyHostToDevice, L.st));
+                        HMX_LANE_HIP(LN, hipMemcpyAsync(S.d_items, S.h_items, na * sizeof(CbItem), hipMemcpyHostToDevice, L.st));
+                        AcaCbArgs A = A0;
+                        A.items     = S.d_items;
+                        A.res       = S.d_res;
+                        A.buf       = S.d_buf;
+                        if (S.row_phase)
+                            hipLaunchKernelGGL(aca_cb_row_kernel<256>, dim3((unsigned)na), dim3(256), 0, L.st, A);
+                        else
+                            hipLaunchKernelGGL(aca_cb_col_kernel<256>, dim3((unsigned)na), dim3(256), 0, L.st, A);
+                        HMX_LANE_HIP(LN, hipGetLastError());
+                        HMX_LANE_HIP(LN, hipMemcpyAsync(S.h_res, S.d_res, na * sizeof(CbResult), hipMemcpyDeviceToHost, L.st));
+                        HMX_LANE_HIP(LN, hipEventRecord(S.done, L.st));
+                        S.pending = true;
+                        any       = true;
+                    }
+                    if (!any)
+                        break;
+                }
+            });
+            if (!ok) {
+                set_error("hmx_hmatrix_compress (host generator): " + LN.error);
+                return HMX_ERR_HIP;
+            }
+            if (phase_timing)
+                fprintf(stderr, "[hmx build]   round %d: %zu blocks in %zu batches on %zu generator threads, %zu parked at a pool of %.2f GB\n", round, todo.size(), nbatches,
+                        LN.lanes.size(), parked.size(), (double)cap * sizeof(scalar) / 1e9);
+            if (parked.empty())
                 break;
-            rcp = phase(false);
-            if (rcp != HMX_OK)
-                return rcp;
+            const int rcg = grow_pool();
+            if (rcg == 1)
+                break; // reported below as an exhausted pool
+            if (rcg != HMX_OK)
+                return rcg;
+            // (largest first again: the order the batches are cut in)
+            std::sort(parked.begin(), parked.end(), [&](const Todo &a, const Todo &b) {
+                const int64_t sa = (int64_t)H.leaves[a.b].t_size + H.leaves[a.b].s_size, sb = (int64_t)H.leaves[b.b].t_size + H.leaves[b.b].s_size;
+                return sa != sb ? sa > sb : a.b < b.b;
+            });
+            todo.swap(parked);
+            parked.clear();
         }
     } else if (!order.empty()) {
         // Rounds: all blocks first; a block that finds the rank-estimated pool exhausted suspends with its state (aca_kernel), the pool
@@ -2085,8 +2442,6 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         // nothing is computed twice, the blocks that had finished keep their crosses.
         // Large blocks whose rank keeps growing leave the one-workgroup kernel after team_q iterations and continue with several workgroups
         // each (aca_team_*_kernel, three launches per iteration over all such blocks).
-        // a zero row pivot and every growth round leave a grant unused: some slack over the exact need
-        const unsigned long long maxcap = (unsigned long long)std::max(1024.0, std::min(need + 2.0 * (double)nvis + 64.0 * 1048576.0, budget));
         std::vector<int32_t> active     = order; // `order` is sorted by n1 + n2, largest first; so is every later list
         DArr<int32_t> d_active;
         std::vector<int32_t> round_ranks(nb, 0);
@@ -2096,26 +2451,6 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         DArr<unsigned int> t_counter;
         DArr<real> t_paux;
         auto since_phase = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - phase_t0).count(); };
-        auto grow_pool = [&]() -> int { // HMX_OK: grown; 1: the budget is used up
-            if (cap >= maxcap)
-                return 1;
-            const unsigned long long newcap = std::min<unsigned long long>(maxcap, std::max<unsigned long long>(2 * cap, cap + 1024));
-            DArr<scalar> bigger;
-            if (bigger.alloc(newcap) != hipSuccess) {
-                (void)hipGetLastError();
-                return 1;
-            }
-            HMX_HIP(hipMemcpy(bigger.d, H.pool.d, (size_t)cap * sizeof(scalar), hipMemcpyDeviceToDevice));
-            std::swap(bigger.d, H.pool.d);
-            std::swap(bigger.n, H.pool.n);
-            std::swap(bigger.cap_, H.pool.cap_);
-            std::swap(bigger.dev_, H.pool.dev_);
-            bigger.release();
-            const unsigned long long old = cap; // the grants that failed pushed the head beyond the old capacity: restart it there
-            HMX_HIP(hipMemcpy(head.d, &old, 8, hipMemcpyHostToDevice));
-            cap = newcap;
-            return HMX_OK;
-        };
         // entries of a line per workgroup: 1024 while the launch has workgroups enough to fill the GPU, 256 when few blocks are left (a
         // workgroup walks the whole history whatever its share, 16 loads in flight per thread either way: N=1e6 Hermitian case, team phase
         // of the second round 1.63 s with 1024 throughout, 1.53 s with 256 throughout -- but the first round 0.92 instead of 0.75 s)
@@ -2273,6 +2608,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     HMX_HIP(hipEventSynchronize(e1));
     float ms = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (use_cb) // the lanes run on their own streams: wall time of the compression (generator included)
+        ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     std::vector<int32_t> ranks(nb, 0);
     H.swapped.assign(nb, 0);
     if (nb) {
@@ -2284,8 +2621,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     int64_t false_pos = 0;
     for (int32_t b : order) {
         if (ranks[b] == -2) {
-            if (!full_pool && (assembled || use_cb))
-                return 1; // the rank estimate was too low: repeat with the whole budget (the device ACA has grown its pool by itself)
+            if (!full_pool && assembled)
+                return 1; // the rank estimate was too low: repeat with the whole budget (the ACA variants have grown their pool by themselves)
             set_error("hmx_hmatrix_compress: compression pool exhausted (not enough free HBM)");
             return HMX_ERR_HIP;
         }
@@ -2313,21 +2650,23 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         }
     }
     phase("pool shrink");
-    if (use_cb) { // dense leaves (and failed admissible ones): HMatrix::compute_dense_data through the host generator
+    if (use_cb) { // dense leaves (and failed admissible ones): HMatrix::compute_dense_data through the host generator, on all its threads
         int64_t tot = 0;
+        std::vector<int32_t> dense_blocks;
         for (size_t b = 0; b < nb; b++)
             if (H.kind[b] != LK_LOWRANK) {
                 H.staged_off[b] = tot;
                 tot += (int64_t)H.leaves[b].t_size * H.leaves[b].s_size;
-            }
-        std::vector<scalar> host(std::max<int64_t>(tot, 1));
-        for (size_t b = 0; b < nb; b++)
-            if (H.kind[b] != LK_LOWRANK) {
-                const hmx_leaf &l = H.leaves[b];
-                gen(l.t_size, l.s_size, l.t_offset, l.s_offset, host.data() + H.staged_off[b]);
+                dense_blocks.push_back((int32_t)b);
                 H.kind[b] = LK_DENSE_STAGED;
             }
-        HMX_HIP(H.dense_stage.upload(host));
+        HMX_HIP(H.dense_stage.alloc(std::max<int64_t>(tot, 1)));
+        HMX_HIP(hipDeviceSynchronize()); // the lanes' streams do not wait for the null stream
+        const int rcf = cb_fill_blocks(H, *cb_lanes, dense_blocks, H.staged_off, H.dense_stage.d);
+        if (rcf != HMX_OK)
+            return rcf;
+        cb_lanes.reset();
+        phase("dense blocks (host generator)");
     } else {
         H.dense_stage.release();
     }

@@ -627,13 +627,16 @@ __global__ __launch_bounds__(NT) void aca_team_col_kernel(AcaTeamArgs T) {
 
 // ---------------------------------------------------------------------------------------------
 // Partially pivoted ACA for a HOST generator (the user's VirtualGenerator::copy_submatrix, a C callback):
-// the same algorithm as aca_kernel, run in lock step over all admissible blocks.  Per iteration the host
+// the same algorithm as aca_kernel, run in lock step over a BATCH of admissible blocks (the host runs many batches concurrently, one
+// or two per generator thread, each on its own stream: engine_body.hpp, "host generator on all cores").  Per iteration the host
 // evaluates one cross row per active block (callback), aca_cb_row_kernel subtracts the previous crosses and
 // picks the column pivot; the host evaluates those columns, aca_cb_col_kernel finishes the iteration (scaling,
 // row pivot, error estimator, stopping test).  All arithmetic except the generator itself stays on the device.
+// A launch covers the batch's active blocks; position p of the launch reads items[p] and leaves res[p] (one packed copy back).
 // ---------------------------------------------------------------------------------------------
 struct AcaCbArgs {
-    const int32_t *active; // block ids handled by this launch
+    const CbItem *items;   // per launch position: block id, first entry of its line in buf
+    CbResult *res;         // per launch position: what the host needs for the next phase
     const int32_t *t_off, *t_size, *s_off, *s_size;
     int symmetric_pivoting;
     double epsilon;
@@ -647,12 +650,11 @@ struct AcaCbArgs {
     unsigned char *visited;
     const int64_t *vis_ptr;
     // per-block state carried between launches
-    int32_t *I1, *I2, *q, *status; // status: 0 active, 1 finished
+    int32_t *I1, *I2, *q;
     real *frob, *aux;
     scalar *gamma;
     unsigned long long *cur_off;
     const scalar *buf;        // host-evaluated entries of this phase, packed
-    const int64_t *buf_off; // per block: first entry in buf
     int32_t *rank_out, *swapped_out;
 };
 
@@ -661,7 +663,8 @@ __global__ __launch_bounds__(NT) void aca_cb_row_kernel(AcaCbArgs A) {
     __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
     __shared__ unsigned long long s_off;
-    const int b = A.active[blockIdx.x];
+    const CbItem item = A.items[blockIdx.x];
+    const int b = item.block;
     const int M = A.t_size[b], N = A.s_size[b];
     const bool swap = A.symmetric_pivoting && !(A.t_off[b] >= A.s_off[b]);
     const int n1 = swap ? N : M, n2 = swap ? M : N;
@@ -672,9 +675,9 @@ __global__ __launch_bounds__(NT) void aca_cb_row_kernel(AcaCbArgs A) {
     const int I1   = A.I1[b];
     auto finish = [&](int rank) {
         if (tid == 0) {
-            A.status[b]      = 1;
-            A.rank_out[b]    = rank;
-            A.swapped_out[b] = swap ? 1 : 0;
+            A.res[blockIdx.x] = CbResult{rank == -2 ? CB_SUSPENDED : CB_FINISHED, I1, 0, 0};
+            A.rank_out[b]     = rank;
+            A.swapped_out[b]  = swap ? 1 : 0;
         }
     };
     if ((long long)q * ((long long)n1 + n2) > (long long)n1 * n2 || q > A.colcap[b]) {
@@ -686,11 +689,11 @@ __global__ __launch_bounds__(NT) void aca_cb_row_kernel(AcaCbArgs A) {
     __syncthreads();
     const unsigned long long off = s_off;
     if (off + (unsigned long long)(n1 + n2) > A.pool_cap) {
-        finish(-2);
+        finish(-2); // nothing of the iteration has happened yet: the block continues from this row once the pool has grown
         return;
     }
     scalar *u1       = A.pool + off + n1;
-    const scalar *in = A.buf + A.buf_off[b];
+    const scalar *in = A.buf + item.off;
     real best = -1;
     int besti = -1;
     for (int k = tid; k < n2; k += NT) {
@@ -720,6 +723,7 @@ __global__ __launch_bounds__(NT) void aca_cb_row_kernel(AcaCbArgs A) {
             A.gamma[b]   = scalar(1) / piv;
             A.cur_off[b] = off;
             A.q[b]       = q; // provisional: the column phase completes iteration q
+            A.res[blockIdx.x] = CbResult{CB_ACTIVE, I1, I2, 0};
         }
     } else { // zero row: rank q-1, or failure when nothing was accepted yet
         finish(q - 1 > 0 ? q - 1 : 0);
@@ -731,7 +735,8 @@ __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
     __shared__ real sval[NT / WAVE];
     __shared__ int sidx[NT / WAVE];
     __shared__ scalar sbuf[(NT / WAVE) * 8];
-    const int b = A.active[blockIdx.x];
+    const CbItem item = A.items[blockIdx.x];
+    const int b = item.block;
     const int M = A.t_size[b], N = A.s_size[b];
     const bool swap = A.symmetric_pivoting && !(A.t_off[b] >= A.s_off[b]);
     const int n1 = swap ? N : M, n2 = swap ? M : N;
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
     const scalar gamma = A.gamma[b];
     const unsigned long long off = A.cur_off[b];
     scalar *u2 = A.pool + off, *u1 = A.pool + off + n1;
-    const scalar *in = A.buf + A.buf_off[b];
+    const scalar *in = A.buf + item.off;
     real best = -1;
     int besti = -1;
     for (int k = tid; k < n1; k += NT) {
@@ -795,13 +800,14 @@ __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
     const int minmn = n1 < n2 ? n1 : n2;
     const bool more = (A.reqrank > 0) ? (q < (A.reqrank < minmn ? A.reqrank : minmn)) : (sqrt(aux / frob) > (real)A.epsilon);
     if (tid == 0) {
+        const int nextI1 = besti >= 0 ? besti : I1;
         vis2[I2]     = 1;
         cross[q - 1] = (int64_t)off;
-        A.I1[b]      = besti >= 0 ? besti : I1;
+        A.I1[b]      = nextI1;
         A.frob[b]    = frob;
         A.aux[b]     = aux;
+        A.res[blockIdx.x] = CbResult{more ? CB_ACTIVE : CB_FINISHED, nextI1, I2, 0};
         if (!more) {
-            A.status[b]      = 1;
             A.rank_out[b]    = q;
             A.swapped_out[b] = swap ? 1 : 0;
         }

@@ -21,6 +21,19 @@ namespace hmx {
 
 constexpr int WAVE = 64;
 
+// lock-step ACA with a host generator (aca_cb_*_kernel): one entry per launch position
+struct CbItem {
+    int64_t off;   // first entry of the block's evaluated line in the launch's buffer
+    int32_t block; // leaf index
+    int32_t pad;
+};
+enum { CB_ACTIVE = 0, CB_FINISHED = 1, CB_SUSPENDED = 2 };
+struct CbResult {
+    int32_t status; // CB_ACTIVE: the block goes on with the next phase; CB_FINISHED; CB_SUSPENDED: the pool ran out before this row phase
+    int32_t I1, I2; // next row pivot / column pivot of the iteration in progress (index-1 / index-2 side)
+    int32_t pad;
+};
+
 struct KernelSpec { // device-evaluable generator
     int kind;
     int dim;

@@ -174,14 +174,19 @@ int hmx_hmatrix_set_kernel(hmx_hmatrix *, int kernel, const double *params, int 
 
 /* generator = the user's VirtualGenerator (hmatrix/interfaces/virtual_generator.hpp:24): a host callback with
  * copy_submatrix semantics -- M x N entries of rows[0..M) x cols[0..N) (USER numbering) written column-major into out.
- * Compression then runs in lock step: the callback produces one cross row / column per active block and iteration,
- * all ACA arithmetic (residual updates, pivot search, error estimate) and every later product stay on the device.
- * Dense leaves and fullACA/SVD blocks are assembled through the callback and uploaded.  The callback is invoked from
- * the calling thread only. */
+ * Compression then runs in lock step over batches of blocks: the callback produces one cross row / column per active block and
+ * iteration, all ACA arithmetic (residual updates, pivot search, error estimate) and every later product stay on the device.
+ * Dense leaves and fullACA/SVD blocks are assembled through the callback (panels of whole columns) and uploaded.
+ * Like htool's own build loop (HMatrixTreeBuilder::openmp_compute_blocks, hmatrix/tree_builder/tree_builder.hpp:603-648: an OpenMP
+ * parallel for over the blocks) the callback is invoked CONCURRENTLY from several host threads, each on blocks of its own, while the
+ * uploads and kernels of the other threads' batches are in flight.  hmx_hmatrix_set_callback_threads(H, n): n = 1 keeps every call on
+ * the calling thread (what htool does under HTOOL_WITH_PYTHON_INTERFACE, tree_builder.hpp:606; for generators that are not
+ * thread-safe), n = 0 (default) uses all cores (at most 64; environment HMX_CALLBACK_THREADS overrides). */
 typedef void (*hmx_generator_fn)(void *user, int M, int N, const int32_t *rows, const int32_t *cols, double *out);
 typedef void (*hmx_generator_fn_s)(void *user, int M, int N, const int32_t *rows, const int32_t *cols, float *out);
 int hmx_hmatrix_set_callback(hmx_hmatrix *, hmx_generator_fn fn, void *user);
 int hmx_hmatrix_set_callback_s(hmx_hmatrix *, hmx_generator_fn_s fn, void *user);
+int hmx_hmatrix_set_callback_threads(hmx_hmatrix *, int threads);
 
 /* HMatrixTreeBuilder::{sequential,openmp}_compute_blocks (tree_builder.hpp:568-666): compress every
  * admissible leaf (fallback to dense when the compressor reports failure), assemble every dense leaf

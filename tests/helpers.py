@@ -36,3 +36,24 @@ def params(name):
 
 def rel_err(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def native_inv_dist_generator(target_coordinates, source_coordinates, delta=1e-5, scale=1.0, cre=1.0, cim=1.0, hermitian=False, dtype=np.float64, threads=0):
+    """examples/host_generator.c (built by __graft_entry__.build() into examples/libhostgen.so) as an htool_amd.NativeGenerator: the user's
+    VirtualGenerator as compiled host code, called by libhmx from `threads` host threads (0: all cores)."""
+    import ctypes as C
+
+    import htool_amd as hm
+
+    class _InvDist(C.Structure):
+        _fields_ = [("dim", C.c_int32), ("pad", C.c_int32), ("target", C.c_void_p), ("source", C.c_void_p), ("delta", C.c_double), ("scale", C.c_double),
+                    ("cre", C.c_double), ("cim", C.c_double), ("hermitian", C.c_int32), ("pad2", C.c_int32)]
+
+    lib = C.CDLL(os.path.join(ROOT, "examples", "libhostgen.so"))
+    xt = np.ascontiguousarray(target_coordinates, dtype=np.float64)
+    xs = np.ascontiguousarray(source_coordinates, dtype=np.float64)
+    dim = xt.shape[1] if xt.ndim == 2 else 3
+    g = _InvDist(dim, 0, xt.ctypes.data, xs.ctypes.data, delta, scale, cre, cim, int(bool(hermitian)), 0)
+    fn = {np.dtype(np.float64): lib.hostgen_inv_dist_f64, np.dtype(np.float32): lib.hostgen_inv_dist_f32,
+          np.dtype(np.complex128): lib.hostgen_inv_dist_z64, np.dtype(np.complex64): lib.hostgen_inv_dist_c32}[np.dtype(dtype)]
+    return hm.NativeGenerator(fn, C.addressof(g), threads=threads, keep=(lib, g, xt, xs))

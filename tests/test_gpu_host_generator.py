@@ -1,0 +1,107 @@
+"""The host-generator route on all cores (hmx_hmatrix_set_callback + hmx_hmatrix_set_callback_threads; the reference's
+HMatrixTreeBuilder::openmp_compute_blocks, hmatrix/tree_builder/tree_builder.hpp:603-648, calls the user's VirtualGenerator from an
+OpenMP parallel for).  The generator is examples/host_generator.c -- compiled code libhmx knows nothing about -- and computes the same
+function as the built-in device kernel, so the two routes must give the same operator BIT FOR BIT: same leaf table, same U / V / dense
+payloads, same products; and the reference's structure, ranks and products on every fixture."""
+import numpy as np
+import pytest
+
+import htool_amd as hm
+from helpers import load, native_inv_dist_generator, params, rel_err
+from test_host_structure import build_trees
+
+pytestmark = pytest.mark.gpu
+
+REAL = ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_p2_symU_rank1", "rect_ball1500_disk1000", "ball_n1200_fullACA", "ball_n1200_SVD",
+        "ball_n1200_reqrank5", "ball_n2000_n_bbox_c8"]
+COMPLEX = ["ball_n2000_z64_hermU", "ball_n2000_z64_partial", "ball_n1200_z64_fullACA"]
+NP = {"f64": np.float64, "f32": np.float32, "z64": np.complex128, "c32": np.complex64}
+
+
+def builder(p):
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    tb.set_low_rank_generator(p["compressor"])
+    tb.set_minimal_target_depth(p["mindepth"])
+    tb.set_minimal_source_depth(p["mindepth"])
+    return tb
+
+
+def both_routes(p, threads):
+    T, S = build_trees(p)
+    dt = NP[p["prec"]]
+    herm = p["sym"] == "H"
+    dev = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], herm) if p["prec"] in ("z64", "c32") else \
+        hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"])
+    host = native_inv_dist_generator(T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], herm, dtype=dt, threads=threads)
+    Hd = builder(p).build(dev, T, S, p["rank"], p["rank"], dtype=dt)
+    Hh = builder(p).build(host, T, S, p["rank"], p["rank"], dtype=dt)
+    return Hd, Hh
+
+
+def same_operator(Hd, Hh):
+    assert np.array_equal(Hh.leaf_table(), Hd.leaf_table())
+    for b, r in enumerate(Hd.ranks):
+        if r >= 0:
+            (U, V), (U2, V2) = Hd.get_block(b), Hh.get_block(b)
+            assert np.array_equal(U, U2) and np.array_equal(V, V2), b
+        else:
+            assert np.array_equal(Hd.get_block(b), Hh.get_block(b)), b
+
+
+@pytest.mark.parametrize("threads", [1, 0, 7])
+@pytest.mark.parametrize("name", REAL + COMPLEX)
+def test_compiled_generator_on_all_threads_builds_the_device_operator(name, threads):
+    p, g = params(name), load(name)
+    Hd, Hh = both_routes(p, threads)
+    same_operator(Hd, Hh)
+    ref = g["leaves"]
+    tab = Hh.leaf_table()
+    if p["compressor"] == "SVD":
+        assert np.array_equal(tab[:, :4], ref[:, :4]) and np.abs(tab[:, 4] - ref[:, 4]).max() <= 1
+    else:
+        assert np.array_equal(tab, ref)
+    rng = np.random.default_rng(3)
+    dt = NP[p["prec"]]
+    x = rng.standard_normal(Hh.nb_cols()).astype(dt)
+    if np.iscomplexobj(x):
+        x = x + 1j * rng.standard_normal(Hh.nb_cols()).astype(dt)
+    yd, yh = np.zeros(Hh.nb_rows(), dtype=dt), np.zeros(Hh.nb_rows(), dtype=dt)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, Hd, x, 0.0, yd)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, Hh, x, 0.0, yh)
+    assert np.array_equal(yd, yh)  # same streams, same kernels
+
+
+@pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_z64_hermU"])
+def test_pool_growth_parks_blocks_and_continues_them(name, monkeypatch):
+    """A pool sized for rank 1 runs out in the first iterations: the blocks are parked with their row pivot, the pool grows and they
+    continue -- several times -- to the same operator."""
+    p = params(name)
+    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "1")
+    Hd, Hh = both_routes(p, 5)
+    monkeypatch.delenv("HMX_POOL_RANK_GUESS")
+    same_operator(Hd, Hh)
+    assert np.array_equal(Hh.leaf_table(), load(name)["leaves"])
+
+
+def test_batches_larger_than_the_first_slot_buffer():
+    """N = 150 000: the first batches hold blocks whose lines add up to more than a slot's first buffer (1 MiB), so the slots grow; the
+    last ones hold thousands of leaf-sized blocks.  Against the device-kernel build."""
+    n = 150000
+    x = hm.create_geometry("ellipse", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(100)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+
+    def build(gen):
+        tb = hm.HMatrixTreeBuilder(1e-4, 10.0, "N", "N")
+        tb.set_low_rank_generator("partialACA")
+        return tb.build(gen, T, T)
+    Hd = build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0))
+    Hh = build(native_inv_dist_generator(x, x, 1e-5, 1.0))
+    assert np.array_equal(Hh.leaf_table(), Hd.leaf_table())
+    rng = np.random.default_rng(1)
+    xin = rng.standard_normal(n)
+    yd, yh = np.zeros(n), np.zeros(n)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, Hd, xin, 0.0, yd)
+    hm.internal_add_hmatrix_vector_product("N", 1.0, Hh, xin, 0.0, yh)
+    assert np.array_equal(yd, yh)
