@@ -696,7 +696,7 @@ def main():
     compress["generator"] = args.generator
     if args.generator == "callback":
         compress["callback_build_s"] = t_build
-        compress["callback_threads"] = args.callback_threads if args.callback_threads > 0 else min(64, os.cpu_count() or 1)
+        compress["callback_threads"] = args.callback_threads if args.callback_threads > 0 else min(64, hm.lib().hmx_host_cores())
     elif rank == 0 and world == 1 and not emu and not args.no_callback_build and os.path.exists(os.path.join(ROOT, "examples", "libhostgen.so")):
         # the literal drop-in route next to the device-kernel build: the SAME operator built again from a user's host generator (compiled code
         # libhmx knows nothing about, called on all cores; lock-step ACA and every product on the device), timed, compared, dropped
@@ -705,7 +705,7 @@ def main():
             Hc = tb.build(host_generator(hm, x, np_dt, cplx, args.sym == "H", args.callback_threads), T, T, brank, brank, device=local_rank, dtype=np_dt)
             torch.cuda.synchronize()
             compress["callback_build_s"] = time.time() - t0
-            compress["callback_threads"] = args.callback_threads if args.callback_threads > 0 else min(64, os.cpu_count() or 1)
+            compress["callback_threads"] = args.callback_threads if args.callback_threads > 0 else min(64, hm.lib().hmx_host_cores())
             compress["callback_ranks_equal_device_build"] = bool(np.array_equal(Hc.leaf_table(), H.leaf_table()))
             stc = Hc.stats()
             compress["callback_entries_per_s"] = (stc["cgen_dense"] + stc["cgen_lowrank"]) / compress["callback_build_s"]

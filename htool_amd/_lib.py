@@ -105,6 +105,11 @@ SYMBOLS = [
     ("hmx_hmatrix_set_callback", C.c_int, [_vp, GENERATOR_FN, _vp]),
     ("hmx_hmatrix_set_callback_s", C.c_int, [_vp, GENERATOR_FN_S, _vp]),
     ("hmx_hmatrix_set_callback_threads", C.c_int, [_vp, C.c_int]),
+    ("hmx_host_cores", C.c_int, []),
+    ("hmx_hmatrix_get_blocks", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    ("hmx_hmatrix_get_blocks_s", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    ("hmx_hmatrix_get_blocks_z", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    ("hmx_hmatrix_get_blocks_c", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     ("hmx_hmatrix_compress", C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
     ("hmx_hmatrix_recompress", C.c_int, [_vp, C.c_double]),
     ("hmx_hmatrix_set_block_lowrank", C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp]),

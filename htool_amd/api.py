@@ -401,6 +401,27 @@ class HMatrix:
         check(get(self._h, leaf, ptr(D), None))
         return D.T
 
+    def get_blocks(self, leaves=None):
+        """Many leaves in one bulk download (hmx_hmatrix_get_blocks: gathered on the device, a few large copies): list of (U, V) /
+        dense blocks in the order of `leaves` (default: every leaf)."""
+        idx = np.arange(len(self.leaves), dtype=np.int64) if leaves is None else np.ascontiguousarray(leaves, dtype=np.int64)
+        keep, pu, pv = [], (C.c_void_p * len(idx))(), (C.c_void_p * len(idx))()
+        for k, b in enumerate(idx):
+            a = self.leaves[int(b)]
+            M, N, r = int(a["t_size"]), int(a["s_size"]), int(self.ranks[int(b)])
+            if r >= 0:
+                U, V = np.empty((r, M), dtype=self.dtype), np.empty((N, r), dtype=self.dtype)
+                keep.append((U.T, V.T))
+                pu[k], pv[k] = U.ctypes.data or None, V.ctypes.data or None
+                if r == 0:  # empty factors have no address: any valid pointer will do, nothing is written
+                    pu[k] = pv[k] = idx.ctypes.data
+            else:
+                D = np.empty((N, M), dtype=self.dtype)
+                keep.append(D.T)
+                pu[k], pv[k] = D.ctypes.data, None
+        check(_fn(self, "hmx_hmatrix_get_blocks")(self._h, len(idx), idx.ctypes.data, C.cast(pu, C.c_void_p), C.cast(pv, C.c_void_p)))
+        return keep
+
     def _ptr(self, arr):
         if self.complex:
             return arr.ctypes.data  # void*: interleaved (re, im)

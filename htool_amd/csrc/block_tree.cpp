@@ -193,7 +193,7 @@ int build_block_tree(hmx_block_tree &bt) {
     const int s_start = bt.source_root_partition >= 0 ? S.on_partition[bt.source_root_partition] : 0;
     Walker W(bt);
     // a user-supplied admissibility condition is a callback into the caller's code (Python, through ctypes): one thread
-    const int hw      = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int hw      = hmx::host_cores();
     const int threads = bt.admissibility ? 1 : std::min(hw, 32);
     if (threads > 1 && (int64_t)T.nodes.size() + (int64_t)S.nodes.size() > 4096)
         W.defer_depth = 6;

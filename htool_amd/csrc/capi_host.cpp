@@ -1,7 +1,10 @@
 // capi_host.cpp -- C ABI entry points that need no GPU: geometry, cluster tree, block tree.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include <algorithm>
 #include "hmx_host.hpp"
@@ -9,9 +12,42 @@
 namespace hmx {
 static thread_local std::string g_error;
 void set_error(const std::string &msg) { g_error = msg; }
+int host_cores() {
+    static const int cores = [] {
+        int n = (int)std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = -1;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+            char q[64] = {0};
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0)
+                quota = atoll(q);
+            fclose(f);
+        } else { // cgroup v1
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (fscanf(g, "%lld", &quota) != 1)
+                    quota = -1;
+                fclose(g);
+            }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(g, "%lld", &period) != 1)
+                    period = -1;
+                fclose(g);
+            }
+        }
+        if (quota > 0 && period > 0)
+            n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+        if (const char *e = getenv("HMX_HOST_CORES"))
+            if (atoi(e) > 0)
+                n = atoi(e);
+        return n;
+    }();
+    return cores;
+}
 } // namespace hmx
 
 extern "C" {
+
+int hmx_host_cores(void) { return hmx::host_cores(); }
+
 
 const char *hmx_last_error(void) { return hmx::g_error.c_str(); }
 

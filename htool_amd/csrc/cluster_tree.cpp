@@ -562,7 +562,7 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
     T.nodes.clear();
     T.on_partition.clear();
     Builder B(n, dim, coords, radii, weights, opt, T.perm);
-    B.psort_threads = std::min(32, (int)std::max(1u, std::thread::hardware_concurrency()));
+    B.psort_threads = std::min(32, hmx::host_cores());
     if (const char *e = std::getenv("HMX_TREE_PSORT_MIN")) // smallest slice handled in chunks on several threads (tests lower it; a huge value disables it)
         B.psort_min = std::max(2, std::atoi(e));
     B.gather_xs(0, n);
@@ -587,7 +587,7 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
     }
     T.permutation_is_local = (sp == 1);
 
-    const int hw = std::max(1u, std::thread::hardware_concurrency());
+    const int hw = hmx::host_cores();
     std::vector<int> level{0};
     const bool given = partition_kind != 0;
     if (given) {

@@ -268,6 +268,22 @@ int hmx_hmatrix_get_block(const hmx_hmatrix *H, int64_t leaf, double *U_or_D, do
     HMX_NEED(H, d, "hmx_hmatrix_get_block");
     HMX_GUARD(hmx::f64::api_get_block(H->d, leaf, U_or_D, V));
 }
+int hmx_hmatrix_get_blocks(const hmx_hmatrix *H, int64_t count, const int64_t *leaves, double *const *U_or_D, double *const *V) {
+    HMX_NEED(H, d, "hmx_hmatrix_get_blocks");
+    HMX_GUARD(hmx::f64::api_get_blocks(H->d, count, leaves, U_or_D, V));
+}
+int hmx_hmatrix_get_blocks_s(const hmx_hmatrix *H, int64_t count, const int64_t *leaves, float *const *U_or_D, float *const *V) {
+    HMX_NEED(H, s, "hmx_hmatrix_get_blocks_s");
+    HMX_GUARD(hmx::f32::api_get_blocks(H->s, count, leaves, U_or_D, V));
+}
+int hmx_hmatrix_get_blocks_z(const hmx_hmatrix *H, int64_t count, const int64_t *leaves, double *const *U_or_D, double *const *V) {
+    HMX_NEED(H, z, "hmx_hmatrix_get_blocks_z");
+    HMX_GUARD(hmx::z64::api_get_blocks(H->z, count, leaves, reinterpret_cast<cplx<double> *const *>(U_or_D), reinterpret_cast<cplx<double> *const *>(V)));
+}
+int hmx_hmatrix_get_blocks_c(const hmx_hmatrix *H, int64_t count, const int64_t *leaves, float *const *U_or_D, float *const *V) {
+    HMX_NEED(H, c, "hmx_hmatrix_get_blocks_c");
+    HMX_GUARD(hmx::c32::api_get_blocks(H->c, count, leaves, reinterpret_cast<cplx<float> *const *>(U_or_D), reinterpret_cast<cplx<float> *const *>(V)));
+}
 int hmx_hmatrix_matvec(hmx_hmatrix *H, char trans, double alpha, const double *in, double beta, double *out, int mem, void *stream) {
     HMX_NEED(H, d, "hmx_hmatrix_matvec");
     HMX_GUARD(hmx::f64::api_matvec(H->d, trans, alpha, in, beta, out, mem, stream));

@@ -13,6 +13,7 @@ int api_set_block_dense(HMat *H, int64_t leaf, const scalar *D);
 int api_finalize(HMat *Hp);
 int api_leaf_ranks(const HMat *H, int32_t *rank);
 int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V);
+int api_get_blocks(const HMat *Hc, int64_t count, const int64_t *leaves, scalar *const *U_or_D, scalar *const *V);
 int api_save(const HMat *Hc, const char *path);
 int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxFileHeader &hd, HMat **out);
 int api_release_factors(HMat *Hp, int with_transposed);

@@ -81,6 +81,7 @@ struct HMat {
 
     // streams
     StreamSet E, R;
+    std::vector<int32_t> dp_leaf, dp_range, dp_col; // (dense leaf, row range, first column in the range) of every slice of a dense leaf, leaf-major
     DArr<int32_t> e_zidx, e_zidx_mirror, e_tdst, e_tdst_mirror;
     DArr<int32_t> r_outidx, r_tcoef, r_tcoef_mirror;
     hvec32 h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag;
@@ -211,7 +212,7 @@ static int build_streams(HMat &H) {
         std::vector<char> mark((size_t)H.nT + 1, 0);
         mark[0] = mark[H.nT] = 1;
         std::vector<int> outside;
-        const size_t NS = std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)nb / 32768 + 1});
+        const size_t NS = std::min<size_t>({(size_t)16, (size_t)host_cores(), (size_t)nb / 32768 + 1});
         std::vector<std::vector<std::pair<int, int>>> sc(NS);
         std::vector<std::thread> th;
         auto slice = [&](size_t t) {
@@ -339,7 +340,7 @@ static int build_streams(HMat &H) {
     {
         const int nre = E.nranges(), nrr = R.nranges();
         const size_t NT = getenv("HMX_LAYOUT_THREADS") ? (size_t)std::max(1, atoi(getenv("HMX_LAYOUT_THREADS")))
-                                                       : std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)nb / 16384 + 1});
+                                                       : std::min<size_t>({(size_t)16, (size_t)host_cores(), (size_t)nb / 16384 + 1});
         struct Part {
             std::vector<int32_t> ecnt, rcnt; // columns this part adds to every E range / R piece
             int64_t n_elr = 0, n_ed = 0, n_rlr = 0, a = 0, p = 0;
@@ -696,6 +697,17 @@ static int build_streams(HMat &H) {
     };
     fill_e(elr_b, elr_r, elr_c, true);
     fill_e(ed_b, ed_r, ed_c, false);
+    { // where the dense leaves' slices sit in the E-streams (bulk download: api_get_blocks); leaf-major, the stored leaves only
+        H.dp_leaf.clear();
+        H.dp_range.clear();
+        H.dp_col.clear();
+        for (size_t q = 0; q < ed_b.size(); q++)
+            if (ed_b[q] < nb_real) {
+                H.dp_leaf.push_back(ed_b[q]);
+                H.dp_range.push_back(ed_r[q]);
+                H.dp_col.push_back(ed_c[q]);
+            }
+    }
     phase_nosync("  e index");
     hvec32 h_outidx(R.total_cols);
     H.h_r_aidx.resize(R.total_cols);
@@ -1680,13 +1692,16 @@ int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, cons
 // ---------------------------------------------------------------------------------------------
 // Host generator on all cores.  The reference compresses the admissible blocks and assembles the dense ones from an OpenMP
 // `parallel for` (HMatrixTreeBuilder::openmp_compute_blocks, hmatrix/tree_builder/tree_builder.hpp:603-648), i.e. the user's
-// VirtualGenerator::copy_submatrix runs on every core unless HTOOL_WITH_PYTHON_INTERFACE is defined (:606).  Here the generator
-// threads are LANES: a lane owns a HIP stream and two slots (pinned host buffer + device buffer + an event), so that it evaluates
-// the generator for one slot while the other slot's upload, kernel and (for the ACA) packed result copy are in flight.
+// VirtualGenerator::copy_submatrix runs on every core unless HTOOL_WITH_PYTHON_INTERFACE is defined (:606).  Here:
+//   * a few DRIVER threads (lanes; at most 8: more threads inside the HIP runtime cost more than they bring -- measured at N = 1e6:
+//     16 lanes 0.68 s, 64 lanes 2.2 s, 256 lanes 21 s for the same work) own a HIP stream and two slots each (a range of one pinned
+//     host buffer + device buffer + an event), so that a lane prepares one slot while the other slot's upload, kernel and (for the ACA)
+//     packed result copy are in flight;
+//   * ALL generator threads (the drivers and the remaining cores as workers) evaluate: a driver cuts the lines of its slot's phase into
+//     chunks of ~16 K entries and shares them out (CbLanes::parallel), helping itself until its own chunks are done.
 //   * ACA: the admissible blocks are cut into batches (largest blocks first); a slot takes a batch and runs the lock-step iteration on
-//     it -- evaluate one line per active block into pinned memory, one H2D copy, one aca_cb_*_kernel launch over the batch, one packed
-//     D2H copy of (status, I1, I2) -- until the batch is done, then takes the next batch.  Batches progress independently, so the
-//     GPU always has other lanes' launches to run while this one's host thread is inside the generator.
+//     it -- one line per active block evaluated into pinned memory, one H2D copy, one aca_cb_*_kernel launch over the batch, one packed
+//     D2H copy of (status, I1, I2) -- until the batch is done, then takes the next batch.  Batches progress independently.
 //   * dense leaves / assembled blocks: panels of whole columns, evaluated into pinned memory and copied to their place.
 // hmx_hmatrix_set_callback_threads(H, 1) (or HMX_CALLBACK_THREADS=1) keeps every call on the calling thread.
 // ---------------------------------------------------------------------------------------------
@@ -1700,65 +1715,13 @@ struct CbSlot {
     bool pending = false;
     // the batch in progress (ACA)
     std::vector<int32_t> active, I1, I2;
+    std::vector<size_t> chunk_first;
     bool row_phase = true;
-    hipError_t ensure(size_t entries, size_t blocks) {
-        hipError_t e;
-        if (entries > cap) {
-            if (h_buf)
-                (void)hipHostFree(h_buf);
-            if (d_buf)
-                (void)hipFree(d_buf);
-            h_buf = d_buf = nullptr;
-            cap   = 0;
-            const size_t want = std::max(entries, (size_t)(1 << 20) / sizeof(scalar));
-            if ((e = hipHostMalloc((void **)&h_buf, want * sizeof(scalar), hipHostMallocDefault)) != hipSuccess)
-                return e;
-            if ((e = hipMalloc((void **)&d_buf, want * sizeof(scalar))) != hipSuccess)
-                return e;
-            cap = want;
-        }
-        if (blocks > cap_blocks) {
-            if (h_items)
-                (void)hipHostFree(h_items);
-            if (d_items)
-                (void)hipFree(d_items);
-            h_items = d_items = nullptr;
-            h_res = d_res = nullptr;
-            cap_blocks    = 0;
-            // items and results share one allocation each (both 16 bytes per position)
-            if ((e = hipHostMalloc((void **)&h_items, blocks * (sizeof(CbItem) + sizeof(CbResult)), hipHostMallocDefault)) != hipSuccess)
-                return e;
-            if ((e = hipMalloc((void **)&d_items, blocks * (sizeof(CbItem) + sizeof(CbResult)))) != hipSuccess)
-                return e;
-            h_res      = reinterpret_cast<CbResult *>(h_items + blocks);
-            d_res      = reinterpret_cast<CbResult *>(d_items + blocks);
-            cap_blocks = blocks;
-        }
-        if (!done && (e = hipEventCreateWithFlags(&done, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess)
-            return e;
-        return hipSuccess;
-    }
     hipError_t wait() {
         if (!pending)
             return hipSuccess;
         pending = false;
         return hipEventSynchronize(done);
-    }
-    void destroy() {
-        if (h_buf)
-            (void)hipHostFree(h_buf);
-        if (d_buf)
-            (void)hipFree(d_buf);
-        if (h_items)
-            (void)hipHostFree(h_items);
-        if (d_items)
-            (void)hipFree(d_items);
-        if (done)
-            (void)hipEventDestroy(done);
-        h_buf = d_buf = nullptr;
-        h_items = d_items = nullptr;
-        done              = nullptr;
-        cap = cap_blocks = 0;
     }
 };
 struct CbLane {
@@ -1767,23 +1730,116 @@ struct CbLane {
 };
 struct CbLanes {
     int device = 0;
-    std::vector<CbLane> lanes;
+    std::vector<CbLane> lanes; // the drivers
+    int nworkers = 0;          // generator threads besides the drivers
     std::mutex mu;
     std::string error; // first failure of any lane
     std::atomic<bool> failed{false};
-    explicit CbLanes(int dev, int n) : device(dev), lanes((size_t)std::max(1, n)) {}
+    // one pinned and one device allocation for all slots
+    scalar *h_all = nullptr, *d_all = nullptr;
+    char *h_meta = nullptr, *d_meta = nullptr;
+    // shared evaluation: jobs = chunked loops published by the drivers
+    struct Job {
+        const std::function<void(size_t)> *body;
+        size_t n;
+        std::atomic<size_t> next{0}, done{0};
+    };
+    std::mutex job_mu;
+    std::condition_variable job_cv;
+    std::deque<Job *> jobs;
+    bool stop = false;
+    std::vector<std::thread> workers;
+
+    CbLanes(int dev, int threads) : device(dev) {
+        threads = std::max(1, threads);
+        static const int max_drivers = getenv("HMX_CALLBACK_DRIVERS") && atoi(getenv("HMX_CALLBACK_DRIVERS")) > 0 ? atoi(getenv("HMX_CALLBACK_DRIVERS")) : 8;
+        const int nd = std::max(1, std::min(threads, max_drivers));
+        lanes.resize((size_t)nd);
+        nworkers = threads - nd;
+        for (int w = 0; w < nworkers; w++)
+            workers.emplace_back([this] { worker_loop(); });
+    }
     CbLanes(const CbLanes &)            = delete;
     CbLanes &operator=(const CbLanes &) = delete;
     ~CbLanes() {
+        {
+            std::lock_guard<std::mutex> lock(job_mu);
+            stop = true;
+        }
+        job_cv.notify_all();
+        for (auto &w : workers)
+            w.join();
         (void)hipSetDevice(device);
         for (auto &L : lanes) {
             if (L.st)
                 (void)hipStreamSynchronize(L.st);
             for (auto &S : L.slot)
-                S.destroy();
+                if (S.done)
+                    (void)hipEventDestroy(S.done);
             if (L.st)
                 (void)hipStreamDestroy(L.st);
         }
+        if (h_all)
+            (void)hipHostFree(h_all);
+        if (d_all)
+            (void)hipFree(d_all);
+        if (h_meta)
+            (void)hipHostFree(h_meta);
+        if (d_meta)
+            (void)hipFree(d_meta);
+    }
+    size_t nslots() const { return 2 * lanes.size(); }
+    // every slot gets room for `entries` evaluated entries and `blocks` launch positions (called before run())
+    hipError_t reserve(size_t entries, size_t blocks) {
+        hipError_t e;
+        entries = (entries + 63) / 64 * 64;
+        blocks  = std::max<size_t>(blocks, 1);
+        if (lanes[0].slot[0].cap < entries) {
+            if (h_all)
+                (void)hipHostFree(h_all);
+            if (d_all)
+                (void)hipFree(d_all);
+            h_all = d_all = nullptr;
+            if ((e = hipHostMalloc((void **)&h_all, nslots() * entries * sizeof(scalar), hipHostMallocDefault)) != hipSuccess)
+                return e;
+            if ((e = hipMalloc((void **)&d_all, nslots() * entries * sizeof(scalar))) != hipSuccess)
+                return e;
+            size_t k = 0;
+            for (auto &L : lanes)
+                for (auto &S : L.slot) {
+                    S.h_buf = h_all + k * entries;
+                    S.d_buf = d_all + k * entries;
+                    S.cap   = entries;
+                    k++;
+                }
+        }
+        if (lanes[0].slot[0].cap_blocks < blocks) {
+            if (h_meta)
+                (void)hipHostFree(h_meta);
+            if (d_meta)
+                (void)hipFree(d_meta);
+            h_meta = d_meta = nullptr;
+            const size_t per = blocks * (sizeof(CbItem) + sizeof(CbResult)); // both 16 bytes per position
+            if ((e = hipHostMalloc((void **)&h_meta, nslots() * per, hipHostMallocDefault)) != hipSuccess)
+                return e;
+            if ((e = hipMalloc((void **)&d_meta, nslots() * per)) != hipSuccess)
+                return e;
+            size_t k = 0;
+            for (auto &L : lanes)
+                for (auto &S : L.slot) {
+                    S.h_items    = reinterpret_cast<CbItem *>(h_meta + k * per);
+                    S.d_items    = reinterpret_cast<CbItem *>(d_meta + k * per);
+                    S.h_res      = reinterpret_cast<CbResult *>(S.h_items + blocks);
+                    S.d_res      = reinterpret_cast<CbResult *>(S.d_items + blocks);
+                    S.cap_blocks = blocks;
+                    k++;
+                }
+        }
+        for (auto &L : lanes)
+            for (auto &S : L.slot)
+                if (!S.done && (e = hipEventCreateWithFlags(&S.done, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess)
+                    return e;
+        return hipSuccess;
     }
     void fail(const std::string &what) {
         std::lock_guard<std::mutex> lock(mu);
@@ -1791,7 +1847,65 @@ struct CbLanes {
             error = what;
         failed = true;
     }
-    // fn(lane index) on every lane, each on its own thread (one lane: the calling thread); false when a lane reported an error
+    void worker_loop() {
+        for (;;) {
+            Job *j   = nullptr;
+            size_t i = 0;
+            {
+                std::unique_lock<std::mutex> lock(job_mu);
+                job_cv.wait(lock, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) {
+                    if (stop)
+                        return;
+                    continue;
+                }
+                j = jobs.front();
+                i = j->next.fetch_add(1);
+                if (i >= j->n) { // exhausted: nobody may find it any more
+                    jobs.pop_front();
+                    continue;
+                }
+            }
+            try {
+                (*j->body)(i);
+            } catch (...) {
+                fail("exception in the generator");
+            }
+            j->done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    // body(0) ... body(n - 1) on all generator threads; returns when every call has returned.  The caller (a driver) takes part.
+    void parallel(size_t n, const std::function<void(size_t)> &body) {
+        if (workers.empty() || n <= 1) {
+            for (size_t i = 0; i < n; i++)
+                body(i);
+            return;
+        }
+        Job job;
+        job.body = &body;
+        job.n    = n;
+        {
+            std::lock_guard<std::mutex> lock(job_mu);
+            jobs.push_back(&job);
+        }
+        job_cv.notify_all();
+        for (;;) {
+            const size_t i = job.next.fetch_add(1);
+            if (i >= n)
+                break;
+            body(i);
+            job.done.fetch_add(1, std::memory_order_release);
+        }
+        {
+            std::lock_guard<std::mutex> lock(job_mu);
+            auto it = std::find(jobs.begin(), jobs.end(), &job);
+            if (it != jobs.end())
+                jobs.erase(it);
+        }
+        while (job.done.load(std::memory_order_acquire) < n) // chunks other threads are still inside
+            std::this_thread::yield();
+    }
+    // fn(lane index) on every driver, each on its own thread (one driver: the calling thread); false when anything reported an error
     template <typename F>
     bool run(F &&fn) {
         auto body = [&](int t) {
@@ -1831,12 +1945,14 @@ struct CbLanes {
             return;                                                                                                     \
         }                                                                                                               \
     } while (0)
+// entries of one shared-out piece of a phase (~50 us of a simple generator)
+constexpr int64_t CB_CHUNK_ENTRIES = 16384;
 
 static int callback_thread_count(const HMat &H) {
     int n = H.callback_threads;
     if (n <= 0) {
         const char *e = getenv("HMX_CALLBACK_THREADS");
-        n             = e && atoi(e) > 0 ? atoi(e) : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+        n             = e && atoi(e) > 0 ? atoi(e) : std::min(64, host_cores());
     }
     return std::max(1, std::min(n, 256));
 }
@@ -1850,17 +1966,21 @@ static int cb_fill_blocks(HMat &H, CbLanes &LN, const std::vector<int32_t> &bloc
         int32_t b, c0, nc;
         int64_t dst;
     };
-    constexpr int64_t PANEL = (int64_t(1) << 20) / (int64_t)sizeof(scalar); // entries per slot fill (1 MiB)
+    int64_t max_rows = 1;
+    for (int32_t b : blocks)
+        max_rows = std::max<int64_t>(max_rows, H.leaves[b].t_size);
+    // entries per slot fill: 8 MiB, at least one column of the tallest block
+    const int64_t GROUP = std::max<int64_t>((int64_t(8) << 20) / (int64_t)sizeof(scalar), max_rows);
     std::vector<Unit> units;
-    std::vector<size_t> group_first{0}; // groups of consecutive units of at most PANEL entries (a single column may exceed it)
+    std::vector<size_t> group_first{0}; // groups of consecutive units of at most GROUP entries
     int64_t in_group = 0;
     for (int32_t b : blocks) {
         const hmx_leaf &l = H.leaves[b];
         const int64_t M = l.t_size, N = l.s_size;
-        const int64_t step = M * N <= PANEL ? N : std::max<int64_t>(1, PANEL / M);
+        const int64_t step = M * N <= CB_CHUNK_ENTRIES ? N : std::max<int64_t>(1, CB_CHUNK_ENTRIES / M); // a unit is what one thread evaluates in one call
         for (int64_t c0 = 0; c0 < N; c0 += step) {
             const int64_t nc = std::min(step, N - c0), ent = M * nc;
-            if (in_group > 0 && in_group + ent > PANEL) {
+            if (in_group > 0 && in_group + ent > GROUP) {
                 group_first.push_back(units.size());
                 in_group = 0;
             }
@@ -1870,6 +1990,9 @@ static int cb_fill_blocks(HMat &H, CbLanes &LN, const std::vector<int32_t> &bloc
     }
     group_first.push_back(units.size());
     const size_t ngroups = group_first.size() - 1;
+    if (units.empty())
+        return HMX_OK;
+    HMX_HIP(LN.reserve((size_t)GROUP, 1));
     std::atomic<size_t> next{0};
     const bool ok = LN.run([&](int t) {
         CbLane &L = LN.lanes[t];
@@ -1887,12 +2010,25 @@ static int cb_fill_blocks(HMat &H, CbLanes &LN, const std::vector<int32_t> &bloc
             const int64_t base = units[u0].dst;
             const Unit &last   = units[u1 - 1];
             const int64_t tot  = last.dst + (int64_t)H.leaves[last.b].t_size * last.nc - base;
-            HMX_LANE_HIP(LN, S.ensure((size_t)tot, 1));
+            // units of ~CB_CHUNK_ENTRIES entries; small leaves are bundled so that a shared-out piece is worth the hand-over
+            std::vector<size_t> piece{u0};
+            int64_t acc = 0;
             for (size_t u = u0; u < u1; u++) {
-                const Unit &U     = units[u];
-                const hmx_leaf &l = H.leaves[U.b];
-                H.callback(H.callback_user, l.t_size, U.nc, H.perm_t.data() + l.t_offset, H.perm_s.data() + l.s_offset + U.c0, S.h_buf + (U.dst - base));
+                acc += (int64_t)H.leaves[units[u].b].t_size * units[u].nc;
+                if (acc >= CB_CHUNK_ENTRIES && u + 1 < u1) {
+                    piece.push_back(u + 1);
+                    acc = 0;
+                }
             }
+            piece.push_back(u1);
+            const std::function<void(size_t)> body = [&](size_t p) {
+                for (size_t u = piece[p]; u < piece[p + 1]; u++) {
+                    const Unit &U     = units[u];
+                    const hmx_leaf &l = H.leaves[U.b];
+                    H.callback(H.callback_user, l.t_size, U.nc, H.perm_t.data() + l.t_offset, H.perm_s.data() + l.s_offset + U.c0, S.h_buf + (U.dst - base));
+                }
+            };
+            LN.parallel(piece.size() - 1, body);
             HMX_LANE_HIP(LN, hipMemcpyAsync(dest + base, S.h_buf, (size_t)tot * sizeof(scalar), hipMemcpyHostToDevice, L.st));
             HMX_LANE_HIP(LN, hipEventRecord(S.done, L.st));
             S.pending = true;
@@ -2274,8 +2410,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         auto line_len = [&](int32_t b) { return (int64_t)std::max(H.leaves[b].t_size, H.leaves[b].s_size); };
         // batch size: small enough that ~4 batches per slot exist (the tail of a lane is one batch), large enough that a phase is worth
         // a launch; at most CB_BATCH_BLOCKS blocks and CB_BATCH_ENTRIES entries per phase
-        constexpr size_t CB_BATCH_BLOCKS   = 2048;
-        const int64_t CB_BATCH_ENTRIES     = (int64_t(4) << 20) / (int64_t)sizeof(scalar);
+        constexpr size_t CB_BATCH_BLOCKS   = 16384;
+        const int64_t CB_BATCH_ENTRIES     = (int64_t(16) << 20) / (int64_t)sizeof(scalar);
         struct Todo {
             int32_t b, I1;
         };
@@ -2289,7 +2425,11 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             int64_t total_entries = 0;
             for (const Todo &t : todo)
                 total_entries += line_len(t.b);
-            const int64_t per_batch = std::max<int64_t>(1, std::min<int64_t>(CB_BATCH_ENTRIES, total_entries / (8 * (int64_t)cb_lanes->lanes.size()) + 1));
+            int64_t longest = 1;
+            for (const Todo &t : todo)
+                longest = std::max(longest, line_len(t.b));
+            const int64_t per_batch = std::max<int64_t>(1, std::min<int64_t>(CB_BATCH_ENTRIES, total_entries / (4 * (int64_t)cb_lanes->nslots()) + 1));
+            HMX_HIP(cb_lanes->reserve((size_t)std::max(per_batch, longest), CB_BATCH_BLOCKS));
             std::vector<size_t> batch_first{0};
             {
                 int64_t ent = 0;
@@ -2319,8 +2459,15 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             A0.frob = dfrob.d; A0.aux = daux.d; A0.gamma = dgamma.d; A0.cur_off = dcur.d;
             A0.rank_out = H.d_rank.d; A0.swapped_out = H.d_swapped.d;
             CbLanes &LN = *cb_lanes;
+            std::atomic<long long> ns_gen{0}, ns_wait{0}, ns_enqueue{0}, n_phases{0}, n_entries{0};
+            auto now_ns = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
             const bool ok = LN.run([&](int t) {
                 CbLane &L = LN.lanes[t];
+                long long l_gen = 0, l_wait = 0, l_enq = 0, l_ph = 0, l_ent = 0;
+                struct Flush {
+                    std::function<void()> f;
+                    ~Flush() { f(); }
+                } flush{[&] { ns_gen += l_gen; ns_wait += l_wait; ns_enqueue += l_enq; n_phases += l_ph; n_entries += l_ent; }};
                 for (auto &S : L.slot) {
                     S.active.clear();
                     S.pending = false;
@@ -2331,7 +2478,9 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                         if (LN.failed)
                             return;
                         if (S.pending) { // digest the phase that was in flight
+                            const long long tw = now_ns();
                             HMX_LANE_HIP(LN, S.wait());
+                            l_wait += now_ns() - tw;
                             size_t w = 0;
                             for (size_t i = 0; i < S.active.size(); i++) {
                                 const CbResult r = S.h_res[i];
@@ -2364,36 +2513,49 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                             }
                             S.row_phase = true;
                         }
-                        // evaluate this phase's lines, then upload + kernel + result copy on the lane's stream
-                        int64_t tot = 0;
-                        for (int32_t b : S.active) {
-                            const hmx_leaf &l = H.leaves[b];
-                            const bool sw     = sympiv && !(l.t_offset >= l.s_offset);
-                            tot += (S.row_phase != sw) ? l.s_size : l.t_size; // row phase: index 2 runs over the source side unless swapped
-                        }
-                        HMX_LANE_HIP(LN, S.ensure((size_t)tot, std::max(S.active.size(), CB_BATCH_BLOCKS)));
-                        int64_t pos = 0;
+                        // evaluate this phase's lines (shared out in chunks to all generator threads), then upload + kernel + result copy on
+                        // the lane's stream
+                        const long long tg = now_ns();
+                        int64_t tot = 0, in_chunk = 0;
+                        S.chunk_first.assign(1, 0);
                         for (size_t i = 0; i < S.active.size(); i++) {
                             const int32_t b   = S.active[i];
                             const hmx_leaf &l = H.leaves[b];
                             const bool sw     = sympiv && !(l.t_offset >= l.s_offset);
-                            scalar *out       = S.h_buf + pos;
-                            S.h_items[i]      = CbItem{pos, b, 0};
-                            if (S.row_phase) { // entries (I1, k), k over index 2
-                                if (!sw)
-                                    gen(1, l.s_size, l.t_offset + S.I1[i], l.s_offset, out);
-                                else
-                                    gen(l.t_size, 1, l.t_offset, l.s_offset + S.I1[i], out);
-                                pos += sw ? l.t_size : l.s_size;
-                            } else { // entries (k, I2), k over index 1
-                                if (!sw)
-                                    gen(l.t_size, 1, l.t_offset, l.s_offset + S.I2[i], out);
-                                else
-                                    gen(1, l.s_size, l.t_offset + S.I2[i], l.s_offset, out);
-                                pos += sw ? l.s_size : l.t_size;
+                            const int64_t len = (S.row_phase != sw) ? l.s_size : l.t_size; // row phase: index 2 runs over the source side unless swapped
+                            S.h_items[i]      = CbItem{tot, b, 0};
+                            tot += len;
+                            in_chunk += len;
+                            if (in_chunk >= CB_CHUNK_ENTRIES && i + 1 < S.active.size()) {
+                                S.chunk_first.push_back(i + 1);
+                                in_chunk = 0;
                             }
                         }
+                        S.chunk_first.push_back(S.active.size());
+                        const std::function<void(size_t)> body = [&](size_t c) {
+                            for (size_t i = S.chunk_first[c]; i < S.chunk_first[c + 1]; i++) {
+                                const hmx_leaf &l = H.leaves[S.active[i]];
+                                const bool sw     = sympiv && !(l.t_offset >= l.s_offset);
+                                scalar *out       = S.h_buf + S.h_items[i].off;
+                                if (S.row_phase) { // entries (I1, k), k over index 2
+                                    if (!sw)
+                                        gen(1, l.s_size, l.t_offset + S.I1[i], l.s_offset, out);
+                                    else
+                                        gen(l.t_size, 1, l.t_offset, l.s_offset + S.I1[i], out);
+                                } else { // entries (k, I2), k over index 1
+                                    if (!sw)
+                                        gen(l.t_size, 1, l.t_offset, l.s_offset + S.I2[i], out);
+                                    else
+                                        gen(1, l.s_size, l.t_offset + S.I2[i], l.s_offset, out);
+                                }
+                            }
+                        };
+                        LN.parallel(S.chunk_first.size() - 1, body);
                         const size_t na = S.active.size();
+                        const long long tq = now_ns();
+                        l_gen += tq - tg;
+                        l_ph++;
+                        l_ent += tot;
                         HMX_LANE_HIP(LN, hipMemcpyAsync(S.d_buf, S.h_buf, (size_t)tot * sizeof(scalar), hipMemcpyHostToDevice, L.st));
                         HMX_LANE_HIP(LN, hipMemcpyAsync(S.d_items, S.h_items, na * sizeof(CbItem), hipMemcpyHostToDevice, L.st));
                         AcaCbArgs A = A0;
@@ -2407,6 +2569,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                         HMX_LANE_HIP(LN, hipGetLastError());
                         HMX_LANE_HIP(LN, hipMemcpyAsync(S.h_res, S.d_res, na * sizeof(CbResult), hipMemcpyDeviceToHost, L.st));
                         HMX_LANE_HIP(LN, hipEventRecord(S.done, L.st));
+                        l_enq += now_ns() - tq;
                         S.pending = true;
                         any       = true;
                     }
@@ -2419,8 +2582,9 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                 return HMX_ERR_HIP;
             }
             if (phase_timing)
-                fprintf(stderr, "[hmx build]   round %d: %zu blocks in %zu batches on %zu generator threads, %zu parked at a pool of %.2f GB\n", round, todo.size(), nbatches,
-                        LN.lanes.size(), parked.size(), (double)cap * sizeof(scalar) / 1e9);
+                fprintf(stderr, "[hmx build]   round %d: %zu blocks in %zu batches, %zu drivers + %d workers, %zu parked at a pool of %.2f GB; %lld phases, %.3e entries; "
+                                "driver-seconds: evaluation %.2f, waiting for the device %.2f, enqueue %.2f\n", round, todo.size(), nbatches,
+                        LN.lanes.size(), LN.nworkers, parked.size(), (double)cap * sizeof(scalar) / 1e9, (long long)n_phases, (double)n_entries, ns_gen * 1e-9, ns_wait * 1e-9, ns_enqueue * 1e-9);
             if (parked.empty())
                 break;
             const int rcg = grow_pool();
@@ -2937,6 +3101,178 @@ int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V) {
             for (int i = 0; i < len; i++)
                 U_or_D[(size_t)(rel + i) + (size_t)M * j] = buf[(size_t)j * len + i];
     }
+    return HMX_OK;
+}
+
+// Bulk download: `count` blocks in a few large device-to-host copies instead of one blocking copy per cross / per slice (what a loop over
+// hmx_hmatrix_get_block costs: 468 754 leaves at N = 1e6).  The blocks are gathered on the device into a staging array in htool's own
+// layouts (get_lr_blocks_kernel / get_dense_blocks_kernel), the staging array crosses PCIe into pinned memory in pieces of 256 MiB, and
+// the host threads copy every block to the caller's pointer while the next piece is in flight.  V[k] may be NULL for dense leaves.
+int api_get_blocks(const HMat *Hc, int64_t count, const int64_t *leaves, scalar *const *U_or_D, scalar *const *V) {
+    HMat *H = const_cast<HMat *>(Hc);
+    if (!H || count < 0 || (count > 0 && (!leaves || !U_or_D))) {
+        set_error("hmx_hmatrix_get_blocks: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    if (!H->finalized) {
+        set_error("hmx_hmatrix_get_blocks: operator not built");
+        return HMX_ERR_STATE;
+    }
+    if (count == 0)
+        return HMX_OK;
+    HMX_HIP(hipSetDevice(H->device));
+    std::vector<GetItem> items((size_t)count);
+    std::vector<int64_t> entries((size_t)count);
+    int64_t largest = 1;
+    bool any_lr     = false;
+    for (int64_t k = 0; k < count; k++) {
+        const int64_t b = leaves[k];
+        if (b < 0 || b >= (int64_t)H->leaves.size() || !U_or_D[k]) {
+            set_error("hmx_hmatrix_get_blocks: leaf index out of range or NULL destination");
+            return HMX_ERR_INVALID;
+        }
+        const hmx_leaf &l = H->leaves[b];
+        const bool lr     = H->kind[b] == LK_LOWRANK;
+        if (lr && (!V || !V[k])) {
+            set_error("hmx_hmatrix_get_blocks: a low-rank leaf needs a destination for V");
+            return HMX_ERR_INVALID;
+        }
+        any_lr     = any_lr || lr;
+        items[k]   = GetItem{0, lr ? H->colptr[b] : 0, (int32_t)b, lr ? l.rank : -1, l.t_size, l.s_size, lr ? H->swapped[b] : 0, l.t_offset - H->T0};
+        entries[k] = lr ? (int64_t)l.rank * ((int64_t)l.t_size + l.s_size) : (int64_t)l.t_size * l.s_size;
+        largest    = std::max(largest, entries[k]);
+    }
+    if (any_lr && H->factors_released) {
+        set_error("hmx_hmatrix_get_blocks: the low-rank factors were released (hmx_hmatrix_release_factors)");
+        return HMX_ERR_STATE;
+    }
+    const int64_t CAP = std::max<int64_t>((int64_t(256) << 20) / (int64_t)sizeof(scalar), largest);
+    struct Piece {
+        scalar *h = nullptr;
+        DArr<scalar> d;
+        DArr<GetItem> d_items;
+        DArr<int32_t> d_pi, d_pr, d_pc;
+        hipEvent_t ev = nullptr;
+        int64_t k0 = 0, k1 = 0;
+        ~Piece() {
+            if (h)
+                (void)hipHostFree(h);
+            if (ev)
+                (void)hipEventDestroy(ev);
+        }
+    } piece[2];
+    hipStream_t st = nullptr;
+    struct StreamGuard {
+        hipStream_t &s;
+        ~StreamGuard() {
+            if (s) {
+                (void)hipStreamSynchronize(s);
+                (void)hipStreamDestroy(s);
+            }
+        }
+    } guard{st};
+    HMX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int64_t total = std::accumulate(entries.begin(), entries.end(), (int64_t)0);
+    const int npieces_needed = total > CAP ? 2 : 1;
+    const int64_t cap_eff     = std::min(CAP, std::max<int64_t>(total, 1));
+    for (int s = 0; s < npieces_needed; s++) {
+        HMX_HIP(hipHostMalloc((void **)&piece[s].h, (size_t)cap_eff * sizeof(scalar), hipHostMallocDefault));
+        HMX_HIP(piece[s].d.alloc((size_t)cap_eff));
+        HMX_HIP(hipEventCreateWithFlags(&piece[s].ev, hipEventDisableTiming | hipEventBlockingSync));
+    }
+    HMX_HIP(hipDeviceSynchronize()); // whatever built or last used the operator
+    auto scatter = [&](Piece &P) { // staging (pinned) -> the caller's blocks, on the host cores
+        const int64_t n = P.k1 - P.k0;
+        const size_t nt = (size_t)std::max<int64_t>(1, std::min<int64_t>({(int64_t)host_cores(), (int64_t)32, n}));
+        std::atomic<int64_t> next{P.k0};
+        auto work = [&] {
+            for (;;) {
+                const int64_t k = next.fetch_add(1);
+                if (k >= P.k1)
+                    break;
+                const GetItem &it = items[k];
+                const scalar *src = P.h + it.dst;
+                if (it.rank >= 0) {
+                    std::memcpy(U_or_D[k], src, (size_t)it.M * it.rank * sizeof(scalar));
+                    std::memcpy(V[k], src + (int64_t)it.M * it.rank, (size_t)it.rank * it.N * sizeof(scalar));
+                } else {
+                    std::memcpy(U_or_D[k], src, (size_t)it.M * it.N * sizeof(scalar));
+                }
+            }
+        };
+        if (nt == 1) {
+            work();
+            return;
+        }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++)
+            th.emplace_back(work);
+        for (auto &x : th)
+            x.join();
+    };
+    int64_t k = 0;
+    int cur   = 0;
+    bool have_prev = false;
+    while (k < count) {
+        Piece &P = piece[cur];
+        // the leaves of this piece
+        int64_t used = 0, k1 = k;
+        std::vector<int32_t> pi, pr, pc;
+        bool lr_here = false;
+        while (k1 < count && used + entries[k1] <= cap_eff) {
+            items[k1].dst = used;
+            used += entries[k1];
+            if (items[k1].rank >= 0) {
+                lr_here = true;
+            } else { // its slices in the E-streams
+                const int32_t b = items[k1].leaf;
+                auto lo = std::lower_bound(H->dp_leaf.begin(), H->dp_leaf.end(), b), hi = std::upper_bound(lo, H->dp_leaf.end(), b);
+                int64_t rows = 0;
+                for (auto itp = lo; itp != hi; ++itp) {
+                    const size_t q = (size_t)(itp - H->dp_leaf.begin());
+                    pi.push_back((int32_t)(k1 - k));
+                    pr.push_back(H->dp_range[q]);
+                    pc.push_back(H->dp_col[q]);
+                    rows += H->E.len[H->dp_range[q]];
+                }
+                if (rows != items[k1].M) {
+                    set_error("hmx_hmatrix_get_blocks: internal lookup failed (dense leaf not found in the streams)");
+                    return HMX_ERR_STATE;
+                }
+            }
+            k1++;
+        }
+        P.k0 = k, P.k1 = k1;
+        HMX_HIP(P.d_items.alloc((size_t)(k1 - k)));
+        HMX_HIP(hipMemcpyAsync(P.d_items.d, items.data() + k, (size_t)(k1 - k) * sizeof(GetItem), hipMemcpyHostToDevice, st));
+        if (lr_here)
+            hipLaunchKernelGGL(get_lr_blocks_kernel, dim3((unsigned)(k1 - k), 4), dim3(256), 0, st, (const GetItem *)P.d_items.d, (const scalar *)H->pool.d, (const int64_t *)H->d_cross_off.d, P.d.d);
+        if (!pi.empty()) {
+            HMX_HIP(P.d_pi.alloc(pi.size()));
+            HMX_HIP(P.d_pr.alloc(pi.size()));
+            HMX_HIP(P.d_pc.alloc(pi.size()));
+            HMX_HIP(hipMemcpyAsync(P.d_pi.d, pi.data(), pi.size() * 4, hipMemcpyHostToDevice, st));
+            HMX_HIP(hipMemcpyAsync(P.d_pr.d, pr.data(), pi.size() * 4, hipMemcpyHostToDevice, st));
+            HMX_HIP(hipMemcpyAsync(P.d_pc.d, pc.data(), pi.size() * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(get_dense_blocks_kernel, dim3((unsigned)pi.size()), dim3(256), 0, st, (const GetItem *)P.d_items.d, (const int32_t *)P.d_pi.d, (const int32_t *)P.d_pr.d,
+                               (const int32_t *)P.d_pc.d, (const scalar *)H->E.stream.d, (const int64_t *)H->E.d_base.d, (const int32_t *)H->E.d_off.d, (const int32_t *)H->E.d_len.d, P.d.d);
+        }
+        HMX_HIP(hipGetLastError());
+        HMX_HIP(hipMemcpyAsync(P.h, P.d.d, (size_t)used * sizeof(scalar), hipMemcpyDeviceToHost, st));
+        HMX_HIP(hipEventRecord(P.ev, st));
+        if (have_prev) // the previous piece is complete in pinned memory: the host threads hand it out while this one is gathered and copied
+            scatter(piece[cur ^ 1]);
+        HMX_HIP(hipStreamSynchronize(st)); // (the small host vectors pi / pr / pc and the item slice must outlive their copies)
+        have_prev = true;
+        k         = k1;
+        cur ^= 1;
+        if (npieces_needed == 1 && k < count) { // (cannot happen: one piece holds everything)
+            set_error("hmx_hmatrix_get_blocks: internal staging error");
+            return HMX_ERR_STATE;
+        }
+    }
+    if (have_prev)
+        scatter(piece[cur ^ 1]);
     return HMX_OK;
 }
 

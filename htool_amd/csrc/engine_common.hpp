@@ -11,7 +11,9 @@
 #include <thread>
 #include <cmath>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -400,7 +402,7 @@ static void make_ranges(std::vector<int> &bp, int maxlen, int origin, std::vecto
 // host loops over millions of (leaf, range) pairs with disjoint outputs: split over a few threads
 template <typename F>
 static void parallel_for(size_t n, F &&body) {
-    const size_t nt = std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), n / 65536 + 1});
+    const size_t nt = std::min<size_t>({(size_t)16, (size_t)host_cores(), n / 65536 + 1});
     if (nt <= 1) {
         body((size_t)0, n);
         return;

@@ -66,6 +66,10 @@ struct hmx_block_tree {
 
 namespace hmx {
 void set_error(const std::string &msg);
+// Cores this process may really use: the hardware threads, capped by the cgroup CPU quota (containers: cpu.max = "1600000 100000" means
+// 16 cores' worth of time however many threads run; more threads than that only get throttled -- measured on a 256-thread box with that
+// quota: 16 threads 6.7 G entries/s, 128 threads 5.1, 256 threads 4.3).  capi_host.cpp.
+int host_cores();
 // partition_kind: 0 none ("simple" partition from size_of_partition), 1 global (partition[i] = part of point i),
 // 2 local (partition[2p], partition[2p+1] = offset, size of part p) -- tree_builder.hpp:87-123
 int build_cluster_tree(int n, int dim, const double *coords, const double *radii, const double *weights,

@@ -26,7 +26,10 @@
 #include <htool/misc/logger.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <complex>
+#include <cstdlib>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <string>
@@ -57,6 +60,7 @@ struct Abi<double> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const double *U, const double *V) { return hmx_hmatrix_set_block_lowrank(h, leaf, r, U, V); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const double *D) { return hmx_hmatrix_set_block_dense(h, leaf, D); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, double *U, double *V) { return hmx_hmatrix_get_block(h, leaf, U, V); }
+    static int get_blocks(const hmx_hmatrix *h, int64_t n, const int64_t *leaves, double *const *U, double *const *V) { return hmx_hmatrix_get_blocks(h, n, leaves, U, V); }
     static int matvec(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec(h, tr, a, in, b, out, mem, stream); }
     static int matmat(hmx_hmatrix *h, char tr, double a, const double *in, double b, double *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major(h, tr, a, in, b, out, mu, mem, stream); }
 };
@@ -68,6 +72,7 @@ struct Abi<float> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const float *U, const float *V) { return hmx_hmatrix_set_block_lowrank_s(h, leaf, r, U, V); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const float *D) { return hmx_hmatrix_set_block_dense_s(h, leaf, D); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, float *U, float *V) { return hmx_hmatrix_get_block_s(h, leaf, U, V); }
+    static int get_blocks(const hmx_hmatrix *h, int64_t n, const int64_t *leaves, float *const *U, float *const *V) { return hmx_hmatrix_get_blocks_s(h, n, leaves, U, V); }
     static int matvec(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec_s(h, tr, a, in, b, out, mem, stream); }
     static int matmat(hmx_hmatrix *h, char tr, float a, const float *in, float b, float *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major_s(h, tr, a, in, b, out, mu, mem, stream); }
 };
@@ -82,6 +87,7 @@ struct Abi<std::complex<double>> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const Z *U, const Z *V) { return hmx_hmatrix_set_block_lowrank_z(h, leaf, r, p(U), p(V)); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const Z *D) { return hmx_hmatrix_set_block_dense_z(h, leaf, p(D)); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, Z *U, Z *V) { return hmx_hmatrix_get_block_z(h, leaf, p(U), p(V)); }
+    static int get_blocks(const hmx_hmatrix *h, int64_t n, const int64_t *leaves, Z *const *U, Z *const *V) { return hmx_hmatrix_get_blocks_z(h, n, leaves, reinterpret_cast<double *const *>(U), reinterpret_cast<double *const *>(V)); }
     static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec_z(h, tr, p(&a), p(in), p(&b), p(out), mem, stream); }
     static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major_z(h, tr, p(&a), p(in), p(&b), p(out), mu, mem, stream); }
 };
@@ -96,6 +102,7 @@ struct Abi<std::complex<float>> {
     static int set_lowrank(hmx_hmatrix *h, int64_t leaf, int r, const Z *U, const Z *V) { return hmx_hmatrix_set_block_lowrank_c(h, leaf, r, p(U), p(V)); }
     static int set_dense(hmx_hmatrix *h, int64_t leaf, const Z *D) { return hmx_hmatrix_set_block_dense_c(h, leaf, p(D)); }
     static int get_block(const hmx_hmatrix *h, int64_t leaf, Z *U, Z *V) { return hmx_hmatrix_get_block_c(h, leaf, p(U), p(V)); }
+    static int get_blocks(const hmx_hmatrix *h, int64_t n, const int64_t *leaves, Z *const *U, Z *const *V) { return hmx_hmatrix_get_blocks_c(h, n, leaves, reinterpret_cast<float *const *>(U), reinterpret_cast<float *const *>(V)); }
     static int matvec(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matvec_c(h, tr, p(&a), p(in), p(&b), p(out), mem, stream); }
     static int matmat(hmx_hmatrix *h, char tr, Z a, const Z *in, Z b, Z *out, int mu, int mem = HMX_MEM_HOST, void *stream = nullptr) { return hmx_hmatrix_matmat_row_major_c(h, tr, p(&a), p(in), p(&b), p(out), mu, mem, stream); }
 };
@@ -298,6 +305,7 @@ class EngineT {
         return m_block_tree && ok(hmx_block_tree_root(m_block_tree, out, &sym, &uplo), "block tree root");
     }
     size_t number_of_leaves() const { return m_leaves.size(); }
+    const hmx_leaf &leaf(size_t b) const { return m_leaves[b]; }
     bool leaf_is_admissible(int64_t leaf) const { return m_leaves[leaf].admissible != 0; }
     int64_t find_leaf(int row_offset, int M, int col_offset, int N) const {
         auto it = m_leaf_of.find(std::make_tuple(row_offset, M, col_offset, N));
@@ -313,27 +321,77 @@ class DeviceLowRankGeneratorT final : public htool::VirtualInternalLowRankGenera
     const EngineT<T> &m_engine;
     mutable std::mutex m_mutex;
     mutable std::vector<int32_t> m_ranks;
+    // every low-rank block of the device operator, downloaded in ONE bulk call (hmx_hmatrix_get_blocks: gathered on the device, a few
+    // large copies) when htool's build loop asks for the first one; handed out by memcpy afterwards -- 324 418 admissible blocks at
+    // N = 1e6 would otherwise be as many blocking device-to-host copies under a mutex.  Host memory: the factors once more (released
+    // by release_cache(), or with the generator).
+    struct FreeDeleter {
+        void operator()(T *p) const { std::free(p); }
+    };
+    mutable std::unique_ptr<T[], FreeDeleter> m_cache; // malloc'ed: not zero-filled, the pages are first touched by the download's threads
+    mutable std::vector<int64_t> m_cache_off;          // per leaf: first entry of U in m_cache (V follows), -1 = not low rank
+    mutable bool m_cached = false, m_cache_ok = false;
+    mutable double m_prefetch_seconds = 0;
+
+    void prefetch() const {
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t nl = m_engine.number_of_leaves();
+        m_ranks.resize(nl + 1);
+        hmx_hmatrix_leaf_ranks(m_engine.hmatrix(), m_ranks.data());
+        m_cache_off.assign(nl, -1);
+        std::vector<int64_t> leaves;
+        int64_t total = 0;
+        for (size_t b = 0; b < nl; b++)
+            if (m_ranks[b] > 0) {
+                m_cache_off[b] = total;
+                total += (int64_t)m_ranks[b] * ((int64_t)m_engine.leaf(b).t_size + m_engine.leaf(b).s_size);
+                leaves.push_back((int64_t)b);
+            }
+        m_cache.reset(static_cast<T *>(std::malloc(std::max<size_t>((size_t)total, 1) * sizeof(T))));
+        if (!m_cache) {
+            htool::Logger::get_instance().log(htool::LogLevel::ERROR, "[hmx] out of host memory for the downloaded low-rank blocks");
+            m_cache_ok = false;
+            m_cached   = true;
+            return;
+        }
+        std::vector<T *> pu(leaves.size()), pv(leaves.size());
+        for (size_t k = 0; k < leaves.size(); k++) {
+            const int64_t b = leaves[k];
+            pu[k]           = m_cache.get() + m_cache_off[b];
+            pv[k]           = pu[k] + (int64_t)m_ranks[b] * m_engine.leaf(b).t_size;
+        }
+        m_cache_ok = leaves.empty() || ok(Abi<T>::get_blocks(m_engine.hmatrix(), (int64_t)leaves.size(), leaves.data(), pu.data(), pv.data()), "get blocks");
+        m_cached   = true;
+        m_prefetch_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
 
   public:
     explicit DeviceLowRankGeneratorT(const EngineT<T> &engine) : m_engine(engine) {}
+    void release_cache() const {
+        std::lock_guard<std::mutex> lock(m_mutex);
+        m_cache.reset();
+        m_cached = false;
+    }
+    double prefetch_seconds() const { return m_prefetch_seconds; } // wall time of the one bulk download
 
     bool copy_low_rank_approximation(int M, int N, int row_offset, int col_offset, htool::LowRankMatrix<T> &lrmat) const override {
         const int64_t leaf = m_engine.find_leaf(row_offset, M, col_offset, N);
         if (leaf < 0)
             return false; // unknown block -> htool falls back to a dense block (tree_builder.hpp:572-577)
-        std::lock_guard<std::mutex> lock(m_mutex);
-        if (m_ranks.empty()) {
-            hmx_stats st;
-            hmx_hmatrix_stats(m_engine.hmatrix(), &st);
-            m_ranks.resize(st.n_dense + st.n_lowrank + 1);
-            hmx_hmatrix_leaf_ranks(m_engine.hmatrix(), m_ranks.data());
+        {
+            std::lock_guard<std::mutex> lock(m_mutex); // the first caller downloads everything; the others wait for it here
+            if (!m_cached)
+                prefetch();
         }
         const int r = m_ranks[leaf];
-        if (r <= 0)
+        if (r <= 0 || !m_cache_ok)
             return false; // compressor failed on the device as well
         lrmat.get_U().resize(M, r);
         lrmat.get_V().resize(r, N);
-        return ok(Abi<T>::get_block(m_engine.hmatrix(), leaf, lrmat.get_U().data(), lrmat.get_V().data()), "get block");
+        const T *src = m_cache.get() + m_cache_off[leaf];
+        std::copy_n(src, (size_t)M * r, lrmat.get_U().data());
+        std::copy_n(src + (size_t)M * r, (size_t)r * N, lrmat.get_V().data());
+        return true;
     }
     bool copy_low_rank_approximation(int M, int N, int row_offset, int col_offset, int, htool::LowRankMatrix<T> &lrmat) const override {
         return copy_low_rank_approximation(M, N, row_offset, col_offset, lrmat); // the device build already used reqrank
@@ -370,14 +428,20 @@ class DeviceDenseBlocksGeneratorT final : public htool::VirtualDenseBlocksGenera
   public:
     explicit DeviceDenseBlocksGeneratorT(const EngineT<T> &engine) : m_engine(engine) {}
     void copy_dense_blocks(const std::vector<int> &M, const std::vector<int> &N, const std::vector<int> &rows, const std::vector<int> &cols, std::vector<T *> &ptr) const override {
+        // one bulk download straight into htool's destinations (hmx_hmatrix_get_blocks)
+        std::vector<int64_t> leaves;
+        std::vector<T *> dst;
         for (size_t b = 0; b < ptr.size(); b++) {
             const int64_t leaf = m_engine.find_leaf(rows[b], M[b], cols[b], N[b]);
             if (leaf < 0) {
                 htool::Logger::get_instance().log(htool::LogLevel::ERROR, "[hmx] dense block not present in the hmx block tree");
                 continue;
             }
-            ok(Abi<T>::get_block(m_engine.hmatrix(), leaf, ptr[b], nullptr), "get dense block");
+            leaves.push_back(leaf);
+            dst.push_back(ptr[b]);
         }
+        if (!leaves.empty())
+            ok(Abi<T>::get_blocks(m_engine.hmatrix(), (int64_t)leaves.size(), leaves.data(), dst.data(), nullptr), "get dense blocks");
     }
 };
 using DeviceDenseBlocksGenerator = DeviceDenseBlocksGeneratorT<double>;

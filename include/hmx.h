@@ -89,6 +89,9 @@ int hmx_device_count(void);
 /* One-time initialisation of the device side (HIP context, load of the library's code object: ~0.2 s), otherwise paid by the
  * first hmx_hmatrix_create / compress.  Optional; for callers that time operator builds. */
 int hmx_device_init(int device_id);
+/* Host cores the library will use for its host-side work (cluster tree, layout, generator threads): the hardware threads capped by the
+ * cgroup CPU quota of the process (a container limited to 16 cores' worth of time gains nothing from 256 threads); HMX_HOST_CORES overrides. */
+int hmx_host_cores(void);
 
 /* ---- test geometries (testing/geometry.hpp:11-61), seeded mt19937(0) --------------------------------- */
 int hmx_geometry(const char *name /* "ellipse" | "disk" | "ball" (n*3 doubles) | "disk2d" (n*2) */, int n, double z, double *coords);
@@ -209,6 +212,15 @@ int hmx_hmatrix_finalize(hmx_hmatrix *);
 /* Download path (so the reference's CPU leaf loop can multiply the engine's blocks): */
 int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *, int32_t *rank /* num_leaves, -1 dense */);
 int hmx_hmatrix_get_block(const hmx_hmatrix *, int64_t leaf, double *U_or_D, double *V);
+/* The same for MANY leaves at once: the blocks are gathered on the device into htool's layouts, cross PCIe in pieces of 256 MiB and are handed
+ * out to U_or_D[k] / V[k] (V[k] may be NULL for a dense leaf; V itself may be NULL when no leaf is low rank) by the host's cores while the next
+ * piece is in flight -- what a plug-in that fills htool's own HMatrix needs (DeviceLowRankGenerator / DeviceDenseBlocksGenerator of
+ * htool_adaptor.hpp: HMatrix::compute_low_rank_data / compute_dense_data, hmatrix/hmatrix.hpp:222-237, for every leaf), instead of one blocking
+ * copy per cross.  _s / _z / _c: the other coefficient types (complex: interleaved). */
+int hmx_hmatrix_get_blocks(const hmx_hmatrix *, int64_t count, const int64_t *leaves, double *const *U_or_D, double *const *V);
+int hmx_hmatrix_get_blocks_s(const hmx_hmatrix *, int64_t count, const int64_t *leaves, float *const *U_or_D, float *const *V);
+int hmx_hmatrix_get_blocks_z(const hmx_hmatrix *, int64_t count, const int64_t *leaves, double *const *U_or_D, double *const *V);
+int hmx_hmatrix_get_blocks_c(const hmx_hmatrix *, int64_t count, const int64_t *leaves, float *const *U_or_D, float *const *V);
 int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);
 /* Complex coefficients: the entry points above that carry coefficients, for HMatrix<std::complex<double>> (_z) and
  * HMatrix<std::complex<float>> (_c).  Symmetry 'S' = complex symmetric (mirror pass with trans 'T'), 'H' = Hermitian (mirror pass

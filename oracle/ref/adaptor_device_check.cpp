@@ -74,7 +74,87 @@ static void report(const char *what, double err, double tol) {
         failures++;
 }
 
-int main() {
+// `adaptor_device_check --time N`: how long the drop-in routes take at size N next to htool's own OpenMP build on the same box
+// (same generator class, same cluster tree, eps = 1e-4, eta = 10, leaf 100, minimal block depth as bench.py's).  Routes: (a) device kernel,
+// (b) htool's builder fed by the device generators (bulk download of every block), (c) the user's VirtualGenerator through the host
+// callback on all cores.  Ranks of (a) and (c) must agree leaf by leaf; (b) must reproduce htool's product.
+#include <chrono>
+#include <omp.h>
+static double seconds_since(const std::chrono::steady_clock::time_point &t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+static int timing(int n) {
+    // htool's OpenMP loops on as many threads as the process really has cores (a container quota of 16 cores on a 256-thread box: 256
+    // OpenMP threads are throttled to a crawl; hmx_host_cores reads the quota) -- what a user would set OMP_NUM_THREADS to
+    if (!std::getenv("OMP_NUM_THREADS"))
+        omp_set_num_threads(hmx_host_cores());
+    std::printf("host cores %d (OpenMP threads %d), N = %d\n", hmx_host_cores(), omp_get_max_threads(), n);
+    std::vector<double> x(3 * (size_t)n);
+    create_rotated_ellipse(3, 4., 1., 0., 0., n, x.data());
+    auto t0 = std::chrono::steady_clock::now();
+    ClusterTreeBuilder<double> ctb;
+    ctb.set_maximal_leaf_size(100);
+    Cluster<double> T = ctb.create_cluster_tree(n, 3, x.data(), 2, 2);
+    std::printf("htool cluster tree (host, htool's own builder)                         %8.3f s\n", seconds_since(t0));
+    const double eps = 1e-4, eta = 10.;
+    int depth = 0; // bench.py's minimal_depth: blocks of at most 31 250 rows
+    for (long long m = n; m > 31250; m /= 2)
+        depth++;
+    Kernel<double> A(x);
+    std::vector<double> in(n), yref(n, 0.), y(n, 0.);
+    for (int i = 0; i < n; i++)
+        in[i] = std::sin(0.37 * i) + 0.1;
+    t0 = std::chrono::steady_clock::now();
+    HMatrixTreeBuilder<double> tb(eps, eta, 'N', 'N');
+    tb.set_minimal_target_depth(depth);
+    tb.set_minimal_source_depth(depth);
+    tb.set_low_rank_generator(std::make_shared<partialACA<double>>(A, T.get_permutation().data(), T.get_permutation().data()));
+    HMatrix<double> Href = tb.openmp_build(A, T, T);
+    const double t_ref   = seconds_since(t0);
+    std::printf("(0) htool's own build (OpenMP, partialACA on the host)                  %8.3f s\n", t_ref);
+    add_hmatrix_vector_product('N', 1., Href, in.data(), 0., yref.data());
+
+    t0 = std::chrono::steady_clock::now();
+    hmx_htool::Engine E(T, T, 3);
+    if (!E.setup_block_tree(eta, 'N', 'N', depth, depth, -1, -1, 0))
+        return 3;
+    const double p[2] = {1e-5, 1.0};
+    if (!E.compress_on_device(HMX_KERNEL_INV_DIST, p, 2, 3, x.data(), x.data(), HMX_PARTIAL_ACA, eps, -1))
+        return 3;
+    hipDeviceSynchronize();
+    std::printf("(a) tree import + block tree + device compression, built-in kernel      %8.3f s\n", seconds_since(t0));
+
+    t0 = std::chrono::steady_clock::now();
+    HMatrixTreeBuilder<double> tb2(eps, eta, 'N', 'N');
+    tb2.set_minimal_target_depth(depth);
+    tb2.set_minimal_source_depth(depth);
+    auto lrgen = std::make_shared<hmx_htool::DeviceLowRankGenerator>(E);
+    tb2.set_low_rank_generator(lrgen);
+    tb2.set_dense_blocks_generator(std::make_shared<hmx_htool::DeviceDenseBlocksGenerator>(E));
+    HMatrix<double> Hdev = tb2.openmp_build(A, T, T);
+    std::printf("(b) htool's builder fed by the device generators                        %8.3f s  (of which the one bulk download of the low-rank blocks: %.3f s)\n", seconds_since(t0), lrgen->prefetch_seconds());
+    add_hmatrix_vector_product('N', 1., Hdev, in.data(), 0., y.data());
+    report("(b) htool CPU product on the GPU-compressed blocks vs htool's own operator", rel(y, yref), 1e-10);
+
+    t0 = std::chrono::steady_clock::now();
+    hmx_htool::Engine Ec(T, T, 3);
+    if (!Ec.setup_block_tree(eta, 'N', 'N', depth, depth, -1, -1, 0) || !Ec.compress_with_generator(A, HMX_PARTIAL_ACA, eps, -1))
+        return 3;
+    hipDeviceSynchronize();
+    const double t_c = seconds_since(t0);
+    std::printf("(c) tree import + block tree + device ACA on the user's VirtualGenerator %8.3f s  (%d host cores; htool's own build / this = %.2f)\n", t_c, hmx_host_cores(), t_ref / t_c);
+    std::vector<int32_t> ra(E.number_of_leaves()), rc(Ec.number_of_leaves());
+    hmx_hmatrix_leaf_ranks(E.hmatrix(), ra.data());
+    hmx_hmatrix_leaf_ranks(Ec.hmatrix(), rc.data());
+    report("(c) ranks of the host-generator build = ranks of the device-kernel build, leaf by leaf", ra == rc ? 0. : 1., 1e-300);
+    std::fill(y.begin(), y.end(), 0.);
+    hmx_hmatrix_matvec_user(Ec.hmatrix(), 'N', 1., in.data(), 0., y.data(), HMX_MEM_HOST, nullptr);
+    report("(c) device product of the host-generator build vs htool on the CPU", rel(y, yref), 1e-10);
+    std::printf(failures ? "adaptor timing: %d FAILED\n" : "adaptor timing: all ok\n", failures);
+    return failures ? 1 : 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 3 && std::string(argv[1]) == "--time")
+        return timing(std::atoi(argv[2]));
     const int n = 4000;
     std::vector<double> x(3 * n);
     create_rotated_ellipse(3, 4., 1., 0., 0., n, x.data());

@@ -23,6 +23,19 @@ def test_reference_with_adaptor_on_device():
     assert "all ok" in out.stdout and out.stdout.count(" ok\n") >= 13
 
 
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/adaptor_device_check not built (needs the reference tree: dev container only)")
+def test_drop_in_routes_timed_next_to_htools_own_build():
+    """`adaptor_device_check --time N`: htool's own OpenMP build, then the same operator through the device kernel, through htool's
+    builder fed by the device generators (bulk block download, called concurrently from htool's OpenMP loop) and through the user's
+    VirtualGenerator on all cores -- the times are printed (collected at N = 1e6 into profiles/ by tools/collect_profiles.sh), the
+    results checked: ranks of the host-generator build equal the device-kernel build's leaf by leaf, products equal htool's."""
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([EXE, "--time", "60000"], capture_output=True, text=True, timeout=900, env=env)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "adaptor timing: all ok" in out.stdout and out.stdout.count(" ok\n") >= 3
+
+
 MPI_EXE = os.path.join(ROOT, "oracle", "_ref", "distributed_device_check")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 

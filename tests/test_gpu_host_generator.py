@@ -105,3 +105,21 @@ def test_batches_larger_than_the_first_slot_buffer():
     hm.internal_add_hmatrix_vector_product("N", 1.0, Hd, xin, 0.0, yd)
     hm.internal_add_hmatrix_vector_product("N", 1.0, Hh, xin, 0.0, yh)
     assert np.array_equal(yd, yh)
+
+
+@pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_z64_hermU", "rect_ball1500_disk1000"])
+def test_bulk_download_equals_block_by_block(name):
+    """hmx_hmatrix_get_blocks (gathered on the device, a few large copies) against hmx_hmatrix_get_block leaf by leaf: bitwise, whole
+    operator and a shuffled subset."""
+    p = params(name)
+    Hd, _ = both_routes(p, 1)
+    one = [Hd.get_block(b) for b in range(len(Hd.ranks))]
+    bulk = Hd.get_blocks()
+    sel = np.random.default_rng(0).permutation(len(Hd.ranks))[: max(1, len(Hd.ranks) // 3)]
+    part = Hd.get_blocks(sel)
+    for got, idx in ((bulk, range(len(Hd.ranks))), (part, sel)):
+        for blk, b in zip(got, idx):
+            if Hd.ranks[b] >= 0:
+                assert np.array_equal(blk[0], one[b][0]) and np.array_equal(blk[1], one[b][1]), b
+            else:
+                assert np.array_equal(blk, one[b]), b
