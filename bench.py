@@ -604,8 +604,9 @@ def main():
             acc.setdefault(name, []).append(ms)
     H.set_profiling(False)
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
-    exp_bytes = esz * (st["expand_coeffs"] + st["a_total"] + n + H.nb_rows())
-    red_bytes = esz * (st["reduce_coeffs"] + st["a_total"] + n)
+    # per launch: the stream once, and per right-hand side the operand vectors (a, x) and the result
+    exp_bytes = esz * (st["expand_coeffs"] + mu * (st["a_total"] + n + H.nb_rows()))
+    red_bytes = esz * (st["reduce_coeffs"] + mu * (st["a_total"] + n))
     # single vector: expand_kernel / reduce_kernel; multi-RHS: the *_mu (LDS operand), *_mus (scalar operand) or *_mfma16 variants
     exp_name = next((k for k in kern_ms if k.startswith("expand")), "expand_kernel")
     red_name = next((k for k in kern_ms if k.startswith("reduce")), "reduce_kernel")

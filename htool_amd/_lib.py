@@ -37,7 +37,8 @@ class Stats(C.Structure):
                 ("cgen_dense", C.c_int64), ("cgen_lowrank", C.c_int64), ("rank_min", C.c_int32),
                 ("rank_max", C.c_int32), ("rank_mean", C.c_double), ("stream_bytes", C.c_int64),
                 ("expand_coeffs", C.c_int64), ("reduce_coeffs", C.c_int64), ("a_total", C.c_int64),
-                ("t_compress_s", C.c_double), ("t_assemble_s", C.c_double), ("t_pack_s", C.c_double)]
+                ("t_compress_s", C.c_double), ("t_assemble_s", C.c_double), ("t_pack_s", C.c_double),
+                ("transposed_bytes", C.c_int64), ("expanded_bytes", C.c_int64)]
 
 
 GENERATOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double))
@@ -106,6 +107,8 @@ SYMBOLS = [
     ("hmx_hmatrix_set_callback_s", C.c_int, [_vp, GENERATOR_FN_S, _vp]),
     ("hmx_hmatrix_set_callback_threads", C.c_int, [_vp, C.c_int]),
     ("hmx_host_cores", C.c_int, []),
+    ("hmx_hmatrix_prepare", C.c_int, [_vp, C.c_char, C.c_int]),
+    ("hmx_device_alloc_count", C.c_int64, []),
     ("hmx_hmatrix_get_blocks", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     ("hmx_hmatrix_get_blocks_s", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     ("hmx_hmatrix_get_blocks_z", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),

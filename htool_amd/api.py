@@ -353,6 +353,11 @@ class HMatrix:
         """Give the compression pool back to the device (products only need the streams); see hmx_hmatrix_release_factors."""
         check(lib().hmx_hmatrix_release_factors(self._h, int(with_transposed)))
 
+    def prepare(self, trans="N", mu=1):
+        """Build / allocate now everything products with this `trans` and this many right-hand sides need (second stream layouts, work
+        vectors, staging buffers): afterwards they allocate nothing (hmx_hmatrix_prepare)."""
+        check(lib().hmx_hmatrix_prepare(self._h, trans.encode(), int(mu)))
+
     def save(self, path):
         """Binary dump of the compressed operator (hmx_hmatrix_save); reload with HMatrixTreeBuilder.load()."""
         check(lib().hmx_hmatrix_save(self._h, str(path).encode()))

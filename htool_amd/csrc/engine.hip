@@ -398,6 +398,7 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *H, char trans, const float *alph
     HMX_GUARD(hmx::c32::api_matmat_row_major(H->c, trans, cval(alpha), CP(in), cval(beta), CPM(out), mu, mem, stream));
 }
 
+int hmx_hmatrix_prepare(hmx_hmatrix *H, char trans, int mu) { HMX_ALL(H, api_prepare, trans, mu); }
 int hmx_hmatrix_release_factors(hmx_hmatrix *H, int with_transposed) { HMX_ALL(H, api_release_factors, with_transposed); }
 int hmx_hmatrix_save(const hmx_hmatrix *H, const char *path) { HMX_ALL(H, api_save, path); }
 int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, hmx_hmatrix **out) {
@@ -1493,6 +1494,7 @@ int hmx_dist_gmv(hmx_dist *Dp, const void *in, void *out, int mu, int dof, void 
 }
 
 double hmx_device_malloc_seconds(void) { return 1e-9 * (double)g_malloc_ns.load(); }
+int64_t hmx_device_alloc_count(void) { return (int64_t)g_alloc_count.load(); }
 int hmx_device_trim_cache(void) {
     DeviceCache::get().trim();
     (void)DeviceSlabs::get().release_idle();

@@ -28,6 +28,7 @@ int api_matmat_row_major(HMat *Hp, char trans, scalar alpha, const scalar *in, s
 int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar beta, scalar *out, int mu, int mem, void *stream);
 int api_set_profiling(HMat *H, int enabled);
 int api_last_kernel_times(const HMat *H, int max, const char **names, float *ms);
+int api_prepare(HMat *Hp, char trans, int mu);
 int api_device_of(const HMat *H);   // device the operator lives on
 void api_destroy(HMat *H);
 // y = w + beta * y on `stream` (the DistributedOperator layer's accumulation of exchanged slices)

@@ -2162,7 +2162,9 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     size_t largest_b = 0;
     HMX_HIP(hmx_mem_largest(&largest_b)); // the pool is ONE array: it must fit the driver's free memory or one hole of a reserved slab
     const double budget        = std::min(0.40 * (double)free_b, 0.95 * (double)largest_b) / sizeof(scalar);
-    unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : 1.25 * estimate));
+    // (the host-generator ACA parks the blocks that find the pool exhausted and continues them after a growth step, so it starts from half
+    // the pessimistic estimate: 16.6 instead of 41.5 GB at N = 1e6, where 14.2 GB are used)
+    unsigned long long cap = (unsigned long long)std::max(1024.0, std::min(std::min(need, budget), full_pool ? need : (use_cb && !assembled ? 0.5 : 1.25) * estimate));
     phase("host scratch tables");
     DArr<unsigned long long> head;
     HMX_HIP(head.alloc(1));
@@ -3416,7 +3418,9 @@ int api_release_factors(HMat *Hp, int with_transposed) {
 int api_stats(const HMat *H, hmx_stats *out) {
     if (!H || !out)
         return HMX_ERR_INVALID;
-    *out = H->stats;
+    *out                  = H->stats;
+    out->transposed_bytes = H->T_op ? H->T_op->stats.stream_bytes : 0;
+    out->expanded_bytes   = H->X_op ? H->X_op->stats.stream_bytes : 0;
     return HMX_OK;
 }
 
@@ -3810,6 +3814,43 @@ int api_last_kernel_times(const HMat *H, int max, const char **names, float *ms)
 }
 
 
+
+// hmx_hmatrix_prepare: everything a product with this `trans` and this many right-hand sides needs beyond the operator itself is built
+// NOW -- the transposed stream layout of a 'T' / 'C' product (ensure_transposed_operator), the expanded view multi-RHS products on
+// compact symmetric storage run on (ensure_expanded_view), work vectors, permutation and staging buffers -- by running one product
+// of that shape on zero operands through each entry point (cluster numbering, user numbering).  Afterwards products of that shape
+// allocate nothing: no latency cliff and no out-of-memory surprise in the middle of a Krylov solve.
+int api_prepare(HMat *Hp, char trans, int mu) {
+    if (!Hp || mu < 1) {
+        set_error("hmx_hmatrix_prepare: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    if (!H.finalized) {
+        set_error("hmx_hmatrix_prepare: operator not built");
+        return HMX_ERR_STATE;
+    }
+    HMX_HIP(hipSetDevice(H.device));
+    const bool n_form = trans == 'N';
+    const size_t nin = (size_t)(n_form ? H.nS : H.nT) * mu, nout = (size_t)(n_form ? H.nT : H.nS) * mu;
+    DArr<scalar> in, out;
+    HMX_HIP(in.alloc(std::max<size_t>(nin, 1)));
+    HMX_HIP(out.alloc(std::max<size_t>(nout, 1)));
+    HMX_HIP(in.zero());
+    HMX_HIP(out.zero());
+    int rc = mu == 1 ? api_matvec(Hp, trans, scalar(1), in.d, scalar(0), out.d, HMX_MEM_DEVICE, nullptr)
+                     : api_matmat_row_major(Hp, trans, scalar(1), in.d, scalar(0), out.d, mu, HMX_MEM_DEVICE, nullptr);
+    if (rc != HMX_OK)
+        return rc;
+    if (H.t_root_is_tree_root || H.perm_local) { // the user-numbering front ends exist for this operator: their staging buffers too
+        rc = mu == 1 ? api_matvec_user(Hp, trans, scalar(1), in.d, scalar(0), out.d, HMX_MEM_DEVICE, nullptr)
+                     : api_matmat_user(Hp, trans, scalar(1), in.d, scalar(0), out.d, mu, HMX_MEM_DEVICE, nullptr);
+        if (rc != HMX_OK)
+            return rc;
+    }
+    HMX_HIP(hipDeviceSynchronize());
+    return HMX_OK;
+}
 
 int api_device_of(const HMat *H) { return H ? H->device : -1; }
 void api_destroy(HMat *H) { delete H; }

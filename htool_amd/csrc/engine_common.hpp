@@ -234,6 +234,8 @@ struct DeviceSlabs {
 // wall time this process spent inside hipMalloc (large allocations sporadically take seconds on this platform: tools/malloc_timing.hip);
 // bench.py reports it next to the build time
 inline std::atomic<long long> g_malloc_ns{0}; // one counter for every translation unit of the library
+// device arrays handed out so far, wherever they came from (driver, reserved slab, in-process cache): hmx_device_alloc_count()
+inline std::atomic<long long> g_alloc_count{0};
 struct MallocTimer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ~MallocTimer() { g_malloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
@@ -293,6 +295,7 @@ struct DArr { // device array with RAII
         n = count;
         if (count == 0)
             return hipSuccess;
+        g_alloc_count++;
         const size_t bytes = count * sizeof(T);
         size_t got         = 0;
         (void)hipGetDevice(&dev_);

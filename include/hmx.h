@@ -82,6 +82,8 @@ typedef struct {
     int64_t reduce_coeffs;       /* coefficients streamed by the reduce kernel (V panels)                   */
     int64_t a_total;             /* sum of ranks (length of the intermediate vector a = V x)                */
     double t_compress_s, t_assemble_s, t_pack_s; /* hipEvent timings of the build phases                   */
+    int64_t transposed_bytes;    /* second stream layout of the transposed operator ('T' / 'C' products), 0 = not built          */
+    int64_t expanded_bytes;      /* expanded view of a compact symmetric operator (multi-RHS products), 0 = not built             */
 } hmx_stats;
 
 const char *hmx_last_error(void);
@@ -248,6 +250,14 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *, char trans, const float *alpha
  * first; bit 1 builds the expanded view that multi-RHS products on compact symmetric storage run on -- without it they fall
  * back to one single-vector product per right-hand side). */
 int hmx_hmatrix_release_factors(hmx_hmatrix *, int with_transposed);
+/* Some products run on a second layout of the operator that is otherwise built inside the FIRST product that needs it: transposed
+ * products ('T' / 'C') on the transposed operator's own streams (1.15 x the operator free in HBM, or the in-place passes with atomics),
+ * multi-RHS products on compact symmetric storage on an expanded view -- plus work vectors and, for the user-numbering front ends,
+ * permutation and staging buffers.  hmx_hmatrix_prepare(H, trans, mu) builds and allocates NOW everything products with this `trans` and
+ * this many right-hand sides (1: the vector products) need; afterwards such products allocate nothing (hmx_device_alloc_count does not
+ * move): no latency cliff or out-of-memory condition in the middle of a Krylov solve.  hmx_stats.transposed_bytes / expanded_bytes say
+ * what the extra layouts cost.  Optional. */
+int hmx_hmatrix_prepare(hmx_hmatrix *, char trans, int mu);
 
 /* Binary dump of the compressed operator (no counterpart in the reference): header, leaf table with
  * ranks, then per leaf U (M x r) and V (r x N) or the dense M x N block, all column-major as in htool's
@@ -414,6 +424,9 @@ int hmx_device_reserve(int device_id, int64_t bytes);
 /* Wall time (seconds) this process has spent inside hipMalloc on behalf of libhmx so far: large allocations sporadically take seconds
  * on this platform, callers that time builds report it separately. */
 double hmx_device_malloc_seconds(void);
+/* Device arrays libhmx has handed out so far in this process (from the driver, a reserved slab or its buffer cache): a product call that
+ * leaves it unchanged allocated nothing. */
+int64_t hmx_device_alloc_count(void);
 
 /* Device bandwidth probe: plain 16 B/lane copy of `bytes` bytes, returns GB/s (read+write counted). */
 int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gbps);

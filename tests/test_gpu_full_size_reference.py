@@ -62,7 +62,7 @@ def test_full_size_matches_the_reference(name):
     # the iteration at which it first drops below eps depends on rounding (MKL's sdot vs the kernel's tree sums): ranks scatter by a
     # few around the reference's, both operators approximate the same matrix to eps.
     if f32:
-        assert np.abs(diff).max() <= 8 and abs(float(diff.sum())) <= 0.02 * float(ref_ranks[ref_ranks > 0].sum())
+        assert np.abs(diff).max() <= 7 and abs(float(diff.sum())) <= 0.02 * float(ref_ranks[ref_ranks > 0].sum())  # 7: the largest scatter observed on any fixture (README)
     else:
         assert ndiff == 0
     rows = g["rows"]

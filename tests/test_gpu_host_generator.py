@@ -123,3 +123,31 @@ def test_bulk_download_equals_block_by_block(name):
                 assert np.array_equal(blk[0], one[b][0]) and np.array_equal(blk[1], one[b][1]), b
             else:
                 assert np.array_equal(blk, one[b]), b
+
+
+@pytest.mark.parametrize("name", ["full_ellipse_n100000", "full_ball_n100000", "full_ellipse_n1000000", "full_ellipse_n100000_symL"])
+def test_host_generator_at_full_size_gives_the_reference_ranks(name):
+    """BASELINE's own sizes through the literal drop-in route: the user's generator as compiled host code on all cores, lock-step ACA on the
+    device.  Every rank must equal htool's (fixtures written by the reference, tests/test_gpu_full_size_reference.py), the product its product."""
+    import hashlib
+
+    from helpers import MANIFEST
+    from oracle.oracle import hashed_vector
+    p, g = MANIFEST[name], load(name)
+    n = p["n"]
+    x = hm.create_geometry(p["geom"], n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(p["leaf"])
+    T = b.create_cluster_tree(n, 3, x, 2, p.get("partitions", 2))
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p.get("sym", "N"), p.get("uplo", "N"))
+    tb.set_low_rank_generator(p["compressor"])
+    tb.set_minimal_target_depth(p.get("mindepth", 0))
+    tb.set_minimal_source_depth(p.get("mindepth", 0))
+    H = tb.build(native_inv_dist_generator(x, x, 1e-5, 1.0), T, T, p.get("rank", -1), p.get("rank", -1))
+    tab = np.asarray(H.leaf_table())
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(tab[:, [0, 1, 2, 3, 5]].astype(np.int32)).tobytes()).digest(), dtype=np.uint8)
+    assert np.array_equal(sha, g["structure_sha256"])
+    assert np.array_equal(tab[:, 4].astype(np.int64), g["ranks"].astype(np.int64))
+    y = np.zeros(H.nb_rows())
+    hm.internal_add_hmatrix_vector_product("N", 1.0, H, hashed_vector(n, 1), 0.0, y)
+    assert rel_err(y[g["rows"]], g["yN_a1b0"]) < 1e-10

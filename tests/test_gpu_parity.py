@@ -807,3 +807,44 @@ def test_user_admissibility_condition_end_to_end():
     y2 = np.zeros(p["n"])
     hm.internal_add_hmatrix_vector_product("N", 1.0, H2, x, 0.0, y2)
     assert rel_err(y2, A @ x) < p["eps"]
+
+
+@pytest.mark.parametrize("name,trans,mu", [("ellipse_n4000_p4_rank2", "T", 1), ("ellipse_n3000_symL_default", "N", 16), ("ball_n2000_partial", "T", 5), ("ball_n2000_p2_symL_rank1", "T", 3)])
+def test_prepare_builds_the_second_layouts_so_that_products_allocate_nothing(name, trans, mu):
+    """hmx_hmatrix_prepare(trans, mu): the transposed stream layout / the expanded view of a compact symmetric operator, work vectors and
+    staging buffers exist BEFORE the first such product; hmx_device_alloc_count does not move inside any product call afterwards, and
+    hmx_stats reports what the extra layouts hold."""
+    import torch
+    p = params(name)
+    T, S, H = build_engine(p)
+    L = hm.lib()
+    assert H.stats()["transposed_bytes"] == 0 and H.stats()["expanded_bytes"] == 0
+    H.prepare(trans, mu)
+    st = H.stats()
+    if trans == "T" and not (p["sym"] == "S" and p["rank"] < 0):
+        assert st["transposed_bytes"] > 0
+    if p["sym"] == "S" and mu > 1 and trans == "N":
+        assert st["expanded_bytes"] > 0
+    nin, nout = (H.nb_cols(), H.nb_rows()) if trans == "N" else (H.nb_rows(), H.nb_cols())
+    rng = np.random.default_rng(0)
+    X = torch.from_numpy(rng.standard_normal((nin, mu))).cuda()
+    Y = torch.zeros((nout, mu), dtype=torch.float64).cuda()
+    x, y = X[:, 0].contiguous(), torch.zeros(nout, dtype=torch.float64).cuda()
+    before = L.hmx_device_alloc_count()
+    for _ in range(2):
+        if mu > 1:
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.0, H, X, 0.0, Y, mu)
+        else:
+            hm.internal_add_hmatrix_vector_product(trans, 1.0, H, x, 0.0, y)
+    torch.cuda.synchronize()
+    assert L.hmx_device_alloc_count() == before, "a product allocated device memory after hmx_hmatrix_prepare"
+    # and the prepared product is the product: against the unprepared operator
+    T2, S2, H2 = build_engine(p)
+    if mu > 1:
+        Y2 = torch.zeros_like(Y)
+        hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.0, H2, X, 0.0, Y2, mu)
+        assert torch.equal(Y, Y2)
+    else:
+        y2 = torch.zeros_like(y)
+        hm.internal_add_hmatrix_vector_product(trans, 1.0, H2, x, 0.0, y2)
+        assert torch.equal(y, y2)
