@@ -5,7 +5,7 @@ Only the hot path lives here: csrc/ holds the HIP kernels 
 operator interface over that ABI; distributed.py is the row-partitioned DistributedOperator.
 """
 from ._lib import HmxError, lib  # noqa: F401
-from .api import (ClusterTreeBuilder, Cluster, HMatrixTreeBuilder, HMatrix, InvDistGenerator, VirtualGenerator, NativeGenerator,  # noqa: F401
+from .api import (ClusterTreeBuilder, Cluster, HMatrixTreeBuilder, HMatrix, InvDistGenerator, HelmholtzGenerator, LaplaceGenerator, VirtualGenerator, NativeGenerator,  # noqa: F401
                   add_hmatrix_vector_product, internal_add_hmatrix_vector_product,
                   internal_add_hmatrix_matrix_product_row_major, add_hmatrix_matrix_product, create_geometry,
                   save_cluster_tree, read_cluster_tree, save_leaves_with_rank, matrix_to_bytes, bytes_to_matrix, trim_device_cache,

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("HMX_LIB_PATH") or os.path.join(_HERE, "libhmx.so")  #
 
 HMX_MEM_HOST, HMX_MEM_DEVICE = 0, 1
 HMX_PREC_F64, HMX_PREC_F32, HMX_PREC_Z64, HMX_PREC_C32 = 0, 1, 2, 3
+HMX_KERNEL_INV_DIST, HMX_KERNEL_HELMHOLTZ, HMX_KERNEL_LAPLACE_SL = 0, 1, 2
 HMX_NUMBERING_PARTITION, HMX_NUMBERING_USER = 0, 1
 COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
 DIRECTIONS = {"largest_extent": 0, "bounding_box": 1}

@@ -231,6 +231,39 @@ class InvDistGenerator:
         self.delta, self.scale = float(delta), float(scale)
         self.cre, self.cim, self.hermitian = float(cre), float(cim), bool(hermitian)
 
+    kernel = _lib.HMX_KERNEL_INV_DIST
+
+    def kernel_params(self):
+        return [self.delta, self.scale, self.cre, self.cim, float(self.hermitian)]
+
+
+class HelmholtzGenerator(InvDistGenerator):
+    """Device-evaluable VirtualGenerator: K(x,y) = exp(i k |x - y|) / (delta + scale * |x - y|) -- the Helmholtz single layer
+    exp(i k r) / (4 pi r) for delta = 0, scale = 4 pi (hmx.h: HMX_KERNEL_HELMHOLTZ).  Complex symmetric; with real coefficient
+    types the real part cos(k r) / (...)."""
+
+    kernel = _lib.HMX_KERNEL_HELMHOLTZ
+
+    def __init__(self, spatial_dimension, target_coordinates, source_coordinates, wavenumber, delta=0.0, scale=4.0 * np.pi):
+        super().__init__(spatial_dimension, target_coordinates, source_coordinates, delta, scale)
+        self.wavenumber = float(wavenumber)
+
+    def kernel_params(self):
+        return [self.delta, self.scale, self.wavenumber]
+
+
+class LaplaceGenerator(InvDistGenerator):
+    """Device-evaluable VirtualGenerator: K(x,y) = (cre + i cim) / (4 pi (delta + |x - y|)) -- the Laplace single layer 1 / (4 pi r)
+    for delta = 0 (hmx.h: HMX_KERNEL_LAPLACE_SL)."""
+
+    kernel = _lib.HMX_KERNEL_LAPLACE_SL
+
+    def __init__(self, spatial_dimension, target_coordinates, source_coordinates, delta=0.0, cre=1.0, cim=0.0):
+        super().__init__(spatial_dimension, target_coordinates, source_coordinates, delta, 1.0, cre, cim)
+
+    def kernel_params(self):
+        return [self.delta, self.cre, self.cim]
+
 
 class VirtualGenerator:
     """User-defined generator, mirror of htool's VirtualGenerator (hmatrix/interfaces/virtual_generator.hpp:17-31):
@@ -644,10 +677,10 @@ class HMatrixTreeBuilder:
             check(lib().hmx_hmatrix_set_callback_threads(h, 0 if generator.parallel else 1))
         elif generator is not None:
             if not isinstance(generator, InvDistGenerator):
-                raise HmxError("generator must be an InvDistGenerator (evaluated on the device) or a VirtualGenerator "
-                               "subclass (evaluated on the host through a callback)")
-            params = np.array([generator.delta, generator.scale, generator.cre, generator.cim, float(generator.hermitian)], dtype=np.float64)
-            check(lib().hmx_hmatrix_set_kernel(h, 0, _dp(params), 5, generator.dim, _dp(generator.xt), _dp(generator.xs)))
+                raise HmxError("generator must be an InvDistGenerator / HelmholtzGenerator / LaplaceGenerator (evaluated on the device), a "
+                               "VirtualGenerator subclass or a NativeGenerator (evaluated on the host through a callback)")
+            params = np.array(generator.kernel_params(), dtype=np.float64)
+            check(lib().hmx_hmatrix_set_kernel(h, generator.kernel, _dp(params), len(params), generator.dim, _dp(generator.xt), _dp(generator.xs)))
         H._build_walltimes = dict(block_tree=t_bt, create=t_create)
         if compress:
             t_c = time.perf_counter()

@@ -1646,13 +1646,18 @@ int api_set_callback_threads(HMat *H, int threads) {
     return HMX_OK;
 }
 int api_set_kernel(HMat *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc) {
-    if (!H || !params || !tc || !sc || kernel != HMX_KERNEL_INV_DIST || nparams < 2 || (dim != 2 && dim != 3)) {
-        set_error("hmx_hmatrix_set_kernel: invalid arguments");
+    const int need_params = kernel == HMX_KERNEL_INV_DIST ? 2 : (kernel == HMX_KERNEL_HELMHOLTZ ? 3 : (kernel == HMX_KERNEL_LAPLACE_SL ? 1 : 1 << 30));
+    if (!H || !params || !tc || !sc || nparams < need_params || (dim != 2 && dim != 3)) {
+        set_error("hmx_hmatrix_set_kernel: invalid arguments (unknown kernel, too few parameters, or a dimension other than 2 / 3)");
         return HMX_ERR_INVALID;
     }
     HMX_HIP(hipSetDevice(H->device));
-    // params: delta, scale [, cre, cim, hermitian] -- the last three only matter for complex coefficients
-    H->ks = KernelSpec{kernel, dim, params[0], params[1], nparams > 2 ? params[2] : 1.0, nparams > 3 ? params[3] : 0.0, (nparams > 4 && params[4] != 0.0) ? 1 : 0};
+    if (kernel == HMX_KERNEL_INV_DIST) // params: delta, scale [, cre, cim, hermitian] -- the last three only matter for complex coefficients
+        H->ks = KernelSpec{KS_INV_DIST, dim, params[0], params[1], nparams > 2 ? params[2] : 1.0, nparams > 3 ? params[3] : 0.0, (nparams > 4 && params[4] != 0.0) ? 1 : 0, 0.0};
+    else if (kernel == HMX_KERNEL_HELMHOLTZ) // params: delta, scale, wavenumber
+        H->ks = KernelSpec{KS_HELMHOLTZ, dim, params[0], params[1], 1.0, 0.0, 0, params[2]};
+    else // HMX_KERNEL_LAPLACE_SL: delta [, cre, cim]
+        H->ks = KernelSpec{KS_LAPLACE_SL, dim, params[0], 1.0, nparams > 1 ? params[1] : 1.0, nparams > 2 ? params[2] : 0.0, 0, 0.0};
     // coordinates permuted once into cluster order so block rows / columns are contiguous
     auto soa = [&](const double *xyz, const std::vector<int32_t> &perm, DArr<double> &X, DArr<double> &Y, DArr<double> &Zc) -> hipError_t {
         const size_t n = perm.size();
@@ -3031,7 +3036,7 @@ int api_finalize(HMat *Hp) {
     HMX_HIP(H.d_staged_off.upload(staged));
     H.staged_off = staged;
     if (!H.has_kernel) { // pack_dense never evaluates the generator on this path, but needs valid pointers
-        H.ks = KernelSpec{0, 3, 0, 0, 1, 0, 0};
+        H.ks = KernelSpec{0, 3, 0, 0, 1, 0, 0, 0};
     }
     return build_streams(H);
 }

@@ -19,16 +19,36 @@ __device__ __forceinline__ V wave_sum_any(V v) {
     return v;
 }
 
-// generator entry in coefficient precision (real: 1/den; complex: (cre + i cim sgn)/den, component-wise division as
-// std::complex<double> / double does)
+// generator entry in coefficient precision.  KS_INV_DIST: real 1/den; complex (cre + i cim sgn)/den, component-wise division as
+// std::complex<double> / double does.  KS_HELMHOLTZ: exp(i k r) / (p0 + p1 r) (real types: its real part).  KS_LAPLACE_SL:
+// (cre [+ i cim]) / (4 pi (p0 + r)).
 __device__ __forceinline__ scalar eval_scalar(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
+    if (ks.kind == KS_INV_DIST) {
 #if HMX_COMPLEX
-    const double den = eval_kernel_den(ks, tx, ty, tz, sx, sy, sz);
-    const double u   = tx - sx;
-    const double sgn = ks.herm ? (u > 0 ? 1.0 : (u < 0 ? -1.0 : 0.0)) : 1.0;
-    return scalar((real)(ks.cre / den), (real)((ks.cim * sgn) / den));
+        const double den = eval_kernel_den(ks, tx, ty, tz, sx, sy, sz);
+        const double u   = tx - sx;
+        const double sgn = ks.herm ? (u > 0 ? 1.0 : (u < 0 ? -1.0 : 0.0)) : 1.0;
+        return scalar((real)(ks.cre / den), (real)((ks.cim * sgn) / den));
 #else
-    return (scalar)eval_kernel(ks, tx, ty, tz, sx, sy, sz);
+        return (scalar)eval_kernel(ks, tx, ty, tz, sx, sy, sz);
+#endif
+    }
+    const double r = sqrt(eval_dist2(ks, tx, ty, tz, sx, sy, sz));
+    if (ks.kind == KS_HELMHOLTZ) {
+        const double den = ks.p0 + ks.p1 * r;
+        double sn, cs;
+        hmx_sincos(ks.wavenumber * r, sn, cs);
+#if HMX_COMPLEX
+        return scalar((real)(cs / den), (real)(sn / den));
+#else
+        return (scalar)(cs / den);
+#endif
+    }
+    const double den = HMX_FOUR_PI * (ks.p0 + r); // KS_LAPLACE_SL
+#if HMX_COMPLEX
+    return scalar((real)(ks.cre / den), (real)(ks.cim / den));
+#else
+    return (scalar)(ks.cre / den);
 #endif
 }
 

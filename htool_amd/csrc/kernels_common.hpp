@@ -34,7 +34,9 @@ struct CbResult {
     int32_t pad;
 };
 
-struct KernelSpec { // device-evaluable generator
+// device-evaluable generator families (include/hmx.h: hmx_kernel)
+enum { KS_INV_DIST = 0, KS_HELMHOLTZ = 1, KS_LAPLACE_SL = 2 };
+struct KernelSpec {
     int kind;
     int dim;
     double p0, p1;
@@ -42,11 +44,12 @@ struct KernelSpec { // device-evaluable generator
     // (the complex symmetric / Hermitian forms of testing/generator_test.hpp:163-205)
     double cre, cim;
     int herm;
+    double wavenumber; // KS_HELMHOLTZ
 };
 
-// K(x,y) = 1/(p0 + p1*|x-y|); squared differences accumulated left to right from 0, one sqrt, one
-// multiply, one add, one divide -- the order of examples/use_hmatrix.cpp:33 / testing/generator_test.hpp:159.
-__device__ __forceinline__ double eval_kernel(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
+// |x - y|^2: squared differences accumulated left to right from 0 -- the order of examples/use_hmatrix.cpp:33 /
+// testing/generator_test.hpp:159
+__device__ __forceinline__ double eval_dist2(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
     double s        = 0.0;
     const double d0 = tx - sx;
     s               = s + d0 * d0;
@@ -56,22 +59,38 @@ __device__ __forceinline__ double eval_kernel(const KernelSpec &ks, double tx, d
         const double d2 = tz - sz;
         s               = s + d2 * d2;
     }
-    return 1.0 / (ks.p0 + ks.p1 * sqrt(s));
+    return s;
 }
-
+// K(x,y) = 1/(p0 + p1*|x-y|): one sqrt, one multiply, one add, one divide
+__device__ __forceinline__ double eval_kernel(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
+    return 1.0 / (ks.p0 + ks.p1 * sqrt(eval_dist2(ks, tx, ty, tz, sx, sy, sz)));
+}
 // the denominator of the same family, for the complex instantiations
 __device__ __forceinline__ double eval_kernel_den(const KernelSpec &ks, double tx, double ty, double tz, double sx, double sy, double sz) {
-    double s        = 0.0;
-    const double d0 = tx - sx;
-    s               = s + d0 * d0;
-    const double d1 = ty - sy;
-    s               = s + d1 * d1;
-    if (ks.dim == 3) {
-        const double d2 = tz - sz;
-        s               = s + d2 * d2;
-    }
-    return ks.p0 + ks.p1 * sqrt(s);
+    return ks.p0 + ks.p1 * sqrt(eval_dist2(ks, tx, ty, tz, sx, sy, sz));
 }
+
+// sin and cos of the Helmholtz phase k r, written out (IEEE operations in a fixed order, no contraction) so that a host generator
+// restating it (a user's own code, the test fixtures' reference driver) produces the same bits: x = n pi/2 + r by a three-constant Cody-Waite reduction
+// (33-bit pieces of pi/2: n * piece is exact for |n| < 2^20, i.e. |x| < 1.6e6), then the classical minimax polynomials of sin and cos
+// on [-pi/4, pi/4] (the coefficients of fdlibm's __kernel_sin / __kernel_cos).  About one ulp; no table, no large-argument path, no
+// scratch memory -- the vendor's sincos carries a Payne-Hanek path whose registers every thread of aca_kernel would pay for.
+__host__ __device__ __forceinline__ void hmx_sincos(double x, double &sn, double &cs) {
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    double r        = x - fn * 1.57079632673412561417e+00;
+    r               = r - fn * 6.07710050630396597660e-11;
+    r               = r - fn * 2.02226624871116645580e-21;
+    const double z  = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s  = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c  = w + (((1.0 - w) - hz) + z * pc);
+    const int q     = (int)((long long)fn & 3);
+    sn              = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    cs              = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+constexpr double HMX_FOUR_PI = 12.566370614359172; // 4 pi, the nearest double
 
 // ---- complex coefficients: htool's HMatrix<std::complex<T>> ----------------------------------------------------------------
 // Layout-compatible with std::complex<T> / C99 T _Complex (interleaved re, im).  operator* and operator/ are the plain

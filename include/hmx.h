@@ -38,14 +38,23 @@ typedef enum { HMX_SPLIT_REGULAR = 0, HMX_SPLIT_GEOMETRIC = 1 } hmx_splitting;
 /* hmatrix/lrmat/{partialACA,sympartialACA,fullACA,SVD}.hpp */
 typedef enum { HMX_PARTIAL_ACA = 0, HMX_SYMPARTIAL_ACA = 1, HMX_FULL_ACA = 2, HMX_SVD = 3 } hmx_compressor;
 
-/* Device-evaluable generators (the user's VirtualGenerator::copy_submatrix, hmatrix/interfaces/virtual_generator.hpp:24,
- * for the BEM-style kernels the reference ships: examples/use_hmatrix.cpp:33, testing/generator_test.hpp:159,185):
- *   HMX_KERNEL_INV_DIST : K(x,y) = 1 / (params[0] + params[1] * |x - y|)                                  */
-typedef enum { HMX_KERNEL_INV_DIST = 0 } hmx_kernel;
-/* With complex coefficients (hmx_hmatrix_create_z / _c) the same family reads
- *   K(x,y) = (params[2] + i * params[3] * sgn) / (params[0] + params[1] * |x - y|),
- * sgn = 1, or, when params[4] != 0, sign(x_target[0] - x_source[0]): the complex symmetric and Hermitian test generators
- * of testing/generator_test.hpp:163-205 (GeneratorTestComplex, ...ComplexSymmetric, ...ComplexHermitian). */
+/* Device-evaluable generators (the user's VirtualGenerator::copy_submatrix, hmatrix/interfaces/virtual_generator.hpp:24, for BEM-style
+ * kernels: the ones the reference ships -- examples/use_hmatrix.cpp:33, testing/generator_test.hpp:159,185 -- and the single-layer kernels
+ * its users bring; r = |x - y|, squared differences summed in coordinate order).  hmx_hmatrix_set_kernel(H, kernel, params, nparams, ...):
+ *   HMX_KERNEL_INV_DIST   : K = 1 / (params[0] + params[1] * r).  With complex coefficients (hmx_hmatrix_create_z / _c)
+ *                           K = (params[2] + i * params[3] * sgn) / (params[0] + params[1] * r), sgn = 1, or, when params[4] != 0,
+ *                           sign(x_target[0] - x_source[0]): the complex symmetric and Hermitian test generators of
+ *                           testing/generator_test.hpp:163-205 (GeneratorTestComplex, ...ComplexSymmetric, ...ComplexHermitian).
+ *   HMX_KERNEL_HELMHOLTZ  : K = exp(i * k * r) / (params[0] + params[1] * r), k = params[2] -- the Helmholtz single layer
+ *                           exp(i k r) / (4 pi r) for params = {0, 4 pi, k} (distinct target and source clouds; a small params[0] regularises
+ *                           coincident points as the reference's test generators do).  Complex symmetric ('S' storage).  Real coefficient
+ *                           types take the real part cos(k r) / (...).  cos / sin are evaluated by a fixed, documented sequence of IEEE
+ *                           operations (Cody-Waite reduction + minimax polynomials, about one ulp for |k r| < 1.6e6: csrc/kernels_common.hpp
+ *                           hmx_sincos), so that a host generator restating it produces the same bits.
+ *   HMX_KERNEL_LAPLACE_SL : K = (params[1] + i * params[2]) / (4 pi * (params[0] + r)), defaults params[1] = 1, params[2] = 0 (the imaginary
+ *                           part only with complex coefficients): the Laplace single layer 1 / (4 pi r) for params[0] = 0.
+ * Anything else goes through hmx_hmatrix_set_callback (the generator on the host's cores, everything else on the device). */
+typedef enum { HMX_KERNEL_INV_DIST = 0, HMX_KERNEL_HELMHOLTZ = 1, HMX_KERNEL_LAPLACE_SL = 2 } hmx_kernel;
 
 /* coefficient type of an hmx_hmatrix: htool's HMatrix<double>, <float>, <std::complex<double>>, <std::complex<float>>
  * (coordinates are fp64 in all four).  Complex values cross this ABI as interleaved (re, im) pairs, the layout of

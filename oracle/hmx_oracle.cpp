@@ -578,6 +578,28 @@ static std::unique_ptr<ClusterTree> create_cluster_tree(int n, int dim, const do
 } // namespace orc
 
 namespace orc {
+// kernel family of the generators built from now on (orc_set_kernel_family; include/hmx.h hmx_kernel) and the sin / cos of the Helmholtz
+// phase: the device kernel's documented IEEE sequence restated (three-constant Cody-Waite reduction, minimax polynomials with fdlibm's
+// coefficients; htool_amd/csrc/kernels_common.hpp hmx_sincos describes it) -- same operations in the same order give the same bits
+static int g_family         = 0;
+static double g_wavenumber = 0;
+static inline int orc_kernel_family() { return g_family; }
+static inline double orc_kernel_wavenumber() { return g_wavenumber; }
+static inline void orc_sincos(double x, double &sn, double &cs) {
+    const double fn = std::rint(x * 6.36619772367581382433e-01);
+    double r        = x - fn * 1.57079632673412561417e+00;
+    r               = r - fn * 6.07710050630396597660e-11;
+    r               = r - fn * 2.02226624871116645580e-21;
+    const double z  = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s  = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c  = w + (((1.0 - w) - hz) + z * pc);
+    const int q     = (int)((long long)fn & 3);
+    sn              = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    cs              = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
 #define ORC_COMPLEX 0
 namespace f64 {
 using real   = double;
@@ -822,6 +844,11 @@ int orc_compress_block(void *tct, void *sct, int dim, const double *xt, const do
 }
 
 // Dense generator block in cluster numbering (column-major), for dense references in tests
+// kernel family of every generator constructed afterwards: 0 inverse distance, 1 Helmholtz (wavenumber), 2 Laplace single layer
+void orc_set_kernel_family(int family, double wavenumber) {
+    orc::g_family     = family;
+    orc::g_wavenumber = wavenumber;
+}
 void orc_generate_block(void *tct, void *sct, int dim, const double *xt, const double *xs, double delta, double scale, int M, int N, int row_off, int col_off, double *out) {
     auto *T = static_cast<ClusterTree *>(tct);
     auto *S = static_cast<ClusterTree *>(sct);

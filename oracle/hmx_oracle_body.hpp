@@ -16,6 +16,18 @@ struct Generator {
     // testing/generator_test.hpp:163-170,189-196) or sign(x_t[0] - x_s[0]) (Hermitian form, :198-205)
     double cre = 1, cim = 0;
     int hermitian = 0;
+    // kernel family (include/hmx.h hmx_kernel): 0 the inverse distance above; 1 Helmholtz exp(i k r) / (delta + scale r) (real types:
+    // its real part); 2 Laplace single layer (cre + i cim) / (4 pi (delta + r)).  Taken from orc_set_kernel_family at construction.
+    int family        = orc_kernel_family();
+    double wavenumber = orc_kernel_wavenumber();
+    inline double distance(int i, int j) const {
+        double s = 0;
+        for (int p = 0; p < dim; p++) {
+            double d = xt[dim * i + p] - xs[dim * j + p];
+            s        = s + d * d;
+        }
+        return std::sqrt(s);
+    }
     inline double denominator(int i, int j) const { // user numbering
         double s = 0;
         for (int p = 0; p < dim; p++) {
@@ -25,6 +37,24 @@ struct Generator {
         return delta + scale * std::sqrt(s);
     }
     inline scalar value(int i, int j) const {
+        if (family == 1) {
+            const double r = distance(i, j), den = delta + scale * r;
+            double sn, cs;
+            orc_sincos(wavenumber * r, sn, cs);
+#if ORC_COMPLEX
+            return scalar((real)(cs / den), (real)(sn / den));
+#else
+            return (scalar)(cs / den);
+#endif
+        }
+        if (family == 2) {
+            const double den = 12.566370614359172 * (delta + distance(i, j));
+#if ORC_COMPLEX
+            return scalar((real)(cre / den), (real)(cim / den));
+#else
+            return (scalar)(cre / den);
+#endif
+        }
 #if ORC_COMPLEX
         const double u   = xt[dim * i] - xs[dim * j];
         const double sgn = hermitian ? (u > 0 ? 1. : (u < 0 ? -1. : 0.)) : 1.;

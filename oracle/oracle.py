@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+KERNELS = {"invdist": 0, "helmholtz": 1, "laplace": 2}  # include/hmx.h hmx_kernel
 COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
 PARTITIONINGS = {  # name -> (direction, splitting, partition_n)
     "pca_regular": (0, 0, 0),
@@ -47,6 +48,8 @@ def lib():
         L.orc_cluster_num_partitions.argtypes = [C.c_void_p]
         L.orc_cluster_get.argtypes = [C.c_void_p, ip, ip, dp, ip]
         L.orc_geometry.argtypes = [C.c_char_p, C.c_int, C.c_double, dp]
+        L.orc_set_kernel_family.argtypes = [C.c_int, C.c_double]
+        L.orc_set_kernel_family.restype = None
         L.orc_hmatrix_build.restype = C.c_void_p
         L.orc_hmatrix_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -128,7 +131,8 @@ class HMatrix:
     """Oracle H-matrix: block tree + compressed leaves + reference-order leaf loop."""
 
     def __init__(self, tct, sct, delta=1e-5, scale=1.0, eps=1e-4, eta=10.0, sym="N", uplo="N", reqrank=-1,
-                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, f32=False, root_partition=-1, _handle=None):
+                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, f32=False, root_partition=-1, _handle=None,
+                 kernel="invdist", wavenumber=0.0):
         """f32=True: htool's HMatrix<float,double> -- fp32 coefficients and arithmetic, fp64 geometry.  Values cross
         this Python boundary as float64 in both cases (converted inside the library)."""
         if _handle is not None:
@@ -136,10 +140,12 @@ class HMatrix:
             self._keep = ()
         else:
             self._keep = (tct, sct)
+            lib().orc_set_kernel_family(KERNELS[kernel], float(wavenumber))  # read by the generator this build constructs
             self.h = lib().orc_hmatrix_build(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta,
                                              scale, eps, eta, sym.encode(), uplo.encode(), reqrank,
                                              COMPRESSORS[compressor], mindepth, mindepth, rank, rank, int(consistent),
                                              int(parallel), int(f32), root_partition)
+            lib().orc_set_kernel_family(0, 0.0)
         n = lib().orc_hmatrix_num_leaves(self.h)
         self.leaves = np.empty((n, 6), dtype=np.int32)
         self.leaves_dfs = np.empty((n, 6), dtype=np.int32)
@@ -216,11 +222,14 @@ class ZHMatrix:
     Values cross this boundary as complex128 (c32=True computes in complex<float> inside)."""
 
     def __init__(self, tct, sct, delta=1e-5, scale=1.0, cre=1.0, cim=1.0, eps=1e-4, eta=10.0, sym="N", uplo="N", reqrank=-1,
-                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, c32=False, root_partition=-1):
+                 compressor="partialACA", mindepth=0, rank=-1, consistent=True, parallel=False, c32=False, root_partition=-1,
+                 kernel="invdist", wavenumber=0.0):
         self._keep = (tct, sct)
+        lib().orc_set_kernel_family(KERNELS[kernel], float(wavenumber))
         self.h = lib().orc_zhmatrix_build(tct.h, sct.h, tct.coords.shape[1], _dp(tct.coords), _dp(sct.coords), delta, scale,
                                           cre, cim, eps, eta, sym.encode(), uplo.encode(), reqrank, COMPRESSORS[compressor],
                                           mindepth, mindepth, rank, rank, int(consistent), int(parallel), int(c32), root_partition)
+        lib().orc_set_kernel_family(0, 0.0)
         n = lib().orc_zhmatrix_num_leaves(self.h)
         self.leaves = np.empty((n, 6), dtype=np.int32)
         self.leaves_dfs = np.empty((n, 6), dtype=np.int32)

@@ -128,6 +128,28 @@ static T make_value(double re, double im) {
 // Kernel family K(x,y) = 1 / (delta + scale * |x-y|), evaluated with the same operation order as the
 // reference's own generators (examples/use_hmatrix.cpp:33, testing/generator_test.hpp:159,185):
 // squared differences accumulated left to right from 0, one sqrt, one multiply, one add, one divide.
+// Two more families (kernel=helmholtz, kernel=laplace: include/hmx.h HMX_KERNEL_HELMHOLTZ / HMX_KERNEL_LAPLACE_SL), written as a user would
+// write them on top of the same distance: exp(i k r) / (delta + scale r) and (cre + i cim) / (4 pi (delta + r)).  sin / cos of the phase are
+// the documented IEEE sequence of the device kernel (Cody-Waite reduction with three 33-bit pieces of pi/2, minimax polynomials with
+// fdlibm's coefficients), restated here so that both sides produce the same bits (compiled with -ffp-contract=off).
+static inline void ref_sincos(double x, double &sn, double &cs) {
+    const double fn = std::rint(x * 6.36619772367581382433e-01);
+    double r        = x - fn * 1.57079632673412561417e+00;
+    r               = r - fn * 6.07710050630396597660e-11;
+    r               = r - fn * 2.02226624871116645580e-21;
+    const double z  = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s  = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c  = w + (((1.0 - w) - hz) + z * pc);
+    const int q     = (int)((long long)fn & 3);
+    sn              = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    cs              = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+static int g_kernel_family  = 0; // 0: inverse distance, 1: Helmholtz, 2: Laplace single layer (set from the command line: kernel=...)
+static double g_wavenumber = 0;
+
 template <typename T>
 class InvDistGenerator : public VirtualGenerator<T> {
     int m_dim;
@@ -149,9 +171,29 @@ class InvDistGenerator : public VirtualGenerator<T> {
         return m_delta + m_scale * std::sqrt(s);
     }
     double get_coef(int i, int j) const { return 1. / denominator(i, j); }
+    double distance(int i, int j) const {
+        double s = 0;
+        for (int p = 0; p < m_dim; p++) {
+            double d = m_xt[m_dim * i + p] - m_xs[m_dim * j + p];
+            s        = s + d * d;
+        }
+        return std::sqrt(s);
+    }
     void copy_submatrix(int M, int N, const int *rows, const int *cols, T *ptr) const override {
         for (int j = 0; j < M; j++)
             for (int k = 0; k < N; k++) {
+                if (g_kernel_family == 1) { // exp(i k r) / (delta + scale r)
+                    const double r = distance(rows[j], cols[k]), den = m_delta + m_scale * r;
+                    double sn, cs;
+                    ref_sincos(g_wavenumber * r, sn, cs);
+                    ptr[j + (size_t)M * k] = make_value<T>(cs / den, sn / den);
+                    continue;
+                }
+                if (g_kernel_family == 2) { // (cre + i cim) / (4 pi (delta + r))
+                    const double den       = 12.566370614359172 * (m_delta + distance(rows[j], cols[k]));
+                    ptr[j + (size_t)M * k] = make_value<T>(m_cre / den, m_cim / den);
+                    continue;
+                }
                 if constexpr (is_cplx<T>::value) {
                     const double u   = m_xt[m_dim * rows[j]] - m_xs[m_dim * cols[k]];
                     const double sgn = m_hermitian ? (u > 0 ? 1. : (u < 0 ? -1. : 0.)) : 1.;
@@ -267,6 +309,9 @@ static int run_hmat(std::map<std::string, std::string> &kv) {
     std::string comp      = gets(kv, "compressor", "partialACA");
     double delta          = getd(kv, "delta", 1e-5);
     double scale          = getd(kv, "scale", 1.);
+    const std::string kernel_name = gets(kv, "kernel", "invdist");
+    g_kernel_family               = kernel_name == "helmholtz" ? 1 : (kernel_name == "laplace" ? 2 : 0);
+    g_wavenumber                  = getd(kv, "wavenumber", 0.);
     int mindepth          = geti(kv, "mindepth", 0);
     int rank              = geti(kv, "rank", -1); // target_partition_number (and symmetry partition)
     int reqrank           = geti(kv, "reqrank", -1);

@@ -79,6 +79,12 @@ CASES = {
     "ball_n1200_z64_SVD": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, compressor="SVD", prec="z64", dump_blocks=1)),
     "ball_n2000_z64_hermU_recompressed": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-4, sym="H", uplo="U", compressor="sympartialACA", prec="z64", recompress=1, dump_blocks=1)),
     "ellipse_n3000_c32_recompressed": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, compressor="partialACA", prec="c32", recompress=1, dump_blocks=1)),
+    # the other device kernel families (include/hmx.h: HMX_KERNEL_HELMHOLTZ exp(i k r) / (delta + scale r), HMX_KERNEL_LAPLACE_SL
+    # 1 / (4 pi (delta + r))), written as user generators in oracle/ref/ref_driver.cpp (kernel=..., wavenumber=...)
+    "ball_n2000_z64_helmholtz": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-4, compressor="partialACA", prec="z64", kernel="helmholtz", wavenumber=5.0, delta=1e-5, scale=12.566370614359172, dump_blocks=2)),
+    "ellipse_n3000_z64_helmholtz_symL": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, sym="S", uplo="L", compressor="sympartialACA", prec="z64", kernel="helmholtz", wavenumber=3.0, delta=1e-5, scale=12.566370614359172, dump_blocks=2)),
+    "ellipse_n3000_helmholtz_real_symL": ("hmat", dict(n=3000, geom="ellipse", leaf=100, eps=1e-4, sym="S", uplo="L", compressor="sympartialACA", kernel="helmholtz", wavenumber=2.0, delta=1e-5, scale=12.566370614359172, dump_blocks=2)),
+    "ball_n2000_laplace": ("hmat", dict(n=2000, geom="ball", leaf=50, eps=1e-4, compressor="partialACA", kernel="laplace", delta=1e-5, dump_blocks=2)),
     "ball_n1200_z64_reqrank5": ("hmat", dict(n=1200, geom="ball", leaf=50, eps=1e-4, reqrank=5, compressor="partialACA", prec="z64", dump_blocks=1)),
     # block-diagonal (local-to-local) operator rooted at the partition clusters: DefaultLocalApproximationBuilder
     "ellipse_n4000_p4_local2": ("hmat", dict(n=4000, geom="ellipse", leaf=100, partitions=4, local=2, eps=1e-4, compressor="partialACA", dump_blocks=1)),

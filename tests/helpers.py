@@ -17,7 +17,8 @@ LRMAT_CASES = sorted(k for k, v in MANIFEST.items() if v["mode"] == "lrmat")
 
 DEFAULTS = dict(nsrc=0, geom="ellipse", sz=0.0, leaf=100, children=2, partitions=2, partitioning="pca_regular", eps=1e-4,
                 eta=10.0, sym="N", uplo="N", compressor="partialACA", delta=1e-5, scale=1.0, mindepth=0, rank=-1,
-                reqrank=-1, alpha=3.0, beta=2.0, consistent=1, prec="f64", local=-1, recompress=0, cre=1.0, cim=1.0, given="none", complete=0)
+                reqrank=-1, alpha=3.0, beta=2.0, consistent=1, prec="f64", local=-1, recompress=0, cre=1.0, cim=1.0, given="none", complete=0,
+                kernel="invdist", wavenumber=0.0)
 
 
 def load(name):
@@ -32,6 +33,19 @@ def params(name):
     if p["compressor"] == "default":  # hmatrix/tree_builder/tree_builder.hpp:384-386
         p["compressor"] = "sympartialACA"
     return p
+
+
+def device_generator(p, T, S):
+    """The fixture's generator as the device-evaluable family it belongs to (include/hmx.h hmx_kernel)."""
+    import htool_amd as hm
+    cplx = p["prec"] in ("z64", "c32")
+    if p["kernel"] == "helmholtz":
+        return hm.HelmholtzGenerator(p["dim"], T.coordinates, S.coordinates, p["wavenumber"], p["delta"], p["scale"])
+    if p["kernel"] == "laplace":
+        return hm.LaplaceGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["cre"], p["cim"] if cplx else 0.0)
+    if cplx:
+        return hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], p["sym"] == "H")
+    return hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"])
 
 
 def rel_err(a, b):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import htool_amd as hm
-from helpers import Z_CASES, load, params, rel_err
+from helpers import Z_CASES, device_generator, load, params, rel_err
 from test_host_structure import build_trees
 
 pytestmark = pytest.mark.gpu
@@ -19,7 +19,7 @@ def build_zengine(p, compress=True, generator=True, dtype=None):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
     tb.set_low_rank_generator(p["compressor"])
-    gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], p["sym"] == "H") if generator else None
+    gen = device_generator(p, T, S) if generator else None
     dt = dtype or (np.complex64 if p["prec"] == "c32" else np.complex128)
     H = tb.build(gen, T, S, p["rank"], p["rank"], compress=compress, dtype=dt)
     if compress and p["recompress"]:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import htool_amd as hm
-from helpers import load, native_inv_dist_generator, params, rel_err
+from helpers import device_generator, load, native_inv_dist_generator, params, rel_err
 from test_host_structure import build_trees
 
 pytestmark = pytest.mark.gpu
@@ -30,8 +30,7 @@ def both_routes(p, threads):
     T, S = build_trees(p)
     dt = NP[p["prec"]]
     herm = p["sym"] == "H"
-    dev = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], herm) if p["prec"] in ("z64", "c32") else \
-        hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"])
+    dev = device_generator(p, T, S)
     host = native_inv_dist_generator(T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], herm, dtype=dt, threads=threads)
     Hd = builder(p).build(dev, T, S, p["rank"], p["rank"], dtype=dt)
     Hh = builder(p).build(host, T, S, p["rank"], p["rank"], dtype=dt)

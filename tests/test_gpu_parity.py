@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import htool_amd as hm
-from helpers import F32_CASES, HMAT_CASES, load, params, rel_err
+from helpers import F32_CASES, HMAT_CASES, device_generator, load, params, rel_err
 from test_host_structure import build_trees
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +26,7 @@ def build_engine(p, compress=True, generator=True):
     tb.set_minimal_target_depth(p["mindepth"])
     tb.set_minimal_source_depth(p["mindepth"])
     tb.set_block_tree_consistency(bool(p["consistent"]))
-    gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]) if generator else None
+    gen = device_generator(p, T, S) if generator else None
     H = tb.build(gen, T, S, p["rank"], p["rank"], compress=compress, local_partitions=(p["local"], p["local"]) if p["local"] >= 0 else None)
     return T, S, H
 
@@ -375,7 +375,7 @@ def test_fp32_engine_against_reference(name):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
     tb.set_low_rank_generator(p["compressor"])
-    H = tb.build(hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]), T, S, p["rank"], p["rank"], dtype=np.float32)
+    H = tb.build(device_generator(p, T, S), T, S, p["rank"], p["rank"], dtype=np.float32)
     tab, ref = H.leaf_table(), g["leaves"]
     assert np.array_equal(tab[:, :4], ref[:, :4]) and np.array_equal(tab[:, 5], ref[:, 5])
     if p["eps"] >= 1e-4:
@@ -790,7 +790,7 @@ def test_user_admissibility_condition_end_to_end():
         d = np.sqrt(sum((t.center[k] - s.center[k]) ** 2 for k in range(3)))
         return 2 * min(t.radius, s.radius) < eta * max(d - t.radius - s.radius, 0.0)
 
-    gen = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"])
+    gen = device_generator(p, T, S)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
     tb.set_low_rank_generator("partialACA")
     tb.set_admissibility_condition(rs)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import htool_amd as hm
-from helpers import MANIFEST, load, params
+from helpers import MANIFEST, device_generator, load, params
 from test_host_structure import build_trees
 
 IO_CASES = sorted(k for k, v in MANIFEST.items() if v["mode"] == "io")
@@ -93,7 +93,7 @@ def test_save_leaves_with_rank_after_device_compression(name, tmp_path):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
     tb.set_low_rank_generator(p["compressor"])
-    A = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"])
+    A = device_generator(p, T, S)
     H = tb.build(A, T, S, p["rank"], p["rank"])
     hm.save_leaves_with_rank(H, tmp_path / "leaves")
     assert np.array_equal(_bytes(tmp_path / "leaves.csv"), g["leaves"])
@@ -111,7 +111,7 @@ def test_operator_binary_dump_roundtrip(name, dtype, tmp_path):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
     tb.set_low_rank_generator(p["compressor"])
-    A = hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"])
+    A = device_generator(p, T, S)
     H = tb.build(A, T, S, p["rank"], p["rank"], dtype=dtype)
     H.save(tmp_path / "op.hmx")
     G = tb.load(tmp_path / "op.hmx", T, S, p["rank"], p["rank"])
@@ -148,7 +148,7 @@ def test_tree_parameters_and_hmatrix_information(name):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"])
     tb.set_low_rank_generator(p["compressor"])
-    H = tb.build(hm.InvDistGenerator(p["dim"], T.coordinates, S.coordinates, p["delta"], p["scale"]), T, S, p["rank"], p["rank"])
+    H = tb.build(device_generator(p, T, S), T, S, p["rank"], p["rank"])
     out = io.StringIO()
     hm.print_tree_parameters(H, out)
     hm.print_hmatrix_information(H, out)

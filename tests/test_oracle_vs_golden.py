@@ -22,7 +22,7 @@ def build_oracle(name):
         S = O.ClusterTree(xs, p["leaf"], p["children"], p["partitions"], p["partitioning"])
     else:
         S = T
-    H = O.HMatrix(T, S, delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
+    H = O.HMatrix(T, S, kernel=p["kernel"], wavenumber=p["wavenumber"], delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
                   reqrank=p["reqrank"], compressor=p["compressor"], mindepth=p["mindepth"], rank=p["rank"], consistent=bool(p["consistent"]), root_partition=p["local"])
     if p["recompress"]:
         H.recompress(p["eps"])
@@ -138,7 +138,7 @@ def test_fp32_oracle_against_reference(name):
     g, p = load(name), params(name)
     xt = O.geometry(p["geom"], p["n"])
     T = O.ClusterTree(xt, p["leaf"], p["children"], p["partitions"], p["partitioning"])
-    H = O.HMatrix(T, T, delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
+    H = O.HMatrix(T, T, kernel=p["kernel"], wavenumber=p["wavenumber"], delta=p["delta"], scale=p["scale"], eps=p["eps"], eta=p["eta"], sym=p["sym"], uplo=p["uplo"],
                   compressor=p["compressor"], rank=p["rank"], f32=True)
     assert np.array_equal(H.leaves[:, :4], g["leaves"][:, :4]) and np.array_equal(H.leaves[:, 5], g["leaves"][:, 5])
     if p["eps"] >= 1e-4:
@@ -173,7 +173,7 @@ def build_zoracle(name):
     S = T
     if p["nsrc"]:
         S = O.ClusterTree(O.geometry(p["sgeom"], p["nsrc"], p["sz"]), p["leaf"], p["children"], p["partitions"], p["partitioning"])
-    H = O.ZHMatrix(T, S, delta=p["delta"], scale=p["scale"], cre=p["cre"], cim=p["cim"], eps=p["eps"], eta=p["eta"], sym=p["sym"],
+    H = O.ZHMatrix(T, S, kernel=p["kernel"], wavenumber=p["wavenumber"], delta=p["delta"], scale=p["scale"], cre=p["cre"], cim=p["cim"], eps=p["eps"], eta=p["eta"], sym=p["sym"],
                    uplo=p["uplo"], reqrank=p["reqrank"], compressor=p["compressor"], rank=p["rank"], c32=p["prec"] == "c32")
     if p["recompress"]:
         H.recompress(p["eps"])
