@@ -201,7 +201,7 @@ def cpu_baseline(H, T, frac, log):
                        "openmp leaf loop, best of 4" % (cut, len(sel), pos * 8 / 1e9)), y, cut
 
 
-def reference_baseline(log, n, geom, eps, eta, leaf, depth):
+def reference_baseline(log, n, geom, eps, eta, leaf, depth, cores=None):
     """htool ITSELF (oracle/_ref/ref_driver: the real headers + the image's MKL, OpenMP policy: openmp_build +
     openmp_internal_add_hmatrix_vector_product) timed on this box's host cores on THE SAME configuration as the GPU run (geometry,
     N, kernel, eps, eta, leaf size, minimal block depth).  Time-boxed (HMX_BENCH_REF_TIMEOUT seconds, default 240: the N=1e6 build
@@ -213,7 +213,7 @@ def reference_baseline(log, n, geom, eps, eta, leaf, depth):
     if not os.path.exists(exe):
         return None
     budget = float(os.environ.get("HMX_BENCH_REF_TIMEOUT", 240))
-    ncpu = os.cpu_count() or 1
+    ncpu = cores or os.cpu_count() or 1  # the cores the process really has (cgroup quota: hmx_host_cores), not the hardware threads
 
     def run(nn, dd, threads, reps, timeout):
         t0 = time.time()
@@ -231,7 +231,7 @@ def reference_baseline(log, n, geom, eps, eta, leaf, depth):
         best, size = None, n
         t_start = time.time()
         # the reference's per-thread temporaries make "all cores" a poor choice for the product: 64 threads first, then 16 if time is left
-        for threads in [t for t in (64, 16) if t <= ncpu] or [ncpu]:
+        for threads in sorted({min(64, ncpu), min(16, ncpu)}, reverse=True):
             left = budget - (time.time() - t_start)
             if left < (30 if best else 5):
                 break
@@ -244,7 +244,7 @@ def reference_baseline(log, n, geom, eps, eta, leaf, depth):
                 best = r
         if best is None and n > 100000:  # fall back to configs[1]
             size = 100000
-            for threads in [t for t in (64, 16) if t <= ncpu] or [ncpu]:
+            for threads in sorted({min(64, ncpu), min(16, ncpu)}, reverse=True):
                 r = run(size, 0, threads, 10, 120)
                 if r and (best is None or r["matvec_s"] < best["matvec_s"]):
                     best = r
@@ -254,13 +254,13 @@ def reference_baseline(log, n, geom, eps, eta, leaf, depth):
                     sample="htool itself (openmp_internal_add_hmatrix_vector_product, MKL sequential BLAS) on the %s: N=%d %s, eps=%g, eta=%g, leaf %d, "
                            "min block depth %d; best of 5 products" % ("same configuration" if size == n else "configs[1] operator (the N=%d build did not fit the time box)" % n,
                                                                         size, geom, eps, eta, leaf, depth if size == n else 0),
-                    build_s=best["build_s"], matvec_s=best["matvec_s"], n=size)
+                    build_s=best["build_s"], matvec_s=best["matvec_s"], n=size, comparable=bool(size == n))
     except Exception as e:
         log("reference driver failed: %r" % (e,))
         return None
 
 
-def reference_mpi_baseline(log, world, n, geom, eps, eta, leaf, depth):
+def reference_mpi_baseline(log, world, n, geom, eps, eta, leaf, depth, cores=None):
     """htool's own MPI + OpenMP CPU path next to the multi-GPU numbers: oracle/_ref/dist_bench (the real headers + MPICH + MKL,
     built in the dev container) under `mpiexec -n world`, cores / world OpenMP threads per rank, on THE SAME configuration --
     every rank builds its block rows (openmp_build), the product is internal_add_distributed_operator_vector_product_global_to_global
@@ -274,7 +274,7 @@ def reference_mpi_baseline(log, world, n, geom, eps, eta, leaf, depth):
         log("no oracle/_ref/dist_bench or mpiexec here: no reference-mpi baseline")
         return None
     budget = float(os.environ.get("HMX_BENCH_REF_TIMEOUT", 240))
-    threads = max(1, (os.cpu_count() or world) // world)
+    threads = max(1, (cores or os.cpu_count() or world) // world)  # cores: what the process really has (cgroup quota)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "libs") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -739,17 +739,27 @@ def main():
             cb["rel_err_engine_vs_cpu_on_sample"] = err
             out["cpu_baseline"] = cb
             # htool itself on the same configuration: the `cpu_baseline` of kind "reference" when its binary is here; the port stays next to it
-            ref = None if args.no_reference or args.sym != "N" else reference_baseline(log, n, args.geom, args.eps, args.eta, args.leaf, d)
+            ref = None if args.no_reference or args.sym != "N" else reference_baseline(log, n, args.geom, args.eps, args.eta, args.leaf, d, hm.lib().hmx_host_cores())
             if ref is not None:
                 out["cpu_baseline_port"] = cb
                 out["cpu_baseline"] = ref
         except Exception as e:  # the baseline is a reported number, never the product path
             out["cpu_baseline"] = dict(value=None, unit="GB/s", cores=0, kind="port", sample="failed: %r" % (e,))
     if use_dist:
-        dist.destroy_process_group()
+        # the measured result must survive whatever the teardown does: bounded wait, then on regardless
+        import threading
+        th = threading.Thread(target=dist.destroy_process_group, daemon=True)
+        th.start()
+        th.join(60)
+        if th.is_alive():
+            log("destroy_process_group did not return within 60 s: continuing without it")
     if rank == 0 and world > 1 and not args.no_cpu_baseline and not args.no_reference and args.dtype == "f64" and args.sym == "N":
         # next to the multi-GPU numbers: htool's own MPI + OpenMP path on this box's host cores (the other ranks have finished)
-        ref = reference_mpi_baseline(log, world, n, args.geom, args.eps, args.eta, args.leaf, d)
+        try:
+            ref = reference_mpi_baseline(log, world, n, args.geom, args.eps, args.eta, args.leaf, d, hm.lib().hmx_host_cores())
+        except Exception as e:  # noqa: BLE001 -- a reported extra: its failure must not cost the GPU result
+            log("reference-mpi baseline failed: %r" % (e,))
+            ref = None
         if ref is not None:
             out["cpu_baseline"] = ref
     if rank == 0:

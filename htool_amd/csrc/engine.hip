@@ -874,9 +874,11 @@ static int dist_exchange_bounds(hmx_dist &D, int chunks, bool multi, hipStream_t
     const int nb = chunks + 1;
     std::vector<int32_t> mine(nb, 0);
     int n  = 1;
-    int rc = multi ? dist_chunk_bounds_mu(D, chunks, &n, mine.data()) : dist_chunk_bounds(D, chunks, &n, mine.data());
-    if (rc != HMX_OK)
-        return rc;
+    const int rc_local = multi ? dist_chunk_bounds_mu(D, chunks, &n, mine.data()) : dist_chunk_bounds(D, chunks, &n, mine.data());
+    if (rc_local != HMX_OK) { // this rank cannot chunk (e.g. the layout could not be built): it still takes part in the collective below and
+        n = 0;                // reports "no chunks", so that ALL ranks fall back to the single exchange together instead of waiting for it
+        std::fill(mine.begin(), mine.end(), 0);
+    }
     // every rank sends (n, bounds[0..chunks]) as doubles (exact; the mock communicators of the tests only know float types)
     std::vector<double> send(nb + 1, 0.0), recv((size_t)(nb + 1) * D.world, 0.0);
     send[0] = n;
@@ -1061,6 +1063,16 @@ int hmx_dist_add_local_to_local_operator(hmx_dist *D, hmx_hmatrix *diag) {
     if (D->local && hmx_hmatrix_precision(D->local) != prec) {
         set_error("hmx_dist_add_local_to_local_operator: the operators of one DistributedOperator have one coefficient type");
         return HMX_ERR_INVALID;
+    }
+    { // the block-diagonal operator of THIS rank: (target partition rank) x (source partition rank), or its products run out of bounds
+        int32_t r[4] = {0, 0, 0, 0};
+        const int rc = diag->d ? hmx::f64::api_root(diag->d, r) : (diag->s ? hmx::f32::api_root(diag->s, r) : (diag->z ? hmx::z64::api_root(diag->z, r) : hmx::c32::api_root(diag->c, r)));
+        if (rc != HMX_OK || r[0] != D->t_off[D->rank] || r[1] != D->t_size[D->rank] || r[2] != D->s_off[D->rank] || r[3] != D->s_size[D->rank]) {
+            set_error("hmx_dist_add_local_to_local_operator: the operator is not the (target partition, source partition) block of this rank: rows [" + std::to_string(r[0]) + ", +" +
+                      std::to_string(r[1]) + "), columns [" + std::to_string(r[2]) + ", +" + std::to_string(r[3]) + ") against partitions [" + std::to_string(D->t_off[D->rank]) + ", +" +
+                      std::to_string(D->t_size[D->rank]) + ") x [" + std::to_string(D->s_off[D->rank]) + ", +" + std::to_string(D->s_size[D->rank]) + ")");
+            return HMX_ERR_INVALID;
+        }
     }
     D->diag = diag;
     dist_set_precision(*D, prec);

@@ -30,6 +30,7 @@ int api_set_profiling(HMat *H, int enabled);
 int api_last_kernel_times(const HMat *H, int max, const char **names, float *ms);
 int api_prepare(HMat *Hp, char trans, int mu);
 int api_device_of(const HMat *H);   // device the operator lives on
+int api_root(const HMat *H, int32_t *t_off_size_s_off_size);
 void api_destroy(HMat *H);
 // y = w + beta * y on `stream` (the DistributedOperator layer's accumulation of exchanged slices)
 void api_axpby(int64_t n, const scalar *w, scalar beta, scalar *y, hipStream_t st);

@@ -675,6 +675,20 @@ static int build_streams(HMat &H) {
         HMX_HIP(hipGetLastError());
     }
     HMX_HIP(hipEventRecord(e1, 0));
+    // The pack kernels now fill the streams while the host builds the index arrays.  Whatever makes this function return before they
+    // are waited for (a failed upload, an operator the fused symmetric layout cannot hold) must not leave them writing into arrays the
+    // caller is about to release, nor an operator that looks built: every early exit waits for the device and marks H unbuilt.
+    struct PackGuard {
+        HMat &H;
+        bool armed = true;
+        ~PackGuard() {
+            if (armed) {
+                (void)hipDeviceSynchronize();
+                (void)hipGetLastError();
+                H.finalized = false;
+            }
+        }
+    } pack_guard{H};
     phase_nosync("pack kernels launched");
     const int64_t zA = H.nS, zP = H.nS + A_total;
     H.zero_slot      = H.nS + A_total + P_total;
@@ -985,7 +999,8 @@ static int build_streams(HMat &H) {
     }
     HMX_HIP(hipEventSynchronize(e1));
     HMX_HIP(hipDeviceSynchronize()); // an error of the pack kernels surfaces here
-    float ms = 0;
+    pack_guard.armed = false;
+    float ms         = 0;
     HMX_HIP(hipEventElapsedTime(&ms, e0, e1));
     for (auto &a : pk)
         a.release();
@@ -3858,6 +3873,12 @@ int api_prepare(HMat *Hp, char trans, int mu) {
 }
 
 int api_device_of(const HMat *H) { return H ? H->device : -1; }
+int api_root(const HMat *H, int32_t *t_off_size_s_off_size) { // root block of the operator, global cluster numbering
+    if (!H || !t_off_size_s_off_size)
+        return HMX_ERR_INVALID;
+    t_off_size_s_off_size[0] = H->T0, t_off_size_s_off_size[1] = H->nT, t_off_size_s_off_size[2] = H->S0, t_off_size_s_off_size[3] = H->nS;
+    return HMX_OK;
+}
 void api_destroy(HMat *H) { delete H; }
 void api_axpby(int64_t n, const scalar *w, scalar beta, scalar *y, hipStream_t st) {
     hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int)n, scalar(1), w, beta, y);
