@@ -44,6 +44,12 @@ struct HMat {
     DArr<int64_t> s_sub_ptr;
     DArr<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order; // second R sweep: per row interval the (parts of) tasks inside it
     int s_nint = 0;
+    // ... and for the multi-RHS form (rowsym_mfma16_kernel: intervals of 64 rows, one wave each); SW16 = [slot][16] partial sums of one sweep
+    DArr<int64_t> s64_sub_ptr;
+    DArr<int32_t> s64_sub_task, s64_sub_row0, s64_sub_nrows, s64_sub_dst, s64_int_order;
+    int s64_nint = 0;
+    int64_t s_slots = 0; // slots of SW (a' | column sums)
+    DArr<scalar> SW16;
     DArr<int32_t> sc_dst, sc_lp, sc_count, sc_k;
     int n_sym_combine = 0, n_sym_combine_wave = 0; // the first n_sym_combine_wave entries have >= 32 partial sums: one wave each
     int s_kmax        = 0;
@@ -764,6 +770,8 @@ static int build_streams(HMat &H) {
     size_t s_fidx_n = 0;
     std::vector<int64_t> s_sub_ptr;
     std::vector<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order;
+    std::vector<int64_t> p64; // the same tables for intervals of 64 rows (multi-RHS form of the second sweep)
+    std::vector<int32_t> t64, r64, n64, d64, o64;
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
     int64_t s_total = 0;
@@ -858,9 +866,6 @@ static int build_streams(HMat &H) {
         // adds the interval's dense mirrored contributions (EW, through the level index) and updates y once.  No partial row sums
         // leave the chip (they were 76 MB per product at N=1e6, written and read again), no separate folding kernel.
         const size_t ntask = R.task_range.size();
-        const int IR       = SYM_IR;
-        const int nint     = (H.nT + IR - 1) / IR;
-        std::vector<int64_t> sub_count(nint + 1, 0);
         std::vector<char> task_mirror(ntask, 0);
         for (size_t t = 0; t < ntask; t++) {
             const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
@@ -877,21 +882,30 @@ static int build_streams(HMat &H) {
                 break;
             }
             task_mirror[t] = 1;
-            for (int I = j0 / IR; I <= (j0 + R.len[r] - 1) / IR; I++)
-                sub_count[I + 1]++;
         }
-        for (int I = 0; I < nint; I++)
-            sub_count[I + 1] += sub_count[I];
-        s_sub_ptr = sub_count;
-        const int64_t nsub = sub_count[nint];
-        s_sub_task.assign(nsub, 0);
-        s_sub_row0.assign(nsub, 0);
-        s_sub_nrows.assign(nsub, 0);
-        s_sub_dst.assign(nsub, 0);
-        std::vector<double> int_work(nint, 0.0);
-        {
+        // the sub-task lists of the intervals of IR rows (launch order of the tasks = order inside every interval's list), heaviest interval first
+        auto build_intervals = [&](int IR, std::vector<int64_t> &sub_ptr, std::vector<int32_t> &sub_task, std::vector<int32_t> &sub_row0, std::vector<int32_t> &sub_nrows,
+                                   std::vector<int32_t> &sub_dst, std::vector<int32_t> &int_order) -> int {
+            const int nint = (H.nT + IR - 1) / IR;
+            std::vector<int64_t> sub_count(nint + 1, 0);
+            for (size_t t = 0; t < ntask; t++) {
+                if (!task_mirror[t])
+                    continue;
+                const int r = R.task_range[t], j0 = R.off[r] + H.S0 - H.T0;
+                for (int I = j0 / IR; I <= (j0 + R.len[r] - 1) / IR; I++)
+                    sub_count[I + 1]++;
+            }
+            for (int I = 0; I < nint; I++)
+                sub_count[I + 1] += sub_count[I];
+            sub_ptr            = sub_count;
+            const int64_t nsub = sub_count[nint];
+            sub_task.assign(nsub, 0);
+            sub_row0.assign(nsub, 0);
+            sub_nrows.assign(nsub, 0);
+            sub_dst.assign(nsub, 0);
+            std::vector<double> int_work(nint, 0.0);
             std::vector<int64_t> pos(sub_count.begin(), sub_count.end() - 1);
-            for (size_t t = 0; t < ntask && !bad; t++) { // launch order of the tasks = order inside every interval's list
+            for (size_t t = 0; t < ntask; t++) {
                 if (!task_mirror[t])
                     continue;
                 const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
@@ -900,17 +914,27 @@ static int build_streams(HMat &H) {
                 for (int I = j0 / IR; I <= (j1 - 1) / IR; I++) {
                     const int lo = std::max(j0, I * IR), hi = std::min(j1, (I + 1) * IR);
                     const int64_t q = pos[I]++;
-                    s_sub_task[q]  = (int32_t)t;
-                    s_sub_row0[q]  = lo - j0;
-                    s_sub_nrows[q] = hi - lo;
-                    s_sub_dst[q]   = lo - I * IR;
+                    sub_task[q]  = (int32_t)t;
+                    sub_row0[q]  = lo - j0;
+                    sub_nrows[q] = hi - lo;
+                    sub_dst[q]   = lo - I * IR;
                     int_work[I] += (double)(hi - lo) * w + 256;
                 }
             }
-        }
-        s_int_order.resize(nint);
-        std::iota(s_int_order.begin(), s_int_order.end(), 0);
-        std::stable_sort(s_int_order.begin(), s_int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
+            int_order.resize(nint);
+            std::iota(int_order.begin(), int_order.end(), 0);
+            std::stable_sort(int_order.begin(), int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
+            return nint;
+        };
+        int nint = 0;
+        if (!bad)
+            nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order);
+#if !HMX_COMPLEX
+        // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows); only a square operator runs it
+        H.s64_nint = 0;
+        if (!bad && H.T0 == H.S0 && H.nT == H.nS)
+            H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64);
+#endif
         phase_nosync("  sym: tasks");
         // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
         for (size_t p = 0; p < ed_b.size() && !bad; p++) {
@@ -996,6 +1020,18 @@ static int build_streams(HMat &H) {
         if (s_fidx_n)
             HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
         HMX_HIP(H.SW.alloc(s_total + 1));
+        H.s_slots = s_total;
+#if !HMX_COMPLEX
+        H.SW16.release();
+        if (H.s64_nint > 0) {
+            HMX_HIP(H.s64_sub_ptr.upload(p64));
+            HMX_HIP(H.s64_sub_task.upload(t64));
+            HMX_HIP(H.s64_sub_row0.upload(r64));
+            HMX_HIP(H.s64_sub_nrows.upload(n64));
+            HMX_HIP(H.s64_sub_dst.upload(d64));
+            HMX_HIP(H.s64_int_order.upload(o64));
+        }
+#endif
     }
     HMX_HIP(hipEventSynchronize(e1));
     HMX_HIP(hipDeviceSynchronize()); // an error of the pack kernels surfaces here
@@ -1387,6 +1423,86 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     HMX_HIP(hipGetLastError());
     return HMX_OK;
 }
+
+#if !HMX_COMPLEX
+// Several right-hand sides on the stored triangle of a square symmetric operator (kernels_body.hpp, "Several right-hand sides on the
+// STORED TRIANGLE"): sweeps of up to 16 right-hand sides; per sweep the reduce stage, the fused pass over the E-streams, the fold of a'
+// and the second pass over the R-streams.  No second layout of the operator: what is added to the compact operator is SW16, 16 partial sums
+// per slot of the single-vector product (N = 1e6 fp64: 1.6 GB next to 9.4 GB of streams; the expanded view it replaces: 18.6 GB).
+static bool sym_mu_fused(const HMat &H) {
+    // HMX_SYM_MU_FUSED=1: always the stored triangle; =0: always the expanded view; unset: the expanded view while HBM has room for it
+    // (it is the faster of the two as long as a row range writes its own partial column sums: N = 4e6 fp32, 16 right-hand sides, one
+    // MI355X: 15.9 ms on 42 + 83 GB against 19.0 ms on 42 + 6 GB), the stored triangle when it has not -- where products with several
+    // right-hand sides used to fall back to one single-vector product per column
+    const int mode = getenv("HMX_SYM_MU_FUSED") ? atoi(getenv("HMX_SYM_MU_FUSED")) : -1;
+    if (!(H.sym_fused && H.s64_nint > 0 && H.T0 == H.S0 && H.nT == H.nS) || mode == 0)
+        return false;
+    if (mode > 0)
+        return true;
+    if (H.X_op)
+        return false;
+    if (H.X_op_failed || H.factors_released)
+        return true;
+    size_t free_b = 0, total_b = 0;
+    return hmx_mem_info(&free_b, &total_b) != hipSuccess || (double)free_b < 2.3 * (double)H.stats.stream_bytes; // ensure_expanded_view's own admission test
+}
+static int run_forward_mu_sym(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
+    const size_t need = (size_t)(H.zero_slot + 1) * mu;
+    if (H.Zmu.n < need)
+        HMX_HIP(H.Zmu.alloc(need));
+    const size_t need16 = (size_t)(H.s_slots + 1) * 16;
+    if (H.SW16.n < need16) {
+        HMX_HIP(H.SW16.alloc(need16));
+        HMX_HIP(hipMemsetAsync(H.SW16.d, 0, need16 * sizeof(scalar), st)); // slot s_slots stays zero for ever: the operand of the columns that are no mirrored leaf's
+    }
+    ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
+                  H.r_outidx.d, X, H.Zmu.d, (int)H.R.task_range.size()};
+    constexpr int W = 4;
+    for (int c = 0; c < mu; c += 16) { // a = V X_s, every sweep
+        const int nrhs = std::min(16, mu - c);
+        if (RA.ntasks > 0)
+            hipLaunchKernelGGL((reduce_mfma16s_kernel<W>), dim3((unsigned)((RA.ntasks + W - 1) / W)), dim3(W * 64), 0, st, RA, mu, c, nrhs);
+        prof_mark(H, st, "reduce_mfma16s_kernel");
+    }
+    if (H.n_combine > 0) {
+        CombineArgs C{H.c_dst.d, H.c_src.d, H.c_stride.d, H.c_count.d, H.Zmu.d, H.n_combine};
+        const int64_t tot = (int64_t)H.n_combine * mu;
+        hipLaunchKernelGGL(combine_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, mu);
+        prof_mark(H, st, "combine_mu_kernel");
+    }
+    for (int c = 0; c < mu; c += 16) {
+        const int nrhs = std::min(16, mu - c);
+        if (H.E.nranges() > 0) {
+            ExpandSymArgs XS{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges(), X, H.nS},
+                             H.s_mdst.d, H.SW16.d, X + (int64_t)(H.T0 - H.S0) * mu, 0};
+            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W>), dim3((unsigned)H.E.nranges()), dim3(W * 64), 0, st, XS, mu, c, nrhs);
+            prof_mark(H, st, "expand_sym_mfma16_kernel");
+        }
+        if (H.n_sym_combine > 0) {
+            const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw; // the first nw entries fold >= 32 partial sums: one wave each
+            if (nw > 0) {
+                CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW16.d, nw};
+                hipLaunchKernelGGL(combine_list_mu_wave_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, C);
+            }
+            if (nt > 0) {
+                CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW16.d, nt};
+                const int64_t tot = (int64_t)nt * 16;
+                hipLaunchKernelGGL(combine_list_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C);
+            }
+            prof_mark(H, st, "combine_sym_mu_kernel");
+        }
+        if (H.s64_nint > 0) {
+            RowSymMuArgs P{{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
+                            H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, H.nT, 0},
+                           H.SW16.d, (int)H.s_slots, H.s64_nint};
+            hipLaunchKernelGGL((rowsym_mfma16_kernel<W>), dim3((unsigned)((H.s64_nint + W - 1) / W)), dim3(W * 64), 0, st, P, mu, c, nrhs);
+            prof_mark(H, st, "rowsym_mfma16_kernel");
+        }
+    }
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+#endif
 
 // transposed pass: out = alpha * sum_leaves leaf^T in + beta * out, accumulated through W with atomics.
 // mirror=true restricts to leaves_for_symmetry and uses target-local output / source... (see ensure_transposed_indices)
@@ -3675,7 +3791,13 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
     HMat *F = nullptr; // the layout a fused pass runs on: the operator itself, or its transposed view
     bool conj_wrap = false;
     (void)conj_wrap;
-    if (H.finalized && (!H.has_mirror || H.sym_expanded || H.sym_fused) && !getenv("HMX_NO_FUSED_MU")) {
+#if !HMX_COMPLEX
+    // a square symmetric operator on compact storage: the fused multi-RHS product on the stored triangle (no expanded view)
+    const bool fused_sym = H.finalized && mu > 1 && sym_mu_fused(H) && !getenv("HMX_NO_FUSED_MU") && (trans == 'N' || (trans == 'T' && H.symmetry_for_leaves == 'S'));
+#else
+    const bool fused_sym = false;
+#endif
+    if (!fused_sym && H.finalized && (!H.has_mirror || H.sym_expanded || H.sym_fused) && !getenv("HMX_NO_FUSED_MU")) {
         const bool square_sym = H.has_mirror && H.T0 == H.S0 && H.nT == H.nS;
         if (trans == 'N' || (trans == 'T' && square_sym && H.symmetry_for_leaves == 'S') || (trans == 'C' && square_sym && H.symmetry_for_leaves == 'H'))
             F = H.sym_fused ? ensure_expanded_view(H) : &H;
@@ -3699,6 +3821,27 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
         din   = H.conj_in.d;
         alpha = hmx_conj(alpha);
         beta  = hmx_conj(beta);
+    }
+#endif
+#if !HMX_COMPLEX
+    if (fused_sym) {
+        H.ev_names.clear();
+        prof_mark(H, st, "begin");
+        rc = run_forward_mu_sym(H, din, alpha, beta, dout, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        if (H.profiling) {
+            HMX_HIP(hipStreamSynchronize(st));
+            H.last_ms.clear();
+            H.last_names.clear();
+            for (size_t k = 1; k < H.ev_names.size(); k++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
+                H.last_ms.push_back(ms);
+                H.last_names.push_back(H.ev_names[k]);
+            }
+        }
+        return HMX_OK;
     }
 #endif
     if (F) {

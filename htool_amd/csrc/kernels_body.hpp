@@ -3411,6 +3411,357 @@ __global__ __launch_bounds__(256) void combine_list_wave_kernel(CombineListArgs 
         A.W[A.dst[e]] = s;
 }
 
+
+#if !HMX_COMPLEX
+// ---------------------------------------------------------------------------------------------
+// Several right-hand sides on the STORED TRIANGLE (symmetric storage, real coefficients): the fused product above for groups of up to 16
+// right-hand sides on the matrix cores.  The reference runs the mirror pass on the same leaves for any number of right-hand sides
+// (hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:100-106,160-170; symm for the diagonal leaves,
+// matrix/linalg/add_matrix_matrix_product_row_major.hpp:87-106); until round 4 such products ran here on an expanded copy of the
+// operator (twice the footprint, twice the traffic).  Three sweeps, as for one vector:
+//   reduce_mfma16s_kernel           a = V X_s over the R-streams (the ordinary multi-RHS reduce stage)
+//   expand_sym_mfma16_kernel        ONE pass over the E-streams: per 64 x 16 stream tile the forward product Y_t += E Z (tile = A operand,
+//                                   rows on the M index) AND the mirrored column sums EW = E^T X_t (the same tile as A operand with its
+//                                   columns on the M index and the rows contracted) -- 16 + 16 MFMAs per tile.  An MFMA contracts over
+//                                   the lane bits 4-5 of both operands, so the two products need the tile in two lane layouts: the
+//                                   forward operands come straight from the registers the loads filled (lane = row) by a 4 x 4
+//                                   transposition between register index and lane quarter (v_permlane32_swap + v_permlane16_swap: no LDS),
+//                                   the mirrored ones from a wave-private LDS copy [row][column] written with 16-byte stores.
+//   combine_list_mu_kernel          a' of the leaves that span several row ranges
+//   rowsym_mfma16_kernel            second pass over the R-streams, Y_s += V^T a': one WAVE owns 64 output rows (accumulators in
+//                                   registers, nothing to fold between waves), stream tiles 16 rows x 64 columns staged through LDS
+//                                   transposed and swizzled so that stores and operand reads both run at two lanes per bank.
+// Partial sums live in SW16 = [slot][16] (the slots of the single-vector product, 16 values each).  Fixed summation order: bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
+    const ExpandArgs &A = S.X;
+    constexpr int PT = 24; // row pitch of the mirrored tile [64 rows][16 columns]: operand reads (16 columns x 4 rows) at two lanes per bank
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * PT > WAVES * WAVE * 16 ? WAVES * 64 * PT : WAVES * WAVE * 16];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const real *E       = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4;
+    real *tile    = lds + wv * 64 * PT;
+    const int row = lane < len ? lane : len - 1; // idle lanes re-read the last row: forward, they only reach accumulator rows that are never stored; mirrored, their X_t operand is zero
+    const int mo  = cbase + (m < nrhs ? m : 0); // ragged group: see expand_mfma16s_kernel
+    // B operand of the mirrored product, constant over the range: X_t[row 4h + kk][rhs m] for the 16 k-steps h (zero beyond the range)
+    real xt[16];
+#pragma unroll
+    for (int h = 0; h < 16; h++) {
+        const int r   = 4 * h + kk;
+        const real xv = S.xrow[(int64_t)(A.range_off[R] + (r < len ? r : len - 1)) * mu + mo];
+        xt[h]         = r < len ? xv : real(0);
+    }
+    acc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    auto load_cols = [&](real(&v)[16], int c) { // 16 whole columns, clamped to the last one (zero operand there)
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int col = c + u < C ? c + u : C - 1;
+            v[u]          = stream_load(E + (int64_t)col * len + row);
+        }
+    };
+    auto operands = [&](real(&b)[4], int c, int zi, int base) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
+            const real bv = expand_operand(A, zc, mu)[mo];
+            b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
+        }
+    };
+    // one step = 16 columns: mirrored column sums (if any of the 16 is a mirrored column), then the forward product
+    auto apply = [&](real(&v)[16], const real(&b)[4], int c, int md, int base) {
+        const unsigned long long mirrored = __ballot(md >= 0);
+        if ((mirrored >> base) & 0xFFFFull) { // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                tile[lane * PT + u] = v[u]; // 16 consecutive elements per lane: 16-byte stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            acc4 am = acc4{0, 0, 0, 0};
+#pragma unroll
+            for (int h = 0; h < 16; h++)
+                am = mfma16(tile[(4 * h + kk) * PT + m], xt[h], am); // A[m = column][k = row 4h + kk], B[k][n = rhs]
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int col = mfma16_row(real(0), lane, j);
+                const int d   = __shfl(md, base + col, WAVE);
+                if (d >= 0 && c + col < C)
+                    S.W[(int64_t)d * 16 + m] = am[j];
+            }
+        }
+        // forward: a[g][t] (row 16 t + m, column 4 g + kk) = register 4 g + kk of lane quarter t -- a 4 x 4 transposition per column group
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            lane_swap32(v[4 * g + 0], v[4 * g + 2]);
+            lane_swap32(v[4 * g + 1], v[4 * g + 3]);
+            lane_swap16(v[4 * g + 0], v[4 * g + 1]);
+            lane_swap16(v[4 * g + 2], v[4 * g + 3]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                acc[t] = mfma16(v[4 * g + t], b[g], acc[t]);
+    };
+    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
+        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
+        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        const int md   = (t0 + lane < C) ? mdst[t0 + lane] : -1;
+        real v0[16], v1[16], b0[4], b1[4];
+        load_cols(v0, t0);
+        operands(b0, t0, zi, 0);
+        if (t0 + 16 < tend) {
+            load_cols(v1, t0 + 16);
+            operands(b1, t0 + 16, zi, 16);
+        }
+        apply(v0, b0, t0, md, 0);
+        if (t0 + 32 < tend) {
+            load_cols(v0, t0 + 32);
+            operands(b0, t0 + 32, zi, 32);
+        }
+        if (t0 + 16 < tend)
+            apply(v1, b1, t0 + 16, md, 16);
+        if (t0 + 48 < tend) {
+            load_cols(v1, t0 + 48);
+            operands(b1, t0 + 48, zi, 48);
+        }
+        if (t0 + 32 < tend)
+            apply(v0, b0, t0 + 32, md, 32);
+        if (t0 + 48 < tend)
+            apply(v1, b1, t0 + 48, md, 48);
+    }
+    // forward result: the waves' accumulators folded through LDS as in expand_mfma16s_kernel
+    real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 16; e += WAVES * WAVE) {
+        const int i = e >> 4, c = e & 15;
+        if (c >= nrhs)
+            continue;
+        real s = red[0][i][c];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++)
+            s += red[w][i][c];
+        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+// ... one wave per entry for the entries with many partial sums (the first `A.n` entries handed to this kernel): the 16 lanes of a lane
+// quarter take the right-hand sides, the four quarters every fourth partial sum; fixed order
+__global__ __launch_bounds__(256) void combine_list_mu_wave_kernel(CombineListArgs A) {
+    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (e >= A.n)
+        return;
+    const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    scalar s0 = scalar(0), s1 = scalar(0);
+    int i = g;
+    for (; i + 4 < cnt; i += 8) { // two loads in flight per lane
+        s0 += A.W[(int64_t)(l[i] + k) * 16 + m];
+        s1 += A.W[(int64_t)(l[i + 4] + k) * 16 + m];
+    }
+    if (i < cnt)
+        s0 += A.W[(int64_t)(l[i] + k) * 16 + m];
+    scalar s = s0 + s1;
+    s += hmx_shfl_xor(s, 16);
+    s += hmx_shfl_xor(s, 32);
+    if (g == 0)
+        A.W[(int64_t)A.dst[e] * 16 + m] = s;
+}
+// a'[dst][0..16) = sum_i SW16[list[lp + i] + k][0..16): one thread per (entry, right-hand side)
+__global__ void combine_list_mu_kernel(CombineListArgs A) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = (int)(id >> 4), m = (int)(id & 15);
+    if (e >= A.n)
+        return;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    // four independent sums keep four (index, value) load pairs in flight; fixed order
+    scalar s0 = scalar(0), s1 = scalar(0), s2 = scalar(0), s3 = scalar(0);
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+        const int32_t l0 = l[i], l1 = l[i + 1], l2 = l[i + 2], l3 = l[i + 3];
+        s0 += A.W[(int64_t)(l0 + k) * 16 + m];
+        s1 += A.W[(int64_t)(l1 + k) * 16 + m];
+        s2 += A.W[(int64_t)(l2 + k) * 16 + m];
+        s3 += A.W[(int64_t)(l3 + k) * 16 + m];
+    }
+    for (; i < cnt; i++)
+        s0 += A.W[(int64_t)(l[i] + k) * 16 + m];
+    A.W[(int64_t)A.dst[e] * 16 + m] = (s0 + s1) + (s2 + s3);
+}
+
+// Second pass over the R-streams for up to 16 right-hand sides.  Interval = 64 output rows = one wave; its sub-tasks are the parts of the
+// (source piece, column chunk) tasks whose rows lie in the interval.  Per sub-task and half of the chunk's (<= 128) columns: the B operands
+// a'[column][rhs] of the 16 k-steps are gathered once, then every 16-row tile of the interval the sub-task touches is loaded (whole rows: two
+// rows of 64 columns per wave-wide load), staged transposed in LDS and multiplied -- 16 MFMAs per 16 x 64 tile; rows of the tile that are
+// not the sub-task's are dropped when the tile's result is added to the interval's accumulators.
+constexpr int SYM_IR_MU = 64;
+struct RowSymMuArgs {
+    RowSymArgs A;         // (sub_* / order refer to the 64-row intervals)
+    const scalar *W16;    // [slot][16]
+    int zero_slot;        // a slot whose 16 values are zero
+    int nint;
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_mfma16_kernel(RowSymMuArgs P, int mu, int cbase, int nrhs) {
+    const RowSymArgs &A = P.A;
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * 16];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos = blockIdx.x * WAVES + wv;
+    if (pos >= P.nint)
+        return; // (no workgroup barrier below: the waves are independent)
+    const int I  = A.order[pos];
+    const int m = lane & 15, kk = lane >> 4;
+    // [64 columns][16 rows], element (row i, column c) at 16 (c ^ ((c >> 1) & 1)) + (i ^ ((c >> 1) & 15)): the stores of a load's two
+    // rows x 64 columns and the operand reads of 16 rows x 4 columns both touch every bank exactly twice
+    real *tile = lds + wv * 64 * 16;
+    acc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    const int lrow = lane >> 5, lc = 2 * (lane & 31); // loads: lane = (row parity, column pair) of a 2-row x 64-column slab
+    // what a sub-task needs, fetched one sub-task ahead: the chain sub-task -> task -> range -> geometry is a dozen dependent loads
+    struct Sub {
+        const real *src;
+        int w, wp, n, dst;
+        int32_t dlo, dhi; // slots of a' for the chunk's columns lane and 64 + lane (-1: not a mirrored leaf's column / beyond the chunk)
+    };
+    auto fetch = [&](int64_t q) {
+        Sub s;
+        const int task = A.sub_task[q], row0 = A.sub_row0[q];
+        s.n   = A.sub_nrows[q];
+        s.dst = A.sub_dst[q];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        s.w   = w;
+        s.wp  = hmx_wp(w);
+        s.src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * s.wp;
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        const int32_t a = A.coef[cb + (lane < w ? lane : 0)], b = A.coef[cb + (64 + lane < w ? 64 + lane : 0)];
+        s.dlo = lane < w ? a : -1;
+        s.dhi = 64 + lane < w ? b : -1;
+        return s;
+    };
+    // a tile = 16 interval rows x 64 columns of one sub-task: rows clamped into the sub-task's (the others are dropped when the result is added)
+    auto load_tile = [&](scalar2(&v)[8], const Sub &s, int c0, int t) {
+        const int cl = c0 + lc < s.wp ? c0 + lc : 0; // lanes beyond the chunk re-read its first pair (their operand is zero)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int r = 16 * t + 2 * u + lrow - s.dst;
+            r     = r < 0 ? 0 : (r >= s.n ? s.n - 1 : r);
+            v[u]  = stream_load(reinterpret_cast<const scalar2 *>(s.src + (int64_t)r * s.wp + cl));
+        }
+    };
+    // B operands of a segment (sub-task, 64-column half): a'[column c0 + 4 h + kk][rhs m]; columns beyond the chunk and columns that are
+    // no mirrored leaf's read a zero slot
+    auto gather_b = [&](real(&b)[16], const Sub &s, int c0) {
+#pragma unroll
+        for (int h = 0; h < 16; h++) {
+            const int d = __shfl(c0 ? s.dhi : s.dlo, 4 * h + kk, WAVE);
+            b[h]        = P.W16[(int64_t)(d >= 0 ? d : P.zero_slot) * 16 + m];
+        }
+    };
+    const int64_t q0 = A.sub_ptr[I], q1 = A.sub_ptr[I + 1];
+    Sub cur{};
+    if (q0 < q1)
+        cur = fetch(q0);
+    for (int64_t q = q0; q < q1; q++) {
+        const Sub nxt = fetch(q + 1 < q1 ? q + 1 : q);
+        const int t_lo = cur.dst >> 4, t_hi = (cur.dst + cur.n - 1) >> 4;
+        for (int c0 = 0; c0 < cur.w; c0 += 64) {
+            real b[16];
+            gather_b(b, cur, c0);
+            scalar2 v[8], vn[8];
+            load_tile(v, cur, c0, t_lo);
+            for (int t = t_lo; t <= t_hi; t++) {
+                load_tile(vn, cur, c0, t < t_hi ? t + 1 : t); // unconditional: the next tile's loads are in flight under this tile's arithmetic
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = 2 * u + lrow, sw = lane & 15, fl = lane & 1; // (c >> 1) & 15 and (c >> 1) & 1 of both columns lc, lc + 1
+                    tile[16 * (lc ^ fl) + (i ^ sw)]       = v[u].x;
+                    tile[16 * ((lc + 1) ^ fl) + (i ^ sw)] = v[u].y;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                acc4 tm = acc4{0, 0, 0, 0};
+#pragma unroll
+                for (int h = 0; h < 16; h++) {
+                    const int c = 4 * h + kk;
+                    tm          = mfma16(tile[16 * (c ^ ((c >> 1) & 1)) + (m ^ ((c >> 1) & 15))], b[h], tm); // A[m = row][k = column c], B[k][n = rhs]
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i    = 16 * t + mfma16_row(real(0), lane, j);
+                    const real add = (i >= cur.dst && i < cur.dst + cur.n) ? tm[j] : real(0);
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+                        if (tt == t)
+                            acc[tt][j] += add;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = vn[u];
+            }
+        }
+        cur = nxt;
+    }
+    // dense mirrored contributions of the interval's rows (column sums the first pass left in SW16, found through the level index), y update.
+    // A lane holds 16 rows (one right-hand side each): level k of all sixteen is fetched together -- sixteen independent chains of two
+    // loads per level instead of one (the levels of a row are few, but every one is two dependent trips to memory)
+    int jr[16], cn[16], kmax = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int jrow = I * SYM_IR_MU + 16 * t + mfma16_row(real(0), lane, j);
+            jr[4 * t + j]  = jrow < A.n ? jrow : A.n - 1;
+            cn[4 * t + j]  = jrow < A.n ? A.count[jr[4 * t + j]] : 0;
+            kmax           = cn[4 * t + j] > kmax ? cn[4 * t + j] : kmax;
+        }
+    for (int k = 0; k < kmax; k++) {
+        int32_t d[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            d[e] = A.fidx[(int64_t)(k < cn[e] ? k : 0) * A.n + jr[e]]; // (level 0 of the row when it has fewer: a valid entry, dropped below)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const real v = P.W16[(int64_t)(k < cn[e] ? d[e] : P.zero_slot) * 16 + m];
+            acc[e >> 2][e & 3] += v;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int jrow = I * SYM_IR_MU + 16 * t + mfma16_row(real(0), lane, j);
+            if (jrow >= A.n || m >= nrhs)
+                continue;
+            real *yo = A.y + (int64_t)jrow * mu + cbase + m;
+            *yo += A.alpha * acc[t][j];
+        }
+}
+
+#endif // !HMX_COMPLEX
+
 // small helpers -----------------------------------------------------------------------------------
 __global__ void axpby_kernel(int n, scalar alpha, const scalar *w, scalar beta, scalar *y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

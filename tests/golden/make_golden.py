@@ -153,10 +153,10 @@ FULL_CASES.update({"full_ellipse_n1000000_p8_rank%d" % r: dict(n=1000000, geom="
 
 
 # BASELINE configs[4] at its own size: N=4e6 fp32, 'S','L', sympartialACA, eps=1e-6, 16 right-hand sides, row-partitioned over 8 ranks
-# (minimal depth 7: N / 2^7 <= 46340).  Three of the eight per-rank operators -- the first, a middle one and the last -- as htool builds
-# and multiplies them (5 GB each).  And configs[0]'s literal workload: N=5000 points in the unit ball, eps=1e-3, partialACA.
+# (minimal depth 7: N / 2^7 <= 46340).  All eight per-rank operators as htool builds
+# and multiplies them (5 GB each; ranks 0, 3, 7 since round 3, the other five since round 4).  And configs[0]'s literal workload: N=5000 points in the unit ball, eps=1e-3, partialACA.
 FULL_CASES.update({"full_ellipse_n4000000_f32_symL_p8_rank%d" % r: dict(n=4000000, geom="ellipse", leaf=100, eps=1e-6, eta=10, sym="S", uplo="L", compressor="sympartialACA",
-                                                                        prec="f32", mu=16, mindepth=7, partitions=8, rank=r) for r in (0, 3, 7)})
+                                                                        prec="f32", mu=16, mindepth=7, partitions=8, rank=r) for r in range(8)})
 FULL_CASES["full_ball_n5000_eps1e-3"] = dict(n=5000, geom="ball", leaf=100, eps=1e-3, eta=10, compressor="partialACA")
 
 

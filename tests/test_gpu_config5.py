@@ -16,8 +16,10 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def test_config5_flags_one_gpu_sixteen_rhs_against_oracle_on_a_row_slab():
+def test_config5_flags_one_gpu_sixteen_rhs_against_oracle_on_a_row_slab(monkeypatch):
     from oracle import oracle as O
+    # the 16-RHS product on the STORED TRIANGLE (default when HBM has no room for an expanded copy; forced here: one GPU has)
+    monkeypatch.setenv("HMX_SYM_MU_FUSED", "1")
     n, mu = int(os.environ.get("HMX_TEST_C5_N", 4000000)), 16
     x = hm.create_geometry("ellipse", n)
     b = hm.ClusterTreeBuilder()
@@ -35,6 +37,10 @@ def test_config5_flags_one_gpu_sixteen_rhs_against_oracle_on_a_row_slab():
     X = rng.random((n, mu)).astype(np.float32)
     Y = np.zeros((n, mu), dtype=np.float32)
     hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, X, 0.0, Y, mu)
+    # the 16-RHS product ran on the STORED TRIANGLE: no expanded copy of the operator was allocated (round 3: 42 GB + 83 GB on this GPU)
+    after = H.stats()
+    assert after["expanded_bytes"] == 0 and after["stream_bytes"] == st["stream_bytes"]
+    assert n < 4000000 or 38e9 < after["stream_bytes"] < 46e9
     # the slab: the smallest cluster ending at n that holds whole leaves and at least n / 256 rows
     tab = np.asarray(H.leaf_table())
     nodes = T.nodes_int()
@@ -65,7 +71,7 @@ def test_config5_flags_one_gpu_sixteen_rhs_against_oracle_on_a_row_slab():
     print("config 5 flags, N=%d: %d + %d leaves, rank %d/%.2f/%d, %.1f GB of streams; slab rows [%d, %d): %d leaves (%.2f GB), mu=%d error vs oracle %.2e"
           % (n, st["n_dense"], st["n_lowrank"], st["rank_min"], st["rank_mean"], st["rank_max"], st["stream_bytes"] / 1e9, lo, n, len(sel), pos * 8 / 1e9, mu, err))
     assert err < 2e-5  # fp32 arithmetic on the same blocks (the fp32 parity bar)
-    # the fused single-vector product on compact storage = column 0 of the 16-RHS product (which runs on the expanded view)
+    # the fused single-vector product on compact storage = column 0 of the 16-RHS product (both on the stored triangle)
     y = np.zeros(n, dtype=np.float32)
     hm.internal_add_hmatrix_vector_product("N", 1.0, H, np.ascontiguousarray(X[:, 0]), 0.0, y)
     assert rel_err(y.astype(np.float64), Y[:, 0].astype(np.float64)) < 2e-5

@@ -824,7 +824,7 @@ def test_prepare_builds_the_second_layouts_so_that_products_allocate_nothing(nam
     if trans == "T" and not (p["sym"] == "S" and p["rank"] < 0):
         assert st["transposed_bytes"] > 0
     if p["sym"] == "S" and mu > 1 and trans == "N":
-        assert st["expanded_bytes"] > 0
+        assert st["expanded_bytes"] > 0  # HBM has room: the expanded view (HMX_SYM_MU_FUSED=1 / no room: the stored triangle, test_stored_triangle_*)
     nin, nout = (H.nb_cols(), H.nb_rows()) if trans == "N" else (H.nb_rows(), H.nb_cols())
     rng = np.random.default_rng(0)
     X = torch.from_numpy(rng.standard_normal((nin, mu))).cuda()
@@ -848,3 +848,56 @@ def test_prepare_builds_the_second_layouts_so_that_products_allocate_nothing(nam
         y2 = torch.zeros_like(y)
         hm.internal_add_hmatrix_vector_product(trans, 1.0, H2, x, 0.0, y2)
         assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("name", ["ellipse_n3000_symL_default", "ellipse_n3000_symU_sympartial", "ball_n2000_symL_eta3"])
+def test_stored_triangle_product_with_several_right_hand_sides(name, f32, monkeypatch):
+    """Several right-hand sides on the STORED TRIANGLE of a square symmetric operator (expand_sym_mfma16_kernel / rowsym_mfma16_kernel:
+    forward product and mirrored column sums of every stream tile in one pass, second pass over the V factors; the reference runs the
+    mirror pass on the same leaves, add_hmatrix_matrix_product_row_major.hpp:100-106,160-170): against the oracle's row-major product on
+    the oracle's own operator for 2, 3, 16, 19 and 40 right-hand sides (ragged sweeps of 16), against the expanded view, with alpha / beta,
+    trans 'T' (= 'N' for 'S'), bitwise reproducible -- and no expanded copy of the operator is allocated."""
+    from oracle import oracle as O
+    p = params(name)
+    dt = np.float32 if f32 else np.float64
+    T, S = build_trees(p)
+    tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    tb.set_low_rank_generator(p["compressor"])
+    H = tb.build(device_generator(p, T, S), T, S, dtype=dt)
+    n = H.nb_rows()
+    monkeypatch.setenv("HMX_SYM_MU_FUSED", "1")
+    for mu, trans in ((2, "N"), (3, "T"), (16, "N"), (19, "N"), (40, "N")):
+        X = O.hashed_vector(n * mu, 61 + mu).reshape(n, mu).astype(dt)
+        Y0 = O.hashed_vector(n * mu, 62 + mu).reshape(n, mu).astype(dt)
+        H.set_profiling(True)
+        Y = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.5, H, X, 0.5, Y, mu)
+        names = [k for k, _ in H.last_kernel_times()]
+        H.set_profiling(False)
+        assert any("expand_sym_mfma16" in k for k in names) and any("rowsym_mfma16" in k for k in names), names
+        # column by column: the fused single-vector product on the same compact storage
+        ref = Y0.copy()
+        for c in range(mu):
+            y = np.ascontiguousarray(Y0[:, c])
+            hm.internal_add_hmatrix_vector_product("N", 1.5, H, np.ascontiguousarray(X[:, c]), 0.5, y)
+            ref[:, c] = y
+        assert rel_err(Y, ref) < (2e-5 if f32 else 1e-12), (mu, rel_err(Y, ref))
+        Y2 = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.5, H, X, 0.5, Y2, mu)
+        assert np.array_equal(Y, Y2)  # fixed summation order
+    assert H.stats()["expanded_bytes"] == 0
+    # ... and the expanded view gives the same product (another summation order)
+    monkeypatch.setenv("HMX_SYM_MU_FUSED", "0")
+    Y3 = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, Y3, mu)
+    assert H.stats()["expanded_bytes"] > 0 and rel_err(Y3, Y) < (2e-5 if f32 else 1e-12)
+    # fixture check in double precision: the reference's own product of this operator
+    if not f32 and "YNrm" in load(name):
+        g = load(name)
+        mu_g = g["YNrm"].shape[1]
+        Xg, Yg = O.hashed_vector(n * mu_g, 5).reshape(n, mu_g), O.hashed_vector(n * mu_g, 6).reshape(n, mu_g)
+        monkeypatch.setenv("HMX_SYM_MU_FUSED", "1")
+        al, be = g["alphabeta"][:2]
+        hm.internal_add_hmatrix_matrix_product_row_major("N", al, H, Xg, be, Yg, mu_g)
+        assert rel_err(Yg, g["YNrm"]) < 1e-10
