@@ -1495,7 +1495,11 @@ static int run_forward_mu_sym(HMat &H, const scalar *X, scalar alpha, scalar bet
             RowSymMuArgs P{{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
                             H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, H.nT, 0},
                            H.SW16.d, (int)H.s_slots, H.s64_nint};
-            hipLaunchKernelGGL((rowsym_mfma16_kernel<W>), dim3((unsigned)((H.s64_nint + W - 1) / W)), dim3(W * 64), 0, st, P, mu, c, nrhs);
+#ifndef HMX_ROWSYM_WAVES
+#define HMX_ROWSYM_WAVES 4
+#endif
+            constexpr int RWV = HMX_ROWSYM_WAVES; // intervals (= waves) per workgroup
+            hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
             prof_mark(H, st, "rowsym_mfma16_kernel");
         }
     }

@@ -3436,7 +3436,10 @@ __global__ __launch_bounds__(256) void combine_list_wave_kernel(CombineListArgs 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
     const ExpandArgs &A = S.X;
-    constexpr int PT = 24; // row pitch of the mirrored tile [64 rows][16 columns]: operand reads (16 columns x 4 rows) at two lanes per bank
+#ifndef HMX_SYMMU_PT
+#define HMX_SYMMU_PT 24
+#endif
+    constexpr int PT = HMX_SYMMU_PT; // row pitch of the mirrored tile [64 rows][16 columns]: operand reads (16 columns x 4 rows) at two lanes per bank
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * PT > WAVES * WAVE * 16 ? WAVES * 64 * PT : WAVES * WAVE * 16];
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3511,6 +3514,22 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
             for (int t = 0; t < 4; t++)
                 acc[t] = mfma16(v[4 * g + t], b[g], acc[t]);
     };
+#ifndef HMX_SYMMU_SINGLE
+#define HMX_SYMMU_SINGLE 0
+#endif
+#if HMX_SYMMU_SINGLE
+    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) { // one step in flight per wave: half the registers, more waves per SIMD
+        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
+        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        const int md   = (t0 + lane < C) ? mdst[t0 + lane] : -1;
+        for (int c = t0; c < tend; c += 16) {
+            real v0[16], b0[4];
+            load_cols(v0, c);
+            operands(b0, c, zi, c - t0);
+            apply(v0, b0, c, md, c - t0);
+        }
+    }
+#else
     for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
         const int tend = (t0 + 64) < C ? (t0 + 64) : C;
         const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
@@ -3538,6 +3557,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
         if (t0 + 48 < tend)
             apply(v1, b1, t0 + 48, md, 48);
     }
+#endif
     // forward result: the waves' accumulators folded through LDS as in expand_mfma16s_kernel
     real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
     __syncthreads();
