@@ -2098,7 +2098,7 @@ typedef Acc4<real>::type acc4;
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs A, int mu, int cbase, int nrhs) {
     constexpr int PITCH = 80; // 64 rows + 16: consecutive tile columns are 32 banks apart, so the 64-bit operand reads (16 rows x 4 columns) do not conflict
-    __shared__ __attribute__((aligned(16))) real lds[WAVES * 16 * PITCH > WAVES * WAVE * 16 ? WAVES * 16 * PITCH : WAVES * WAVE * 16];
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 16 * PITCH > WAVES * WAVE * 16 ? WAVES * 16 * PITCH : WAVES * WAVE * 16]; // (HMX_EXPAND_PERMLANE: only the final fold of the waves uses it)
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
@@ -2130,24 +2130,51 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
             b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
         }
     };
-    auto apply = [&](const real(&v)[16], const real(&b)[4]) {
-        __builtin_amdgcn_wave_barrier();
+    // Round 4: the operand layout WITHOUT LDS for 4-byte coefficients.  The loads fill register u of lane r with E[row r][column c + u]; the
+    // MFMA wants, for column group g and row tile t, lane (m, kk) to hold E[row 16 t + m][column c + 4 g + kk] -- register 4 g + kk of lane
+    // quarter t.  That is a 4 x 4 transposition between register index and lane quarter per column group: v_permlane32_swap on (0, 2),
+    // (1, 3), then v_permlane16_swap on (0, 1), (2, 3).  Sixteen swaps instead of sixteen LDS stores + sixteen LDS loads + a fence per step;
+    // the same MFMAs on the same operands in the same order, so the results are bitwise those of the staged form.  Same box, alternating
+    // (profiles/r4_ab_permlane.log): fp32 expand stage 1.07 -> 1.04 ms at N = 1e6; fp64 (two swaps per register) 1.97 -> 2.03 ms, so
+    // 8-byte coefficients keep the LDS tile.  -DHMX_EXPAND_PERMLANE=0 / 1 forces one form for both.
+#ifdef HMX_EXPAND_PERMLANE
+    constexpr bool PERM = HMX_EXPAND_PERMLANE != 0;
+#else
+    constexpr bool PERM = sizeof(real) == 4;
+#endif
+    auto apply = [&](real(&v)[16], const real(&b)[4]) {
+        if constexpr (PERM) {
 #pragma unroll
-        for (int u = 0; u < 16; u++)
-            tile[u][lane] = v[u];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        real a[4][4];
+            for (int g = 0; g < 4; g++) {
+                lane_swap32(v[4 * g + 0], v[4 * g + 2]);
+                lane_swap32(v[4 * g + 1], v[4 * g + 3]);
+                lane_swap16(v[4 * g + 0], v[4 * g + 1]);
+                lane_swap16(v[4 * g + 2], v[4 * g + 3]);
+            }
 #pragma unroll
-        for (int g = 0; g < 4; g++)
+            for (int g = 0; g < 4; g++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                a[g][t] = tile[4 * g + kk][16 * t + m];
+                for (int t = 0; t < 4; t++)
+                    acc[t] = mfma16(v[4 * g + t], b[g], acc[t]);
+        } else {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int g = 0; g < 4; g++)
+            for (int u = 0; u < 16; u++)
+                tile[u][lane] = v[u];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            real a[4][4];
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                acc[t] = mfma16(a[g][t], b[g], acc[t]);
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    a[g][t] = tile[4 * g + kk][16 * t + m];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[t] = mfma16(a[g][t], b[g], acc[t]);
+        }
     };
     // wave w takes the 64-column tiles w, w + WAVES, ...; inside a tile four steps of 16 columns, loads one step ahead
     for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
