@@ -798,22 +798,18 @@ __global__ __launch_bounds__(NT) void aca_cb_col_kernel(AcaCbArgs A) {
         block_sum_group<NT, 2>(acc2, sbuf);
         aux           = hmx_abs(acc2[0]) * hmx_abs(acc2[1]);
         scalar frob_aux = 0;
-        for (int j0 = 0; j0 < q - 1; j0 += 4) {
-            scalar acc[8]  = {};
+        for (int j0 = 0; j0 < q - 1; j0 += 4) { // the sums of aca_kernel, four history crosses at a time (aca_dots4: no indexed private array)
             const int nj = (q - 1 - j0) < 4 ? (q - 1 - j0) : 4;
-            for (int g = 0; g < nj; g++) {
-                const scalar *cj = A.pool + cross[j0 + g];
-                scalar a1 = 0, a2 = 0;
-                for (int k = tid; k < n2; k += NT)
-                    a1 += hmx_conj(cj[n1 + k]) * u1[k];
-                for (int k = tid; k < n1; k += NT)
-                    a2 += hmx_conj(cj[k]) * u2[k];
-                acc[2 * g]     = a1;
-                acc[2 * g + 1] = a2;
-            }
+            scalar acc[8];
+            aca_dots4<NT>(A.pool, cross, j0, nj, n1, n2, u1, u2, acc);
             block_sum_group<NT, 8>(acc, sbuf);
-            for (int g = 0; g < nj; g++)
-                frob_aux += acc[2 * g] * acc[2 * g + 1];
+            frob_aux += acc[0] * acc[1];
+            if (nj > 1)
+                frob_aux += acc[2] * acc[3];
+            if (nj > 2)
+                frob_aux += acc[4] * acc[5];
+            if (nj > 3)
+                frob_aux += acc[6] * acc[7];
         }
         frob += aux + 2 * hmx_re(frob_aux);
     }
@@ -3040,7 +3036,9 @@ __device__ __forceinline__ scalar reduce8(const scalar (&v)[8], int lane) {
         u[k] = a + b;
     }
     const bool b3 = lane & 8;
-    scalar r = (b3 ? u[1] : u[0]) + dpp_move<0x128>(b3 ? u[0] : u[1]); // row_ror:8 = lane ^ 8 inside a row of 16
+    // (component-wise select: a lane-dependent choice between two complex values otherwise becomes a dynamically indexed private array --
+    // 48 bytes of scratch and four scratch instructions per group of eight columns in the complex-double kernels until round 4)
+    scalar r = hmx_select(b3, u[1], u[0]) + dpp_move<0x128>(hmx_select(b3, u[0], u[1])); // row_ror:8 = lane ^ 8 inside a row of 16
     r += dpp_move<0x141>(r);                                           // row_half_mirror
     r += dpp_move<0xB1>(r);                                            // quad_perm [1,0,3,2]
     r += dpp_move<0x4E>(r);                                            // quad_perm [2,3,0,1]
@@ -3239,7 +3237,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
             // stream itself: on MI355X 1.6 % of written bytes takes 15-30 % off a streaming read, tools/read_write_mix.hip; staging
             // the sums in LDS until the end of the workgroup, 128-byte aligned runs or non-temporal stores change nothing.)
             const scalar r = reduce8(p, lane);
-            mine           = (lane & 7) == (j >> 3) ? r : mine;
+            mine           = hmx_select((lane & 7) == (j >> 3), r, mine);
             if (j + 8 >= nc) {
                 const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
                 if (md >= 0)
@@ -3370,7 +3368,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_kernel(RowSymArgs A) {
                 // as in expand_sym_kernel: lane 8 s + g keeps the sum of row 64 b + 8 g + s; after 64 rows one transposing ds_bpermute
                 const scalar r = reduce8(v, lane);
                 const int g    = (i0 >> 3) & 7;
-                mine           = (lane & 7) == g ? r : mine;
+                mine           = hmx_select((lane & 7) == g, r, mine);
                 if (g == 7 || i0 + 8 >= len) {
                     const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
                     const int i    = (i0 & ~63) + lane;

@@ -149,6 +149,10 @@ template <typename T> __device__ __forceinline__ T hmx_abs2(cplx<T> v) { const T
 __host__ __device__ __forceinline__ bool hmx_is_zero(double v) { return v == 0.0; }
 __host__ __device__ __forceinline__ bool hmx_is_zero(float v) { return v == 0.0f; }
 template <typename T> __host__ __device__ __forceinline__ bool hmx_is_zero(cplx<T> v) { return v.re == T(0) && v.im == T(0); }
+// c ? a : b, component by component for complex values (registers, never an indexed private array)
+__device__ __forceinline__ double hmx_select(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ float hmx_select(bool c, float a, float b) { return c ? a : b; }
+template <typename T> __device__ __forceinline__ cplx<T> hmx_select(bool c, cplx<T> a, cplx<T> b) { return cplx<T>(c ? a.re : b.re, c ? a.im : b.im); }
 __device__ __forceinline__ double hmx_shfl_xor(double v, int o) { return __shfl_xor(v, o, WAVE); }
 __device__ __forceinline__ float hmx_shfl_xor(float v, int o) { return __shfl_xor(v, o, WAVE); }
 __device__ __forceinline__ int hmx_shfl_xor(int v, int o) { return __shfl_xor(v, o, WAVE); }

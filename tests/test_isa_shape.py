@@ -90,10 +90,14 @@ def test_single_vector_kernels_keep_their_occupancy_and_load_shape(tmp_path):
         if re.search(r"3(f64|f32)13reduce_kernelILi\d", name):
             assert m["private_segment_fixed_size"] == 0 and m["vgpr_count"] <= 72, (name, m)  # 7 waves per SIMD
             checked += 1
-        if re.search(r"3f64(17expand_sym_kernel|13rowsym_kernel)", name):
+        if re.search(r"3(f64|z64)(17expand_sym_kernel|13rowsym_kernel)", name):
+            # (complex double: a lane-dependent `c ? a : b` between two complex values used to become an indexed private array -- 48 bytes of
+            # scratch in the hot loop, Hermitian N = 1e6 product 14.4 ms; with component-wise selects 12.7 ms)
             assert m["private_segment_fixed_size"] == 0, (name, m)
             checked += 1
-    assert checked >= 15, checked  # expand_kernel<4|8> x 4 types, reduce_kernel<1|4> x 2, the fused symmetric pair
+        if re.search(r"aca_cb_(row|col)_kernel|sym_mfma16_kernel|rowsym_mfma16_kernel", name):
+            assert m["private_segment_fixed_size"] == 0, (name, m)
+    assert checked >= 18, checked  # expand_kernel<4|8> x 4 types, reduce_kernel<1|4> x 2, the fused symmetric kernels (real and complex double)
     for sym, op, least in (("_ZN3hmx3f6413reduce_kernelILi1EEEvNS0_10ReduceArgsE", "global_load_dwordx4", 8), ("_ZN3hmx3f6413expand_kernelILi4EEEvNS0_10ExpandArgsE", "global_load_dwordx2", 8)):
         asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, where[sym]], capture_output=True, text=True, check=True).stdout
         ops = collections.Counter(l.split()[0] for l in asm.split("\n") if l.startswith("\t"))
