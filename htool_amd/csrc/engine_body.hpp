@@ -2185,12 +2185,10 @@ static int cb_fill_blocks(HMat &H, CbLanes &LN, const std::vector<int32_t> &bloc
 
 static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqrank, bool full_pool);
 int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank) {
-    // The cross pool is first sized from a rank estimate (allocations beyond a few tens of GB take seconds on this
-    // platform: tools/malloc_timing.hip); if a block runs out of pool the compression is repeated with the full budget.
-    int rc = api_compress_impl(Hp, compressor, epsilon, reqrank, false);
-    if (rc == 1)
-        rc = api_compress_impl(Hp, compressor, epsilon, reqrank, true);
-    return rc;
+    // The cross pool is first sized from a rank estimate (allocations beyond a few tens of GB take seconds on this platform:
+    // tools/malloc_timing.hip) and GROWS when blocks run out of it: the ACA variants suspend / park such blocks and continue them, fullACA
+    // and SVD compress them again -- nothing else is repeated (until round 4 those two and the host-generator ACA repeated the whole build).
+    return api_compress_impl(Hp, compressor, epsilon, reqrank, false);
 }
 static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqrank, bool full_pool) {
     if (!Hp) {
@@ -2367,7 +2365,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     // compression must be repeated) and is 3-4 times the ranks smooth kernels really give; large allocations cost
     // seconds on some boxes (tools/malloc_timing.hip) and the pool competes with the streams for HBM.  So every K-th
     // block of the size-sorted list (<= ~4000 blocks) is compressed first into a small pool, and the full pool is sized
-    // at 1.3 x (measured / guessed) of the estimate.  An overflow still leads to the full-pool retry.  HMX_POOL_SAMPLE=0: off.
+    // at 1.3 x (measured / guessed) of the estimate.  The pool grows if the sample misled (grow_pool).  HMX_POOL_SAMPLE=0: off.
     if (!assembled && !use_cb && !full_pool && order.size() >= 20000 && (double)cap * sizeof(scalar) >= 4e9 && reqrank < 0 &&
         !(getenv("HMX_POOL_SAMPLE") && atoi(getenv("HMX_POOL_SAMPLE")) == 0) && !getenv("HMX_POOL_RANK_GUESS")) {
         const size_t K = std::max<size_t>(1, order.size() / 4096);
@@ -2474,13 +2472,23 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         HMX_HIP(scratch.alloc(slab));
         std::vector<int64_t> soff(nb, 0);
         DArr<int64_t> d_soff;
+        // Rounds: all blocks first; the blocks that found the pool exhausted (rank -2) are compressed again -- they only -- after the pool has
+        // grown (a block of these compressors is assembled and compressed from scratch in one go, so "again" costs that block, not the build)
+        std::vector<int32_t> todo = order;
+        DArr<int32_t> d_todo;
+        for (int round = 0;; round++) {
+        const int32_t *todo_dev = d_order.d;
+        if (round > 0) {
+            HMX_HIP(d_todo.upload(todo));
+            todo_dev = d_todo.d;
+        }
         size_t pos = 0;
-        while (pos < order.size()) {
+        while (pos < todo.size()) {
             int64_t used = 0;
             size_t end   = pos;
-            while (end < order.size() && used + need_elems[order[end]] <= slab) {
-                soff[order[end]] = used;
-                used += need_elems[order[end]];
+            while (end < todo.size() && used + need_elems[todo[end]] <= slab) {
+                soff[todo[end]] = used;
+                used += need_elems[todo[end]];
                 end++;
             }
             HMX_HIP(d_soff.upload(soff));
@@ -2491,12 +2499,12 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                 std::vector<int64_t> preoff(nb, 0);
                 int64_t tot = 0;
                 for (size_t k = pos; k < end; k++) {
-                    preoff[order[k]] = tot;
-                    tot += (int64_t)H.leaves[order[k]].t_size * H.leaves[order[k]].s_size;
+                    preoff[todo[k]] = tot;
+                    tot += (int64_t)H.leaves[todo[k]].t_size * H.leaves[todo[k]].s_size;
                 }
                 HMX_HIP(pre.alloc(std::max<int64_t>(tot, 1)));
                 HMX_HIP(hipDeviceSynchronize());
-                const int rcf = cb_fill_blocks(H, *cb_lanes, std::vector<int32_t>(order.begin() + pos, order.begin() + end), preoff, pre.d);
+                const int rcf = cb_fill_blocks(H, *cb_lanes, std::vector<int32_t>(todo.begin() + pos, todo.begin() + end), preoff, pre.d);
                 if (rcf != HMX_OK)
                     return rcf;
                 HMX_HIP(d_preoff.upload(preoff));
@@ -2506,7 +2514,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             D.ks = H.ks;
             D.tx = H.tx.d; D.ty = H.ty.d; D.tz = H.tz.d;
             D.sx = H.sx.d; D.sy = H.sy.d; D.sz = H.sz.d;
-            D.order = d_order.d + pos;
+            D.order = todo_dev + pos;
             D.t_off = H.d_t_off.d; D.t_size = H.d_t_size.d; D.s_off = H.d_s_off.d; D.s_size = H.d_s_size.d;
             D.scratch_off = d_soff.d;
             D.scratch     = scratch.d;
@@ -2526,6 +2534,23 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipDeviceSynchronize());
             pos = end;
+        }
+        std::vector<int32_t> rr(nb, 0);
+        HMX_HIP(hipMemcpy(rr.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
+        std::vector<int32_t> failed;
+        for (int32_t b : todo)
+            if (rr[b] == -2)
+                failed.push_back(b);
+        if (failed.empty())
+            break;
+        if (phase_timing)
+            fprintf(stderr, "[hmx build]   round %d: %zu of %zu blocks found the pool of %.2f GB exhausted\n", round, failed.size(), todo.size(), (double)cap * sizeof(scalar) / 1e9);
+        const int rcg = grow_pool();
+        if (rcg == 1)
+            break; // reported below as an exhausted pool
+        if (rcg != HMX_OK)
+            return rcg;
+        todo.swap(failed);
         }
     } else if (!order.empty() && use_cb) {
         // lock-step ACA: the generator runs on the host (on all cores: "Host generator on all cores" above), everything else on the
@@ -2927,8 +2952,6 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     int64_t false_pos = 0;
     for (int32_t b : order) {
         if (ranks[b] == -2) {
-            if (!full_pool && assembled)
-                return 1; // the rank estimate was too low: repeat with the whole budget (the ACA variants have grown their pool by themselves)
             set_error("hmx_hmatrix_compress: compression pool exhausted (not enough free HBM)");
             return HMX_ERR_HIP;
         }

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 REAL = ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_p2_symU_rank1", "rect_ball1500_disk1000", "ball_n1200_fullACA", "ball_n1200_SVD",
         "ball_n1200_reqrank5", "ball_n2000_n_bbox_c8"]
 COMPLEX = ["ball_n2000_z64_hermU", "ball_n2000_z64_partial", "ball_n1200_z64_fullACA"]
+SINGLE = ["ellipse_n3000_f32_partial", "ellipse_n3000_f32_symL_eps1e-6", "ball_n2000_c32_hermL", "ellipse_n3000_c32_partial"]
 NP = {"f64": np.float64, "f32": np.float32, "z64": np.complex128, "c32": np.complex64}
 
 
@@ -48,14 +49,16 @@ def same_operator(Hd, Hh):
 
 
 @pytest.mark.parametrize("threads", [1, 0, 7])
-@pytest.mark.parametrize("name", REAL + COMPLEX)
+@pytest.mark.parametrize("name", REAL + COMPLEX + SINGLE)
 def test_compiled_generator_on_all_threads_builds_the_device_operator(name, threads):
     p, g = params(name), load(name)
     Hd, Hh = both_routes(p, threads)
     same_operator(Hd, Hh)
     ref = g["leaves"]
     tab = Hh.leaf_table()
-    if p["compressor"] == "SVD":
+    if p["prec"] in ("f32", "c32"):  # single precision: the two routes agree bit for bit (above); against the reference the structure is exact and
+        assert np.array_equal(tab[:, :4], ref[:, :4])  # the ranks are compared where tests/test_gpu_parity.py / test_gpu_complex.py compare them
+    elif p["compressor"] == "SVD":
         assert np.array_equal(tab[:, :4], ref[:, :4]) and np.abs(tab[:, 4] - ref[:, 4]).max() <= 1
     else:
         assert np.array_equal(tab, ref)

@@ -694,11 +694,11 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
             assert rel_err(Y, Ho.matmat_row_major(X, "T", 1.5, -0.5, Y0)) < 1e-12
 
 
-@pytest.mark.parametrize("name", ["ellipse_n3000_partial", "ball_n1500_eps1e-12", "ball_n1200_fullACA", "ball_n2000_symL_eta3"])
+@pytest.mark.parametrize("name", ["ellipse_n3000_partial", "ball_n1500_eps1e-12", "ball_n1200_fullACA", "ball_n1200_SVD", "ball_n2000_symL_eta3"])
 def test_pool_estimate_too_low_is_retried(name, monkeypatch):
     """The cross pool is sized from a rank estimate.  When the pool runs out, the blocks of the device ACA suspend, the pool grows and
-    they continue with their next iteration (several rounds with a guess of 1); fullACA / SVD repeat the compression with the whole
-    budget.  Either way the operator is the one the reference builds."""
+    they continue with their next iteration (several rounds with a guess of 1); the blocks of fullACA / SVD that found it exhausted --
+    and only they -- are compressed again after it has grown.  Either way the operator is the one the reference builds."""
     p, g = params(name), load(name)
     monkeypatch.setenv("HMX_POOL_RANK_GUESS", "1")
     T, S, H = build_engine(p)
