@@ -40,6 +40,8 @@ struct HMat {
     bool sym_expanded = false; // ... and they were laid out explicitly (no mirror pass needed)
     // compact symmetric storage, fused product (expand_sym_kernel / rowsym_kernel): slots in SW = [a' | EW (column sums, E-column order)]
     bool sym_fused = false;
+    bool trans_tables_failed = false;
+    bool trans_fused = false; // tables of the transposed product on the stored data present (build_trans_tables): s_* below, output rows = source positions
     DArr<int32_t> s_mdst, s_coef, s_count, s_list, s_fidx;
     DArr<int64_t> s_sub_ptr;
     DArr<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order; // second R sweep: per row interval the (parts of) tasks inside it
@@ -133,6 +135,299 @@ struct HMat {
 };
 
 
+// ---- mirrored products: slots of the partial results ------------------------------------------------------------------------------
+// The tables behind the fused symmetric product (every leaf of the stored triangle is also applied transposed) and -- `tmode`, round 4 --
+// behind the TRANSPOSED product of an ordinary operator on its stored data (every leaf is applied transposed ONLY; the reference swaps the
+// cluster roles on the same leaves, hmatrix/linalg/add_hmatrix_vector_product.hpp:74-81): the output rows are then the SOURCE positions.
+struct MirrorCtx {
+    const std::vector<hmx_leaf> &XL;
+    const std::vector<int> &XK;
+    int64_t nb;
+    const std::vector<int32_t> &elr_b, &elr_r, &elr_c, &ed_b, &ed_r, &ed_c, &rlr_b, &rlr_r, &rlr_c; // (leaf, range, first column) pairs of the E- / R-streams
+    const std::vector<int64_t> &aoff;
+    int64_t A_total;
+    bool tmode;
+    std::function<void(const char *)> phase;
+};
+static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
+    StreamSet &E = H.E, &R = H.R;
+    const std::vector<hmx_leaf> &XL = M.XL;
+    const std::vector<int> &XK      = M.XK;
+    const int64_t nb = M.nb, A_total = M.A_total;
+    const std::vector<int32_t> &elr_b = M.elr_b, &elr_r = M.elr_r, &elr_c = M.elr_c, &ed_b = M.ed_b, &ed_r = M.ed_r, &ed_c = M.ed_c, &rlr_b = M.rlr_b, &rlr_r = M.rlr_r, &rlr_c = M.rlr_c;
+    const std::vector<int64_t> &aoff = M.aoff;
+    const bool tmode = M.tmode;
+    auto phase_nosync = [&](const char *name) {
+        if (M.phase)
+            M.phase(name);
+    };
+    const int nOut    = tmode ? H.nS : H.nT;     // output rows of the mirrored products
+    const int r_shift = tmode ? 0 : H.S0 - H.T0; // R piece offset (source-local) -> output row
+    const int d_base  = tmode ? H.S0 : H.T0;     // global column of a dense leaf -> output row
+    auto is_mir       = [&](int64_t b) { return tmode || XL[b].mirror != 0; };
+    // W = [a' | EW].  expand_sym_kernel stores the column sums of a row range at EW[epad(range) + column] (E-column order: one
+    // contiguous, 128-byte aligned run per range).  combine_list_kernel folds the partial a' of a leaf that spans several ranges
+    // through a list of its column-group positions.  The second R sweep (rowsym_kernel) is owner-computes: one workgroup per interval
+    // of SYM_IR target rows applies every (part of a) task inside it, folds the row sums in LDS, adds the interval's dense mirrored
+    // column sums (EW, through a level-major index) and updates y once.  All in a fixed order: results are bit-reproducible.
+    hvec32 s_mdst, s_coef;
+    std::vector<int32_t> s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
+    std::unique_ptr<int32_t[]> s_fidx; // level-major, s_kmax x nT: left uninitialised (only the entries below count[j] are ever read)
+    size_t s_fidx_n = 0;
+    std::vector<int64_t> s_sub_ptr;
+    std::vector<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order;
+    std::vector<int64_t> p64; // the same tables for intervals of 64 rows (multi-RHS form of the second sweep)
+    std::vector<int32_t> t64, r64, n64, d64, o64;
+    H.n_sym_combine = 0;
+    H.s_kmax        = 0;
+    int64_t s_total = 0;
+    s_mdst.resize(E.total_cols); // sized without initialisation, filled by several threads
+    s_coef.resize(R.total_cols);
+    parallel_for(s_mdst.size(), [&](size_t lo, size_t hi) { std::fill(s_mdst.begin() + lo, s_mdst.begin() + hi, -1); });
+    parallel_for(s_coef.size(), [&](size_t lo, size_t hi) { std::fill(s_coef.begin() + lo, s_coef.begin() + hi, -1); });
+    s_cnt.assign(nOut, 0);
+    bool bad = false;
+    std::vector<int64_t> epad(E.nranges());
+    int64_t EWN = 0;
+    for (int r = 0; r < E.nranges(); r++) {
+        epad[r] = EWN;
+        EWN += (E.cols[r] + 15) & ~15;
+    }
+    const int64_t EWBASE = (A_total + 15) & ~int64_t(15), RWBASE = EWBASE + EWN;
+    // low-rank mirrored leaves: column sums land in EW; a leaf inside ONE range is complete there (a' is read from EW),
+    // otherwise a list of its column-group positions feeds combine_list_kernel, which writes a'[aoff + k]
+    std::vector<int32_t> nrange(nb, 0);
+    for (size_t p = 0; p < elr_b.size(); p++)
+        nrange[elr_b[p]]++;
+    std::vector<int64_t> lptr(nb, -1);
+    int64_t LN = 0;
+    for (int64_t b = 0; b < nb; b++)
+        if (is_mir(b) && XK[b] == LK_LOWRANK && XL[b].rank > 0 && nrange[b] > 1) {
+            lptr[b] = LN;
+            LN += nrange[b];
+        }
+    phase_nosync("  sym: setup");
+    s_list.assign(LN, 0);
+    std::vector<int64_t> single_slot(nb, -1);
+    {
+        // the pairs of a leaf are consecutive in elr_* (leaf-major) and cover consecutive ranges: position in the leaf's list = r - first range
+        std::vector<int32_t> first_range(nb, -1);
+        for (size_t p = 0; p < elr_b.size(); p++)
+            if (first_range[elr_b[p]] < 0)
+                first_range[elr_b[p]] = elr_r[p];
+        parallel_for(elr_b.size(), [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; p++) {
+                const int b = elr_b[p], r = elr_r[p];
+                if (!is_mir(b))
+                    continue;
+                const int64_t base = EWBASE + epad[r] + elr_c[p];
+                if (nrange[b] == 1)
+                    single_slot[b] = base;
+                else
+                    s_list[lptr[b] + (r - first_range[b])] = (int32_t)base;
+                int32_t *dst = s_mdst.data() + E.colbase[r] + elr_c[p];
+                for (int k = 0; k < XL[b].rank; k++)
+                    dst[k] = (int32_t)(base + k);
+            }
+        });
+    }
+    phase_nosync("  sym: lr columns");
+    H.n_sym_combine_wave = 0;
+    {
+        size_t entries = 0;
+        for (int64_t b = 0; b < nb; b++)
+            if (lptr[b] >= 0)
+                entries += (size_t)XL[b].rank;
+        for (auto *v : {&s_cd, &s_clp, &s_cc, &s_ck})
+            v->reserve(entries);
+    }
+    for (int pass = 0; pass < 2; pass++) // entries with many partial sums first (one wave each), then the rest (one thread each)
+        for (int64_t b = 0; b < nb; b++)
+            if (lptr[b] >= 0 && (nrange[b] >= 32) == (pass == 0)) {
+                for (int k = 0; k < XL[b].rank; k++) {
+                    s_cd.push_back((int32_t)(aoff[b] + k));
+                    s_clp.push_back((int32_t)lptr[b]);
+                    s_cc.push_back(nrange[b]);
+                    s_ck.push_back(k);
+                }
+                if (pass == 0)
+                    H.n_sym_combine_wave += XL[b].rank;
+            }
+    phase_nosync("  sym: combine entries");
+    parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
+        for (size_t p = lo; p < hi; p++) {
+            const int b = rlr_b[p];
+            if (!is_mir(b))
+                continue;
+            const int64_t base = single_slot[b] >= 0 ? single_slot[b] : aoff[b];
+            int32_t *dst       = s_coef.data() + R.colbase[rlr_r[p]] + rlr_c[p];
+            for (int k = 0; k < XL[b].rank; k++)
+                dst[k] = (int32_t)(base + k);
+        }
+    });
+    phase_nosync("  sym: coef");
+    // Second R sweep, owner-computes: the target rows are cut into intervals of SYM_IR rows and ONE workgroup per interval applies
+    // every (piece, chunk) task -- or the part of it -- whose rows lie in the interval, folds the row sums of its waves in LDS,
+    // adds the interval's dense mirrored contributions (EW, through the level index) and updates y once.  No partial row sums
+    // leave the chip (they were 76 MB per product at N=1e6, written and read again), no separate folding kernel.
+    const size_t ntask = R.task_range.size();
+    std::vector<char> task_mirror(ntask, 0);
+    for (size_t t = 0; t < ntask; t++) {
+        const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
+        const int w = std::min(cw, R.cols[r] - ch * cw);
+        const int32_t *cf = s_coef.data() + R.colbase[r] + (int64_t)ch * cw;
+        bool any = false;
+        for (int c = 0; c < w && !any; c++)
+            any = cf[c] >= 0;
+        if (!any)
+            continue;
+        const int j0 = R.off[r] + r_shift;
+        if (j0 < 0 || j0 + R.len[r] > nOut) {
+            bad = true;
+            break;
+        }
+        task_mirror[t] = 1;
+    }
+    // the sub-task lists of the intervals of IR rows (launch order of the tasks = order inside every interval's list), heaviest interval first
+    auto build_intervals = [&](int IR, std::vector<int64_t> &sub_ptr, std::vector<int32_t> &sub_task, std::vector<int32_t> &sub_row0, std::vector<int32_t> &sub_nrows,
+                               std::vector<int32_t> &sub_dst, std::vector<int32_t> &int_order) -> int {
+        const int nint = (nOut + IR - 1) / IR;
+        std::vector<int64_t> sub_count(nint + 1, 0);
+        for (size_t t = 0; t < ntask; t++) {
+            if (!task_mirror[t])
+                continue;
+            const int r = R.task_range[t], j0 = R.off[r] + r_shift;
+            for (int I = j0 / IR; I <= (j0 + R.len[r] - 1) / IR; I++)
+                sub_count[I + 1]++;
+        }
+        for (int I = 0; I < nint; I++)
+            sub_count[I + 1] += sub_count[I];
+        sub_ptr            = sub_count;
+        const int64_t nsub = sub_count[nint];
+        sub_task.assign(nsub, 0);
+        sub_row0.assign(nsub, 0);
+        sub_nrows.assign(nsub, 0);
+        sub_dst.assign(nsub, 0);
+        std::vector<double> int_work(nint, 0.0);
+        std::vector<int64_t> pos(sub_count.begin(), sub_count.end() - 1);
+        for (size_t t = 0; t < ntask; t++) {
+            if (!task_mirror[t])
+                continue;
+            const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
+            const int w = std::min(cw, R.cols[r] - ch * cw);
+            const int j0 = R.off[r] + r_shift, j1 = j0 + R.len[r];
+            for (int I = j0 / IR; I <= (j1 - 1) / IR; I++) {
+                const int lo = std::max(j0, I * IR), hi = std::min(j1, (I + 1) * IR);
+                const int64_t q = pos[I]++;
+                sub_task[q]  = (int32_t)t;
+                sub_row0[q]  = lo - j0;
+                sub_nrows[q] = hi - lo;
+                sub_dst[q]   = lo - I * IR;
+                int_work[I] += (double)(hi - lo) * w + 256;
+            }
+        }
+        int_order.resize(nint);
+        std::iota(int_order.begin(), int_order.end(), 0);
+        std::stable_sort(int_order.begin(), int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
+        return nint;
+    };
+    int nint = 0;
+    if (!bad)
+        nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order);
+#if !HMX_COMPLEX
+    // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows); only a square operator runs it
+    H.s64_nint = 0;
+    if (!bad && !tmode && H.T0 == H.S0 && H.nT == H.nS)
+        H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64);
+#endif
+    phase_nosync("  sym: tasks");
+    // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
+    for (size_t p = 0; p < ed_b.size() && !bad; p++) {
+        const hmx_leaf &l = XL[ed_b[p]];
+        if (!(tmode || l.mirror))
+            continue;
+        const int j0 = l.s_offset - d_base;
+        if (j0 < 0 || j0 + l.s_size > nOut) {
+            bad = true;
+            break;
+        }
+        for (int j = 0; j < l.s_size; j++)
+            s_cnt[j0 + j]++;
+    }
+    if (bad) {
+        set_error("symmetric storage needs the mirrored leaves' source clusters inside the target rows of the operator");
+        return HMX_ERR_UNSUPPORTED;
+    }
+    s_total = RWBASE;
+    for (int32_t c : s_cnt)
+        H.s_kmax = std::max(H.s_kmax, (int)c);
+    if (s_total >= (int64_t(1) << 31) - 1 || (int64_t)H.s_kmax * nOut >= (int64_t(1) << 40)) {
+        set_error("operator too large for 32-bit slots of the fused symmetric product (HMX_SYM_EXPANDED=1 selects the expanded layout)");
+        return HMX_ERR_UNSUPPORTED;
+    }
+    phase_nosync("  sym: dense count");
+    s_fidx_n = (size_t)H.s_kmax * nOut;
+    s_fidx.reset(new int32_t[std::max<size_t>(s_fidx_n, 1)]);
+    std::vector<int32_t> fill(nOut, 0);
+    // every thread owns an interval of the mirrored columns and walks ALL pairs (leaf-major), clipped to its interval: the levels of a
+    // column are numbered in the pairs' order, as the one-thread loop numbers them
+    parallel_for((size_t)nOut, [&](size_t clo, size_t chi) {
+        for (size_t p = 0; p < ed_b.size(); p++) {
+            const int b = ed_b[p], r = ed_r[p];
+            const hmx_leaf &l = XL[b];
+            if (!(tmode || l.mirror))
+                continue;
+            const int j0 = l.s_offset - d_base;
+            const int ja = std::max(0, (int)clo - j0), jb = std::min((int)l.s_size, (int)chi - j0);
+            if (ja >= jb)
+                continue;
+            const int64_t base = EWBASE + epad[r] + ed_c[p];
+            int32_t *dst       = s_mdst.data() + E.colbase[r] + ed_c[p];
+            for (int j = ja; j < jb; j++) {
+                dst[j]                                               = (int32_t)(base + j);
+                s_fidx[(size_t)(fill[j0 + j]++) * nOut + (j0 + j)] = (int32_t)(base + j);
+            }
+        }
+    });
+    H.s_nint = nint;
+    phase_nosync("  sym: fidx fill");
+    H.n_sym_combine = (int)s_cd.size();
+    phase_nosync("fused symmetric slots");
+
+    // ---- uploads (the first one waits for whatever is queued on the null stream: the pack kernels of build_streams) ----
+    HMX_HIP(H.s_mdst.upload(s_mdst));
+    HMX_HIP(H.s_coef.upload(s_coef));
+    HMX_HIP(H.s_count.upload(s_cnt));
+    HMX_HIP(H.s_sub_ptr.upload(s_sub_ptr));
+    HMX_HIP(H.s_sub_task.upload(s_sub_task));
+    HMX_HIP(H.s_sub_row0.upload(s_sub_row0));
+    HMX_HIP(H.s_sub_nrows.upload(s_sub_nrows));
+    HMX_HIP(H.s_sub_dst.upload(s_sub_dst));
+    HMX_HIP(H.s_int_order.upload(s_int_order));
+    HMX_HIP(H.sc_dst.upload(s_cd));
+    HMX_HIP(H.sc_lp.upload(s_clp));
+    HMX_HIP(H.sc_count.upload(s_cc));
+    HMX_HIP(H.sc_k.upload(s_ck));
+    HMX_HIP(H.s_list.upload(s_list));
+    HMX_HIP(H.s_fidx.alloc(std::max<size_t>(s_fidx_n, 1)));
+    if (s_fidx_n)
+        HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HMX_HIP(H.SW.alloc(s_total + 1));
+    H.s_slots = s_total;
+#if !HMX_COMPLEX
+    H.SW16.release();
+    if (H.s64_nint > 0) {
+        HMX_HIP(H.s64_sub_ptr.upload(p64));
+        HMX_HIP(H.s64_sub_task.upload(t64));
+        HMX_HIP(H.s64_sub_row0.upload(r64));
+        HMX_HIP(H.s64_sub_nrows.upload(n64));
+        HMX_HIP(H.s64_sub_dst.upload(d64));
+        HMX_HIP(H.s64_int_order.upload(o64));
+    }
+#endif
+    return HMX_OK;
+}
+
 static int build_streams(HMat &H) {
     Timer tim;
     const bool phase_timing = getenv("HMX_BUILD_TIMING") && atoi(getenv("HMX_BUILD_TIMING"));
@@ -175,7 +470,7 @@ static int build_streams(HMat &H) {
     if (!H.view_of) { // the layout changes: views built earlier are stale
         H.T_op.reset();
         H.X_op.reset();
-        H.T_op_failed = H.X_op_failed = false;
+        H.T_op_failed = H.X_op_failed = H.trans_tables_failed = false;
     }
     std::vector<hmx_leaf> XL = H.leaves;
     std::vector<int> XK      = H.kind;
@@ -758,236 +1053,15 @@ static int build_streams(HMat &H) {
     H.n_combine = (int)cd.size();
     // transposed-pass destinations are derived from h_e_zidx on first use (ensure_transposed_indices)
 
-    // ---- fused symmetric product: slots of the mirrored partial results ----------------------------------------------------
-    // W = [a' | EW].  expand_sym_kernel stores the column sums of a row range at EW[epad(range) + column] (E-column order: one
-    // contiguous, 128-byte aligned run per range).  combine_list_kernel folds the partial a' of a leaf that spans several ranges
-    // through a list of its column-group positions.  The second R sweep (rowsym_kernel) is owner-computes: one workgroup per interval
-    // of SYM_IR target rows applies every (part of a) task inside it, folds the row sums in LDS, adds the interval's dense mirrored
-    // column sums (EW, through a level-major index) and updates y once.  All in a fixed order: results are bit-reproducible.
-    hvec32 s_mdst, s_coef;
-    std::vector<int32_t> s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
-    std::unique_ptr<int32_t[]> s_fidx; // level-major, s_kmax x nT: left uninitialised (only the entries below count[j] are ever read)
-    size_t s_fidx_n = 0;
-    std::vector<int64_t> s_sub_ptr;
-    std::vector<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order;
-    std::vector<int64_t> p64; // the same tables for intervals of 64 rows (multi-RHS form of the second sweep)
-    std::vector<int32_t> t64, r64, n64, d64, o64;
+    // ---- fused symmetric product: slots of the mirrored partial results (build_mirror_tables) -------------------------------------------
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
-    int64_t s_total = 0;
+    H.trans_fused   = false; // the tables of the stored-data transposed product belonged to the layout that is being replaced
     if (H.sym_fused) {
-        s_mdst.resize(E.total_cols); // sized without initialisation, filled by several threads
-        s_coef.resize(R.total_cols);
-        parallel_for(s_mdst.size(), [&](size_t lo, size_t hi) { std::fill(s_mdst.begin() + lo, s_mdst.begin() + hi, -1); });
-        parallel_for(s_coef.size(), [&](size_t lo, size_t hi) { std::fill(s_coef.begin() + lo, s_coef.begin() + hi, -1); });
-        s_cnt.assign(H.nT, 0);
-        bool bad = false;
-        std::vector<int64_t> epad(E.nranges());
-        int64_t EWN = 0;
-        for (int r = 0; r < E.nranges(); r++) {
-            epad[r] = EWN;
-            EWN += (E.cols[r] + 15) & ~15;
-        }
-        const int64_t EWBASE = (A_total + 15) & ~int64_t(15), RWBASE = EWBASE + EWN;
-        // low-rank mirrored leaves: column sums land in EW; a leaf inside ONE range is complete there (a' is read from EW),
-        // otherwise a list of its column-group positions feeds combine_list_kernel, which writes a'[aoff + k]
-        std::vector<int32_t> nrange(nb, 0);
-        for (size_t p = 0; p < elr_b.size(); p++)
-            nrange[elr_b[p]]++;
-        std::vector<int64_t> lptr(nb, -1);
-        int64_t LN = 0;
-        for (int64_t b = 0; b < nb; b++)
-            if (XL[b].mirror && XK[b] == LK_LOWRANK && XL[b].rank > 0 && nrange[b] > 1) {
-                lptr[b] = LN;
-                LN += nrange[b];
-            }
-        phase_nosync("  sym: setup");
-        s_list.assign(LN, 0);
-        std::vector<int64_t> single_slot(nb, -1);
-        {
-            // the pairs of a leaf are consecutive in elr_* (leaf-major) and cover consecutive ranges: position in the leaf's list = r - first range
-            std::vector<int32_t> first_range(nb, -1);
-            for (size_t p = 0; p < elr_b.size(); p++)
-                if (first_range[elr_b[p]] < 0)
-                    first_range[elr_b[p]] = elr_r[p];
-            parallel_for(elr_b.size(), [&](size_t lo, size_t hi) {
-                for (size_t p = lo; p < hi; p++) {
-                    const int b = elr_b[p], r = elr_r[p];
-                    if (!XL[b].mirror)
-                        continue;
-                    const int64_t base = EWBASE + epad[r] + elr_c[p];
-                    if (nrange[b] == 1)
-                        single_slot[b] = base;
-                    else
-                        s_list[lptr[b] + (r - first_range[b])] = (int32_t)base;
-                    int32_t *dst = s_mdst.data() + E.colbase[r] + elr_c[p];
-                    for (int k = 0; k < XL[b].rank; k++)
-                        dst[k] = (int32_t)(base + k);
-                }
-            });
-        }
-        phase_nosync("  sym: lr columns");
-        H.n_sym_combine_wave = 0;
-        {
-            size_t entries = 0;
-            for (int64_t b = 0; b < nb; b++)
-                if (lptr[b] >= 0)
-                    entries += (size_t)XL[b].rank;
-            for (auto *v : {&s_cd, &s_clp, &s_cc, &s_ck})
-                v->reserve(entries);
-        }
-        for (int pass = 0; pass < 2; pass++) // entries with many partial sums first (one wave each), then the rest (one thread each)
-            for (int64_t b = 0; b < nb; b++)
-                if (lptr[b] >= 0 && (nrange[b] >= 32) == (pass == 0)) {
-                    for (int k = 0; k < XL[b].rank; k++) {
-                        s_cd.push_back((int32_t)(aoff[b] + k));
-                        s_clp.push_back((int32_t)lptr[b]);
-                        s_cc.push_back(nrange[b]);
-                        s_ck.push_back(k);
-                    }
-                    if (pass == 0)
-                        H.n_sym_combine_wave += XL[b].rank;
-                }
-        phase_nosync("  sym: combine entries");
-        parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
-            for (size_t p = lo; p < hi; p++) {
-                const int b = rlr_b[p];
-                if (!XL[b].mirror)
-                    continue;
-                const int64_t base = single_slot[b] >= 0 ? single_slot[b] : aoff[b];
-                int32_t *dst       = s_coef.data() + R.colbase[rlr_r[p]] + rlr_c[p];
-                for (int k = 0; k < XL[b].rank; k++)
-                    dst[k] = (int32_t)(base + k);
-            }
-        });
-        phase_nosync("  sym: coef");
-        // Second R sweep, owner-computes: the target rows are cut into intervals of SYM_IR rows and ONE workgroup per interval applies
-        // every (piece, chunk) task -- or the part of it -- whose rows lie in the interval, folds the row sums of its waves in LDS,
-        // adds the interval's dense mirrored contributions (EW, through the level index) and updates y once.  No partial row sums
-        // leave the chip (they were 76 MB per product at N=1e6, written and read again), no separate folding kernel.
-        const size_t ntask = R.task_range.size();
-        std::vector<char> task_mirror(ntask, 0);
-        for (size_t t = 0; t < ntask; t++) {
-            const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
-            const int w = std::min(cw, R.cols[r] - ch * cw);
-            const int32_t *cf = s_coef.data() + R.colbase[r] + (int64_t)ch * cw;
-            bool any = false;
-            for (int c = 0; c < w && !any; c++)
-                any = cf[c] >= 0;
-            if (!any)
-                continue;
-            const int j0 = R.off[r] + H.S0 - H.T0;
-            if (j0 < 0 || j0 + R.len[r] > H.nT) {
-                bad = true;
-                break;
-            }
-            task_mirror[t] = 1;
-        }
-        // the sub-task lists of the intervals of IR rows (launch order of the tasks = order inside every interval's list), heaviest interval first
-        auto build_intervals = [&](int IR, std::vector<int64_t> &sub_ptr, std::vector<int32_t> &sub_task, std::vector<int32_t> &sub_row0, std::vector<int32_t> &sub_nrows,
-                                   std::vector<int32_t> &sub_dst, std::vector<int32_t> &int_order) -> int {
-            const int nint = (H.nT + IR - 1) / IR;
-            std::vector<int64_t> sub_count(nint + 1, 0);
-            for (size_t t = 0; t < ntask; t++) {
-                if (!task_mirror[t])
-                    continue;
-                const int r = R.task_range[t], j0 = R.off[r] + H.S0 - H.T0;
-                for (int I = j0 / IR; I <= (j0 + R.len[r] - 1) / IR; I++)
-                    sub_count[I + 1]++;
-            }
-            for (int I = 0; I < nint; I++)
-                sub_count[I + 1] += sub_count[I];
-            sub_ptr            = sub_count;
-            const int64_t nsub = sub_count[nint];
-            sub_task.assign(nsub, 0);
-            sub_row0.assign(nsub, 0);
-            sub_nrows.assign(nsub, 0);
-            sub_dst.assign(nsub, 0);
-            std::vector<double> int_work(nint, 0.0);
-            std::vector<int64_t> pos(sub_count.begin(), sub_count.end() - 1);
-            for (size_t t = 0; t < ntask; t++) {
-                if (!task_mirror[t])
-                    continue;
-                const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
-                const int w = std::min(cw, R.cols[r] - ch * cw);
-                const int j0 = R.off[r] + H.S0 - H.T0, j1 = j0 + R.len[r];
-                for (int I = j0 / IR; I <= (j1 - 1) / IR; I++) {
-                    const int lo = std::max(j0, I * IR), hi = std::min(j1, (I + 1) * IR);
-                    const int64_t q = pos[I]++;
-                    sub_task[q]  = (int32_t)t;
-                    sub_row0[q]  = lo - j0;
-                    sub_nrows[q] = hi - lo;
-                    sub_dst[q]   = lo - I * IR;
-                    int_work[I] += (double)(hi - lo) * w + 256;
-                }
-            }
-            int_order.resize(nint);
-            std::iota(int_order.begin(), int_order.end(), 0);
-            std::stable_sort(int_order.begin(), int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
-            return nint;
-        };
-        int nint = 0;
-        if (!bad)
-            nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order);
-#if !HMX_COMPLEX
-        // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows); only a square operator runs it
-        H.s64_nint = 0;
-        if (!bad && H.T0 == H.S0 && H.nT == H.nS)
-            H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64);
-#endif
-        phase_nosync("  sym: tasks");
-        // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
-        for (size_t p = 0; p < ed_b.size() && !bad; p++) {
-            const hmx_leaf &l = XL[ed_b[p]];
-            if (!l.mirror)
-                continue;
-            const int j0 = l.s_offset - H.T0;
-            if (j0 < 0 || j0 + l.s_size > H.nT) {
-                bad = true;
-                break;
-            }
-            for (int j = 0; j < l.s_size; j++)
-                s_cnt[j0 + j]++;
-        }
-        if (bad) {
-            set_error("symmetric storage needs the mirrored leaves' source clusters inside the target rows of the operator");
-            return HMX_ERR_UNSUPPORTED;
-        }
-        s_total = RWBASE;
-        for (int32_t c : s_cnt)
-            H.s_kmax = std::max(H.s_kmax, (int)c);
-        if (s_total >= (int64_t(1) << 31) - 1 || (int64_t)H.s_kmax * H.nT >= (int64_t(1) << 40)) {
-            set_error("operator too large for 32-bit slots of the fused symmetric product (HMX_SYM_EXPANDED=1 selects the expanded layout)");
-            return HMX_ERR_UNSUPPORTED;
-        }
-        phase_nosync("  sym: dense count");
-        s_fidx_n = (size_t)H.s_kmax * H.nT;
-        s_fidx.reset(new int32_t[std::max<size_t>(s_fidx_n, 1)]);
-        std::vector<int32_t> fill(H.nT, 0);
-        // every thread owns an interval of the mirrored columns and walks ALL pairs (leaf-major), clipped to its interval: the levels of a
-        // column are numbered in the pairs' order, as the one-thread loop numbers them
-        parallel_for((size_t)H.nT, [&](size_t clo, size_t chi) {
-            for (size_t p = 0; p < ed_b.size(); p++) {
-                const int b = ed_b[p], r = ed_r[p];
-                const hmx_leaf &l = XL[b];
-                if (!l.mirror)
-                    continue;
-                const int j0 = l.s_offset - H.T0;
-                const int ja = std::max(0, (int)clo - j0), jb = std::min((int)l.s_size, (int)chi - j0);
-                if (ja >= jb)
-                    continue;
-                const int64_t base = EWBASE + epad[r] + ed_c[p];
-                int32_t *dst       = s_mdst.data() + E.colbase[r] + ed_c[p];
-                for (int j = ja; j < jb; j++) {
-                    dst[j]                                               = (int32_t)(base + j);
-                    s_fidx[(size_t)(fill[j0 + j]++) * H.nT + (j0 + j)] = (int32_t)(base + j);
-                }
-            }
-        });
-        H.s_nint = nint;
-        phase_nosync("  sym: fidx fill");
-        H.n_sym_combine = (int)s_cd.size();
-        phase_nosync("fused symmetric slots");
+        MirrorCtx M{XL, XK, nb, elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c, aoff, A_total, false, [&](const char *n) { phase_nosync(n); }};
+        const int rcm = build_mirror_tables(H, M);
+        if (rcm != HMX_OK)
+            return rcm;
     }
 
     phase_nosync("index arrays");
@@ -1001,38 +1075,6 @@ static int build_streams(HMat &H) {
     HMX_HIP(H.Z.alloc(H.zero_slot + 1));
     HMX_HIP(H.Z.zero());
     HMX_HIP(H.W.alloc(std::max(H.nS, H.nT) + A_total + 1));
-    if (H.sym_fused) {
-        HMX_HIP(H.s_mdst.upload(s_mdst));
-        HMX_HIP(H.s_coef.upload(s_coef));
-        HMX_HIP(H.s_count.upload(s_cnt));
-        HMX_HIP(H.s_sub_ptr.upload(s_sub_ptr));
-        HMX_HIP(H.s_sub_task.upload(s_sub_task));
-        HMX_HIP(H.s_sub_row0.upload(s_sub_row0));
-        HMX_HIP(H.s_sub_nrows.upload(s_sub_nrows));
-        HMX_HIP(H.s_sub_dst.upload(s_sub_dst));
-        HMX_HIP(H.s_int_order.upload(s_int_order));
-        HMX_HIP(H.sc_dst.upload(s_cd));
-        HMX_HIP(H.sc_lp.upload(s_clp));
-        HMX_HIP(H.sc_count.upload(s_cc));
-        HMX_HIP(H.sc_k.upload(s_ck));
-        HMX_HIP(H.s_list.upload(s_list));
-        HMX_HIP(H.s_fidx.alloc(std::max<size_t>(s_fidx_n, 1)));
-        if (s_fidx_n)
-            HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
-        HMX_HIP(H.SW.alloc(s_total + 1));
-        H.s_slots = s_total;
-#if !HMX_COMPLEX
-        H.SW16.release();
-        if (H.s64_nint > 0) {
-            HMX_HIP(H.s64_sub_ptr.upload(p64));
-            HMX_HIP(H.s64_sub_task.upload(t64));
-            HMX_HIP(H.s64_sub_row0.upload(r64));
-            HMX_HIP(H.s64_sub_nrows.upload(n64));
-            HMX_HIP(H.s64_sub_dst.upload(d64));
-            HMX_HIP(H.s64_int_order.upload(o64));
-        }
-#endif
-    }
     HMX_HIP(hipEventSynchronize(e1));
     HMX_HIP(hipDeviceSynchronize()); // an error of the pack kernels surfaces here
     pack_guard.armed = false;
@@ -1207,7 +1249,7 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         if (H.s_nint > 0) {
             RowSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d,
                          H.s_int_order.d, H.s_sub_ptr.d, H.s_sub_task.d, H.s_sub_row0.d, H.s_sub_nrows.d, H.s_sub_dst.d,
-                         H.SW.d, H.s_fidx.d, H.s_count.d, y, alpha, H.nT, H.symmetry_for_leaves == 'H' ? 1 : 0};
+                         H.SW.d, H.s_fidx.d, H.s_count.d, y, alpha, H.nT, H.symmetry_for_leaves == 'H' ? 1 : 0, scalar(0), 1};
             hipLaunchKernelGGL(rowsym_kernel<SYM_WAVES>, dim3(H.s_nint), dim3(SYM_WAVES * 64), 0, st, A);
             prof_mark(H, st, "rowsym_kernel");
         }
@@ -1237,6 +1279,132 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_
         default: hipLaunchKernelGGL(expand_kernel<4>, dim3(H.E.nranges()), dim3(256), 0, st, X); break;
         }
         prof_mark(H, st, "expand_kernel");
+    }
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+// ---- the transposed product on the STORED data (round 4) ------------------------------------------------------------------------------
+// y_s = alpha A^T x_t + beta y_s of an ordinary ('N') operator without a second layout and without atomics: the reference swaps the cluster
+// roles on the same leaves (hmatrix/linalg/add_hmatrix_vector_product.hpp:74-81); here the machinery of the fused symmetric product runs with
+// every leaf mirrored and nothing applied forward:
+//   expand_sym_kernel<W, false>   one sweep over the E-streams: column sums E^T x_t per row range -- a slice of a' = U^T x_t for a low-rank leaf,
+//                                 the leaf's contribution to an output row for a dense one -- into their slots
+//   combine_list_kernel           a' of the leaves that span several row ranges, fixed order
+//   rowsym_kernel                 one sweep over the R-streams, owner-computes: y_s = alpha (V^T a' + dense contributions) + beta y_s
+// The tables (slot per E column, coefficient slot per R column, the intervals' sub-task lists, the dense contributions per output row: about
+// 3 % of the operator's bytes) are built on demand by build_trans_tables -- hmx_hmatrix_prepare(H, 'T', ...) or the first such product.
+// Every stored coefficient is read once, as in the forward product; fixed summation order: bit-reproducible.
+static int build_trans_tables(HMat &H) {
+    if (H.trans_fused)
+        return HMX_OK;
+    if (!H.finalized || H.has_mirror || H.view_of)
+        return HMX_ERR_UNSUPPORTED;
+    HMX_HIP(hipSetDevice(H.device));
+    const StreamSet &E = H.E, &R = H.R;
+    const int64_t nb   = (int64_t)H.leaves.size();
+    const int nre = E.nranges(), nrr = R.nranges();
+    // the (leaf, range, first column) pairs of the layout: columns were given out leaf by leaf in the leaves' own order (build_streams)
+    std::vector<int32_t> t_pos2range((size_t)H.nT + 1, -1);
+    for (int r = 0; r < nre; r++)
+        t_pos2range[E.off[r]] = r;
+    std::vector<std::pair<int, int>> sclusters;
+    for (int64_t b = 0; b < nb; b++)
+        if (H.kind[b] == LK_LOWRANK && H.leaves[b].rank > 0)
+            sclusters.emplace_back(H.leaves[b].s_offset, H.leaves[b].s_size);
+    std::sort(sclusters.begin(), sclusters.end());
+    sclusters.erase(std::unique(sclusters.begin(), sclusters.end()), sclusters.end());
+    std::vector<int32_t> first(sclusters.size() + 1, 0); // the pieces of the distinct source clusters follow one another in the clusters' order and partition them
+    int piece = 0;
+    for (size_t c = 0; c < sclusters.size(); c++) {
+        first[c] = piece;
+        for (int covered = 0; covered < sclusters[c].second && piece < nrr; piece++)
+            covered += R.len[piece];
+    }
+    first[sclusters.size()] = piece;
+    std::vector<int32_t> ecnt(nre, 0), rcnt(nrr, 0), elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c;
+    std::vector<int64_t> aoff(nb, -1);
+    int64_t A_total = 0;
+    bool ok         = piece == nrr;
+    for (int64_t b = 0; b < nb && ok; b++) {
+        const hmx_leaf &l = H.leaves[b];
+        const bool lr     = H.kind[b] == LK_LOWRANK;
+        if (lr && l.rank <= 0)
+            continue;
+        const int ncols = lr ? l.rank : l.s_size, lo = l.t_offset - H.T0, hi = lo + l.t_size;
+        if (lo < 0 || hi > H.nT || t_pos2range[lo] < 0) {
+            ok = false;
+            break;
+        }
+        for (int r = t_pos2range[lo]; r < nre && E.off[r] < hi; r++) {
+            (lr ? elr_b : ed_b).push_back((int32_t)b);
+            (lr ? elr_r : ed_r).push_back(r);
+            (lr ? elr_c : ed_c).push_back(ecnt[r]);
+            ecnt[r] += ncols;
+        }
+        if (lr) {
+            aoff[b] = A_total;
+            A_total += l.rank;
+            const size_t sc = std::lower_bound(sclusters.begin(), sclusters.end(), std::make_pair((int)l.s_offset, (int)l.s_size)) - sclusters.begin();
+            for (int r = first[sc]; r < first[sc + 1]; r++) {
+                rlr_b.push_back((int32_t)b);
+                rlr_r.push_back(r);
+                rlr_c.push_back(rcnt[r]);
+                rcnt[r] += l.rank;
+            }
+        }
+    }
+    for (int r = 0; r < nre && ok; r++)
+        ok = ecnt[r] == E.cols[r];
+    for (int r = 0; r < nrr && ok; r++)
+        ok = rcnt[r] == R.cols[r];
+    if (!ok || A_total != H.A_total) {
+        set_error("transposed product on the stored data: the layout could not be retraced (internal error)");
+        return HMX_ERR_STATE;
+    }
+    MirrorCtx M{H.leaves, H.kind, nb, elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c, aoff, A_total, true, nullptr};
+    const int rc = build_mirror_tables(H, M);
+    if (rc != HMX_OK) {
+        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx, &H.s_sub_task, &H.s_sub_row0, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
+            a->release();
+        H.s_sub_ptr.release();
+        H.SW.release();
+        return rc;
+    }
+    H.trans_fused = true;
+    return HMX_OK;
+}
+
+static int run_transposed_fused(HMat &H, const scalar *in, scalar alpha, scalar beta, scalar *out, hipStream_t st) {
+    static const int EW_env = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 0;
+    const int EW            = EW_env ? EW_env : (H.E.nranges() <= 4096 ? 8 : 4);
+    if (H.E.nranges() > 0) {
+        ExpandSymArgs X{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, nullptr, H.Z.d, nullptr, alpha, beta, H.E.nranges(), nullptr, 0},
+                        H.s_mdst.d, H.SW.d, in, 0};
+        switch (EW) {
+        case 8: hipLaunchKernelGGL((expand_sym_kernel<8, false>), dim3(H.E.nranges()), dim3(512), 0, st, X); break;
+        default: hipLaunchKernelGGL((expand_sym_kernel<4, false>), dim3(H.E.nranges()), dim3(256), 0, st, X); break;
+        }
+        prof_mark(H, st, "expand_colsum_kernel");
+    }
+    if (H.n_sym_combine > 0) {
+        const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw;
+        if (nw > 0) {
+            CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW.d, nw};
+            hipLaunchKernelGGL(combine_list_wave_kernel, dim3((nw + 3) / 4), dim3(256), 0, st, C);
+        }
+        if (nt > 0) {
+            CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW.d, nt};
+            hipLaunchKernelGGL(combine_list_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, C);
+        }
+        prof_mark(H, st, "combine_sym_kernel");
+    }
+    if (H.s_nint > 0) {
+        RowSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d,
+                     H.s_int_order.d, H.s_sub_ptr.d, H.s_sub_task.d, H.s_sub_row0.d, H.s_sub_nrows.d, H.s_sub_dst.d,
+                     H.SW.d, H.s_fidx.d, H.s_count.d, out, alpha, H.nS, 0, beta, 0};
+        hipLaunchKernelGGL(rowsym_kernel<SYM_WAVES>, dim3(H.s_nint), dim3(SYM_WAVES * 64), 0, st, A);
+        prof_mark(H, st, "rowsym_kernel");
     }
     HMX_HIP(hipGetLastError());
     return HMX_OK;
@@ -1679,18 +1847,36 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
     // a square operator stored symmetrically IS its own transpose ('S') / conjugate transpose ('H', handled above as 'C')
     if (trans == 'T' && !inner && H.symmetry_for_leaves == 'S' && H.has_mirror && H.T0 == H.S0 && H.nT == H.nS)
         trans = 'N';
+    bool done = false;
     if (trans == 'T') {
-        if (HMat *T = ensure_transposed_operator(H)) {
-            T->profiling = H.profiling;
-            rc           = matvec_device(*T, 'N', alpha, in, beta, out, st, true);
-            if (rc == HMX_OK && H.profiling) {
-                H.last_ms    = T->last_ms;
-                H.last_names = T->last_names;
+        // An ordinary operator: on the STORED data (run_transposed_fused; tables of ~3 % of the operator built on first use or by
+        // hmx_hmatrix_prepare) unless a transposed layout exists already (a multi-RHS 'T' product builds one, HBM permitting) or
+        // HMX_TRANS_STREAMS=1 asks for it: a second copy of the streams is then the price of the last 10 % of speed.  HMX_TRANS_TABLES=0: never.
+        const int want_streams = getenv("HMX_TRANS_STREAMS") ? atoi(getenv("HMX_TRANS_STREAMS")) : -1; // (read per call: tests switch them in-process)
+        const bool want_tables = !(getenv("HMX_TRANS_TABLES") && !atoi(getenv("HMX_TRANS_TABLES")));
+        if (!H.has_mirror && !H.view_of && !H.T_op && want_streams != 1 && want_tables) {
+            if (!H.trans_fused && !H.trans_tables_failed && build_trans_tables(H) != HMX_OK) {
+                H.trans_tables_failed = true;
+                (void)hipGetLastError();
             }
-            return rc;
+            if (H.trans_fused) {
+                rc   = run_transposed_fused(H, in, alpha, beta, out, st);
+                done = true;
+            }
         }
+        if (!done)
+            if (HMat *T = ensure_transposed_operator(H)) {
+                T->profiling = H.profiling;
+                rc           = matvec_device(*T, 'N', alpha, in, beta, out, st, true);
+                if (rc == HMX_OK && H.profiling) {
+                    H.last_ms    = T->last_ms;
+                    H.last_names = T->last_names;
+                }
+                return rc;
+            }
     }
-    if (trans == 'N') {
+    if (done) {
+    } else if (trans == 'N') {
         rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st, H.sym_fused);
         if (rc == HMX_OK && H.has_mirror && !H.sym_expanded && !H.sym_fused)
             rc = run_transposed(H, true, in, alpha, scalar(1), out, st);
@@ -3583,6 +3769,9 @@ int api_stats(const HMat *H, hmx_stats *out) {
         return HMX_ERR_INVALID;
     *out                  = H->stats;
     out->transposed_bytes = H->T_op ? H->T_op->stats.stream_bytes : 0;
+    if (H->trans_fused) // the tables of the transposed product on the stored data
+        out->transposed_bytes += (int64_t)((H->s_mdst.n + H->s_coef.n + H->s_count.n + H->sc_dst.n + H->sc_lp.n + H->sc_count.n + H->sc_k.n + H->s_list.n + H->s_fidx.n + H->s_sub_task.n +
+                                            H->s_sub_row0.n + H->s_sub_nrows.n + H->s_sub_dst.n + H->s_int_order.n) * sizeof(int32_t) + H->s_sub_ptr.n * sizeof(int64_t) + H->SW.n * sizeof(scalar));
     out->expanded_bytes   = H->X_op ? H->X_op->stats.stream_bytes : 0;
     return HMX_OK;
 }

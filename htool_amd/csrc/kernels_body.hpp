@@ -3174,10 +3174,12 @@ struct ExpandSymArgs {
 // The wave's columns are walked in groups of eight (sixteen for 4-byte coefficients), flattened over its 64-column tiles and
 // software-pipelined: the loads of group g + 1 are issued before group g is reduced, so the dependent chain of the eight-way
 // reduction never leaves the wave without loads in flight.
-template <int WAVES>
+// FWD = false: the mirrored column sums only -- the first sweep of the TRANSPOSED product of an ordinary operator on its stored data (every
+// column is then a mirrored one, the forward operands and y are not touched; run_transposed_fused).
+template <int WAVES, bool FWD = true>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
     const ExpandArgs &A = S.X;
-    __shared__ scalar part[WAVES][WAVE];
+    __shared__ scalar part[FWD ? WAVES : 1][WAVE];
     const int R = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int len = A.range_len[R], C = A.range_cols[R];
@@ -3213,14 +3215,16 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
     bool mir = false;
     auto tile_setup = [&](int c0) { // gathered coefficients and mirror slots of the (up to) 64 columns of a tile
         nc  = (C - c0) < 64 ? (C - c0) : 64;
-        z   = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
+        if constexpr (FWD)
+            z = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
         md  = lane < nc ? mdst[c0 + lane] : -1;
         mir = __any(md >= 0); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
     };
     auto process = [&](const scalar(&v)[GS], int jg) {
+        if constexpr (FWD)
 #pragma unroll
-        for (int u = 0; u < GS; u++)
-            acc = hmx_fma(v[u], readlane_val(z, (jg + u) & 63), acc);
+            for (int u = 0; u < GS; u++)
+                acc = hmx_fma(v[u], readlane_val(z, (jg + u) & 63), acc);
         if (mir)
 #pragma unroll
             for (int h = 0; h < GS; h += 8) {
@@ -3271,15 +3275,17 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
         process(vb, j);
         c0 = n0, j = nj;
     }
-    part[wv][lane] = active ? acc : scalar(0);
-    __syncthreads();
-    if (wv == 0 && active) {
-        scalar s = part[0][lane];
+    if constexpr (FWD) {
+        part[wv][lane] = active ? acc : scalar(0);
+        __syncthreads();
+        if (wv == 0 && active) {
+            scalar s = part[0][lane];
 #pragma unroll
-        for (int k = 1; k < WAVES; k++)
-            s += part[k][lane];
-        scalar *yo = A.y + A.range_off[R] + lane;
-        *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+            for (int k = 1; k < WAVES; k++)
+                s += part[k][lane];
+            scalar *yo = A.y + A.range_off[R] + lane;
+            *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        }
     }
 }
 
@@ -3315,6 +3321,8 @@ struct RowSymArgs {
     scalar alpha;
     int n;                    // rows of the operator (stride of fidx)
     int herm;
+    scalar beta;              // accumulate = 0 (transposed product on the stored data: this sweep owns y): y = alpha * sums + beta * y
+    int accumulate;           // 1: y += alpha * sums (the forward sweep of the symmetric product has written y already)
 };
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *WAVE) void rowsym_kernel(RowSymArgs A) {
@@ -3399,7 +3407,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_kernel(RowSymArgs A) {
         const int cnt = A.count[j];
         for (int k = 0; k < cnt; k++)
             sum += A.W[A.fidx[(int64_t)k * A.n + j]];
-        A.y[j] += A.alpha * sum;
+        if (A.accumulate)
+            A.y[j] += A.alpha * sum;
+        else
+            A.y[j] = hmx_is_zero(A.beta) ? A.alpha * sum : A.alpha * sum + A.beta * A.y[j];
     }
 }
 

@@ -657,8 +657,9 @@ def test_host_callback_generator_exception_surfaces():
 @pytest.mark.parametrize("name", ["rect_ball1500_disk1000", "ellipse_n4000_p4_rank2", "ball_n2000_p2_symL_rank1", "ellipse_n3000_symL_default"])
 @pytest.mark.parametrize("mu", [1, 3, 16])
 def test_transposed_products_both_layouts(name, mu, monkeypatch):
-    """trans='T' through the transposed stream layout (default; fused for several right-hand sides) and through the
-    in-place passes (HMX_TRANS_STREAMS=0: wave reductions + atomics): both equal the CPU leaf loop on the same blocks."""
+    """trans='T' on the stored data (default for one vector on an ordinary operator: mirrored column sums + owner-computes second sweep, no
+    second layout, bit-reproducible), through the in-place passes (HMX_TRANS_STREAMS=0 HMX_TRANS_TABLES=0: wave reductions + atomics) and
+    through the transposed stream layout (HMX_TRANS_STREAMS=1; what several right-hand sides use): all equal the CPU leaf loop on the same blocks."""
     from oracle import oracle as O
     p = params(name)
     T, S, H = build_engine(p)
@@ -680,13 +681,20 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
     Ho = O.HMatrix.from_blocks(tab, np.array(offs), np.concatenate(data), root, H.get_symmetry_for_leaves(), H.get_UPLO_for_leaves())
     nr, nc = H.nb_rows(), H.nb_cols()
     rng = np.random.default_rng(3)
-    for layout in ("1", "0"):
+    for layout, tables in (("0", "1"), ("0", "0"), ("1", "1")):  # (the transposed layout last: once built it is the one that runs)
         monkeypatch.setenv("HMX_TRANS_STREAMS", layout)
+        monkeypatch.setenv("HMX_TRANS_TABLES", tables)
         if mu == 1:
             x, y0 = rng.standard_normal(nr), rng.standard_normal(nc)
             y = y0.copy()
             hm.internal_add_hmatrix_vector_product("T", 1.5, H, x, -0.5, y)
             assert rel_err(y, Ho.matvec(x, "T", 1.5, -0.5, y0)) < 1e-12
+            if (layout, tables) == ("0", "1") and p["sym"] == "N":
+                assert H.stats()["transposed_bytes"] > 0  # the tables, a few per cent of the operator
+                assert H.stats()["transposed_bytes"] < 0.5 * H.stats()["stream_bytes"] + (1 << 20)
+                y2 = y0.copy()
+                hm.internal_add_hmatrix_vector_product("T", 1.5, H, x, -0.5, y2)
+                assert np.array_equal(y, y2)  # fixed summation order
         else:
             X, Y0 = rng.standard_normal((nr, mu)), rng.standard_normal((nc, mu))
             Y = Y0.copy()
