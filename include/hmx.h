@@ -91,7 +91,7 @@ typedef struct {
     int64_t reduce_coeffs;       /* coefficients streamed by the reduce kernel (V panels)                   */
     int64_t a_total;             /* sum of ranks (length of the intermediate vector a = V x)                */
     double t_compress_s, t_assemble_s, t_pack_s; /* hipEvent timings of the build phases                   */
-    int64_t transposed_bytes;    /* second stream layout of the transposed operator ('T' / 'C' products), 0 = not built          */
+    int64_t transposed_bytes;    /* what 'T' / 'C' products hold besides the operator: the tables of the product on the stored data (~3 %) and / or the transposed stream layout; 0 = nothing built */
     int64_t expanded_bytes;      /* expanded view of a compact symmetric operator (multi-RHS products), 0 = not built             */
 } hmx_stats;
 
@@ -255,14 +255,19 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *, char trans, const float *alpha
 
 /* Memory: after compression the device holds the streams the products read AND the pool they were packed from (kept for
  * get_block / save / recompress / the transposed layout; 14 GB next to 18.5 GB of streams at N=1e6).  This gives the pool back:
- * only products remain possible (a transposed product uses the in-place passes unless bit 0 of with_transposed built its layout
- * first; bit 1 builds the expanded view that multi-RHS products on compact symmetric storage run on -- without it they fall
+ * only products remain possible (transposed single-vector products run on the stored data and do not need the pool; bit 0 of
+ * with_transposed builds the transposed stream layout first, which the fused multi-RHS 'T' products run on; bit 1 builds the expanded view that multi-RHS products on compact symmetric storage run on -- without it they fall
  * back to one single-vector product per right-hand side). */
 int hmx_hmatrix_release_factors(hmx_hmatrix *, int with_transposed);
-/* Some products run on a second layout of the operator that is otherwise built inside the FIRST product that needs it: transposed
- * products ('T' / 'C') on the transposed operator's own streams (1.15 x the operator free in HBM, or the in-place passes with atomics),
- * multi-RHS products on compact symmetric storage on an expanded view -- plus work vectors and, for the user-numbering front ends,
- * permutation and staging buffers.  hmx_hmatrix_prepare(H, trans, mu) builds and allocates NOW everything products with this `trans` and
+/* Transposed products ('T' / 'C').  One vector: on the STORED data, as the reference does (it swaps the cluster roles on the same leaves,
+ * hmatrix/linalg/add_hmatrix_vector_product.hpp:74-81) -- column sums of the E-streams per row range, then an owner-computes sweep over the
+ * R-streams; every coefficient is read once, no atomics, bit-reproducible; index tables of about 3 % of the operator are built on first use.
+ * Several right-hand sides: fused multi-RHS kernels on a transposed stream layout (a second copy of the streams; needs 1.15 x the operator
+ * free in HBM, otherwise one single-vector product per right-hand side).  Environment: HMX_TRANS_STREAMS=1 also runs single vectors on the
+ * transposed layout (N = 1e6: 2.8 instead of 3.1 ms), =0 never builds it; HMX_TRANS_TABLES=0 falls back to the in-place passes with atomics.
+ * Multi-RHS products on compact symmetric storage run on an expanded view when HBM has room for it (otherwise on the stored triangle).
+ * All of these -- plus work vectors and, for the user-numbering front ends, permutation and staging buffers -- are otherwise built inside
+ * the FIRST product that needs them.  hmx_hmatrix_prepare(H, trans, mu) builds and allocates NOW everything products with this `trans` and
  * this many right-hand sides (1: the vector products) need; afterwards such products allocate nothing (hmx_device_alloc_count does not
  * move): no latency cliff or out-of-memory condition in the middle of a Krylov solve.  hmx_stats.transposed_bytes / expanded_bytes say
  * what the extra layouts cost.  Optional. */
