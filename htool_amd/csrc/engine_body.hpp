@@ -337,7 +337,7 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
 #if !HMX_COMPLEX
     // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows); only a square operator runs it
     H.s64_nint = 0;
-    if (!bad && !tmode && H.T0 == H.S0 && H.nT == H.nS)
+    if (!bad && (tmode || (H.T0 == H.S0 && H.nT == H.nS)))
         H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64);
 #endif
     phase_nosync("  sym: tasks");
@@ -1661,12 +1661,56 @@ static int run_forward_mu_sym(HMat &H, const scalar *X, scalar alpha, scalar bet
         }
         if (H.s64_nint > 0) {
             RowSymMuArgs P{{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
-                            H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, H.nT, 0},
+                            H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, H.nT, 0, scalar(0), 1},
                            H.SW16.d, (int)H.s_slots, H.s64_nint};
 #ifndef HMX_ROWSYM_WAVES
 #define HMX_ROWSYM_WAVES 4
 #endif
             constexpr int RWV = HMX_ROWSYM_WAVES; // intervals (= waves) per workgroup
+            hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
+            prof_mark(H, st, "rowsym_mfma16_kernel");
+        }
+    }
+    HMX_HIP(hipGetLastError());
+    return HMX_OK;
+}
+
+// Several right-hand sides of the transposed product on the STORED data (run_transposed_fused for groups of 16 on the matrix cores): the
+// kernels of the stored-triangle product with every leaf mirrored and nothing applied forward.  Runs when HBM has no room for the
+// transposed stream layout the fused multi-RHS kernels prefer (until round 4: one single-vector product per right-hand side then).
+static int run_transposed_fused_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
+    const size_t need16 = (size_t)(H.s_slots + 1) * 16;
+    if (H.SW16.n < need16) {
+        HMX_HIP(H.SW16.alloc(need16));
+        HMX_HIP(hipMemsetAsync(H.SW16.d, 0, need16 * sizeof(scalar), st)); // slot s_slots stays zero for ever
+    }
+    constexpr int W = 4;
+    for (int c = 0; c < mu; c += 16) {
+        const int nrhs = std::min(16, mu - c);
+        if (H.E.nranges() > 0) {
+            ExpandSymArgs XS{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, nullptr, nullptr, nullptr, alpha, beta, H.E.nranges(), nullptr, 0},
+                             H.s_mdst.d, H.SW16.d, X, 0};
+            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W, false>), dim3((unsigned)H.E.nranges()), dim3(W * 64), 0, st, XS, mu, c, nrhs);
+            prof_mark(H, st, "expand_colsum_mfma16_kernel");
+        }
+        if (H.n_sym_combine > 0) {
+            const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw;
+            if (nw > 0) {
+                CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW16.d, nw};
+                hipLaunchKernelGGL(combine_list_mu_wave_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, C);
+            }
+            if (nt > 0) {
+                CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW16.d, nt};
+                const int64_t tot = (int64_t)nt * 16;
+                hipLaunchKernelGGL(combine_list_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C);
+            }
+            prof_mark(H, st, "combine_sym_mu_kernel");
+        }
+        if (H.s64_nint > 0) {
+            RowSymMuArgs P{{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
+                            H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, H.nS, 0, beta, 0},
+                           H.SW16.d, (int)H.s_slots, H.s64_nint};
+            constexpr int RWV = HMX_ROWSYM_WAVES;
             hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
             prof_mark(H, st, "rowsym_mfma16_kernel");
         }
@@ -4058,6 +4102,35 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
             }
         }
         return HMX_OK;
+    }
+#endif
+#if !HMX_COMPLEX
+    // no transposed layout (no room for it in HBM, or HMX_TRANS_STREAMS=0): the transposed product on the stored data, 16 right-hand sides per sweep
+    if (!F && trans == 'T' && mu > 1 && H.finalized && !H.has_mirror && !H.view_of && !(getenv("HMX_TRANS_TABLES") && !atoi(getenv("HMX_TRANS_TABLES"))) &&
+        !getenv("HMX_NO_FUSED_MU")) {
+        if (!H.trans_fused && !H.trans_tables_failed && build_trans_tables(H) != HMX_OK) {
+            H.trans_tables_failed = true;
+            (void)hipGetLastError();
+        }
+        if (H.trans_fused && H.s64_nint > 0) {
+            H.ev_names.clear();
+            prof_mark(H, st, "begin");
+            rc = run_transposed_fused_mu(H, din, alpha, beta, dout, mu, st);
+            if (rc != HMX_OK)
+                return rc;
+            if (H.profiling) {
+                HMX_HIP(hipStreamSynchronize(st));
+                H.last_ms.clear();
+                H.last_names.clear();
+                for (size_t k = 1; k < H.ev_names.size(); k++) {
+                    float ms = 0;
+                    (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
+                    H.last_ms.push_back(ms);
+                    H.last_names.push_back(H.ev_names[k]);
+                }
+            }
+            return HMX_OK;
+        }
     }
 #endif
     if (F) {

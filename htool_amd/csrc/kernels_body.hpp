@@ -3469,7 +3469,8 @@ __global__ __launch_bounds__(256) void combine_list_wave_kernel(CombineListArgs 
 //                                   transposed and swizzled so that stores and operand reads both run at two lanes per bank.
 // Partial sums live in SW16 = [slot][16] (the slots of the single-vector product, 16 values each).  Fixed summation order: bit-reproducible.
 // ---------------------------------------------------------------------------------------------
-template <int WAVES>
+// FWD = false: the mirrored column sums only (transposed product of an ordinary operator on its stored data, several right-hand sides)
+template <int WAVES, bool FWD = true>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
     const ExpandArgs &A = S.X;
 #ifndef HMX_SYMMU_PT
@@ -3507,12 +3508,13 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
         }
     };
     auto operands = [&](real(&b)[4], int c, int zi, int base) {
+        if constexpr (FWD)
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
-            const real bv = expand_operand(A, zc, mu)[mo];
-            b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
-        }
+            for (int g = 0; g < 4; g++) {
+                const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
+                const real bv = expand_operand(A, zc, mu)[mo];
+                b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
+            }
     };
     // one step = 16 columns: mirrored column sums (if any of the 16 is a mirrored column), then the forward product
     auto apply = [&](real(&v)[16], const real(&b)[4], int c, int md, int base) {
@@ -3537,18 +3539,20 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
             }
         }
         // forward: a[g][t] (row 16 t + m, column 4 g + kk) = register 4 g + kk of lane quarter t -- a 4 x 4 transposition per column group
+        if constexpr (FWD) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            lane_swap32(v[4 * g + 0], v[4 * g + 2]);
-            lane_swap32(v[4 * g + 1], v[4 * g + 3]);
-            lane_swap16(v[4 * g + 0], v[4 * g + 1]);
-            lane_swap16(v[4 * g + 2], v[4 * g + 3]);
+            for (int g = 0; g < 4; g++) {
+                lane_swap32(v[4 * g + 0], v[4 * g + 2]);
+                lane_swap32(v[4 * g + 1], v[4 * g + 3]);
+                lane_swap16(v[4 * g + 0], v[4 * g + 1]);
+                lane_swap16(v[4 * g + 2], v[4 * g + 3]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[t] = mfma16(v[4 * g + t], b[g], acc[t]);
         }
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                acc[t] = mfma16(v[4 * g + t], b[g], acc[t]);
     };
 #ifndef HMX_SYMMU_SINGLE
 #define HMX_SYMMU_SINGLE 0
@@ -3556,7 +3560,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
 #if HMX_SYMMU_SINGLE
     for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) { // one step in flight per wave: half the registers, more waves per SIMD
         const int tend = (t0 + 64) < C ? (t0 + 64) : C;
-        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        const int zi   = !FWD ? 0 : ((t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1]);
         const int md   = (t0 + lane < C) ? mdst[t0 + lane] : -1;
         for (int c = t0; c < tend; c += 16) {
             real v0[16], b0[4];
@@ -3568,7 +3572,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
 #else
     for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
         const int tend = (t0 + 64) < C ? (t0 + 64) : C;
-        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+        const int zi   = !FWD ? 0 : ((t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1]);
         const int md   = (t0 + lane < C) ? mdst[t0 + lane] : -1;
         real v0[16], v1[16], b0[4], b1[4];
         load_cols(v0, t0);
@@ -3594,6 +3598,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
             apply(v1, b1, t0 + 48, md, 48);
     }
 #endif
+    if constexpr (!FWD)
+        return;
     // forward result: the waves' accumulators folded through LDS as in expand_mfma16s_kernel
     real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
     __syncthreads();
@@ -3812,7 +3818,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_mfma16_kernel(RowSymMuArgs
             if (jrow >= A.n || m >= nrhs)
                 continue;
             real *yo = A.y + (int64_t)jrow * mu + cbase + m;
-            *yo += A.alpha * acc[t][j];
+            if (A.accumulate)
+                *yo += A.alpha * acc[t][j];
+            else
+                *yo = A.beta == real(0) ? A.alpha * acc[t][j] : A.alpha * acc[t][j] + A.beta * (*yo);
         }
 }
 

@@ -700,6 +700,11 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
             Y = Y0.copy()
             hm.internal_add_hmatrix_matrix_product_row_major("T", 1.5, H, X, -0.5, Y, mu)
             assert rel_err(Y, Ho.matmat_row_major(X, "T", 1.5, -0.5, Y0)) < 1e-12
+            if (layout, tables) == ("0", "1") and p["sym"] == "N":  # no transposed layout allowed: the stored data, 16 right-hand sides per sweep
+                assert 0 < H.stats()["transposed_bytes"] < 0.5 * H.stats()["stream_bytes"] + (1 << 20)
+                Y2 = Y0.copy()
+                hm.internal_add_hmatrix_matrix_product_row_major("T", 1.5, H, X, -0.5, Y2, mu)
+                assert np.array_equal(Y, Y2)
 
 
 @pytest.mark.parametrize("name", ["ellipse_n3000_partial", "ball_n1500_eps1e-12", "ball_n1200_fullACA", "ball_n1200_SVD", "ball_n2000_symL_eta3"])
