@@ -609,7 +609,7 @@ def main():
     red_bytes = esz * (st["reduce_coeffs"] + mu * (st["a_total"] + n))
     # single vector: expand_kernel / reduce_kernel; multi-RHS: the *_mu (LDS operand), *_mus (scalar operand) or *_mfma16 variants
     exp_name = next((k for k in kern_ms if k.startswith("expand")), "expand_kernel")
-    red_name = next((k for k in kern_ms if k.startswith("reduce")), "reduce_kernel")
+    red_name = next((k for k in kern_ms if k.startswith("reduce")), None) or next((k for k in kern_ms if k.startswith("rowsym")), "reduce_kernel")  # (the sweep over the R-streams: rowsym_kernel in a transposed product on the stored data)
     exp_ms = kern_ms.get(exp_name, float("nan"))
     achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
     # HBM traffic of the dominant kernel: measured separately with rocprofv3 --pmc and stored with the sha256 of the kernel
@@ -625,7 +625,7 @@ def main():
             log("profiles/traffic.json was measured on other kernel sources (hash differs): roofline.traffic = null")
     roofline = dict(bound="hbm", kernel=exp_name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
                     traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
-                    kernels_ms=kern_ms, reduce_kernel_GBps=red_bytes / (kern_ms.get(red_name, float("nan")) * 1e-3) / 1e9)
+                    kernels_ms=kern_ms, reduce_kernel_GBps=(red_bytes / (kern_ms[red_name] * 1e-3) / 1e9) if kern_ms.get(red_name) else None)
 
     # measured device copy bandwidth (16 B/lane copy kernel, read+write) as the practical HBM ceiling on this box
     import ctypes

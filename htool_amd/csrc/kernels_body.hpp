@@ -260,7 +260,10 @@ __device__ __forceinline__ void aca_dots4(const scalar *pool, const int64_t *cro
 #if HMX_COMPLEX
 #define HMX_ACA_OCCUPANCY
 #else
-#define HMX_ACA_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4))) // <= 128 registers: the many small blocks want workgroups in flight, not loads
+#ifndef HMX_ACA_WAVES_EU
+#define HMX_ACA_WAVES_EU 4
+#endif
+#define HMX_ACA_OCCUPANCY __attribute__((amdgpu_waves_per_eu(HMX_ACA_WAVES_EU))) // <= 128 registers: the many small blocks want workgroups in flight, not loads
 #endif
 template <int NT>
 __global__ __launch_bounds__(NT) HMX_ACA_OCCUPANCY void aca_kernel(AcaArgs A) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Register / LDS / scratch use of the kernels in libhmx.so: `python tools/kernel_regs.py [regex]` (reads the AMDGPU metadata notes of every
+"""Register / LDS / scratch use of the kernels in libhmx.so: `[HMX_LIB_PATH=variant.so] python tools/kernel_regs.py [regex]` (reads the AMDGPU metadata notes of every
 gfx950 code object in the library; VGPR + AGPR together decide the waves per SIMD: 512 / (vgpr + agpr) on gfx950)."""
 import os
 import pathlib
@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_isa_shape as t  # noqa: E402
 
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
+t.LIB = os.environ.get("HMX_LIB_PATH", t.LIB)  # a build variant (tools/variant.sh)
 with tempfile.TemporaryDirectory() as d:
     rows = []
     for co in t.code_objects(pathlib.Path(d)):
