@@ -261,7 +261,7 @@ __device__ __forceinline__ void aca_dots4(const scalar *pool, const int64_t *cro
 #define HMX_ACA_OCCUPANCY
 #else
 #ifndef HMX_ACA_WAVES_EU
-#define HMX_ACA_WAVES_EU 4
+#define HMX_ACA_WAVES_EU 4 // (the fp64 kernel wants 132 registers: 12 bytes of scratch at 4; with 3 and no scratch the N = 1e6 build is no faster, 87-110 against 79-100 ms)
 #endif
 #define HMX_ACA_OCCUPANCY __attribute__((amdgpu_waves_per_eu(HMX_ACA_WAVES_EU))) // <= 128 registers: the many small blocks want workgroups in flight, not loads
 #endif
