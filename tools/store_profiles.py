@@ -1,4 +1,4 @@
-"""Copies what tools/collect_profiles.sh left under gpurun_out/{r4_n1e6,r4_sym,r4_mu16} into profiles/ (tracked) and rewrites profiles/traffic.json
+"""Copies what tools/collect_profiles.sh left under gpurun_out/{r4_n1e6,r4_sym,r4_mu16,r4_transT} into profiles/ (tracked) and rewrites profiles/traffic.json
 with the sha256 of the kernel sources the counters were measured on.  Run in the dev container right after the gpurun call."""
 import json
 import os
@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 os.chdir(ROOT)
-for tag, name in (("r4_n1e6", "r4_bench_n1e6"), ("r4_sym", "r4_bench_n1e6_sym"), ("r4_mu16", "r4_bench_n1e6_mu16")):
+for tag, name in (("r4_n1e6", "r4_bench_n1e6"), ("r4_sym", "r4_bench_n1e6_sym"), ("r4_mu16", "r4_bench_n1e6_mu16"), ("r4_transT", "r4_bench_n1e6_transT")):
     d = "gpurun_out/" + tag
     shutil.copy(d + "/kernel_stats.csv", "profiles/%s_kernel_stats.csv" % name)
     shutil.copy(d + "/under_rocprof.json", "profiles/%s_under_rocprof.json" % name)
@@ -26,6 +26,7 @@ for tag, name in (("r4_n1e6", "r4_bench_n1e6"), ("r4_sym", "r4_bench_n1e6_sym"),
     json.dump(summ, open("profiles/%s_pmc_summary.json" % name, "w"), indent=1, sort_keys=True)
 n, s = json.load(open("profiles/r4_bench_n1e6_pmc_summary.json")), json.load(open("profiles/r4_bench_n1e6_sym_pmc_summary.json"))
 m16 = json.load(open("profiles/r4_bench_n1e6_mu16_pmc_summary.json"))
+tT = json.load(open("profiles/r4_bench_n1e6_transT_pmc_summary.json"))
 
 
 def tot(x):
@@ -46,6 +47,8 @@ rec = dict(round=4, kernel_sources_sha256=bench.kernel_sources_hash(),
            rowsym_kernel_hbm_bytes_per_launch=tot(pick(s, "rowsym_kernel")), rowsym_kernel_write_bytes=pick(s, "rowsym_kernel")["write_bytes"],
            sym_product_hbm_bytes_total=sum(tot(v) for k, v in s.items() if "read16" not in k),
            mu16_expand_kernel_hbm_bytes_per_launch=tot(pick(m16, "expand_mfma16s")), mu16_reduce_kernel_hbm_bytes_per_launch=tot(pick(m16, "reduce_mfma16s")),
-           mu16_product_hbm_bytes_total=sum(tot(v) for k, v in m16.items() if "read16" not in k))
+           mu16_product_hbm_bytes_total=sum(tot(v) for k, v in m16.items() if "read16" not in k),
+           transT_colsum_kernel_hbm_bytes_per_launch=tot(pick(tT, "expand_sym_kernel")), transT_rowsym_kernel_hbm_bytes_per_launch=tot(pick(tT, "rowsym_kernel")),
+           transT_product_hbm_bytes_total=sum(tot(v) for k, v in tT.items() if any(s in k for s in ("expand_sym", "rowsym", "combine_list"))))
 json.dump(rec, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
