@@ -5,6 +5,8 @@ Bars: block structure and ranks identical to the reference; dense entries bit-ex
 (the reference's axpy goes through MKL, FMA use vendor-defined); H-matvec <= 1e-10 relative against the
 reference's own result, and <= 1e-12 against the CPU leaf loop multiplying the SAME compressed blocks.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -916,3 +918,50 @@ def test_stored_triangle_product_with_several_right_hand_sides(name, f32, monkey
         al, be = g["alphabeta"][:2]
         hm.internal_add_hmatrix_matrix_product_row_major("N", al, H, Xg, be, Yg, mu_g)
         assert rel_err(Yg, g["YNrm"]) < 1e-10
+
+
+@pytest.mark.parametrize("n,nsrc,leaf,eta,dtype", [(150, 150, 200, 10.0, np.float64), (700, 300, 50, 10.0, np.float64), (3000, 3000, 100, 1e9, np.float64), (2500, 1200, 60, 5.0, np.float32),
+                                                    (1800, 1800, 100, 10.0, np.complex128)])
+def test_transposed_product_on_the_stored_data_edge_shapes(n, nsrc, leaf, eta, dtype):
+    """The stored-data transposed product (mirrored column sums + owner-computes sweep) on operators at the edges of its tables: a single dense leaf
+    (no R-streams at all), a rectangular operator with small leaves, an operator that is one admissible low-rank leaf per root child (eta huge: no
+    dense leaves, leaves spanning dozens of row ranges), single precision, complex ('T' and 'C') -- against the products of the downloaded blocks."""
+    xt, xs = hm.create_geometry("ball", n), hm.create_geometry("ball", nsrc) + (3.0 if eta > 1e6 else 0.0)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(leaf)
+    T, S = b.create_cluster_tree(n, 3, xt, 2, 2), b.create_cluster_tree(nsrc, 3, xs, 2, 2)
+    tb = hm.HMatrixTreeBuilder(1e-6, eta, "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    cplx = np.dtype(dtype).kind == "c"
+    H = tb.build(hm.InvDistGenerator(3, xt, xs, 1e-3, 1.0, **(dict(cre=0.7, cim=-0.4) if cplx else {})), T, S, dtype=dtype)
+    tab = H.leaf_table()
+    A = np.zeros((n, nsrc), dtype=dtype)
+    for k in range(len(tab)):
+        blk = H.get_block(k)
+        t0, tn, s0, sn = tab[k, :4]
+        A[t0:t0 + tn, s0:s0 + sn] = blk[0] @ blk[1] if tab[k, 4] >= 0 else blk
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n).astype(dtype)
+    y0 = rng.standard_normal(nsrc).astype(dtype)
+    if cplx:
+        x, y0 = x + 1j * rng.standard_normal(n), y0 - 0.5j * rng.standard_normal(nsrc)
+    tol = 2e-5 if np.dtype(dtype).itemsize == 4 else 1e-12
+    for trans in ("T", "C") if cplx else ("T",):
+        y = y0.copy()
+        hm.internal_add_hmatrix_vector_product(trans, 1.5, H, x, -0.5, y)
+        At = A.T if trans == "T" else A.conj().T
+        assert rel_err(y, 1.5 * (At @ x) - 0.5 * y0) < tol, trans
+        y2 = y0.copy()
+        hm.internal_add_hmatrix_vector_product(trans, 1.5, H, x, -0.5, y2)
+        assert np.array_equal(y, y2)
+    st = H.stats()
+    assert st["transposed_bytes"] > 0 and st["transposed_bytes"] < st["stream_bytes"] + (1 << 20)
+    if not cplx:  # several right-hand sides, no transposed layout allowed: 16 per sweep on the stored data
+        os.environ["HMX_TRANS_STREAMS"] = "0"
+        try:
+            X, Y0 = rng.standard_normal((n, 19)).astype(dtype), rng.standard_normal((nsrc, 19)).astype(dtype)
+            Y = Y0.copy()
+            hm.internal_add_hmatrix_matrix_product_row_major("T", 2.0, H, X, 1.0, Y, 19)
+            assert rel_err(Y, 2.0 * (A.T @ X) + Y0) < tol
+        finally:
+            del os.environ["HMX_TRANS_STREAMS"]
