@@ -99,6 +99,7 @@ struct HMat {
     int64_t zero_slot   = 0;
     DArr<scalar> Z, W, Zmu;
     DArr<scalar> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
+    DArr<scalar> herm_in, herm_out;                  // conjugated operand / result of the mirror pass of a Hermitian operator in the in-place transposed fallback
     DArr<scalar> conj_in;                             // conjugated input of a trans = 'C' product
     DArr<scalar> mm_in, mm_out;                       // row-major cluster-numbered operands of the column-major front end
     // trans = 'T': the transposed operator laid out in its own streams (built on first use from the same crosses /
@@ -1928,7 +1929,23 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
         rc = run_transposed(H, false, in, alpha, beta, out, st);
         if (rc == HMX_OK && H.has_mirror && !H.sym_expanded) {
             // mirror leaves applied un-transposed: input indexed by target positions, output by source positions
-            rc = run_forward(H, H.e_zidx_mirror.d, in, 1, alpha, scalar(1), out + (H.T0 - H.S0), st);
+#if HMX_COMPLEX
+            if (H.symmetry_for_leaves == 'H') {
+                // Hermitian storage: the mirrored leaf of B is B^H, its transpose conj(B): out_t += alpha conj(B) x = conj(conj(alpha) B conj(x)).
+                // (Only reached without a transposed layout -- no room in HBM, HMX_TRANS_STREAMS=0 -- for a row-restricted Hermitian operator; until
+                // round 4 this pass applied B itself: wrong by the imaginary parts, found by tools/fuzz_parity.py with HMX_TRANS_STREAMS=0.)
+                if (H.herm_in.n < (size_t)H.nT)
+                    HMX_HIP(H.herm_in.alloc(H.nT));
+                if (H.herm_out.n < (size_t)H.nT)
+                    HMX_HIP(H.herm_out.alloc(H.nT));
+                const unsigned gr = (unsigned)((H.nT + 255) / 256);
+                hipLaunchKernelGGL(conj_kernel, dim3(gr), dim3(256), 0, st, (int64_t)H.nT, in, H.herm_in.d);
+                rc = run_forward(H, H.e_zidx_mirror.d, H.herm_in.d, 1, hmx_conj(alpha), scalar(0), H.herm_out.d, st);
+                if (rc == HMX_OK)
+                    hipLaunchKernelGGL(add_conj_kernel, dim3(gr), dim3(256), 0, st, (int64_t)H.nT, (const scalar *)H.herm_out.d, out + (H.T0 - H.S0));
+            } else
+#endif
+                rc = run_forward(H, H.e_zidx_mirror.d, in, 1, alpha, scalar(1), out + (H.T0 - H.S0), st);
         }
     }
     if (rc != HMX_OK)

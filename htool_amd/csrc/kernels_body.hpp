@@ -3924,3 +3924,8 @@ __global__ void conj_kernel(int64_t n, const scalar *in, scalar *out) {
     if (i < n)
         out[i] = hmx_conj(in[i]);
 }
+__global__ void add_conj_kernel(int64_t n, const scalar *in, scalar *out) { // out += conj(in)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] += hmx_conj(in[i]);
+}

@@ -323,3 +323,25 @@ def test_complex_symmetric_other_layouts(knob, monkeypatch):
         y = y0T.copy()
         hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y)
         assert rel_err(y, g[key]) < tol
+
+
+@pytest.mark.parametrize("name", ["ball_n2000_z64_p2_hermL_rank0", "ball_n2000_z64_hermU", "ball_n2000_z64_partial"])
+@pytest.mark.parametrize("streams,tables", [("0", "1"), ("0", "0"), ("1", "1")])
+def test_conjugate_transposed_products_without_the_transposed_layout(name, streams, tables, monkeypatch):
+    """'C' (and 'T' where the reference allows it) with the transposed stream layout forbidden: an ordinary operator runs on its stored data (or,
+    HMX_TRANS_TABLES=0, through the in-place passes), a row-restricted Hermitian operator through the in-place passes with its mirrored leaves
+    applied CONJUGATED (until round 4 they were applied as stored: wrong by their imaginary parts -- found by tools/fuzz_parity.py)."""
+    monkeypatch.setenv("HMX_TRANS_STREAMS", streams)
+    monkeypatch.setenv("HMX_TRANS_TABLES", tables)
+    p, g = params(name), load(name)
+    T, S, H = build_zengine(p)
+    x, xT, y0, y0T, alpha, beta = zinputs(H, g)
+    for trans, key in (("T", "yT"), ("C", "yC")):
+        if key in g:
+            y = y0T.copy()
+            hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y)
+            assert rel_err(y, g[key]) < 1e-10, (trans, rel_err(y, g[key]))
+            X = np.stack([xT, 2 * xT, -xT], axis=1).copy()
+            Y = np.stack([y0T, y0T, y0T], axis=1).copy()
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, 3)
+            assert rel_err(Y[:, 0], g[key]) < 1e-10 and rel_err(Y[:, 1] - beta * y0T, 2 * (g[key] - beta * y0T)) < 1e-9
