@@ -720,6 +720,14 @@ int build_cluster_tree(int n, int dim, const double *coords, const double *radii
         }
         level.swap(next);
     }
+    // A branch that became a leaf above the partition level (maximal_leaf_size too large for this many points and parts) leaves ranks without
+    // a cluster: the reference then keeps null entries in its list of partition clusters (child constructor, cluster_node.hpp:35-42) and
+    // whatever walks the partition dereferences them.  Refused here.
+    for (int id : T.on_partition)
+        if (id < 0) {
+            set_error("hmx_cluster_tree_create: the tree stops above the partition level (a cluster of at most maximal_leaf_size points before size_of_partition parts exist): fewer parts or a smaller leaf size");
+            return HMX_ERR_INVALID;
+        }
     return HMX_OK;
 }
 

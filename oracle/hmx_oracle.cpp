@@ -664,7 +664,13 @@ int orc_cluster_num_nodes(void *h) {
     preorder_nodes(*static_cast<ClusterTree *>(h)->root, [&](const Cluster &) { n++; });
     return n;
 }
-int orc_cluster_num_partitions(void *h) { return static_cast<ClusterTree *>(h)->td.on_partition.size(); }
+// (a rank whose cluster was never created -- a branch that became a leaf above the partition level, tree_builder.hpp:185-192 -- has no entry)
+int orc_cluster_num_partitions(void *h) {
+    int n = 0;
+    for (const Cluster *c : static_cast<ClusterTree *>(h)->td.on_partition)
+        n += c != nullptr;
+    return n;
+}
 void orc_cluster_get(void *h, int *perm, int *nodes_int, double *nodes_real, int *partition) {
     auto *T = static_cast<ClusterTree *>(h);
     std::copy(T->td.perm.begin(), T->td.perm.end(), perm);
@@ -683,10 +689,13 @@ void orc_cluster_get(void *h, int *perm, int *nodes_int, double *nodes_real, int
             r[1 + q] = q < (int)c.center.size() ? c.center[q] : 0.;
         i++;
     });
-    for (size_t k = 0; k < T->td.on_partition.size(); k++) {
-        partition[2 * k]     = T->td.on_partition[k]->offset;
-        partition[2 * k + 1] = T->td.on_partition[k]->size;
-    }
+    size_t w = 0;
+    for (size_t k = 0; k < T->td.on_partition.size(); k++)
+        if (T->td.on_partition[k]) {
+            partition[2 * w]     = T->td.on_partition[k]->offset;
+            partition[2 * w + 1] = T->td.on_partition[k]->size;
+            w++;
+        }
 }
 
 struct OracleH {

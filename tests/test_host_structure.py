@@ -245,3 +245,22 @@ def test_cluster_tree_from_nodes_round_trip_and_validation():
         hm.cluster_tree_from_nodes(T.get_permutation(), ni_bad, nr, idx, 60, x)
     with pytest.raises(hm.HmxError, match="partition"):
         hm.cluster_tree_from_nodes(T.get_permutation(), ni, nr, idx[:-1], 60, x)
+
+
+def test_tree_that_stops_above_the_partition_level_is_refused():
+    """197 points, leaves of up to 98, four parts on a binary tree: the root's first child (98 points) is a leaf one level above the partition, so
+    ranks 0 and 1 never get a cluster.  The reference keeps null entries for them in its list of partition clusters (cluster_node.hpp:35-42) and
+    whatever walks the partition dereferences them; the engine refuses the tree, the oracle (which crashed here until round 4: found by
+    tools/fuzz_parity.py) reports the two parts that exist."""
+    from oracle import oracle as O
+    x = hm.create_geometry("ball", 197)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(98)
+    b.set_partitioning_strategy("bounding_box", "regular", True)
+    with pytest.raises(hm.HmxError, match="partition level"):
+        b.create_cluster_tree(197, 3, x, 2, 4)
+    To = O.ClusterTree(x, 98, 2, 4, "n_bbox_regular")
+    assert To.partition.tolist() == [[98, 49], [147, 50]]
+    b.set_maximal_leaf_size(40)  # small enough: four parts
+    T = b.create_cluster_tree(197, 3, x, 2, 4)
+    assert len(T.get_clusters_on_partition()) == 4 and np.array_equal(T.get_permutation(), O.ClusterTree(x, 40, 2, 4, "n_bbox_regular").perm)

@@ -36,6 +36,8 @@ while time.time() - t0 < budget:
     rank = int(rng.integers(-1, parts)) if rng.random() < 0.4 else -1
     mind = int(rng.choice([0, 0, 1, 2]))
     cfg = dict(geom=geom, n=n, leaf=leaf, children=children, parts=parts, strat=strat, eta=eta, eps=eps, prec=prec, sym=sym, uplo=uplo, comp=comp, rank=rank, mind=mind)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(cfg, flush=True)
     dim = 2 if geom == "disk2d" else 3
     x = hm.create_geometry(geom, n)
     b = hm.ClusterTreeBuilder()
