@@ -58,6 +58,18 @@ while time.time() - t0 < budget:
     dt = {"f64": np.float64, "f32": np.float32, "z64": np.complex128, "c32": np.complex64}[prec]
     cre, cim = (0.7, -0.4) if cplx else (1.0, 0.0)
     H = tb.build(hm.InvDistGenerator(dim, x, x, 1e-5, 1.0, cre, cim, sym == "H"), T, T, rank, rank, dtype=dt)
+    if rng.random() < 0.2 and comp != "fullACA":  # the same operator through the host-generator route (compiled VirtualGenerator on 1 / 3 / all threads): bit for bit
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import native_inv_dist_generator
+        thr = int(rng.choice([1, 3, 0]))
+        Hh = tb.build(native_inv_dist_generator(x, x, 1e-5, 1.0, cre, cim, sym == "H", dtype=dt, threads=thr), T, T, rank, rank, dtype=dt)
+        assert np.array_equal(Hh.leaf_table(), H.leaf_table()), ("host generator: structure / ranks", cfg, thr)
+        xv = (rng.standard_normal(H.nb_cols()) + (1j * rng.standard_normal(H.nb_cols()) if cplx else 0)).astype(dt)
+        ya, yb = np.zeros(H.nb_rows(), dtype=dt), np.zeros(H.nb_rows(), dtype=dt)
+        hm.internal_add_hmatrix_vector_product("N", 1.0, H, xv, 0.0, ya)
+        hm.internal_add_hmatrix_vector_product("N", 1.0, Hh, xv, 0.0, yb)
+        assert np.array_equal(ya, yb), ("host generator: product", cfg, thr)
+        del Hh
     if cplx:
         Ho = O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=cre, cim=cim, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, c32=prec == "c32")
     else:
