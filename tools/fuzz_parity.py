@@ -57,8 +57,13 @@ while time.time() - t0 < budget:
     tb.set_minimal_source_depth(mind)
     dt = {"f64": np.float64, "f32": np.float32, "z64": np.complex128, "c32": np.complex64}[prec]
     cre, cim = (0.7, -0.4) if cplx else (1.0, 0.0)
-    H = tb.build(hm.InvDistGenerator(dim, x, x, 1e-5, 1.0, cre, cim, sym == "H"), T, T, rank, rank, dtype=dt)
-    if rng.random() < 0.2 and comp != "fullACA":  # the same operator through the host-generator route (compiled VirtualGenerator on 1 / 3 / all threads): bit for bit
+    kern = "invdist" if sym == "H" else str(rng.choice(["invdist", "invdist", "helmholtz", "laplace"]))  # device kernel family (include/hmx.h hmx_kernel)
+    wk = float(rng.choice([0.5, 3.0, 12.0]))
+    cfg.update(kernel=kern, wavenumber=wk)
+    gen = {"invdist": lambda: hm.InvDistGenerator(dim, x, x, 1e-5, 1.0, cre, cim, sym == "H"), "helmholtz": lambda: hm.HelmholtzGenerator(dim, x, x, wk, 1e-5, 1.0),
+           "laplace": lambda: hm.LaplaceGenerator(dim, x, x, 1e-5, cre, cim)}[kern]()
+    H = tb.build(gen, T, T, rank, rank, dtype=dt)
+    if rng.random() < 0.2 and comp != "fullACA" and kern == "invdist":  # the same operator through the host-generator route (compiled VirtualGenerator on 1 / 3 / all threads): bit for bit
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import native_inv_dist_generator
         thr = int(rng.choice([1, 3, 0]))
@@ -71,9 +76,9 @@ while time.time() - t0 < budget:
         assert np.array_equal(ya, yb), ("host generator: product", cfg, thr)
         del Hh
     if cplx:
-        Ho = O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=cre, cim=cim, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, c32=prec == "c32")
+        Ho = O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=cre, cim=cim, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, c32=prec == "c32", kernel=kern, wavenumber=wk)
     else:
-        Ho = O.HMatrix(To, To, delta=1e-5, scale=1.0, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, f32=prec == "f32")
+        Ho = O.HMatrix(To, To, delta=1e-5, scale=1.0, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, f32=prec == "f32", kernel=kern, wavenumber=wk)
     lt = H.leaf_table()
     assert np.array_equal(lt[:, :4], Ho.leaves[:, :4]) and np.array_equal(lt[:, 5], Ho.leaves[:, 5]), ("structure", cfg)
     single = prec in ("f32", "c32")
