@@ -217,8 +217,13 @@ MOCK_SCRIPT = textwrap.dedent('''
         return out
 
     n = 3001 if WORLD == 3 else 4000  # 3 ranks: unequal parts (grouped broadcasts); 4 ranks: equal parts (all-gather)
-    x3 = hm.create_geometry("ball", n)
-    b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(50)
+    geom, leaf = "ball", 50
+    if len(sys.argv) > 2:  # a random operator instead: size, geometry, leaf size from the seed (unequal parts whatever the rank count)
+        r0 = np.random.default_rng(int(sys.argv[2]))
+        n, geom, leaf = int(r0.integers(1500, 7000)), str(r0.choice(["ball", "ellipse", "disk"])), int(r0.integers(20, 120))
+        print("random operator: n = %%d, %%s, leaf %%d" %% (n, geom, leaf))
+    x3 = hm.create_geometry(geom, n)
+    b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(leaf)
     T = b.create_cluster_tree(n, 3, x3, 2, WORLD)
     parts = T.get_clusters_on_partition()
     assert len(parts) == WORLD
@@ -493,6 +498,16 @@ def test_c_level_distributed_operator_multi_rank_with_mock_collectives(world):
     every chunk's rows exchanged on the side stream); real and complex.
     Reference: the single-process product of the whole operator."""
     out = subprocess.run([sys.executable, "-c", MOCK_SCRIPT, str(world)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HMX_NO_TORCH="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok ") == 3 and "calls" in out.stdout, out.stdout
+    print(out.stdout)
+
+
+@pytest.mark.parametrize("world,seed", [(2, 5), (3, 6), (4, 7), (4, 8), (3, 9)])
+def test_c_level_distributed_operator_multi_rank_on_random_operators(world, seed):
+    """The same program on operators drawn from a seed (size 1 500 - 7 000, geometry, leaf size; 2, 3 and 4 ranks with unequal parts)."""
+    out = subprocess.run([sys.executable, "-c", MOCK_SCRIPT, str(world), str(seed)], capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, HMX_NO_TORCH="1"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("ok ") == 3 and "calls" in out.stdout, out.stdout
