@@ -2660,10 +2660,14 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     phase("pool allocation");
     // a zero row pivot and every growth round leave a grant unused: some slack over the exact need
     const unsigned long long maxcap = (unsigned long long)std::max(1024.0, std::min(need + 2.0 * (double)nvis + 64.0 * 1048576.0, budget));
-    auto grow_pool = [&]() -> int { // HMX_OK: grown; 1: the budget is used up
-        if (cap >= maxcap)
+    // grow_pool(): doubled (the ACA variants: their suspended / parked blocks CONTINUE, nothing granted so far is lost).  grow_pool(extra): room for
+    // `extra` more elements beyond what is granted -- fullACA / SVD compress a block that ran out AGAIN from scratch, its first grants are lost, so
+    // doubling rounds would spend the pool on abandoned crosses; with the failed blocks' full need added they all finish in the next round.
+    auto grow_pool = [&](unsigned long long extra = 0) -> int { // HMX_OK: grown; 1: the budget is used up
+        const unsigned long long limit = extra ? (unsigned long long)std::min((double)cap + (double)extra + 1024.0, budget) : maxcap;
+        if (cap >= limit)
             return 1;
-        const unsigned long long newcap = std::min<unsigned long long>(maxcap, std::max<unsigned long long>(2 * cap, cap + 1024));
+        const unsigned long long newcap = extra ? limit : std::min<unsigned long long>(maxcap, std::max<unsigned long long>(2 * cap, cap + 1024));
         DArr<scalar> bigger;
         if (bigger.alloc(newcap) != hipSuccess) {
             (void)hipGetLastError();
@@ -2792,7 +2796,10 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             break;
         if (phase_timing)
             fprintf(stderr, "[hmx build]   round %d: %zu of %zu blocks found the pool of %.2f GB exhausted\n", round, failed.size(), todo.size(), (double)cap * sizeof(scalar) / 1e9);
-        const int rcg = grow_pool();
+        unsigned long long extra = 0; // everything the failed blocks can ask for
+        for (int32_t b : failed)
+            extra += (unsigned long long)(colcap[b] + 1) * (unsigned long long)(H.leaves[b].t_size + H.leaves[b].s_size); // (+1: a grant may precede the "not advantageous" test)
+        const int rcg = grow_pool(std::max<unsigned long long>(extra, 1));
         if (rcg == 1)
             break; // reported below as an exhausted pool
         if (rcg != HMX_OK)
