@@ -18,6 +18,8 @@ STRAT = {"pca_regular": ("largest_extent", "regular", False), "pca_geometric": (
          "bbox_regular": ("bounding_box", "regular", False), "bbox_geometric": ("bounding_box", "geometric", False),
          "n_pca_regular": ("largest_extent", "regular", True), "n_bbox_regular": ("bounding_box", "regular", True)}
 rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+if os.environ.get("FUZZ_RESERVE_GB"):  # every large device array of the library out of one slab (first fit, coalescing free list)
+    assert hm.lib().hmx_device_reserve(0, int(float(os.environ["FUZZ_RESERVE_GB"]) * (1 << 30))) == 0
 t0, done, worst = time.time(), 0, 0.0
 while time.time() - t0 < budget:
     geom = rng.choice(["ellipse", "disk", "ball", "disk2d"])
@@ -84,6 +86,15 @@ while time.time() - t0 < budget:
         Ho = O.HMatrix(To, To, delta=1e-5, scale=1.0, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, f32=prec == "f32", kernel=kern, wavenumber=wk)
     lt = H.leaf_table()
     assert np.array_equal(lt[:, :4], Ho.leaves[:, :4]) and np.array_equal(lt[:, 5], Ho.leaves[:, 5]), ("structure", cfg)
+    if os.environ.get("FUZZ_ROUNDTRIP") and rng.random() < 0.5:  # binary dump and reload: the products below then run on the reloaded operator
+        path = "/tmp/fuzz_%d.hmx" % os.getpid()
+        H.save(path)
+        H2 = tb.load(path, T, T, rank, rank)
+        assert np.array_equal(H2.leaf_table(), lt), ("reload: structure / ranks", cfg)
+        os.remove(path)
+        H = H2
+    if os.environ.get("FUZZ_RELEASE") and rng.random() < 0.5:  # only the streams remain
+        H.release_factors(bool(rng.integers(0, 2)))
     single = prec in ("f32", "c32")
     if not single:
         assert np.array_equal(lt[:, 4], Ho.leaves[:, 4]), ("ranks", cfg, int((lt[:, 4] != Ho.leaves[:, 4]).sum()))
