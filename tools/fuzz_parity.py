@@ -122,5 +122,26 @@ while time.time() - t0 < budget:
         hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, mu)
         e = rel(Y, Ho.matmat_row_major(X.astype(big), trans, alpha, beta, Y0.astype(big)))
         assert e < tol, ("matmat", trans, mu, e, cfg)
+    if rank == -1 and os.environ.get("FUZZ_USER"):  # user-numbering front ends = the cluster-numbering products of the permuted operands, bit for bit
+        perm = T.get_permutation()
+        for trans in transes:
+            xu = (rng.standard_normal(nc) + (1j * rng.standard_normal(nc) if cplx else 0)).astype(dt)
+            y0 = (rng.standard_normal(nr) + (1j * rng.standard_normal(nr) if cplx else 0)).astype(dt)
+            yu, yc = y0.copy(), y0[perm].copy()
+            hm.add_hmatrix_vector_product(trans, alpha, H, xu, beta, yu)
+            hm.internal_add_hmatrix_vector_product(trans, alpha, H, xu[perm].copy(), beta, yc)
+            assert np.array_equal(yu[perm], yc), ("user numbering: vector", trans, cfg)
+            mu = int(rng.choice([1, 2, 5, 16, 19]))
+            Bu = np.asfortranarray((rng.standard_normal((nc, mu)) + (1j * rng.standard_normal((nc, mu)) if cplx else 0)).astype(dt))
+            C0 = np.asfortranarray((rng.standard_normal((nr, mu)) + (1j * rng.standard_normal((nr, mu)) if cplx else 0)).astype(dt))
+            Cu, Yc = C0.copy(order="F"), np.ascontiguousarray(C0[perm])
+            hm.add_hmatrix_matrix_product(trans, alpha, H, Bu, beta, Cu)
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, np.ascontiguousarray(Bu[perm]), beta, Yc, mu)
+            assert np.array_equal(Cu[perm], Yc), ("user numbering: column-major matrix", trans, mu, cfg)
+        ids = rng.choice(len(lt), size=min(len(lt), 40), replace=False)  # bulk download = block by block
+        for k, blk in zip(ids, H.get_blocks(ids)) if not os.environ.get("FUZZ_RELEASE") else ():
+            one = H.get_block(int(k))
+            same = (np.array_equal(blk[0], one[0]) and np.array_equal(blk[1], one[1])) if lt[k, 4] >= 0 else np.array_equal(blk, one)
+            assert same, ("bulk download", int(k), cfg)
     done += 1
 print("fuzz parity: %d random configurations ok in %.0fs, worst double-precision product error %.2e" % (done, time.time() - t0, worst))
