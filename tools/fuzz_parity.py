@@ -53,6 +53,18 @@ while time.time() - t0 < budget:
     assert np.array_equal(T.get_permutation(), To.perm), ("perm", cfg)
     if len(T.get_clusters_on_partition()) != parts:
         continue
+    # a rectangular operator now and then: another point set and its own cluster tree on the source side
+    xs, S, So = x, T, To
+    if sym == "N" and rank == -1 and rng.random() < 0.25:
+        ns = int(rng.integers(40, NMAX))
+        xs = hm.create_geometry(str(rng.choice(["disk2d"] if dim == 2 else ["ellipse", "disk", "ball"])), ns) + 0.25
+        leaf_s = int(rng.integers(5, 120))
+        bs = hm.ClusterTreeBuilder()
+        bs.set_maximal_leaf_size(leaf_s)
+        S = bs.create_cluster_tree(ns, dim, xs, 2, 1)
+        So = O.ClusterTree(xs, leaf_s, 2, 1, "pca_regular")
+        assert np.array_equal(S.get_permutation(), So.perm), ("source perm", cfg)
+        cfg.update(ns=ns, leaf_s=leaf_s)
     tb = hm.HMatrixTreeBuilder(eps, eta, sym, uplo)
     tb.set_low_rank_generator(comp)
     tb.set_minimal_target_depth(mind)
@@ -62,14 +74,14 @@ while time.time() - t0 < budget:
     kern = "invdist" if sym == "H" else str(rng.choice(["invdist", "invdist", "helmholtz", "laplace"]))  # device kernel family (include/hmx.h hmx_kernel)
     wk = float(rng.choice([0.5, 3.0, 12.0]))
     cfg.update(kernel=kern, wavenumber=wk)
-    gen = {"invdist": lambda: hm.InvDistGenerator(dim, x, x, 1e-5, 1.0, cre, cim, sym == "H"), "helmholtz": lambda: hm.HelmholtzGenerator(dim, x, x, wk, 1e-5, 1.0),
-           "laplace": lambda: hm.LaplaceGenerator(dim, x, x, 1e-5, cre, cim)}[kern]()
-    H = tb.build(gen, T, T, rank, rank, dtype=dt)
+    gen = {"invdist": lambda: hm.InvDistGenerator(dim, x, xs, 1e-5, 1.0, cre, cim, sym == "H"), "helmholtz": lambda: hm.HelmholtzGenerator(dim, x, xs, wk, 1e-5, 1.0),
+           "laplace": lambda: hm.LaplaceGenerator(dim, x, xs, 1e-5, cre, cim)}[kern]()
+    H = tb.build(gen, T, S, rank, rank, dtype=dt)
     if rng.random() < 0.2 and comp != "fullACA" and kern == "invdist":  # the same operator through the host-generator route (compiled VirtualGenerator on 1 / 3 / all threads): bit for bit
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import native_inv_dist_generator
         thr = int(rng.choice([1, 3, 0]))
-        Hh = tb.build(native_inv_dist_generator(x, x, 1e-5, 1.0, cre, cim, sym == "H", dtype=dt, threads=thr), T, T, rank, rank, dtype=dt)
+        Hh = tb.build(native_inv_dist_generator(x, xs, 1e-5, 1.0, cre, cim, sym == "H", dtype=dt, threads=thr), T, S, rank, rank, dtype=dt)
         assert np.array_equal(Hh.leaf_table(), H.leaf_table()), ("host generator: structure / ranks", cfg, thr)
         xv = (rng.standard_normal(H.nb_cols()) + (1j * rng.standard_normal(H.nb_cols()) if cplx else 0)).astype(dt)
         ya, yb = np.zeros(H.nb_rows(), dtype=dt), np.zeros(H.nb_rows(), dtype=dt)
@@ -81,15 +93,15 @@ while time.time() - t0 < budget:
             assert np.array_equal(ya, yb), ("host generator: product", cfg, thr)
         del Hh
     if cplx:
-        Ho = O.ZHMatrix(To, To, delta=1e-5, scale=1.0, cre=cre, cim=cim, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, c32=prec == "c32", kernel=kern, wavenumber=wk)
+        Ho = O.ZHMatrix(To, So, delta=1e-5, scale=1.0, cre=cre, cim=cim, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, c32=prec == "c32", kernel=kern, wavenumber=wk)
     else:
-        Ho = O.HMatrix(To, To, delta=1e-5, scale=1.0, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, f32=prec == "f32", kernel=kern, wavenumber=wk)
+        Ho = O.HMatrix(To, So, delta=1e-5, scale=1.0, eps=eps, eta=eta, sym=sym, uplo=uplo, compressor=comp, mindepth=mind, rank=rank, f32=prec == "f32", kernel=kern, wavenumber=wk)
     lt = H.leaf_table()
     assert np.array_equal(lt[:, :4], Ho.leaves[:, :4]) and np.array_equal(lt[:, 5], Ho.leaves[:, 5]), ("structure", cfg)
     if os.environ.get("FUZZ_ROUNDTRIP") and rng.random() < 0.5:  # binary dump and reload: the products below then run on the reloaded operator
         path = "/tmp/fuzz_%d.hmx" % os.getpid()
         H.save(path)
-        H2 = tb.load(path, T, T, rank, rank)
+        H2 = tb.load(path, T, S, rank, rank)
         assert np.array_equal(H2.leaf_table(), lt), ("reload: structure / ranks", cfg)
         os.remove(path)
         H = H2
@@ -123,21 +135,23 @@ while time.time() - t0 < budget:
         e = rel(Y, Ho.matmat_row_major(X.astype(big), trans, alpha, beta, Y0.astype(big)))
         assert e < tol, ("matmat", trans, mu, e, cfg)
     if rank == -1 and os.environ.get("FUZZ_USER"):  # user-numbering front ends = the cluster-numbering products of the permuted operands, bit for bit
-        perm = T.get_permutation()
+        perm_t, perm_s = T.get_permutation(), S.get_permutation()
         for trans in transes:
-            xu = (rng.standard_normal(nc) + (1j * rng.standard_normal(nc) if cplx else 0)).astype(dt)
-            y0 = (rng.standard_normal(nr) + (1j * rng.standard_normal(nr) if cplx else 0)).astype(dt)
-            yu, yc = y0.copy(), y0[perm].copy()
+            perm, permo = (perm_s, perm_t) if trans == "N" else (perm_t, perm_s)  # of the input / of the output
+            nin, nout = (nc, nr) if trans == "N" else (nr, nc)
+            xu = (rng.standard_normal(nin) + (1j * rng.standard_normal(nin) if cplx else 0)).astype(dt)
+            y0 = (rng.standard_normal(nout) + (1j * rng.standard_normal(nout) if cplx else 0)).astype(dt)
+            yu, yc = y0.copy(), y0[permo].copy()
             hm.add_hmatrix_vector_product(trans, alpha, H, xu, beta, yu)
             hm.internal_add_hmatrix_vector_product(trans, alpha, H, xu[perm].copy(), beta, yc)
-            assert np.array_equal(yu[perm], yc), ("user numbering: vector", trans, cfg)
+            assert np.array_equal(yu[permo], yc), ("user numbering: vector", trans, cfg)
             mu = int(rng.choice([1, 2, 5, 16, 19]))
-            Bu = np.asfortranarray((rng.standard_normal((nc, mu)) + (1j * rng.standard_normal((nc, mu)) if cplx else 0)).astype(dt))
-            C0 = np.asfortranarray((rng.standard_normal((nr, mu)) + (1j * rng.standard_normal((nr, mu)) if cplx else 0)).astype(dt))
-            Cu, Yc = C0.copy(order="F"), np.ascontiguousarray(C0[perm])
+            Bu = np.asfortranarray((rng.standard_normal((nin, mu)) + (1j * rng.standard_normal((nin, mu)) if cplx else 0)).astype(dt))
+            C0 = np.asfortranarray((rng.standard_normal((nout, mu)) + (1j * rng.standard_normal((nout, mu)) if cplx else 0)).astype(dt))
+            Cu, Yc = C0.copy(order="F"), np.ascontiguousarray(C0[permo])
             hm.add_hmatrix_matrix_product(trans, alpha, H, Bu, beta, Cu)
             hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, np.ascontiguousarray(Bu[perm]), beta, Yc, mu)
-            assert np.array_equal(Cu[perm], Yc), ("user numbering: column-major matrix", trans, mu, cfg)
+            assert np.array_equal(Cu[permo], Yc), ("user numbering: column-major matrix", trans, mu, cfg)
         ids = rng.choice(len(lt), size=min(len(lt), 40), replace=False)  # bulk download = block by block
         for k, blk in zip(ids, H.get_blocks(ids)) if not os.environ.get("FUZZ_RELEASE") else ():
             one = H.get_block(int(k))
