@@ -467,6 +467,9 @@ class NativeCommunicator:
         def store(ptr, t):
             a = np.ascontiguousarray(t.numpy())
             assert hip.hipMemcpy(ptr, a.ctypes.data, a.nbytes, 1) == 0
+            # a copy from pageable memory may return once the data is staged: the kernels that read `ptr` run on non-blocking streams, which
+            # the null stream does not order -- wait for the transfer itself (a rare wrong product in the two-process tests otherwise)
+            hip.hipStreamSynchronize(None)
 
         def all_gather(send, recv, count, dt, comm, stream):
             hip.hipStreamSynchronize(stream)
