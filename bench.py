@@ -680,6 +680,20 @@ def main():
             for _ in range(5):
                 hm.internal_add_hmatrix_vector_product("N", 1.0, H, xh, 0.0, yh)
             extras["host_vectors_pcie_inclusive_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+            if args.sym == "N" and world == 1:
+                # the transposed product of the same operator: on the STORED data (mirrored column sums + owner-computes second sweep; no second
+                # layout, bit-reproducible); the first call builds its index tables
+                xt, yt = xin.clone(), torch.zeros(H.nb_cols(), dtype=t_dt, device=dev)
+                t0 = time.perf_counter()
+                hm.internal_add_hmatrix_vector_product("T", 1.0, H, xt, 0.0, yt)
+                torch.cuda.synchronize()
+                extras["transposed_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    hm.internal_add_hmatrix_vector_product("T", 1.0, H, xt, 0.0, yt)
+                torch.cuda.synchronize()
+                extras["transposed_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+                extras["transposed_tables_GB"] = H.stats()["transposed_bytes"] / 1e9
         except Exception as e:  # noqa: BLE001
             extras["error"] = repr(e)
     # compression as throughput (entries/s, not roofline): kernel entries the ACA evaluated per second of ACA kernel time,
