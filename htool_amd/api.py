@@ -99,9 +99,12 @@ class Cluster:
         return np.array([[c.radius, c.center[0], c.center[1], c.center[2]] for c in s], dtype=np.float64)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().hmx_cluster_tree_destroy(self._h)
-            self._h = None
+        try:  # (at interpreter shutdown the modules `lib` needs may be gone already: nothing to release then)
+            if getattr(self, "_h", None):
+                lib().hmx_cluster_tree_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 def save_cluster_tree(cluster, filename):
@@ -530,12 +533,15 @@ class HMatrix:
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().hmx_hmatrix_destroy(self._h)
-            self._h = None
-        if getattr(self, "_bt", None):
-            lib().hmx_block_tree_destroy(self._bt)
-            self._bt = None
+        try:
+            if getattr(self, "_h", None):
+                lib().hmx_hmatrix_destroy(self._h)
+                self._h = None
+            if getattr(self, "_bt", None):
+                lib().hmx_block_tree_destroy(self._bt)
+                self._bt = None
+        except Exception:
+            pass
 
 
 class BlockTree:
@@ -555,9 +561,12 @@ class BlockTree:
         self.symmetry_for_leaves, self.uplo_for_leaves = sym.raw.decode(), uplo.raw.decode()
 
     def __del__(self):
-        if getattr(self, "_bt", None):
-            lib().hmx_block_tree_destroy(self._bt)
-            self._bt = None
+        try:
+            if getattr(self, "_bt", None):
+                lib().hmx_block_tree_destroy(self._bt)
+                self._bt = None
+        except Exception:
+            pass
 
 
 class HMatrixTreeBuilder:
