@@ -1,4 +1,4 @@
-"""examples/c_abi_hmatrix.c -- the reference's examples/c_abi_hmatrix.cpp written against the C ABI (include/hmx.h) -- built by
+"""examples/use_hmatrix.c -- the reference's examples/use_hmatrix.cpp written against the C ABI (include/hmx.h) -- built by
 __graft_entry__.build() (plain gcc, linked to libhmx.so) and run on the GPU: the user's generator class as a host callback, symmetric storage,
 eta = 200, epsilon = 0.01, the product in user numbering against the dense product; then the same operator from the built-in device kernel,
 whose product must be bit-identical."""
@@ -10,12 +10,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "examples", "c_abi_hmatrix")
+EXE = os.path.join(ROOT, "examples", "use_hmatrix")
 
 
 def ensure_built():
     if not os.path.exists(EXE):  # normally built by __graft_entry__.build()
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_hmatrix.c"), "-o", EXE,
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "use_hmatrix.c"), "-o", EXE,
                                "-L", os.path.join(ROOT, "htool_amd"), "-lhmx", "-Wl,-rpath,$ORIGIN/../htool_amd", "-lm"])
 
 
