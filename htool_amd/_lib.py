@@ -14,6 +14,13 @@ HMX_MEM_HOST, HMX_MEM_DEVICE = 0, 1
 HMX_PREC_F64, HMX_PREC_F32, HMX_PREC_Z64, HMX_PREC_C32 = 0, 1, 2, 3
 HMX_KERNEL_INV_DIST, HMX_KERNEL_HELMHOLTZ, HMX_KERNEL_LAPLACE_SL = 0, 1, 2
 HMX_NUMBERING_PARTITION, HMX_NUMBERING_USER = 0, 1
+# hmx_option (include/hmx.h): name -> id
+OPTIONS = {"r_piece_rows": 1, "r_tree_pieces": 2, "layout_threads": 3, "task_order": 4, "sym_storage": 5, "build_timing": 6,
+           "reduce_waves": 10, "expand_waves": 11, "multi_rhs_fused": 12, "matrix_cores": 13, "matrix_cores_f32": 14, "wide_sweeps": 15,
+           "scalar_operands": 16, "sym_multi_rhs": 17, "sym_no_view": 18, "transposed_layout": 19,
+           "callback_threads": 30, "callback_drivers": 31, "pool_sample": 32, "pool_rank_guess": 33, "aca_teams": 34, "aca_team_min": 35,
+           "aca_team_after": 36, "aca_team_slice": 37}
+DIST_OPTIONS = {"force_collectives": 1, "no_allgather": 2, "no_reduce_scatter": 3}
 COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
 DIRECTIONS = {"largest_extent": 0, "bounding_box": 1}
 SPLITTINGS = {"regular": 0, "geometric": 1}
@@ -122,6 +129,11 @@ SYMBOLS = [
     ("hmx_hmatrix_leaf_ranks", C.c_int, [_vp, _ip]),
     ("hmx_hmatrix_get_block", C.c_int, [_vp, C.c_int64, _dp, _dp]),
     ("hmx_hmatrix_stats", C.c_int, [_vp, C.POINTER(Stats)]),
+    ("hmx_hmatrix_set_option", C.c_int, [_vp, C.c_int, C.c_double]),
+    ("hmx_hmatrix_get_option", C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
+    ("hmx_dist_set_option", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("hmx_hmatrix_stats_sized", C.c_int, [_vp, C.POINTER(Stats), C.c_size_t]),
+    ("hmx_abi_version", C.c_int, []),
     ("hmx_hmatrix_release_factors", C.c_int, [_vp, C.c_int]),
     ("hmx_hmatrix_save", C.c_int, [_vp, C.c_char_p]),
     ("hmx_hmatrix_load", C.c_int, [_vp, C.c_int, C.c_char_p, C.POINTER(_vp)]),

@@ -385,6 +385,19 @@ class HMatrix:
         self._sym, self._uplo = sym.raw.decode(), uplo.raw.decode()
         self.refresh_leaves()
 
+    def set_option(self, name, value):
+        """hmx_hmatrix_set_option: `name` is a key of htool_amd._lib.OPTIONS (the hmx_option enumerators of include/hmx.h in lower case
+        without the prefix).  Product options may change between any two products; layout / build options only before the build
+        (HMatrixTreeBuilder.set_option)."""
+        if name not in _lib.OPTIONS:
+            raise HmxError("unknown option %r (known: %s)" % (name, ", ".join(sorted(_lib.OPTIONS))))
+        check(lib().hmx_hmatrix_set_option(self._h, _lib.OPTIONS[name], float(value)))
+
+    def get_option(self, name):
+        v = C.c_double(0.0)
+        check(lib().hmx_hmatrix_get_option(self._h, _lib.OPTIONS[name], C.byref(v)))
+        return v.value
+
     def release_factors(self, with_transposed=False):
         """Give the compression pool back to the device (products only need the streams); see hmx_hmatrix_release_factors."""
         check(lib().hmx_hmatrix_release_factors(self._h, int(with_transposed)))
@@ -520,7 +533,7 @@ class HMatrix:
 
     def stats(self):
         s = _lib.Stats()
-        check(lib().hmx_hmatrix_stats(self._h, C.byref(s)))
+        check(lib().hmx_hmatrix_stats_sized(self._h, C.byref(s), C.sizeof(s)))
         return {k: getattr(s, k) for k, _ in s._fields_}
 
     def set_profiling(self, on):
@@ -579,6 +592,7 @@ class HMatrixTreeBuilder:
         self._recompressed = False  # RecompressedLowRankGenerator form of the compressor
         self._adm_error = None
         self._adm = None            # user admissibility condition (ctypes thunk), None: Rjasanow-Steinbach
+        self._options = {}          # engine options applied to every operator this builder creates (set_option)
 
     def set_low_rank_generator(self, name, recompressed=False):
         """One of the device compressors; recompressed=True wraps it like htool's RecompressedLowRankGenerator
@@ -588,6 +602,13 @@ class HMatrixTreeBuilder:
             raise HmxError("unknown compressor %r" % name)
         self._compressor = name
         self._recompressed = bool(recompressed)
+
+    def set_option(self, name, value):
+        """An engine option (htool_amd._lib.OPTIONS; include/hmx.h hmx_option) for every operator this builder creates: applied right after
+        the operator is created, i.e. before compression and layout -- the place for layout and build options."""
+        if name not in _lib.OPTIONS:
+            raise HmxError("unknown option %r (known: %s)" % (name, ", ".join(sorted(_lib.OPTIONS))))
+        self._options[name] = float(value)
 
     def set_minimal_target_depth(self, d):
         self._mint = int(d)
@@ -675,6 +696,8 @@ class HMatrixTreeBuilder:
         t_create = time.perf_counter() - t_create
         H._tree_parameters = dict(eta=self._eta, epsilon=self._eps, min_target_depth=self._mint, min_source_depth=self._mins)
         H._block_tree_walltime = t_bt
+        for name, value in self._options.items():
+            H.set_option(name, value)
         if isinstance(generator, NativeGenerator):
             H._callback = generator  # keeps the library and the user data alive as long as the operator
             fn_t = _lib.GENERATOR_FN_S if H.prec in (_lib.HMX_PREC_F32, _lib.HMX_PREC_C32) else _lib.GENERATOR_FN

@@ -250,13 +250,31 @@ int hmx_hmatrix_set_callback_s(hmx_hmatrix *H, hmx_generator_fn_s fn, void *user
     HMX_GUARD(hmx::f32::api_set_callback(H->s, fn, user));
 }
 int hmx_hmatrix_set_callback_threads(hmx_hmatrix *H, int threads) { HMX_ALL(H, api_set_callback_threads, threads); }
+int hmx_hmatrix_set_option(hmx_hmatrix *H, int option, double value) { HMX_ALL(H, api_set_option, option, value); }
+int hmx_hmatrix_get_option(const hmx_hmatrix *H, int option, double *value) { HMX_ALL(H, api_get_option, option, value); }
 int hmx_hmatrix_compress(hmx_hmatrix *H, int compressor, double epsilon, int reqrank) {
     HMX_ALL(H, api_compress, compressor, epsilon, reqrank);
 }
 int hmx_hmatrix_recompress(hmx_hmatrix *H, double epsilon) { HMX_ALL(H, api_recompress, epsilon); }
 int hmx_hmatrix_finalize(hmx_hmatrix *H) { HMX_ALL(H, api_finalize); }
 int hmx_hmatrix_leaf_ranks(const hmx_hmatrix *H, int32_t *rank) { HMX_ALL(H, api_leaf_ranks, rank); }
-int hmx_hmatrix_stats(const hmx_hmatrix *H, hmx_stats *out) { HMX_ALL(H, api_stats, out); }
+static int stats_full(const hmx_hmatrix *H, hmx_stats *out) { HMX_ALL(H, api_stats, out); }
+int hmx_abi_version(void) { return HMX_ABI_VERSION; }
+int hmx_hmatrix_stats_sized(const hmx_hmatrix *H, hmx_stats *out, size_t struct_size) {
+    if (!out || struct_size == 0) {
+        hmx::set_error("hmx_hmatrix_stats: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    hmx_stats full{};
+    const int rc = stats_full(H, &full);
+    if (rc != HMX_OK)
+        return rc;
+    std::memcpy(out, &full, std::min(struct_size, sizeof(hmx_stats))); // a caller with an older, shorter struct gets its prefix
+    return HMX_OK;
+}
+#undef hmx_hmatrix_stats
+// binaries built before hmx_hmatrix_stats became a macro over the sized call: the first version's fields only
+int hmx_hmatrix_stats(const hmx_hmatrix *H, hmx_stats *out) { return hmx_hmatrix_stats_sized(H, out, offsetof(hmx_stats, transposed_bytes)); }
 int hmx_hmatrix_set_profiling(hmx_hmatrix *H, int enabled) { HMX_ALL(H, api_set_profiling, enabled); }
 int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *H, int max, const char **names, float *ms) {
     if (!H)
@@ -499,7 +517,10 @@ struct hmx_dist {
     int dtype  = 8;     // ncclFloat64 / ncclFloat32 of the underlying real type
     int reals  = 1;     // real numbers per coefficient (2 for complex)
     DArr<char> work, work2;
-    bool force = false; // HMX_DIST_FORCE_COLLECTIVES=1: call RCCL even with one rank (tests)
+    // hmx_dist_set_option (the environment variables of the same names give the initial values, read once in hmx_dist_create)
+    bool force             = false; // HMX_DIST_OPT_FORCE_COLLECTIVES: call RCCL even with one rank (tests)
+    bool no_allgather      = false; // HMX_DIST_OPT_NO_ALLGATHER: one grouped broadcast per rank even for equal parts
+    bool no_reduce_scatter = false; // HMX_DIST_OPT_NO_REDUCE_SCATTER: all-reduce + slice in the transposed local-to-local product
     int (*reduce_scatter)(const void *, void *, size_t, int, int, void *, void *) = nullptr; // ncclReduceScatter, when available
     // point-to-point exchange of the output slices (hmx_dist_set_point_to_point): ncclSend / ncclRecv, and whether they are in use
     int (*send)(const void *, size_t, int, int, void *, void *) = nullptr;
@@ -615,7 +636,7 @@ static int dist_gather_slices(hmx_dist &D, const std::vector<int> &off, const st
     bool equal = off[0] == 0;
     for (int k = 1; k < D.world; k++)
         equal = equal && size[k] == size[0];
-    if (equal && !(getenv("HMX_DIST_NO_ALLGATHER") && atoi(getenv("HMX_DIST_NO_ALLGATHER")))) {
+    if (equal && !D.no_allgather) {
         HMX_NCCL(D.api.all_gather(local, out, (size_t)size[0] * D.reals * per, D.dtype, D.comm, st));
         return HMX_OK;
     }
@@ -977,6 +998,30 @@ int hmx_dist_set_output_collective(hmx_dist *D, int all_reduce) {
     D->allreduce_out = all_reduce != 0;
     return HMX_OK;
 }
+int hmx_dist_set_option(hmx_dist *D, int option, int value) {
+    if (!D) {
+        set_error("hmx_dist_set_option: NULL handle");
+        return HMX_ERR_INVALID;
+    }
+    switch (option) {
+    case HMX_DIST_OPT_FORCE_COLLECTIVES:
+        if (value != 0 && !D->api.all_gather) { // created with one rank and no table: the collectives were never looked up
+            void *rs = nullptr, *sd = nullptr, *rv = nullptr;
+            const int rc = dist_api_from_library(D->api, &rs, &sd, &rv);
+            if (rc != HMX_OK)
+                return rc;
+            D->reduce_scatter = reinterpret_cast<decltype(D->reduce_scatter)>(rs);
+            D->send           = reinterpret_cast<decltype(D->send)>(sd);
+            D->recv           = reinterpret_cast<decltype(D->recv)>(rv);
+        }
+        D->force = value != 0;
+        break;
+    case HMX_DIST_OPT_NO_ALLGATHER: D->no_allgather = value != 0; break;
+    case HMX_DIST_OPT_NO_REDUCE_SCATTER: D->no_reduce_scatter = value != 0; break;
+    default: set_error("hmx_dist_set_option: unknown option " + std::to_string(option)); return HMX_ERR_INVALID;
+    }
+    return HMX_OK;
+}
 /* Events on the caller's stream around the non-local part of hmx_dist_matvec_global_to_global (trans = 'N'). */
 int hmx_dist_set_profiling(hmx_dist *D, int enabled) {
     if (!D) {
@@ -1029,7 +1074,9 @@ int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hm
     D->comm  = nccl_comm;
     D->rank  = rank;
     D->world = world_size;
-    D->force = getenv("HMX_DIST_FORCE_COLLECTIVES") && atoi(getenv("HMX_DIST_FORCE_COLLECTIVES"));
+    D->force             = getenv("HMX_DIST_FORCE_COLLECTIVES") && atoi(getenv("HMX_DIST_FORCE_COLLECTIVES"));
+    D->no_allgather      = getenv("HMX_DIST_NO_ALLGATHER") && atoi(getenv("HMX_DIST_NO_ALLGATHER"));
+    D->no_reduce_scatter = getenv("HMX_DIST_NO_REDUCE_SCATTER") && atoi(getenv("HMX_DIST_NO_REDUCE_SCATTER"));
     if (api) {
         D->api = *api;
     } else if (world_size > 1 || D->force) {
@@ -1310,7 +1357,7 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
     if (D.world > 1 || D.force) {
         // the reference's MPI_Alltoallv + p axpys (local_to_local.hpp:77) is a reduce-scatter: with equal, contiguous partitions
         // ncclReduceScatter delivers exactly this rank's slice (N / p instead of N per rank); otherwise all-reduce + slice
-        bool equal = D.s_off[0] == 0 && D.reduce_scatter != nullptr && !(getenv("HMX_DIST_NO_REDUCE_SCATTER") && atoi(getenv("HMX_DIST_NO_REDUCE_SCATTER")));
+        bool equal = D.s_off[0] == 0 && D.reduce_scatter != nullptr && !D.no_reduce_scatter;
         for (int k = 1; k < D.world && equal; k++)
             equal = D.s_size[k] == D.s_size[0] && D.s_off[k] == k * D.s_size[0];
         if (equal) {
@@ -1362,7 +1409,7 @@ int hmx_dist_matmat_row_major_local_to_local(hmx_dist *Dp, char trans, const voi
     const int off = D.s_off[D.rank], n = D.s_size[D.rank];
     const char *w = D.work2.d + (size_t)off * e;
     if (D.world > 1 || D.force) {
-        bool equal = D.s_off[0] == 0 && D.reduce_scatter != nullptr && !(getenv("HMX_DIST_NO_REDUCE_SCATTER") && atoi(getenv("HMX_DIST_NO_REDUCE_SCATTER")));
+        bool equal = D.s_off[0] == 0 && D.reduce_scatter != nullptr && !D.no_reduce_scatter;
         for (int k = 1; k < D.world && equal; k++)
             equal = D.s_size[k] == D.s_size[0] && D.s_off[k] == k * D.s_size[0];
         if (equal) {

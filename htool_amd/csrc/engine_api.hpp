@@ -6,6 +6,8 @@ int api_create(const hmx_block_tree *bt, int device_id, HMat **out);
 int api_set_kernel(HMat *H, int kernel, const double *params, int nparams, int dim, const double *tc, const double *sc);
 int api_set_callback(HMat *H, void (*fn)(void *, int, int, const int32_t *, const int32_t *, scalar *), void *user);
 int api_set_callback_threads(HMat *H, int threads);
+int api_set_option(HMat *H, int option, double value);
+int api_get_option(const HMat *H, int option, double *value);
 int api_compress(HMat *Hp, int compressor, double epsilon, int reqrank);
 int api_recompress(HMat *Hp, double epsilon);
 int api_set_block_lowrank(HMat *H, int64_t leaf, int rank, const scalar *U, const scalar *V);

@@ -29,6 +29,7 @@ struct StreamSet {
 
 struct HMat {
     int device = 0;
+    Options opt = Options::from_environment(); // hmx_hmatrix_set_option; the environment gives the initial values only (read here, once)
     // structure (copied from the block tree)
     std::vector<hmx_leaf> leaves;
     std::vector<int> kind; // LeafKind per leaf
@@ -70,7 +71,7 @@ struct HMat {
     // host generator: VirtualGenerator::copy_submatrix semantics (user numbering, column-major output)
     void (*callback)(void *, int, int, const int32_t *, const int32_t *, scalar *) = nullptr;
     void *callback_user = nullptr;
-    int callback_threads = 0; // host threads that may call the generator concurrently: 0 = all cores (HMX_CALLBACK_THREADS), 1 = the calling thread only
+    int callback_threads = 0; // host threads that may call the generator concurrently (hmx_hmatrix_set_callback_threads): 0 = option HMX_OPT_CALLBACK_THREADS (whose 0 = all cores), 1 = the calling thread only
     DArr<scalar> dense_stage; // dense leaves evaluated by the host generator (pack_dense reads them from here)
     bool has_kernel = false;
     KernelSpec ks{};
@@ -90,16 +91,15 @@ struct HMat {
     // streams
     StreamSet E, R;
     std::vector<int32_t> dp_leaf, dp_range, dp_col; // (dense leaf, row range, first column in the range) of every slice of a dense leaf, leaf-major
-    DArr<int32_t> e_zidx, e_zidx_mirror, e_tdst, e_tdst_mirror;
-    DArr<int32_t> r_outidx, r_tcoef, r_tcoef_mirror;
-    hvec32 h_e_zidx, h_e_mirrorflag, h_r_aidx, h_r_mirrorflag;
+    DArr<int32_t> e_zidx;
+    DArr<int32_t> r_outidx;
+    hvec32 h_e_zidx;
     DArr<int32_t> c_dst, c_src, c_stride, c_count;
     int n_combine       = 0;
     int64_t A_total     = 0, P_total = 0;
     int64_t zero_slot   = 0;
-    DArr<scalar> Z, W, Zmu;
+    DArr<scalar> Z, Zmu;
     DArr<scalar> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
-    DArr<scalar> herm_in, herm_out;                  // conjugated operand / result of the mirror pass of a Hermitian operator in the in-place transposed fallback
     DArr<scalar> conj_in;                             // conjugated input of a trans = 'C' product
     DArr<scalar> mm_in, mm_out;                       // row-major cluster-numbered operands of the column-major front end
     // trans = 'T': the transposed operator laid out in its own streams (built on first use from the same crosses /
@@ -431,7 +431,7 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
 
 static int build_streams(HMat &H) {
     Timer tim;
-    const bool phase_timing = getenv("HMX_BUILD_TIMING") && atoi(getenv("HMX_BUILD_TIMING"));
+    const bool phase_timing = H.opt.i(HMX_OPT_BUILD_TIMING) != 0;
     double phase_last       = 0;
     auto phase_nosync       = [&](const char *name) { // host phases that run while the pack kernels are in flight
         if (!phase_timing)
@@ -447,21 +447,15 @@ static int build_streams(HMat &H) {
     };
     const int64_t nb_real = (int64_t)H.leaves.size();
     constexpr int TR_MAX = 64;
-    const int SR_MAX     = getenv("HMX_SR_MAX") ? std::max(64, atoi(getenv("HMX_SR_MAX"))) : 512;
-    // Symmetric storage ('S','L'/'U'): by default every leaf of leaves_for_symmetry is ALSO laid out as its transpose
-    // (same crosses, roles of U and V exchanged; same dense generator), i.e. the streams hold the full operator and
-    // the product is a single untransposed pass through the tuned kernels (incl. the fused multi-RHS path).
-    // That costs the memory symmetric storage would save; HMX_SYM_COMPACT=1 keeps the compact form and uses the
-    // mirror pass (colreduce/rowreduce kernels) instead.  Measured at N=1e6 fp64: 3.0 ms expanded vs 3.9 ms compact.
-    // Default since round 2: COMPACT storage with the fused product (each stored coefficient of a dense leaf and of a U factor is
-    // read once, V factors twice: see expand_sym_kernel) -- half the HBM footprint and 0.7 x the traffic of the expanded layout.
-    // HMX_SYM_EXPANDED=1 restores the expanded layout, HMX_SYM_COMPACT=1 the compact layout with the atomics-based mirror pass.
-    const bool want_expanded = getenv("HMX_SYM_EXPANDED") && atoi(getenv("HMX_SYM_EXPANDED"));
-    const bool want_atomic   = getenv("HMX_SYM_COMPACT") && atoi(getenv("HMX_SYM_COMPACT"));
+    const int SR_MAX     = std::max(64, H.opt.i(HMX_OPT_R_PIECE_ROWS));
+    // Symmetric / Hermitian storage ('S' / 'H', 'L' / 'U'): the streams hold the STORED TRIANGLE and the product is fused -- each stored
+    // coefficient of a dense leaf and of a U factor is read once, V factors twice (expand_sym_kernel, rowsym_kernel): half the HBM footprint and
+    // 0.7 x the traffic of the expanded layout.  HMX_OPT_SYM_STORAGE = 1 lays every leaf of leaves_for_symmetry out ALSO as its (conjugate)
+    // transpose (same crosses, roles of U and V exchanged; same dense generator): the full operator, one untransposed pass.
+    const bool want_expanded = H.opt.i(HMX_OPT_SYM_STORAGE) == 1;
     const int herm           = H.symmetry_for_leaves == 'H' ? 1 : 0; // 'H': the mirrored leaf is the CONJUGATE transpose
-    H.sym_expanded           = H.has_mirror && want_expanded && !want_atomic;
-    // the atomics-based mirror pass has no conjugating form: Hermitian storage is fused (or expanded)
-    H.sym_fused = H.has_mirror && !H.sym_expanded && (!want_atomic || herm) && !H.view_of;
+    H.sym_expanded           = H.has_mirror && want_expanded;
+    H.sym_fused              = H.has_mirror && !H.sym_expanded && !H.view_of;
     if (H.view_of && H.has_mirror)
         H.sym_expanded = true; // a transposed view is only ever built from an expanded layout
     // a transposed view borrows crosses, staged blocks and generator from its owner
@@ -500,7 +494,6 @@ static int build_streams(HMat &H) {
             xconj.push_back(herm); // Hermitian storage: the mirrored copy is the conjugate (transpose)
         }
     const int64_t nb = (int64_t)XL.size();
-    const bool mirror_flags = H.has_mirror && !H.sym_expanded;
     // ---- ranges ---------------------------------------------------------------------------------
     // E ranges partition the local rows at every block boundary (each output row has exactly one owner).
     // R ranges are per DISTINCT source cluster of the low-rank leaves (cut into pieces of <= SR_MAX rows): a
@@ -561,7 +554,7 @@ static int build_streams(HMat &H) {
     // Pieces of a source cluster larger than SR_MAX: its descendants of at most SR_MAX rows in the source cluster tree (when the
     // tree is known and cuts reasonably: binary trees halve, so pieces are SR_MAX / 2 ... SR_MAX rows), otherwise steps of SR_MAX rows
     // from the cluster's start.  Along the tree the pieces of every cluster level nest inside the same windows (below).
-    const bool want_tree_pieces = !(getenv("HMX_R_TREE_PIECES") && !atoi(getenv("HMX_R_TREE_PIECES")));
+    const bool want_tree_pieces = H.opt.i(HMX_OPT_R_TREE_PIECES) != 0;
     std::map<std::pair<int, int>, int> node_of;
     if (want_tree_pieces)
         for (size_t v = 0; v < H.tree_s.size(); v++)
@@ -641,8 +634,7 @@ static int build_streams(HMat &H) {
     // loop gives (columns in leaf order, pair lists leaf-major) -- 58 ms of a 320 ms build at N = 1e6 before.
     {
         const int nre = E.nranges(), nrr = R.nranges();
-        const size_t NT = getenv("HMX_LAYOUT_THREADS") ? (size_t)std::max(1, atoi(getenv("HMX_LAYOUT_THREADS")))
-                                                       : std::min<size_t>({(size_t)16, (size_t)host_cores(), (size_t)nb / 16384 + 1});
+        const size_t NT = H.opt.i(HMX_OPT_LAYOUT_THREADS) > 0 ? (size_t)H.opt.i(HMX_OPT_LAYOUT_THREADS) : std::min<size_t>({(size_t)16, (size_t)host_cores(), (size_t)nb / 16384 + 1});
         struct Part {
             std::vector<int32_t> ecnt, rcnt; // columns this part adds to every E range / R piece
             int64_t n_elr = 0, n_ed = 0, n_rlr = 0, a = 0, p = 0;
@@ -815,7 +807,7 @@ static int build_streams(HMat &H) {
     std::iota(E.task_range.begin(), E.task_range.end(), 0);
     // launch order: heaviest first (shorter tail); HMX_SORT_TASKS=2: heaviest first only across power-of-two weight classes,
     // address order inside a class (neighbouring workgroups stream neighbouring memory)
-    const int sort_mode = getenv("HMX_SORT_TASKS") ? atoi(getenv("HMX_SORT_TASKS")) : 1;
+    const int sort_mode = H.opt.i(HMX_OPT_TASK_ORDER);
     auto weight_class = [](int64_t w) { int c = 0; while (w > 1) { w >>= 1; c++; } return c; };
     if (sort_mode == 1 || sort_mode == 2) {
         std::vector<int64_t> wk(E.nranges());
@@ -897,11 +889,6 @@ static int build_streams(HMat &H) {
         H.s_sub_ptr.release();
         H.SW.release();
     }
-    H.e_zidx_mirror.release();
-    H.e_tdst.release();
-    H.e_tdst_mirror.release();
-    H.r_tcoef.release();
-    H.r_tcoef_mirror.release();
     HMX_HIP(E.upload_meta());
     HMX_HIP(R.upload_meta());
     HMX_HIP(E.stream.alloc(std::max<int64_t>(E.elems, 1)));
@@ -995,7 +982,6 @@ static int build_streams(HMat &H) {
     const int64_t zA = H.nS, zP = H.nS + A_total;
     H.zero_slot      = H.nS + A_total + P_total;
     H.h_e_zidx.resize(E.total_cols); // every column belongs to exactly one (leaf, range) pair: written completely below
-    H.h_e_mirrorflag.resize(mirror_flags ? E.total_cols : 0);
     auto fill_e = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
         parallel_for(pb.size(), [&](size_t lo, size_t hi) { // every (leaf, range) pair owns its own columns
             for (size_t p = lo; p < hi; p++) {
@@ -1006,8 +992,6 @@ static int build_streams(HMat &H) {
                 int32_t *dst      = H.h_e_zidx.data() + E.colbase[r] + pc[p];
                 for (int j = 0; j < ncols; j++)
                     dst[j] = (int32_t)(z0 + j);
-                if (mirror_flags)
-                    std::fill_n(H.h_e_mirrorflag.data() + E.colbase[r] + pc[p], ncols, l.mirror ? 1 : 0);
             }
         });
     };
@@ -1026,18 +1010,13 @@ static int build_streams(HMat &H) {
     }
     phase_nosync("  e index");
     hvec32 h_outidx(R.total_cols);
-    H.h_r_aidx.resize(R.total_cols);
-    H.h_r_mirrorflag.resize(mirror_flags ? R.total_cols : 0);
     parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++) {
             const int b = rlr_b[p], r = rlr_r[p];
             const hmx_leaf &l = XL[b];
             const int64_t cb  = R.colbase[r] + rlr_c[p];
             for (int k = 0; k < l.rank; k++) {
-                H.h_r_aidx[cb + k] = (int32_t)(aoff[b] + k);
                 h_outidx[cb + k]   = ns_of[b] == 1 ? (int32_t)(zA + aoff[b] + k) : (int32_t)(zP + poff[b] + (int64_t)(r - s_first[b]) * l.rank + k);
-                if (mirror_flags)
-                    H.h_r_mirrorflag[cb + k] = l.mirror ? 1 : 0;
             }
         }
     });
@@ -1052,8 +1031,6 @@ static int build_streams(HMat &H) {
                 cc.push_back(ns_of[b]);
             }
     H.n_combine = (int)cd.size();
-    // transposed-pass destinations are derived from h_e_zidx on first use (ensure_transposed_indices)
-
     // ---- fused symmetric product: slots of the mirrored partial results (build_mirror_tables) -------------------------------------------
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
@@ -1075,7 +1052,6 @@ static int build_streams(HMat &H) {
     HMX_HIP(H.c_count.upload(cc));
     HMX_HIP(H.Z.alloc(H.zero_slot + 1));
     HMX_HIP(H.Z.zero());
-    HMX_HIP(H.W.alloc(std::max(H.nS, H.nT) + A_total + 1));
     HMX_HIP(hipEventSynchronize(e1));
     HMX_HIP(hipDeviceSynchronize()); // an error of the pack kernels surfaces here
     pack_guard.armed = false;
@@ -1094,37 +1070,6 @@ static int build_streams(HMat &H) {
         if (XK[b] == LK_LOWRANK && XL[b].rank > 0)
             H.stats.reduce_coeffs += (int64_t)XL[b].rank * XL[b].s_size;
     H.finalized          = true;
-    return HMX_OK;
-}
-
-// lazily built index arrays for the transposed / mirrored passes
-static int ensure_transposed_indices(HMat &H) {
-    if (H.e_tdst.d || H.E.total_cols == 0)
-        return HMX_OK;
-    // true transposed product: W = [out (nS, source-local) | aT]; mirror pass: W = [out (nT, target-local) | aT]
-    const int64_t nE = H.E.total_cols, nR = H.R.total_cols;
-    std::vector<int32_t> tall(nE), tmir(nE), call(nR), cmir(nR), zmir(nE);
-    for (int64_t c = 0; c < nE; c++) {
-        // column c multiplies Z[z]: z < nS is the source position of a dense column, z >= nS the `a` slot of a low-rank one
-        const int32_t z  = H.h_e_zidx[c];
-        const bool mir   = H.has_mirror && !H.sym_expanded && H.h_e_mirrorflag[c];
-        const bool lr    = z >= H.nS;
-        tall[c]          = z; // W = [out (nS, source-local) | aT]: the same index
-        tmir[c]          = !mir ? -1 : (lr ? (int32_t)(H.nT + (z - H.nS)) : z + H.S0 - H.T0);
-        zmir[c]          = mir ? H.h_e_zidx[c] : (int32_t)H.zero_slot;
-    }
-    for (int64_t c = 0; c < nR; c++) {
-        const bool mir = H.has_mirror && !H.sym_expanded && H.h_r_mirrorflag[c];
-        call[c]        = (int32_t)(H.nS + H.h_r_aidx[c]);
-        cmir[c]        = mir ? (int32_t)(H.nT + H.h_r_aidx[c]) : -1;
-    }
-    HMX_HIP(H.e_tdst.upload(tall));
-    HMX_HIP(H.r_tcoef.upload(call));
-    if (H.has_mirror && !H.sym_expanded) {
-        HMX_HIP(H.e_tdst_mirror.upload(tmir));
-        HMX_HIP(H.r_tcoef_mirror.upload(cmir));
-        HMX_HIP(H.e_zidx_mirror.upload(zmir));
-    }
     return HMX_OK;
 }
 
@@ -1187,26 +1132,14 @@ static int ensure_expand_chunks(HMat &H, int nchunks) {
     return HMX_OK;
 }
 
-static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, int x_shift, scalar alpha, scalar beta, scalar *y, hipStream_t st, bool sym_fused = false,
+static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, scalar alpha, scalar beta, scalar *y, hipStream_t st, bool sym_fused = false,
                        int nchunks = 0, after_chunk_fn after_chunk = nullptr, void *after_user = nullptr) {
-    // Z[x region] <- x.  x_shift != 0 (mirror pass of a transposed product): the input is indexed by target
-    // positions, the x region by source positions.
-    const scalar *xin = x_src; // x_shift == 0: both stages read the caller's vector directly, nothing is copied
-    int nx            = H.nS;
-    if (x_shift != 0) {
-        HMX_HIP(hipMemsetAsync(H.Z.d, 0, (size_t)H.nS * sizeof(scalar), st));
-        const int lo = std::max(H.S0, H.T0), hi = std::min(H.S0 + H.nS, H.T0 + H.nT);
-        if (hi > lo)
-            HMX_HIP(hipMemcpyAsync(H.Z.d + (lo - H.S0), x_src + (lo - H.T0), (size_t)(hi - lo) * sizeof(scalar), hipMemcpyDeviceToDevice, st));
-        xin = H.Z.d;
-        nx  = 0;
-        prof_mark(H, st, "copy_x");
-    }
-    static const int RW = getenv("HMX_REDUCE_WAVES") ? atoi(getenv("HMX_REDUCE_WAVES")) : 1; // 1 (default: one wave per workgroup frees its slot as soon as its task ends) or 4
+    const scalar *xin = x_src; // both stages read the caller's vector directly, nothing is copied into Z's x region
+    const int nx      = H.nS;
+    const int RW      = H.opt.i(HMX_OPT_REDUCE_WAVES) == 4 ? 4 : 1; // 1 (default: one wave per workgroup frees its slot as soon as its task ends) or 4
     // expand: 4 waves per row range; when there are too few ranges to fill the chip more than once (<= 4096: the per-rank share
     // of an 8-GPU run, or N ~ 1e5) 8 waves per range shorten the tail of the heavy ranges (-5 %), at full size they cost 2 %
-    static const int EW_env = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 0;
-    const int EW            = EW_env ? EW_env : (H.E.nranges() <= 4096 ? 8 : 4);
+    const int EW = H.opt.i(HMX_OPT_EXPAND_WAVES) ? H.opt.i(HMX_OPT_EXPAND_WAVES) : (H.E.nranges() <= 4096 ? 8 : 4);
     const int ntasks = (int)H.R.task_range.size();
     if (ntasks > 0) {
         ReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
@@ -1377,8 +1310,7 @@ static int build_trans_tables(HMat &H) {
 }
 
 static int run_transposed_fused(HMat &H, const scalar *in, scalar alpha, scalar beta, scalar *out, hipStream_t st) {
-    static const int EW_env = getenv("HMX_EXPAND_WAVES") ? atoi(getenv("HMX_EXPAND_WAVES")) : 0;
-    const int EW            = EW_env ? EW_env : (H.E.nranges() <= 4096 ? 8 : 4);
+    const int EW = H.opt.i(HMX_OPT_EXPAND_WAVES) ? H.opt.i(HMX_OPT_EXPAND_WAVES) : (H.E.nranges() <= 4096 ? 8 : 4);
     if (H.E.nranges() > 0) {
         ExpandSymArgs X{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, nullptr, H.Z.d, nullptr, alpha, beta, H.E.nranges(), nullptr, 0},
                         H.s_mdst.d, H.SW.d, in, 0};
@@ -1414,16 +1346,15 @@ static int run_transposed_fused(HMat &H, const scalar *in, scalar alpha, scalar 
 // Wave-uniform operand of the multi-RHS VALU reduce kernel through the scalar cache instead of LDS (real coefficient types).
 // Measured at N=1e6, mu=16, fp32: reduce 0.85 ms (scalar) vs 0.98 ms (LDS); the same trick in the expand stage lost (1.22 vs 1.14 ms: the
 // gathered coefficient rows miss the scalar cache) and was removed.  Default: fp32 only.  HMX_MU_SCALAR=0 / 1: never / also for fp64.
-static bool mu_scalar_operands() {
-    const char *e = getenv("HMX_MU_SCALAR");
-    const int v   = e ? atoi(e) : -1;
+static bool mu_scalar_operands(const HMat &H) {
+    const int v = H.opt.i(HMX_OPT_SCALAR_OPERANDS);
     return v < 0 ? sizeof(scalar) == 4 : v != 0;
 }
 template <int MU>
 static void launch_mu(HMat &H, ReduceArgs &RA, int mu, int cbase, hipStream_t st) {
     constexpr int RW = 4;
 #if !HMX_COMPLEX
-    if (MU >= 4 && mu_scalar_operands()) {
+    if (MU >= 4 && mu_scalar_operands(H)) {
         if constexpr (MU >= 4)
             if (RA.ntasks > 0)
                 hipLaunchKernelGGL((reduce_mus_kernel<RW, MU>), dim3((RA.ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, RA, mu, cbase);
@@ -1458,15 +1389,15 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     // Those kernels take RAGGED groups (missing right-hand sides are operands nobody stores the results of): 9 ... 15 real right-hand
     // sides are one group of 16 instead of 8 + 4 + 2 + 1 (four sweeps), 3 and 5 ... 7 likewise.  Exact groups of 8, 4, 2, 1 run the VALU
     // kernels.  HMX_NO_MFMA=1: VALU kernels throughout (A/B comparison; fp32: HMX_MFMA_F32=0), HMX_MFMA_WIDE=0: no sweeps of 32 (complex: 16).
-    const bool no_mfma = getenv("HMX_NO_MFMA") && atoi(getenv("HMX_NO_MFMA"));
+    const bool no_mfma = H.opt.i(HMX_OPT_MATRIX_CORES) == 0;
 #if HMX_COMPLEX
     const bool use_mfma = !no_mfma;
     constexpr int GMAX  = 8; // widest VALU kernel
 #else
-    const bool use_mfma = !no_mfma && (sizeof(scalar) == 8 || !(getenv("HMX_MFMA_F32") && atoi(getenv("HMX_MFMA_F32")) == 0));
+    const bool use_mfma = !no_mfma && (sizeof(scalar) == 8 || H.opt.i(HMX_OPT_MATRIX_CORES_F32) != 0);
     constexpr int GMAX  = 16;
 #endif
-    static const int wide = getenv("HMX_MFMA_WIDE") ? atoi(getenv("HMX_MFMA_WIDE")) : 1;
+    const int wide = H.opt.i(HMX_OPT_WIDE_SWEEPS);
     // fn(kernel width, first column, right-hand sides in the group); the two stages need not cut the right-hand sides into the same
     // groups (stage 2 starts when all of stage 1 is done), but they do
     auto for_groups = [&](auto &&fn) {
@@ -1603,7 +1534,7 @@ static bool sym_mu_fused(const HMat &H) {
     // (it is the faster of the two as long as a row range writes its own partial column sums: N = 4e6 fp32, 16 right-hand sides, one
     // MI355X: 15.9 ms on 42 + 83 GB against 19.0 ms on 42 + 6 GB), the stored triangle when it has not -- where products with several
     // right-hand sides used to fall back to one single-vector product per column
-    const int mode = getenv("HMX_SYM_MU_FUSED") ? atoi(getenv("HMX_SYM_MU_FUSED")) : -1;
+    const int mode = H.opt.i(HMX_OPT_SYM_MULTI_RHS);
     if (!(H.sym_fused && H.s64_nint > 0 && H.T0 == H.S0 && H.nT == H.nS) || mode == 0)
         return false;
     if (mode > 0)
@@ -1721,36 +1652,6 @@ static int run_transposed_fused_mu(HMat &H, const scalar *X, scalar alpha, scala
 }
 #endif
 
-// transposed pass: out = alpha * sum_leaves leaf^T in + beta * out, accumulated through W with atomics.
-// mirror=true restricts to leaves_for_symmetry and uses target-local output / source... (see ensure_transposed_indices)
-static int run_transposed(HMat &H, bool mirror, const scalar *in, scalar alpha, scalar beta, scalar *out, hipStream_t st) {
-    int rc = ensure_transposed_indices(H);
-    if (rc != HMX_OK)
-        return rc;
-    const int nout = mirror ? H.nT : H.nS;
-    HMX_HIP(hipMemsetAsync(H.W.d, 0, (size_t)(nout + H.A_total) * sizeof(scalar), st));
-    constexpr int CW = 4, RW = 4;
-    if (H.E.nranges() > 0) {
-        // true transposed: `in` is target-local; mirror pass: `in` is source-local, rows are target positions
-        const scalar *in_eff = mirror ? in + (H.T0 - H.S0) : in;
-        ColReduceArgs A{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, mirror ? H.e_tdst_mirror.d : H.e_tdst.d, in_eff, H.W.d, H.E.nranges()};
-        hipLaunchKernelGGL(colreduce_kernel<CW>, dim3(H.E.nranges()), dim3(CW * 64), 0, st, A);
-        prof_mark(H, st, "colreduce_kernel");
-    }
-    const int ntasks = (int)H.R.task_range.size();
-    if (ntasks > 0) {
-        // rows of the R-streams are source positions; the mirror pass writes them into a target-local vector
-        RowReduceArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
-                        mirror ? H.r_tcoef_mirror.d : H.r_tcoef.d, H.W.d, ntasks, mirror ? H.S0 - H.T0 : 0};
-        hipLaunchKernelGGL(rowreduce_kernel<RW>, dim3((ntasks + RW - 1) / RW), dim3(RW * 64), 0, st, A);
-        prof_mark(H, st, "rowreduce_kernel");
-    }
-    hipLaunchKernelGGL(axpby_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, alpha, H.W.d, beta, out);
-    prof_mark(H, st, "axpby_kernel");
-    HMX_HIP(hipGetLastError());
-    return HMX_OK;
-}
-
 // trans = 'T' at the speed of trans = 'N': the transposed operator gets its own E-/R-streams (same crosses with the roles of
 // U and V exchanged, dense leaves regenerated / read transposed), built on the first transposed product.  Costs a second
 // copy of the streams in HBM; HMX_TRANS_STREAMS=0, compact symmetric storage or an allocation failure fall back to the
@@ -1760,7 +1661,7 @@ static HMat *ensure_transposed_operator(HMat &H) {
     if (H.T_op)
         return H.T_op.get();
     // (a fused symmetric owner is fine: the view lays the mirrored leaves out explicitly, see build_streams)
-    if (H.factors_released || H.T_op_failed || H.view_of || (H.has_mirror && !H.sym_expanded && !H.sym_fused) || (getenv("HMX_TRANS_STREAMS") && !atoi(getenv("HMX_TRANS_STREAMS"))))
+    if (H.factors_released || H.T_op_failed || H.view_of || H.opt.i(HMX_OPT_TRANSPOSED_LAYOUT) == 0)
         return nullptr;
     size_t free_b = 0, total_b = 0;
     // a fused symmetric owner holds the stored triangle only, its transposed view the whole operator
@@ -1770,6 +1671,7 @@ static HMat *ensure_transposed_operator(HMat &H) {
     }
     std::unique_ptr<HMat> T(new HMat());
     T->device  = H.device;
+    T->opt     = H.opt;
     T->view_of = &H;
     T->leaves  = H.leaves;
     for (auto &l : T->leaves) {
@@ -1807,7 +1709,7 @@ static HMat *ensure_transposed_operator(HMat &H) {
 static HMat *ensure_expanded_view(HMat &H) {
     if (H.X_op)
         return H.X_op.get();
-    if (!H.sym_fused || H.factors_released || H.X_op_failed || H.view_of || (getenv("HMX_SYM_NO_VIEW") && atoi(getenv("HMX_SYM_NO_VIEW"))))
+    if (!H.sym_fused || H.factors_released || H.X_op_failed || H.view_of || H.opt.i(HMX_OPT_SYM_NO_VIEW) != 0)
         return nullptr;
     size_t free_b = 0, total_b = 0;
     if (hmx_mem_info(&free_b, &total_b) != hipSuccess || (double)free_b < 2.3 * (double)H.stats.stream_bytes) {
@@ -1816,6 +1718,7 @@ static HMat *ensure_expanded_view(HMat &H) {
     }
     std::unique_ptr<HMat> X(new HMat());
     X->device          = H.device;
+    X->opt             = H.opt;
     X->view_of         = &H;
     X->view_transposed = false;
     X->leaves          = H.leaves;
@@ -1896,10 +1799,10 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
     if (trans == 'T') {
         // An ordinary operator: on the STORED data (run_transposed_fused; tables of ~3 % of the operator built on first use or by
         // hmx_hmatrix_prepare) unless a transposed layout exists already (a multi-RHS 'T' product builds one, HBM permitting) or
-        // HMX_TRANS_STREAMS=1 asks for it: a second copy of the streams is then the price of the last 10 % of speed.  HMX_TRANS_TABLES=0: never.
-        const int want_streams = getenv("HMX_TRANS_STREAMS") ? atoi(getenv("HMX_TRANS_STREAMS")) : -1; // (read per call: tests switch them in-process)
-        const bool want_tables = !(getenv("HMX_TRANS_TABLES") && !atoi(getenv("HMX_TRANS_TABLES")));
-        if (!H.has_mirror && !H.view_of && !H.T_op && want_streams != 1 && want_tables) {
+        // HMX_OPT_TRANSPOSED_LAYOUT = 1 asks for it: a second copy of the streams is then the price of the last 10 % of speed.
+        // A row-restricted symmetric operator (mirrored leaves among ordinary ones) always runs on its transposed view.
+        const int want_streams = H.opt.i(HMX_OPT_TRANSPOSED_LAYOUT);
+        if (!H.has_mirror && !H.view_of && !H.T_op && want_streams != 1) {
             if (!H.trans_fused && !H.trans_tables_failed && build_trans_tables(H) != HMX_OK) {
                 H.trans_tables_failed = true;
                 (void)hipGetLastError();
@@ -1909,44 +1812,25 @@ static int matvec_device(HMat &H, char trans, scalar alpha, const scalar *in, sc
                 done = true;
             }
         }
-        if (!done)
-            if (HMat *T = ensure_transposed_operator(H)) {
-                T->profiling = H.profiling;
-                rc           = matvec_device(*T, 'N', alpha, in, beta, out, st, true);
-                if (rc == HMX_OK && H.profiling) {
-                    H.last_ms    = T->last_ms;
-                    H.last_names = T->last_names;
-                }
-                return rc;
+        if (!done) {
+            HMat *T = ensure_transposed_operator(H);
+            if (!T) {
+                set_error(std::string("hmx_hmatrix_matvec: the transposed product of this operator needs its transposed stream layout, which cannot be built (") +
+                          (H.factors_released ? "the factors were released: call hmx_hmatrix_release_factors with bit 0 of with_transposed set"
+                                              : (H.opt.i(HMX_OPT_TRANSPOSED_LAYOUT) == 0 ? "HMX_OPT_TRANSPOSED_LAYOUT is 0" : "not enough free device memory")) +
+                          ")");
+                return HMX_ERR_UNSUPPORTED;
             }
-    }
-    if (done) {
-    } else if (trans == 'N') {
-        rc = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st, H.sym_fused);
-        if (rc == HMX_OK && H.has_mirror && !H.sym_expanded && !H.sym_fused)
-            rc = run_transposed(H, true, in, alpha, scalar(1), out, st);
-    } else {
-        rc = run_transposed(H, false, in, alpha, beta, out, st);
-        if (rc == HMX_OK && H.has_mirror && !H.sym_expanded) {
-            // mirror leaves applied un-transposed: input indexed by target positions, output by source positions
-#if HMX_COMPLEX
-            if (H.symmetry_for_leaves == 'H') {
-                // Hermitian storage: the mirrored leaf of B is B^H, its transpose conj(B): out_t += alpha conj(B) x = conj(conj(alpha) B conj(x)).
-                // (Only reached without a transposed layout -- no room in HBM, HMX_TRANS_STREAMS=0 -- for a row-restricted Hermitian operator; until
-                // round 4 this pass applied B itself: wrong by the imaginary parts, found by tools/fuzz_parity.py with HMX_TRANS_STREAMS=0.)
-                if (H.herm_in.n < (size_t)H.nT)
-                    HMX_HIP(H.herm_in.alloc(H.nT));
-                if (H.herm_out.n < (size_t)H.nT)
-                    HMX_HIP(H.herm_out.alloc(H.nT));
-                const unsigned gr = (unsigned)((H.nT + 255) / 256);
-                hipLaunchKernelGGL(conj_kernel, dim3(gr), dim3(256), 0, st, (int64_t)H.nT, in, H.herm_in.d);
-                rc = run_forward(H, H.e_zidx_mirror.d, H.herm_in.d, 1, hmx_conj(alpha), scalar(0), H.herm_out.d, st);
-                if (rc == HMX_OK)
-                    hipLaunchKernelGGL(add_conj_kernel, dim3(gr), dim3(256), 0, st, (int64_t)H.nT, (const scalar *)H.herm_out.d, out + (H.T0 - H.S0));
-            } else
-#endif
-                rc = run_forward(H, H.e_zidx_mirror.d, in, 1, alpha, scalar(1), out + (H.T0 - H.S0), st);
+            T->profiling = H.profiling;
+            rc           = matvec_device(*T, 'N', alpha, in, beta, out, st, true);
+            if (rc == HMX_OK && H.profiling) {
+                H.last_ms    = T->last_ms;
+                H.last_names = T->last_names;
+            }
+            return rc;
         }
+    } else {
+        rc = run_forward(H, H.e_zidx.d, in, alpha, beta, out, st, H.sym_fused);
     }
     if (rc != HMX_OK)
         return rc;
@@ -2019,6 +1903,38 @@ int api_create(const hmx_block_tree *bt, int device_id, HMat **out) {
 }
 
 
+// hmx_hmatrix_set_option / get_option (include/hmx.h: hmx_option).  Layout options are fixed once the streams exist, build options once the
+// blocks are compressed; product options may change between any two products.
+int api_set_option(HMat *H, int option, double value) {
+    const OptionSpec *sp = H ? Options::spec(option) : nullptr;
+    if (!sp) {
+        set_error("hmx_hmatrix_set_option: unknown option " + std::to_string(option));
+        return HMX_ERR_INVALID;
+    }
+    if (!(value >= sp->lo && value <= sp->hi)) {
+        set_error(std::string("hmx_hmatrix_set_option: value out of range for ") + sp->env + " [" + std::to_string(sp->lo) + ", " + std::to_string(sp->hi) + "]");
+        return HMX_ERR_INVALID;
+    }
+    if (sp->when != OPT_PRODUCT && H->finalized && H->opt.v[option] != value) {
+        set_error(std::string("hmx_hmatrix_set_option: ") + sp->env + " is a " + (sp->when == OPT_LAYOUT ? "layout" : "build") + " option: set it before hmx_hmatrix_compress / hmx_hmatrix_finalize");
+        return HMX_ERR_STATE;
+    }
+    H->opt.v[option] = value;
+    if (H->T_op)
+        H->T_op->opt.v[option] = value;
+    if (H->X_op)
+        H->X_op->opt.v[option] = value;
+    return HMX_OK;
+}
+int api_get_option(const HMat *H, int option, double *value) {
+    const OptionSpec *sp = (H && value) ? Options::spec(option) : nullptr;
+    if (!sp) {
+        set_error("hmx_hmatrix_get_option: unknown option or NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    *value = H->opt.v[option];
+    return HMX_OK;
+}
 int api_set_callback_threads(HMat *H, int threads) {
     if (!H || threads < 0) {
         set_error("hmx_hmatrix_set_callback_threads: invalid arguments");
@@ -2137,9 +2053,8 @@ struct CbLanes {
     bool stop = false;
     std::vector<std::thread> workers;
 
-    CbLanes(int dev, int threads) : device(dev) {
+    CbLanes(int dev, int threads, int max_drivers) : device(dev) {
         threads = std::max(1, threads);
-        static const int max_drivers = getenv("HMX_CALLBACK_DRIVERS") && atoi(getenv("HMX_CALLBACK_DRIVERS")) > 0 ? atoi(getenv("HMX_CALLBACK_DRIVERS")) : 8;
         const int nd = std::max(1, std::min(threads, max_drivers));
         lanes.resize((size_t)nd);
         nworkers = threads - nd;
@@ -2276,11 +2191,22 @@ struct CbLanes {
             jobs.push_back(&job);
         }
         job_cv.notify_all();
+        // `job` lives on this frame and the workers hold a pointer to it: whatever body() does on this thread -- the user's generator may
+        // throw -- the job leaves the queue and every chunk a worker is still inside has returned before the frame is unwound
+        std::exception_ptr thrown;
+        size_t claimed = 0; // chunks this thread took and did not finish (an exception: at most one)
         for (;;) {
             const size_t i = job.next.fetch_add(1);
             if (i >= n)
                 break;
-            body(i);
+            try {
+                body(i);
+            } catch (...) {
+                thrown = std::current_exception();
+                fail("exception in the generator");
+                claimed = 1;
+                break;
+            }
             job.done.fetch_add(1, std::memory_order_release);
         }
         {
@@ -2289,8 +2215,12 @@ struct CbLanes {
             if (it != jobs.end())
                 jobs.erase(it);
         }
-        while (job.done.load(std::memory_order_acquire) < n) // chunks other threads are still inside
+        // chunks nobody has claimed yet will never run now that the job is off the queue: after an exception only the claimed ones are waited for
+        const size_t taken = std::min(n, job.next.load());
+        while (job.done.load(std::memory_order_acquire) + claimed < (thrown ? taken : n))
             std::this_thread::yield();
+        if (thrown)
+            std::rethrow_exception(thrown);
     }
     // fn(lane index) on every driver, each on its own thread (one driver: the calling thread); false when anything reported an error
     template <typename F>
@@ -2336,11 +2266,9 @@ struct CbLanes {
 constexpr int64_t CB_CHUNK_ENTRIES = 16384;
 
 static int callback_thread_count(const HMat &H) {
-    int n = H.callback_threads;
-    if (n <= 0) {
-        const char *e = getenv("HMX_CALLBACK_THREADS");
-        n             = e && atoi(e) > 0 ? atoi(e) : std::min(64, host_cores());
-    }
+    int n = H.callback_threads; // hmx_hmatrix_set_callback_threads: an explicit count wins
+    if (n <= 0)
+        n = H.opt.i(HMX_OPT_CALLBACK_THREADS) > 0 ? H.opt.i(HMX_OPT_CALLBACK_THREADS) : std::min(64, host_cores());
     return std::max(1, std::min(n, 256));
 }
 
@@ -2448,7 +2376,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         return HMX_ERR_STATE;
     }
     // HMX_BUILD_TIMING=1: wall-clock of the build phases on stderr (tools/build_timing.py)
-    const bool phase_timing = getenv("HMX_BUILD_TIMING") && atoi(getenv("HMX_BUILD_TIMING"));
+    const bool phase_timing = H.opt.i(HMX_OPT_BUILD_TIMING) != 0;
     auto phase_t0           = std::chrono::steady_clock::now();
     auto phase              = [&](const char *name) {
         if (!phase_timing)
@@ -2484,7 +2412,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     // into a dense leaf exactly when the reference's does (the slot table costs 8 bytes per possible cross: ~2 GB at N = 1e6)
     constexpr int64_t RANK_CAP = INT32_MAX;
     // expected rank of an admissible block: grows like log(1/eps) for the asymptotically smooth kernels H-matrices are for
-    const double rank_guess = getenv("HMX_POOL_RANK_GUESS") ? atof(getenv("HMX_POOL_RANK_GUESS"))
+    const bool rank_guess_given = H.opt.d(HMX_OPT_POOL_RANK_GUESS) > 0;
+    const double rank_guess     = rank_guess_given ? H.opt.d(HMX_OPT_POOL_RANK_GUESS)
                               : (reqrank > 0 ? (double)reqrank : std::max(16.0, 8.0 + 3.0 * std::log10(1.0 / std::max(epsilon, 1e-16))));
     for (size_t b = 0; b < nb; b++) {
         const hmx_leaf &l = H.leaves[b];
@@ -2614,7 +2543,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     // block of the size-sorted list (<= ~4000 blocks) is compressed first into a small pool, and the full pool is sized
     // at 1.3 x (measured / guessed) of the estimate.  The pool grows if the sample misled (grow_pool).  HMX_POOL_SAMPLE=0: off.
     if (!assembled && !use_cb && !full_pool && order.size() >= 20000 && (double)cap * sizeof(scalar) >= 4e9 && reqrank < 0 &&
-        !(getenv("HMX_POOL_SAMPLE") && atoi(getenv("HMX_POOL_SAMPLE")) == 0) && !getenv("HMX_POOL_RANK_GUESS")) {
+        H.opt.i(HMX_OPT_POOL_SAMPLE) != 0 && !rank_guess_given) {
         const size_t K = std::max<size_t>(1, order.size() / 4096);
         std::vector<int32_t> sample;
         double guess_s = 0;
@@ -2687,7 +2616,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     // the host generator's threads (lanes: stream + two pinned / device slot pairs each), shared by the ACA and the assembly of dense blocks
     std::unique_ptr<CbLanes> cb_lanes;
     if (use_cb)
-        cb_lanes.reset(new CbLanes(H.device, callback_thread_count(H)));
+        cb_lanes.reset(new CbLanes(H.device, callback_thread_count(H), std::max(1, H.opt.i(HMX_OPT_CALLBACK_DRIVERS))));
     const auto wall0 = std::chrono::steady_clock::now();
     DEvent e0, e1;
     HMX_HIP(hipEventRecord(e0, 0));
@@ -3039,7 +2968,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         // entries of a line per workgroup: 1024 while the launch has workgroups enough to fill the GPU, 256 when few blocks are left (a
         // workgroup walks the whole history whatever its share, 16 loads in flight per thread either way: N=1e6 Hermitian case, team phase
         // of the second round 1.63 s with 1024 throughout, 1.53 s with 256 throughout -- but the first round 0.92 instead of 0.75 s)
-        const int team_slice_env = getenv("HMX_ACA_TEAM_SLICE") && atoi(getenv("HMX_ACA_TEAM_SLICE")) > 0 ? std::max(64, atoi(getenv("HMX_ACA_TEAM_SLICE"))) : 0;
+        const int team_slice_env = H.opt.i(HMX_OPT_ACA_TEAM_SLICE) > 0 ? std::max(64, H.opt.i(HMX_OPT_ACA_TEAM_SLICE)) : 0;
         auto run_team = [&](const std::vector<int32_t> &blocks, int round) -> int {
             if (!t_status.d) {
                 HMX_HIP(t_status.alloc(nb));
@@ -3122,9 +3051,9 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                 fprintf(stderr, "[hmx build]   round %d (%.0f ms): %zu blocks continued by workgroup teams, %d launches (host waited %.0f ms for the kernels, %.0f ms for status copies)\n", round, since_phase(), blocks.size(), launches, t_wait, t_copy);
             return HMX_OK;
         };
-        const bool team_ok = reqrank < 0 && !(getenv("HMX_ACA_TEAM") && atoi(getenv("HMX_ACA_TEAM")) == 0);
-        const int team_min = team_ok ? (getenv("HMX_ACA_TEAM_MIN") ? atoi(getenv("HMX_ACA_TEAM_MIN")) : 4096) : 0;
-        const int team_q   = getenv("HMX_ACA_TEAM_Q") ? atoi(getenv("HMX_ACA_TEAM_Q")) : 48;
+        const bool team_ok = reqrank < 0 && H.opt.i(HMX_OPT_ACA_TEAMS) != 0;
+        const int team_min = team_ok ? H.opt.i(HMX_OPT_ACA_TEAM_MIN) : 0;
+        const int team_q   = H.opt.i(HMX_OPT_ACA_TEAM_AFTER);
         hipStream_t side = nullptr; // the blocks below team_min, concurrently with the large ones and their teams
         struct SideGuard {
             hipStream_t &s;
@@ -3920,7 +3849,7 @@ int api_matvec_chunked(HMat *Hp, scalar alpha, const scalar *in, scalar beta, sc
     H.ev_names.clear();
     const bool prof = H.profiling; // per-kernel events make no sense with interleaved collectives
     H.profiling     = false;
-    const int rc    = run_forward(H, H.e_zidx.d, in, 0, alpha, beta, out, st, false, nchunks, after_chunk, user);
+    const int rc    = run_forward(H, H.e_zidx.d, in, alpha, beta, out, st, false, nchunks, after_chunk, user);
     H.profiling     = prof;
     if (used)
         *used = H.chunk_plan_n;
@@ -3953,9 +3882,15 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
 // The layout a trans = 'N' product with several right-hand sides runs on: the operator's own streams, or (compact symmetric storage) its
 // expanded view -- same rows, its own row ranges.  nullptr: no fused multi-RHS path (one pass per right-hand side).
 static HMat *matmat_layout_n(HMat &H) {
-    if (!(H.finalized && (!H.has_mirror || H.sym_expanded || H.sym_fused) && !getenv("HMX_NO_FUSED_MU")))
+    if (!(H.finalized && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0))
         return nullptr;
-    return H.sym_fused ? ensure_expanded_view(H) : &H;
+    if (!H.sym_fused)
+        return &H;
+#if !HMX_COMPLEX
+    if (sym_mu_fused(H)) // the product runs on the stored triangle (rows receive mirrored contributions after the E pass): single exchange, and no view is built
+        return nullptr;
+#endif
+    return ensure_expanded_view(H);
 }
 // api_matvec_chunked for mu right-hand sides (row-major, device pointers, trans = 'N'): after_chunk(user, c, row_lo, row_hi) is called on the
 // host right after the expand kernels of row chunk c (all groups of right-hand sides) were launched on `stream`.
@@ -4077,11 +4012,11 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
     (void)conj_wrap;
 #if !HMX_COMPLEX
     // a square symmetric operator on compact storage: the fused multi-RHS product on the stored triangle (no expanded view)
-    const bool fused_sym = H.finalized && mu > 1 && sym_mu_fused(H) && !getenv("HMX_NO_FUSED_MU") && (trans == 'N' || (trans == 'T' && H.symmetry_for_leaves == 'S'));
+    const bool fused_sym = H.finalized && mu > 1 && sym_mu_fused(H) && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0 && (trans == 'N' || (trans == 'T' && H.symmetry_for_leaves == 'S'));
 #else
     const bool fused_sym = false;
 #endif
-    if (!fused_sym && H.finalized && (!H.has_mirror || H.sym_expanded || H.sym_fused) && !getenv("HMX_NO_FUSED_MU")) {
+    if (!fused_sym && H.finalized && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0) {
         const bool square_sym = H.has_mirror && H.T0 == H.S0 && H.nT == H.nS;
         if (trans == 'N' || (trans == 'T' && square_sym && H.symmetry_for_leaves == 'S') || (trans == 'C' && square_sym && H.symmetry_for_leaves == 'H'))
             F = H.sym_fused ? ensure_expanded_view(H) : &H;
@@ -4130,8 +4065,7 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
 #endif
 #if !HMX_COMPLEX
     // no transposed layout (no room for it in HBM, or HMX_TRANS_STREAMS=0): the transposed product on the stored data, 16 right-hand sides per sweep
-    if (!F && trans == 'T' && mu > 1 && H.finalized && !H.has_mirror && !H.view_of && !(getenv("HMX_TRANS_TABLES") && !atoi(getenv("HMX_TRANS_TABLES"))) &&
-        !getenv("HMX_NO_FUSED_MU")) {
+    if (!F && trans == 'T' && mu > 1 && H.finalized && !H.has_mirror && !H.view_of && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0) {
         if (!H.trans_fused && !H.trans_tables_failed && build_trans_tables(H) != HMX_OK) {
             H.trans_tables_failed = true;
             (void)hipGetLastError();
@@ -4318,7 +4252,10 @@ int api_prepare(HMat *Hp, char trans, int mu) {
                      : api_matmat_row_major(Hp, trans, scalar(1), in.d, scalar(0), out.d, mu, HMX_MEM_DEVICE, nullptr);
     if (rc != HMX_OK)
         return rc;
-    if (H.t_root_is_tree_root || H.perm_local) { // the user-numbering front ends exist for this operator: their staging buffers too
+    // the user-numbering front ends exist for this operator (the predicate api_matvec_user / api_matmat_user apply: a stable permutation AND
+    // the whole source cluster -- a block-diagonal / local-to-local operator on a local-permutation tree has the first, not the second):
+    // their staging buffers too
+    if ((H.t_root_is_tree_root || H.perm_local) && H.S0 == 0 && H.nS == H.nS_total) {
         rc = mu == 1 ? api_matvec_user(Hp, trans, scalar(1), in.d, scalar(0), out.d, HMX_MEM_DEVICE, nullptr)
                      : api_matmat_user(Hp, trans, scalar(1), in.d, scalar(0), out.d, mu, HMX_MEM_DEVICE, nullptr);
         if (rc != HMX_OK)

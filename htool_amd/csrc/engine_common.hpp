@@ -366,6 +366,74 @@ struct DEvent { // hipEvent_t with RAII, so error returns between create and des
     operator hipEvent_t() const { return e; }
 };
 
+// ---- per-operator options (include/hmx.h: hmx_option) ------------------------------------------------------------------------------
+// One table: id, environment variable that gives the INITIAL value when an operator is created, default, valid range, when it may change.
+// Nothing outside Options::from_environment() reads these variables: builds and products look at the operator's own values.
+enum OptWhen { OPT_LAYOUT, OPT_BUILD, OPT_PRODUCT };
+struct OptionSpec {
+    int id;
+    const char *env;
+    bool env_inverted; // HMX_NO_*: the variable switches the feature OFF
+    double def, lo, hi;
+    OptWhen when;
+};
+static const OptionSpec HMX_OPTION_SPECS[] = {
+    {HMX_OPT_R_PIECE_ROWS, "HMX_SR_MAX", false, 512, 64, 1 << 20, OPT_LAYOUT},
+    {HMX_OPT_R_TREE_PIECES, "HMX_R_TREE_PIECES", false, 1, 0, 1, OPT_LAYOUT},
+    {HMX_OPT_LAYOUT_THREADS, "HMX_LAYOUT_THREADS", false, 0, 0, 1024, OPT_LAYOUT},
+    {HMX_OPT_TASK_ORDER, "HMX_SORT_TASKS", false, 1, 0, 2, OPT_LAYOUT},
+    {HMX_OPT_SYM_STORAGE, "HMX_SYM_EXPANDED", false, 0, 0, 1, OPT_LAYOUT},
+    {HMX_OPT_BUILD_TIMING, "HMX_BUILD_TIMING", false, 0, 0, 1, OPT_BUILD},
+    {HMX_OPT_REDUCE_WAVES, "HMX_REDUCE_WAVES", false, 0, 0, 8, OPT_PRODUCT},
+    {HMX_OPT_EXPAND_WAVES, "HMX_EXPAND_WAVES", false, 0, 0, 8, OPT_PRODUCT},
+    {HMX_OPT_MULTI_RHS_FUSED, "HMX_NO_FUSED_MU", true, 1, 0, 1, OPT_PRODUCT},
+    {HMX_OPT_MATRIX_CORES, "HMX_NO_MFMA", true, 1, 0, 1, OPT_PRODUCT},
+    {HMX_OPT_MATRIX_CORES_F32, "HMX_MFMA_F32", false, 1, 0, 1, OPT_PRODUCT},
+    {HMX_OPT_WIDE_SWEEPS, "HMX_MFMA_WIDE", false, 1, 0, 1, OPT_PRODUCT},
+    {HMX_OPT_SCALAR_OPERANDS, "HMX_MU_SCALAR", false, -1, -1, 1, OPT_PRODUCT},
+    {HMX_OPT_SYM_MULTI_RHS, "HMX_SYM_MU_FUSED", false, -1, -1, 1, OPT_PRODUCT},
+    {HMX_OPT_SYM_NO_VIEW, "HMX_SYM_NO_VIEW", false, 0, 0, 1, OPT_PRODUCT},
+    {HMX_OPT_TRANSPOSED_LAYOUT, "HMX_TRANS_STREAMS", false, -1, -1, 1, OPT_PRODUCT},
+    {HMX_OPT_CALLBACK_THREADS, "HMX_CALLBACK_THREADS", false, 0, 0, 256, OPT_BUILD},
+    {HMX_OPT_CALLBACK_DRIVERS, "HMX_CALLBACK_DRIVERS", false, 8, 1, 64, OPT_BUILD},
+    {HMX_OPT_POOL_SAMPLE, "HMX_POOL_SAMPLE", false, 1, 0, 1, OPT_BUILD},
+    {HMX_OPT_POOL_RANK_GUESS, "HMX_POOL_RANK_GUESS", false, 0, 0, 1e6, OPT_BUILD},
+    {HMX_OPT_ACA_TEAMS, "HMX_ACA_TEAM", false, 1, 0, 1, OPT_BUILD},
+    {HMX_OPT_ACA_TEAM_MIN, "HMX_ACA_TEAM_MIN", false, 4096, 2, 1 << 30, OPT_BUILD},
+    {HMX_OPT_ACA_TEAM_AFTER, "HMX_ACA_TEAM_Q", false, 48, 1, 1 << 20, OPT_BUILD},
+    {HMX_OPT_ACA_TEAM_SLICE, "HMX_ACA_TEAM_SLICE", false, 0, 0, 1 << 20, OPT_BUILD},
+};
+struct Options {
+    static constexpr int MAX_ID = 40;
+    double v[MAX_ID];
+    static const OptionSpec *spec(int id) {
+        for (const OptionSpec &s : HMX_OPTION_SPECS)
+            if (s.id == id)
+                return &s;
+        return nullptr;
+    }
+    Options() {
+        for (double &x : v)
+            x = 0;
+        for (const OptionSpec &s : HMX_OPTION_SPECS)
+            v[s.id] = s.def;
+    }
+    // the process environment as the initial values of a NEW operator (A/B runs of unmodified programs); out-of-range values are clamped
+    static Options from_environment() {
+        Options o;
+        for (const OptionSpec &s : HMX_OPTION_SPECS)
+            if (const char *e = getenv(s.env)) {
+                double x = atof(e);
+                if (s.env_inverted)
+                    x = x != 0 ? 0 : 1;
+                o.v[s.id] = std::min(s.hi, std::max(s.lo, x));
+            }
+        return o;
+    }
+    int i(int id) const { return (int)v[id]; }
+    double d(int id) const { return v[id]; }
+};
+
 // One family of streams (E = expand over target ranges, R = reduce over source ranges)
 enum LeafKind { LK_PENDING = 0, LK_DENSE_GEN = 1, LK_DENSE_STAGED = 2, LK_LOWRANK = 3 };
 

@@ -3009,10 +3009,7 @@ __global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))
 #endif // HMX_COMPLEX
 
 // ---------------------------------------------------------------------------------------------
-// Transposed / mirrored passes (trans = 'T', and the symmetric mirror pass
-// add_hmatrix_vector_product.hpp:97-103,154-163).  Same streams, read in the "wrong" orientation:
-// every column (resp. row) needs a cross-lane reduction and results are accumulated with fp64 atomics
-// into a zeroed work vector W = [out | aT].  Correct and coalesced, but not the tuned path.
+// Wave reductions of the mirrored / transposed sweeps (columns of the E-streams, rows of the R-streams read "the other way")
 // ---------------------------------------------------------------------------------------------
 // Eight wave-wide sums for the price of ~1.25: each butterfly step halves the number of live values while
 // halving the lane group that owns them.  On return lane l with (l & 7) == 0 holds the complete sum of input
@@ -3063,96 +3060,6 @@ __device__ __forceinline__ scalar reduce8(const scalar (&v)[8], int lane) {
 #endif
 }
 __device__ __forceinline__ int reduce8_slot(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
-
-struct ColReduceArgs { // over E-streams: W[dst[c]] += sum_i E[i,c] * in[R.off + i]
-    const scalar *stream;
-    const int32_t *order;
-    const int32_t *range_off, *range_len, *range_cols;
-    const int64_t *range_base, *range_colbase;
-    const int32_t *dst; // per column, -1 = skip
-    const scalar *in;
-    scalar *W;
-    int nranges;
-};
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void colreduce_kernel(ColReduceArgs A) {
-    const int R = A.order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int len = A.range_len[R], C = A.range_cols[R];
-    const scalar *E    = A.stream + A.range_base[R] + (lane < len ? lane : 0);
-    const int32_t *dst = A.dst + A.range_colbase[R];
-    const scalar xin   = lane < len ? A.in[A.range_off[R] + lane] : scalar(0);
-    const int slot     = reduce8_slot(lane);
-    for (int c0 = wv * 8; c0 < C; c0 += WAVES * 8) {
-        scalar v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            v[u] = (c0 + u < C) ? stream_load(E + (int64_t)(c0 + u) * len) * xin : scalar(0);
-        const scalar r = reduce8(v, lane);
-        if ((lane & 7) == 0 && c0 + slot < C) {
-            const int d = dst[c0 + slot];
-            if (d >= 0)
-                hmx_atomic_add(&A.W[d], r);
-        }
-    }
-}
-
-struct RowReduceArgs { // over R-streams: W[S.off + i] += sum_col Rs[i,col] * W[coef[col]]
-    const scalar *stream;
-    const int32_t *task_range, *task_chunk;
-    const int32_t *range_off, *range_len, *range_cols, *range_cw;
-    const int64_t *range_base, *range_colbase;
-    const int32_t *coef; // per column index into W, -1 = skip
-    scalar *W;
-    int ntasks;
-    int row_shift; // added to the range's local offset to address W (mirror pass: S0 - T0)
-};
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void rowreduce_kernel(RowReduceArgs A) {
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    if (task >= A.ntasks)
-        return;
-    const int lane = threadIdx.x & 63;
-    const int S = A.task_range[task], ch = A.task_chunk[task];
-    const int len = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-    int w = C - ch * cw;
-    w     = w > cw ? cw : w;
-    const int wp      = hmx_wp(w);
-    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
-    const bool active = col0 < wp;
-    const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * len * cw;
-    const int64_t cb  = A.range_colbase[S] + ch * cw;
-    scalar c0 = scalar(0), c1 = scalar(0);
-    bool any = false;
-    if (col0 < w) {
-        const int d = A.coef[cb + col0];
-        c0          = d >= 0 ? A.W[d] : scalar(0);
-        any         = d >= 0;
-    }
-    if (col1 < w) {
-        const int d = A.coef[cb + col1];
-        c1          = d >= 0 ? A.W[d] : scalar(0);
-        any         = any || d >= 0;
-    }
-    if (!__any(any))
-        return; // no selected column in this chunk (e.g. mirror pass over an off-diagonal stripe)
-    const int slot = reduce8_slot(lane);
-    scalar *out    = A.W + A.range_off[S] + A.row_shift;
-    for (int i0 = 0; i0 < len; i0 += 8) {
-        scalar v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            v[u] = scalar(0);
-            if (active && i0 + u < len) {
-                const scalar2 e = load_pair(src + (int64_t)(i0 + u) * wp, col0, col1, wp);
-                v[u]              = hmx_fma(e.x, c0, e.y * c1);
-            }
-        }
-        const scalar r = reduce8(v, lane);
-        if ((lane & 7) == 0 && i0 + slot < len)
-            hmx_atomic_add(&out[i0 + slot], r);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fused symmetric / Hermitian product on the COMPACT layout (only the stored triangle is in HBM):
@@ -3923,9 +3830,4 @@ __global__ void conj_kernel(int64_t n, const scalar *in, scalar *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
         out[i] = hmx_conj(in[i]);
-}
-__global__ void add_conj_kernel(int64_t n, const scalar *in, scalar *out) { // out += conj(in)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        out[i] += hmx_conj(in[i]);
 }

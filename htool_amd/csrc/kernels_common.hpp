@@ -160,12 +160,6 @@ template <typename T> __device__ __forceinline__ cplx<T> hmx_shfl_xor(cplx<T> v,
 __device__ __forceinline__ double hmx_shfl(double v, int l) { return __shfl(v, l, WAVE); }
 __device__ __forceinline__ float hmx_shfl(float v, int l) { return __shfl(v, l, WAVE); }
 template <typename T> __device__ __forceinline__ cplx<T> hmx_shfl(cplx<T> v, int l) { return cplx<T>(__shfl(v.re, l, WAVE), __shfl(v.im, l, WAVE)); }
-__device__ __forceinline__ void hmx_atomic_add(double *p, double v) { atomicAdd(p, v); }
-__device__ __forceinline__ void hmx_atomic_add(float *p, float v) { atomicAdd(p, v); }
-template <typename T> __device__ __forceinline__ void hmx_atomic_add(cplx<T> *p, cplx<T> v) {
-    atomicAdd(&p->re, v.re);
-    atomicAdd(&p->im, v.im);
-}
 __device__ __forceinline__ double readlane_val(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);

@@ -264,11 +264,22 @@ class EngineT {
     // compression on the device with the USER's generator: htool::VirtualGenerator<T>::copy_submatrix is called on
     // the host for one cross row / column per block and ACA iteration (and for the dense leaves); the ACA arithmetic
     // and every later product run on the GPU.  `A` must outlive this call only.
-    bool compress_with_generator(const htool::VirtualGenerator<T> &A, int compressor, double epsilon, int reqrank) {
+    // `generator_threads`: host threads that may call A.copy_submatrix CONCURRENTLY.  The default follows htool's own build loop
+    // (hmatrix/tree_builder/tree_builder.hpp:603-648): it calls the generator from an OpenMP parallel for only when htool is compiled
+    // with OpenMP and without HTOOL_WITH_PYTHON_INTERFACE (:606) -- a generator written for such a build is thread-safe by htool's own
+    // contract, so all cores are used (0); in every other build the generator has only ever been called from one thread (it may hold
+    // the GIL, or simply not be re-entrant), and it stays on the calling thread (1).
+#if defined(_OPENMP) && !defined(HTOOL_WITH_PYTHON_INTERFACE)
+    static constexpr int default_generator_threads = 0;
+#else
+    static constexpr int default_generator_threads = 1;
+#endif
+    bool compress_with_generator(const htool::VirtualGenerator<T> &A, int compressor, double epsilon, int reqrank, int generator_threads = default_generator_threads) {
         auto thunk = [](void *user, int M, int N, const int32_t *rows, const int32_t *cols, typename Abi<T>::R *out) {
             static_cast<const htool::VirtualGenerator<T> *>(user)->copy_submatrix(M, N, rows, cols, reinterpret_cast<T *>(out));
         };
-        return ok(Abi<T>::set_callback(m_hmatrix, thunk, const_cast<htool::VirtualGenerator<T> *>(&A)), "set callback") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
+        return ok(Abi<T>::set_callback(m_hmatrix, thunk, const_cast<htool::VirtualGenerator<T> *>(&A)), "set callback") &&
+               ok(hmx_hmatrix_set_callback_threads(m_hmatrix, generator_threads), "set callback threads") && ok(hmx_hmatrix_compress(m_hmatrix, compressor, epsilon, reqrank), "compress");
     }
 
     // htool-built H-matrix (any generator, any compressor) -> device

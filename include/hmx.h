@@ -194,13 +194,63 @@ int hmx_hmatrix_set_kernel(hmx_hmatrix *, int kernel, const double *params, int 
  * Like htool's own build loop (HMatrixTreeBuilder::openmp_compute_blocks, hmatrix/tree_builder/tree_builder.hpp:603-648: an OpenMP
  * parallel for over the blocks) the callback is invoked CONCURRENTLY from several host threads, each on blocks of its own, while the
  * uploads and kernels of the other threads' batches are in flight.  hmx_hmatrix_set_callback_threads(H, n): n = 1 keeps every call on
- * the calling thread (what htool does under HTOOL_WITH_PYTHON_INTERFACE, tree_builder.hpp:606; for generators that are not
- * thread-safe), n = 0 (default) uses all cores (at most 64; environment HMX_CALLBACK_THREADS overrides). */
+ * the calling thread (what htool does under HTOOL_WITH_PYTHON_INTERFACE or without OpenMP, tree_builder.hpp:606; for generators that are
+ * not thread-safe), n = 0 (default) uses all cores (at most 64; the environment variable HMX_CALLBACK_THREADS gives another count for
+ * n = 0 only: an explicit n >= 1 always wins).
+ * CONTRACT: with the default the generator MUST be re-entrant -- it is called from threads the library created, several at a time,
+ * exactly as htool's OpenMP build calls it.  A generator that is not (one that holds an interpreter lock, caches into shared state, or
+ * was written for a non-OpenMP htool build) needs hmx_hmatrix_set_callback_threads(H, 1) before hmx_hmatrix_compress.  The C++ adaptor
+ * (htool_adaptor.hpp, compress_with_generator) chooses by htool's own compile-time rule; htool_amd.api pins Python generators to 1. */
 typedef void (*hmx_generator_fn)(void *user, int M, int N, const int32_t *rows, const int32_t *cols, double *out);
 typedef void (*hmx_generator_fn_s)(void *user, int M, int N, const int32_t *rows, const int32_t *cols, float *out);
 int hmx_hmatrix_set_callback(hmx_hmatrix *, hmx_generator_fn fn, void *user);
 int hmx_hmatrix_set_callback_s(hmx_hmatrix *, hmx_generator_fn_s fn, void *user);
 int hmx_hmatrix_set_callback_threads(hmx_hmatrix *, int threads);
+
+/* Per-operator options: the counterpart of HMatrixTreeBuilder's setters (hmatrix/tree_builder/tree_builder.hpp:239-264) for what is specific
+ * to this engine -- layout, kernel selection, compression tuning.  Every operator carries its own values: two operators of one process may
+ * differ, and no product or build ever reads the environment.  The defaults are what bench.py measures; each option also has an environment
+ * variable of the same meaning that is read ONCE, when the operator is created (hmx_hmatrix_create* / hmx_hmatrix_load), as the initial value
+ * -- for A/B runs of unmodified programs.  Values are integers passed as double (HMX_OPT_POOL_RANK_GUESS is fractional).
+ *   when        "layout": before hmx_hmatrix_compress / hmx_hmatrix_finalize (afterwards: HMX_ERR_STATE);
+ *               "build":  before hmx_hmatrix_compress;  "product": any time, takes effect at the next product. */
+typedef enum {
+    /* ---- layout ---- */
+    HMX_OPT_R_PIECE_ROWS      = 1,  /* layout  512   rows per R-stream piece (>= 64)                                         HMX_SR_MAX           */
+    HMX_OPT_R_TREE_PIECES     = 2,  /* layout  1     pieces of large source clusters follow the cluster tree (0: fixed steps) HMX_R_TREE_PIECES    */
+    HMX_OPT_LAYOUT_THREADS    = 3,  /* layout  0     host threads of the pair-list construction (0: automatic, <= 16)        HMX_LAYOUT_THREADS   */
+    HMX_OPT_TASK_ORDER        = 4,  /* layout  1     launch order: 1 heaviest first, 0 address order, 2 weight classes       HMX_SORT_TASKS       */
+    HMX_OPT_SYM_STORAGE       = 5,  /* layout  0     symmetric / Hermitian operators: 0 stored triangle + fused product,
+                                                     1 mirrored leaves laid out explicitly (twice the memory)                HMX_SYM_EXPANDED     */
+    HMX_OPT_BUILD_TIMING      = 6,  /* build   0     per-phase build times on stderr                                         HMX_BUILD_TIMING     */
+    /* ---- products ---- */
+    HMX_OPT_REDUCE_WAVES      = 10, /* product 0     waves per workgroup of the single-vector reduce stage (0: automatic)    HMX_REDUCE_WAVES     */
+    HMX_OPT_EXPAND_WAVES      = 11, /* product 0     ... of the expand stage (0: automatic: 4, or 8 for <= 4096 row ranges)  HMX_EXPAND_WAVES     */
+    HMX_OPT_MULTI_RHS_FUSED   = 12, /* product 1     several right-hand sides in one sweep over the streams (0: one product
+                                                     per right-hand side)                                                    HMX_NO_FUSED_MU (inverted) */
+    HMX_OPT_MATRIX_CORES      = 13, /* product 1     groups of 16 / 32 (complex: 8 / 16) right-hand sides on the matrix cores
+                                                     (0: VALU kernels throughout)                                            HMX_NO_MFMA (inverted) */
+    HMX_OPT_MATRIX_CORES_F32  = 14, /* product 1     ... for 4-byte real coefficients too                                    HMX_MFMA_F32         */
+    HMX_OPT_WIDE_SWEEPS       = 15, /* product 1     more than 16 (complex: 8) right-hand sides: sweeps of up to 32 (16)     HMX_MFMA_WIDE        */
+    HMX_OPT_SCALAR_OPERANDS   = 16, /* product -1    VALU multi-RHS reduce stage with operands in scalar registers
+                                                     (-1: automatic = 4-byte coefficients only)                              HMX_MU_SCALAR        */
+    HMX_OPT_SYM_MULTI_RHS     = 17, /* product -1    several right-hand sides on a square symmetric operator: 1 on the stored
+                                                     triangle, 0 on an expanded view of the operator, -1 automatic           HMX_SYM_MU_FUSED     */
+    HMX_OPT_SYM_NO_VIEW       = 18, /* product 0     never build the expanded view                                            HMX_SYM_NO_VIEW      */
+    HMX_OPT_TRANSPOSED_LAYOUT = 19, /* product -1    transposed stream layout: -1 for several right-hand sides only (HBM
+                                                     permitting), 1 also for single vectors, 0 never (stored data only)      HMX_TRANS_STREAMS    */
+    /* ---- compression ---- */
+    HMX_OPT_CALLBACK_THREADS  = 30, /* build   0     = hmx_hmatrix_set_callback_threads                                      HMX_CALLBACK_THREADS */
+    HMX_OPT_CALLBACK_DRIVERS  = 31, /* build   8     generator threads that also drive a HIP stream                          HMX_CALLBACK_DRIVERS */
+    HMX_OPT_POOL_SAMPLE       = 32, /* build   1     size the cross pool from a sample run over every K-th block             HMX_POOL_SAMPLE      */
+    HMX_OPT_POOL_RANK_GUESS   = 33, /* build   0     a-priori rank the pool is sized for (0: 8 + 3 log10(1/eps), >= 16)      HMX_POOL_RANK_GUESS  */
+    HMX_OPT_ACA_TEAMS         = 34, /* build   1     large high-rank blocks continue in teams of workgroups                  HMX_ACA_TEAM         */
+    HMX_OPT_ACA_TEAM_MIN      = 35, /* build   4096  ... from this many rows + columns                                       HMX_ACA_TEAM_MIN     */
+    HMX_OPT_ACA_TEAM_AFTER    = 36, /* build   48    ... after this many iterations                                          HMX_ACA_TEAM_Q       */
+    HMX_OPT_ACA_TEAM_SLICE    = 37  /* build   0     entries of a line per workgroup of a team (0: adaptive 1024 / 256)      HMX_ACA_TEAM_SLICE   */
+} hmx_option;
+int hmx_hmatrix_set_option(hmx_hmatrix *, int option /* hmx_option */, double value);
+int hmx_hmatrix_get_option(const hmx_hmatrix *, int option, double *value);
 
 /* HMatrixTreeBuilder::{sequential,openmp}_compute_blocks (tree_builder.hpp:568-666): compress every
  * admissible leaf (fallback to dense when the compressor reports failure), assemble every dense leaf
@@ -232,7 +282,16 @@ int hmx_hmatrix_get_blocks(const hmx_hmatrix *, int64_t count, const int64_t *le
 int hmx_hmatrix_get_blocks_s(const hmx_hmatrix *, int64_t count, const int64_t *leaves, float *const *U_or_D, float *const *V);
 int hmx_hmatrix_get_blocks_z(const hmx_hmatrix *, int64_t count, const int64_t *leaves, double *const *U_or_D, double *const *V);
 int hmx_hmatrix_get_blocks_c(const hmx_hmatrix *, int64_t count, const int64_t *leaves, float *const *U_or_D, float *const *V);
+/* hmx_stats may grow at its END in later versions of this header.  hmx_hmatrix_stats_sized writes at most `struct_size` bytes, so a caller
+ * compiled against an older (shorter) hmx_stats is never overrun; hmx_hmatrix_stats(H, out) in source code is that call with
+ * sizeof(hmx_stats) of the header it was compiled with.  (The exported function of the same name, kept for binaries built before the macro
+ * existed, fills only the fields hmx_stats had in its first version -- up to and including t_pack_s.)  hmx_abi_version() returns
+ * HMX_ABI_VERSION of the library: it changes when a struct grows or an entry point is added, never for existing signatures. */
+#define HMX_ABI_VERSION 5
+int hmx_abi_version(void);
+int hmx_hmatrix_stats_sized(const hmx_hmatrix *, hmx_stats *out, size_t struct_size);
 int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);
+#define hmx_hmatrix_stats(H, out) hmx_hmatrix_stats_sized((H), (out), sizeof(hmx_stats))
 /* Complex coefficients: the entry points above that carry coefficients, for HMatrix<std::complex<double>> (_z) and
  * HMatrix<std::complex<float>> (_c).  Symmetry 'S' = complex symmetric (mirror pass with trans 'T'), 'H' = Hermitian (mirror pass
  * with trans 'C', hemv on the diagonal leaves): hmatrix/linalg/add_hmatrix_vector_product.hpp:36-54,70.  trans in {'N','T','C'};
@@ -256,8 +315,9 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *, char trans, const float *alpha
 /* Memory: after compression the device holds the streams the products read AND the pool they were packed from (kept for
  * get_block / save / recompress / the transposed layout; 14 GB next to 18.5 GB of streams at N=1e6).  This gives the pool back:
  * only products remain possible (transposed single-vector products run on the stored data and do not need the pool; bit 0 of
- * with_transposed builds the transposed stream layout first, which the fused multi-RHS 'T' products run on; bit 1 builds the expanded view that multi-RHS products on compact symmetric storage run on -- without it they fall
- * back to one single-vector product per right-hand side). */
+ * with_transposed builds the transposed stream layout first, which the fused multi-RHS 'T' products prefer; bit 1 builds the expanded
+ * view of a compact symmetric operator first -- without them such products run on the stored data / the stored triangle, which needs
+ * no second layout). */
 int hmx_hmatrix_release_factors(hmx_hmatrix *, int with_transposed);
 /* Transposed products ('T' / 'C').  One vector: on the STORED data, as the reference does (it swaps the cluster roles on the same leaves,
  * hmatrix/linalg/add_hmatrix_vector_product.hpp:74-81) -- column sums of the E-streams per row range, then an owner-computes sweep over the
@@ -413,6 +473,14 @@ int hmx_dist_set_point_to_point(hmx_dist *, int (*send)(const void *buf, size_t 
  * zero-padded length-N output vector ("RCCL all-reduce of the output vector": p times the bytes for the same result; single exchange,
  * not chunked).  Every rank must choose the same. */
 int hmx_dist_set_output_collective(hmx_dist *, int all_reduce);
+/* Test / A-B switches of one DistributedOperator (every rank the same value).  The environment variables HMX_DIST_FORCE_COLLECTIVES,
+ * HMX_DIST_NO_ALLGATHER, HMX_DIST_NO_REDUCE_SCATTER give the initial values, read once in hmx_dist_create. */
+typedef enum {
+    HMX_DIST_OPT_FORCE_COLLECTIVES = 1, /* issue the collectives even with one rank */
+    HMX_DIST_OPT_NO_ALLGATHER      = 2, /* grouped broadcasts instead of ncclAllGather for equal parts */
+    HMX_DIST_OPT_NO_REDUCE_SCATTER = 3  /* all-reduce + slice instead of ncclReduceScatter (transposed local-to-local product) */
+} hmx_dist_option;
+int hmx_dist_set_option(hmx_dist *, int option /* hmx_dist_option */, int value);
 /* Exposed exchange time, measured: with profiling on, hmx_dist_matvec_global_to_global (trans = 'N') records events on the caller's
  * stream at its start, after its last local kernel and when the whole result is there.  hmx_dist_last_exchange_ms returns
  * local_ms = start -> last local kernel done and exposed_ms = from there to the end (the exchange minus whatever ran under the local

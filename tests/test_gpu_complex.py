@@ -15,9 +15,14 @@ from test_host_structure import build_trees
 pytestmark = pytest.mark.gpu
 
 
-def build_zengine(p, compress=True, generator=True, dtype=None):
+ENGINE_OPTIONS = {}  # options every operator of build_zengine gets (tests that re-run other tests on another code path set it)
+
+
+def build_zengine(p, compress=True, generator=True, dtype=None, options=None):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    for k, v in dict(ENGINE_OPTIONS, **(options or {})).items():
+        tb.set_option(k, v)
     tb.set_low_rank_generator(p["compressor"])
     gen = device_generator(p, T, S) if generator else None
     dt = dtype or (np.complex64 if p["prec"] == "c32" else np.complex128)
@@ -66,10 +71,8 @@ def test_complex_compression_matches_reference(name):
 @pytest.mark.parametrize("name", Z_CASES)
 def test_complex_workgroup_teams_build_the_same_operator(name, monkeypatch):
     """The team kernels of the ACA (tests/test_gpu_parity.py::test_workgroup_teams_build_the_same_operator) for complex coefficients."""
-    monkeypatch.setenv("HMX_ACA_TEAM_MIN", "48")
-    monkeypatch.setenv("HMX_ACA_TEAM_Q", "2")
-    monkeypatch.setenv("HMX_ACA_TEAM_SLICE", "64")
-    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "3")
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "ENGINE_OPTIONS", dict(aca_team_min=48, aca_team_after=2, aca_team_slice=64, pool_rank_guess=3))
     test_complex_compression_matches_reference(name)
     test_complex_products_match_reference(name)
 
@@ -177,10 +180,10 @@ def test_eight_complex_rhs_on_the_matrix_cores(dtype, tol, mu, monkeypatch):
         if Ho is not None:
             ref = Ho.matmat_row_major(X, trans, alpha, beta, Y0)
         else:
-            monkeypatch.setenv("HMX_NO_MFMA", "1")
+            H.set_option("matrix_cores", 0)
             ref = Y0.copy()
             hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, ref, mu)
-            monkeypatch.delenv("HMX_NO_MFMA")
+            H.set_option("matrix_cores", 1)
         assert rel_err(Y, ref) < tol, (trans, rel_err(Y, ref))
 
 
@@ -304,16 +307,12 @@ def test_complex_dtype_mismatch_is_refused():
         hm.internal_add_hmatrix_vector_product("N", 1.0, H, np.zeros(p["n"]), 0.0, np.zeros(p["n"]))
 
 
-@pytest.mark.parametrize("knob", ["HMX_SYM_COMPACT", "HMX_SYM_EXPANDED"])
-def test_complex_symmetric_other_layouts(knob, monkeypatch):
-    """The default layout of symmetric / Hermitian storage is compact with the fused product (what every other test here runs).
-    HMX_SYM_COMPACT=1 with complex symmetric ('S') storage: the mirror pass through the in-place transposed kernels (complex
-    atomics; Hermitian storage has no such pass and stays fused).  HMX_SYM_EXPANDED=1: mirrored leaves laid out explicitly
-    (conjugated for 'H')."""
-    monkeypatch.setenv(knob, "1")
+def test_complex_symmetric_expanded_layout():
+    """The default layout of symmetric / Hermitian storage is the stored triangle with the fused product (what every other test here runs).
+    Option sym_storage = 1: mirrored leaves laid out explicitly (conjugated for 'H')."""
     for name in ("ellipse_n3000_z64_symL", "ball_n2000_z64_hermU", "ball_n2000_c32_hermL"):
         p, g = params(name), load(name)
-        T, S, H = build_zengine(p)
+        T, S, H = build_zengine(p, options=dict(sym_storage=1))
         x, xT, y0, y0T, alpha, beta = zinputs(H, g)
         tol = 1e-5 if p["prec"] == "c32" else 1e-10
         y = y0.copy()
@@ -326,19 +325,22 @@ def test_complex_symmetric_other_layouts(knob, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["ball_n2000_z64_p2_hermL_rank0", "ball_n2000_z64_hermU", "ball_n2000_z64_partial"])
-@pytest.mark.parametrize("streams,tables", [("0", "1"), ("0", "0"), ("1", "1")])
-def test_conjugate_transposed_products_without_the_transposed_layout(name, streams, tables, monkeypatch):
-    """'C' (and 'T' where the reference allows it) with the transposed stream layout forbidden: an ordinary operator runs on its stored data (or,
-    HMX_TRANS_TABLES=0, through the in-place passes), a row-restricted Hermitian operator through the in-place passes with its mirrored leaves
-    applied CONJUGATED (until round 4 they were applied as stored: wrong by their imaginary parts -- found by tools/fuzz_parity.py)."""
-    monkeypatch.setenv("HMX_TRANS_STREAMS", streams)
-    monkeypatch.setenv("HMX_TRANS_TABLES", tables)
+@pytest.mark.parametrize("layout", [0, 1])
+def test_conjugate_transposed_products_without_the_transposed_layout(name, layout):
+    """'C' (and 'T' where the reference allows it) with the transposed stream layout forbidden (option transposed_layout = 0): an ordinary operator
+    runs on its stored data; a row-restricted Hermitian operator (mirrored leaves among ordinary ones) only runs on its transposed view, where the
+    mirrored leaves are applied CONJUGATED -- forbidding the view is reported as an error."""
     p, g = params(name), load(name)
     T, S, H = build_zengine(p)
+    H.set_option("transposed_layout", layout)
     x, xT, y0, y0T, alpha, beta = zinputs(H, g)
     for trans, key in (("T", "yT"), ("C", "yC")):
         if key in g:
             y = y0T.copy()
+            if layout == 0 and p["sym"] != "N" and p["rank"] >= 0:
+                with pytest.raises(hm.HmxError, match="transposed stream layout"):
+                    hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y)
+                continue
             hm.internal_add_hmatrix_vector_product(trans, alpha, H, xT, beta, y)
             assert rel_err(y, g[key]) < 1e-10, (trans, rel_err(y, g[key]))
             X = np.stack([xT, 2 * xT, -xT], axis=1).copy()

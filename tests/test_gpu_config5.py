@@ -16,10 +16,9 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def test_config5_flags_one_gpu_sixteen_rhs_against_oracle_on_a_row_slab(monkeypatch):
+def test_config5_flags_one_gpu_sixteen_rhs_against_oracle_on_a_row_slab():
     from oracle import oracle as O
     # the 16-RHS product on the STORED TRIANGLE (default when HBM has no room for an expanded copy; forced here: one GPU has)
-    monkeypatch.setenv("HMX_SYM_MU_FUSED", "1")
     n, mu = int(os.environ.get("HMX_TEST_C5_N", 4000000)), 16
     x = hm.create_geometry("ellipse", n)
     b = hm.ClusterTreeBuilder()
@@ -31,6 +30,7 @@ def test_config5_flags_one_gpu_sixteen_rhs_against_oracle_on_a_row_slab(monkeypa
     tb.set_minimal_target_depth(d)
     tb.set_minimal_source_depth(d)
     H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, dtype=np.float32)
+    H.set_option("sym_multi_rhs", 1)
     st = H.stats()
     assert st["n_false_positive"] == 0 and st["rank_max"] < 64
     rng = np.random.default_rng(5)

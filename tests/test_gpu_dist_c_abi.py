@@ -1,5 +1,5 @@
 """The C-level DistributedOperator (hmx_dist_*, include/hmx.h) without torch: libhmx + the system RCCL, one rank (the only size one
-GPU offers; with HMX_DIST_FORCE_COLLECTIVES=1 the collectives are really issued on a one-rank communicator, through both the
+GPU offers; with the option force_collectives the collectives are really issued on a one-rank communicator, through both the
 all-gather and the grouped-broadcast route).  Device memory through the HIP runtime directly.  Subprocess: HMX_NO_TORCH must be set
 before libhmx is loaded."""
 import os
@@ -18,7 +18,7 @@ SCRIPT = textwrap.dedent('''
     os.environ["HMX_NO_TORCH"] = "1"
     sys.path.insert(0, %r)
     import htool_amd as hm
-    from htool_amd._lib import lib, check
+    from htool_amd._lib import lib, check, DIST_OPTIONS
     L = lib()
     hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
     rccl = C.CDLL("/opt/rocm/lib/librccl.so", mode=C.RTLD_GLOBAL)
@@ -48,6 +48,9 @@ SCRIPT = textwrap.dedent('''
         H = tb.build(hm.InvDistGenerator(3, x3, x3, 1e-5, 1.0, 1.0, 0.5 if cplx else 0.0), T, T, 0, 0, dtype=dtype)
         D = C.c_void_p()
         check(L.hmx_dist_create(H._h, T._h, T._h, comm, 0, 1, None, C.byref(D)))
+        forced = "force_collectives" in OPTIONS
+        for name in OPTIONS:  # per-operator switches (hmx_dist_set_option), not process state
+            check(L.hmx_dist_set_option(D, DIST_OPTIONS[name], 1))
         xin = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
         y0 = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dtype)
         ab = np.array([1.5 - (0.5j if cplx else 0), 0.25 + (1j if cplx else 0)], dtype=dtype)
@@ -64,13 +67,13 @@ SCRIPT = textwrap.dedent('''
                 assert err < (1e-5 if dtype == np.float32 else 1e-13), (np.dtype(dtype).name, trans, fn.__name__, err)
                 hip.hipFree(dx); hip.hipFree(dy)
         # the overlapped exchange (row-chunked expand stage, every chunk's rows exchanged on the side stream): with
-        # HMX_DIST_FORCE_COLLECTIVES=1 through the real RCCL (all-gather of the chunk bounds, grouped broadcasts, events)
+        # the option force_collectives: through the real RCCL (all-gather of the chunk bounds, grouped broadcasts, events)
         ref = y0.copy()
         hm.internal_add_hmatrix_vector_product("N", ab[0], H, xin, ab[1], ref)
         for chunks in (2, 3, 0):
             check(L.hmx_dist_set_overlap(D, chunks, None))
             used = L.hmx_dist_overlap_chunks(D)
-            assert used == (chunks if os.environ.get("HMX_DIST_FORCE_COLLECTIVES") else 0), (chunks, used)
+            assert used == (chunks if forced else 0), (chunks, used)
             dx, dy = dev(xin), dev(y0)
             check(L.hmx_dist_matvec_global_to_global(D, b"N", pa, dx, pb, dy, None))
             assert hip.hipDeviceSynchronize() == 0
@@ -82,10 +85,10 @@ SCRIPT = textwrap.dedent('''
 ''') % ROOT
 
 
-@pytest.mark.parametrize("env", [{}, {"HMX_DIST_FORCE_COLLECTIVES": "1"}, {"HMX_DIST_FORCE_COLLECTIVES": "1", "HMX_DIST_NO_ALLGATHER": "1"}])
-def test_c_level_distributed_operator(env):
-    e = dict(os.environ, HMX_NO_TORCH="1", **env)
-    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=e)
+@pytest.mark.parametrize("options", [[], ["force_collectives"], ["force_collectives", "no_allgather"]])
+def test_c_level_distributed_operator(options):
+    e = dict(os.environ, HMX_NO_TORCH="1")
+    out = subprocess.run([sys.executable, "-c", "OPTIONS = %r\n" % (options,) + SCRIPT], capture_output=True, text=True, timeout=600, env=e)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("ok ") == 3, out.stdout
 

@@ -27,14 +27,18 @@ def builder(p):
     return tb
 
 
-def both_routes(p, threads):
+def both_routes(p, threads, options=None):
     T, S = build_trees(p)
     dt = NP[p["prec"]]
     herm = p["sym"] == "H"
     dev = device_generator(p, T, S)
     host = native_inv_dist_generator(T.coordinates, S.coordinates, p["delta"], p["scale"], p["cre"], p["cim"], herm, dtype=dt, threads=threads)
-    Hd = builder(p).build(dev, T, S, p["rank"], p["rank"], dtype=dt)
-    Hh = builder(p).build(host, T, S, p["rank"], p["rank"], dtype=dt)
+    bd, bh = builder(p), builder(p)
+    for k, v in (options or {}).items():
+        bd.set_option(k, v)
+        bh.set_option(k, v)
+    Hd = bd.build(dev, T, S, p["rank"], p["rank"], dtype=dt)
+    Hh = bh.build(host, T, S, p["rank"], p["rank"], dtype=dt)
     return Hd, Hh
 
 
@@ -74,13 +78,11 @@ def test_compiled_generator_on_all_threads_builds_the_device_operator(name, thre
 
 
 @pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_z64_hermU"])
-def test_pool_growth_parks_blocks_and_continues_them(name, monkeypatch):
+def test_pool_growth_parks_blocks_and_continues_them(name):
     """A pool sized for rank 1 runs out in the first iterations: the blocks are parked with their row pivot, the pool grows and they
     continue -- several times -- to the same operator."""
     p = params(name)
-    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "1")
-    Hd, Hh = both_routes(p, 5)
-    monkeypatch.delenv("HMX_POOL_RANK_GUESS")
+    Hd, Hh = both_routes(p, 5, options=dict(pool_rank_guess=1))
     same_operator(Hd, Hh)
     assert np.array_equal(Hh.leaf_table(), load(name)["leaves"])
 

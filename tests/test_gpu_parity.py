@@ -6,6 +6,7 @@ Bars: block structure and ranks identical to the reference; dense entries bit-ex
 reference's own result, and <= 1e-12 against the CPU leaf loop multiplying the SAME compressed blocks.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -20,9 +21,14 @@ DEVICE_COMPRESSORS = ("partialACA", "sympartialACA", "fullACA", "SVD")
 ACA_CASES = [c for c in HMAT_CASES if params(c)["compressor"] in ("partialACA", "sympartialACA")]
 
 
-def build_engine(p, compress=True, generator=True):
+ENGINE_OPTIONS = {}  # options every operator of build_engine gets (tests that re-run other tests on another code path set it)
+
+
+def build_engine(p, compress=True, generator=True, options=None):
     T, S = build_trees(p)
     tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+    for k, v in dict(ENGINE_OPTIONS, **(options or {})).items():  # engine options of this operator (hmx_hmatrix_set_option), set before the build
+        tb.set_option(k, v)
     # fixtures written with htool's RecompressedLowRankGenerator / recompression(hmatrix): the wrapped form of the compressor
     tb.set_low_rank_generator(p["compressor"] if p["compressor"] in DEVICE_COMPRESSORS else "partialACA", recompressed=bool(compress and p["recompress"]))
     tb.set_minimal_target_depth(p["mindepth"])
@@ -408,18 +414,14 @@ def test_fp32_engine_against_reference(name):
 SYM_CASES = [c for c in ACA_CASES if params(c)["sym"] == "S"]
 
 
-@pytest.mark.parametrize("layout", ["fused", "atomic", "expanded"])
+@pytest.mark.parametrize("layout", ["fused", "expanded"])
 @pytest.mark.parametrize("name", SYM_CASES)
-def test_symmetric_storage_layouts(name, layout, monkeypatch):
-    """Symmetric storage has three device layouts: compact with the fused product (default: only the stored triangle in HBM,
-    forward product and mirrored column sums in one sweep), compact with the atomics-based mirror pass (HMX_SYM_COMPACT=1) and
-    expanded (HMX_SYM_EXPANDED=1, mirrored leaves laid out explicitly).  All must reproduce the reference."""
-    if layout == "atomic":
-        monkeypatch.setenv("HMX_SYM_COMPACT", "1")
-    elif layout == "expanded":
-        monkeypatch.setenv("HMX_SYM_EXPANDED", "1")
+def test_symmetric_storage_layouts(name, layout):
+    """Symmetric storage has two device layouts: the stored triangle with the fused product (default: forward product and mirrored column
+    sums in one sweep) and expanded (option sym_storage = 1: mirrored leaves laid out explicitly).  Both must reproduce the reference."""
     p, g = params(name), load(name)
-    T, S, H = build_engine(p)
+    T, S, H = build_engine(p, options=dict(sym_storage=1) if layout == "expanded" else None)
+    assert H.get_option("sym_storage") == (1 if layout == "expanded" else 0)
     assert np.array_equal(H.leaf_table(), g["leaves"])
     x, xT, y0, y0T = inputs(H)
     alpha, beta = g["alphabeta"][:2]
@@ -472,10 +474,10 @@ def test_sixteen_rhs_mfma_path_against_the_oracle(sym, trans):
 
 @pytest.mark.parametrize("mu", [17, 23, 32, 40, 70])
 @pytest.mark.parametrize("sym,trans,f32", [("N", "N", False), ("S", "N", False), ("N", "T", False), ("N", "N", True)])
-def test_sweeps_of_32_right_hand_sides_against_the_oracle(mu, sym, trans, f32, monkeypatch):
+def test_sweeps_of_32_right_hand_sides_against_the_oracle(mu, sym, trans, f32):
     """More than 16 right-hand sides: sweeps of up to 32 (expand_mfma32s_kernel / reduce_mfma32s_kernel: every tile element feeds two
     MFMAs; 17 ... 31 as one ragged sweep, 40 = 32 + 8, 70 = 32 + 32 + 6) against the oracle's row-major product on the operator the
-    oracle compressed, and against the 16-wide sweeps (HMX_MFMA_WIDE=0) -- bitwise where those run on the matrix cores for every column
+    oracle compressed, and against the 16-wide sweeps (option wide_sweeps = 0) -- bitwise where those run on the matrix cores for every column
     (23 = 16 + ragged 7, 32, 70): each result column is then the same sum in the same order."""
     from oracle import oracle as O
     n = 3000
@@ -500,33 +502,25 @@ def test_sweeps_of_32_right_hand_sides_against_the_oracle(mu, sym, trans, f32, m
     assert any("mfma32s" in k for k in names), names
     ref = Ho.matmat_row_major(X.astype(np.float64), trans, 1.5, 0.5, Y0.astype(np.float64))
     assert rel_err(Y, ref) < (5e-4 if f32 else 1e-12), rel_err(Y, ref)
-    monkeypatch.setenv("HMX_MFMA_WIDE", "0")  # read once per process: a fresh process for the 16-wide sweeps
-    import subprocess, sys, os, tempfile
-    with tempfile.TemporaryDirectory() as d:
-        np.save(os.path.join(d, "Y.npy"), Y)
-        code = (
-            "import sys, numpy as np; sys.path.insert(0, %r); import htool_amd as hm; from oracle import oracle as O\n"
-            "n, mu = %d, %d\n"
-            "x = hm.create_geometry('ball', n); b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(70); T = b.create_cluster_tree(n, 3, x, 2, 2)\n"
-            "tb = hm.HMatrixTreeBuilder(1e-6, 10.0, %r, %r); tb.set_low_rank_generator(%r)\n"
-            "H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T, dtype=np.%s)\n"
-            "X = O.hashed_vector(n * mu, 41).reshape(n, mu).astype(np.%s); Y = O.hashed_vector(n * mu, 42).reshape(n, mu).astype(np.%s)\n"
-            "H.set_profiling(True); hm.internal_add_hmatrix_matrix_product_row_major(%r, 1.5, H, X, 0.5, Y, mu)\n"
-            "assert not any('mfma32s' in k for k, _ in H.last_kernel_times())\n"
-            "W = np.load(%r); bitwise = %r\n"
-            "assert (np.array_equal(Y, W) if bitwise else np.linalg.norm(Y - W) <= %g * np.linalg.norm(W)), float(np.abs(Y - W).max())\n"
-        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, mu, sym, "L" if sym == "S" else "N", comp, dt.__name__, dt.__name__, dt.__name__, trans,
-             os.path.join(d, "Y.npy"), mu in (23, 32, 70), 1e-5 if f32 else 1e-13)  # 17 = 16 + 1, 40 = 32 + 8: the 16-wide run finishes on the VALU kernels
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ))
-        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    # the same operator with sweeps of 16 (a per-operator option: no second process, no second build)
+    H.set_option("wide_sweeps", 0)
+    H.set_profiling(True)
+    W = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.5, H, X, 0.5, W, mu)
+    assert not any("mfma32s" in k for k, _ in H.last_kernel_times())
+    H.set_profiling(False)
+    H.set_option("wide_sweeps", 1)
+    if mu in (23, 32, 70):  # 17 = 16 + 1, 40 = 32 + 8: the 16-wide run finishes on the VALU kernels
+        assert np.array_equal(Y, W), float(np.abs(Y - W).max())
+    else:
+        assert rel_err(W, Y) <= (1e-5 if f32 else 1e-13)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-5)])
-def test_sixteen_rhs_mfma_path(dtype, tol, monkeypatch):
+def test_sixteen_rhs_mfma_path(dtype, tol):
     """mu = 16 runs on the matrix cores (v_mfma_f64_16x16x4 / v_mfma_f32_16x16x4).  Checked against 16 separate
-    single-vector products, against the VALU multi-RHS kernels (HMX_NO_MFMA=1), with ragged mu (19 = 16 + 2 + 1) and
-    with alpha/beta, on a symmetric (expanded) and a rectangular operator."""
-    monkeypatch.setenv("HMX_MFMA_F32", "1")  # exercise the fp32 MFMA form too (off by default: slower than VALU)
+    single-vector products, against the VALU multi-RHS kernels (option matrix_cores = 0), with ragged mu (19 = 16 + 2 + 1) and
+    with alpha/beta, on a symmetric and a rectangular operator."""
     n = 5000
     x = hm.create_geometry("ball", n)
     xs = hm.create_geometry("disk", 3000, 2.0)
@@ -550,19 +544,19 @@ def test_sixteen_rhs_mfma_path(dtype, tol, monkeypatch):
                 hm.internal_add_hmatrix_vector_product("N", 1.5, H, np.ascontiguousarray(X[:, c]), 0.5, y)
                 ref[:, c] = y
             assert rel_err(Y, ref) < tol
-            monkeypatch.setenv("HMX_NO_MFMA", "1")
+            H.set_option("matrix_cores", 0)
             Yv = Y0.copy()
             hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, Yv, mu)
             assert rel_err(Y, Yv) < tol
             # VALU kernels with the wave-uniform operand in LDS (0) / in scalar registers (1): same arithmetic, same order
             out = {}
-            for mode in ("0", "1"):
-                monkeypatch.setenv("HMX_MU_SCALAR", mode)
+            for mode in (0, 1):
+                H.set_option("scalar_operands", mode)
                 out[mode] = Y0.copy()
                 hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, out[mode], mu)
-            monkeypatch.delenv("HMX_MU_SCALAR")
-            monkeypatch.delenv("HMX_NO_MFMA")
-            assert rel_err(out["0"], Yv) < tol and rel_err(out["1"], out["0"]) < tol
+            H.set_option("scalar_operands", -1)
+            H.set_option("matrix_cores", 1)
+            assert rel_err(out[0], Yv) < tol and rel_err(out[1], out[0]) < tol
 
 
 def test_reference_examples_reproduce_published_errors():
@@ -658,10 +652,11 @@ def test_host_callback_generator_exception_surfaces():
 
 @pytest.mark.parametrize("name", ["rect_ball1500_disk1000", "ellipse_n4000_p4_rank2", "ball_n2000_p2_symL_rank1", "ellipse_n3000_symL_default"])
 @pytest.mark.parametrize("mu", [1, 3, 16])
-def test_transposed_products_both_layouts(name, mu, monkeypatch):
+def test_transposed_products_both_layouts(name, mu):
     """trans='T' on the stored data (default for one vector on an ordinary operator: mirrored column sums + owner-computes second sweep, no
-    second layout, bit-reproducible), through the in-place passes (HMX_TRANS_STREAMS=0 HMX_TRANS_TABLES=0: wave reductions + atomics) and
-    through the transposed stream layout (HMX_TRANS_STREAMS=1; what several right-hand sides use): all equal the CPU leaf loop on the same blocks."""
+    second layout, bit-reproducible; option transposed_layout = 0 forbids anything else) and through the transposed stream layout
+    (transposed_layout = 1; what several right-hand sides prefer): both equal the CPU leaf loop on the same blocks.  A row-restricted symmetric
+    operator has mirrored leaves among ordinary ones and only runs on its transposed view: forbidding it is an error, not a slow path."""
     from oracle import oracle as O
     p = params(name)
     T, S, H = build_engine(p)
@@ -683,15 +678,18 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
     Ho = O.HMatrix.from_blocks(tab, np.array(offs), np.concatenate(data), root, H.get_symmetry_for_leaves(), H.get_UPLO_for_leaves())
     nr, nc = H.nb_rows(), H.nb_cols()
     rng = np.random.default_rng(3)
-    for layout, tables in (("0", "1"), ("0", "0"), ("1", "1")):  # (the transposed layout last: once built it is the one that runs)
-        monkeypatch.setenv("HMX_TRANS_STREAMS", layout)
-        monkeypatch.setenv("HMX_TRANS_TABLES", tables)
+    for layout in (0, 1):  # (the transposed layout last: once built it is the one that runs)
+        H.set_option("transposed_layout", layout)
+        if layout == 0 and p["sym"] != "N" and p["rank"] >= 0:
+            with pytest.raises(hm.HmxError, match="transposed stream layout"):
+                hm.internal_add_hmatrix_vector_product("T", 1.5, H, rng.standard_normal(nr), 0.0, np.zeros(nc))
+            continue
         if mu == 1:
             x, y0 = rng.standard_normal(nr), rng.standard_normal(nc)
             y = y0.copy()
             hm.internal_add_hmatrix_vector_product("T", 1.5, H, x, -0.5, y)
             assert rel_err(y, Ho.matvec(x, "T", 1.5, -0.5, y0)) < 1e-12
-            if (layout, tables) == ("0", "1") and p["sym"] == "N":
+            if layout == 0 and p["sym"] == "N":
                 assert H.stats()["transposed_bytes"] > 0  # the tables, a few per cent of the operator
                 assert H.stats()["transposed_bytes"] < 0.5 * H.stats()["stream_bytes"] + (1 << 20)
                 y2 = y0.copy()
@@ -702,7 +700,7 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
             Y = Y0.copy()
             hm.internal_add_hmatrix_matrix_product_row_major("T", 1.5, H, X, -0.5, Y, mu)
             assert rel_err(Y, Ho.matmat_row_major(X, "T", 1.5, -0.5, Y0)) < 1e-12
-            if (layout, tables) == ("0", "1") and p["sym"] == "N":  # no transposed layout allowed: the stored data, 16 right-hand sides per sweep
+            if layout == 0 and p["sym"] == "N":  # no transposed layout allowed: the stored data, 16 right-hand sides per sweep
                 assert 0 < H.stats()["transposed_bytes"] < 0.5 * H.stats()["stream_bytes"] + (1 << 20)
                 Y2 = Y0.copy()
                 hm.internal_add_hmatrix_matrix_product_row_major("T", 1.5, H, X, -0.5, Y2, mu)
@@ -710,13 +708,12 @@ def test_transposed_products_both_layouts(name, mu, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["ellipse_n3000_partial", "ball_n1500_eps1e-12", "ball_n1200_fullACA", "ball_n1200_SVD", "ball_n2000_symL_eta3"])
-def test_pool_estimate_too_low_is_retried(name, monkeypatch):
+def test_pool_estimate_too_low_is_retried(name):
     """The cross pool is sized from a rank estimate.  When the pool runs out, the blocks of the device ACA suspend, the pool grows and
     they continue with their next iteration (several rounds with a guess of 1); the blocks of fullACA / SVD that found it exhausted --
     and only they -- are compressed again after it has grown.  Either way the operator is the one the reference builds."""
     p, g = params(name), load(name)
-    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "1")
-    T, S, H = build_engine(p)
+    T, S, H = build_engine(p, options=dict(pool_rank_guess=1))
     assert np.array_equal(H.leaf_table(), g["leaves"])
     x, xT, y0, y0T = inputs(H)
     alpha, beta = g["alphabeta"][:2]
@@ -730,11 +727,9 @@ def test_workgroup_teams_build_the_same_operator(name, monkeypatch):
     """Large blocks whose rank keeps growing are continued by teams of workgroups (aca_team_*_kernel, three launches per iteration).
     Forced onto the fixtures here -- every block of 48 rows + columns or more after two iterations, 64 entries of a line per
     workgroup, and a pool that runs out on the way: structure, ranks, factors and products are the reference's."""
-    monkeypatch.setenv("HMX_ACA_TEAM_MIN", "48")
-    monkeypatch.setenv("HMX_ACA_TEAM_Q", "2")
-    monkeypatch.setenv("HMX_ACA_TEAM_SLICE", "64")
+    monkeypatch.setattr(sys.modules[__name__], "ENGINE_OPTIONS", dict(aca_team_min=48, aca_team_after=2, aca_team_slice=64))
     test_compression_matches_reference(name)
-    monkeypatch.setenv("HMX_POOL_RANK_GUESS", "3")
+    monkeypatch.setattr(sys.modules[__name__], "ENGINE_OPTIONS", dict(aca_team_min=48, aca_team_after=2, aca_team_slice=64, pool_rank_guess=3))
     test_compression_matches_reference(name)
     test_matvec_matches_reference(name)
 
@@ -867,9 +862,52 @@ def test_prepare_builds_the_second_layouts_so_that_products_allocate_nothing(nam
         assert torch.equal(y, y2)
 
 
+def test_operators_with_different_options_coexist_in_one_process():
+    """Options are per operator (hmx_hmatrix_set_option; the counterpart of HMatrixTreeBuilder's setters, tree_builder.hpp:239-264), not
+    process state: three operators on the same fixture with different storage layouts, piece sizes and kernel selections, multiplied in
+    turn, each keep their own settings and all reproduce the reference; a layout option cannot change once the streams exist."""
+    name = "ellipse_n3000_symL_default"
+    p, g = params(name), load(name)
+    Ha = build_engine(p)[2]
+    Hb = build_engine(p, options=dict(sym_storage=1, r_piece_rows=128, task_order=0))[2]
+    Hc = build_engine(p, options=dict(r_tree_pieces=0, layout_threads=3, expand_waves=8, reduce_waves=4))[2]
+    assert (Ha.get_option("sym_storage"), Hb.get_option("sym_storage"), Hc.get_option("sym_storage")) == (0, 1, 0)
+    assert Hb.stats()["stream_bytes"] > 1.5 * Ha.stats()["stream_bytes"]  # the expanded layout holds both triangles
+    with pytest.raises(hm.HmxError, match="layout option"):
+        Ha.set_option("sym_storage", 1)
+    with pytest.raises(hm.HmxError, match="out of range"):
+        Ha.set_option("expand_waves", 99)
+    with pytest.raises(hm.HmxError):
+        Ha.set_option("no_such_option", 1)
+    Hb.set_option("matrix_cores", 0)  # product options change at any time, per operator
+    x, xT, y0, y0T = inputs(Ha)
+    alpha, beta = g["alphabeta"][:2]
+    mu = g["YNrm"].shape[1]
+    from oracle.oracle import hashed_vector
+    n = Ha.nb_rows()
+    for rnd in range(2):
+        for H in (Ha, Hb, Hc, Hb, Ha):
+            y = y0.copy()
+            hm.internal_add_hmatrix_vector_product("N", alpha, H, x, beta, y)
+            assert rel_err(y, g["yN"]) < 1e-10
+            X, Y = hashed_vector(n * mu, 5).reshape(n, mu), hashed_vector(n * mu, 6).reshape(n, mu)
+            hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y, mu)
+            assert rel_err(Y, g["YNrm"]) < 1e-10
+            X16, Y16 = hashed_vector(n * 16, 7).reshape(n, 16), np.zeros((n, 16))
+            H.set_profiling(True)
+            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, X16, 0.0, Y16, 16)
+            names = [k for k, _ in H.last_kernel_times()]
+            H.set_profiling(False)
+            assert any("mfma" in k for k in names) == (H is not Hb), names  # Hb was told to stay off the matrix cores
+            if H is Ha and rnd == 0:
+                ref16 = Y16.copy()
+            assert rel_err(Y16, ref16) < 1e-12
+    assert Hb.get_option("matrix_cores") == 0 and Ha.get_option("matrix_cores") == 1
+
+
 @pytest.mark.parametrize("f32", [False, True])
 @pytest.mark.parametrize("name", ["ellipse_n3000_symL_default", "ellipse_n3000_symU_sympartial", "ball_n2000_symL_eta3"])
-def test_stored_triangle_product_with_several_right_hand_sides(name, f32, monkeypatch):
+def test_stored_triangle_product_with_several_right_hand_sides(name, f32):
     """Several right-hand sides on the STORED TRIANGLE of a square symmetric operator (expand_sym_mfma16_kernel / rowsym_mfma16_kernel:
     forward product and mirrored column sums of every stream tile in one pass, second pass over the V factors; the reference runs the
     mirror pass on the same leaves, add_hmatrix_matrix_product_row_major.hpp:100-106,160-170): against the oracle's row-major product on
@@ -883,7 +921,7 @@ def test_stored_triangle_product_with_several_right_hand_sides(name, f32, monkey
     tb.set_low_rank_generator(p["compressor"])
     H = tb.build(device_generator(p, T, S), T, S, dtype=dt)
     n = H.nb_rows()
-    monkeypatch.setenv("HMX_SYM_MU_FUSED", "1")
+    H.set_option("sym_multi_rhs", 1)
     for mu, trans in ((2, "N"), (3, "T"), (16, "N"), (19, "N"), (40, "N")):
         X = O.hashed_vector(n * mu, 61 + mu).reshape(n, mu).astype(dt)
         Y0 = O.hashed_vector(n * mu, 62 + mu).reshape(n, mu).astype(dt)
@@ -905,7 +943,7 @@ def test_stored_triangle_product_with_several_right_hand_sides(name, f32, monkey
         assert np.array_equal(Y, Y2)  # fixed summation order
     assert H.stats()["expanded_bytes"] == 0
     # ... and the expanded view gives the same product (another summation order)
-    monkeypatch.setenv("HMX_SYM_MU_FUSED", "0")
+    H.set_option("sym_multi_rhs", 0)
     Y3 = Y0.copy()
     hm.internal_add_hmatrix_matrix_product_row_major("N", 1.5, H, X, 0.5, Y3, mu)
     assert H.stats()["expanded_bytes"] > 0 and rel_err(Y3, Y) < (2e-5 if f32 else 1e-12)
@@ -914,7 +952,7 @@ def test_stored_triangle_product_with_several_right_hand_sides(name, f32, monkey
         g = load(name)
         mu_g = g["YNrm"].shape[1]
         Xg, Yg = O.hashed_vector(n * mu_g, 5).reshape(n, mu_g), O.hashed_vector(n * mu_g, 6).reshape(n, mu_g)
-        monkeypatch.setenv("HMX_SYM_MU_FUSED", "1")
+        H.set_option("sym_multi_rhs", 1)
         al, be = g["alphabeta"][:2]
         hm.internal_add_hmatrix_matrix_product_row_major("N", al, H, Xg, be, Yg, mu_g)
         assert rel_err(Yg, g["YNrm"]) < 1e-10
@@ -957,11 +995,8 @@ def test_transposed_product_on_the_stored_data_edge_shapes(n, nsrc, leaf, eta, d
     st = H.stats()
     assert st["transposed_bytes"] > 0 and st["transposed_bytes"] < st["stream_bytes"] + (1 << 20)
     if not cplx:  # several right-hand sides, no transposed layout allowed: 16 per sweep on the stored data
-        os.environ["HMX_TRANS_STREAMS"] = "0"
-        try:
-            X, Y0 = rng.standard_normal((n, 19)).astype(dtype), rng.standard_normal((nsrc, 19)).astype(dtype)
-            Y = Y0.copy()
-            hm.internal_add_hmatrix_matrix_product_row_major("T", 2.0, H, X, 1.0, Y, 19)
-            assert rel_err(Y, 2.0 * (A.T @ X) + Y0) < tol
-        finally:
-            del os.environ["HMX_TRANS_STREAMS"]
+        H.set_option("transposed_layout", 0)
+        X, Y0 = rng.standard_normal((n, 19)).astype(dtype), rng.standard_normal((nsrc, 19)).astype(dtype)
+        Y = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major("T", 2.0, H, X, 1.0, Y, 19)
+        assert rel_err(Y, 2.0 * (A.T @ X) + Y0) < tol
