@@ -335,12 +335,10 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     int nint = 0;
     if (!bad)
         nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order);
-#if !HMX_COMPLEX
-    // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows); only a square operator runs it
+    // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows; rowsym_mu_kernel: one workgroup)
     H.s64_nint = 0;
-    if (!bad && (tmode || (H.T0 == H.S0 && H.nT == H.nS)))
+    if (!bad)
         H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64);
-#endif
     phase_nosync("  sym: tasks");
     // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
     for (size_t p = 0; p < ed_b.size() && !bad; p++) {
@@ -415,7 +413,6 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
         HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
     HMX_HIP(H.SW.alloc(s_total + 1));
     H.s_slots = s_total;
-#if !HMX_COMPLEX
     H.SW16.release();
     if (H.s64_nint > 0) {
         HMX_HIP(H.s64_sub_ptr.upload(p64));
@@ -425,7 +422,6 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
         HMX_HIP(H.s64_sub_dst.upload(d64));
         HMX_HIP(H.s64_int_order.upload(o64));
     }
-#endif
     return HMX_OK;
 }
 
@@ -1524,45 +1520,126 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
     return HMX_OK;
 }
 
-#if !HMX_COMPLEX
-// Several right-hand sides on the stored triangle of a square symmetric operator (kernels_body.hpp, "Several right-hand sides on the
-// STORED TRIANGLE"): sweeps of up to 16 right-hand sides; per sweep the reduce stage, the fused pass over the E-streams, the fold of a'
-// and the second pass over the R-streams.  No second layout of the operator: what is added to the compact operator is SW16, 16 partial sums
-// per slot of the single-vector product (N = 1e6 fp64: 1.6 GB next to 9.4 GB of streams; the expanded view it replaces: 18.6 GB).
+// Several right-hand sides on the STORED TRIANGLE of a symmetric / Hermitian operator (kernels_body.hpp, "Several right-hand sides on the
+// stored data"): sweeps of up to SWW right-hand sides (16 real, 8 complex); per sweep the reduce stage, the fused pass over the E-streams, the
+// fold of a' and the second pass over the R-streams.  No second layout of the operator: what is added to the compact operator is SW16, SWW
+// partial sums per slot of the single-vector product (N = 1e6 fp64: 1.6 GB next to 9.4 GB of streams; the expanded view: 18.6 GB).
+// Real coefficients run on the matrix cores (expand_sym_mfma16_kernel, rowsym_mfma16_kernel), complex ones on the VALU (expand_sym_mu_kernel,
+// rowsym_mu_kernel; round 5 -- before, complex operators without room for the view ran one single-vector product per right-hand side).
 static bool sym_mu_fused(const HMat &H) {
-    // HMX_SYM_MU_FUSED=1: always the stored triangle; =0: always the expanded view; unset: the expanded view while HBM has room for it
-    // (it is the faster of the two as long as a row range writes its own partial column sums: N = 4e6 fp32, 16 right-hand sides, one
-    // MI355X: 15.9 ms on 42 + 83 GB against 19.0 ms on 42 + 6 GB), the stored triangle when it has not -- where products with several
-    // right-hand sides used to fall back to one single-vector product per column
+    // HMX_OPT_SYM_MULTI_RHS = 1: always the stored triangle; 0: always the expanded view; -1: the expanded view while HBM has room for it
+    // (the faster of the two today: N = 4e6 fp32, 16 right-hand sides, one MI355X: 15.9 ms on 42 + 83 GB against 18 ms on 42 + 6 GB),
+    // the stored triangle when it has not, or when the factors the view is built from were released
     const int mode = H.opt.i(HMX_OPT_SYM_MULTI_RHS);
-    if (!(H.sym_fused && H.s64_nint > 0 && H.T0 == H.S0 && H.nT == H.nS) || mode == 0)
+    if (!(H.sym_fused && H.s64_nint > 0) || mode == 0)
         return false;
     if (mode > 0)
         return true;
     if (H.X_op)
         return false;
-    if (H.X_op_failed || H.factors_released)
+    if (H.X_op_failed || H.factors_released || H.opt.i(HMX_OPT_SYM_NO_VIEW) != 0)
         return true;
     size_t free_b = 0, total_b = 0;
     return hmx_mem_info(&free_b, &total_b) != hipSuccess || (double)free_b < 2.3 * (double)H.stats.stream_bytes; // ensure_expanded_view's own admission test
+}
+static int ensure_sw16(HMat &H, hipStream_t st) {
+    const size_t need16 = (size_t)(H.s_slots + 1) * SWW;
+    if (H.SW16.n < need16) {
+        HMX_HIP(H.SW16.alloc(need16));
+        HMX_HIP(hipMemsetAsync(H.SW16.d, 0, need16 * sizeof(scalar), st)); // slot s_slots stays zero for ever: the operand of the columns that are no mirrored leaf's
+    }
+    return HMX_OK;
+}
+// the sweeps over E (forward + mirrored column sums, or -- fwd = false -- the column sums only), the folds of a' and the second sweep over R
+// for the nrhs right-hand sides starting at column c.  herm: mirrored leaves are conjugate transposes.
+static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow, scalar alpha, scalar beta, scalar *Y, int nout, int accumulate, int herm, int mu, int c, int nrhs, hipStream_t st) {
+    constexpr int W = 4;
+    if (H.E.nranges() > 0) {
+        ExpandSymArgs XS{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, fwd ? H.e_zidx.d : nullptr, fwd ? H.Zmu.d : nullptr,
+                          fwd ? Y : nullptr, alpha, beta, H.E.nranges(), fwd ? X : nullptr, fwd ? H.nS : 0},
+                         H.s_mdst.d, H.SW16.d, xrow, herm};
+        const dim3 grid((unsigned)H.E.nranges()), wg(W * 64);
+#if HMX_COMPLEX
+#define HMX_SYM_MU_E(MU)                                                                                      \
+    do {                                                                                                      \
+        if (fwd)                                                                                              \
+            hipLaunchKernelGGL((expand_sym_mu_kernel<W, MU, true>), grid, wg, 0, st, XS, mu, c, nrhs);        \
+        else                                                                                                  \
+            hipLaunchKernelGGL((expand_sym_mu_kernel<W, MU, false>), grid, wg, 0, st, XS, mu, c, nrhs);       \
+    } while (0)
+        if (nrhs <= 2)
+            HMX_SYM_MU_E(2);
+        else if (nrhs <= 4)
+            HMX_SYM_MU_E(4);
+        else
+            HMX_SYM_MU_E(8);
+#undef HMX_SYM_MU_E
+        prof_mark(H, st, fwd ? "expand_sym_mu_kernel" : "expand_colsum_mu_kernel");
+#else
+        if (fwd)
+            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W, true>), grid, wg, 0, st, XS, mu, c, nrhs);
+        else
+            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W, false>), grid, wg, 0, st, XS, mu, c, nrhs);
+        prof_mark(H, st, fwd ? "expand_sym_mfma16_kernel" : "expand_colsum_mfma16_kernel");
+#endif
+    }
+    if (H.n_sym_combine > 0) {
+        const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw; // the first nw entries fold >= 32 partial sums: one wave each
+        if (nw > 0) {
+            CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW16.d, nw};
+            hipLaunchKernelGGL(combine_list_mu_wave_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, C);
+        }
+        if (nt > 0) {
+            CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW16.d, nt};
+            const int64_t tot = (int64_t)nt * SWW;
+            hipLaunchKernelGGL(combine_list_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C);
+        }
+        prof_mark(H, st, "combine_sym_mu_kernel");
+    }
+    if (H.s64_nint > 0) {
+        RowSymArgs RS{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
+                      H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, nout, herm, beta, accumulate};
+#if HMX_COMPLEX
+        const dim3 grid((unsigned)H.s64_nint), wg(W * 64);
+        if (nrhs <= 2)
+            hipLaunchKernelGGL((rowsym_mu_kernel<W, 2>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
+        else if (nrhs <= 4)
+            hipLaunchKernelGGL((rowsym_mu_kernel<W, 4>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
+        else
+            hipLaunchKernelGGL((rowsym_mu_kernel<W, 8>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
+        prof_mark(H, st, "rowsym_mu_kernel");
+#else
+        RowSymMuArgs P{RS, H.SW16.d, (int)H.s_slots, H.s64_nint};
+#ifndef HMX_ROWSYM_WAVES
+#define HMX_ROWSYM_WAVES 4
+#endif
+        constexpr int RWV = HMX_ROWSYM_WAVES; // intervals (= waves) per workgroup
+        hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
+        prof_mark(H, st, "rowsym_mfma16_kernel");
+#endif
+    }
+    return HMX_OK;
 }
 static int run_forward_mu_sym(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
         HMX_HIP(H.Zmu.alloc(need));
-    const size_t need16 = (size_t)(H.s_slots + 1) * 16;
-    if (H.SW16.n < need16) {
-        HMX_HIP(H.SW16.alloc(need16));
-        HMX_HIP(hipMemsetAsync(H.SW16.d, 0, need16 * sizeof(scalar), st)); // slot s_slots stays zero for ever: the operand of the columns that are no mirrored leaf's
-    }
+    int rc = ensure_sw16(H, st);
+    if (rc != HMX_OK)
+        return rc;
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                   H.r_outidx.d, X, H.Zmu.d, (int)H.R.task_range.size()};
     constexpr int W = 4;
-    for (int c = 0; c < mu; c += 16) { // a = V X_s, every sweep
-        const int nrhs = std::min(16, mu - c);
-        if (RA.ntasks > 0)
+    for (int c = 0; c < mu; c += SWW) { // a = V X_s, every sweep
+        const int nrhs = std::min(SWW, mu - c);
+        if (RA.ntasks > 0) {
+#if HMX_COMPLEX
+            hipLaunchKernelGGL((reduce_zmfma8s_kernel<W>), dim3((unsigned)((RA.ntasks + W - 1) / W)), dim3(W * 64), 0, st, RA, mu, c, nrhs);
+#else
             hipLaunchKernelGGL((reduce_mfma16s_kernel<W>), dim3((unsigned)((RA.ntasks + W - 1) / W)), dim3(W * 64), 0, st, RA, mu, c, nrhs);
-        prof_mark(H, st, "reduce_mfma16s_kernel");
+#endif
+        }
+        prof_mark(H, st, HMX_COMPLEX ? "reduce_zmfma8s_kernel" : "reduce_mfma16s_kernel");
     }
     if (H.n_combine > 0) {
         CombineArgs C{H.c_dst.d, H.c_src.d, H.c_stride.d, H.c_count.d, H.Zmu.d, H.n_combine};
@@ -1570,87 +1647,31 @@ static int run_forward_mu_sym(HMat &H, const scalar *X, scalar alpha, scalar bet
         hipLaunchKernelGGL(combine_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, mu);
         prof_mark(H, st, "combine_mu_kernel");
     }
-    for (int c = 0; c < mu; c += 16) {
-        const int nrhs = std::min(16, mu - c);
-        if (H.E.nranges() > 0) {
-            ExpandSymArgs XS{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, H.e_zidx.d, H.Zmu.d, Y, alpha, beta, H.E.nranges(), X, H.nS},
-                             H.s_mdst.d, H.SW16.d, X + (int64_t)(H.T0 - H.S0) * mu, 0};
-            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W>), dim3((unsigned)H.E.nranges()), dim3(W * 64), 0, st, XS, mu, c, nrhs);
-            prof_mark(H, st, "expand_sym_mfma16_kernel");
-        }
-        if (H.n_sym_combine > 0) {
-            const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw; // the first nw entries fold >= 32 partial sums: one wave each
-            if (nw > 0) {
-                CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW16.d, nw};
-                hipLaunchKernelGGL(combine_list_mu_wave_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, C);
-            }
-            if (nt > 0) {
-                CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW16.d, nt};
-                const int64_t tot = (int64_t)nt * 16;
-                hipLaunchKernelGGL(combine_list_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C);
-            }
-            prof_mark(H, st, "combine_sym_mu_kernel");
-        }
-        if (H.s64_nint > 0) {
-            RowSymMuArgs P{{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
-                            H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, H.nT, 0, scalar(0), 1},
-                           H.SW16.d, (int)H.s_slots, H.s64_nint};
-#ifndef HMX_ROWSYM_WAVES
-#define HMX_ROWSYM_WAVES 4
-#endif
-            constexpr int RWV = HMX_ROWSYM_WAVES; // intervals (= waves) per workgroup
-            hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
-            prof_mark(H, st, "rowsym_mfma16_kernel");
-        }
+    const int herm = H.symmetry_for_leaves == 'H' ? 1 : 0;
+    for (int c = 0; c < mu; c += SWW) {
+        rc = sym_mu_sweeps(H, true, X, X + (int64_t)(H.T0 - H.S0) * mu, alpha, beta, Y, H.nT, 1, herm, mu, c, std::min(SWW, mu - c), st);
+        if (rc != HMX_OK)
+            return rc;
     }
     HMX_HIP(hipGetLastError());
     return HMX_OK;
 }
 
-// Several right-hand sides of the transposed product on the STORED data (run_transposed_fused for groups of 16 on the matrix cores): the
-// kernels of the stored-triangle product with every leaf mirrored and nothing applied forward.  Runs when HBM has no room for the
-// transposed stream layout the fused multi-RHS kernels prefer (until round 4: one single-vector product per right-hand side then).
+// Several right-hand sides of the transposed product on the STORED data (run_transposed_fused for groups of SWW): the kernels of the
+// stored-triangle product with every leaf mirrored and nothing applied forward.  Runs when HBM has no room for the transposed stream layout
+// the fused multi-RHS kernels prefer (until round 4: one single-vector product per right-hand side then; complex types until round 5).
 static int run_transposed_fused_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
-    const size_t need16 = (size_t)(H.s_slots + 1) * 16;
-    if (H.SW16.n < need16) {
-        HMX_HIP(H.SW16.alloc(need16));
-        HMX_HIP(hipMemsetAsync(H.SW16.d, 0, need16 * sizeof(scalar), st)); // slot s_slots stays zero for ever
-    }
-    constexpr int W = 4;
-    for (int c = 0; c < mu; c += 16) {
-        const int nrhs = std::min(16, mu - c);
-        if (H.E.nranges() > 0) {
-            ExpandSymArgs XS{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, nullptr, nullptr, nullptr, alpha, beta, H.E.nranges(), nullptr, 0},
-                             H.s_mdst.d, H.SW16.d, X, 0};
-            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W, false>), dim3((unsigned)H.E.nranges()), dim3(W * 64), 0, st, XS, mu, c, nrhs);
-            prof_mark(H, st, "expand_colsum_mfma16_kernel");
-        }
-        if (H.n_sym_combine > 0) {
-            const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw;
-            if (nw > 0) {
-                CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW16.d, nw};
-                hipLaunchKernelGGL(combine_list_mu_wave_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, C);
-            }
-            if (nt > 0) {
-                CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW16.d, nt};
-                const int64_t tot = (int64_t)nt * 16;
-                hipLaunchKernelGGL(combine_list_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C);
-            }
-            prof_mark(H, st, "combine_sym_mu_kernel");
-        }
-        if (H.s64_nint > 0) {
-            RowSymMuArgs P{{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
-                            H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, H.nS, 0, beta, 0},
-                           H.SW16.d, (int)H.s_slots, H.s64_nint};
-            constexpr int RWV = HMX_ROWSYM_WAVES;
-            hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
-            prof_mark(H, st, "rowsym_mfma16_kernel");
-        }
+    int rc = ensure_sw16(H, st);
+    if (rc != HMX_OK)
+        return rc;
+    for (int c = 0; c < mu; c += SWW) {
+        rc = sym_mu_sweeps(H, false, nullptr, X, alpha, beta, Y, H.nS, 0, 0, mu, c, std::min(SWW, mu - c), st);
+        if (rc != HMX_OK)
+            return rc;
     }
     HMX_HIP(hipGetLastError());
     return HMX_OK;
 }
-#endif
 
 // trans = 'T' at the speed of trans = 'N': the transposed operator gets its own E-/R-streams (same crosses with the roles of
 // U and V exchanged, dense leaves regenerated / read transposed), built on the first transposed product.  Costs a second
@@ -3886,10 +3907,8 @@ static HMat *matmat_layout_n(HMat &H) {
         return nullptr;
     if (!H.sym_fused)
         return &H;
-#if !HMX_COMPLEX
     if (sym_mu_fused(H)) // the product runs on the stored triangle (rows receive mirrored contributions after the E pass): single exchange, and no view is built
         return nullptr;
-#endif
     return ensure_expanded_view(H);
 }
 // api_matvec_chunked for mu right-hand sides (row-major, device pointers, trans = 'N'): after_chunk(user, c, row_lo, row_hi) is called on the
@@ -3999,36 +4018,62 @@ int api_matvec_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar
 static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, scalar beta, scalar *dout, int mu, hipStream_t st) {
     int rc;
     const int nin = trans == 'N' ? H.nS : H.nT, nout = trans == 'N' ? H.nT : H.nS;
-    if (H.tmp_in2.n < (size_t)nin)
-        HMX_HIP(H.tmp_in2.alloc(nin));
-    if (H.tmp_out2.n < (size_t)nout)
-        HMX_HIP(H.tmp_out2.alloc(nout));
 #if !HMX_COMPLEX
     if (trans == 'C' && H.symmetry_for_leaves != 'S')
         trans = 'T'; // real coefficients
 #endif
-    HMat *F = nullptr; // the layout a fused pass runs on: the operator itself, or its transposed view
+    const bool fused_ok   = H.finalized && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0;
+    const bool square_sym = H.has_mirror && H.T0 == H.S0 && H.nT == H.nS;
+    // a square symmetric ('S') operator is its own transpose, a square Hermitian one its own conjugate transpose
+    const bool as_n = trans == 'N' || (trans == 'T' && square_sym && H.symmetry_for_leaves == 'S') || (trans == 'C' && square_sym && H.symmetry_for_leaves == 'H');
+    auto collect_times = [&](HMat &F) -> int {
+        if (H.profiling) {
+            HMX_HIP(hipStreamSynchronize(st));
+            H.last_ms.clear();
+            H.last_names.clear();
+            for (size_t k = 1; k < F.ev_names.size(); k++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, F.ev[k - 1], F.ev[k]);
+                H.last_ms.push_back(ms);
+                H.last_names.push_back(F.ev_names[k]);
+            }
+        }
+        return HMX_OK;
+    };
+    // 1. symmetric / Hermitian storage, untransposed: the stored triangle itself (sym_mu_fused decides between it and the expanded view)
+    if (fused_ok && mu > 1 && as_n && sym_mu_fused(H)) {
+        H.ev_names.clear();
+        prof_mark(H, st, "begin");
+        rc = run_forward_mu_sym(H, din, alpha, beta, dout, mu, st);
+        return rc != HMX_OK ? rc : collect_times(H);
+    }
+    // 2. a layout the fused multi-RHS kernels run on: the operator's own streams, its expanded view, or its transposed layout
+    HMat *F        = nullptr;
     bool conj_wrap = false;
-    (void)conj_wrap;
-#if !HMX_COMPLEX
-    // a square symmetric operator on compact storage: the fused multi-RHS product on the stored triangle (no expanded view)
-    const bool fused_sym = H.finalized && mu > 1 && sym_mu_fused(H) && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0 && (trans == 'N' || (trans == 'T' && H.symmetry_for_leaves == 'S'));
-#else
-    const bool fused_sym = false;
-#endif
-    if (!fused_sym && H.finalized && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0) {
-        const bool square_sym = H.has_mirror && H.T0 == H.S0 && H.nT == H.nS;
-        if (trans == 'N' || (trans == 'T' && square_sym && H.symmetry_for_leaves == 'S') || (trans == 'C' && square_sym && H.symmetry_for_leaves == 'H'))
+    if (fused_ok && (!H.has_mirror || H.sym_expanded || H.sym_fused)) {
+        if (as_n)
             F = H.sym_fused ? ensure_expanded_view(H) : &H;
         else if (trans == 'T' && !(HMX_COMPLEX && H.symmetry_for_leaves == 'H'))
             F = ensure_transposed_operator(H);
 #if HMX_COMPLEX
         else if (trans == 'C' && H.symmetry_for_leaves != 'S') { // conj o 'T' o conj on all right-hand sides at once
             F         = ensure_transposed_operator(H);
-            conj_wrap = F != nullptr;
+            conj_wrap = true;
         }
 #endif
     }
+    // 3. no such layout (no room in HBM, HMX_OPT_TRANSPOSED_LAYOUT = 0, factors released): the stored data -- the stored triangle of a
+    //    symmetric operator whatever the option says, the transposed product of an ordinary operator through its mirrored sweeps.  Nothing
+    //    falls back to one product per right-hand side any more.
+    const bool stored_sym   = !F && fused_ok && mu > 1 && as_n && H.sym_fused && H.s64_nint > 0;
+    const bool stored_trans = !F && fused_ok && mu > 1 && !as_n && (trans == 'T' || conj_wrap) && !H.has_mirror && !H.view_of;
+    if (stored_trans && !H.trans_fused && !H.trans_tables_failed && build_trans_tables(H) != HMX_OK) {
+        H.trans_tables_failed = true;
+        (void)hipGetLastError();
+    }
+    const bool use_stored_trans = stored_trans && H.trans_fused && H.s64_nint > 0;
+    if (!(F || stored_sym || use_stored_trans))
+        conj_wrap = false;
 #if HMX_COMPLEX
     if (conj_wrap) {
         const int64_t tin = (int64_t)nin * mu, tout = (int64_t)nout * mu;
@@ -4042,83 +4087,41 @@ static int matmat_device(HMat &H, char trans, scalar alpha, const scalar *din, s
         beta  = hmx_conj(beta);
     }
 #endif
-#if !HMX_COMPLEX
-    if (fused_sym) {
-        H.ev_names.clear();
-        prof_mark(H, st, "begin");
-        rc = run_forward_mu_sym(H, din, alpha, beta, dout, mu, st);
-        if (rc != HMX_OK)
-            return rc;
-        if (H.profiling) {
-            HMX_HIP(hipStreamSynchronize(st));
-            H.last_ms.clear();
-            H.last_names.clear();
-            for (size_t k = 1; k < H.ev_names.size(); k++) {
-                float ms = 0;
-                (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
-                H.last_ms.push_back(ms);
-                H.last_names.push_back(H.ev_names[k]);
-            }
-        }
-        return HMX_OK;
-    }
-#endif
-#if !HMX_COMPLEX
-    // no transposed layout (no room for it in HBM, or HMX_TRANS_STREAMS=0): the transposed product on the stored data, 16 right-hand sides per sweep
-    if (!F && trans == 'T' && mu > 1 && H.finalized && !H.has_mirror && !H.view_of && H.opt.i(HMX_OPT_MULTI_RHS_FUSED) != 0) {
-        if (!H.trans_fused && !H.trans_tables_failed && build_trans_tables(H) != HMX_OK) {
-            H.trans_tables_failed = true;
-            (void)hipGetLastError();
-        }
-        if (H.trans_fused && H.s64_nint > 0) {
-            H.ev_names.clear();
-            prof_mark(H, st, "begin");
-            rc = run_transposed_fused_mu(H, din, alpha, beta, dout, mu, st);
-            if (rc != HMX_OK)
-                return rc;
-            if (H.profiling) {
-                HMX_HIP(hipStreamSynchronize(st));
-                H.last_ms.clear();
-                H.last_names.clear();
-                for (size_t k = 1; k < H.ev_names.size(); k++) {
-                    float ms = 0;
-                    (void)hipEventElapsedTime(&ms, H.ev[k - 1], H.ev[k]);
-                    H.last_ms.push_back(ms);
-                    H.last_names.push_back(H.ev_names[k]);
-                }
-            }
-            return HMX_OK;
-        }
-    }
-#endif
-    if (F) {
-        // fused path: the streams are read once for up to 16 right-hand sides
-        F->profiling = H.profiling;
-        F->ev_names.clear();
-        prof_mark(*F, st, "begin");
-        rc = run_forward_mu(*F, din, alpha, beta, dout, mu, st);
-        if (rc != HMX_OK)
-            return rc;
-        if (H.profiling) {
-            HMX_HIP(hipStreamSynchronize(st));
-            H.last_ms.clear();
-            H.last_names.clear();
-            for (size_t k = 1; k < F->ev_names.size(); k++) {
-                float ms = 0;
-                (void)hipEventElapsedTime(&ms, F->ev[k - 1], F->ev[k]);
-                H.last_ms.push_back(ms);
-                H.last_names.push_back(F->ev_names[k]);
-            }
-        }
+    auto conj_back = [&]() {
 #if HMX_COMPLEX
         if (conj_wrap) {
             const int64_t tout = (int64_t)nout * mu;
             hipLaunchKernelGGL(conj_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, tout, (const scalar *)dout, dout);
         }
 #endif
-        return HMX_OK;
+    };
+    if (F) {
+        F->profiling = H.profiling;
+        F->ev_names.clear();
+        prof_mark(*F, st, "begin");
+        rc = run_forward_mu(*F, din, alpha, beta, dout, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        rc = collect_times(*F);
+        conj_back();
+        return rc;
     }
-    // compact symmetric storage, or no room for the transposed layout: one pass per right-hand side
+    if (stored_sym || use_stored_trans) {
+        H.ev_names.clear();
+        prof_mark(H, st, "begin");
+        rc = stored_sym ? run_forward_mu_sym(H, din, alpha, beta, dout, mu, st) : run_transposed_fused_mu(H, din, alpha, beta, dout, mu, st);
+        if (rc != HMX_OK)
+            return rc;
+        rc = collect_times(H);
+        conj_back();
+        return rc;
+    }
+    // what is left: fused products switched off (HMX_OPT_MULTI_RHS_FUSED = 0), or a row-restricted symmetric operator's transposed product
+    // without room for its transposed view -- one product per right-hand side (the second reports the missing view itself)
+    if (H.tmp_in2.n < (size_t)nin)
+        HMX_HIP(H.tmp_in2.alloc(nin));
+    if (H.tmp_out2.n < (size_t)nout)
+        HMX_HIP(H.tmp_out2.alloc(nout));
     for (int c = 0; c < mu; c++) {
         hipLaunchKernelGGL(col_extract_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, mu, c, din, H.tmp_in2.d);
         if (!hmx_is_zero(beta))

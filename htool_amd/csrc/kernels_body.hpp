@@ -2114,34 +2114,60 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
 #pragma unroll
     for (int t = 0; t < 4; t++)
         acc[t] = acc4{0, 0, 0, 0};
-    auto load_cols = [&](real(&v)[16], int c) { // 16 whole columns, clamped to the last one (zero operand there)
+    // The wave's work as ONE sequence of steps of 16 columns: wave w owns the 64-column tiles w, w + WAVES, ... of the range, step s covers the
+    // columns col_of(s) ... + 16; every tile is full except the range's last.
+    const int ntile_all = (C + 63) >> 6;
+    int n = 0; // steps of this wave
+    if (wv < ntile_all) {
+        n = 4 * ((ntile_all - 1 - wv) / WAVES + 1);
+        if ((ntile_all - 1 - wv) % WAVES == 0) // the range's last tile is this wave's
+            n -= 4 - ((C - 64 * (ntile_all - 1) + 15) >> 4);
+    }
+    auto col_of = [&](int s) { return (((s >> 2) * WAVES + wv) << 6) + ((s & 3) << 4); };
+    // THREE stages in flight, every load unconditional: the indices of step s + 2, the operand gathers and the 16 stream columns of step
+    // s + 1, the arithmetic of step s.  Steps beyond the wave's last re-load its last step (nobody uses the result).  Unconditional because
+    // s_waitcnt vmcnt counts loads in issue order and the compiler derives the count at a use from what is CERTAINLY outstanding there: behind
+    // an `if (more columns) prefetch;` that is the path without the prefetch, and every use then waits for the prefetch itself -- an
+    // s_waitcnt vmcnt(0) per step, the pipeline drained once per 16 columns (round 5, read off the ISA of the round-3 kernel; the same rule as
+    // in expand_sym_kernel).  The zero operand of a column beyond the range is selected when the step is applied, not behind the load (a
+    // select waits on the spot), and HMX_SCHED_FENCE() keeps the load groups in program order (the scheduler sinks independent loads towards
+    // their use otherwise: the gathers ended up LAST in the queue).  tests/test_isa_shape.py: no vmcnt(0) in the loop.
+    auto load_idx = [&](int s) { // lane l: the Z index of column col_of(s) + (l & 15)
+        const int c = col_of(s < n ? s : n - 1) + m;
+        return zidx[c < C ? c : C - 1];
+    };
+    auto gathers = [&](real(&b)[4], int zi) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int zc = __shfl(zi, 4 * g + kk, WAVE);
+            b[g]         = expand_operand(A, zc, mu)[mo];
+        }
+    };
+    auto load_cols = [&](real(&v)[16], int s) { // 16 whole columns, clamped to the range's last one (zero operand there)
+        const int c = col_of(s < n ? s : n - 1);
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int col = c + u < C ? c + u : C - 1;
             v[u]          = stream_load(E + (int64_t)col * len + row);
         }
     };
-    auto operands = [&](real(&b)[4], int c, int zi, int base) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
-            const real bv = expand_operand(A, zc, mu)[mo];
-            b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
-        }
-    };
     // Round 4: the operand layout WITHOUT LDS for 4-byte coefficients.  The loads fill register u of lane r with E[row r][column c + u]; the
     // MFMA wants, for column group g and row tile t, lane (m, kk) to hold E[row 16 t + m][column c + 4 g + kk] -- register 4 g + kk of lane
     // quarter t.  That is a 4 x 4 transposition between register index and lane quarter per column group: v_permlane32_swap on (0, 2),
     // (1, 3), then v_permlane16_swap on (0, 1), (2, 3).  Sixteen swaps instead of sixteen LDS stores + sixteen LDS loads + a fence per step;
-    // the same MFMAs on the same operands in the same order, so the results are bitwise those of the staged form.  Same box, alternating
-    // (profiles/r4_ab_permlane.log): fp32 expand stage 1.07 -> 1.04 ms at N = 1e6; fp64 (two swaps per register) 1.97 -> 2.03 ms, so
-    // 8-byte coefficients keep the LDS tile.  -DHMX_EXPAND_PERMLANE=0 / 1 forces one form for both.
+    // the same MFMAs on the same operands in the same order, so the results are bitwise those of the staged form.  8-byte coefficients (two
+    // swaps per register) keep the LDS tile.  -DHMX_EXPAND_PERMLANE=0 / 1 forces one form for both.
 #ifdef HMX_EXPAND_PERMLANE
     constexpr bool PERM = HMX_EXPAND_PERMLANE != 0;
 #else
     constexpr bool PERM = sizeof(real) == 4;
 #endif
-    auto apply = [&](real(&v)[16], const real(&b)[4]) {
+    auto apply = [&](real(&v)[16], const real(&braw)[4], int s) {
+        const int c = col_of(s);
+        real b[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            b[g] = (c + 4 * g + kk < C) ? braw[g] : real(0);
         if constexpr (PERM) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -2175,32 +2201,27 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs 
                     acc[t] = mfma16(a[g][t], b[g], acc[t]);
         }
     };
-    // wave w takes the 64-column tiles w, w + WAVES, ...; inside a tile four steps of 16 columns, loads one step ahead
-    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
-        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
-        const int zi   = (t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1];
+    if (n > 0) {
         real v0[16], v1[16], b0[4], b1[4];
-        load_cols(v0, t0);
-        operands(b0, t0, zi, 0);
-        if (t0 + 16 < tend) {
-            load_cols(v1, t0 + 16);
-            operands(b1, t0 + 16, zi, 16);
+        int i0 = load_idx(0), i1 = load_idx(1);
+        gathers(b0, i0);
+        load_cols(v0, 0);
+        HMX_SCHED_FENCE();
+        for (int s = 0; s < n; s += 2) {
+            i0 = load_idx(s + 2);
+            gathers(b1, i1);
+            load_cols(v1, s + 1);
+            HMX_SCHED_FENCE();
+            apply(v0, b0, s);
+            HMX_SCHED_FENCE();
+            i1 = load_idx(s + 3);
+            gathers(b0, i0);
+            load_cols(v0, s + 2);
+            HMX_SCHED_FENCE();
+            if (s + 1 < n)
+                apply(v1, b1, s + 1);
+            HMX_SCHED_FENCE();
         }
-        apply(v0, b0);
-        if (t0 + 32 < tend) {
-            load_cols(v0, t0 + 32);
-            operands(b0, t0 + 32, zi, 32);
-        }
-        if (t0 + 16 < tend)
-            apply(v1, b1);
-        if (t0 + 48 < tend) {
-            load_cols(v1, t0 + 48);
-            operands(b1, t0 + 48, zi, 48);
-        }
-        if (t0 + 32 < tend)
-            apply(v0, b0);
-        if (t0 + 48 < tend)
-            apply(v1, b1);
     }
     // accumulator tile t, register j of lane l = (row 16t + mfma16_row, rhs l & 15): stage as [row][rhs] (the tile buffers are done with)
     real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
@@ -2350,7 +2371,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
     // Tile pitch per variant: 144 / 80 / 48 elements (= 16 mod 32: the operand reads of 4 rows x 16 columns do not conflict).
     // fp32 only: measured on one box (profiles/r3_ab_rpl.log), fp32 reduce stage -8 % on the whole N = 1e6 operator and -4 % on one rank's
     // share of config 5; the fp64 stage does not gain from the 2-row form (a row of 64 fp64 columns already is a 512-byte load) and loses 3 %.
-    constexpr int RPL_MAX = sizeof(real) == 8 ? 1 : 4;
+#ifndef HMX_REDUCE_RPL64
+#define HMX_REDUCE_RPL64 4
+#endif
+    constexpr int RPL_MAX = sizeof(real) == 8 ? HMX_REDUCE_RPL64 : 4;
     constexpr int TILE    = RPL_MAX == 4 ? 32 * 48 : 8 * 144;
     static_assert(TILE >= 8 * 144, "tile buffer");
     __shared__ __attribute__((aligned(16))) real lds[WAVES * TILE];
@@ -2386,15 +2410,23 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
                 v[u]          = stream_load(reinterpret_cast<const scalar2 *>(src + (int64_t)row * wp + c2));
             }
         };
+        // operand loads only ISSUE here (rows clamped into the piece); the zero of a row beyond it is selected when the step is applied: a
+        // select right behind the load makes the wave wait for every load issued before it -- the step in flight included (see expand_mfma16s_kernel)
         auto operands = [&](real(&b)[KS], int i0) {
 #pragma unroll
             for (int h = 0; h < KS; h++) {
                 const int row = i0 + 4 * h + kk;
-                const real bv = xs[(int64_t)(row < len ? row : len - 1) * mu + mo];
-                b[h]          = row < len ? bv : real(0);
+                b[h]          = xs[(int64_t)(row < len ? row : len - 1) * mu + mo];
             }
         };
-        auto apply = [&](const scalar2(&v)[8], const real(&b)[KS]) {
+        // All NT column tiles of the variant, unconditionally: a tile beyond the chunk's last column multiplies what the idle lanes re-read
+        // (finite stream data) into accumulators nobody stores.  With one `if (t < ntile)` per MFMA the compiler emitted ds_read -> s_waitcnt
+        // lgkmcnt(0) -> v_mfma -> branch sixteen times in a row (round 5, read off the ISA): an LDS round trip exposed per MFMA.
+        auto apply = [&](const scalar2(&v)[8], const real(&braw)[KS], int i0) {
+            real b[KS];
+#pragma unroll
+            for (int h = 0; h < KS; h++)
+                b[h] = (i0 + 4 * h + kk < len) ? braw[h] : real(0);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < 8; u++)
@@ -2402,28 +2434,36 @@ __global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int h = 0; h < KS; h++)
+            for (int h = 0; h < KS; h++) {
+                real a[NT];
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    if (t < ntile)
-                        acc[t] = mfma16(tile[(4 * h + kk) * PITCH + 16 * t + m], b[h], acc[t]);
+                    a[t] = tile[(4 * h + kk) * PITCH + 16 * t + m];
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[t] = mfma16(a[t], b[h], acc[t]);
+            }
         };
         scalar2 v0[8], v1[8];
         real b0[KS], b1[KS];
-        load_rows(v0, 0);
         operands(b0, 0);
+        load_rows(v0, 0);
+        HMX_SCHED_FENCE();
+        // every prefetch unconditional (rows beyond the piece are clamped into it, their operand is zeroed at use): the compiler can then
+        // count the loads outstanding at each use -- behind an `if (more rows)` it assumes the path without the prefetch and waits for
+        // everything (see expand_mfma16s_kernel)
         for (int i0 = 0; i0 < len; i0 += 2 * RS) {
-            if (i0 + RS < len) {
-                load_rows(v1, i0 + RS);
-                operands(b1, i0 + RS);
-            }
-            apply(v0, b0);
-            if (i0 + 2 * RS < len) {
-                load_rows(v0, i0 + 2 * RS);
-                operands(b0, i0 + 2 * RS);
-            }
+            operands(b1, i0 + RS);
+            load_rows(v1, i0 + RS);
+            HMX_SCHED_FENCE();
+            apply(v0, b0, i0);
+            HMX_SCHED_FENCE();
+            operands(b0, i0 + 2 * RS);
+            load_rows(v0, i0 + 2 * RS);
+            HMX_SCHED_FENCE();
             if (i0 + RS < len)
-                apply(v1, b1);
+                apply(v1, b1, i0 + RS);
+            HMX_SCHED_FENCE();
         }
     };
     if (RPL_MAX >= 4 && wp <= 32)
@@ -3358,6 +3398,277 @@ __global__ __launch_bounds__(256) void combine_list_wave_kernel(CombineListArgs 
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Several right-hand sides on the stored data: partial sums live in SW16 = [slot][SWW] (the slots of the single-vector product, SWW
+// coefficients each: 16 real or 8 complex right-hand sides per sweep -- 128 resp. 64 bytes per slot in single, twice that in double precision).
+// ---------------------------------------------------------------------------------------------
+constexpr int SWW = HMX_COMPLEX ? 8 : 16;
+// a'[dst][0..SWW) = sum_i SW16[list[lp + i] + k][0..SWW): the partial column sums of a mirrored low-rank leaf that spans several row ranges.
+// One wave per entry for the entries with many partial sums (the first `A.n` entries handed to this kernel): SWW lanes take the right-hand
+// sides, the 64 / SWW lane groups every (64 / SWW)-th partial sum; fixed order
+__global__ __launch_bounds__(256) void combine_list_mu_wave_kernel(CombineListArgs A) {
+    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (e >= A.n)
+        return;
+    constexpr int NG = 64 / SWW;
+    const int lane = threadIdx.x & 63, m = lane % SWW, g = lane / SWW;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    scalar s0 = scalar(0), s1 = scalar(0);
+    int i = g;
+    for (; i + NG < cnt; i += 2 * NG) { // two loads in flight per lane
+        s0 += A.W[(int64_t)(l[i] + k) * SWW + m];
+        s1 += A.W[(int64_t)(l[i + NG] + k) * SWW + m];
+    }
+    if (i < cnt)
+        s0 += A.W[(int64_t)(l[i] + k) * SWW + m];
+    scalar s = s0 + s1;
+#pragma unroll
+    for (int o = SWW; o < 64; o <<= 1)
+        s += hmx_shfl_xor(s, o);
+    if (g == 0)
+        A.W[(int64_t)A.dst[e] * SWW + m] = s;
+}
+// ... one thread per (entry, right-hand side) for the rest
+__global__ void combine_list_mu_kernel(CombineListArgs A) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = (int)(id / SWW), m = (int)(id % SWW);
+    if (e >= A.n)
+        return;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    // four independent sums keep four (index, value) load pairs in flight; fixed order
+    scalar s0 = scalar(0), s1 = scalar(0), s2 = scalar(0), s3 = scalar(0);
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+        const int32_t l0 = l[i], l1 = l[i + 1], l2 = l[i + 2], l3 = l[i + 3];
+        s0 += A.W[(int64_t)(l0 + k) * SWW + m];
+        s1 += A.W[(int64_t)(l1 + k) * SWW + m];
+        s2 += A.W[(int64_t)(l2 + k) * SWW + m];
+        s3 += A.W[(int64_t)(l3 + k) * SWW + m];
+    }
+    for (; i < cnt; i++)
+        s0 += A.W[(int64_t)(l[i] + k) * SWW + m];
+    A.W[(int64_t)A.dst[e] * SWW + m] = (s0 + s1) + (s2 + s3);
+}
+
+// The fused symmetric / Hermitian product (expand_sym_kernel, rowsym_kernel) for MU right-hand sides at a time on the VALU: what complex
+// coefficients run on the stored triangle and, with every leaf mirrored and nothing applied forward (FWD = false), in the transposed product on
+// the stored data (the reference: the mirror pass of hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:100-106,160-170 with the complex
+// symm / hemm leaf products of matrix/linalg/add_matrix_matrix_product_row_major.hpp:113-139).  Same sweeps, same slots, same fixed order as for
+// one vector; per column of the E-streams MU forward FMAs and MU column sums (reduce8 per right-hand side), per row of the R-streams MU row
+// sums.  The streams are read once for the whole group where the fallback before round 5 ran one single-vector product per right-hand side.
+template <int WAVES, int MU, bool FWD = true>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mu_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
+    const ExpandArgs &A = S.X;
+    __shared__ scalar part[FWD ? WAVES : 1][FWD ? WAVE : 1][FWD ? MU : 1];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    const bool active   = lane < len;
+    const int row       = active ? lane : 0;
+    const bool herm     = S.herm != 0;
+    scalar xr[MU], acc[MU]; // the input at this lane's row (idle lanes and missing right-hand sides: exact zeros), the forward sums
+#pragma unroll
+    for (int j = 0; j < MU; j++) {
+        xr[j]  = (active && j < nrhs) ? S.xrow[(int64_t)(A.range_off[R] + lane) * mu + cbase + j] : scalar(0);
+        acc[j] = scalar(0);
+    }
+    constexpr int GS = 8;
+    auto load_group = [&](scalar(&v)[GS], int c0, int j) { // always eight loads, no branches: see expand_sym_kernel
+        const int last    = C - c0 - j - 1; // >= 0
+        const scalar *col = E + (int64_t)(c0 + j) * len + row;
+#pragma unroll
+        for (int u = 0; u < GS; u++)
+            v[u] = stream_load(col + (int64_t)(u < last ? u : last) * len);
+    };
+    auto advance = [&](int &c0, int &j) {
+        j += GS;
+        if (j >= 64 || c0 + j >= C) {
+            c0 += WAVES * 64;
+            j = 0;
+        }
+    };
+    scalar z[MU], mine[MU];
+#pragma unroll
+    for (int j = 0; j < MU; j++)
+        z[j] = mine[j] = scalar(0);
+    int md = -1, nc = 0;
+    bool mir = false;
+    auto tile_setup = [&](int c0) {
+        nc = (C - c0) < 64 ? (C - c0) : 64;
+        if constexpr (FWD) {
+            const scalar *zr = expand_operand(A, zidx[c0 + (lane < nc ? lane : 0)], mu) + cbase;
+#pragma unroll
+            for (int j = 0; j < MU; j++)
+                z[j] = (lane < nc && j < nrhs) ? zr[j < nrhs ? j : 0] : scalar(0);
+        }
+        md  = lane < nc ? mdst[c0 + lane] : -1;
+        mir = __any(md >= 0);
+    };
+    auto process = [&](const scalar(&v)[GS], int jg) {
+        if constexpr (FWD)
+#pragma unroll
+            for (int u = 0; u < GS; u++)
+#pragma unroll
+                for (int j = 0; j < MU; j++)
+                    acc[j] = hmx_fma(v[u], readlane_val(z[j], (jg + u) & 63), acc[j]);
+        if (mir && jg < nc) {
+#pragma unroll
+            for (int j = 0; j < MU; j++) {
+                scalar p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    p[u] = (herm ? hmx_conj(v[u]) : v[u]) * xr[j];
+                const scalar r = reduce8(p, lane); // lane 8 s + g of lane group s = lane >> 3 keeps the sum of column jg + s: see expand_sym_kernel
+                mine[j]        = hmx_select((lane & 7) == (jg >> 3), r, mine[j]);
+            }
+            if (jg + 8 >= nc) {
+#pragma unroll
+                for (int j = 0; j < MU; j++) {
+                    const scalar t = hmx_shfl(mine[j], 8 * (lane & 7) + (lane >> 3)); // the sum of column c in lane c
+                    if (md >= 0 && j < nrhs)
+                        S.W[(int64_t)md * SWW + j] = t;
+                }
+            }
+        }
+    };
+    scalar va[GS], vb[GS];
+    int c0 = wv * 64, j = 0;
+    if (c0 < C)
+        load_group(va, c0, 0);
+    while (c0 < C) {
+        int n0 = c0, nj = j;
+        advance(n0, nj);
+        bool more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(vb, more ? n0 : c0, more ? nj : j);
+        process(va, j);
+        if (!more)
+            break;
+        c0 = n0, j = nj;
+        advance(n0, nj);
+        more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(va, more ? n0 : c0, more ? nj : j);
+        process(vb, j);
+        c0 = n0, j = nj;
+    }
+    if constexpr (FWD) {
+#pragma unroll
+        for (int j = 0; j < MU; j++)
+            part[wv][lane][j] = active ? acc[j] : scalar(0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < len * MU; e += WAVES * WAVE) {
+            const int i = e / MU, jj = e - i * MU;
+            if (jj >= nrhs)
+                continue;
+            scalar s = part[0][i][jj];
+#pragma unroll
+            for (int k = 1; k < WAVES; k++)
+                s += part[k][i][jj];
+            scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + jj;
+            *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        }
+    }
+}
+
+// second sweep over the R-streams for MU right-hand sides (rowsym_kernel's scheme on intervals of SYM_IR_MU rows: one workgroup per
+// interval, wave w its sub-tasks w, w + WAVES, ..., row sums folded in LDS, the dense mirrored contributions and the y update at the end)
+constexpr int SYM_IR_MU = 64;
+template <int WAVES, int MU>
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSymArgs A, const scalar *W16, int mu, int cbase, int nrhs) {
+    __shared__ scalar acc[WAVES][SYM_IR_MU][MU];
+    const int I    = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int r = lane; r < SYM_IR_MU * MU; r += WAVE)
+        (&acc[wv][0][0])[r] = scalar(0);
+    const bool herm = A.herm != 0;
+    constexpr int GS = 8;
+    for (int64_t q = A.sub_ptr[I] + wv; q < A.sub_ptr[I + 1]; q += WAVES) {
+        const int task = A.sub_task[q], row0 = A.sub_row0[q], len = A.sub_nrows[q];
+        scalar(*dst)[MU] = &acc[wv][A.sub_dst[q]];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        const int wp      = hmx_wp(w);
+        const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * wp;
+        const int64_t cb  = A.range_colbase[S] + ch * cw;
+        const int d0 = col0 < w ? A.coef[cb + col0] : -1, d1 = col1 < w ? A.coef[cb + col1] : -1;
+        scalar c0[MU], c1[MU], mine[MU];
+#pragma unroll
+        for (int j = 0; j < MU; j++) {
+            c0[j]   = (d0 >= 0 && j < nrhs) ? W16[(int64_t)d0 * SWW + j] : scalar(0);
+            c1[j]   = (d1 >= 0 && j < nrhs) ? W16[(int64_t)d1 * SWW + j] : scalar(0);
+            mine[j] = scalar(0);
+        }
+        auto load_rows = [&](scalar2(&e)[GS], int i0) {
+#pragma unroll
+            for (int u = 0; u < GS; u++) {
+                const int i = i0 + u < len ? i0 + u : len - 1;
+                e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
+            }
+        };
+        auto process = [&](const scalar2(&e)[GS], int i0) {
+            if (i0 >= len)
+                return;
+            const int g = (i0 >> 3) & 7;
+#pragma unroll
+            for (int j = 0; j < MU; j++) {
+                scalar v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = herm ? hmx_fma(hmx_conj(e[u].x), c0[j], hmx_conj(e[u].y) * c1[j]) : hmx_fma(e[u].x, c0[j], e[u].y * c1[j]);
+                const scalar r = reduce8(v, lane); // lane 8 s + g keeps the sum of row 64 b + 8 g + s: see rowsym_kernel
+                mine[j]        = hmx_select((lane & 7) == g, r, mine[j]);
+            }
+            if (g == 7 || i0 + 8 >= len) {
+                const int i = (i0 & ~63) + lane;
+#pragma unroll
+                for (int j = 0; j < MU; j++) {
+                    const scalar t = hmx_shfl(mine[j], 8 * (lane & 7) + (lane >> 3));
+                    if (i < len)
+                        dst[i][j] += t; // this wave's slice: no other wave touches it
+                }
+            }
+        };
+        scalar2 ea[GS], eb[GS];
+        load_rows(ea, 0);
+        for (int i0 = 0; i0 < len; i0 += 2 * GS) { // unconditional prefetches (clamped to the last row)
+            load_rows(eb, i0 + GS);
+            process(ea, i0);
+            load_rows(ea, i0 + 2 * GS);
+            process(eb, i0 + GS);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < SYM_IR_MU * MU; e += WAVES * WAVE) {
+        const int r = e / MU, jj = e - r * MU;
+        const int j = I * SYM_IR_MU + r;
+        if (j >= A.n || jj >= nrhs)
+            continue;
+        scalar sum = acc[0][r][jj];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            sum += acc[k][r][jj];
+        const int cnt = A.count[j];
+        for (int k = 0; k < cnt; k++)
+            sum += W16[(int64_t)A.fidx[(int64_t)k * A.n + j] * SWW + jj];
+        scalar *yo = A.y + (int64_t)j * mu + cbase + jj;
+        if (A.accumulate)
+            *yo += A.alpha * sum;
+        else
+            *yo = hmx_is_zero(A.beta) ? A.alpha * sum : A.alpha * sum + A.beta * (*yo);
+    }
+}
+
 #if !HMX_COMPLEX
 // ---------------------------------------------------------------------------------------------
 // Several right-hand sides on the STORED TRIANGLE (symmetric storage, real coefficients): the fused product above for groups of up to 16
@@ -3410,46 +3721,74 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
 #pragma unroll
     for (int t = 0; t < 4; t++)
         acc[t] = acc4{0, 0, 0, 0};
-    auto load_cols = [&](real(&v)[16], int c) { // 16 whole columns, clamped to the last one (zero operand there)
+    // the wave's columns as one sequence of 16-column steps, three stages in flight, every load unconditional: see expand_mfma16s_kernel
+    const int ntile_all = (C + 63) >> 6;
+    int n = 0;
+    if (wv < ntile_all) {
+        n = 4 * ((ntile_all - 1 - wv) / WAVES + 1);
+        if ((ntile_all - 1 - wv) % WAVES == 0)
+            n -= 4 - ((C - 64 * (ntile_all - 1) + 15) >> 4);
+    }
+    auto col_of = [&](int s) { return (((s >> 2) * WAVES + wv) << 6) + ((s & 3) << 4); };
+    struct Idx {
+        int z, md; // lane l: Z index and mirror slot of column col_of(s) + (l & 15)
+    };
+    auto load_idx = [&](int s) {
+        const int c  = col_of(s < n ? s : n - 1) + m;
+        const int cc = c < C ? c : C - 1;
+        Idx ix;
+        ix.z  = FWD ? zidx[cc] : 0;
+        ix.md = mdst[cc];
+        return ix;
+    };
+    auto gathers = [&](real(&b)[4], const Idx &ix) {
+        if constexpr (FWD)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int zc = __shfl(ix.z, 4 * g + kk, WAVE);
+                b[g]         = expand_operand(A, zc, mu)[mo];
+            }
+    };
+    auto load_cols = [&](real(&v)[16], int s) { // 16 whole columns, clamped to the range's last one (zero operand there, sums never stored)
+        const int c = col_of(s < n ? s : n - 1);
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int col = c + u < C ? c + u : C - 1;
             v[u]          = stream_load(E + (int64_t)col * len + row);
         }
     };
-    auto operands = [&](real(&b)[4], int c, int zi, int base) {
-        if constexpr (FWD)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int zc  = __shfl(zi, base + 4 * g + kk, WAVE);
-                const real bv = expand_operand(A, zc, mu)[mo];
-                b[g]          = (c + 4 * g + kk < C) ? bv : real(0);
-            }
-    };
     // one step = 16 columns: mirrored column sums (if any of the 16 is a mirrored column), then the forward product
-    auto apply = [&](real(&v)[16], const real(&b)[4], int c, int md, int base) {
-        const unsigned long long mirrored = __ballot(md >= 0);
-        if ((mirrored >> base) & 0xFFFFull) { // wave-uniform
+    auto apply = [&](real(&v)[16], const real(&braw)[4], int mdi, int s) {
+        const int c  = col_of(s);
+        const int md = (c + m < C) ? mdi : -1;
+        if (__any(md >= 0)) { // wave-uniform: steps without mirrored columns (diagonal leaves, the other ranks' columns of a row-partitioned operator) skip all of it
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < 16; u++)
                 tile[lane * PT + u] = v[u]; // 16 consecutive elements per lane: 16-byte stores
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            real ta[16];
+#pragma unroll
+            for (int h = 0; h < 16; h++)
+                ta[h] = tile[(4 * h + kk) * PT + m];
             acc4 am = acc4{0, 0, 0, 0};
 #pragma unroll
             for (int h = 0; h < 16; h++)
-                am = mfma16(tile[(4 * h + kk) * PT + m], xt[h], am); // A[m = column][k = row 4h + kk], B[k][n = rhs]
+                am = mfma16(ta[h], xt[h], am); // A[m = column][k = row 4h + kk], B[k][n = rhs]
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int col = mfma16_row(real(0), lane, j);
-                const int d   = __shfl(md, base + col, WAVE);
-                if (d >= 0 && c + col < C)
+                const int d = __shfl(md, mfma16_row(real(0), lane, j), WAVE);
+                if (d >= 0)
                     S.W[(int64_t)d * 16 + m] = am[j];
             }
         }
         // forward: a[g][t] (row 16 t + m, column 4 g + kk) = register 4 g + kk of lane quarter t -- a 4 x 4 transposition per column group
         if constexpr (FWD) {
+            real b[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                b[g] = (c + 4 * g + kk < C) ? braw[g] : real(0);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 lane_swap32(v[4 * g + 0], v[4 * g + 2]);
@@ -3464,50 +3803,30 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
                     acc[t] = mfma16(v[4 * g + t], b[g], acc[t]);
         }
     };
-#ifndef HMX_SYMMU_SINGLE
-#define HMX_SYMMU_SINGLE 0
-#endif
-#if HMX_SYMMU_SINGLE
-    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) { // one step in flight per wave: half the registers, more waves per SIMD
-        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
-        const int zi   = !FWD ? 0 : ((t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1]);
-        const int md   = (t0 + lane < C) ? mdst[t0 + lane] : -1;
-        for (int c = t0; c < tend; c += 16) {
-            real v0[16], b0[4];
-            load_cols(v0, c);
-            operands(b0, c, zi, c - t0);
-            apply(v0, b0, c, md, c - t0);
-        }
-    }
-#else
-    for (int t0 = wv * 64; t0 < C; t0 += WAVES * 64) {
-        const int tend = (t0 + 64) < C ? (t0 + 64) : C;
-        const int zi   = !FWD ? 0 : ((t0 + lane < C) ? zidx[t0 + lane] : zidx[C - 1]);
-        const int md   = (t0 + lane < C) ? mdst[t0 + lane] : -1;
+    if (n > 0) {
         real v0[16], v1[16], b0[4], b1[4];
-        load_cols(v0, t0);
-        operands(b0, t0, zi, 0);
-        if (t0 + 16 < tend) {
-            load_cols(v1, t0 + 16);
-            operands(b1, t0 + 16, zi, 16);
+        Idx i0 = load_idx(0), i1 = load_idx(1);
+        gathers(b0, i0);
+        load_cols(v0, 0);
+        HMX_SCHED_FENCE();
+        for (int s = 0; s < n; s += 2) {
+            const int md0 = i0.md;
+            i0 = load_idx(s + 2);
+            gathers(b1, i1);
+            load_cols(v1, s + 1);
+            HMX_SCHED_FENCE();
+            apply(v0, b0, md0, s);
+            HMX_SCHED_FENCE();
+            const int md1 = i1.md;
+            i1 = load_idx(s + 3);
+            gathers(b0, i0);
+            load_cols(v0, s + 2);
+            HMX_SCHED_FENCE();
+            if (s + 1 < n)
+                apply(v1, b1, md1, s + 1);
+            HMX_SCHED_FENCE();
         }
-        apply(v0, b0, t0, md, 0);
-        if (t0 + 32 < tend) {
-            load_cols(v0, t0 + 32);
-            operands(b0, t0 + 32, zi, 32);
-        }
-        if (t0 + 16 < tend)
-            apply(v1, b1, t0 + 16, md, 16);
-        if (t0 + 48 < tend) {
-            load_cols(v1, t0 + 48);
-            operands(b1, t0 + 48, zi, 48);
-        }
-        if (t0 + 32 < tend)
-            apply(v0, b0, t0 + 32, md, 32);
-        if (t0 + 48 < tend)
-            apply(v1, b1, t0 + 48, md, 48);
     }
-#endif
     if constexpr (!FWD)
         return;
     // forward result: the waves' accumulators folded through LDS as in expand_mfma16s_kernel
@@ -3532,58 +3851,11 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSy
     }
 }
 
-// ... one wave per entry for the entries with many partial sums (the first `A.n` entries handed to this kernel): the 16 lanes of a lane
-// quarter take the right-hand sides, the four quarters every fourth partial sum; fixed order
-__global__ __launch_bounds__(256) void combine_list_mu_wave_kernel(CombineListArgs A) {
-    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (e >= A.n)
-        return;
-    const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const int32_t *l = A.list + A.lp[e];
-    const int cnt = A.count[e], k = A.k[e];
-    scalar s0 = scalar(0), s1 = scalar(0);
-    int i = g;
-    for (; i + 4 < cnt; i += 8) { // two loads in flight per lane
-        s0 += A.W[(int64_t)(l[i] + k) * 16 + m];
-        s1 += A.W[(int64_t)(l[i + 4] + k) * 16 + m];
-    }
-    if (i < cnt)
-        s0 += A.W[(int64_t)(l[i] + k) * 16 + m];
-    scalar s = s0 + s1;
-    s += hmx_shfl_xor(s, 16);
-    s += hmx_shfl_xor(s, 32);
-    if (g == 0)
-        A.W[(int64_t)A.dst[e] * 16 + m] = s;
-}
-// a'[dst][0..16) = sum_i SW16[list[lp + i] + k][0..16): one thread per (entry, right-hand side)
-__global__ void combine_list_mu_kernel(CombineListArgs A) {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = (int)(id >> 4), m = (int)(id & 15);
-    if (e >= A.n)
-        return;
-    const int32_t *l = A.list + A.lp[e];
-    const int cnt = A.count[e], k = A.k[e];
-    // four independent sums keep four (index, value) load pairs in flight; fixed order
-    scalar s0 = scalar(0), s1 = scalar(0), s2 = scalar(0), s3 = scalar(0);
-    int i = 0;
-    for (; i + 4 <= cnt; i += 4) {
-        const int32_t l0 = l[i], l1 = l[i + 1], l2 = l[i + 2], l3 = l[i + 3];
-        s0 += A.W[(int64_t)(l0 + k) * 16 + m];
-        s1 += A.W[(int64_t)(l1 + k) * 16 + m];
-        s2 += A.W[(int64_t)(l2 + k) * 16 + m];
-        s3 += A.W[(int64_t)(l3 + k) * 16 + m];
-    }
-    for (; i < cnt; i++)
-        s0 += A.W[(int64_t)(l[i] + k) * 16 + m];
-    A.W[(int64_t)A.dst[e] * 16 + m] = (s0 + s1) + (s2 + s3);
-}
-
 // Second pass over the R-streams for up to 16 right-hand sides.  Interval = 64 output rows = one wave; its sub-tasks are the parts of the
 // (source piece, column chunk) tasks whose rows lie in the interval.  Per sub-task and half of the chunk's (<= 128) columns: the B operands
 // a'[column][rhs] of the 16 k-steps are gathered once, then every 16-row tile of the interval the sub-task touches is loaded (whole rows: two
 // rows of 64 columns per wave-wide load), staged transposed in LDS and multiplied -- 16 MFMAs per 16 x 64 tile; rows of the tile that are
 // not the sub-task's are dropped when the tile's result is added to the interval's accumulators.
-constexpr int SYM_IR_MU = 64;
 struct RowSymMuArgs {
     RowSymArgs A;         // (sub_* / order refer to the 64-row intervals)
     const scalar *W16;    // [slot][16]
@@ -3655,43 +3927,57 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_mfma16_kernel(RowSymMuArgs
     Sub cur{};
     if (q0 < q1)
         cur = fetch(q0);
+    // one tile: staged transposed in LDS, 16 MFMAs, rows that are not the sub-task's dropped when the result joins the accumulators
+    auto tile_product = [&](const scalar2(&v)[8], const real(&b)[16], const Sub &s, int t) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = 2 * u + lrow, sw = lane & 15, fl = lane & 1; // (c >> 1) & 15 and (c >> 1) & 1 of both columns lc, lc + 1
+            tile[16 * (lc ^ fl) + (i ^ sw)]       = v[u].x;
+            tile[16 * ((lc + 1) ^ fl) + (i ^ sw)] = v[u].y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        real ta[16];
+#pragma unroll
+        for (int h = 0; h < 16; h++) {
+            const int c = 4 * h + kk;
+            ta[h]       = tile[16 * (c ^ ((c >> 1) & 1)) + (m ^ ((c >> 1) & 15))];
+        }
+        acc4 tm = acc4{0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 16; h++)
+            tm = mfma16(ta[h], b[h], tm); // A[m = row][k = column c], B[k][n = rhs]
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i    = 16 * t + mfma16_row(real(0), lane, j);
+            const real add = (i >= s.dst && i < s.dst + s.n) ? tm[j] : real(0);
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++)
+                if (tt == t)
+                    acc[tt][j] += add;
+        }
+    };
     for (int64_t q = q0; q < q1; q++) {
         const Sub nxt = fetch(q + 1 < q1 ? q + 1 : q);
         const int t_lo = cur.dst >> 4, t_hi = (cur.dst + cur.n - 1) >> 4;
         for (int c0 = 0; c0 < cur.w; c0 += 64) {
             real b[16];
             gather_b(b, cur, c0);
-            scalar2 v[8], vn[8];
-            load_tile(v, cur, c0, t_lo);
-            for (int t = t_lo; t <= t_hi; t++) {
-                load_tile(vn, cur, c0, t < t_hi ? t + 1 : t); // unconditional: the next tile's loads are in flight under this tile's arithmetic
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = 2 * u + lrow, sw = lane & 15, fl = lane & 1; // (c >> 1) & 15 and (c >> 1) & 1 of both columns lc, lc + 1
-                    tile[16 * (lc ^ fl) + (i ^ sw)]       = v[u].x;
-                    tile[16 * ((lc + 1) ^ fl) + (i ^ sw)] = v[u].y;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                acc4 tm = acc4{0, 0, 0, 0};
-#pragma unroll
-                for (int h = 0; h < 16; h++) {
-                    const int c = 4 * h + kk;
-                    tm          = mfma16(tile[16 * (c ^ ((c >> 1) & 1)) + (m ^ ((c >> 1) & 15))], b[h], tm); // A[m = row][k = column c], B[k][n = rhs]
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int i    = 16 * t + mfma16_row(real(0), lane, j);
-                    const real add = (i >= cur.dst && i < cur.dst + cur.n) ? tm[j] : real(0);
-#pragma unroll
-                    for (int tt = 0; tt < 4; tt++)
-                        if (tt == t)
-                            acc[tt][j] += add;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    v[u] = vn[u];
+            // two tile buffers used in turn (no register copies: a copy waits for the load it copies), the next tile's loads always issued --
+            // clamped to the segment's last tile -- before the current tile is worked on
+            scalar2 va[8], vb[8];
+            load_tile(va, cur, c0, t_lo);
+            for (int t = t_lo; t <= t_hi; t += 2) {
+                load_tile(vb, cur, c0, t + 1 <= t_hi ? t + 1 : t_hi);
+                HMX_SCHED_FENCE();
+                tile_product(va, b, cur, t);
+                HMX_SCHED_FENCE();
+                load_tile(va, cur, c0, t + 2 <= t_hi ? t + 2 : t_hi);
+                HMX_SCHED_FENCE();
+                if (t + 1 <= t_hi)
+                    tile_product(vb, b, cur, t + 1);
+                HMX_SCHED_FENCE();
             }
         }
         cur = nxt;
@@ -3709,29 +3995,37 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_mfma16_kernel(RowSymMuArgs
             cn[4 * t + j]  = jrow < A.n ? A.count[jr[4 * t + j]] : 0;
             kmax           = cn[4 * t + j] > kmax ? cn[4 * t + j] : kmax;
         }
+    // the sixteen y values of the lane are fetched NOW, together, unconditionally (rows beyond the operator read its last row, right-hand sides
+    // beyond the group the group's first): with the load inside each row's own `if (row exists) y = ...` the compiler emitted load -> wait ->
+    // store sixteen times in a row, sixteen trips to memory one after the other at the end of every interval (round 5, read off the ISA)
+    const bool need_y = A.accumulate || !(A.beta == real(0));
+    const int mcol    = cbase + (m < nrhs ? m : 0);
+    real yv[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        yv[e] = need_y ? A.y[(int64_t)jr[e] * mu + mcol] : real(0);
     for (int k = 0; k < kmax; k++) {
         int32_t d[16];
 #pragma unroll
         for (int e = 0; e < 16; e++)
             d[e] = A.fidx[(int64_t)(k < cn[e] ? k : 0) * A.n + jr[e]]; // (level 0 of the row when it has fewer: a valid entry, dropped below)
+        real w[16];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const real v = P.W16[(int64_t)(k < cn[e] ? d[e] : P.zero_slot) * 16 + m];
-            acc[e >> 2][e & 3] += v;
-        }
+        for (int e = 0; e < 16; e++)
+            w[e] = P.W16[(int64_t)(k < cn[e] ? d[e] : P.zero_slot) * 16 + m];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            acc[e >> 2][e & 3] += w[e];
     }
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int jrow = I * SYM_IR_MU + 16 * t + mfma16_row(real(0), lane, j);
-            if (jrow >= A.n || m >= nrhs)
-                continue;
-            real *yo = A.y + (int64_t)jrow * mu + cbase + m;
-            if (A.accumulate)
-                *yo += A.alpha * acc[t][j];
-            else
-                *yo = A.beta == real(0) ? A.alpha * acc[t][j] : A.alpha * acc[t][j] + A.beta * (*yo);
+            const real y0  = yv[4 * t + j];
+            const real out = A.accumulate ? y0 + A.alpha * acc[t][j] : (A.beta == real(0) ? A.alpha * acc[t][j] : A.alpha * acc[t][j] + A.beta * y0);
+            if (jrow < A.n && m < nrhs)
+                A.y[(int64_t)jrow * mu + cbase + m] = out;
         }
 }
 

@@ -319,6 +319,10 @@ __device__ __forceinline__ void stream_load2(const float *p, int n, float &a, fl
 template <typename T> struct Acc4;
 template <> struct Acc4<double> { typedef hmx_d4 type; };
 template <> struct Acc4<float> { typedef hmx_f4 type; };
+// Nothing is scheduled across this point: the software-pipelined kernels use it to keep their load groups in program order (s_waitcnt vmcnt
+// counts loads in the order they were issued: a gather the compiler sinks behind the next step's stream loads turns every wait for it into a
+// drain of the whole queue)
+#define HMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ hmx_d4 mfma16(double a, double b, hmx_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ hmx_f4 mfma16(float a, float b, hmx_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int mfma16_row(double, int lane, int reg) { return (lane >> 4) + 4 * reg; }

@@ -1067,4 +1067,13 @@ int orc_num_threads() {
     return 1;
 #endif
 }
+// threads of the OpenMP leaf loops from now on (bench.py: the cores the process really has under a cgroup quota, not the hardware threads)
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0)
+        omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 } // extern "C"

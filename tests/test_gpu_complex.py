@@ -347,3 +347,52 @@ def test_conjugate_transposed_products_without_the_transposed_layout(name, layou
             Y = np.stack([y0T, y0T, y0T], axis=1).copy()
             hm.internal_add_hmatrix_matrix_product_row_major(trans, alpha, H, X, beta, Y, 3)
             assert rel_err(Y[:, 0], g[key]) < 1e-10 and rel_err(Y[:, 1] - beta * y0T, 2 * (g[key] - beta * y0T)) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["ellipse_n3000_z64_symL", "ball_n2000_z64_hermU", "ball_n2000_c32_hermL", "ball_n2000_z64_p2_hermL_rank0"])
+def test_complex_stored_triangle_product_with_several_right_hand_sides(name):
+    """Several right-hand sides on the STORED TRIANGLE of a complex symmetric / Hermitian operator (expand_sym_mu_kernel / rowsym_mu_kernel: the
+    fused product for groups of 8 on the VALU; the reference runs the mirror pass on the same leaves with complex symm / hemm,
+    hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:100-106,160-170, matrix/linalg/add_matrix_matrix_product_row_major.hpp:113-139):
+    2, 3, 8, 11 and 19 right-hand sides (ragged groups of 8) against the fused single-vector product column by column, against the expanded
+    view and the reference's own row-major product; no expanded copy is allocated, results are bit-reproducible; a row-restricted Hermitian
+    operator (mirrored leaves among ordinary ones) runs the same sweeps."""
+    from oracle.oracle import hashed_zvector
+    p, g = params(name), load(name)
+    T, S, H = build_zengine(p)
+    H.set_option("sym_multi_rhs", 1)
+    x, xT, y0, y0T, alpha, beta = zinputs(H, g)
+    tol = 2e-5 if p["prec"] == "c32" else 1e-12
+    nr, nc = H.nb_rows(), H.nb_cols()
+    rng = np.random.default_rng(11)
+    for mu in (2, 3, 8, 11, 19):
+        X = (rng.standard_normal((nc, mu)) + 1j * rng.standard_normal((nc, mu))).astype(H.dtype)
+        Y0 = (rng.standard_normal((nr, mu)) - 1j * rng.standard_normal((nr, mu))).astype(H.dtype)
+        H.set_profiling(True)
+        Y = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y, mu)
+        names = [k for k, _ in H.last_kernel_times()]
+        H.set_profiling(False)
+        assert any("expand_sym_mu" in k for k in names) and any("rowsym_mu" in k for k in names), names
+        ref = Y0.copy()
+        for c in range(mu):
+            y = np.ascontiguousarray(Y0[:, c])
+            hm.internal_add_hmatrix_vector_product("N", alpha, H, np.ascontiguousarray(X[:, c]), beta, y)
+            ref[:, c] = y
+        assert rel_err(Y, ref) < tol, (mu, rel_err(Y, ref))
+        Y2 = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y2, mu)
+        assert np.array_equal(Y, Y2)  # fixed summation order
+    assert H.stats()["expanded_bytes"] == 0
+    if p["sym"] == "H" and p["rank"] < 0:  # a square Hermitian operator is its own conjugate transpose: 'C' runs the same sweeps
+        Yc = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major("C", alpha, H, X, beta, Yc, mu)
+        assert np.array_equal(Yc, Y)
+    Xg = hashed_zvector(nc * 2, 5).reshape(nc, 2).astype(H.dtype)
+    Yg = hashed_zvector(nr * 2, 6).reshape(nr, 2).astype(H.dtype)
+    hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, Xg, beta, Yg, 2)
+    assert rel_err(Yg, g["YNrm"]) < (1e-5 if p["prec"] == "c32" else 1e-10)  # the reference's own product
+    H.set_option("sym_multi_rhs", 0)  # ... and the expanded view gives the same product (another summation order)
+    Y3 = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y3, mu)
+    assert H.stats()["expanded_bytes"] > 0 and rel_err(Y3, Y) < tol

@@ -60,6 +60,13 @@ def test_staged_matrix_core_kernels_issue_their_loads_back_to_back(tmp_path):
         drained = sum(1 for l in asm.split("\n") if "s_waitcnt vmcnt(0)" in l)
         assert ops["v_mfma_f64_16x16x4_f64"] + ops["v_mfma_f32_16x16x4_f32"] >= 32, sym
         assert ops["scratch_load_dword"] + ops["scratch_store_dword"] == 0, sym
+        if re.search(r"3(?:f64|f32)21expand_mfma16s_kernel", sym):
+            # round 5: every prefetch unconditional, load groups pinned in program order -- the compiler can count what is outstanding, so a step
+            # is applied while the whole next step (indices, 4 gathers, 16 stream columns) stays in flight: the loop's waits are vmcnt(20 ... 36),
+            # the only vmcnt(0) left are the prologue's index load and the write-out.  (Behind `if (more columns) prefetch;` every use waited for
+            # the prefetch itself: one drain per 16 columns.)
+            depths = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", asm)]
+            assert drained <= 3 and max(depths) >= 30 and sum(1 for d in depths if d >= 20) >= 12, (sym, drained, sorted(depths))
         if "expand" in sym:
             # the loop has no divergent branch at all: the three are the tile loop's tail and the write-out of the rows
             assert ops["s_cbranch_execz"] <= (6 if ("mfma32s" in sym or "zmfma16s" in sym) else 4) and drained <= 8, (sym, ops["s_cbranch_execz"], drained)  # 32-wide: two write-outs
