@@ -1,0 +1,985 @@
+// kernels_symmetric.hpp -- mirrored sweeps: the fused symmetric / Hermitian product and the transposed product on the stored data, single vector and several right-hand sides.
+// Part of the engine's device code: included by kernels_body.hpp inside namespace hmx::{f64,f32,z64,c32}, written against `scalar` / `real`.  No include guard on purpose.
+
+// ---------------------------------------------------------------------------------------------
+// Wave reductions of the mirrored / transposed sweeps (columns of the E-streams, rows of the R-streams read "the other way")
+// ---------------------------------------------------------------------------------------------
+// Eight wave-wide sums for the price of ~1.25: each butterfly step halves the number of live values while
+// halving the lane group that owns them.  On return lane l with (l & 7) == 0 holds the complete sum of input
+// value number 4*bit5(l) + 2*bit4(l) + bit3(l).
+// The lane exchanges are v_permlane32_swap / v_permlane16_swap / DPP row operations: no LDS traffic and none of ds_bpermute's
+// latency in the dependent chain (-DHMX_REDUCE8_DPP=0 restores the ds_bpermute butterfly for A/B runs).  After the three halving
+// steps the eight lanes of a group all-reduce with row_half_mirror (l <-> 7 - l) and the two quad permutations.
+#ifndef HMX_REDUCE8_DPP
+#define HMX_REDUCE8_DPP 1
+#endif
+__device__ __forceinline__ scalar reduce8(const scalar (&v)[8], int lane) {
+#if HMX_REDUCE8_DPP
+    scalar t[4], u[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        scalar a = v[k], b = v[k + 4];
+        lane_swap32(a, b);
+        t[k] = a + b;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        scalar a = t[k], b = t[k + 2];
+        lane_swap16(a, b);
+        u[k] = a + b;
+    }
+    const bool b3 = lane & 8;
+    // (component-wise select: a lane-dependent choice between two complex values otherwise becomes a dynamically indexed private array --
+    // 48 bytes of scratch and four scratch instructions per group of eight columns in the complex-double kernels until round 4)
+    scalar r = hmx_select(b3, u[1], u[0]) + dpp_move<0x128>(hmx_select(b3, u[0], u[1])); // row_ror:8 = lane ^ 8 inside a row of 16
+    r += dpp_move<0x141>(r);                                           // row_half_mirror
+    r += dpp_move<0xB1>(r);                                            // quad_perm [1,0,3,2]
+    r += dpp_move<0x4E>(r);                                            // quad_perm [2,3,0,1]
+    return r;
+#else
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    scalar t[4], u[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        t[k] = (b5 ? v[k + 4] : v[k]) + hmx_shfl_xor(b5 ? v[k] : v[k + 4], 32);
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+        u[k] = (b4 ? t[k + 2] : t[k]) + hmx_shfl_xor(b4 ? t[k] : t[k + 2], 16);
+    scalar r = (b3 ? u[1] : u[0]) + hmx_shfl_xor(b3 ? u[0] : u[1], 8);
+    r += hmx_shfl_xor(r, 4);
+    r += hmx_shfl_xor(r, 2);
+    r += hmx_shfl_xor(r, 1);
+    return r;
+#endif
+}
+__device__ __forceinline__ int reduce8_slot(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
+
+// ---------------------------------------------------------------------------------------------
+// Fused symmetric / Hermitian product on the COMPACT layout (only the stored triangle is in HBM):
+// add_hmatrix_vector_product.hpp:97-103,158-161 -- every leaf of leaves_for_symmetry is applied twice, out[t] += B in[s] and
+// out[s] += B^T in[t] (B^H for 'H').  Here that is ONE sweep over the E-streams: while the tile of a row range sits in
+// registers as lane = row for the forward product, the same registers give, per mirrored column, the column sum
+// sum_i E[i,c] x_t[i] (eight wave reductions at a time, reduce8).  For a dense leaf that is the leaf's contribution to an output
+// row; for a low-rank leaf B = U V it is a slice of a' = U^T x_t, and y_s += V^T a' needs a second sweep over the R-streams once
+// a' is complete (the one factor a streaming product must read twice: U-expand needs V x_s and V-expand needs U^T x_t, so with
+// one read of U the two V passes lie before and after it).  Nothing is accumulated with atomics: the column sums have their own
+// slots in W = [a' | EW] assigned at layout time (E-column order: every row range writes one contiguous run), a' of a leaf spanning
+// several ranges is folded in a fixed order (combine_list_kernel), and the second sweep (rowsym_kernel) owns the output rows it
+// updates -- results are bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+struct ExpandSymArgs {
+    ExpandArgs X;
+    const int32_t *mdst; // per E column: slot in W of its column sum, -1: not a mirrored column
+    scalar *W;
+    const scalar *xrow;  // the input at the TARGET positions of this operator: xrow[range_off + i]
+    int herm;            // 'H' storage: the mirrored leaf is the conjugate transpose
+};
+// The wave's columns are walked in groups of eight (sixteen for 4-byte coefficients), flattened over its 64-column tiles and
+// software-pipelined: the loads of group g + 1 are issued before group g is reduced, so the dependent chain of the eight-way
+// reduction never leaves the wave without loads in flight.
+// FWD = false: the mirrored column sums only -- the first sweep of the TRANSPOSED product of an ordinary operator on its stored data (every
+// column is then a mirrored one, the forward operands and y are not touched; run_transposed_fused).
+template <int WAVES, bool FWD = true>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
+    const ExpandArgs &A = S.X;
+    __shared__ scalar part[FWD ? WAVES : 1][WAVE];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    const bool active   = lane < len;
+    const int row       = active ? lane : 0;
+    const scalar xr     = active ? S.xrow[A.range_off[R] + lane] : scalar(0); // idle lanes contribute exact zeros to the column sums
+    const bool herm     = S.herm != 0;
+    scalar acc = scalar(0);
+    // always eight loads, no branches (the compiler can then count them: s_waitcnt vmcnt(8) keeps the next group in flight while
+    // this one is used): beyond the last column of the range the last column is read again -- its products meet the zero
+    // coefficients of the lanes >= nc and its column sums are never stored
+    // (4-byte coefficients: groups of sixteen, reduced as two eights -- a wave's load is then only 256 bytes, sixteen are needed in flight)
+    constexpr int GS = sizeof(scalar) == 4 ? 16 : 8;
+    auto load_group = [&](scalar(&v)[GS], int c0, int j) {
+        const int last    = C - c0 - j - 1; // >= 0
+        const scalar *col = E + (int64_t)(c0 + j) * len + row;
+#pragma unroll
+        for (int u = 0; u < GS; u++)
+            v[u] = stream_load(col + (int64_t)(u < last ? u : last) * len);
+    };
+    auto advance = [&](int &c0, int &j) {
+        j += GS;
+        if (j >= 64 || c0 + j >= C) {
+            c0 += WAVES * 64;
+            j = 0;
+        }
+    };
+    scalar z = scalar(0), mine = scalar(0);
+    int md = -1, nc = 0;
+    bool mir = false;
+    auto tile_setup = [&](int c0) { // gathered coefficients and mirror slots of the (up to) 64 columns of a tile
+        nc  = (C - c0) < 64 ? (C - c0) : 64;
+        if constexpr (FWD)
+            z = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
+        md  = lane < nc ? mdst[c0 + lane] : -1;
+        mir = __any(md >= 0); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
+    };
+    auto process = [&](const scalar(&v)[GS], int jg) {
+        if constexpr (FWD)
+#pragma unroll
+            for (int u = 0; u < GS; u++)
+                acc = hmx_fma(v[u], readlane_val(z, (jg + u) & 63), acc);
+        if (mir)
+#pragma unroll
+            for (int h = 0; h < GS; h += 8) {
+            const int j = jg + h;
+            if (j >= nc)
+                break;
+            scalar p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                p[u] = (herm ? hmx_conj(v[h + u]) : v[h + u]) * xr;
+            // every lane of lane group s = lane >> 3 now holds the sum of column j + s; lane 8 s + g keeps the one of group g = j / 8,
+            // so that after the tile's last group an 8 x 8 transposition of the lane index (one ds_bpermute) puts the sum of
+            // column c into lane c: ONE coalesced store per tile instead of eight 8-lane stores.  (What the stores cost is the write
+            // stream itself: on MI355X 1.6 % of written bytes takes 15-30 % off a streaming read, tools/read_write_mix.hip; staging
+            // the sums in LDS until the end of the workgroup, 128-byte aligned runs or non-temporal stores change nothing.)
+            const scalar r = reduce8(p, lane);
+            mine           = hmx_select((lane & 7) == (j >> 3), r, mine);
+            if (j + 8 >= nc) {
+                const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
+                if (md >= 0)
+                    S.W[md] = t;
+            }
+        }
+    };
+    // order inside a step: (tile setup, its own dependent loads) -> prefetch of the next group -> arithmetic on the current
+    // one; the prefetch is unconditional (past the end it re-reads the current group) so that exactly eight newer loads are
+    // outstanding whenever a group is consumed
+    scalar va[GS], vb[GS];
+    int c0 = wv * 64, j = 0;
+    if (c0 < C)
+        load_group(va, c0, 0);
+    while (c0 < C) {
+        int n0 = c0, nj = j;
+        advance(n0, nj);
+        bool more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(vb, more ? n0 : c0, more ? nj : j);
+        process(va, j);
+        if (!more)
+            break;
+        c0 = n0, j = nj;
+        advance(n0, nj);
+        more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(va, more ? n0 : c0, more ? nj : j);
+        process(vb, j);
+        c0 = n0, j = nj;
+    }
+    if constexpr (FWD) {
+        part[wv][lane] = active ? acc : scalar(0);
+        __syncthreads();
+        if (wv == 0 && active) {
+            scalar s = part[0][lane];
+#pragma unroll
+            for (int k = 1; k < WAVES; k++)
+                s += part[k][lane];
+            scalar *yo = A.y + A.range_off[R] + lane;
+            *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        }
+    }
+}
+
+// Second sweep over the R-streams, owner-computes: y_s += V^T a' (conjugated for 'H').  The target rows are cut into intervals of
+// SYM_IR rows; one workgroup per interval walks the (parts of) (source piece, column chunk) tasks whose rows lie in it -- an R-stream
+// chunk is row-major, so any row sub-range of a piece is one contiguous block -- wave w taking the sub-tasks w, w + WAVES, ... of the
+// interval's list.  Per sub-task: lane = column pair, eight (fp32: sixteen) rows per group with the next group's loads in flight,
+// reduce8 over the rows, and after 64 rows one transposing ds_bpermute that puts the sum of row i into lane i, which adds it to the
+// wave's slice of an LDS accumulator.  At the end the waves' slices are added in order, the interval's dense mirrored contributions
+// (column sums expand_sym_kernel left in EW, found through the level-major index) are added, and y is updated ONCE per row: no
+// partial row sums go through HBM, no folding kernel.  Fixed order everywhere: bit-reproducible.
+#ifndef HMX_SYM_IR
+#define HMX_SYM_IR 256
+#endif
+#ifndef HMX_SYM_WAVES
+#define HMX_SYM_WAVES 4
+#endif
+constexpr int SYM_IR    = HMX_SYM_IR; // rows per interval
+constexpr int SYM_WAVES = HMX_SYM_WAVES;
+struct RowSymArgs {
+    const scalar *stream;
+    const int32_t *task_range, *task_chunk;
+    const int32_t *range_len, *range_cols, *range_cw;
+    const int64_t *range_base, *range_colbase;
+    const int32_t *coef;      // per R column: slot of a'[col] in W, -1: not a mirrored column
+    const int32_t *order;     // launch position -> interval (heaviest first)
+    const int64_t *sub_ptr;   // per interval: its sub-tasks [sub_ptr[I], sub_ptr[I + 1])
+    const int32_t *sub_task, *sub_row0, *sub_nrows, *sub_dst; // task, first row inside the piece, rows, first row inside the interval
+    const scalar *W;          // [a' | EW]
+    const int32_t *fidx;      // dense mirrored contributions of output row j: W[fidx[k * n + j]], k < count[j]
+    const int32_t *count;
+    scalar *y;
+    scalar alpha;
+    int n;                    // rows of the operator (stride of fidx)
+    int herm;
+    scalar beta;              // accumulate = 0 (transposed product on the stored data: this sweep owns y): y = alpha * sums + beta * y
+    int accumulate;           // 1: y += alpha * sums (the forward sweep of the symmetric product has written y already)
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_kernel(RowSymArgs A) {
+    __shared__ scalar acc[WAVES][SYM_IR];
+    const int I    = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int r = lane; r < SYM_IR; r += WAVE)
+        acc[wv][r] = scalar(0);
+    const bool herm = A.herm != 0;
+    constexpr int GS = sizeof(scalar2) <= 8 ? 16 : 8;
+    for (int64_t q = A.sub_ptr[I] + wv; q < A.sub_ptr[I + 1]; q += WAVES) {
+        const int task = A.sub_task[q], row0 = A.sub_row0[q], len = A.sub_nrows[q];
+        scalar *dst = &acc[wv][A.sub_dst[q]];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        const int wp      = hmx_wp(w);
+        const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * wp;
+        const int64_t cb  = A.range_colbase[S] + ch * cw;
+        scalar c0 = scalar(0), c1 = scalar(0);
+        if (col0 < w) {
+            const int d = A.coef[cb + col0];
+            c0          = d >= 0 ? A.W[d] : scalar(0);
+        }
+        if (col1 < w) {
+            const int d = A.coef[cb + col1];
+            c1          = d >= 0 ? A.W[d] : scalar(0);
+        }
+        scalar mine = scalar(0);
+        // always GS loads, no branches: rows beyond the sub-task re-read its last row (their sums are dropped), lanes beyond the
+        // chunk read column 0 and multiply it with their zero coefficients
+        auto load_rows = [&](scalar2(&e)[GS], int i0) {
+#pragma unroll
+            for (int u = 0; u < GS; u++) {
+                const int i = i0 + u < len ? i0 + u : len - 1;
+                e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
+            }
+        };
+        auto process = [&](const scalar2(&e)[GS], int ig) {
+#pragma unroll
+            for (int h = 0; h < GS; h += 8) {
+                const int i0 = ig + h;
+                if (i0 >= len)
+                    break;
+                scalar v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = herm ? hmx_fma(hmx_conj(e[h + u].x), c0, hmx_conj(e[h + u].y) * c1) : hmx_fma(e[h + u].x, c0, e[h + u].y * c1);
+                // as in expand_sym_kernel: lane 8 s + g keeps the sum of row 64 b + 8 g + s; after 64 rows one transposing ds_bpermute
+                const scalar r = reduce8(v, lane);
+                const int g    = (i0 >> 3) & 7;
+                mine           = hmx_select((lane & 7) == g, r, mine);
+                if (g == 7 || i0 + 8 >= len) {
+                    const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
+                    const int i    = (i0 & ~63) + lane;
+                    if (i < len)
+                        dst[i] += t; // this wave's slice: no other wave touches it, the sub-tasks of a wave run one after the other
+                }
+            }
+        };
+        scalar2 ea[GS], eb[GS];
+        load_rows(ea, 0);
+        for (int i0 = 0; i0 < len; i0 += 2 * GS) { // unconditional prefetches (clamped to the last row): exactly GS newer loads outstanding at every use
+            load_rows(eb, i0 + GS);
+            process(ea, i0);
+            load_rows(ea, i0 + 2 * GS);
+            if (i0 + GS < len)
+                process(eb, i0 + GS);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < SYM_IR; r += WAVES * WAVE) {
+        const int j = I * SYM_IR + r;
+        if (j >= A.n)
+            break;
+        scalar sum = acc[0][r];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            sum += acc[k][r];
+        const int cnt = A.count[j];
+        for (int k = 0; k < cnt; k++)
+            sum += A.W[A.fidx[(int64_t)k * A.n + j]];
+        if (A.accumulate)
+            A.y[j] += A.alpha * sum;
+        else
+            A.y[j] = hmx_is_zero(A.beta) ? A.alpha * sum : A.alpha * sum + A.beta * A.y[j];
+    }
+}
+
+// a'[dst] = sum_i W[list[lp + i] + k]: the partial column sums of a mirrored low-rank leaf that spans several row ranges, one list
+// entry (position of the leaf's column group in EW) per range
+struct CombineListArgs {
+    const int32_t *dst, *lp, *count, *k, *list;
+    scalar *W;
+    int n;
+};
+__global__ void combine_list_kernel(CombineListArgs A) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n)
+        return;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    scalar s = scalar(0);
+    for (int i = 0; i < cnt; i++)
+        s += A.W[l[i] + k];
+    A.W[A.dst[e]] = s;
+}
+__global__ __launch_bounds__(256) void combine_list_wave_kernel(CombineListArgs A) {
+    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (e >= A.n)
+        return;
+    const int lane   = threadIdx.x & 63;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    scalar s = scalar(0);
+    for (int i = lane; i < cnt; i += 64)
+        s += A.W[l[i] + k];
+    s = wave_sum_dpp(s);
+    if (lane == 0)
+        A.W[A.dst[e]] = s;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Several right-hand sides on the stored data: partial sums live in SW16 = [slot][SWW] (the slots of the single-vector product, SWW
+// coefficients each: 16 real or 8 complex right-hand sides per sweep -- 128 resp. 64 bytes per slot in single, twice that in double precision).
+// ---------------------------------------------------------------------------------------------
+constexpr int SWW = HMX_COMPLEX ? 8 : 16;
+// a'[dst][0..SWW) = sum_i SW16[list[lp + i] + k][0..SWW): the partial column sums of a mirrored low-rank leaf that spans several row ranges.
+// One wave per entry for the entries with many partial sums (the first `A.n` entries handed to this kernel): SWW lanes take the right-hand
+// sides, the 64 / SWW lane groups every (64 / SWW)-th partial sum; fixed order
+__global__ __launch_bounds__(256) void combine_list_mu_wave_kernel(CombineListArgs A) {
+    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (e >= A.n)
+        return;
+    constexpr int NG = 64 / SWW;
+    const int lane = threadIdx.x & 63, m = lane % SWW, g = lane / SWW;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    scalar s0 = scalar(0), s1 = scalar(0);
+    int i = g;
+    for (; i + NG < cnt; i += 2 * NG) { // two loads in flight per lane
+        s0 += A.W[(int64_t)(l[i] + k) * SWW + m];
+        s1 += A.W[(int64_t)(l[i + NG] + k) * SWW + m];
+    }
+    if (i < cnt)
+        s0 += A.W[(int64_t)(l[i] + k) * SWW + m];
+    scalar s = s0 + s1;
+#pragma unroll
+    for (int o = SWW; o < 64; o <<= 1)
+        s += hmx_shfl_xor(s, o);
+    if (g == 0)
+        A.W[(int64_t)A.dst[e] * SWW + m] = s;
+}
+// ... one thread per (entry, right-hand side) for the rest
+__global__ void combine_list_mu_kernel(CombineListArgs A) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = (int)(id / SWW), m = (int)(id % SWW);
+    if (e >= A.n)
+        return;
+    const int32_t *l = A.list + A.lp[e];
+    const int cnt = A.count[e], k = A.k[e];
+    // four independent sums keep four (index, value) load pairs in flight; fixed order
+    scalar s0 = scalar(0), s1 = scalar(0), s2 = scalar(0), s3 = scalar(0);
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+        const int32_t l0 = l[i], l1 = l[i + 1], l2 = l[i + 2], l3 = l[i + 3];
+        s0 += A.W[(int64_t)(l0 + k) * SWW + m];
+        s1 += A.W[(int64_t)(l1 + k) * SWW + m];
+        s2 += A.W[(int64_t)(l2 + k) * SWW + m];
+        s3 += A.W[(int64_t)(l3 + k) * SWW + m];
+    }
+    for (; i < cnt; i++)
+        s0 += A.W[(int64_t)(l[i] + k) * SWW + m];
+    A.W[(int64_t)A.dst[e] * SWW + m] = (s0 + s1) + (s2 + s3);
+}
+
+// The fused symmetric / Hermitian product (expand_sym_kernel, rowsym_kernel) for MU right-hand sides at a time on the VALU: what complex
+// coefficients run on the stored triangle and, with every leaf mirrored and nothing applied forward (FWD = false), in the transposed product on
+// the stored data (the reference: the mirror pass of hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:100-106,160-170 with the complex
+// symm / hemm leaf products of matrix/linalg/add_matrix_matrix_product_row_major.hpp:113-139).  Same sweeps, same slots, same fixed order as for
+// one vector; per column of the E-streams MU forward FMAs and MU column sums (reduce8 per right-hand side), per row of the R-streams MU row
+// sums.  The streams are read once for the whole group where the fallback before round 5 ran one single-vector product per right-hand side.
+template <int WAVES, int MU, bool FWD = true>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mu_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
+    const ExpandArgs &A = S.X;
+    __shared__ scalar part[FWD ? WAVES : 1][FWD ? WAVE : 1][FWD ? MU : 1];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    const bool active   = lane < len;
+    const int row       = active ? lane : 0;
+    const bool herm     = S.herm != 0;
+    scalar xr[MU], acc[MU]; // the input at this lane's row (idle lanes and missing right-hand sides: exact zeros), the forward sums
+#pragma unroll
+    for (int j = 0; j < MU; j++) {
+        xr[j]  = (active && j < nrhs) ? S.xrow[(int64_t)(A.range_off[R] + lane) * mu + cbase + j] : scalar(0);
+        acc[j] = scalar(0);
+    }
+    constexpr int GS = 8;
+    auto load_group = [&](scalar(&v)[GS], int c0, int j) { // always eight loads, no branches: see expand_sym_kernel
+        const int last    = C - c0 - j - 1; // >= 0
+        const scalar *col = E + (int64_t)(c0 + j) * len + row;
+#pragma unroll
+        for (int u = 0; u < GS; u++)
+            v[u] = stream_load(col + (int64_t)(u < last ? u : last) * len);
+    };
+    auto advance = [&](int &c0, int &j) {
+        j += GS;
+        if (j >= 64 || c0 + j >= C) {
+            c0 += WAVES * 64;
+            j = 0;
+        }
+    };
+    scalar z[MU], mine[MU];
+#pragma unroll
+    for (int j = 0; j < MU; j++)
+        z[j] = mine[j] = scalar(0);
+    int md = -1, nc = 0;
+    bool mir = false;
+    auto tile_setup = [&](int c0) {
+        nc = (C - c0) < 64 ? (C - c0) : 64;
+        if constexpr (FWD) {
+            const scalar *zr = expand_operand(A, zidx[c0 + (lane < nc ? lane : 0)], mu) + cbase;
+#pragma unroll
+            for (int j = 0; j < MU; j++)
+                z[j] = (lane < nc && j < nrhs) ? zr[j < nrhs ? j : 0] : scalar(0);
+        }
+        md  = lane < nc ? mdst[c0 + lane] : -1;
+        mir = __any(md >= 0);
+    };
+    auto process = [&](const scalar(&v)[GS], int jg) {
+        if constexpr (FWD)
+#pragma unroll
+            for (int u = 0; u < GS; u++)
+#pragma unroll
+                for (int j = 0; j < MU; j++)
+                    acc[j] = hmx_fma(v[u], readlane_val(z[j], (jg + u) & 63), acc[j]);
+        if (mir && jg < nc) {
+#pragma unroll
+            for (int j = 0; j < MU; j++) {
+                scalar p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    p[u] = (herm ? hmx_conj(v[u]) : v[u]) * xr[j];
+                const scalar r = reduce8(p, lane); // lane 8 s + g of lane group s = lane >> 3 keeps the sum of column jg + s: see expand_sym_kernel
+                mine[j]        = hmx_select((lane & 7) == (jg >> 3), r, mine[j]);
+            }
+            if (jg + 8 >= nc) {
+#pragma unroll
+                for (int j = 0; j < MU; j++) {
+                    const scalar t = hmx_shfl(mine[j], 8 * (lane & 7) + (lane >> 3)); // the sum of column c in lane c
+                    if (md >= 0 && j < nrhs)
+                        S.W[(int64_t)md * SWW + j] = t;
+                }
+            }
+        }
+    };
+    scalar va[GS], vb[GS];
+    int c0 = wv * 64, j = 0;
+    if (c0 < C)
+        load_group(va, c0, 0);
+    while (c0 < C) {
+        int n0 = c0, nj = j;
+        advance(n0, nj);
+        bool more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(vb, more ? n0 : c0, more ? nj : j);
+        process(va, j);
+        if (!more)
+            break;
+        c0 = n0, j = nj;
+        advance(n0, nj);
+        more = n0 < C;
+        if (j == 0)
+            tile_setup(c0);
+        load_group(va, more ? n0 : c0, more ? nj : j);
+        process(vb, j);
+        c0 = n0, j = nj;
+    }
+    if constexpr (FWD) {
+#pragma unroll
+        for (int j = 0; j < MU; j++)
+            part[wv][lane][j] = active ? acc[j] : scalar(0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < len * MU; e += WAVES * WAVE) {
+            const int i = e / MU, jj = e - i * MU;
+            if (jj >= nrhs)
+                continue;
+            scalar s = part[0][i][jj];
+#pragma unroll
+            for (int k = 1; k < WAVES; k++)
+                s += part[k][i][jj];
+            scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + jj;
+            *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+        }
+    }
+}
+
+// second sweep over the R-streams for MU right-hand sides (rowsym_kernel's scheme on intervals of SYM_IR_MU rows: one workgroup per
+// interval, wave w its sub-tasks w, w + WAVES, ..., row sums folded in LDS, the dense mirrored contributions and the y update at the end)
+constexpr int SYM_IR_MU = 64;
+template <int WAVES, int MU>
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSymArgs A, const scalar *W16, int mu, int cbase, int nrhs) {
+    __shared__ scalar acc[WAVES][SYM_IR_MU][MU];
+    const int I    = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int r = lane; r < SYM_IR_MU * MU; r += WAVE)
+        (&acc[wv][0][0])[r] = scalar(0);
+    const bool herm = A.herm != 0;
+    constexpr int GS = 8;
+    for (int64_t q = A.sub_ptr[I] + wv; q < A.sub_ptr[I + 1]; q += WAVES) {
+        const int task = A.sub_task[q], row0 = A.sub_row0[q], len = A.sub_nrows[q];
+        scalar(*dst)[MU] = &acc[wv][A.sub_dst[q]];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        const int wp      = hmx_wp(w);
+        const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * wp;
+        const int64_t cb  = A.range_colbase[S] + ch * cw;
+        const int d0 = col0 < w ? A.coef[cb + col0] : -1, d1 = col1 < w ? A.coef[cb + col1] : -1;
+        scalar c0[MU], c1[MU], mine[MU];
+#pragma unroll
+        for (int j = 0; j < MU; j++) {
+            c0[j]   = (d0 >= 0 && j < nrhs) ? W16[(int64_t)d0 * SWW + j] : scalar(0);
+            c1[j]   = (d1 >= 0 && j < nrhs) ? W16[(int64_t)d1 * SWW + j] : scalar(0);
+            mine[j] = scalar(0);
+        }
+        auto load_rows = [&](scalar2(&e)[GS], int i0) {
+#pragma unroll
+            for (int u = 0; u < GS; u++) {
+                const int i = i0 + u < len ? i0 + u : len - 1;
+                e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
+            }
+        };
+        auto process = [&](const scalar2(&e)[GS], int i0) {
+            if (i0 >= len)
+                return;
+            const int g = (i0 >> 3) & 7;
+#pragma unroll
+            for (int j = 0; j < MU; j++) {
+                scalar v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = herm ? hmx_fma(hmx_conj(e[u].x), c0[j], hmx_conj(e[u].y) * c1[j]) : hmx_fma(e[u].x, c0[j], e[u].y * c1[j]);
+                const scalar r = reduce8(v, lane); // lane 8 s + g keeps the sum of row 64 b + 8 g + s: see rowsym_kernel
+                mine[j]        = hmx_select((lane & 7) == g, r, mine[j]);
+            }
+            if (g == 7 || i0 + 8 >= len) {
+                const int i = (i0 & ~63) + lane;
+#pragma unroll
+                for (int j = 0; j < MU; j++) {
+                    const scalar t = hmx_shfl(mine[j], 8 * (lane & 7) + (lane >> 3));
+                    if (i < len)
+                        dst[i][j] += t; // this wave's slice: no other wave touches it
+                }
+            }
+        };
+        scalar2 ea[GS], eb[GS];
+        load_rows(ea, 0);
+        for (int i0 = 0; i0 < len; i0 += 2 * GS) { // unconditional prefetches (clamped to the last row)
+            load_rows(eb, i0 + GS);
+            process(ea, i0);
+            load_rows(ea, i0 + 2 * GS);
+            process(eb, i0 + GS);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < SYM_IR_MU * MU; e += WAVES * WAVE) {
+        const int r = e / MU, jj = e - r * MU;
+        const int j = I * SYM_IR_MU + r;
+        if (j >= A.n || jj >= nrhs)
+            continue;
+        scalar sum = acc[0][r][jj];
+#pragma unroll
+        for (int k = 1; k < WAVES; k++)
+            sum += acc[k][r][jj];
+        const int cnt = A.count[j];
+        for (int k = 0; k < cnt; k++)
+            sum += W16[(int64_t)A.fidx[(int64_t)k * A.n + j] * SWW + jj];
+        scalar *yo = A.y + (int64_t)j * mu + cbase + jj;
+        if (A.accumulate)
+            *yo += A.alpha * sum;
+        else
+            *yo = hmx_is_zero(A.beta) ? A.alpha * sum : A.alpha * sum + A.beta * (*yo);
+    }
+}
+
+#if !HMX_COMPLEX
+// ---------------------------------------------------------------------------------------------
+// Several right-hand sides on the STORED TRIANGLE (symmetric storage, real coefficients): the fused product above for groups of up to 16
+// right-hand sides on the matrix cores.  The reference runs the mirror pass on the same leaves for any number of right-hand sides
+// (hmatrix/linalg/add_hmatrix_matrix_product_row_major.hpp:100-106,160-170; symm for the diagonal leaves,
+// matrix/linalg/add_matrix_matrix_product_row_major.hpp:87-106); until round 4 such products ran here on an expanded copy of the
+// operator (twice the footprint, twice the traffic).  Three sweeps, as for one vector:
+//   reduce_mfma16s_kernel           a = V X_s over the R-streams (the ordinary multi-RHS reduce stage)
+//   expand_sym_mfma16_kernel        ONE pass over the E-streams: per 64 x 16 stream tile the forward product Y_t += E Z (tile = A operand,
+//                                   rows on the M index) AND the mirrored column sums EW = E^T X_t (the same tile as A operand with its
+//                                   columns on the M index and the rows contracted) -- 16 + 16 MFMAs per tile.  An MFMA contracts over
+//                                   the lane bits 4-5 of both operands, so the two products need the tile in two lane layouts: the
+//                                   forward operands come straight from the registers the loads filled (lane = row) by a 4 x 4
+//                                   transposition between register index and lane quarter (v_permlane32_swap + v_permlane16_swap: no LDS),
+//                                   the mirrored ones from a wave-private LDS copy [row][column] written with 16-byte stores.
+//   combine_list_mu_kernel          a' of the leaves that span several row ranges
+//   rowsym_mfma16_kernel            second pass over the R-streams, Y_s += V^T a': one WAVE owns 64 output rows (accumulators in
+//                                   registers, nothing to fold between waves), stream tiles 16 rows x 64 columns staged through LDS
+//                                   transposed and swizzled so that stores and operand reads both run at two lanes per bank.
+// Partial sums live in SW16 = [slot][16] (the slots of the single-vector product, 16 values each).  Fixed summation order: bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+// FWD = false: the mirrored column sums only (transposed product of an ordinary operator on its stored data, several right-hand sides)
+template <int WAVES, bool FWD = true>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
+    const ExpandArgs &A = S.X;
+#ifndef HMX_SYMMU_PT
+#define HMX_SYMMU_PT 24
+#endif
+    constexpr int PT = HMX_SYMMU_PT; // row pitch of the mirrored tile [64 rows][16 columns]: operand reads (16 columns x 4 rows) at two lanes per bank
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * PT > WAVES * WAVE * 16 ? WAVES * 64 * PT : WAVES * WAVE * 16];
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const real *E       = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4;
+    real *tile    = lds + wv * 64 * PT;
+    const int row = lane < len ? lane : len - 1; // idle lanes re-read the last row: forward, they only reach accumulator rows that are never stored; mirrored, their X_t operand is zero
+    const int mo  = cbase + (m < nrhs ? m : 0); // ragged group: see expand_mfma16s_kernel
+    // B operand of the mirrored product, constant over the range: X_t[row 4h + kk][rhs m] for the 16 k-steps h (zero beyond the range)
+    real xt[16];
+#pragma unroll
+    for (int h = 0; h < 16; h++) {
+        const int r   = 4 * h + kk;
+        const real xv = S.xrow[(int64_t)(A.range_off[R] + (r < len ? r : len - 1)) * mu + mo];
+        xt[h]         = r < len ? xv : real(0);
+    }
+    acc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    // the wave's columns as one sequence of 16-column steps, three stages in flight, every load unconditional: see expand_mfma16s_kernel
+    const int ntile_all = (C + 63) >> 6;
+    int n = 0;
+    if (wv < ntile_all) {
+        n = 4 * ((ntile_all - 1 - wv) / WAVES + 1);
+        if ((ntile_all - 1 - wv) % WAVES == 0)
+            n -= 4 - ((C - 64 * (ntile_all - 1) + 15) >> 4);
+    }
+    auto col_of = [&](int s) { return (((s >> 2) * WAVES + wv) << 6) + ((s & 3) << 4); };
+    struct Idx {
+        int z, md; // lane l: Z index and mirror slot of column col_of(s) + (l & 15)
+    };
+    auto load_idx = [&](int s) {
+        const int c  = col_of(s < n ? s : n - 1) + m;
+        const int cc = c < C ? c : C - 1;
+        Idx ix;
+        ix.z  = FWD ? zidx[cc] : 0;
+        ix.md = mdst[cc];
+        return ix;
+    };
+    auto gathers = [&](real(&b)[4], const Idx &ix) {
+        if constexpr (FWD)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int zc = __shfl(ix.z, 4 * g + kk, WAVE);
+                b[g]         = expand_operand(A, zc, mu)[mo];
+            }
+    };
+    auto load_cols = [&](real(&v)[16], int s) { // 16 whole columns, clamped to the range's last one (zero operand there, sums never stored)
+        const int c = col_of(s < n ? s : n - 1);
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int col = c + u < C ? c + u : C - 1;
+            v[u]          = stream_load(E + (int64_t)col * len + row);
+        }
+    };
+    // one step = 16 columns: mirrored column sums (if any of the 16 is a mirrored column), then the forward product
+    auto apply = [&](real(&v)[16], const real(&braw)[4], int mdi, int s) {
+        const int c  = col_of(s);
+        const int md = (c + m < C) ? mdi : -1;
+        if (__any(md >= 0)) { // wave-uniform: steps without mirrored columns (diagonal leaves, the other ranks' columns of a row-partitioned operator) skip all of it
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                tile[lane * PT + u] = v[u]; // 16 consecutive elements per lane: 16-byte stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            real ta[16];
+#pragma unroll
+            for (int h = 0; h < 16; h++)
+                ta[h] = tile[(4 * h + kk) * PT + m];
+            acc4 am = acc4{0, 0, 0, 0};
+#pragma unroll
+            for (int h = 0; h < 16; h++)
+                am = mfma16(ta[h], xt[h], am); // A[m = column][k = row 4h + kk], B[k][n = rhs]
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int d = __shfl(md, mfma16_row(real(0), lane, j), WAVE);
+                if (d >= 0)
+                    S.W[(int64_t)d * 16 + m] = am[j];
+            }
+        }
+        // forward: a[g][t] (row 16 t + m, column 4 g + kk) = register 4 g + kk of lane quarter t -- a 4 x 4 transposition per column group
+        if constexpr (FWD) {
+            real b[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                b[g] = (c + 4 * g + kk < C) ? braw[g] : real(0);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                lane_swap32(v[4 * g + 0], v[4 * g + 2]);
+                lane_swap32(v[4 * g + 1], v[4 * g + 3]);
+                lane_swap16(v[4 * g + 0], v[4 * g + 1]);
+                lane_swap16(v[4 * g + 2], v[4 * g + 3]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[t] = mfma16(v[4 * g + t], b[g], acc[t]);
+        }
+    };
+    if (n > 0) {
+        real v0[16], v1[16], b0[4], b1[4];
+        Idx i0 = load_idx(0), i1 = load_idx(1);
+        gathers(b0, i0);
+        load_cols(v0, 0);
+        HMX_SCHED_FENCE();
+        for (int s = 0; s < n; s += 2) {
+            const int md0 = i0.md;
+            i0 = load_idx(s + 2);
+            gathers(b1, i1);
+            load_cols(v1, s + 1);
+            HMX_SCHED_FENCE();
+            apply(v0, b0, md0, s);
+            HMX_SCHED_FENCE();
+            const int md1 = i1.md;
+            i1 = load_idx(s + 3);
+            gathers(b0, i0);
+            load_cols(v0, s + 2);
+            HMX_SCHED_FENCE();
+            if (s + 1 < n)
+                apply(v1, b1, md1, s + 1);
+            HMX_SCHED_FENCE();
+        }
+    }
+    if constexpr (!FWD)
+        return;
+    // forward result: the waves' accumulators folded through LDS as in expand_mfma16s_kernel
+    real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 16; e += WAVES * WAVE) {
+        const int i = e >> 4, c = e & 15;
+        if (c >= nrhs)
+            continue;
+        real s = red[0][i][c];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++)
+            s += red[w][i][c];
+        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
+    }
+}
+
+// Second pass over the R-streams for up to 16 right-hand sides.  Interval = 64 output rows = one wave; its sub-tasks are the parts of the
+// (source piece, column chunk) tasks whose rows lie in the interval.  Per sub-task and half of the chunk's (<= 128) columns: the B operands
+// a'[column][rhs] of the 16 k-steps are gathered once, then every 16-row tile of the interval the sub-task touches is loaded (whole rows: two
+// rows of 64 columns per wave-wide load), staged transposed in LDS and multiplied -- 16 MFMAs per 16 x 64 tile; rows of the tile that are
+// not the sub-task's are dropped when the tile's result is added to the interval's accumulators.
+struct RowSymMuArgs {
+    RowSymArgs A;         // (sub_* / order refer to the 64-row intervals)
+    const scalar *W16;    // [slot][16]
+    int zero_slot;        // a slot whose 16 values are zero
+    int nint;
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_mfma16_kernel(RowSymMuArgs P, int mu, int cbase, int nrhs) {
+    const RowSymArgs &A = P.A;
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * 16];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos = blockIdx.x * WAVES + wv;
+    if (pos >= P.nint)
+        return; // (no workgroup barrier below: the waves are independent)
+    const int I  = A.order[pos];
+    const int m = lane & 15, kk = lane >> 4;
+    // [64 columns][16 rows], element (row i, column c) at 16 (c ^ ((c >> 1) & 1)) + (i ^ ((c >> 1) & 15)): the stores of a load's two
+    // rows x 64 columns and the operand reads of 16 rows x 4 columns both touch every bank exactly twice
+    real *tile = lds + wv * 64 * 16;
+    acc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    const int lrow = lane >> 5, lc = 2 * (lane & 31); // loads: lane = (row parity, column pair) of a 2-row x 64-column slab
+    // what a sub-task needs, fetched one sub-task ahead: the chain sub-task -> task -> range -> geometry is a dozen dependent loads
+    struct Sub {
+        const real *src;
+        int w, wp, n, dst;
+        int32_t dlo, dhi; // slots of a' for the chunk's columns lane and 64 + lane (-1: not a mirrored leaf's column / beyond the chunk)
+    };
+    auto fetch = [&](int64_t q) {
+        Sub s;
+        const int task = A.sub_task[q], row0 = A.sub_row0[q];
+        s.n   = A.sub_nrows[q];
+        s.dst = A.sub_dst[q];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        s.w   = w;
+        s.wp  = hmx_wp(w);
+        s.src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * s.wp;
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        const int32_t a = A.coef[cb + (lane < w ? lane : 0)], b = A.coef[cb + (64 + lane < w ? 64 + lane : 0)];
+        s.dlo = lane < w ? a : -1;
+        s.dhi = 64 + lane < w ? b : -1;
+        return s;
+    };
+    // a tile = 16 interval rows x 64 columns of one sub-task: rows clamped into the sub-task's (the others are dropped when the result is added)
+    auto load_tile = [&](scalar2(&v)[8], const Sub &s, int c0, int t) {
+        const int cl = c0 + lc < s.wp ? c0 + lc : 0; // lanes beyond the chunk re-read its first pair (their operand is zero)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int r = 16 * t + 2 * u + lrow - s.dst;
+            r     = r < 0 ? 0 : (r >= s.n ? s.n - 1 : r);
+            v[u]  = stream_load(reinterpret_cast<const scalar2 *>(s.src + (int64_t)r * s.wp + cl));
+        }
+    };
+    // B operands of a segment (sub-task, 64-column half): a'[column c0 + 4 h + kk][rhs m]; columns beyond the chunk and columns that are
+    // no mirrored leaf's read a zero slot
+    auto gather_b = [&](real(&b)[16], const Sub &s, int c0) {
+#pragma unroll
+        for (int h = 0; h < 16; h++) {
+            const int d = __shfl(c0 ? s.dhi : s.dlo, 4 * h + kk, WAVE);
+            b[h]        = P.W16[(int64_t)(d >= 0 ? d : P.zero_slot) * 16 + m];
+        }
+    };
+    const int64_t q0 = A.sub_ptr[I], q1 = A.sub_ptr[I + 1];
+    Sub cur{};
+    if (q0 < q1)
+        cur = fetch(q0);
+    // one tile: staged transposed in LDS, 16 MFMAs, rows that are not the sub-task's dropped when the result joins the accumulators
+    auto tile_product = [&](const scalar2(&v)[8], const real(&b)[16], const Sub &s, int t) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = 2 * u + lrow, sw = lane & 15, fl = lane & 1; // (c >> 1) & 15 and (c >> 1) & 1 of both columns lc, lc + 1
+            tile[16 * (lc ^ fl) + (i ^ sw)]       = v[u].x;
+            tile[16 * ((lc + 1) ^ fl) + (i ^ sw)] = v[u].y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        real ta[16];
+#pragma unroll
+        for (int h = 0; h < 16; h++) {
+            const int c = 4 * h + kk;
+            ta[h]       = tile[16 * (c ^ ((c >> 1) & 1)) + (m ^ ((c >> 1) & 15))];
+        }
+        acc4 tm = acc4{0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 16; h++)
+            tm = mfma16(ta[h], b[h], tm); // A[m = row][k = column c], B[k][n = rhs]
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i    = 16 * t + mfma16_row(real(0), lane, j);
+            const real add = (i >= s.dst && i < s.dst + s.n) ? tm[j] : real(0);
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++)
+                if (tt == t)
+                    acc[tt][j] += add;
+        }
+    };
+    for (int64_t q = q0; q < q1; q++) {
+        const Sub nxt = fetch(q + 1 < q1 ? q + 1 : q);
+        const int t_lo = cur.dst >> 4, t_hi = (cur.dst + cur.n - 1) >> 4;
+        for (int c0 = 0; c0 < cur.w; c0 += 64) {
+            real b[16];
+            gather_b(b, cur, c0);
+            // two tile buffers used in turn (no register copies: a copy waits for the load it copies), the next tile's loads always issued --
+            // clamped to the segment's last tile -- before the current tile is worked on
+            scalar2 va[8], vb[8];
+            load_tile(va, cur, c0, t_lo);
+            for (int t = t_lo; t <= t_hi; t += 2) {
+                load_tile(vb, cur, c0, t + 1 <= t_hi ? t + 1 : t_hi);
+                HMX_SCHED_FENCE();
+                tile_product(va, b, cur, t);
+                HMX_SCHED_FENCE();
+                load_tile(va, cur, c0, t + 2 <= t_hi ? t + 2 : t_hi);
+                HMX_SCHED_FENCE();
+                if (t + 1 <= t_hi)
+                    tile_product(vb, b, cur, t + 1);
+                HMX_SCHED_FENCE();
+            }
+        }
+        cur = nxt;
+    }
+    // dense mirrored contributions of the interval's rows (column sums the first pass left in SW16, found through the level index), y update.
+    // A lane holds 16 rows (one right-hand side each): level k of all sixteen is fetched together -- sixteen independent chains of two
+    // loads per level instead of one (the levels of a row are few, but every one is two dependent trips to memory)
+    int jr[16], cn[16], kmax = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int jrow = I * SYM_IR_MU + 16 * t + mfma16_row(real(0), lane, j);
+            jr[4 * t + j]  = jrow < A.n ? jrow : A.n - 1;
+            cn[4 * t + j]  = jrow < A.n ? A.count[jr[4 * t + j]] : 0;
+            kmax           = cn[4 * t + j] > kmax ? cn[4 * t + j] : kmax;
+        }
+    // the sixteen y values of the lane are fetched NOW, together, unconditionally (rows beyond the operator read its last row, right-hand sides
+    // beyond the group the group's first): with the load inside each row's own `if (row exists) y = ...` the compiler emitted load -> wait ->
+    // store sixteen times in a row, sixteen trips to memory one after the other at the end of every interval (round 5, read off the ISA)
+    const bool need_y = A.accumulate || !(A.beta == real(0));
+    const int mcol    = cbase + (m < nrhs ? m : 0);
+    real yv[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        yv[e] = need_y ? A.y[(int64_t)jr[e] * mu + mcol] : real(0);
+    for (int k = 0; k < kmax; k++) {
+        int32_t d[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            d[e] = A.fidx[(int64_t)(k < cn[e] ? k : 0) * A.n + jr[e]]; // (level 0 of the row when it has fewer: a valid entry, dropped below)
+        real w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = P.W16[(int64_t)(k < cn[e] ? d[e] : P.zero_slot) * 16 + m];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            acc[e >> 2][e & 3] += w[e];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int jrow = I * SYM_IR_MU + 16 * t + mfma16_row(real(0), lane, j);
+            const real y0  = yv[4 * t + j];
+            const real out = A.accumulate ? y0 + A.alpha * acc[t][j] : (A.beta == real(0) ? A.alpha * acc[t][j] : A.alpha * acc[t][j] + A.beta * y0);
+            if (jrow < A.n && m < nrhs)
+                A.y[(int64_t)jrow * mu + cbase + m] = out;
+        }
+}
+
+#endif // !HMX_COMPLEX

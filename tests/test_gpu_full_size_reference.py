@@ -56,13 +56,35 @@ def test_full_size_matches_the_reference(name):
     diff = tab[:, 4].astype(np.int64) - ref_ranks
     ndiff = int(np.count_nonzero(diff))
     print("%s: %d leaves, %d ranks differ from the reference (max |diff| %d)" % (name, len(tab), ndiff, int(np.abs(diff).max())))
-    # the stopping test sums in another order than BLAS dot, so a rank could move by one when the estimate lands
-    # within rounding of epsilon.  fp64: not a single leaf may differ; fp32 (24-bit estimates): at most a handful, by one.
-    # fp32 at eps = 1e-6 is another matter: the estimate sqrt(aux / frob) is itself only good to a few 1e-7 in 24-bit arithmetic, so
-    # the iteration at which it first drops below eps depends on rounding (MKL's sdot vs the kernel's tree sums): ranks scatter by a
-    # few around the reference's, both operators approximate the same matrix to eps.
+    # fp64 (and complex double): the stopping test sums in another order than BLAS dot, so a rank could move by one when the estimate lands
+    # within rounding of epsilon -- it never does: not a single leaf may differ.
+    # fp32 at eps = 1e-6 (configs[4]) is another matter, and the criterion is on the APPROXIMATION, not on a fitted rank distance.  After q
+    # rank-1 updates in 24-bit arithmetic a residual entry carries rounding noise of about q u |A| (u = 2^-24), i.e. q u / eps ~ 1 relative to
+    # a residual that has decayed to eps |A|: the stopping test sqrt(aux / frob) <= eps runs at the noise floor of the arithmetic, and the
+    # iteration at which it first dips below eps is decided by rounding -- in htool (MKL sdot) as here (tree sums).  What must hold instead:
+    #   (a) where the ranks differ, the device's factors truncated to the SMALLER of the two ranks already meet the accuracy target up to the
+    #       estimator's own slack (ACA's estimate bounds the last correction, not the remaining error: a few eps) -- the extra iterations of
+    #       either side are noise-floor iterations, no accuracy is lost or gained (tools/f32_rank_study.py: median 1.0 eps, largest 4.6 eps);
+    #   (b) no bias: the sums of all ranks agree to 0.5 % (observed 0.04 %);
+    #   (c) the distance decays geometrically, as a stopping time at a noise floor does (observed ratio 0.3 per step: 69 / 25 / 5 / 1 %
+    #       at distance 1 / 2 / 3 / >= 4): at most a tenth of the differing leaves beyond distance 2, none beyond 12 (p < 1e-6 per leaf).
     if f32:
-        assert np.abs(diff).max() <= 7 and abs(float(diff.sum())) <= 0.02 * float(ref_ranks[ref_ranks > 0].sum())  # 7: the largest scatter observed on any fixture (README)
+        ad = np.abs(diff)
+        assert abs(float(diff.sum())) <= 0.005 * float(ref_ranks[ref_ranks > 0].sum())
+        assert ndiff == 0 or (float((ad >= 3).sum()) <= 0.10 * ndiff and ad.max() <= 12), np.bincount(ad)
+        cand = [i for i in np.nonzero(diff)[0] if int(tab[i, 1]) * int(tab[i, 3]) <= 2000000]
+        pick = np.random.default_rng(0).choice(cand, size=min(40, len(cand)), replace=False) if cand else []
+        perm = np.asarray(T.get_permutation())
+        xs = x.reshape(n, 3)
+        worst = 0.0
+        for i, (U, V) in zip(pick, H.get_blocks(pick) if len(pick) else []):
+            t0, m, s0, nn = (int(v) for v in tab[i, :4])
+            P, Q = xs[perm[t0:t0 + m]], xs[perm[s0:s0 + nn]]
+            A = 1.0 / (1e-5 + np.sqrt(((P[:, None, :] - Q[None, :, :]) ** 2).sum(-1)))
+            r = int(min(tab[i, 4], ref_ranks[i]))
+            worst = max(worst, float(np.linalg.norm(A - U[:, :r].astype(np.float64) @ V[:r, :].astype(np.float64)) / np.linalg.norm(A)))
+        print("%s: true relative error of the device's blocks truncated to min(rank, reference rank) on %d differing leaves: at most %.2e (eps %g)" % (name, len(pick), worst, p["eps"]))
+        assert worst <= 8 * p["eps"], worst
     else:
         assert ndiff == 0
     rows = g["rows"]

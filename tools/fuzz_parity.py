@@ -102,8 +102,11 @@ while time.time() - t0 < budget:
         assert np.array_equal(H2.leaf_table(), lt), ("reload: structure / ranks", cfg)
         os.remove(path)
         H = H2
+    no_view = os.environ.get("HMX_TRANS_STREAMS") == "0"
     if os.environ.get("FUZZ_RELEASE") and rng.random() < 0.5:  # only the streams remain
-        H.release_factors(bool(rng.integers(0, 2)))
+        with_t = bool(rng.integers(0, 2))
+        H.release_factors(with_t)
+        no_view = no_view or not with_t
     single = prec in ("f32", "c32")
     if not single:
         assert np.array_equal(lt[:, 4], Ho.leaves[:, 4]), ("ranks", cfg, int((lt[:, 4] != Ho.leaves[:, 4]).sum()))
@@ -113,6 +116,16 @@ while time.time() - t0 < budget:
         tol = max(tol, 30 * eps)
     alpha, beta = (1.5 - 0.5j, 0.25 + 1j) if cplx else (1.5, 0.25)
     transes = ["N"] + (["T"] if sym != "H" else []) + (["C"] if cplx and sym != "S" else [])
+    if sym != "N" and rank >= 0 and parts > 1 and no_view and bool(np.asarray(lt)[:, 5].any()):  # (column 5: the leaf is in leaves_for_symmetry)
+        # a row-restricted symmetric / Hermitian operator (mirrored leaves among ordinary ones) multiplies transposed on its transposed VIEW only;
+        # with the view forbidden or impossible (factors released without it) the product is an error, not a slow path
+        for trans in transes[1:]:
+            try:
+                hm.internal_add_hmatrix_vector_product(trans, alpha, H, np.zeros(nr, dtype=dt), beta, np.zeros(nc, dtype=dt))
+                raise AssertionError(("transposed product without its view did not fail", trans, cfg))
+            except hm.HmxError as e:
+                assert "transposed stream layout" in str(e), (str(e), cfg)
+        transes = ["N"]
     for trans in transes:
         nin, nout = (nc, nr) if trans == "N" else (nr, nc)
         xin = (rng.standard_normal(nin) + (1j * rng.standard_normal(nin) if cplx else 0)).astype(dt)
