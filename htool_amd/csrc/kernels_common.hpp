@@ -323,6 +323,22 @@ template <> struct Acc4<float> { typedef hmx_f4 type; };
 // counts loads in the order they were issued: a gather the compiler sinks behind the next step's stream loads turns every wait for it into a
 // drain of the whole queue)
 #define HMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// occupancy hints of the matrix-core kernels (waves per SIMD the register allocator must make room for); empty: the compiler's choice.
+// Set per build for A/B runs: tools/variant.sh <name> "-DHMX_WPE_EXPAND_MFMA16S_KERNEL=__attribute__((amdgpu_waves_per_eu(3)))"
+#ifndef HMX_WPE_EXPAND_MFMA16S_KERNEL
+// fp64: 172 registers by the compiler's own choice = 2 waves per SIMD; asked for 3 (<= 168 registers, no scratch) the expand stage of 16 fp64
+// right-hand sides takes 2.04 instead of 2.35 ms on the same box (round 5).  4-byte coefficients need ~100 registers either way.
+#define HMX_WPE_EXPAND_MFMA16S_KERNEL __attribute__((amdgpu_waves_per_eu(3)))
+#endif
+#ifndef HMX_WPE_REDUCE_MFMA16S_KERNEL
+#define HMX_WPE_REDUCE_MFMA16S_KERNEL
+#endif
+#ifndef HMX_WPE_EXPAND_SYM_MFMA16_KERNEL
+#define HMX_WPE_EXPAND_SYM_MFMA16_KERNEL
+#endif
+#ifndef HMX_WPE_ROWSYM_MFMA16_KERNEL
+#define HMX_WPE_ROWSYM_MFMA16_KERNEL
+#endif
 __device__ __forceinline__ hmx_d4 mfma16(double a, double b, hmx_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ hmx_f4 mfma16(float a, float b, hmx_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int mfma16_row(double, int lane, int reg) { return (lane >> 4) + 4 * reg; }

@@ -353,7 +353,7 @@ typedef Acc4<real>::type acc4;
 // 64 x 16 tile goes through a wave-private LDS buffer (80-element column pitch: the operand reads 16 rows x 4 columns are free of bank
 // conflicts) to reach the lanes in operand layout.  LDS traffic is 16 bytes per streamed 8, a quarter of the pipe.
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void expand_mfma16s_kernel(ExpandArgs A, int mu, int cbase, int nrhs) {
+__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_MFMA16S_KERNEL void expand_mfma16s_kernel(ExpandArgs A, int mu, int cbase, int nrhs) {
     constexpr int PITCH = 80; // 64 rows + 16: consecutive tile columns are 32 banks apart, so the 64-bit operand reads (16 rows x 4 columns) do not conflict
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 16 * PITCH > WAVES * WAVE * 16 ? WAVES * 16 * PITCH : WAVES * WAVE * 16]; // (HMX_EXPAND_PERMLANE: only the final fold of the waves uses it)
     const int R = A.order[blockIdx.x];
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(WAVES *WAVE) __attribute__((amdgpu_waves_per_eu(2))
 // with the next eight in flight, and the 8 x 128 tile reaches the lanes in operand layout through a wave-private LDS buffer
 // (144-element row pitch: rows 32 banks apart).
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void reduce_mfma16s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
+__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_REDUCE_MFMA16S_KERNEL void reduce_mfma16s_kernel(ReduceArgs A, int mu, int cbase, int nrhs) {
     // Rows per wave-wide load: a chunk of <= 64 (<= 32) columns puts 2 (4) consecutive rows into one load instruction -- the chunk is a
     // contiguous row-major block, lane l reads the column pair 2 (l mod LPR) of row l / LPR -- instead of leaving half (three quarters) of
     // the lanes idle; a step is then 16 (32) rows and 4 (8) k-steps over 4 (2) column tiles: the same 16 MFMAs per 8 loads.  On one

@@ -645,7 +645,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSymArgs A, co
 // ---------------------------------------------------------------------------------------------
 // FWD = false: the mirrored column sums only (transposed product of an ordinary operator on its stored data, several right-hand sides)
 template <int WAVES, bool FWD = true>
-__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mfma16_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
+__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void expand_sym_mfma16_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
     const ExpandArgs &A = S.X;
 #ifndef HMX_SYMMU_PT
 #define HMX_SYMMU_PT 24
@@ -816,7 +816,7 @@ struct RowSymMuArgs {
     int nint;
 };
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void rowsym_mfma16_kernel(RowSymMuArgs P, int mu, int cbase, int nrhs) {
+__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_ROWSYM_MFMA16_KERNEL void rowsym_mfma16_kernel(RowSymMuArgs P, int mu, int cbase, int nrhs) {
     const RowSymArgs &A = P.A;
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * 16];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
