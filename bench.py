@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--callback-threads", type=int, default=0, help="host threads that call the generator (0: all cores, at most 64)")
     ap.add_argument("--no-callback-build", action="store_true", help="do not time a second build of the operator through the host-generator route")
     ap.add_argument("--no-reference", action="store_true", help="skip the timing of htool itself (oracle/_ref/ref_driver) on the host cores")
+    ap.add_argument("--option", action="append", default=[], help="engine option name=value for the operator (hmx_hmatrix_set_option; htool_amd._lib.OPTIONS), e.g. sym_multi_rhs=1")
     ap.add_argument("--dump-product", default=None, help="after the timed region: y = A x for x = the oracle's hashed_vector(n, 1), through the step's own path; rank 0 writes "
                     "y (partition numbering) and the cluster permutation to this .npz (tests compare it with the reference's fixtures)")
     return ap.parse_args()
@@ -417,6 +418,8 @@ def main():
     d = minimal_depth(n)
     tb.set_minimal_target_depth(d)
     tb.set_minimal_source_depth(d)
+    for kv in args.option:
+        tb.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     cplx = args.dtype in ("z64", "c32")
     t_init = time.time()
     hm.lib().hmx_device_init(local_rank)  # HIP context + load of libhmx's code object: not part of an operator build
@@ -625,6 +628,8 @@ def main():
                    algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
                    build_s=dict(geometry=t_geom, cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"],
                                 **{k: round(v, 4) for k, v in getattr(H, "_build_walltimes", {}).items()}))
+        if args.option:
+            cfg["options"] = list(args.option)
         if use_dist:  # a SCALE record explains itself: how many ranks the communicator really has, which exchange ran, what each variant cost
             cfg.update(rccl_ranks=dist_info.get("rccl_ranks"), communicator=dist_info.get("communicator"), dist_impl=dist_info.get("impl"),
                        exchange_variant=dist_info.get("exchange_variant", "all-gather after the product"), exchange_trials_ms=dist_info.get("exchange_trials_ms"),
@@ -664,10 +669,13 @@ def main():
         flag_dev = dev if backend == "nccl" else "cpu"
         out = Yg if mu > 1 else y
         ref = torch.zeros_like(out)
-        if mu > 1:
-            D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, ref, mu)
-        else:
-            D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, ref)
+        def torch_reference():
+            if mu > 1:
+                D.internal_add_distributed_operator_matrix_product_row_major_global_to_global("N", 1.0, A, Xmu, 0.0, ref, mu)
+            else:
+                D.internal_add_distributed_operator_vector_product_global_to_global("N", 1.0, A, xin, 0.0, ref)
+            torch.cuda.synchronize()
+        guarded("reference product of the torch.distributed layer", torch_reference)
 
         def reproduces():
             out.zero_()

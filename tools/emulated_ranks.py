@@ -4,7 +4,7 @@
 (`bench.py --emulate-world 8 --emulate-rank k`: builds and times exactly what rank k of the 8-GPU run holds, no exchange), next to the
 whole operator on one GPU.  What it yields is a PREDICTION of the local part of an 8-GPU step -- the slowest rank bounds it -- and of the
 parallel efficiency before the output exchange; the pool has no 8-GPU node, so this is the only scaling evidence it can produce.
-    python3 tools/emulated_ranks.py > gpurun_out/r4_emulated_ranks.json"""
+    python3 tools/emulated_ranks.py > gpurun_out/r5_emulated_ranks.json"""
 import json
 import os
 import subprocess

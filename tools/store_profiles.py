@@ -1,5 +1,6 @@
-"""Copies what tools/collect_profiles.sh left under gpurun_out/{r4_n1e6,r4_sym,r4_mu16,r4_transT} into profiles/ (tracked) and rewrites profiles/traffic.json
-with the sha256 of the kernel sources the counters were measured on.  Run in the dev container right after the gpurun call."""
+"""Copies what tools/collect_profiles.sh left under gpurun_out/{rN_n1e6,rN_sym,rN_mu16,rN_transT,...} into profiles/ (tracked) and rewrites
+profiles/traffic.json with the sha256 of the kernel sources the counters were measured on.  Run in the dev container right after the gpurun call:
+    python3 tools/store_profiles.py r5"""
 import json
 import os
 import shutil
@@ -10,7 +11,9 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 os.chdir(ROOT)
-for tag, name in (("r4_n1e6", "r4_bench_n1e6"), ("r4_sym", "r4_bench_n1e6_sym"), ("r4_mu16", "r4_bench_n1e6_mu16"), ("r4_transT", "r4_bench_n1e6_transT")):
+RN = sys.argv[1] if len(sys.argv) > 1 else "r5"
+EXTRA = [(RN + "_sym_mu16_stored", RN + "_bench_n1e6_sym_mu16_stored_triangle"), (RN + "_sym_mu16_view", RN + "_bench_n1e6_sym_mu16_expanded_view"), (RN + "_c5_rank3", RN + "_bench_c5_rank3of8")]
+for tag, name in [(RN + "_n1e6", RN + "_bench_n1e6"), (RN + "_sym", RN + "_bench_n1e6_sym"), (RN + "_mu16", RN + "_bench_n1e6_mu16"), (RN + "_transT", RN + "_bench_n1e6_transT")] + [e for e in EXTRA if os.path.isdir("gpurun_out/" + e[0])]:
     d = "gpurun_out/" + tag
     shutil.copy(d + "/kernel_stats.csv", "profiles/%s_kernel_stats.csv" % name)
     shutil.copy(d + "/under_rocprof.json", "profiles/%s_under_rocprof.json" % name)
@@ -24,9 +27,9 @@ for tag, name in (("r4_n1e6", "r4_bench_n1e6"), ("r4_sym", "r4_bench_n1e6_sym"),
         summ[k] = dict(FETCH_SIZE_KB_mean=fs.get("mean"), fetch_bytes_x2=2 * 1024 * fs["mean"] if fs else None, WRITE_SIZE_KB_mean=ws.get("mean"),
                        write_bytes=1024 * ws["mean"] if ws else None, launches=fs.get("n"))
     json.dump(summ, open("profiles/%s_pmc_summary.json" % name, "w"), indent=1, sort_keys=True)
-n, s = json.load(open("profiles/r4_bench_n1e6_pmc_summary.json")), json.load(open("profiles/r4_bench_n1e6_sym_pmc_summary.json"))
-m16 = json.load(open("profiles/r4_bench_n1e6_mu16_pmc_summary.json"))
-tT = json.load(open("profiles/r4_bench_n1e6_transT_pmc_summary.json"))
+n, s = json.load(open("profiles/%s_bench_n1e6_pmc_summary.json" % RN)), json.load(open("profiles/%s_bench_n1e6_sym_pmc_summary.json" % RN))
+m16 = json.load(open("profiles/%s_bench_n1e6_mu16_pmc_summary.json" % RN))
+tT = json.load(open("profiles/%s_bench_n1e6_transT_pmc_summary.json" % RN))
 
 
 def tot(x):
@@ -37,7 +40,7 @@ def pick(d, sub):
     return next(v for k, v in d.items() if sub in k)
 
 
-rec = dict(round=4, kernel_sources_sha256=bench.kernel_sources_hash(),
+rec = dict(round=int(RN[1:]), kernel_sources_sha256=bench.kernel_sources_hash(),
            workload="bench.py N=1e6 ellipse eps=1e-4 (1 GPU): default (partialACA, 'N') and --sym S (sympartialACA, 'S','L', compact storage, fused product)",
            method="rocprofv3 --kernel-trace --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE (tools/collect_profiles.sh, tools/pmc_summary.py); values in KB; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM): in the same runs the 8 GiB read16_kernel reports 4.194e6 KB = 1/2 of 8 GiB; WRITE_SIZE exact",
