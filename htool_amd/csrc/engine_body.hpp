@@ -1535,6 +1535,12 @@ static bool sym_mu_fused(const HMat &H) {
         return false;
     if (mode > 0)
         return true;
+#if HMX_COMPLEX
+    // complex coefficients: the stored triangle is as fast as the view (N = 1e6 Hermitian complex double, 8 right-hand sides: 17.0 ms on 54.8 GB
+    // against 18.2 ms on 54.8 + 108.5 GB; complex symmetric 6.4 against 6.6 ms) -- the mirrored product packs both planes of 8 columns into one
+    // MFMA per k-step -- so nothing is built unless it is asked for
+    return true;
+#endif
     if (H.X_op)
         return false;
     if (H.X_op_failed || H.factors_released || H.opt.i(HMX_OPT_SYM_NO_VIEW) != 0)
@@ -1567,14 +1573,22 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
         else                                                                                                  \
             hipLaunchKernelGGL((expand_sym_mu_kernel<W, MU, false>), grid, wg, 0, st, XS, mu, c, nrhs);       \
     } while (0)
-        if (nrhs <= 2)
-            HMX_SYM_MU_E(2);
-        else if (nrhs <= 4)
-            HMX_SYM_MU_E(4);
-        else
-            HMX_SYM_MU_E(8);
+        if (H.opt.i(HMX_OPT_MATRIX_CORES) != 0) { // groups of up to 8 on the matrix cores (ragged groups: operands nobody stores the results of)
+            if (fwd)
+                hipLaunchKernelGGL((expand_sym_zmfma8_kernel<W, true>), grid, wg, 0, st, XS, mu, c, nrhs);
+            else
+                hipLaunchKernelGGL((expand_sym_zmfma8_kernel<W, false>), grid, wg, 0, st, XS, mu, c, nrhs);
+            prof_mark(H, st, fwd ? "expand_sym_zmfma8_kernel" : "expand_colsum_zmfma8_kernel");
+        } else {
+            if (nrhs <= 2)
+                HMX_SYM_MU_E(2);
+            else if (nrhs <= 4)
+                HMX_SYM_MU_E(4);
+            else
+                HMX_SYM_MU_E(8);
+            prof_mark(H, st, fwd ? "expand_sym_mu_kernel" : "expand_colsum_mu_kernel");
+        }
 #undef HMX_SYM_MU_E
-        prof_mark(H, st, fwd ? "expand_sym_mu_kernel" : "expand_colsum_mu_kernel");
 #else
         if (fwd)
             hipLaunchKernelGGL((expand_sym_mfma16_kernel<W, true>), grid, wg, 0, st, XS, mu, c, nrhs);
@@ -1601,13 +1615,18 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
                       H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, nout, herm, beta, accumulate};
 #if HMX_COMPLEX
         const dim3 grid((unsigned)H.s64_nint), wg(W * 64);
-        if (nrhs <= 2)
+        if (H.opt.i(HMX_OPT_MATRIX_CORES) != 0) {
+            RowSymZArgs PZ{RS, reinterpret_cast<const real *>(H.SW16.d), (int)H.s_slots, H.s64_nint};
+            hipLaunchKernelGGL((rowsym_zmfma8_kernel<W>), dim3((unsigned)((H.s64_nint + W - 1) / W)), wg, 0, st, PZ, mu, c, nrhs);
+            prof_mark(H, st, "rowsym_zmfma8_kernel");
+        } else if (nrhs <= 2)
             hipLaunchKernelGGL((rowsym_mu_kernel<W, 2>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
         else if (nrhs <= 4)
             hipLaunchKernelGGL((rowsym_mu_kernel<W, 4>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
         else
             hipLaunchKernelGGL((rowsym_mu_kernel<W, 8>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
-        prof_mark(H, st, "rowsym_mu_kernel");
+        if (H.opt.i(HMX_OPT_MATRIX_CORES) == 0)
+            prof_mark(H, st, "rowsym_mu_kernel");
 #else
         RowSymMuArgs P{RS, H.SW16.d, (int)H.s_slots, H.s64_nint};
 #ifndef HMX_ROWSYM_WAVES

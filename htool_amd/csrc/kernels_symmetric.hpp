@@ -622,6 +622,410 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSymArgs A, co
     }
 }
 
+#if HMX_COMPLEX
+// ---------------------------------------------------------------------------------------------
+// Groups of 8 COMPLEX right-hand sides on the stored data on the MATRIX CORES (round 5; the VALU kernels above are what every group width
+// falls back to when HMX_OPT_MATRIX_CORES is 0).  Planes as in expand_zmfma8s_kernel: a row of 8 complex operands is 16 reals
+// (re0, im0, re1, im1, ...), n = 2 rhs + part is the MFMA's free index,
+//     forward   Y[row][n]  = sum_col  E_re[row][col] Z[col][n]  + E_im[row][col] Z'[col][n],       Z'[n] = n even ? -Z[n + 1] : Z[n - 1]
+//     mirrored  EW[col][n] = sum_row  E_re[row][col] X[row][n] +- E_im[row][col] X'[row][n]        (-: Hermitian storage, conj(E))
+// The mirrored product packs BOTH planes of 8 columns into the M index of ONE 16 x 16 x 4 MFMA (M < 8: re of column M, M >= 8: im of column
+// M - 8) against the operand X alone: D[M < 8] = E_re^T X, D[M >= 8] = E_im^T X, and E_im^T X' is D[M >= 8] with neighbouring n exchanged and
+// the even ones negated -- a lane exchange AFTER the 16 k-steps instead of a second MFMA per k-step.  One wave-private LDS tile
+// [64 rows][8 re | 8 im] (pitch 20 reals) serves both products: read down the rows for the mirrored operand, across the columns for the forward one.
+// ---------------------------------------------------------------------------------------------
+typedef Acc4<real>::type zsacc4;
+// the packed result of the mirrored / row product: tm = D of the M-packed MFMA.  Returns nval values val[k] with their M index idx[k] (< 8)
+// -- P1[idx][n] + s P2[idx][n'] -- valid in the lanes `ok` says (all lanes for 8-byte reals: register j and j + 2 of one lane are M and M + 8;
+// the lower two lane quarters for 4-byte reals: M + 8 sits 32 lanes up)
+__device__ __forceinline__ int zpack_combine(const zsacc4 &tm, int lane, bool conj, real (&val)[4], int (&idx)[4], bool &ok) {
+    if constexpr (sizeof(real) == 8) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const real o  = hmx_shfl_xor(tm[j + 2], 1);
+            const real sw = (lane & 1) ? o : -o;
+            val[j]        = conj ? tm[j] - sw : tm[j] + sw;
+            idx[j]        = (lane >> 4) + 4 * j;
+        }
+        ok = true;
+        return 2;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const real o  = hmx_shfl(tm[j], ((lane ^ 1) + 32) & 63);
+            const real sw = (lane & 1) ? o : -o;
+            val[j]        = conj ? tm[j] - sw : tm[j] + sw;
+            idx[j]        = 4 * ((lane >> 4) & 1) + j;
+        }
+        ok = lane < 32;
+        return 4;
+    }
+}
+
+template <int WAVES, bool FWD = true>
+__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_zmfma8_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
+    const ExpandArgs &A = S.X;
+    constexpr int P = 20, STEP = 8; // tile pitch in reals: conflict-free (8-byte reals) / two lanes per bank (4-byte) for both read directions
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * P];
+    static_assert(64 * P >= WAVE * 16, "the final fold of the waves reuses the tiles");
+    const int R = A.order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int len = A.range_len[R], C = A.range_cols[R];
+    const scalar *E     = A.stream + A.range_base[R];
+    const int32_t *zidx = A.z_idx + A.range_colbase[R];
+    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    const int m = lane & 15, kk = lane >> 4;
+    real *tile     = lds + wv * 64 * P;
+    real *W16r     = reinterpret_cast<real *>(S.W); // [slot][16 reals = 8 complex right-hand sides]
+    const int row  = lane < len ? lane : len - 1;
+    const int mo   = m < 2 * nrhs ? m : 0; // ragged group: see expand_mfma16s_kernel
+    const bool herm = S.herm != 0;
+    // B operand of the mirrored product, constant over the range: X_t[row 4h + kk] as 16 reals, element n = m (zero beyond the range)
+    real xt[16];
+#pragma unroll
+    for (int h = 0; h < 16; h++) {
+        const int r   = 4 * h + kk;
+        const real xv = reinterpret_cast<const real *>(S.xrow + (int64_t)(A.range_off[R] + (r < len ? r : len - 1)) * mu + cbase)[mo];
+        xt[h]         = r < len ? xv : real(0);
+    }
+    zsacc4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = zsacc4{0, 0, 0, 0};
+    // the wave's columns as one sequence of 8-column steps, three stages in flight, every load unconditional: see expand_mfma16s_kernel
+    const int ntile_all = (C + 63) >> 6;
+    int n = 0;
+    if (wv < ntile_all) {
+        n = 8 * ((ntile_all - 1 - wv) / WAVES + 1);
+        if ((ntile_all - 1 - wv) % WAVES == 0)
+            n -= 8 - ((C - 64 * (ntile_all - 1) + 7) >> 3);
+    }
+    auto col_of = [&](int s) { return (((s >> 3) * WAVES + wv) << 6) + ((s & 7) << 3); };
+    struct Idx {
+        int z, md; // lane l: Z index and mirror slot of column col_of(s) + (l & 7)
+    };
+    auto load_idx = [&](int s) {
+        const int c  = col_of(s < n ? s : n - 1) + (lane & 7);
+        const int cc = c < C ? c : C - 1;
+        Idx ix;
+        ix.z  = FWD ? zidx[cc] : 0;
+        ix.md = mdst[cc];
+        return ix;
+    };
+    auto gathers = [&](real(&b)[2], const Idx &ix) {
+        if constexpr (FWD)
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int zc = __shfl(ix.z, 4 * g + kk, WAVE);
+                b[g]         = reinterpret_cast<const real *>(expand_operand(A, zc, mu) + cbase)[mo];
+            }
+    };
+    auto load_cols = [&](scalar(&v)[STEP], int s) {
+        const int c = col_of(s < n ? s : n - 1);
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            const int col = c + u < C ? c + u : C - 1;
+            v[u]          = stream_load(E + (int64_t)col * len + row);
+        }
+    };
+    auto apply = [&](const scalar(&v)[STEP], const real(&braw)[2], int mdi, int s) {
+        const int c = col_of(s);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < STEP; u++) {
+            tile[lane * P + u]     = v[u].re;
+            tile[lane * P + 8 + u] = v[u].im;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int md = (c + (lane & 7) < C) ? mdi : -1;
+        if (__any(md >= 0)) { // wave-uniform: steps without mirrored columns skip all of it
+            real ta[16];
+#pragma unroll
+            for (int h = 0; h < 16; h++)
+                ta[h] = tile[(4 * h + kk) * P + m]; // A[M = m][k = row 4h + kk]: m < 8 re of column m, m >= 8 im of column m - 8
+            zsacc4 tm = zsacc4{0, 0, 0, 0};
+#pragma unroll
+            for (int h = 0; h < 16; h++)
+                tm = mfma16(ta[h], xt[h], tm);
+            real val[4];
+            int idx[4];
+            bool ok;
+            const int nv = zpack_combine(tm, lane, herm, val, idx, ok);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < nv) {
+                    const int d = __shfl(md, idx[k], WAVE); // slot of column c + idx[k]
+                    if (ok && d >= 0)
+                        W16r[(int64_t)d * 16 + m] = val[k];
+                }
+        }
+        if constexpr (FWD) {
+            real b[2], bs[2];
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                b[g]  = (c + 4 * g + kk < C) ? braw[g] : real(0);
+                bs[g] = zmfma_swapped(b[g], lane);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                real are[4], aim[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    are[t] = tile[(16 * t + m) * P + 4 * g + kk];
+                    aim[t] = tile[(16 * t + m) * P + 8 + 4 * g + kk];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    acc[t] = mfma16(are[t], b[g], acc[t]);
+                    acc[t] = mfma16(aim[t], bs[g], acc[t]);
+                }
+            }
+        }
+    };
+    if (n > 0) {
+        scalar v0[STEP], v1[STEP];
+        real b0[2], b1[2];
+        Idx i0 = load_idx(0), i1 = load_idx(1);
+        gathers(b0, i0);
+        load_cols(v0, 0);
+        HMX_SCHED_FENCE();
+        for (int s = 0; s < n; s += 2) {
+            const int md0 = i0.md;
+            i0 = load_idx(s + 2);
+            gathers(b1, i1);
+            load_cols(v1, s + 1);
+            HMX_SCHED_FENCE();
+            apply(v0, b0, md0, s);
+            HMX_SCHED_FENCE();
+            const int md1 = i1.md;
+            i1 = load_idx(s + 3);
+            gathers(b0, i0);
+            load_cols(v0, s + 2);
+            HMX_SCHED_FENCE();
+            if (s + 1 < n)
+                apply(v1, b1, md1, s + 1);
+            HMX_SCHED_FENCE();
+        }
+    }
+    if constexpr (!FWD)
+        return;
+    // forward result: accumulator tile t, register j of lane l = (row 16 t + mfma16_row, real column l & 15 = 2 rhs + part), folded over the waves
+    real(*red)[WAVE][16] = reinterpret_cast<real(*)[WAVE][16]>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            red[wv][16 * t + mfma16_row(real(0), lane, j)][m] = acc[t][j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 8; e += WAVES * WAVE) {
+        const int i = e >> 3, c = e & 7;
+        if (c >= nrhs)
+            continue;
+        scalar sum(red[0][i][2 * c], red[0][i][2 * c + 1]);
+#pragma unroll
+        for (int w = 1; w < WAVES; w++)
+            sum += scalar(red[w][i][2 * c], red[w][i][2 * c + 1]);
+        scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        *yo        = hmx_is_zero(A.beta) ? A.alpha * sum : A.alpha * sum + A.beta * (*yo);
+    }
+}
+
+// Second pass over the R-streams for 8 complex right-hand sides: Y_s[row][n] += sum_col op(V[row][col]) a'[col][n], one WAVE per 64 output rows
+// as in rowsym_mfma16_kernel.  Tiles of 8 rows x 64 columns, both planes packed into the M index of one MFMA per k-step (M < 8: re of row M,
+// M >= 8: im of row M - 8; zpack_combine turns D into P1 +- P2'), staged transposed and swizzled in LDS exactly as the real kernel stages its
+// 16-row tiles.  Accumulators hold the combined values of the interval's eight tiles.
+struct RowSymZArgs {
+    RowSymArgs A;      // (sub_* / order refer to the 64-row intervals)
+    const real *W16r;  // [slot][16 reals]
+    int zero_slot;
+    int nint;
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSymZArgs P, int mu, int cbase, int nrhs) {
+    const RowSymArgs &A = P.A;
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * 16];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos = blockIdx.x * WAVES + wv;
+    if (pos >= P.nint)
+        return; // (no workgroup barrier below: the waves are independent)
+    const int I  = A.order[pos];
+    const int m = lane & 15, kk = lane >> 4;
+    const int mo = m < 2 * nrhs ? m : 0;
+    const bool herm = A.herm != 0;
+    real *tile = lds + wv * 64 * 16;
+    auto taddr = [](int c, int i) { return 16 * (c ^ ((c >> 1) & 1)) + (i ^ ((c >> 1) & 15)); }; // element (slot i, column c): see rowsym_mfma16_kernel
+    constexpr int NV = sizeof(real) == 8 ? 2 : 4; // combined values per lane and tile (zpack_combine)
+    real acc[8][NV];
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            acc[t][k] = real(0);
+    struct Sub {
+        const scalar *src;
+        int w, wp, n, dst;
+        int32_t dlo, dhi;
+    };
+    auto fetch = [&](int64_t q) {
+        Sub s;
+        const int task = A.sub_task[q], row0 = A.sub_row0[q];
+        s.n   = A.sub_nrows[q];
+        s.dst = A.sub_dst[q];
+        const int S = A.task_range[task], ch = A.task_chunk[task];
+        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
+        int w = C - ch * cw;
+        w     = w > cw ? cw : w;
+        s.w   = w;
+        s.wp  = hmx_wp(w);
+        s.src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * s.wp;
+        const int64_t cb = A.range_colbase[S] + ch * cw;
+        const int32_t a = A.coef[cb + (lane < w ? lane : 0)], b = A.coef[cb + (64 + lane < w ? 64 + lane : 0)];
+        s.dlo = lane < w ? a : -1;
+        s.dhi = 64 + lane < w ? b : -1;
+        return s;
+    };
+#if HMX_SPLIT_COLS
+    constexpr int NL = 8; // loads per tile: one row x 64 columns (16-byte coefficients) each
+    typedef scalar tile_vec;
+#else
+    constexpr int NL = 4; // two rows x 64 columns (8-byte coefficients, a column pair per lane) each
+    typedef scalar2 tile_vec;
+    const int lrow = lane >> 5, lc = 2 * (lane & 31);
+#endif
+    // tile t8 = interval rows 8 t8 ... 8 t8 + 7, columns c0 ... c0 + 63 of the sub-task's chunk; rows clamped into the sub-task
+    auto load_tile = [&](tile_vec(&v)[NL], const Sub &s, int c0, int t8) {
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+#if HMX_SPLIT_COLS
+            int r = 8 * t8 + u - s.dst;
+            r     = r < 0 ? 0 : (r >= s.n ? s.n - 1 : r);
+            v[u]  = stream_load(s.src + (int64_t)r * s.wp + (c0 + lane < s.wp ? c0 + lane : 0));
+#else
+            int r = 8 * t8 + 2 * u + lrow - s.dst;
+            r     = r < 0 ? 0 : (r >= s.n ? s.n - 1 : r);
+            v[u]  = stream_load(reinterpret_cast<const scalar2 *>(s.src + (int64_t)r * s.wp + (c0 + lc < s.wp ? c0 + lc : 0)));
+#endif
+        }
+    };
+    auto gather_b = [&](real(&b)[16], const Sub &s, int c0) {
+#pragma unroll
+        for (int h = 0; h < 16; h++) {
+            const int d = __shfl(c0 ? s.dhi : s.dlo, 4 * h + kk, WAVE);
+            b[h]        = P.W16r[(int64_t)(d >= 0 ? d : P.zero_slot) * 16 + mo];
+        }
+    };
+    auto tile_product = [&](const tile_vec(&v)[NL], const real(&b)[16], const Sub &s, int t8) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+#if HMX_SPLIT_COLS
+            tile[taddr(lane, u)]     = v[u].re;
+            tile[taddr(lane, 8 + u)] = v[u].im;
+#else
+            const int i = 2 * u + lrow;
+            tile[taddr(lc, i)]         = v[u].x.re;
+            tile[taddr(lc, 8 + i)]     = v[u].x.im;
+            tile[taddr(lc + 1, i)]     = v[u].y.re;
+            tile[taddr(lc + 1, 8 + i)] = v[u].y.im;
+#endif
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        real ta[16];
+#pragma unroll
+        for (int h = 0; h < 16; h++)
+            ta[h] = tile[taddr(4 * h + kk, m)]; // A[M = m][k = column 4h + kk]: m < 8 re of row m, m >= 8 im of row m - 8
+        zsacc4 tm = zsacc4{0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 16; h++)
+            tm = mfma16(ta[h], b[h], tm);
+        real val[4];
+        int idx[4];
+        bool ok;
+        const int nv = zpack_combine(tm, lane, herm, val, idx, ok);
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int i    = 8 * t8 + idx[k < nv ? k : 0];
+            const real add = (ok && i >= s.dst && i < s.dst + s.n) ? val[k] : real(0);
+#pragma unroll
+            for (int tt = 0; tt < 8; tt++)
+                if (tt == t8)
+                    acc[tt][k] += add;
+        }
+    };
+    const int64_t q0 = A.sub_ptr[I], q1 = A.sub_ptr[I + 1];
+    Sub cur{};
+    if (q0 < q1)
+        cur = fetch(q0);
+    for (int64_t q = q0; q < q1; q++) {
+        const Sub nxt = fetch(q + 1 < q1 ? q + 1 : q);
+        const int t_lo = cur.dst >> 3, t_hi = (cur.dst + cur.n - 1) >> 3;
+        for (int c0 = 0; c0 < cur.w; c0 += 64) {
+            real b[16];
+            gather_b(b, cur, c0);
+            tile_vec va[NL], vb[NL];
+            load_tile(va, cur, c0, t_lo);
+            for (int t = t_lo; t <= t_hi; t += 2) {
+                load_tile(vb, cur, c0, t + 1 <= t_hi ? t + 1 : t_hi);
+                HMX_SCHED_FENCE();
+                tile_product(va, b, cur, t);
+                HMX_SCHED_FENCE();
+                load_tile(va, cur, c0, t + 2 <= t_hi ? t + 2 : t_hi);
+                HMX_SCHED_FENCE();
+                if (t + 1 <= t_hi)
+                    tile_product(vb, b, cur, t + 1);
+                HMX_SCHED_FENCE();
+            }
+        }
+        cur = nxt;
+    }
+    // dense mirrored contributions + y update.  A lane holds, per tile, NV values: real column n = m (= 2 rhs + part) of the rows 8 t8 + idx.
+    // The complex factors alpha / beta need both parts of a value: the partner is the neighbouring lane (m ^ 1).
+    const bool lane_ok = sizeof(real) == 8 || lane < 32;
+    const real a_re = A.alpha.re, a_im = (lane & 1) ? A.alpha.im : -A.alpha.im;
+    const real b_re = A.beta.re, b_im = (lane & 1) ? A.beta.im : -A.beta.im;
+    real *yr = reinterpret_cast<real *>(A.y);
+#pragma unroll
+    for (int t8 = 0; t8 < 8; t8++) {
+        int jr[NV], cn[NV], kmax = 0;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int idxk = sizeof(real) == 8 ? (lane >> 4) + 4 * k : 4 * ((lane >> 4) & 1) + k;
+            const int jrow = I * SYM_IR_MU + 8 * t8 + idxk;
+            jr[k]          = jrow < A.n ? jrow : A.n - 1;
+            cn[k]          = (lane_ok && jrow < A.n) ? A.count[jr[k]] : 0;
+            kmax           = cn[k] > kmax ? cn[k] : kmax;
+        }
+        real yv[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            yv[k] = yr[((int64_t)jr[k] * mu + cbase) * 2 + mo];
+        for (int lev = 0; lev < kmax; lev++) {
+            int32_t d[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++)
+                d[k] = A.fidx[(int64_t)(lev < cn[k] ? lev : 0) * A.n + jr[k]];
+#pragma unroll
+            for (int k = 0; k < NV; k++)
+                acc[t8][k] += P.W16r[(int64_t)(lev < cn[k] ? d[k] : P.zero_slot) * 16 + mo];
+        }
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int idxk = sizeof(real) == 8 ? (lane >> 4) + 4 * k : 4 * ((lane >> 4) & 1) + k;
+            const int jrow = I * SYM_IR_MU + 8 * t8 + idxk;
+            const real own = acc[t8][k], oth = hmx_shfl_xor(own, 1);
+            const real av  = a_re * own + a_im * oth; // this lane's part of alpha * value
+            const real yo  = yv[k], yp = hmx_shfl_xor(yo, 1);
+            const real out = A.accumulate ? yo + av : (hmx_is_zero(A.beta) ? av : av + (b_re * yo + b_im * yp));
+            if (lane_ok && jrow < A.n && m < 2 * nrhs)
+                yr[((int64_t)jrow * mu + cbase) * 2 + m] = out;
+        }
+    }
+}
+#endif // HMX_COMPLEX
+
 #if !HMX_COMPLEX
 // ---------------------------------------------------------------------------------------------
 // Several right-hand sides on the STORED TRIANGLE (symmetric storage, real coefficients): the fused product above for groups of up to 16

@@ -234,8 +234,9 @@ typedef enum {
     HMX_OPT_WIDE_SWEEPS       = 15, /* product 1     more than 16 (complex: 8) right-hand sides: sweeps of up to 32 (16)     HMX_MFMA_WIDE        */
     HMX_OPT_SCALAR_OPERANDS   = 16, /* product -1    VALU multi-RHS reduce stage with operands in scalar registers
                                                      (-1: automatic = 4-byte coefficients only)                              HMX_MU_SCALAR        */
-    HMX_OPT_SYM_MULTI_RHS     = 17, /* product -1    several right-hand sides on a square symmetric operator: 1 on the stored
-                                                     triangle, 0 on an expanded view of the operator, -1 automatic           HMX_SYM_MU_FUSED     */
+    HMX_OPT_SYM_MULTI_RHS     = 17, /* product -1    several right-hand sides on a symmetric / Hermitian operator: 1 on the stored
+                                                     triangle, 0 on an expanded view of the operator, -1 automatic (complex: the
+                                                     stored triangle; real: the view while HBM has room for it)             HMX_SYM_MU_FUSED     */
     HMX_OPT_SYM_NO_VIEW       = 18, /* product 0     never build the expanded view                                            HMX_SYM_NO_VIEW      */
     HMX_OPT_TRANSPOSED_LAYOUT = 19, /* product -1    transposed stream layout: -1 for several right-hand sides only (HBM
                                                      permitting), 1 also for single vectors, 0 never (stored data only)      HMX_TRANS_STREAMS    */

@@ -372,8 +372,15 @@ def test_complex_stored_triangle_product_with_several_right_hand_sides(name):
         Y = Y0.copy()
         hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y, mu)
         names = [k for k, _ in H.last_kernel_times()]
-        H.set_profiling(False)
+        assert any("expand_sym_zmfma8" in k for k in names) and any("rowsym_zmfma8" in k for k in names), names  # groups of 8 on the matrix cores
+        H.set_option("matrix_cores", 0)  # ... and the same sweeps on the VALU (groups of 2 / 4 / 8)
+        Yv = Y0.copy()
+        hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Yv, mu)
+        names = [k for k, _ in H.last_kernel_times()]
         assert any("expand_sym_mu" in k for k in names) and any("rowsym_mu" in k for k in names), names
+        H.set_option("matrix_cores", 1)
+        H.set_profiling(False)
+        assert rel_err(Yv, Y) < tol, (mu, rel_err(Yv, Y))
         ref = Y0.copy()
         for c in range(mu):
             y = np.ascontiguousarray(Y0[:, c])

@@ -1,8 +1,15 @@
 #!/bin/bash
-# randomised parity sweeps with the alternative code paths forced through the environment (initial option values of every operator)
-set -x
-HMX_SYM_NO_VIEW=1 python3 tools/fuzz_parity.py 100 31 2>&1 | tail -3
-HMX_SYM_MU_FUSED=1 python3 tools/fuzz_parity.py 80 32 2>&1 | tail -3
-HMX_TRANS_STREAMS=0 python3 tools/fuzz_parity.py 80 33 2>&1 | tail -3
-HMX_SYM_NO_VIEW=1 HMX_TRANS_STREAMS=0 FUZZ_RELEASE=1 python3 tools/fuzz_parity.py 80 34 2>&1 | tail -3
-python3 tools/fuzz_parity.py 80 35 2>&1 | tail -3
+# randomised parity sweeps with the alternative code paths forced through the environment (= the initial option values of every operator)
+# usage: bash tools/fuzz_forced_paths.sh [seconds per sweep]
+T=${1:-80}
+run() { echo "== $*"; env "$@" python3 tools/fuzz_parity.py $T $SEED 2>&1 | tail -2; SEED=$((SEED+1)); }
+SEED=41
+run HMX_SYM_NO_VIEW=1
+run HMX_SYM_MU_FUSED=1
+run HMX_TRANS_STREAMS=0
+run HMX_SYM_NO_VIEW=1 HMX_TRANS_STREAMS=0 FUZZ_RELEASE=1
+run HMX_NO_MFMA=1 HMX_SYM_MU_FUSED=1
+run HMX_SYM_EXPANDED=1 FUZZ_USER=1
+run HMX_POOL_RANK_GUESS=1 FUZZ_ROUNDTRIP=1
+run HMX_SR_MAX=128 HMX_R_TREE_PIECES=0 HMX_SORT_TASKS=0 HMX_REDUCE_WAVES=4 HMX_EXPAND_WAVES=8
+run FUZZ_USER=1 FUZZ_RESERVE_GB=8
