@@ -1694,8 +1694,8 @@ static int run_transposed_fused_mu(HMat &H, const scalar *X, scalar alpha, scala
 
 // trans = 'T' at the speed of trans = 'N': the transposed operator gets its own E-/R-streams (same crosses with the roles of
 // U and V exchanged, dense leaves regenerated / read transposed), built on the first transposed product.  Costs a second
-// copy of the streams in HBM; HMX_TRANS_STREAMS=0, compact symmetric storage or an allocation failure fall back to the
-// in-place passes (colreduce / rowreduce kernels: wave reductions + atomics).
+// copy of the streams in HBM.  nullptr: not possible (HMX_OPT_TRANSPOSED_LAYOUT = 0, factors released, no room) -- the callers then run
+// on the stored data (run_transposed_fused, run_transposed_fused_mu) or, for a row-restricted symmetric operator, report the reason.
 static int build_streams(HMat &H);
 static HMat *ensure_transposed_operator(HMat &H) {
     if (H.T_op)
@@ -3778,8 +3778,9 @@ int api_load(const hmx_block_tree *bt, int device_id, FILE *f, const HmxFileHead
 }
 
 // Give the compression pool (the ACA crosses / uploaded blocks the streams were packed from) back: products only need the
-// streams.  Afterwards low-rank blocks can no longer be downloaded, saved or recompressed, and a transposed product that has not
-// built its layout yet uses the in-place passes.  with_transposed != 0 builds the transposed layout first.
+// streams.  Afterwards low-rank blocks can no longer be downloaded, saved or recompressed, and no second layout can be built any more:
+// transposed products run on the stored data (a row-restricted symmetric operator needs its transposed view: bit 0 of with_transposed
+// builds it first), multi-RHS products of symmetric operators on the stored triangle (bit 1 builds the expanded view first).
 int api_release_factors(HMat *Hp, int with_transposed) {
     if (!Hp || !Hp->finalized) {
         set_error("hmx_hmatrix_release_factors: operator not built");

@@ -324,9 +324,11 @@ int hmx_hmatrix_release_factors(hmx_hmatrix *, int with_transposed);
  * hmatrix/linalg/add_hmatrix_vector_product.hpp:74-81) -- column sums of the E-streams per row range, then an owner-computes sweep over the
  * R-streams; every coefficient is read once, no atomics, bit-reproducible; index tables of about 3 % of the operator are built on first use.
  * Several right-hand sides: fused multi-RHS kernels on a transposed stream layout (a second copy of the streams; needs 1.15 x the operator
- * free in HBM; otherwise the stored-data form for 16 right-hand sides per sweep, 1.5 x slower; complex: one product per right-hand side).  Environment: HMX_TRANS_STREAMS=1 also runs single vectors on the
- * transposed layout (N = 1e6: 2.8 instead of 3.1 ms), =0 never builds it; HMX_TRANS_TABLES=0 falls back to the in-place passes with atomics.
- * Multi-RHS products on compact symmetric storage run on an expanded view when HBM has room for it (otherwise on the stored triangle).
+ * free in HBM), otherwise the same stored-data form for 16 real / 8 complex right-hand sides per sweep on the matrix cores (1.4-1.5 x slower).
+ * HMX_OPT_TRANSPOSED_LAYOUT = 1 also runs single vectors on the transposed layout (N = 1e6: 2.8 instead of 3.1 ms), 0 never builds it.  A
+ * row-restricted symmetric / Hermitian operator (mirrored leaves among ordinary ones) multiplies transposed on its transposed view only:
+ * without it (option 0, no room, factors released without bit 0 of with_transposed) the call fails with HMX_ERR_UNSUPPORTED and says why.
+ * Multi-RHS products on symmetric / Hermitian storage: HMX_OPT_SYM_MULTI_RHS (stored triangle, or an expanded view of the operator).
  * All of these -- plus work vectors and, for the user-numbering front ends, permutation and staging buffers -- are otherwise built inside
  * the FIRST product that needs them.  hmx_hmatrix_prepare(H, trans, mu) builds and allocates NOW everything products with this `trans` and
  * this many right-hand sides (1: the vector products) need; afterwards such products allocate nothing (hmx_device_alloc_count does not
