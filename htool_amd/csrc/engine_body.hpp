@@ -2,6 +2,64 @@
 // underlying real type) and included four times by engine.hip: namespaces hmx::f64, hmx::f32 (scalar = double / float) and
 // hmx::z64, hmx::c32 (scalar = cplx<double> / cplx<float>, HMX_COMPLEX = 1).  No include guard on purpose.
 
+#ifndef HMX_ROWSYM_WAVES
+#define HMX_ROWSYM_WAVES 4 // intervals (= waves) per workgroup of rowsym_mfma16_kernel
+#endif
+// Launch order that keeps the tasks of one UNIT (tasks that gather the same operand rows: the row ranges of a few hundred consecutive
+// rows, the chunks of the pieces over the same rows of x) on one XCD, one after the other, so that a unit's operand rows are fetched from
+// HBM once and then found in that XCD's L2.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one: observed, used for
+// speed only -- MI355X_MICROARCH.md, Workgroup dispatch); `per_group` consecutive launch positions belong to one workgroup.  Units are dealt
+// heaviest first, round-robin over the eight lists, each list exactly as long as the number of positions of its label (a unit that does not
+// fit is continued on the next list with room).  With several right-hand sides an operand row is 16 values: without this the multi-RHS
+// kernels fetched 19-45 % more than their streams (profiles/r5_*_pmc_summary.json).
+static std::vector<int32_t> xcd_deal(const std::vector<int64_t> &unit, const std::vector<int64_t> &weight, int per_group) {
+    const int64_t n = (int64_t)unit.size();
+    std::vector<int32_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return unit[a] < unit[b]; }); // tasks of a unit adjacent, in their given order
+    struct U {
+        int64_t first, count, w;
+    };
+    std::vector<U> units;
+    for (int64_t i = 0; i < n;) {
+        int64_t j = i, w = 0;
+        while (j < n && unit[idx[j]] == unit[idx[i]])
+            w += weight[idx[j++]];
+        units.push_back({i, j - i, w});
+        i = j;
+    }
+    std::stable_sort(units.begin(), units.end(), [](const U &a, const U &b) { return a.w > b.w; });
+    constexpr int X = 8;
+    const int64_t ngroups = (n + per_group - 1) / per_group;
+    int64_t cap[X] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t g = 0; g < ngroups; g++)
+        cap[g % X] += std::min<int64_t>(per_group, n - g * per_group);
+    std::vector<int32_t> list[X];
+    int cursor = 0;
+    for (const U &u : units) {
+        int64_t done = 0;
+        while (done < u.count) {
+            while ((int64_t)list[cursor].size() >= cap[cursor])
+                cursor = (cursor + 1) % X;
+            const int64_t take = std::min<int64_t>(u.count - done, cap[cursor] - (int64_t)list[cursor].size());
+            for (int64_t k = 0; k < take; k++)
+                list[cursor].push_back(idx[u.first + done + k]);
+            done += take;
+            if (done < u.count)
+                cursor = (cursor + 1) % X;
+        }
+        cursor = (cursor + 1) % X;
+    }
+    std::vector<int32_t> order(n);
+    int64_t used[X] = {0, 0, 0, 0, 0, 0, 0, 0}, p = 0;
+    for (int64_t g = 0; g < ngroups; g++) {
+        const int x = (int)(g % X);
+        for (int64_t k = 0; k < per_group && p < n; k++)
+            order[p++] = list[x][used[x]++];
+    }
+    return order;
+}
+
 struct StreamSet {
     std::vector<int32_t> off, len, cols, cw; // per range: local offset, rows, columns, chunk width (R only)
     std::vector<int64_t> base, colbase;  // per range: first element in `stream`, first entry in index arrays
@@ -291,7 +349,7 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     }
     // the sub-task lists of the intervals of IR rows (launch order of the tasks = order inside every interval's list), heaviest interval first
     auto build_intervals = [&](int IR, std::vector<int64_t> &sub_ptr, std::vector<int32_t> &sub_task, std::vector<int32_t> &sub_row0, std::vector<int32_t> &sub_nrows,
-                               std::vector<int32_t> &sub_dst, std::vector<int32_t> &int_order) -> int {
+                               std::vector<int32_t> &sub_dst, std::vector<int32_t> &int_order, int per_group) -> int {
         const int nint = (nOut + IR - 1) / IR;
         std::vector<int64_t> sub_count(nint + 1, 0);
         for (size_t t = 0; t < ntask; t++) {
@@ -329,16 +387,25 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
         }
         int_order.resize(nint);
         std::iota(int_order.begin(), int_order.end(), 0);
-        std::stable_sort(int_order.begin(), int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
+        if (H.opt.i(HMX_OPT_TASK_ORDER) == 3) { // intervals over the same rows gather the same a' (see xcd_deal)
+            const int unit_rows = std::max(IR, H.opt.i(HMX_OPT_XCD_UNIT_ROWS));
+            std::vector<int64_t> unit(nint), wk(nint);
+            for (int I = 0; I < nint; I++) {
+                unit[I] = (int64_t)I * IR / unit_rows;
+                wk[I]   = (int64_t)int_work[I];
+            }
+            int_order = xcd_deal(unit, wk, per_group);
+        } else
+            std::stable_sort(int_order.begin(), int_order.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
         return nint;
     };
     int nint = 0;
     if (!bad)
-        nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order);
+        nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order, 1);
     // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows; rowsym_mu_kernel: one workgroup)
     H.s64_nint = 0;
     if (!bad)
-        H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64);
+        H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64, HMX_ROWSYM_WAVES); // (a wave per interval in rowsym_mfma16_kernel)
     phase_nosync("  sym: tasks");
     // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
     for (size_t p = 0; p < ed_b.size() && !bad; p++) {
@@ -802,9 +869,19 @@ static int build_streams(HMat &H) {
     E.task_range.resize(E.nranges());
     std::iota(E.task_range.begin(), E.task_range.end(), 0);
     // launch order: heaviest first (shorter tail); HMX_SORT_TASKS=2: heaviest first only across power-of-two weight classes,
-    // address order inside a class (neighbouring workgroups stream neighbouring memory)
+    // address order inside a class (neighbouring workgroups stream neighbouring memory); 3: heaviest UNIT first, a unit = the tasks of
+    // `xcd_unit_rows` consecutive rows (they gather the same operand rows), kept on one XCD one after the other (xcd_deal)
     const int sort_mode = H.opt.i(HMX_OPT_TASK_ORDER);
+    const int unit_rows = std::max(1, H.opt.i(HMX_OPT_XCD_UNIT_ROWS));
     auto weight_class = [](int64_t w) { int c = 0; while (w > 1) { w >>= 1; c++; } return c; };
+    if (sort_mode == 3) {
+        std::vector<int64_t> unit(E.nranges()), wk(E.nranges());
+        for (int r = 0; r < E.nranges(); r++) {
+            unit[r] = E.off[r] / unit_rows;
+            wk[r]   = (int64_t)E.len[r] * E.cols[r];
+        }
+        E.task_range = xcd_deal(unit, wk, 1);
+    }
     if (sort_mode == 1 || sort_mode == 2) {
         std::vector<int64_t> wk(E.nranges());
         for (int r = 0; r < E.nranges(); r++)
@@ -859,7 +936,14 @@ static int build_streams(HMat &H) {
         std::vector<int64_t> wk(ord.size()); // the key once per task, not once per comparison
         for (size_t t = 0; t < ord.size(); t++)
             wk[t] = sort_mode == 2 ? (int64_t)weight_class(work((int)t)) : work((int)t);
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return wk[a] > wk[b]; });
+        if (sort_mode == 3) { // unit = the pieces (of every level of the source tree) over the same `xcd_unit_rows` rows of x
+            std::vector<int64_t> unit(ord.size());
+            for (size_t t = 0; t < ord.size(); t++)
+                unit[t] = R.off[R.task_range[t]] / unit_rows;
+            const std::vector<int32_t> o = xcd_deal(unit, wk, 1);
+            ord.assign(o.begin(), o.end());
+        } else
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return wk[a] > wk[b]; });
         std::vector<int32_t> tr(ord.size()), tc(ord.size());
         for (size_t k = 0; k < ord.size(); k++) {
             tr[k] = R.task_range[ord[k]];
@@ -1629,9 +1713,6 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
             prof_mark(H, st, "rowsym_mu_kernel");
 #else
         RowSymMuArgs P{RS, H.SW16.d, (int)H.s_slots, H.s64_nint};
-#ifndef HMX_ROWSYM_WAVES
-#define HMX_ROWSYM_WAVES 4
-#endif
         constexpr int RWV = HMX_ROWSYM_WAVES; // intervals (= waves) per workgroup
         hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
         prof_mark(H, st, "rowsym_mfma16_kernel");

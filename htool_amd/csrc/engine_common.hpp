@@ -381,7 +381,8 @@ static const OptionSpec HMX_OPTION_SPECS[] = {
     {HMX_OPT_R_PIECE_ROWS, "HMX_SR_MAX", false, 512, 64, 1 << 20, OPT_LAYOUT},
     {HMX_OPT_R_TREE_PIECES, "HMX_R_TREE_PIECES", false, 1, 0, 1, OPT_LAYOUT},
     {HMX_OPT_LAYOUT_THREADS, "HMX_LAYOUT_THREADS", false, 0, 0, 1024, OPT_LAYOUT},
-    {HMX_OPT_TASK_ORDER, "HMX_SORT_TASKS", false, 1, 0, 2, OPT_LAYOUT},
+    {HMX_OPT_TASK_ORDER, "HMX_SORT_TASKS", false, 1, 0, 3, OPT_LAYOUT},
+    {HMX_OPT_XCD_UNIT_ROWS, "HMX_XCD_UNIT_ROWS", false, 512, 64, 1 << 20, OPT_LAYOUT},
     {HMX_OPT_SYM_STORAGE, "HMX_SYM_EXPANDED", false, 0, 0, 1, OPT_LAYOUT},
     {HMX_OPT_BUILD_TIMING, "HMX_BUILD_TIMING", false, 0, 0, 1, OPT_BUILD},
     {HMX_OPT_REDUCE_WAVES, "HMX_REDUCE_WAVES", false, 0, 0, 8, OPT_PRODUCT},

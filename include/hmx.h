@@ -219,7 +219,10 @@ typedef enum {
     HMX_OPT_R_PIECE_ROWS      = 1,  /* layout  512   rows per R-stream piece (>= 64)                                         HMX_SR_MAX           */
     HMX_OPT_R_TREE_PIECES     = 2,  /* layout  1     pieces of large source clusters follow the cluster tree (0: fixed steps) HMX_R_TREE_PIECES    */
     HMX_OPT_LAYOUT_THREADS    = 3,  /* layout  0     host threads of the pair-list construction (0: automatic, <= 16)        HMX_LAYOUT_THREADS   */
-    HMX_OPT_TASK_ORDER        = 4,  /* layout  1     launch order: 1 heaviest first, 0 address order, 2 weight classes       HMX_SORT_TASKS       */
+    HMX_OPT_TASK_ORDER        = 4,  /* layout  1     launch order: 1 heaviest first, 0 address order, 2 weight classes,
+                                                     3 heaviest unit first, a unit's tasks kept on one XCD (they gather the
+                                                     same operand rows: found in that XCD's L2 after the first fetch)        HMX_SORT_TASKS       */
+    HMX_OPT_XCD_UNIT_ROWS     = 7,  /* layout  512   rows per unit of launch order 3 (>= 64)                                 HMX_XCD_UNIT_ROWS    */
     HMX_OPT_SYM_STORAGE       = 5,  /* layout  0     symmetric / Hermitian operators: 0 stored triangle + fused product,
                                                      1 mirrored leaves laid out explicitly (twice the memory)                HMX_SYM_EXPANDED     */
     HMX_OPT_BUILD_TIMING      = 6,  /* build   0     per-phase build times on stderr                                         HMX_BUILD_TIMING     */

@@ -734,6 +734,31 @@ def test_workgroup_teams_build_the_same_operator(name, monkeypatch):
     test_matvec_matches_reference(name)
 
 
+@pytest.mark.parametrize("unit_rows", [64, 512])
+@pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_p2_symU_rank1", "rect_ball1500_disk1000", "ellipse_n4000_p4_rank2"])
+def test_xcd_grouped_launch_order(name, unit_rows, monkeypatch):
+    """Launch order 3 (tasks that gather the same operand rows kept on one XCD, one after the other: a pure permutation of the launch
+    positions of every sweep -- E ranges, R tasks, the intervals of the symmetric second sweep): the same operator, the same products, for
+    one vector and several right-hand sides, on the stored triangle and on the expanded view."""
+    monkeypatch.setattr(sys.modules[__name__], "ENGINE_OPTIONS", dict(task_order=3, xcd_unit_rows=unit_rows))
+    test_matvec_matches_reference(name)
+    p = params(name)
+    H1, H3 = build_engine(p, options=dict(task_order=1))[2], build_engine(p)[2]
+    assert H3.get_option("task_order") == 3 and np.array_equal(H1.leaf_table(), H3.leaf_table())
+    from oracle.oracle import hashed_vector
+    nr, nc = H1.nb_rows(), H1.nb_cols()
+    for mu, sym_multi_rhs in ((16, 0), (16, 1), (5, 1)):
+        X = hashed_vector(nc * mu, 11).reshape(nc, mu)
+        Y1, Y3 = np.zeros((nr, mu)), np.zeros((nr, mu))
+        for H, Y in ((H1, Y1), (H3, Y3)):
+            H.set_option("sym_multi_rhs", sym_multi_rhs)
+            hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, X, 0.0, Y, mu)
+        if p["sym"] == "N":
+            assert np.array_equal(Y1, Y3)  # fixed summation order inside every task: the launch order changes no bit
+        else:  # the second sweep of the symmetric product adds an interval's sub-tasks in task order: same sums, another order
+            assert rel_err(Y3, Y1) < 1e-13
+
+
 def test_trans_c_for_real_coefficients():
     """For real coefficients the conjugate transpose is the transpose (BLAS 'C'); like the reference, 'C' on symmetric
     ('S') leaves is refused (add_hmatrix_vector_product.hpp:59-62)."""

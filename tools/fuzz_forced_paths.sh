@@ -13,3 +13,4 @@ run HMX_SYM_EXPANDED=1 FUZZ_USER=1
 run HMX_POOL_RANK_GUESS=1 FUZZ_ROUNDTRIP=1
 run HMX_SR_MAX=128 HMX_R_TREE_PIECES=0 HMX_SORT_TASKS=0 HMX_REDUCE_WAVES=4 HMX_EXPAND_WAVES=8
 run FUZZ_USER=1 FUZZ_RESERVE_GB=8
+run HMX_SORT_TASKS=3 HMX_XCD_UNIT_ROWS=128 HMX_SYM_MU_FUSED=1

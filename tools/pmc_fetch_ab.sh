@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: HBM fetch bytes per kernel (PMC FETCH_SIZE, its own rocprofv3 run) of one bench command under several option settings
+#   usage: bash tools/pmc_fetch_ab.sh "<bench flags>" "<option=value>" ["<option=value>" ...]
+export TMPDIR=/tmp
+FLAGS=$1; shift
+for O in "$@"; do
+  D=/tmp/pmc_ab_$$_${O//[^a-z0-9]/_}
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $FLAGS --option $O > /dev/null 2> $D.err
+  echo "== $FLAGS | $O"
+  python3 tools/pmc_summary.py $D --json | python3 -c "
+import json,sys
+d=json.load(sys.stdin)
+for k,v in d.items():
+    if 'read16' in k or 'copy16' in k: continue
+    print('   %-52s fetch %.2f GB (n=%d)'%(k[:52], v['FETCH_SIZE']['mean']*1024*2/1e9, v['FETCH_SIZE']['n']))  # KB -> bytes, x2: the guide's gfx950 correction
+"
+  rm -rf $D
+done
