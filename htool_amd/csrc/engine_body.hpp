@@ -2658,6 +2658,8 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
         A.st_q = st_q.d; A.st_I1 = st_I1.d; A.st_I2 = st_I2.d; A.st_frob = st_frob.d; A.st_aux = st_aux.d;
         return A;
     };
+    // blocks with both sides <= wave_max points are compressed by one wave each (aca_wave_kernel), the others by one workgroup each
+    const int wave_max = (!assembled && !use_cb) ? std::min(H.opt.i(HMX_OPT_ACA_WAVE_MAX), 64 * ACA_WAVE_KR) : 0;
     // Pool sizing from a SAMPLE of the blocks.  The a-priori rank guess has to be pessimistic (it decides whether the
     // compression must be repeated) and is 3-4 times the ranks smooth kernels really give; large allocations cost
     // seconds on some boxes (tools/malloc_timing.hip) and the pool competes with the streams for HBM.  So every K-th
@@ -2686,7 +2688,10 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             bool overflow = false;
             for (int32_t b : sample) {
                 overflow = overflow || r[b] == -2;
-                used_s += (double)std::max(r[b], 1) * (double)(H.leaves[b].t_size + H.leaves[b].s_size); // failed blocks still take one cross
+                int crosses = std::max(r[b], 1); // failed blocks still take one cross
+                if (std::max(H.leaves[b].t_size, H.leaves[b].s_size) <= wave_max) // aca_wave_kernel takes its pool space ACA_WAVE_CHUNK crosses at a time
+                    crosses = (crosses + ACA_WAVE_CHUNK - 1) / ACA_WAVE_CHUNK * ACA_WAVE_CHUNK;
+                used_s += (double)crosses * (double)(H.leaves[b].t_size + H.leaves[b].s_size);
             }
             if (!overflow && guess_s > 0) {
                 const double ratio = std::min(1.0, 1.3 * used_s / guess_s + 0.02);
@@ -2709,7 +2714,7 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     HMX_HIP(H.pool.alloc(cap));
     phase("pool allocation");
     // a zero row pivot and every growth round leave a grant unused: some slack over the exact need
-    const unsigned long long maxcap = (unsigned long long)std::max(1024.0, std::min(need + 2.0 * (double)nvis + 64.0 * 1048576.0, budget));
+    const unsigned long long maxcap = (unsigned long long)std::max(1024.0, std::min(need + (2.0 + ACA_WAVE_CHUNK) * (double)nvis + 64.0 * 1048576.0, budget));
     // grow_pool(): doubled (the ACA variants: their suspended / parked blocks CONTINUE, nothing granted so far is lost).  grow_pool(extra): room for
     // `extra` more elements beyond what is granted -- fullACA / SVD compress a block that ran out AGAIN from scratch, its first grants are lost, so
     // doubling rounds would spend the pool on abandoned crosses; with the failed blocks' full need added they all finish in the next round.
@@ -3184,6 +3189,21 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             }
         } side_guard{side};
         HMX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        // ... and one stream per size class of the one-wave kernel: the classes take 4-8 ms each when alone on the GPU, behind one another on ONE
+        // stream the last two only started when the first -- sharing the GPU with the workgroup kernels -- had finished (profiles/r5_aca_trace.log)
+        hipStream_t wave_stream[3] = {nullptr, nullptr, nullptr};
+        SideGuard wave_guard0{wave_stream[0]}, wave_guard1{wave_stream[1]}, wave_guard2{wave_stream[2]};
+        for (auto &ws : wave_stream)
+            HMX_HIP(hipStreamCreateWithFlags(&ws, hipStreamNonBlocking));
+#ifdef HMX_ACA_SERIAL // measurement only: every compression kernel on the null stream, one after the other (tools/aca_trace.sh)
+        (void)hipStreamDestroy(side);
+        side = nullptr;
+        for (auto &ws : wave_stream) {
+            (void)hipStreamDestroy(ws);
+            ws = nullptr;
+        }
+#endif
+        DArr<int32_t> d_medium, d_small;
         for (int round = 0;; round++) {
             AcaArgs A  = aca_args(H.pool.d, cap, round == 0 ? d_order.d : d_active.d);
             A.team_min = team_min;
@@ -3194,14 +3214,49 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
             size_t nbig = 0;
             while (team_min > 0 && nbig < active.size() && (int64_t)H.leaves[active[nbig]].t_size + H.leaves[active[nbig]].s_size >= team_min)
                 nbig++;
-            HMX_HIP(hipDeviceSynchronize()); // uploads, pool growth and state resets on the null stream, before the side stream reads them
-            if (active.size() > nbig) {
+            // ... and of those, the blocks with both sides <= wave_max points go to aca_wave_kernel (one wave per block) on a stream of their own
+            // (three size classes, largest first: 4, 2 or 1 entries of a line per lane)
+            std::vector<int32_t> medium, small, small_class[3];
+            for (size_t i = nbig; i < active.size(); i++) {
+                const int side_max = std::max(H.leaves[active[i]].t_size, H.leaves[active[i]].s_size);
+                if (side_max <= wave_max)
+                    small_class[side_max <= 64 ? 2 : (side_max <= 128 ? 1 : 0)].push_back(active[i]);
+                else
+                    medium.push_back(active[i]);
+            }
+            for (const auto &c : small_class)
+                small.insert(small.end(), c.begin(), c.end());
+            if (!small.empty()) {
+                HMX_HIP(d_medium.upload(medium));
+                HMX_HIP(d_small.upload(small));
+            }
+            HMX_HIP(hipDeviceSynchronize()); // uploads, pool growth and state resets on the null stream, before the side streams read them
+            if (nbig > 0) // the longest launch (few blocks, the highest ranks) first
+                hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)nbig), dim3(256), 0, 0, A);
+            if (!small.empty()) {
+                constexpr int WV = 4;
+                AcaArgs W = A;
+                W.order   = d_small.d;
+                auto grid = [](size_t n) { return dim3((unsigned)((n + WV - 1) / WV)); };
+                if (!small_class[0].empty())
+                    hipLaunchKernelGGL((aca_wave_kernel<WV, 4>), grid(small_class[0].size()), dim3(WV * 64), 0, wave_stream[0], W, (int)small_class[0].size());
+                W.order += small_class[0].size();
+                if (!small_class[1].empty())
+                    hipLaunchKernelGGL((aca_wave_kernel<WV, 2>), grid(small_class[1].size()), dim3(WV * 64), 0, wave_stream[1], W, (int)small_class[1].size());
+                W.order += small_class[1].size();
+                if (!small_class[2].empty())
+                    hipLaunchKernelGGL((aca_wave_kernel<WV, 1>), grid(small_class[2].size()), dim3(WV * 64), 0, wave_stream[2], W, (int)small_class[2].size());
+                if (!medium.empty()) {
+                    AcaArgs S = A;
+                    S.order   = d_medium.d;
+                    hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)medium.size()), dim3(256), 0, side, S);
+                }
+            } else if (active.size() > nbig) {
                 AcaArgs S = A;
                 S.order += nbig;
                 hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)(active.size() - nbig)), dim3(256), 0, side, S);
             }
             if (nbig > 0) {
-                hipLaunchKernelGGL(aca_kernel<256>, dim3((unsigned)nbig), dim3(256), 0, 0, A);
                 HMX_HIP(hipGetLastError());
                 HMX_HIP(hipMemcpy(round_ranks.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
                 std::vector<int32_t> handed;
@@ -3218,10 +3273,12 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
                 }
             }
             HMX_HIP(hipStreamSynchronize(side));
+            for (auto &ws : wave_stream)
+                HMX_HIP(hipStreamSynchronize(ws));
             HMX_HIP(hipGetLastError());
             HMX_HIP(hipMemcpy(round_ranks.data(), H.d_rank.d, nb * 4, hipMemcpyDeviceToHost));
             if (phase_timing)
-                fprintf(stderr, "[hmx build]   round %d (%.0f ms): one-workgroup kernel over the other %zu blocks done\n", round, since_phase(), active.size() - nbig);
+                fprintf(stderr, "[hmx build]   round %d (%.0f ms): one-workgroup kernel over %zu blocks, one-wave kernel over %zu blocks done\n", round, since_phase(), medium.size(), small.size());
             std::vector<int32_t> suspended;
             for (int32_t b : active)
                 if (round_ranks[b] == -2)

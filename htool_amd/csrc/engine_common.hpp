@@ -403,6 +403,7 @@ static const OptionSpec HMX_OPTION_SPECS[] = {
     {HMX_OPT_ACA_TEAM_MIN, "HMX_ACA_TEAM_MIN", false, 4096, 2, 1 << 30, OPT_BUILD},
     {HMX_OPT_ACA_TEAM_AFTER, "HMX_ACA_TEAM_Q", false, 48, 1, 1 << 20, OPT_BUILD},
     {HMX_OPT_ACA_TEAM_SLICE, "HMX_ACA_TEAM_SLICE", false, 0, 0, 1 << 20, OPT_BUILD},
+    {HMX_OPT_ACA_WAVE_MAX, "HMX_ACA_WAVE_MAX", false, 256, 0, 256, OPT_BUILD},
 };
 struct Options {
     static constexpr int MAX_ID = 40;

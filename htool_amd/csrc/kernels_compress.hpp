@@ -340,6 +340,251 @@ __global__ __launch_bounds__(NT) HMX_ACA_OCCUPANCY void aca_kernel(AcaArgs A) {
     }
 }
 
+// The same iteration for SMALL blocks (both sides <= 64 ACA_WAVE_KR points: most admissible blocks sit at the bottom levels of the block
+// tree) by ONE WAVE per block, WAVES independent blocks per workgroup: no workgroup barrier, no LDS -- aca_kernel spends these blocks'
+// iterations in some fifteen __syncthreads each, with four blocks per compute unit in flight where there is room for sixteen and more.
+// Lane l keeps the entries l, l + 64, ... of the current cross (and their visited flags) in registers; the history's pool offsets and
+// coefficients are fetched by the lanes (one cross each) and handed round by v_readlane.  Crosses, pivots, estimator and ranks are
+// aca_kernel's bit for bit: every entry sums its history in the same order, and the estimator's sums are formed exactly as there --
+// register r of the lanes is wave r of aca_kernel<256> (thread k holds entry k there too, blocks of <= 256 points per side), so
+// wave_sum_any per register, then the registers in order, reproduces block_sum_group's order of additions.
+// Pool space is taken ACA_WAVE_CHUNK crosses at a time: one returning atomic on the pool head per iteration of every small block would be
+// more than the ~90 per microsecond a single address sustains (MI355X_MICROARCH.md, dequeue); what a block leaves unused of its last
+// chunk stays a hole in the pool (cross_off holds every cross's own offset, nothing assumes they are adjacent).
+constexpr int ACA_WAVE_KR    = 4; // largest instantiation: blocks of up to 256 points per side (KR = 1, 2, 4: one launch per size class)
+constexpr int ACA_WAVE_CHUNK = 4;
+template <int WAVES, int KR>
+__global__ __launch_bounds__(WAVES *WAVE) void aca_wave_kernel(AcaArgs A, int nblocks) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos  = blockIdx.x * WAVES + wv;
+    if (pos >= nblocks)
+        return; // (no workgroup barrier below: the waves are independent)
+    const int b      = A.order[pos];
+    const int M      = A.t_size[b], N = A.s_size[b];
+    const int roff   = A.t_off[b], coff = A.s_off[b];
+    const bool swap  = A.symmetric_pivoting && !(roff >= coff);
+    const int n1     = swap ? N : M, n2 = swap ? M : N;
+    const int nr1 = (n1 + WAVE - 1) / WAVE, nr2 = (n2 + WAVE - 1) / WAVE; // registers in use per lane (<= KR)
+    const double *p1x = swap ? A.sx + coff : A.tx + roff, *p1y = swap ? A.sy + coff : A.ty + roff, *p1z = swap ? A.sz + coff : A.tz + roff;
+    const double *p2x = swap ? A.tx + roff : A.sx + coff, *p2y = swap ? A.ty + roff : A.sy + coff, *p2z = swap ? A.tz + roff : A.sz + coff;
+    unsigned char *vis1 = A.visited + A.vis_ptr[b];
+    unsigned char *vis2 = vis1 + n1;
+    int64_t *cross      = A.cross_off + A.colptr[b];
+    const int cap       = A.colcap[b];
+    bool seen1[KR], seen2[KR]; // visited flags of the lane's entries (kept in global memory too: the state of a suspended block)
+#pragma unroll
+    for (int r = 0; r < KR; r++) {
+        const int k = lane + WAVE * r;
+        seen1[r]    = k < n1 ? vis1[k] != 0 : true;
+        seen2[r]    = k < n2 ? vis2[k] != 0 : true;
+    }
+    int I1 = A.st_I1[b], I2 = A.st_I2[b], q = A.st_q[b];
+    real frob = A.st_frob[b], aux = A.st_aux[b];
+    const int reqrank = A.reqrank;
+    const int minmn   = n1 < n2 ? n1 : n2;
+    unsigned long long chunk_off = 0;
+    int granted = 0;
+    auto bcast64 = [](int64_t v, int l) {
+        const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+        return (int64_t)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    };
+    // one line of a cross: v[r] = A(line, k) - sum_j hist_j[coef_index] * hist_j[line_base + k], j in history order (aca_cross_line)
+    auto line = [&](int n, int nr, int nq, int64_t coef_index, int64_t line_base, auto eval, scalar(&v)[KR]) {
+        int kk[KR];
+#pragma unroll
+        for (int r = 0; r < KR; r++) {
+            const int k = lane + WAVE * r;
+            kk[r]       = k < n ? k : n - 1;
+            v[r]        = scalar(0);
+            if (r < nr)
+                v[r] = eval(kk[r]);
+        }
+        for (int j0 = 0; j0 < nq; j0 += WAVE) {
+            const int tile = (nq - j0) < WAVE ? (nq - j0) : WAVE;
+            int64_t o = 0;
+            scalar cf = scalar(0);
+            if (lane < tile) {
+                o  = cross[j0 + lane];
+                cf = -A.pool[o + coef_index];
+                o += line_base;
+            }
+            // four crosses per step, their loads issued together (a clamped cross is loaded again and not applied); applied in history order
+            for (int jj = 0; jj < tile; jj += 4) {
+                scalar coef[4], h[4][KR];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int jc     = jj + u < tile ? jj + u : tile - 1;
+                    coef[u]          = readlane_val(cf, jc);
+                    const scalar *cj = A.pool + bcast64(o, jc);
+#pragma unroll
+                    for (int r = 0; r < KR; r++)
+                        if (r < nr)
+                            h[u][r] = cj[kk[r]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (jj + u < tile)
+#pragma unroll
+                        for (int r = 0; r < KR; r++)
+                            if (r < nr)
+                                v[r] = coef[u] * h[u][r] + v[r];
+            }
+        }
+    };
+    // maximum of |.| over the entries not visited yet, ties -> larger index (block_argmax's rule: independent of the order of comparison)
+    auto pivot = [&](const scalar(&v)[KR], const bool(&seen)[KR], int n, int skip) {
+        real best = -1;
+        int besti = -1;
+#pragma unroll
+        for (int r = 0; r < KR; r++) {
+            const int k = lane + WAVE * r;
+            if (k < n && !seen[r] && k != skip) {
+                const real a = hmx_abs(v[r]);
+                if (a >= best) {
+                    best  = a;
+                    besti = k;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const real ov = hmx_shfl_xor(best, o);
+            const int oi  = hmx_shfl_xor(besti, o);
+            if (ov > best || (ov == best && oi > besti)) {
+                best  = ov;
+                besti = oi;
+            }
+        }
+        return besti;
+    };
+    auto entry_of = [&](const scalar(&v)[KR], int k) { // v's entry k, to every lane
+        scalar e = v[0];
+#pragma unroll
+        for (int r = 1; r < KR; r++)
+            e = (k >> 6) == r ? v[r] : e;
+        return hmx_shfl(e, k & 63);
+    };
+    // sum over the entries k < n of term(r), as block_sum_group<256> adds them: per register (= wave of aca_kernel) the butterfly, then the registers in order
+    auto sum_as_block = [&](auto term, int nr) {
+        scalar s = wave_sum_any(term(0));
+#pragma unroll
+        for (int r = 1; r < KR; r++)
+            if (r < nr)
+                s += wave_sum_any(term(r));
+        return s;
+    };
+    while (((reqrank > 0) && (q < (reqrank < minmn ? reqrank : minmn))) || ((reqrank < 0) && (q == 0 || sqrt(aux / frob) > (real)A.epsilon))) {
+        auto suspend = [&](int completed) {
+            if (lane == 0) {
+                A.st_q[b]    = completed;
+                A.st_I1[b]   = I1;
+                A.st_I2[b]   = I2;
+                A.st_frob[b] = frob;
+                A.st_aux[b]  = aux;
+            }
+        };
+        q += 1;
+        if ((long long)q * ((long long)n1 + n2) > (long long)n1 * n2 || q > cap) { // not advantageous any more
+            q = -1;
+            break;
+        }
+        if (granted == 0) {
+            unsigned long long got = 0;
+            if (lane == 0)
+                got = atomicAdd(A.pool_head, (unsigned long long)ACA_WAVE_CHUNK * (unsigned long long)(n1 + n2));
+            chunk_off = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(got & 0xffffffffull));
+            granted   = ACA_WAVE_CHUNK;
+            if (chunk_off + (unsigned long long)ACA_WAVE_CHUNK * (unsigned long long)(n1 + n2) > A.pool_cap) {
+                suspend(q - 1);
+                q = -2;
+                break;
+            }
+        }
+        const unsigned long long off = chunk_off + (unsigned long long)(ACA_WAVE_CHUNK - granted) * (unsigned long long)(n1 + n2);
+        granted--;
+        scalar *u2 = A.pool + off;      // new uu (length n1)
+        scalar *u1 = A.pool + off + n1; // new vv (length n2)
+        // ---- cross row: entries (I1, k), k over index 2 ------------------------------------------
+        const double ax = p1x[I1], ay = p1y[I1], az = p1z[I1];
+        auto row_entry = [&](int k) { return swap ? eval_scalar(A.ks, p2x[k], p2y[k], p2z[k], ax, ay, az) : eval_scalar(A.ks, ax, ay, az, p2x[k], p2y[k], p2z[k]); };
+        scalar r1[KR], r2[KR];
+        line(n2, nr2, q - 1, I1, n1, row_entry, r1);
+#pragma unroll
+        for (int r = 0; r < KR; r++)
+            if (lane + WAVE * r < n2)
+                u1[lane + WAVE * r] = r1[r];
+        const int besti2 = pivot(r1, seen2, n2, -1);
+        if (besti2 >= 0)
+            I2 = besti2;
+#pragma unroll
+        for (int r = 0; r < KR; r++)
+            seen1[r] = seen1[r] || lane + WAVE * r == I1;
+        if (lane == 0)
+            vis1[I1] = 1;
+        const scalar piv   = entry_of(r1, I2);
+        const scalar gamma = scalar(1) / piv;
+        if (hmx_abs(piv) > 1e-15) {
+            // ---- cross column: entries (k, I2), k over index 1 -----------------------------------
+            const double bx = p2x[I2], by = p2y[I2], bz = p2z[I2];
+            auto col_entry = [&](int k) { return swap ? eval_scalar(A.ks, bx, by, bz, p1x[k], p1y[k], p1z[k]) : eval_scalar(A.ks, p1x[k], p1y[k], p1z[k], bx, by, bz); };
+            line(n1, nr1, q - 1, (int64_t)n1 + I2, 0, col_entry, r2);
+#pragma unroll
+            for (int r = 0; r < KR; r++) {
+                r2[r] = r2[r] * gamma;
+                if (lane + WAVE * r < n1)
+                    u2[lane + WAVE * r] = r2[r];
+            }
+            const int besti1 = pivot(r2, seen1, n1, I1);
+            const int nextI1 = besti1 >= 0 ? besti1 : I1;
+#pragma unroll
+            for (int r = 0; r < KR; r++)
+                seen2[r] = seen2[r] || lane + WAVE * r == I2;
+            if (lane == 0) {
+                vis2[I2]     = 1;
+                cross[q - 1] = (int64_t)off;
+            }
+            if (reqrank < 0) {
+                // error estimator (partialACA.hpp:136-148): |c.c||r.r| + 2 sum_j (vv_j.r)(uu_j.c)
+                const scalar cc = sum_as_block([&](int r) { scalar a = scalar(0); if (lane + WAVE * r < n1) a += hmx_conj(r2[r]) * r2[r]; return a; }, nr1);
+                const scalar rr = sum_as_block([&](int r) { scalar a = scalar(0); if (lane + WAVE * r < n2) a += hmx_conj(r1[r]) * r1[r]; return a; }, nr2);
+                aux             = hmx_abs(cc) * hmx_abs(rr);
+                scalar frob_aux = 0;
+                for (int j0 = 0; j0 < q - 1; j0 += WAVE) {
+                    const int tile  = (q - 1 - j0) < WAVE ? (q - 1 - j0) : WAVE;
+                    const int64_t o = lane < tile ? cross[j0 + lane] : 0;
+                    for (int jj = 0; jj < tile; jj++) {
+                        const scalar *cj = A.pool + bcast64(o, jj);
+                        scalar h1[KR], h2[KR]; // the loads first: 2 KR independent streams
+#pragma unroll
+                        for (int r = 0; r < KR; r++) {
+                            const int k = lane + WAVE * r;
+                            h2[r] = (r < nr2 && k < n2) ? cj[n1 + k] : scalar(0);
+                            h1[r] = (r < nr1 && k < n1) ? cj[k] : scalar(0);
+                        }
+                        const scalar d2 = sum_as_block([&](int r) { scalar a = scalar(0); if (lane + WAVE * r < n2) a += hmx_conj(h2[r]) * r1[r]; return a; }, nr2);
+                        const scalar d1 = sum_as_block([&](int r) { scalar a = scalar(0); if (lane + WAVE * r < n1) a += hmx_conj(h1[r]) * r2[r]; return a; }, nr1);
+                        frob_aux += d2 * d1;
+                    }
+                }
+                frob += aux + 2 * hmx_re(frob_aux);
+            }
+            // the crosses written above are read back (other lanes, later iterations) through this CU's own L1 / L2: stores complete first
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            I1 = nextI1;
+        } else {
+            q -= 1;
+            if (q == 0)
+                q = -1;
+            break;
+        }
+    }
+    if (lane == 0) {
+        A.rank_out[b]    = q > 0 ? q : (q <= -2 ? q : 0);
+        A.swapped_out[b] = swap ? 1 : 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same iteration for a TEAM of G workgroups per block.  One workgroup streams some tens of GB/s: a 15 625 x 15 625 block of rank 476
 // walks 113 GB of its own history, seconds on one compute unit while the rest of the GPU has long finished.  So large blocks leave

@@ -251,7 +251,9 @@ typedef enum {
     HMX_OPT_ACA_TEAMS         = 34, /* build   1     large high-rank blocks continue in teams of workgroups                  HMX_ACA_TEAM         */
     HMX_OPT_ACA_TEAM_MIN      = 35, /* build   4096  ... from this many rows + columns                                       HMX_ACA_TEAM_MIN     */
     HMX_OPT_ACA_TEAM_AFTER    = 36, /* build   48    ... after this many iterations                                          HMX_ACA_TEAM_Q       */
-    HMX_OPT_ACA_TEAM_SLICE    = 37  /* build   0     entries of a line per workgroup of a team (0: adaptive 1024 / 256)      HMX_ACA_TEAM_SLICE   */
+    HMX_OPT_ACA_TEAM_SLICE    = 37, /* build   0     entries of a line per workgroup of a team (0: adaptive 1024 / 256)      HMX_ACA_TEAM_SLICE   */
+    HMX_OPT_ACA_WAVE_MAX      = 38  /* build   256   admissible blocks with both sides <= this many points are compressed by
+                                                     one wave each (0: one workgroup per block throughout; <= 256)           HMX_ACA_WAVE_MAX     */
 } hmx_option;
 int hmx_hmatrix_set_option(hmx_hmatrix *, int option /* hmx_option */, double value);
 int hmx_hmatrix_get_option(const hmx_hmatrix *, int option, double *value);

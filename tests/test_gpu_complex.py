@@ -403,3 +403,11 @@ def test_complex_stored_triangle_product_with_several_right_hand_sides(name):
     Y3 = Y0.copy()
     hm.internal_add_hmatrix_matrix_product_row_major("N", alpha, H, X, beta, Y3, mu)
     assert H.stats()["expanded_bytes"] > 0 and rel_err(Y3, Y) < tol
+
+
+@pytest.mark.parametrize("name", [c for c in Z_CASES if params(c)["compressor"] in ("partialACA", "sympartialACA")])
+def test_one_wave_kernel_builds_the_same_crosses_complex(name):
+    """aca_wave_kernel against aca_kernel, complex coefficients: bit for bit (see test_gpu_parity.check_one_wave_kernel)."""
+    from test_gpu_parity import check_one_wave_kernel
+    p = params(name)
+    check_one_wave_kernel(lambda opts: build_zengine(p, options=opts)[2])

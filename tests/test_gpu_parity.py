@@ -734,6 +734,41 @@ def test_workgroup_teams_build_the_same_operator(name, monkeypatch):
     test_matvec_matches_reference(name)
 
 
+@pytest.mark.parametrize("name", ACA_CASES)
+def test_one_wave_kernel_builds_the_same_crosses(name):
+    """Small admissible blocks (both sides <= aca_wave_max points) are compressed by one wave each (aca_wave_kernel) instead of one workgroup
+    each (aca_kernel): ranks, pivots and factors must be the workgroup kernel's BIT FOR BIT -- the same history order per entry, the
+    estimator's sums added in block_sum_group's order -- with the pool space of the small blocks taken four crosses at a time.  Also with a
+    pool that runs out on the way (suspended blocks continue in the kernel they started in) and for the three size classes alone."""
+    p = params(name)
+    check_one_wave_kernel(lambda opts: build_engine(p, options=opts)[2])
+
+
+def check_one_wave_kernel(build):
+    H0 = build(dict(aca_wave_max=0))
+    lr = np.nonzero(np.asarray(H0.ranks) >= 0)[0]
+    ref = H0.get_blocks(lr)
+    for opts in (dict(aca_wave_max=256), dict(aca_wave_max=64), dict(aca_wave_max=128, pool_rank_guess=2)):
+        H = build(opts)
+        assert np.array_equal(H.leaf_table(), H0.leaf_table())
+        for (U, V), (U0, V0) in zip(H.get_blocks(lr), ref):
+            assert np.array_equal(U, U0) and np.array_equal(V, V0)
+
+
+@pytest.mark.parametrize("name", F32_CASES)
+def test_one_wave_kernel_builds_the_same_crosses_fp32(name):
+    p = params(name)
+    T, S = build_trees(p)
+
+    def build(opts):
+        tb = hm.HMatrixTreeBuilder(p["eps"], p["eta"], p["sym"], p["uplo"], p["reqrank"])
+        for k, v in opts.items():
+            tb.set_option(k, v)
+        tb.set_low_rank_generator(p["compressor"])
+        return tb.build(device_generator(p, T, S), T, S, p["rank"], p["rank"], dtype=np.float32)
+    check_one_wave_kernel(build)
+
+
 @pytest.mark.parametrize("unit_rows", [64, 512])
 @pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_p2_symU_rank1", "rect_ball1500_disk1000", "ellipse_n4000_p4_rank2"])
 def test_xcd_grouped_launch_order(name, unit_rows, monkeypatch):
