@@ -137,7 +137,7 @@ def kernel_sources_hash():
     """sha256 over the device sources: profiles/traffic.json records it, a PMC measurement of an older binary is not reported."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels_common.hpp", "kernels_body.hpp", "kernels_compress.hpp", "kernels_pack.hpp", "kernels_matvec.hpp", "kernels_multi_rhs.hpp", "kernels_symmetric.hpp", "kernels_util.hpp", "engine_body.hpp", "engine_common.hpp", "engine_api.hpp", "engine_inst.hip", "engine.hip"):
+    for f in ("kernels_common.hpp", "kernels_body.hpp", "kernels_compress.hpp", "kernels_pack.hpp", "kernels_matvec.hpp", "kernels_multi_rhs.hpp", "kernels_symmetric.hpp", "kernels_util.hpp", "engine_body.hpp", "engine_state.hpp", "engine_layout.hpp", "engine_products.hpp", "engine_build.hpp", "engine_access.hpp", "engine_entry.hpp", "engine_common.hpp", "engine_api.hpp", "engine_inst.hip", "engine.hip"):
         with open(os.path.join(ROOT, "htool_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
