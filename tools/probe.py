@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--build-option", action="append", default=[], help="name=value, set before the build (layout / build options)")
     ap.add_argument("--variant", action="append", default=[], help="'default' or comma-separated name=value product options")
     ap.add_argument("--check", action="store_true", help="compare every variant's result with the first variant's")
+    ap.add_argument("--move-buffers", action="store_true", help="before every variant after the first: new X / Y tensors and a product with more right-hand sides (the "
+                    "operator's work area is then allocated again, elsewhere) -- how much of a difference is the placement of the buffers")
     args = ap.parse_args()
 
     import torch
@@ -91,8 +93,23 @@ def main():
             hm.internal_add_hmatrix_vector_product(args.trans, 1.0, H, X, 0.0, Y)
 
     ref = None
+
+    def ref_done(m):
+        return m > 0
     b_alg = esz * (st["cgen_dense"] + st["cgen_lowrank"] + mu * (n + H.nb_rows()))
+    moves = 0
     for var in args.variant or ["default"]:
+        if args.move_buffers and ref_done(moves):
+            keep = [torch.empty((3 + 5 * moves) << 20, dtype=torch.uint8, device=dev)]  # shifts what torch hands out next
+            X, Y = X.clone(), torch.zeros_like(Y)
+            if mu > 1:
+                mu2 = mu + 16 * (moves + 1)
+                X2 = torch.zeros((nin, mu2), dtype=t_dt, device=dev)
+                Y2 = torch.zeros((nout, mu2), dtype=t_dt, device=dev)
+                hm.internal_add_hmatrix_matrix_product_row_major(args.trans, 1.0, H, X2, 0.0, Y2, mu2)
+                del X2, Y2
+            del keep
+        moves += 1
         opts = {} if var == "default" else dict(kv.split("=") for kv in var.split(","))
         saved = {k: H.get_option(k) for k in opts}
         for k, v in opts.items():
