@@ -426,13 +426,13 @@ def main():
     t_init = time.time() - t_init
     # One slab from the driver before anything is timed (hmx_device_reserve): hipMalloc stalls for seconds while the driver scrubs
     # what the PREVIOUS process released (tools/malloc_after_exit.hip), and a build allocates its two largest arrays right there.
-    # 64 KB per point and 8-byte coefficient for the surface geometries (N=1e6 fp64: 64 GB for a 19 GB pool + 18.6 GB of streams), 200 KB
-    # for the volume (ball: 102 + 92 GB), at most 60 % of what is free;
+    # 60 % of what is free (round 5; before: 64 KB per point): the slab is also where the library looks for a place for the small arrays its
+    # sweeps WRITE -- a write stream costs a streaming read 12-16 % when both lie in the same third of the physical memory, 7-10 % otherwise
+    # (hmx_option place_written, tools/placement_rw.hip), and a slab of a third of the memory or less is often all of one kind;
     # whatever does not fit is allocated as before, `compress.malloc_s` says what hipMalloc still cost.  HMX_BENCH_RESERVE_GB=0: off.
     free_b, _ = torch.cuda.mem_get_info(local_rank)
     share = max(1, world if os.environ.get("HMX_BENCH_SAME_DEVICE") else 1)
-    want = float(os.environ["HMX_BENCH_RESERVE_GB"]) * 1e9 if "HMX_BENCH_RESERVE_GB" in os.environ else (204800.0 if args.geom == "ball" else 65536.0) * n * np.dtype(
-        {"f64": np.float64, "f32": np.float32, "z64": np.complex128, "c32": np.complex64}[args.dtype]).itemsize / 8 / max(1, world if use_dist else 1)
+    want = float(os.environ["HMX_BENCH_RESERVE_GB"]) * 1e9 if "HMX_BENCH_RESERVE_GB" in os.environ else 0.6 * free_b / share
     reserve_b = int(min(0.6 * free_b / share, want))
     t_res = time.time()
     reserved = reserve_b >= (1 << 30) and hm.lib().hmx_device_reserve(local_rank, reserve_b) == 0
@@ -616,7 +616,10 @@ def main():
                         # nothing left out: cluster tree on the host + device initialisation + the slab reservation (the hipMalloc stall the
                         # timed build no longer pays) + the device build; and the operator's stored coefficients per second of all that
                         device_init_s=t_init, device_total_with_reserve_s=t_build + t_res, end_to_end_s=t_tree + t_init + t_res + t_build,
-                        entries_per_s_end_to_end=(st["cgen_dense"] + st["cgen_lowrank"]) / (t_tree + t_init + t_res + t_build))
+                        entries_per_s_end_to_end=(st["cgen_dense"] + st["cgen_lowrank"]) / (t_tree + t_init + t_res + t_build),
+                        # hmx_option place_written: GB/s of the placement probe for the array the reduce stage writes (0: nothing tried)
+                        written_array_placement=dict(stream_alone_GBps=st.get("placed_read_gbps"), first_fit_GBps=st.get("placed_first_gbps"),
+                                                     chosen_GBps=st.get("placed_gbps"), places_tried=st.get("placed_tried")))
 
         return compress
 

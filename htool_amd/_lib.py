@@ -19,7 +19,7 @@ OPTIONS = {"r_piece_rows": 1, "r_tree_pieces": 2, "layout_threads": 3, "task_ord
            "reduce_waves": 10, "expand_waves": 11, "multi_rhs_fused": 12, "matrix_cores": 13, "matrix_cores_f32": 14, "wide_sweeps": 15,
            "scalar_operands": 16, "sym_multi_rhs": 17, "sym_no_view": 18, "transposed_layout": 19,
            "callback_threads": 30, "callback_drivers": 31, "pool_sample": 32, "pool_rank_guess": 33, "aca_teams": 34, "aca_team_min": 35,
-           "aca_team_after": 36, "aca_team_slice": 37, "aca_wave_max": 38}
+           "aca_team_after": 36, "aca_team_slice": 37, "aca_wave_max": 38, "place_written": 39}
 DIST_OPTIONS = {"force_collectives": 1, "no_allgather": 2, "no_reduce_scatter": 3}
 COMPRESSORS = {"partialACA": 0, "sympartialACA": 1, "fullACA": 2, "SVD": 3}
 DIRECTIONS = {"largest_extent": 0, "bounding_box": 1}
@@ -46,7 +46,8 @@ class Stats(C.Structure):
                 ("rank_max", C.c_int32), ("rank_mean", C.c_double), ("stream_bytes", C.c_int64),
                 ("expand_coeffs", C.c_int64), ("reduce_coeffs", C.c_int64), ("a_total", C.c_int64),
                 ("t_compress_s", C.c_double), ("t_assemble_s", C.c_double), ("t_pack_s", C.c_double),
-                ("transposed_bytes", C.c_int64), ("expanded_bytes", C.c_int64)]
+                ("transposed_bytes", C.c_int64), ("expanded_bytes", C.c_int64),
+                ("placed_read_gbps", C.c_double), ("placed_first_gbps", C.c_double), ("placed_gbps", C.c_double), ("placed_tried", C.c_int64)]
 
 
 GENERATOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double))

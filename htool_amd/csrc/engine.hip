@@ -62,6 +62,65 @@ static __global__ __launch_bounds__(256) void read16_kernel(const double2 *__res
     out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = (s0 + s1) + (s2 + s3);
 }
 
+// placement probe (hmx_placement_probe): the streaming read above over `nslices` slices spread evenly over a stream, while every wave
+// stores 512 bytes to the candidate array every second step (1.6 % of the bytes it reads: the ratio of the write streams of the products)
+static __global__ __launch_bounds__(256) void placement_probe_kernel(const double2 *__restrict__ in, int64_t n_total, int nslices, int64_t slice_elems, double *__restrict__ out,
+                                                                     int64_t out_elems) {
+    const int per_slice = gridDim.x / nslices, sl = blockIdx.x / per_slice, bl = blockIdx.x % per_slice;
+    if (sl >= nslices)
+        return;
+    const int64_t slice0 = nslices > 1 ? (n_total - slice_elems) / (nslices - 1) * sl : 0;
+    const int64_t per    = slice_elems / per_slice;
+    const double2 *p     = in + slice0 + per * bl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t runs = out_elems / 64; // 512-byte runs of the candidate
+    int64_t run        = ((int64_t)blockIdx.x * 4 + wave) * (runs / ((int64_t)gridDim.x * 4) > 0 ? runs / ((int64_t)gridDim.x * 4) : 1);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int64_t it = 0;
+    for (int64_t i = threadIdx.x; i + 3 * 256 < per; i += 4 * 256, it++) {
+        const double2 a = stream_load(p + i), b = stream_load(p + i + 256), c = stream_load(p + i + 512), d = stream_load(p + i + 768);
+        s0 += a.x + a.y;
+        s1 += b.x + b.y;
+        s2 += c.x + c.y;
+        s3 += d.x + d.y;
+        if (out && (it & 1) == 0) {
+            out[(run % runs) * 64 + lane] = (s0 + s1) + (s2 + s3);
+            run++;
+        }
+    }
+    if (s0 == 12345.678 && out)
+        out[lane] = s1;
+}
+
+// GB/s of a streaming read of (a sample of) [stream, stream + stream_bytes) while a small write stream goes to [cand, cand + cand_bytes);
+// cand = nullptr: the read alone.  On MI355X the pair runs 12-16 % faster when the two lie in different thirds of the physical memory
+// (tools/placement_rw.hip) -- which third a virtual address belongs to is the driver's business, so it is measured.
+// The candidate's contents are overwritten.
+double placement_probe(const void *stream, size_t stream_bytes, void *cand, size_t cand_bytes, hipStream_t st) {
+    const int nslices = 8, grid = 2048;
+    int64_t n_total   = (int64_t)(stream_bytes / 16);
+    int64_t slice     = std::min<int64_t>(n_total / nslices, (int64_t)(256u << 20) / 16); // <= 8 x 256 MiB read per launch
+    slice             = slice / (grid / nslices * 1024) * (grid / nslices * 1024);
+    if (slice <= 0 || (cand && cand_bytes < (size_t)grid * 4 * 512))
+        return 0.0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return 0.0;
+    auto launch = [&]() {
+        hipLaunchKernelGGL(placement_probe_kernel, dim3(grid), dim3(256), 0, st, (const double2 *)stream, n_total, nslices, slice, (double *)cand, (int64_t)(cand_bytes / 8));
+    };
+    launch();
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < 3; r++)
+        launch();
+    (void)hipEventRecord(e1, st);
+    float ms = 0;
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ok ? 3.0 * (double)slice * nslices * 16 / (ms * 1e-3) / 1e9 : 0.0;
+}
+
 } // namespace hmx
 
 // The opaque handle of the C ABI: one of the four instantiations

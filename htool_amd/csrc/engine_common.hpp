@@ -162,6 +162,40 @@ struct DeviceSlabs {
         }
         return nullptr;
     }
+    // ... a range as close as possible to the fraction `frac` of a slab's extent (frac = 1: from the top): for arrays that should NOT lie
+    // next to what first fit hands out (place_written)
+    void *take_at(int dev, size_t bytes, double frac, size_t *got) {
+        const size_t need = (bytes + GRAIN - 1) / GRAIN * GRAIN;
+        std::lock_guard<std::mutex> lock(mu);
+        Slab *best_s = nullptr;
+        size_t best_off = 0, best_dist = ~size_t(0), best_range = 0;
+        for (Slab &s : slabs) {
+            if (s.device != dev)
+                continue;
+            const size_t target = (size_t)(frac * (double)(s.bytes - std::min(s.bytes, need))) / GRAIN * GRAIN;
+            for (const auto &r : s.free_at) {
+                if (r.second < need)
+                    continue;
+                const size_t lo = r.first, hi = r.first + r.second - need; // possible starts inside this free range
+                const size_t at = target < lo ? lo : (target > hi ? hi : target);
+                const size_t dist = at > target ? at - target : target - at;
+                if (dist < best_dist) {
+                    best_dist = dist, best_off = at, best_range = r.first, best_s = &s;
+                }
+            }
+        }
+        if (!best_s)
+            return nullptr;
+        const size_t r_off = best_range, r_len = best_s->free_at[best_range];
+        best_s->free_at.erase(best_range);
+        if (best_off > r_off)
+            best_s->free_at[r_off] = best_off - r_off;
+        if (best_off + need < r_off + r_len)
+            best_s->free_at[best_off + need] = r_off + r_len - (best_off + need);
+        best_s->in_use += need;
+        *got = need;
+        return best_s->base + best_off;
+    }
     // true when p belongs to a slab (and is free again afterwards)
     bool give_back(void *p, size_t bytes) {
         std::lock_guard<std::mutex> lock(mu);
@@ -321,6 +355,30 @@ struct DArr { // device array with RAII
         }
         return e;
     }
+    // from a reserved slab only, near the fraction `frac` of its extent; hipErrorOutOfMemory when no slab has room there
+    hipError_t alloc_at(size_t count, double frac) {
+        release();
+        n = count;
+        if (count == 0)
+            return hipSuccess;
+        (void)hipGetDevice(&dev_);
+        size_t got = 0;
+        if (void *p = DeviceSlabs::get().take_at(dev_, count * sizeof(T), frac, &got)) {
+            g_alloc_count++;
+            d    = static_cast<T *>(p);
+            cap_ = got;
+            return hipSuccess;
+        }
+        n = 0;
+        return hipErrorOutOfMemory;
+    }
+    void swap(DArr &o) {
+        std::swap(d, o.d);
+        std::swap(n, o.n);
+        std::swap(cap_, o.cap_);
+        std::swap(dev_, o.dev_);
+        std::swap(plain_, o.plain_);
+    }
     template <typename A>
     hipError_t upload(const std::vector<T, A> &h) {
         hipError_t e = alloc(h.size());
@@ -351,6 +409,47 @@ static hipError_t hmx_mem_largest(size_t *largest_b) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     *largest_b = std::max(free_b, DeviceSlabs::get().largest_hole(dev));
+    return hipSuccess;
+}
+
+// ---- where the WRITTEN arrays of a product go --------------------------------------------------------------------------------------
+// A streaming read loses 12-16 % of its rate to a write stream of 0.4-1.6 % of its bytes when both lie in the same third of the physical
+// memory (HBM3E stacks of 12 dies: three groups per channel), and 7-10 % when they do not (tools/placement_rw.hip).  Which third a virtual
+// address belongs to is the driver's business (a 64 GB slab is one third, or pieces of two or three), so it is MEASURED: the small arrays
+// the sweeps write (the reduced coefficients a, partial sums, column sums) are tried at a few places of the reserved slab against a sample
+// of the stream that is read while they are written, and stay where the pair runs fastest.  Without a reserved slab (hmx_device_reserve)
+// nothing is tried: the driver decides.
+double placement_probe(const void *stream, size_t stream_bytes, void *cand, size_t cand_bytes, hipStream_t st); // engine.hip
+struct PlacementReport {
+    double read_only = 0, first = 0, chosen = 0; // GB/s of the probe: the stream alone, with the array where first fit put it, where it stays
+    int tried = 0;
+};
+template <typename T>
+static hipError_t place_written(DArr<T> &arr, size_t count, const void *stream, size_t stream_bytes, bool enabled, PlacementReport *rep = nullptr) {
+    const hipError_t e0 = arr.alloc(count);
+    if (e0 != hipSuccess || !enabled || count == 0 || !stream || stream_bytes < (size_t(256) << 20) || !DeviceSlabs::get().owns(arr.d) || !DeviceSlabs::get().owns(stream))
+        return e0;
+    const size_t bytes = count * sizeof(T);
+    PlacementReport r;
+    r.read_only = placement_probe(stream, stream_bytes, nullptr, 0, nullptr);
+    r.first = r.chosen = placement_probe(stream, stream_bytes, arr.d, bytes, nullptr);
+    r.tried = 1;
+    if (r.first > 0 && r.first < 0.915 * r.read_only) // (different thirds: 0.90-0.93 of the read alone at 1.6 % written; the same third: 0.77-0.80)
+        for (double frac : {1.0, 0.5, 0.75, 0.25, 0.0, 0.875, 0.625, 0.375, 0.125}) {
+            DArr<T> cand;
+            if (cand.alloc_at(count, frac) != hipSuccess)
+                continue;
+            const double rate = placement_probe(stream, stream_bytes, cand.d, bytes, nullptr);
+            r.tried++;
+            if (rate > 1.03 * r.chosen) {
+                arr.swap(cand); // (the loser goes back to the slab when `cand` leaves the scope)
+                r.chosen = rate;
+            }
+            if (r.chosen >= 0.915 * r.read_only)
+                break;
+        }
+    if (rep)
+        *rep = r;
     return hipSuccess;
 }
 
@@ -403,6 +502,7 @@ static const OptionSpec HMX_OPTION_SPECS[] = {
     {HMX_OPT_ACA_TEAM_MIN, "HMX_ACA_TEAM_MIN", false, 4096, 2, 1 << 30, OPT_BUILD},
     {HMX_OPT_ACA_TEAM_AFTER, "HMX_ACA_TEAM_Q", false, 48, 1, 1 << 20, OPT_BUILD},
     {HMX_OPT_ACA_TEAM_SLICE, "HMX_ACA_TEAM_SLICE", false, 0, 0, 1 << 20, OPT_BUILD},
+    {HMX_OPT_PLACE_WRITTEN, "HMX_PLACE_WRITTEN", false, 1, 0, 1, OPT_PRODUCT},
     {HMX_OPT_ACA_WAVE_MAX, "HMX_ACA_WAVE_MAX", false, 256, 0, 256, OPT_BUILD},
 };
 struct Options {

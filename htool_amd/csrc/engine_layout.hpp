@@ -285,7 +285,7 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     HMX_HIP(H.s_fidx.alloc(std::max<size_t>(s_fidx_n, 1)));
     if (s_fidx_n)
         HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HMX_HIP(H.SW.alloc(s_total + 1));
+    HMX_HIP(place_written(H.SW, (size_t)s_total + 1, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_sw)); // column sums: written while E is read
     H.s_slots = s_total;
     H.SW16.release();
     if (H.s64_nint > 0) {
@@ -937,8 +937,13 @@ static int build_streams(HMat &H) {
     HMX_HIP(H.c_src.upload(cs));
     HMX_HIP(H.c_stride.upload(cst));
     HMX_HIP(H.c_count.upload(cc));
-    HMX_HIP(H.Z.alloc(H.zero_slot + 1));
+    // Z = [x | a | partial sums]: written by the reduce stage while the R-stream is read (place_written: where that pair runs fastest)
+    HMX_HIP(place_written(H.Z, (size_t)H.zero_slot + 1, R.stream.d, (size_t)R.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_z));
     HMX_HIP(H.Z.zero());
+    if (phase_timing) // where the arrays of a product lie
+        fprintf(stderr, "[hmx build]   arrays: E-stream %p (%.3f GB), R-stream %p (%.3f GB), Z %p (placement probe: R alone %.0f GB/s, with Z at first fit %.0f, where it stays %.0f; %d places tried)\n",
+                (void *)E.stream.d, E.elems * sizeof(scalar) / 1e9, (void *)R.stream.d, R.elems * sizeof(scalar) / 1e9, (void *)H.Z.d, H.placed_z.read_only, H.placed_z.first, H.placed_z.chosen,
+                H.placed_z.tried);
     HMX_HIP(hipEventSynchronize(e1));
     HMX_HIP(hipDeviceSynchronize()); // an error of the pack kernels surfaces here
     pack_guard.armed = false;

@@ -307,7 +307,7 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
                           void *after_user = nullptr) {
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
-        HMX_HIP(H.Zmu.alloc(need));
+        HMX_HIP(place_written(H.Zmu, need, H.R.stream.d, (size_t)H.R.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_zmu));
     // the x region of Zmu is never filled: both stages read the caller's X directly
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                   H.r_outidx.d, X, H.Zmu.d, (int)H.R.task_range.size()};
@@ -483,7 +483,7 @@ static bool sym_mu_fused(const HMat &H) {
 static int ensure_sw16(HMat &H, hipStream_t st) {
     const size_t need16 = (size_t)(H.s_slots + 1) * SWW;
     if (H.SW16.n < need16) {
-        HMX_HIP(H.SW16.alloc(need16));
+        HMX_HIP(place_written(H.SW16, need16, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_sw16));
         HMX_HIP(hipMemsetAsync(H.SW16.d, 0, need16 * sizeof(scalar), st)); // slot s_slots stays zero for ever: the operand of the columns that are no mirrored leaf's
     }
     return HMX_OK;
@@ -571,7 +571,7 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
 static int run_forward_mu_sym(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
-        HMX_HIP(H.Zmu.alloc(need));
+        HMX_HIP(place_written(H.Zmu, need, H.R.stream.d, (size_t)H.R.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_zmu));
     int rc = ensure_sw16(H, st);
     if (rc != HMX_OK)
         return rc;

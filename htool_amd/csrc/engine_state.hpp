@@ -156,6 +156,7 @@ struct HMat {
     int64_t A_total     = 0, P_total = 0;
     int64_t zero_slot   = 0;
     DArr<scalar> Z, Zmu;
+    PlacementReport placed_z, placed_zmu, placed_sw, placed_sw16; // what place_written measured for the arrays the sweeps write
     DArr<scalar> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
     DArr<scalar> conj_in;                             // conjugated input of a trans = 'C' product
     DArr<scalar> mm_in, mm_out;                       // row-major cluster-numbered operands of the column-major front end

@@ -93,6 +93,10 @@ typedef struct {
     double t_compress_s, t_assemble_s, t_pack_s; /* hipEvent timings of the build phases                   */
     int64_t transposed_bytes;    /* what 'T' / 'C' products hold besides the operator: the tables of the product on the stored data (~3 %) and / or the transposed stream layout; 0 = nothing built */
     int64_t expanded_bytes;      /* expanded view of a compact symmetric operator (multi-RHS products), 0 = not built             */
+    /* HMX_OPT_PLACE_WRITTEN, the array the reduce stage writes (a = V x): GB/s of the placement probe -- the R-stream read alone, with the
+       array where first fit put it, where it stays -- and the places tried (0: nothing tried: no reserved slab, small operator, option off) */
+    double placed_read_gbps, placed_first_gbps, placed_gbps;
+    int64_t placed_tried;
 } hmx_stats;
 
 const char *hmx_last_error(void);
@@ -252,8 +256,13 @@ typedef enum {
     HMX_OPT_ACA_TEAM_MIN      = 35, /* build   4096  ... from this many rows + columns                                       HMX_ACA_TEAM_MIN     */
     HMX_OPT_ACA_TEAM_AFTER    = 36, /* build   48    ... after this many iterations                                          HMX_ACA_TEAM_Q       */
     HMX_OPT_ACA_TEAM_SLICE    = 37, /* build   0     entries of a line per workgroup of a team (0: adaptive 1024 / 256)      HMX_ACA_TEAM_SLICE   */
-    HMX_OPT_ACA_WAVE_MAX      = 38  /* build   256   admissible blocks with both sides <= this many points are compressed by
+    HMX_OPT_ACA_WAVE_MAX      = 38, /* build   256   admissible blocks with both sides <= this many points are compressed by
                                                      one wave each (0: one workgroup per block throughout; <= 256)           HMX_ACA_WAVE_MAX     */
+    HMX_OPT_PLACE_WRITTEN     = 39  /* product 1     the small arrays the sweeps WRITE (reduced coefficients, partial sums) are
+                                                     tried at a few places of the reserved slab (hmx_device_reserve) against the
+                                                     stream read meanwhile and stay where the pair runs fastest: on MI355X a write
+                                                     stream costs a streaming read 12-16 % in the same third of the physical memory,
+                                                     7-10 % elsewhere (0: wherever first fit puts them)                       HMX_PLACE_WRITTEN    */
 } hmx_option;
 int hmx_hmatrix_set_option(hmx_hmatrix *, int option /* hmx_option */, double value);
 int hmx_hmatrix_get_option(const hmx_hmatrix *, int option, double *value);
@@ -293,7 +302,7 @@ int hmx_hmatrix_get_blocks_c(const hmx_hmatrix *, int64_t count, const int64_t *
  * sizeof(hmx_stats) of the header it was compiled with.  (The exported function of the same name, kept for binaries built before the macro
  * existed, fills only the fields hmx_stats had in its first version -- up to and including t_pack_s.)  hmx_abi_version() returns
  * HMX_ABI_VERSION of the library: it changes when a struct grows or an entry point is added, never for existing signatures. */
-#define HMX_ABI_VERSION 5
+#define HMX_ABI_VERSION 6
 int hmx_abi_version(void);
 int hmx_hmatrix_stats_sized(const hmx_hmatrix *, hmx_stats *out, size_t struct_size);
 int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);

@@ -769,6 +769,45 @@ def test_one_wave_kernel_builds_the_same_crosses_fp32(name):
     check_one_wave_kernel(build)
 
 
+def test_written_arrays_are_placed_by_measurement():
+    """hmx_option place_written: with a reserved slab (hmx_device_reserve) the arrays the sweeps write -- the reduced coefficients, the column
+    sums of the symmetric product, their multi-RHS forms -- are tried at several places of the slab against the stream read meanwhile and
+    stay where the pair runs fastest.  A matter of addresses only: the products are bitwise those of an operator built without it; the
+    statistics say what was measured.  (Run in a process of its own: a slab stays with the process.)"""
+    import subprocess
+    code = r"""
+import numpy as np, htool_amd as hm, json
+from oracle.oracle import hashed_vector
+hm.lib().hmx_device_init(0)
+assert hm.lib().hmx_device_reserve(0, 24 << 30) == 0
+n = 300000
+x = hm.create_geometry("ellipse", n)
+b = hm.ClusterTreeBuilder(); b.set_maximal_leaf_size(100)
+T = b.create_cluster_tree(n, 3, x, 2, 2)
+out = {}
+for place in (0, 1):
+    tb = hm.HMatrixTreeBuilder(1e-4, 10.0, "S", "L"); tb.set_low_rank_generator("sympartialACA")
+    tb.set_option("place_written", place)
+    tb.set_minimal_target_depth(3); tb.set_minimal_source_depth(3)
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T)
+    y = np.zeros(n); hm.internal_add_hmatrix_vector_product("N", 1.0, H, hashed_vector(n, 1), 0.0, y)
+    X, Y = hashed_vector(n * 16, 2).reshape(n, 16), np.zeros((n, 16))
+    H.set_option("sym_multi_rhs", 1)
+    hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, X, 0.0, Y, 16)
+    st = H.stats()
+    out[place] = dict(y=float(np.abs(y).sum()), Y=float(np.abs(Y).sum()), tried=int(st["placed_tried"]), first=st["placed_first_gbps"], chosen=st["placed_gbps"], read=st["placed_read_gbps"], stream=int(st["stream_bytes"]))
+    np.save("/tmp/hmx_place_%d.npy" % place, np.concatenate([y, Y.ravel()]))
+print("RESULT " + json.dumps(out))
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert out["0"]["tried"] == 0 and out["1"]["tried"] >= 1, out  # the operator's R-stream is > 256 MiB: the probe ran
+    assert out["1"]["chosen"] >= out["1"]["first"] > 0 and out["1"]["read"] > out["1"]["chosen"], out
+    assert np.array_equal(np.load("/tmp/hmx_place_0.npy"), np.load("/tmp/hmx_place_1.npy"))  # addresses only
+
+
 @pytest.mark.parametrize("unit_rows", [64, 512])
 @pytest.mark.parametrize("name", ["ball_n2000_partial", "ellipse_n3000_symL_default", "ball_n2000_p2_symU_rank1", "rect_ball1500_disk1000", "ellipse_n4000_p4_rank2"])
 def test_xcd_grouped_launch_order(name, unit_rows, monkeypatch):

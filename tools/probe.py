@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--build-option", action="append", default=[], help="name=value, set before the build (layout / build options)")
     ap.add_argument("--variant", action="append", default=[], help="'default' or comma-separated name=value product options")
     ap.add_argument("--check", action="store_true", help="compare every variant's result with the first variant's")
+    ap.add_argument("--reserve-gb", type=float, default=0.0, help="size of the slab reserved before the build (default: bench.py's rule, 64 KB per point, <= 60 %% of the free memory)")
     ap.add_argument("--move-buffers", action="store_true", help="before every variant after the first: new X / Y tensors and a product with more right-hand sides (the "
                     "operator's work area is then allocated again, elsewhere) -- how much of a difference is the placement of the buffers")
     args = ap.parse_args()
@@ -65,7 +66,7 @@ def main():
     t_dt = {"f64": torch.float64, "f32": torch.float32, "z64": torch.complex128, "c32": torch.complex64}[args.dtype]
     hm.lib().hmx_device_init(0)
     free_b, _ = torch.cuda.mem_get_info(0)
-    hm.lib().hmx_device_reserve(0, int(min(0.6 * free_b, 65536.0 * n * np.dtype(np_dt).itemsize / 8 / max(1, emu))))
+    hm.lib().hmx_device_reserve(0, int(args.reserve_gb * 1e9) if args.reserve_gb > 0 else int(min(0.6 * free_b, 65536.0 * n * np.dtype(np_dt).itemsize / 8 / max(1, emu))))
     gen = hm.InvDistGenerator(3, x, x, 1e-5, 1.0, 1.0, 1.0 if cplx else 0.0, args.sym == "H")
     brank = args.emulate_rank if emu else -1
     t0 = time.time()
