@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 typedef double d2 __attribute__((ext_vector_type(2)));
 template <int WRITE>
 __global__ __launch_bounds__(256) void rw(const d2 *__restrict__ in, double *__restrict__ out, int64_t n, int every, int64_t out_elems) {
@@ -56,6 +57,16 @@ int main() {
     const int64_t n = rbytes / 16, oe = zbytes / 8;
     const int grid = 4096;
     printf("base %p\n", (void *)B);
+    // how the price of the write stream falls with its share, same class (written region next to the read region) against the best of the others
+    {
+        const int64_t ro = 2 * GB;
+        for (int every : {1, 2, 8, 32, 64, 128}) {
+            double same = run(rw<1>, (const d2 *)(B + ro), (double *)(B + ro + rbytes), n, every, oe, grid), best = 0;
+            for (int64_t z = 32 * GB; z + zbytes <= total; z += 24 * GB)
+                best = std::max(best, run(rw<1>, (const d2 *)(B + ro), (double *)(B + z), n, every, oe, grid));
+            printf("written share %.3f %%: %.0f GB/s next to the read region, %.0f GB/s at the best of the other places\n", 100.0 * 512 / (every * 4 * 4096.0), same, best);
+        }
+    }
     // the map: written region every 2 GiB over the whole allocation, for three positions of the read region (1.6 % written)
     for (int64_t ro : {2 * GB, 70 * GB, 134 * GB, 198 * GB, 240 * GB}) {
         printf("read region at %lld GiB; GB/s with the written region at 0, 4, 8, ... GiB:\n", (long long)(ro / GB));
