@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--build-option", action="append", default=[], help="name=value, set before the build (layout / build options)")
     ap.add_argument("--variant", action="append", default=[], help="'default' or comma-separated name=value product options")
     ap.add_argument("--check", action="store_true", help="compare every variant's result with the first variant's")
+    ap.add_argument("--spacer-gb", type=float, default=0.0, help="with --move-buffers: allocate (and keep) this much between two placements of X / Y")
     ap.add_argument("--reserve-gb", type=float, default=0.0, help="size of the slab reserved before the build (default: bench.py's rule, 64 KB per point, <= 60 %% of the free memory)")
     ap.add_argument("--move-buffers", action="store_true", help="before every variant after the first: new X / Y tensors and a product with more right-hand sides (the "
                     "operator's work area is then allocated again, elsewhere) -- how much of a difference is the placement of the buffers")
@@ -99,8 +100,11 @@ def main():
         return m > 0
     b_alg = esz * (st["cgen_dense"] + st["cgen_lowrank"] + mu * (n + H.nb_rows()))
     moves = 0
+    spacers = []
     for var in args.variant or ["default"]:
         if args.move_buffers and ref_done(moves):
+            if args.spacer_gb > 0:  # what torch hands out next lies `spacer_gb` further on (the spacers stay: physical memory is handed out in order)
+                spacers.append(torch.empty(int(args.spacer_gb * (1 << 30)), dtype=torch.uint8, device=dev))
             keep = [torch.empty((3 + 5 * moves) << 20, dtype=torch.uint8, device=dev)]  # shifts what torch hands out next
             X, Y = X.clone(), torch.zeros_like(Y)
             if mu > 1:
