@@ -12,8 +12,8 @@ static int with_buffers(HMat &H, char trans, const scalar *in, scalar *out, int 
     }
     if (H.tmp_in.n < nin)
         HMX_HIP(H.tmp_in.alloc(nin));
-    if (H.tmp_out.n < nout)
-        HMX_HIP(H.tmp_out.alloc(nout));
+    if (H.tmp_out.n < nout) // the product's output while the E-stream is read: the library's own buffer goes where that pair runs fastest (place_written)
+        HMX_HIP(place_written(H.tmp_out, nout, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0));
     HMX_HIP(hipMemcpyAsync(H.tmp_in.d, in, nin * sizeof(scalar), hipMemcpyHostToDevice, st));
     if (!hmx_is_zero(beta))
         HMX_HIP(hipMemcpyAsync(H.tmp_out.d, out, nout * sizeof(scalar), hipMemcpyHostToDevice, st));
@@ -204,8 +204,8 @@ int api_matvec_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar
     const int bin = trans == 'N' ? H.S0 : H.T0, bout = trans == 'N' ? H.T0 : H.S0;
     if (H.tmp_in2.n < (size_t)nin)
         HMX_HIP(H.tmp_in2.alloc(nin));
-    if (H.tmp_out2.n < (size_t)nout)
-        HMX_HIP(H.tmp_out2.alloc(nout));
+    if (H.tmp_out2.n < (size_t)nout) // (the output in cluster numbering: see with_buffers)
+        HMX_HIP(place_written(H.tmp_out2, (size_t)nout, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0));
     hipLaunchKernelGGL(gather_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, pin, bin, din, H.tmp_in2.d, 1);
     if (!hmx_is_zero(beta))
         hipLaunchKernelGGL(gather_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const scalar *)dout, H.tmp_out2.d, 1);
@@ -400,7 +400,7 @@ int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar
     if ((int64_t)H.mm_in.n < tin)
         HMX_HIP(H.mm_in.alloc(tin));
     if ((int64_t)H.mm_out.n < tout)
-        HMX_HIP(H.mm_out.alloc(tout));
+        HMX_HIP(place_written(H.mm_out, tout, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0)); // (see with_buffers)
     hipLaunchKernelGGL(gather_cm_kernel, dim3((unsigned)((tin + 255) / 256)), dim3(256), 0, st, nin, mu, pin, bin, din, H.mm_in.d);
     if (!hmx_is_zero(beta))
         hipLaunchKernelGGL(gather_cm_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, nout, mu, pout, bout, (const scalar *)dout, H.mm_out.d);
