@@ -66,8 +66,11 @@ __global__ void pack_lr_reduce_kernel(PackLrArgs P, int64_t npairs) {
     const int n1  = P.swapped[b] ? P.s_size[b] : P.t_size[b];
     const int rel = P.range_off[S] + P.origin - P.s_off[b];
     const int64_t *cross = P.cross_off + P.colptr[b];
+    // consecutive threads take consecutive COLUMNS of one row: the leaf's r coefficients of a row are adjacent in the (row-major) chunk, one
+    // run of r elements per row instead of 64 scattered 8-byte stores per wave; the reads (r crosses, neighbouring elements by neighbouring
+    // rows) come out of L1 / L2.  (With the rows on consecutive threads this kernel moved its 15.7 GB at 1.1 TB/s.)
     for (int e = threadIdx.x; e < r * len; e += blockDim.x) {
-        const int k = e / len, i = e - k * len;
+        const int i = e / r, k = e - i * r;
         const scalar *src = P.pool + cross[k] + (P.swapped[b] ? 0 : n1); // V(k,:) = vv_k, or uu_k when swapped
         P.stream[rstream_index(P.range_base[S], len, C, P.range_cw[S], i, col + k)] = P.conjflag[b] ? hmx_conj(src[rel + i]) : src[rel + i];
     }
