@@ -427,7 +427,7 @@ def main():
     # One slab from the driver before anything is timed (hmx_device_reserve): hipMalloc stalls for seconds while the driver scrubs
     # what the PREVIOUS process released (tools/malloc_after_exit.hip), and a build allocates its two largest arrays right there.
     # 60 % of what is free (round 5; before: 64 KB per point): the slab is also where the library looks for a place for the small arrays its
-    # sweeps WRITE -- a write stream costs a streaming read 12-16 % when both lie in the same third of the physical memory, 7-10 % otherwise
+    # sweeps WRITE -- a write stream costs a streaming read 16-23 % when both lie in the same third of the physical memory, 7-10 % otherwise
     # (hmx_option place_written, tools/placement_rw.hip), and a slab of a third of the memory or less is often all of one kind;
     # whatever does not fit is allocated as before, `compress.malloc_s` says what hipMalloc still cost.  HMX_BENCH_RESERVE_GB=0: off.
     free_b, _ = torch.cuda.mem_get_info(local_rank)

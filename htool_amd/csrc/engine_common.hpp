@@ -413,7 +413,7 @@ static hipError_t hmx_mem_largest(size_t *largest_b) {
 }
 
 // ---- where the WRITTEN arrays of a product go --------------------------------------------------------------------------------------
-// A streaming read loses 12-16 % of its rate to a write stream of 0.4-1.6 % of its bytes when both lie in the same third of the physical
+// A streaming read loses 16-23 % of its rate to a write stream of 0.4-1.6 % of its bytes when both lie in the same third of the physical
 // memory (HBM3E stacks of 12 dies: three groups per channel), and 7-10 % when they do not (tools/placement_rw.hip).  Which third a virtual
 // address belongs to is the driver's business (a 64 GB slab is one third, or pieces of two or three), so it is MEASURED: the small arrays
 // the sweeps write (the reduced coefficients a, partial sums, column sums) are tried at a few places of the reserved slab against a sample

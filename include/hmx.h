@@ -261,7 +261,7 @@ typedef enum {
     HMX_OPT_PLACE_WRITTEN     = 39  /* product 1     the small arrays the sweeps WRITE (reduced coefficients, partial sums) are
                                                      tried at a few places of the reserved slab (hmx_device_reserve) against the
                                                      stream read meanwhile and stay where the pair runs fastest: on MI355X a write
-                                                     stream costs a streaming read 12-16 % in the same third of the physical memory,
+                                                     stream costs a streaming read 16-23 % in the same third of the physical memory,
                                                      7-10 % elsewhere (0: wherever first fit puts them)                       HMX_PLACE_WRITTEN    */
 } hmx_option;
 int hmx_hmatrix_set_option(hmx_hmatrix *, int option /* hmx_option */, double value);
@@ -517,8 +517,9 @@ int hmx_device_trim_cache(void);
 /* Takes `bytes` of device memory from the driver ONCE; device arrays of 1 MiB and more that libhmx allocates afterwards (cross pool,
  * streams, views, work vectors) are carved out of such slabs before hipMalloc is asked, and return to them when released.  For callers
  * that build operators repeatedly or time a build: on this platform hipMalloc stalls for seconds while the driver scrubs memory that
- * was released shortly before, by this or by the previous process.  May be called several times (one more slab each);
- * hmx_device_trim_cache frees the slabs nothing lives in. */
+ * was released shortly before, by this or by the previous process.  A slab is also where HMX_OPT_PLACE_WRITTEN looks for a good place for
+ * the arrays the products write: a generous one (half of the free memory) offers addresses of more than one kind.  May be called
+ * several times (one more slab each); hmx_device_trim_cache frees the slabs nothing lives in. */
 int hmx_device_reserve(int device_id, int64_t bytes);
 /* Wall time (seconds) this process has spent inside hipMalloc on behalf of libhmx so far: large allocations sporadically take seconds
  * on this platform, callers that time builds report it separately. */
