@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--callback-threads", type=int, default=0, help="host threads that call the generator (0: all cores, at most 64)")
     ap.add_argument("--no-callback-build", action="store_true", help="do not time a second build of the operator through the host-generator route")
     ap.add_argument("--no-reference", action="store_true", help="skip the timing of htool itself (oracle/_ref/ref_driver) on the host cores")
+    ap.add_argument("--output-placement", default="operator", choices=["operator", "torch"], help="where the product's output vector comes from: the operator's own allocator (placed where its sweeps write fastest) or torch.zeros")
     ap.add_argument("--option", action="append", default=[], help="engine option name=value for the operator (hmx_hmatrix_set_option; htool_amd._lib.OPTIONS), e.g. sym_multi_rhs=1")
     ap.add_argument("--dump-product", default=None, help="after the timed region: y = A x for x = the oracle's hashed_vector(n, 1), through the step's own path; rank 0 writes "
                     "y (partition numbering) and the cluster permutation to this .npz (tests compare it with the reference's fixtures)")
@@ -94,12 +95,29 @@ def spawn_ranks_if_needed(args):
     sock.close()
     procs, out0 = [], None
     import tempfile
+    # rank 0 writes the line of the first COMPLETE measurement (the plain exchange) here as soon as it exists: whatever happens afterwards
+    # -- a rank that aborts inside an untested exchange variant, a hang the watchdog cannot report -- the parent still has a line to relay
+    side_fd, side_path = tempfile.mkstemp(prefix="hmx_bench_plain_", suffix=".json")
+    os.close(side_fd)
+
+    def complete_line(raw):
+        for ln in reversed(raw.decode(errors="replace").splitlines()):
+            ln = ln.strip()
+            if ln.startswith("{") and ln.endswith("}"):
+                try:
+                    json.loads(ln)
+                    return ln
+                except ValueError:
+                    pass
+        return None
+
     with tempfile.TemporaryFile() as cap:  # rank 0's stdout (the JSON line); a pipe nobody drains while we poll could fill up
         for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HMX_BENCH_SIDE_FILE=side_path)
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             env.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=cap if r == 0 else subprocess.DEVNULL))
+            procs.append(subprocess.Popen([sys.executable, os.environ.get("HMX_BENCH_CHILD_SCRIPT", os.path.abspath(__file__))] + sys.argv[1:], env=env,  # (the variable: tests of this supervisor with stand-in ranks)
+                                          stdout=cap if r == 0 else subprocess.DEVNULL))
         # supervise: the first rank that fails (OOM, RCCL initialisation) takes the others down instead of leaving them in a collective
         # for ever; an overall limit bounds a hang (HMX_BENCH_SPAWN_TIMEOUT seconds, default 3600)
         deadline = time.time() + float(os.environ.get("HMX_BENCH_SPAWN_TIMEOUT", 3600))
@@ -111,9 +129,15 @@ def spawn_ranks_if_needed(args):
             bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
             if bad or time.time() > deadline:
                 failed = ("rank %d exited with code %s" % (bad[0], rcs[bad[0]])) if bad else "time limit reached"
-                for p in procs:
+                for p in procs[1:]:
                     if p.poll() is None:
                         p.terminate()
+                # rank 0 gets a few seconds for its own way out (its watchdog reports the plain exchange, or it finishes) before it is stopped too
+                t_grace = time.time() + float(os.environ.get("HMX_BENCH_RANK0_GRACE", 8))
+                while procs[0].poll() is None and time.time() < t_grace:
+                    time.sleep(0.1)
+                if procs[0].poll() is None:
+                    procs[0].terminate()
                 t_kill = time.time() + 10
                 while any(p.poll() is None for p in procs) and time.time() < t_kill:
                     time.sleep(0.1)
@@ -125,8 +149,19 @@ def spawn_ranks_if_needed(args):
         rcs = [p.wait() for p in procs]
         cap.seek(0)
         out0 = cap.read()
+    try:
+        with open(side_path, "rb") as fh:
+            side = fh.read()
+        os.unlink(side_path)
+    except OSError:
+        side = b""
     if failed:
-        print("bench.py: %s; remaining ranks stopped" % failed, file=sys.stderr)
+        # the measurement that was complete before the failure is not thrown away: rank 0's own line if it got one out, else the side file
+        line = complete_line(out0) or complete_line(side)
+        print("bench.py: %s; remaining ranks stopped%s" % (failed, "; relaying the measurement completed before the failure" if line else ""), file=sys.stderr)
+        if line:
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
         sys.exit(1)
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
@@ -356,6 +391,10 @@ class Watchdog:
                 stage, fb = self.stage, self.fallback
             if late:
                 self.log("WATCHDOG: stage '%s' did not finish in time -- %s" % (stage, "reporting the plain exchange measured before it" if fb else "no complete measurement yet"))
+                # the fallback is host-only code (it formats numbers measured earlier); should it block all the same, this second timer ends
+                # the process: the parent then relays the side file the plain measurement was written to (spawn_ranks_if_needed)
+                import threading
+                threading.Timer(5.0, lambda: os._exit(4)).start()
                 try:
                     if fb:
                         fb(stage)
@@ -469,12 +508,22 @@ def main():
     A.add_global_to_local_operator(D.RestrictedGlobalToLocalHMatrix(H))
     xin = torch.from_numpy(np.random.default_rng(1).random(n).astype(np_dt)).to(dev)  # partition numbering, resident in HBM
     y = torch.zeros(n, dtype=t_dt, device=dev)
-    y_loc = torch.zeros(H.nb_rows(), dtype=t_dt, device=dev)
+
+    def output_buffer(shape):
+        """The product's output: resident in HBM either way; by default from the operator (hmx_hmatrix_alloc_vector: where its sweeps write
+        fastest -- the expand kernels' two speeds are where y lies relative to the E-streams), --output-placement torch: torch.zeros"""
+        if args.output_placement == "operator":
+            try:
+                return H.empty_output(shape, args.trans if args.trans in ("N", "T", "C") else "N")
+            except Exception as e:  # noqa: BLE001
+                log("operator-placed output unavailable (%r): torch.zeros" % (e,))
+        return torch.zeros(shape, dtype=t_dt, device=dev)
+    y_loc = output_buffer(H.nb_rows())
 
     mu = args.mu
     if mu > 1:
         Xmu = torch.from_numpy(np.random.default_rng(2).random((n, mu)).astype(np_dt)).to(dev)
-        Ymu = torch.zeros((H.nb_rows(), mu), dtype=t_dt, device=dev)
+        Ymu = output_buffer((H.nb_rows(), mu))
 
     # N > 1, single vector: the C-level DistributedOperator (one C call per step, its own RCCL communicator).  Every rank must take
     # the same path: the outcome of the set-up is agreed on over the process group before anything is timed.
@@ -528,6 +577,10 @@ def main():
     b_alg = torch.tensor([esz * (st["cgen_dense"] + st["cgen_lowrank"] + mu * (n + H.nb_rows()))], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(b_alg, op=dist.ReduceOp.SUM)
+    # a HOST number from here on: the watchdog's fallback assembles the JSON line while a collective may hang on the device -- nothing on
+    # that path may touch torch or HIP (a device-to-host copy would wait for the stream the hung kernel sits on)
+    b_alg_f = float(b_alg.item())
+    del b_alg
     wd = Watchdog(log) if use_dist else None
     stage_limit = float(os.environ.get("HMX_BENCH_STAGE_TIMEOUT", 180))  # seconds a stage with collectives may take before the watchdog reports the last complete measurement
 
@@ -624,15 +677,16 @@ def main():
         return compress
 
     def assemble(ms_per_step, dist_info, graphed):
-        value = float(b_alg.item()) / (ms_per_step * 1e-3) / 1e9
+        value = b_alg_f / (ms_per_step * 1e-3) / 1e9
         cfg = dict(mu=mu, sym=args.sym, trans=args.trans, recompressed=bool(args.recompress), workload="H-matvec N=%d %s, eta=%g, %s eps=%g, leaf %d, %s, kernel 1/(1e-5+r), min block depth %d" % (n, {"f64": "fp64", "f32": "fp32", "z64": "complex fp64", "c32": "complex fp32"}[args.dtype], args.eta, "partialACA" if args.sym == "N" else "sympartialACA (S,L)", args.eps, args.leaf, args.geom, d),
                    parallelism=("row-partition x%d + all-gather%s" % (world, ", local kernels replayed from a HIP graph" if graphed else (", hmx_dist_* (C)" if native is not None else ""))) if part else "single GPU",
                    n_dense=int(st["n_dense"]), n_lowrank=int(st["n_lowrank"]), rank_mean=st["rank_mean"],
-                   algorithmic_GB=float(b_alg.item()) / 1e9, hbm_roofline_frac=value / (8000.0 * world),
+                   algorithmic_GB=b_alg_f / 1e9, hbm_roofline_frac=value / (8000.0 * world),
                    build_s=dict(geometry=t_geom, cluster_tree=t_tree, device_total=t_build, aca=st["t_compress_s"],
                                 **{k: round(v, 4) for k, v in getattr(H, "_build_walltimes", {}).items()}))
         if args.option:
             cfg["options"] = list(args.option)
+        cfg["output_placement"] = args.output_placement
         if use_dist:  # a SCALE record explains itself: how many ranks the communicator really has, which exchange ran, what each variant cost
             cfg.update(rccl_ranks=dist_info.get("rccl_ranks"), communicator=dist_info.get("communicator"), dist_impl=dist_info.get("impl"),
                        exchange_variant=dist_info.get("exchange_variant", "all-gather after the product"), exchange_trials_ms=dist_info.get("exchange_trials_ms"),
@@ -644,16 +698,17 @@ def main():
             o["dist"] = dist_info
         return o
 
+    def json_clean(v):  # strict JSON: no NaN / Infinity
+        if isinstance(v, dict):
+            return {k: json_clean(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [json_clean(x) for x in v]
+        if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
+            return None
+        return v
+
     def emit(o):
-        def clean(v):  # strict JSON: no NaN / Infinity
-            if isinstance(v, dict):
-                return {k: clean(x) for k, x in v.items()}
-            if isinstance(v, (list, tuple)):
-                return [clean(x) for x in v]
-            if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
-                return None
-            return v
-        os.write(json_fd, (json.dumps(clean(o)) + "\n").encode())
+        os.write(json_fd, (json.dumps(json_clean(o)) + "\n").encode())
 
 
     roofline = compress = None
@@ -697,19 +752,28 @@ def main():
             plain_ms = guarded("plain exchange, timed", lambda: measure(args.steps))
             log("plain exchange (all-gather after the product): %.4f ms per step over %d steps" % (plain_ms, args.steps))
 
-            def report_plain(stage):
+            def vname(k):
+                return "allreduce" if k[2] else "%d%s" % (k[0], "+p2p" if k[1] else "")
+
+            def plain_line(note):
+                return assemble(plain_ms, dict(dist_info, overlap_chunks=0, point_to_point=False, output_collective="exchange of the slices", exchange_variant="0",
+                                               exchange_trials_ms={vname(k): v for k, v in trials.items()}, exchange_failures=failures, watchdog=note), False)
+
+            def report_plain(stage):  # host-only: numbers measured earlier, no torch / HIP call (a collective may be hanging on the device)
                 if rank == 0:
-                    emit(assemble(plain_ms, dict(dist_info, overlap_chunks=0, point_to_point=False, output_collective="exchange of the slices", exchange_variant="0",
-                                                 exchange_trials_ms={vname(k): v for k, v in trials.items()}, exchange_failures=failures,
-                                                 watchdog="stage '%s' did not finish within %g s: the timing of the plain exchange, measured before it, is reported" % (stage, stage_limit)), False))
+                    emit(plain_line("stage '%s' did not finish within %g s: the timing of the plain exchange, measured before it, is reported" % (stage, stage_limit)))
+            trials, failures = {}, {}
             wd.set_fallback(report_plain)
+            if rank == 0 and os.environ.get("HMX_BENCH_SIDE_FILE"):  # the parent relays this if the run dies before its own line (spawn_ranks_if_needed)
+                try:
+                    with open(os.environ["HMX_BENCH_SIDE_FILE"], "w") as fh:
+                        fh.write(json.dumps(json_clean(plain_line("side file: written when the plain exchange had been timed; the run ended before its own line"))) + "\n")
+                except OSError as e:
+                    log("side file not written: %r" % (e,))
             pin_c, pin_p = os.environ.get("HMX_DIST_OVERLAP"), os.environ.get("HMX_DIST_P2P")
             chunk_choices = [int(pin_c)] if pin_c is not None else [0, 2, 4]
             p2p_choices = [bool(int(pin_p))] if pin_p is not None else [False, True]
-            trials, failures = {}, {}
 
-            def vname(k):
-                return "allreduce" if k[2] else "%d%s" % (k[0], "+p2p" if k[1] else "")
 
             def agree(ok):  # a variant counts only when it worked on EVERY rank (over the torch process group: not the communicator under test)
                 flag = torch.tensor([1 if ok else 0], device=flag_dev)

@@ -117,6 +117,8 @@ SYMBOLS = [
     ("hmx_hmatrix_set_callback_threads", C.c_int, [_vp, C.c_int]),
     ("hmx_host_cores", C.c_int, []),
     ("hmx_hmatrix_prepare", C.c_int, [_vp, C.c_char, C.c_int]),
+    ("hmx_hmatrix_alloc_vector", C.c_int, [_vp, C.c_char, C.c_int64, C.POINTER(C.c_void_p)]),
+    ("hmx_hmatrix_free_vector", C.c_int, [_vp, C.c_void_p]),
     ("hmx_device_alloc_count", C.c_int64, []),
     ("hmx_hmatrix_get_blocks", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     ("hmx_hmatrix_get_blocks_s", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
@@ -168,6 +170,8 @@ SYMBOLS = [
     ("hmx_device_trim_cache", C.c_int, []),
     ("hmx_device_malloc_seconds", C.c_double, []),
     ("hmx_device_reserve", C.c_int, [C.c_int, C.c_int64]),
+    ("hmx_device_slab_alloc_at", C.c_int, [C.c_int, C.c_int64, C.c_double, C.POINTER(C.c_void_p)]),
+    ("hmx_device_slab_free", C.c_int, [C.c_int, C.c_void_p, C.c_int64]),
     ("hmx_device_copy_bandwidth", C.c_int, [C.c_int, C.c_int64, C.c_int, _dp]),
     ("hmx_device_read_bandwidth", C.c_int, [C.c_int, C.c_int64, C.c_int, _dp]),
 ]

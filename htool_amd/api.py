@@ -367,6 +367,22 @@ def _stream_ptr(v):
     return None
 
 
+class _OwnedVector:
+    """__cuda_array_interface__ view of a vector hmx_hmatrix_alloc_vector handed out (torch.as_tensor keeps this object alive with the tensor)."""
+
+    def __init__(self, owner, ptr, shape, dt):
+        self._owner, self._ptr = owner, ptr
+        self.__cuda_array_interface__ = dict(shape=shape, typestr=dt.str, data=(ptr, False), version=2, strides=None)
+
+    def __del__(self):
+        try:
+            if self._ptr and getattr(self._owner, "_h", None):
+                lib().hmx_hmatrix_free_vector(self._owner._h, self._ptr)
+        except Exception:
+            pass
+        self._ptr = None
+
+
 class HMatrix:
     """Compressed operator resident in HBM."""
 
@@ -406,6 +422,18 @@ class HMatrix:
         """Build / allocate now everything products with this `trans` and this many right-hand sides need (second stream layouts, work
         vectors, staging buffers): afterwards they allocate nothing (hmx_hmatrix_prepare)."""
         check(lib().hmx_hmatrix_prepare(self._h, trans.encode(), int(mu)))
+
+    def empty_output(self, shape, trans="N"):
+        """A zero-filled torch tensor (this operator's coefficient type, on its device) for products of this operator to WRITE: any device tensor
+        is a valid output, one from here lies where the operator's sweeps write fastest (hmx_hmatrix_alloc_vector).  The memory belongs to the
+        operator and lives as long as the tensor or the operator, whichever ends first -- keep the operator alive while the tensor is in use."""
+        import torch
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        dt = np.dtype(self.dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        check(lib().hmx_hmatrix_alloc_vector(self._h, trans.encode(), nbytes, C.byref(p)))
+        return torch.as_tensor(_OwnedVector(self, p.value, shape, dt), device="cuda:%d" % getattr(self, "_device", 0))
 
     def save(self, path):
         """Binary dump of the compressed operator (hmx_hmatrix_save); reload with HMatrixTreeBuilder.load()."""
@@ -693,6 +721,7 @@ class HMatrixTreeBuilder:
         t_create = time.perf_counter()
         check(getattr(lib(), "hmx_hmatrix_create" + _PREC[prec[0]]["sfx"])(bt, device, C.byref(h)))
         H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
+        H._device = int(device)
         t_create = time.perf_counter() - t_create
         H._tree_parameters = dict(eta=self._eta, epsilon=self._eps, min_target_depth=self._mint, min_source_depth=self._mins)
         H._block_tree_walltime = t_bt
@@ -745,6 +774,7 @@ class HMatrixTreeBuilder:
             lib().hmx_block_tree_destroy(bt)
             raise
         H = HMatrix(bt, h, target_root_cluster_tree, source_root_cluster_tree)
+        H._device = int(device)
         H._tree_parameters = dict(eta=self._eta, epsilon=self._eps, min_target_depth=self._mint, min_source_depth=self._mins)
         return H
 

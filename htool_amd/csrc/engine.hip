@@ -96,7 +96,7 @@ static __global__ __launch_bounds__(256) void placement_probe_kernel(const doubl
 // cand = nullptr: the read alone.  On MI355X the pair runs 12-16 % faster when the two lie in different thirds of the physical memory
 // (tools/placement_rw.hip) -- which third a virtual address belongs to is the driver's business, so it is measured.
 // The candidate's contents are overwritten.
-double placement_probe(const void *stream, size_t stream_bytes, void *cand, size_t cand_bytes, hipStream_t st) {
+double placement_probe(const void *stream, size_t stream_bytes, void *cand, size_t cand_bytes, hipStream_t st, hipEvent_t after) {
     const int nslices = 8, grid = 2048;
     int64_t n_total   = (int64_t)(stream_bytes / 16);
     int64_t slice     = std::min<int64_t>(n_total / nslices, (int64_t)(256u << 20) / 16); // <= 8 x 256 MiB read per launch
@@ -106,6 +106,8 @@ double placement_probe(const void *stream, size_t stream_bytes, void *cand, size
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         return 0.0;
+    if (after)
+        (void)hipStreamWaitEvent(st, after, 0);
     auto launch = [&]() {
         hipLaunchKernelGGL(placement_probe_kernel, dim3(grid), dim3(256), 0, st, (const double2 *)stream, n_total, nslices, slice, (double *)cand, (int64_t)(cand_bytes / 8));
     };
@@ -332,8 +334,9 @@ int hmx_hmatrix_stats_sized(const hmx_hmatrix *H, hmx_stats *out, size_t struct_
     return HMX_OK;
 }
 #undef hmx_hmatrix_stats
-// binaries built before hmx_hmatrix_stats became a macro over the sized call: the first version's fields only
-int hmx_hmatrix_stats(const hmx_hmatrix *H, hmx_stats *out) { return hmx_hmatrix_stats_sized(H, out, offsetof(hmx_stats, transposed_bytes)); }
+// binaries built before hmx_hmatrix_stats became a macro over the sized call: the struct as the last header without the macro declared it
+// (everything before placed_read_gbps -- transposed_bytes and expanded_bytes included: that header had them)
+int hmx_hmatrix_stats(const hmx_hmatrix *H, hmx_stats *out) { return hmx_hmatrix_stats_sized(H, out, offsetof(hmx_stats, placed_read_gbps)); }
 int hmx_hmatrix_set_profiling(hmx_hmatrix *H, int enabled) { HMX_ALL(H, api_set_profiling, enabled); }
 int hmx_hmatrix_last_kernel_times(const hmx_hmatrix *H, int max, const char **names, float *ms) {
     if (!H)
@@ -485,6 +488,8 @@ int hmx_hmatrix_matmat_row_major_c(hmx_hmatrix *H, char trans, const float *alph
 }
 
 int hmx_hmatrix_prepare(hmx_hmatrix *H, char trans, int mu) { HMX_ALL(H, api_prepare, trans, mu); }
+int hmx_hmatrix_alloc_vector(hmx_hmatrix *H, char trans, int64_t bytes, void **ptr) { HMX_ALL(H, api_alloc_vector, trans, bytes, ptr); }
+int hmx_hmatrix_free_vector(hmx_hmatrix *H, void *ptr) { HMX_ALL(H, api_free_vector, ptr); }
 int hmx_hmatrix_release_factors(hmx_hmatrix *H, int with_transposed) { HMX_ALL(H, api_release_factors, with_transposed); }
 int hmx_hmatrix_save(const hmx_hmatrix *H, const char *path) { HMX_ALL(H, api_save, path); }
 int hmx_hmatrix_load(const hmx_block_tree *bt, int device_id, const char *path, hmx_hmatrix **out) {
@@ -1639,6 +1644,36 @@ int hmx_device_reserve(int device_id, int64_t bytes) {
         (void)hipGetLastError();
         set_error("hmx_device_reserve: hipMalloc of the slab failed");
         return HMX_ERR_HIP;
+    }
+    return HMX_OK;
+}
+
+int hmx_device_slab_alloc_at(int device_id, int64_t bytes, double frac, void **ptr) {
+    const int rc = ensure_device(device_id);
+    if (rc != HMX_OK)
+        return rc;
+    if (!ptr || bytes <= 0 || !(frac >= 0.0 && frac <= 1.0)) {
+        set_error("hmx_device_slab_alloc_at: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    size_t got = 0;
+    void *p    = DeviceSlabs::get().take_at(device_id, (size_t)bytes, frac, &got);
+    if (!p) {
+        set_error("hmx_device_slab_alloc_at: no reserved slab has room (hmx_device_reserve)");
+        return HMX_ERR_STATE;
+    }
+    *ptr = p;
+    return HMX_OK;
+}
+int hmx_device_slab_free(int device_id, void *ptr, int64_t bytes) {
+    const int rc = ensure_device(device_id);
+    if (rc != HMX_OK)
+        return rc;
+    HMX_HIP(hipDeviceSynchronize());
+    const size_t need = ((size_t)bytes + DeviceSlabs::GRAIN - 1) / DeviceSlabs::GRAIN * DeviceSlabs::GRAIN;
+    if (!ptr || bytes <= 0 || !DeviceSlabs::get().give_back(ptr, need)) {
+        set_error("hmx_device_slab_free: not a range of a reserved slab");
+        return HMX_ERR_INVALID;
     }
     return HMX_OK;
 }

@@ -31,6 +31,8 @@ int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar
 int api_set_profiling(HMat *H, int enabled);
 int api_last_kernel_times(const HMat *H, int max, const char **names, float *ms);
 int api_prepare(HMat *Hp, char trans, int mu);
+int api_alloc_vector(HMat *Hp, char trans, int64_t bytes, void **ptr);
+int api_free_vector(HMat *Hp, void *ptr);
 int api_device_of(const HMat *H);   // device the operator lives on
 int api_root(const HMat *H, int32_t *t_off_size_s_off_size);
 void api_destroy(HMat *H);

@@ -1391,7 +1391,11 @@ static int api_compress_impl(HMat *Hp, int compressor, double epsilon, int reqra
     } else {
         H.dense_stage.release();
     }
-    int rc = build_streams(H);
+    int rc;
+    {
+        ProbeScope probes(H);
+        rc = build_streams(H);
+    }
     phase("stream layout + packing");
     if (rc != HMX_OK)
         return rc;
@@ -1486,6 +1490,7 @@ int api_recompress(HMat *Hp, double epsilon) {
     for (int32_t b : order)
         H.leaves[b].rank = ranks[b];
     const hmx_stats keep = H.stats;
+    ProbeScope probes(H);
     const int rc         = build_streams(H);
     H.stats.n_false_positive = keep.n_false_positive;
     H.stats.t_compress_s     = keep.t_compress_s;
@@ -1588,5 +1593,6 @@ int api_finalize(HMat *Hp) {
     if (!H.has_kernel) { // pack_dense never evaluates the generator on this path, but needs valid pointers
         H.ks = KernelSpec{0, 3, 0, 0, 1, 0, 0, 0};
     }
+    ProbeScope probes(H);
     return build_streams(H);
 }

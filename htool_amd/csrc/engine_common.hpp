@@ -126,6 +126,7 @@ struct DeviceSlabs {
     };
     std::mutex mu;
     std::vector<Slab> slabs;
+    std::atomic<long long> generation{0}; // changes when a slab comes or goes: what was measured about places of the old ones is void (PlacementCache)
     static constexpr size_t GRAIN = size_t(2) << 20;
     static DeviceSlabs &get() {
         static DeviceSlabs s;
@@ -141,6 +142,7 @@ struct DeviceSlabs {
         Slab s{static_cast<char *>(p), bytes, dev, {}, 0};
         s.free_at[0] = bytes;
         slabs.push_back(std::move(s));
+        generation++;
         return hipSuccess;
     }
     void *take(int dev, size_t bytes, size_t *got) {
@@ -256,6 +258,7 @@ struct DeviceSlabs {
             if (slabs[i].in_use == 0) {
                 (void)hipFree(slabs[i].base);
                 slabs.erase(slabs.begin() + i);
+                generation++;
             } else {
                 kept += slabs[i].bytes;
                 i++;
@@ -419,35 +422,123 @@ static hipError_t hmx_mem_largest(size_t *largest_b) {
 // the sweeps write (the reduced coefficients a, partial sums, column sums) are tried at a few places of the reserved slab against a sample
 // of the stream that is read while they are written, and stay where the pair runs fastest.  Without a reserved slab (hmx_device_reserve)
 // nothing is tried: the driver decides.
-double placement_probe(const void *stream, size_t stream_bytes, void *cand, size_t cand_bytes, hipStream_t st); // engine.hip
+// Round 6: probes run in builds only (hmx_hmatrix_compress / finalize / recompress), on a stream of their own that waits for what the build
+// has queued -- never inside a product call, never on the null stream.  A build leaves the winning place of the arrays written next to its
+// E- and R-streams in the operator (HMat::place_e / place_r); arrays a product allocates later (work areas of the multi-RHS and host-memory
+// entry points) go there without measuring anything (place_like).  What was measured is remembered per slab and stream position
+// (PlacementCache): an operator rebuilt at the same place -- parameter sweeps, bench.py's second build -- launches no probe at all.
+double placement_probe(const void *stream, size_t stream_bytes, void *cand, size_t cand_bytes, hipStream_t st, hipEvent_t after); // engine.hip
 struct PlacementReport {
     double read_only = 0, first = 0, chosen = 0; // GB/s of the probe: the stream alone, with the array where first fit put it, where it stays
-    int tried = 0;
+    int tried = 0;                               // candidates probed by THIS call (0: nothing measured -- no slab, disabled, or a cache hit)
+    double frac = -1;                            // where the array stays: fraction of the slab's extent handed to take_at, -1 = where first fit put it
+    bool cached = false;
+    bool known  = false;                         // measured now or before: `frac` means something
 };
+struct PlacementCache {
+    struct Key {
+        uintptr_t stream_gb;
+        size_t bytes_gb;
+        bool operator<(const Key &o) const { return stream_gb != o.stream_gb ? stream_gb < o.stream_gb : bytes_gb < o.bytes_gb; }
+    };
+    std::mutex mu;
+    std::map<Key, PlacementReport> seen;
+    long long generation = -1; // DeviceSlabs::generation the entries belong to
+    void sync_generation() {   // (under mu) a slab came or went: the same virtual addresses may now be other memory
+        const long long g = DeviceSlabs::get().generation.load();
+        if (g != generation) {
+            seen.clear();
+            generation = g;
+        }
+    }
+    static PlacementCache &get() {
+        static PlacementCache c;
+        return c;
+    }
+    static Key key(const void *stream, size_t bytes) { return Key{(uintptr_t)stream >> 28, bytes >> 28}; } // 256 MiB: the classes come in pieces of >= 8 GiB
+    bool find(const void *stream, size_t bytes, PlacementReport *r) {
+        std::lock_guard<std::mutex> lock(mu);
+        sync_generation();
+        auto it = seen.find(key(stream, bytes));
+        if (it == seen.end())
+            return false;
+        *r = it->second;
+        return true;
+    }
+    void store(const void *stream, size_t bytes, const PlacementReport &r) {
+        std::lock_guard<std::mutex> lock(mu);
+        sync_generation();
+        seen[key(stream, bytes)] = r;
+    }
+};
+// the array at the place `frac` of a slab (-1 or no room there: wherever first fit puts it), zero-filled on `st`; measures nothing
 template <typename T>
-static hipError_t place_written(DArr<T> &arr, size_t count, const void *stream, size_t stream_bytes, bool enabled, PlacementReport *rep = nullptr) {
-    const hipError_t e0 = arr.alloc(count);
-    if (e0 != hipSuccess || !enabled || count == 0 || !stream || stream_bytes < (size_t(256) << 20) || !DeviceSlabs::get().owns(arr.d) || !DeviceSlabs::get().owns(stream))
-        return e0;
-    const size_t bytes = count * sizeof(T);
+static hipError_t place_like(DArr<T> &arr, size_t count, double frac, hipStream_t st) {
+    hipError_t e = hipErrorOutOfMemory;
+    if (frac >= 0 && count * sizeof(T) >= (size_t(1) << 20))
+        e = arr.alloc_at(count, frac);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = arr.alloc(count);
+    }
+    if (e != hipSuccess || count == 0)
+        return e;
+    return hipMemsetAsync(arr.d, 0, count * sizeof(T), st);
+}
+// `after`: an event recorded behind the work the probe must not overlap with (a build's pack kernels on the null stream); the probes run on a
+// stream of their own.  The array is zero-filled afterwards (the probe writes sums of stream bytes into its candidates).
+template <typename T>
+static hipError_t place_written(DArr<T> &arr, size_t count, const void *stream, size_t stream_bytes, bool enabled, PlacementReport *rep = nullptr, hipEvent_t after = nullptr) {
     PlacementReport r;
-    r.read_only = placement_probe(stream, stream_bytes, nullptr, 0, nullptr);
-    r.first = r.chosen = placement_probe(stream, stream_bytes, arr.d, bytes, nullptr);
+    const size_t bytes = count * sizeof(T);
+    const bool eligible = enabled && count > 0 && stream && stream_bytes >= (size_t(256) << 20) && bytes >= (size_t(1) << 20) && DeviceSlabs::get().owns(stream);
+    if (eligible && PlacementCache::get().find(stream, stream_bytes, &r)) { // measured before for a stream at this place: no probe
+        r.tried  = 0;
+        r.cached = true;
+        r.known  = true;
+        if (rep)
+            *rep = r;
+        return place_like(arr, count, r.frac, nullptr);
+    }
+    const hipError_t e0 = arr.alloc(count);
+    if (e0 != hipSuccess || !eligible || !DeviceSlabs::get().owns(arr.d)) {
+        if (e0 == hipSuccess && count > 0)
+            (void)hipMemsetAsync(arr.d, 0, bytes, nullptr);
+        return e0;
+    }
+    hipStream_t ps = nullptr;
+    if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return hipMemsetAsync(arr.d, 0, bytes, nullptr);
+    }
+    r.read_only = placement_probe(stream, stream_bytes, nullptr, 0, ps, after);
+    r.first = r.chosen = placement_probe(stream, stream_bytes, arr.d, bytes, ps, nullptr);
     r.tried = 1;
-    if (r.first > 0 && r.first < 0.915 * r.read_only) // (different thirds: 0.90-0.93 of the read alone at 1.6 % written; the same third: 0.77-0.80)
+    // different thirds: 0.90-0.93 of the read alone at 1.6 % written (0.85-0.88 on operators' streams); the same third: 0.75-0.80.  The search
+    // ends with the first place that is out of the stream's third: another one would not be better
+    auto good = [&] { return r.chosen >= 0.85 * r.read_only || r.chosen >= 1.10 * r.first; };
+    if (r.first > 0 && !good())
         for (double frac : {1.0, 0.5, 0.75, 0.25, 0.0, 0.875, 0.625, 0.375, 0.125}) {
             DArr<T> cand;
             if (cand.alloc_at(count, frac) != hipSuccess)
                 continue;
-            const double rate = placement_probe(stream, stream_bytes, cand.d, bytes, nullptr);
+            const double rate = placement_probe(stream, stream_bytes, cand.d, bytes, ps, nullptr);
             r.tried++;
             if (rate > 1.03 * r.chosen) {
+                (void)hipStreamSynchronize(ps);
                 arr.swap(cand); // (the loser goes back to the slab when `cand` leaves the scope)
                 r.chosen = rate;
+                r.frac   = frac;
             }
-            if (r.chosen >= 0.915 * r.read_only)
+            if (good())
                 break;
         }
+    (void)hipMemsetAsync(arr.d, 0, bytes, ps);
+    (void)hipStreamSynchronize(ps);
+    (void)hipStreamDestroy(ps);
+    r.known = r.first > 0;
+    if (r.known)
+        PlacementCache::get().store(stream, stream_bytes, r);
     if (rep)
         *rep = r;
     return hipSuccess;

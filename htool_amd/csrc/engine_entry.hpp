@@ -13,7 +13,7 @@ static int with_buffers(HMat &H, char trans, const scalar *in, scalar *out, int 
     if (H.tmp_in.n < nin)
         HMX_HIP(H.tmp_in.alloc(nin));
     if (H.tmp_out.n < nout) // the product's output while the E-stream is read: the library's own buffer goes where that pair runs fastest (place_written)
-        HMX_HIP(place_written(H.tmp_out, nout, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0));
+        HMX_HIP(place_array(H, H.tmp_out, nout, 0, st));
     HMX_HIP(hipMemcpyAsync(H.tmp_in.d, in, nin * sizeof(scalar), hipMemcpyHostToDevice, st));
     if (!hmx_is_zero(beta))
         HMX_HIP(hipMemcpyAsync(H.tmp_out.d, out, nout * sizeof(scalar), hipMemcpyHostToDevice, st));
@@ -205,7 +205,7 @@ int api_matvec_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar
     if (H.tmp_in2.n < (size_t)nin)
         HMX_HIP(H.tmp_in2.alloc(nin));
     if (H.tmp_out2.n < (size_t)nout) // (the output in cluster numbering: see with_buffers)
-        HMX_HIP(place_written(H.tmp_out2, (size_t)nout, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0));
+        HMX_HIP(place_array(H, H.tmp_out2, (size_t)nout, 0, st));
     hipLaunchKernelGGL(gather_kernel, dim3((nin + 255) / 256), dim3(256), 0, st, nin, pin, bin, din, H.tmp_in2.d, 1);
     if (!hmx_is_zero(beta))
         hipLaunchKernelGGL(gather_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, nout, pout, bout, (const scalar *)dout, H.tmp_out2.d, 1);
@@ -400,7 +400,7 @@ int api_matmat_user(HMat *Hp, char trans, scalar alpha, const scalar *in, scalar
     if ((int64_t)H.mm_in.n < tin)
         HMX_HIP(H.mm_in.alloc(tin));
     if ((int64_t)H.mm_out.n < tout)
-        HMX_HIP(place_written(H.mm_out, tout, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0)); // (see with_buffers)
+        HMX_HIP(place_array(H, H.mm_out, tout, 0, st)); // (see with_buffers)
     hipLaunchKernelGGL(gather_cm_kernel, dim3((unsigned)((tin + 255) / 256)), dim3(256), 0, st, nin, mu, pin, bin, din, H.mm_in.d);
     if (!hmx_is_zero(beta))
         hipLaunchKernelGGL(gather_cm_kernel, dim3((unsigned)((tout + 255) / 256)), dim3(256), 0, st, nout, mu, pout, bout, (const scalar *)dout, H.mm_out.d);
@@ -451,6 +451,7 @@ int api_prepare(HMat *Hp, char trans, int mu) {
         return HMX_ERR_STATE;
     }
     HMX_HIP(hipSetDevice(H.device));
+    ProbeScope probes(H); // the one place besides the builds where the written arrays' places may be measured (views built below inherit it)
     const bool n_form = trans == 'N';
     const size_t nin = (size_t)(n_form ? H.nS : H.nT) * mu, nout = (size_t)(n_form ? H.nT : H.nS) * mu;
     DArr<scalar> in, out;
@@ -472,6 +473,51 @@ int api_prepare(HMat *Hp, char trans, int mu) {
             return rc;
     }
     HMX_HIP(hipDeviceSynchronize());
+    return HMX_OK;
+}
+
+// hmx_hmatrix_alloc_vector: an output vector of this operator's products, where its sweeps write fastest (place_array; probes allowed here)
+int api_alloc_vector(HMat *Hp, char trans, int64_t bytes, void **ptr) {
+    if (!Hp || !ptr || bytes <= 0 || !(trans == 'N' || trans == 'T' || trans == 'C')) {
+        set_error("hmx_hmatrix_alloc_vector: invalid arguments");
+        return HMX_ERR_INVALID;
+    }
+    HMat &H = *Hp;
+    if (!H.finalized) {
+        set_error("hmx_hmatrix_alloc_vector: operator not built");
+        return HMX_ERR_STATE;
+    }
+    HMX_HIP(hipSetDevice(H.device));
+    ProbeScope probes(H);
+    std::unique_ptr<DArr<scalar>> a(new DArr<scalar>());
+    const size_t count = ((size_t)bytes + sizeof(scalar) - 1) / sizeof(scalar);
+    // 'N': y is written by the expand stage (E-streams); transposed on the stored data: by the second sweep over the R-streams.  A transposed
+    // product that runs on its own stream layout writes next to THAT layout's E-stream: its operator decides
+    HMat &W        = (trans != 'N' && H.T_op) ? *H.T_op : H;
+    const int pair = (trans == 'N' || &W != &H) ? 0 : 1;
+    if (&W != &H)
+        W.may_probe = true;
+    const hipError_t e = place_array(W, *a, count, pair, nullptr);
+    if (&W != &H)
+        W.may_probe = false;
+    HMX_HIP(e);
+    HMX_HIP(hipDeviceSynchronize());
+    *ptr = a->d;
+    H.user_vectors[a->d] = std::move(a);
+    return HMX_OK;
+}
+int api_free_vector(HMat *Hp, void *ptr) {
+    if (!Hp) {
+        set_error("hmx_hmatrix_free_vector: NULL operator");
+        return HMX_ERR_INVALID;
+    }
+    auto it = Hp->user_vectors.find(ptr);
+    if (it == Hp->user_vectors.end()) {
+        set_error("hmx_hmatrix_free_vector: not a vector of this operator");
+        return HMX_ERR_INVALID;
+    }
+    HMX_HIP(hipSetDevice(Hp->device));
+    Hp->user_vectors.erase(it);
     return HMX_OK;
 }
 

@@ -14,6 +14,7 @@ struct MirrorCtx {
     int64_t A_total;
     bool tmode;
     std::function<void(const char *)> phase;
+    hipEvent_t after = nullptr; // recorded behind the work a placement probe must not overlap with (the pack kernels of a build)
 };
 static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     StreamSet &E = H.E, &R = H.R;
@@ -42,8 +43,7 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     size_t s_fidx_n = 0;
     std::vector<int64_t> s_sub_ptr;
     std::vector<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order;
-    std::vector<int64_t> p64; // the same tables for intervals of 64 rows (multi-RHS form of the second sweep)
-    std::vector<int32_t> t64, r64, n64, d64, o64;
+    std::vector<int32_t> o64; // launch order of the intervals of the multi-RHS form of the second sweep (below)
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
     int64_t s_total = 0;
@@ -209,10 +209,86 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     int nint = 0;
     if (!bad)
         nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order, 1);
-    // the same for the multi-RHS form of the second sweep (rowsym_mfma16_kernel: one wave per 64 rows; rowsym_mu_kernel: one workgroup)
+    // The multi-RHS form of the second sweep (rowsym_mfma16_kernel / rowsym_zmfma8_kernel: one WAVE per interval; rowsym_mu_kernel: one workgroup):
+    // intervals of at most SYM_IR_MU rows cut AT the boundaries of the mirrored pieces, so that every (piece, chunk) task covers whole
+    // intervals -- no sub-task of a few rows at the edge of a fixed 64-row grid (clusters of 61 rows against intervals of 64: every piece
+    // met two intervals, a quarter more tiles than the stream holds).  Per interval the kernel walks SEGMENTS: one per (sub-task, 64-column half
+    // of its chunk), each a ready record (first element, row pitch, columns, first entry of the coefficient-slot table) instead of the
+    // chain sub-task -> task -> piece -> geometry of a dozen dependent loads.
     H.s64_nint = 0;
-    if (!bad)
-        H.s64_nint = build_intervals(SYM_IR_MU, p64, t64, r64, n64, d64, o64, HMX_ROWSYM_WAVES); // (a wave per interval in rowsym_mfma16_kernel)
+    std::vector<int32_t> i64_off;  // interval I = output rows [i64_off[I], i64_off[I + 1])
+    std::vector<int64_t> g64_ptr;  // per interval: its segments [g64_ptr[I], g64_ptr[I + 1])
+    std::vector<int64_t> g64_src, g64_cb;
+    std::vector<int32_t> g64_wp, g64_w;
+    if (!bad) {
+        std::vector<char> cut((size_t)nOut + 1, 0);
+        cut[0] = cut[nOut] = 1;
+        for (size_t t = 0; t < ntask; t++)
+            if (task_mirror[t]) {
+                const int r = R.task_range[t], j0 = R.off[r] + r_shift;
+                cut[j0] = cut[j0 + R.len[r]] = 1;
+            }
+        std::vector<int> bp;
+        for (int j = 0; j <= nOut; j++)
+            if (cut[j])
+                bp.push_back(j);
+        std::vector<int32_t> ilen;
+        make_ranges(bp, SYM_IR_MU, 0, i64_off, ilen);
+        const int nint = (int)i64_off.size();
+        i64_off.push_back(nOut);
+        std::vector<int32_t> row2int((size_t)nOut + 1, 0);
+        for (int I = 0; I < nint; I++)
+            for (int j = i64_off[I]; j < i64_off[I + 1]; j++)
+                row2int[j] = I;
+        row2int[nOut] = nint;
+        auto halves = [&](size_t t) {
+            const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
+            return (std::min(cw, R.cols[r] - ch * cw) + 63) / 64;
+        };
+        std::vector<int64_t> cnt((size_t)nint + 1, 0);
+        for (size_t t = 0; t < ntask; t++)
+            if (task_mirror[t]) {
+                const int r = R.task_range[t], j0 = R.off[r] + r_shift;
+                for (int I = row2int[j0]; I < row2int[j0 + R.len[r]]; I++)
+                    cnt[I + 1] += halves(t);
+            }
+        for (int I = 0; I < nint; I++)
+            cnt[I + 1] += cnt[I];
+        g64_ptr = cnt;
+        const int64_t nseg = cnt[nint];
+        g64_src.assign(nseg, 0), g64_cb.assign(nseg, 0), g64_wp.assign(nseg, 0), g64_w.assign(nseg, 0);
+        std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+        std::vector<double> int_work(nint, 0.0);
+        for (size_t t = 0; t < ntask; t++) { // launch order of the tasks = order inside every interval's list, as for the single-vector form
+            if (!task_mirror[t])
+                continue;
+            const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
+            const int w = std::min(cw, R.cols[r] - ch * cw), wp = hmx_wp(w);
+            const int j0 = R.off[r] + r_shift;
+            for (int I = row2int[j0]; I < row2int[j0 + R.len[r]]; I++)
+                for (int c0 = 0; c0 < w; c0 += 64) {
+                    const int64_t q = pos[I]++;
+                    g64_src[q] = R.base[r] + (int64_t)ch * R.len[r] * cw + (int64_t)(i64_off[I] - j0) * wp + c0;
+                    g64_cb[q]  = R.colbase[r] + (int64_t)ch * cw + c0;
+                    g64_wp[q]  = wp;
+                    g64_w[q]   = std::min(64, w - c0);
+                    int_work[I] += (double)(i64_off[I + 1] - i64_off[I]) * std::min(64, w - c0) + 256;
+                }
+        }
+        o64.resize(nint);
+        std::iota(o64.begin(), o64.end(), 0);
+        if (H.opt.i(HMX_OPT_TASK_ORDER) == 3) { // intervals over the same rows gather the same a' (see xcd_deal)
+            const int unit_rows = std::max(SYM_IR_MU, H.opt.i(HMX_OPT_XCD_UNIT_ROWS));
+            std::vector<int64_t> unit(nint), wk(nint);
+            for (int I = 0; I < nint; I++) {
+                unit[I] = (int64_t)i64_off[I] / unit_rows;
+                wk[I]   = (int64_t)int_work[I];
+            }
+            o64 = xcd_deal(unit, wk, HMX_ROWSYM_WAVES);
+        } else
+            std::stable_sort(o64.begin(), o64.end(), [&](int a, int b) { return int_work[a] > int_work[b]; });
+        H.s64_nint = nint;
+    }
     phase_nosync("  sym: tasks");
     // dense mirrored columns: contributions per output row, numbered in layout order ("levels")
     for (size_t p = 0; p < ed_b.size() && !bad; p++) {
@@ -285,15 +361,16 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     HMX_HIP(H.s_fidx.alloc(std::max<size_t>(s_fidx_n, 1)));
     if (s_fidx_n)
         HMX_HIP(hipMemcpy(H.s_fidx.d, s_fidx.get(), s_fidx_n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HMX_HIP(place_written(H.SW, (size_t)s_total + 1, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_sw)); // column sums: written while E is read
+    HMX_HIP(place_array(H, H.SW, (size_t)s_total + 1, 0, nullptr, &H.placed_sw, M.after)); // column sums: written while E is read
     H.s_slots = s_total;
     H.SW16.release();
     if (H.s64_nint > 0) {
-        HMX_HIP(H.s64_sub_ptr.upload(p64));
-        HMX_HIP(H.s64_sub_task.upload(t64));
-        HMX_HIP(H.s64_sub_row0.upload(r64));
-        HMX_HIP(H.s64_sub_nrows.upload(n64));
-        HMX_HIP(H.s64_sub_dst.upload(d64));
+        HMX_HIP(H.s64_int_off.upload(i64_off));
+        HMX_HIP(H.s64_seg_ptr.upload(g64_ptr));
+        HMX_HIP(H.s64_seg_src.upload(g64_src));
+        HMX_HIP(H.s64_seg_cb.upload(g64_cb));
+        HMX_HIP(H.s64_seg_wp.upload(g64_wp));
+        HMX_HIP(H.s64_seg_w.upload(g64_w));
         HMX_HIP(H.s64_int_order.upload(o64));
     }
     return HMX_OK;
@@ -316,6 +393,8 @@ static int build_streams(HMat &H) {
         phase_nosync(name);
     };
     const int64_t nb_real = (int64_t)H.leaves.size();
+    H.place_e_known = H.place_r_known = false; // new streams: what an earlier layout of this operator measured about places is void
+    H.place_e = H.place_r = -1;
     constexpr int TR_MAX = 64;
     const int SR_MAX     = std::max(64, H.opt.i(HMX_OPT_R_PIECE_ROWS));
     // Symmetric / Hermitian storage ('S' / 'H', 'L' / 'U'): the streams hold the STORED TRIANGLE and the product is fused -- each stored
@@ -923,7 +1002,7 @@ static int build_streams(HMat &H) {
     H.s_kmax        = 0;
     H.trans_fused   = false; // the tables of the stored-data transposed product belonged to the layout that is being replaced
     if (H.sym_fused) {
-        MirrorCtx M{XL, XK, nb, elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c, aoff, A_total, false, [&](const char *n) { phase_nosync(n); }};
+        MirrorCtx M{XL, XK, nb, elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c, aoff, A_total, false, [&](const char *n) { phase_nosync(n); }, e1};
         const int rcm = build_mirror_tables(H, M);
         if (rcm != HMX_OK)
             return rcm;
@@ -938,12 +1017,11 @@ static int build_streams(HMat &H) {
     HMX_HIP(H.c_stride.upload(cst));
     HMX_HIP(H.c_count.upload(cc));
     // Z = [x | a | partial sums]: written by the reduce stage while the R-stream is read (place_written: where that pair runs fastest)
-    HMX_HIP(place_written(H.Z, (size_t)H.zero_slot + 1, R.stream.d, (size_t)R.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_z));
-    HMX_HIP(H.Z.zero());
+    HMX_HIP(place_array(H, H.Z, (size_t)H.zero_slot + 1, 1, nullptr, &H.placed_z, e1));
     if (phase_timing) // where the arrays of a product lie
-        fprintf(stderr, "[hmx build]   arrays: E-stream %p (%.3f GB), R-stream %p (%.3f GB), Z %p (placement probe: R alone %.0f GB/s, with Z at first fit %.0f, where it stays %.0f; %d places tried)\n",
+        fprintf(stderr, "[hmx build]   arrays: E-stream %p (%.3f GB), R-stream %p (%.3f GB), Z %p (placement probe: R alone %.0f GB/s, with Z at first fit %.0f, where it stays %.0f; %d places tried%s)\n",
                 (void *)E.stream.d, E.elems * sizeof(scalar) / 1e9, (void *)R.stream.d, R.elems * sizeof(scalar) / 1e9, (void *)H.Z.d, H.placed_z.read_only, H.placed_z.first, H.placed_z.chosen,
-                H.placed_z.tried);
+                H.placed_z.tried, H.placed_z.cached ? ", remembered from an earlier build at this place" : "");
     HMX_HIP(hipEventSynchronize(e1));
     HMX_HIP(hipDeviceSynchronize()); // an error of the pack kernels surfaces here
     pack_guard.armed = false;

@@ -307,7 +307,7 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
                           void *after_user = nullptr) {
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
-        HMX_HIP(place_written(H.Zmu, need, H.R.stream.d, (size_t)H.R.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_zmu));
+        HMX_HIP(place_array(H, H.Zmu, need, 1, st, &H.placed_zmu));
     // the x region of Zmu is never filled: both stages read the caller's X directly
     ReduceArgs RA{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_off.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d,
                   H.r_outidx.d, X, H.Zmu.d, (int)H.R.task_range.size()};
@@ -483,8 +483,7 @@ static bool sym_mu_fused(const HMat &H) {
 static int ensure_sw16(HMat &H, hipStream_t st) {
     const size_t need16 = (size_t)(H.s_slots + 1) * SWW;
     if (H.SW16.n < need16) {
-        HMX_HIP(place_written(H.SW16, need16, H.E.stream.d, (size_t)H.E.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_sw16));
-        HMX_HIP(hipMemsetAsync(H.SW16.d, 0, need16 * sizeof(scalar), st)); // slot s_slots stays zero for ever: the operand of the columns that are no mirrored leaf's
+        HMX_HIP(place_array(H, H.SW16, need16, 0, st, &H.placed_sw16)); // (zero-filled: slot s_slots stays zero for ever -- the operand of the columns that are no mirrored leaf's)
     }
     return HMX_OK;
 }
@@ -543,26 +542,24 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
         prof_mark(H, st, "combine_sym_mu_kernel");
     }
     if (H.s64_nint > 0) {
-        RowSymArgs RS{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d, H.s64_int_order.d,
-                      H.s64_sub_ptr.d, H.s64_sub_task.d, H.s64_sub_row0.d, H.s64_sub_nrows.d, H.s64_sub_dst.d, H.SW16.d, H.s_fidx.d, H.s_count.d, Y, alpha, nout, herm, beta, accumulate};
+        RowSegArgs RS{H.R.stream.d, H.s64_int_order.d, H.s64_int_off.d, H.s64_seg_ptr.d, H.s64_seg_src.d, H.s64_seg_cb.d, H.s64_seg_wp.d, H.s64_seg_w.d, H.s_coef.d,
+                      H.SW16.d, (int)H.s_slots, H.s64_nint, H.s_fidx.d, H.s_count.d, Y, alpha, beta, nout, herm, accumulate};
 #if HMX_COMPLEX
         const dim3 grid((unsigned)H.s64_nint), wg(W * 64);
         if (H.opt.i(HMX_OPT_MATRIX_CORES) != 0) {
-            RowSymZArgs PZ{RS, reinterpret_cast<const real *>(H.SW16.d), (int)H.s_slots, H.s64_nint};
-            hipLaunchKernelGGL((rowsym_zmfma8_kernel<W>), dim3((unsigned)((H.s64_nint + W - 1) / W)), wg, 0, st, PZ, mu, c, nrhs);
+            hipLaunchKernelGGL((rowsym_zmfma8_kernel<W>), dim3((unsigned)((H.s64_nint + W - 1) / W)), wg, 0, st, RS, mu, c, nrhs);
             prof_mark(H, st, "rowsym_zmfma8_kernel");
         } else if (nrhs <= 2)
-            hipLaunchKernelGGL((rowsym_mu_kernel<W, 2>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
+            hipLaunchKernelGGL((rowsym_mu_kernel<W, 2>), grid, wg, 0, st, RS, mu, c, nrhs);
         else if (nrhs <= 4)
-            hipLaunchKernelGGL((rowsym_mu_kernel<W, 4>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
+            hipLaunchKernelGGL((rowsym_mu_kernel<W, 4>), grid, wg, 0, st, RS, mu, c, nrhs);
         else
-            hipLaunchKernelGGL((rowsym_mu_kernel<W, 8>), grid, wg, 0, st, RS, (const scalar *)H.SW16.d, mu, c, nrhs);
+            hipLaunchKernelGGL((rowsym_mu_kernel<W, 8>), grid, wg, 0, st, RS, mu, c, nrhs);
         if (H.opt.i(HMX_OPT_MATRIX_CORES) == 0)
             prof_mark(H, st, "rowsym_mu_kernel");
 #else
-        RowSymMuArgs P{RS, H.SW16.d, (int)H.s_slots, H.s64_nint};
         constexpr int RWV = HMX_ROWSYM_WAVES; // intervals (= waves) per workgroup
-        hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, P, mu, c, nrhs);
+        hipLaunchKernelGGL((rowsym_mfma16_kernel<RWV>), dim3((unsigned)((H.s64_nint + RWV - 1) / RWV)), dim3(RWV * 64), 0, st, RS, mu, c, nrhs);
         prof_mark(H, st, "rowsym_mfma16_kernel");
 #endif
     }
@@ -571,7 +568,7 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
 static int run_forward_mu_sym(HMat &H, const scalar *X, scalar alpha, scalar beta, scalar *Y, int mu, hipStream_t st) {
     const size_t need = (size_t)(H.zero_slot + 1) * mu;
     if (H.Zmu.n < need)
-        HMX_HIP(place_written(H.Zmu, need, H.R.stream.d, (size_t)H.R.elems * sizeof(scalar), H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0, &H.placed_zmu));
+        HMX_HIP(place_array(H, H.Zmu, need, 1, st, &H.placed_zmu));
     int rc = ensure_sw16(H, st);
     if (rc != HMX_OK)
         return rc;
@@ -659,6 +656,7 @@ static HMat *ensure_transposed_operator(HMat &H) {
     T->swapped             = H.swapped;
     T->staged_off          = H.staged_off;
     T->profiling           = H.profiling;
+    T->may_probe           = H.may_probe; // a view built inside hmx_hmatrix_prepare may measure; one built by a product call may not
     const hmx_stats keep   = H.stats;
     const int rc           = build_streams(*T);
     (void)keep;
@@ -703,6 +701,7 @@ static HMat *ensure_expanded_view(HMat &H) {
     X->swapped             = H.swapped;
     X->staged_off          = H.staged_off;
     X->profiling           = H.profiling;
+    X->may_probe           = H.may_probe; // (see ensure_transposed_operator)
     if (build_streams(*X) != HMX_OK) {
         H.X_op_failed = true;
         (void)hipGetLastError();

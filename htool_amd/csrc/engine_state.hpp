@@ -105,8 +105,9 @@ struct HMat {
     DArr<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order; // second R sweep: per row interval the (parts of) tasks inside it
     int s_nint = 0;
     // ... and for the multi-RHS form (rowsym_mfma16_kernel: intervals of 64 rows, one wave each); SW16 = [slot][16] partial sums of one sweep
-    DArr<int64_t> s64_sub_ptr;
-    DArr<int32_t> s64_sub_task, s64_sub_row0, s64_sub_nrows, s64_sub_dst, s64_int_order;
+    DArr<int32_t> s64_int_off, s64_int_order; // interval I = output rows [int_off[I], int_off[I + 1]) (at most SYM_IR_MU, cut at the mirrored pieces' boundaries)
+    DArr<int64_t> s64_seg_ptr, s64_seg_src, s64_seg_cb; // per interval its segments; per segment: first stream element, first entry of the coefficient-slot table
+    DArr<int32_t> s64_seg_wp, s64_seg_w;                // ... row pitch of the chunk, columns of the segment (<= 64)
     int s64_nint = 0;
     int64_t s_slots = 0; // slots of SW (a' | column sums)
     DArr<scalar> SW16;
@@ -157,6 +158,11 @@ struct HMat {
     int64_t zero_slot   = 0;
     DArr<scalar> Z, Zmu;
     PlacementReport placed_z, placed_zmu, placed_sw, placed_sw16; // what place_written measured for the arrays the sweeps write
+    // Where the arrays written next to the E- / R-streams go (fraction of the slab's extent, -1: first fit; *_known: measured or found in the
+    // PlacementCache).  Measured only while may_probe is set: inside hmx_hmatrix_compress / finalize / recompress / prepare, never in a product
+    // call -- arrays a product allocates later go to the known place without measuring anything (place_array).
+    double place_e = -1, place_r = -1;
+    bool place_e_known = false, place_r_known = false, may_probe = false;
     DArr<scalar> tmp_in, tmp_out, tmp_in2, tmp_out2; // staging for host vectors / permutations / multi-RHS
     DArr<scalar> conj_in;                             // conjugated input of a trans = 'C' product
     DArr<scalar> mm_in, mm_out;                       // row-major cluster-numbered operands of the column-major front end
@@ -179,6 +185,8 @@ struct HMat {
     std::vector<int32_t> chunk_first, chunk_count, chunk_row_lo, chunk_row_hi;
     DArr<int32_t> d_chunk_order;
 
+    std::map<void *, std::unique_ptr<DArr<scalar>>> user_vectors; // hmx_hmatrix_alloc_vector
+
     hmx_stats stats{};
     // profiling
     bool profiling = false;
@@ -191,4 +199,29 @@ struct HMat {
         for (auto e : ev)
             (void)hipEventDestroy(e);
     }
+};
+
+// An array a sweep writes while it reads the E-stream (pair = 0) or the R-stream (pair = 1): where that pair runs fastest.  The place is
+// measured at most once per operator and stream, and only while H.may_probe is set (builds and hmx_hmatrix_prepare); everywhere else -- every
+// product call -- the array goes to the place already known, or to wherever first fit puts it, and nothing is launched but its zero-fill on `st`.
+static hipError_t place_array(HMat &H, DArr<scalar> &arr, size_t count, int pair, hipStream_t st, PlacementReport *rep = nullptr, hipEvent_t after = nullptr) {
+    const StreamSet &S = pair == 0 ? H.E : H.R;
+    double &frac       = pair == 0 ? H.place_e : H.place_r;
+    bool &known        = pair == 0 ? H.place_e_known : H.place_r_known;
+    if (H.may_probe && !known && H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0) {
+        PlacementReport r;
+        const hipError_t e = place_written(arr, count, S.stream.d, (size_t)S.elems * sizeof(scalar), true, &r, after);
+        if (e == hipSuccess && r.known)
+            frac = r.frac, known = true;
+        if (rep)
+            *rep = r;
+        return e;
+    }
+    return place_like(arr, count, known ? frac : -1.0, st);
+}
+struct ProbeScope { // placement probes are allowed inside this scope only (builds, hmx_hmatrix_prepare)
+    HMat &H;
+    const bool before;
+    explicit ProbeScope(HMat &h) : H(h), before(h.may_probe) { H.may_probe = true; }
+    ~ProbeScope() { H.may_probe = before; }
 };

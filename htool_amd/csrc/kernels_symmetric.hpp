@@ -531,42 +531,63 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mu_kernel(ExpandSymArg
     }
 }
 
-// second sweep over the R-streams for MU right-hand sides (rowsym_kernel's scheme on intervals of SYM_IR_MU rows: one workgroup per
-// interval, wave w its sub-tasks w, w + WAVES, ..., row sums folded in LDS, the dense mirrored contributions and the y update at the end)
+// ---- second sweep over the R-streams for several right-hand sides: intervals and segments ------------------------------------------------
+// The output rows are cut into INTERVALS of at most SYM_IR_MU rows at the boundaries of the mirrored pieces (build_mirror_tables), so every
+// (piece, chunk) task covers whole intervals.  Per interval the kernels walk SEGMENTS -- one per (task over the interval, 64-column half of
+// its chunk), a ready record each: first stream element (row 0 of the interval, first column of the half), row pitch, columns, first entry
+// of the coefficient-slot table -- in the launch order of the tasks (fixed: bit-reproducible).
 constexpr int SYM_IR_MU = 64;
+struct RowSegArgs {
+    const scalar *stream;
+    const int32_t *order;   // launch position -> interval (heaviest first)
+    const int32_t *int_off; // interval I = output rows [int_off[I], int_off[I + 1])
+    const int64_t *seg_ptr; // per interval: its segments [seg_ptr[I], seg_ptr[I + 1])
+    const int64_t *seg_src, *seg_cb;
+    const int32_t *seg_wp, *seg_w;
+    const int32_t *coef;    // per R column: slot of a'[col] in W16, -1: not a mirrored column
+    const scalar *W16;      // [slot][SWW]
+    int zero_slot;          // a slot whose values are zero
+    int nint;
+    const int32_t *fidx;    // dense mirrored contributions of output row j: W16[fidx[k * n + j]], k < count[j]
+    const int32_t *count;
+    scalar *y;
+    scalar alpha, beta;     // accumulate = 0: y = alpha * sums + beta * y (transposed product on the stored data: this sweep owns y)
+    int n;                  // rows of the operator (stride of fidx)
+    int herm;
+    int accumulate;         // 1: y += alpha * sums (the forward sweep of the symmetric product has written y already)
+};
+// VALU form (what complex coefficients run when HMX_OPT_MATRIX_CORES is 0): one workgroup per interval, wave w its segments w, w + WAVES, ...,
+// lane = column pair, row sums by reduce8 and folded in LDS, the dense mirrored contributions and the y update at the end
 template <int WAVES, int MU>
-__global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSymArgs A, const scalar *W16, int mu, int cbase, int nrhs) {
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSegArgs A, int mu, int cbase, int nrhs) {
     __shared__ scalar acc[WAVES][SYM_IR_MU][MU];
     const int I    = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = A.int_off[I], len = A.int_off[I + 1] - r0;
     for (int r = lane; r < SYM_IR_MU * MU; r += WAVE)
         (&acc[wv][0][0])[r] = scalar(0);
     const bool herm = A.herm != 0;
     constexpr int GS = 8;
-    for (int64_t q = A.sub_ptr[I] + wv; q < A.sub_ptr[I + 1]; q += WAVES) {
-        const int task = A.sub_task[q], row0 = A.sub_row0[q], len = A.sub_nrows[q];
-        scalar(*dst)[MU] = &acc[wv][A.sub_dst[q]];
-        const int S = A.task_range[task], ch = A.task_chunk[task];
-        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-        int w = C - ch * cw;
-        w     = w > cw ? cw : w;
-        const int wp      = hmx_wp(w);
+    for (int64_t q = A.seg_ptr[I] + wv; q < A.seg_ptr[I + 1]; q += WAVES) {
+        scalar(*dst)[MU] = &acc[wv][0];
+        const int w = A.seg_w[q], wp = A.seg_wp[q];
         const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
-        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * wp;
-        const int64_t cb  = A.range_colbase[S] + ch * cw;
+        const scalar *src = A.stream + A.seg_src[q];
+        const int64_t cb  = A.seg_cb[q];
         const int d0 = col0 < w ? A.coef[cb + col0] : -1, d1 = col1 < w ? A.coef[cb + col1] : -1;
         scalar c0[MU], c1[MU], mine[MU];
 #pragma unroll
         for (int j = 0; j < MU; j++) {
-            c0[j]   = (d0 >= 0 && j < nrhs) ? W16[(int64_t)d0 * SWW + j] : scalar(0);
-            c1[j]   = (d1 >= 0 && j < nrhs) ? W16[(int64_t)d1 * SWW + j] : scalar(0);
+            c0[j]   = (d0 >= 0 && j < nrhs) ? A.W16[(int64_t)d0 * SWW + j] : scalar(0);
+            c1[j]   = (d1 >= 0 && j < nrhs) ? A.W16[(int64_t)d1 * SWW + j] : scalar(0);
             mine[j] = scalar(0);
         }
+        const int wl = (w + 1) & ~1; // columns of the segment that exist in the stream (an odd chunk keeps a zero column)
         auto load_rows = [&](scalar2(&e)[GS], int i0) {
 #pragma unroll
             for (int u = 0; u < GS; u++) {
                 const int i = i0 + u < len ? i0 + u : len - 1;
-                e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, wp);
+                e[u]        = load_pair(src + (int64_t)i * wp, col0, col1, HMX_SPLIT_COLS ? w : wl);
             }
         };
         auto process = [&](const scalar2(&e)[GS], int i0) {
@@ -604,8 +625,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSymArgs A, co
     __syncthreads();
     for (int e = threadIdx.x; e < SYM_IR_MU * MU; e += WAVES * WAVE) {
         const int r = e / MU, jj = e - r * MU;
-        const int j = I * SYM_IR_MU + r;
-        if (j >= A.n || jj >= nrhs)
+        const int j = r0 + r;
+        if (r >= len || jj >= nrhs)
             continue;
         scalar sum = acc[0][r][jj];
 #pragma unroll
@@ -613,7 +634,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_mu_kernel(RowSymArgs A, co
             sum += acc[k][r][jj];
         const int cnt = A.count[j];
         for (int k = 0; k < cnt; k++)
-            sum += W16[(int64_t)A.fidx[(int64_t)k * A.n + j] * SWW + jj];
+            sum += A.W16[(int64_t)A.fidx[(int64_t)k * A.n + j] * SWW + jj];
         scalar *yo = A.y + (int64_t)j * mu + cbase + jj;
         if (A.accumulate)
             *yo += A.alpha * sum;
@@ -832,28 +853,23 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_zmfma8_kernel(ExpandSy
     }
 }
 
-// Second pass over the R-streams for 8 complex right-hand sides: Y_s[row][n] += sum_col op(V[row][col]) a'[col][n], one WAVE per 64 output rows
+// Second pass over the R-streams for 8 complex right-hand sides: Y_s[row][n] += sum_col op(V[row][col]) a'[col][n], one WAVE per interval
 // as in rowsym_mfma16_kernel.  Tiles of 8 rows x 64 columns, both planes packed into the M index of one MFMA per k-step (M < 8: re of row M,
 // M >= 8: im of row M - 8; zpack_combine turns D into P1 +- P2'), staged transposed and swizzled in LDS exactly as the real kernel stages its
 // 16-row tiles.  Accumulators hold the combined values of the interval's eight tiles.
-struct RowSymZArgs {
-    RowSymArgs A;      // (sub_* / order refer to the 64-row intervals)
-    const real *W16r;  // [slot][16 reals]
-    int zero_slot;
-    int nint;
-};
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSymZArgs P, int mu, int cbase, int nrhs) {
-    const RowSymArgs &A = P.A;
+__global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSegArgs A, int mu, int cbase, int nrhs) {
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * 16];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pos = blockIdx.x * WAVES + wv;
-    if (pos >= P.nint)
+    if (pos >= A.nint)
         return; // (no workgroup barrier below: the waves are independent)
     const int I  = A.order[pos];
+    const int r0 = A.int_off[I], ilen = A.int_off[I + 1] - r0;
     const int m = lane & 15, kk = lane >> 4;
     const int mo = m < 2 * nrhs ? m : 0;
     const bool herm = A.herm != 0;
+    const real *W16r = reinterpret_cast<const real *>(A.W16); // [slot][16 reals]
     real *tile = lds + wv * 64 * 16;
     auto taddr = [](int c, int i) { return 16 * (c ^ ((c >> 1) & 1)) + (i ^ ((c >> 1) & 15)); }; // element (slot i, column c): see rowsym_mfma16_kernel
     constexpr int NV = sizeof(real) == 8 ? 2 : 4; // combined values per lane and tile (zpack_combine)
@@ -863,27 +879,20 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSymZArgs 
 #pragma unroll
         for (int k = 0; k < NV; k++)
             acc[t][k] = real(0);
-    struct Sub {
+    struct Seg {
         const scalar *src;
-        int w, wp, n, dst;
-        int32_t dlo, dhi;
+        int w, wp;
+        int32_t slot; // lane l: slot of a' of the segment's column l (the zero slot: no mirrored leaf's column / beyond the segment)
     };
+    const int64_t q0 = A.seg_ptr[I], q1 = A.seg_ptr[I + 1];
     auto fetch = [&](int64_t q) {
-        Sub s;
-        const int task = A.sub_task[q], row0 = A.sub_row0[q];
-        s.n   = A.sub_nrows[q];
-        s.dst = A.sub_dst[q];
-        const int S = A.task_range[task], ch = A.task_chunk[task];
-        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-        int w = C - ch * cw;
-        w     = w > cw ? cw : w;
-        s.w   = w;
-        s.wp  = hmx_wp(w);
-        s.src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * s.wp;
-        const int64_t cb = A.range_colbase[S] + ch * cw;
-        const int32_t a = A.coef[cb + (lane < w ? lane : 0)], b = A.coef[cb + (64 + lane < w ? 64 + lane : 0)];
-        s.dlo = lane < w ? a : -1;
-        s.dhi = 64 + lane < w ? b : -1;
+        q = q < q1 ? q : q1 - 1;
+        Seg s;
+        s.src = A.stream + A.seg_src[q];
+        s.w   = A.seg_w[q];
+        s.wp  = A.seg_wp[q];
+        const int32_t c = A.coef[A.seg_cb[q] + (lane < s.w ? lane : 0)];
+        s.slot          = (lane < s.w && c >= 0) ? c : A.zero_slot;
         return s;
     };
 #if HMX_SPLIT_COLS
@@ -894,29 +903,29 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSymZArgs 
     typedef scalar2 tile_vec;
     const int lrow = lane >> 5, lc = 2 * (lane & 31);
 #endif
-    // tile t8 = interval rows 8 t8 ... 8 t8 + 7, columns c0 ... c0 + 63 of the sub-task's chunk; rows clamped into the sub-task
-    auto load_tile = [&](tile_vec(&v)[NL], const Sub &s, int c0, int t8) {
+    // tile t8 = interval rows 8 t8 ... 8 t8 + 7, the segment's columns; rows clamped into the interval
+    auto load_tile = [&](tile_vec(&v)[NL], const Seg &s, int t8) {
 #pragma unroll
         for (int u = 0; u < NL; u++) {
 #if HMX_SPLIT_COLS
-            int r = 8 * t8 + u - s.dst;
-            r     = r < 0 ? 0 : (r >= s.n ? s.n - 1 : r);
-            v[u]  = stream_load(s.src + (int64_t)r * s.wp + (c0 + lane < s.wp ? c0 + lane : 0));
+            int r = 8 * t8 + u;
+            r     = r >= ilen ? ilen - 1 : r;
+            v[u]  = stream_load(s.src + (int64_t)r * s.wp + (lane < s.w ? lane : 0));
 #else
-            int r = 8 * t8 + 2 * u + lrow - s.dst;
-            r     = r < 0 ? 0 : (r >= s.n ? s.n - 1 : r);
-            v[u]  = stream_load(reinterpret_cast<const scalar2 *>(s.src + (int64_t)r * s.wp + (c0 + lc < s.wp ? c0 + lc : 0)));
+            int r = 8 * t8 + 2 * u + lrow;
+            r     = r >= ilen ? ilen - 1 : r;
+            v[u]  = stream_load(reinterpret_cast<const scalar2 *>(s.src + (int64_t)r * s.wp + (lc < s.w ? lc : 0)));
 #endif
         }
     };
-    auto gather_b = [&](real(&b)[16], const Sub &s, int c0) {
+    auto gather_b = [&](real(&b)[16], const Seg &s) {
 #pragma unroll
         for (int h = 0; h < 16; h++) {
-            const int d = __shfl(c0 ? s.dhi : s.dlo, 4 * h + kk, WAVE);
-            b[h]        = P.W16r[(int64_t)(d >= 0 ? d : P.zero_slot) * 16 + mo];
+            const int d = __shfl(s.slot, 4 * h + kk, WAVE);
+            b[h]        = W16r[(int64_t)d * 16 + mo];
         }
     };
-    auto tile_product = [&](const tile_vec(&v)[NL], const real(&b)[16], const Sub &s, int t8) {
+    auto tile_product = [&](const tile_vec(&v)[NL], const real(&b)[16], int t8) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < NL; u++) {
@@ -948,36 +957,33 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSymZArgs 
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const int i    = 8 * t8 + idx[k < nv ? k : 0];
-            const real add = (ok && i >= s.dst && i < s.dst + s.n) ? val[k] : real(0);
+            const real add = (ok && i < ilen) ? val[k] : real(0);
 #pragma unroll
             for (int tt = 0; tt < 8; tt++)
                 if (tt == t8)
                     acc[tt][k] += add;
         }
     };
-    const int64_t q0 = A.sub_ptr[I], q1 = A.sub_ptr[I + 1];
-    Sub cur{};
+    const int t_hi = (ilen - 1) >> 3;
+    Seg cur{};
     if (q0 < q1)
         cur = fetch(q0);
     for (int64_t q = q0; q < q1; q++) {
-        const Sub nxt = fetch(q + 1 < q1 ? q + 1 : q);
-        const int t_lo = cur.dst >> 3, t_hi = (cur.dst + cur.n - 1) >> 3;
-        for (int c0 = 0; c0 < cur.w; c0 += 64) {
-            real b[16];
-            gather_b(b, cur, c0);
-            tile_vec va[NL], vb[NL];
-            load_tile(va, cur, c0, t_lo);
-            for (int t = t_lo; t <= t_hi; t += 2) {
-                load_tile(vb, cur, c0, t + 1 <= t_hi ? t + 1 : t_hi);
-                HMX_SCHED_FENCE();
-                tile_product(va, b, cur, t);
-                HMX_SCHED_FENCE();
-                load_tile(va, cur, c0, t + 2 <= t_hi ? t + 2 : t_hi);
-                HMX_SCHED_FENCE();
-                if (t + 1 <= t_hi)
-                    tile_product(vb, b, cur, t + 1);
-                HMX_SCHED_FENCE();
-            }
+        const Seg nxt = fetch(q + 1);
+        real b[16];
+        gather_b(b, cur);
+        tile_vec va[NL], vb[NL];
+        load_tile(va, cur, 0);
+        for (int t = 0; t <= t_hi; t += 2) {
+            load_tile(vb, cur, t + 1 <= t_hi ? t + 1 : t_hi);
+            HMX_SCHED_FENCE();
+            tile_product(va, b, t);
+            HMX_SCHED_FENCE();
+            load_tile(va, cur, t + 2 <= t_hi ? t + 2 : t_hi);
+            HMX_SCHED_FENCE();
+            if (t + 1 <= t_hi)
+                tile_product(vb, b, t + 1);
+            HMX_SCHED_FENCE();
         }
         cur = nxt;
     }
@@ -993,9 +999,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSymZArgs 
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const int idxk = sizeof(real) == 8 ? (lane >> 4) + 4 * k : 4 * ((lane >> 4) & 1) + k;
-            const int jrow = I * SYM_IR_MU + 8 * t8 + idxk;
-            jr[k]          = jrow < A.n ? jrow : A.n - 1;
-            cn[k]          = (lane_ok && jrow < A.n) ? A.count[jr[k]] : 0;
+            const int ir   = 8 * t8 + idxk;
+            jr[k]          = r0 + (ir < ilen ? ir : ilen - 1);
+            cn[k]          = (lane_ok && ir < ilen) ? A.count[jr[k]] : 0;
             kmax           = cn[k] > kmax ? cn[k] : kmax;
         }
         real yv[NV];
@@ -1009,18 +1015,18 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSymZArgs 
                 d[k] = A.fidx[(int64_t)(lev < cn[k] ? lev : 0) * A.n + jr[k]];
 #pragma unroll
             for (int k = 0; k < NV; k++)
-                acc[t8][k] += P.W16r[(int64_t)(lev < cn[k] ? d[k] : P.zero_slot) * 16 + mo];
+                acc[t8][k] += W16r[(int64_t)(lev < cn[k] ? d[k] : A.zero_slot) * 16 + mo];
         }
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const int idxk = sizeof(real) == 8 ? (lane >> 4) + 4 * k : 4 * ((lane >> 4) & 1) + k;
-            const int jrow = I * SYM_IR_MU + 8 * t8 + idxk;
+            const int ir   = 8 * t8 + idxk;
             const real own = acc[t8][k], oth = hmx_shfl_xor(own, 1);
             const real av  = a_re * own + a_im * oth; // this lane's part of alpha * value
             const real yo  = yv[k], yp = hmx_shfl_xor(yo, 1);
             const real out = A.accumulate ? yo + av : (hmx_is_zero(A.beta) ? av : av + (b_re * yo + b_im * yp));
-            if (lane_ok && jrow < A.n && m < 2 * nrhs)
-                yr[((int64_t)jrow * mu + cbase) * 2 + m] = out;
+            if (lane_ok && ir < ilen && m < 2 * nrhs)
+                yr[((int64_t)(r0 + ir) * mu + cbase) * 2 + m] = out;
         }
     }
 }
@@ -1208,84 +1214,63 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
     }
 }
 
-// Second pass over the R-streams for up to 16 right-hand sides.  Interval = 64 output rows = one wave; its sub-tasks are the parts of the
-// (source piece, column chunk) tasks whose rows lie in the interval.  Per sub-task and half of the chunk's (<= 128) columns: the B operands
-// a'[column][rhs] of the 16 k-steps are gathered once, then every 16-row tile of the interval the sub-task touches is loaded (whole rows: two
-// rows of 64 columns per wave-wide load), staged transposed in LDS and multiplied -- 16 MFMAs per 16 x 64 tile; rows of the tile that are
-// not the sub-task's are dropped when the tile's result is added to the interval's accumulators.
-struct RowSymMuArgs {
-    RowSymArgs A;         // (sub_* / order refer to the 64-row intervals)
-    const scalar *W16;    // [slot][16]
-    int zero_slot;        // a slot whose 16 values are zero
-    int nint;
-};
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_ROWSYM_MFMA16_KERNEL void rowsym_mfma16_kernel(RowSymMuArgs P, int mu, int cbase, int nrhs) {
-    const RowSymArgs &A = P.A;
-    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * 16];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pos = blockIdx.x * WAVES + wv;
-    if (pos >= P.nint)
-        return; // (no workgroup barrier below: the waves are independent)
-    const int I  = A.order[pos];
+// Second pass over the R-streams for up to 16 right-hand sides: Y_s[row][rhs] += sum_col V[row][col] a'[col][rhs].  One WAVE per interval
+// (accumulators in registers, nothing to fold between waves); per segment the B operands a'[column][rhs] of the 16 k-steps are gathered once
+// and every 16-row tile of the interval is loaded (whole rows: two rows of 64 columns per wave-wide load), staged transposed in LDS and
+// multiplied: 16 MFMAs per 16 x 64 tile.
+// Round 6: ONE software pipeline over all tiles of all segments of the interval.  Before, every (sub-task, half) started its own two-tile
+// pipeline: four or five tiles, then a drain -- and the first tile's loads, the segment's sixteen operand gathers and the next sub-task's chain
+// of index loads all waited for in the open (3.2 TB/s where the sweep moves 1.5 x its stream).  Now tile (segment q, t) is computed while the
+// loads of the NEXT tile -- of this segment or the first of segment q + 1 -- are in flight, the operands of segment q + 1 are gathered a share per
+// step during segment q, and the record of segment q + 2 is fetched at the start of segment q.  NT (tiles per segment = ceil(rows / 16)) is a
+// template parameter: every load is unconditional and in program order (kernels_common.hpp, HMX_SCHED_FENCE), buffers and accumulators are
+// indexed by constants.  Reads past the interval's last segment re-read that segment (nobody uses them).
+template <int NT>
+__device__ __forceinline__ void rowsym_mfma16_run(const RowSegArgs &A, real *tile, int I, int r0, int ilen, int lane, int mu, int cbase, int nrhs) {
     const int m = lane & 15, kk = lane >> 4;
-    // [64 columns][16 rows], element (row i, column c) at 16 (c ^ ((c >> 1) & 1)) + (i ^ ((c >> 1) & 15)): the stores of a load's two
-    // rows x 64 columns and the operand reads of 16 rows x 4 columns both touch every bank exactly twice
-    real *tile = lds + wv * 64 * 16;
-    acc4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-        acc[t] = acc4{0, 0, 0, 0};
     const int lrow = lane >> 5, lc = 2 * (lane & 31); // loads: lane = (row parity, column pair) of a 2-row x 64-column slab
-    // what a sub-task needs, fetched one sub-task ahead: the chain sub-task -> task -> range -> geometry is a dozen dependent loads
-    struct Sub {
+    acc4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+        acc[t] = acc4{0, 0, 0, 0};
+    struct Seg {
         const real *src;
-        int w, wp, n, dst;
-        int32_t dlo, dhi; // slots of a' for the chunk's columns lane and 64 + lane (-1: not a mirrored leaf's column / beyond the chunk)
+        int w, wp;
+        int32_t slot; // lane l: slot of a' of the segment's column l (the zero slot: no mirrored leaf's column / beyond the segment)
     };
+    const int64_t q0 = A.seg_ptr[I], q1 = A.seg_ptr[I + 1];
     auto fetch = [&](int64_t q) {
-        Sub s;
-        const int task = A.sub_task[q], row0 = A.sub_row0[q];
-        s.n   = A.sub_nrows[q];
-        s.dst = A.sub_dst[q];
-        const int S = A.task_range[task], ch = A.task_chunk[task];
-        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-        int w = C - ch * cw;
-        w     = w > cw ? cw : w;
-        s.w   = w;
-        s.wp  = hmx_wp(w);
-        s.src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * s.wp;
-        const int64_t cb = A.range_colbase[S] + ch * cw;
-        const int32_t a = A.coef[cb + (lane < w ? lane : 0)], b = A.coef[cb + (64 + lane < w ? 64 + lane : 0)];
-        s.dlo = lane < w ? a : -1;
-        s.dhi = 64 + lane < w ? b : -1;
+        q = q < q1 ? q : q1 - 1;
+        Seg s;
+        s.src = A.stream + A.seg_src[q];
+        s.w   = A.seg_w[q];
+        s.wp  = A.seg_wp[q];
+        const int32_t c = A.coef[A.seg_cb[q] + (lane < s.w ? lane : 0)];
+        s.slot          = (lane < s.w && c >= 0) ? c : A.zero_slot;
         return s;
     };
-    // a tile = 16 interval rows x 64 columns of one sub-task: rows clamped into the sub-task's (the others are dropped when the result is added)
-    auto load_tile = [&](scalar2(&v)[8], const Sub &s, int c0, int t) {
-        const int cl = c0 + lc < s.wp ? c0 + lc : 0; // lanes beyond the chunk re-read its first pair (their operand is zero)
+    // a tile = 16 interval rows x 64 columns of one segment; rows beyond the interval re-read its last row (their results are never stored),
+    // lanes beyond the segment its first pair (their operand is the zero slot)
+    auto load_tile = [&](scalar2(&v)[8], const Seg &s, int t) {
+        const int cl = lc < s.w ? lc : 0;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            int r = 16 * t + 2 * u + lrow - s.dst;
-            r     = r < 0 ? 0 : (r >= s.n ? s.n - 1 : r);
+            int r = 16 * t + 2 * u + lrow;
+            r     = r < ilen ? r : ilen - 1;
             v[u]  = stream_load(reinterpret_cast<const scalar2 *>(s.src + (int64_t)r * s.wp + cl));
         }
     };
-    // B operands of a segment (sub-task, 64-column half): a'[column c0 + 4 h + kk][rhs m]; columns beyond the chunk and columns that are
-    // no mirrored leaf's read a zero slot
-    auto gather_b = [&](real(&b)[16], const Sub &s, int c0) {
+    auto gather_b = [&](real(&b)[16], const Seg &s, int h0, int h1) { // a'[column 4 h + kk][rhs m] for the k-steps h0 <= h < h1
 #pragma unroll
-        for (int h = 0; h < 16; h++) {
-            const int d = __shfl(c0 ? s.dhi : s.dlo, 4 * h + kk, WAVE);
-            b[h]        = P.W16[(int64_t)(d >= 0 ? d : P.zero_slot) * 16 + m];
-        }
+        for (int h = 0; h < 16; h++)
+            if (h >= h0 && h < h1) {
+                const int d = __shfl(s.slot, 4 * h + kk, WAVE);
+                b[h]        = A.W16[(int64_t)d * 16 + m];
+            }
     };
-    const int64_t q0 = A.sub_ptr[I], q1 = A.sub_ptr[I + 1];
-    Sub cur{};
-    if (q0 < q1)
-        cur = fetch(q0);
-    // one tile: staged transposed in LDS, 16 MFMAs, rows that are not the sub-task's dropped when the result joins the accumulators
-    auto tile_product = [&](const scalar2(&v)[8], const real(&b)[16], const Sub &s, int t) {
+    // [64 columns][16 rows], element (row i, column c) at 16 (c ^ ((c >> 1) & 1)) + (i ^ ((c >> 1) & 15)): the stores of a load's two
+    // rows x 64 columns and the operand reads of 16 rows x 4 columns both touch every bank exactly twice
+    auto tile_product = [&](const scalar2(&v)[8], const real(&b)[16], acc4 &dst) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -1306,84 +1291,108 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_ROWSYM_MFMA16_KERNEL void rows
         for (int h = 0; h < 16; h++)
             tm = mfma16(ta[h], b[h], tm); // A[m = row][k = column c], B[k][n = rhs]
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i    = 16 * t + mfma16_row(real(0), lane, j);
-            const real add = (i >= s.dst && i < s.dst + s.n) ? tm[j] : real(0);
-#pragma unroll
-            for (int tt = 0; tt < 4; tt++)
-                if (tt == t)
-                    acc[tt][j] += add;
-        }
+        for (int j = 0; j < 4; j++)
+            dst[j] += tm[j];
     };
-    for (int64_t q = q0; q < q1; q++) {
-        const Sub nxt = fetch(q + 1 < q1 ? q + 1 : q);
-        const int t_lo = cur.dst >> 4, t_hi = (cur.dst + cur.n - 1) >> 4;
-        for (int c0 = 0; c0 < cur.w; c0 += 64) {
-            real b[16];
-            gather_b(b, cur, c0);
-            // two tile buffers used in turn (no register copies: a copy waits for the load it copies), the next tile's loads always issued --
-            // clamped to the segment's last tile -- before the current tile is worked on
-            scalar2 va[8], vb[8];
-            load_tile(va, cur, c0, t_lo);
-            for (int t = t_lo; t <= t_hi; t += 2) {
-                load_tile(vb, cur, c0, t + 1 <= t_hi ? t + 1 : t_hi);
-                HMX_SCHED_FENCE();
-                tile_product(va, b, cur, t);
-                HMX_SCHED_FENCE();
-                load_tile(va, cur, c0, t + 2 <= t_hi ? t + 2 : t_hi);
-                HMX_SCHED_FENCE();
-                if (t + 1 <= t_hi)
-                    tile_product(vb, b, cur, t + 1);
-                HMX_SCHED_FENCE();
+    if (q0 < q1) {
+        constexpr int SPI   = (NT & 1) ? 2 : 1;     // segments per trip of the loop: an odd number of tiles flips the two tile buffers
+        constexpr int SHARE = (16 + NT - 1) / NT;   // operand gathers of the next segment per step
+        Seg cur = fetch(q0), nxt = fetch(q0 + 1);
+        real bc[16], bn[16];
+        gather_b(bc, cur, 0, 16);
+        scalar2 v[2][8];
+        load_tile(v[0], cur, 0);
+        HMX_SCHED_FENCE();
+        for (int64_t q = q0; q < q1; q += SPI) {
+#pragma unroll
+            for (int p = 0; p < SPI; p++) {
+                if (p > 0 && q + p >= q1)
+                    break;
+                const Seg nx2 = fetch(q + p + 2);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int cb = (p * NT + t) & 1; // (a constant after unrolling)
+                    gather_b(bn, nxt, t * SHARE, (t + 1) * SHARE < 16 ? (t + 1) * SHARE : 16);
+                    if (t + 1 < NT)
+                        load_tile(v[cb ^ 1], cur, t + 1);
+                    else
+                        load_tile(v[cb ^ 1], nxt, 0);
+                    HMX_SCHED_FENCE();
+                    tile_product(v[cb], bc, acc[t]);
+                    HMX_SCHED_FENCE();
+                }
+#pragma unroll
+                for (int h = 0; h < 16; h++)
+                    bc[h] = bn[h];
+                cur = nxt;
+                nxt = nx2;
             }
         }
-        cur = nxt;
     }
     // dense mirrored contributions of the interval's rows (column sums the first pass left in SW16, found through the level index), y update.
-    // A lane holds 16 rows (one right-hand side each): level k of all sixteen is fetched together -- sixteen independent chains of two
-    // loads per level instead of one (the levels of a row are few, but every one is two dependent trips to memory)
-    int jr[16], cn[16], kmax = 0;
+    // A lane holds 4 NT rows (one right-hand side each): level k of all of them is fetched together -- independent chains of two loads per
+    // level instead of one (the levels of a row are few, but every one is two dependent trips to memory)
+    constexpr int NR = 4 * NT;
+    int jr[NR], cn[NR], kmax = 0;
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int jrow = I * SYM_IR_MU + 16 * t + mfma16_row(real(0), lane, j);
-            jr[4 * t + j]  = jrow < A.n ? jrow : A.n - 1;
-            cn[4 * t + j]  = jrow < A.n ? A.count[jr[4 * t + j]] : 0;
-            kmax           = cn[4 * t + j] > kmax ? cn[4 * t + j] : kmax;
+            const int ir  = 16 * t + mfma16_row(real(0), lane, j);
+            jr[4 * t + j] = r0 + (ir < ilen ? ir : ilen - 1);
+            cn[4 * t + j] = ir < ilen ? A.count[jr[4 * t + j]] : 0;
+            kmax          = cn[4 * t + j] > kmax ? cn[4 * t + j] : kmax;
         }
-    // the sixteen y values of the lane are fetched NOW, together, unconditionally (rows beyond the operator read its last row, right-hand sides
-    // beyond the group the group's first): with the load inside each row's own `if (row exists) y = ...` the compiler emitted load -> wait ->
-    // store sixteen times in a row, sixteen trips to memory one after the other at the end of every interval (round 5, read off the ISA)
+    // the y values of the lane are fetched NOW, together, unconditionally (rows beyond the interval read its last row, right-hand sides beyond
+    // the group the group's first): with the load inside each row's own `if (row exists) y = ...` the compiler emitted load -> wait -> store
+    // once per row, one trip to memory after the other at the end of every interval (round 5, read off the ISA)
     const bool need_y = A.accumulate || !(A.beta == real(0));
     const int mcol    = cbase + (m < nrhs ? m : 0);
-    real yv[16];
+    real yv[NR];
 #pragma unroll
-    for (int e = 0; e < 16; e++)
+    for (int e = 0; e < NR; e++)
         yv[e] = need_y ? A.y[(int64_t)jr[e] * mu + mcol] : real(0);
     for (int k = 0; k < kmax; k++) {
-        int32_t d[16];
+        int32_t d[NR];
 #pragma unroll
-        for (int e = 0; e < 16; e++)
+        for (int e = 0; e < NR; e++)
             d[e] = A.fidx[(int64_t)(k < cn[e] ? k : 0) * A.n + jr[e]]; // (level 0 of the row when it has fewer: a valid entry, dropped below)
-        real w[16];
+        real w[NR];
 #pragma unroll
-        for (int e = 0; e < 16; e++)
-            w[e] = P.W16[(int64_t)(k < cn[e] ? d[e] : P.zero_slot) * 16 + m];
+        for (int e = 0; e < NR; e++)
+            w[e] = A.W16[(int64_t)(k < cn[e] ? d[e] : A.zero_slot) * 16 + m];
 #pragma unroll
-        for (int e = 0; e < 16; e++)
+        for (int e = 0; e < NR; e++)
             acc[e >> 2][e & 3] += w[e];
     }
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int jrow = I * SYM_IR_MU + 16 * t + mfma16_row(real(0), lane, j);
+            const int ir   = 16 * t + mfma16_row(real(0), lane, j);
             const real y0  = yv[4 * t + j];
             const real out = A.accumulate ? y0 + A.alpha * acc[t][j] : (A.beta == real(0) ? A.alpha * acc[t][j] : A.alpha * acc[t][j] + A.beta * y0);
-            if (jrow < A.n && m < nrhs)
-                A.y[(int64_t)jrow * mu + cbase + m] = out;
+            if (ir < ilen && m < nrhs)
+                A.y[(int64_t)(r0 + ir) * mu + cbase + m] = out;
         }
+}
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_ROWSYM_MFMA16_KERNEL void rowsym_mfma16_kernel(RowSegArgs A, int mu, int cbase, int nrhs) {
+    __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * 16];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos = blockIdx.x * WAVES + wv;
+    if (pos >= A.nint)
+        return; // (no workgroup barrier below: the waves are independent)
+    const int I  = A.order[pos];
+    const int r0 = A.int_off[I], ilen = A.int_off[I + 1] - r0;
+    real *tile = lds + wv * 64 * 16;
+    switch ((ilen + 15) >> 4) { // wave-uniform
+    case 4: rowsym_mfma16_run<4>(A, tile, I, r0, ilen, lane, mu, cbase, nrhs); break;
+    case 3: rowsym_mfma16_run<3>(A, tile, I, r0, ilen, lane, mu, cbase, nrhs); break;
+    case 2: rowsym_mfma16_run<2>(A, tile, I, r0, ilen, lane, mu, cbase, nrhs); break;
+    case 1: rowsym_mfma16_run<1>(A, tile, I, r0, ilen, lane, mu, cbase, nrhs); break;
+    default: break; // an empty interval
+    }
 }
 
 #endif // !HMX_COMPLEX

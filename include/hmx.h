@@ -300,9 +300,9 @@ int hmx_hmatrix_get_blocks_c(const hmx_hmatrix *, int64_t count, const int64_t *
 /* hmx_stats may grow at its END in later versions of this header.  hmx_hmatrix_stats_sized writes at most `struct_size` bytes, so a caller
  * compiled against an older (shorter) hmx_stats is never overrun; hmx_hmatrix_stats(H, out) in source code is that call with
  * sizeof(hmx_stats) of the header it was compiled with.  (The exported function of the same name, kept for binaries built before the macro
- * existed, fills only the fields hmx_stats had in its first version -- up to and including t_pack_s.)  hmx_abi_version() returns
+ * existed, fills the fields hmx_stats had in the last header without the macro -- everything before placed_read_gbps.)  hmx_abi_version() returns
  * HMX_ABI_VERSION of the library: it changes when a struct grows or an entry point is added, never for existing signatures. */
-#define HMX_ABI_VERSION 6
+#define HMX_ABI_VERSION 7
 int hmx_abi_version(void);
 int hmx_hmatrix_stats_sized(const hmx_hmatrix *, hmx_stats *out, size_t struct_size);
 int hmx_hmatrix_stats(const hmx_hmatrix *, hmx_stats *out);
@@ -349,6 +349,18 @@ int hmx_hmatrix_release_factors(hmx_hmatrix *, int with_transposed);
  * move): no latency cliff or out-of-memory condition in the middle of a Krylov solve.  hmx_stats.transposed_bytes / expanded_bytes say
  * what the extra layouts cost.  Optional. */
 int hmx_hmatrix_prepare(hmx_hmatrix *, char trans, int mu);
+
+/* Device memory for a vector (or a row-major block of right-hand sides) that products of this operator WRITE -- y of
+ * add_hmatrix_vector_product / Y of add_hmatrix_matrix_product_row_major (hmatrix/linalg/add_hmatrix_vector_product.hpp:17-32; the reference's
+ * callers own plain std::vector's).  Any device pointer is a valid output; one from here lies where this operator's sweeps write fastest.  On
+ * MI355X a streaming read loses 16-23 % to a write stream of ~1 % of its bytes when both lie in the same third of the physical memory and
+ * 7-10 % when they do not; for the arrays the library owns that is settled at build time, the OUTPUT belongs to the caller -- the two speeds
+ * of the expand kernels (N = 1e6, 16 right-hand sides: 2.03 / 2.33 ms; one vector: 1.71 / 1.78 ms) are nothing but where y lies relative to the
+ * E-streams (profiles/r6_modes_*.log).  trans = 'N': written while the E-streams are read; 'T' / 'C': while the R-streams are read (stored-data
+ * form).  Measured once per operator (a few probe launches, here -- never inside a product) when hmx_device_reserve gave the library a slab
+ * to choose from; otherwise a plain allocation.  Zero-filled.  Freed by hmx_hmatrix_free_vector or with the operator. */
+int hmx_hmatrix_alloc_vector(hmx_hmatrix *, char trans, int64_t bytes, void **device_ptr);
+int hmx_hmatrix_free_vector(hmx_hmatrix *, void *device_ptr);
 
 /* Binary dump of the compressed operator (no counterpart in the reference): header, leaf table with
  * ranks, then per leaf U (M x r) and V (r x N) or the dense M x N block, all column-major as in htool's
@@ -521,6 +533,11 @@ int hmx_device_trim_cache(void);
  * the arrays the products write: a generous one (half of the free memory) offers addresses of more than one kind.  May be called
  * several times (one more slab each); hmx_device_trim_cache frees the slabs nothing lives in. */
 int hmx_device_reserve(int device_id, int64_t bytes);
+/* Diagnostics (tools/output_place_probe.py): a range of a reserved slab as close as possible to the fraction `frac` (0 ... 1) of its extent,
+ * and its return.  What hmx_hmatrix_alloc_vector does after measuring, with the place given by hand: how a kernel's time depends on where
+ * the vector it writes lies. */
+int hmx_device_slab_alloc_at(int device_id, int64_t bytes, double frac, void **device_ptr);
+int hmx_device_slab_free(int device_id, void *device_ptr, int64_t bytes);
 /* Wall time (seconds) this process has spent inside hipMalloc on behalf of libhmx so far: large allocations sporadically take seconds
  * on this platform, callers that time builds report it separately. */
 double hmx_device_malloc_seconds(void);

@@ -18,6 +18,6 @@ for rep in range(2):
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     t = time.time(); check(lib().hmx_hmatrix_set_kernel(h, 0, dp(params), 2, 3, dp(x), dp(x))); t3 = time.time() - t
     t = time.time(); check(lib().hmx_hmatrix_compress(h, 0, 1e-4, -1)); t4 = time.time() - t
-    s = _lib.Stats(); check(lib().hmx_hmatrix_stats(h, C.byref(s)))
+    s = _lib.Stats(); check(lib().hmx_hmatrix_stats_sized(h, C.byref(s), C.sizeof(s)))
     print("rep %d: block tree %.2f  create %.2f  set_kernel %.2f  compress %.2f (aca kernel %.3f, pack %.3f of which kernels %.3f)" % (rep, t1, t2, t3, t4, s.t_compress_s, s.t_pack_s, s.t_assemble_s))
     lib().hmx_hmatrix_destroy(h)

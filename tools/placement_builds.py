@@ -32,7 +32,7 @@ def main():
     x1 = torch.from_numpy(rng.random(n)).to(dev)
     y1 = torch.zeros(n, dtype=torch.float64, device=dev)
     keep = []
-    for trial in range(10):
+    for trial in range(int(os.environ.get("HMX_PLACEMENT_BUILDS", "10"))):
         tb = hm.HMatrixTreeBuilder(1e-4, 10.0, "N", "N")
         tb.set_low_rank_generator("partialACA")
         d = bench.minimal_depth(n)
