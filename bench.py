@@ -607,6 +607,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()) / nsteps * 1e3
 
+    b_alg_local = esz * (st["cgen_dense"] + st["cgen_lowrank"] + mu * (n + H.nb_rows()))  # this rank's operator alone
+
     def local_roofline():
         """Roofline of the dominant kernel of the rank-LOCAL product (HIP events on the launch stream; no collective inside)."""
         # ---- roofline of the dominant kernel: HIP events on the launch stream, same steps ------------------------
@@ -632,25 +634,36 @@ def main():
         achieved = exp_bytes / (exp_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: measured separately with rocprofv3 --pmc and stored with the sha256 of the kernel
         # sources it was measured on -- a number collected on other kernels is not reported
-        traffic = None
+        traffic = traffic_source = product_traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and world == 1 and n == 1000000 and args.geom == "ellipse" and args.trans == "N" and mu == 1 and not emu and not use_dist and args.dtype == "f64":
+        std = world == 1 and n == 1000000 and args.geom == "ellipse" and not emu and not use_dist and args.dtype == "f64" and args.eps == 1e-4
+        c5 = (world == 1 and n == 4000000 and args.geom == "ellipse" and emu == 8 and args.emulate_rank == 3 and args.dtype == "f32" and args.sym == "S" and mu == 16
+              and args.eps == 1e-6 and args.trans == "N")
+        if os.path.exists(tf) and (std or c5):
             rec = json.load(open(tf))
-            key = "expand_kernel_hbm_bytes_per_launch" if args.sym == "N" else "expand_sym_kernel_hbm_bytes_per_launch"
+            # (dominant kernel's bytes per launch, the whole product's bytes) of the workloads the PMC passes cover
+            keys = {("N", "N", 1): ("expand_kernel_hbm_bytes_per_launch", "product_hbm_bytes_total"), ("S", "N", 1): ("expand_sym_kernel_hbm_bytes_per_launch", "sym_product_hbm_bytes_total"),
+                    ("N", "N", 16): ("mu16_expand_kernel_hbm_bytes_per_launch", "mu16_product_hbm_bytes_total"), ("N", "T", 1): ("transT_colsum_kernel_hbm_bytes_per_launch", "transT_product_hbm_bytes_total"),
+                    ("S", "N", 16): ("sym_mu16_expand_kernel_hbm_bytes_per_launch", "sym_mu16_product_hbm_bytes_total")}
+            kk = ("c5_rank3_expand_kernel_hbm_bytes_per_launch", "c5_rank3_product_hbm_bytes_total") if c5 else keys.get((args.sym, args.trans, mu))
             if rec.get("kernel_sources_sha256") == kernel_sources_hash():
-                traffic = rec.get(key)
+                if kk:
+                    traffic, product_traffic = rec.get(kk[0]), rec.get(kk[1])
+                    traffic_source = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE (x 2 on gfx950) + WRITE_SIZE, separate passes, round %s, kernel sources sha256 %s" % (rec.get("round"), rec["kernel_sources_sha256"][:16])
             else:
                 log("profiles/traffic.json was measured on other kernel sources (hash differs): roofline.traffic = null")
         roofline = dict(bound="hbm", kernel=exp_name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
-                        traffic=traffic, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
+                        traffic=traffic, traffic_source=traffic_source, algorithmic_bytes_per_launch=exp_bytes, avg_launch_ms=exp_ms,
                         kernels_ms=kern_ms, reduce_kernel_GBps=(red_bytes / (kern_ms[red_name] * 1e-3) / 1e9) if kern_ms.get(red_name) else None)
+        if product_traffic:  # the whole product: HBM bytes all its kernels moved by the counters over the algorithmic bytes of the line (1: nothing read twice, nothing extra)
+            roofline["product_traffic"] = product_traffic
+            roofline["moved_over_algorithmic"] = product_traffic / b_alg_local
 
         # measured device copy bandwidth (16 B/lane copy kernel, read+write) as the practical HBM ceiling on this box
         import ctypes
         bw = ctypes.c_double(0.0)
         hm.lib().hmx_device_copy_bandwidth(local_rank, 2 << 30, 5, ctypes.byref(bw))
-        roofline["measured_copy_GBps"] = bw.value
-        roofline["frac_of_measured_copy"] = achieved / bw.value if bw.value > 0 else None
+        roofline["measured_copy_GBps"] = bw.value  # (read + write: no ceiling for a sweep that reads; the read-only rate below is)
         rbw = ctypes.c_double(0)
         hm.lib().hmx_device_read_bandwidth(local_rank, 8 << 30, 5, ctypes.byref(rbw))  # what a pure streaming read reaches on this box
         roofline["measured_read_GBps"] = rbw.value

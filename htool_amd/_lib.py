@@ -15,7 +15,7 @@ HMX_PREC_F64, HMX_PREC_F32, HMX_PREC_Z64, HMX_PREC_C32 = 0, 1, 2, 3
 HMX_KERNEL_INV_DIST, HMX_KERNEL_HELMHOLTZ, HMX_KERNEL_LAPLACE_SL = 0, 1, 2
 HMX_NUMBERING_PARTITION, HMX_NUMBERING_USER = 0, 1
 # hmx_option (include/hmx.h): name -> id
-OPTIONS = {"r_piece_rows": 1, "r_tree_pieces": 2, "layout_threads": 3, "task_order": 4, "sym_storage": 5, "build_timing": 6, "xcd_unit_rows": 7,
+OPTIONS = {"r_piece_rows": 1, "r_tree_pieces": 2, "layout_threads": 3, "task_order": 4, "sym_storage": 5, "build_timing": 6, "xcd_unit_rows": 7, "sym_group": 8, "sym_group_slots": 9,
            "reduce_waves": 10, "expand_waves": 11, "multi_rhs_fused": 12, "matrix_cores": 13, "matrix_cores_f32": 14, "wide_sweeps": 15,
            "scalar_operands": 16, "sym_multi_rhs": 17, "sym_no_view": 18, "transposed_layout": 19,
            "callback_threads": 30, "callback_drivers": 31, "pool_sample": 32, "pool_rank_guess": 33, "aca_teams": 34, "aca_team_min": 35,
@@ -150,6 +150,7 @@ SYMBOLS = [
     ("hmx_dist_create", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     ("hmx_dist_destroy", None, [_vp]),
     ("hmx_dist_add_local_to_local_operator", C.c_int, [_vp, _vp]),
+    ("hmx_dist_add_global_to_local_operator", C.c_int, [_vp, _vp]),
     ("hmx_dist_matvec_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matvec_local_to_local", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, _vp]),
     ("hmx_dist_matmat_row_major_global_to_global", C.c_int, [_vp, C.c_char, _vp, _vp, _vp, _vp, C.c_int, _vp]),

@@ -566,6 +566,10 @@ int hmx_device_copy_bandwidth(int device_id, int64_t bytes, int reps, double *gb
 struct hmx_dist {
     hmx_hmatrix *local = nullptr; // the global-to-local operator (the rank's block rows), may be absent
     hmx_hmatrix *diag  = nullptr; // a local-to-local operator (hmx_dist_add_local_to_local_operator: the block-diagonal H-matrix of partition `rank`)
+    // DistributedOperator holds VECTORS of both kinds and loops over them (distributed_operator.hpp:47-53, global_to_global.hpp:63-72): the
+    // operators registered after the first of each kind (hmx_dist_add_global_to_local_operator, further hmx_dist_add_local_to_local_operator calls)
+    std::vector<hmx_hmatrix *> more_local, more_diag;
+    bool one_operator() const { return local && !diag && more_local.empty() && more_diag.empty(); } // what the chunked / overlapped exchange is built for
     void *comm         = nullptr;
     int rank = 0, world = 1;
     hmx_rccl_api api{};
@@ -742,17 +746,36 @@ static const void *dist_one(const hmx_dist &D) {
 static int dist_local_matmat(hmx_dist &D, char trans, const void *alpha, const void *in, const void *beta, void *out, int mu, hipStream_t st) {
     const size_t row = D.esz * (size_t)mu;
     bool first = true;
-    if (D.local) {
-        const int rc = mu == 1 ? dist_op_product(D.local, trans, alpha, in, beta, out, st) : dist_op_matmat(D.local, trans, alpha, in, beta, out, mu, st);
-        if (rc != HMX_OK)
-            return rc;
-        first = false;
-    }
-    if (D.diag) {
+    auto g2l = [&](hmx_hmatrix *H) {
+        const void *b = first ? beta : dist_one(D);
+        first         = false;
+        return mu == 1 ? dist_op_product(H, trans, alpha, in, b, out, st) : dist_op_matmat(H, trans, alpha, in, b, out, mu, st);
+    };
+    auto l2l = [&](hmx_hmatrix *H) {
         const void *in2 = trans == 'N' ? static_cast<const void *>(static_cast<const char *>(in) + (size_t)D.s_off[D.rank] * row) : in;
         void *out2      = trans == 'N' ? out : static_cast<void *>(static_cast<char *>(out) + (size_t)D.s_off[D.rank] * row);
         const void *b2  = first ? beta : dist_one(D);
-        const int rc    = mu == 1 ? dist_op_product(D.diag, trans, alpha, in2, b2, out2, st) : dist_op_matmat(D.diag, trans, alpha, in2, b2, out2, mu, st);
+        first           = false;
+        return mu == 1 ? dist_op_product(H, trans, alpha, in2, b2, out2, st) : dist_op_matmat(H, trans, alpha, in2, b2, out2, mu, st);
+    };
+    // the order of global_to_global.hpp:63-72: every global-to-local operator, then every local-to-local operator; beta once
+    if (D.local) {
+        const int rc = g2l(D.local);
+        if (rc != HMX_OK)
+            return rc;
+    }
+    for (hmx_hmatrix *H : D.more_local) {
+        const int rc = g2l(H);
+        if (rc != HMX_OK)
+            return rc;
+    }
+    if (D.diag) {
+        const int rc = l2l(D.diag);
+        if (rc != HMX_OK)
+            return rc;
+    }
+    for (hmx_hmatrix *H : D.more_diag) {
+        const int rc = l2l(H);
         if (rc != HMX_OK)
             return rc;
     }
@@ -774,7 +797,7 @@ static int dist_local_product_chunked(hmx_dist &D, const void *alpha, const void
 }
 static int dist_chunk_bounds(hmx_dist &D, int nchunks, int *n, int32_t *b) {
     hmx_hmatrix *H = D.local;
-    if (!H || D.diag) { // the chunked expand stage exists for ONE operator: with a local-to-local operator registered the exchange stays whole
+    if (!H || !D.one_operator()) { // the chunked expand stage exists for ONE operator: with more registered the exchange stays whole
         *n   = 1;
         b[0] = 0;
         b[1] = D.t_size[D.rank];
@@ -790,7 +813,7 @@ static int dist_chunk_bounds(hmx_dist &D, int nchunks, int *n, int32_t *b) {
 }
 static int dist_chunk_bounds_mu(hmx_dist &D, int nchunks, int *n, int32_t *b) {
     hmx_hmatrix *H = D.local;
-    if (!H || D.diag) {
+    if (!H || !D.one_operator()) {
         *n   = 1;
         b[0] = 0;
         b[1] = D.t_size[D.rank];
@@ -1173,7 +1196,7 @@ int hmx_dist_create(hmx_hmatrix *local, const hmx_cluster_tree *target, const hm
  * (implementations/local_to_local_operators/hmatrix.hpp:15-56): the H-matrix on (target partition rank) x (source partition rank), built
  * on a block tree from hmx_block_tree_create_local -- DefaultLocalApproximationBuilder's block-diagonal operator (utility.hpp:64-88).
  * Every product then adds its contribution on the rank's slices, after the global-to-local operator's (which may be absent: create the
- * hmx_dist with local = NULL).  One of each kind at most; same coefficient type. */
+ * hmx_dist with local = NULL).  May be called several times (the reference keeps a vector); same coefficient type. */
 int hmx_dist_add_local_to_local_operator(hmx_dist *D, hmx_hmatrix *diag) {
     if (!D || !diag) {
         set_error("hmx_dist_add_local_to_local_operator: NULL argument");
@@ -1194,7 +1217,41 @@ int hmx_dist_add_local_to_local_operator(hmx_dist *D, hmx_hmatrix *diag) {
             return HMX_ERR_INVALID;
         }
     }
-    D->diag = diag;
+    if (D->diag)
+        D->more_diag.push_back(diag); // (the reference keeps a vector: distributed_operator.hpp:50-53)
+    else
+        D->diag = diag;
+    dist_set_precision(*D, prec);
+    D->nchunks = 0; // see dist_chunk_bounds
+    return HMX_OK;
+}
+/* DistributedOperator::add_global_to_local_operator (distributed_operator/distributed_operator.hpp:47-49): ANOTHER operator from the whole
+ * source numbering to this rank's rows -- the reference keeps a vector of them and every product loops over it (global_to_global.hpp:63-66),
+ * e.g. an H-matrix plus a correction.  Root block: (target partition rank) x (the whole source cluster); same coefficient type.  Kept by
+ * reference.  With more than one operator the output exchange is the plain one (the chunked / overlapped forms are built for one operator). */
+int hmx_dist_add_global_to_local_operator(hmx_dist *D, hmx_hmatrix *op) {
+    if (!D || !op) {
+        set_error("hmx_dist_add_global_to_local_operator: NULL argument");
+        return HMX_ERR_INVALID;
+    }
+    const int prec       = hmx_hmatrix_precision(op);
+    hmx_hmatrix *any_old = D->local ? D->local : D->diag;
+    if (any_old && hmx_hmatrix_precision(any_old) != prec) {
+        set_error("hmx_dist_add_global_to_local_operator: the operators of one DistributedOperator have one coefficient type");
+        return HMX_ERR_INVALID;
+    }
+    int32_t r[4] = {0, 0, 0, 0};
+    const int rc = op->d ? hmx::f64::api_root(op->d, r) : (op->s ? hmx::f32::api_root(op->s, r) : (op->z ? hmx::z64::api_root(op->z, r) : hmx::c32::api_root(op->c, r)));
+    if (rc != HMX_OK || r[0] != D->t_off[D->rank] || r[1] != D->t_size[D->rank] || r[2] != 0 || r[3] != D->ns) {
+        set_error("hmx_dist_add_global_to_local_operator: the operator is not the (target partition of this rank) x (whole source cluster) block: rows [" + std::to_string(r[0]) + ", +" +
+                  std::to_string(r[1]) + "), columns [" + std::to_string(r[2]) + ", +" + std::to_string(r[3]) + ") against [" + std::to_string(D->t_off[D->rank]) + ", +" +
+                  std::to_string(D->t_size[D->rank]) + ") x [0, +" + std::to_string(D->ns) + ")");
+        return HMX_ERR_INVALID;
+    }
+    if (D->local)
+        D->more_local.push_back(op);
+    else
+        D->local = op;
     dist_set_precision(*D, prec);
     D->nchunks = 0; // see dist_chunk_bounds
     return HMX_OK;
@@ -1328,7 +1385,7 @@ int hmx_dist_matmat_row_major_global_to_global(hmx_dist *Dp, char trans, const v
             HMX_HIP(D.work.alloc((size_t)n * e));
         if (!dist_beta_is_zero(D, beta))
             HMX_HIP(hipMemcpyAsync(D.work.d, yb + (size_t)off * e, (size_t)n * e, hipMemcpyDeviceToDevice, st));
-        if (D.overlap > 1 && mu > 1 && (D.world > 1 || D.force) && D.local && !D.diag) {
+        if (D.overlap > 1 && mu > 1 && (D.world > 1 || D.force) && D.one_operator()) {
             // expand stage in row chunks on `st`, every chunk's (mu-interleaved) rows exchanged on the side stream under the next chunk's
             // kernels -- hmx_dist_matvec_global_to_global's scheme; the chunk rows of the multi-RHS layout are agreed on at the first call
             if (!D.mu_bounds_known) {
@@ -1394,7 +1451,7 @@ int hmx_dist_matvec_local_to_local(hmx_dist *Dp, char trans, const void *alpha, 
         set_error("hmx_dist: no operator registered");
         return HMX_ERR_STATE;
     }
-    if (!D.local) // local-to-local operators only (local_to_local.hpp:27-31): local slices in and out, nothing to exchange
+    if (!D.local && D.more_local.empty() && D.more_diag.empty()) // ONE local-to-local operator only (local_to_local.hpp:27-31): local slices in and out, nothing to exchange
         return dist_op_product(D.diag, trans, alpha, x_local, beta, y_local, st);
     if (trans == 'N') { // all-gather of x, then the local product straight into the local slice
         const size_t bytes = (size_t)D.ns * e;
@@ -1454,7 +1511,7 @@ int hmx_dist_matmat_row_major_local_to_local(hmx_dist *Dp, char trans, const voi
         set_error("hmx_dist: no operator registered");
         return HMX_ERR_STATE;
     }
-    if (!D.local) // local-to-local operators only: nothing to exchange
+    if (!D.local && D.more_local.empty() && D.more_diag.empty()) // ONE local-to-local operator only: nothing to exchange
         return dist_op_matmat(D.diag, trans, alpha, X_local, beta, Y_local, mu, st);
     const size_t e = D.esz * (size_t)mu; // bytes per row
     const size_t bytes = (size_t)D.ns * e;

@@ -574,6 +574,8 @@ static const OptionSpec HMX_OPTION_SPECS[] = {
     {HMX_OPT_TASK_ORDER, "HMX_SORT_TASKS", false, 1, 0, 3, OPT_LAYOUT},
     {HMX_OPT_XCD_UNIT_ROWS, "HMX_XCD_UNIT_ROWS", false, 512, 64, 1 << 20, OPT_LAYOUT},
     {HMX_OPT_SYM_STORAGE, "HMX_SYM_EXPANDED", false, 0, 0, 1, OPT_LAYOUT},
+    {HMX_OPT_SYM_GROUP, "HMX_SYM_GROUP", false, 4, 1, 16, OPT_LAYOUT},
+    {HMX_OPT_SYM_GROUP_SLOTS, "HMX_SYM_GROUP_SLOTS", false, -1, -1, 1024, OPT_LAYOUT},
     {HMX_OPT_BUILD_TIMING, "HMX_BUILD_TIMING", false, 0, 0, 1, OPT_BUILD},
     {HMX_OPT_REDUCE_WAVES, "HMX_REDUCE_WAVES", false, 0, 0, 8, OPT_PRODUCT},
     {HMX_OPT_EXPAND_WAVES, "HMX_EXPAND_WAVES", false, 0, 0, 8, OPT_PRODUCT},

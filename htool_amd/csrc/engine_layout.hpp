@@ -59,41 +59,129 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
         epad[r] = EWN;
         EWN += (E.cols[r] + 15) & ~15;
     }
-    const int64_t EWBASE = (A_total + 15) & ~int64_t(15), RWBASE = EWBASE + EWN;
-    // low-rank mirrored leaves: column sums land in EW; a leaf inside ONE range is complete there (a' is read from EW),
-    // otherwise a list of its column-group positions feeds combine_list_kernel, which writes a'[aoff + k]
-    std::vector<int32_t> nrange(nb, 0);
+    const int64_t EWBASE = (A_total + 15) & ~int64_t(15), FLBASE = EWBASE + EWN;
+    // ---- groups of row ranges (round 6) -----------------------------------------------------------------------------------------------
+    // One workgroup of the mirrored sweep takes a GROUP of G consecutive row ranges, one after the other.  A mirrored column whose sum
+    // belongs with the sums of columns of OTHER ranges of the group -- the r columns of a low-rank leaf that spans several of them (partial
+    // sums of the same a'), the columns of dense leaves of the group that share their source cluster (contributions to the same output rows)
+    // -- is not written out per range: it is added to an accumulator in LDS and the group writes the folded sums once, as one contiguous run
+    // (the FLUSH slots of the group).  With 16 right-hand sides the partial sums were a quarter of the bytes the sweep reads, written and
+    // then read again by the folding kernels; at N = 1e6, G = 4, it is 40 % of that.  mdst >= 0: slot in W, written per range; <= -2:
+    // accumulator -2 - mdst of the group.  The candidates that would save most go first while the group's LDS budget lasts (`gcap` accumulators);
+    // the others keep their own slots.  G = 1: no accumulators, the layout of rounds 2-5.  Fixed order of the additions (range by range; a
+    // column is one lane's): bit-reproducible.
+    const int nre = E.nranges();
+    const int G   = std::max(1, H.opt.i(HMX_OPT_SYM_GROUP));
+    // accumulators per group: what leaves the 16-RHS sweep its waves per SIMD -- LDS decides: tiles + accumulators of two workgroups per CU for
+    // 8-byte reals (36.9 KB + 320 x 128 B each), of three for 4-byte reals (20.5 KB + 512 x 64 B) in 160 KB
+    const int gcap_auto = sizeof(real) == 8 ? 320 : 512;
+    const int gcap = G > 1 ? (H.opt.i(HMX_OPT_SYM_GROUP_SLOTS) < 0 ? gcap_auto : H.opt.i(HMX_OPT_SYM_GROUP_SLOTS)) : 0;
+    const int ng  = (nre + G - 1) / G;
+    // pair -> accumulator of its group (-1: own slots); dense: and whether the pair is the first of its key (it alone counts as a contribution)
+    std::vector<int32_t> lr_acc(elr_b.size(), -1), d_acc(ed_b.size(), -1);
+    std::vector<char> d_first(ed_b.size(), 1);
+    std::vector<int32_t> gna(ng, 0);
+    if (gcap > 0) {
+        struct Cand {
+            int32_t g, count, width, kind; // kind 0: run of low-rank pairs [lo, hi) of elr_*, 1: dense pairs dk[lo .. hi)
+            int64_t lo, hi;
+        };
+        std::vector<Cand> cand;
+        for (size_t p = 0; p < elr_b.size();) { // the pairs of a leaf are consecutive (leaf-major) and cover consecutive ranges
+            size_t q = p + 1;
+            while (q < elr_b.size() && elr_b[q] == elr_b[p] && elr_r[q] / G == elr_r[p] / G)
+                q++;
+            if (q - p >= 2 && is_mir(elr_b[p]))
+                cand.push_back({elr_r[p] / G, (int32_t)(q - p), (int32_t)XL[elr_b[p]].rank, 0, (int64_t)p, (int64_t)q});
+            p = q;
+        }
+        std::vector<std::pair<int64_t, int32_t>> dk; // (group, source offset) -> dense pair
+        for (size_t p = 0; p < ed_b.size(); p++)
+            if (is_mir(ed_b[p]))
+                dk.emplace_back(((int64_t)(ed_r[p] / G) << 32) | (uint32_t)XL[ed_b[p]].s_offset, (int32_t)p);
+        std::sort(dk.begin(), dk.end());
+        for (size_t i = 0; i < dk.size();) {
+            size_t j = i + 1;
+            bool same_size = true;
+            while (j < dk.size() && dk[j].first == dk[i].first) {
+                same_size = same_size && XL[ed_b[dk[j].second]].s_size == XL[ed_b[dk[i].second]].s_size;
+                j++;
+            }
+            if (j - i >= 2 && same_size)
+                cand.push_back({(int32_t)(dk[i].first >> 32), (int32_t)(j - i), (int32_t)XL[ed_b[dk[i].second]].s_size, 1, (int64_t)i, (int64_t)j});
+            i = j;
+        }
+        std::sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) {
+            if (x.g != y.g) return x.g < y.g;
+            if (x.count != y.count) return x.count > y.count; // saves (count - 1) writes per accumulator
+            if (x.kind != y.kind) return x.kind < y.kind;
+            return x.lo < y.lo;
+        });
+        for (const Cand &c : cand) {
+            if (gna[c.g] + c.width > gcap)
+                continue;
+            const int32_t at = gna[c.g];
+            gna[c.g] += c.width;
+            if (c.kind == 0)
+                for (int64_t p = c.lo; p < c.hi; p++)
+                    lr_acc[p] = at;
+            else
+                for (int64_t i = c.lo; i < c.hi; i++) {
+                    d_acc[dk[i].second]   = at;
+                    d_first[dk[i].second] = i == c.lo;
+                }
+        }
+    }
+    std::vector<int64_t> gfl(ng + 1, 0); // flush slots of group g: FLBASE + gfl[g] ... (16-aligned runs)
+    for (int g = 0; g < ng; g++)
+        gfl[g + 1] = gfl[g] + ((gna[g] + 15) & ~15);
+    const int64_t RWBASE = FLBASE + gfl[ng];
+    phase_nosync("  sym: groups");
+    // low-rank mirrored leaves: a leaf whose column sums end up in ONE place (one range, or one group's accumulators) is complete there (a'
+    // is read from that slot), otherwise a list of the places of its partial sums feeds combine_list_kernel, which writes a'[aoff + k]
+    std::vector<int32_t> nlist(nb, 0);
     for (size_t p = 0; p < elr_b.size(); p++)
-        nrange[elr_b[p]]++;
+        if (lr_acc[p] < 0 || p == 0 || elr_b[p - 1] != elr_b[p] || lr_acc[p - 1] != lr_acc[p] || elr_r[p - 1] / G != elr_r[p] / G)
+            nlist[elr_b[p]]++;
     std::vector<int64_t> lptr(nb, -1);
     int64_t LN = 0;
     for (int64_t b = 0; b < nb; b++)
-        if (is_mir(b) && XK[b] == LK_LOWRANK && XL[b].rank > 0 && nrange[b] > 1) {
+        if (is_mir(b) && XK[b] == LK_LOWRANK && XL[b].rank > 0 && nlist[b] > 1) {
             lptr[b] = LN;
-            LN += nrange[b];
+            LN += nlist[b];
         }
     phase_nosync("  sym: setup");
     s_list.assign(LN, 0);
     std::vector<int64_t> single_slot(nb, -1);
     {
-        // the pairs of a leaf are consecutive in elr_* (leaf-major) and cover consecutive ranges: position in the leaf's list = r - first range
-        std::vector<int32_t> first_range(nb, -1);
+        // first pair of every leaf (the pairs of a leaf are consecutive): the threads below walk whole leaves
+        std::vector<int64_t> leaf_first;
         for (size_t p = 0; p < elr_b.size(); p++)
-            if (first_range[elr_b[p]] < 0)
-                first_range[elr_b[p]] = elr_r[p];
-        parallel_for(elr_b.size(), [&](size_t lo, size_t hi) {
-            for (size_t p = lo; p < hi; p++) {
-                const int b = elr_b[p], r = elr_r[p];
+            if (p == 0 || elr_b[p - 1] != elr_b[p])
+                leaf_first.push_back((int64_t)p);
+        leaf_first.push_back((int64_t)elr_b.size());
+        parallel_for(leaf_first.size() - 1, [&](size_t lo, size_t hi) {
+            for (size_t li = lo; li < hi; li++) {
+                const int b = elr_b[leaf_first[li]];
                 if (!is_mir(b))
                     continue;
-                const int64_t base = EWBASE + epad[r] + elr_c[p];
-                if (nrange[b] == 1)
-                    single_slot[b] = base;
-                else
-                    s_list[lptr[b] + (r - first_range[b])] = (int32_t)base;
-                int32_t *dst = s_mdst.data() + E.colbase[r] + elr_c[p];
-                for (int k = 0; k < XL[b].rank; k++)
-                    dst[k] = (int32_t)(base + k);
+                int64_t at = 0; // position in the leaf's list
+                for (int64_t p = leaf_first[li]; p < leaf_first[li + 1]; p++) {
+                    const int r = elr_r[p];
+                    const bool acc = lr_acc[p] >= 0;
+                    const bool first_of_run = !acc || p == leaf_first[li] || lr_acc[p - 1] != lr_acc[p] || elr_r[p - 1] / G != r / G;
+                    const int64_t base = acc ? FLBASE + gfl[r / G] + lr_acc[p] : EWBASE + epad[r] + elr_c[p];
+                    if (first_of_run) {
+                        if (nlist[b] == 1)
+                            single_slot[b] = base;
+                        else
+                            s_list[lptr[b] + at] = (int32_t)base;
+                        at++;
+                    }
+                    int32_t *dst = s_mdst.data() + E.colbase[r] + elr_c[p];
+                    for (int k = 0; k < XL[b].rank; k++)
+                        dst[k] = acc ? (int32_t)(-2 - (lr_acc[p] + k)) : (int32_t)(base + k);
+                }
             }
         });
     }
@@ -109,11 +197,11 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     }
     for (int pass = 0; pass < 2; pass++) // entries with many partial sums first (one wave each), then the rest (one thread each)
         for (int64_t b = 0; b < nb; b++)
-            if (lptr[b] >= 0 && (nrange[b] >= 32) == (pass == 0)) {
+            if (lptr[b] >= 0 && (nlist[b] >= 32) == (pass == 0)) {
                 for (int k = 0; k < XL[b].rank; k++) {
                     s_cd.push_back((int32_t)(aoff[b] + k));
                     s_clp.push_back((int32_t)lptr[b]);
-                    s_cc.push_back(nrange[b]);
+                    s_cc.push_back(nlist[b]);
                     s_ck.push_back(k);
                 }
                 if (pass == 0)
@@ -300,6 +388,8 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
             bad = true;
             break;
         }
+        if (!d_first[p])
+            continue; // folded with an earlier pair of its group: one contribution for all of them
         for (int j = 0; j < l.s_size; j++)
             s_cnt[j0 + j]++;
     }
@@ -330,11 +420,13 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
             const int ja = std::max(0, (int)clo - j0), jb = std::min((int)l.s_size, (int)chi - j0);
             if (ja >= jb)
                 continue;
-            const int64_t base = EWBASE + epad[r] + ed_c[p];
+            const bool acc     = d_acc[p] >= 0;
+            const int64_t base = acc ? FLBASE + gfl[r / G] + d_acc[p] : EWBASE + epad[r] + ed_c[p];
             int32_t *dst       = s_mdst.data() + E.colbase[r] + ed_c[p];
             for (int j = ja; j < jb; j++) {
-                dst[j]                                               = (int32_t)(base + j);
-                s_fidx[(size_t)(fill[j0 + j]++) * nOut + (j0 + j)] = (int32_t)(base + j);
+                dst[j] = acc ? (int32_t)(-2 - (d_acc[p] + j)) : (int32_t)(base + j);
+                if (d_first[p])
+                    s_fidx[(size_t)(fill[j0 + j]++) * nOut + (j0 + j)] = (int32_t)(base + j);
             }
         }
     });
@@ -344,6 +436,31 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     phase_nosync("fused symmetric slots");
 
     // ---- uploads (the first one waits for whatever is queued on the null stream: the pack kernels of build_streams) ----
+    {   // launch order of the groups: heaviest first
+        std::vector<int64_t> gw(ng, 0);
+        for (int r = 0; r < nre; r++)
+            gw[r / G] += (int64_t)E.len[r] * E.cols[r];
+        std::vector<int32_t> gorder(ng), gflush(ng);
+        std::iota(gorder.begin(), gorder.end(), 0);
+        std::stable_sort(gorder.begin(), gorder.end(), [&](int x, int y) { return gw[x] > gw[y]; });
+        for (int g = 0; g < ng; g++)
+            gflush[g] = (int32_t)(FLBASE + gfl[g]);
+        HMX_HIP(H.s_grp_order.upload(gorder));
+        HMX_HIP(H.s_grp_flush.upload(gflush));
+        HMX_HIP(H.s_grp_na.upload(gna));
+        H.s_ngroups = ng;
+        H.s_group   = G;
+        H.s_gcap    = 0;
+        for (int g = 0; g < ng; g++)
+            H.s_gcap = std::max(H.s_gcap, (int)gna[g]);
+        if (H.opt.i(HMX_OPT_BUILD_TIMING) != 0) { // how many partial sums a sweep still writes
+            int64_t own = 0, folded = 0;
+            for (int32_t v : s_mdst)
+                (v >= 0 ? own : folded) += v != -1;
+            fprintf(stderr, "[hmx build]   mirrored sweeps: groups of %d row ranges, %lld column sums written per range + %lld folded in LDS into %lld written per group (largest group: %d accumulators)\n",
+                    G, (long long)own, (long long)folded, (long long)std::accumulate(gna.begin(), gna.end(), (int64_t)0), H.s_gcap);
+        }
+    }
     HMX_HIP(H.s_mdst.upload(s_mdst));
     HMX_HIP(H.s_coef.upload(s_coef));
     HMX_HIP(H.s_count.upload(s_cnt));

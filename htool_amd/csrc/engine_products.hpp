@@ -14,6 +14,18 @@ static void prof_mark(HMat &H, hipStream_t st, const char *name) {
     H.ev_names.push_back(name);
 }
 
+// the mirrored sweeps keep their group's accumulators in dynamic LDS (beyond the 64 KB a kernel may use without saying so)
+#define HMX_LAUNCH_GROUPED(kernel, grid, block, lds_bytes, st, ...)                                                                    \
+    do {                                                                                                                                \
+        static size_t allowed_ = 0;                                                                                                     \
+        if ((size_t)(lds_bytes) > allowed_) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes)); \
+            (void)hipGetLastError();                                                                                                    \
+            allowed_ = (size_t)(lds_bytes);                                                                                             \
+        }                                                                                                                               \
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, st, __VA_ARGS__);                                                            \
+    } while (0)
+
 // forward pass on device pointers: y = alpha * (sum over leaves) x + beta * y using the fast kernels
 // zidx: coefficient index array of the E-streams (all leaves, or mirror leaves only)
 static int ensure_expand_chunks(HMat &H, int nchunks) {
@@ -87,12 +99,12 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, scalar
         // compact symmetric storage: forward product and mirrored column sums in one sweep over the E-streams, then a' is
         // folded, the R-streams are swept a second time (y_s += V^T a') and the output levels are added in their fixed order
         if (H.E.nranges() > 0) {
-            ExpandSymArgs X{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx},
-                            H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0};
-            const size_t lds = 0;
+            ExpandSymArgs X{{H.E.stream.d, H.s_grp_order.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, zidx, H.Z.d, y, alpha, beta, H.E.nranges(), xin, nx},
+                            H.s_mdst.d, H.SW.d, x_src + (H.T0 - H.S0), H.symmetry_for_leaves == 'H' ? 1 : 0, H.s_grp_flush.d, H.s_grp_na.d, H.s_group};
+            const size_t lds = (size_t)H.s_gcap * sizeof(scalar);
             switch (EW) {
-            case 8: hipLaunchKernelGGL(expand_sym_kernel<8>, dim3(H.E.nranges()), dim3(512), lds, st, X); break;
-            default: hipLaunchKernelGGL(expand_sym_kernel<4>, dim3(H.E.nranges()), dim3(256), lds, st, X); break;
+            case 8: HMX_LAUNCH_GROUPED(expand_sym_kernel<8>, dim3(H.s_ngroups), dim3(512), lds, st, X); break;
+            default: HMX_LAUNCH_GROUPED(expand_sym_kernel<4>, dim3(H.s_ngroups), dim3(256), lds, st, X); break;
             }
             prof_mark(H, st, "expand_sym_kernel");
         }
@@ -240,11 +252,12 @@ static int build_trans_tables(HMat &H) {
 static int run_transposed_fused(HMat &H, const scalar *in, scalar alpha, scalar beta, scalar *out, hipStream_t st) {
     const int EW = H.opt.i(HMX_OPT_EXPAND_WAVES) ? H.opt.i(HMX_OPT_EXPAND_WAVES) : (H.E.nranges() <= 4096 ? 8 : 4);
     if (H.E.nranges() > 0) {
-        ExpandSymArgs X{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, nullptr, H.Z.d, nullptr, alpha, beta, H.E.nranges(), nullptr, 0},
-                        H.s_mdst.d, H.SW.d, in, 0};
+        ExpandSymArgs X{{H.E.stream.d, H.s_grp_order.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, nullptr, H.Z.d, nullptr, alpha, beta, H.E.nranges(), nullptr, 0},
+                        H.s_mdst.d, H.SW.d, in, 0, H.s_grp_flush.d, H.s_grp_na.d, H.s_group};
+        const size_t lds = (size_t)H.s_gcap * sizeof(scalar);
         switch (EW) {
-        case 8: hipLaunchKernelGGL((expand_sym_kernel<8, false>), dim3(H.E.nranges()), dim3(512), 0, st, X); break;
-        default: hipLaunchKernelGGL((expand_sym_kernel<4, false>), dim3(H.E.nranges()), dim3(256), 0, st, X); break;
+        case 8: HMX_LAUNCH_GROUPED((expand_sym_kernel<8, false>), dim3(H.s_ngroups), dim3(512), lds, st, X); break;
+        default: HMX_LAUNCH_GROUPED((expand_sym_kernel<4, false>), dim3(H.s_ngroups), dim3(256), lds, st, X); break;
         }
         prof_mark(H, st, "expand_colsum_kernel");
     }
@@ -459,26 +472,13 @@ static int run_forward_mu(HMat &H, const scalar *X, scalar alpha, scalar beta, s
 // Real coefficients run on the matrix cores (expand_sym_mfma16_kernel, rowsym_mfma16_kernel), complex ones on the VALU (expand_sym_mu_kernel,
 // rowsym_mu_kernel; round 5 -- before, complex operators without room for the view ran one single-vector product per right-hand side).
 static bool sym_mu_fused(const HMat &H) {
-    // HMX_OPT_SYM_MULTI_RHS = 1: always the stored triangle; 0: always the expanded view; -1: the expanded view while HBM has room for it
-    // (the faster of the two today: N = 4e6 fp32, 16 right-hand sides, one MI355X: 15.9 ms on 42 + 83 GB against 18 ms on 42 + 6 GB),
-    // the stored triangle when it has not, or when the factors the view is built from were released
+    // HMX_OPT_SYM_MULTI_RHS = 1 or -1 (the default): the stored triangle; 0: an expanded view of the operator (twice the memory, twice the
+    // traffic by construction).  Until round 5 the view was the default for real coefficients while HBM had room for it -- it was the faster of
+    // the two (N = 1e6 fp64, 16 right-hand sides: 3.6 against 3.7-4.2 ms).  Round 6 (column sums folded per group of row ranges in LDS, the second
+    // sweep over the R-streams as one pipeline per interval, two / three waves per SIMD): 3.3 ms on the stored triangle against 3.8 on the view,
+    // one rank's operator of BASELINE configs[4] 2.2 ms either way at 7.6 instead of 18.2 GB -- nothing is built unless it is asked for.
     const int mode = H.opt.i(HMX_OPT_SYM_MULTI_RHS);
-    if (!(H.sym_fused && H.s64_nint > 0) || mode == 0)
-        return false;
-    if (mode > 0)
-        return true;
-#if HMX_COMPLEX
-    // complex coefficients: the stored triangle is as fast as the view (N = 1e6 Hermitian complex double, 8 right-hand sides: 17.0 ms on 54.8 GB
-    // against 18.2 ms on 54.8 + 108.5 GB; complex symmetric 6.4 against 6.6 ms) -- the mirrored product packs both planes of 8 columns into one
-    // MFMA per k-step -- so nothing is built unless it is asked for
-    return true;
-#endif
-    if (H.X_op)
-        return false;
-    if (H.X_op_failed || H.factors_released || H.opt.i(HMX_OPT_SYM_NO_VIEW) != 0)
-        return true;
-    size_t free_b = 0, total_b = 0;
-    return hmx_mem_info(&free_b, &total_b) != hipSuccess || (double)free_b < 2.3 * (double)H.stats.stream_bytes; // ensure_expanded_view's own admission test
+    return H.sym_fused && H.s64_nint > 0 && mode != 0;
 }
 static int ensure_sw16(HMat &H, hipStream_t st) {
     const size_t need16 = (size_t)(H.s_slots + 1) * SWW;
@@ -492,23 +492,24 @@ static int ensure_sw16(HMat &H, hipStream_t st) {
 static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow, scalar alpha, scalar beta, scalar *Y, int nout, int accumulate, int herm, int mu, int c, int nrhs, hipStream_t st) {
     constexpr int W = 4;
     if (H.E.nranges() > 0) {
-        ExpandSymArgs XS{{H.E.stream.d, H.E.d_task_range.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, fwd ? H.e_zidx.d : nullptr, fwd ? H.Zmu.d : nullptr,
+        ExpandSymArgs XS{{H.E.stream.d, H.s_grp_order.d, H.E.d_off.d, H.E.d_len.d, H.E.d_cols.d, H.E.d_base.d, H.E.d_colbase.d, fwd ? H.e_zidx.d : nullptr, fwd ? H.Zmu.d : nullptr,
                           fwd ? Y : nullptr, alpha, beta, H.E.nranges(), fwd ? X : nullptr, fwd ? H.nS : 0},
-                         H.s_mdst.d, H.SW16.d, xrow, herm};
-        const dim3 grid((unsigned)H.E.nranges()), wg(W * 64);
+                         H.s_mdst.d, H.SW16.d, xrow, herm, H.s_grp_flush.d, H.s_grp_na.d, H.s_group};
+        const dim3 grid((unsigned)H.s_ngroups), wg(W * 64);
+        const size_t lds = (size_t)H.s_gcap * SWW * sizeof(scalar); // the group's accumulators
 #if HMX_COMPLEX
 #define HMX_SYM_MU_E(MU)                                                                                      \
     do {                                                                                                      \
         if (fwd)                                                                                              \
-            hipLaunchKernelGGL((expand_sym_mu_kernel<W, MU, true>), grid, wg, 0, st, XS, mu, c, nrhs);        \
+            HMX_LAUNCH_GROUPED((expand_sym_mu_kernel<W, MU, true>), grid, wg, lds, st, XS, mu, c, nrhs);       \
         else                                                                                                  \
-            hipLaunchKernelGGL((expand_sym_mu_kernel<W, MU, false>), grid, wg, 0, st, XS, mu, c, nrhs);       \
+            HMX_LAUNCH_GROUPED((expand_sym_mu_kernel<W, MU, false>), grid, wg, lds, st, XS, mu, c, nrhs);      \
     } while (0)
         if (H.opt.i(HMX_OPT_MATRIX_CORES) != 0) { // groups of up to 8 on the matrix cores (ragged groups: operands nobody stores the results of)
             if (fwd)
-                hipLaunchKernelGGL((expand_sym_zmfma8_kernel<W, true>), grid, wg, 0, st, XS, mu, c, nrhs);
+                HMX_LAUNCH_GROUPED((expand_sym_zmfma8_kernel<W, true>), grid, wg, lds, st, XS, mu, c, nrhs);
             else
-                hipLaunchKernelGGL((expand_sym_zmfma8_kernel<W, false>), grid, wg, 0, st, XS, mu, c, nrhs);
+                HMX_LAUNCH_GROUPED((expand_sym_zmfma8_kernel<W, false>), grid, wg, lds, st, XS, mu, c, nrhs);
             prof_mark(H, st, fwd ? "expand_sym_zmfma8_kernel" : "expand_colsum_zmfma8_kernel");
         } else {
             if (nrhs <= 2)
@@ -522,9 +523,9 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
 #undef HMX_SYM_MU_E
 #else
         if (fwd)
-            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W, true>), grid, wg, 0, st, XS, mu, c, nrhs);
+            HMX_LAUNCH_GROUPED((expand_sym_mfma16_kernel<W, true>), grid, wg, lds, st, XS, mu, c, nrhs);
         else
-            hipLaunchKernelGGL((expand_sym_mfma16_kernel<W, false>), grid, wg, 0, st, XS, mu, c, nrhs);
+            HMX_LAUNCH_GROUPED((expand_sym_mfma16_kernel<W, false>), grid, wg, lds, st, XS, mu, c, nrhs);
         prof_mark(H, st, fwd ? "expand_sym_mfma16_kernel" : "expand_colsum_mfma16_kernel");
 #endif
     }

@@ -110,6 +110,9 @@ struct HMat {
     DArr<int32_t> s64_seg_wp, s64_seg_w;                // ... row pitch of the chunk, columns of the segment (<= 64)
     int s64_nint = 0;
     int64_t s_slots = 0; // slots of SW (a' | column sums)
+    // groups of row ranges of the mirrored sweeps (build_mirror_tables): launch order, first flush slot and number of LDS accumulators per group
+    DArr<int32_t> s_grp_order, s_grp_flush, s_grp_na;
+    int s_ngroups = 0, s_group = 1, s_gcap = 0; // groups, ranges per group, the largest number of accumulators of a group
     DArr<scalar> SW16;
     DArr<int32_t> sc_dst, sc_lp, sc_count, sc_k;
     int n_sym_combine = 0, n_sym_combine_wave = 0; // the first n_sym_combine_wave entries have >= 32 partial sums: one wave each

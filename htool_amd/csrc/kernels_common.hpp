@@ -331,13 +331,30 @@ template <> struct Acc4<float> { typedef hmx_f4 type; };
 #define HMX_WPE_EXPAND_MFMA16S_KERNEL __attribute__((amdgpu_waves_per_eu(3)))
 #endif
 #ifndef HMX_WPE_REDUCE_MFMA16S_KERNEL
+#if HMX_INST == 0
+// fp64: 192 registers by the compiler's own choice = 2 waves per SIMD; asked for 3 (<= 168): see the A/B in profiles/r6_variants.log
+#define HMX_WPE_REDUCE_MFMA16S_KERNEL __attribute__((amdgpu_waves_per_eu(3)))
+#else
 #define HMX_WPE_REDUCE_MFMA16S_KERNEL
 #endif
+#endif
+// The stored-triangle kernels (round 6): two waves per SIMD for 8-byte coefficients (<= 256 registers of the unified file, accumulation registers
+// included), three for 4-byte ones (<= 168).  Their dependent chains -- LDS round trip of the transposed tile, sixteen MFMAs into one
+// accumulator -- are hidden by the OTHER waves of the SIMD, not by loads in flight: the same instructions at 264 registers (one wave per
+// SIMD; the loop over a group's ranges had cost 24 registers) took 1.93 instead of 1.50 ms, SQ_WAVE_CYCLES halved (profiles/r6_pmc_ab_loop.log).
 #ifndef HMX_WPE_EXPAND_SYM_MFMA16_KERNEL
-#define HMX_WPE_EXPAND_SYM_MFMA16_KERNEL
+#if HMX_INST == 0
+#define HMX_WPE_EXPAND_SYM_MFMA16_KERNEL __attribute__((amdgpu_waves_per_eu(2)))
+#else
+#define HMX_WPE_EXPAND_SYM_MFMA16_KERNEL __attribute__((amdgpu_waves_per_eu(3)))
+#endif
 #endif
 #ifndef HMX_WPE_ROWSYM_MFMA16_KERNEL
-#define HMX_WPE_ROWSYM_MFMA16_KERNEL
+#if HMX_INST == 0
+#define HMX_WPE_ROWSYM_MFMA16_KERNEL __attribute__((amdgpu_waves_per_eu(2)))
+#else
+#define HMX_WPE_ROWSYM_MFMA16_KERNEL __attribute__((amdgpu_waves_per_eu(3)))
+#endif
 #endif
 __device__ __forceinline__ hmx_d4 mfma16(double a, double b, hmx_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ hmx_f4 mfma16(float a, float b, hmx_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }

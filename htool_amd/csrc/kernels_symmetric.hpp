@@ -73,7 +73,31 @@ struct ExpandSymArgs {
     scalar *W;
     const scalar *xrow;  // the input at the TARGET positions of this operator: xrow[range_off + i]
     int herm;            // 'H' storage: the mirrored leaf is the conjugate transpose
+    // groups of row ranges (build_mirror_tables): X.order is the launch order of the GROUPS, group g = ranges [g G, (g + 1) G); mdst <= -2 is
+    // accumulator -2 - mdst of the group (dynamic LDS: grp_na[g] accumulators of one value -- several right-hand sides: SWW values -- each),
+    // written to W[grp_flush[g] + ...] when the group's last range is done
+    const int32_t *grp_flush, *grp_na;
+    int G;
 };
+// the group's accumulators: zeroed before its first range, written out after its last one (all threads of the workgroup; vals = values per accumulator)
+extern __shared__ __attribute__((aligned(16))) unsigned char hmx_group_lds[];
+__device__ __forceinline__ void group_acc_zero(scalar *gacc, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        gacc[i] = scalar(0);
+}
+// a range's geometry inside the loop over a group's ranges: loaded after barriers and stores of the same kernel, the compiler no longer reads it
+// through the scalar cache and treats it as one value per lane -- every bound and base address of the sweep then lives in vector registers
+// (the 16-RHS sweep over the E-streams: 1.93 instead of 1.50 ms with identical instructions otherwise, round 6).  It IS wave-uniform: say so.
+__device__ __forceinline__ int uniform_value(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uniform_value(int64_t v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ void group_acc_flush(const scalar *gacc, scalar *W, int64_t first, int n) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        W[first + i] = gacc[i];
+}
 // The wave's columns are walked in groups of eight (sixteen for 4-byte coefficients), flattened over its 64-column tiles and
 // software-pipelined: the loads of group g + 1 are issued before group g is reduced, so the dependent chain of the eight-way
 // reduction never leaves the wave without loads in flight.
@@ -83,15 +107,22 @@ template <int WAVES, bool FWD = true>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
     const ExpandArgs &A = S.X;
     __shared__ scalar part[FWD ? WAVES : 1][WAVE];
-    const int R = A.order[blockIdx.x];
+    const int grp  = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int len = A.range_len[R], C = A.range_cols[R];
-    const scalar *E     = A.stream + A.range_base[R];
-    const int32_t *zidx = A.z_idx + A.range_colbase[R];
-    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    scalar *gacc   = reinterpret_cast<scalar *>(hmx_group_lds);
+    const int gna  = S.grp_na[grp];
+    group_acc_zero(gacc, gna);
+    const int R_end = (grp + 1) * S.G < A.nranges ? (grp + 1) * S.G : A.nranges;
+    for (int R = grp * S.G; R < R_end; R++) {
+    __syncthreads(); // the accumulators are zero / the previous range is done with `part`
+    const int len = uniform_value(A.range_len[R]), C = uniform_value(A.range_cols[R]), roff = uniform_value(A.range_off[R]);
+    const int64_t rbase = uniform_value(A.range_base[R]), rcolbase = uniform_value(A.range_colbase[R]);
+    const scalar *E     = A.stream + rbase;
+    const int32_t *zidx = A.z_idx + rcolbase;
+    const int32_t *mdst = S.mdst + rcolbase;
     const bool active   = lane < len;
     const int row       = active ? lane : 0;
-    const scalar xr     = active ? S.xrow[A.range_off[R] + lane] : scalar(0); // idle lanes contribute exact zeros to the column sums
+    const scalar xr     = active ? S.xrow[roff + lane] : scalar(0); // idle lanes contribute exact zeros to the column sums
     const bool herm     = S.herm != 0;
     scalar acc = scalar(0);
     // always eight loads, no branches (the compiler can then count them: s_waitcnt vmcnt(8) keeps the next group in flight while
@@ -121,7 +152,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
         if constexpr (FWD)
             z = lane < nc ? *expand_operand(A, zidx[c0 + lane], 1) : scalar(0);
         md  = lane < nc ? mdst[c0 + lane] : -1;
-        mir = __any(md >= 0); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
+        mir = __any(md != -1); // wave-uniform: tiles without mirrored columns (diagonal leaves, off-diagonal stripes) skip the reductions
     };
     auto process = [&](const scalar(&v)[GS], int jg) {
         if constexpr (FWD)
@@ -149,6 +180,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
                 const scalar t = hmx_shfl(mine, 8 * (lane & 7) + (lane >> 3));
                 if (md >= 0)
                     S.W[md] = t;
+                else if (md <= -2)
+                    gacc[-2 - md] += t; // (one lane of the workgroup per accumulator and range: see build_mirror_tables)
             }
         }
     };
@@ -186,10 +219,12 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S
 #pragma unroll
             for (int k = 1; k < WAVES; k++)
                 s += part[k][lane];
-            scalar *yo = A.y + A.range_off[R] + lane;
+            scalar *yo = A.y + roff + lane;
             *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
         }
     }
+    } // ranges of the group
+    group_acc_flush(gacc, S.W, S.grp_flush[grp], gna);
 }
 
 // Second sweep over the R-streams, owner-computes: y_s += V^T a' (conjugated for 'H').  The target rows are cut into intervals of
@@ -415,19 +450,26 @@ template <int WAVES, int MU, bool FWD = true>
 __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mu_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
     const ExpandArgs &A = S.X;
     __shared__ scalar part[FWD ? WAVES : 1][FWD ? WAVE : 1][FWD ? MU : 1];
-    const int R = A.order[blockIdx.x];
+    const int grp  = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int len = A.range_len[R], C = A.range_cols[R];
-    const scalar *E     = A.stream + A.range_base[R];
-    const int32_t *zidx = A.z_idx + A.range_colbase[R];
-    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    scalar *gacc   = reinterpret_cast<scalar *>(hmx_group_lds); // [accumulator][SWW]
+    const int gna  = S.grp_na[grp];
+    group_acc_zero(gacc, gna * SWW);
+    const int R_end = (grp + 1) * S.G < A.nranges ? (grp + 1) * S.G : A.nranges;
+    for (int R = grp * S.G; R < R_end; R++) {
+    __syncthreads(); // the accumulators are zero / the previous range is done with `part`
+    const int len = uniform_value(A.range_len[R]), C = uniform_value(A.range_cols[R]), roff = uniform_value(A.range_off[R]);
+    const int64_t rbase = uniform_value(A.range_base[R]), rcolbase = uniform_value(A.range_colbase[R]);
+    const scalar *E     = A.stream + rbase;
+    const int32_t *zidx = A.z_idx + rcolbase;
+    const int32_t *mdst = S.mdst + rcolbase;
     const bool active   = lane < len;
     const int row       = active ? lane : 0;
     const bool herm     = S.herm != 0;
     scalar xr[MU], acc[MU]; // the input at this lane's row (idle lanes and missing right-hand sides: exact zeros), the forward sums
 #pragma unroll
     for (int j = 0; j < MU; j++) {
-        xr[j]  = (active && j < nrhs) ? S.xrow[(int64_t)(A.range_off[R] + lane) * mu + cbase + j] : scalar(0);
+        xr[j]  = (active && j < nrhs) ? S.xrow[(int64_t)(roff + lane) * mu + cbase + j] : scalar(0);
         acc[j] = scalar(0);
     }
     constexpr int GS = 8;
@@ -460,7 +502,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mu_kernel(ExpandSymArg
                 z[j] = (lane < nc && j < nrhs) ? zr[j < nrhs ? j : 0] : scalar(0);
         }
         md  = lane < nc ? mdst[c0 + lane] : -1;
-        mir = __any(md >= 0);
+        mir = __any(md != -1);
     };
     auto process = [&](const scalar(&v)[GS], int jg) {
         if constexpr (FWD)
@@ -485,6 +527,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mu_kernel(ExpandSymArg
                     const scalar t = hmx_shfl(mine[j], 8 * (lane & 7) + (lane >> 3)); // the sum of column c in lane c
                     if (md >= 0 && j < nrhs)
                         S.W[(int64_t)md * SWW + j] = t;
+                    else if (md <= -2 && j < nrhs)
+                        gacc[(-2 - md) * SWW + j] += t;
                 }
             }
         }
@@ -525,10 +569,12 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_mu_kernel(ExpandSymArg
 #pragma unroll
             for (int k = 1; k < WAVES; k++)
                 s += part[k][i][jj];
-            scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + jj;
+            scalar *yo = A.y + (int64_t)(roff + i) * mu + cbase + jj;
             *yo        = hmx_is_zero(A.beta) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
         }
     }
+    } // ranges of the group
+    group_acc_flush(gacc, S.W, (int64_t)S.grp_flush[grp] * SWW, gna * SWW);
 }
 
 // ---- second sweep over the R-streams for several right-hand sides: intervals and segments ------------------------------------------------
@@ -689,12 +735,18 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_zmfma8_kernel(ExpandSy
     constexpr int P = 20, STEP = 8; // tile pitch in reals: conflict-free (8-byte reals) / two lanes per bank (4-byte) for both read directions
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * P];
     static_assert(64 * P >= WAVE * 16, "the final fold of the waves reuses the tiles");
-    const int R = A.order[blockIdx.x];
+    const int grp  = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int len = A.range_len[R], C = A.range_cols[R];
-    const scalar *E     = A.stream + A.range_base[R];
-    const int32_t *zidx = A.z_idx + A.range_colbase[R];
-    const int32_t *mdst = S.mdst + A.range_colbase[R];
+    real *gacc     = reinterpret_cast<real *>(hmx_group_lds); // [accumulator][16 reals = 8 complex right-hand sides]
+    const int gna  = S.grp_na[grp];
+    group_acc_zero(reinterpret_cast<scalar *>(gacc), gna * SWW);
+    const int R_end = (grp + 1) * S.G < A.nranges ? (grp + 1) * S.G : A.nranges;
+    auto range_pass = [&](const int R) {
+    const int len = uniform_value(A.range_len[R]), C = uniform_value(A.range_cols[R]), roff = uniform_value(A.range_off[R]);
+    const int64_t rbase = uniform_value(A.range_base[R]), rcolbase = uniform_value(A.range_colbase[R]);
+    const scalar *E     = A.stream + rbase;
+    const int32_t *zidx = A.z_idx + rcolbase;
+    const int32_t *mdst = S.mdst + rcolbase;
     const int m = lane & 15, kk = lane >> 4;
     real *tile     = lds + wv * 64 * P;
     real *W16r     = reinterpret_cast<real *>(S.W); // [slot][16 reals = 8 complex right-hand sides]
@@ -706,7 +758,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_zmfma8_kernel(ExpandSy
 #pragma unroll
     for (int h = 0; h < 16; h++) {
         const int r   = 4 * h + kk;
-        const real xv = reinterpret_cast<const real *>(S.xrow + (int64_t)(A.range_off[R] + (r < len ? r : len - 1)) * mu + cbase)[mo];
+        const real xv = reinterpret_cast<const real *>(S.xrow + (int64_t)(roff + (r < len ? r : len - 1)) * mu + cbase)[mo];
         xt[h]         = r < len ? xv : real(0);
     }
     zsacc4 acc[4];
@@ -760,7 +812,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_zmfma8_kernel(ExpandSy
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int md = (c + (lane & 7) < C) ? mdi : -1;
-        if (__any(md >= 0)) { // wave-uniform: steps without mirrored columns skip all of it
+        if (__any(md != -1)) { // wave-uniform: steps without mirrored columns skip all of it
             real ta[16];
 #pragma unroll
             for (int h = 0; h < 16; h++)
@@ -779,6 +831,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_zmfma8_kernel(ExpandSy
                     const int d = __shfl(md, idx[k], WAVE); // slot of column c + idx[k]
                     if (ok && d >= 0)
                         W16r[(int64_t)d * 16 + m] = val[k];
+                    else if (ok && d <= -2)
+                        gacc[(-2 - d) * 16 + m] += val[k];
                 }
         }
         if constexpr (FWD) {
@@ -848,9 +902,15 @@ __global__ __launch_bounds__(WAVES *WAVE) void expand_sym_zmfma8_kernel(ExpandSy
 #pragma unroll
         for (int w = 1; w < WAVES; w++)
             sum += scalar(red[w][i][2 * c], red[w][i][2 * c + 1]);
-        scalar *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        scalar *yo = A.y + (int64_t)(roff + i) * mu + cbase + c;
         *yo        = hmx_is_zero(A.beta) ? A.alpha * sum : A.alpha * sum + A.beta * (*yo);
     }
+    }; // range_pass
+    for (int R = grp * S.G; R < R_end; R++) {
+        __syncthreads(); // the accumulators are zero / the previous range is done with the tiles
+        range_pass(R);
+    }
+    group_acc_flush(reinterpret_cast<const scalar *>(gacc), S.W, (int64_t)S.grp_flush[grp] * SWW, gna * SWW);
 }
 
 // Second pass over the R-streams for 8 complex right-hand sides: Y_s[row][n] += sum_col op(V[row][col]) a'[col][n], one WAVE per interval
@@ -1058,16 +1118,29 @@ template <int WAVES, bool FWD = true>
 __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void expand_sym_mfma16_kernel(ExpandSymArgs S, int mu, int cbase, int nrhs) {
     const ExpandArgs &A = S.X;
 #ifndef HMX_SYMMU_PT
-#define HMX_SYMMU_PT 24
+#define HMX_SYMMU_PT (sizeof(real) == 8 ? 18 : 20)
 #endif
-    constexpr int PT = HMX_SYMMU_PT; // row pitch of the mirrored tile [64 rows][16 columns]: operand reads (16 columns x 4 rows) at two lanes per bank
+    // row pitch of the mirrored tile [64 rows][16 columns]: 16-byte stores stay aligned and conflict-free (a lane's row starts 36 / 20 dwords after
+    // its neighbour's), operand reads (16 columns x 4 rows) at two lanes per bank at most.  Round 6: 18 / 20 instead of 24 -- LDS, not registers,
+    // decides how many of these workgroups a CU holds once a group's accumulators sit next to the tiles
+    constexpr int PT = HMX_SYMMU_PT;
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * PT > WAVES * WAVE * 16 ? WAVES * 64 * PT : WAVES * WAVE * 16];
-    const int R = A.order[blockIdx.x];
+    const int grp  = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int len = A.range_len[R], C = A.range_cols[R];
-    const real *E       = A.stream + A.range_base[R];
-    const int32_t *zidx = A.z_idx + A.range_colbase[R];
-    const int32_t *mdst = S.mdst + A.range_colbase[R];
+#if defined(HMX_SYM_FLAT) && !defined(HMX_SYM_FLAT_LDS)
+    real *gacc = nullptr;
+#else
+    real *gacc     = reinterpret_cast<real *>(hmx_group_lds); // [accumulator][16 right-hand sides]
+    const int gna  = S.grp_na[grp];
+    group_acc_zero(gacc, gna * 16);
+#endif
+    const int R_end = (grp + 1) * S.G < A.nranges ? (grp + 1) * S.G : A.nranges;
+    auto range_pass = [&](const int R) {
+    const int len = uniform_value(A.range_len[R]), C = uniform_value(A.range_cols[R]), roff = uniform_value(A.range_off[R]);
+    const int64_t rbase = uniform_value(A.range_base[R]), rcolbase = uniform_value(A.range_colbase[R]);
+    const real *E       = A.stream + rbase;
+    const int32_t *zidx = A.z_idx + rcolbase;
+    const int32_t *mdst = S.mdst + rcolbase;
     const int m = lane & 15, kk = lane >> 4;
     real *tile    = lds + wv * 64 * PT;
     const int row = lane < len ? lane : len - 1; // idle lanes re-read the last row: forward, they only reach accumulator rows that are never stored; mirrored, their X_t operand is zero
@@ -1077,7 +1150,7 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
 #pragma unroll
     for (int h = 0; h < 16; h++) {
         const int r   = 4 * h + kk;
-        const real xv = S.xrow[(int64_t)(A.range_off[R] + (r < len ? r : len - 1)) * mu + mo];
+        const real xv = S.xrow[(int64_t)(roff + (r < len ? r : len - 1)) * mu + mo];
         xt[h]         = r < len ? xv : real(0);
     }
     acc4 acc[4];
@@ -1120,17 +1193,38 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
             v[u]          = stream_load(E + (int64_t)col * len + row);
         }
     };
-    // one step = 16 columns: mirrored column sums (if any of the 16 is a mirrored column), then the forward product
+    // one step = 16 columns: mirrored column sums (if any of the 16 is a mirrored column) and the forward product.  Order inside a step: the
+    // tile goes to LDS, then the registers are transposed for the forward operands (vector ALU work under the LDS round trip), then the
+    // mirrored MFMAs, the stores of their sums, the forward MFMAs
     auto apply = [&](real(&v)[16], const real(&braw)[4], int mdi, int s) {
         const int c  = col_of(s);
         const int md = (c + m < C) ? mdi : -1;
-        if (__any(md >= 0)) { // wave-uniform: steps without mirrored columns (diagonal leaves, the other ranks' columns of a row-partitioned operator) skip all of it
+        const bool mirrored = __any(md != -1); // wave-uniform: steps without mirrored columns (diagonal leaves, the other ranks' columns of a row-partitioned operator) skip all of it
+        if (mirrored) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < 16; u++)
                 tile[lane * PT + u] = v[u]; // 16 consecutive elements per lane: 16-byte stores
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
+        // forward: a[g][t] (row 16 t + m, column 4 g + kk) = register 4 g + kk of lane quarter t -- a 4 x 4 transposition per column group
+        real b[4];
+        if constexpr (FWD) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                b[g] = (c + 4 * g + kk < C) ? braw[g] : real(0);
+#ifndef HMX_SYMMU_SWAPS_LATE
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                lane_swap32(v[4 * g + 0], v[4 * g + 2]);
+                lane_swap32(v[4 * g + 1], v[4 * g + 3]);
+                lane_swap16(v[4 * g + 0], v[4 * g + 1]);
+                lane_swap16(v[4 * g + 2], v[4 * g + 3]);
+            }
+#endif
+        }
+        if (mirrored) {
             real ta[16];
 #pragma unroll
             for (int h = 0; h < 16; h++)
@@ -1144,14 +1238,14 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
                 const int d = __shfl(md, mfma16_row(real(0), lane, j), WAVE);
                 if (d >= 0)
                     S.W[(int64_t)d * 16 + m] = am[j];
+#ifndef HMX_SYM_NO_GACC
+                else if (d <= -2)
+                    gacc[(-2 - d) * 16 + m] += am[j]; // (one lane of the workgroup per accumulator value and range: see build_mirror_tables)
+#endif
             }
         }
-        // forward: a[g][t] (row 16 t + m, column 4 g + kk) = register 4 g + kk of lane quarter t -- a 4 x 4 transposition per column group
         if constexpr (FWD) {
-            real b[4];
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                b[g] = (c + 4 * g + kk < C) ? braw[g] : real(0);
+#ifdef HMX_SYMMU_SWAPS_LATE
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 lane_swap32(v[4 * g + 0], v[4 * g + 2]);
@@ -1159,6 +1253,7 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
                 lane_swap16(v[4 * g + 0], v[4 * g + 1]);
                 lane_swap16(v[4 * g + 2], v[4 * g + 3]);
             }
+#endif
 #pragma unroll
             for (int g = 0; g < 4; g++)
 #pragma unroll
@@ -1167,6 +1262,47 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
         }
     };
     if (n > 0) {
+#ifndef HMX_SYMMU_BUFS
+#define HMX_SYMMU_BUFS 2
+#endif
+#if HMX_SYMMU_BUFS == 3
+        // THREE column buffers used in turn: while step s is computed the columns of steps s + 1 and s + 2 are in flight (and the indices of
+        // step s + 3).  What a wave has in flight is all it has against the stream's latency: these kernels hold one (8-byte coefficients) or
+        // two waves per SIMD, and with one step ahead -- 8 KB / 4 KB per wave, 32 KB per CU -- the sweep stood at 4 TB/s whatever else was done
+        // to it (round 6: bytes in flight per CU / latency under load, not matrix-core time, is what bounded it)
+        real v0[16], v1[16], v2[16], b0[4], b1[4], b2[4];
+        Idx i0 = load_idx(0), i1 = load_idx(1), i2 = load_idx(2);
+        gathers(b0, i0);
+        load_cols(v0, 0);
+        gathers(b1, i1);
+        load_cols(v1, 1);
+        HMX_SCHED_FENCE();
+        for (int s = 0; s < n; s += 3) {
+            const int md0 = i0.md;
+            i0 = load_idx(s + 3);
+            gathers(b2, i2);
+            load_cols(v2, s + 2);
+            HMX_SCHED_FENCE();
+            apply(v0, b0, md0, s);
+            HMX_SCHED_FENCE();
+            const int md1 = i1.md;
+            i1 = load_idx(s + 4);
+            gathers(b0, i0);
+            load_cols(v0, s + 3);
+            HMX_SCHED_FENCE();
+            if (s + 1 < n)
+                apply(v1, b1, md1, s + 1);
+            HMX_SCHED_FENCE();
+            const int md2 = i2.md;
+            i2 = load_idx(s + 5);
+            gathers(b1, i1);
+            load_cols(v1, s + 4);
+            HMX_SCHED_FENCE();
+            if (s + 2 < n)
+                apply(v2, b2, md2, s + 2);
+            HMX_SCHED_FENCE();
+        }
+#else
         real v0[16], v1[16], b0[4], b1[4];
         Idx i0 = load_idx(0), i1 = load_idx(1);
         gathers(b0, i0);
@@ -1189,6 +1325,7 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
                 apply(v1, b1, md1, s + 1);
             HMX_SCHED_FENCE();
         }
+#endif
     }
     if constexpr (!FWD)
         return;
@@ -1209,9 +1346,30 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
 #pragma unroll
         for (int w = 1; w < WAVES; w++)
             s += red[w][i][c];
-        real *yo = A.y + (int64_t)(A.range_off[R] + i) * mu + cbase + c;
+        real *yo = A.y + (int64_t)(roff + i) * mu + cbase + c;
         *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
     }
+    }; // range_pass
+#if defined(HMX_SYM_FLAT_LOOP)
+    for (int R = grp * S.G; R < R_end; R++) {
+        __syncthreads();
+        range_pass(R);
+    }
+#elif defined(HMX_SYM_FLAT_LDS)
+    (void)R_end;
+    __syncthreads();
+    range_pass(grp);
+    group_acc_flush(gacc, S.W, (int64_t)S.grp_flush[grp] * 16, gna * 16);
+#elif defined(HMX_SYM_FLAT)
+    (void)R_end;
+    range_pass(grp);
+#else
+    for (int R = grp * S.G; R < R_end; R++) {
+        __syncthreads(); // the accumulators are zero / the previous range is done with the tiles
+        range_pass(R);
+    }
+    group_acc_flush(gacc, S.W, (int64_t)S.grp_flush[grp] * 16, gna * 16);
+#endif
 }
 
 // Second pass over the R-streams for up to 16 right-hand sides: Y_s[row][rhs] += sum_col V[row][col] a'[col][rhs].  One WAVE per interval
@@ -1270,7 +1428,9 @@ __device__ __forceinline__ void rowsym_mfma16_run(const RowSegArgs &A, real *til
     };
     // [64 columns][16 rows], element (row i, column c) at 16 (c ^ ((c >> 1) & 1)) + (i ^ ((c >> 1) & 15)): the stores of a load's two
     // rows x 64 columns and the operand reads of 16 rows x 4 columns both touch every bank exactly twice
-    auto tile_product = [&](const scalar2(&v)[8], const real(&b)[16], acc4 &dst) {
+    // refill: the segment's last tile -- every operand register is loaded with the NEXT segment's value right behind the MFMA that read it last
+    // (one set of sixteen operand registers instead of two: the second set had cost the kernel its second wave per SIMD, or spills)
+    auto tile_product = [&](const scalar2(&v)[8], real(&b)[16], acc4 &dst, const Seg &next, bool refill) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -1280,28 +1440,37 @@ __device__ __forceinline__ void rowsym_mfma16_run(const RowSegArgs &A, real *til
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        real ta[16];
+        // two halves of eight k-steps: eight operand registers live at a time (the sixteen cost two waves per SIMD their place in the file).
+        // Every segment covers whole intervals, so the tile's result joins the interval's accumulator as the MFMAs' own C operand
 #pragma unroll
-        for (int h = 0; h < 16; h++) {
-            const int c = 4 * h + kk;
-            ta[h]       = tile[16 * (c ^ ((c >> 1) & 1)) + (m ^ ((c >> 1) & 15))];
+        for (int half = 0; half < 2; half++) {
+            real ta[8];
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const int c = 4 * (8 * half + h) + kk;
+                ta[h]       = tile[16 * (c ^ ((c >> 1) & 1)) + (m ^ ((c >> 1) & 15))];
+            }
+#pragma unroll
+            for (int h = 0; h < 8; h++)
+                dst = mfma16(ta[h], b[8 * half + h], dst); // A[m = row][k = column c], B[k][n = rhs]
+            if (refill)
+                gather_b(b, next, 8 * half, 8 * half + 8);
         }
-        acc4 tm = acc4{0, 0, 0, 0};
-#pragma unroll
-        for (int h = 0; h < 16; h++)
-            tm = mfma16(ta[h], b[h], tm); // A[m = row][k = column c], B[k][n = rhs]
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            dst[j] += tm[j];
     };
     if (q0 < q1) {
-        constexpr int SPI   = (NT & 1) ? 2 : 1;     // segments per trip of the loop: an odd number of tiles flips the two tile buffers
-        constexpr int SHARE = (16 + NT - 1) / NT;   // operand gathers of the next segment per step
+        // DIST tiles are in flight while one is computed (D = DIST + 1 buffers, used in turn)
+        constexpr int DMAX  = 2;
+        constexpr int D     = NT + 1 < DMAX ? NT + 1 : DMAX;
+        constexpr int DIST  = D - 1;                   // <= NT: a prefetch never reaches beyond the next segment
+        constexpr int SPI   = (NT % D) ? D : 1;        // segments per trip of the loop: the buffer of step n is n mod D, the pattern repeats after SPI segments
+        static_assert((SPI * NT) % D == 0 && DIST <= NT, "buffer rotation");
         Seg cur = fetch(q0), nxt = fetch(q0 + 1);
-        real bc[16], bn[16];
+        real bc[16];
         gather_b(bc, cur, 0, 16);
-        scalar2 v[2][8];
-        load_tile(v[0], cur, 0);
+        scalar2 v[D][8];
+#pragma unroll
+        for (int t = 0; t < DIST; t++)
+            load_tile(v[t], cur, t);
         HMX_SCHED_FENCE();
         for (int64_t q = q0; q < q1; q += SPI) {
 #pragma unroll
@@ -1311,19 +1480,15 @@ __device__ __forceinline__ void rowsym_mfma16_run(const RowSegArgs &A, real *til
                 const Seg nx2 = fetch(q + p + 2);
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const int cb = (p * NT + t) & 1; // (a constant after unrolling)
-                    gather_b(bn, nxt, t * SHARE, (t + 1) * SHARE < 16 ? (t + 1) * SHARE : 16);
-                    if (t + 1 < NT)
-                        load_tile(v[cb ^ 1], cur, t + 1);
+                    const int n = p * NT + t; // (a constant after unrolling)
+                    if (t + DIST < NT)
+                        load_tile(v[(n + DIST) % D], cur, t + DIST);
                     else
-                        load_tile(v[cb ^ 1], nxt, 0);
+                        load_tile(v[(n + DIST) % D], nxt, t + DIST - NT);
                     HMX_SCHED_FENCE();
-                    tile_product(v[cb], bc, acc[t]);
+                    tile_product(v[n % D], bc, acc[t], nxt, t == NT - 1);
                     HMX_SCHED_FENCE();
                 }
-#pragma unroll
-                for (int h = 0; h < 16; h++)
-                    bc[h] = bn[h];
                 cur = nxt;
                 nxt = nx2;
             }

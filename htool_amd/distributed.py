@@ -558,6 +558,20 @@ class NativeDistributedOperator:
         if communicator.send is not None:  # known, not in use: set_point_to_point(True) switches the slice exchange over
             check(self._L.hmx_dist_set_point_to_point(self._h, communicator.send, communicator.recv, 0))
         self._scal = {}
+        self._more = []  # operators registered later: kept alive with this object (the C layer keeps references)
+
+    def add_global_to_local_operator(self, hmatrix):
+        """DistributedOperator::add_global_to_local_operator (distributed_operator.hpp:47-49): one more (target partition rank) x (whole source)
+        operator; every product adds it after the first (hmx_dist_add_global_to_local_operator)."""
+        from ._lib import check
+        check(self._L.hmx_dist_add_global_to_local_operator(self._h, hmatrix._h))
+        self._more.append(hmatrix)
+
+    def add_local_to_local_operator(self, block_diagonal_hmatrix):
+        """DistributedOperator::add_local_to_local_operator (distributed_operator.hpp:50-53): may be called several times."""
+        from ._lib import check
+        check(self._L.hmx_dist_add_local_to_local_operator(self._h, block_diagonal_hmatrix._h))
+        self._more.append(block_diagonal_hmatrix)
 
     def __del__(self):
         try:

@@ -229,6 +229,11 @@ typedef enum {
     HMX_OPT_XCD_UNIT_ROWS     = 7,  /* layout  512   rows per unit of launch order 3 (>= 64)                                 HMX_XCD_UNIT_ROWS    */
     HMX_OPT_SYM_STORAGE       = 5,  /* layout  0     symmetric / Hermitian operators: 0 stored triangle + fused product,
                                                      1 mirrored leaves laid out explicitly (twice the memory)                HMX_SYM_EXPANDED     */
+    HMX_OPT_SYM_GROUP         = 8,  /* layout  4     stored-data mirrored sweeps: consecutive row ranges one workgroup takes in turn, folding in LDS
+                                        the column sums that belong together (a leaf's partial a', dense leaves with one source
+                                        cluster); 1: every range writes all its sums (rounds 2-5)                              HMX_SYM_GROUP        */
+    HMX_OPT_SYM_GROUP_SLOTS   = 9,  /* layout  -1    LDS accumulators per group (x 16 right-hand sides x coefficient size bytes); -1: what keeps
+                                                     two (8-byte reals: 320) / three (4-byte: 512) workgroups of the 16-RHS sweep on a CU   HMX_SYM_GROUP_SLOTS  */
     HMX_OPT_BUILD_TIMING      = 6,  /* build   0     per-phase build times on stderr                                         HMX_BUILD_TIMING     */
     /* ---- products ---- */
     HMX_OPT_REDUCE_WAVES      = 10, /* product 0     waves per workgroup of the single-vector reduce stage (0: automatic)    HMX_REDUCE_WAVES     */
@@ -241,9 +246,9 @@ typedef enum {
     HMX_OPT_WIDE_SWEEPS       = 15, /* product 1     more than 16 (complex: 8) right-hand sides: sweeps of up to 32 (16)     HMX_MFMA_WIDE        */
     HMX_OPT_SCALAR_OPERANDS   = 16, /* product -1    VALU multi-RHS reduce stage with operands in scalar registers
                                                      (-1: automatic = 4-byte coefficients only)                              HMX_MU_SCALAR        */
-    HMX_OPT_SYM_MULTI_RHS     = 17, /* product -1    several right-hand sides on a symmetric / Hermitian operator: 1 on the stored
-                                                     triangle, 0 on an expanded view of the operator, -1 automatic (complex: the
-                                                     stored triangle; real: the view while HBM has room for it)             HMX_SYM_MU_FUSED     */
+    HMX_OPT_SYM_MULTI_RHS     = 17, /* product -1    several right-hand sides on a symmetric / Hermitian operator: 1 or -1 on the stored
+                                                     triangle (nothing else is built), 0 on an expanded view of the operator
+                                                     (twice the memory; the default for real coefficients until round 5)      HMX_SYM_MU_FUSED     */
     HMX_OPT_SYM_NO_VIEW       = 18, /* product 0     never build the expanded view                                            HMX_SYM_NO_VIEW      */
     HMX_OPT_TRANSPOSED_LAYOUT = 19, /* product -1    transposed stream layout: -1 for several right-hand sides only (HBM
                                                      permitting), 1 also for single vectors, 0 never (stored data only)      HMX_TRANS_STREAMS    */
@@ -427,6 +432,12 @@ void hmx_dist_destroy(hmx_dist *);
  * an operator that consists of local-to-local operators only (its local-to-local products then exchange nothing).  Kept by
  * reference; same coefficient type as `local`. */
 int hmx_dist_add_local_to_local_operator(hmx_dist *, hmx_hmatrix *diag);
+/* DistributedOperator::add_global_to_local_operator (distributed_operator/distributed_operator.hpp:47-49): one more operator from the whole
+ * source numbering to this rank's rows.  The reference holds vectors of both kinds of operators and every product loops over them
+ * (global_to_global.hpp:63-72: all global-to-local operators, then all local-to-local ones, beta applied once); so does this layer --
+ * both add functions may be called several times.  Root block of `op`: (target partition rank) x (whole source cluster); same coefficient
+ * type as the others; kept by reference.  With more than one operator registered the output exchange is the plain one. */
+int hmx_dist_add_global_to_local_operator(hmx_dist *, hmx_hmatrix *op);
 /* y = alpha * op(A) * x + beta * y, x and y whole vectors replicated on every rank (global_to_global.hpp:18-85); the coefficient
  * type is the local operator's: pointers to double / float / interleaved complex accordingly, alpha / beta as in the matvec
  * entry points of that type but always passed by pointer here. */

@@ -421,6 +421,39 @@ MOCK_SCRIPT = textwrap.dedent('''
                 e1 = np.linalg.norm(outs[k][0] - diag) / np.linalg.norm(diag)
                 e2 = np.linalg.norm(outs[k][1] - (rows + diag)) / np.linalg.norm(rows + diag)
                 assert e1 < 1e-12 and e2 < 1e-12, (np.dtype(dtype).name, "two operators", trans, k, e1, e2)
+        # ... and VECTORS of both kinds, as the reference holds them (distributed_operator.hpp:47-53): the same two operators registered a second
+        # time (hmx_dist_add_global_to_local_operator, a second hmx_dist_add_local_to_local_operator): every product doubles
+        for k in range(WORLD):
+            check(L.hmx_dist_add_global_to_local_operator(Ds[k], Hloc[k]._h))
+            check(L.hmx_dist_add_local_to_local_operator(Ds[k], Hdiag[k]._h))
+            assert L.hmx_dist_add_global_to_local_operator(Ds[k], Hdiag[k]._h) == -1 and b"whole source" in L.hmx_last_error()  # not a block row
+        for trans in ("N", "T"):
+            outs, fails = {}, []
+            def twice_rank(k):
+                try:
+                    dx, dy = dev(xin), dev(y0.copy())
+                    check(L.hmx_dist_matvec_global_to_global(Ds[k], trans.encode(), pa, dx, pb, dy, None))
+                    assert hip.hipDeviceSynchronize() == 0
+                    outs[k] = host(dy, y0)
+                except BaseException as e:
+                    fails.append(e)
+                    barrier.abort()
+            th = [threading.Thread(target=twice_rank, args=(k,)) for k in range(WORLD)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not fails, fails
+            rows = np.zeros_like(y0)
+            hm.internal_add_hmatrix_vector_product(trans, 1.0, Hfull, xin, 0.0, rows)
+            diag = np.zeros_like(y0)
+            for k in range(WORLD):
+                off, sz = int(parts[k][0]), int(parts[k][1])
+                yk = np.zeros(sz, dtype=dtype)
+                hm.internal_add_hmatrix_vector_product(trans, 1.0, Hdiag[k], np.ascontiguousarray(xin[off:off + sz]), 0.0, yk)
+                diag[off:off + sz] = yk
+            want = ab[0] * 2 * (rows + diag) + ab[1] * y0
+            for k in range(WORLD):
+                e = np.linalg.norm(outs[k] - want) / np.linalg.norm(want)
+                assert e < 1e-12, (np.dtype(dtype).name, "vectors of operators", trans, k, e)
         for D in Ds + Dd:
             L.hmx_dist_destroy(D)
         print("ok", np.dtype(dtype).name)
@@ -457,9 +490,43 @@ MOCK_SCRIPT = textwrap.dedent('''
     [t.join() for t in th]
     assert not fails, fails
     assert max(errs) < 1e-12, errs
-    # ... but the product with SEVERAL right-hand sides runs on the expanded view of every rank's operator, which has an expand stage like
-    # any other: it is chunked (its own row chunks, agreed on inside the first product) and the chunks' rows are exchanged on the side stream
+    # ... and so does the product with SEVERAL right-hand sides: it runs on the stored triangle too (round 6: the default), rows receive mirrored
+    # contributions after the E pass, the exchange stays whole
     mu = 5
+    X, Y0 = rng.standard_normal((n, mu)), rng.standard_normal((n, mu))
+    ref = Y0.copy()
+    hm.internal_add_hmatrix_matrix_product_row_major("N", ab[0], Hfull, X, ab[1], ref, mu)
+    errs, fails = [None] * WORLD, []
+    def sym_mm_stored_rank(k):
+        try:
+            dx, dy = dev(X), dev(Y0)
+            check(L.hmx_dist_matmat_row_major_global_to_global(Ds[k], b"N", pa, dx, pb, dy, mu, None))
+            assert hip.hipDeviceSynchronize() == 0
+            assert L.hmx_dist_overlap_chunks(Ds[k]) == 0 and L.hmx_dist_overlap_chunks_multi(Ds[k]) <= 1
+            assert Hloc[k].stats()["expanded_bytes"] == 0
+            errs[k] = np.linalg.norm(host(dy, Y0) - ref) / np.linalg.norm(ref)
+        except BaseException as e:
+            fails.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=sym_mm_stored_rank, args=(k,)) for k in range(WORLD)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not fails, fails
+    assert max(errs) < 1e-12, errs
+    # ... but on the expanded VIEW of every rank's operator (HMX_OPT_SYM_MULTI_RHS = 0), which has an expand stage like any other, the product is
+    # chunked (its own row chunks, agreed on inside the first product) and the chunks' rows are exchanged on the side stream
+    for k in range(WORLD):
+        Hloc[k].set_option("sym_multi_rhs", 0)
+    def reset_rank(k):
+        try:
+            check(L.hmx_dist_set_overlap(Ds[k], 3, None))
+        except BaseException as e:
+            fails.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=reset_rank, args=(k,)) for k in range(WORLD)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not fails, fails
     X, Y0 = rng.standard_normal((n, mu)), rng.standard_normal((n, mu))
     ref = Y0.copy()
     hm.internal_add_hmatrix_matrix_product_row_major("N", ab[0], Hfull, X, ab[1], ref, mu)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / LDS / scratch use of the kernels in libhmx.so: `[HMX_LIB_PATH=variant.so] python tools/kernel_regs.py [regex]` (reads the AMDGPU metadata notes of every
-gfx950 code object in the library; VGPR + AGPR together decide the waves per SIMD: 512 / (vgpr + agpr) on gfx950)."""
+gfx950 code object in the library; vgpr = .vgpr_count of the metadata = architectural + accumulation registers TOGETHER on gfx950's unified file: waves per SIMD = 512 / vgpr -- confirmed by SQ_WAVE_CYCLES in round 6: a kernel at 240 (40 of them AGPRs) runs two waves per SIMD, at 264 one)."""
 import os
 import pathlib
 import re
@@ -25,7 +25,7 @@ with tempfile.TemporaryDirectory() as d:
             name = re.sub(r"\(.*", "", name).replace("void ", "")
             if pat.search(name):
                 v, a = int(f["vgpr_count"]), int(f["agpr_count"])
-                rows.append((name, v, a, int(f["sgpr_count"]), int(f["group_segment_fixed_size"]), int(f["private_segment_fixed_size"]), min(8, 512 // max(1, (v + a + 7) // 8 * 8))))
+                rows.append((name, v, a, int(f["sgpr_count"]), int(f["group_segment_fixed_size"]), int(f["private_segment_fixed_size"]), min(8, 512 // max(1, (v + 7) // 8 * 8))))
     print("%-52s %5s %5s %5s %7s %7s %6s" % ("kernel", "vgpr", "agpr", "sgpr", "lds", "scratch", "waves"))
     for r in sorted(rows):
         print("%-52s %5d %5d %5d %7d %7d %6d" % r)

@@ -32,6 +32,15 @@ m16 = json.load(open("profiles/%s_bench_n1e6_mu16_pmc_summary.json" % RN))
 tT = json.load(open("profiles/%s_bench_n1e6_transT_pmc_summary.json" % RN))
 
 
+def opt(name):
+    f = "profiles/%s_%s_pmc_summary.json" % (RN, name)
+    return json.load(open(f)) if os.path.exists(f) else None
+
+
+s16, c5 = opt("bench_n1e6_sym_mu16_stored_triangle"), opt("bench_c5_rank3of8")
+PRODUCT = ("reduce", "expand", "combine", "rowsym")  # kernels of a product (not the bandwidth probes, not the build)
+
+
 def tot(x):
     return x["fetch_bytes_x2"] + x["write_bytes"]
 
@@ -44,6 +53,7 @@ rec = dict(round=int(RN[1:]), kernel_sources_sha256=bench.kernel_sources_hash(),
            workload="bench.py N=1e6 ellipse eps=1e-4 (1 GPU): default (partialACA, 'N') and --sym S (sympartialACA, 'S','L', compact storage, fused product)",
            method="rocprofv3 --kernel-trace --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE (tools/collect_profiles.sh, tools/pmc_summary.py); values in KB; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM): in the same runs the 8 GiB read16_kernel reports 4.194e6 KB = 1/2 of 8 GiB; WRITE_SIZE exact",
+           product_hbm_bytes_total=sum(tot(v) for k, v in n.items() if any(x in k for x in PRODUCT)),
            expand_kernel_hbm_bytes_per_launch=tot(pick(n, "expand_kernel")), expand_kernel_fetch_bytes=pick(n, "expand_kernel")["fetch_bytes_x2"],
            expand_kernel_write_bytes=pick(n, "expand_kernel")["write_bytes"], reduce_kernel_hbm_bytes_per_launch=tot(pick(n, "reduce_kernel")),
            expand_sym_kernel_hbm_bytes_per_launch=tot(pick(s, "expand_sym_kernel")), expand_sym_kernel_write_bytes=pick(s, "expand_sym_kernel")["write_bytes"],
@@ -53,5 +63,10 @@ rec = dict(round=int(RN[1:]), kernel_sources_sha256=bench.kernel_sources_hash(),
            mu16_product_hbm_bytes_total=sum(tot(v) for k, v in m16.items() if "read16" not in k),
            transT_colsum_kernel_hbm_bytes_per_launch=tot(pick(tT, "expand_sym_kernel")), transT_rowsym_kernel_hbm_bytes_per_launch=tot(pick(tT, "rowsym_kernel")),
            transT_product_hbm_bytes_total=sum(tot(v) for k, v in tT.items() if any(s in k for s in ("expand_sym", "rowsym", "combine_list"))))
+if s16:
+    rec.update(sym_mu16_expand_kernel_hbm_bytes_per_launch=tot(pick(s16, "expand_sym_mfma16")), sym_mu16_rowsym_kernel_hbm_bytes_per_launch=tot(pick(s16, "rowsym_mfma16")),
+               sym_mu16_product_hbm_bytes_total=sum(tot(v) for k, v in s16.items() if any(x in k for x in PRODUCT)))
+if c5:
+    rec.update(c5_rank3_expand_kernel_hbm_bytes_per_launch=tot(pick(c5, "expand")), c5_rank3_product_hbm_bytes_total=sum(tot(v) for k, v in c5.items() if any(x in k for x in PRODUCT)))
 json.dump(rec, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
