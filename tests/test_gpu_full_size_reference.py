@@ -84,7 +84,7 @@ def test_full_size_matches_the_reference(name):
             r = int(min(tab[i, 4], ref_ranks[i]))
             worst = max(worst, float(np.linalg.norm(A - U[:, :r].astype(np.float64) @ V[:r, :].astype(np.float64)) / np.linalg.norm(A)))
         print("%s: true relative error of the device's blocks truncated to min(rank, reference rank) on %d differing leaves: at most %.2e (eps %g)" % (name, len(pick), worst, p["eps"]))
-        assert worst <= 8 * p["eps"], worst
+        assert worst <= 6 * p["eps"], worst  # (guard: observed 4.6 eps; the estimator bounds the last correction, not the remaining error -- DESIGN.md section 2)
     else:
         assert ndiff == 0
     rows = g["rows"]

@@ -777,14 +777,14 @@ def test_one_wave_kernel_builds_the_same_crosses_fp32(name):
     check_one_wave_kernel(build)
 
 
-def test_written_arrays_are_placed_by_measurement():
+def test_written_arrays_are_placed_by_measurement(tmp_path):
     """hmx_option place_written: with a reserved slab (hmx_device_reserve) the arrays the sweeps write -- the reduced coefficients, the column
     sums of the symmetric product, their multi-RHS forms -- are tried at several places of the slab against the stream read meanwhile and
     stay where the pair runs fastest.  A matter of addresses only: the products are bitwise those of an operator built without it; the
     statistics say what was measured.  (Run in a process of its own: a slab stays with the process.)"""
     import subprocess
     code = r"""
-import numpy as np, htool_amd as hm, json
+import numpy as np, htool_amd as hm, json, os, sys
 from oracle.oracle import hashed_vector
 hm.lib().hmx_device_init(0)
 assert hm.lib().hmx_device_reserve(0, 24 << 30) == 0
@@ -804,16 +804,16 @@ for place in (0, 1):
     hm.internal_add_hmatrix_matrix_product_row_major("N", 1.0, H, X, 0.0, Y, 16)
     st = H.stats()
     out[place] = dict(y=float(np.abs(y).sum()), Y=float(np.abs(Y).sum()), tried=int(st["placed_tried"]), first=st["placed_first_gbps"], chosen=st["placed_gbps"], read=st["placed_read_gbps"], stream=int(st["stream_bytes"]))
-    np.save("/tmp/hmx_place_%d.npy" % place, np.concatenate([y, Y.ravel()]))
+    np.save(os.path.join(sys.argv[1], "hmx_place_%d.npy" % place), np.concatenate([y, Y.ravel()]))
 print("RESULT " + json.dumps(out))
 """
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     import json
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
     assert out["0"]["tried"] == 0 and out["1"]["tried"] >= 1, out  # the operator's R-stream is > 256 MiB: the probe ran
-    assert out["1"]["chosen"] >= out["1"]["first"] > 0 and out["1"]["read"] > out["1"]["chosen"], out
-    assert np.array_equal(np.load("/tmp/hmx_place_0.npy"), np.load("/tmp/hmx_place_1.npy"))  # addresses only
+    assert out["1"]["chosen"] >= out["1"]["first"] > 0, out        # (no inequality between two timings of about a millisecond: noise can flip it)
+    assert np.array_equal(np.load(tmp_path / "hmx_place_0.npy"), np.load(tmp_path / "hmx_place_1.npy"))  # addresses only
 
 
 @pytest.mark.parametrize("unit_rows", [64, 512])
@@ -1107,3 +1107,38 @@ def test_transposed_product_on_the_stored_data_edge_shapes(n, nsrc, leaf, eta, d
         Y = Y0.copy()
         hm.internal_add_hmatrix_matrix_product_row_major("T", 2.0, H, X, 1.0, Y, 19)
         assert rel_err(Y, 2.0 * (A.T @ X) + Y0) < tol
+
+
+def test_output_vectors_from_the_operator():
+    """hmx_hmatrix_alloc_vector / free_vector (HMatrix.empty_output): a zero-filled device vector of the operator's coefficient type for its
+    products to write -- with a reserved slab placed where the operator's sweeps write fastest, without one a plain allocation; products into
+    it are bitwise those into any other tensor; foreign pointers and double frees are refused."""
+    import ctypes as C
+    import torch
+    from oracle.oracle import hashed_vector
+    n = 3000
+    x = hm.create_geometry("ellipse", n)
+    b = hm.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(100)
+    T = b.create_cluster_tree(n, 3, x, 2, 2)
+    tb = hm.HMatrixTreeBuilder(1e-4, 10.0, "N", "N")
+    tb.set_low_rank_generator("partialACA")
+    H = tb.build(hm.InvDistGenerator(3, x, x, 1e-5, 1.0), T, T)
+    xin = torch.from_numpy(hashed_vector(n, 1)).cuda()
+    X = torch.from_numpy(hashed_vector(n * 16, 2).reshape(n, 16)).cuda()
+    for trans in ("N", "T"):
+        y, Y = H.empty_output(n, trans), H.empty_output((n, 16), trans)
+        assert y.dtype == torch.float64 and tuple(Y.shape) == (n, 16) and float(y.abs().sum()) == 0.0 and float(Y.abs().sum()) == 0.0
+        y2, Y2 = torch.zeros(n, dtype=torch.float64).cuda(), torch.zeros((n, 16), dtype=torch.float64).cuda()
+        hm.internal_add_hmatrix_vector_product(trans, 1.0, H, xin, 0.0, y)
+        hm.internal_add_hmatrix_vector_product(trans, 1.0, H, xin, 0.0, y2)
+        hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.0, H, X, 0.0, Y, 16)
+        hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.0, H, X, 0.0, Y2, 16)
+        assert torch.equal(y, y2) and torch.equal(Y, Y2)
+    L = hm.lib()
+    p = C.c_void_p()
+    assert L.hmx_hmatrix_alloc_vector(H._h, b"N", 4096, C.byref(p)) == 0 and p.value
+    assert L.hmx_hmatrix_free_vector(H._h, p) == 0
+    assert L.hmx_hmatrix_free_vector(H._h, p) != 0 and b"not a vector of this operator" in L.hmx_last_error()
+    assert L.hmx_hmatrix_alloc_vector(H._h, b"X", 4096, C.byref(p)) != 0
+    del y, Y  # (the tensors give their memory back to the operator)
