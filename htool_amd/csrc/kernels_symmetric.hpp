@@ -1127,13 +1127,9 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
     __shared__ __attribute__((aligned(16))) real lds[WAVES * 64 * PT > WAVES * WAVE * 16 ? WAVES * 64 * PT : WAVES * WAVE * 16];
     const int grp  = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#if defined(HMX_SYM_FLAT) && !defined(HMX_SYM_FLAT_LDS)
-    real *gacc = nullptr;
-#else
     real *gacc     = reinterpret_cast<real *>(hmx_group_lds); // [accumulator][16 right-hand sides]
     const int gna  = S.grp_na[grp];
     group_acc_zero(gacc, gna * 16);
-#endif
     const int R_end = (grp + 1) * S.G < A.nranges ? (grp + 1) * S.G : A.nranges;
     auto range_pass = [&](const int R) {
     const int len = uniform_value(A.range_len[R]), C = uniform_value(A.range_cols[R]), roff = uniform_value(A.range_off[R]);
@@ -1214,7 +1210,6 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
 #pragma unroll
             for (int g = 0; g < 4; g++)
                 b[g] = (c + 4 * g + kk < C) ? braw[g] : real(0);
-#ifndef HMX_SYMMU_SWAPS_LATE
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 lane_swap32(v[4 * g + 0], v[4 * g + 2]);
@@ -1222,7 +1217,6 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
                 lane_swap16(v[4 * g + 0], v[4 * g + 1]);
                 lane_swap16(v[4 * g + 2], v[4 * g + 3]);
             }
-#endif
         }
         if (mirrored) {
             real ta[16];
@@ -1238,22 +1232,11 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
                 const int d = __shfl(md, mfma16_row(real(0), lane, j), WAVE);
                 if (d >= 0)
                     S.W[(int64_t)d * 16 + m] = am[j];
-#ifndef HMX_SYM_NO_GACC
                 else if (d <= -2)
                     gacc[(-2 - d) * 16 + m] += am[j]; // (one lane of the workgroup per accumulator value and range: see build_mirror_tables)
-#endif
             }
         }
         if constexpr (FWD) {
-#ifdef HMX_SYMMU_SWAPS_LATE
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                lane_swap32(v[4 * g + 0], v[4 * g + 2]);
-                lane_swap32(v[4 * g + 1], v[4 * g + 3]);
-                lane_swap16(v[4 * g + 0], v[4 * g + 1]);
-                lane_swap16(v[4 * g + 2], v[4 * g + 3]);
-            }
-#endif
 #pragma unroll
             for (int g = 0; g < 4; g++)
 #pragma unroll
@@ -1350,26 +1333,11 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_MFMA16_KERNEL void 
         *yo      = A.beta == real(0) ? A.alpha * s : A.alpha * s + A.beta * (*yo);
     }
     }; // range_pass
-#if defined(HMX_SYM_FLAT_LOOP)
-    for (int R = grp * S.G; R < R_end; R++) {
-        __syncthreads();
-        range_pass(R);
-    }
-#elif defined(HMX_SYM_FLAT_LDS)
-    (void)R_end;
-    __syncthreads();
-    range_pass(grp);
-    group_acc_flush(gacc, S.W, (int64_t)S.grp_flush[grp] * 16, gna * 16);
-#elif defined(HMX_SYM_FLAT)
-    (void)R_end;
-    range_pass(grp);
-#else
     for (int R = grp * S.G; R < R_end; R++) {
         __syncthreads(); // the accumulators are zero / the previous range is done with the tiles
         range_pass(R);
     }
     group_acc_flush(gacc, S.W, (int64_t)S.grp_flush[grp] * 16, gna * 16);
-#endif
 }
 
 // Second pass over the R-streams for up to 16 right-hand sides: Y_s[row][rhs] += sum_col V[row][col] a'[col][rhs].  One WAVE per interval
