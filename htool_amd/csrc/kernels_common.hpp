@@ -356,6 +356,13 @@ template <> struct Acc4<float> { typedef hmx_f4 type; };
 #define HMX_WPE_ROWSYM_MFMA16_KERNEL __attribute__((amdgpu_waves_per_eu(3)))
 #endif
 #endif
+// single-vector symmetric sweeps (empty: the compiler's choice; A/B by tools/variant.sh)
+#ifndef HMX_WPE_EXPAND_SYM_KERNEL
+#define HMX_WPE_EXPAND_SYM_KERNEL
+#endif
+#ifndef HMX_WPE_ROWSYM_KERNEL
+#define HMX_WPE_ROWSYM_KERNEL
+#endif
 __device__ __forceinline__ hmx_d4 mfma16(double a, double b, hmx_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ hmx_f4 mfma16(float a, float b, hmx_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int mfma16_row(double, int lane, int reg) { return (lane >> 4) + 4 * reg; }

@@ -104,7 +104,7 @@ __device__ __forceinline__ void group_acc_flush(const scalar *gacc, scalar *W, i
 // FWD = false: the mirrored column sums only -- the first sweep of the TRANSPOSED product of an ordinary operator on its stored data (every
 // column is then a mirrored one, the forward operands and y are not touched; run_transposed_fused).
 template <int WAVES, bool FWD = true>
-__global__ __launch_bounds__(WAVES *WAVE) void expand_sym_kernel(ExpandSymArgs S) {
+__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_EXPAND_SYM_KERNEL void expand_sym_kernel(ExpandSymArgs S) {
     const ExpandArgs &A = S.X;
     __shared__ scalar part[FWD ? WAVES : 1][WAVE];
     const int grp  = A.order[blockIdx.x];
@@ -263,7 +263,7 @@ struct RowSymArgs {
     int accumulate;           // 1: y += alpha * sums (the forward sweep of the symmetric product has written y already)
 };
 template <int WAVES>
-__global__ __launch_bounds__(WAVES *WAVE) void rowsym_kernel(RowSymArgs A) {
+__global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_ROWSYM_KERNEL void rowsym_kernel(RowSymArgs A) {
     __shared__ scalar acc[WAVES][SYM_IR];
     const int I    = A.order[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
