@@ -476,7 +476,12 @@ int api_prepare(HMat *Hp, char trans, int mu) {
     return HMX_OK;
 }
 
-// hmx_hmatrix_alloc_vector: an output vector of this operator's products, where its sweeps write fastest (place_array; probes allowed here)
+// hmx_hmatrix_alloc_vector: an output vector of this operator's products, where its sweeps write fastest.  When `bytes` is the size of an output
+// of this operator (rows x a number of right-hand sides) and a reserved slab offers places to choose from, the place is decided by the operator's
+// OWN product: the product of that shape (zero operands) is timed with the vector at first fit and at nine places spread over the slab, and the
+// vector stays where the product ran fastest (N = 1e6 fp64, 16 right-hand sides: the expand stage takes 2.03 or 2.30 ms depending on nothing
+// else -- profiles/r6_modes_output_place.log; the synthetic probe of place_written, made for arrays of 1-2 % of a stream, picked a slow place in
+// one process of three).  ~25 products, once, outside any product call of the caller.  Otherwise: place_array (probe allowed here), or plain.
 int api_alloc_vector(HMat *Hp, char trans, int64_t bytes, void **ptr) {
     if (!Hp || !ptr || bytes <= 0 || !(trans == 'N' || trans == 'T' || trans == 'C')) {
         set_error("hmx_hmatrix_alloc_vector: invalid arguments");
@@ -491,16 +496,70 @@ int api_alloc_vector(HMat *Hp, char trans, int64_t bytes, void **ptr) {
     ProbeScope probes(H);
     std::unique_ptr<DArr<scalar>> a(new DArr<scalar>());
     const size_t count = ((size_t)bytes + sizeof(scalar) - 1) / sizeof(scalar);
-    // 'N': y is written by the expand stage (E-streams); transposed on the stored data: by the second sweep over the R-streams.  A transposed
-    // product that runs on its own stream layout writes next to THAT layout's E-stream: its operator decides
-    HMat &W        = (trans != 'N' && H.T_op) ? *H.T_op : H;
-    const int pair = (trans == 'N' || &W != &H) ? 0 : 1;
-    if (&W != &H)
-        W.may_probe = true;
-    const hipError_t e = place_array(W, *a, count, pair, nullptr);
-    if (&W != &H)
-        W.may_probe = false;
-    HMX_HIP(e);
+    const size_t nout = (size_t)(trans == 'N' ? H.nT : H.nS), nin = (size_t)(trans == 'N' ? H.nS : H.nT);
+    const int mu = (nout > 0 && count % nout == 0 && count / nout <= 4096) ? (int)(count / nout) : 0;
+    bool placed  = false;
+    if (mu >= 1 && bytes >= (int64_t(1) << 20) && H.opt.i(HMX_OPT_PLACE_WRITTEN) != 0 && DeviceSlabs::get().owns(H.E.stream.d)) {
+        DArr<scalar> in;
+        HMX_HIP(in.alloc(nin * (size_t)mu));
+        HMX_HIP(in.zero());
+        DEvent e0, e1;
+        auto product = [&](scalar *out) {
+            return mu == 1 ? matvec_device(H, trans, scalar(1), in.d, scalar(0), out, nullptr) : matmat_device(H, trans, scalar(1), in.d, scalar(0), out, mu, nullptr);
+        };
+        auto timed = [&](scalar *out, float *ms) -> int { // the second of two products
+            int rc = product(out);
+            if (rc != HMX_OK)
+                return rc;
+            HMX_HIP(hipEventRecord(e0, nullptr));
+            rc = product(out);
+            if (rc != HMX_OK)
+                return rc;
+            HMX_HIP(hipEventRecord(e1, nullptr));
+            HMX_HIP(hipEventSynchronize(e1));
+            HMX_HIP(hipEventElapsedTime(ms, e0, e1));
+            return HMX_OK;
+        };
+        const bool was_profiling = H.profiling;
+        H.profiling              = false;
+        HMX_HIP(a->alloc(count));
+        float best = 0;
+        int rc     = product(a->d); // (whatever the first product of this shape builds and allocates is built now, not inside a timing)
+        if (rc == HMX_OK)
+            rc = timed(a->d, &best);
+        if (rc == HMX_OK && DeviceSlabs::get().owns(a->d)) {
+            for (double frac : {0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, 1.0}) {
+                DArr<scalar> cand;
+                if (cand.alloc_at(count, frac) != hipSuccess)
+                    continue;
+                float ms = 0;
+                if (timed(cand.d, &ms) != HMX_OK)
+                    break;
+                if (ms < 0.985f * best) {
+                    a->swap(cand);
+                    best = ms;
+                }
+                HMX_HIP(hipDeviceSynchronize()); // before `cand` (the loser) goes back to the slab
+            }
+        }
+        H.profiling = was_profiling;
+        if (rc != HMX_OK)
+            return rc;
+        HMX_HIP(hipMemset(a->d, 0, count * sizeof(scalar)));
+        placed = true;
+    }
+    if (!placed) {
+        // 'N': y is written by the expand stage (E-streams); transposed on the stored data: by the second sweep over the R-streams.  A transposed
+        // product that runs on its own stream layout writes next to THAT layout's E-stream: its operator decides
+        HMat &W        = (trans != 'N' && H.T_op) ? *H.T_op : H;
+        const int pair = (trans == 'N' || &W != &H) ? 0 : 1;
+        if (&W != &H)
+            W.may_probe = true;
+        const hipError_t e = place_array(W, *a, count, pair, nullptr);
+        if (&W != &H)
+            W.may_probe = false;
+        HMX_HIP(e);
+    }
     HMX_HIP(hipDeviceSynchronize());
     *ptr = a->d;
     H.user_vectors[a->d] = std::move(a);

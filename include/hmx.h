@@ -360,10 +360,12 @@ int hmx_hmatrix_prepare(hmx_hmatrix *, char trans, int mu);
  * callers own plain std::vector's).  Any device pointer is a valid output; one from here lies where this operator's sweeps write fastest.  On
  * MI355X a streaming read loses 16-23 % to a write stream of ~1 % of its bytes when both lie in the same third of the physical memory and
  * 7-10 % when they do not; for the arrays the library owns that is settled at build time, the OUTPUT belongs to the caller -- the two speeds
- * of the expand kernels (N = 1e6, 16 right-hand sides: 2.03 / 2.33 ms; one vector: 1.71 / 1.78 ms) are nothing but where y lies relative to the
- * E-streams (profiles/r6_modes_*.log).  trans = 'N': written while the E-streams are read; 'T' / 'C': while the R-streams are read (stored-data
- * form).  Measured once per operator (a few probe launches, here -- never inside a product) when hmx_device_reserve gave the library a slab
- * to choose from; otherwise a plain allocation.  Zero-filled.  Freed by hmx_hmatrix_free_vector or with the operator. */
+ * of the 16-RHS expand kernel round 5 could not explain (N = 1e6 fp64: 2.03 / 2.30 ms) are nothing but where Y lies relative to the E-streams
+ * (profiles/r6_modes_output_place.log).  When `bytes` is the size of an output of this operator (its rows -- trans 'T' / 'C': columns -- times a
+ * number of right-hand sides) and hmx_device_reserve gave the library a slab to choose from, the operator's own product of that shape is timed
+ * on zero operands with the vector at ten places, and the vector stays where it ran fastest (about 25 products, once, here -- never inside a
+ * product call of the caller); otherwise the placement probe of the build decides, or the driver.  Zero-filled.  Freed by
+ * hmx_hmatrix_free_vector or with the operator. */
 int hmx_hmatrix_alloc_vector(hmx_hmatrix *, char trans, int64_t bytes, void **device_ptr);
 int hmx_hmatrix_free_vector(hmx_hmatrix *, void *device_ptr);
 

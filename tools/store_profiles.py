@@ -53,7 +53,7 @@ rec = dict(round=int(RN[1:]), kernel_sources_sha256=bench.kernel_sources_hash(),
            workload="bench.py N=1e6 ellipse eps=1e-4 (1 GPU): default (partialACA, 'N') and --sym S (sympartialACA, 'S','L', compact storage, fused product)",
            method="rocprofv3 --kernel-trace --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE (tools/collect_profiles.sh, tools/pmc_summary.py); values in KB; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM): in the same runs the 8 GiB read16_kernel reports 4.194e6 KB = 1/2 of 8 GiB; WRITE_SIZE exact",
-           product_hbm_bytes_total=sum(tot(v) for k, v in n.items() if any(x in k for x in PRODUCT)),
+           product_hbm_bytes_total=sum(tot(v) for k, v in n.items() if any(k.endswith(x) or (x + "<") in k for x in ("::expand_kernel", "::reduce_kernel", "::combine_kernel"))),  # (the bench also times a transposed product: other kernels)
            expand_kernel_hbm_bytes_per_launch=tot(pick(n, "expand_kernel")), expand_kernel_fetch_bytes=pick(n, "expand_kernel")["fetch_bytes_x2"],
            expand_kernel_write_bytes=pick(n, "expand_kernel")["write_bytes"], reduce_kernel_hbm_bytes_per_launch=tot(pick(n, "reduce_kernel")),
            expand_sym_kernel_hbm_bytes_per_launch=tot(pick(s, "expand_sym_kernel")), expand_sym_kernel_write_bytes=pick(s, "expand_sym_kernel")["write_bytes"],
