@@ -440,6 +440,11 @@ class HMatrix:
         check(lib().hmx_hmatrix_save(self._h, str(path).encode()))
 
     def refresh_leaves(self):
+        """The leaf table and the ranks changed (build, recompression, upload): read again when next asked for (a download of the ranks --
+        12 ms at N = 1e6 -- that a caller who only multiplies never needs)."""
+        self._leaves = self._ranks = None
+
+    def _load_leaves(self):
         L = lib()
         n = L.hmx_block_tree_num_leaves(self._bt)
         leaves = (_lib.Leaf * n)()
@@ -447,8 +452,19 @@ class HMatrix:
         arr = np.ctypeslib.as_array(leaves).copy() if n else np.zeros(0, dtype=[("t_offset", "<i4")])
         ranks = np.zeros(n, dtype=np.int32)
         check(L.hmx_hmatrix_leaf_ranks(self._h, ranks.ctypes.data_as(C.POINTER(C.c_int32))))
-        self.leaves = arr
-        self.ranks = ranks
+        self._leaves, self._ranks = arr, ranks
+
+    @property
+    def leaves(self):
+        if self._leaves is None:
+            self._load_leaves()
+        return self._leaves
+
+    @property
+    def ranks(self):
+        if self._ranks is None:
+            self._load_leaves()
+        return self._ranks
 
     # htool getters
     def nb_rows(self):

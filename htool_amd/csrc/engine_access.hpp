@@ -47,20 +47,14 @@ int api_get_block(const HMat *Hc, int64_t leaf, scalar *U_or_D, scalar *V) {
     }
     // dense: gather the slices back out of the E-streams
     const StreamSet &E = H->E;
-    int r0 = (int)(std::lower_bound(E.off.begin(), E.off.end(), l.t_offset - H->T0) - E.off.begin());
-    for (int r = r0; r < E.nranges() && E.off[r] < l.t_offset - H->T0 + M; r++) {
-        // find this block's first column in range r: scan the z index of the range for its x position
-        const int64_t cb = E.colbase[r];
-        int col          = -1;
-        for (int c = 0; c < E.cols[r]; c++)
-            if (H->h_e_zidx[cb + c] == l.s_offset - H->S0) { // a dense column (index below nS) starting at this block's first source point
-                col = c;
-                break;
-            }
-        if (col < 0) {
-            set_error("hmx_hmatrix_get_block: internal lookup failed");
-            return HMX_ERR_STATE;
-        }
+    // the block's slices: (leaf, range, first column) triples, leaf-major (build_streams)
+    const size_t q0 = (size_t)(std::lower_bound(H->dp_leaf.begin(), H->dp_leaf.end(), (int32_t)leaf) - H->dp_leaf.begin());
+    if (q0 >= H->dp_leaf.size() || H->dp_leaf[q0] != (int32_t)leaf) {
+        set_error("hmx_hmatrix_get_block: internal lookup failed");
+        return HMX_ERR_STATE;
+    }
+    for (size_t q = q0; q < H->dp_leaf.size() && H->dp_leaf[q] == (int32_t)leaf; q++) {
+        const int r = H->dp_range[q], col = H->dp_col[q];
         const int len = E.len[r], rel = E.off[r] - (l.t_offset - H->T0);
         std::vector<scalar> buf((size_t)len * N);
         HMX_HIP(hipMemcpy(buf.data(), E.stream.d + E.base[r] + (int64_t)col * len, buf.size() * sizeof(scalar), hipMemcpyDeviceToHost));

@@ -1023,6 +1023,30 @@ static int build_streams(HMat &H) {
         HMX_HIP(pk[7].upload(ed_r));
         HMX_HIP(pk[8].upload(ed_c));
     }
+    // per leaf / per pair first indices of the product kernels' index arrays (fill_index_kernel below): uploaded BEFORE the pack kernels are
+    // launched, like the pair lists -- a blocking copy behind them would wait for them
+    const int64_t zA = H.nS, zP = H.nS + A_total;
+    DArr<int32_t> d_ncols, d_z0e, d_o0;
+    {
+        std::vector<int32_t> ncols(nb), z0(nb);
+        for (int64_t b = 0; b < nb; b++) {
+            const bool lr = XK[b] == LK_LOWRANK;
+            ncols[b]      = lr ? XL[b].rank : XL[b].s_size;
+            z0[b]         = lr ? (int32_t)(zA + aoff[b]) : (int32_t)(XL[b].s_offset - H.S0);
+        }
+        std::vector<int32_t> o0(rlr_b.size());
+        parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; p++) {
+                const int b = rlr_b[p];
+                o0[p] = ns_of[b] == 1 ? (int32_t)(zA + aoff[b]) : (int32_t)(zP + poff[b] + (int64_t)(rlr_r[p] - s_first[b]) * XL[b].rank);
+            }
+        });
+        HMX_HIP(d_ncols.upload(ncols));
+        HMX_HIP(d_z0e.upload(z0));
+        HMX_HIP(d_o0.upload(o0));
+        HMX_HIP(H.e_zidx.alloc(std::max<int64_t>(E.total_cols, 1)));
+        HMX_HIP(H.r_outidx.alloc(std::max<int64_t>(R.total_cols, 1)));
+    }
     HMX_HIP(hipEventRecord(e0, 0));
     if (!elr_b.empty()) {
         PackLrArgs P{SRC.pool.d, SRC.d_cross_off.d, H.d_colptr.d, H.d_rank.d, H.d_swapped.d, H.d_t_off.d, H.d_t_size.d, H.d_s_off.d, H.d_s_size.d,
@@ -1062,25 +1086,24 @@ static int build_streams(HMat &H) {
         }
     } pack_guard{H};
     phase_nosync("pack kernels launched");
-    const int64_t zA = H.nS, zP = H.nS + A_total;
     H.zero_slot      = H.nS + A_total + P_total;
-    H.h_e_zidx.resize(E.total_cols); // every column belongs to exactly one (leaf, range) pair: written completely below
-    auto fill_e = [&](const std::vector<int32_t> &pb, const std::vector<int32_t> &pr, const std::vector<int32_t> &pc, bool lr) {
-        parallel_for(pb.size(), [&](size_t lo, size_t hi) { // every (leaf, range) pair owns its own columns
-            for (size_t p = lo; p < hi; p++) {
-                const int b = pb[p], r = pr[p];
-                const hmx_leaf &l = XL[b];
-                const int ncols   = lr ? l.rank : l.s_size;
-                const int64_t z0  = lr ? zA + aoff[b] : (int64_t)(l.s_offset - H.S0);
-                int32_t *dst      = H.h_e_zidx.data() + E.colbase[r] + pc[p];
-                for (int j = 0; j < ncols; j++)
-                    dst[j] = (int32_t)(z0 + j);
-            }
-        });
-    };
-    fill_e(elr_b, elr_r, elr_c, true);
-    fill_e(ed_b, ed_r, ed_c, false);
-    { // where the dense leaves' slices sit in the E-streams (bulk download: api_get_blocks); leaf-major, the stored leaves only
+    // e_zidx / r_outidx: filled on the device from the pair lists (fill_index_kernel), behind the pack kernels on the same stream
+    {
+        if (!elr_b.empty()) {
+            FillIndexArgs F{pk[0].d, pk[1].d, pk[2].d, E.d_colbase.d, d_ncols.d, d_z0e.d, H.e_zidx.d, 0};
+            hipLaunchKernelGGL(fill_index_kernel, dim3((unsigned)((elr_b.size() + 3) / 4)), dim3(256), 0, 0, F, (int64_t)elr_b.size());
+        }
+        if (!ed_b.empty()) {
+            FillIndexArgs F{pk[6].d, pk[7].d, pk[8].d, E.d_colbase.d, d_ncols.d, d_z0e.d, H.e_zidx.d, 0};
+            hipLaunchKernelGGL(fill_index_kernel, dim3((unsigned)((ed_b.size() + 3) / 4)), dim3(256), 0, 0, F, (int64_t)ed_b.size());
+        }
+        if (!rlr_b.empty()) {
+            FillIndexArgs F{pk[3].d, pk[4].d, pk[5].d, R.d_colbase.d, d_ncols.d, d_o0.d, H.r_outidx.d, 1};
+            hipLaunchKernelGGL(fill_index_kernel, dim3((unsigned)((rlr_b.size() + 3) / 4)), dim3(256), 0, 0, F, (int64_t)rlr_b.size());
+        }
+        HMX_HIP(hipGetLastError());
+    }
+    { // where the dense leaves' slices sit in the E-streams (hmx_hmatrix_get_block / bulk download: api_get_blocks); leaf-major, the stored leaves only
         H.dp_leaf.clear();
         H.dp_range.clear();
         H.dp_col.clear();
@@ -1091,19 +1114,7 @@ static int build_streams(HMat &H) {
                 H.dp_col.push_back(ed_c[q]);
             }
     }
-    phase_nosync("  e index");
-    hvec32 h_outidx(R.total_cols);
-    parallel_for(rlr_b.size(), [&](size_t lo, size_t hi) {
-        for (size_t p = lo; p < hi; p++) {
-            const int b = rlr_b[p], r = rlr_r[p];
-            const hmx_leaf &l = XL[b];
-            const int64_t cb  = R.colbase[r] + rlr_c[p];
-            for (int k = 0; k < l.rank; k++) {
-                h_outidx[cb + k]   = ns_of[b] == 1 ? (int32_t)(zA + aoff[b] + k) : (int32_t)(zP + poff[b] + (int64_t)(r - s_first[b]) * l.rank + k);
-            }
-        }
-    });
-    phase_nosync("  r index");
+    phase_nosync("  e / r index (device)");
     std::vector<int32_t> cd, cs, cst, cc;
     for (int64_t b = 0; b < nb; b++)
         if (poff[b] >= 0)
@@ -1127,8 +1138,6 @@ static int build_streams(HMat &H) {
 
     phase_nosync("index arrays");
     // ---- uploads of the index arrays (the first one waits for the pack kernels: same stream) ----------------------------------------
-    HMX_HIP(H.e_zidx.upload(H.h_e_zidx));
-    HMX_HIP(H.r_outidx.upload(h_outidx));
     HMX_HIP(H.c_dst.upload(cd));
     HMX_HIP(H.c_src.upload(cs));
     HMX_HIP(H.c_stride.upload(cst));

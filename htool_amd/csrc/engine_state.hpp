@@ -154,7 +154,6 @@ struct HMat {
     std::vector<int32_t> dp_leaf, dp_range, dp_col; // (dense leaf, row range, first column in the range) of every slice of a dense leaf, leaf-major
     DArr<int32_t> e_zidx;
     DArr<int32_t> r_outidx;
-    hvec32 h_e_zidx;
     DArr<int32_t> c_dst, c_src, c_stride, c_count;
     int n_combine       = 0;
     int64_t A_total     = 0, P_total = 0;

@@ -140,3 +140,26 @@ __global__ void pack_dense_kernel(PackDenseArgs P, int64_t npairs) {
         dst[e] = v;
     }
 }
+
+// The index arrays of the product kernels, filled on the device from the pair lists the pack kernels already have (round 6: the host filled
+// 23.6 M entries and uploaded 94 MB at N = 1e6 -- 24 ms of a 150 ms build):
+//   E: column c of (leaf b, range r) gathers Z[z0[b] + c], z0 = nS + a-offset of a low-rank leaf, the first source position of a dense one
+//   R: column k of (leaf b, piece s) writes Z[o0 + k], o0 = the leaf's a slots (one piece) or its partial slots of that piece
+struct FillIndexArgs {
+    const int32_t *pair_block, *pair_range, *pair_col;
+    const int64_t *range_colbase;
+    const int32_t *ncols; // per leaf: rank (low rank) or source size (dense)
+    const int32_t *z0;    // E: per leaf; R: per PAIR (o0)
+    int32_t *out;
+    int per_pair;         // z0 indexed by pair (R) instead of by leaf (E)
+};
+__global__ __launch_bounds__(256) void fill_index_kernel(FillIndexArgs A, int64_t npairs) {
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npairs)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int b = A.pair_block[p], n = A.ncols[b], z = A.per_pair ? A.z0[p] : A.z0[b];
+    int32_t *dst = A.out + A.range_colbase[A.pair_range[p]] + A.pair_col[p];
+    for (int j = lane; j < n; j += 64)
+        dst[j] = z + j;
+}
