@@ -350,11 +350,8 @@ template <> struct Acc4<float> { typedef hmx_f4 type; };
 #endif
 #endif
 #ifndef HMX_WPE_ROWSYM_MFMA16_KERNEL
-#if HMX_INST == 0
+// (fp32 too: at three waves -- 168 registers -- the four instantiations of the interval loop spill 32 bytes into the hot loop)
 #define HMX_WPE_ROWSYM_MFMA16_KERNEL __attribute__((amdgpu_waves_per_eu(2)))
-#else
-#define HMX_WPE_ROWSYM_MFMA16_KERNEL __attribute__((amdgpu_waves_per_eu(3)))
-#endif
 #endif
 // single-vector symmetric sweeps (empty: the compiler's choice; A/B by tools/variant.sh)
 #ifndef HMX_WPE_EXPAND_SYM_KERNEL

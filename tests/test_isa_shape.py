@@ -90,6 +90,7 @@ def test_single_vector_kernels_keep_their_occupancy_and_load_shape(tmp_path):
             name = re.search(r"\.name:\s+(\S+)", blk).group(1)
             meta[name] = {k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1)) for k in ("vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
     checked = 0
+    occupancy_checked = []
     for name, m in meta.items():
         if re.search(r"3(f64|f32|z64|c32)13expand_kernelILi\d", name):
             assert m["private_segment_fixed_size"] == 0 and m["vgpr_count"] <= 64, (name, m)  # 8 waves per SIMD
@@ -104,6 +105,24 @@ def test_single_vector_kernels_keep_their_occupancy_and_load_shape(tmp_path):
             checked += 1
         if re.search(r"aca_cb_(row|col)_kernel|sym_mfma16_kernel|rowsym_mfma16_kernel", name):
             assert m["private_segment_fixed_size"] == 0, (name, m)
+        # Round 6: the stored-triangle matrix-core kernels live on their waves per SIMD.  vgpr_count is the whole allocation in the unified register
+        # file (accumulation registers included): <= 256 = two waves, <= 168 = three.  The loop over a group's row ranges once cost the fp64 E pass
+        # 24 registers -- 264 -- and with them a third of its speed, with identical instruction counts (profiles/r6_pmc_ab_loop.log).
+        if re.search(r"3f64(24expand_sym_mfma16_kernelILi4ELb1E|20rowsym_mfma16_kernel)", name):
+            assert m["vgpr_count"] <= 256, (name, m)
+            occupancy_checked.append(name)
+        if re.search(r"3f3224expand_sym_mfma16_kernelILi4ELb1E", name):
+            assert m["vgpr_count"] <= 168, (name, m)
+            occupancy_checked.append(name)
+        if re.search(r"3f6421reduce_mfma16s_kernel", name):
+            assert m["vgpr_count"] <= 168, (name, m)
+            occupancy_checked.append(name)
+        # ... and on the LDS that goes with it: tiles + a group's accumulators of two (fp32: three) workgroups per CU in 160 KB
+        if re.search(r"3f6424expand_sym_mfma16_kernelILi4ELb1E", name):
+            assert m["group_segment_fixed_size"] + 320 * 16 * 8 <= 80 * 1024, (name, m)
+        if re.search(r"3f3224expand_sym_mfma16_kernelILi4ELb1E", name):
+            assert 3 * (m["group_segment_fixed_size"] + 512 * 16 * 4) <= 160 * 1024, (name, m)
+    assert len(occupancy_checked) >= 4, occupancy_checked
     assert checked >= 18, checked  # expand_kernel<4|8> x 4 types, reduce_kernel<1|4> x 2, the fused symmetric kernels (real and complex double)
     for sym, op, least in (("_ZN3hmx3f6413reduce_kernelILi1EEEvNS0_10ReduceArgsE", "global_load_dwordx4", 8), ("_ZN3hmx3f6413expand_kernelILi4EEEvNS0_10ExpandArgsE", "global_load_dwordx2", 8)):
         asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, where[sym]], capture_output=True, text=True, check=True).stdout
