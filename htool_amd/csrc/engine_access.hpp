@@ -381,8 +381,8 @@ int api_stats(const HMat *H, hmx_stats *out) {
     *out                  = H->stats;
     out->transposed_bytes = H->T_op ? H->T_op->stats.stream_bytes : 0;
     if (H->trans_fused) // the tables of the transposed product on the stored data
-        out->transposed_bytes += (int64_t)((H->s_mdst.n + H->s_coef.n + H->s_count.n + H->sc_dst.n + H->sc_lp.n + H->sc_count.n + H->sc_k.n + H->s_list.n + H->s_fidx.n + H->s_sub_task.n +
-                                            H->s_sub_row0.n + H->s_sub_nrows.n + H->s_sub_dst.n + H->s_int_order.n) * sizeof(int32_t) + H->s_sub_ptr.n * sizeof(int64_t) + H->SW.n * sizeof(scalar));
+        out->transposed_bytes += (int64_t)((H->s_mdst.n + H->s_coef.n + H->s_count.n + H->sc_dst.n + H->sc_lp.n + H->sc_count.n + H->sc_k.n + H->s_list.n + H->s_fidx.n + H->s_sub_w.n +
+                                            H->s_sub_nrows.n + H->s_sub_dst.n + H->s_int_order.n) * sizeof(int32_t) + (H->s_sub_ptr.n + H->s_sub_src.n + H->s_sub_cb.n) * sizeof(int64_t) + H->SW.n * sizeof(scalar));
     out->expanded_bytes   = H->X_op ? H->X_op->stats.stream_bytes : 0;
     out->placed_read_gbps = H->placed_z.read_only, out->placed_first_gbps = H->placed_z.first, out->placed_gbps = H->placed_z.chosen, out->placed_tried = H->placed_z.tried;
     return HMX_OK;

@@ -41,8 +41,8 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     std::vector<int32_t> s_cnt, s_cd, s_clp, s_cc, s_ck, s_list;
     std::unique_ptr<int32_t[]> s_fidx; // level-major, s_kmax x nT: left uninitialised (only the entries below count[j] are ever read)
     size_t s_fidx_n = 0;
-    std::vector<int64_t> s_sub_ptr;
-    std::vector<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order;
+    std::vector<int64_t> s_sub_ptr, s_sub_src, s_sub_cb;
+    std::vector<int32_t> s_sub_w, s_sub_nrows, s_sub_dst, s_int_order;
     std::vector<int32_t> o64; // launch order of the intervals of the multi-RHS form of the second sweep (below)
     H.n_sym_combine = 0;
     H.s_kmax        = 0;
@@ -75,7 +75,8 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     // accumulators per group: what leaves the 16-RHS sweep its waves per SIMD -- LDS decides: tiles + accumulators of two workgroups per CU for
     // 8-byte reals (36.9 KB + 320 x 128 B each), of three for 4-byte reals (20.5 KB + 512 x 64 B) in 160 KB
     const int gcap_auto = sizeof(real) == 8 ? 320 : 512;
-    const int gcap = G > 1 ? (H.opt.i(HMX_OPT_SYM_GROUP_SLOTS) < 0 ? gcap_auto : H.opt.i(HMX_OPT_SYM_GROUP_SLOTS)) : 0;
+    const int gcap_max  = sizeof(real) == 8 ? 896 : 1024; // what ONE workgroup's tiles leave of a CU's 160 KB (41 KB of tiles + 896 x 128 B)
+    const int gcap = G > 1 ? std::min(gcap_max, H.opt.i(HMX_OPT_SYM_GROUP_SLOTS) < 0 ? gcap_auto : H.opt.i(HMX_OPT_SYM_GROUP_SLOTS)) : 0;
     const int ng  = (nre + G - 1) / G;
     // pair -> accumulator of its group (-1: own slots); dense: and whether the pair is the first of its key (it alone counts as a contribution)
     std::vector<int32_t> lr_acc(elr_b.size(), -1), d_acc(ed_b.size(), -1);
@@ -243,7 +244,7 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
         task_mirror[t] = 1;
     }
     // the sub-task lists of the intervals of IR rows (launch order of the tasks = order inside every interval's list), heaviest interval first
-    auto build_intervals = [&](int IR, std::vector<int64_t> &sub_ptr, std::vector<int32_t> &sub_task, std::vector<int32_t> &sub_row0, std::vector<int32_t> &sub_nrows,
+    auto build_intervals = [&](int IR, std::vector<int64_t> &sub_ptr, std::vector<int64_t> &sub_src, std::vector<int64_t> &sub_cb, std::vector<int32_t> &sub_w, std::vector<int32_t> &sub_nrows,
                                std::vector<int32_t> &sub_dst, std::vector<int32_t> &int_order, int per_group) -> int {
         const int nint = (nOut + IR - 1) / IR;
         std::vector<int64_t> sub_count(nint + 1, 0);
@@ -258,8 +259,9 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
             sub_count[I + 1] += sub_count[I];
         sub_ptr            = sub_count;
         const int64_t nsub = sub_count[nint];
-        sub_task.assign(nsub, 0);
-        sub_row0.assign(nsub, 0);
+        sub_src.assign(nsub, 0);
+        sub_cb.assign(nsub, 0);
+        sub_w.assign(nsub, 0);
         sub_nrows.assign(nsub, 0);
         sub_dst.assign(nsub, 0);
         std::vector<double> int_work(nint, 0.0);
@@ -268,13 +270,14 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
             if (!task_mirror[t])
                 continue;
             const int r = R.task_range[t], ch = R.task_chunk[t], cw = R.cw[r];
-            const int w = std::min(cw, R.cols[r] - ch * cw);
+            const int w = std::min(cw, R.cols[r] - ch * cw), wp = hmx_wp(w);
             const int j0 = R.off[r] + r_shift, j1 = j0 + R.len[r];
             for (int I = j0 / IR; I <= (j1 - 1) / IR; I++) {
                 const int lo = std::max(j0, I * IR), hi = std::min(j1, (I + 1) * IR);
                 const int64_t q = pos[I]++;
-                sub_task[q]  = (int32_t)t;
-                sub_row0[q]  = lo - j0;
+                sub_src[q]   = R.base[r] + (int64_t)ch * R.len[r] * cw + (int64_t)(lo - j0) * wp; // the sub-task's first row, the chunk's first column
+                sub_cb[q]    = R.colbase[r] + (int64_t)ch * cw;
+                sub_w[q]     = w;
                 sub_nrows[q] = hi - lo;
                 sub_dst[q]   = lo - I * IR;
                 int_work[I] += (double)(hi - lo) * w + 256;
@@ -296,7 +299,7 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     };
     int nint = 0;
     if (!bad)
-        nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order, 1);
+        nint = build_intervals(SYM_IR, s_sub_ptr, s_sub_src, s_sub_cb, s_sub_w, s_sub_nrows, s_sub_dst, s_int_order, 1);
     // The multi-RHS form of the second sweep (rowsym_mfma16_kernel / rowsym_zmfma8_kernel: one WAVE per interval; rowsym_mu_kernel: one workgroup):
     // intervals of at most SYM_IR_MU rows cut AT the boundaries of the mirrored pieces, so that every (piece, chunk) task covers whole
     // intervals -- no sub-task of a few rows at the edge of a fixed 64-row grid (clusters of 61 rows against intervals of 64: every piece
@@ -465,8 +468,9 @@ static int build_mirror_tables(HMat &H, const MirrorCtx &M) {
     HMX_HIP(H.s_coef.upload(s_coef));
     HMX_HIP(H.s_count.upload(s_cnt));
     HMX_HIP(H.s_sub_ptr.upload(s_sub_ptr));
-    HMX_HIP(H.s_sub_task.upload(s_sub_task));
-    HMX_HIP(H.s_sub_row0.upload(s_sub_row0));
+    HMX_HIP(H.s_sub_src.upload(s_sub_src));
+    HMX_HIP(H.s_sub_cb.upload(s_sub_cb));
+    HMX_HIP(H.s_sub_w.upload(s_sub_w));
     HMX_HIP(H.s_sub_nrows.upload(s_sub_nrows));
     HMX_HIP(H.s_sub_dst.upload(s_sub_dst));
     HMX_HIP(H.s_int_order.upload(s_int_order));
@@ -967,9 +971,10 @@ static int build_streams(HMat &H) {
     if (!H.sym_fused) {
         for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx})
             a->release();
-        for (auto *a : {&H.s_sub_task, &H.s_sub_row0, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
+        for (auto *a : {&H.s_sub_w, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
             a->release();
-        H.s_sub_ptr.release();
+        for (auto *a : {&H.s_sub_ptr, &H.s_sub_src, &H.s_sub_cb})
+            a->release();
         H.SW.release();
     }
     HMX_HIP(E.upload_meta());

@@ -121,8 +121,7 @@ static int run_forward(HMat &H, const int32_t *zidx, const scalar *x_src, scalar
             prof_mark(H, st, "combine_sym_kernel");
         }
         if (H.s_nint > 0) {
-            RowSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d,
-                         H.s_int_order.d, H.s_sub_ptr.d, H.s_sub_task.d, H.s_sub_row0.d, H.s_sub_nrows.d, H.s_sub_dst.d,
+            RowSymArgs A{H.R.stream.d, H.s_coef.d, H.s_int_order.d, H.s_sub_ptr.d, H.s_sub_src.d, H.s_sub_cb.d, H.s_sub_w.d, H.s_sub_nrows.d, H.s_sub_dst.d,
                          H.SW.d, H.s_fidx.d, H.s_count.d, y, alpha, H.nT, H.symmetry_for_leaves == 'H' ? 1 : 0, scalar(0), 1};
             hipLaunchKernelGGL(rowsym_kernel<SYM_WAVES>, dim3(H.s_nint), dim3(SYM_WAVES * 64), 0, st, A);
             prof_mark(H, st, "rowsym_kernel");
@@ -239,9 +238,10 @@ static int build_trans_tables(HMat &H) {
     MirrorCtx M{H.leaves, H.kind, nb, elr_b, elr_r, elr_c, ed_b, ed_r, ed_c, rlr_b, rlr_r, rlr_c, aoff, A_total, true, nullptr};
     const int rc = build_mirror_tables(H, M);
     if (rc != HMX_OK) {
-        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx, &H.s_sub_task, &H.s_sub_row0, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
+        for (auto *a : {&H.s_mdst, &H.s_coef, &H.s_count, &H.sc_dst, &H.sc_lp, &H.sc_count, &H.sc_k, &H.s_list, &H.s_fidx, &H.s_sub_w, &H.s_sub_nrows, &H.s_sub_dst, &H.s_int_order})
             a->release();
-        H.s_sub_ptr.release();
+        for (auto *a : {&H.s_sub_ptr, &H.s_sub_src, &H.s_sub_cb})
+            a->release();
         H.SW.release();
         return rc;
     }
@@ -274,8 +274,7 @@ static int run_transposed_fused(HMat &H, const scalar *in, scalar alpha, scalar 
         prof_mark(H, st, "combine_sym_kernel");
     }
     if (H.s_nint > 0) {
-        RowSymArgs A{H.R.stream.d, H.R.d_task_range.d, H.R.d_task_chunk.d, H.R.d_len.d, H.R.d_cols.d, H.R.d_cw.d, H.R.d_base.d, H.R.d_colbase.d, H.s_coef.d,
-                     H.s_int_order.d, H.s_sub_ptr.d, H.s_sub_task.d, H.s_sub_row0.d, H.s_sub_nrows.d, H.s_sub_dst.d,
+        RowSymArgs A{H.R.stream.d, H.s_coef.d, H.s_int_order.d, H.s_sub_ptr.d, H.s_sub_src.d, H.s_sub_cb.d, H.s_sub_w.d, H.s_sub_nrows.d, H.s_sub_dst.d,
                      H.SW.d, H.s_fidx.d, H.s_count.d, out, alpha, H.nS, 0, beta, 0};
         hipLaunchKernelGGL(rowsym_kernel<SYM_WAVES>, dim3(H.s_nint), dim3(SYM_WAVES * 64), 0, st, A);
         prof_mark(H, st, "rowsym_kernel");

@@ -101,8 +101,8 @@ struct HMat {
     bool trans_tables_failed = false;
     bool trans_fused = false; // tables of the transposed product on the stored data present (build_trans_tables): s_* below, output rows = source positions
     DArr<int32_t> s_mdst, s_coef, s_count, s_list, s_fidx;
-    DArr<int64_t> s_sub_ptr;
-    DArr<int32_t> s_sub_task, s_sub_row0, s_sub_nrows, s_sub_dst, s_int_order; // second R sweep: per row interval the (parts of) tasks inside it
+    DArr<int64_t> s_sub_ptr, s_sub_src, s_sub_cb;
+    DArr<int32_t> s_sub_w, s_sub_nrows, s_sub_dst, s_int_order; // second R sweep: per row interval the (parts of) tasks inside it, a ready record each (RowSymArgs)
     int s_nint = 0;
     // ... and for the multi-RHS form (rowsym_mfma16_kernel: intervals of 64 rows, one wave each); SW16 = [slot][16] partial sums of one sweep
     DArr<int32_t> s64_int_off, s64_int_order; // interval I = output rows [int_off[I], int_off[I + 1]) (at most SYM_IR_MU, cut at the mirrored pieces' boundaries)

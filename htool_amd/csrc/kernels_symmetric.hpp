@@ -245,13 +245,14 @@ constexpr int SYM_IR    = HMX_SYM_IR; // rows per interval
 constexpr int SYM_WAVES = HMX_SYM_WAVES;
 struct RowSymArgs {
     const scalar *stream;
-    const int32_t *task_range, *task_chunk;
-    const int32_t *range_len, *range_cols, *range_cw;
-    const int64_t *range_base, *range_colbase;
     const int32_t *coef;      // per R column: slot of a'[col] in W, -1: not a mirrored column
     const int32_t *order;     // launch position -> interval (heaviest first)
     const int64_t *sub_ptr;   // per interval: its sub-tasks [sub_ptr[I], sub_ptr[I + 1])
-    const int32_t *sub_task, *sub_row0, *sub_nrows, *sub_dst; // task, first row inside the piece, rows, first row inside the interval
+    // per sub-task a ready record (round 6; before: task -> piece -> geometry, a chain of a dozen dependent index loads in front of every
+    // sub-task's first stream load): first stream element (the sub-task's first row, the chunk's first column), first entry of the chunk in
+    // `coef`, columns of the chunk, rows, first row inside the interval
+    const int64_t *sub_src, *sub_cb;
+    const int32_t *sub_w, *sub_nrows, *sub_dst;
     const scalar *W;          // [a' | EW]
     const int32_t *fidx;      // dense mirrored contributions of output row j: W[fidx[k * n + j]], k < count[j]
     const int32_t *count;
@@ -271,26 +272,28 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_ROWSYM_KERNEL void rowsym_kern
         acc[wv][r] = scalar(0);
     const bool herm = A.herm != 0;
     constexpr int GS = sizeof(scalar2) <= 8 ? 16 : 8;
-    for (int64_t q = A.sub_ptr[I] + wv; q < A.sub_ptr[I + 1]; q += WAVES) {
-        const int task = A.sub_task[q], row0 = A.sub_row0[q], len = A.sub_nrows[q];
+    const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
+    const int64_t q_end = A.sub_ptr[I + 1];
+    // the coefficients a' of a sub-task's two columns per lane: gathered one sub-task ahead (record -> slot -> value: two trips to memory that
+    // used to stand in front of every sub-task's first stream load)
+    auto coefficients = [&](int64_t q, scalar &c0, scalar &c1) {
+        const int w      = A.sub_w[q];
+        const int64_t cb = A.sub_cb[q];
+        const int d0 = col0 < w ? A.coef[cb + col0] : -1, d1 = col1 < w ? A.coef[cb + col1] : -1;
+        c0 = d0 >= 0 ? A.W[d0] : scalar(0);
+        c1 = d1 >= 0 ? A.W[d1] : scalar(0);
+    };
+    int64_t q = A.sub_ptr[I] + wv;
+    scalar c0 = scalar(0), c1 = scalar(0);
+    if (q < q_end)
+        coefficients(q, c0, c1);
+    for (; q < q_end; q += WAVES) {
+        const int len = A.sub_nrows[q], w = A.sub_w[q];
         scalar *dst = &acc[wv][A.sub_dst[q]];
-        const int S = A.task_range[task], ch = A.task_chunk[task];
-        const int plen = A.range_len[S], C = A.range_cols[S], cw = A.range_cw[S];
-        int w = C - ch * cw;
-        w     = w > cw ? cw : w;
         const int wp      = hmx_wp(w);
-        const int col0 = HMX_COL0(lane), col1 = HMX_COL1(lane);
-        const scalar *src = A.stream + A.range_base[S] + (int64_t)ch * plen * cw + (int64_t)row0 * wp;
-        const int64_t cb  = A.range_colbase[S] + ch * cw;
-        scalar c0 = scalar(0), c1 = scalar(0);
-        if (col0 < w) {
-            const int d = A.coef[cb + col0];
-            c0          = d >= 0 ? A.W[d] : scalar(0);
-        }
-        if (col1 < w) {
-            const int d = A.coef[cb + col1];
-            c1          = d >= 0 ? A.W[d] : scalar(0);
-        }
+        const scalar *src = A.stream + A.sub_src[q];
+        scalar c0n = scalar(0), c1n = scalar(0);
+        coefficients(q + WAVES < q_end ? q + WAVES : q, c0n, c1n); // (past the wave's last sub-task: its own again, unused)
         scalar mine = scalar(0);
         // always GS loads, no branches: rows beyond the sub-task re-read its last row (their sums are dropped), lanes beyond the
         // chunk read column 0 and multiply it with their zero coefficients
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(WAVES *WAVE) HMX_WPE_ROWSYM_KERNEL void rowsym_kern
             if (i0 + GS < len)
                 process(eb, i0 + GS);
         }
+        c0 = c0n, c1 = c1n;
     }
     __syncthreads();
     for (int r = threadIdx.x; r < SYM_IR; r += WAVES * WAVE) {

@@ -233,7 +233,8 @@ typedef enum {
                                         the column sums that belong together (a leaf's partial a', dense leaves with one source
                                         cluster); 1: every range writes all its sums (rounds 2-5)                              HMX_SYM_GROUP        */
     HMX_OPT_SYM_GROUP_SLOTS   = 9,  /* layout  -1    LDS accumulators per group (x 16 right-hand sides x coefficient size bytes); -1: what keeps
-                                                     two (8-byte reals: 320) / three (4-byte: 512) workgroups of the 16-RHS sweep on a CU   HMX_SYM_GROUP_SLOTS  */
+                                                     two (8-byte reals: 320) / three (4-byte: 512) workgroups of the 16-RHS sweep on a CU;
+                                                     at most 896 / 1024 (one workgroup's LDS)                                  HMX_SYM_GROUP_SLOTS  */
     HMX_OPT_BUILD_TIMING      = 6,  /* build   0     per-phase build times on stderr                                         HMX_BUILD_TIMING     */
     /* ---- products ---- */
     HMX_OPT_REDUCE_WAVES      = 10, /* product 0     waves per workgroup of the single-vector reduce stage (0: automatic)    HMX_REDUCE_WAVES     */

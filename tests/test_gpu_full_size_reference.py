@@ -84,7 +84,10 @@ def test_full_size_matches_the_reference(name):
             r = int(min(tab[i, 4], ref_ranks[i]))
             worst = max(worst, float(np.linalg.norm(A - U[:, :r].astype(np.float64) @ V[:r, :].astype(np.float64)) / np.linalg.norm(A)))
         print("%s: true relative error of the device's blocks truncated to min(rank, reference rank) on %d differing leaves: at most %.2e (eps %g)" % (name, len(pick), worst, p["eps"]))
-        assert worst <= 6 * p["eps"], worst  # (guard: observed 4.6 eps; the estimator bounds the last correction, not the remaining error -- DESIGN.md section 2)
+        # guard, not model: ACA's estimate bounds the last correction, not the remaining error -- "a few eps" is all the theory gives.  Observed over the ten fp32
+        # full-size fixtures (deterministic: fixed sample, bit-reproducible device results): 4.6 eps (N = 1e5, one vector) ... 7.9 eps (N = 4e6, rank 4 of 8).  Round 6
+        # tried 6 eps on the strength of the first figure alone and failed two fixtures
+        assert worst <= 10 * p["eps"], worst
     else:
         assert ndiff == 0
     rows = g["rows"]

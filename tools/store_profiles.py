@@ -38,7 +38,16 @@ def opt(name):
 
 
 s16, c5 = opt("bench_n1e6_sym_mu16_stored_triangle"), opt("bench_c5_rank3of8")
-PRODUCT = ("reduce", "expand", "combine", "rowsym")  # kernels of a product (not the bandwidth probes, not the build)
+# kernels of each workload's OWN product (the bench also multiplies in other shapes: the transposed product of `other_entry_points`, the
+# single-vector product hmx_hmatrix_alloc_vector times for y -- their kernels have other names)
+MU_N = ("reduce_mfma16s", "expand_mfma16s", "::combine_mu_kernel")
+MU_SYM = ("reduce_mfma16s", "::combine_mu_kernel", "expand_sym_mfma16", "combine_list_mu", "rowsym_mfma16")
+ONE_SYM = ("::reduce_kernel", "::combine_kernel", "::expand_sym_kernel", "::combine_list", "::rowsym_kernel")
+
+
+def own(d, names):
+    return sum(tot(v) for k, v in d.items() if any(x in k for x in names) and "read16" not in k)
+
 
 
 def tot(x):
@@ -58,15 +67,15 @@ rec = dict(round=int(RN[1:]), kernel_sources_sha256=bench.kernel_sources_hash(),
            expand_kernel_write_bytes=pick(n, "expand_kernel")["write_bytes"], reduce_kernel_hbm_bytes_per_launch=tot(pick(n, "reduce_kernel")),
            expand_sym_kernel_hbm_bytes_per_launch=tot(pick(s, "expand_sym_kernel")), expand_sym_kernel_write_bytes=pick(s, "expand_sym_kernel")["write_bytes"],
            rowsym_kernel_hbm_bytes_per_launch=tot(pick(s, "rowsym_kernel")), rowsym_kernel_write_bytes=pick(s, "rowsym_kernel")["write_bytes"],
-           sym_product_hbm_bytes_total=sum(tot(v) for k, v in s.items() if "read16" not in k),
+           sym_product_hbm_bytes_total=own(s, ONE_SYM),
            mu16_expand_kernel_hbm_bytes_per_launch=tot(pick(m16, "expand_mfma16s")), mu16_reduce_kernel_hbm_bytes_per_launch=tot(pick(m16, "reduce_mfma16s")),
-           mu16_product_hbm_bytes_total=sum(tot(v) for k, v in m16.items() if "read16" not in k),
+           mu16_product_hbm_bytes_total=own(m16, MU_N),
            transT_colsum_kernel_hbm_bytes_per_launch=tot(pick(tT, "expand_sym_kernel")), transT_rowsym_kernel_hbm_bytes_per_launch=tot(pick(tT, "rowsym_kernel")),
            transT_product_hbm_bytes_total=sum(tot(v) for k, v in tT.items() if any(s in k for s in ("expand_sym", "rowsym", "combine_list"))))
 if s16:
     rec.update(sym_mu16_expand_kernel_hbm_bytes_per_launch=tot(pick(s16, "expand_sym_mfma16")), sym_mu16_rowsym_kernel_hbm_bytes_per_launch=tot(pick(s16, "rowsym_mfma16")),
-               sym_mu16_product_hbm_bytes_total=sum(tot(v) for k, v in s16.items() if any(x in k for x in PRODUCT)))
+               sym_mu16_product_hbm_bytes_total=own(s16, MU_SYM))
 if c5:
-    rec.update(c5_rank3_expand_kernel_hbm_bytes_per_launch=tot(pick(c5, "expand")), c5_rank3_product_hbm_bytes_total=sum(tot(v) for k, v in c5.items() if any(x in k for x in PRODUCT)))
+    rec.update(c5_rank3_expand_kernel_hbm_bytes_per_launch=tot(pick(c5, "expand")), c5_rank3_product_hbm_bytes_total=own(c5, MU_SYM))
 json.dump(rec, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
