@@ -529,16 +529,12 @@ static int sym_mu_sweeps(HMat &H, bool fwd, const scalar *X, const scalar *xrow,
 #endif
     }
     if (H.n_sym_combine > 0) {
-        const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw; // the first nw entries fold >= 32 partial sums: one wave each
-        if (nw > 0) {
-            CombineListArgs C{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW16.d, nw};
-            hipLaunchKernelGGL(combine_list_mu_wave_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, C);
-        }
-        if (nt > 0) {
-            CombineListArgs C{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW16.d, nt};
-            const int64_t tot = (int64_t)nt * SWW;
-            hipLaunchKernelGGL(combine_list_mu_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C);
-        }
+        const int nw = H.n_sym_combine_wave, nt = H.n_sym_combine - nw; // the first nw entries fold >= 32 partial sums: one wave each; both kinds in one launch
+        CombineListArgs CW{H.sc_dst.d, H.sc_lp.d, H.sc_count.d, H.sc_k.d, H.s_list.d, H.SW16.d, nw};
+        CombineListArgs CT{H.sc_dst.d + nw, H.sc_lp.d + nw, H.sc_count.d + nw, H.sc_k.d + nw, H.s_list.d, H.SW16.d, nt};
+        const int wave_blocks = (nw + 3) / 4;
+        const int64_t thread_blocks = ((int64_t)nt * SWW + 255) / 256;
+        hipLaunchKernelGGL(combine_list_mu_both_kernel, dim3((unsigned)(wave_blocks + thread_blocks)), dim3(256), 0, st, CW, CT, wave_blocks);
         prof_mark(H, st, "combine_sym_mu_kernel");
     }
     if (H.s64_nint > 0) {

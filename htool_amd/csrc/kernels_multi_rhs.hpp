@@ -185,9 +185,19 @@ __global__ void combine_mu_kernel(CombineArgs A, int mu) {
     const int e = (int)(t / mu), c = (int)(t - (int64_t)e * mu);
     const scalar *p = A.Z + (int64_t)A.src[e] * mu + c;
     const int st = A.stride[e], cnt = A.count[e];
+    // the partial sums four at a time: four loads in flight, the additions in the order they always had (bitwise the same result)
+    const int64_t step = (int64_t)st * mu;
     scalar s = scalar(0);
-    for (int k = 0; k < cnt; k++)
-        s += p[(int64_t)k * st * mu];
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        const scalar v0 = p[k * step], v1 = p[(k + 1) * step], v2 = p[(k + 2) * step], v3 = p[(k + 3) * step];
+        s += v0;
+        s += v1;
+        s += v2;
+        s += v3;
+    }
+    for (; k < cnt; k++)
+        s += p[k * step];
     A.Z[(int64_t)A.dst[e] * mu + c] = s;
 }
 

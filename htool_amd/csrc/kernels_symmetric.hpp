@@ -395,11 +395,13 @@ __global__ __launch_bounds__(256) void combine_list_wave_kernel(CombineListArgs 
 // coefficients each: 16 real or 8 complex right-hand sides per sweep -- 128 resp. 64 bytes per slot in single, twice that in double precision).
 // ---------------------------------------------------------------------------------------------
 constexpr int SWW = HMX_COMPLEX ? 8 : 16;
-// a'[dst][0..SWW) = sum_i SW16[list[lp + i] + k][0..SWW): the partial column sums of a mirrored low-rank leaf that spans several row ranges.
-// One wave per entry for the entries with many partial sums (the first `A.n` entries handed to this kernel): SWW lanes take the right-hand
-// sides, the 64 / SWW lane groups every (64 / SWW)-th partial sum; fixed order
-__global__ __launch_bounds__(256) void combine_list_mu_wave_kernel(CombineListArgs A) {
-    const int e = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+// a'[dst][0..SWW) = sum_i SW16[list[lp + i] + k][0..SWW): the partial column sums of a mirrored low-rank leaf that spans several row ranges / groups.
+// One wave per entry for the entries with many partial sums: SWW lanes take the right-hand sides, the 64 / SWW lane groups every (64 / SWW)-th
+// partial sum; one thread per (entry, right-hand side) for the rest; fixed order.  Both kinds in ONE launch (combine_list_mu_both_kernel: the wave
+// entries in the first `wave_blocks` workgroups): the two are independent and each too small to fill the chip for long (45 + 90 us one after the
+// other at N = 1e6, round 6)
+__device__ __forceinline__ void combine_list_mu_wave_body(const CombineListArgs &A, int block) {
+    const int e = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));
     if (e >= A.n)
         return;
     constexpr int NG = 64 / SWW;
@@ -421,9 +423,7 @@ __global__ __launch_bounds__(256) void combine_list_mu_wave_kernel(CombineListAr
     if (g == 0)
         A.W[(int64_t)A.dst[e] * SWW + m] = s;
 }
-// ... one thread per (entry, right-hand side) for the rest
-__global__ void combine_list_mu_kernel(CombineListArgs A) {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void combine_list_mu_thread_body(const CombineListArgs &A, int64_t id) {
     const int e = (int)(id / SWW), m = (int)(id % SWW);
     if (e >= A.n)
         return;
@@ -442,6 +442,12 @@ __global__ void combine_list_mu_kernel(CombineListArgs A) {
     for (; i < cnt; i++)
         s0 += A.W[(int64_t)(l[i] + k) * SWW + m];
     A.W[(int64_t)A.dst[e] * SWW + m] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void combine_list_mu_both_kernel(CombineListArgs Wv, CombineListArgs Th, int wave_blocks) {
+    if ((int)blockIdx.x < wave_blocks)
+        combine_list_mu_wave_body(Wv, blockIdx.x);
+    else
+        combine_list_mu_thread_body(Th, (int64_t)(blockIdx.x - wave_blocks) * 256 + threadIdx.x);
 }
 
 // The fused symmetric / Hermitian product (expand_sym_kernel, rowsym_kernel) for MU right-hand sides at a time on the VALU: what complex
@@ -1111,7 +1117,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void rowsym_zmfma8_kernel(RowSegArgs A
 //                                   forward operands come straight from the registers the loads filled (lane = row) by a 4 x 4
 //                                   transposition between register index and lane quarter (v_permlane32_swap + v_permlane16_swap: no LDS),
 //                                   the mirrored ones from a wave-private LDS copy [row][column] written with 16-byte stores.
-//   combine_list_mu_kernel          a' of the leaves that span several row ranges
+//   combine_list_mu_both_kernel     a' of the leaves that span several row ranges / groups
 //   rowsym_mfma16_kernel            second pass over the R-streams, Y_s += V^T a': one WAVE owns 64 output rows (accumulators in
 //                                   registers, nothing to fold between waves), stream tiles 16 rows x 64 columns staged through LDS
 //                                   transposed and swizzled so that stores and operand reads both run at two lanes per bank.
