@@ -543,10 +543,14 @@ int api_alloc_vector(HMat *Hp, char trans, int64_t bytes, void **ptr) {
             }
         }
         H.profiling = was_profiling;
-        if (rc != HMX_OK)
-            return rc;
-        HMX_HIP(hipMemset(a->d, 0, count * sizeof(scalar)));
-        placed = true;
+        if (rc == HMX_OK) {
+            HMX_HIP(hipMemset(a->d, 0, count * sizeof(scalar)));
+            placed = true;
+        } else { // a product this operator refuses (trans = 'C' on 'S' leaves, a transposed view that cannot be built): no reason to refuse the memory
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+            a->release();
+        }
     }
     if (!placed) {
         // 'N': y is written by the expand stage (E-streams); transposed on the stored data: by the second sweep over the R-streams.  A transposed
