@@ -841,6 +841,33 @@ def test_xcd_grouped_launch_order(name, unit_rows, monkeypatch):
             assert rel_err(Y3, Y1) < 1e-13
 
 
+@pytest.mark.parametrize("group,slots", [(1, -1), (2, 7), (3, 0), (8, -1), (16, 64), (4, 1024)])
+@pytest.mark.parametrize("name", ["ellipse_n3000_symL_default", "ball_n2000_symL_eta3", "ball_n2000_p2_symU_rank1", "ball_n2000_partial"])
+def test_groups_of_row_ranges_of_the_mirrored_sweeps(name, group, slots, monkeypatch):
+    """Round 6: a workgroup of a mirrored sweep takes `sym_group` consecutive row ranges in turn and folds, in at most `sym_group_slots`
+    accumulators in LDS, the column sums that belong together (build_mirror_tables).  Whatever the group size and however few accumulators
+    there are (none at all, a handful: the rest keep their own slots; more than one workgroup's LDS holds: clamped), the operator is the same
+    and its products are the reference's: one vector (symmetric storage: fused product; an ordinary operator: the transposed product on the
+    stored data), several right-hand sides on the stored triangle / stored data, against the default layout."""
+    monkeypatch.setattr(sys.modules[__name__], "ENGINE_OPTIONS", dict(sym_group=group, sym_group_slots=slots))
+    test_matvec_matches_reference(name)
+    p = params(name)
+    Hd, Hg = build_engine(p, options=dict(sym_group=4, sym_group_slots=-1))[2], build_engine(p)[2]
+    assert Hg.get_option("sym_group") == group and np.array_equal(Hd.leaf_table(), Hg.leaf_table())
+    from oracle.oracle import hashed_vector
+    sym = p["sym"] != "N"
+    trans = "N" if sym else "T"
+    nin, nout = (Hd.nb_cols(), Hd.nb_rows()) if trans == "N" else (Hd.nb_rows(), Hd.nb_cols())
+    for mu in (16, 5):
+        X = hashed_vector(nin * mu, 13).reshape(nin, mu)
+        Yd, Yg = np.zeros((nout, mu)), np.zeros((nout, mu))
+        for H, Y in ((Hd, Yd), (Hg, Yg)):
+            H.set_option("transposed_layout", 0)  # an ordinary operator: 'T' on the stored data (the mirrored sweeps), not on a second layout
+            hm.internal_add_hmatrix_matrix_product_row_major(trans, 1.0, H, X, 0.0, Y, mu)
+            assert H.stats()["expanded_bytes"] == 0 and H.stats()["transposed_bytes"] < H.stats()["stream_bytes"]
+        assert rel_err(Yg, Yd) < 1e-13  # the same sums, folded in another order
+
+
 def test_trans_c_for_real_coefficients():
     """For real coefficients the conjugate transpose is the transpose (BLAS 'C'); like the reference, 'C' on symmetric
     ('S') leaves is refused (add_hmatrix_vector_product.hpp:59-62)."""
