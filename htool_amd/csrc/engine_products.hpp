@@ -17,11 +17,14 @@ static void prof_mark(HMat &H, hipStream_t st, const char *name) {
 // the mirrored sweeps keep their group's accumulators in dynamic LDS (beyond the 64 KB a kernel may use without saying so)
 #define HMX_LAUNCH_GROUPED(kernel, grid, block, lds_bytes, st, ...)                                                                    \
     do {                                                                                                                                \
-        static size_t allowed_ = 0;                                                                                                     \
-        if ((size_t)(lds_bytes) > allowed_) {                                                                                           \
+        static std::atomic<size_t> allowed_[16]; /* per device: the attribute belongs to the function ON a device */                     \
+        int dev_ = 0;                                                                                                                   \
+        (void)hipGetDevice(&dev_);                                                                                                      \
+        dev_ &= 15;                                                                                                                     \
+        if ((size_t)(lds_bytes) > allowed_[dev_].load()) {                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes)); \
             (void)hipGetLastError();                                                                                                    \
-            allowed_ = (size_t)(lds_bytes);                                                                                             \
+            allowed_[dev_].store((size_t)(lds_bytes));                                                                                  \
         }                                                                                                                               \
         hipLaunchKernelGGL(kernel, grid, block, lds_bytes, st, __VA_ARGS__);                                                            \
     } while (0)
