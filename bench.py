@@ -646,6 +646,12 @@ def main():
                     ("N", "N", 16): ("mu16_expand_kernel_hbm_bytes_per_launch", "mu16_product_hbm_bytes_total"), ("N", "T", 1): ("transT_colsum_kernel_hbm_bytes_per_launch", "transT_product_hbm_bytes_total"),
                     ("S", "N", 16): ("sym_mu16_expand_kernel_hbm_bytes_per_launch", "sym_mu16_product_hbm_bytes_total")}
             kk = ("c5_rank3_expand_kernel_hbm_bytes_per_launch", "c5_rank3_product_hbm_bytes_total") if c5 else keys.get((args.sym, args.trans, mu))
+            # the counters were collected on the default path of each workload: a line whose engine options choose another path (--option
+            # sym_multi_rhs=0: the expanded view, other kernels) must not carry them
+            expected = {"N": {1: "expand_kernel", 16: "expand_mfma16s_kernel"}, "S": {1: "expand_sym_kernel", 16: "expand_sym_mfma16_kernel"}}
+            want = "expand_colsum_kernel" if args.trans == "T" else expected.get(args.sym, {}).get(mu)
+            if args.option or exp_name != want:
+                kk = None
             if rec.get("kernel_sources_sha256") == kernel_sources_hash():
                 if kk:
                     traffic, product_traffic = rec.get(kk[0]), rec.get(kk[1])
